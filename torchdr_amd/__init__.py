@@ -1,0 +1,6 @@
+"""torchdr_amd -- MI355X-native neighbor-embedding hot path behind TorchDR's plugin API."""
+
+__version__ = "0.1.0"
+
+from torchdr_amd.distance import pairwise_distances, pairwise_distances_indexed  # noqa: F401
+from torchdr_amd.distributed import DistributedContext  # noqa: F401
