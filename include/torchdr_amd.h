@@ -1,0 +1,112 @@
+/*
+ * torchdr_amd -- C ABI of the MI355X (gfx950) neighbor-embedding hot path.
+ *
+ * The reference (TorchDR, /root/reference/torchdr) is 100 % Python: its "FFI" for this path is the
+ * sequence of ATen / MKL / Faiss calls made by the Python plugin classes.  Each entry point below
+ * replaces one such sequence; the reference interface it stands in for is cited as file:line.
+ *
+ * Conventions
+ *   - plain `extern "C"`, raw DEVICE pointers + sizes, `void* stream` = hipStream_t (NULL = default);
+ *   - return 0 on success, negative = argument / capability error (TDR_ERR_*), positive = hipError_t;
+ *   - asynchronous on `stream`; never allocates caller-visible memory (outputs and workspaces are
+ *     passed in, with `*_workspace_bytes` / `*_floats` size queries);
+ *   - all matrices row-major fp32; kNN indices int32 (utils/utils.py:216), CSR row pointers int64.
+ */
+#ifndef TORCHDR_AMD_H
+#define TORCHDR_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDR_OK 0
+#define TDR_ERR_BAD_ARG (-1)
+#define TDR_ERR_UNSUPPORTED (-2)
+#define TDR_ERR_WORKSPACE (-3)
+
+#define TDR_METRIC_SQEUCLIDEAN 0
+#define TDR_METRIC_EUCLIDEAN 1
+#define TDR_METRIC_ANGULAR 2
+
+/* ---- K1: pairwise distances / exact kNN ------------------------------------------------------
+ * replaces distance/torch.py:21-125 (pairwise_distances_torch), utils/utils.py:173-216 (kmin),
+ * distance/faiss.py:224-403 (IndexFlatL2 search) and the chunked form distance/base.py:183-206. */
+
+/* floats needed by the packed (MFMA tile image) copy of an n x d block; 0 if d is unsupported (> 256). */
+int64_t tdr_packed_floats(int64_t n, int d);
+
+/* X (n x d, row stride ldx) -> packed tile images (+ squared norms, ATen summation order,
+ * distance/torch.py:82).  norms_out (n) may be NULL. */
+int tdr_pack_rows_f32(const float* X, int64_t n, int d, int64_t ldx, float* packed, float* norms_out, void* stream);
+
+int64_t tdr_knn_workspace_bytes(int64_t nq, int64_t n_db, int k);
+int tdr_knn_max_k(int d);
+
+/* k smallest distances of each of nq packed queries against n_db packed database rows.
+ * q_offset: global row id of query 0 (for exclude_self: skip database row q_offset + i,
+ * distance/torch.py:111-116).  out_d (nq,k) ascending, out_i (nq,k) int32, ties by index. */
+int tdr_knn_packed_f32(const float* qp, int64_t nq, int64_t q_offset, const float* yp, int64_t n_db, int d, int k,
+                       int metric, int exclude_self, float* out_d, int32_t* out_i, void* ws, int64_t ws_bytes,
+                       void* stream);
+
+/* dense nq x n_db matrix (k=None path, distance/torch.py:91-116); diag_add (1e12) on C[i][q_offset+i]. */
+int tdr_dense_dist_packed_f32(const float* qp, int64_t nq, int64_t q_offset, const float* yp, int64_t n_db, int d,
+                              int metric, int exclude_self, float diag_add, float* out, int64_t ldo, void* stream);
+
+/* gathered distances out[i][c] = ||X[q_i] - Y[keys[i][c]]||^2 (distance/base.py:384-385); negative
+ * indices wrap like PyTorch indexing. */
+int tdr_indexed_sqdist_f32(const float* X, int64_t nx, int d, const float* Y, int64_t ny, const int64_t* q,
+                           int64_t nq, int nk, int take_sqrt, const int64_t* keys, float* out, void* stream);
+
+/* ---- K2 / K3: per-row root searches --------------------------------------------------------------
+ * replace utils/root_search.py:17-77,147-198 driven by affinity/knn_normalized.py:445-465 (UMAP) and
+ * affinity/entropic.py:272-310 (+ bounds :96-113). */
+int tdr_umap_search_f32(const float* C, int64_t n, int k, float target, int max_iter, float tol, float* rho,
+                        float* eps, float* P, void* stream);
+
+int tdr_entropic_search_f32(const float* C, int64_t n, int k, float target, float log_n, int max_iter, float tol,
+                            int use_bounds, float tN_logratio, float tN_m1, float log_ratio, float beta_u_num,
+                            float* eps, float* log_norm, float* log_P, void* stream);
+
+/* ---- K4: sparse symmetrisation -------------------------------------------------------------------
+ * replaces utils/sparse.py:7-206 (symmetrize_sparse) and, with ext edges, :209-342
+ * (distributed_symmetrize_sparse).  Two phases around the one host read of nnz = rowptr[n]. */
+int64_t tdr_sym_workspace_bytes(int64_t n, int k);
+int tdr_sym_count_f32(const float* vals, const int32_t* cols, int64_t n, int k, int64_t row_offset,
+                      const int32_t* ext_row, const int32_t* ext_col, int64_t n_ext, void* ws, int64_t ws_bytes,
+                      int64_t* rowptr, void* stream);
+int tdr_sym_fill_f32(int64_t n, int k, int64_t row_offset, int mode, const int32_t* ext_row, const int32_t* ext_col,
+                     const float* ext_val, int64_t n_ext, void* ws, const int64_t* rowptr, int32_t* tcols,
+                     float* tvals, int32_t* cols, float* vals, void* stream);
+/* CSR -> padded (n, width) with (0, -1) fill (pack_to_rowwise, utils/sparse.py:89-135). */
+int tdr_csr_to_padded_f32(const int64_t* rowptr, const int32_t* cols, const float* vals, int64_t n, int64_t width,
+                          float* pv, int64_t* pi, void* stream);
+
+/* ---- K5 / K6 / K9: embedding loop ----------------------------------------------------------------- */
+/* neighbor_embedding/umap.py:215-234 */
+int tdr_umap_prepare_f32(const float* vals, int64_t nnz, int max_iter, float* eps_per, float* next, void* scratch,
+                         void* stream);
+/* neighbor_embedding/umap.py:236-292 + neighbor_embedding/base.py:617-649 (negatives) */
+int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int64_t* rowptr,
+                      const int32_t* cols, const float* eps_per, float* next, float a, float b, int n_iter,
+                      int neg_rate, int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep,
+                      float eps, float* grad, void* stream);
+/* gradients of neighbor_embedding/largevis.py:181-201 (kind 0) and tsne.py:162-170 (kind 1, attraction) */
+int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nn,
+                    const float* P, int k, int kind, float exag, float rep_coef, int n_neg, const int64_t* neg_inj,
+                    uint64_t seed, int n_iter, float* grad, void* stream);
+/* gradient pieces of neighbor_embedding/tsne.py:172-180 (dense Student-t partition function) */
+int tdr_tsne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* F, double* S,
+                           void* stream);
+int tdr_add_scaled_f32(float* grad, const float* F, const double* S, float coef, int64_t n, void* stream);
+/* torch.optim.SGD step of affinity_matcher.py:427 (+ the NaN guard of :315) */
+int tdr_sgd_step_f32(float* Z, const float* grad, float* buf, int64_t n, float lr, float momentum, int first,
+                     int* nan_flag, int n_iter, void* stream);
+int tdr_fill_f32(float* p, int64_t n, float v, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TORCHDR_AMD_H */

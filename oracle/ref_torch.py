@@ -1,0 +1,310 @@
+"""TEST INFRASTRUCTURE ONLY -- plain-torch (CPU) restatement of the reference's hot-path algorithms.
+
+Never imported by the product (``torchdr_amd/``).  Each function cites the reference
+file:line (under /root/reference/torchdr) it follows.  Pinned by the golden vectors in
+``tests/golden/`` that were produced by importing the real reference in the build container
+(``tests/golden/make_golden.py``); see ``tests/test_oracle_golden.py``.
+"""
+
+import math
+
+import torch
+
+# --------------------------------------------------------------------------------------------
+# kNN -- distance/torch.py:82-122, utils/utils.py:203-216, distance/base.py:183-206 (chunked form)
+# --------------------------------------------------------------------------------------------
+
+
+def knn_chunked(X, k, metric="sqeuclidean", exclude_self=True, Y=None, chunk=4096, rows=None):
+    """Row-chunked form of the reference's dense formulation (same arithmetic per element:
+    ``(xn + yn) - 2 * (X @ Y.T)`` with MKL sgemm, then topk).  ``rows``: optional (start, stop)
+    to compute only a slice of query rows (CPU-baseline sampling)."""
+    Yd = X if Y is None else Y
+    xn = (X**2).sum(-1)
+    yn = xn if Y is None else (Yd**2).sum(-1)
+    r0, r1 = (0, X.shape[0]) if rows is None else rows
+    outC, outI = [], []
+    for s in range(r0, r1, chunk):
+        e = min(s + chunk, r1)
+        dot = X[s:e] @ Yd.T
+        if metric == "angular":
+            C = -dot
+        else:
+            C = xn[s:e, None] + yn[None, :] - 2 * dot
+            if metric == "euclidean":
+                C = C.clamp(min=0).sqrt()
+        if exclude_self and Y is None:
+            idx = torch.arange(s, e)
+            C[idx - s, idx] = C[idx - s, idx] + 1e12
+        v, i = C.topk(k, dim=1, largest=False)
+        outC.append(v)
+        outI.append(i.int())
+    return torch.cat(outC), torch.cat(outI)
+
+
+def canonical_rows(C, I):
+    """Order each row by (distance, index) -- the parity protocol's canonical form."""
+    o = torch.argsort(I.long(), dim=1, stable=True)
+    C, I = torch.gather(C, 1, o), torch.gather(I, 1, o)
+    o = torch.argsort(C, dim=1, stable=True)
+    return torch.gather(C, 1, o), torch.gather(I, 1, o)
+
+
+# --------------------------------------------------------------------------------------------
+# Root search -- utils/root_search.py:17-77 (binary_search), :147-198 (init_bounds)
+# --------------------------------------------------------------------------------------------
+
+TOL = 1e-6
+
+
+def init_bounds(f, n, begin=None, end=None, max_iter=100, dtype=torch.float32):
+    b = torch.full((n,), 1.0, dtype=dtype) if begin is None else begin.clone().to(dtype)
+    e = torch.full((n,), 1.0, dtype=dtype) if end is None else end.clone().to(dtype)
+    for _ in range(max_iter):
+        m = f(b) > 0
+        if not m.any():
+            break
+        e = torch.where(m, torch.minimum(e, b), e)
+        b = torch.where(m, b * 0.5, b)
+    for _ in range(max_iter):
+        m = f(e) < 0
+        if not m.any():
+            break
+        b = torch.where(m, torch.maximum(b, e), b)
+        e = torch.where(m, e * 2.0, e)
+    return b, e
+
+
+def binary_search(f, n, begin=None, end=None, max_iter=100, dtype=torch.float32):
+    tol = torch.tensor(TOL, dtype=dtype)
+    b, e = init_bounds(f, n, begin, end, max_iter, dtype)
+    f_b = f(b)
+    m = (b + e) * 0.5
+    f_m = f(m)
+    for _ in range(max_iter):
+        active = f_m.abs() >= tol
+        if not active.any():
+            break
+        same = f_m * f_b > 0
+        m1 = active & same
+        b = torch.where(m1, m, b)
+        f_b = torch.where(m1, f_m, f_b)
+        m2 = active & ~same
+        e = torch.where(m2, m, e)
+        m = (b + e) * 0.5
+        f_m = f(m)
+    return m
+
+
+# --------------------------------------------------------------------------------------------
+# UMAP affinity -- affinity/knn_normalized.py:417-496 (sparse path, before symmetrisation)
+# --------------------------------------------------------------------------------------------
+
+
+def umap_affinity(C, n_neighbors, max_iter=100):
+    """C: (n,k) kNN distances.  Returns rho (n,), eps (n,), P (n,k)."""
+    rho = C.min(dim=1).values
+    target = torch.log2(torch.tensor(float(n_neighbors), dtype=C.dtype))
+
+    def gap(eps):
+        lp = -(C - rho[:, None]) / eps[:, None]
+        return lp.logsumexp(1).exp() - target
+
+    eps = binary_search(gap, C.shape[0], max_iter=max_iter, dtype=C.dtype)
+    P = (-(C - rho[:, None]) / eps[:, None]).exp()
+    return rho, eps, P
+
+
+# --------------------------------------------------------------------------------------------
+# Entropic affinity -- affinity/entropic.py:51-115 (bounds), :230-312 (search + normalisation)
+# --------------------------------------------------------------------------------------------
+
+
+def entropy_log(lp):
+    # utils/utils.py:166-168  H = -sum exp(lp) * (lp - 1)
+    return -(lp.exp() * (lp - 1)).sum(1)
+
+
+def entropic_bounds(C, perplexity):
+    """Vladymyrov & Carreira-Perpinan bounds as the reference evaluates them (entropic.py:51-115):
+    note tN is the number of ROWS of C (n_samples) even when C is the (n,k) kNN block."""
+    dtype = C.dtype
+    tN = torch.tensor(float(C.shape[0]), dtype=dtype)
+    perp = torch.tensor(float(perplexity), dtype=dtype)
+    max_val = torch.minimum(torch.sqrt(2.0 * tN), perp)
+
+    def find_p1(x):
+        return torch.log(max_val) - 2.0 * (1.0 - x) * torch.log(tN / (2.0 * (1.0 - x)))
+
+    p1 = binary_search(
+        find_p1, 1, begin=torch.tensor([0.75], dtype=dtype), end=torch.tensor([1.0 - 1e-6], dtype=dtype),
+        max_iter=1000, dtype=dtype,
+    ).squeeze()
+    dN = C.max(dim=1).values
+    d12 = C.topk(2, dim=1, largest=False).values
+    d1, d2 = d12[:, 0], d12[:, 1]
+    Delta_N = dN - d1
+    Delta_2 = d2 - d1
+    log_ratio = torch.log(tN / perp)
+    beta_L = torch.max((tN * log_ratio) / ((tN - 1) * Delta_N), torch.sqrt(log_ratio / (dN.pow(2) - d1.pow(2))))
+    beta_U = (torch.log((tN - 1) * p1 / (1.0 - p1))) / Delta_2
+    return 1 / beta_U, 1 / beta_L
+
+
+def entropic_affinity(C, perplexity, n_total, max_iter=100, use_bounds=True):
+    """C: (n,k).  Returns eps (n,), log_norm (n,), log_P (n,k) = -C/eps - LSE - log(n_total)."""
+    perp = int(perplexity)
+    target = math.log(perp) + 1.0
+    target_t = torch.log(torch.tensor(float(perp), dtype=C.dtype)) + 1
+
+    def gap(eps):
+        lp = -C / eps[:, None]
+        lp = lp - lp.logsumexp(1, keepdim=True)
+        return entropy_log(lp) - target_t
+
+    if use_bounds:
+        begin, end = entropic_bounds(C, perp)
+        begin = begin + 1e-6
+    else:
+        begin = end = None
+    eps = binary_search(gap, C.shape[0], begin=begin, end=end, max_iter=max_iter, dtype=C.dtype)
+    lp = -C / eps[:, None]
+    log_norm = lp.logsumexp(1, keepdim=True)
+    lp = lp - log_norm
+    lp = lp - torch.log(torch.tensor(float(n_total), dtype=C.dtype))
+    del target
+    return eps, log_norm.squeeze(1), lp
+
+
+# --------------------------------------------------------------------------------------------
+# Symmetrisation -- utils/sparse.py:7-206 (flatten_sparse, merge_symmetry, pack_to_rowwise)
+# --------------------------------------------------------------------------------------------
+
+
+def symmetrize_sparse(values, indices, mode="sum_minus_prod"):
+    """Q = P + P^T - P o P^T on the union pattern; duplicates summed; rows padded with
+    (0, -1), columns ascending.  Returns (values (n,deg), indices int64 (n,deg))."""
+    n, k = values.shape
+    i = torch.arange(n).repeat_interleave(k)
+    j = indices.reshape(-1).long()
+    v = values.reshape(-1)
+    keys = torch.cat([i * n + j, j * n + i])
+    vals = torch.cat([v, v])
+    is_p = torch.arange(keys.numel()) < v.numel()
+    uniq, inv = torch.unique(keys, sorted=True, return_inverse=True)
+    vP = torch.zeros(uniq.numel(), dtype=v.dtype).scatter_add_(0, inv, vals * is_p.to(v.dtype))
+    vPT = torch.zeros(uniq.numel(), dtype=v.dtype).scatter_add_(0, inv, vals * (~is_p).to(v.dtype))
+    out = vP + vPT if mode == "sum" else vP + vPT - vP * vPT
+    io, jo = uniq // n, uniq % n
+    counts = torch.bincount(io, minlength=n)
+    deg = int(counts.max().item()) if io.numel() else 0
+    V = torch.zeros((n, deg), dtype=v.dtype)
+    J = torch.full((n, deg), -1, dtype=torch.long)
+    offs = torch.zeros(n + 1, dtype=torch.long)
+    offs[1:] = counts.cumsum(0)
+    slot = torch.arange(io.numel()) - offs[io]
+    V[io, slot] = out
+    J[io, slot] = jo
+    return V, J
+
+
+# --------------------------------------------------------------------------------------------
+# UMAP loop -- neighbor_embedding/umap.py:215-292, neighbor_embedding/base.py:617-649
+# --------------------------------------------------------------------------------------------
+
+
+def umap_prepare(A, max_iter):
+    """umap.py:215-234: epochs_per_sample = A_max / (A + 1e-3), inf where A <= A_max / max_iter."""
+    A_max = A.max()
+    small = A <= A_max / max_iter
+    eps_per = (A + 1e-3).reciprocal() * A_max
+    eps_per = eps_per.masked_fill(small, float("inf"))
+    return eps_per, eps_per.clone()
+
+
+def umap_gradients(Z, NN, eps_per, next_, neg, n_iter, a, b, neg_rate=5, eps=1e-3, rows=None):
+    """One evaluation of umap.py:236-292.  Z (N,c); NN (n,K) int64 (-1 pads wrap to row N-1, as
+    PyTorch indexing does in the reference); neg (n, n_neg) int64.  Mutates ``next_`` in place.
+    Returns (grad_attr, grad_rep, active_mask)."""
+    rows = torch.arange(NN.shape[0]) if rows is None else rows
+    Zi = Z[rows]
+    diff = Zi[:, None, :] - Z[NN]
+    D = (diff**2).sum(-1)
+    pos = D > 0
+    D_ = 1 + a * D**b
+    coef = D.pow(b - 1) * (2 * a * b) / D_
+    coef = coef.masked_fill(~pos, 0)
+    act = next_ <= n_iter + 1
+    next_[act] += eps_per[act]
+    coef = coef.masked_fill(~act, 0)
+    g_attr = torch.einsum("ijk,ij->ik", diff, coef).clamp(-4, 4)
+
+    diffn = Zi[:, None, :] - Z[neg]
+    Dn = (diffn**2).sum(-1)
+    Dn_ = 1 + a * Dn**b
+    cn = ((Dn + eps) * Dn_).reciprocal() * (-2 * b)
+    cnt = (act.sum(1) * neg_rate).long()
+    col = torch.arange(neg.shape[1])
+    cn = cn.masked_fill(col[None, :] >= cnt[:, None], 0)
+    g_rep = torch.einsum("ijk,ij->ik", diffn, cn).clamp(-4, 4)
+    return g_attr, g_rep, act
+
+
+def sample_negatives(n_total, rows, n_neg, generator=None):
+    """neighbor_embedding/base.py:628-636: randint(0, N-1) then +1 where >= own index."""
+    r = torch.randint(0, n_total - 1, (rows.numel(), n_neg), generator=generator)
+    return r + (r >= rows[:, None]).long()
+
+
+# --------------------------------------------------------------------------------------------
+# LargeVis / TSNE -- neighbor_embedding/largevis.py:181-201, tsne.py:162-180 (closed forms of
+# the autograd gradients, SURVEY.md appendix A.4, verified against autograd in the tests)
+# --------------------------------------------------------------------------------------------
+
+
+def ne_attraction_grad(Z, NN, P, kind, rows=None):
+    """d/dZ of  -sum_ij P_ij log Q_ij ;  largevis: Q = 1/(2+d), tsne: log Q = -log(1+d).
+    Both endpoints of every edge receive gradient."""
+    rows = torch.arange(NN.shape[0]) if rows is None else rows
+    NN = NN.long()
+    diff = Z[rows][:, None, :] - Z[NN]
+    D = (diff**2).sum(-1)
+    w = 2 * P / ((2 + D) if kind == "largevis" else (1 + D))
+    g = torch.zeros_like(Z)
+    contrib = w[:, :, None] * diff
+    g.index_add_(0, rows, contrib.sum(1))
+    g.index_add_(0, NN.reshape(-1), -contrib.reshape(-1, Z.shape[1]))
+    return g
+
+
+def largevis_repulsion_grad(Z, neg, n_total, rows=None):
+    """d/dZ of  -(1/N) sum log(1 - Q), Q = 1/(2+d)  ->  w = -(2/N) / ((1+d)(2+d))."""
+    rows = torch.arange(neg.shape[0]) if rows is None else rows
+    diff = Z[rows][:, None, :] - Z[neg]
+    D = (diff**2).sum(-1)
+    w = -(2.0 / n_total) / ((1 + D) * (2 + D))
+    g = torch.zeros_like(Z)
+    contrib = w[:, :, None] * diff
+    g.index_add_(0, rows, contrib.sum(1))
+    g.index_add_(0, neg.reshape(-1), -contrib.reshape(-1, Z.shape[1]))
+    return g
+
+
+def tsne_repulsion_grad(Z):
+    """d/dZ of log sum_ij (1+d_ij)^-1 (diagonal included, tsne.py:172-180):
+    g_i = -(4/S) sum_j (z_i - z_j) / (1+d_ij)^2."""
+    D = torch.cdist(Z.double(), Z.double()) ** 2
+    W = 1.0 / (1.0 + D)
+    S = W.sum()
+    W2 = W * W
+    g = -(4.0 / S) * (W2.sum(1, keepdim=True) * Z.double() - W2 @ Z.double())
+    return g.to(Z.dtype), S.to(Z.dtype)
+
+
+def sgd_momentum_step(Z, grad, buf, lr, momentum):
+    """torch.optim.SGD (no dampening / nesterov / weight decay): buf = momentum*buf + grad
+    (first step: buf = grad); Z -= lr * buf."""
+    if momentum == 0:
+        return Z - lr * grad, buf
+    buf = grad.clone() if buf is None else buf * momentum + grad
+    return Z - lr * buf, buf

@@ -1,0 +1,229 @@
+"""Generate the golden vectors in tests/golden/*.npz by IMPORTING THE REAL REFERENCE (TorchDR at
+/root/reference, CPU ``backend=None``) in the build container.  The reference never travels to the
+GPU box; these small fixtures (inputs + expected outputs) do.
+
+    python tests/golden/make_golden.py
+
+Environment used: python 3.10, torch 2.10.0+rocm7.0 (CPU, MKL 2024.2), 8 threads.
+"""
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import torchdr  # noqa: E402
+from torchdr.affinity import EntropicAffinity, UMAPAffinity  # noqa: E402
+from torchdr.distance import pairwise_distances, pairwise_distances_indexed  # noqa: E402
+from torchdr.distributed import DistributedContext  # noqa: E402
+from torchdr.utils.sparse import symmetrize_sparse  # noqa: E402
+
+from tests.conftest import gmm  # noqa: E402
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def knn_fixtures():
+    cases = []
+    for (n, d, s, k, metric, excl) in [
+        (1024, 128, 2.0, 30, "sqeuclidean", True),
+        (1024, 128, 10.0, 30, "sqeuclidean", True),
+        (1024, 32, 0.0, 15, "sqeuclidean", True),
+        (1000, 50, 2.0, 90, "euclidean", True),
+        (1024, 32, 2.0, 15, "angular", True),
+        (777, 128, 2.0, 30, "sqeuclidean", False),
+    ]:
+        X = gmm(n, d, s, seed=11)
+        C, I = pairwise_distances(X, metric=metric, backend=None, exclude_diag=excl, k=k, return_indices=True)
+        # the reference's top-(k+8) distances: lets the harness classify boundary ties
+        Cw, _ = pairwise_distances(X, metric=metric, backend=None, exclude_diag=excl, k=k + 8, return_indices=True)
+        cases.append(dict(n=n, d=d, s=s, k=k, metric=metric, excl=excl, C=C, I=I, Cw=Cw))
+    flat = {}
+    for i, c in enumerate(cases):
+        for key, v in c.items():
+            flat[f"c{i}_{key}"] = v if not isinstance(v, str) else np.array(v)
+    flat["n_cases"] = len(cases)
+    # cross (X != Y) and k >= N
+    X = gmm(300, 40, 2.0, seed=12)
+    Y = gmm(200, 40, 2.0, seed=13)
+    Cx, Ix = pairwise_distances(X, Y, metric="sqeuclidean", backend=None, k=10, return_indices=True)
+    flat["cross_C"], flat["cross_I"] = Cx, Ix
+    Cd, Id = pairwise_distances(X, metric="sqeuclidean", backend=None, exclude_diag=True, k=300, return_indices=True)
+    assert Id is None
+    flat["dense_excl"] = Cd
+    save("knn", **flat)
+
+
+def indexed_fixture():
+    g = torch.Generator().manual_seed(5)
+    Z = torch.randn(50, 2, generator=g)
+    q = torch.arange(10, 30)
+    keys = torch.randint(0, 50, (20, 7), generator=g)
+    keys[3, 2] = -1
+    D = pairwise_distances_indexed(Z, query_indices=q, key_indices=keys, metric="sqeuclidean")
+    save("indexed", Z=Z, q=q, keys=keys, D=D)
+
+
+def affinity_fixtures():
+    X = gmm(600, 20, 2.0, seed=21)
+    out = {"X": X}
+    for nn in (10, 30):
+        aff = UMAPAffinity(n_neighbors=nn, symmetrize=False, backend=None, max_iter=100)
+        P, I = aff(X)
+        C, I2 = pairwise_distances(X, metric="sqeuclidean", backend=None, exclude_diag=True, k=nn, return_indices=True)
+        assert torch.equal(I, I2)
+        out[f"umap{nn}_C"], out[f"umap{nn}_I"], out[f"umap{nn}_P"] = C, I, P
+        out[f"umap{nn}_rho"], out[f"umap{nn}_eps"] = aff.rho_, aff.eps_
+        affs = UMAPAffinity(n_neighbors=nn, symmetrize=True, backend=None, max_iter=100)
+        Ps, Is = affs(X)
+        out[f"umap{nn}_Psym"], out[f"umap{nn}_Isym"] = Ps, Is
+    for perp in (5, 30):
+        aff = EntropicAffinity(perplexity=perp, backend=None, max_iter=100)
+        logP, I = aff(X, log=True)
+        k = I.shape[1]
+        C, I2 = pairwise_distances(X, metric="sqeuclidean", backend=None, exclude_diag=True, k=k, return_indices=True)
+        assert torch.equal(I, I2)
+        out[f"ent{perp}_C"], out[f"ent{perp}_I"], out[f"ent{perp}_logP"] = C, I, logP
+        out[f"ent{perp}_eps"], out[f"ent{perp}_lognorm"] = aff.eps_, aff.log_normalization_
+    save("affinity", **out)
+
+
+def symmetrize_fixture():
+    g = torch.Generator().manual_seed(31)
+    n, k = 40, 6
+    vals = torch.rand(n, k, generator=g)
+    idx = torch.randint(0, n, (n, k), generator=g)
+    idx[0, 1] = idx[0, 0]          # duplicate column in a row
+    idx[0, 2] = idx[0, 0]          # triple
+    idx[5, 0] = 5                  # self loop
+    for mode in ("sum_minus_prod", "sum"):
+        V, J = symmetrize_sparse(vals, idx, mode=mode)
+        if mode == "sum_minus_prod":
+            out = dict(vals=vals, idx=idx, V=V, J=J)
+        else:
+            out.update(V_sum=V, J_sum=J)
+    save("symmetrize", **out)
+
+
+def umap_step_fixture():
+    """State before / after three optimisation steps of the real UMAP (hooks capture everything)."""
+    from torchdr import UMAP
+
+    torch.manual_seed(0)
+    X = gmm(500, 16, 2.0, seed=41)
+    rec = {}
+
+    class Probe(UMAP):
+        def on_affinity_computation_end(self):
+            super().on_affinity_computation_end()
+            rec["A_padded_eps_per"] = self.epochs_per_sample.clone()
+            rec["NN"] = self.NN_indices_.clone()
+
+        def _training_step(self):
+            t = int(self.n_iter_)
+            if t < 3:
+                rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                rec[f"neg_{t}"] = self.neg_indices_.clone()
+                rec[f"next_{t}"] = self.epoch_of_next_sample.clone()
+                rec[f"lr_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["lr"]))
+            out = super()._training_step()
+            if t < 3:
+                rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+                rec[f"nextafter_{t}"] = self.epoch_of_next_sample.clone()
+            return out
+
+    m = Probe(n_neighbors=10, max_iter=20, backend=None, init="normal", random_state=0)
+    m.fit_transform(X)
+    # affinity recomputed for the harness (the estimator overwrote its buffer with epochs_per_sample)
+    Ps, Is = UMAPAffinity(n_neighbors=10, backend=None, max_iter=100)(X)
+    rec.update(X=X, Psym=Ps, Isym=Is, a=torch.tensor(m._a), b=torch.tensor(m._b), max_iter=torch.tensor(20))
+    # full LR sequence of the default LinearLR(1 -> 0)
+    p = torch.zeros(1, requires_grad=True)
+    opt = torch.optim.SGD([p], lr=1.0)
+    sch = torch.optim.lr_scheduler.LinearLR(opt, start_factor=torch.tensor(1.0), end_factor=torch.tensor(0), total_iters=20)
+    lrs = []
+    for _ in range(20):
+        lrs.append(float(opt.param_groups[0]["lr"]))
+        opt.step()
+        sch.step()
+    rec["lr_seq"] = torch.tensor(lrs, dtype=torch.float64)
+    save("umap_step", **rec)
+
+
+def ne_step_fixture():
+    """LargeVis / TSNE: (Z, NN, P, neg) -> loss gradient via autograd, momentum step."""
+    from torchdr import TSNE, LargeVis
+
+    X = gmm(400, 16, 2.0, seed=51)
+    out = {"X": X}
+    for name, cls, kw in (("largevis", LargeVis, dict(perplexity=5)), ("tsne", TSNE, dict(perplexity=8))):
+        rec = {}
+
+        class Probe(cls):
+            def _training_step(self):
+                t = int(self.n_iter_)
+                if t < 2:
+                    rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                    if hasattr(self, "neg_indices_"):
+                        rec[f"neg_{t}"] = self.neg_indices_.clone()
+                    rec[f"lr_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["lr"]))
+                    rec[f"mom_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["momentum"]))
+                    rec[f"exag_{t}"] = torch.tensor(float(self.early_exaggeration_coeff_))
+                    if t == 0:
+                        rec["P"] = self.affinity_in_.clone()
+                        rec["NN"] = self.NN_indices_.clone()
+                loss = super()._training_step()
+                if t < 2:
+                    rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                    rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+                    rec[f"loss_{t}"] = loss.detach().clone()
+                return loss
+
+        torch.manual_seed(1)
+        m = Probe(max_iter=4, backend=None, init="normal", random_state=1, **kw)
+        m.fit_transform(X)
+        for k_, v in rec.items():
+            out[f"{name}_{k_}"] = v
+    save("ne_step", **out)
+
+
+def distributed_fixture():
+    out = {}
+    for n in (97, 100, 103):
+        for w in (3, 4, 7, 8):
+            ctx = DistributedContext(force_enable=True)
+            ctx.world_size = w
+            bounds = []
+            for r in range(w):
+                ctx.rank = r
+                bounds.append(ctx.compute_chunk_bounds(n))
+            out[f"bounds_{n}_{w}"] = np.array(bounds)
+            out[f"owner_{n}_{w}"] = DistributedContext.get_rank_for_indices(torch.arange(n), n, w)
+    save("distributed", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    knn_fixtures()
+    indexed_fixture()
+    affinity_fixtures()
+    symmetrize_fixture()
+    umap_step_fixture()
+    ne_step_fixture()
+    distributed_fixture()
+    print("reference version:", torchdr.__version__)

@@ -1,0 +1,138 @@
+"""K2 / K3 / K4 parity (GPU): root searches and symmetrisation vs golden vectors of the real reference."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_oracle_golden import load
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5  # north_star tolerance for affinities (relative, fp32)
+
+
+def test_umap_sigma_search_vs_reference():
+    from torchdr_amd.affinity.knn_normalized import umap_sigma_search
+
+    g = load("affinity")
+    for nn in (10, 30):
+        rho, eps, P = umap_sigma_search(g[f"umap{nn}_C"].cuda(), nn, 100)
+        assert torch.equal(rho.cpu(), g[f"umap{nn}_rho"])
+        assert torch.allclose(eps.cpu(), g[f"umap{nn}_eps"], rtol=RTOL, atol=0)
+        assert torch.allclose(P.cpu(), g[f"umap{nn}_P"], rtol=RTOL, atol=1e-8)
+
+
+def test_entropic_search_vs_reference():
+    from torchdr_amd.affinity.entropic import entropic_search
+
+    g = load("affinity")
+    n = g["X"].shape[0]
+    for perp in (5, 30):
+        eps, lognorm, logP = entropic_search(g[f"ent{perp}_C"].cuda(), perp, n, 100)
+        assert torch.allclose(eps.cpu(), g[f"ent{perp}_eps"], rtol=RTOL, atol=0)
+        ref = g[f"ent{perp}_logP"]
+        assert torch.allclose(logP.cpu(), ref, rtol=RTOL, atol=RTOL * float(ref.abs().max()))
+        assert torch.allclose(logP.exp().cpu(), ref.exp(), rtol=1e-4, atol=1e-9)
+        # invariant the reference's own tests pin: row entropy == log(perp) + 1 (test_affinity.py:209-210)
+        p = (logP + np.log(n)).exp()
+        H = -(p * (p.log() - 1)).sum(1)
+        assert torch.allclose(H.cpu(), torch.full((n,), float(np.log(perp) + 1)), atol=1e-3)
+    # multi-GPU style search without bounds reaches the same root
+    eps_nb, _, _ = entropic_search(g["ent30_C"].cuda(), 30, n, 100, use_bounds=False)
+    assert torch.allclose(eps_nb.cpu(), g["ent30_eps"], rtol=1e-4)
+
+
+def test_large_k_searches():
+    """k > 32 / > 64 / > 128 code paths against the plain-torch oracle."""
+    from oracle import ref_torch as R
+    from torchdr_amd.affinity.entropic import entropic_search
+    from torchdr_amd.affinity.knn_normalized import umap_sigma_search
+
+    gen = torch.Generator().manual_seed(3)
+    for k in (45, 90, 200):
+        C = (torch.rand(300, k, generator=gen) * 5 + 0.1).sort(1).values
+        rho, eps, P = umap_sigma_search(C.cuda(), k, 100)
+        r2, e2, P2 = R.umap_affinity(C, k, 100)
+        assert torch.equal(rho.cpu(), r2) and torch.allclose(eps.cpu(), e2, rtol=RTOL)
+        assert torch.allclose(P.cpu(), P2, rtol=RTOL, atol=1e-8)
+        perp = k // 3
+        e, ln, lp = entropic_search(C.cuda(), perp, 300, 100)
+        e2, ln2, lp2 = R.entropic_affinity(C, perp, 300, 100)
+        assert torch.allclose(e.cpu(), e2, rtol=RTOL)
+        assert torch.allclose(lp.cpu(), lp2, rtol=RTOL, atol=1e-5)
+
+
+def test_symmetrize_vs_reference():
+    from torchdr_amd.utils.sparse import symmetrize_sparse, symmetrize_to_csr
+
+    g = load("symmetrize")
+    V, J = symmetrize_sparse(g["vals"].cuda(), g["idx"].cuda())
+    assert J.dtype == torch.int64
+    assert torch.equal(J.cpu(), g["J"])
+    assert torch.allclose(V.cpu(), g["V"], rtol=0, atol=1e-7)
+    V, J = symmetrize_sparse(g["vals"].cuda(), g["idx"].cuda(), mode="sum")
+    assert torch.equal(J.cpu(), g["J_sum"]) and torch.allclose(V.cpu(), g["V_sum"], rtol=0, atol=1e-7)
+    a = load("affinity")
+    for nn in (10, 30):
+        V, J = symmetrize_sparse(a[f"umap{nn}_P"].cuda(), a[f"umap{nn}_I"].cuda())
+        assert torch.equal(J.cpu(), a[f"umap{nn}_Isym"])
+        assert torch.equal(V.cpu(), a[f"umap{nn}_Psym"])  # same op order => bit-identical
+        csr = symmetrize_to_csr(a[f"umap{nn}_P"].cuda(), a[f"umap{nn}_I"].cuda())
+        assert csr.nnz == int((a[f"umap{nn}_Isym"] >= 0).sum())
+
+
+def test_symmetrize_chunked_with_ext_edges_equals_single():
+    """Multi-GPU symmetrisation logic on one device: split rows into 3 'ranks', route the
+    transposed edges by hand (parallel.route_edges), symmetrise each chunk -> must equal the
+    corresponding rows of the single-chunk result (reference semantics of sparse.py:170-206)."""
+    from torchdr_amd.distributed import chunk_bounds
+    from torchdr_amd.parallel import route_edges
+    from torchdr_amd.utils.sparse import symmetrize_to_csr
+
+    a = load("affinity")
+    P, I = a["umap10_P"].cuda(), a["umap10_I"].cuda()
+    n = P.shape[0]
+    full = symmetrize_to_csr(P, I)
+    W = 3
+    routed = []
+    for r in range(W):
+        s, e = chunk_bounds(n, r, W)
+        routed.append(route_edges(P[s:e], I[s:e], s, n, W, r))
+    for r in range(W):
+        s, e = chunk_bounds(n, r, W)
+        src = torch.cat([routed[o][r][0] for o in range(W) if o != r])
+        dst = torch.cat([routed[o][r][1] for o in range(W) if o != r])
+        val = torch.cat([routed[o][r][2] for o in range(W) if o != r])
+        ext = ((dst - s).to(torch.int32), src, val)
+        part = symmetrize_to_csr(P[s:e], I[s:e], row_offset=s, n_total=n, ext=ext)
+        b0, b1 = int(full.rowptr[s]), int(full.rowptr[e])
+        assert torch.equal(part.rowptr.cpu() + b0, full.rowptr[s:e + 1].cpu())
+        assert torch.equal(part.cols.cpu(), full.cols[b0:b1].cpu())
+        assert torch.equal(part.vals.cpu(), full.vals[b0:b1].cpu())
+
+
+def test_affinity_plugins_end_to_end():
+    from torchdr_amd.affinity import EntropicAffinity, UMAPAffinity
+
+    a = load("affinity")
+    X = a["X"].cuda()
+    for nn in (10, 30):
+        aff = UMAPAffinity(n_neighbors=nn, max_iter=100)
+        V, J = aff(X)
+        assert torch.equal(J.cpu(), a[f"umap{nn}_Isym"])
+        assert torch.allclose(V.cpu(), a[f"umap{nn}_Psym"], rtol=RTOL, atol=1e-8)
+        assert torch.allclose(aff.eps_.cpu(), a[f"umap{nn}_eps"], rtol=RTOL)
+        P, I = UMAPAffinity(n_neighbors=nn, max_iter=100, symmetrize=False)(X)
+        assert torch.equal(I.cpu(), a[f"umap{nn}_I"]) and I.dtype == torch.int32
+    for perp in (5, 30):
+        aff = EntropicAffinity(perplexity=perp, max_iter=100)
+        logP, I = aff(X, log=True)
+        assert torch.equal(I.cpu(), a[f"ent{perp}_I"])
+        assert torch.allclose(logP.cpu(), a[f"ent{perp}_logP"], rtol=RTOL, atol=1e-4)
+        Pn, _ = aff(X)  # log=False exponentiates (affinity/base.py:554)
+        assert torch.allclose(Pn.sum(1).cpu(), torch.full((X.shape[0],), 1.0 / X.shape[0]), rtol=1e-4)
+    # numpy input is accepted by the plugin surface
+    V2, J2 = UMAPAffinity(n_neighbors=10, max_iter=100)(a["X"].numpy())
+    assert torch.equal(J2.cpu(), a["umap10_Isym"])

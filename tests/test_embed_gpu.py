@@ -1,0 +1,147 @@
+"""K5 / K6 / K9 parity (GPU): embedding-loop kernels vs golden vectors of the real reference."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import gmm
+from tests.test_oracle_golden import load
+
+pytestmark = pytest.mark.gpu
+
+
+def padded_to_csr(V, J):
+    mask = J >= 0
+    rowptr = torch.zeros(V.shape[0] + 1, dtype=torch.int64)
+    rowptr[1:] = mask.sum(1).cumsum(0)
+    return rowptr, J[mask].to(torch.int32), V[mask]
+
+
+def test_indexed_sqdist():
+    from torchdr_amd.distance import pairwise_distances_indexed
+
+    g = load("indexed")
+    D = pairwise_distances_indexed(g["Z"].cuda(), query_indices=g["q"].cuda(), key_indices=g["keys"].cuda())
+    assert torch.equal(D.cpu(), g["D"])
+
+
+def test_umap_three_steps_vs_reference():
+    from torchdr_amd import _lib
+
+    L = _lib.lib()
+    g = load("umap_step")
+    a, b, T = float(g["a"]), float(g["b"]), int(g["max_iter"])
+    rowptr, cols, vals = (t.cuda() for t in padded_to_csr(g["Psym"], g["Isym"]))
+    n = g["X"].shape[0]
+    nnz = cols.numel()
+    eps_per = torch.empty(nnz, device="cuda")
+    nxt = torch.empty(nnz, device="cuda")
+    scratch = torch.zeros(2, dtype=torch.int32, device="cuda")
+    _lib.check(L.tdr_umap_prepare_f32(_lib.ptr(vals), nnz, T, _lib.ptr(eps_per), _lib.ptr(nxt), _lib.ptr(scratch),
+                                      _lib.stream_ptr()), "prepare")
+    mask = g["Isym"] >= 0
+    assert torch.equal(eps_per.cpu(), g["A_padded_eps_per"][mask])
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for t in range(3):
+        Z = g[f"Z_{t}"].cuda().contiguous()
+        nxt = g[f"next_{t}"][mask].cuda().contiguous()
+        neg = g[f"neg_{t}"].cuda().contiguous()
+        grad = torch.empty((n, 2), device="cuda")
+        _lib.check(
+            L.tdr_umap_grad_f32(_lib.ptr(Z), 2, n, 0, n, _lib.ptr(rowptr), _lib.ptr(cols), _lib.ptr(eps_per),
+                                _lib.ptr(nxt), a, b, t, 5, neg.shape[1], _lib.ptr(neg), 0, 1.0, 1.0, 1e-3,
+                                _lib.ptr(grad), _lib.stream_ptr()), "umap_grad")
+        ref = g[f"grad_{t}"]
+        assert torch.allclose(grad.cpu(), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+        assert torch.equal(nxt.cpu(), g[f"nextafter_{t}"][mask])
+        refg = ref.cuda().contiguous()
+        _lib.check(L.tdr_sgd_step_f32(_lib.ptr(Z), _lib.ptr(refg), None, Z.numel(), float(g[f"lr_{t}"]), 0.0, 0,
+                                      _lib.ptr(flag), t, _lib.stream_ptr()), "sgd")
+        assert torch.allclose(Z.cpu(), g[f"Zafter_{t}"], rtol=1e-6, atol=1e-7)
+    assert int(flag.item()) == 0
+
+
+@pytest.mark.parametrize("name", ["largevis", "tsne"])
+def test_ne_gradients_vs_reference_autograd(name):
+    from torchdr_amd import _lib
+
+    L = _lib.lib()
+    g = load("ne_step")
+    n = g["X"].shape[0]
+    P, NN = g[f"{name}_P"].cuda().contiguous(), g[f"{name}_NN"].to(torch.int32).cuda().contiguous()
+    k = P.shape[1]
+    buf = torch.empty((n, 2), device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for t in range(2):
+        Z = g[f"{name}_Z_{t}"].cuda().contiguous()
+        exag = float(g[f"{name}_exag_{t}"])
+        grad = torch.zeros((n, 2), device="cuda")
+        if name == "largevis":
+            neg = g[f"{name}_neg_{t}"].cuda().contiguous()
+            rc = L.tdr_ne_grad_f32(_lib.ptr(Z), 2, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, 0, exag, 2.0 / n,
+                                   neg.shape[1], _lib.ptr(neg), 0, t, _lib.ptr(grad), _lib.stream_ptr())
+            _lib.check(rc, "ne_grad")
+        else:
+            rc = L.tdr_ne_grad_f32(_lib.ptr(Z), 2, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, 1, exag, 0.0, 0, None, 0,
+                                   t, _lib.ptr(grad), _lib.stream_ptr())
+            _lib.check(rc, "ne_grad")
+            F = torch.empty((n, 2), device="cuda")
+            S = torch.zeros(1, dtype=torch.float64, device="cuda")
+            _lib.check(L.tdr_tsne_repulsion_f32(_lib.ptr(Z), 2, n, 0, n, _lib.ptr(F), _lib.ptr(S), _lib.stream_ptr()),
+                       "tsne_rep")
+            _lib.check(L.tdr_add_scaled_f32(_lib.ptr(grad), _lib.ptr(F), _lib.ptr(S), -4.0, n * 2,
+                                            _lib.stream_ptr()), "add_scaled")
+        ref = g[f"{name}_grad_{t}"]
+        assert torch.allclose(grad.cpu(), ref, rtol=1e-4, atol=2e-6 * float(ref.abs().max()))
+        refg = ref.cuda().contiguous()
+        _lib.check(L.tdr_sgd_step_f32(_lib.ptr(Z), _lib.ptr(refg), _lib.ptr(buf), Z.numel(), float(g[f"{name}_lr_{t}"]),
+                                      float(g[f"{name}_mom_{t}"]), 1 if t == 0 else 0, _lib.ptr(flag), t,
+                                      _lib.stream_ptr()), "sgd")
+        assert torch.allclose(Z.cpu(), g[f"{name}_Zafter_{t}"], rtol=1e-5, atol=1e-7)
+
+
+def knn_preservation(X, Z, k=15):
+    """Fraction of each point's k nearest input neighbours that are also among its k nearest in the
+    embedding (the reference's neighborhood_preservation metric, eval/neighborhood_preservation.py)."""
+    import oracle
+
+    _, Ix = oracle.knn(X, k)
+    _, Iz = oracle.knn(Z, k)
+    hits = (Ix[:, :, None] == Iz[:, None, :]).any(2).float().mean()
+    return float(hits)
+
+
+def test_umap_fit_transform_end_to_end():
+    from torchdr_amd import UMAP
+
+    n = 6000
+    X = gmm(n, 32, 4.0, seed=5)
+    labels = torch.arange(n) % 60
+    m = UMAP(n_neighbors=15, max_iter=300, random_state=0)
+    Z = m.fit_transform(X.numpy())  # numpy in -> numpy out (wrappers.py:162-186)
+    assert isinstance(Z, np.ndarray) and Z.shape == (n, 2) and np.isfinite(Z).all()
+    assert m.is_fitted_ and int(m.n_iter_) == 299
+    Zt = torch.from_numpy(Z)
+    # clusters separate: same-cluster points are closer than the global spread
+    cent = torch.stack([Zt[labels == c].mean(0) for c in range(60)])
+    within = (Zt - cent[labels]).norm(dim=1).mean()
+    between = torch.cdist(cent, cent).mean()
+    assert within < 0.25 * between, (within, between)
+    assert knn_preservation(X, Zt, 15) > 0.25
+    # tensor on the GPU in -> tensor on the GPU out; transform() returns the training embedding
+    Zg = UMAP(n_neighbors=15, max_iter=50, random_state=0).fit_transform(X.cuda())
+    assert Zg.is_cuda and Zg.shape == (n, 2)
+
+
+def test_umap_errors_and_duplicates():
+    from torchdr_amd import UMAP
+
+    with pytest.raises(ValueError, match="Number of samples is smaller than n_neighbors"):
+        UMAP(n_neighbors=30).fit_transform(torch.randn(20, 5))
+    with pytest.raises(ValueError, match="infinite"):
+        UMAP().fit_transform(torch.full((100, 4), float("inf")))
+    X = gmm(500, 8, 2.0, seed=9)
+    Xd = torch.cat([X, X[:25]])
+    Z = UMAP(n_neighbors=10, max_iter=20, random_state=1).fit_transform(Xd)
+    assert Z.shape == (525, 2)
+    assert torch.equal(Z[:25], Z[500:])  # duplicates share their embedding (base.py:132-148)

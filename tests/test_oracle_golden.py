@@ -1,0 +1,164 @@
+"""CPU: the oracle (oracle/knn_oracle.c + oracle/ref_torch.py) pinned against golden vectors produced by
+the REAL reference (tests/golden/make_golden.py, run in the build container)."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import ref_torch as R
+from tests.conftest import gmm
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiub" else z[k]) for k in z.files}
+
+
+def boundary_safe_rows(Cw, k):
+    """Rows whose k-th and (k+1)-th reference distances differ: there the top-k SET is unambiguous."""
+    return Cw[:, k - 1] != Cw[:, k]
+
+
+def test_knn_oracle_vs_reference_golden():
+    g = load("knn")
+    for i in range(int(g["n_cases"])):
+        n, d, s, k = (int(g[f"c{i}_{x}"]) if x != "s" else float(g[f"c{i}_{x}"]) for x in ("n", "d", "s", "k"))
+        metric = str(g[f"c{i}_metric"])
+        excl = bool(g[f"c{i}_excl"])
+        X = gmm(n, d, s, seed=11)
+        C, I = oracle.knn(X, k, metric, excl)
+        Cr, Ir = R.canonical_rows(g[f"c{i}_C"], g[f"c{i}_I"])
+        safe = boundary_safe_rows(g[f"c{i}_Cw"], k)
+        assert safe.float().mean() > 0.9
+        if metric == "euclidean":
+            # ATen's vectorised sqrt is not correctly rounded: values agree to 1 ulp
+            # (and distinct squared distances can share one root, so compare index SETS per row)
+            assert torch.allclose(C, Cr, rtol=2e-7, atol=0)
+            assert torch.equal(I[safe].sort(1).values, Ir[safe].sort(1).values)
+            continue
+        assert torch.equal(C, Cr), f"case {i}: distances not bit-identical"
+        # rows whose k-th / (k+1)-th reference distances differ have an unambiguous top-k set:
+        # there the canonical (distance, index) order must agree exactly
+        assert torch.equal(I[safe], Ir[safe]), f"case {i}: indices differ on tie-free rows"
+    # cross and dense
+    X = gmm(300, 40, 2.0, seed=12)
+    Y = gmm(200, 40, 2.0, seed=13)
+    C, I = oracle.knn(X, 10, "sqeuclidean", False, Y=Y)
+    Cr, Ir = R.canonical_rows(g["cross_C"], g["cross_I"])
+    assert torch.equal(C, Cr) and torch.equal(I, Ir)
+    _, _, full = oracle.knn(X, 0, "sqeuclidean", False, want_full=True)
+    idx = torch.arange(300)
+    full[idx, idx] = full[idx, idx] + 1e12
+    assert torch.equal(full, g["dense_excl"])
+
+
+def test_ref_torch_chunked_knn_matches_c_oracle():
+    X = gmm(3000, 64, 2.0, seed=3)
+    C, I = R.canonical_rows(*R.knn_chunked(X, 20, chunk=1000))
+    Co, Io = oracle.knn(X, 20)
+    assert torch.equal(C, Co)
+    assert (I != Io).any(1).float().mean() < 0.01
+
+
+def test_sqnorms_match_aten():
+    for d in (1, 5, 7, 8, 50, 128, 256, 300, 1000, 2050):
+        X = torch.randn(37, d) * 3
+        assert torch.equal(oracle.sqnorms(X), (X**2).sum(-1))
+
+
+def test_umap_affinity_oracle():
+    g = load("affinity")
+    for nn in (10, 30):
+        rho, eps, P = R.umap_affinity(g[f"umap{nn}_C"], nn, max_iter=100)
+        assert torch.equal(rho, g[f"umap{nn}_rho"])
+        assert torch.allclose(eps, g[f"umap{nn}_eps"], rtol=1e-6)
+        assert torch.allclose(P, g[f"umap{nn}_P"], rtol=1e-5, atol=1e-7)
+        V, J = R.symmetrize_sparse(g[f"umap{nn}_P"], g[f"umap{nn}_I"])
+        assert torch.equal(J, g[f"umap{nn}_Isym"])
+        assert torch.equal(V, g[f"umap{nn}_Psym"])
+
+
+def test_entropic_affinity_oracle():
+    g = load("affinity")
+    n = g["X"].shape[0]
+    for perp in (5, 30):
+        eps, lognorm, logP = R.entropic_affinity(g[f"ent{perp}_C"], perp, n, max_iter=100)
+        assert torch.allclose(eps, g[f"ent{perp}_eps"], rtol=1e-6)
+        assert torch.allclose(logP, g[f"ent{perp}_logP"], rtol=1e-5, atol=1e-5)
+        assert torch.allclose(lognorm, g[f"ent{perp}_lognorm"].squeeze(), rtol=1e-5, atol=1e-5)
+
+
+def test_symmetrize_oracle_with_duplicates_and_self_loops():
+    g = load("symmetrize")
+    V, J = R.symmetrize_sparse(g["vals"], g["idx"])
+    assert torch.equal(J, g["J"]) and torch.allclose(V, g["V"], rtol=0, atol=1e-7)
+    V, J = R.symmetrize_sparse(g["vals"], g["idx"], mode="sum")
+    assert torch.equal(J, g["J_sum"]) and torch.allclose(V, g["V_sum"], rtol=0, atol=1e-7)
+
+
+def test_umap_step_oracle():
+    g = load("umap_step")
+    a, b, T = float(g["a"]), float(g["b"]), int(g["max_iter"])
+    eps_per, nxt = R.umap_prepare(g["Psym"], T)
+    assert torch.equal(eps_per, g["A_padded_eps_per"])
+    NN = g["NN"]
+    assert torch.equal(NN, g["Isym"])
+    for t in range(3):
+        Z = g[f"Z_{t}"]
+        nxt = g[f"next_{t}"].clone()
+        ga, gr, _ = R.umap_gradients(Z, NN, eps_per, nxt, g[f"neg_{t}"], t, a, b)
+        grad = ga + gr
+        assert torch.allclose(grad, g[f"grad_{t}"], rtol=1e-5, atol=1e-6)
+        assert torch.equal(nxt, g[f"nextafter_{t}"])
+        Znew, _ = R.sgd_momentum_step(Z, g[f"grad_{t}"], None, float(g[f"lr_{t}"]), 0.0)
+        assert torch.allclose(Znew, g[f"Zafter_{t}"], rtol=1e-6, atol=1e-7)
+    # default LinearLR(1 -> 0): lr_t = 1 - t/T up to the recursion's fp32 rounding
+    lr = g["lr_seq"]
+    assert torch.allclose(lr, 1 - torch.arange(T, dtype=torch.float64) / T, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["largevis", "tsne"])
+def test_ne_step_oracle(name):
+    g = load("ne_step")
+    n = g["X"].shape[0]
+    P, NN = g[f"{name}_P"], g[f"{name}_NN"]
+    buf = None
+    for t in range(2):
+        Z = g[f"{name}_Z_{t}"]
+        exag = float(g[f"{name}_exag_{t}"])
+        grad = exag * R.ne_attraction_grad(Z, NN, P, name)
+        if name == "largevis":
+            grad = grad + R.largevis_repulsion_grad(Z, g[f"{name}_neg_{t}"], n)
+        else:
+            grad = grad + R.tsne_repulsion_grad(Z)[0]
+        ref = g[f"{name}_grad_{t}"]
+        assert torch.allclose(grad, ref, rtol=1e-4, atol=1e-6 * float(ref.abs().max()))
+        Znew, buf = R.sgd_momentum_step(Z, ref, buf, float(g[f"{name}_lr_{t}"]), float(g[f"{name}_mom_{t}"]))
+        assert torch.allclose(Znew, g[f"{name}_Zafter_{t}"], rtol=1e-5, atol=1e-7)
+
+
+def test_indexed_oracle():
+    g = load("indexed")
+    Z, q, keys = g["Z"], g["q"], g["keys"]
+    D = ((Z[q][:, None, :] - Z[keys]) ** 2).sum(-1)
+    assert torch.equal(D, g["D"])
+
+
+def test_distributed_tables():
+    from torchdr_amd.distributed import DistributedContext, chunk_bounds
+
+    g = load("distributed")
+    for n in (97, 100, 103):
+        for w in (3, 4, 7, 8):
+            b = np.array([chunk_bounds(n, r, w) for r in range(w)])
+            assert (b == g[f"bounds_{n}_{w}"].numpy()).all()
+            own = DistributedContext.get_rank_for_indices(torch.arange(n), n, w)
+            assert torch.equal(own, g[f"owner_{n}_{w}"])
+            ctx = DistributedContext(force_enable=True)
+            ctx.world_size, ctx.rank = w, w - 1
+            assert ctx.compute_chunk_bounds(n) == tuple(b[-1])

@@ -4,3 +4,7 @@ __version__ = "0.1.0"
 
 from torchdr_amd.distance import pairwise_distances, pairwise_distances_indexed  # noqa: F401
 from torchdr_amd.distributed import DistributedContext  # noqa: F401
+from torchdr_amd.affinity import (  # noqa: F401,E402
+    Affinity, LogAffinity, SparseAffinity, SparseLogAffinity, EntropicAffinity, UMAPAffinity,
+)
+from torchdr_amd.neighbor_embedding import UMAP  # noqa: F401,E402

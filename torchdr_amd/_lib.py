@@ -32,54 +32,41 @@ TDR_ERRORS = {
 }
 
 
-def _declare(lib):
-    def sig(name, restype, *argtypes):
-        fn = getattr(lib, name)
-        fn.restype = restype
-        fn.argtypes = list(argtypes)
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "torchdr_amd.h")
 
-    sig("tdr_packed_floats", c_i64, c_i64, c_i32)
-    sig("tdr_pack_rows_f32", c_i32, c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_ptr)
-    sig("tdr_knn_workspace_bytes", c_i64, c_i64, c_i64, c_i32)
-    sig("tdr_knn_max_k", c_i32, c_i32)
-    sig(
-        "tdr_knn_packed_f32", c_i32,
-        c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
-    )
-    sig(
-        "tdr_dense_dist_packed_f32", c_i32,
-        c_ptr, c_i64, c_i64, c_ptr, c_i64, c_i32, c_i32, c_i32, c_f32, c_ptr, c_i64, c_ptr,
-    )
-    for name, args in _OPTIONAL_SIGS.items():
-        if hasattr(lib, name):
-            sig(name, args[0], *args[1:])
-
-
-# Filled by the modules that own the corresponding kernels (kept here so that the loader has
-# one table of every exported symbol; tests check it against include/torchdr_amd.h).
-_OPTIONAL_SIGS = {
-    "tdr_indexed_sqdist_f32": (c_i32, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr),
-    "tdr_umap_search_f32": (c_i32, c_ptr, c_i64, c_i32, c_f32, c_i32, c_f32, c_ptr, c_ptr, c_ptr, c_ptr),
-    "tdr_entropic_search_f32": (
-        c_i32, c_ptr, c_i64, c_i32, c_f32, c_i32, c_f32, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr,
-    ),
-    "tdr_sym_workspace_bytes": (c_i64, c_i64, c_i32),
-    "tdr_sym_count_f32": (c_i32, c_ptr, c_ptr, c_i64, c_i32, c_i64, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr),
-    "tdr_sym_fill_f32": (c_i32, c_ptr, c_i64, c_i32, c_i64, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr),
-    "tdr_csr_to_padded_f32": (c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_ptr),
-    "tdr_umap_prepare_f32": (c_i32, c_ptr, c_i64, c_f32, c_f32, c_ptr, c_ptr, c_ptr),
-    "tdr_umap_grad_f32": (
-        c_i32, c_ptr, c_i32, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_f32, c_f32, c_f32,
-        c_i32, c_i32, c_ptr, c_u64, c_f32, c_f32, c_ptr, c_ptr,
-    ),
-    "tdr_sgd_step_f32": (c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_i32, c_ptr, c_ptr, c_ptr),
-    "tdr_ne_grad_f32": (
-        c_i32, c_ptr, c_i32, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_i32, c_i32, c_f32, c_f32, c_i32, c_ptr,
-        c_u64, c_i32, c_ptr, c_ptr, c_ptr,
-    ),
-    "tdr_tsne_repulsion_f32": (c_i32, c_ptr, c_i32, c_i64, c_i64, c_i64, c_f32, c_ptr, c_ptr, c_ptr, c_ptr),
-    "tdr_fill_f32": (c_i32, c_ptr, c_i64, c_f32, c_ptr),
+_CTYPES = {
+    "int": c_i32, "int64_t": c_i64, "float": c_f32, "double": c_f64, "uint64_t": c_u64, "uint32_t": ctypes.c_uint32,
 }
+
+
+def parse_header(path=HEADER_PATH):
+    """Prototypes declared in include/torchdr_amd.h -> {name: (restype, [argtypes])}.
+
+    The header is the single source of truth for the C ABI; the ctypes signatures are derived
+    from it so they cannot drift."""
+    import re
+
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|int64_t)\s+(tdr_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        argtypes = []
+        for a in [x.strip() for x in args.replace("\n", " ").split(",") if x.strip()]:
+            if "*" in a:
+                argtypes.append(c_ptr)
+            else:
+                ty = a.replace("const", "").split()[0]
+                argtypes.append(_CTYPES[ty])
+        protos[name] = (_CTYPES[ret], argtypes)
+    return protos
+
+
+def _declare(lib):
+    for name, (restype, argtypes) in parse_header().items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
 
 
 def lib():

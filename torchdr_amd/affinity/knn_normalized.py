@@ -1,0 +1,84 @@
+"""UMAP input affinity on the GPU -- mirror of ``UMAPAffinity``
+(reference ``affinity/knn_normalized.py:335-496``)."""
+
+import math
+from typing import Union
+
+import torch
+
+from torchdr_amd import _lib
+from torchdr_amd.affinity.base import SparseAffinity
+from torchdr_amd.utils import check_neighbor_param
+from torchdr_amd.utils.sparse import symmetrize_to_csr
+
+_TOL = 1e-6  # utils/root_search.py:13
+
+
+def umap_sigma_search(C: torch.Tensor, n_neighbors, max_iter: int):
+    """rho_i = min_j C_ij; eps_i with sum_j exp(-(C_ij - rho_i)/eps_i) = log2(n_neighbors); P = exp(.).
+    (knn_normalized.py:445-465, K3 ``tdr_umap_search_f32``.)"""
+    _lib.require_gpu(C, "C")
+    C = C.contiguous().float()
+    n, k = C.shape
+    rho = torch.empty(n, dtype=torch.float32, device=C.device)
+    eps = torch.empty(n, dtype=torch.float32, device=C.device)
+    P = torch.empty_like(C)
+    target = float(torch.log2(torch.tensor(n_neighbors, dtype=torch.float32)))
+    _lib.check(
+        _lib.lib().tdr_umap_search_f32(_lib.ptr(C), n, k, target, int(max_iter), _TOL, _lib.ptr(rho), _lib.ptr(eps),
+                                       _lib.ptr(P), _lib.stream_ptr()),
+        "tdr_umap_search_f32",
+    )
+    return rho, eps, P
+
+
+class UMAPAffinity(SparseAffinity):
+    r"""UMAP input affinity: :math:`P_{ij} = \exp(-(C_{ij} - \rho_i)/\sigma_i)`,
+    :math:`\sum_j P_{ij} = \log_2(\mathrm{n\_neighbors})`, symmetrised as
+    :math:`P + P^\top - P \circ P^\top`.  Constructor arguments as in the reference
+    (``knn_normalized.py:385-415``)."""
+
+    def __init__(self, n_neighbors: float = 30, max_iter: int = 1000, sparsity: bool = True,
+                 metric: str = "sqeuclidean", zero_diag: bool = True, device: str = "auto",
+                 backend: Union[str, None] = None, verbose: bool = False, compile: bool = False,
+                 symmetrize: bool = True, distributed: Union[bool, str] = "auto", _pre_processed: bool = False):
+        self.n_neighbors = n_neighbors
+        self.max_iter = max_iter
+        self.symmetrize = symmetrize
+        super().__init__(metric=metric, zero_diag=zero_diag, device=device, backend=backend, verbose=verbose,
+                         sparsity=sparsity, compile=compile, distributed=distributed,
+                         _pre_processed=_pre_processed)
+
+    def _compute_sparse_affinity(self, X: torch.Tensor, return_indices: bool = True, return_csr: bool = False,
+                                 **kwargs):
+        n_samples_in = self._get_n_samples(X)
+        n_neighbors = check_neighbor_param(self.n_neighbors, n_samples_in)
+        if not self.sparsity:
+            raise NotImplementedError(
+                "[torchdr_amd] UMAPAffinity(sparsity=False) (dense N x N affinity) is not part of the "
+                "accelerated path; use sparsity=True."
+            )
+        if self.verbose:
+            self.logger.info(f"Sparsity mode enabled, computing {n_neighbors} nearest neighbors...")
+        C_, indices = self._distance_matrix(X, k=int(n_neighbors), return_indices=True)
+        rho, eps, P = umap_sigma_search(C_, n_neighbors, self.max_iter)
+        self.register_buffer("rho_", rho, persistent=False)
+        self.register_buffer("eps_", eps, persistent=False)
+
+        if not self.symmetrize:
+            return (P, indices) if return_indices else P
+
+        self.logger.info("Symmetrizing affinity matrix...")
+        if self.is_multi_gpu:
+            from torchdr_amd.parallel import exchange_transposed_edges
+
+            ext = exchange_transposed_edges(P, indices, self.chunk_start_, n_samples_in, self.world_size)
+            csr = symmetrize_to_csr(P, indices, "sum_minus_prod", row_offset=self.chunk_start_,
+                                    n_total=n_samples_in, ext=ext)
+        else:
+            csr = symmetrize_to_csr(P, indices, "sum_minus_prod", n_total=n_samples_in)
+        self._csr_ = csr
+        if return_csr:
+            return csr
+        values, idx = csr.to_padded()
+        return (values, idx) if return_indices else values

@@ -1,0 +1,309 @@
+"""Affinity-matching optimisation loop -- mirror of ``torchdr/affinity_matcher.py``
+(``AffinityMatcher``: ``_fit_transform`` :201-352, ``_training_step`` :354-430, ``_init_embedding``
+:493-573, optimizer / scheduler configuration :577-657, hooks :475-489).
+
+MI355X-first differences:
+  * gradients always come from the closed-form HIP kernels (K5/K6/K9); there is no autograd graph;
+  * with ``optimizer="SGD"`` the update is the fused ``tdr_sgd_step_f32`` kernel; any other
+    ``torch.optim`` class steps on the kernel-produced gradient (generic path);
+  * the learning-rate sequence is produced by the real ``torch.optim.lr_scheduler`` object driving a
+    host-side dummy parameter, so arbitrary schedulers keep their exact torch semantics;
+  * the per-iteration NaN guard (reference :315) is a device-side flag checked every
+    ``check_interval`` iterations and after the loop (no host sync per step).
+"""
+
+from typing import Any, Dict, Optional, Type, Union
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from torchdr_amd import _lib
+from torchdr_amd.affinity import Affinity, SparseAffinity
+from torchdr_amd.base import DRModule
+from torchdr_amd.utils import compute_device, to_torch
+
+
+class AffinityMatcher(DRModule):
+    # the reference hands torch.optim a TENSOR learning rate here (affinity_matcher.py:621) but a plain
+    # float in NeighborEmbedding (neighbor_embedding/base.py:342); scheduler arithmetic follows suit.
+    _lr_as_tensor = True
+
+    def __init__(self, affinity_in: Affinity, affinity_out: Optional[Affinity] = None,
+                 kwargs_affinity_out: Optional[Dict] = None, n_components: int = 2,
+                 loss_fn: str = "square_loss", kwargs_loss: Optional[Dict] = None,
+                 optimizer: Union[str, Type[torch.optim.Optimizer]] = "Adam",
+                 optimizer_kwargs: Optional[Dict] = None, lr: Union[float, str] = 1e0,
+                 scheduler: Optional[Union[str, Type[torch.optim.lr_scheduler.LRScheduler]]] = None,
+                 scheduler_kwargs: Optional[Dict] = None, min_grad_norm: float = 1e-7, max_iter: int = 1000,
+                 init: Union[str, torch.Tensor, np.ndarray] = "pca", init_scaling: float = 1e-4,
+                 device: str = "auto", backend=None, verbose: bool = False,
+                 random_state: Optional[float] = None, check_interval: int = 50, compile: bool = False,
+                 encoder=None, **kwargs):
+        super().__init__(n_components=n_components, device=device, backend=backend, verbose=verbose,
+                         random_state=random_state, compile=compile, **kwargs)
+        if encoder is not None:
+            raise NotImplementedError("[torchdr_amd] parametric (encoder) embeddings are out of scope.")
+        self.optimizer = optimizer
+        self.optimizer_kwargs = optimizer_kwargs
+        self.lr = lr
+        self.min_grad_norm = min_grad_norm
+        self.check_interval = check_interval
+        self.max_iter = max_iter
+        self.scheduler = scheduler
+        self.scheduler_kwargs = scheduler_kwargs
+        self.loss_fn = loss_fn
+        self.kwargs_loss = kwargs_loss
+        self.init = init
+        self.init_scaling = init_scaling
+        if not isinstance(affinity_in, Affinity) and not affinity_in == "precomputed":
+            raise ValueError('[TorchDR] affinity_in must be an Affinity instance or "precomputed".')
+        self.affinity_in = affinity_in
+        if isinstance(self.affinity_in, Affinity):
+            self.affinity_in._pre_processed = True
+            self.affinity_in.compile = self.compile
+        if affinity_out is not None:
+            if not isinstance(affinity_out, Affinity):
+                raise ValueError("[TorchDR] ERROR : affinity_out must be an Affinity instance when not None.")
+            affinity_out._pre_processed = True
+        self.affinity_out = affinity_out
+        self.kwargs_affinity_out = kwargs_affinity_out
+        self.encoder = None
+        self.n_iter_ = torch.tensor(-1, dtype=torch.long)
+
+    # ------------------------------------------------------------------------------------------
+    def _compute_affinity_in(self, X):
+        """Reference :269-286.  Subclasses may override to ask the affinity for a device-native
+        layout (UMAP asks for CSR)."""
+        if isinstance(self.affinity_in, SparseAffinity):
+            affinity_matrix, nn_indices = self.affinity_in(X, return_indices=True)
+            self.register_buffer("NN_indices_", nn_indices, persistent=False)
+        else:
+            affinity_matrix = self.affinity_in(X)
+        self.register_buffer("affinity_in_", affinity_matrix, persistent=False)
+
+    def _fit_transform(self, X: torch.Tensor, y: Optional[Any] = None) -> torch.Tensor:
+        self.n_samples_in_, self.n_features_in_ = X.shape
+        self.device_ = compute_device(X, self.device)
+        X = X.to(self.device_)
+        if X.dtype != torch.float32:
+            raise NotImplementedError(
+                f"[torchdr_amd] only float32 inputs are supported by the HIP path (got {X.dtype})."
+            )
+
+        self.on_affinity_computation_start()
+        if self.affinity_in == "precomputed":
+            raise NotImplementedError('[torchdr_amd] affinity_in="precomputed" is not part of the accelerated path.')
+        if self.verbose:
+            self.logger.info(
+                f"----- Computing the input affinity matrix with {self.affinity_in.__class__.__name__} -----"
+            )
+        self._compute_affinity_in(X)
+        self.on_affinity_computation_end()
+
+        if self.verbose:
+            self.logger.info("----- Optimizing the embedding -----")
+        self._init_embedding(X)
+        self._set_learning_rate()
+        self._configure_optimizer()
+        self._configure_scheduler()
+        del X
+
+        self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self.device_)
+        grad_norm = float("nan")
+        for step in range(self.max_iter):
+            self.n_iter_.fill_(step)
+            self.on_training_step_start()
+            self._training_step()
+            self.on_training_step_end()
+            if step % self.check_interval == 0:
+                self._raise_if_nan()
+                grad_norm = float(self._last_grad.norm(2).item())
+                if self.verbose:
+                    self.logger.info(
+                        f"[{step}/{self.max_iter}] Grad norm: {grad_norm:.2e} | LR: {self._current_lr():.2e}"
+                    )
+                if grad_norm < self.min_grad_norm:
+                    if self.verbose:
+                        self.logger.info(f"Convergence reached at iter {step} with grad norm: {grad_norm:.2e}.")
+                    break
+        self._raise_if_nan()
+        self.clear_memory()
+        return self.embedding_
+
+    def _raise_if_nan(self):
+        it = int(self._nan_flag.item())
+        if it != 0:
+            raise ValueError(f"[TorchDR] ERROR AffinityMatcher : NaNs in the embeddings at iter {it - 1}.")
+
+    # ------------------------------------------------------------------------------------------
+    def _training_step(self):
+        """Reference :354-430 with closed-form gradients.  ``_compute_gradients`` returns either the
+        chunk's rows (``rows_only=True``: UMAP, only row i moves) or a full (N, c) buffer that other
+        ranks also scatter into (LargeVis / TSNE)."""
+        grad, rows_only = self._compute_gradients()
+        world = getattr(self, "world_size", 1)
+        if world > 1:
+            from torchdr_amd.parallel import allgather_rows, allreduce_
+
+            if rows_only:
+                grad = allgather_rows(grad, self.n_samples_in_, world)  # replaces the zero-padded all-reduce (:395-413)
+            else:
+                allreduce_(grad)  # :425
+        self._last_grad = grad
+        self._optimizer_step(grad)
+        if self.scheduler_ is not None:
+            self._lr_opt.step()
+            self.scheduler_.step()
+        return None
+
+    def _compute_gradients(self):
+        raise NotImplementedError("[TorchDR] ERROR : _compute_gradients method must be implemented.")
+
+    def _current_lr(self) -> float:
+        return float(self._lr_opt.param_groups[0]["lr"])
+
+    def _optimizer_step(self, grad):
+        lr = self._current_lr()
+        if self._fused_sgd:
+            L = _lib.lib()
+            mom = float(self._sgd_momentum)
+            if mom != 0.0 and self._momentum_buf is None:
+                self._momentum_buf = torch.empty_like(self.embedding_)
+                first = 1
+            else:
+                first = 0
+            _lib.check(
+                L.tdr_sgd_step_f32(_lib.ptr(self.embedding_), _lib.ptr(grad), _lib.ptr(self._momentum_buf),
+                                   self.embedding_.numel(), lr, mom, first, _lib.ptr(self._nan_flag),
+                                   int(self.n_iter_), _lib.stream_ptr()),
+                "tdr_sgd_step_f32",
+            )
+        else:
+            for g in self.optimizer_.param_groups:
+                g["lr"] = lr
+            self.embedding_.grad = grad
+            self.optimizer_.step()
+            self.optimizer_.zero_grad(set_to_none=True)
+
+    # ------------------------------------------------------------------------------------------
+    def on_affinity_computation_start(self):
+        pass
+
+    def on_affinity_computation_end(self):
+        pass
+
+    def on_training_step_start(self):
+        pass
+
+    def on_training_step_end(self):
+        pass
+
+    # ------------------------------------------------------------------------------------------
+    def _init_embedding(self, X):
+        """Reference :493-573 (A.5): Z0 = init_scaling * E / std(E[:, 0])."""
+        n = X.shape[0]
+        if isinstance(self.init, (torch.Tensor, np.ndarray)):
+            emb = to_torch(self.init).to(device=self.device_, dtype=X.dtype)
+        elif self.init in ("normal", "random"):
+            emb = torch.randn((n, self.n_components), device=self.device_, dtype=X.dtype)
+        elif self.init == "pca":
+            emb = pca_scores(X, self.n_components)
+        else:
+            raise ValueError(f"[TorchDR] ERROR : init {self.init} not supported in {self.__class__.__name__}.")
+        self.embedding_ = (self.init_scaling * emb / emb[:, 0].std()).contiguous()
+        return self.embedding_
+
+    def _set_learning_rate(self):
+        if self.lr == "auto":
+            if self.verbose:
+                self.logger.warning("lr set to 'auto' without any implemented rule. Setting lr=1.0 by default.")
+            self.lr_ = 1.0
+        else:
+            self.lr_ = self.lr
+
+    def _resolve_optimizer_kwargs(self):
+        return self.optimizer_kwargs or {}
+
+    def _configure_optimizer(self):
+        kwargs = dict(self._resolve_optimizer_kwargs())
+        if isinstance(self.optimizer, str):
+            try:
+                optimizer_class = getattr(torch.optim, self.optimizer)
+            except AttributeError:
+                raise ValueError(f"[TorchDR] ERROR: Optimizer '{self.optimizer}' not found in torch.optim.")
+        else:
+            if not issubclass(self.optimizer, torch.optim.Optimizer):
+                raise ValueError(
+                    "[TorchDR] ERROR: optimizer must be a string (name of an optimizer in "
+                    "torch.optim) or a subclass of torch.optim.Optimizer."
+                )
+            optimizer_class = self.optimizer
+        # host-side LR holder: the scheduler drives THIS optimizer; its lr is read every step
+        self._lr_param = torch.zeros(1, requires_grad=True)
+        lr0 = torch.tensor(float(self.lr_)) if self._lr_as_tensor else float(self.lr_)
+        self._lr_opt = torch.optim.SGD([self._lr_param], lr=lr0)
+        self._fused_sgd = optimizer_class is torch.optim.SGD and set(kwargs) <= {"momentum"}
+        self._momentum_buf = None
+        if self._fused_sgd:
+            self._sgd_momentum = kwargs.get("momentum", 0.0)
+            self.optimizer_ = self._lr_opt
+        else:
+            self.embedding_.requires_grad_(True)
+            self.optimizer_ = optimizer_class([self.embedding_], lr=float(self.lr_), **kwargs)
+        return self.optimizer_
+
+    def _configure_scheduler(self, n_iter: Optional[int] = None):
+        n_iter = n_iter or self.max_iter
+        if self.scheduler is None:
+            self.scheduler_ = None
+            return None
+        kwargs = self.scheduler_kwargs or {}
+        if isinstance(self.scheduler, str):
+            try:
+                scheduler_class = getattr(torch.optim.lr_scheduler, self.scheduler)
+            except AttributeError:
+                raise ValueError(
+                    f"[TorchDR] ERROR: Scheduler '{self.scheduler}' not found in torch.optim.lr_scheduler."
+                )
+        else:
+            if not issubclass(self.scheduler, torch.optim.lr_scheduler.LRScheduler):
+                raise ValueError(
+                    "[TorchDR] ERROR: scheduler must be a string (name of a scheduler in "
+                    "torch.optim.lr_scheduler) or a subclass of torch.optim.lr_scheduler.LRScheduler."
+                )
+            scheduler_class = self.scheduler
+        self.scheduler_ = scheduler_class(self._lr_opt, **kwargs)
+        return self.scheduler_
+
+    def clear_memory(self):
+        super().clear_memory()
+        if isinstance(self.affinity_in, Affinity):
+            self.affinity_in.clear_memory()
+        if isinstance(self.affinity_out, Affinity):
+            self.affinity_out.clear_memory()
+        for attr in ["optimizer_", "scheduler_", "lr_", "_lr_opt", "_lr_param", "_momentum_buf", "_last_grad",
+                     "_nan_flag"]:
+            if hasattr(self, attr):
+                delattr(self, attr)
+        if isinstance(self.embedding_, torch.Tensor) and self.embedding_.requires_grad:
+            self.embedding_ = self.embedding_.detach()
+
+
+def pca_scores(X: torch.Tensor, n_components: int) -> torch.Tensor:
+    """PCA scores U*S of the centred data with the reference's sign convention
+    (spectral_embedding/pca.py:169-178 + utils/utils.py:292-298 ``svd_flip``, u-based).
+
+    Computed from the D x D covariance eigen-decomposition (one GEMM + a tiny eigh) instead of a
+    thin SVD of the N x D block: same subspace and signs, O(N D^2) on the GPU.  Initialisation
+    only -- the scores are rescaled to std 1e-4 right after (A.5)."""
+    mean = X.mean(0, keepdim=True)
+    Xc = X - mean
+    cov = Xc.T @ Xc
+    evals, evecs = torch.linalg.eigh(cov.double())
+    V = evecs[:, -n_components:].flip(1).to(X.dtype)  # top components, descending
+    E = Xc @ V
+    idx = E.abs().argmax(0)
+    signs = torch.sign(E[idx, torch.arange(E.shape[1], device=E.device)])
+    signs = torch.where(signs == 0, torch.ones_like(signs), signs)
+    return E * signs[None, :]

@@ -1,0 +1,304 @@
+// K2 / K3 -- per-row root searches for the entropic and UMAP affinities, plus the gathered
+// (indexed) squared distances used by the embedding loop.
+//
+// Replaces (citations under /root/reference/torchdr):
+//   utils/root_search.py:17-77    binary_search   (tol 1e-6 on |f(m)|, masked in-place updates)
+//   utils/root_search.py:147-198  init_bounds     (halve b while f(b) > 0, double e while f(e) < 0)
+//   affinity/knn_normalized.py:445-465  UMAP:     f(eps) = exp(LSE_j(-(C_ij - rho_i)/eps)) - log2(k)
+//   affinity/entropic.py:272-310        entropic: f(eps) = H(log_softmax(-C_i/eps)) - (log(perp) + 1)
+//   affinity/entropic.py:96-113         Vladymyrov bounds (per-row part; the scalar p1 root is host-side)
+//   distance/base.py:384-385            indexed squared distances by direct difference
+//
+// One row group of G lanes (G = 32 for k <= 32, else 64) runs the WHOLE bracketing + bisection for its
+// row in registers: the reference's global masked loop (one host sync per iteration, root_search.py:62)
+// becomes a per-row early exit, which is equivalent because inactive rows stop moving (:61-75).
+#include "tdr_common.h"
+
+namespace tdr {
+
+constexpr int MAX_ITEMS = 4;  // k <= 64 * 4
+
+struct UmapF {
+    float rho, target;
+    template <int G, int ITEMS>
+    __device__ __forceinline__ float eval(const float (&c)[ITEMS], const bool (&valid)[ITEMS], float eps) const {
+        float lp[ITEMS];
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t) {
+            lp[t] = valid[t] ? (-(c[t] - rho)) / eps : -__builtin_inff();
+            m = fmaxf(m, lp[t]);
+        }
+        m = group_max<G>(m);
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t) s += valid[t] ? expf(lp[t] - m) : 0.f;
+        s = group_sum<G>(s);
+        const float lse = m + logf(s);
+        return expf(lse) - target;
+    }
+};
+
+struct EntropicF {
+    float target;
+    template <int G, int ITEMS>
+    __device__ __forceinline__ float eval(const float (&c)[ITEMS], const bool (&valid)[ITEMS], float eps) const {
+        float lp[ITEMS];
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t) {
+            lp[t] = valid[t] ? (-c[t]) / eps : -__builtin_inff();
+            m = fmaxf(m, lp[t]);
+        }
+        m = group_max<G>(m);
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t) s += valid[t] ? expf(lp[t] - m) : 0.f;
+        s = group_sum<G>(s);
+        const float lse = m + logf(s);
+        float h = 0.f;
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t) {
+            const float l = lp[t] - lse;
+            h += valid[t] ? expf(l) * (l - 1.0f) : 0.f;
+        }
+        h = group_sum<G>(h);
+        return (-h) - target;
+    }
+};
+
+// root_search.py:17-77 + :147-198 for one row; every lane of the group carries the same scalars.
+template <int G, int ITEMS, typename F>
+__device__ __forceinline__ float row_binary_search(const F& f, const float (&c)[ITEMS], const bool (&valid)[ITEMS],
+                                                   float b, float e, int max_iter, float tol) {
+    for (int it = 0; it < max_iter; ++it) {
+        if (!(f.template eval<G, ITEMS>(c, valid, b) > 0.f)) break;
+        e = fminf(e, b);
+        b = b * 0.5f;
+    }
+    for (int it = 0; it < max_iter; ++it) {
+        if (!(f.template eval<G, ITEMS>(c, valid, e) < 0.f)) break;
+        b = fmaxf(b, e);
+        e = e * 2.0f;
+    }
+    float f_b = f.template eval<G, ITEMS>(c, valid, b);
+    float m = (b + e) * 0.5f;
+    float f_m = f.template eval<G, ITEMS>(c, valid, m);
+    for (int it = 0; it < max_iter; ++it) {
+        if (!(fabsf(f_m) >= tol)) break;
+        if (f_m * f_b > 0.f) { b = m; f_b = f_m; }
+        else e = m;
+        m = (b + e) * 0.5f;
+        f_m = f.template eval<G, ITEMS>(c, valid, m);
+    }
+    return m;
+}
+
+template <int G, int ITEMS>
+__global__ __launch_bounds__(256) void umap_search_kernel(const float* __restrict__ C, int64_t n, int k, float target,
+                                                          int max_iter, float tol, float* __restrict__ rho_out,
+                                                          float* __restrict__ eps_out, float* __restrict__ P_out) {
+    const int gl = threadIdx.x % G;
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (row >= n) return;
+    float c[ITEMS];
+    bool valid[ITEMS];
+    float mn = __builtin_inff();
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+        const int j = gl + t * G;
+        valid[t] = j < k;
+        c[t] = valid[t] ? C[(size_t)row * k + j] : 0.f;
+        if (valid[t]) mn = fminf(mn, c[t]);
+    }
+    UmapF f;
+    f.rho = group_min<G>(mn);
+    f.target = target;
+    const float eps = row_binary_search<G, ITEMS>(f, c, valid, 1.0f, 1.0f, max_iter, tol);
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t)
+        if (valid[t]) P_out[(size_t)row * k + gl + t * G] = expf((-(c[t] - f.rho)) / eps);
+    if (gl == 0) { rho_out[row] = f.rho; eps_out[row] = eps; }
+}
+
+struct EntropicScalars {
+    float target;      // log(perp) + 1
+    int use_bounds;    // entropic.py:280-287
+    float tN_logratio; // tN * log(tN / perp)
+    float tN_m1;       // tN - 1
+    float log_ratio;   // log(tN / perp)
+    float beta_u_num;  // log((tN - 1) * p1 / (1 - p1))
+    float log_n;       // log(n_total)
+};
+
+template <int G, int ITEMS>
+__global__ __launch_bounds__(256) void entropic_search_kernel(const float* __restrict__ C, int64_t n, int k,
+                                                              EntropicScalars S, int max_iter, float tol,
+                                                              float* __restrict__ eps_out,
+                                                              float* __restrict__ lognorm_out,
+                                                              float* __restrict__ logP_out) {
+    const int gl = threadIdx.x % G;
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (row >= n) return;
+    float c[ITEMS];
+    bool valid[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+        const int j = gl + t * G;
+        valid[t] = j < k;
+        c[t] = valid[t] ? C[(size_t)row * k + j] : 0.f;
+    }
+    float b = 1.0f, e = 1.0f;
+    if (S.use_bounds) {
+        // d1 <= d2 = two smallest, dN = largest of the row (entropic.py:96-100)
+        float mx = -__builtin_inff(), m1 = __builtin_inff();
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t)
+            if (valid[t]) { mx = fmaxf(mx, c[t]); m1 = fminf(m1, c[t]); }
+        const float dN = group_max<G>(mx);
+        const float d1 = group_min<G>(m1);
+        // second smallest: smallest among all but ONE occurrence of d1
+        unsigned long long eqmask_any = 0;
+        float m2 = __builtin_inff();
+        int first_eq = 1 << 30;
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t)
+            if (valid[t] && c[t] == d1) first_eq = min(first_eq, gl + t * G);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) first_eq = min(first_eq, __shfl_xor(first_eq, o, 64));
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t)
+            if (valid[t] && (gl + t * G) != first_eq) m2 = fminf(m2, c[t]);
+        const float d2 = group_min<G>(m2);
+        (void)eqmask_any;
+        const float Delta_N = dN - d1;
+        const float Delta_2 = d2 - d1;
+        const float bl1 = S.tN_logratio / (S.tN_m1 * Delta_N);
+        const float bl2 = sqrtf(S.log_ratio / (dN * dN - d1 * d1));
+        const float beta_L = fmaxf(bl1, bl2);
+        const float beta_U = S.beta_u_num / Delta_2;
+        b = 1.0f / beta_U + 1e-6f;
+        e = 1.0f / beta_L;
+    }
+    EntropicF f;
+    f.target = S.target;
+    const float eps = row_binary_search<G, ITEMS>(f, c, valid, b, e, max_iter, tol);
+    // log P = -C/eps - LSE - log N  (entropic.py:299-310)
+    float lp[ITEMS];
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+        lp[t] = valid[t] ? (-c[t]) / eps : -__builtin_inff();
+        m = fmaxf(m, lp[t]);
+    }
+    m = group_max<G>(m);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) s += valid[t] ? expf(lp[t] - m) : 0.f;
+    s = group_sum<G>(s);
+    const float lse = m + logf(s);
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t)
+        if (valid[t]) logP_out[(size_t)row * k + gl + t * G] = (lp[t] - lse) - S.log_n;
+    if (gl == 0) { eps_out[row] = eps; lognorm_out[row] = lse; }
+}
+
+// distance/base.py:384-385 -- out[i][c] = sum_d (X[q_i][d] - Y[key[i][c]][d])^2 ; negative keys wrap.
+__global__ __launch_bounds__(256) void indexed_sqdist_kernel(const float* __restrict__ X, int64_t nx, int d,
+                                                             const float* __restrict__ Y, int64_t ny,
+                                                             const int64_t* __restrict__ q, int64_t nq, int nk,
+                                                             int take_sqrt, const int64_t* __restrict__ keys,
+                                                             float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nq * nk) return;
+    const int64_t i = idx / nk;
+    int64_t qi = q[i];
+    if (qi < 0) qi += nx;
+    int64_t kj = keys[idx];
+    if (kj < 0) kj += ny;
+    const float* x = X + (size_t)qi * d;
+    const float* y = Y + (size_t)kj * d;
+    float acc = 0.f;
+    for (int t = 0; t < d; ++t) {
+        const float df = x[t] - y[t];
+        acc = __fadd_rn(acc, __fmul_rn(df, df));
+    }
+    out[idx] = take_sqrt ? sqrtf(acc) : acc;
+}
+
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+template <typename K, typename... A>
+static int launch_rows(K kern, int G, int64_t n, hipStream_t st, A... args) {
+    const int rows_per_block = 256 / G;
+    const unsigned grid = (unsigned)((n + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, args...);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TDR_OK : (int)e;
+}
+
+}  // namespace tdr
+
+using namespace tdr;
+
+extern "C" {
+
+/* UMAP sigma search: C (n,k) -> rho (n), eps (n), P (n,k).  target = log2(n_neighbors). */
+int tdr_umap_search_f32(const float* C, int64_t n, int k, float target, int max_iter, float tol, float* rho,
+                        float* eps, float* P, void* stream) {
+    if (!C || !rho || !eps || !P || n <= 0 || k <= 0) return TDR_ERR_BAD_ARG;
+    if (k > 64 * MAX_ITEMS) return TDR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (k <= 32) return launch_rows(umap_search_kernel<32, 1>, 32, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
+    if (k <= 64) return launch_rows(umap_search_kernel<64, 1>, 64, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
+    if (k <= 128) return launch_rows(umap_search_kernel<64, 2>, 64, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
+    return launch_rows(umap_search_kernel<64, 4>, 64, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
+}
+
+/*
+ * Entropic (perplexity) search: C (n,k) -> eps (n), log_norm (n), log_P (n,k).
+ *   target = log(perp) + 1; log_n = log(n_total);
+ *   use_bounds != 0: per-row Vladymyrov bounds from the host-computed scalars
+ *     tN_logratio = tN*log(tN/perp), tN_m1 = tN-1, log_ratio = log(tN/perp),
+ *     beta_u_num = log((tN-1)*p1/(1-p1))   (entropic.py:96-113, tN = number of rows of C).
+ */
+int tdr_entropic_search_f32(const float* C, int64_t n, int k, float target, float log_n, int max_iter, float tol,
+                            int use_bounds, float tN_logratio, float tN_m1, float log_ratio, float beta_u_num,
+                            float* eps, float* log_norm, float* log_P, void* stream) {
+    if (!C || !eps || !log_norm || !log_P || n <= 0 || k <= 0) return TDR_ERR_BAD_ARG;
+    if (k > 64 * MAX_ITEMS) return TDR_ERR_UNSUPPORTED;
+    if (use_bounds && k < 2) return TDR_ERR_BAD_ARG;
+    EntropicScalars S;
+    S.target = target; S.use_bounds = use_bounds; S.tN_logratio = tN_logratio; S.tN_m1 = tN_m1;
+    S.log_ratio = log_ratio; S.beta_u_num = beta_u_num; S.log_n = log_n;
+    hipStream_t st = (hipStream_t)stream;
+    if (k <= 32) return launch_rows(entropic_search_kernel<32, 1>, 32, n, st, C, n, k, S, max_iter, tol, eps, log_norm, log_P);
+    if (k <= 64) return launch_rows(entropic_search_kernel<64, 1>, 64, n, st, C, n, k, S, max_iter, tol, eps, log_norm, log_P);
+    if (k <= 128) return launch_rows(entropic_search_kernel<64, 2>, 64, n, st, C, n, k, S, max_iter, tol, eps, log_norm, log_P);
+    return launch_rows(entropic_search_kernel<64, 4>, 64, n, st, C, n, k, S, max_iter, tol, eps, log_norm, log_P);
+}
+
+/* Gathered squared (or Euclidean) distances: out (nq, nk). q/keys are int64; negative keys wrap. */
+int tdr_indexed_sqdist_f32(const float* X, int64_t nx, int d, const float* Y, int64_t ny, const int64_t* q,
+                           int64_t nq, int nk, int take_sqrt, const int64_t* keys, float* out, void* stream) {
+    if (!X || !Y || !q || !keys || !out || nq < 0 || nk < 0 || d <= 0) return TDR_ERR_BAD_ARG;
+    if (nq == 0 || nk == 0) return TDR_OK;
+    const int64_t total = nq * nk;
+    hipLaunchKernelGGL(indexed_sqdist_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       X, nx, d, Y, ny, q, nq, nk, take_sqrt, keys, out);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+int tdr_fill_f32(float* p, int64_t n, float v, void* stream) {
+    if (!p || n < 0) return TDR_ERR_BAD_ARG;
+    if (n == 0) return TDR_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, n, v);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+}  // extern "C"

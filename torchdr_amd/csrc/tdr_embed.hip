@@ -1,0 +1,394 @@
+// K5 / K6 / K9 -- the attraction-repulsion gradient loop of the neighbor-embedding methods.
+//
+// Replaces (citations under /root/reference/torchdr):
+//   neighbor_embedding/umap.py:215-234   epochs_per_sample / epoch_of_next_sample set-up
+//   neighbor_embedding/umap.py:236-292   UMAP closed-form attractive / repulsive gradients
+//   neighbor_embedding/base.py:617-649   per-step negative sampling (torch.randint)
+//   neighbor_embedding/largevis.py:181-201, tsne.py:162-180   losses whose autograd gradients are the
+//                                        closed forms below
+//   affinity_matcher.py:427-429          torch.optim.SGD(momentum) step
+//
+// Layout: embedding Z (N, NC) fp32 row-major, replicated per GPU; the affinity graph is CSR (UMAP) or the
+// rectangular (n, k) kNN block (LargeVis / TSNE).  One row group of G lanes walks a row's edges with
+// coalesced loads of (col, eps_per, next), gathers z_j from the L2 / Infinity-Cache resident Z, and
+// reduces the NC-dimensional force with DPP shuffles.  Negatives are generated in-kernel with a
+// counter-based Philox keyed by (seed, iteration, row, column), only for the 5*active columns the
+// reference actually uses (it samples 150 and masks ~110 of them); an injected index table reproduces
+// the reference's per-step arithmetic exactly for the parity tests.
+#include "tdr_common.h"
+
+namespace tdr {
+
+// ---- umap.py:215-234 ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ v, int64_t n, unsigned* __restrict__ amax_bits) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, v[i]);
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));  // values are >= 0
+}
+
+__global__ __launch_bounds__(256) void umap_prepare_kernel(const float* __restrict__ v, int64_t n,
+                                                           const unsigned* __restrict__ amax_bits, float max_iter,
+                                                           float* __restrict__ eps_per, float* __restrict__ next) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float amax = __uint_as_float(*amax_bits);
+    const float thr = amax / max_iter;
+    const float a = v[i];
+    float e = __fmul_rn(1.0f / __fadd_rn(a, 1e-3f), amax);
+    if (a <= thr) e = __builtin_inff();
+    eps_per[i] = e;
+    next[i] = e;
+}
+
+template <int NC>
+struct Vec {
+    float v[NC];
+};
+
+template <int NC>
+__device__ __forceinline__ Vec<NC> load_z(const float* __restrict__ Z, int64_t i) {
+    Vec<NC> r;
+    if (NC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(Z + (size_t)i * 2);
+        r.v[0] = t.x; r.v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) r.v[c] = Z[(size_t)i * NC + c];
+    }
+    return r;
+}
+
+__device__ __forceinline__ int64_t sample_negative(uint64_t seed, uint32_t iter, int64_t grow, int col, int64_t n_total) {
+    // neighbor_embedding/base.py:628-636 : r ~ U{0..N-2}, then +1 where r >= own index
+    const uint4 rnd = philox4x32(seed, (uint64_t)grow, ((uint64_t)iter << 32) | (uint32_t)col);
+    const uint64_t wide = ((uint64_t)rnd.x << 32) | rnd.y;
+    int64_t r = (int64_t)(wide % (uint64_t)(n_total - 1));
+    if (r >= grow) r += 1;
+    return r;
+}
+
+struct UmapStepParams {
+    const float* Z;          // (N, NC)
+    int64_t n_total;         // N
+    int64_t row0;            // first global row of this chunk
+    int64_t n_rows;          // rows in this chunk
+    const int64_t* rowptr;   // (n_rows + 1)
+    const int32_t* cols;     // global column ids
+    const float* eps_per;    // epochs_per_sample   (nnz)
+    float* next;             // epoch_of_next_sample (nnz), updated in place
+    float a, b;
+    float t1;                // n_iter + 1
+    int neg_rate;            // negative_sample_rate
+    int n_negatives;         // int(neg_rate * n_neighbors)
+    const int64_t* neg_inj;  // optional (n_rows, n_negatives) injected negatives, else Philox
+    uint64_t seed;
+    uint32_t iter;
+    float exag, rep;         // early_exaggeration_coeff_, repulsion_strength
+    float eps;               // 1e-3
+    float* grad;             // (n_rows, NC)
+};
+
+template <int NC, int G>
+__global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) {
+    const int gl = threadIdx.x % G;
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (r >= P.n_rows) return;
+    const int64_t gi = P.row0 + r;
+    const Vec<NC> zi = load_z<NC>(P.Z, gi);
+    const float two_ab = 2.0f * P.a * P.b;
+    const float bm1 = P.b - 1.0f;
+
+    float ga[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ga[c] = 0.f;
+    int act = 0;
+    const int64_t e0 = P.rowptr[r], e1 = P.rowptr[r + 1];
+    for (int64_t e = e0 + gl; e < e1; e += G) {
+        const float nx = P.next[e];
+        if (nx <= P.t1) {
+            P.next[e] = nx + P.eps_per[e];
+            act++;
+            const Vec<NC> zj = load_z<NC>(P.Z, P.cols[e]);
+            float df[NC];
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d = __fadd_rn(d, __fmul_rn(df[c], df[c])); }
+            if (d > 0.f) {
+                const float den = 1.0f + P.a * powf(d, P.b);
+                const float coef = (powf(d, bm1) * two_ab) / den;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) ga[c] += coef * df[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ga[c] = group_sum<G>(ga[c]);
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) act += __shfl_xor(act, o, 64);
+
+    float gr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) gr[c] = 0.f;
+    int n_use = act * P.neg_rate;
+    if (n_use > P.n_negatives) n_use = P.n_negatives;
+    for (int col = gl; col < n_use; col += G) {
+        int64_t j;
+        if (P.neg_inj) j = P.neg_inj[(size_t)r * P.n_negatives + col];
+        else j = sample_negative(P.seed, P.iter, gi, col, P.n_total);
+        const Vec<NC> zj = load_z<NC>(P.Z, j);
+        float df[NC];
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d = __fadd_rn(d, __fmul_rn(df[c], df[c])); }
+        const float den = 1.0f + P.a * powf(d, P.b);
+        const float coef = (1.0f / ((d + P.eps) * den)) * (-2.0f * P.b);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) gr[c] += coef * df[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) gr[c] = group_sum<G>(gr[c]);
+    if (gl == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float a_ = fminf(fmaxf(ga[c], -4.f), 4.f);
+            const float r_ = fminf(fmaxf(gr[c], -4.f), 4.f);
+            P.grad[(size_t)r * NC + c] = P.exag * a_ + P.rep * r_;
+        }
+    }
+}
+
+// ---- LargeVis / TSNE sparse terms -------------------------------------------------------------------
+struct NeStepParams {
+    const float* Z;
+    int64_t n_total, row0, n_rows;
+    const int32_t* nn;       // (n_rows, k)
+    const float* P;          // (n_rows, k) affinities (not log)
+    int k;
+    int kind;                // 0 largevis, 1 tsne
+    float exag;              // multiplies the attractive term
+    float rep_coef;          // largevis: repulsion_strength * 2 / N
+    int n_neg;               // negatives per row (0 = none)
+    const int64_t* neg_inj;  // optional (n_rows, n_neg)
+    uint64_t seed;
+    uint32_t iter;
+    float* grad;             // (N, NC) zero-initialised; both endpoints receive atomics
+};
+
+template <int NC, int G>
+__global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
+    const int gl = threadIdx.x % G;
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (r >= S.n_rows) return;
+    const int64_t gi = S.row0 + r;
+    const Vec<NC> zi = load_z<NC>(S.Z, gi);
+    float g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) g[c] = 0.f;
+    const float off = (S.kind == 0) ? 2.0f : 1.0f;
+    for (int p = gl; p < S.k; p += G) {
+        const int64_t j = S.nn[(size_t)r * S.k + p];
+        const float pij = S.P[(size_t)r * S.k + p];
+        const Vec<NC> zj = load_z<NC>(S.Z, j);
+        float df[NC];
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d += df[c] * df[c]; }
+        const float w = S.exag * 2.0f * pij / (off + d);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float t = w * df[c];
+            g[c] += t;
+            unsafeAtomicAdd(&S.grad[(size_t)j * NC + c], -t);
+        }
+    }
+    for (int col = gl; col < S.n_neg; col += G) {
+        int64_t j;
+        if (S.neg_inj) j = S.neg_inj[(size_t)r * S.n_neg + col];
+        else j = sample_negative(S.seed, S.iter, gi, col, S.n_total);
+        const Vec<NC> zj = load_z<NC>(S.Z, j);
+        float df[NC];
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d += df[c] * df[c]; }
+        const float w = -S.rep_coef / ((1.0f + d) * (2.0f + d));
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float t = w * df[c];
+            g[c] += t;
+            unsafeAtomicAdd(&S.grad[(size_t)j * NC + c], -t);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        g[c] = group_sum<G>(g[c]);
+        if (gl == 0) unsafeAtomicAdd(&S.grad[(size_t)gi * NC + c], g[c]);
+    }
+}
+
+// ---- TSNE dense repulsion (tsne.py:172-180): S = sum_ij w_ij, F_i = sum_j (z_i - z_j) w_ij^2 ---------
+template <int NC>
+__global__ __launch_bounds__(256) void tsne_repulsion_kernel(const float* __restrict__ Z, int64_t n_total, int64_t row0,
+                                                             int64_t n_rows, float* __restrict__ F, double* __restrict__ S) {
+    __shared__ float tile[256 * NC];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = r < n_rows;
+    Vec<NC> zi;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) zi.v[c] = have ? Z[(size_t)(row0 + r) * NC + c] : 0.f;
+    float f[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) f[c] = 0.f;
+    float s = 0.f;
+    for (int64_t j0 = 0; j0 < n_total; j0 += 256) {
+        __syncthreads();
+        const int64_t j = j0 + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) tile[threadIdx.x * NC + c] = (j < n_total) ? Z[(size_t)j * NC + c] : 0.f;
+        __syncthreads();
+        const int lim = (int)((n_total - j0 < 256) ? (n_total - j0) : 256);
+        for (int t = 0; t < lim; ++t) {
+            float df[NC];
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - tile[t * NC + c]; d += df[c] * df[c]; }
+            const float w = 1.0f / (1.0f + d);
+            s += w;
+            const float w2 = w * w;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) f[c] += w2 * df[c];
+        }
+    }
+    if (have) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) F[(size_t)r * NC + c] = f[c];
+    } else s = 0.f;
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(S, (double)s);
+}
+
+// grad[row0 + r] += coef / S * F[r]
+__global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ grad, const float* __restrict__ F,
+                                                         const double* __restrict__ S, float coef, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float sc = coef / (float)(*S);
+    grad[i] += sc * F[i];
+}
+
+// ---- SGD(momentum) step, torch.optim.SGD semantics (no dampening / nesterov / weight decay) ----------
+__global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ Z, const float* __restrict__ grad,
+                                                       float* __restrict__ buf, int64_t n, float lr, float momentum,
+                                                       int first, int* __restrict__ nan_flag, int iter) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float g = grad[i];
+    if (momentum != 0.f) {
+        const float bprev = first ? 0.f : buf[i];
+        g = first ? g : __fadd_rn(__fmul_rn(bprev, momentum), g);
+        buf[i] = g;
+    }
+    const float z = fmaf(-lr, g, Z[i]);
+    Z[i] = z;
+    if (z != z) atomicCAS(nan_flag, 0, iter + 1);  // first iteration that produced a NaN (+1)
+}
+
+template <int G, typename Prm>
+static int launch_group(void (*kern)(const Prm), const Prm& P, int64_t n_rows, hipStream_t st) {
+    const int rpb = 256 / G;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n_rows + rpb - 1) / rpb)), dim3(256), 0, st, P);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TDR_OK : (int)e;
+}
+
+}  // namespace tdr
+
+using namespace tdr;
+
+extern "C" {
+
+/* umap.py:215-234 on the nnz CSR values: eps_per = A_max/(A+1e-3) (inf where A <= A_max/max_iter), next = copy.
+ * scratch: >= 4 bytes of device memory. */
+int tdr_umap_prepare_f32(const float* vals, int64_t nnz, int max_iter, float* eps_per, float* next, void* scratch,
+                         void* stream) {
+    if (!vals || !eps_per || !next || !scratch || nnz <= 0 || max_iter <= 0) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(scratch, 0, 4, st);
+    if (e != hipSuccess) return (int)e;
+    int64_t blocks = (nnz + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, vals, nnz, (unsigned*)scratch);
+    hipLaunchKernelGGL(umap_prepare_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st, vals, nnz,
+                       (const unsigned*)scratch, (float)max_iter, eps_per, next);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* One evaluation of UMAP's closed-form gradient for rows [row0, row0 + n_rows): grad (n_rows, nc). */
+int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int64_t* rowptr,
+                      const int32_t* cols, const float* eps_per, float* next, float a, float b, int n_iter,
+                      int neg_rate, int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep,
+                      float eps, float* grad, void* stream) {
+    if (!Z || !rowptr || !cols || !eps_per || !next || !grad || n_rows <= 0 || n_total < 2) return TDR_ERR_BAD_ARG;
+    if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
+    UmapStepParams P;
+    P.Z = Z; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.rowptr = rowptr; P.cols = cols;
+    P.eps_per = eps_per; P.next = next; P.a = a; P.b = b; P.t1 = (float)(n_iter + 1); P.neg_rate = neg_rate;
+    P.n_negatives = n_negatives; P.neg_inj = neg_inj; P.seed = seed; P.iter = (uint32_t)n_iter; P.exag = exag;
+    P.rep = rep; P.eps = eps; P.grad = grad;
+    hipStream_t st = (hipStream_t)stream;
+    if (nc == 2) return launch_group<32>(umap_grad_kernel<2, 32>, P, n_rows, st);
+    return launch_group<32>(umap_grad_kernel<3, 32>, P, n_rows, st);
+}
+
+/* Sparse attraction (+ LargeVis negative-sample repulsion) gradient; grad (N, nc) must be zeroed by the
+ * caller; both endpoints of every edge receive their share through fp32 atomics. */
+int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nn,
+                    const float* P_, int k, int kind, float exag, float rep_coef, int n_neg, const int64_t* neg_inj,
+                    uint64_t seed, int n_iter, float* grad, void* stream) {
+    if (!Z || !nn || !P_ || !grad || n_rows <= 0 || k <= 0 || n_total < 2) return TDR_ERR_BAD_ARG;
+    if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
+    if (kind != 0 && kind != 1) return TDR_ERR_BAD_ARG;
+    NeStepParams S;
+    S.Z = Z; S.n_total = n_total; S.row0 = row0; S.n_rows = n_rows; S.nn = nn; S.P = P_; S.k = k; S.kind = kind;
+    S.exag = exag; S.rep_coef = rep_coef; S.n_neg = n_neg; S.neg_inj = neg_inj; S.seed = seed;
+    S.iter = (uint32_t)n_iter; S.grad = grad;
+    hipStream_t st = (hipStream_t)stream;
+    if (nc == 2) return launch_group<16>(ne_grad_kernel<2, 16>, S, n_rows, st);
+    return launch_group<16>(ne_grad_kernel<3, 16>, S, n_rows, st);
+}
+
+/* TSNE dense repulsion for rows [row0, row0+n_rows): F (n_rows, nc) = sum_j (z_i - z_j)/(1+d)^2 and
+ * *S (double, device, caller-zeroed) += sum_ij 1/(1+d_ij). */
+int tdr_tsne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* F, double* S,
+                           void* stream) {
+    if (!Z || !F || !S || n_rows <= 0) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n_rows + 255) / 256);
+    if (nc == 2) hipLaunchKernelGGL(tsne_repulsion_kernel<2>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S);
+    else if (nc == 3) hipLaunchKernelGGL(tsne_repulsion_kernel<3>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S);
+    else return TDR_ERR_UNSUPPORTED;
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* grad[i] += (coef / *S) * F[i] for i < n (flat). */
+int tdr_add_scaled_f32(float* grad, const float* F, const double* S, float coef, int64_t n, void* stream) {
+    if (!grad || !F || !S || n <= 0) return TDR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(add_scaled_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, grad, F, S, coef, n);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* In-place SGD step on n flat elements. buf may be NULL when momentum == 0. nan_flag: device int, set to
+ * (iteration + 1) by the first step that produces a NaN (check_NaNs, affinity_matcher.py:315). */
+int tdr_sgd_step_f32(float* Z, const float* grad, float* buf, int64_t n, float lr, float momentum, int first,
+                     int* nan_flag, int n_iter, void* stream) {
+    if (!Z || !grad || !nan_flag || n <= 0) return TDR_ERR_BAD_ARG;
+    if (momentum != 0.f && !buf) return TDR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Z, grad, buf, n, lr, momentum, first, nan_flag, n_iter);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+}  // extern "C"

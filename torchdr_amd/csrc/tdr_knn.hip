@@ -32,6 +32,9 @@ constexpr int TILE_ROWS = 32;
 // Empty list slot: (+inf, 0xffffffff) -- compares above every real candidate.
 constexpr uint64_t KEY_SENTINEL = 0xFF800000FFFFFFFFull;
 
+// Correctly rounded fp32 sqrt (via the fp64 root: 53 >= 2*24+2 bits makes the double rounding exact).
+__device__ __forceinline__ float sqrt_rn(float x) { return (float)sqrt((double)x); }
+
 __host__ __device__ __forceinline__ int64_t tile_stride_floats(int kq) { return (int64_t)kq * 256 + 32; }
 
 // ---------------------------------------------------------------------------------------------
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
                         P.ws_keys[((size_t)split * P.nq + qi) * k + rank] = mine;
                     } else {
                         float c = u2f((uint32_t)(mine >> 32));
-                        if (P.metric == 1) c = __fsqrt_rn(fmaxf(c, 0.f));
+                        if (P.metric == 1) c = sqrt_rn(fmaxf(c, 0.f));
                         P.out_d[(size_t)qi * k + rank] = c;
                         P.out_i[(size_t)qi * k + rank] = (int32_t)(uint32_t)(mine & 0xffffffffu);
                     }
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const uint64_t* __restri
         for (int pp = 0; pp < total; ++pp) rank += (mybuf[pp] < mine) ? 1 : 0;
         if (p < total && rank < k && mine != KEY_SENTINEL) {
             float c = u2f((uint32_t)(mine >> 32));
-            if (metric == 1) c = __fsqrt_rn(fmaxf(c, 0.f));
+            if (metric == 1) c = sqrt_rn(fmaxf(c, 0.f));
             out_d[(size_t)qi * k + rank] = c;
             out_i[(size_t)qi * k + rank] = (int32_t)(uint32_t)(mine & 0xffffffffu);
         }
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void dense_dist_kernel(const float* __restr
         if (metric == 2) c = -acc[r];
         else {
             c = __fsub_rn(__fadd_rn(xn, img[KQ * 256 + i]), __fmul_rn(2.0f, acc[r]));
-            if (metric == 1) c = __fsqrt_rn(fmaxf(c, 0.f));
+            if (metric == 1) c = sqrt_rn(fmaxf(c, 0.f));
         }
         if (exclude_self && j == gq + q_offset) c = __fadd_rn(c, diag_add);
         out[(size_t)gq * ldo + j] = c;

@@ -21,6 +21,10 @@ _METRIC_ID = {"sqeuclidean": 0, "euclidean": 1, "angular": 2}
 # Value the reference adds to the diagonal when exclude_diag=True (distance/torch.py:115).
 _DIAG_ADD = 1e12
 
+# bench.py sets this to a list to collect (start_event, end_event, n_queries) around every scan launch
+# (HIP events on the launch stream); None = no instrumentation.
+PROFILE = None
+
 
 class PackedPoints:
     """A point block rewritten into MFMA tile images (+ squared norms) on the device.
@@ -88,6 +92,9 @@ def knn_packed(
     ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
     tile_floats = L.tdr_packed_floats(32, d)
     qdata = Q.data[(q0 // 32) * tile_floats:]
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     _lib.check(
         L.tdr_knn_packed_f32(
             _lib.ptr(qdata), nq, q_offset + q0, _lib.ptr(Y.data), Y.n, d, k, _METRIC_ID[metric],
@@ -96,6 +103,9 @@ def knn_packed(
         ),
         "tdr_knn_packed_f32",
     )
+    if PROFILE is not None:
+        ev1.record()
+        PROFILE.append((ev0, ev1, nq))
     return out_d, out_i
 
 

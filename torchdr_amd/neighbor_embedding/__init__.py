@@ -1,0 +1,2 @@
+from .base import NeighborEmbedding, NegativeSamplingNeighborEmbedding  # noqa: F401
+from .umap import UMAP, find_ab_params  # noqa: F401

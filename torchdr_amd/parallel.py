@@ -1,0 +1,88 @@
+"""Multi-GPU exchange steps of the hot path (one process per GPU, RCCL over xGMI through
+``torch.distributed``; ``gloo`` works for the CPU-side tests of the routing logic).
+
+Call sites being replaced:
+  C2  affinity_matcher.py:395-413  zero-padded all-reduce of per-rank rows  -> all-gather of rows
+  C3  affinity_matcher.py:425      all-reduce of the full gradient          -> all-reduce (RCCL)
+  C4/C5 utils/sparse.py:259-309    edge routing for the symmetrisation      -> all-to-all-v with
+        INTEGER (int32) index payload (the reference ships indices as fp32, exact only below 2^24).
+"""
+
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+from torchdr_amd.distributed import DistributedContext, chunk_bounds
+
+
+def allreduce_(t: torch.Tensor):
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def allgather_rows(local_rows: torch.Tensor, n_total: int, world_size: int) -> torch.Tensor:
+    """Concatenate every rank's row chunk (chunks differ by at most one row)."""
+    sizes = [chunk_bounds(n_total, r, world_size) for r in range(world_size)]
+    max_rows = max(e - s for s, e in sizes)
+    nc = local_rows.shape[1]
+    pad = local_rows
+    if local_rows.shape[0] < max_rows:
+        pad = torch.cat([local_rows, local_rows.new_zeros(max_rows - local_rows.shape[0], nc)])
+    out = local_rows.new_empty((world_size * max_rows, nc))
+    dist.all_gather_into_tensor(out, pad.contiguous())
+    if all(e - s == max_rows for s, e in sizes):
+        return out
+    parts = [out[r * max_rows: r * max_rows + (e - s)] for r, (s, e) in enumerate(sizes)]
+    return torch.cat(parts)
+
+
+def route_edges(values: torch.Tensor, indices: torch.Tensor, chunk_start: int, n_total: int, world_size: int,
+                rank: int):
+    """Split this rank's edges (i -> j, v) by the owner of j.  Returns per-destination lists of
+    (src_global int32, dst_global int32, v fp32) for destinations != rank (pure tensor logic; no comm)."""
+    n, k = values.shape
+    src = (torch.arange(n, device=values.device, dtype=torch.int64) + chunk_start).repeat_interleave(k)
+    dst = indices.reshape(-1).to(torch.int64)
+    v = values.reshape(-1)
+    owner = DistributedContext.get_rank_for_indices(dst, n_total, world_size)
+    order = torch.argsort(owner, stable=True)
+    owner_s, src_s, dst_s, v_s = owner[order], src[order], dst[order], v[order]
+    counts = torch.bincount(owner_s, minlength=world_size)
+    out = []
+    offs = 0
+    for r, c in enumerate(counts.tolist()):
+        sl = slice(offs, offs + c)
+        offs += c
+        if r == rank:
+            out.append(None)
+        else:
+            out.append((src_s[sl].to(torch.int32), dst_s[sl].to(torch.int32), v_s[sl].contiguous()))
+    return out
+
+
+def exchange_transposed_edges(values, indices, chunk_start, n_total, world_size) -> Tuple[torch.Tensor, ...]:
+    """All-to-all-v of the edges whose transpose lives on another rank (reference sparse.py:259-309).
+    Returns (ext_row int32 local, ext_col int32 global, ext_val fp32) for ``symmetrize_to_csr``."""
+    rank = dist.get_rank()
+    dev = values.device
+    routed = route_edges(values, indices, chunk_start, n_total, world_size, rank)
+    send_counts = torch.tensor([0 if p is None else p[0].numel() for p in routed], dtype=torch.int64, device=dev)
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts)
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+
+    def cat(idx, dtype):
+        parts = [p[idx] for p in routed if p is not None and p[idx].numel() > 0]
+        return torch.cat(parts) if parts else torch.empty(0, dtype=dtype, device=dev)
+
+    send_src, send_dst, send_v = cat(0, torch.int32), cat(1, torch.int32), cat(2, torch.float32)
+    total = int(sum(rc))
+    recv_src = torch.empty(total, dtype=torch.int32, device=dev)
+    recv_dst = torch.empty(total, dtype=torch.int32, device=dev)
+    recv_v = torch.empty(total, dtype=torch.float32, device=dev)
+    dist.all_to_all_single(recv_src, send_src, output_split_sizes=rc, input_split_sizes=sc)
+    dist.all_to_all_single(recv_dst, send_dst, output_split_sizes=rc, input_split_sizes=sc)
+    dist.all_to_all_single(recv_v, send_v, output_split_sizes=rc, input_split_sizes=sc)
+    # received edge (src -> dst) with dst owned here: it is entry (dst, src) of P^T
+    return (recv_dst - chunk_start).to(torch.int32), recv_src, recv_v

@@ -1,0 +1,17 @@
+"""Host-side numeric glue mirroring the hot subset of ``torchdr/utils`` (reference
+``utils/utils.py``, ``utils/wrappers.py``, ``utils/validation.py``, ``utils/sparse.py``)."""
+
+from .misc import (  # noqa: F401
+    bool_arg,
+    seed_everything,
+    set_logger,
+    compute_device,
+)
+from .validation import (  # noqa: F401
+    check_NaNs,
+    check_neighbor_param,
+    check_nonnegativity,
+    validate_tensor,
+)
+from .wrappers import handle_input_output, restore_original_format, to_torch  # noqa: F401
+from .sparse import CSRAffinity, symmetrize_sparse, symmetrize_to_csr  # noqa: F401

@@ -1,0 +1,92 @@
+"""Sparse symmetrisation on the GPU (K4) -- stands in for ``torchdr/utils/sparse.py``."""
+
+from typing import Tuple
+
+import torch
+
+from torchdr_amd import _lib
+
+
+class CSRAffinity:
+    """Symmetrised affinity graph in CSR form (rows = this rank's chunk, columns global)."""
+
+    def __init__(self, rowptr, cols, vals, row_offset=0, n_total=None):
+        self.rowptr = rowptr  # int64 (n+1)
+        self.cols = cols      # int32 (nnz)
+        self.vals = vals      # fp32  (nnz)
+        self.row_offset = row_offset
+        self.n = rowptr.numel() - 1
+        self.n_total = n_total if n_total is not None else self.n
+
+    @property
+    def nnz(self):
+        return self.cols.numel()
+
+    def max_degree(self) -> int:
+        return int((self.rowptr[1:] - self.rowptr[:-1]).max().item())
+
+    def to_padded(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(values (n, max_deg), indices int64 (n, max_deg)) padded with (0, -1): the layout the
+        reference returns (``pack_to_rowwise``, sparse.py:89-135)."""
+        width = self.max_degree()
+        pv = torch.empty((self.n, width), dtype=torch.float32, device=self.vals.device)
+        pi = torch.empty((self.n, width), dtype=torch.int64, device=self.vals.device)
+        _lib.check(
+            _lib.lib().tdr_csr_to_padded_f32(
+                _lib.ptr(self.rowptr), _lib.ptr(self.cols), _lib.ptr(self.vals), self.n, width, _lib.ptr(pv),
+                _lib.ptr(pi), _lib.stream_ptr(),
+            ),
+            "tdr_csr_to_padded_f32",
+        )
+        return pv, pi
+
+
+_MODE = {"sum_minus_prod": 0, "sum": 1}
+
+
+def symmetrize_to_csr(values, indices, mode="sum_minus_prod", row_offset=0, n_total=None, ext=None) -> CSRAffinity:
+    """``Q = P + P^T - P o P^T`` (or ``P + P^T``) of the row-wise (n, k) block -> CSR.
+
+    ``ext`` = (rows int32 local, cols int32 global, vals fp32): transposed edges received from
+    other ranks (multi-GPU path, reference ``sparse.py:209-342``)."""
+    if mode not in _MODE:
+        raise ValueError(f"Unsupported mode {mode!r}")
+    _lib.require_gpu(values, "values")
+    L = _lib.lib()
+    vals = values.contiguous().float()
+    cols = indices.to(torch.int32).contiguous()
+    n, k = vals.shape
+    dev = vals.device
+    ws_bytes = L.tdr_sym_workspace_bytes(n, k)
+    ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+    rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    if ext is not None and ext[0].numel() > 0:
+        er, ec, ev = (ext[0].to(torch.int32).contiguous(), ext[1].to(torch.int32).contiguous(),
+                      ext[2].float().contiguous())
+        n_ext = er.numel()
+    else:
+        er = ec = ev = None
+        n_ext = 0
+    st = _lib.stream_ptr()
+    _lib.check(
+        L.tdr_sym_count_f32(_lib.ptr(vals), _lib.ptr(cols), n, k, row_offset, _lib.ptr(er), _lib.ptr(ec), n_ext,
+                            _lib.ptr(ws), ws_bytes, _lib.ptr(rowptr), st),
+        "tdr_sym_count_f32",
+    )
+    nnz = int(rowptr[n].item())  # the one host sync (reference: sparse.py:119 `.max().item()`)
+    tcols = torch.empty(nnz, dtype=torch.int32, device=dev)
+    tvals = torch.empty(nnz, dtype=torch.float32, device=dev)
+    ocols = torch.empty(nnz, dtype=torch.int32, device=dev)
+    ovals = torch.empty(nnz, dtype=torch.float32, device=dev)
+    _lib.check(
+        L.tdr_sym_fill_f32(n, k, row_offset, _MODE[mode], _lib.ptr(er), _lib.ptr(ec), _lib.ptr(ev), n_ext,
+                           _lib.ptr(ws), _lib.ptr(rowptr), _lib.ptr(tcols), _lib.ptr(tvals), _lib.ptr(ocols),
+                           _lib.ptr(ovals), st),
+        "tdr_sym_fill_f32",
+    )
+    return CSRAffinity(rowptr, ocols, ovals, row_offset=row_offset, n_total=n_total if n_total else n)
+
+
+def symmetrize_sparse(values, indices, mode="sum_minus_prod"):
+    """Drop-in for ``torchdr.utils.sparse.symmetrize_sparse`` (sparse.py:170-206): padded output."""
+    return symmetrize_to_csr(values, indices, mode).to_padded()

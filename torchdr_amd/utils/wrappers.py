@@ -1,0 +1,54 @@
+"""Input/output type round trip (reference ``utils/wrappers.py:41-103, 131-192``)."""
+
+import functools
+
+import torch
+
+from .validation import validate_tensor
+
+try:
+    import pandas as pd
+except ImportError:  # pragma: no cover
+    pd = None
+
+
+def to_torch(x, return_backend_device=False):
+    if pd is not None and isinstance(x, pd.DataFrame):
+        x = x.values
+    if isinstance(x, torch.Tensor):
+        backend, device, x_ = "torch", x.device, x
+    else:
+        backend, device = "numpy", "cpu"
+        try:
+            x_ = torch.as_tensor(x)
+        except (TypeError, ValueError):
+            raise ValueError("Input could not be converted to a tensor.")
+    if not x_.dtype.is_floating_point:
+        x_ = x_.float()
+    return (x_, backend, device) if return_backend_device else x_
+
+
+def restore_original_format(x, backend="torch", device="cpu"):
+    if not isinstance(x, torch.Tensor):
+        return x
+    if backend == "numpy":
+        return x.detach().cpu().numpy()
+    return x.to(device=device)
+
+
+def handle_input_output(_func=None, *, accept_sparse=False, ensure_min_samples=1, ensure_min_features=1,
+                        ensure_2d=True, **check_kwargs):
+    def deco(func):
+        @functools.wraps(func)
+        def wrapper(self, X, *args, **kwargs):
+            X_, backend, device = to_torch(X, return_backend_device=True)
+            X_ = validate_tensor(
+                X_, accept_sparse=accept_sparse, ensure_min_samples=ensure_min_samples,
+                ensure_min_features=ensure_min_features, ensure_2d=ensure_2d, **check_kwargs,
+            )
+            out = func(self, X_, *args, **kwargs)
+            return restore_original_format(out, backend=backend, device=device)
+
+        return wrapper
+
+    return deco if _func is None else deco(_func)
