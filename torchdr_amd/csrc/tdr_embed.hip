@@ -60,10 +60,13 @@ __device__ __forceinline__ Vec<NC> load_z(const float* __restrict__ Z, int64_t i
 }
 
 __device__ __forceinline__ int64_t sample_negative(uint64_t seed, uint32_t iter, int64_t grow, int col, int64_t n_total) {
-    // neighbor_embedding/base.py:628-636 : r ~ U{0..N-2}, then +1 where r >= own index
-    const uint4 rnd = philox4x32(seed, (uint64_t)grow, ((uint64_t)iter << 32) | (uint32_t)col);
-    const uint64_t wide = ((uint64_t)rnd.x << 32) | rnd.y;
-    int64_t r = (int64_t)(wide % (uint64_t)(n_total - 1));
+    // neighbor_embedding/base.py:628-636 : r ~ U{0..N-2}, then +1 where r >= own index.
+    // One Philox block serves 4 consecutive columns; 32 random bits are mapped to [0, N-1) by the
+    // multiply-shift range reduction (bias < N / 2^32).
+    const uint4 rnd = philox4x32(seed, (uint64_t)grow, ((uint64_t)iter << 32) | (uint32_t)(col >> 2));
+    const int sel = col & 3;
+    const uint32_t x = sel == 0 ? rnd.x : sel == 1 ? rnd.y : sel == 2 ? rnd.z : rnd.w;
+    int64_t r = (int64_t)(((uint64_t)x * (uint64_t)(n_total - 1)) >> 32);
     if (r >= grow) r += 1;
     return r;
 }
@@ -97,7 +100,6 @@ __global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) 
     const int64_t gi = P.row0 + r;
     const Vec<NC> zi = load_z<NC>(P.Z, gi);
     const float two_ab = 2.0f * P.a * P.b;
-    const float bm1 = P.b - 1.0f;
 
     float ga[NC];
 #pragma unroll
@@ -115,8 +117,9 @@ __global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) 
 #pragma unroll
             for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d = __fadd_rn(d, __fmul_rn(df[c], df[c])); }
             if (d > 0.f) {
-                const float den = 1.0f + P.a * powf(d, P.b);
-                const float coef = (powf(d, bm1) * two_ab) / den;
+                const float pb = powf(d, P.b);
+                const float den = 1.0f + P.a * pb;
+                const float coef = ((pb / d) * two_ab) / den;  // d^(b-1) = d^b / d
 #pragma unroll
                 for (int c = 0; c < NC; ++c) ga[c] += coef * df[c];
             }

@@ -199,33 +199,38 @@ __device__ __forceinline__ void stage_store(float* dst, const f32x4 (&regs)[(KQ 
     }
 }
 
-// One candidate against the per-query list (keys laid out [p][32 queries], unsorted, with the
-// current maximum tracked in tau_key/tau_pos).  Replace-max + rescan: O(k) LDS reads, only on
-// the rare path.
-__device__ __forceinline__ void list_insert(uint64_t* keys, int k, int q, uint64_t key, uint64_t& tk, int& tp) {
-    if (key < tk) {
-        keys[tp * 32 + q] = key;
-        uint64_t best = 0;
-        int bp = 0;
-        for (int p = 0; p < k; ++p) {
-            const uint64_t v = keys[p * 32 + q];
-            if (v >= best) { best = v; bp = p; }
+// Cooperative sorted insertion: the whole wavefront inserts ONE candidate into one query's ascending
+// k-entry list L (LDS, lane p owns entries p and p+64).  Every lane reads its entry and its left
+// neighbour, the shifted list is written back -- no rescans, no cross-lane traffic: ~2 LDS round trips.
+template <int ITEMS>
+__device__ __forceinline__ void coop_insert(uint64_t* L, int k, uint64_t cand, int lane) {
+    const uint64_t tk = L[k - 1];  // uniform address: LDS broadcast
+    if (cand >= tk) return;        // wave-uniform
+    uint64_t cur[ITEMS], prev[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+        const int p = lane + 64 * t;
+        cur[t] = (p < k) ? L[p] : KEY_SENTINEL;
+        prev[t] = (p > 0 && p < k) ? L[p - 1] : 0ull;
+    }
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+        const int p = lane + 64 * t;
+        if (p < k) {
+            const uint64_t nv = (cur[t] < cand) ? cur[t] : ((p == 0 || prev[t] < cand) ? cand : prev[t]);
+            if (nv != cur[t]) L[p] = nv;
         }
-        tk = best;
-        tp = bp;
     }
 }
 
-template <int KQ>
+template <int KQ, int ITEMS>
 __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int TILE_F = KQ * 256 + 32;
     float* tile0 = reinterpret_cast<float*>(smem_raw);
     float* tile1 = tile0 + TILE_F;
-    uint64_t* keys_all = reinterpret_cast<uint64_t*>(tile1 + TILE_F);  // [4 waves][k][32]
+    uint64_t* keys_all = reinterpret_cast<uint64_t*>(tile1 + TILE_F);  // [4 waves][32 queries][k] ascending
     const int k = P.k;
-    uint64_t* tauk_all = keys_all + (size_t)4 * k * 32;                // [4][32]
-    int* taup_all = reinterpret_cast<int*>(tauk_all + 4 * 32);         // [4][32]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -233,8 +238,6 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
     const int q = lane & 31;
     const int h = lane >> 5;
     uint64_t* keys = keys_all + (size_t)wave * k * 32;
-    uint64_t* tauk = tauk_all + wave * 32;
-    int* taup = taup_all + wave * 32;
 
     const int64_t n_qtiles = (P.nq + 31) / 32;
     const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
@@ -260,7 +263,6 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
 
     // --- per-query lists
     for (int p = lane; p < k * 32; p += 64) keys[p] = KEY_SENTINEL;
-    if (lane < 32) { tauk[lane] = KEY_SENTINEL; taup[lane] = 0; }
     const bool lane_valid = wave_active && (gq < P.nq);
     float tau_d = lane_valid ? __builtin_inff() : -__builtin_inff();
 
@@ -281,20 +283,56 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
     int cur = 0;
     for (int T = t_begin; T < t_end; ++T) {
         const bool has_next = (T + 1) < t_end;
+#ifndef TDR_ABLATE_NOSTAGE
         if (has_next) stage_load<KQ>(P.yp + (size_t)(T + 1) * TILE_F, regs, tid);
+#endif
         const float* img = cur ? tile1 : tile0;
 
         if (wave_active) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // A fragments are double-buffered in registers in groups of 4 quads (16 MFMAs = 1024 pipe
+            // cycles per group), so the ds_read_b128 of group g+1 is in flight while group g multiplies.
+            {
+                constexpr int GQ = 4, NG = KQ / GQ;
+                const float* ap = img + lane * 4;
+                f32x4 a0[GQ], a1[GQ];
 #pragma unroll
-            for (int t = 0; t < KQ; ++t) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(img + t * 256 + lane * 4);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[4 * t + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b[4 * t + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b[4 * t + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b[4 * t + 3], acc, 0, 0, 0);
+                for (int u = 0; u < GQ; ++u) a0[u] = *reinterpret_cast<const f32x4*>(ap + u * 256);
+#pragma unroll
+                for (int g = 0; g < NG; g += 2) {
+                    if (g + 1 < NG) {
+#pragma unroll
+                        for (int u = 0; u < GQ; ++u)
+                            a1[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 1) * GQ + u) * 256);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
+#pragma unroll
+                    for (int u = 0; u < GQ; ++u) {
+                        const int t = g * GQ + u;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][0], b[4 * t + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][1], b[4 * t + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][2], b[4 * t + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][3], b[4 * t + 3], acc, 0, 0, 0);
+                    }
+                    if (g + 1 < NG) {
+                        if (g + 2 < NG) {
+#pragma unroll
+                            for (int u = 0; u < GQ; ++u)
+                                a0[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 2) * GQ + u) * 256);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < GQ; ++u) {
+                            const int t = (g + 1) * GQ + u;
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][0], b[4 * t + 0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][1], b[4 * t + 1], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][2], b[4 * t + 2], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][3], b[4 * t + 3], acc, 0, 0, 0);
+                        }
+                    }
+                }
             }
             // epilogue: lane holds database rows (r&3) + 8*(r>>2) + 4*h of this tile for query q
             float dv[16];
@@ -313,55 +351,55 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
                     hits |= (c <= tau_d) ? (1u << r) : 0u;
                 }
             }
+#ifdef TDR_ABLATE_NOINSERT
+            asm volatile("" ::"v"(hits));
+            hits = 0;
+#endif
             if (__any(hits != 0)) {
                 const int64_t row_base = (int64_t)T * 32 + 4 * h;
-#pragma unroll 1
-                for (int half = 0; half < 2; ++half) {
-                    if (h == half && hits != 0) {
-                        uint64_t tk = tauk[q];
-                        int tp = taup[q];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            if (hits & (1u << r)) {
-                                const int64_t j = row_base + (r & 3) + 8 * (r >> 2);
-                                const bool ok = (j < P.n_db) && !(P.exclude_self && j == gq_global);
-                                if (ok) list_insert(keys, k, q, mkkey(dv[r], (uint32_t)j), tk, tp);
-                            }
-                        }
-                        tauk[q] = tk;
-                        taup[q] = tp;
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t j = row_base + (r & 3) + 8 * (r >> 2);
+                    const bool cand_ok = ((hits >> r) & 1u) && (j < P.n_db) && !(P.exclude_self && j == gq_global);
+                    unsigned long long m = __ballot(cand_ok);
+                    if (m == 0) continue;  // wave-uniform
+                    const uint32_t khi = f2u(dv[r]);
+                    const uint32_t klo = (uint32_t)j;
+                    while (m) {
+                        const int src = __builtin_ctzll(m);
+                        m &= m - 1;
+                        const uint32_t chi = __builtin_amdgcn_readlane(khi, src);
+                        const uint32_t clo = __builtin_amdgcn_readlane(klo, src);
+                        coop_insert<ITEMS>(keys + (size_t)(src & 31) * k, k, ((uint64_t)chi << 32) | clo, lane);
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
-                tau_d = lane_valid ? u2f((uint32_t)(tauk[q] >> 32)) : -__builtin_inff();
+                tau_d = lane_valid ? u2f((uint32_t)(keys[(size_t)q * k + k - 1] >> 32)) : -__builtin_inff();
             }
         }
 
+#ifndef TDR_ABLATE_NOSTAGE
         if (has_next) stage_store<KQ>(cur ? tile0 : tile1, regs, tid);
+#endif
+#ifndef TDR_ABLATE_NOBARRIER
         __syncthreads();
+#endif
         cur ^= 1;
     }
 
-    // --- emit: rank-sort each query's list (keys are unique) and write it out
+    // --- emit: every list is already ascending by (distance, index)
     if (wave_active) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         for (int jq = 0; jq < 32; ++jq) {
             const int64_t qi = qt * 32 + jq;
             if (qi >= P.nq) break;
-            for (int p0 = 0; p0 < k; p0 += 64) {
-                const int p = p0 + lane;
-                uint64_t mine = (p < k) ? keys[p * 32 + jq] : KEY_SENTINEL;
-                int rank = 0;
-                for (int pp = 0; pp < k; ++pp) rank += (keys[pp * 32 + jq] < mine) ? 1 : 0;
-                if (p < k) {
-                    if (P.n_splits > 1) {
-                        P.ws_keys[((size_t)split * P.nq + qi) * k + rank] = mine;
-                    } else {
-                        float c = u2f((uint32_t)(mine >> 32));
-                        if (P.metric == 1) c = sqrt_rn(fmaxf(c, 0.f));
-                        P.out_d[(size_t)qi * k + rank] = c;
-                        P.out_i[(size_t)qi * k + rank] = (int32_t)(uint32_t)(mine & 0xffffffffu);
-                    }
+            for (int p = lane; p < k; p += 64) {
+                const uint64_t mine = keys[(size_t)jq * k + p];
+                if (P.n_splits > 1) {
+                    P.ws_keys[((size_t)split * P.nq + qi) * k + p] = mine;
+                } else {
+                    float c = u2f((uint32_t)(mine >> 32));
+                    if (P.metric == 1) c = sqrt_rn(fmaxf(c, 0.f));
+                    P.out_d[(size_t)qi * k + p] = c;
+                    P.out_i[(size_t)qi * k + p] = (int32_t)(uint32_t)(mine & 0xffffffffu);
                 }
             }
         }
@@ -462,18 +500,23 @@ static inline int pick_kq(int d) {
 using namespace tdr;
 
 static size_t knn_lds_bytes(int kq, int k) {
-    return (size_t)2 * (kq * 256 + 32) * sizeof(float) + (size_t)4 * k * 32 * sizeof(uint64_t) +
-           (size_t)4 * 32 * sizeof(uint64_t) + (size_t)4 * 32 * sizeof(int);
+    return (size_t)2 * (kq * 256 + 32) * sizeof(float) + (size_t)4 * k * 32 * sizeof(uint64_t);
 }
 
-template <int KQ>
-static int launch_scan(const KnnParams& P, int n_wgs, size_t lds, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scan_kernel<KQ>),
+template <int KQ, int ITEMS>
+static int launch_scan_i(const KnnParams& P, int n_wgs, size_t lds, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scan_kernel<KQ, ITEMS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(knn_scan_kernel<KQ>, dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((knn_scan_kernel<KQ, ITEMS>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(256), lds, st, P);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
+}
+template <int KQ>
+static int launch_scan(const KnnParams& P, int n_wgs, size_t lds, hipStream_t st) {
+    if (P.k <= 64) return launch_scan_i<KQ, 1>(P, n_wgs, lds, st);
+    if (P.k <= 128) return launch_scan_i<KQ, 2>(P, n_wgs, lds, st);
+    return launch_scan_i<KQ, 3>(P, n_wgs, lds, st);
 }
 
 extern "C" {
