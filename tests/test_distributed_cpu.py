@@ -1,0 +1,119 @@
+"""N > 1 host logic on CPU: world_size-2 gloo processes exercise the exchange steps of the row-sharded
+path (edge routing all-to-all-v, row all-gather, gradient all-reduce) that RCCL runs on the GPUs."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.test_oracle_golden import load
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_rows, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from torchdr_amd.distributed import DistributedContext, chunk_bounds
+        from torchdr_amd.parallel import allgather_rows, allreduce_, exchange_transposed_edges
+
+        a = load("affinity")
+        P, I = a["umap10_P"][:n_rows], a["umap10_I"][:n_rows].clamp(max=n_rows - 1)
+        ctx = DistributedContext()
+        assert ctx.is_initialized and ctx.world_size == world and ctx.rank == rank
+        s, e = ctx.compute_chunk_bounds(n_rows)
+        assert (s, e) == chunk_bounds(n_rows, rank, world)
+        er, ec, ev = exchange_transposed_edges(P[s:e], I[s:e], s, n_rows, world)
+        # expected: every edge (i -> j) of OTHER ranks whose target j is owned here
+        owner = DistributedContext.get_rank_for_indices(torch.arange(n_rows), n_rows, world)
+        ii = torch.arange(n_rows).repeat_interleave(P.shape[1])
+        jj = I.reshape(-1).long()
+        vv = P.reshape(-1)
+        m = (owner[jj] == rank) & (owner[ii] != rank)
+        exp = sorted(zip((jj[m] - s).tolist(), ii[m].tolist(), vv[m].tolist()))
+        got = sorted(zip(er.tolist(), ec.tolist(), ev.tolist()))
+        assert got == exp, f"rank {rank}: routed edges differ"
+        # all-gather of uneven row chunks reassembles the full matrix
+        full = torch.arange(n_rows * 2, dtype=torch.float32).reshape(n_rows, 2)
+        out = allgather_rows(full[s:e].clone(), n_rows, world)
+        assert torch.equal(out, full)
+        g = torch.full((4, 2), float(rank + 1))
+        allreduce_(g)
+        assert torch.equal(g, torch.full((4, 2), float(sum(range(1, world + 1)))))
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [600, 599])
+def test_exchange_steps_world_size_2(n_rows):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, n_rows, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))
+
+
+def test_route_edges_partition():
+    """route_edges is a pure partition of the edge list (no communication)."""
+    from torchdr_amd.distributed import DistributedContext
+    from torchdr_amd.parallel import route_edges
+
+    a = load("affinity")
+    P, I = a["umap30_P"], a["umap30_I"]
+    n, k = P.shape
+    W = 4
+    routed = route_edges(P, I, 0, n, W, rank=1)
+    assert routed[1] is None
+    total = sum(p[0].numel() for p in routed if p is not None)
+    owner = DistributedContext.get_rank_for_indices(I.reshape(-1).long(), n, W)
+    assert total == int((owner != 1).sum())
+    for r, p in enumerate(routed):
+        if p is None:
+            continue
+        assert (DistributedContext.get_rank_for_indices(p[1].long(), n, W) == r).all()
+
+
+def test_abi_header_matches_library():
+    """Every prototype of include/torchdr_amd.h is exported by the built shared object (no compute)."""
+    import ctypes
+
+    from torchdr_amd import _lib
+
+    protos = _lib.parse_header()
+    assert len(protos) >= 20
+    so = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(so, name), f"{name} declared in the header but not exported"
+    # host-only queries work without a GPU
+    so.tdr_packed_floats.restype = ctypes.c_int64
+    so.tdr_packed_floats.argtypes = [ctypes.c_int64, ctypes.c_int]
+    assert so.tdr_packed_floats(64, 128) == 2 * (16 * 256 + 32)
+    assert so.tdr_packed_floats(64, 300) == 0
+    so.tdr_knn_max_k.argtypes = [ctypes.c_int]
+    assert so.tdr_knn_max_k(128) >= 90
+
+
+def test_product_fails_loudly_without_gpu():
+    from torchdr_amd import UMAP
+    from torchdr_amd.distance import pairwise_distances
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU"):
+        pairwise_distances(torch.randn(50, 4), k=3)
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU"):
+        UMAP(n_neighbors=5).fit_transform(torch.randn(100, 4))

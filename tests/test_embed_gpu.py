@@ -147,3 +147,59 @@ def test_umap_errors_and_duplicates():
     Z = UMAP(n_neighbors=10, max_iter=20, random_state=1).fit_transform(Xd)
     assert Z.shape == (525, 2)
     assert torch.equal(Z[:25], Z[500:])  # duplicates share their embedding (base.py:132-148)
+
+
+@pytest.mark.parametrize(
+    "name,kw,ref_score",
+    [
+        # ref_score: neighbourhood preservation of the REAL reference (CPU) on the same data / settings
+        ("LargeVis", dict(perplexity=10, max_iter=300), 0.186),
+        ("TSNE", dict(perplexity=10, max_iter=400), 0.175),
+    ],
+)
+def test_largevis_tsne_end_to_end_quality(name, kw, ref_score):
+    import torchdr_amd
+
+    X = gmm(3000, 32, 4.0, seed=5)
+    m = getattr(torchdr_amd, name)(random_state=0, **kw)
+    Z = m.fit_transform(X.cuda())
+    assert Z.shape == (3000, 2) and torch.isfinite(Z).all()
+    assert int(m.n_iter_) == kw["max_iter"] - 1
+    score = knn_preservation(X, Z.detach().cpu().contiguous(), 15)
+    assert score > ref_score - 0.03, (score, ref_score)
+
+
+def test_tsne_exaggeration_switch_and_schedules():
+    """Optimizer / scheduler plumbing mirrors the reference (neighbor_embedding/base.py:282-350):
+    TSNE lr = max(N/12/4, 50) and momentum 0.5 until the switch, then N/4 and 0.8 with a fresh
+    momentum buffer; LargeVis: LinearLR with torch defaults (1/3 -> 1 over 5 steps)."""
+    import torchdr_amd
+
+    X = gmm(1200, 16, 3.0, seed=2).cuda()
+    seen = {}
+
+    class Probe(torchdr_amd.TSNE):
+        def _optimizer_step(self, grad):
+            t = int(self.n_iter_)
+            if t in (0, 4, 5, 6):
+                seen[t] = (self._current_lr(), self._sgd_momentum, float(self.early_exaggeration_coeff_),
+                           self._momentum_buf is None)
+            super()._optimizer_step(grad)
+
+    Probe(perplexity=8, max_iter=8, early_exaggeration_iter=5, random_state=0).fit_transform(X)
+    assert seen[0] == (50.0, 0.5, 12.0, True)
+    assert seen[4][1] == 0.5 and seen[4][2] == 12.0
+    assert seen[5] == (50.0, 0.5, 12.0, False)       # the switch happens AFTER step 5 (on_training_step_end)
+    assert seen[6] == (300.0, 0.8, 1.0, True)        # rebuilt optimizer: new lr, momentum, empty buffer
+
+    lrs = []
+
+    class ProbeL(torchdr_amd.LargeVis):
+        def _optimizer_step(self, grad):
+            lrs.append(self._current_lr())
+            super()._optimizer_step(grad)
+
+    ProbeL(perplexity=5, max_iter=8, random_state=0).fit_transform(X)
+    base = 1200 / 4
+    expect = [base * (1 / 3 + (2 / 3) * min(t, 5) / 5) for t in range(8)]
+    assert np.allclose(lrs, expect, rtol=1e-6)

@@ -7,4 +7,4 @@ from torchdr_amd.distributed import DistributedContext  # noqa: F401
 from torchdr_amd.affinity import (  # noqa: F401,E402
     Affinity, LogAffinity, SparseAffinity, SparseLogAffinity, EntropicAffinity, UMAPAffinity,
 )
-from torchdr_amd.neighbor_embedding import UMAP  # noqa: F401,E402
+from torchdr_amd.neighbor_embedding import UMAP, LargeVis, TSNE  # noqa: F401,E402

@@ -1,2 +1,4 @@
 from .base import NeighborEmbedding, NegativeSamplingNeighborEmbedding  # noqa: F401
 from .umap import UMAP, find_ab_params  # noqa: F401
+from .largevis import LargeVis  # noqa: F401
+from .tsne import TSNE  # noqa: F401

@@ -1,0 +1,62 @@
+"""LargeVis on MI355X -- mirror of ``torchdr/neighbor_embedding/largevis.py`` (reference :108-201)."""
+
+from typing import Dict, Optional, Type, Union
+
+import torch
+
+from torchdr_amd import _lib
+from torchdr_amd.affinity import EntropicAffinity
+from torchdr_amd.neighbor_embedding.base import NegativeSamplingNeighborEmbedding
+
+
+class LargeVis(NegativeSamplingNeighborEmbedding):
+    r"""LargeVis: entropic input affinity, :math:`Q_{ij} = 1/(2 + \|z_i - z_j\|^2)`, loss
+    :math:`-\sum_{ij} P_{ij}\log Q_{ij} - \tfrac1N\sum_{i,\,j\in\mathrm{Neg}(i)}\log(1 - Q_{ij})`
+    (reference ``largevis.py:181-201``).  Its gradient is evaluated in closed form by
+    ``tdr_ne_grad_f32`` (both endpoints of every edge move, as with autograd's gather backward).
+    Defaults as the reference: ``lr="auto"`` (= max(N/4, 50)), SGD momentum 0.8, ``LinearLR`` with
+    torch's default arguments (lr ramps 1/3 -> 1 over the first 5 steps)."""
+
+    def __init__(self, perplexity: float = 30, n_components: int = 2, lr: Union[float, str] = "auto",
+                 optimizer: Union[str, Type[torch.optim.Optimizer]] = "SGD",
+                 optimizer_kwargs: Union[Dict, str] = "auto",
+                 scheduler: Optional[Union[str, Type[torch.optim.lr_scheduler.LRScheduler]]] = "LinearLR",
+                 scheduler_kwargs: Optional[Dict] = None, init: str = "pca", init_scaling: float = 1e-4,
+                 min_grad_norm: float = 1e-7, max_iter: int = 1000, device: str = "auto", backend="faiss",
+                 verbose: bool = False, random_state: Optional[float] = None, max_iter_affinity: int = 100,
+                 metric: str = "sqeuclidean", n_negatives: int = 5, sparsity: bool = True,
+                 early_exaggeration_coeff: Optional[float] = None, early_exaggeration_iter: Optional[int] = None,
+                 check_interval: int = 50, discard_NNs: bool = False, compile: bool = False,
+                 distributed: Union[bool, str] = "auto", **kwargs):
+        self.metric = metric
+        self.perplexity = perplexity
+        self.max_iter_affinity = max_iter_affinity
+        self.sparsity = sparsity
+        affinity_in = EntropicAffinity(perplexity=perplexity, metric=metric, max_iter=max_iter_affinity,
+                                       device=device, backend=backend, verbose=verbose, sparsity=sparsity,
+                                       distributed=distributed)
+        super().__init__(affinity_in=affinity_in, n_components=n_components, optimizer=optimizer,
+                         optimizer_kwargs=optimizer_kwargs, min_grad_norm=min_grad_norm, max_iter=max_iter, lr=lr,
+                         scheduler=scheduler, scheduler_kwargs=scheduler_kwargs, init=init,
+                         init_scaling=init_scaling, device=device, backend=backend, verbose=verbose,
+                         random_state=random_state, early_exaggeration_coeff=early_exaggeration_coeff,
+                         early_exaggeration_iter=early_exaggeration_iter, n_negatives=n_negatives,
+                         check_interval=check_interval, discard_NNs=discard_NNs, compile=compile,
+                         distributed=distributed, **kwargs)
+
+    def _compute_gradients(self):
+        n, nc = self.n_samples_in_, self.n_components
+        grad = torch.zeros((n, nc), dtype=torch.float32, device=self.device_)
+        nn = self.NN_indices_
+        P = self.affinity_in_
+        neg = self._neg_ptr_tensor()
+        _lib.check(
+            _lib.lib().tdr_ne_grad_f32(
+                _lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_, _lib.ptr(nn), _lib.ptr(P),
+                P.shape[1], 0, float(self.early_exaggeration_coeff_), float(self.repulsion_strength) * 2.0 / n,
+                int(self.n_negatives), _lib.ptr(neg), self._neg_seed, int(self.n_iter_), _lib.ptr(grad),
+                _lib.stream_ptr(),
+            ),
+            "tdr_ne_grad_f32",
+        )
+        return grad, False
