@@ -106,6 +106,16 @@ int tdr_sgd_step_f32(float* Z, const float* grad, float* buf, int64_t n, float l
                      int* nan_flag, int n_iter, void* stream);
 int tdr_fill_f32(float* p, int64_t n, float v, void* stream);
 
+/* ---- K7 / K8: matrix-free dense affinities (TSNEkhorn) ------------------------------------------------
+ * affinity/entropic.py:37-42,518-565 (_log_Pse, row entropy / logsumexp of the dual-ascent loop) */
+int tdr_sea_rowstats_f32(const float* packed, int64_t n, int d, const float* side, int exclude_diag, float diag_add,
+                         float* psum, float* ent, void* stream);
+/* gradient of neighbor_embedding/tsnekhorn.py:210-230 w.r.t. the embedding (duals detached) */
+int tdr_khorn_grad_f32(const float* packed, int64_t n, int d, const float* side, float log_n, float* grad, void* stream);
+/* affinity/entropic.py:733-740: one symmetric log-domain Sinkhorn update, student kernel on the embedding */
+int tdr_sinkhorn_pass_f32(const float* Z, int nc, const float* f, const float* Ef, float fmax, int64_t n, int zero_diag,
+                          float diag_add, float* f_new, float* resid2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

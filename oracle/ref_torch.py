@@ -308,3 +308,63 @@ def sgd_momentum_step(Z, grad, buf, lr, momentum):
         return Z - lr * grad, buf
     buf = grad.clone() if buf is None else buf * momentum + grad
     return Z - lr * buf, buf
+
+
+# --------------------------------------------------------------------------------------------
+# TSNEkhorn -- affinity/entropic.py:437-577 (SEA, first-order optimizer branch), :693-755 (Sinkhorn,
+# student kernel), neighbor_embedding/tsnekhorn.py:210-230 (loss; gradient in closed form)
+# --------------------------------------------------------------------------------------------
+
+
+def sea_affinity(C, perplexity, lr=1e-1, max_iter=100, tol=1e-3, eps_square=True, optimizer="Adam"):
+    """C: dense (n, n) squared distances (diagonal as the caller wants it).  Returns
+    (eps, mu, log_P - log n, n_iter); log_P is the matrix evaluated BEFORE the last dual step (:573)."""
+    n = C.shape[0]
+    target = torch.log(torch.tensor(float(perplexity), dtype=C.dtype)) + 1
+    eps = torch.ones(n, dtype=C.dtype)
+    mu = torch.ones(n, dtype=C.dtype)
+    opt = getattr(torch.optim, optimizer)([eps, mu], lr=lr)
+    log_P = None
+    k = 0
+    for k in range(max_iter):
+        e = eps**2 if eps_square else eps
+        log_P = (mu[:, None] + mu[None, :] - 2 * C) / (e[:, None] + e[None, :])
+        H = entropy_log(log_P)
+        P_sum = log_P.logsumexp(1).exp()
+        g_eps = H - target
+        if eps_square:
+            g_eps = 2 * eps.clone() * g_eps
+        g_mu = P_sum - 1
+        eps.grad, mu.grad = g_eps, g_mu
+        opt.step()
+        if not eps_square:
+            eps.clamp_(min=0)
+        if torch.norm(g_eps) < tol and torch.norm(g_mu) < tol:
+            break
+    return eps, mu, log_P - math.log(n), k
+
+
+def sinkhorn_student(Z, init_dual=None, max_iter=5, tol=1e-5, zero_diag=True):
+    n = Z.shape[0]
+    D = torch.cdist(Z, Z) ** 2 if False else ((Z[:, None, :] - Z[None, :, :]) ** 2).sum(-1)
+    if zero_diag:
+        D = D + torch.diag(torch.full((n,), 1e12, dtype=Z.dtype))
+    log_K = -(1 + D).log()
+    dual = torch.zeros(n, dtype=Z.dtype) if init_dual is None else init_dual.clone()
+    k = 0
+    for k in range(max_iter):
+        red = -(log_K + dual[:, None]).logsumexp(0)
+        dual = 0.5 * (dual + red)
+        if torch.norm(dual - red) < tol:
+            break
+    return dual, log_K, k
+
+
+def tsnekhorn_grad(Z, log_P, dual, log_K):
+    """Closed-form gradient of CE(P, log Q) + sum(Q) with the dual detached:
+    4 sum_j (P_ij - Q_ij)/(1 + d_ij) (z_i - z_j);  log Q = dual_i + dual_j + log K - log n."""
+    n = Z.shape[0]
+    log_Q = dual[:, None] + dual[None, :] + log_K - math.log(n)
+    W = log_K.exp()  # 1/(1+d)
+    M = (log_P.exp() - log_Q.exp()) * W
+    return 4 * (M.sum(1, keepdim=True) * Z - M @ Z)

@@ -227,3 +227,47 @@ if __name__ == "__main__":
     ne_step_fixture()
     distributed_fixture()
     print("reference version:", torchdr.__version__)
+
+
+def tsnekhorn_fixture():
+    from torchdr import TSNEkhorn
+    from torchdr.affinity import SinkhornAffinity, SymmetricEntropicAffinity
+
+    X = gmm(256, 16, 2.0, seed=61)
+    out = {"X": X}
+    sea = SymmetricEntropicAffinity(perplexity=10, lr=1e-1, max_iter=30, tol=1e-3, zero_diag=False, backend=None)
+    logP = sea(X, log=True)
+    out.update(sea_logP=logP, sea_eps=sea.eps_.detach(), sea_mu=sea.mu_.detach(), sea_n_iter=torch.tensor(int(sea.n_iter_)))
+    sea_z = SymmetricEntropicAffinity(perplexity=10, lr=1e-1, max_iter=8, tol=1e-3, zero_diag=True, backend=None)
+    out["sea_zd_logP"] = sea_z(X, log=True)
+    g = torch.Generator().manual_seed(62)
+    Z = torch.randn(256, 2, generator=g) * 3
+    init = torch.randn(256, generator=g) * 0.1
+    sk = SinkhornAffinity(base_kernel="student", max_iter=5, backend=None)
+    logQ = sk(Z, log=True, init_dual=init.clone())
+    out.update(sk_Z=Z, sk_init=init, sk_dual=sk.dual_.detach(), sk_logQ=logQ)
+    rec = {}
+
+    class Probe(TSNEkhorn):
+        def _training_step(self):
+            t = int(self.n_iter_)
+            if t < 2:
+                rec[f"Z_{t}"] = self.embedding_.detach().clone()
+            loss = super()._training_step()
+            if t < 2:
+                rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                rec[f"dual_{t}"] = self.dual_sinkhorn_.detach().clone()
+                rec[f"loss_{t}"] = loss.detach().clone()
+                rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+                if t == 0:
+                    rec["logP"] = self.affinity_in_.log().detach().clone() if False else None
+            return loss
+
+    torch.manual_seed(3)
+    m = Probe(perplexity=10, max_iter=3, max_iter_affinity_in=30, init="normal", init_scaling=1.0,
+              min_grad_norm=1e-12, lr=1.0, optimizer="SGD", optimizer_kwargs=None, backend=None, random_state=3)
+    m.fit_transform(X)
+    for k_, v in rec.items():
+        if v is not None:
+            out[f"tk_{k_}"] = v
+    save("tsnekhorn", **out)

@@ -162,3 +162,35 @@ def test_distributed_tables():
             ctx = DistributedContext(force_enable=True)
             ctx.world_size, ctx.rank = w, w - 1
             assert ctx.compute_chunk_bounds(n) == tuple(b[-1])
+
+
+def test_tsnekhorn_oracle():
+    g = load("tsnekhorn")
+    X = g["X"]
+    n = X.shape[0]
+    _, _, C = oracle.knn(X, 0, "sqeuclidean", False, want_full=True)
+    eps, mu, logP, k = R.sea_affinity(C, 10, lr=1e-1, max_iter=30, tol=1e-3)
+    assert k == int(g["sea_n_iter"])
+    assert torch.allclose(eps, g["sea_eps"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(mu, g["sea_mu"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(logP, g["sea_logP"], rtol=1e-4, atol=1e-3)
+    Cz = C.clone()
+    idx = torch.arange(n)
+    Cz[idx, idx] += 1e12
+    _, _, logPz, _ = R.sea_affinity(Cz, 10, lr=1e-1, max_iter=8, tol=1e-3)
+    off = ~torch.eye(n, dtype=torch.bool)
+    assert torch.allclose(logPz[off], g["sea_zd_logP"][off], rtol=1e-4, atol=1e-3)
+    dual, log_K, _ = R.sinkhorn_student(g["sk_Z"], g["sk_init"], 5, 1e-5)
+    assert torch.allclose(dual, g["sk_dual"], rtol=1e-5, atol=1e-6)
+    logQ = dual[:, None] + dual[None, :] + log_K - np.log(n)
+    assert torch.allclose(logQ, g["sk_logQ"], rtol=1e-5, atol=1e-5)
+    # TSNEkhorn gradient: closed form vs the reference's autograd
+    init = None
+    for t in range(2):
+        Z = g[f"tk_Z_{t}"]
+        dual, log_K, _ = R.sinkhorn_student(Z, init, 5, 1e-5)
+        init = dual
+        assert torch.allclose(dual, g[f"tk_dual_{t}"], rtol=1e-5, atol=1e-6)
+        grad = R.tsnekhorn_grad(Z, g["sea_logP"], dual, log_K)
+        ref = g[f"tk_grad_{t}"]
+        assert torch.allclose(grad, ref, rtol=1e-3, atol=1e-5 * float(ref.abs().max()))

@@ -1,0 +1,108 @@
+"""K7 / K8 parity (GPU): matrix-free SEA, Sinkhorn and the TSNEkhorn force vs golden vectors of the reference."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import gmm
+from tests.test_oracle_golden import load
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sea_matrix_free_vs_reference():
+    from torchdr_amd.affinity import SymmetricEntropicAffinity
+
+    g = load("tsnekhorn")
+    X = g["X"].cuda()
+    n = X.shape[0]
+    sea = SymmetricEntropicAffinity(perplexity=10, lr=1e-1, max_iter=30, tol=1e-3, zero_diag=False)
+    logP = sea(X, log=True)
+    assert int(sea.n_iter_) == int(g["sea_n_iter"])
+    assert torch.allclose(sea.eps_.cpu(), g["sea_eps"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(sea.mu_.cpu(), g["sea_mu"], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(logP.cpu(), g["sea_logP"], rtol=1e-4, atol=2e-3)
+    assert torch.allclose(logP.exp().cpu(), g["sea_logP"].exp(), rtol=2e-3, atol=1e-9)
+    assert torch.allclose(logP, logP.T, atol=1e-5)  # symmetry (reference test_affinity.py:260)
+    seaz = SymmetricEntropicAffinity(perplexity=10, lr=1e-1, max_iter=8, tol=1e-3, zero_diag=True)
+    lz = seaz(X, log=True).cpu()
+    off = ~torch.eye(n, dtype=torch.bool)
+    assert torch.allclose(lz[off], g["sea_zd_logP"][off], rtol=1e-4, atol=2e-3)
+
+
+def test_sea_rowstats_vs_oracle_medium():
+    """Row statistics at a size with many tiles / several workgroups, against a dense fp64 evaluation."""
+    import oracle
+    from torchdr_amd.affinity.entropic import sea_rowstats
+    from torchdr_amd.distance import PackedPoints
+
+    X = gmm(3000, 64, 2.0, seed=8)
+    _, _, C = oracle.knn(X, 0, "sqeuclidean", False, want_full=True)
+    gen = torch.Generator().manual_seed(1)
+    mu = torch.rand(3000, generator=gen) * 2 - 1
+    e = torch.rand(3000, generator=gen) * 20 + 40
+    lp = (mu[:, None] + mu[None, :] - 2 * C.double()) / (e[:, None] + e[None, :]).double()
+    S_ref = lp.exp().sum(1)
+    H_ref = -(lp.exp() * (lp - 1)).sum(1)
+    S, H = sea_rowstats(PackedPoints(X.cuda()), mu.cuda(), e.cuda(), False)
+    assert torch.allclose(S.cpu().double(), S_ref, rtol=2e-5)
+    assert torch.allclose(H.cpu().double(), H_ref, rtol=2e-5, atol=1e-4)
+
+
+def test_sinkhorn_student_vs_reference():
+    from torchdr_amd.affinity import SinkhornAffinity
+
+    g = load("tsnekhorn")
+    sk = SinkhornAffinity(base_kernel="student", max_iter=5)
+    logQ = sk(g["sk_Z"].cuda(), log=True, init_dual=g["sk_init"].cuda())
+    assert torch.allclose(sk.dual_.cpu(), g["sk_dual"], rtol=1e-5, atol=2e-6)
+    assert torch.allclose(logQ.cpu(), g["sk_logQ"], rtol=1e-5, atol=1e-5)
+    # run to convergence: doubly stochastic (rows of Q sum to 1/n) -- reference test_affinity.py:294
+    sk2 = SinkhornAffinity(base_kernel="student", max_iter=1000, tol=1e-5)
+    Q = sk2(g["sk_Z"].cuda())
+    assert torch.allclose(Q.sum(1).cpu(), torch.full((256,), 1 / 256), rtol=1e-3)
+    with pytest.raises(NotImplementedError):
+        SinkhornAffinity(base_kernel="gaussian")(g["sk_Z"].cuda())
+
+
+def test_tsnekhorn_gradient_and_steps_vs_reference_autograd():
+    import torchdr_amd
+    from torchdr_amd import _lib
+    from torchdr_amd.affinity.entropic import sinkhorn_student_dual
+    from torchdr_amd.distance import PackedPoints
+
+    g = load("tsnekhorn")
+    X = g["X"].cuda()
+    n = X.shape[0]
+    sea = torchdr_amd.SymmetricEntropicAffinity(perplexity=10, lr=1e-1, max_iter=30, tol=1e-3, zero_diag=False)
+    packed = sea.fit_duals(X)
+    mu, e = sea.dual_side()
+    init = None
+    for t in range(2):
+        Z = g[f"tk_Z_{t}"].cuda().contiguous()
+        dual, _ = sinkhorn_student_dual(Z, init, 5, 1e-5, True)
+        init = dual
+        assert torch.allclose(dual.cpu(), g[f"tk_dual_{t}"], rtol=1e-5, atol=2e-6)
+        side = torch.stack([mu, e, Z[:, 0], Z[:, 1], dual.exp()], dim=1).contiguous()
+        grad = torch.empty((n, 2), device="cuda")
+        _lib.check(_lib.lib().tdr_khorn_grad_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), float(np.log(n)),
+                                                 _lib.ptr(grad), _lib.stream_ptr()), "khorn")
+        ref = g[f"tk_grad_{t}"]
+        assert torch.allclose(grad.cpu(), ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()))
+
+
+def test_tsnekhorn_estimator():
+    import torchdr_amd
+
+    X = gmm(1500, 32, 4.0, seed=5)
+    m = torchdr_amd.TSNEkhorn(perplexity=10, max_iter=60, max_iter_affinity_in=40, init="normal", init_scaling=1.0,
+                              lr=1.0, optimizer="SGD", optimizer_kwargs=None, min_grad_norm=1e-12, random_state=0)
+    Z = m.fit_transform(X.cuda())
+    assert Z.shape == (1500, 2) and torch.isfinite(Z).all()
+    # defaults reproduce the reference's behaviour on small inits: the loop stops at iteration 0 because the
+    # gradient norm is below min_grad_norm = 1e-4
+    m2 = torchdr_amd.TSNEkhorn(perplexity=10, max_iter=50, max_iter_affinity_in=20, random_state=0)
+    m2.fit_transform(X.cuda())
+    assert int(m2.n_iter_) == 0
+    with pytest.raises(ValueError, match="does not support distributed"):
+        torchdr_amd.TSNEkhorn(distributed=True)

@@ -124,3 +124,187 @@ class EntropicAffinity(SparseLogAffinity):
         self.register_buffer("eps_", eps, persistent=False)
         self.register_buffer("log_normalization_", log_norm.unsqueeze(1), persistent=False)
         return (log_P, indices) if return_indices else log_P
+
+
+# ------------------------------------------------------------------------------------------------------
+# Symmetric entropic affinity (SEA) and Sinkhorn affinity -- matrix-free (reference :315-577, :580-755)
+# ------------------------------------------------------------------------------------------------------
+from torchdr_amd.affinity.base import LogAffinity  # noqa: E402
+from torchdr_amd.distance.base import PackedPoints, dense_packed  # noqa: E402
+from torchdr_amd.utils import check_NaNs  # noqa: E402
+
+_DENSE_LIMIT = 30000  # largest N for which the dense (N, N) API output is materialised
+
+
+def sea_rowstats(packed: PackedPoints, mu: torch.Tensor, e: torch.Tensor, zero_diag: bool):
+    """(P_sum, H) of the implicit matrix exp((mu_i+mu_j-2C_ij)/(e_i+e_j)) -- K7 ``tdr_sea_rowstats_f32``."""
+    n = packed.n
+    side = torch.stack([mu, e], dim=1).contiguous()
+    psum = torch.empty(n, dtype=torch.float32, device=mu.device)
+    ent = torch.empty(n, dtype=torch.float32, device=mu.device)
+    _lib.check(
+        _lib.lib().tdr_sea_rowstats_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), 1 if zero_diag else 0,
+                                        1e12, _lib.ptr(psum), _lib.ptr(ent), _lib.stream_ptr()),
+        "tdr_sea_rowstats_f32",
+    )
+    return psum, ent
+
+
+class SymmetricEntropicAffinity(LogAffinity):
+    r"""Symmetric entropic affinity of SNEkhorn (reference ``entropic.py:315-577``): dual ascent on
+    :math:`(\varepsilon, \mu)` so that :math:`P_{ij} = \exp((\mu_i + \mu_j - 2C_{ij})/(\varepsilon_i^2 +
+    \varepsilon_j^2))` has unit row sums and row entropies :math:`\log\xi + 1`.
+
+    The dual loop is **matrix-free**: every iteration recomputes the pairwise distances tile by tile on
+    the MFMA pipe and reduces them to the two row statistics the gradients need (no N x N buffer).
+    ``fit_duals`` runs just that (what ``TSNEkhorn`` uses); calling the object returns the dense
+    log-affinity like the reference does, for N up to ``_DENSE_LIMIT``.  Only the first-order optimizers
+    path (``optimizer != "LBFGS"``, reference :518-571) is implemented."""
+
+    def __init__(self, perplexity: float = 30, lr: float = 1e-1, eps_square: bool = True, tol: float = 1e-3,
+                 max_iter: int = 500, check_interval: int = 50, optimizer: str = "Adam",
+                 metric: str = "sqeuclidean", zero_diag: bool = True, device: str = "auto", backend=None,
+                 verbose: bool = False, compile: bool = False, _pre_processed: bool = False):
+        super().__init__(metric=metric, zero_diag=zero_diag, device=device, backend=None, verbose=verbose,
+                         compile=compile, _pre_processed=_pre_processed)
+        self.perplexity = perplexity
+        self.lr = lr
+        self.eps_square = eps_square
+        self.tol = tol
+        self.max_iter = max_iter
+        self.check_interval = check_interval
+        self.optimizer = optimizer
+        self.n_iter_ = torch.tensor(0, dtype=torch.long)
+
+    def fit_duals(self, X: torch.Tensor) -> PackedPoints:
+        if self.metric != "sqeuclidean":
+            raise NotImplementedError("[torchdr_amd] SymmetricEntropicAffinity supports metric='sqeuclidean'.")
+        if self.optimizer == "LBFGS":
+            raise NotImplementedError("[torchdr_amd] SymmetricEntropicAffinity: LBFGS is not implemented.")
+        n = X.shape[0]
+        packed = PackedPoints(X)
+        perplexity = check_neighbor_param(self.perplexity, n)
+        target = torch.log(torch.tensor(float(perplexity), dtype=torch.float32, device=X.device)) + 1
+        eps = torch.ones(n, dtype=torch.float32, device=X.device)
+        mu = torch.ones(n, dtype=torch.float32, device=X.device)
+        self.register_buffer("eps_", eps, persistent=False)
+        self.register_buffer("mu_", mu, persistent=False)
+        optimizer = getattr(torch.optim, self.optimizer)([self.eps_, self.mu_], lr=self.lr)
+        k = 0
+        for k in range(self.max_iter):
+            with torch.no_grad():
+                optimizer.zero_grad()
+                e = self.eps_ ** 2 if self.eps_square else self.eps_
+                # duals BEFORE this step define the returned matrix (reference returns the pre-step log_P, :573)
+                self._dual_snapshot = (self.mu_.clone(), e.clone())
+                P_sum, H = sea_rowstats(packed, self.mu_, e, self.zero_diag)
+                grad_eps = H - target
+                if self.eps_square:
+                    grad_eps = 2 * self.eps_.clone().detach() * grad_eps
+                grad_mu = P_sum - 1
+                self.eps_.grad = grad_eps
+                self.mu_.grad = grad_mu
+                optimizer.step()
+                if not self.eps_square:
+                    self.eps_.clamp_(min=0)
+                check_NaNs([self.eps_, self.mu_],
+                           msg="[TorchDR] ERROR Affinity: NaN at iter {k}, consider decreasing the learning rate.")
+                if self.verbose and (k % self.check_interval == 0):
+                    perps = (H - 1).exp()
+                    self.logger.info(
+                        f"[{k}/{self.max_iter}] Perplexity:{float(perps.mean()): .2e} "
+                        f"(std:{float(perps.std()): .2e}), Marginal:{float(P_sum.mean()): .2e} "
+                        f"(std:{float(P_sum.std()): .2e})"
+                    )
+                if torch.norm(grad_eps) < self.tol and torch.norm(grad_mu) < self.tol:
+                    if self.verbose:
+                        self.logger.info(f"Convergence reached at iter {k}.")
+                    break
+        self.n_iter_ = k
+        return packed
+
+    def dual_side(self):
+        """(mu, e) that define the returned affinity: the duals of the LAST evaluated iterate."""
+        return self._dual_snapshot
+
+    def _compute_log_affinity(self, X: torch.Tensor):
+        n = X.shape[0]
+        if n > _DENSE_LIMIT:
+            raise MemoryError(
+                f"[torchdr_amd] dense SEA output for N={n} would need {4 * n * n / 2**30:.0f} GiB; "
+                "use TSNEkhorn (matrix-free) or SymmetricEntropicAffinity.fit_duals."
+            )
+        packed = self.fit_duals(X)
+        mu, e = self.dual_side()
+        C = dense_packed(packed, packed, "sqeuclidean", self.zero_diag)
+        log_P = (mu[:, None] + mu[None, :] - 2 * C) / (e[:, None] + e[None, :])
+        log_P -= math.log(n)
+        return log_P
+
+
+def sinkhorn_student_dual(Z: torch.Tensor, init_dual, max_iter: int, tol: float, zero_diag: bool = True):
+    """Symmetric Sinkhorn fixed point on the embedding (student kernel, eps = 1): reference
+    ``entropic.py:728-748``.  Returns (dual, n_iter)."""
+    _lib.require_gpu(Z, "Z")
+    Zc = Z.detach().contiguous().float()
+    n, nc = Zc.shape
+    f = torch.zeros(n, dtype=torch.float32, device=Z.device) if init_dual is None else init_dual.clone().float()
+    f_new = torch.empty_like(f)
+    resid2 = torch.zeros(1, dtype=torch.float32, device=Z.device)
+    L = _lib.lib()
+    k = 0
+    for k in range(max_iter):
+        fmax = float(f.max())
+        Ef = (f - fmax).exp()
+        resid2.zero_()
+        _lib.check(
+            L.tdr_sinkhorn_pass_f32(_lib.ptr(Zc), nc, _lib.ptr(f), _lib.ptr(Ef), fmax, n, 1 if zero_diag else 0,
+                                    1e12, _lib.ptr(f_new), _lib.ptr(resid2), _lib.stream_ptr()),
+            "tdr_sinkhorn_pass_f32",
+        )
+        f, f_new = f_new, f
+        if float(resid2.sqrt()) < tol:
+            break
+    return f, k
+
+
+class SinkhornAffinity(LogAffinity):
+    r"""Doubly stochastic affinity by symmetric log-domain Sinkhorn (reference ``entropic.py:580-755``).
+    The accelerated path covers what TSNEkhorn uses: ``base_kernel="student"``, ``eps=1`` on a 2-D / 3-D
+    embedding, no gradient tracking; other settings raise ``NotImplementedError``."""
+
+    def __init__(self, eps: float = 1.0, tol: float = 1e-5, max_iter: int = 1000, base_kernel: str = "gaussian",
+                 metric: str = "sqeuclidean", zero_diag: bool = True, device: str = "auto", backend=None,
+                 verbose: bool = False, with_grad: bool = False, compile: bool = False,
+                 _pre_processed: bool = False):
+        super().__init__(metric=metric, zero_diag=zero_diag, device=device, backend=None, verbose=verbose,
+                         compile=compile, _pre_processed=_pre_processed)
+        self.eps = eps
+        self.tol = tol
+        self.max_iter = max_iter
+        self.base_kernel = base_kernel
+        self.with_grad = with_grad
+
+    def fit_dual(self, X: torch.Tensor, init_dual=None):
+        if self.base_kernel != "student" or self.eps != 1.0 or self.with_grad or X.shape[1] not in (2, 3) \
+                or self.metric != "sqeuclidean":
+            raise NotImplementedError(
+                "[torchdr_amd] SinkhornAffinity: only base_kernel='student', eps=1, with_grad=False on a "
+                "2-D/3-D input is accelerated (the TSNEkhorn configuration)."
+            )
+        dual, k = sinkhorn_student_dual(X, init_dual, self.max_iter, self.tol, self.zero_diag)
+        self.register_buffer("dual_", dual, persistent=False)
+        self.n_iter_ = k
+        return dual
+
+    def _compute_log_affinity(self, X: torch.Tensor, init_dual=None):
+        n = X.shape[0]
+        if n > _DENSE_LIMIT:
+            raise MemoryError(f"[torchdr_amd] dense Sinkhorn output for N={n} is not materialised; use fit_dual.")
+        dual = self.fit_dual(X, init_dual)
+        Xc = X.detach().float()
+        D = ((Xc[:, None, :] - Xc[None, :, :]) ** 2).sum(-1)
+        if self.zero_diag:
+            D = D + torch.diag(torch.full((n,), 1e12, device=X.device))
+        log_K = -(1 + D).log()
+        return dual[:, None] + dual[None, :] + log_K - math.log(n)

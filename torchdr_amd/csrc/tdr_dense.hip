@@ -1,0 +1,374 @@
+// K7 / K8 -- matrix-free dense affinities for TSNEkhorn (symmetric entropic affinity in, Sinkhorn out).
+//
+// Replaces (citations under /root/reference/torchdr):
+//   affinity/entropic.py:37-42, 518-565   _log_Pse + row entropy + row logsumexp of the dense N x N
+//                                         log-affinity inside the dual-ascent loop of SymmetricEntropicAffinity
+//   affinity/entropic.py:45-48, 733-748   symmetric log-domain Sinkhorn iterations (student base kernel)
+//   neighbor_embedding/tsnekhorn.py:210-230  loss  CE(P, log Q) + sum(Q)  whose gradient w.r.t. the embedding is
+//                                         4 * sum_j (P_ij - Q_ij) / (1 + d_ij) * (z_i - z_j)   (duals detached)
+//
+// The reference materialises N x N matrices (160 GB each at N = 200k).  Here nothing of size N^2 exists:
+// the pairwise squared distances are recomputed tile by tile on the fp32 MFMA pipe from the packed point
+// images (same operand layout, same k-ordered FMA chain as the kNN scan in tdr_knn.hip), and each pass
+// reduces the tile on the fly -- a lane owns one row i of the affinity matrix and folds its 16 columns
+// per tile into running sums held in registers (flash-attention style streaming reductions).
+#include "tdr_common.h"
+
+namespace tdr {
+
+template <int KQ>
+__device__ __forceinline__ void dstage_load(const float* __restrict__ src, f32x4 (&regs)[(KQ * 64 + 8 + 255) / 256],
+                                            int tid) {
+    constexpr int NV = KQ * 64 + 8;
+    constexpr int IT = (NV + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < NV) regs[it] = *reinterpret_cast<const f32x4*>(src + (size_t)idx * 4);
+    }
+}
+template <int KQ>
+__device__ __forceinline__ void dstage_store(float* dst, const f32x4 (&regs)[(KQ * 64 + 8 + 255) / 256], int tid) {
+    constexpr int NV = KQ * 64 + 8;
+    constexpr int IT = (NV + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + it * 256;
+        if (idx < NV) *reinterpret_cast<f32x4*>(dst + (size_t)idx * 4) = regs[it];
+    }
+}
+
+struct PairScanParams {
+    const float* qp;       // packed rows (queries)
+    const float* yp;       // packed columns (database) -- same object for the symmetric passes
+    int64_t nq, q_offset, n_db;
+    int n_db_tiles;
+    const float* side;     // (n_db, SIDE) per-column scalars, row-major
+    const float* qside;    // (nq, SIDE) per-row scalars
+    float c0, c1;          // epilogue constants
+    float diag_add;        // added to C[i][i] when exclude_diag (distance/torch.py:111-116)
+    int exclude_diag;
+    float* out0;           // per-row outputs
+    float* out1;
+};
+
+// ---- epilogues ---------------------------------------------------------------------------------------
+// SEA row statistics: lp_ij = (mu_i + mu_j - 2 C_ij) / (e_i + e_j); outputs P_sum_i = sum_j exp(lp_ij) and
+// H_i = -sum_j exp(lp_ij) (lp_ij - 1)   (entropic.py:522-525; P is NOT normalised inside the entropy).
+struct SeaStats {
+    static constexpr int SIDE = 2;  // mu, e (= eps^2 or eps)
+    float mu_i, e_i, m, s, t;
+    __device__ __forceinline__ void init(const float* qs) { mu_i = qs[0]; e_i = qs[1]; m = -__builtin_inff(); s = 0.f; t = 0.f; }
+    __device__ __forceinline__ void add(float c, const float* sj, const PairScanParams&) {
+        const float lp = (mu_i + sj[0] - 2.0f * c) * __builtin_amdgcn_rcpf(e_i + sj[1]);
+        if (lp > m) {  // rescale running sums to the new maximum
+            const float sc = __expf(m - lp);
+            s *= sc; t *= sc; m = lp;
+        }
+        const float p = __expf(lp - m);
+        s += p;
+        t = fmaf(p, lp, t);
+    }
+    __device__ __forceinline__ void merge(const SeaStats& o) {
+        const float mm = fmaxf(m, o.m);
+        const float a = (m == -__builtin_inff()) ? 0.f : __expf(m - mm);
+        const float b = (o.m == -__builtin_inff()) ? 0.f : __expf(o.m - mm);
+        s = s * a + o.s * b; t = t * a + o.t * b; m = mm;
+    }
+    __device__ __forceinline__ void shfl_from(const SeaStats& x, int src) {
+        m = __shfl(x.m, src, 64); s = __shfl(x.s, src, 64); t = __shfl(x.t, src, 64); mu_i = x.mu_i; e_i = x.e_i;
+    }
+    __device__ __forceinline__ void store(int64_t row, const PairScanParams& P) const {
+        const float em = expf(m);
+        const float S = em * s, T = em * t;
+        P.out0[row] = S;
+        P.out1[row] = -(T - S);
+    }
+};
+
+// TSNEkhorn force: g_i = 4 * sum_j (P_ij - Q_ij) w_ij (z_i - z_j), w = 1/(1+|z_i-z_j|^2),
+//   P_ij = exp((mu_i+mu_j-2C_ij)/(e_i+e_j) - log N),  Q_ij = E_i E_j w_ij / N  with E = exp(dual)
+//   (the diagonal term vanishes with z_i - z_i).  side = (mu, e, z0, z1, E); out0 = grad (n, 2).
+struct KhornForce {
+    static constexpr int SIDE = 5;
+    float mu_i, e_i, z0, z1, E_i, g0, g1;
+    __device__ __forceinline__ void init(const float* qs) { mu_i = qs[0]; e_i = qs[1]; z0 = qs[2]; z1 = qs[3]; E_i = qs[4]; g0 = 0.f; g1 = 0.f; }
+    __device__ __forceinline__ void add(float c, const float* sj, const PairScanParams& P) {
+        const float lp = (mu_i + sj[0] - 2.0f * c) * __builtin_amdgcn_rcpf(e_i + sj[1]) - P.c0;  // c0 = log N
+        const float p = __expf(lp);
+        const float d0 = z0 - sj[2], d1 = z1 - sj[3];
+        const float w = __builtin_amdgcn_rcpf(1.0f + d0 * d0 + d1 * d1);
+        const float q = E_i * sj[4] * w * P.c1;  // c1 = 1/N
+        const float coef = (p - q) * w;
+        g0 = fmaf(coef, d0, g0);
+        g1 = fmaf(coef, d1, g1);
+    }
+    __device__ __forceinline__ void merge(const KhornForce& o) { g0 += o.g0; g1 += o.g1; }
+    __device__ __forceinline__ void shfl_from(const KhornForce& x, int src) { g0 = __shfl(x.g0, src, 64); g1 = __shfl(x.g1, src, 64); }
+    __device__ __forceinline__ void store(int64_t row, const PairScanParams& P) const {
+        P.out0[row * 2 + 0] = 4.0f * g0;
+        P.out0[row * 2 + 1] = 4.0f * g1;
+    }
+};
+
+template <int KQ, class Epi>
+__global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TILE_F = KQ * 256 + 32;
+    constexpr int SIDE = Epi::SIDE;
+    float* tile0 = reinterpret_cast<float*>(smem_raw);
+    float* tile1 = tile0 + TILE_F;
+    float* side0 = tile1 + TILE_F;  // [32][SIDE]
+    float* side1 = side0 + 32 * SIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 31, h = lane >> 5;
+    const int64_t n_qtiles = (P.nq + 31) / 32;
+    const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
+    const bool wave_active = qt < n_qtiles;
+    const int64_t gq = qt * 32 + q;
+    const bool lane_valid = wave_active && gq < P.nq;
+
+    float b[4 * KQ];
+    float xn = 0.f;
+    Epi epi;
+    {
+        float qs[SIDE];
+#pragma unroll
+        for (int c = 0; c < SIDE; ++c) qs[c] = lane_valid ? P.qside[(size_t)gq * SIDE + c] : 1.0f;
+        epi.init(qs);
+    }
+    if (wave_active) {
+        const float* qimg = P.qp + (size_t)qt * TILE_F;
+#pragma unroll
+        for (int t = 0; t < KQ; ++t) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(qimg + t * 256 + lane * 4);
+            b[4 * t + 0] = v[0]; b[4 * t + 1] = v[1]; b[4 * t + 2] = v[2]; b[4 * t + 3] = v[3];
+        }
+        xn = qimg[KQ * 256 + q];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4 * KQ; ++t) b[t] = 0.f;
+    }
+
+    constexpr int IT = (KQ * 64 + 8 + 255) / 256;
+    f32x4 regs[IT];
+    float sreg = 0.f;
+    auto side_load = [&](int T) {
+        if (tid < 32 * SIDE) {
+            const int64_t idx = (int64_t)T * 32 * SIDE + tid;
+            sreg = (idx < P.n_db * SIDE) ? P.side[idx] : 0.f;
+        }
+    };
+    dstage_load<KQ>(P.yp, regs, tid);
+    side_load(0);
+    dstage_store<KQ>(tile0, regs, tid);
+    if (tid < 32 * SIDE) side0[tid] = sreg;
+    __syncthreads();
+
+    int cur = 0;
+    for (int T = 0; T < P.n_db_tiles; ++T) {
+        const bool has_next = (T + 1) < P.n_db_tiles;
+        if (has_next) { dstage_load<KQ>(P.yp + (size_t)(T + 1) * TILE_F, regs, tid); side_load(T + 1); }
+        const float* img = cur ? tile1 : tile0;
+        const float* sd = cur ? side1 : side0;
+        if (wave_active) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            {
+                constexpr int GQ = (KQ >= 4) ? 4 : KQ, NG = KQ / GQ;
+                const float* ap = img + lane * 4;
+                f32x4 a0[GQ], a1[GQ];
+#pragma unroll
+                for (int u = 0; u < GQ; ++u) a0[u] = *reinterpret_cast<const f32x4*>(ap + u * 256);
+#pragma unroll
+                for (int g = 0; g < NG; g += 2) {
+                    if (g + 1 < NG) {
+#pragma unroll
+                        for (int u = 0; u < GQ; ++u) a1[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 1) * GQ + u) * 256);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < GQ; ++u) {
+                        const int t = g * GQ + u;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][0], b[4 * t + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][1], b[4 * t + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][2], b[4 * t + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][3], b[4 * t + 3], acc, 0, 0, 0);
+                    }
+                    if (g + 1 < NG) {
+                        if (g + 2 < NG) {
+#pragma unroll
+                            for (int u = 0; u < GQ; ++u) a0[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 2) * GQ + u) * 256);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < GQ; ++u) {
+                            const int t = (g + 1) * GQ + u;
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][0], b[4 * t + 0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][1], b[4 * t + 1], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][2], b[4 * t + 2], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][3], b[4 * t + 3], acc, 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            const float* ynp = img + KQ * 256 + 4 * h;
+            const int64_t row_base = (int64_t)T * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 y4 = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const int i = e + 8 * g + 4 * h;  // database row inside the tile
+                    const int64_t j = row_base + e + 8 * g;
+                    float c = __fsub_rn(__fadd_rn(xn, y4[e]), __fmul_rn(2.0f, acc[r]));
+                    if (P.exclude_diag && j == gq + P.q_offset) c = __fadd_rn(c, P.diag_add);
+                    if (j < P.n_db) {
+                        float sj[SIDE];
+#pragma unroll
+                        for (int s_ = 0; s_ < SIDE; ++s_) sj[s_] = sd[i * SIDE + s_];
+                        epi.add(c, sj, P);
+                    }
+                }
+            }
+        }
+        if (has_next) {
+            dstage_store<KQ>(cur ? tile0 : tile1, regs, tid);
+            if (tid < 32 * SIDE) (cur ? side0 : side1)[tid] = sreg;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // combine the two lanes (h = 0, 1) that share a row
+    if (wave_active) {
+        Epi other;
+        other.shfl_from(epi, lane ^ 32);
+        epi.merge(other);
+        if (h == 0 && lane_valid) epi.store(gq, P);
+    }
+}
+
+// ---- Sinkhorn pass on the 2-D / 3-D embedding (student kernel), entropic.py:733-740 --------------------
+//   red_j = -LSE_i(log K_ij + f_i),  log K_ij = -log(1 + d_ij) / eps,  d_ii += 1e12 when zero_diag
+// With eps == 1:  red_j = -( fmax + log sum_i exp(f_i - fmax) / (1 + d_ij) )  -- no per-pair transcendental.
+// out[j] = 0.5 * (f_j + red_j)  (the averaged update), resid2 += (out[j] - red_j)^2  (convergence test :738).
+template <int NC>
+__global__ __launch_bounds__(256) void sinkhorn_pass_kernel(const float* __restrict__ Z, const float* __restrict__ f,
+                                                            const float* __restrict__ Ef, float fmax, int64_t n,
+                                                            int zero_diag, float diag_add, float* __restrict__ f_new,
+                                                            float* __restrict__ resid2) {
+    __shared__ float tile[256 * (NC + 1)];
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = j < n;
+    float zj[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) zj[c] = have ? Z[(size_t)j * NC + c] : 0.f;
+    float s = 0.f;
+    for (int64_t i0 = 0; i0 < n; i0 += 256) {
+        __syncthreads();
+        const int64_t i = i0 + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) tile[threadIdx.x * (NC + 1) + c] = (i < n) ? Z[(size_t)i * NC + c] : 0.f;
+        tile[threadIdx.x * (NC + 1) + NC] = (i < n) ? Ef[i] : 0.f;
+        __syncthreads();
+        const int lim = (int)((n - i0 < 256) ? (n - i0) : 256);
+        for (int t = 0; t < lim; ++t) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const float df = zj[c] - tile[t * (NC + 1) + c]; d = fmaf(df, df, d); }
+            if (zero_diag && (i0 + t) == j) d += diag_add;
+            s = fmaf(tile[t * (NC + 1) + NC], __builtin_amdgcn_rcpf(1.0f + d), s);
+        }
+    }
+    float r2 = 0.f;
+    if (have) {
+        const float red = -(fmax + logf(s));
+        const float fn = 0.5f * (f[j] + red);
+        f_new[j] = fn;
+        const float df = fn - red;
+        r2 = df * df;
+    }
+    r2 = wave_sum(r2);
+    if ((threadIdx.x & 63) == 0 && r2 != 0.f) atomicAdd(resid2, r2);
+}
+
+static inline int dense_pick_kq(int d) {
+    if (d <= 32) return 4;
+    if (d <= 64) return 8;
+    if (d <= 128) return 16;
+    if (d <= 256) return 32;
+    return 0;
+}
+
+template <class Epi>
+static int launch_pair_scan(const PairScanParams& P, int d, hipStream_t st) {
+    const int kq = dense_pick_kq(d);
+    if (kq == 0) return TDR_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)2 * (kq * 256 + 32) * sizeof(float) + (size_t)2 * 32 * Epi::SIDE * sizeof(float);
+    const unsigned grid = (unsigned)((P.nq + 127) / 128);
+#define TDR_LAUNCH(KQV)                                                                                          \
+    {                                                                                                            \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pair_scan_kernel<KQV, Epi>),            \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+        if (e != hipSuccess) return (int)e;                                                                      \
+        hipLaunchKernelGGL((pair_scan_kernel<KQV, Epi>), dim3(grid), dim3(256), lds, st, P);                     \
+    }
+    switch (kq) {
+        case 4: TDR_LAUNCH(4) break;
+        case 8: TDR_LAUNCH(8) break;
+        case 16: TDR_LAUNCH(16) break;
+        default: TDR_LAUNCH(32) break;
+    }
+#undef TDR_LAUNCH
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TDR_OK : (int)e;
+}
+
+}  // namespace tdr
+
+using namespace tdr;
+
+extern "C" {
+
+/* SEA row statistics over the implicit N x N matrix lp_ij = (mu_i + mu_j - 2 C_ij)/(e_i + e_j):
+ *   psum[i] = sum_j exp(lp_ij),  ent[i] = -sum_j exp(lp_ij)(lp_ij - 1).
+ * packed: tile images of X (tdr_pack_rows_f32); side: (n, 2) row-major (mu, e) with e = eps^2 or eps. */
+int tdr_sea_rowstats_f32(const float* packed, int64_t n, int d, const float* side, int exclude_diag, float diag_add,
+                         float* psum, float* ent, void* stream) {
+    if (!packed || !side || !psum || !ent || n <= 0) return TDR_ERR_BAD_ARG;
+    PairScanParams P;
+    P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
+    P.side = side; P.qside = side; P.c0 = 0.f; P.c1 = 0.f; P.diag_add = diag_add; P.exclude_diag = exclude_diag;
+    P.out0 = psum; P.out1 = ent;
+    return launch_pair_scan<SeaStats>(P, d, (hipStream_t)stream);
+}
+
+/* TSNEkhorn embedding gradient (n, 2): 4 sum_j (P_ij - Q_ij)/(1+d_ij) (z_i - z_j).
+ * side: (n, 5) row-major (mu, e, z0, z1, exp(dual)); log_n = log(n). */
+int tdr_khorn_grad_f32(const float* packed, int64_t n, int d, const float* side, float log_n, float* grad, void* stream) {
+    if (!packed || !side || !grad || n <= 0) return TDR_ERR_BAD_ARG;
+    PairScanParams P;
+    P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
+    P.side = side; P.qside = side; P.c0 = log_n; P.c1 = 1.0f / (float)n; P.diag_add = 0.f; P.exclude_diag = 0;
+    P.out0 = grad; P.out1 = nullptr;
+    return launch_pair_scan<KhornForce>(P, d, (hipStream_t)stream);
+}
+
+/* One symmetric Sinkhorn update on the embedding Z (n, nc), student kernel, eps = 1:
+ *   f_new = 0.5 (f + red), red_j = -LSE_i(-log(1 + d_ij) + f_i);  *resid2 (device, caller-zeroed) += |f_new - red|^2.
+ * Ef = exp(f - fmax) precomputed by the caller (fmax = max f). */
+int tdr_sinkhorn_pass_f32(const float* Z, int nc, const float* f, const float* Ef, float fmax, int64_t n, int zero_diag,
+                          float diag_add, float* f_new, float* resid2, void* stream) {
+    if (!Z || !f || !Ef || !f_new || !resid2 || n <= 0) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (nc == 2) hipLaunchKernelGGL(sinkhorn_pass_kernel<2>, dim3(grid), dim3(256), 0, st, Z, f, Ef, fmax, n, zero_diag, diag_add, f_new, resid2);
+    else if (nc == 3) hipLaunchKernelGGL(sinkhorn_pass_kernel<3>, dim3(grid), dim3(256), 0, st, Z, f, Ef, fmax, n, zero_diag, diag_add, f_new, resid2);
+    else return TDR_ERR_UNSUPPORTED;
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+}  // extern "C"

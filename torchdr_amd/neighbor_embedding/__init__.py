@@ -2,3 +2,4 @@ from .base import NeighborEmbedding, NegativeSamplingNeighborEmbedding  # noqa: 
 from .umap import UMAP, find_ab_params  # noqa: F401
 from .largevis import LargeVis  # noqa: F401
 from .tsne import TSNE  # noqa: F401
+from .tsnekhorn import TSNEkhorn  # noqa: F401
