@@ -146,7 +146,9 @@ class NeighborEmbedding(AffinityMatcher):
     def _init_embedding(self, X: torch.Tensor):
         super()._init_embedding(X)
         if self.world_size > 1:
-            dist.broadcast(self.embedding_, src=0)  # reference :421
+            from torchdr_amd.parallel import broadcast_
+
+            broadcast_(self.embedding_, src=0)  # reference :421
         return self.embedding_
 
 

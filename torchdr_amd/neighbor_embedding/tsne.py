@@ -67,7 +67,9 @@ class TSNE(NeighborEmbedding):
             "tdr_tsne_repulsion_f32",
         )
         if self.world_size > 1:
-            dist.all_reduce(S, op=dist.ReduceOp.SUM)
+            from torchdr_amd.parallel import allreduce_
+
+            allreduce_(S)
         rows = grad[self.chunk_start_: self.chunk_start_ + self.chunk_size_]
         _lib.check(
             L.tdr_add_scaled_f32(_lib.ptr(rows), _lib.ptr(F), _lib.ptr(S), -4.0 * float(self.repulsion_strength),

@@ -16,9 +16,39 @@ import torch.distributed as dist
 from torchdr_amd.distributed import DistributedContext, chunk_bounds
 
 
+def _host_staged() -> bool:
+    """gloo has no device collectives for every op used here; stage through host memory then
+    (CPU-side tests and single-GPU multi-process debugging).  RCCL ("nccl") works on device buffers."""
+    return dist.get_backend() == "gloo"
+
+
 def allreduce_(t: torch.Tensor):
+    if _host_staged() and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+        return t
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def broadcast_(t: torch.Tensor, src: int = 0):
+    if _host_staged() and t.is_cuda:
+        h = t.cpu()
+        dist.broadcast(h, src=src)
+        t.copy_(h)
+        return t
+    dist.broadcast(t, src=src)
+    return t
+
+
+def _all_to_all_single(out, inp, out_splits=None, in_splits=None):
+    if _host_staged() and inp.is_cuda:
+        ho, hi = out.cpu(), inp.cpu()
+        dist.all_to_all_single(ho, hi, output_split_sizes=out_splits, input_split_sizes=in_splits)
+        out.copy_(ho)
+        return
+    dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
 
 
 def allgather_rows(local_rows: torch.Tensor, n_total: int, world_size: int) -> torch.Tensor:
@@ -30,7 +60,12 @@ def allgather_rows(local_rows: torch.Tensor, n_total: int, world_size: int) -> t
     if local_rows.shape[0] < max_rows:
         pad = torch.cat([local_rows, local_rows.new_zeros(max_rows - local_rows.shape[0], nc)])
     out = local_rows.new_empty((world_size * max_rows, nc))
-    dist.all_gather_into_tensor(out, pad.contiguous())
+    if _host_staged() and pad.is_cuda:
+        ho = out.cpu()
+        dist.all_gather_into_tensor(ho, pad.contiguous().cpu())
+        out.copy_(ho)
+    else:
+        dist.all_gather_into_tensor(out, pad.contiguous())
     if all(e - s == max_rows for s, e in sizes):
         return out
     parts = [out[r * max_rows: r * max_rows + (e - s)] for r, (s, e) in enumerate(sizes)]
@@ -69,7 +104,7 @@ def exchange_transposed_edges(values, indices, chunk_start, n_total, world_size)
     routed = route_edges(values, indices, chunk_start, n_total, world_size, rank)
     send_counts = torch.tensor([0 if p is None else p[0].numel() for p in routed], dtype=torch.int64, device=dev)
     recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts)
+    _all_to_all_single(recv_counts, send_counts)
     sc, rc = send_counts.tolist(), recv_counts.tolist()
 
     def cat(idx, dtype):
@@ -81,8 +116,8 @@ def exchange_transposed_edges(values, indices, chunk_start, n_total, world_size)
     recv_src = torch.empty(total, dtype=torch.int32, device=dev)
     recv_dst = torch.empty(total, dtype=torch.int32, device=dev)
     recv_v = torch.empty(total, dtype=torch.float32, device=dev)
-    dist.all_to_all_single(recv_src, send_src, output_split_sizes=rc, input_split_sizes=sc)
-    dist.all_to_all_single(recv_dst, send_dst, output_split_sizes=rc, input_split_sizes=sc)
-    dist.all_to_all_single(recv_v, send_v, output_split_sizes=rc, input_split_sizes=sc)
+    _all_to_all_single(recv_src, send_src, rc, sc)
+    _all_to_all_single(recv_dst, send_dst, rc, sc)
+    _all_to_all_single(recv_v, send_v, rc, sc)
     # received edge (src -> dst) with dst owned here: it is entry (dst, src) of P^T
     return (recv_dst - chunk_start).to(torch.int32), recv_src, recv_v
