@@ -101,7 +101,7 @@ def test_abi_header_matches_library():
     # host-only queries work without a GPU
     so.tdr_packed_floats.restype = ctypes.c_int64
     so.tdr_packed_floats.argtypes = [ctypes.c_int64, ctypes.c_int]
-    assert so.tdr_packed_floats(64, 128) == 2 * (16 * 256 + 32)
+    assert so.tdr_packed_floats(64, 128) == 2 * (16 * 256 + 64)
     assert so.tdr_packed_floats(64, 300) == 0
     so.tdr_knn_max_k.argtypes = [ctypes.c_int]
     assert so.tdr_knn_max_k(128) >= 90

@@ -5,5 +5,7 @@ timeout 900 python -m pytest tests -m gpu -q -x > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest exit $?" >> gpurun_out/pytest_gpu.log
 tail -5 gpurun_out/pytest_gpu.log
 timeout 600 python tools/knn_ablate.py 400000 > gpurun_out/ablate.log 2>&1; cat gpurun_out/ablate.log | grep lib
-timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_1m.log 2>&1; tail -1 gpurun_out/bench_1m.log | python -c "
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_bench -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/bench_1m.log 2>&1
+cd $GRAFT_REPO_ROOT; tail -1 gpurun_out/bench_1m.log | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print({k:d[k] for k in ('value','ms_per_step','knn_build_sec')}, d['roofline']['achieved'])"
+f=$(find gpurun_out/prof_bench -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f" | cut -c1-160

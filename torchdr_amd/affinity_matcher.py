@@ -24,6 +24,43 @@ from torchdr_amd.base import DRModule
 from torchdr_amd.utils import compute_device, to_torch
 
 
+_LR_TABLE_CACHE = {}
+
+
+def lr_schedule_table(scheduler_class, scheduler_kwargs, lr0, lr_as_tensor, n_steps):
+    """Learning rate seen by optimisation step 0 .. n_steps-1, produced by the REAL torch scheduler object
+    stepping a throw-away SGD optimizer (exact torch semantics for any scheduler class, including the fp32
+    recursion LinearLR runs when its factors are tensors).  Pure function of its arguments -> memoised, so
+    the ~40 us/step of Python scheduler overhead is paid once per configuration, not once per iteration."""
+    def _key(v):
+        return (float(v), str(v.dtype)) if isinstance(v, torch.Tensor) else v
+
+    key = (scheduler_class, tuple(sorted((k, _key(v)) for k, v in (scheduler_kwargs or {}).items())), float(lr0),
+           bool(lr_as_tensor), int(n_steps))
+    try:
+        hit = _LR_TABLE_CACHE.get(key)
+    except TypeError:  # unhashable kwargs: no memoisation
+        hit, key = None, None
+    if hit is not None:
+        return hit
+    p = torch.zeros(1, requires_grad=True)
+    opt = torch.optim.SGD([p], lr=torch.tensor(float(lr0)) if lr_as_tensor else float(lr0))
+    if scheduler_class is None:
+        table = [float(lr0)] * n_steps
+    else:
+        sch = scheduler_class(opt, **(scheduler_kwargs or {}))
+        table = []
+        for _ in range(n_steps):
+            table.append(float(opt.param_groups[0]["lr"]))
+            opt.step()
+            sch.step()
+    if key is not None:
+        if len(_LR_TABLE_CACHE) > 64:
+            _LR_TABLE_CACHE.clear()
+        _LR_TABLE_CACHE[key] = table
+    return table
+
+
 class AffinityMatcher(DRModule):
     # the reference hands torch.optim a TENSOR learning rate here (affinity_matcher.py:621) but a plain
     # float in NeighborEmbedding (neighbor_embedding/base.py:342); scheduler arithmetic follows suit.
@@ -138,7 +175,8 @@ class AffinityMatcher(DRModule):
 
     # ------------------------------------------------------------------------------------------
     def _training_step(self):
-        """Reference :354-430 with closed-form gradients.  ``_compute_gradients`` returns either the
+        """Reference :354-430 with closed-form gradients (optimizer step, then scheduler step = advance
+        in the learning-rate table).  ``_compute_gradients`` returns either the
         chunk's rows (``rows_only=True``: UMAP, only row i moves) or a full (N, c) buffer that other
         ranks also scatter into (LargeVis / TSNE)."""
         grad, rows_only = self._compute_gradients()
@@ -152,16 +190,14 @@ class AffinityMatcher(DRModule):
                 allreduce_(grad)  # :425
         self._last_grad = grad
         self._optimizer_step(grad)
-        if self.scheduler_ is not None:
-            self._lr_opt.step()
-            self.scheduler_.step()
+        self._lr_pos += 1
         return None
 
     def _compute_gradients(self):
         raise NotImplementedError("[TorchDR] ERROR : _compute_gradients method must be implemented.")
 
     def _current_lr(self) -> float:
-        return float(self._lr_opt.param_groups[0]["lr"])
+        return self._lr_table[min(self._lr_pos, len(self._lr_table) - 1)]
 
     def _optimizer_step(self, grad):
         lr = self._current_lr()
@@ -239,41 +275,39 @@ class AffinityMatcher(DRModule):
                     "torch.optim) or a subclass of torch.optim.Optimizer."
                 )
             optimizer_class = self.optimizer
-        # host-side LR holder: the scheduler drives THIS optimizer; its lr is read every step
-        self._lr_param = torch.zeros(1, requires_grad=True)
-        lr0 = torch.tensor(float(self.lr_)) if self._lr_as_tensor else float(self.lr_)
-        self._lr_opt = torch.optim.SGD([self._lr_param], lr=lr0)
         self._fused_sgd = optimizer_class is torch.optim.SGD and set(kwargs) <= {"momentum"}
         self._momentum_buf = None
         if self._fused_sgd:
             self._sgd_momentum = kwargs.get("momentum", 0.0)
-            self.optimizer_ = self._lr_opt
+            self.optimizer_ = None  # the fused kernel is the optimizer
         else:
             self.embedding_.requires_grad_(True)
             self.optimizer_ = optimizer_class([self.embedding_], lr=float(self.lr_), **kwargs)
         return self.optimizer_
 
     def _configure_scheduler(self, n_iter: Optional[int] = None):
+        """Resolve the scheduler class (reference :625-657) and tabulate the learning rates it produces."""
         n_iter = n_iter or self.max_iter
-        if self.scheduler is None:
-            self.scheduler_ = None
-            return None
-        kwargs = self.scheduler_kwargs or {}
-        if isinstance(self.scheduler, str):
-            try:
-                scheduler_class = getattr(torch.optim.lr_scheduler, self.scheduler)
-            except AttributeError:
-                raise ValueError(
-                    f"[TorchDR] ERROR: Scheduler '{self.scheduler}' not found in torch.optim.lr_scheduler."
-                )
-        else:
-            if not issubclass(self.scheduler, torch.optim.lr_scheduler.LRScheduler):
-                raise ValueError(
-                    "[TorchDR] ERROR: scheduler must be a string (name of a scheduler in "
-                    "torch.optim.lr_scheduler) or a subclass of torch.optim.lr_scheduler.LRScheduler."
-                )
-            scheduler_class = self.scheduler
-        self.scheduler_ = scheduler_class(self._lr_opt, **kwargs)
+        scheduler_class = None
+        if self.scheduler is not None:
+            if isinstance(self.scheduler, str):
+                try:
+                    scheduler_class = getattr(torch.optim.lr_scheduler, self.scheduler)
+                except AttributeError:
+                    raise ValueError(
+                        f"[TorchDR] ERROR: Scheduler '{self.scheduler}' not found in torch.optim.lr_scheduler."
+                    )
+            else:
+                if not issubclass(self.scheduler, torch.optim.lr_scheduler.LRScheduler):
+                    raise ValueError(
+                        "[TorchDR] ERROR: scheduler must be a string (name of a scheduler in "
+                        "torch.optim.lr_scheduler) or a subclass of torch.optim.lr_scheduler.LRScheduler."
+                    )
+                scheduler_class = self.scheduler
+        self.scheduler_ = scheduler_class
+        self._lr_table = lr_schedule_table(scheduler_class, self.scheduler_kwargs, self.lr_, self._lr_as_tensor,
+                                           int(self.max_iter))
+        self._lr_pos = 0
         return self.scheduler_
 
     def clear_memory(self):
@@ -282,8 +316,7 @@ class AffinityMatcher(DRModule):
             self.affinity_in.clear_memory()
         if isinstance(self.affinity_out, Affinity):
             self.affinity_out.clear_memory()
-        for attr in ["optimizer_", "scheduler_", "lr_", "_lr_opt", "_lr_param", "_momentum_buf", "_last_grad",
-                     "_nan_flag"]:
+        for attr in ["optimizer_", "scheduler_", "lr_", "_lr_table", "_momentum_buf", "_last_grad", "_nan_flag"]:
             if hasattr(self, attr):
                 delattr(self, attr)
         if isinstance(self.embedding_, torch.Tensor) and self.embedding_.requires_grad:

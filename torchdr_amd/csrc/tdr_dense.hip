@@ -17,9 +17,9 @@
 namespace tdr {
 
 template <int KQ>
-__device__ __forceinline__ void dstage_load(const float* __restrict__ src, f32x4 (&regs)[(KQ * 64 + 8 + 255) / 256],
+__device__ __forceinline__ void dstage_load(const float* __restrict__ src, f32x4 (&regs)[(KQ * 64 + 16 + 255) / 256],
                                             int tid) {
-    constexpr int NV = KQ * 64 + 8;
+    constexpr int NV = KQ * 64 + 16;
     constexpr int IT = (NV + 255) / 256;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -28,8 +28,8 @@ __device__ __forceinline__ void dstage_load(const float* __restrict__ src, f32x4
     }
 }
 template <int KQ>
-__device__ __forceinline__ void dstage_store(float* dst, const f32x4 (&regs)[(KQ * 64 + 8 + 255) / 256], int tid) {
-    constexpr int NV = KQ * 64 + 8;
+__device__ __forceinline__ void dstage_store(float* dst, const f32x4 (&regs)[(KQ * 64 + 16 + 255) / 256], int tid) {
+    constexpr int NV = KQ * 64 + 16;
     constexpr int IT = (NV + 255) / 256;
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -114,7 +114,7 @@ struct KhornForce {
 template <int KQ, class Epi>
 __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int TILE_F = KQ * 256 + 32;
+    constexpr int TILE_F = KQ * 256 + 64;
     constexpr int SIDE = Epi::SIDE;
     float* tile0 = reinterpret_cast<float*>(smem_raw);
     float* tile1 = tile0 + TILE_F;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
         for (int t = 0; t < 4 * KQ; ++t) b[t] = 0.f;
     }
 
-    constexpr int IT = (KQ * 64 + 8 + 255) / 256;
+    constexpr int IT = (KQ * 64 + 16 + 255) / 256;
     f32x4 regs[IT];
     float sreg = 0.f;
     auto side_load = [&](int T) {
@@ -306,7 +306,7 @@ template <class Epi>
 static int launch_pair_scan(const PairScanParams& P, int d, hipStream_t st) {
     const int kq = dense_pick_kq(d);
     if (kq == 0) return TDR_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)2 * (kq * 256 + 32) * sizeof(float) + (size_t)2 * 32 * Epi::SIDE * sizeof(float);
+    const size_t lds = (size_t)2 * (kq * 256 + 64) * sizeof(float) + (size_t)2 * 32 * Epi::SIDE * sizeof(float);
     const unsigned grid = (unsigned)((P.nq + 127) / 128);
 #define TDR_LAUNCH(KQV)                                                                                          \
     {                                                                                                            \

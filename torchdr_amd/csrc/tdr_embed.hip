@@ -11,11 +11,12 @@
 // Layout: embedding Z (N, NC) fp32 row-major, replicated per GPU; the affinity graph is CSR (UMAP) or the
 // rectangular (n, k) kNN block (LargeVis / TSNE).  One row group of G lanes walks a row's edges with
 // coalesced loads of (col, eps_per, next), gathers z_j from the L2 / Infinity-Cache resident Z, and
-// reduces the NC-dimensional force with DPP shuffles.  Negatives are generated in-kernel with a
-// counter-based Philox keyed by (seed, iteration, row, column), only for the 5*active columns the
+// reduces the NC-dimensional force with wave shuffles.  Negatives are generated in-kernel with a
+// counter-based hash generator keyed by (seed, iteration, row, column), only for the 5*active columns the
 // reference actually uses (it samples 150 and masks ~110 of them); an injected index table reproduces
 // the reference's per-step arithmetic exactly for the parity tests.
 #include "tdr_common.h"
+#include <stdlib.h>
 
 namespace tdr {
 
@@ -59,17 +60,36 @@ __device__ __forceinline__ Vec<NC> load_z(const float* __restrict__ Z, int64_t i
     return r;
 }
 
-__device__ __forceinline__ int64_t sample_negative(uint64_t seed, uint32_t iter, int64_t grow, int col, int64_t n_total) {
+// Counter-based hash generator for the negatives: three chained rounds of the "triple32" integer mixer
+// (xorshift-multiply, bias-tested avalanche) over (seed, row) -> (+iteration) -> (+column).  The first two
+// rounds are per row / per iteration and hoisted out of the column loop, so one negative costs ~10 VALU ops
+// (Philox4x32-10 costs ~90 and made the kernel instruction-bound).
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 17; x *= 0xed5ad4bbu;
+    x ^= x >> 11; x *= 0xac4c1b51u;
+    x ^= x >> 15; x *= 0x31848babu;
+    x ^= x >> 14;
+    return x;
+}
+__device__ __forceinline__ uint32_t neg_row_key(uint64_t seed, uint32_t iter, int64_t grow) {
+    uint32_t h = mix32((uint32_t)grow ^ (uint32_t)seed);
+    h = mix32(h + (uint32_t)((uint64_t)grow >> 32) * 0x9E3779B9u + (uint32_t)(seed >> 32));
+    return mix32(h ^ (iter * 0x85EBCA6Bu + 0xC2B2AE35u));
+}
+__device__ __forceinline__ int64_t sample_negative(uint32_t row_key, int64_t grow, int col, int64_t n_total) {
     // neighbor_embedding/base.py:628-636 : r ~ U{0..N-2}, then +1 where r >= own index.
-    // One Philox block serves 4 consecutive columns; 32 random bits are mapped to [0, N-1) by the
-    // multiply-shift range reduction (bias < N / 2^32).
-    const uint4 rnd = philox4x32(seed, (uint64_t)grow, ((uint64_t)iter << 32) | (uint32_t)(col >> 2));
-    const int sel = col & 3;
-    const uint32_t x = sel == 0 ? rnd.x : sel == 1 ? rnd.y : sel == 2 ? rnd.z : rnd.w;
+    // 32 random bits -> [0, N-1) by multiply-shift range reduction (bias < N / 2^32).
+    const uint32_t x = mix32(row_key + (uint32_t)col * 0x9E3779B9u);
     int64_t r = (int64_t)(((uint64_t)x * (uint64_t)(n_total - 1)) >> 32);
     if (r >= grow) r += 1;
     return r;
 }
+
+// d^b through the hardware log2 / exp2 (relative error ~ |b log2 d| * 2^-23, i.e. <= ~3e-6 for the
+// distances an embedding produces) and reciprocals through v_rcp_f32 (1 ulp): the force coefficients stay
+// well inside the 1e-5 parity budget while the kernel drops from ~300 to ~80 VALU ops per edge.
+__device__ __forceinline__ float fast_pow(float d, float b) { return __builtin_amdgcn_exp2f(b * __builtin_amdgcn_logf(d)); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 struct UmapStepParams {
     const float* Z;          // (N, NC)
@@ -92,34 +112,66 @@ struct UmapStepParams {
     float* grad;             // (n_rows, NC)
 };
 
-template <int NC, int G>
+template <int NC>
+__device__ __forceinline__ float sqdist(const Vec<NC>& a, const Vec<NC>& b, float (&df)[NC]) {
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { df[c] = a.v[c] - b.v[c]; d = __fadd_rn(d, __fmul_rn(df[c], df[c])); }
+    return d;
+}
+
+// Both loops run U group-widths per pass with every load issued before the first use: the dependent chain
+// per row is rowptr -> {next, cols} -> z_j gather -> math (3 memory levels) and U random gathers are in
+// flight per lane -- the kernel is bound by the latency of the random 8-byte reads of Z (8 MB at N = 1M,
+// larger than one XCD's L2), so memory-level parallelism is what buys throughput.  `cols` is read for every
+// edge (4 B) so that the gather does not wait for the activity test; eps_per only where the edge fires.
+template <int NC, int G, int U>
 __global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) {
     const int gl = threadIdx.x % G;
     const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     if (r >= P.n_rows) return;
     const int64_t gi = P.row0 + r;
+    const int64_t e0 = P.rowptr[r], e1 = P.rowptr[r + 1];
     const Vec<NC> zi = load_z<NC>(P.Z, gi);
     const float two_ab = 2.0f * P.a * P.b;
+    const float INF = __builtin_inff();
 
     float ga[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) ga[c] = 0.f;
     int act = 0;
-    const int64_t e0 = P.rowptr[r], e1 = P.rowptr[r + 1];
-    for (int64_t e = e0 + gl; e < e1; e += G) {
-        const float nx = P.next[e];
-        if (nx <= P.t1) {
-            P.next[e] = nx + P.eps_per[e];
-            act++;
-            const Vec<NC> zj = load_z<NC>(P.Z, P.cols[e]);
-            float df[NC];
-            float d = 0.f;
+    for (int64_t base = e0; base < e1; base += U * G) {
+        float nx[U];
+        int32_t cj[U];
+        bool on[U];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d = __fadd_rn(d, __fmul_rn(df[c], df[c])); }
-            if (d > 0.f) {
-                const float pb = powf(d, P.b);
-                const float den = 1.0f + P.a * pb;
-                const float coef = ((pb / d) * two_ab) / den;  // d^(b-1) = d^b / d
+        for (int u = 0; u < U; ++u) {
+            const int64_t e = base + u * G + gl;
+            const bool v = e < e1;
+            nx[u] = v ? P.next[e] : INF;
+            cj[u] = v ? P.cols[e] : (int32_t)gi;
+        }
+        Vec<NC> zj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            on[u] = nx[u] <= P.t1;
+            zj[u] = load_z<NC>(P.Z, on[u] ? cj[u] : (int32_t)gi);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (on[u]) {
+                const int64_t e = base + u * G + gl;
+                P.next[e] = nx[u] + P.eps_per[e];
+                act++;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float df[NC];
+            const float d = sqdist<NC>(zi, zj[u], df);
+            if (on[u] && d > 0.f) {
+                const float pb = fast_pow(d, P.b);
+                const float coef = (pb * two_ab) * fast_rcp(d * (1.0f + P.a * pb));  // 2ab d^(b-1) / (1 + a d^b)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) ga[c] += coef * df[c];
             }
@@ -135,19 +187,32 @@ __global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) 
     for (int c = 0; c < NC; ++c) gr[c] = 0.f;
     int n_use = act * P.neg_rate;
     if (n_use > P.n_negatives) n_use = P.n_negatives;
-    for (int col = gl; col < n_use; col += G) {
-        int64_t j;
-        if (P.neg_inj) j = P.neg_inj[(size_t)r * P.n_negatives + col];
-        else j = sample_negative(P.seed, P.iter, gi, col, P.n_total);
-        const Vec<NC> zj = load_z<NC>(P.Z, j);
-        float df[NC];
-        float d = 0.f;
+    const uint32_t rkey = neg_row_key(P.seed, P.iter, gi);
+    const float m2b = -2.0f * P.b;
+    for (int base = 0; base < n_use; base += U * G) {
+        int64_t jn[U];
+        bool v[U];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d = __fadd_rn(d, __fmul_rn(df[c], df[c])); }
-        const float den = 1.0f + P.a * powf(d, P.b);
-        const float coef = (1.0f / ((d + P.eps) * den)) * (-2.0f * P.b);
+        for (int u = 0; u < U; ++u) {
+            const int col = base + u * G + gl;
+            v[u] = col < n_use;
+            jn[u] = gi;
+            if (v[u]) jn[u] = P.neg_inj ? P.neg_inj[(size_t)r * P.n_negatives + col] : sample_negative(rkey, gi, col, P.n_total);
+        }
+        Vec<NC> zj[U];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) gr[c] += coef * df[c];
+        for (int u = 0; u < U; ++u) zj[u] = load_z<NC>(P.Z, jn[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float df[NC];
+            const float d = sqdist<NC>(zi, zj[u], df);
+            if (v[u]) {
+                const float den = 1.0f + P.a * (d > 0.f ? fast_pow(d, P.b) : 0.f);
+                const float coef = fast_rcp((d + P.eps) * den) * m2b;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) gr[c] += coef * df[c];
+            }
+        }
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) gr[c] = group_sum<G>(gr[c]);
@@ -205,10 +270,11 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
             unsafeAtomicAdd(&S.grad[(size_t)j * NC + c], -t);
         }
     }
+    const uint32_t rkey = neg_row_key(S.seed, S.iter, gi);
     for (int col = gl; col < S.n_neg; col += G) {
         int64_t j;
         if (S.neg_inj) j = S.neg_inj[(size_t)r * S.n_neg + col];
-        else j = sample_negative(S.seed, S.iter, gi, col, S.n_total);
+        else j = sample_negative(rkey, gi, col, S.n_total);
         const Vec<NC> zj = load_z<NC>(S.Z, j);
         float df[NC];
         float d = 0.f;
@@ -340,8 +406,17 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
     P.n_negatives = n_negatives; P.neg_inj = neg_inj; P.seed = seed; P.iter = (uint32_t)n_iter; P.exag = exag;
     P.rep = rep; P.eps = eps; P.grad = grad;
     hipStream_t st = (hipStream_t)stream;
-    if (nc == 2) return launch_group<32>(umap_grad_kernel<2, 32>, P, n_rows, st);
-    return launch_group<32>(umap_grad_kernel<3, 32>, P, n_rows, st);
+    // group width / unroll depth: TDR_UMAP_GEOM=0 (32x2), 1 (16x4, default), 2 (8x8) -- tuning knob
+    static int geom = -1;
+    if (geom < 0) { const char* g = getenv("TDR_UMAP_GEOM"); geom = g ? atoi(g) : 1; }
+    if (nc == 2) {
+        if (geom == 0) return launch_group<32>(umap_grad_kernel<2, 32, 2>, P, n_rows, st);
+        if (geom == 2) return launch_group<8>(umap_grad_kernel<2, 8, 8>, P, n_rows, st);
+        return launch_group<16>(umap_grad_kernel<2, 16, 4>, P, n_rows, st);
+    }
+    if (geom == 0) return launch_group<32>(umap_grad_kernel<3, 32, 2>, P, n_rows, st);
+    if (geom == 2) return launch_group<8>(umap_grad_kernel<3, 8, 8>, P, n_rows, st);
+    return launch_group<16>(umap_grad_kernel<3, 16, 4>, P, n_rows, st);
 }
 
 /* Sparse attraction (+ LargeVis negative-sample repulsion) gradient; grad (N, nc) must be zeroed by the

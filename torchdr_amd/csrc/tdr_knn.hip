@@ -35,7 +35,9 @@ constexpr uint64_t KEY_SENTINEL = 0xFF800000FFFFFFFFull;
 // Correctly rounded fp32 sqrt (via the fp64 root: 53 >= 2*24+2 bits makes the double rounding exact).
 __device__ __forceinline__ float sqrt_rn(float x) { return (float)sqrt((double)x); }
 
-__host__ __device__ __forceinline__ int64_t tile_stride_floats(int kq) { return (int64_t)kq * 256 + 32; }
+// tile image = kq blocks of 256 floats + 32 norms + 32 floats of padding (so the norms travel as one
+// 64-lane dword LDS-DMA)
+__host__ __device__ __forceinline__ int64_t tile_stride_floats(int kq) { return (int64_t)kq * 256 + 64; }
 
 // ---------------------------------------------------------------------------------------------
 // ATen (AVX2 build) summation order for one "lane column": elements sq(v) = x[v*stride]^2
@@ -177,26 +179,22 @@ struct KnnParams {
     uint64_t* ws_keys;    // (n_splits, nq, k) partial keys when n_splits > 1
 };
 
+// HBM -> LDS staging of one tile image by LDS-DMA (global_load_lds: no VGPR round trip, no ds_write pass).
+// The image is a linear byte run, so wave w copies the 1-KiB blocks t = w, w+4, ... (destination =
+// wave-uniform base + lane*16) and wave 0 adds the 256-byte norm block with a dword-wide copy.
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
 template <int KQ>
-__device__ __forceinline__ void stage_load(const float* __restrict__ src, f32x4 (&regs)[(KQ * 64 + 8 + 255) / 256],
-                                           int tid) {
-    constexpr int NV = KQ * 64 + 8;
-    constexpr int IT = (NV + 255) / 256;
+__device__ __forceinline__ void stage_dma(const float* __restrict__ src, float* dst, int wave, int lane) {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int idx = tid + it * 256;
-        if (idx < NV) regs[it] = *reinterpret_cast<const f32x4*>(src + (size_t)idx * 4);
+    for (int t = 0; t < KQ; t += 4) {
+        const int blk = t + wave;
+        if (blk < KQ)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + blk * 256 + lane * 4), (lptr_t)(dst + blk * 256), 16, 0, 0);
     }
-}
-template <int KQ>
-__device__ __forceinline__ void stage_store(float* dst, const f32x4 (&regs)[(KQ * 64 + 8 + 255) / 256], int tid) {
-    constexpr int NV = KQ * 64 + 8;
-    constexpr int IT = (NV + 255) / 256;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int idx = tid + it * 256;
-        if (idx < NV) *reinterpret_cast<f32x4*>(dst + (size_t)idx * 4) = regs[it];
-    }
+    if (wave == 0)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + KQ * 256 + lane), (lptr_t)(dst + KQ * 256), 4, 0, 0);
 }
 
 // Cooperative sorted insertion: the whole wavefront inserts ONE candidate into one query's ascending
@@ -226,7 +224,7 @@ __device__ __forceinline__ void coop_insert(uint64_t* L, int k, uint64_t cand, i
 template <int KQ, int ITEMS>
 __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int TILE_F = KQ * 256 + 32;
+    constexpr int TILE_F = KQ * 256 + 64;
     float* tile0 = reinterpret_cast<float*>(smem_raw);
     float* tile1 = tile0 + TILE_F;
     uint64_t* keys_all = reinterpret_cast<uint64_t*>(tile1 + TILE_F);  // [4 waves][32 queries][k] ascending
@@ -271,12 +269,7 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
     int t_end = t_begin + P.tiles_per_split;
     if (t_end > P.n_db_tiles) t_end = P.n_db_tiles;
 
-    constexpr int IT = (KQ * 64 + 8 + 255) / 256;
-    f32x4 regs[IT];
-    if (t_begin < t_end) {
-        stage_load<KQ>(P.yp + (size_t)t_begin * TILE_F, regs, tid);
-        stage_store<KQ>(tile0, regs, tid);
-    }
+    if (t_begin < t_end) stage_dma<KQ>(P.yp + (size_t)t_begin * TILE_F, tile0, wave, lane);
     __syncthreads();
 
     const bool angular = (P.metric == 2);
@@ -284,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
     for (int T = t_begin; T < t_end; ++T) {
         const bool has_next = (T + 1) < t_end;
 #ifndef TDR_ABLATE_NOSTAGE
-        if (has_next) stage_load<KQ>(P.yp + (size_t)(T + 1) * TILE_F, regs, tid);
+        if (has_next) stage_dma<KQ>(P.yp + (size_t)(T + 1) * TILE_F, cur ? tile0 : tile1, wave, lane);
 #endif
         const float* img = cur ? tile1 : tile0;
 
@@ -377,9 +370,6 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
             }
         }
 
-#ifndef TDR_ABLATE_NOSTAGE
-        if (has_next) stage_store<KQ>(cur ? tile0 : tile1, regs, tid);
-#endif
 #ifndef TDR_ABLATE_NOBARRIER
         __syncthreads();
 #endif
@@ -447,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void dense_dist_kernel(const float* __restr
                                                             int64_t q_offset, int64_t n_db, int metric,
                                                             int exclude_self, float diag_add,
                                                             float* __restrict__ out, int64_t ldo) {
-    constexpr int TILE_F = KQ * 256 + 32;
+    constexpr int TILE_F = KQ * 256 + 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane & 31, h = lane >> 5;
     const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
@@ -500,7 +490,7 @@ static inline int pick_kq(int d) {
 using namespace tdr;
 
 static size_t knn_lds_bytes(int kq, int k) {
-    return (size_t)2 * (kq * 256 + 32) * sizeof(float) + (size_t)4 * k * 32 * sizeof(uint64_t);
+    return (size_t)2 * (kq * 256 + 64) * sizeof(float) + (size_t)4 * k * 32 * sizeof(uint64_t);
 }
 
 template <int KQ, int ITEMS>

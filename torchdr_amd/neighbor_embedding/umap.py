@@ -91,7 +91,10 @@ class UMAP(NegativeSamplingNeighborEmbedding):
 
     def _compute_gradients(self):
         csr: CSRAffinity = self._csr
-        grad = torch.empty((self.chunk_size_, self.n_components), dtype=torch.float32, device=self.device_)
+        if self.world_size > 1 or getattr(self, "_grad_buf", None) is None:
+            self._grad_buf = torch.empty((self.chunk_size_, self.n_components), dtype=torch.float32,
+                                         device=self.device_)
+        grad = self._grad_buf
         neg = self._neg_ptr_tensor()
         _lib.check(
             _lib.lib().tdr_umap_grad_f32(
@@ -108,6 +111,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
 
     def clear_memory(self):
         super().clear_memory()
-        for attr in ("_csr", "epochs_per_sample", "epoch_of_next_sample", "_exclusion"):
+        for attr in ("_csr", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf"):
             if hasattr(self, attr):
                 delattr(self, attr)
