@@ -25,6 +25,7 @@
 //     ordered by the canonical (distance, index) key.
 //   * Optional database split (gridDim.y) for small query counts, merged by knn_merge_kernel.
 #include "tdr_common.h"
+#include <stdlib.h>
 
 namespace tdr {
 
@@ -185,10 +186,10 @@ struct KnnParams {
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int KQ>
+template <int KQ, int NW>
 __device__ __forceinline__ void stage_dma(const float* __restrict__ src, float* dst, int wave, int lane) {
 #pragma unroll
-    for (int t = 0; t < KQ; t += 4) {
+    for (int t = 0; t < KQ; t += NW) {
         const int blk = t + wave;
         if (blk < KQ)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + blk * 256 + lane * 4), (lptr_t)(dst + blk * 256), 16, 0, 0);
@@ -199,35 +200,48 @@ __device__ __forceinline__ void stage_dma(const float* __restrict__ src, float* 
 
 // Cooperative sorted insertion: the whole wavefront inserts ONE candidate into one query's ascending
 // k-entry list L (LDS, lane p owns entries p and p+64).  Every lane reads its entry and its left
-// neighbour, the shifted list is written back -- no rescans, no cross-lane traffic: ~2 LDS round trips.
+// neighbour, the shifted list is written back -- no rescans, no cross-lane traffic beyond two readlanes:
+// one LDS round trip.  Returns true and the new k-th key when the candidate entered the list.
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
 template <int ITEMS>
-__device__ __forceinline__ void coop_insert(uint64_t* L, int k, uint64_t cand, int lane) {
-    const uint64_t tk = L[k - 1];  // uniform address: LDS broadcast
-    if (cand >= tk) return;        // wave-uniform
-    uint64_t cur[ITEMS], prev[ITEMS];
+__device__ __forceinline__ bool coop_insert(uint64_t* L, int k, uint64_t cand, int lane, uint64_t& new_tail) {
+    uint64_t cur[ITEMS], prev[ITEMS], nv[ITEMS];
 #pragma unroll
     for (int t = 0; t < ITEMS; ++t) {
         const int p = lane + 64 * t;
         cur[t] = (p < k) ? L[p] : KEY_SENTINEL;
         prev[t] = (p > 0 && p < k) ? L[p - 1] : 0ull;
     }
+    const int tl = (k - 1) & 63, ti = (k - 1) >> 6;  // lane / item that hold the k-th entry (wave-uniform)
+    uint64_t tk = 0;
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t)
+        if (t == ti) tk = readlane_u64(cur[t], tl);
+    if (cand >= tk) return false;  // wave-uniform
 #pragma unroll
     for (int t = 0; t < ITEMS; ++t) {
         const int p = lane + 64 * t;
-        if (p < k) {
-            const uint64_t nv = (cur[t] < cand) ? cur[t] : ((p == 0 || prev[t] < cand) ? cand : prev[t]);
-            if (nv != cur[t]) L[p] = nv;
-        }
+        nv[t] = (cur[t] < cand) ? cur[t] : ((p == 0 || prev[t] < cand) ? cand : prev[t]);
+        if (p < k && nv[t] != cur[t]) L[p] = nv[t];
     }
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t)
+        if (t == ti) new_tail = readlane_u64(nv[t], tl);
+    return true;
 }
 
-template <int KQ, int ITEMS>
-__global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
+template <int KQ, int ITEMS, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 6) ? 3 : 2) void knn_scan_kernel(const KnnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int TILE_F = KQ * 256 + 64;
     float* tile0 = reinterpret_cast<float*>(smem_raw);
     float* tile1 = tile0 + TILE_F;
-    uint64_t* keys_all = reinterpret_cast<uint64_t*>(tile1 + TILE_F);  // [4 waves][32 queries][k] ascending
+    uint64_t* keys_all = reinterpret_cast<uint64_t*>(tile1 + TILE_F);  // [NW waves][32 queries][k] ascending
     const int k = P.k;
 
     const int tid = threadIdx.x;
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
     uint64_t* keys = keys_all + (size_t)wave * k * 32;
 
     const int64_t n_qtiles = (P.nq + 31) / 32;
-    const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t qt = (int64_t)blockIdx.x * NW + wave;
     const bool wave_active = qt < n_qtiles;
     const int64_t gq = qt * 32 + q;  // local query id owned by this lane
     const int64_t gq_global = gq + P.q_offset;
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
     int t_end = t_begin + P.tiles_per_split;
     if (t_end > P.n_db_tiles) t_end = P.n_db_tiles;
 
-    if (t_begin < t_end) stage_dma<KQ>(P.yp + (size_t)t_begin * TILE_F, tile0, wave, lane);
+    if (t_begin < t_end) stage_dma<KQ, NW>(P.yp + (size_t)t_begin * TILE_F, tile0, wave, lane);
     __syncthreads();
 
     const bool angular = (P.metric == 2);
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
     for (int T = t_begin; T < t_end; ++T) {
         const bool has_next = (T + 1) < t_end;
 #ifndef TDR_ABLATE_NOSTAGE
-        if (has_next) stage_dma<KQ>(P.yp + (size_t)(T + 1) * TILE_F, cur ? tile0 : tile1, wave, lane);
+        if (has_next) stage_dma<KQ, NW>(P.yp + (size_t)(T + 1) * TILE_F, cur ? tile0 : tile1, wave, lane);
 #endif
         const float* img = cur ? tile1 : tile0;
 
@@ -348,25 +362,34 @@ __global__ __launch_bounds__(256, 2) void knn_scan_kernel(const KnnParams P) {
             asm volatile("" ::"v"(hits));
             hits = 0;
 #endif
-            if (__any(hits != 0)) {
-                const int64_t row_base = (int64_t)T * 32 + 4 * h;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t j = row_base + (r & 3) + 8 * (r >> 2);
-                    const bool cand_ok = ((hits >> r) & 1u) && (j < P.n_db) && !(P.exclude_self && j == gq_global);
-                    unsigned long long m = __ballot(cand_ok);
-                    if (m == 0) continue;  // wave-uniform
-                    const uint32_t khi = f2u(dv[r]);
-                    const uint32_t klo = (uint32_t)j;
-                    while (m) {
-                        const int src = __builtin_ctzll(m);
-                        m &= m - 1;
-                        const uint32_t chi = __builtin_amdgcn_readlane(khi, src);
-                        const uint32_t clo = __builtin_amdgcn_readlane(klo, src);
-                        coop_insert<ITEMS>(keys + (size_t)(src & 31) * k, k, ((uint64_t)chi << 32) | clo, lane);
+            unsigned long long lm = __ballot(hits != 0);
+            // Rare path, driven from the scalar unit: walk the hit lanes, and for each the set bits of its
+            // 16-bit hit mask; candidate value and index are wave-uniform (readlane), only the list update
+            // itself is vector work.
+            while (lm) {
+                const int src = __builtin_ctzll(lm);
+                lm &= lm - 1;
+                unsigned hm = __builtin_amdgcn_readlane(hits, src);
+                const int sq = src & 31;
+                const int64_t rowb = (int64_t)T * 32 + 4 * (src >> 5);
+                const int64_t gqs = qt * 32 + sq + P.q_offset;
+                while (hm) {
+                    const int r = __builtin_ctz(hm);
+                    hm &= hm - 1;
+                    float dval = 0.f;
+                    switch (r) {
+#define TDR_RL(R) case R: dval = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv[R]), src)); break;
+                        TDR_RL(0) TDR_RL(1) TDR_RL(2) TDR_RL(3) TDR_RL(4) TDR_RL(5) TDR_RL(6) TDR_RL(7)
+                        TDR_RL(8) TDR_RL(9) TDR_RL(10) TDR_RL(11) TDR_RL(12) TDR_RL(13) TDR_RL(14) TDR_RL(15)
+#undef TDR_RL
+                    }
+                    const int64_t j = rowb + (r & 3) + 8 * (r >> 2);
+                    if (j >= P.n_db || (P.exclude_self && j == gqs) || (qt * 32 + sq) >= P.nq) continue;
+                    uint64_t new_tail;
+                    if (coop_insert<ITEMS>(keys + (size_t)sq * k, k, mkkey(dval, (uint32_t)j), lane, new_tail)) {
+                        if (q == sq) tau_d = u2f((uint32_t)(new_tail >> 32));
                     }
                 }
-                tau_d = lane_valid ? u2f((uint32_t)(keys[(size_t)q * k + k - 1] >> 32)) : -__builtin_inff();
             }
         }
 
@@ -489,24 +512,36 @@ static inline int pick_kq(int d) {
 
 using namespace tdr;
 
-static size_t knn_lds_bytes(int kq, int k) {
-    return (size_t)2 * (kq * 256 + 64) * sizeof(float) + (size_t)4 * k * 32 * sizeof(uint64_t);
+static size_t knn_lds_bytes(int kq, int k, int nw = 4) {
+    return (size_t)2 * (kq * 256 + 64) * sizeof(float) + (size_t)nw * k * 32 * sizeof(uint64_t);
 }
 
-template <int KQ, int ITEMS>
-static int launch_scan_i(const KnnParams& P, int n_wgs, size_t lds, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scan_kernel<KQ, ITEMS>),
+// waves per workgroup: 4 (128 queries, default) | 6 | 8 -- tuning knob TDR_KNN_NW
+static int knn_nw() {
+    static int nw = 0;
+    if (nw == 0) { const char* e = getenv("TDR_KNN_NW"); nw = e ? atoi(e) : 4; if (nw != 6 && nw != 8) nw = 4; }
+    return nw;
+}
+
+template <int KQ, int ITEMS, int NW>
+static int launch_scan_w(const KnnParams& P, int n_wgs, size_t lds, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scan_kernel<KQ, ITEMS, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((knn_scan_kernel<KQ, ITEMS>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((knn_scan_kernel<KQ, ITEMS, NW>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(NW * 64), lds, st, P);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
+template <int KQ, int ITEMS>
+static int launch_scan_i(const KnnParams& P, int n_wgs, size_t lds, int nw, hipStream_t st) {
+    if (nw == 6) return launch_scan_w<KQ, ITEMS, 6>(P, n_wgs, lds, st);
+    if (nw == 8) return launch_scan_w<KQ, ITEMS, 8>(P, n_wgs, lds, st);
+    return launch_scan_w<KQ, ITEMS, 4>(P, n_wgs, lds, st);
+}
 template <int KQ>
-static int launch_scan(const KnnParams& P, int n_wgs, size_t lds, hipStream_t st) {
-    if (P.k <= 64) return launch_scan_i<KQ, 1>(P, n_wgs, lds, st);
-    if (P.k <= 128) return launch_scan_i<KQ, 2>(P, n_wgs, lds, st);
-    return launch_scan_i<KQ, 3>(P, n_wgs, lds, st);
+static int launch_scan(const KnnParams& P, int n_wgs, size_t lds, int nw, hipStream_t st) {
+    if (P.k <= 64) return launch_scan_i<KQ, 1>(P, n_wgs, lds, nw, st);
+    return launch_scan_i<KQ, 2>(P, n_wgs, lds, nw, st);
 }
 
 extern "C" {
@@ -532,11 +567,26 @@ int tdr_pack_rows_f32(const float* X, int64_t n, int d, int64_t ldx, float* pack
     return TDR_OK;
 }
 
-// Workspace bytes for tdr_knn_packed_f32 (partial lists when the database is split).
-static int choose_splits(int64_t nq, int n_db_tiles) {
-    const int64_t wgs = (nq + 127) / 128;
-    if (wgs >= 1024) return 1;
-    int64_t s = (1024 + wgs - 1) / wgs;
+// Launch plan.  A workgroup owns 128 queries and two workgroups fit a CU, so the chip runs `slots` of them
+// at a time and a launch of W workgroups takes ceil(W / slots) rounds.  (1) Few queries: slice the
+// database over gridDim.y so that >= ~2 rounds of workgroups exist.  (2) Many queries: the main launch
+// covers an exact multiple of `slots` workgroups and the leftover query tiles (the partial last round)
+// go to a second launch with the database sliced, so that round is spread over every CU too.
+static int device_slots() {
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        slots = 2 * cus;
+    }
+    return slots;
+}
+
+static int choose_splits(int64_t wgs, int n_db_tiles, int target_wgs) {
+    if (wgs >= target_wgs) return 1;
+    int64_t s = (target_wgs + wgs - 1) / wgs;
     const int64_t max_by_tiles = n_db_tiles / 64 > 0 ? n_db_tiles / 64 : 1;
     if (s > max_by_tiles) s = max_by_tiles;
     if (s > 32) s = 32;
@@ -544,11 +594,49 @@ static int choose_splits(int64_t nq, int n_db_tiles) {
     return (int)s;
 }
 
+struct KnnPlan {
+    int64_t main_wgs;   // workgroups of the un-split main launch (0 = none)
+    int64_t tail_wgs;   // workgroups of the split launch (0 = none)
+    int tail_splits;
+};
+
+static KnnPlan make_plan(int64_t nq, int n_db_tiles, int nw = 4) {
+    const int slots = device_slots() * (nw == 8 ? 1 : 2) / 2;
+    const int64_t wgs = (nq + 32 * nw - 1) / (32 * nw);
+    KnnPlan pl;
+    if (wgs < 2 * (int64_t)slots) {  // small problem: one split launch
+        pl.main_wgs = 0; pl.tail_wgs = wgs; pl.tail_splits = choose_splits(wgs, n_db_tiles, 2 * slots);
+        return pl;
+    }
+    const int64_t rem = wgs % slots;
+    if (rem == 0 || rem * 10 > (int64_t)slots * 9) {  // last round (almost) full: nothing to gain
+        pl.main_wgs = wgs; pl.tail_wgs = 0; pl.tail_splits = 1;
+        return pl;
+    }
+    pl.main_wgs = wgs - rem;
+    pl.tail_wgs = rem;
+    pl.tail_splits = choose_splits(rem, n_db_tiles, slots);
+    return pl;
+}
+
 int64_t tdr_knn_workspace_bytes(int64_t nq, int64_t n_db, int k) {
     const int n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
-    const int s = choose_splits(nq, n_db_tiles);
-    if (s <= 1) return 0;
-    return (int64_t)s * nq * k * (int64_t)sizeof(uint64_t);
+    // upper bound over the workgroup shapes the launcher may pick
+    int64_t best = 0;
+    for (int nw : {4, 6, 8}) {
+        const KnnPlan pl = make_plan(nq, n_db_tiles, nw);
+        if (pl.tail_wgs == 0 || pl.tail_splits <= 1) continue;
+        const int64_t tail_q = nq - pl.main_wgs * 32 * nw;
+        const int64_t b = (int64_t)pl.tail_splits * tail_q * k * (int64_t)sizeof(uint64_t);
+        if (b > best) best = b;
+    }
+    return best;
+}
+static int64_t unused_ws_bytes_(int64_t nq, int n_db_tiles, int k, int nw) {
+    const KnnPlan pl = make_plan(nq, n_db_tiles, nw);
+    if (pl.tail_wgs == 0 || pl.tail_splits <= 1) return 0;
+    const int64_t tail_q = nq - pl.main_wgs * 32 * nw;
+    return (int64_t)pl.tail_splits * tail_q * k * (int64_t)sizeof(uint64_t);
 }
 
 // Largest k the scan kernel supports for dimension d (LDS budget 160 KiB per workgroup).
@@ -577,35 +665,46 @@ int tdr_knn_packed_f32(const float* qp, int64_t nq, int64_t q_offset, const floa
     if (k > tdr_knn_max_k(d)) return TDR_ERR_UNSUPPORTED;
     if (n_db > 0x7fffffffLL) return TDR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    KnnParams P;
-    P.qp = qp; P.yp = yp; P.nq = nq; P.q_offset = q_offset; P.n_db = n_db; P.k = k; P.metric = metric;
-    P.exclude_self = exclude_self;
-    P.n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
-    P.n_splits = choose_splits(nq, P.n_db_tiles);
-    P.tiles_per_split = (P.n_db_tiles + P.n_splits - 1) / P.n_splits;
-    P.out_d = out_d; P.out_i = out_i; P.ws_keys = (uint64_t*)ws;
-    if (P.n_splits > 1) {
-        const int64_t need = (int64_t)P.n_splits * nq * k * (int64_t)sizeof(uint64_t);
-        if (!ws || ws_bytes < need) return TDR_ERR_WORKSPACE;
-    }
-    const int n_wgs = (int)((nq + 127) / 128);
-    const size_t lds = knn_lds_bytes(kq, k);
-    int rc;
-    switch (kq) {
-        case 4: rc = launch_scan<4>(P, n_wgs, lds, st); break;
-        case 8: rc = launch_scan<8>(P, n_wgs, lds, st); break;
-        case 16: rc = launch_scan<16>(P, n_wgs, lds, st); break;
-        default: rc = launch_scan<32>(P, n_wgs, lds, st); break;
-    }
-    if (rc != TDR_OK) return rc;
-    if (P.n_splits > 1) {
-        const size_t mlds = (size_t)4 * P.n_splits * k * sizeof(uint64_t);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_merge_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), mlds, st,
-                           (const uint64_t*)ws, nq, k, P.n_splits, metric, out_d, out_i);
-        TDR_CHECK_LAUNCH();
+    const int n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
+    int nw = knn_nw();
+    if (knn_lds_bytes(kq, k, nw) > 160 * 1024 || kq > 16) nw = 4;
+    const KnnPlan pl = make_plan(nq, n_db_tiles, nw);
+    const size_t lds = knn_lds_bytes(kq, k, nw);
+    const int64_t tile_f = tile_stride_floats(kq);
+    const int qpw = 32 * nw;  // queries per workgroup
+    // part 0 = main (un-split) launch, part 1 = tail launch (database sliced)
+    for (int part = 0; part < 2; ++part) {
+        const int64_t wgs = part == 0 ? pl.main_wgs : pl.tail_wgs;
+        if (wgs == 0) continue;
+        const int64_t q_begin = part == 0 ? 0 : pl.main_wgs * qpw;
+        const int64_t q_count = part == 0 ? (pl.tail_wgs ? pl.main_wgs * qpw : nq) : nq - q_begin;
+        KnnParams P;
+        P.qp = qp + (q_begin / 32) * tile_f; P.yp = yp; P.nq = q_count; P.q_offset = q_offset + q_begin; P.n_db = n_db;
+        P.k = k; P.metric = metric; P.exclude_self = exclude_self; P.n_db_tiles = n_db_tiles;
+        P.n_splits = part == 0 ? 1 : pl.tail_splits;
+        P.tiles_per_split = (P.n_db_tiles + P.n_splits - 1) / P.n_splits;
+        P.out_d = out_d + q_begin * k; P.out_i = out_i + q_begin * k; P.ws_keys = (uint64_t*)ws;
+        if (P.n_splits > 1) {
+            const int64_t need = (int64_t)P.n_splits * q_count * k * (int64_t)sizeof(uint64_t);
+            if (!ws || ws_bytes < need) return TDR_ERR_WORKSPACE;
+        }
+        int rc;
+        switch (kq) {
+            case 4: rc = launch_scan<4>(P, (int)wgs, lds, nw, st); break;
+            case 8: rc = launch_scan<8>(P, (int)wgs, lds, nw, st); break;
+            case 16: rc = launch_scan<16>(P, (int)wgs, lds, nw, st); break;
+            default: rc = launch_scan<32>(P, (int)wgs, lds, nw, st); break;
+        }
+        if (rc != TDR_OK) return rc;
+        if (P.n_splits > 1) {
+            const size_t mlds = (size_t)4 * P.n_splits * k * sizeof(uint64_t);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_merge_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((q_count + 3) / 4)), dim3(256), mlds, st,
+                               (const uint64_t*)ws, q_count, k, P.n_splits, metric, P.out_d, P.out_i);
+            TDR_CHECK_LAUNCH();
+        }
     }
     return TDR_OK;
 }
