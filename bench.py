@@ -162,6 +162,17 @@ def main():
     flops = 2.0 * nq * args.n * args.d
     achieved = flops / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
 
+    # HBM-side traffic of the dominant kernel: PMC pass committed under profiles/ (separate rocprofv3 --pmc
+    # runs of the same kernel on the same workload; FETCH_SIZE doubled per the gfx950 note of the guide)
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_knn_scan_pmc.json")
+    if world == 1 and (args.n, args.d, args.k) == (1_000_000, 128, 30) and os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+        except Exception:
+            traffic = None
+
     if rank == 0:
         out = {
             "metric": "samples/sec (fit_transform) + kNN-graph build sec, UMAP N=1M D=128 k=30",
@@ -184,9 +195,10 @@ def main():
             },
             "knn_build_sec": scan_avg_ms * 1e-3,
             "roofline": {
-                "kernel": "tdr::knn_scan_kernel<16>" if args.d > 64 and args.d <= 128 else "tdr::knn_scan_kernel",
+                "kernel": "tdr::knn_scan_kernel<16,1,4>" if 64 < args.d <= 128 else "tdr::knn_scan_kernel",
                 "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_note": "bytes at the L2->fabric boundary per launch (incl. Infinity Cache hits), from profiles/r01_knn_scan_pmc.json",
                 "algorithmic_flops_per_launch": flops, "avg_launch_ms": scan_avg_ms,
             },
         }

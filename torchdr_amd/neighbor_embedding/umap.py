@@ -53,6 +53,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         self.sparsity = True
         self._use_closed_form_gradients = True
         self._eps = 1e-3
+        self.a, self.b = a, b  # as given (sklearn get_params); the fitted curve parameters live in _a / _b
         if a is None or b is None:
             a, b = find_ab_params(self.spread, self.min_dist)
         self._a = a
