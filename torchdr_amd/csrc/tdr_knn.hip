@@ -235,13 +235,154 @@ __device__ __forceinline__ bool coop_insert(uint64_t* L, int k, uint64_t cand, i
     return true;
 }
 
+// ---- one tile step of the scan (software pipelined) -----------------------------------------------------
+// Multiplies tile T into `acc` (one k-ordered MFMA chain) and, IN THE SAME INSTRUCTION STREAM, finishes
+// tile T-1 out of `accp`: its 16 candidate distances per lane are formed between the MFMAs of tile T (an
+// in-order wavefront can only overlap VALU with a 64-cycle MFMA if the VALU sits between MFMAs in program
+// order), folded into a running minimum and tested against the lane's k-th-best threshold with ONE compare.
+// Only when some lane of the wavefront has a survivor is the per-value hit mask built and the scalar-driven
+// insertion loop entered.
+struct ScanCtx {
+    const KnnParams* P;
+    uint64_t* keys;   // this wave's lists [32][k]
+    int k, lane, q, h;
+    int64_t qt;       // query tile of this wave
+    float xn;
+    bool angular;
+};
+
+// Rare path.  For each of the lane's 16 candidate slots the compare against the threshold IS the ballot
+// (v_cmp writes the 64-lane mask to SGPRs); slots without a survivor cost one scalar test.  Survivors are
+// walked from the scalar unit: value and row index are wave-uniform (readlane), only the list update itself
+// is vector work.  tau_d is refreshed after every insertion, so later slots filter with the new threshold.
+template <int ITEMS>
+__device__ __forceinline__ void scan_insert(const ScanCtx& C, const float (&dv)[16], int Tprev, float& tau_d) {
+    const KnnParams& P = *C.P;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        unsigned long long m = __ballot(dv[r] <= tau_d);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const int sq = src & 31;
+            const int64_t j = (int64_t)Tprev * 32 + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2);
+            if (j >= P.n_db || (P.exclude_self && j == C.qt * 32 + sq + P.q_offset)) continue;
+            const float dval = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv[r]), src));
+            uint64_t new_tail;
+            if (coop_insert<ITEMS>(C.keys + (size_t)sq * C.k, C.k, mkkey(dval, (uint32_t)j), C.lane, new_tail)) {
+                if (C.q == sq) tau_d = u2f((uint32_t)(new_tail >> 32));
+            }
+        }
+    }
+}
+
+// candidate values of one finished tile: c = (||x||^2 + ||y||^2) - 2 x.y  (distance/torch.py:91); rows
+// (r&3) + 8*(r>>2) + 4*h of the tile.  `part` selects which quarter (4 values) to form -- the caller spreads
+// the four parts over the MFMA groups of the next tile.
+__device__ __forceinline__ void form_part(const ScanCtx& C, const f32x16& accp, const float* ynp, int g, float (&dv)[16],
+                                          float& cmin) {
+    const f32x4 y4 = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        float c;
+        if (C.angular) c = -accp[r];
+        else c = __builtin_fmaf(-2.0f, accp[r], __fadd_rn(C.xn, y4[e]));  // 2*acc is exact: same rounding as s - 2*acc
+        dv[r] = c;
+        cmin = fminf(cmin, c);
+    }
+}
+
+template <int KQ, int ITEMS, bool HAVE_PREV>
+__device__ __forceinline__ void tile_step(const ScanCtx& C, const float* __restrict__ img, const float (&b)[4 * KQ],
+                                          f32x16& acc, const f32x16& accp, const float* ynp_prev, int Tprev,
+                                          float& tau_d) {
+    constexpr int GQ = (KQ >= 4) ? 4 : KQ, NG = KQ / GQ;
+    constexpr int PARTS_PER_GROUP = (4 + NG - 1) / NG;  // spread the 4 quarters of the previous tile over the groups
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float dv[16];
+    float cmin = __builtin_inff();
+    const float* ap = img + C.lane * 4;
+    f32x4 a0[GQ], a1[GQ];
+#pragma unroll
+    for (int u = 0; u < GQ; ++u) a0[u] = *reinterpret_cast<const f32x4*>(ap + u * 256);
+    int part = 0;
+#pragma unroll
+    for (int g = 0; g < NG; g += 2) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int u = 0; u < GQ; ++u) a1[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 1) * GQ + u) * 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
+        if (HAVE_PREV) {
+#pragma unroll
+            for (int pp = 0; pp < PARTS_PER_GROUP; ++pp)
+                if (part + pp < 4) form_part(C, accp, ynp_prev, part + pp, dv, cmin);
+        }
+        part += PARTS_PER_GROUP;
+#pragma unroll
+        for (int u = 0; u < GQ; ++u) {
+            const int t = g * GQ + u;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][0], b[4 * t + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][1], b[4 * t + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][2], b[4 * t + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][3], b[4 * t + 3], acc, 0, 0, 0);
+        }
+        if (g + 1 < NG) {
+            if (g + 2 < NG) {
+#pragma unroll
+                for (int u = 0; u < GQ; ++u) a0[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 2) * GQ + u) * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (HAVE_PREV) {
+#pragma unroll
+                for (int pp = 0; pp < PARTS_PER_GROUP; ++pp)
+                    if (part + pp < 4) form_part(C, accp, ynp_prev, part + pp, dv, cmin);
+            }
+            part += PARTS_PER_GROUP;
+#pragma unroll
+            for (int u = 0; u < GQ; ++u) {
+                const int t = (g + 1) * GQ + u;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][0], b[4 * t + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][1], b[4 * t + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][2], b[4 * t + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][3], b[4 * t + 3], acc, 0, 0, 0);
+            }
+        }
+    }
+    if (HAVE_PREV) {
+#ifdef TDR_ABLATE_NOINSERT
+        asm volatile("" ::"v"(cmin));
+        cmin = __builtin_inff();
+#endif
+        if (__any(cmin <= tau_d)) scan_insert<ITEMS>(C, dv, Tprev, tau_d);
+    }
+}
+
+// finish the last tile (no next tile to hide it behind)
+template <int ITEMS>
+__device__ __forceinline__ void tile_drain(const ScanCtx& C, const f32x16& accp, const float* ynp_prev, int Tprev,
+                                           float& tau_d) {
+    float dv[16];
+    float cmin = __builtin_inff();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) form_part(C, accp, ynp_prev, g, dv, cmin);
+#ifdef TDR_ABLATE_NOINSERT
+    cmin = __builtin_inff();
+#endif
+    if (__any(cmin <= tau_d)) scan_insert<ITEMS>(C, dv, Tprev, tau_d);
+}
+
 template <int KQ, int ITEMS, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 6) ? 3 : 2) void knn_scan_kernel(const KnnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int TILE_F = KQ * 256 + 64;
+    constexpr int IMG_F = KQ * 256;  // the LDS copy holds the blocks only; norms go to the ring below
     float* tile0 = reinterpret_cast<float*>(smem_raw);
-    float* tile1 = tile0 + TILE_F;
-    uint64_t* keys_all = reinterpret_cast<uint64_t*>(tile1 + TILE_F);  // [NW waves][32 queries][k] ascending
+    float* tile1 = tile0 + IMG_F;
+    float* nring = tile1 + IMG_F;                                          // [4 slots][64 floats]
+    uint64_t* keys_all = reinterpret_cast<uint64_t*>(nring + 4 * 64);      // [NW waves][32 queries][k] ascending
     const int k = P.k;
 
     const int tid = threadIdx.x;
@@ -255,7 +396,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 6) ? 3 : 2) void knn_scan_kernel(co
     const int64_t qt = (int64_t)blockIdx.x * NW + wave;
     const bool wave_active = qt < n_qtiles;
     const int64_t gq = qt * 32 + q;  // local query id owned by this lane
-    const int64_t gq_global = gq + P.q_offset;
 
     // --- query block -> registers (B operand), once per workgroup lifetime
     float b[4 * KQ];
@@ -273,7 +413,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 6) ? 3 : 2) void knn_scan_kernel(co
         for (int t = 0; t < 4 * KQ; ++t) b[t] = 0.f;
     }
 
-    // --- per-query lists
     for (int p = lane; p < k * 32; p += 64) keys[p] = KEY_SENTINEL;
     const bool lane_valid = wave_active && (gq < P.nq);
     float tau_d = lane_valid ? __builtin_inff() : -__builtin_inff();
@@ -283,121 +422,71 @@ __global__ __launch_bounds__(NW * 64, (NW == 6) ? 3 : 2) void knn_scan_kernel(co
     int t_end = t_begin + P.tiles_per_split;
     if (t_end > P.n_db_tiles) t_end = P.n_db_tiles;
 
-    if (t_begin < t_end) stage_dma<KQ, NW>(P.yp + (size_t)t_begin * TILE_F, tile0, wave, lane);
+    ScanCtx C;
+    C.P = &P; C.keys = keys; C.k = k; C.lane = lane; C.q = q; C.h = h; C.qt = qt; C.xn = xn;
+    C.angular = (P.metric == 2);
+
+    // stage(T): tile image -> tile[(T - t_begin) & 1], norms -> nring[(T - t_begin) & 3]
+    auto stage = [&](int T) {
+        const int rel = T - t_begin;
+        const float* src = P.yp + (size_t)T * TILE_F;
+        float* dst = (rel & 1) ? tile1 : tile0;
+#pragma unroll
+        for (int t = 0; t < KQ; t += NW) {
+            const int blk = t + wave;
+            if (blk < KQ)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + blk * 256 + lane * 4), (lptr_t)(dst + blk * 256), 16, 0, 0);
+        }
+        if (wave == NW - 1)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + KQ * 256 + lane), (lptr_t)(nring + (rel & 3) * 64), 4, 0, 0);
+    };
+    if (t_begin < t_end) stage(t_begin);
     __syncthreads();
 
-    const bool angular = (P.metric == 2);
-    int cur = 0;
-    for (int T = t_begin; T < t_end; ++T) {
-        const bool has_next = (T + 1) < t_end;
+    f32x16 accA, accB;
+    int T = t_begin;
+#define TDR_IMG(Tx, buf) (buf)
+#define TDR_YN(Tx) (nring + (((Tx) - t_begin) & 3) * 64 + 4 * h)
+    // first tile: nothing to finish yet
+    if (T < t_end) {
 #ifndef TDR_ABLATE_NOSTAGE
-        if (has_next) stage_dma<KQ, NW>(P.yp + (size_t)(T + 1) * TILE_F, cur ? tile0 : tile1, wave, lane);
+        if (T + 1 < t_end) stage(T + 1);
 #endif
-        const float* img = cur ? tile1 : tile0;
-
-        if (wave_active) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            // A fragments are double-buffered in registers in groups of 4 quads (16 MFMAs = 1024 pipe
-            // cycles per group), so the ds_read_b128 of group g+1 is in flight while group g multiplies.
-            {
-                constexpr int GQ = 4, NG = KQ / GQ;
-                const float* ap = img + lane * 4;
-                f32x4 a0[GQ], a1[GQ];
-#pragma unroll
-                for (int u = 0; u < GQ; ++u) a0[u] = *reinterpret_cast<const f32x4*>(ap + u * 256);
-#pragma unroll
-                for (int g = 0; g < NG; g += 2) {
-                    if (g + 1 < NG) {
-#pragma unroll
-                        for (int u = 0; u < GQ; ++u)
-                            a1[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 1) * GQ + u) * 256);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMA group
-#pragma unroll
-                    for (int u = 0; u < GQ; ++u) {
-                        const int t = g * GQ + u;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][0], b[4 * t + 0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][1], b[4 * t + 1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][2], b[4 * t + 2], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][3], b[4 * t + 3], acc, 0, 0, 0);
-                    }
-                    if (g + 1 < NG) {
-                        if (g + 2 < NG) {
-#pragma unroll
-                            for (int u = 0; u < GQ; ++u)
-                                a0[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 2) * GQ + u) * 256);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < GQ; ++u) {
-                            const int t = (g + 1) * GQ + u;
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][0], b[4 * t + 0], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][1], b[4 * t + 1], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][2], b[4 * t + 2], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][3], b[4 * t + 3], acc, 0, 0, 0);
-                        }
-                    }
-                }
-            }
-            // epilogue: lane holds database rows (r&3) + 8*(r>>2) + 4*h of this tile for query q
-            float dv[16];
-            unsigned hits = 0;
-            const float* ynp = img + KQ * 256 + 4 * h;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 y4 = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    float c;
-                    if (angular) c = -acc[r];
-                    else c = __fsub_rn(__fadd_rn(xn, y4[e]), __fmul_rn(2.0f, acc[r]));
-                    dv[r] = c;
-                    hits |= (c <= tau_d) ? (1u << r) : 0u;
-                }
-            }
-#ifdef TDR_ABLATE_NOINSERT
-            asm volatile("" ::"v"(hits));
-            hits = 0;
-#endif
-            unsigned long long lm = __ballot(hits != 0);
-            // Rare path, driven from the scalar unit: walk the hit lanes, and for each the set bits of its
-            // 16-bit hit mask; candidate value and index are wave-uniform (readlane), only the list update
-            // itself is vector work.
-            while (lm) {
-                const int src = __builtin_ctzll(lm);
-                lm &= lm - 1;
-                unsigned hm = __builtin_amdgcn_readlane(hits, src);
-                const int sq = src & 31;
-                const int64_t rowb = (int64_t)T * 32 + 4 * (src >> 5);
-                const int64_t gqs = qt * 32 + sq + P.q_offset;
-                while (hm) {
-                    const int r = __builtin_ctz(hm);
-                    hm &= hm - 1;
-                    float dval = 0.f;
-                    switch (r) {
-#define TDR_RL(R) case R: dval = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv[R]), src)); break;
-                        TDR_RL(0) TDR_RL(1) TDR_RL(2) TDR_RL(3) TDR_RL(4) TDR_RL(5) TDR_RL(6) TDR_RL(7)
-                        TDR_RL(8) TDR_RL(9) TDR_RL(10) TDR_RL(11) TDR_RL(12) TDR_RL(13) TDR_RL(14) TDR_RL(15)
-#undef TDR_RL
-                    }
-                    const int64_t j = rowb + (r & 3) + 8 * (r >> 2);
-                    if (j >= P.n_db || (P.exclude_self && j == gqs) || (qt * 32 + sq) >= P.nq) continue;
-                    uint64_t new_tail;
-                    if (coop_insert<ITEMS>(keys + (size_t)sq * k, k, mkkey(dval, (uint32_t)j), lane, new_tail)) {
-                        if (q == sq) tau_d = u2f((uint32_t)(new_tail >> 32));
-                    }
-                }
-            }
-        }
-
+        if (wave_active) tile_step<KQ, ITEMS, false>(C, TDR_IMG(T, tile0), b, accA, accA, nring, T, tau_d);
 #ifndef TDR_ABLATE_NOBARRIER
         __syncthreads();
 #endif
-        cur ^= 1;
+        ++T;
     }
+    // steady state, unrolled by two so that the accumulators / buffers are static
+    while (T < t_end) {
+        {   // odd relative tile: image in tile1, finishes the tile held in accA
+#ifndef TDR_ABLATE_NOSTAGE
+            if (T + 1 < t_end) stage(T + 1);
+#endif
+            if (wave_active)
+                tile_step<KQ, ITEMS, true>(C, TDR_IMG(T, tile1), b, accB, accA, TDR_YN(T - 1), T - 1, tau_d);
+#ifndef TDR_ABLATE_NOBARRIER
+            __syncthreads();
+#endif
+            ++T;
+        }
+        if (T < t_end) {  // even relative tile: image in tile0, finishes accB
+#ifndef TDR_ABLATE_NOSTAGE
+            if (T + 1 < t_end) stage(T + 1);
+#endif
+            if (wave_active)
+                tile_step<KQ, ITEMS, true>(C, TDR_IMG(T, tile0), b, accA, accB, TDR_YN(T - 1), T - 1, tau_d);
+#ifndef TDR_ABLATE_NOBARRIER
+            __syncthreads();
+#endif
+            ++T;
+        } else {
+            accA = accB;  // the last computed tile is always drained from accA below
+        }
+    }
+    if (wave_active && t_begin < t_end)
+        tile_drain<ITEMS>(C, accA, TDR_YN(t_end - 1), t_end - 1, tau_d);
 
     // --- emit: every list is already ascending by (distance, index)
     if (wave_active) {
@@ -513,7 +602,7 @@ static inline int pick_kq(int d) {
 using namespace tdr;
 
 static size_t knn_lds_bytes(int kq, int k, int nw = 4) {
-    return (size_t)2 * (kq * 256 + 64) * sizeof(float) + (size_t)nw * k * 32 * sizeof(uint64_t);
+    return (size_t)2 * (kq * 256) * sizeof(float) + (size_t)4 * 64 * sizeof(float) + (size_t)nw * k * 32 * sizeof(uint64_t);
 }
 
 // waves per workgroup: 4 (128 queries, default) | 6 | 8 -- tuning knob TDR_KNN_NW
