@@ -91,9 +91,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--d", type=int, default=128)
-    ap.add_argument("--k", type=int, default=30)
+    ap.add_argument("--npoints", dest="n", type=int, default=1_000_000)
+    ap.add_argument("--dim", dest="d", type=int, default=128)
+    ap.add_argument("--neighbors", dest="k", type=int, default=30)
     ap.add_argument("--max-iter", type=int, default=1000)
     ap.add_argument("--scale", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
