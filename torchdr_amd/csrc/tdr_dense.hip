@@ -16,28 +16,6 @@
 
 namespace tdr {
 
-template <int KQ>
-__device__ __forceinline__ void dstage_load(const float* __restrict__ src, f32x4 (&regs)[(KQ * 64 + 16 + 255) / 256],
-                                            int tid) {
-    constexpr int NV = KQ * 64 + 16;
-    constexpr int IT = (NV + 255) / 256;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int idx = tid + it * 256;
-        if (idx < NV) regs[it] = *reinterpret_cast<const f32x4*>(src + (size_t)idx * 4);
-    }
-}
-template <int KQ>
-__device__ __forceinline__ void dstage_store(float* dst, const f32x4 (&regs)[(KQ * 64 + 16 + 255) / 256], int tid) {
-    constexpr int NV = KQ * 64 + 16;
-    constexpr int IT = (NV + 255) / 256;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int idx = tid + it * 256;
-        if (idx < NV) *reinterpret_cast<f32x4*>(dst + (size_t)idx * 4) = regs[it];
-    }
-}
-
 struct PairScanParams {
     const float* qp;       // packed rows (queries)
     const float* yp;       // packed columns (database) -- same object for the symmetric passes
@@ -111,15 +89,103 @@ struct KhornForce {
     }
 };
 
+typedef __attribute__((address_space(1))) const void* dgptr_t;
+typedef __attribute__((address_space(3))) void* dlptr_t;
+
+// One tile step, software pipelined like the kNN scan (tdr_knn.hip): the MFMA chain of tile T runs with the
+// row reduction of tile T-1 (held in `accp`) placed BETWEEN its MFMAs, so the exp-heavy epilogue executes in
+// the shadow of the 64-cycle matrix instructions.  Quarter `g` of the previous tile = its rows 8g+4h .. +3.
+template <class Epi>
+__device__ __forceinline__ void reduce_part(Epi& epi, const PairScanParams& P, const f32x16& accp, const float* ynp,
+                                            const float* sd, int g, int h, float xn, int64_t row_base, int64_t gq) {
+    constexpr int SIDE = Epi::SIDE;
+    const f32x4 y4 = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const int i = e + 8 * g + 4 * h;  // database row inside the tile
+        const int64_t j = row_base + e + 8 * g;
+        float c = __builtin_fmaf(-2.0f, accp[r], __fadd_rn(xn, y4[e]));
+        if (P.exclude_diag && j == gq + P.q_offset) c = __fadd_rn(c, P.diag_add);
+        if (j < P.n_db) {
+            float sj[SIDE];
+#pragma unroll
+            for (int s_ = 0; s_ < SIDE; ++s_) sj[s_] = sd[i * SIDE + s_];
+            epi.add(c, sj, P);
+        }
+    }
+}
+
+template <int KQ, class Epi, bool HAVE_PREV>
+__device__ __forceinline__ void pair_tile_step(Epi& epi, const PairScanParams& P, const float* __restrict__ img,
+                                               const float (&b)[4 * KQ], f32x16& acc, const f32x16& accp,
+                                               const float* ynp_prev, const float* sd_prev, int lane, int h, float xn,
+                                               int64_t row_base_prev, int64_t gq) {
+    constexpr int GQ = (KQ >= 4) ? 4 : KQ, NG = KQ / GQ;
+    constexpr int PARTS_PER_GROUP = (4 + NG - 1) / NG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ap = img + lane * 4;
+    f32x4 a0[GQ], a1[GQ];
+#pragma unroll
+    for (int u = 0; u < GQ; ++u) a0[u] = *reinterpret_cast<const f32x4*>(ap + u * 256);
+    int part = 0;
+#pragma unroll
+    for (int g = 0; g < NG; g += 2) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int u = 0; u < GQ; ++u) a1[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 1) * GQ + u) * 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (HAVE_PREV) {
+#pragma unroll
+            for (int pp = 0; pp < PARTS_PER_GROUP; ++pp)
+                if (part + pp < 4) reduce_part<Epi>(epi, P, accp, ynp_prev, sd_prev, part + pp, h, xn, row_base_prev, gq);
+        }
+        part += PARTS_PER_GROUP;
+#pragma unroll
+        for (int u = 0; u < GQ; ++u) {
+            const int t = g * GQ + u;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][0], b[4 * t + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][1], b[4 * t + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][2], b[4 * t + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][3], b[4 * t + 3], acc, 0, 0, 0);
+        }
+        if (g + 1 < NG) {
+            if (g + 2 < NG) {
+#pragma unroll
+                for (int u = 0; u < GQ; ++u) a0[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 2) * GQ + u) * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (HAVE_PREV) {
+#pragma unroll
+                for (int pp = 0; pp < PARTS_PER_GROUP; ++pp)
+                    if (part + pp < 4) reduce_part<Epi>(epi, P, accp, ynp_prev, sd_prev, part + pp, h, xn, row_base_prev, gq);
+            }
+            part += PARTS_PER_GROUP;
+#pragma unroll
+            for (int u = 0; u < GQ; ++u) {
+                const int t = (g + 1) * GQ + u;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][0], b[4 * t + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][1], b[4 * t + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][2], b[4 * t + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][3], b[4 * t + 3], acc, 0, 0, 0);
+            }
+        }
+    }
+}
+
 template <int KQ, class Epi>
 __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int TILE_F = KQ * 256 + 64;
+    constexpr int IMG_F = KQ * 256;
     constexpr int SIDE = Epi::SIDE;
+    constexpr int SIDE_SLOT = 32 * SIDE;
     float* tile0 = reinterpret_cast<float*>(smem_raw);
-    float* tile1 = tile0 + TILE_F;
-    float* side0 = tile1 + TILE_F;  // [32][SIDE]
-    float* side1 = side0 + 32 * SIDE;
+    float* tile1 = tile0 + IMG_F;
+    float* nring = tile1 + IMG_F;       // [4 slots][64]  squared norms of the tile's rows
+    float* sring = nring + 4 * 64;      // [4 slots][32][SIDE] per-column scalars
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 31, h = lane >> 5;
     const int64_t n_qtiles = (P.nq + 31) / 32;
@@ -150,99 +216,76 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
         for (int t = 0; t < 4 * KQ; ++t) b[t] = 0.f;
     }
 
-    constexpr int IT = (KQ * 64 + 16 + 255) / 256;
-    f32x4 regs[IT];
+    const int n_tiles = P.n_db_tiles;
+    // stage(T): image -> tile[T & 1] and norms -> nring[T & 3] by LDS-DMA; side scalars -> sring[T & 3] (the
+    // caller stores `sreg` right before the barrier, when the DMA has long landed)
     float sreg = 0.f;
-    auto side_load = [&](int T) {
-        if (tid < 32 * SIDE) {
-            const int64_t idx = (int64_t)T * 32 * SIDE + tid;
+    auto stage = [&](int T) {
+        const float* src = P.yp + (size_t)T * TILE_F;
+        float* dst = (T & 1) ? tile1 : tile0;
+#pragma unroll
+        for (int t = 0; t < KQ; t += 4) {
+            const int blk = t + wave;
+            if (blk < KQ)
+                __builtin_amdgcn_global_load_lds((dgptr_t)(src + blk * 256 + lane * 4), (dlptr_t)(dst + blk * 256), 16, 0, 0);
+        }
+        if (wave == 3)
+            __builtin_amdgcn_global_load_lds((dgptr_t)(src + KQ * 256 + lane), (dlptr_t)(nring + (T & 3) * 64), 4, 0, 0);
+        if (tid < SIDE_SLOT) {
+            const int64_t idx = (int64_t)T * SIDE_SLOT + tid;
             sreg = (idx < P.n_db * SIDE) ? P.side[idx] : 0.f;
         }
     };
-    dstage_load<KQ>(P.yp, regs, tid);
-    side_load(0);
-    dstage_store<KQ>(tile0, regs, tid);
-    if (tid < 32 * SIDE) side0[tid] = sreg;
+    auto stage_side_store = [&](int T) {
+        if (tid < SIDE_SLOT) sring[(T & 3) * SIDE_SLOT + tid] = sreg;
+    };
+    if (n_tiles > 0) { stage(0); stage_side_store(0); }
     __syncthreads();
 
-    int cur = 0;
-    for (int T = 0; T < P.n_db_tiles; ++T) {
-        const bool has_next = (T + 1) < P.n_db_tiles;
-        if (has_next) { dstage_load<KQ>(P.yp + (size_t)(T + 1) * TILE_F, regs, tid); side_load(T + 1); }
-        const float* img = cur ? tile1 : tile0;
-        const float* sd = cur ? side1 : side0;
-        if (wave_active) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            {
-                constexpr int GQ = (KQ >= 4) ? 4 : KQ, NG = KQ / GQ;
-                const float* ap = img + lane * 4;
-                f32x4 a0[GQ], a1[GQ];
-#pragma unroll
-                for (int u = 0; u < GQ; ++u) a0[u] = *reinterpret_cast<const f32x4*>(ap + u * 256);
-#pragma unroll
-                for (int g = 0; g < NG; g += 2) {
-                    if (g + 1 < NG) {
-#pragma unroll
-                        for (int u = 0; u < GQ; ++u) a1[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 1) * GQ + u) * 256);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < GQ; ++u) {
-                        const int t = g * GQ + u;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][0], b[4 * t + 0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][1], b[4 * t + 1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][2], b[4 * t + 2], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][3], b[4 * t + 3], acc, 0, 0, 0);
-                    }
-                    if (g + 1 < NG) {
-                        if (g + 2 < NG) {
-#pragma unroll
-                            for (int u = 0; u < GQ; ++u) a0[u] = *reinterpret_cast<const f32x4*>(ap + ((g + 2) * GQ + u) * 256);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < GQ; ++u) {
-                            const int t = (g + 1) * GQ + u;
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][0], b[4 * t + 0], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][1], b[4 * t + 1], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][2], b[4 * t + 2], acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][3], b[4 * t + 3], acc, 0, 0, 0);
-                        }
-                    }
-                }
-            }
-            const float* ynp = img + KQ * 256 + 4 * h;
-            const int64_t row_base = (int64_t)T * 32 + 4 * h;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 y4 = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    const int i = e + 8 * g + 4 * h;  // database row inside the tile
-                    const int64_t j = row_base + e + 8 * g;
-                    float c = __fsub_rn(__fadd_rn(xn, y4[e]), __fmul_rn(2.0f, acc[r]));
-                    if (P.exclude_diag && j == gq + P.q_offset) c = __fadd_rn(c, P.diag_add);
-                    if (j < P.n_db) {
-                        float sj[SIDE];
-#pragma unroll
-                        for (int s_ = 0; s_ < SIDE; ++s_) sj[s_] = sd[i * SIDE + s_];
-                        epi.add(c, sj, P);
-                    }
-                }
-            }
-        }
-        if (has_next) {
-            dstage_store<KQ>(cur ? tile0 : tile1, regs, tid);
-            if (tid < 32 * SIDE) (cur ? side0 : side1)[tid] = sreg;
-        }
+    f32x16 accA, accB;
+    int T = 0;
+    if (T < n_tiles) {
+        const bool nx = T + 1 < n_tiles;
+        if (nx) stage(T + 1);
+        if (wave_active)
+            pair_tile_step<KQ, Epi, false>(epi, P, tile0, b, accA, accA, nring, sring, lane, h, xn, 0, gq);
+        if (nx) stage_side_store(T + 1);
         __syncthreads();
-        cur ^= 1;
+        ++T;
     }
-    // combine the two lanes (h = 0, 1) that share a row
-    if (wave_active) {
+    while (T < n_tiles) {
+        {
+            const bool nx = T + 1 < n_tiles;
+            if (nx) stage(T + 1);
+            if (wave_active)
+                pair_tile_step<KQ, Epi, true>(epi, P, (T & 1) ? tile1 : tile0, b, accB, accA,
+                                              nring + ((T - 1) & 3) * 64 + 4 * h, sring + ((T - 1) & 3) * SIDE_SLOT, lane, h,
+                                              xn, (int64_t)(T - 1) * 32 + 4 * h, gq);
+            if (nx) stage_side_store(T + 1);
+            __syncthreads();
+            ++T;
+        }
+        if (T < n_tiles) {
+            const bool nx = T + 1 < n_tiles;
+            if (nx) stage(T + 1);
+            if (wave_active)
+                pair_tile_step<KQ, Epi, true>(epi, P, (T & 1) ? tile1 : tile0, b, accA, accB,
+                                              nring + ((T - 1) & 3) * 64 + 4 * h, sring + ((T - 1) & 3) * SIDE_SLOT, lane, h,
+                                              xn, (int64_t)(T - 1) * 32 + 4 * h, gq);
+            if (nx) stage_side_store(T + 1);
+            __syncthreads();
+            ++T;
+        } else {
+            accA = accB;
+        }
+    }
+    if (wave_active && n_tiles > 0) {
+        const int Tl = n_tiles - 1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            reduce_part<Epi>(epi, P, accA, nring + (Tl & 3) * 64 + 4 * h, sring + (Tl & 3) * SIDE_SLOT, g, h, xn,
+                             (int64_t)Tl * 32 + 4 * h, gq);
+        // combine the two lanes (h = 0, 1) that share a row
         Epi other;
         other.shfl_from(epi, lane ^ 32);
         epi.merge(other);
@@ -306,7 +349,8 @@ template <class Epi>
 static int launch_pair_scan(const PairScanParams& P, int d, hipStream_t st) {
     const int kq = dense_pick_kq(d);
     if (kq == 0) return TDR_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)2 * (kq * 256 + 64) * sizeof(float) + (size_t)2 * 32 * Epi::SIDE * sizeof(float);
+    const size_t lds = (size_t)2 * (kq * 256) * sizeof(float) + (size_t)4 * 64 * sizeof(float) +
+                       (size_t)4 * 32 * Epi::SIDE * sizeof(float);
     const unsigned grid = (unsigned)((P.nq + 127) / 128);
 #define TDR_LAUNCH(KQV)                                                                                          \
     {                                                                                                            \
