@@ -155,7 +155,7 @@ class AffinityMatcher(DRModule):
             self.on_training_step_end()
             if step % self.check_interval == 0:
                 self._raise_if_nan()
-                grad_norm = float(self._last_grad.norm(2).item())
+                grad_norm = self._grad_norm()
                 if self.verbose:
                     self.logger.info(
                         f"[{step}/{self.max_iter}] Grad norm: {grad_norm:.2e} | LR: {self._current_lr():.2e}"
@@ -176,22 +176,49 @@ class AffinityMatcher(DRModule):
     # ------------------------------------------------------------------------------------------
     def _training_step(self):
         """Reference :354-430 with closed-form gradients (optimizer step, then scheduler step = advance
-        in the learning-rate table).  ``_compute_gradients`` returns either the
-        chunk's rows (``rows_only=True``: UMAP, only row i moves) or a full (N, c) buffer that other
-        ranks also scatter into (LargeVis / TSNE)."""
+        in the learning-rate table).  ``_compute_gradients`` returns either the chunk's rows
+        (``rows_only=True``: UMAP, only row i moves) or a full (N, c) buffer that other ranks also scatter
+        into (LargeVis / TSNE).
+
+        Multi-GPU, rows-only + fused SGD: each rank steps ITS rows and the updated rows are all-gathered
+        (1/W of the reference's zero-padded gradient all-reduce, :395-413, and no full-size optimizer pass);
+        otherwise the gradient is all-gathered / all-reduced (:425) and every rank steps the full embedding."""
         grad, rows_only = self._compute_gradients()
         world = getattr(self, "world_size", 1)
+        if world > 1 and rows_only and self._fused_sgd:
+            from torchdr_amd.parallel import allgather_rows
+
+            c0, c1 = self.chunk_start_, self.chunk_start_ + self.chunk_size_
+            rows = self.embedding_[c0:c1]
+            self._last_grad = grad
+            self._last_grad_is_chunk = True
+            self._sgd_kernel(rows, grad, chunk=True)
+            self.embedding_.copy_(allgather_rows(rows, self.n_samples_in_, world))
+            self._lr_pos += 1
+            return None
         if world > 1:
             from torchdr_amd.parallel import allgather_rows, allreduce_
 
             if rows_only:
-                grad = allgather_rows(grad, self.n_samples_in_, world)  # replaces the zero-padded all-reduce (:395-413)
+                grad = allgather_rows(grad, self.n_samples_in_, world)
             else:
                 allreduce_(grad)  # :425
         self._last_grad = grad
+        self._last_grad_is_chunk = False
         self._optimizer_step(grad)
         self._lr_pos += 1
         return None
+
+    def _grad_norm(self) -> float:
+        """2-norm of the full gradient (reference :331-342), reduced over ranks when only chunks are held."""
+        g = self._last_grad
+        if getattr(self, "_last_grad_is_chunk", False):
+            from torchdr_amd.parallel import allreduce_
+
+            sq = (g * g).sum().reshape(1)
+            allreduce_(sq)
+            return float(sq.sqrt().item())
+        return float(g.norm(2).item())
 
     def _compute_gradients(self):
         raise NotImplementedError("[TorchDR] ERROR : _compute_gradients method must be implemented.")
@@ -199,23 +226,26 @@ class AffinityMatcher(DRModule):
     def _current_lr(self) -> float:
         return self._lr_table[min(self._lr_pos, len(self._lr_table) - 1)]
 
-    def _optimizer_step(self, grad):
-        lr = self._current_lr()
-        if self._fused_sgd:
-            L = _lib.lib()
-            mom = float(self._sgd_momentum)
-            if mom != 0.0 and self._momentum_buf is None:
-                self._momentum_buf = torch.empty_like(self.embedding_)
-                first = 1
-            else:
-                first = 0
-            _lib.check(
-                L.tdr_sgd_step_f32(_lib.ptr(self.embedding_), _lib.ptr(grad), _lib.ptr(self._momentum_buf),
-                                   self.embedding_.numel(), lr, mom, first, _lib.ptr(self._nan_flag),
-                                   int(self.n_iter_), _lib.stream_ptr()),
-                "tdr_sgd_step_f32",
-            )
+    def _sgd_kernel(self, Z, grad, chunk=False):
+        """Fused torch.optim.SGD(momentum) step on the rows ``Z`` (a contiguous view of the embedding)."""
+        mom = float(self._sgd_momentum)
+        if mom != 0.0 and self._momentum_buf is None:
+            self._momentum_buf = torch.empty_like(Z)
+            first = 1
         else:
+            first = 0
+        _lib.check(
+            _lib.lib().tdr_sgd_step_f32(_lib.ptr(Z), _lib.ptr(grad), _lib.ptr(self._momentum_buf), Z.numel(),
+                                        self._current_lr(), mom, first, _lib.ptr(self._nan_flag), int(self.n_iter_),
+                                        _lib.stream_ptr()),
+            "tdr_sgd_step_f32",
+        )
+
+    def _optimizer_step(self, grad):
+        if self._fused_sgd:
+            self._sgd_kernel(self.embedding_, grad)
+        else:
+            lr = self._current_lr()
             for g in self.optimizer_.param_groups:
                 g["lr"] = lr
             self.embedding_.grad = grad
