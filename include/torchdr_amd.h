@@ -95,8 +95,9 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
                       float eps, float* grad, void* stream);
 /* gradients of neighbor_embedding/largevis.py:181-201 (kind 0) and tsne.py:162-170 (kind 1, attraction) */
 int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nn,
-                    const float* P, int k, int kind, float exag, float rep_coef, int n_neg, const int64_t* neg_inj,
-                    uint64_t seed, int n_iter, float* grad, void* stream);
+                    const float* P, int k, const int64_t* t_rowptr, const int32_t* t_src, const float* t_val, int kind,
+                    float exag, float rep_coef, int n_neg, const int64_t* neg_inj, uint64_t seed, int n_iter,
+                    float* grad, void* stream);
 /* gradient pieces of neighbor_embedding/tsne.py:172-180 (dense Student-t partition function) */
 int tdr_tsne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* F, double* S,
                            void* stream);

@@ -61,15 +61,18 @@ def test_umap_three_steps_vs_reference():
     assert int(flag.item()) == 0
 
 
+@pytest.mark.parametrize("pull", [False, True])
 @pytest.mark.parametrize("name", ["largevis", "tsne"])
-def test_ne_gradients_vs_reference_autograd(name):
+def test_ne_gradients_vs_reference_autograd(name, pull):
     from torchdr_amd import _lib
+    from torchdr_amd.neighbor_embedding.base import build_transposed_graph
 
     L = _lib.lib()
     g = load("ne_step")
     n = g["X"].shape[0]
     P, NN = g[f"{name}_P"].cuda().contiguous(), g[f"{name}_NN"].to(torch.int32).cuda().contiguous()
     k = P.shape[1]
+    tg = build_transposed_graph(P, NN, 0, n, 1) if pull else (None, None, None)
     buf = torch.empty((n, 2), device="cuda")
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
     for t in range(2):
@@ -78,12 +81,13 @@ def test_ne_gradients_vs_reference_autograd(name):
         grad = torch.zeros((n, 2), device="cuda")
         if name == "largevis":
             neg = g[f"{name}_neg_{t}"].cuda().contiguous()
-            rc = L.tdr_ne_grad_f32(_lib.ptr(Z), 2, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, 0, exag, 2.0 / n,
-                                   neg.shape[1], _lib.ptr(neg), 0, t, _lib.ptr(grad), _lib.stream_ptr())
+            rc = L.tdr_ne_grad_f32(_lib.ptr(Z), 2, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]),
+                                   _lib.ptr(tg[2]), 0, exag, 2.0 / n, neg.shape[1], _lib.ptr(neg), 0, t, _lib.ptr(grad),
+                                   _lib.stream_ptr())
             _lib.check(rc, "ne_grad")
         else:
-            rc = L.tdr_ne_grad_f32(_lib.ptr(Z), 2, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, 1, exag, 0.0, 0, None, 0,
-                                   t, _lib.ptr(grad), _lib.stream_ptr())
+            rc = L.tdr_ne_grad_f32(_lib.ptr(Z), 2, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]),
+                                   _lib.ptr(tg[2]), 1, exag, 0.0, 0, None, 0, t, _lib.ptr(grad), _lib.stream_ptr())
             _lib.check(rc, "ne_grad")
             F = torch.empty((n, 2), device="cuda")
             S = torch.zeros(1, dtype=torch.float64, device="cuda")

@@ -25,7 +25,7 @@ if "c2" in which:
     timed("C2 UMAP N=100k D=128 k=30 fit_transform", lambda: t.UMAP(n_neighbors=30, random_state=0).fit_transform(X))
 if "c3" in which:
     X = gmm(1_000_000, 128, 2.0).cuda()
-    timed("C3 LargeVis N=1M D=128 perplexity 5 (kNN width 15), 500 iters", lambda: t.LargeVis(perplexity=5, max_iter=500, random_state=0).fit_transform(X), 1)
+    timed("C3 LargeVis N=1M D=128 perplexity 5 (kNN width 15), 500 iters", lambda: t.LargeVis(perplexity=5, max_iter=500, random_state=0).fit_transform(X), 2)
     timed("C3b LargeVis N=1M D=128 perplexity 15 (kNN width 45), 500 iters", lambda: t.LargeVis(perplexity=15, max_iter=500, random_state=0).fit_transform(X), 1)
 if "c5" in which:
     n = 200_000

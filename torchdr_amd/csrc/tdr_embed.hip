@@ -241,6 +241,11 @@ struct NeStepParams {
     uint64_t seed;
     uint32_t iter;
     float* grad;             // (N, NC) zero-initialised; both endpoints receive atomics
+    // optional transposed graph (in-edges of this chunk's rows): when present the neighbour edges are
+    // evaluated pull-style by BOTH endpoints' rows and no atomics are issued for them
+    const int64_t* t_rowptr; // (n_rows + 1) or NULL
+    const int32_t* t_src;    // global source row of each in-edge
+    const float* t_val;      // P of each in-edge
 };
 
 template <int NC, int G>
@@ -254,6 +259,9 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) g[c] = 0.f;
     const float off = (S.kind == 0) ? 2.0f : 1.0f;
+    const bool pull = S.t_rowptr != nullptr;
+    // out-edges i -> j : +w (z_i - z_j) on i, and -w (z_i - z_j) on j (pushed with atomics unless j's own row
+    // pulls it from the transposed graph)
     for (int p = gl; p < S.k; p += G) {
         const int64_t j = S.nn[(size_t)r * S.k + p];
         const float pij = S.P[(size_t)r * S.k + p];
@@ -267,7 +275,21 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
         for (int c = 0; c < NC; ++c) {
             const float t = w * df[c];
             g[c] += t;
-            unsafeAtomicAdd(&S.grad[(size_t)j * NC + c], -t);
+            if (!pull) unsafeAtomicAdd(&S.grad[(size_t)j * NC + c], -t);
+        }
+    }
+    if (pull) {
+        // in-edges s -> i carry -w (z_s - z_i) = +w (z_i - z_s): the same expression as an out-edge
+        const int64_t e1 = S.t_rowptr[r + 1];
+        for (int64_t e = S.t_rowptr[r] + gl; e < e1; e += G) {
+            const Vec<NC> zs = load_z<NC>(S.Z, S.t_src[e]);
+            float df[NC];
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zs.v[c]; d += df[c] * df[c]; }
+            const float w = S.exag * 2.0f * S.t_val[e] / (off + d);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) g[c] += w * df[c];
         }
     }
     const uint32_t rkey = neg_row_key(S.seed, S.iter, gi);
@@ -420,10 +442,13 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
 }
 
 /* Sparse attraction (+ LargeVis negative-sample repulsion) gradient; grad (N, nc) must be zeroed by the
- * caller; both endpoints of every edge receive their share through fp32 atomics. */
+ * caller.  Both endpoints of every edge receive their share: with the transposed graph (t_rowptr / t_src /
+ * t_val = in-edges of rows [row0, row0+n_rows)) each row pulls its in-edges itself and only the negative
+ * samples use fp32 atomics; without it (NULL) every neighbour edge pushes to its far endpoint atomically. */
 int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nn,
-                    const float* P_, int k, int kind, float exag, float rep_coef, int n_neg, const int64_t* neg_inj,
-                    uint64_t seed, int n_iter, float* grad, void* stream) {
+                    const float* P_, int k, const int64_t* t_rowptr, const int32_t* t_src, const float* t_val, int kind,
+                    float exag, float rep_coef, int n_neg, const int64_t* neg_inj, uint64_t seed, int n_iter,
+                    float* grad, void* stream) {
     if (!Z || !nn || !P_ || !grad || n_rows <= 0 || k <= 0 || n_total < 2) return TDR_ERR_BAD_ARG;
     if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
     if (kind != 0 && kind != 1) return TDR_ERR_BAD_ARG;
@@ -431,6 +456,8 @@ int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64
     S.Z = Z; S.n_total = n_total; S.row0 = row0; S.n_rows = n_rows; S.nn = nn; S.P = P_; S.k = k; S.kind = kind;
     S.exag = exag; S.rep_coef = rep_coef; S.n_neg = n_neg; S.neg_inj = neg_inj; S.seed = seed;
     S.iter = (uint32_t)n_iter; S.grad = grad;
+    if (t_rowptr && (!t_src || !t_val)) return TDR_ERR_BAD_ARG;
+    S.t_rowptr = t_rowptr; S.t_src = t_src; S.t_val = t_val;
     hipStream_t st = (hipStream_t)stream;
     if (nc == 2) return launch_group<16>(ne_grad_kernel<2, 16>, S, n_rows, st);
     return launch_group<16>(ne_grad_kernel<3, 16>, S, n_rows, st);

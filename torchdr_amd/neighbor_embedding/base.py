@@ -152,6 +152,33 @@ class NeighborEmbedding(AffinityMatcher):
         return self.embedding_
 
 
+def build_transposed_graph(P, NN, chunk_start, n_total, world_size):
+    """In-edges of this rank's rows of the rectangular (n, k) graph as CSR (rowptr int64, src int32 global,
+    val fp32): edge i -> j with weight P_ij becomes an entry of row j.  Lets the gradient kernel evaluate the
+    far-endpoint share of every neighbour edge pull-style (no atomics).  Edges whose target row lives on another
+    rank are routed there with the same all-to-all-v as the symmetrisation."""
+    n, k = P.shape
+    dev = P.device
+    src = (torch.arange(n, device=dev, dtype=torch.int64) + chunk_start).repeat_interleave(k)
+    dst = NN.reshape(-1).to(torch.int64)
+    val = P.reshape(-1)
+    if world_size > 1:
+        from torchdr_amd.parallel import exchange_transposed_edges
+
+        local = (dst >= chunk_start) & (dst < chunk_start + n)
+        er, ec, ev = exchange_transposed_edges(P, NN, chunk_start, n_total, world_size)
+        rows = torch.cat([dst[local] - chunk_start, er.to(torch.int64)])
+        srcs = torch.cat([src[local], ec.to(torch.int64)])
+        vals = torch.cat([val[local], ev])
+    else:
+        rows, srcs, vals = dst, src, val
+    order = torch.argsort(rows, stable=True)
+    counts = torch.bincount(rows, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = counts.cumsum(0)
+    return rowptr, srcs[order].to(torch.int32).contiguous(), vals[order].contiguous()
+
+
 class NegativeSamplingNeighborEmbedding(NeighborEmbedding):
     """Repulsion through per-step negative samples (reference :426-649).  Negatives are drawn
     in-kernel (Philox, keyed by seed / iteration / row / column) uniformly from all points except

@@ -6,7 +6,7 @@ import torch
 
 from torchdr_amd import _lib
 from torchdr_amd.affinity import EntropicAffinity
-from torchdr_amd.neighbor_embedding.base import NegativeSamplingNeighborEmbedding
+from torchdr_amd.neighbor_embedding.base import NegativeSamplingNeighborEmbedding, build_transposed_graph
 
 
 class LargeVis(NegativeSamplingNeighborEmbedding):
@@ -44,6 +44,11 @@ class LargeVis(NegativeSamplingNeighborEmbedding):
                          check_interval=check_interval, discard_NNs=discard_NNs, compile=compile,
                          distributed=distributed, **kwargs)
 
+    def on_affinity_computation_end(self):
+        super().on_affinity_computation_end()
+        self._tgraph = build_transposed_graph(self.affinity_in_, self.NN_indices_, self.chunk_start_,
+                                              self.n_samples_in_, self.world_size)
+
     def _compute_gradients(self):
         n, nc = self.n_samples_in_, self.n_components
         grad = torch.zeros((n, nc), dtype=torch.float32, device=self.device_)
@@ -53,10 +58,16 @@ class LargeVis(NegativeSamplingNeighborEmbedding):
         _lib.check(
             _lib.lib().tdr_ne_grad_f32(
                 _lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_, _lib.ptr(nn), _lib.ptr(P),
-                P.shape[1], 0, float(self.early_exaggeration_coeff_), float(self.repulsion_strength) * 2.0 / n,
+                P.shape[1], _lib.ptr(self._tgraph[0]), _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]), 0,
+                float(self.early_exaggeration_coeff_), float(self.repulsion_strength) * 2.0 / n,
                 int(self.n_negatives), _lib.ptr(neg), self._neg_seed, int(self.n_iter_), _lib.ptr(grad),
                 _lib.stream_ptr(),
             ),
             "tdr_ne_grad_f32",
         )
         return grad, False
+
+    def clear_memory(self):
+        super().clear_memory()
+        if hasattr(self, "_tgraph"):
+            delattr(self, "_tgraph")

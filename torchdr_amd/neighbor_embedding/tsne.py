@@ -7,7 +7,7 @@ import torch.distributed as dist
 
 from torchdr_amd import _lib
 from torchdr_amd.affinity import EntropicAffinity
-from torchdr_amd.neighbor_embedding.base import NeighborEmbedding
+from torchdr_amd.neighbor_embedding.base import NeighborEmbedding, build_transposed_graph
 
 
 class TSNE(NeighborEmbedding):
@@ -46,6 +46,16 @@ class TSNE(NeighborEmbedding):
                          early_exaggeration_iter=early_exaggeration_iter, check_interval=check_interval,
                          compile=compile, distributed=distributed, **kwargs)
 
+    def on_affinity_computation_end(self):
+        super().on_affinity_computation_end()
+        self._tgraph = build_transposed_graph(self.affinity_in_, self.NN_indices_, self.chunk_start_,
+                                              self.n_samples_in_, self.world_size)
+
+    def clear_memory(self):
+        super().clear_memory()
+        if hasattr(self, "_tgraph"):
+            delattr(self, "_tgraph")
+
     def _compute_gradients(self):
         L = _lib.lib()
         n, nc = self.n_samples_in_, self.n_components
@@ -54,7 +64,8 @@ class TSNE(NeighborEmbedding):
         P = self.affinity_in_
         _lib.check(
             L.tdr_ne_grad_f32(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
-                              _lib.ptr(self.NN_indices_), _lib.ptr(P), P.shape[1], 1,
+                              _lib.ptr(self.NN_indices_), _lib.ptr(P), P.shape[1], _lib.ptr(self._tgraph[0]),
+                              _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]), 1,
                               float(self.early_exaggeration_coeff_), 0.0, 0, None, 0, int(self.n_iter_),
                               _lib.ptr(grad), st),
             "tdr_ne_grad_f32",
