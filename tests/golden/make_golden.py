@@ -226,6 +226,8 @@ if __name__ == "__main__":
     umap_step_fixture()
     ne_step_fixture()
     distributed_fixture()
+    tsnekhorn_fixture()
+    dense_affinity_fixture()
     print("reference version:", torchdr.__version__)
 
 
@@ -271,3 +273,15 @@ def tsnekhorn_fixture():
         if v is not None:
             out[f"tk_{k_}"] = v
     save("tsnekhorn", **out)
+
+
+def dense_affinity_fixture():
+    X = gmm(300, 12, 2.0, seed=71)
+    out = {"X": X}
+    aff = EntropicAffinity(perplexity=10, sparsity=False, backend=None, max_iter=100)
+    out["ent_logP"] = aff(X, log=True, return_indices=False)
+    out["ent_eps"] = aff.eps_
+    au = UMAPAffinity(n_neighbors=10, sparsity=False, backend=None, max_iter=100)
+    out["umap_P"] = au(X, return_indices=False)
+    out["umap_eps"], out["umap_rho"] = au.eps_, au.rho_
+    save("affinity_dense", **out)

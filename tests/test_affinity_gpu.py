@@ -142,3 +142,23 @@ def test_affinity_plugins_end_to_end():
     # numpy input is accepted by the plugin surface
     V2, J2 = UMAPAffinity(n_neighbors=10, max_iter=100)(a["X"].numpy())
     assert torch.equal(J2.cpu(), a["umap10_Isym"])
+
+
+def test_dense_affinities_sparsity_false():
+    """sparsity=False: full N x N rows through the streaming search kernels, vs the real reference."""
+    from torchdr_amd.affinity import EntropicAffinity, UMAPAffinity
+
+    g = load("affinity_dense")
+    X = g["X"].cuda()
+    n = X.shape[0]
+    aff = EntropicAffinity(perplexity=10, sparsity=False, max_iter=100)
+    logP = aff(X, log=True, return_indices=False)
+    assert logP.shape == (n, n)
+    assert torch.allclose(aff.eps_.cpu(), g["ent_eps"], rtol=RTOL)
+    off = ~torch.eye(n, dtype=torch.bool)
+    assert torch.allclose(logP.cpu()[off], g["ent_logP"][off], rtol=RTOL, atol=1e-4)
+    assert torch.isinf(logP.cpu().diagonal()).all() or (logP.cpu().diagonal() < -1e6).all()  # zero diagonal
+    P, idx = UMAPAffinity(n_neighbors=10, sparsity=False, max_iter=100)(X)
+    assert idx is None and P.shape == (n, n)
+    assert torch.allclose(P.cpu(), g["umap_P"], rtol=1e-4, atol=1e-7)
+    assert torch.allclose(P, P.T)

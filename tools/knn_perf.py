@@ -22,5 +22,8 @@ def run(n, d, k, reps=2):
     print(json.dumps(res), flush=True)
 
 if __name__ == "__main__":
-    for n in [int(a) for a in sys.argv[1:]] or [100_000]:
-        run(n, 128, 30)
+    # usage: knn_perf.py N [N ...] [d=DIM] [k=K]
+    d = next((int(a[2:]) for a in sys.argv[1:] if a.startswith("d=")), 128)
+    k = next((int(a[2:]) for a in sys.argv[1:] if a.startswith("k=")), 30)
+    for n in [int(a) for a in sys.argv[1:] if a.isdigit()] or [100_000]:
+        run(n, d, k)

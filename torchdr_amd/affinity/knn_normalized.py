@@ -54,10 +54,14 @@ class UMAPAffinity(SparseAffinity):
         n_samples_in = self._get_n_samples(X)
         n_neighbors = check_neighbor_param(self.n_neighbors, n_samples_in)
         if not self.sparsity:
-            raise NotImplementedError(
-                "[torchdr_amd] UMAPAffinity(sparsity=False) (dense N x N affinity) is not part of the "
-                "accelerated path; use sparsity=True."
-            )
+            # dense N x N affinity (knn_normalized.py:443, 488-493): the row search streams each full row
+            C_, _ = self._distance_matrix(X, return_indices=True)
+            rho, eps, P = umap_sigma_search(C_, n_neighbors, self.max_iter)
+            self.register_buffer("rho_", rho, persistent=False)
+            self.register_buffer("eps_", eps, persistent=False)
+            if self.symmetrize:
+                P = P + P.T - P * P.T
+            return (P, None) if return_indices else P
         if self.verbose:
             self.logger.info(f"Sparsity mode enabled, computing {n_neighbors} nearest neighbors...")
         C_, indices = self._distance_matrix(X, k=int(n_neighbors), return_indices=True)

@@ -203,6 +203,112 @@ __global__ __launch_bounds__(256) void entropic_search_kernel(const float* __res
     if (gl == 0) { eps_out[row] = eps; lognorm_out[row] = lse; }
 }
 
+// ---- streaming variants (any row length; dense N x N affinities, sparsity=False) ----------------------
+// One wavefront per row; the row is re-read from global memory (L2-resident) at every evaluation.
+struct StreamRow {
+    const float* c;
+    int k, lane;
+};
+__device__ __forceinline__ float stream_umap_f(const StreamRow& R, float rho, float target, float eps) {
+    float m = -__builtin_inff();
+    for (int j = R.lane; j < R.k; j += 64) m = fmaxf(m, (-(R.c[j] - rho)) / eps);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = R.lane; j < R.k; j += 64) s += expf((-(R.c[j] - rho)) / eps - m);
+    s = wave_sum(s);
+    return expf(m + logf(s)) - target;
+}
+__device__ __forceinline__ float stream_entropic_f(const StreamRow& R, float target, float eps, float* lse_out) {
+    float m = -__builtin_inff();
+    for (int j = R.lane; j < R.k; j += 64) m = fmaxf(m, (-R.c[j]) / eps);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = R.lane; j < R.k; j += 64) s += expf((-R.c[j]) / eps - m);
+    s = wave_sum(s);
+    const float lse = m + logf(s);
+    float h = 0.f;
+    for (int j = R.lane; j < R.k; j += 64) {
+        const float l = (-R.c[j]) / eps - lse;
+        h += expf(l) * (l - 1.0f);
+    }
+    h = wave_sum(h);
+    if (lse_out) *lse_out = lse;
+    return (-h) - target;
+}
+
+template <typename F>
+__device__ __forceinline__ float stream_binary_search(F f, float b, float e, int max_iter, float tol) {
+    for (int it = 0; it < max_iter; ++it) {
+        if (!(f(b) > 0.f)) break;
+        e = fminf(e, b);
+        b = b * 0.5f;
+    }
+    for (int it = 0; it < max_iter; ++it) {
+        if (!(f(e) < 0.f)) break;
+        b = fmaxf(b, e);
+        e = e * 2.0f;
+    }
+    float f_b = f(b);
+    float m = (b + e) * 0.5f;
+    float f_m = f(m);
+    for (int it = 0; it < max_iter; ++it) {
+        if (!(fabsf(f_m) >= tol)) break;
+        if (f_m * f_b > 0.f) { b = m; f_b = f_m; }
+        else e = m;
+        m = (b + e) * 0.5f;
+        f_m = f(m);
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void umap_search_stream_kernel(const float* __restrict__ C, int64_t n, int k, float target,
+                                                                 int max_iter, float tol, float* __restrict__ rho_out,
+                                                                 float* __restrict__ eps_out, float* __restrict__ P_out) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    StreamRow R;
+    R.c = C + (size_t)row * k; R.k = k; R.lane = threadIdx.x & 63;
+    float mn = __builtin_inff();
+    for (int j = R.lane; j < k; j += 64) mn = fminf(mn, R.c[j]);
+    const float rho = -wave_max(-mn);
+    const float eps = stream_binary_search([&](float x) { return stream_umap_f(R, rho, target, x); }, 1.0f, 1.0f, max_iter, tol);
+    for (int j = R.lane; j < k; j += 64) P_out[(size_t)row * k + j] = expf((-(R.c[j] - rho)) / eps);
+    if (R.lane == 0) { rho_out[row] = rho; eps_out[row] = eps; }
+}
+
+__global__ __launch_bounds__(256) void entropic_search_stream_kernel(const float* __restrict__ C, int64_t n, int k,
+                                                                     EntropicScalars S, int max_iter, float tol,
+                                                                     float* __restrict__ eps_out, float* __restrict__ lognorm_out,
+                                                                     float* __restrict__ logP_out) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    StreamRow R;
+    R.c = C + (size_t)row * k; R.k = k; R.lane = threadIdx.x & 63;
+    float b = 1.0f, e = 1.0f;
+    if (S.use_bounds) {
+        float mx = -__builtin_inff(), m1 = __builtin_inff();
+        for (int j = R.lane; j < k; j += 64) { mx = fmaxf(mx, R.c[j]); m1 = fminf(m1, R.c[j]); }
+        const float dN = wave_max(mx);
+        const float d1 = -wave_max(-m1);
+        int first_eq = 1 << 30;
+        for (int j = R.lane; j < k; j += 64) if (R.c[j] == d1) first_eq = min(first_eq, j);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) first_eq = min(first_eq, __shfl_xor(first_eq, o, 64));
+        float m2 = __builtin_inff();
+        for (int j = R.lane; j < k; j += 64) if (j != first_eq) m2 = fminf(m2, R.c[j]);
+        const float d2 = -wave_max(-m2);
+        const float beta_L = fmaxf(S.tN_logratio / (S.tN_m1 * (dN - d1)), sqrtf(S.log_ratio / (dN * dN - d1 * d1)));
+        const float beta_U = S.beta_u_num / (d2 - d1);
+        b = 1.0f / beta_U + 1e-6f;
+        e = 1.0f / beta_L;
+    }
+    const float eps = stream_binary_search([&](float x) { return stream_entropic_f(R, S.target, x, nullptr); }, b, e, max_iter, tol);
+    float lse;
+    stream_entropic_f(R, S.target, eps, &lse);
+    for (int j = R.lane; j < k; j += 64) logP_out[(size_t)row * k + j] = ((-R.c[j]) / eps - lse) - S.log_n;
+    if (R.lane == 0) { eps_out[row] = eps; lognorm_out[row] = lse; }
+}
+
 // distance/base.py:384-385 -- out[i][c] = sum_d (X[q_i][d] - Y[key[i][c]][d])^2 ; negative keys wrap.
 __global__ __launch_bounds__(256) void indexed_sqdist_kernel(const float* __restrict__ X, int64_t nx, int d,
                                                              const float* __restrict__ Y, int64_t ny,
@@ -250,8 +356,13 @@ extern "C" {
 int tdr_umap_search_f32(const float* C, int64_t n, int k, float target, int max_iter, float tol, float* rho,
                         float* eps, float* P, void* stream) {
     if (!C || !rho || !eps || !P || n <= 0 || k <= 0) return TDR_ERR_BAD_ARG;
-    if (k > 64 * MAX_ITEMS) return TDR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    if (k > 64 * MAX_ITEMS) {
+        hipLaunchKernelGGL(umap_search_stream_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, C, n, k, target, max_iter,
+                           tol, rho, eps, P);
+        TDR_CHECK_LAUNCH();
+        return TDR_OK;
+    }
     if (k <= 32) return launch_rows(umap_search_kernel<32, 1>, 32, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
     if (k <= 64) return launch_rows(umap_search_kernel<64, 1>, 64, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
     if (k <= 128) return launch_rows(umap_search_kernel<64, 2>, 64, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
@@ -269,12 +380,17 @@ int tdr_entropic_search_f32(const float* C, int64_t n, int k, float target, floa
                             int use_bounds, float tN_logratio, float tN_m1, float log_ratio, float beta_u_num,
                             float* eps, float* log_norm, float* log_P, void* stream) {
     if (!C || !eps || !log_norm || !log_P || n <= 0 || k <= 0) return TDR_ERR_BAD_ARG;
-    if (k > 64 * MAX_ITEMS) return TDR_ERR_UNSUPPORTED;
     if (use_bounds && k < 2) return TDR_ERR_BAD_ARG;
     EntropicScalars S;
     S.target = target; S.use_bounds = use_bounds; S.tN_logratio = tN_logratio; S.tN_m1 = tN_m1;
     S.log_ratio = log_ratio; S.beta_u_num = beta_u_num; S.log_n = log_n;
     hipStream_t st = (hipStream_t)stream;
+    if (k > 64 * MAX_ITEMS) {
+        hipLaunchKernelGGL(entropic_search_stream_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, C, n, k, S, max_iter,
+                           tol, eps, log_norm, log_P);
+        TDR_CHECK_LAUNCH();
+        return TDR_OK;
+    }
     if (k <= 32) return launch_rows(entropic_search_kernel<32, 1>, 32, n, st, C, n, k, S, max_iter, tol, eps, log_norm, log_P);
     if (k <= 64) return launch_rows(entropic_search_kernel<64, 1>, 64, n, st, C, n, k, S, max_iter, tol, eps, log_norm, log_P);
     if (k <= 128) return launch_rows(entropic_search_kernel<64, 2>, 64, n, st, C, n, k, S, max_iter, tol, eps, log_norm, log_P);
