@@ -236,73 +236,97 @@ __device__ __forceinline__ bool coop_insert(uint64_t* L, int k, uint64_t cand, i
 }
 
 // ---- one tile step of the scan (software pipelined) -----------------------------------------------------
-// Multiplies tile T into `acc` (one k-ordered MFMA chain) and, IN THE SAME INSTRUCTION STREAM, finishes
-// tile T-1 out of `accp`: its 16 candidate distances per lane are formed between the MFMAs of tile T (an
-// in-order wavefront can only overlap VALU with a 64-cycle MFMA if the VALU sits between MFMAs in program
-// order), folded into a running minimum and tested against the lane's k-th-best threshold with ONE compare.
-// Only when some lane of the wavefront has a survivor is the per-value hit mask built and the scalar-driven
-// insertion loop entered.
+// A wavefront owns QB blocks of 32 queries (QB = 1: 2 wavefronts per SIMD; QB = 2: one wavefront per SIMD that
+// drives two independent MFMA chains off the same A fragments -- half the LDS reads, barriers and staging
+// per matrix instruction, and 256 queries per workgroup halve the L2 traffic).
+// tile_step multiplies tile T into `acc` (one k-ordered MFMA chain per query block) and, IN THE SAME
+// INSTRUCTION STREAM, finishes tile T-1 out of `accp`: its candidate distances are formed between the MFMAs
+// of tile T (an in-order wavefront overlaps VALU with a 64-cycle MFMA only if the VALU sits between MFMAs in
+// program order), folded into a running minimum and tested against the lane's k-th-best threshold with ONE
+// compare.  Only when some lane has a survivor is the scalar-driven insertion loop entered.
+template <int QB>
 struct ScanCtx {
     const KnnParams* P;
-    uint64_t* keys;   // this wave's lists [32][k]
+    uint64_t* keys;   // this wave's lists [QB][32][k]
     int k, lane, q, h;
-    int64_t qt;       // query tile of this wave
-    float xn;
+    int64_t qt0;      // first query tile of this wave (tiles qt0 .. qt0 + QB - 1)
+    float xn[QB];
     bool angular;
 };
 
-// Rare path.  For each of the lane's 16 candidate slots the compare against the threshold IS the ballot
-// (v_cmp writes the 64-lane mask to SGPRs); slots without a survivor cost one scalar test.  Survivors are
-// walked from the scalar unit: value and row index are wave-uniform (readlane), only the list update itself
-// is vector work.  tau_d is refreshed after every insertion, so later slots filter with the new threshold.
-template <int ITEMS>
-__device__ __forceinline__ void scan_insert(const ScanCtx& C, const float (&dv)[16], int Tprev, float& tau_d) {
+// Rare path.  For each candidate slot the compare against the threshold IS the ballot (v_cmp writes the
+// 64-lane mask to SGPRs); slots without a survivor cost one scalar test.  Survivors are walked from the
+// scalar unit: value and row index are wave-uniform (readlane), only the list update itself is vector work.
+// tau_d is refreshed after every insertion, so later slots filter with the new threshold.
+template <int ITEMS, int QB>
+__device__ __forceinline__ void scan_insert(const ScanCtx<QB>& C, const float (&dv)[QB][16], int Tprev, float (&tau_d)[QB]) {
     const KnnParams& P = *C.P;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        unsigned long long m = __ballot(dv[r] <= tau_d);
-        while (m) {
-            const int src = __builtin_ctzll(m);
-            m &= m - 1;
-            const int sq = src & 31;
-            const int64_t j = (int64_t)Tprev * 32 + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2);
-            if (j >= P.n_db || (P.exclude_self && j == C.qt * 32 + sq + P.q_offset)) continue;
-            const float dval = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv[r]), src));
-            uint64_t new_tail;
-            if (coop_insert<ITEMS>(C.keys + (size_t)sq * C.k, C.k, mkkey(dval, (uint32_t)j), C.lane, new_tail)) {
-                if (C.q == sq) tau_d = u2f((uint32_t)(new_tail >> 32));
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned long long m = __ballot(dv[qb][r] <= tau_d[qb]);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const int sq = src & 31;
+                const int64_t j = (int64_t)Tprev * 32 + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2);
+                if (j >= P.n_db || (P.exclude_self && j == (C.qt0 + qb) * 32 + sq + P.q_offset)) continue;
+                const float dval =
+                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv[qb][r]), src));
+                uint64_t new_tail;
+                if (coop_insert<ITEMS>(C.keys + ((size_t)qb * 32 + sq) * C.k, C.k, mkkey(dval, (uint32_t)j), C.lane,
+                                       new_tail)) {
+                    if (C.q == sq) tau_d[qb] = u2f((uint32_t)(new_tail >> 32));
+                }
             }
         }
     }
 }
 
 // candidate values of one finished tile: c = (||x||^2 + ||y||^2) - 2 x.y  (distance/torch.py:91); rows
-// (r&3) + 8*(r>>2) + 4*h of the tile.  `part` selects which quarter (4 values) to form -- the caller spreads
-// the four parts over the MFMA groups of the next tile.
-__device__ __forceinline__ void form_part(const ScanCtx& C, const f32x16& accp, const float* ynp, int g, float (&dv)[16],
-                                          float& cmin) {
+// (r&3) + 8*(r>>2) + 4*h of the tile.  `g` selects which quarter (4 values) to form -- the caller spreads
+// the four quarters over the MFMA groups of the next tile.
+template <int QB>
+__device__ __forceinline__ void form_part(const ScanCtx<QB>& C, const f32x16 (&accp)[QB], const float* ynp, int g,
+                                          float (&dv)[QB][16], float (&cmin)[QB]) {
     const f32x4 y4 = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        float c;
-        if (C.angular) c = -accp[r];
-        else c = __builtin_fmaf(-2.0f, accp[r], __fadd_rn(C.xn, y4[e]));  // 2*acc is exact: same rounding as s - 2*acc
-        dv[r] = c;
-        cmin = fminf(cmin, c);
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float c;
+            if (C.angular) c = -accp[qb][r];
+            else c = __builtin_fmaf(-2.0f, accp[qb][r], __fadd_rn(C.xn[qb], y4[e]));  // 2*acc exact: same rounding as s - 2*acc
+            dv[qb][r] = c;
+            cmin[qb] = fminf(cmin[qb], c);
+        }
     }
 }
 
-template <int KQ, int ITEMS, bool HAVE_PREV>
-__device__ __forceinline__ void tile_step(const ScanCtx& C, const float* __restrict__ img, const float (&b)[4 * KQ],
-                                          f32x16& acc, const f32x16& accp, const float* ynp_prev, int Tprev,
-                                          float& tau_d) {
+template <int QB>
+__device__ __forceinline__ bool any_survivor(const float (&cmin)[QB], const float (&tau_d)[QB]) {
+    bool hit = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) hit |= (cmin[qb] <= tau_d[qb]);
+    return __any(hit);
+}
+
+template <int KQ, int ITEMS, int QB, bool HAVE_PREV>
+__device__ __forceinline__ void tile_step(const ScanCtx<QB>& C, const float* __restrict__ img, const float (&b)[QB][4 * KQ],
+                                          f32x16 (&acc)[QB], const f32x16 (&accp)[QB], const float* ynp_prev, int Tprev,
+                                          float (&tau_d)[QB]) {
     constexpr int GQ = (KQ >= 4) ? 4 : KQ, NG = KQ / GQ;
     constexpr int PARTS_PER_GROUP = (4 + NG - 1) / NG;  // spread the 4 quarters of the previous tile over the groups
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float dv[16];
-    float cmin = __builtin_inff();
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[qb][r] = 0.f;
+    float dv[QB][16];
+    float cmin[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) cmin[qb] = __builtin_inff();
     const float* ap = img + C.lane * 4;
     f32x4 a0[GQ], a1[GQ];
 #pragma unroll
@@ -318,16 +342,17 @@ __device__ __forceinline__ void tile_step(const ScanCtx& C, const float* __restr
         if (HAVE_PREV) {
 #pragma unroll
             for (int pp = 0; pp < PARTS_PER_GROUP; ++pp)
-                if (part + pp < 4) form_part(C, accp, ynp_prev, part + pp, dv, cmin);
+                if (part + pp < 4) form_part<QB>(C, accp, ynp_prev, part + pp, dv, cmin);
         }
         part += PARTS_PER_GROUP;
 #pragma unroll
         for (int u = 0; u < GQ; ++u) {
             const int t = g * GQ + u;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][0], b[4 * t + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][1], b[4 * t + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][2], b[4 * t + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][3], b[4 * t + 3], acc, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u][e], b[qb][4 * t + e], acc[qb], 0, 0, 0);
         }
         if (g + 1 < NG) {
             if (g + 2 < NG) {
@@ -338,51 +363,56 @@ __device__ __forceinline__ void tile_step(const ScanCtx& C, const float* __restr
             if (HAVE_PREV) {
 #pragma unroll
                 for (int pp = 0; pp < PARTS_PER_GROUP; ++pp)
-                    if (part + pp < 4) form_part(C, accp, ynp_prev, part + pp, dv, cmin);
+                    if (part + pp < 4) form_part<QB>(C, accp, ynp_prev, part + pp, dv, cmin);
             }
             part += PARTS_PER_GROUP;
 #pragma unroll
             for (int u = 0; u < GQ; ++u) {
                 const int t = (g + 1) * GQ + u;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][0], b[4 * t + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][1], b[4 * t + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][2], b[4 * t + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][3], b[4 * t + 3], acc, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u][e], b[qb][4 * t + e], acc[qb], 0, 0, 0);
             }
         }
     }
     if (HAVE_PREV) {
 #ifdef TDR_ABLATE_NOINSERT
-        asm volatile("" ::"v"(cmin));
-        cmin = __builtin_inff();
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) { asm volatile("" ::"v"(cmin[qb])); cmin[qb] = __builtin_inff(); }
 #endif
-        if (__any(cmin <= tau_d)) scan_insert<ITEMS>(C, dv, Tprev, tau_d);
+        if (any_survivor<QB>(cmin, tau_d)) scan_insert<ITEMS, QB>(C, dv, Tprev, tau_d);
     }
 }
 
 // finish the last tile (no next tile to hide it behind)
-template <int ITEMS>
-__device__ __forceinline__ void tile_drain(const ScanCtx& C, const f32x16& accp, const float* ynp_prev, int Tprev,
-                                           float& tau_d) {
-    float dv[16];
-    float cmin = __builtin_inff();
+template <int ITEMS, int QB>
+__device__ __forceinline__ void tile_drain(const ScanCtx<QB>& C, const f32x16 (&accp)[QB], const float* ynp_prev, int Tprev,
+                                           float (&tau_d)[QB]) {
+    float dv[QB][16];
+    float cmin[QB];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) form_part(C, accp, ynp_prev, g, dv, cmin);
+    for (int qb = 0; qb < QB; ++qb) cmin[qb] = __builtin_inff();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) form_part<QB>(C, accp, ynp_prev, g, dv, cmin);
 #ifdef TDR_ABLATE_NOINSERT
-    cmin = __builtin_inff();
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) cmin[qb] = __builtin_inff();
 #endif
-    if (__any(cmin <= tau_d)) scan_insert<ITEMS>(C, dv, Tprev, tau_d);
+    if (any_survivor<QB>(cmin, tau_d)) scan_insert<ITEMS, QB>(C, dv, Tprev, tau_d);
 }
 
-template <int KQ, int ITEMS, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 6) ? 3 : 2) void knn_scan_kernel(const KnnParams P) {
+template <int KQ, int ITEMS, int QB>
+__global__ __launch_bounds__(256, (QB == 2) ? 1 : 2) void knn_scan_kernel(const KnnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NW = 4;
     constexpr int TILE_F = KQ * 256 + 64;
     constexpr int IMG_F = KQ * 256;  // the LDS copy holds the blocks only; norms go to the ring below
     float* tile0 = reinterpret_cast<float*>(smem_raw);
     float* tile1 = tile0 + IMG_F;
     float* nring = tile1 + IMG_F;                                          // [4 slots][64 floats]
-    uint64_t* keys_all = reinterpret_cast<uint64_t*>(nring + 4 * 64);      // [NW waves][32 queries][k] ascending
+    uint64_t* keys_all = reinterpret_cast<uint64_t*>(nring + 4 * 64);      // [NW waves][QB][32 queries][k] ascending
     const int k = P.k;
 
     const int tid = threadIdx.x;
@@ -390,40 +420,44 @@ __global__ __launch_bounds__(NW * 64, (NW == 6) ? 3 : 2) void knn_scan_kernel(co
     const int wave = tid >> 6;
     const int q = lane & 31;
     const int h = lane >> 5;
-    uint64_t* keys = keys_all + (size_t)wave * k * 32;
+    uint64_t* keys = keys_all + (size_t)wave * QB * k * 32;
 
     const int64_t n_qtiles = (P.nq + 31) / 32;
-    const int64_t qt = (int64_t)blockIdx.x * NW + wave;
-    const bool wave_active = qt < n_qtiles;
-    const int64_t gq = qt * 32 + q;  // local query id owned by this lane
+    const int64_t qt0 = ((int64_t)blockIdx.x * NW + wave) * QB;
+    const bool wave_active = qt0 < n_qtiles;
 
-    // --- query block -> registers (B operand), once per workgroup lifetime
-    float b[4 * KQ];
-    float xn = 0.f;
-    if (wave_active) {
-        const float* qimg = P.qp + (size_t)qt * TILE_F;
+    // --- query blocks -> registers (B operands), once per workgroup lifetime
+    float b[QB][4 * KQ];
+    ScanCtx<QB> C;
+    float tau_d[QB];
 #pragma unroll
-        for (int t = 0; t < KQ; ++t) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(qimg + t * 256 + lane * 4);
-            b[4 * t + 0] = v[0]; b[4 * t + 1] = v[1]; b[4 * t + 2] = v[2]; b[4 * t + 3] = v[3];
+    for (int qb = 0; qb < QB; ++qb) {
+        const int64_t qt = qt0 + qb;
+        const bool blk_active = qt < n_qtiles;
+        if (blk_active) {
+            const float* qimg = P.qp + (size_t)qt * TILE_F;
+#pragma unroll
+            for (int t = 0; t < KQ; ++t) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(qimg + t * 256 + lane * 4);
+                b[qb][4 * t + 0] = v[0]; b[qb][4 * t + 1] = v[1]; b[qb][4 * t + 2] = v[2]; b[qb][4 * t + 3] = v[3];
+            }
+            C.xn[qb] = qimg[KQ * 256 + q];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4 * KQ; ++t) b[qb][t] = 0.f;
+            C.xn[qb] = 0.f;
         }
-        xn = qimg[KQ * 256 + q];
-    } else {
-#pragma unroll
-        for (int t = 0; t < 4 * KQ; ++t) b[t] = 0.f;
+        const bool lane_valid = blk_active && (qt * 32 + q < P.nq);
+        tau_d[qb] = lane_valid ? __builtin_inff() : -__builtin_inff();
     }
-
-    for (int p = lane; p < k * 32; p += 64) keys[p] = KEY_SENTINEL;
-    const bool lane_valid = wave_active && (gq < P.nq);
-    float tau_d = lane_valid ? __builtin_inff() : -__builtin_inff();
+    for (int p = lane; p < QB * k * 32; p += 64) keys[p] = KEY_SENTINEL;
 
     const int split = blockIdx.y;
     const int t_begin = split * P.tiles_per_split;
     int t_end = t_begin + P.tiles_per_split;
     if (t_end > P.n_db_tiles) t_end = P.n_db_tiles;
 
-    ScanCtx C;
-    C.P = &P; C.keys = keys; C.k = k; C.lane = lane; C.q = q; C.h = h; C.qt = qt; C.xn = xn;
+    C.P = &P; C.keys = keys; C.k = k; C.lane = lane; C.q = q; C.h = h; C.qt0 = qt0;
     C.angular = (P.metric == 2);
 
     // stage(T): tile image -> tile[(T - t_begin) & 1], norms -> nring[(T - t_begin) & 3]
@@ -443,16 +477,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 6) ? 3 : 2) void knn_scan_kernel(co
     if (t_begin < t_end) stage(t_begin);
     __syncthreads();
 
-    f32x16 accA, accB;
+    f32x16 accA[QB], accB[QB];
     int T = t_begin;
-#define TDR_IMG(Tx, buf) (buf)
 #define TDR_YN(Tx) (nring + (((Tx) - t_begin) & 3) * 64 + 4 * h)
     // first tile: nothing to finish yet
     if (T < t_end) {
 #ifndef TDR_ABLATE_NOSTAGE
         if (T + 1 < t_end) stage(T + 1);
 #endif
-        if (wave_active) tile_step<KQ, ITEMS, false>(C, TDR_IMG(T, tile0), b, accA, accA, nring, T, tau_d);
+        if (wave_active) tile_step<KQ, ITEMS, QB, false>(C, tile0, b, accA, accA, nring, T, tau_d);
 #ifndef TDR_ABLATE_NOBARRIER
         __syncthreads();
 #endif
@@ -464,8 +497,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 6) ? 3 : 2) void knn_scan_kernel(co
 #ifndef TDR_ABLATE_NOSTAGE
             if (T + 1 < t_end) stage(T + 1);
 #endif
-            if (wave_active)
-                tile_step<KQ, ITEMS, true>(C, TDR_IMG(T, tile1), b, accB, accA, TDR_YN(T - 1), T - 1, tau_d);
+            if (wave_active) tile_step<KQ, ITEMS, QB, true>(C, tile1, b, accB, accA, TDR_YN(T - 1), T - 1, tau_d);
 #ifndef TDR_ABLATE_NOBARRIER
             __syncthreads();
 #endif
@@ -475,23 +507,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 6) ? 3 : 2) void knn_scan_kernel(co
 #ifndef TDR_ABLATE_NOSTAGE
             if (T + 1 < t_end) stage(T + 1);
 #endif
-            if (wave_active)
-                tile_step<KQ, ITEMS, true>(C, TDR_IMG(T, tile0), b, accA, accB, TDR_YN(T - 1), T - 1, tau_d);
+            if (wave_active) tile_step<KQ, ITEMS, QB, true>(C, tile0, b, accA, accB, TDR_YN(T - 1), T - 1, tau_d);
 #ifndef TDR_ABLATE_NOBARRIER
             __syncthreads();
 #endif
             ++T;
         } else {
-            accA = accB;  // the last computed tile is always drained from accA below
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) accA[qb] = accB[qb];  // the last computed tile is always drained from accA
         }
     }
-    if (wave_active && t_begin < t_end)
-        tile_drain<ITEMS>(C, accA, TDR_YN(t_end - 1), t_end - 1, tau_d);
+    if (wave_active && t_begin < t_end) tile_drain<ITEMS, QB>(C, accA, TDR_YN(t_end - 1), t_end - 1, tau_d);
+#undef TDR_YN
 
     // --- emit: every list is already ascending by (distance, index)
     if (wave_active) {
-        for (int jq = 0; jq < 32; ++jq) {
-            const int64_t qi = qt * 32 + jq;
+        for (int jq = 0; jq < 32 * QB; ++jq) {
+            const int64_t qi = qt0 * 32 + jq;
             if (qi >= P.nq) break;
             for (int p = lane; p < k; p += 64) {
                 const uint64_t mine = keys[(size_t)jq * k + p];
@@ -601,36 +633,45 @@ static inline int pick_kq(int d) {
 
 using namespace tdr;
 
-static size_t knn_lds_bytes(int kq, int k, int nw = 4) {
-    return (size_t)2 * (kq * 256) * sizeof(float) + (size_t)4 * 64 * sizeof(float) + (size_t)nw * k * 32 * sizeof(uint64_t);
+// Workgroup shape: 4 wavefronts x QB query blocks of 32 (QB = 1: 128 queries, 2 workgroups per CU;
+// QB = 2: 256 queries, 1 workgroup per CU, two MFMA chains per wavefront).  TDR_KNN_QB overrides.
+static size_t knn_lds_bytes(int kq, int k, int qb) {
+    return (size_t)2 * (kq * 256) * sizeof(float) + (size_t)4 * 64 * sizeof(float) +
+           (size_t)4 * qb * k * 32 * sizeof(uint64_t);
 }
 
-// waves per workgroup: 4 (128 queries, default) | 6 | 8 -- tuning knob TDR_KNN_NW
-static int knn_nw() {
-    static int nw = 0;
-    if (nw == 0) { const char* e = getenv("TDR_KNN_NW"); nw = e ? atoi(e) : 4; if (nw != 6 && nw != 8) nw = 4; }
-    return nw;
+static int knn_qb_pref() {
+    static int qb = 0;
+    if (qb == 0) { const char* e = getenv("TDR_KNN_QB"); qb = e ? atoi(e) : 1; if (qb != 2) qb = 1; }
+    return qb;
 }
 
-template <int KQ, int ITEMS, int NW>
+static int knn_qb(int kq, int k) {
+    int qb = knn_qb_pref();
+    if (qb == 2 && (kq > 16 || knn_lds_bytes(kq, k, 2) > 160 * 1024)) qb = 1;
+    return qb;
+}
+
+template <int KQ, int ITEMS, int QB>
 static int launch_scan_w(const KnnParams& P, int n_wgs, size_t lds, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scan_kernel<KQ, ITEMS, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_scan_kernel<KQ, ITEMS, QB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((knn_scan_kernel<KQ, ITEMS, NW>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(NW * 64), lds, st, P);
+    hipLaunchKernelGGL((knn_scan_kernel<KQ, ITEMS, QB>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(256), lds, st, P);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
 template <int KQ, int ITEMS>
-static int launch_scan_i(const KnnParams& P, int n_wgs, size_t lds, int nw, hipStream_t st) {
-    if (nw == 6) return launch_scan_w<KQ, ITEMS, 6>(P, n_wgs, lds, st);
-    if (nw == 8) return launch_scan_w<KQ, ITEMS, 8>(P, n_wgs, lds, st);
-    return launch_scan_w<KQ, ITEMS, 4>(P, n_wgs, lds, st);
+static int launch_scan_i(const KnnParams& P, int n_wgs, size_t lds, int qb, hipStream_t st) {
+    if constexpr (KQ <= 16) {
+        if (qb == 2) return launch_scan_w<KQ, ITEMS, 2>(P, n_wgs, lds, st);
+    }
+    return launch_scan_w<KQ, ITEMS, 1>(P, n_wgs, lds, st);
 }
 template <int KQ>
-static int launch_scan(const KnnParams& P, int n_wgs, size_t lds, int nw, hipStream_t st) {
-    if (P.k <= 64) return launch_scan_i<KQ, 1>(P, n_wgs, lds, nw, st);
-    return launch_scan_i<KQ, 2>(P, n_wgs, lds, nw, st);
+static int launch_scan(const KnnParams& P, int n_wgs, size_t lds, int qb, hipStream_t st) {
+    if (P.k <= 64) return launch_scan_i<KQ, 1>(P, n_wgs, lds, qb, st);
+    return launch_scan_i<KQ, 2>(P, n_wgs, lds, qb, st);
 }
 
 extern "C" {
@@ -689,9 +730,9 @@ struct KnnPlan {
     int tail_splits;
 };
 
-static KnnPlan make_plan(int64_t nq, int n_db_tiles, int nw = 4) {
-    const int slots = device_slots() * (nw == 8 ? 1 : 2) / 2;
-    const int64_t wgs = (nq + 32 * nw - 1) / (32 * nw);
+static KnnPlan make_plan(int64_t nq, int n_db_tiles, int qb) {
+    const int slots = device_slots() / qb;  // QB = 2 workgroups are alone on their CU
+    const int64_t wgs = (nq + 128 * qb - 1) / (128 * qb);
     KnnPlan pl;
     if (wgs < 2 * (int64_t)slots) {  // small problem: one split launch
         pl.main_wgs = 0; pl.tail_wgs = wgs; pl.tail_splits = choose_splits(wgs, n_db_tiles, 2 * slots);
@@ -710,22 +751,15 @@ static KnnPlan make_plan(int64_t nq, int n_db_tiles, int nw = 4) {
 
 int64_t tdr_knn_workspace_bytes(int64_t nq, int64_t n_db, int k) {
     const int n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
-    // upper bound over the workgroup shapes the launcher may pick
-    int64_t best = 0;
-    for (int nw : {4, 6, 8}) {
-        const KnnPlan pl = make_plan(nq, n_db_tiles, nw);
+    int64_t best = 0;  // upper bound over the workgroup shapes the launcher may pick
+    for (int qb = 1; qb <= 2; ++qb) {
+        const KnnPlan pl = make_plan(nq, n_db_tiles, qb);
         if (pl.tail_wgs == 0 || pl.tail_splits <= 1) continue;
-        const int64_t tail_q = nq - pl.main_wgs * 32 * nw;
+        const int64_t tail_q = nq - pl.main_wgs * 128 * qb;
         const int64_t b = (int64_t)pl.tail_splits * tail_q * k * (int64_t)sizeof(uint64_t);
         if (b > best) best = b;
     }
     return best;
-}
-static int64_t unused_ws_bytes_(int64_t nq, int n_db_tiles, int k, int nw) {
-    const KnnPlan pl = make_plan(nq, n_db_tiles, nw);
-    if (pl.tail_wgs == 0 || pl.tail_splits <= 1) return 0;
-    const int64_t tail_q = nq - pl.main_wgs * 32 * nw;
-    return (int64_t)pl.tail_splits * tail_q * k * (int64_t)sizeof(uint64_t);
 }
 
 // Largest k the scan kernel supports for dimension d (LDS budget 160 KiB per workgroup).
@@ -733,7 +767,7 @@ int tdr_knn_max_k(int d) {
     const int kq = pick_kq(d);
     if (kq == 0) return 0;
     int k = 0;
-    while (knn_lds_bytes(kq, k + 1) <= 160 * 1024) ++k;
+    while (knn_lds_bytes(kq, k + 1, 1) <= 160 * 1024) ++k;
     return k;
 }
 
@@ -755,12 +789,11 @@ int tdr_knn_packed_f32(const float* qp, int64_t nq, int64_t q_offset, const floa
     if (n_db > 0x7fffffffLL) return TDR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
-    int nw = knn_nw();
-    if (knn_lds_bytes(kq, k, nw) > 160 * 1024 || kq > 16) nw = 4;
-    const KnnPlan pl = make_plan(nq, n_db_tiles, nw);
-    const size_t lds = knn_lds_bytes(kq, k, nw);
+    const int qb = knn_qb(kq, k);
+    const KnnPlan pl = make_plan(nq, n_db_tiles, qb);
+    const size_t lds = knn_lds_bytes(kq, k, qb);
     const int64_t tile_f = tile_stride_floats(kq);
-    const int qpw = 32 * nw;  // queries per workgroup
+    const int qpw = 128 * qb;  // queries per workgroup
     // part 0 = main (un-split) launch, part 1 = tail launch (database sliced)
     for (int part = 0; part < 2; ++part) {
         const int64_t wgs = part == 0 ? pl.main_wgs : pl.tail_wgs;
@@ -779,10 +812,10 @@ int tdr_knn_packed_f32(const float* qp, int64_t nq, int64_t q_offset, const floa
         }
         int rc;
         switch (kq) {
-            case 4: rc = launch_scan<4>(P, (int)wgs, lds, nw, st); break;
-            case 8: rc = launch_scan<8>(P, (int)wgs, lds, nw, st); break;
-            case 16: rc = launch_scan<16>(P, (int)wgs, lds, nw, st); break;
-            default: rc = launch_scan<32>(P, (int)wgs, lds, nw, st); break;
+            case 4: rc = launch_scan<4>(P, (int)wgs, lds, qb, st); break;
+            case 8: rc = launch_scan<8>(P, (int)wgs, lds, qb, st); break;
+            case 16: rc = launch_scan<16>(P, (int)wgs, lds, qb, st); break;
+            default: rc = launch_scan<32>(P, (int)wgs, lds, qb, st); break;
         }
         if (rc != TDR_OK) return rc;
         if (P.n_splits > 1) {
