@@ -102,3 +102,19 @@ def test_discard_nns_and_nan_guard():
     bad[17, 1] = np.nan
     with pytest.raises(ValueError, match="NaNs in the embeddings at iter 0"):
         torchdr_amd.TSNE(perplexity=8, max_iter=60, init=bad, random_state=0).fit_transform(X.cuda())
+
+
+def test_indexed_distances_block_forms():
+    """1-D / None index forms of pairwise_distances_indexed (reference base.py:335-376)."""
+    import oracle
+    from torchdr_amd.distance import pairwise_distances_indexed
+
+    X = torch.randn(200, 24, generator=torch.Generator().manual_seed(1))
+    qi = torch.tensor([3, 50, 199, 0])
+    ki = torch.arange(10, 90)
+    D = pairwise_distances_indexed(X.cuda(), query_indices=qi.cuda(), key_indices=ki.cuda())
+    _, _, full = oracle.knn(X[qi], 0, "sqeuclidean", False, Y=X[ki], want_full=True)
+    assert D.shape == (4, 80) and torch.equal(D.cpu(), full)
+    D2 = pairwise_distances_indexed(X.cuda(), key_indices=ki.cuda(), metric="euclidean")
+    assert D2.shape == (200, 80)
+    assert torch.allclose(D2.cpu(), torch.cdist(X, X[ki]), atol=1e-4)

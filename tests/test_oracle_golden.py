@@ -194,3 +194,24 @@ def test_tsnekhorn_oracle():
         grad = R.tsnekhorn_grad(Z, g["sea_logP"], dual, log_K)
         ref = g[f"tk_grad_{t}"]
         assert torch.allclose(grad, ref, rtol=1e-3, atol=1e-5 * float(ref.abs().max()))
+
+
+def test_numeric_helpers_cpu():
+    """API-parity helpers (utils/utils.py, utils/root_search.py): the reference's own unit checks
+    (test_utils.py:45-82: roots of x^2 - 1)."""
+    from torchdr_amd.utils import binary_search, cross_entropy_loss, entropy, kmax, kmin, logsumexp_red, sum_red
+
+    r = binary_search(lambda x: x**2 - 1, 5, begin=0.5, end=2.0)
+    assert torch.allclose(r, torch.ones(5), atol=1e-5)
+    r = binary_search(lambda x: x**2 - 1, 3)  # default [1, 1] bracket expands by itself
+    assert torch.allclose(r, torch.ones(3), atol=1e-5)
+    A = torch.tensor([[3.0, 1.0, 2.0], [0.5, 4.0, -1.0]])
+    v, i = kmin(A, 2, dim=1)
+    assert torch.equal(v, torch.tensor([[1.0, 2.0], [-1.0, 0.5]])) and i.dtype == torch.int32
+    v, i = kmax(A, 1, dim=1)
+    assert torch.equal(v, torch.tensor([[3.0], [4.0]]))
+    assert kmin(A, 5, dim=1)[1] is None
+    P = torch.softmax(torch.randn(4, 6), 1)
+    assert torch.allclose(entropy(P.log(), log=True), entropy(P, log=False), atol=1e-6)
+    assert sum_red(P, 1).shape == (4, 1) and logsumexp_red(P.log(), 1).shape == (4, 1)
+    assert torch.allclose(cross_entropy_loss(P, P.log(), log=True), cross_entropy_loss(P, P))

@@ -233,11 +233,13 @@ def pairwise_distances_indexed(
         raise NotImplementedError(f"Metric '{metric}' not implemented for indexed distances")
     if query_indices is not None and query_indices.dim() != 1:
         raise NotImplementedError("2D query indices not yet supported")
-    if key_indices is None or key_indices.dim() != 2:
-        raise NotImplementedError(
-            "[torchdr_amd] pairwise_distances_indexed supports the per-query key form "
-            "(2-D key_indices) used by the embedding loop."
-        )
+    if key_indices is not None and key_indices.dim() not in (1, 2):
+        raise ValueError(f"key_indices must be 1D or 2D, got {key_indices.dim()}D")
+    if key_indices is None or key_indices.dim() == 1:
+        # queries x keys block (reference base.py:357-376, torch.cdist): gather the rows, dense MFMA kernel
+        Xq = X if query_indices is None else X[query_indices.to(X.device).long()]
+        Yk = Y if key_indices is None else Y[key_indices.to(Y.device).long()]
+        return dense_packed(PackedPoints(Xq.float().contiguous()), PackedPoints(Yk.float().contiguous()), metric, False)
     L = _lib.lib()
     Xc = X.contiguous().float()
     Yc = Y.contiguous().float()

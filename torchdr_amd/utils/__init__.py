@@ -15,3 +15,6 @@ from .validation import (  # noqa: F401
 )
 from .wrappers import handle_input_output, restore_original_format, to_torch  # noqa: F401
 from .sparse import CSRAffinity, symmetrize_sparse, symmetrize_to_csr  # noqa: F401
+from .numeric import (  # noqa: F401
+    binary_search, cross_entropy_loss, entropy, init_bounds, kmax, kmin, logsumexp_red, sum_red,
+)
