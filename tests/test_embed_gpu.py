@@ -207,3 +207,67 @@ def test_tsne_exaggeration_switch_and_schedules():
     base = 1200 / 4
     expect = [base * (1 / 3 + (2 / 3) * min(t, 5) / 5) for t in range(8)]
     assert np.allclose(lrs, expect, rtol=1e-6)
+
+
+def test_umap_estimator_trajectory_vs_reference():
+    """Whole-estimator parity: OUR UMAP (kNN -> sigma search -> CSR symmetrisation -> epoch counters -> 3
+    optimisation steps with the fused SGD / LR table) started from the reference's initial embedding and fed
+    the reference's own negative samples must reproduce the reference's embedding after 3 steps."""
+    import torchdr_amd
+
+    g = load("umap_step")
+    X = g["X"].cuda()
+
+    class Replay(torchdr_amd.UMAP):
+        def _init_embedding(self, X_):
+            self.embedding_ = g["Z_0"].to(self.device_).contiguous()
+            return self.embedding_
+
+        def on_training_step_start(self):
+            super().on_training_step_start()
+            t = int(self.n_iter_)
+            self.neg_indices_ = g[f"neg_{t}"] if t < 3 else None
+
+        def on_training_step_end(self):
+            super().on_training_step_end()
+            t = int(self.n_iter_)
+            if t < 3:
+                ref = g[f"Zafter_{t}"]
+                got = self.embedding_.detach().cpu()
+                assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max())), f"step {t}"
+
+    m = Replay(n_neighbors=10, max_iter=int(g["max_iter"]), random_state=0)
+    m.fit_transform(X)
+    assert int(m.n_iter_) == int(g["max_iter"]) - 1
+
+
+@pytest.mark.parametrize("name", ["largevis", "tsne"])
+def test_largevis_tsne_estimator_trajectory_vs_reference(name):
+    import torchdr_amd
+
+    g = load("ne_step")
+    X = g["X"].cuda()
+    cls, kw = (torchdr_amd.LargeVis, dict(perplexity=5)) if name == "largevis" else (torchdr_amd.TSNE, dict(perplexity=8))
+    seen = {}
+
+    class Replay(cls):
+        def _init_embedding(self, X_):
+            self.embedding_ = g[f"{name}_Z_0"].to(self.device_).contiguous()
+            return self.embedding_
+
+        def on_training_step_start(self):
+            super().on_training_step_start()
+            t = int(self.n_iter_)
+            if name == "largevis":
+                self.neg_indices_ = g[f"{name}_neg_{t}"] if t < 2 else None
+
+        def on_training_step_end(self):
+            super().on_training_step_end()
+            t = int(self.n_iter_)
+            if t < 2:
+                seen[t] = self.embedding_.detach().cpu().clone()
+
+    Replay(max_iter=4, random_state=1, **kw).fit_transform(X)
+    for t in range(2):
+        ref = g[f"{name}_Zafter_{t}"]
+        assert torch.allclose(seen[t], ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max())), f"{name} step {t}"
