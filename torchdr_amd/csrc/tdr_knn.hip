@@ -259,25 +259,31 @@ struct ScanCtx {
 // scalar unit: value and row index are wave-uniform (readlane), only the list update itself is vector work.
 // tau_d is refreshed after every insertion, so later slots filter with the new threshold.
 template <int ITEMS, int QB>
-__device__ __forceinline__ void scan_insert(const ScanCtx<QB>& C, const float (&dv)[QB][16], int Tprev, float (&tau_d)[QB]) {
+__device__ __forceinline__ void scan_insert(const ScanCtx<QB>& C, const float (&dv)[QB][16], const float (&pmin)[QB][4],
+                                            int Tprev, float (&tau_d)[QB]) {
     const KnnParams& P = *C.P;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            unsigned long long m = __ballot(dv[qb][r] <= tau_d[qb]);
-            while (m) {
-                const int src = __builtin_ctzll(m);
-                m &= m - 1;
-                const int sq = src & 31;
-                const int64_t j = (int64_t)Tprev * 32 + 4 * (src >> 5) + (r & 3) + 8 * (r >> 2);
-                if (j >= P.n_db || (P.exclude_self && j == (C.qt0 + qb) * 32 + sq + P.q_offset)) continue;
-                const float dval =
-                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv[qb][r]), src));
-                uint64_t new_tail;
-                if (coop_insert<ITEMS>(C.keys + ((size_t)qb * 32 + sq) * C.k, C.k, mkkey(dval, (uint32_t)j), C.lane,
-                                       new_tail)) {
-                    if (C.q == sq) tau_d[qb] = u2f((uint32_t)(new_tail >> 32));
+        for (int g = 0; g < 4; ++g) {
+            if (!__any(pmin[qb][g] <= tau_d[qb])) continue;  // quarter without survivors: one scalar test
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                unsigned long long m = __ballot(dv[qb][r] <= tau_d[qb]);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int sq = src & 31;
+                    const int64_t j = (int64_t)Tprev * 32 + 4 * (src >> 5) + e + 8 * g;
+                    if (j >= P.n_db || (P.exclude_self && j == (C.qt0 + qb) * 32 + sq + P.q_offset)) continue;
+                    const float dval =
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv[qb][r]), src));
+                    uint64_t new_tail;
+                    if (coop_insert<ITEMS>(C.keys + ((size_t)qb * 32 + sq) * C.k, C.k, mkkey(dval, (uint32_t)j), C.lane,
+                                           new_tail)) {
+                        if (C.q == sq) tau_d[qb] = u2f((uint32_t)(new_tail >> 32));
+                    }
                 }
             }
         }
@@ -289,10 +295,11 @@ __device__ __forceinline__ void scan_insert(const ScanCtx<QB>& C, const float (&
 // the four quarters over the MFMA groups of the next tile.
 template <int QB>
 __device__ __forceinline__ void form_part(const ScanCtx<QB>& C, const f32x16 (&accp)[QB], const float* ynp, int g,
-                                          float (&dv)[QB][16], float (&cmin)[QB]) {
+                                          float (&dv)[QB][16], float (&pmin)[QB][4]) {
     const f32x4 y4 = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
+        float m = __builtin_inff();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
@@ -300,16 +307,18 @@ __device__ __forceinline__ void form_part(const ScanCtx<QB>& C, const f32x16 (&a
             if (C.angular) c = -accp[qb][r];
             else c = __builtin_fmaf(-2.0f, accp[qb][r], __fadd_rn(C.xn[qb], y4[e]));  // 2*acc exact: same rounding as s - 2*acc
             dv[qb][r] = c;
-            cmin[qb] = fminf(cmin[qb], c);
+            m = fminf(m, c);
         }
+        pmin[qb][g] = m;  // minimum of this quarter: the rare path only scans quarters that hold a survivor
     }
 }
 
 template <int QB>
-__device__ __forceinline__ bool any_survivor(const float (&cmin)[QB], const float (&tau_d)[QB]) {
+__device__ __forceinline__ bool any_survivor(const float (&pmin)[QB][4], const float (&tau_d)[QB]) {
     bool hit = false;
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) hit |= (cmin[qb] <= tau_d[qb]);
+    for (int qb = 0; qb < QB; ++qb)
+        hit |= (fminf(fminf(pmin[qb][0], pmin[qb][1]), fminf(pmin[qb][2], pmin[qb][3])) <= tau_d[qb]);
     return __any(hit);
 }
 
@@ -324,9 +333,7 @@ __device__ __forceinline__ void tile_step(const ScanCtx<QB>& C, const float* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[qb][r] = 0.f;
     float dv[QB][16];
-    float cmin[QB];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) cmin[qb] = __builtin_inff();
+    float pmin[QB][4];
     const float* ap = img + C.lane * 4;
     f32x4 a0[GQ], a1[GQ];
 #pragma unroll
@@ -342,7 +349,7 @@ __device__ __forceinline__ void tile_step(const ScanCtx<QB>& C, const float* __r
         if (HAVE_PREV) {
 #pragma unroll
             for (int pp = 0; pp < PARTS_PER_GROUP; ++pp)
-                if (part + pp < 4) form_part<QB>(C, accp, ynp_prev, part + pp, dv, cmin);
+                if (part + pp < 4) form_part<QB>(C, accp, ynp_prev, part + pp, dv, pmin);
         }
         part += PARTS_PER_GROUP;
 #pragma unroll
@@ -363,7 +370,7 @@ __device__ __forceinline__ void tile_step(const ScanCtx<QB>& C, const float* __r
             if (HAVE_PREV) {
 #pragma unroll
                 for (int pp = 0; pp < PARTS_PER_GROUP; ++pp)
-                    if (part + pp < 4) form_part<QB>(C, accp, ynp_prev, part + pp, dv, cmin);
+                    if (part + pp < 4) form_part<QB>(C, accp, ynp_prev, part + pp, dv, pmin);
             }
             part += PARTS_PER_GROUP;
 #pragma unroll
@@ -380,9 +387,11 @@ __device__ __forceinline__ void tile_step(const ScanCtx<QB>& C, const float* __r
     if (HAVE_PREV) {
 #ifdef TDR_ABLATE_NOINSERT
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) { asm volatile("" ::"v"(cmin[qb])); cmin[qb] = __builtin_inff(); }
+        for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { asm volatile("" ::"v"(pmin[qb][g])); pmin[qb][g] = __builtin_inff(); }
 #endif
-        if (any_survivor<QB>(cmin, tau_d)) scan_insert<ITEMS, QB>(C, dv, Tprev, tau_d);
+        if (any_survivor<QB>(pmin, tau_d)) scan_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_d);
     }
 }
 
@@ -391,16 +400,16 @@ template <int ITEMS, int QB>
 __device__ __forceinline__ void tile_drain(const ScanCtx<QB>& C, const f32x16 (&accp)[QB], const float* ynp_prev, int Tprev,
                                            float (&tau_d)[QB]) {
     float dv[QB][16];
-    float cmin[QB];
+    float pmin[QB][4];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) cmin[qb] = __builtin_inff();
-#pragma unroll
-    for (int g = 0; g < 4; ++g) form_part<QB>(C, accp, ynp_prev, g, dv, cmin);
+    for (int g = 0; g < 4; ++g) form_part<QB>(C, accp, ynp_prev, g, dv, pmin);
 #ifdef TDR_ABLATE_NOINSERT
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) cmin[qb] = __builtin_inff();
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pmin[qb][g] = __builtin_inff();
 #endif
-    if (any_survivor<QB>(cmin, tau_d)) scan_insert<ITEMS, QB>(C, dv, Tprev, tau_d);
+    if (any_survivor<QB>(pmin, tau_d)) scan_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_d);
 }
 
 template <int KQ, int ITEMS, int QB>
