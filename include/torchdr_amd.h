@@ -93,11 +93,17 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
                       const int32_t* cols, const float* eps_per, float* next, float a, float b, int n_iter,
                       int neg_rate, int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep,
                       float eps, float* grad, void* stream);
-/* gradients of neighbor_embedding/largevis.py:181-201 (kind 0) and tsne.py:162-170 (kind 1, attraction) */
+/* gradients of neighbor_embedding/largevis.py:181-201 (kind 0), tsne.py:162-170 (kind 1, attraction only),
+ * sne.py:160-168 (kind 2, attraction only) and infotsne.py:178-197 (kind 3: Student-t attraction + the row
+ * log-sum-exp over the sampled negatives, rep_coef = 2 * repulsion_strength / N) */
 int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nn,
                     const float* P, int k, const int64_t* t_rowptr, const int32_t* t_src, const float* t_val, int kind,
                     float exag, float rep_coef, int n_neg, const int64_t* neg_inj, uint64_t seed, int n_iter,
                     float* grad, void* stream);
+/* gradient of neighbor_embedding/sne.py:170-179 (dense row log-sum-exp of -d), two passes */
+int tdr_sne_rowsum_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* R, void* stream);
+int tdr_sne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const float* R,
+                          float coef, float* grad, void* stream);
 /* gradient pieces of neighbor_embedding/tsne.py:172-180 (dense Student-t partition function) */
 int tdr_tsne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* F, double* S,
                            void* stream);

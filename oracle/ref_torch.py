@@ -263,13 +263,13 @@ def sample_negatives(n_total, rows, n_neg, generator=None):
 
 
 def ne_attraction_grad(Z, NN, P, kind, rows=None):
-    """d/dZ of  -sum_ij P_ij log Q_ij ;  largevis: Q = 1/(2+d), tsne: log Q = -log(1+d).
-    Both endpoints of every edge receive gradient."""
+    """d/dZ of  -sum_ij P_ij log Q_ij ;  largevis: Q = 1/(2+d), tsne / infotsne: log Q = -log(1+d),
+    sne: log Q = -d (sne.py:160-168).  Both endpoints of every edge receive gradient."""
     rows = torch.arange(NN.shape[0]) if rows is None else rows
     NN = NN.long()
     diff = Z[rows][:, None, :] - Z[NN]
     D = (diff**2).sum(-1)
-    w = 2 * P / ((2 + D) if kind == "largevis" else (1 + D))
+    w = 2 * P if kind == "sne" else 2 * P / ((2 + D) if kind == "largevis" else (1 + D))
     g = torch.zeros_like(Z)
     contrib = w[:, :, None] * diff
     g.index_add_(0, rows, contrib.sum(1))
@@ -299,6 +299,31 @@ def tsne_repulsion_grad(Z):
     W2 = W * W
     g = -(4.0 / S) * (W2.sum(1, keepdim=True) * Z.double() - W2 @ Z.double())
     return g.to(Z.dtype), S.to(Z.dtype)
+
+
+def sne_repulsion_grad(Z):
+    """d/dZ of (1/N) sum_i logsumexp_j(-d_ij) (dense, diagonal included; sne.py:170-179):
+    g_i = -(2/N) sum_j e_ij (1/R_i + 1/R_j) (z_i - z_j), e = exp(-d), R_i = sum_j e_ij."""
+    Zd = Z.double()
+    E = torch.exp(-(torch.cdist(Zd, Zd) ** 2))
+    invR = 1.0 / E.sum(1)
+    W = E * (invR[:, None] + invR[None, :])
+    g = -(2.0 / Z.shape[0]) * (W.sum(1, keepdim=True) * Zd - W @ Zd)
+    return g.to(Z.dtype)
+
+
+def infotsne_repulsion_grad(Z, neg, n_total, rows=None):
+    """d/dZ of (1/N) sum_i log sum_{n in Neg(i)} q_in, q = 1/(1+d) (infotsne.py:188-197):
+    edge weight w_in = -(2/N) q_in^2 / sum_n q_in on (z_i - z_n); both endpoints move."""
+    rows = torch.arange(neg.shape[0]) if rows is None else rows
+    diff = Z[rows][:, None, :] - Z[neg]
+    Q = 1.0 / (1.0 + (diff**2).sum(-1))
+    w = -(2.0 / n_total) * Q * Q / Q.sum(1, keepdim=True)
+    g = torch.zeros_like(Z)
+    contrib = w[:, :, None] * diff
+    g.index_add_(0, rows, contrib.sum(1))
+    g.index_add_(0, neg.reshape(-1), -contrib.reshape(-1, Z.shape[1]))
+    return g
 
 
 def sgd_momentum_step(Z, grad, buf, lr, momentum):

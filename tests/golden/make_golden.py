@@ -202,6 +202,44 @@ def ne_step_fixture():
     save("ne_step", **out)
 
 
+def ne2_step_fixture():
+    """SNE / InfoTSNE (the SURVEY section 8f "next" estimators): autograd gradient + momentum step."""
+    from torchdr import SNE, InfoTSNE
+
+    X = gmm(400, 16, 2.0, seed=53)
+    out = {"X": X}
+    for name, cls, kw in (("sne", SNE, dict(perplexity=6)), ("infotsne", InfoTSNE, dict(perplexity=7, n_negatives=40))):
+        rec = {}
+
+        class Probe(cls):
+            def _training_step(self):
+                t = int(self.n_iter_)
+                if t < 2:
+                    rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                    if hasattr(self, "neg_indices_"):
+                        rec[f"neg_{t}"] = self.neg_indices_.clone()
+                    rec[f"lr_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["lr"]))
+                    rec[f"mom_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["momentum"]))
+                    rec[f"exag_{t}"] = torch.tensor(float(self.early_exaggeration_coeff_))
+                    if t == 0:
+                        rec["P"] = self.affinity_in_.clone()
+                        rec["NN"] = self.NN_indices_.clone()
+                loss = super()._training_step()
+                if t < 2:
+                    rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                    rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+                    rec[f"loss_{t}"] = loss.detach().clone()
+                return loss
+
+        torch.manual_seed(2)
+        # init scaling 1.0 so that the Gaussian / Student kernels are away from their flat d ~ 0 regime
+        m = Probe(max_iter=4, backend=None, init="normal", init_scaling=1.0, random_state=2, **kw)
+        m.fit_transform(X)
+        for k_, v in rec.items():
+            out[f"{name}_{k_}"] = v
+    save("ne2_step", **out)
+
+
 def distributed_fixture():
     out = {}
     for n in (97, 100, 103):
@@ -215,20 +253,6 @@ def distributed_fixture():
             out[f"bounds_{n}_{w}"] = np.array(bounds)
             out[f"owner_{n}_{w}"] = DistributedContext.get_rank_for_indices(torch.arange(n), n, w)
     save("distributed", **out)
-
-
-if __name__ == "__main__":
-    torch.set_num_threads(8)
-    knn_fixtures()
-    indexed_fixture()
-    affinity_fixtures()
-    symmetrize_fixture()
-    umap_step_fixture()
-    ne_step_fixture()
-    distributed_fixture()
-    tsnekhorn_fixture()
-    dense_affinity_fixture()
-    print("reference version:", torchdr.__version__)
 
 
 def tsnekhorn_fixture():
@@ -285,3 +309,13 @@ def dense_affinity_fixture():
     out["umap_P"] = au(X, return_indices=False)
     out["umap_eps"], out["umap_rho"] = au.eps_, au.rho_
     save("affinity_dense", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    ALL = dict(knn=knn_fixtures, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
+               umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne2_step=ne2_step_fixture,
+               distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture)
+    for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
+        ALL[name]()
+    print("reference version:", torchdr.__version__)

@@ -41,7 +41,9 @@ def _worker(rank, world, port, ret):
         # --- estimators: every rank ends with the same finite embedding
         for cls, kw in ((torchdr_amd.UMAP, dict(n_neighbors=12, max_iter=40)),
                         (torchdr_amd.LargeVis, dict(perplexity=6, max_iter=25)),
-                        (torchdr_amd.TSNE, dict(perplexity=6, max_iter=25))):
+                        (torchdr_amd.TSNE, dict(perplexity=6, max_iter=25)),
+                        (torchdr_amd.SNE, dict(perplexity=6, max_iter=25)),
+                        (torchdr_amd.InfoTSNE, dict(perplexity=6, max_iter=25, n_negatives=30))):
             m = cls(random_state=0, **kw)
             assert m.world_size == world
             Z = m.fit_transform(X)
@@ -50,6 +52,9 @@ def _worker(rank, world, port, ret):
             gathered = [torch.empty_like(h) for _ in range(world)]
             dist.all_gather(gathered, h)
             assert torch.equal(gathered[0], gathered[1]), f"{cls.__name__}: ranks diverged"
+            if cls is torchdr_amd.SNE:  # no sampling: the sharded run must reproduce the single-process one
+                Z1 = cls(random_state=0, distributed=False, **kw).fit_transform(X)
+                assert torch.allclose(Z, Z1, rtol=1e-3, atol=1e-4 * float(Z1.abs().max()))
         ret[rank] = True
     finally:
         dist.destroy_process_group()

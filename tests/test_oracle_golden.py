@@ -142,6 +142,27 @@ def test_ne_step_oracle(name):
         assert torch.allclose(Znew, g[f"{name}_Zafter_{t}"], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("name", ["sne", "infotsne"])
+def test_ne2_step_oracle(name):
+    """SNE / InfoTSNE closed-form gradients vs the reference's autograd (fixture ne2_step)."""
+    g = load("ne2_step")
+    n = g["X"].shape[0]
+    P, NN = g[f"{name}_P"], g[f"{name}_NN"]
+    buf = None
+    for t in range(2):
+        Z = g[f"{name}_Z_{t}"]
+        exag = float(g[f"{name}_exag_{t}"])
+        grad = exag * R.ne_attraction_grad(Z, NN, P, name)
+        if name == "sne":
+            grad = grad + R.sne_repulsion_grad(Z)
+        else:
+            grad = grad + R.infotsne_repulsion_grad(Z, g[f"{name}_neg_{t}"], n)
+        ref = g[f"{name}_grad_{t}"]
+        assert torch.allclose(grad, ref, rtol=1e-4, atol=2e-6 * float(ref.abs().max()))
+        Znew, buf = R.sgd_momentum_step(Z, ref, buf, float(g[f"{name}_lr_{t}"]), float(g[f"{name}_mom_{t}"]))
+        assert torch.allclose(Znew, g[f"{name}_Zafter_{t}"], rtol=1e-5, atol=1e-7)
+
+
 def test_indexed_oracle():
     g = load("indexed")
     Z, q, keys = g["Z"], g["q"], g["keys"]

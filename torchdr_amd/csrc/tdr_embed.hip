@@ -233,7 +233,7 @@ struct NeStepParams {
     const int32_t* nn;       // (n_rows, k)
     const float* P;          // (n_rows, k) affinities (not log)
     int k;
-    int kind;                // 0 largevis, 1 tsne
+    int kind;                // 0 largevis, 1 tsne (attraction), 2 sne (attraction), 3 infotsne
     float exag;              // multiplies the attractive term
     float rep_coef;          // largevis: repulsion_strength * 2 / N
     int n_neg;               // negatives per row (0 = none)
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) g[c] = 0.f;
     const float off = (S.kind == 0) ? 2.0f : 1.0f;
+    const bool gauss = S.kind == 2;  // SNE: log Q = -d, the edge weight has no denominator
     const bool pull = S.t_rowptr != nullptr;
     // out-edges i -> j : +w (z_i - z_j) on i, and -w (z_i - z_j) on j (pushed with atomics unless j's own row
     // pulls it from the transposed graph)
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
         float d = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d += df[c] * df[c]; }
-        const float w = S.exag * 2.0f * pij / (off + d);
+        const float w = S.exag * 2.0f * pij * (gauss ? 1.0f : 1.0f / (off + d));
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float t = w * df[c];
@@ -287,12 +288,29 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
             float d = 0.f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zs.v[c]; d += df[c] * df[c]; }
-            const float w = S.exag * 2.0f * S.t_val[e] / (off + d);
+            const float w = S.exag * 2.0f * S.t_val[e] * (gauss ? 1.0f : 1.0f / (off + d));
 #pragma unroll
             for (int c = 0; c < NC; ++c) g[c] += w * df[c];
         }
     }
     const uint32_t rkey = neg_row_key(S.seed, S.iter, gi);
+    // InfoTSNE (kind 3): the repulsion is the row's log-sum over its negatives of q = 1/(1+d); its
+    // derivative weights each negative by q^2 / sum_n q -> one extra pass for the row normaliser
+    float inv_rowsum = 0.f;
+    if (S.kind == 3) {
+        float s = 0.f;
+        for (int col = gl; col < S.n_neg; col += G) {
+            int64_t j;
+            if (S.neg_inj) j = S.neg_inj[(size_t)r * S.n_neg + col];
+            else j = sample_negative(rkey, gi, col, S.n_total);
+            const Vec<NC> zj = load_z<NC>(S.Z, j);
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const float t = zi.v[c] - zj.v[c]; d += t * t; }
+            s += 1.0f / (1.0f + d);
+        }
+        inv_rowsum = 1.0f / group_sum<G>(s);
+    }
     for (int col = gl; col < S.n_neg; col += G) {
         int64_t j;
         if (S.neg_inj) j = S.neg_inj[(size_t)r * S.n_neg + col];
@@ -302,7 +320,13 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
         float d = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d += df[c] * df[c]; }
-        const float w = -S.rep_coef / ((1.0f + d) * (2.0f + d));
+        float w;
+        if (S.kind == 3) {
+            const float q = 1.0f / (1.0f + d);
+            w = -S.rep_coef * q * q * inv_rowsum;
+        } else {
+            w = -S.rep_coef / ((1.0f + d) * (2.0f + d));
+        }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float t = w * df[c];
@@ -365,6 +389,74 @@ __global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ gra
     if (i >= n) return;
     const float sc = coef / (float)(*S);
     grad[i] += sc * F[i];
+}
+
+// ---- SNE dense repulsion (sne.py:170-179): (1/N) sum_i log sum_j exp(-d_ij), diagonal included -------
+// pass 1: R_i = sum_j exp(-d_ij) for the rows of this chunk
+template <int NC>
+__global__ __launch_bounds__(256) void sne_rowsum_kernel(const float* __restrict__ Z, int64_t n_total, int64_t row0,
+                                                         int64_t n_rows, float* __restrict__ R) {
+    __shared__ float tile[256 * NC];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = r < n_rows;
+    Vec<NC> zi;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) zi.v[c] = have ? Z[(size_t)(row0 + r) * NC + c] : 0.f;
+    float s = 0.f;
+    for (int64_t j0 = 0; j0 < n_total; j0 += 256) {
+        __syncthreads();
+        const int64_t j = j0 + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) tile[threadIdx.x * NC + c] = (j < n_total) ? Z[(size_t)j * NC + c] : 0.f;
+        __syncthreads();
+        const int lim = (int)((n_total - j0 < 256) ? (n_total - j0) : 256);
+        for (int t = 0; t < lim; ++t) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const float u = zi.v[c] - tile[t * NC + c]; d += u * u; }
+            s += __expf(-d);
+        }
+    }
+    if (have) R[r] = s;
+}
+
+// pass 2: grad_i += coef * sum_j exp(-d_ij) (1/R_i + 1/R_j) (z_i - z_j)   (R: all n_total rows)
+template <int NC>
+__global__ __launch_bounds__(256) void sne_repulsion_kernel(const float* __restrict__ Z, int64_t n_total, int64_t row0,
+                                                            int64_t n_rows, const float* __restrict__ R, float coef,
+                                                            float* __restrict__ grad) {
+    __shared__ float tile[256 * (NC + 1)];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = r < n_rows;
+    Vec<NC> zi;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) zi.v[c] = have ? Z[(size_t)(row0 + r) * NC + c] : 0.f;
+    const float inv_ri = have ? 1.0f / R[row0 + r] : 0.f;
+    float f[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) f[c] = 0.f;
+    for (int64_t j0 = 0; j0 < n_total; j0 += 256) {
+        __syncthreads();
+        const int64_t j = j0 + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) tile[threadIdx.x * (NC + 1) + c] = (j < n_total) ? Z[(size_t)j * NC + c] : 0.f;
+        tile[threadIdx.x * (NC + 1) + NC] = (j < n_total) ? 1.0f / R[j] : 0.f;
+        __syncthreads();
+        const int lim = (int)((n_total - j0 < 256) ? (n_total - j0) : 256);
+        for (int t = 0; t < lim; ++t) {
+            float df[NC];
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - tile[t * (NC + 1) + c]; d += df[c] * df[c]; }
+            const float w = __expf(-d) * (inv_ri + tile[t * (NC + 1) + NC]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) f[c] += w * df[c];
+        }
+    }
+    if (have) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) grad[(size_t)(row0 + r) * NC + c] += coef * f[c];
+    }
 }
 
 // ---- SGD(momentum) step, torch.optim.SGD semantics (no dampening / nesterov / weight decay) ----------
@@ -451,7 +543,7 @@ int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64
                     float* grad, void* stream) {
     if (!Z || !nn || !P_ || !grad || n_rows <= 0 || k <= 0 || n_total < 2) return TDR_ERR_BAD_ARG;
     if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
-    if (kind != 0 && kind != 1) return TDR_ERR_BAD_ARG;
+    if (kind < 0 || kind > 3) return TDR_ERR_BAD_ARG;
     NeStepParams S;
     S.Z = Z; S.n_total = n_total; S.row0 = row0; S.n_rows = n_rows; S.nn = nn; S.P = P_; S.k = k; S.kind = kind;
     S.exag = exag; S.rep_coef = rep_coef; S.n_neg = n_neg; S.neg_inj = neg_inj; S.seed = seed;
@@ -472,6 +564,32 @@ int tdr_tsne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0
     const unsigned grid = (unsigned)((n_rows + 255) / 256);
     if (nc == 2) hipLaunchKernelGGL(tsne_repulsion_kernel<2>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S);
     else if (nc == 3) hipLaunchKernelGGL(tsne_repulsion_kernel<3>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S);
+    else return TDR_ERR_UNSUPPORTED;
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* SNE dense repulsion, pass 1: R[r] = sum_j exp(-|z_{row0+r} - z_j|^2) for r < n_rows (sne.py:170-179). */
+int tdr_sne_rowsum_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* R, void* stream) {
+    if (!Z || !R || n_rows <= 0) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n_rows + 255) / 256);
+    if (nc == 2) hipLaunchKernelGGL(sne_rowsum_kernel<2>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R);
+    else if (nc == 3) hipLaunchKernelGGL(sne_rowsum_kernel<3>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R);
+    else return TDR_ERR_UNSUPPORTED;
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* SNE dense repulsion, pass 2: grad (n_total, nc) rows [row0, row0+n_rows) += coef * sum_j exp(-d_ij)
+ * (1/R_i + 1/R_j) (z_i - z_j); R holds the row sums of ALL n_total rows. */
+int tdr_sne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const float* R,
+                          float coef, float* grad, void* stream) {
+    if (!Z || !R || !grad || n_rows <= 0) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n_rows + 255) / 256);
+    if (nc == 2) hipLaunchKernelGGL(sne_repulsion_kernel<2>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad);
+    else if (nc == 3) hipLaunchKernelGGL(sne_repulsion_kernel<3>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad);
     else return TDR_ERR_UNSUPPORTED;
     TDR_CHECK_LAUNCH();
     return TDR_OK;

@@ -3,3 +3,5 @@ from .umap import UMAP, find_ab_params  # noqa: F401
 from .largevis import LargeVis  # noqa: F401
 from .tsne import TSNE  # noqa: F401
 from .tsnekhorn import TSNEkhorn  # noqa: F401
+from .sne import SNE  # noqa: F401
+from .infotsne import InfoTSNE  # noqa: F401

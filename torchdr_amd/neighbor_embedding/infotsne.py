@@ -1,0 +1,74 @@
+"""InfoTSNE on MI355X -- mirror of ``torchdr/neighbor_embedding/infotsne.py`` (reference :106-197)."""
+
+from typing import Dict, Optional, Type, Union
+
+import torch
+
+from torchdr_amd import _lib
+from torchdr_amd.affinity import EntropicAffinity
+from torchdr_amd.neighbor_embedding.base import NegativeSamplingNeighborEmbedding, build_transposed_graph
+
+
+class InfoTSNE(NegativeSamplingNeighborEmbedding):
+    r"""InfoTSNE (InfoNCE with a Student-t kernel): attraction :math:`\sum_{ij} P_{ij}\log(1 + d_{ij})` on
+    the kNN graph, repulsion :math:`\tfrac1N\sum_i\log\sum_{n\in\mathrm{Neg}(i)}(1 + d_{in})^{-1}` over
+    ``n_negatives`` uniformly sampled negatives per row (reference ``infotsne.py:178-197``).  One launch
+    of ``tdr_ne_grad_f32`` (kind 3) evaluates the closed-form gradient: a first sweep over the row's
+    negatives forms the normaliser :math:`\sum_n q_{in}`, a second applies the weights
+    :math:`-\tfrac2N q_{in}^2/\sum_n q_{in}` to both endpoints.  Defaults as the reference: early
+    exaggeration 12 for 250 iterations, 300 negatives, ``lr="auto"``, SGD momentum 0.5 -> 0.8,
+    ``LinearLR`` with torch's default arguments."""
+
+    def __init__(self, perplexity: float = 30, n_components: int = 2, lr: Union[float, str] = "auto",
+                 optimizer: Union[str, Type[torch.optim.Optimizer]] = "SGD",
+                 optimizer_kwargs: Union[Dict, str] = "auto",
+                 scheduler: Optional[Union[str, Type[torch.optim.lr_scheduler.LRScheduler]]] = "LinearLR",
+                 scheduler_kwargs: Optional[Dict] = None, init: str = "pca", init_scaling: float = 1e-4,
+                 min_grad_norm: float = 1e-7, max_iter: int = 1000, device: str = "auto", backend="faiss",
+                 verbose: bool = False, random_state: Optional[float] = None,
+                 early_exaggeration_coeff: Optional[float] = 12, early_exaggeration_iter: Optional[int] = 250,
+                 max_iter_affinity: int = 100, metric: str = "sqeuclidean", n_negatives: int = 300,
+                 sparsity: bool = True, check_interval: int = 50, discard_NNs: bool = False, compile: bool = False,
+                 distributed: Union[bool, str] = "auto", **kwargs):
+        self.metric = metric
+        self.perplexity = perplexity
+        self.max_iter_affinity = max_iter_affinity
+        self.sparsity = sparsity
+        affinity_in = EntropicAffinity(perplexity=perplexity, metric=metric, max_iter=max_iter_affinity,
+                                       device=device, backend=backend, verbose=verbose, sparsity=sparsity,
+                                       distributed=distributed)
+        super().__init__(affinity_in=affinity_in, n_components=n_components, optimizer=optimizer,
+                         optimizer_kwargs=optimizer_kwargs, min_grad_norm=min_grad_norm, max_iter=max_iter, lr=lr,
+                         scheduler=scheduler, scheduler_kwargs=scheduler_kwargs, init=init,
+                         init_scaling=init_scaling, device=device, backend=backend, verbose=verbose,
+                         random_state=random_state, early_exaggeration_coeff=early_exaggeration_coeff,
+                         early_exaggeration_iter=early_exaggeration_iter, n_negatives=n_negatives,
+                         check_interval=check_interval, discard_NNs=discard_NNs, compile=compile,
+                         distributed=distributed, **kwargs)
+
+    def on_affinity_computation_end(self):
+        super().on_affinity_computation_end()
+        self._tgraph = build_transposed_graph(self.affinity_in_, self.NN_indices_, self.chunk_start_,
+                                              self.n_samples_in_, self.world_size)
+
+    def _compute_gradients(self):
+        n, nc = self.n_samples_in_, self.n_components
+        grad = torch.zeros((n, nc), dtype=torch.float32, device=self.device_)
+        P = self.affinity_in_
+        neg = self._neg_ptr_tensor()
+        _lib.check(
+            _lib.lib().tdr_ne_grad_f32(
+                _lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_, _lib.ptr(self.NN_indices_),
+                _lib.ptr(P), P.shape[1], _lib.ptr(self._tgraph[0]), _lib.ptr(self._tgraph[1]),
+                _lib.ptr(self._tgraph[2]), 3, float(self.early_exaggeration_coeff_),
+                float(self.repulsion_strength) * 2.0 / n, int(self.n_negatives), _lib.ptr(neg), self._neg_seed,
+                int(self.n_iter_), _lib.ptr(grad), _lib.stream_ptr(),
+            ),
+            "tdr_ne_grad_f32",
+        )
+        return grad, False
+
+    def clear_memory(self):
+        super().clear_memory()
+        if hasattr(self, "_tgraph"):
+            delattr(self, "_tgraph")
