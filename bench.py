@@ -156,7 +156,7 @@ def main():
     elapsed = float(t.item())
 
     # kernel-level numbers for the dominant kernel (HIP events recorded on the launch stream)
-    scan_ms = [e0.elapsed_time(e1) for (e0, e1, _) in knn_events]
+    scan_ms = [e[0].elapsed_time(e[1]) for e in knn_events]
     nq = knn_events[0][2] if knn_events else 0
     scan_avg_ms = sum(scan_ms) / max(len(scan_ms), 1)
     flops = 2.0 * nq * args.n * args.d

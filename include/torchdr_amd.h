@@ -60,6 +60,25 @@ int tdr_dense_dist_packed_f32(const float* qp, int64_t nq, int64_t q_offset, con
 int tdr_indexed_sqdist_f32(const float* X, int64_t nx, int d, const float* Y, int64_t ny, const int64_t* q,
                            int64_t nq, int nk, int take_sqrt, const int64_t* keys, float* out, void* stream);
 
+/* ---- K1s: two-stage exact kNN (fp16-split screening on the f16 matrix pipe + exact fp32 rescoring) ----
+ * Same results, bit for bit, as tdr_knn_packed_f32 (hence as distance/torch.py:82-120 + utils/utils.py:215):
+ * the screening pass only decides WHICH pairs get their reference-arithmetic distance evaluated, with a
+ * worst-case error band (torchdr_amd/csrc/tdr_knn_screen.hip header).  sqeuclidean / euclidean, D <= 128. */
+int tdr_knn_screen_supported(int d, int k);
+int64_t tdr_packed16_floats(int64_t n, int d);
+/* meta: 2 x uint32 on the device, zeroed by the caller; accumulates max |X| (and max norms[i] when norms != NULL)
+ * over every block that will share one fp16 scale (queries + database). */
+int tdr_screen_meta_f32(const float* X, int64_t n, int d, int64_t ldx, const float* norms, uint32_t* meta, void* stream);
+int tdr_pack16_f32(const float* X, int64_t n, int d, int64_t ldx, const float* norms, const uint32_t* meta,
+                   float* packed16, void* stream);
+int64_t tdr_knn_screen_workspace_bytes(int64_t nq, int64_t n_db, int d, int k);
+/* flags[i] = 1: the screening list of query i overflowed, its output rows are invalid and must be recomputed with
+ * tdr_knn_packed_f32; *n_flagged (device int32, caller-zeroed) counts such queries. */
+int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
+                       const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
+                       int metric, int exclude_self, const uint32_t* meta, float* out_d, int32_t* out_i, int32_t* flags,
+                       int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- K2 / K3: per-row root searches --------------------------------------------------------------
  * replace utils/root_search.py:17-77,147-198 driven by affinity/knn_normalized.py:445-465 (UMAP) and
  * affinity/entropic.py:272-310 (+ bounds :96-113). */

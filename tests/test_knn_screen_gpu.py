@@ -1,0 +1,94 @@
+"""Two-stage exact kNN (fp16-split screening + exact rescoring) vs the one-stage exact kernel: the two paths
+must agree BIT FOR BIT (values and indices), on every data regime -- including the ones where the screening
+band overflows and the flagged queries are recomputed by the one-stage kernel."""
+
+import pytest
+import torch
+
+from tests.conftest import gmm
+
+pytestmark = pytest.mark.gpu
+
+
+def both_paths(X, k, metric, exclude, Y=None):
+    from torchdr_amd.distance import base as dbase
+
+    old = dbase.SCREEN_MODE
+    try:
+        dbase.SCREEN_MODE = "0"
+        Xp = dbase.PackedPoints(X)
+        Yp = Xp if Y is None else dbase.PackedPoints(Y)
+        C0, I0 = dbase.knn_packed(Xp, Yp, k, metric, exclude)
+        assert dbase.LAST_KNN["path"] == "exact"
+        dbase.SCREEN_MODE = "force"
+        Xp = dbase.PackedPoints(X)
+        Yp = Xp if Y is None else dbase.PackedPoints(Y)
+        C1, I1 = dbase.knn_packed(Xp, Yp, k, metric, exclude)
+        assert dbase.LAST_KNN["path"] == "screen"
+        flagged = dbase.LAST_KNN["flagged"]
+    finally:
+        dbase.SCREEN_MODE = old
+    return (C0, I0), (C1, I1), flagged
+
+
+@pytest.mark.parametrize("scale", [0.0, 2.0, 10.0])
+@pytest.mark.parametrize("d,k", [(128, 30), (128, 15), (32, 30), (50, 10), (64, 45), (100, 90)])
+def test_screen_equals_exact(d, k, scale):
+    X = gmm(6000, d, scale, seed=11 + d + k).cuda()
+    (C0, I0), (C1, I1), flagged = both_paths(X, k, "sqeuclidean", True)
+    assert torch.equal(I0, I1), f"indices differ ({int((I0 != I1).sum())} entries, {flagged} flagged)"
+    assert torch.equal(C0, C1)
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean"])
+@pytest.mark.parametrize("exclude", [False, True])
+def test_screen_bit_exact_vs_oracle(metric, exclude):
+    """Directly against the CPU oracle (itself pinned bit-exactly by the reference's golden vectors)."""
+    import oracle
+    from torchdr_amd.distance import base as dbase
+
+    for scale in (0.0, 2.0, 10.0):
+        X = gmm(2048, 128, scale)
+        old = dbase.SCREEN_MODE
+        try:
+            dbase.SCREEN_MODE = "force"
+            Xp = dbase.PackedPoints(X.cuda())
+            C, I = dbase.knn_packed(Xp, Xp, 30, metric, exclude)
+            assert dbase.LAST_KNN["path"] == "screen"
+        finally:
+            dbase.SCREEN_MODE = old
+        Co, Io = oracle.knn(X, 30, metric, exclude)
+        assert torch.equal(I.cpu(), Io), f"scale {scale}: {(I.cpu() != Io).any(1).sum().item()} rows differ"
+        assert torch.equal(C.cpu(), Co)
+
+
+def test_screen_cross_and_ragged():
+    X = gmm(4097, 96, 2.0, seed=3).cuda()
+    Y = (gmm(7001, 96, 2.0, seed=4) * 3.0).cuda()  # different magnitude: the shared scale must cover both blocks
+    (C0, I0), (C1, I1), _ = both_paths(X, 20, "sqeuclidean", False, Y=Y)
+    assert torch.equal(I0, I1) and torch.equal(C0, C1)
+
+
+def test_screen_overflow_falls_back_to_exact():
+    """A large common offset makes ||x|| ||y|| huge relative to the neighbour distances: the worst-case band
+    swallows the spare list slots, queries are flagged and recomputed exactly."""
+    X = (gmm(5000, 64, 1.0, seed=8) + 300.0).cuda()
+    (C0, I0), (C1, I1), flagged = both_paths(X, 30, "sqeuclidean", True)
+    assert flagged > 0
+    assert torch.equal(I0, I1) and torch.equal(C0, C1)
+
+
+def test_screen_duplicates_and_tiny_values():
+    base = gmm(3000, 48, 2.0, seed=5)
+    X = torch.cat([base, base[:500], base[:100] * 1e-6]).cuda()  # exact duplicates (tied distances) + tiny rows
+    (C0, I0), (C1, I1), _ = both_paths(X, 25, "sqeuclidean", True)
+    assert torch.equal(I0, I1) and torch.equal(C0, C1)
+
+
+def test_screen_split_launch_small_query_count():
+    """Few queries against a large database: the database is sliced over gridDim.y and the rescoring stage
+    merges the per-slice candidate lists."""
+    Y = gmm(200_000, 128, 2.0, seed=6).cuda()
+    X = Y[:1000].contiguous()
+    (C0, I0), (C1, I1), _ = both_paths(X, 30, "sqeuclidean", False, Y=Y)
+    assert torch.equal(I0, I1) and torch.equal(C0, C1)

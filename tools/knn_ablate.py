@@ -10,6 +10,8 @@ def run(libpath, n, d=128, k=30):
     _lib._lib = None
     _lib.LIB_PATH = libpath
     from torchdr_amd.distance import PackedPoints, knn_packed
+    from torchdr_amd.distance import base as dbase
+    dbase.SCREEN_MODE = os.environ.get("TDR_KNN_SCREEN", "force")
     X = gmm(n, d, 2.0).cuda()
     P = PackedPoints(X)
     best = 1e9

@@ -1,0 +1,808 @@
+// K1s -- two-stage exact kNN for gfx950: fp16-split SCREENING on the 2.5 PFLOP/s matrix pipe, then
+// exact fp32 RESCORING of the few survivors.  Results are bit-identical to the one-stage exact kernel
+// (tdr_knn.hip) and therefore to the reference CPU backend (distance/torch.py:82-120 + utils/utils.py:215).
+//
+// Why it is exact.  Let d_j be the distance the reference computes in fp32 and a_j the screening value
+//     a_j = (||x||^2 + ||y_j||^2) - 2 * (h.h' + h.l' + l.h'),        x = h + l + eps,  h, l in fp16
+// (h = fp16(s x), l = fp16(s x - h), s a power of two chosen so that max |s x| lies in [2^13, 2^14): the split
+// keeps 22 significant bits and the scaling is exact).  For every pair |a_j - d_j| <= E_q with
+//     E_q = c_rel * ||x_q|| * max_j ||y_j|| + c_abs * (||x_q||^2 + max_j ||y_j||^2) + c_den
+// (screen_band below: fp16-split representation error 3 * 2^-22, fp32 accumulation of 3*D products in ANY
+// order, the reference's own fp32 rounding, all as worst-case bounds).  If a_(k) is the k-th smallest
+// screening value, the true k-th smallest distance is <= a_(k) + E_q, so every true neighbour has
+// a_j <= a_(k) + 2 E_q: the candidate set {j : a_j <= a_(k) + 2 E_q} contains the exact top-k.  The scan keeps
+// the L >= k smallest screening values per query (L - k spare slots); if the spare slots overflow (list full
+// and a_(L) <= a_(k) + 2 E_q) the query is flagged and the caller re-runs it through the one-stage exact
+// kernel.  Survivors are re-evaluated by knn_rescore_kernel with the reference's arithmetic (k-ordered fmaf
+// chain, same association of the norm sum) and ranked by the canonical (distance, index) key.
+//
+// Cost: 3 v_mfma_f32_32x32x16_f16 per 16 features (24 x 32 cycles per 32x32 tile at D = 128) instead of
+// 64 x 64 cycles of v_mfma_f32_32x32x2_f32 -- 5.3x fewer matrix-pipe cycles -- with the same 16 KiB tile image,
+// LDS-DMA staging and software-pipelined epilogue as the one-stage kernel.
+#include "tdr_common.h"
+#include <stdlib.h>
+
+namespace tdr {
+namespace scr {
+
+constexpr int TILE_ROWS = 32;
+constexpr uint64_t KEY_SENTINEL = 0xFF800000FFFFFFFFull;  // (+inf, 0xffffffff)
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ float sqrt_rn(float x) { return (float)sqrt((double)x); }
+
+// tile image of 32 rows: ks slices x {H block, L block} of 1 KiB + 32 norms + 32 floats of padding
+__host__ __device__ __forceinline__ int64_t tile16_stride_floats(int ks) { return (int64_t)ks * 512 + 64; }
+
+// meta[0] = bits of max |x| over every element that will be packed, meta[1] = bits of max ||y||^2 (database)
+// scale s = 2^(13 - floor(log2(amax))): max |s x| in [2^13, 2^14) (fp16 max 65504; l stays normal down to
+// |s x| = 2^-3, below that its absolute error is 2^-25, accounted for by c_den)
+__device__ __forceinline__ int scale_exp(uint32_t amax_bits) {
+    int ex = (int)((amax_bits >> 23) & 255u) - 127;
+    if ((amax_bits & 0x7fffffffu) == 0u) ex = 13;   // all-zero data: s = 1
+    if (ex < -100) ex = -100;                        // subnormal-range data: keep s finite
+    return 13 - ex;
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(e + 127) << 23); }
+
+// 2 * E_q (see the header): dpad = padded feature count, xn = ||x_q||^2, ymax2 = max ||y||^2, se = scale exponent
+__device__ __forceinline__ float screen_band(float xn, float ymax2, int dpad, int se) {
+    const float u = 5.9604645e-08f;  // 2^-24
+    const float c_rel = 2.0f * (3.0f * 2.3841858e-07f + (3.0f * dpad + 16.0f) * u + (dpad + 4.0f) * u) * 1.01f;
+    const float c_abs = 8.0f * u;
+    // absolute part of the fp16 rounding of tiny elements (|s x| < 2^-3): 2^-25 per element in scaled units
+    const float inv_s = pow2f(-se);
+    const float c_den = 2.0f * 2.9802322e-08f * sqrtf((float)dpad) * 1.01f * inv_s;
+    const float nx = sqrtf(xn) * 1.0001f, ny = sqrtf(ymax2) * 1.0001f;
+    const float e = c_rel * nx * ny + c_abs * (xn + ymax2) + c_den * (nx + ny);
+    return 2.0f * e * 1.01f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// meta reductions
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t n, uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// strided variant for row-padded inputs (ldx > d)
+__global__ __launch_bounds__(256) void absmax2d_kernel(const float* __restrict__ x, int64_t n, int d, int64_t ldx,
+                                                       uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    const int64_t total = n * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / d;
+        const int c = (int)(i - r * d);
+        m = max(m, __float_as_uint(x[r * ldx + c]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pack16_kernel: X (n x d fp32) -> fp16-split tile images.  Block (2*s + term) of tile b is 1 KiB:
+//   lane (g*32 + i), element e  <-  term(s_scale * X[32b + i][16 s + 8 g + e]),   term 0 = h, term 1 = l
+// i.e. exactly the A/B fragment of v_mfma_f32_32x32x16_f16 for K-slice s (both operands use the same
+// lane -> k map, so any consistent element order yields the dot product).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X, int64_t n, int d, int64_t ldx, int ks,
+                                                     const float* __restrict__ norms, const uint32_t* __restrict__ meta,
+                                                     float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int dimg = ks * 16;
+    const int ld = dimg + 4;
+    const int64_t row0 = (int64_t)blockIdx.x * TILE_ROWS;
+    const int tid = threadIdx.x;
+    const float s = pow2f(scale_exp(meta[0]));
+    for (int idx = tid; idx < TILE_ROWS * dimg; idx += 256) {
+        const int r = idx / dimg, c = idx - r * dimg;
+        float v = 0.f;
+        if (row0 + r < n && c < d) v = X[(size_t)(row0 + r) * ldx + c];
+        xs[r * ld + c] = v * s;  // exact (power of two; inputs are finite and far from the fp32 range ends)
+    }
+    __syncthreads();
+    char* img = reinterpret_cast<char*>(out + (size_t)blockIdx.x * tile16_stride_floats(ks));
+    for (int idx = tid; idx < ks * 64; idx += 256) {
+        const int sl = idx >> 6, l = idx & 63, g = l >> 5, i = l & 31;
+        const float* xr = xs + i * ld + 16 * sl + 8 * g;
+        f16x8 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = xr[e];
+            const _Float16 h = (_Float16)v;              // round to nearest even
+            const float r = __fsub_rn(v, (float)h);       // exact
+            hv[e] = h;
+            lv[e] = (_Float16)r;
+        }
+        *reinterpret_cast<f16x8*>(img + (size_t)(2 * sl) * 1024 + l * 16) = hv;
+        *reinterpret_cast<f16x8*>(img + (size_t)(2 * sl + 1) * 1024 + l * 16) = lv;
+    }
+    if (tid < 64) {
+        float* nb = reinterpret_cast<float*>(img + (size_t)ks * 2048);
+        float v = 0.f;
+        if (tid < 32) v = (row0 + tid < n) ? norms[row0 + tid] : __builtin_inff();
+        nb[tid] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Screening scan
+// ---------------------------------------------------------------------------------------------------------
+struct ScreenParams {
+    const float* qp;      // fp16-split query images
+    const float* yp;      // fp16-split database images
+    const uint32_t* meta;
+    int64_t nq, q_offset, n_db;
+    int k;                // neighbours wanted
+    int L;                // list length (k <= L)
+    int exclude_self;
+    int n_db_tiles, tiles_per_split, n_splits;
+    int dpad;
+    uint64_t* cand;       // (n_splits, nq, L) ascending screening keys
+};
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Cooperative sorted insertion into an ascending len-entry list (lane p owns entries p, p + 64).  Returns the
+// new k-th (position kpos) and last (position len - 1) keys when the candidate entered.
+template <int ITEMS>
+__device__ __forceinline__ bool coop_insert2(uint64_t* Lst, int len, int kpos, uint64_t cand, int lane, uint64_t& new_kth,
+                                             uint64_t& new_tail) {
+    uint64_t cur[ITEMS], prev[ITEMS], nv[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+        const int p = lane + 64 * t;
+        cur[t] = (p < len) ? Lst[p] : KEY_SENTINEL;
+        prev[t] = (p > 0 && p < len) ? Lst[p - 1] : 0ull;
+    }
+    const int tl = (len - 1) & 63, ti = (len - 1) >> 6;
+    const int kl = kpos & 63, ki = kpos >> 6;
+    uint64_t tk = 0;
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t)
+        if (t == ti) tk = readlane_u64(cur[t], tl);
+    if (cand >= tk) return false;  // wave-uniform
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+        const int p = lane + 64 * t;
+        nv[t] = (cur[t] < cand) ? cur[t] : ((p == 0 || prev[t] < cand) ? cand : prev[t]);
+        if (p < len && nv[t] != cur[t]) Lst[p] = nv[t];
+    }
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+        if (t == ti) new_tail = readlane_u64(nv[t], tl);
+        if (t == ki) new_kth = readlane_u64(nv[t], kl);
+    }
+    return true;
+}
+
+struct SCtx {
+    const ScreenParams* P;
+    uint64_t* keys;  // this wave's lists [32][L]
+    int lane, q, h;
+    int64_t qt;      // query tile of this wave
+    float xn, band, m2s;
+};
+
+// The hot filter works on the REDUCED value c' = ||y||^2 - 2 s^-2 acc (one fma per candidate) against the
+// lane's reduced threshold tau_r = (tau - ||x||^2) rounded up; only a survivor gets its full screening value
+// a = c' + ||x||^2, which is what the lists hold.
+__device__ __forceinline__ float reduce_tau(float tau, float xn) {
+    return (tau - xn) + 2.3841858e-07f * (fabsf(tau) + xn);  // + 4u (|tau| + xn): never rejects an a <= tau
+}
+
+template <int ITEMS>
+__device__ __forceinline__ void screen_insert(const SCtx& C, const float (&dv)[16], const float (&pmin)[4], int Tprev,
+                                              float& tau_r) {
+    const ScreenParams& P = *C.P;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if (!__any(pmin[g] <= tau_r)) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            unsigned long long m = __ballot(dv[r] <= tau_r);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                const int sq = src & 31;
+                const int64_t j = (int64_t)Tprev * 32 + 4 * (src >> 5) + e + 8 * g;
+                if (j >= P.n_db || (P.exclude_self && j == C.qt * 32 + sq + P.q_offset)) continue;
+                const float cred = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv[r]), src));
+                const float xq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, C.xn), sq));
+                uint64_t nk, nt;
+                if (coop_insert2<ITEMS>(C.keys + (size_t)sq * P.L, P.L, P.k - 1, mkkey(cred + xq, (uint32_t)j), C.lane, nk, nt)) {
+                    if (C.q == sq)
+                        tau_r = reduce_tau(fminf(u2f((uint32_t)(nk >> 32)) + C.band, u2f((uint32_t)(nt >> 32))), C.xn);
+                }
+            }
+        }
+    }
+}
+
+// reduced screening values of one quarter (4 rows) of a finished tile
+__device__ __forceinline__ void sform_part(const SCtx& C, const f32x16& acc, const f32x4 (&yn)[4], int g, float (&dv)[16],
+                                           float (&pmin)[4]) {
+#ifdef SABL_NOEPI
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv[4 * g + e] = __builtin_inff();
+    pmin[g] = __builtin_inff();
+    return;
+#endif
+    const f32x4 y4 = yn[g];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dv[4 * g + e] = __builtin_fmaf(C.m2s, acc[4 * g + e], y4[e]);
+    pmin[g] = fminf(fminf(dv[4 * g], dv[4 * g + 1]), fminf(dv[4 * g + 2], dv[4 * g + 3]));
+}
+
+#if defined(SABL_NOLDSA)
+#define TDR_LDA(ptr, S) bh[(S) & (KS - 1)]
+#else
+#define TDR_LDA(ptr, S) (*reinterpret_cast<const f16x8*>(ptr))
+#endif
+// h.h' + h.l' + l.h' of one K-slice into the single accumulator chain (the fp32 accumulation of all 3*D products,
+// in whatever order, is inside screen_band's worst-case bound)
+#if defined(SABL_NOMFMA)
+#define TDR_MMA3(AH, AL, S) do { acc[0] += (float)(AH)[0] + (float)(AL)[0]; } while (0)
+#else
+#define TDR_MMA3(AH, AL, S)                                                          \
+    do {                                                                             \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bh[S], acc, 0, 0, 0);       \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bl[S], acc, 0, 0, 0);       \
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, bh[S], acc, 0, 0, 0);       \
+    } while (0)
+#endif
+
+// One tile step: multiply tile T (A fragments from LDS) into acc and finish tile T-1 out of `prev` between the
+// MFMA groups.  Slices are processed in double-buffered groups of GS.
+template <int KS, int ITEMS, bool HAVE_PREV>
+__device__ __forceinline__ void stile_step(const SCtx& C, const char* __restrict__ img, const f16x8 (&bh)[KS],
+                                           const f16x8 (&bl)[KS], f32x16& acc, const f32x16& prev,
+                                           const float* ynp_prev, int Tprev, float& tau_r) {
+    constexpr int GS = (KS >= 2) ? 2 : 1, NG = KS / GS;
+    constexpr int PPG = (4 + NG - 1) / NG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float dv[16];
+    float pmin[4];
+    // norms of the previous tile's rows first: LDS returns in order, so everything issued after them (the A
+    // fragment prefetches) may stay in flight while the epilogue consumes them
+    f32x4 yn[4];
+    if (HAVE_PREV) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) yn[g] = *reinterpret_cast<const f32x4*>(ynp_prev + 8 * g);
+    }
+    const char* ap = img + C.lane * 16;
+    f16x8 ah0[GS], al0[GS], ah1[GS], al1[GS];
+#pragma unroll
+    for (int u = 0; u < GS; ++u) {
+        ah0[u] = TDR_LDA(ap + (2 * u) * 1024, u);
+        al0[u] = TDR_LDA(ap + (2 * u + 1) * 1024, u + 1);
+    }
+    int part = 0;
+#pragma unroll
+    for (int g = 0; g < NG; g += 2) {
+        if (g + 1 < NG) {
+#pragma unroll
+            for (int u = 0; u < GS; ++u) {
+                ah1[u] = TDR_LDA(ap + (2 * ((g + 1) * GS + u)) * 1024, g + u);
+                al1[u] = TDR_LDA(ap + (2 * ((g + 1) * GS + u) + 1) * 1024, g + u + 1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (HAVE_PREV) {
+#pragma unroll
+            for (int pp = 0; pp < PPG; ++pp)
+                if (part + pp < 4) sform_part(C, prev, yn, part + pp, dv, pmin);
+        }
+        part += PPG;
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+            const int s = g * GS + u;
+            TDR_MMA3(ah0[u], al0[u], s);
+        }
+        if (g + 1 < NG) {
+            if (g + 2 < NG) {
+#pragma unroll
+                for (int u = 0; u < GS; ++u) {
+                    ah0[u] = TDR_LDA(ap + (2 * ((g + 2) * GS + u)) * 1024, g + u + 2);
+                    al0[u] = TDR_LDA(ap + (2 * ((g + 2) * GS + u) + 1) * 1024, g + u + 3);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (HAVE_PREV) {
+#pragma unroll
+                for (int pp = 0; pp < PPG; ++pp)
+                    if (part + pp < 4) sform_part(C, prev, yn, part + pp, dv, pmin);
+            }
+            part += PPG;
+#pragma unroll
+            for (int u = 0; u < GS; ++u) {
+                const int s = (g + 1) * GS + u;
+                TDR_MMA3(ah1[u], al1[u], s);
+            }
+        }
+    }
+    if (HAVE_PREV) {
+#ifdef SABL_NOINSERT
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { asm volatile("" ::"v"(pmin[g])); pmin[g] = __builtin_inff(); }
+#endif
+        if (__any(fminf(fminf(pmin[0], pmin[1]), fminf(pmin[2], pmin[3])) <= tau_r))
+            screen_insert<ITEMS>(C, dv, pmin, Tprev, tau_r);
+    }
+}
+
+template <int ITEMS>
+__device__ __forceinline__ void stile_drain(const SCtx& C, const f32x16& prev, const float* ynp_prev, int Tprev,
+                                            float& tau_r) {
+    float dv[16];
+    float pmin[4];
+    f32x4 yn[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) yn[g] = *reinterpret_cast<const f32x4*>(ynp_prev + 8 * g);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) sform_part(C, prev, yn, g, dv, pmin);
+    if (__any(fminf(fminf(pmin[0], pmin[1]), fminf(pmin[2], pmin[3])) <= tau_r)) screen_insert<ITEMS>(C, dv, pmin, Tprev, tau_r);
+}
+
+// NW wavefronts per workgroup (4: 128 queries, two workgroups per CU when the lists fit 80 KiB; 8: 256 queries,
+// one workgroup per CU -- the staged tile, its LDS-DMA instructions and the barrier are shared by twice the queries)
+template <int KS, int ITEMS, int NW>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && ITEMS == 1) ? 2 : 1) void knn_screen_kernel(const ScreenParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int IMG_B = KS * 2048;                 // bytes of the fragment blocks of one tile
+    constexpr int TILE_F = KS * 512 + 64;            // floats per tile image in HBM
+    constexpr int NBLK = 2 * KS;                     // 1-KiB blocks per tile
+    char* tile0 = smem_raw;
+    char* tile1 = tile0 + IMG_B;
+    float* nring = reinterpret_cast<float*>(tile1 + IMG_B);              // [4 slots][64 floats]
+    uint64_t* keys_all = reinterpret_cast<uint64_t*>(nring + 4 * 64);    // [NW][32][L]
+    const int Ln = P.L;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 31, h = lane >> 5;
+    uint64_t* keys = keys_all + (size_t)wave * Ln * 32;
+
+    const int64_t n_qtiles = (P.nq + 31) / 32;
+    const int64_t qt = (int64_t)blockIdx.x * NW + wave;
+    const bool wave_active = qt < n_qtiles;
+
+    const int se = scale_exp(P.meta[0]);
+    SCtx C;
+    C.P = &P; C.keys = keys; C.lane = lane; C.q = q; C.h = h; C.qt = qt;
+    C.m2s = -2.0f * pow2f(-2 * se);
+
+    f16x8 bh[KS], bl[KS];
+    if (wave_active) {
+        const char* qimg = reinterpret_cast<const char*>(P.qp + (size_t)qt * TILE_F);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bh[s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s) * 1024 + lane * 16);
+            bl[s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s + 1) * 1024 + lane * 16);
+        }
+        C.xn = reinterpret_cast<const float*>(qimg + IMG_B)[q];
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bh[s][e] = (_Float16)0.f; bl[s][e] = (_Float16)0.f; }
+        C.xn = 0.f;
+    }
+    const bool lane_valid = wave_active && (qt * 32 + q < P.nq);
+    if (!lane_valid) C.xn = 0.f;  // rows beyond nq carry +inf norms in the image
+    C.band = screen_band(C.xn, __uint_as_float(P.meta[1]), P.dpad, se);
+    float tau_r = lane_valid ? __builtin_inff() : -__builtin_inff();
+    for (int p = lane; p < Ln * 32; p += 64) keys[p] = KEY_SENTINEL;
+
+    const int split = blockIdx.y;
+    const int t_begin = split * P.tiles_per_split;
+    int t_end = t_begin + P.tiles_per_split;
+    if (t_end > P.n_db_tiles) t_end = P.n_db_tiles;
+
+    auto stage = [&](int T) {
+        const int rel = T - t_begin;
+        const float* src = P.yp + (size_t)T * TILE_F;
+        char* dst = (rel & 1) ? tile1 : tile0;
+#pragma unroll
+        for (int t = 0; t < NBLK; t += NW) {
+            const int blk = t + wave;
+            if (blk < NBLK)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + blk * 256 + lane * 4), (lptr_t)(dst + blk * 1024), 16, 0, 0);
+        }
+        if (wave == NW - 1)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + NBLK * 256 + lane), (lptr_t)(nring + (rel & 3) * 64), 4, 0, 0);
+    };
+    if (t_begin < t_end) stage(t_begin);
+    __syncthreads();
+
+    f32x16 accA, accB;
+    int T = t_begin;
+#define TDR_YN(Tx) (nring + (((Tx) - t_begin) & 3) * 64 + 4 * h)
+#ifdef SABL_NOSTAGE
+#define TDR_STAGE(Tx)
+#else
+#define TDR_STAGE(Tx) if ((Tx) < t_end) stage(Tx)
+#endif
+#ifdef SABL_NOBARRIER
+#define TDR_SYNC()
+#else
+#define TDR_SYNC() __syncthreads()
+#endif
+    if (T < t_end) {
+        TDR_STAGE(T + 1);
+        if (wave_active) stile_step<KS, ITEMS, false>(C, tile0, bh, bl, accA, accA, nring, T, tau_r);
+        TDR_SYNC();
+        ++T;
+    }
+    while (T < t_end) {
+        {
+            TDR_STAGE(T + 1);
+            if (wave_active) stile_step<KS, ITEMS, true>(C, tile1, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
+            TDR_SYNC();
+            ++T;
+        }
+        if (T < t_end) {
+            TDR_STAGE(T + 1);
+            if (wave_active) stile_step<KS, ITEMS, true>(C, tile0, bh, bl, accA, accB, TDR_YN(T - 1), T - 1, tau_r);
+            TDR_SYNC();
+            ++T;
+        } else {
+            accA = accB;
+        }
+    }
+    if (wave_active && t_begin < t_end) stile_drain<ITEMS>(C, accA, TDR_YN(t_end - 1), t_end - 1, tau_r);
+#undef TDR_YN
+
+    if (wave_active) {
+        for (int jq = 0; jq < 32; ++jq) {
+            const int64_t qi = qt * 32 + jq;
+            if (qi >= P.nq) break;
+            for (int p = lane; p < Ln; p += 64)
+                P.cand[((size_t)split * P.nq + qi) * Ln + p] = keys[(size_t)jq * Ln + p];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Rescoring: one wavefront per query.  Candidates (all splits) -> global k-th screening value -> band ->
+// exact fp32 distance of every candidate inside the band (reference arithmetic) -> rank by (distance, index).
+// A query whose spare list slots overflowed in any split is flagged for the exact one-stage kernel.
+// ---------------------------------------------------------------------------------------------------------
+struct RescoreParams {
+    const uint64_t* cand;  // (n_splits, nq, L)
+    const float* Xq;       // (nq, d) row-major queries, row stride ldq
+    const float* Y;        // (n_db, d) row-major database, row stride ldy
+    const float* norms_q;  // (nq) reference-order squared norms
+    const float* norms_y;  // (n_db)
+    const uint32_t* meta;
+    int64_t nq, ldq, ldy;
+    int d, dpad, k, L, n_splits, metric;
+    float* out_d;
+    int32_t* out_i;
+    int32_t* flags;        // (nq) 1 = overflow
+    int32_t* n_flagged;    // device counter
+};
+
+__global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = P.n_splits * P.L;
+    const int dq = (P.d + 3) & ~3;
+    // per-wave LDS: approx keys [total], exact keys [total], query row [dq], scalar
+    const size_t per_wave = (size_t)2 * total * sizeof(uint64_t) + (size_t)dq * sizeof(float) + 16;
+    char* base = smem_raw + (size_t)wave * per_wave;
+    uint64_t* ak = reinterpret_cast<uint64_t*>(base);
+    uint64_t* ek = ak + total;
+    float* xq = reinterpret_cast<float*>(ek + total);
+    uint32_t* sc = reinterpret_cast<uint32_t*>(xq + dq);
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= P.nq) return;  // no block-level barrier below: wavefronts are independent
+
+    for (int p = lane; p < total; p += 64) {
+        const int s = p / P.L, r = p - s * P.L;
+        ak[p] = P.cand[((size_t)s * P.nq + qi) * P.L + r];
+    }
+    for (int c = lane; c < dq; c += 64) xq[c] = (c < P.d) ? P.Xq[(size_t)qi * P.ldq + c] : 0.f;
+    if (lane == 0) sc[0] = 0xFF800000u;
+    const float nx = P.norms_q[qi];
+    const int se = scale_exp(P.meta[0]);
+    const float band = screen_band(nx, __uint_as_float(P.meta[1]), P.dpad, se);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    // overflow test per split: list full and its last entry inside that split's band
+    bool ovf = false;
+    for (int s = lane; s < P.n_splits; s += 64) {
+        const uint64_t kl = ak[s * P.L + P.L - 1], kk = ak[s * P.L + P.k - 1];
+        if (kl != KEY_SENTINEL && P.L > P.k) ovf |= u2f((uint32_t)(kl >> 32)) <= u2f((uint32_t)(kk >> 32)) + band;
+        if (P.L == P.k) ovf = true;
+    }
+    const bool any_ovf = __any(ovf);
+
+    // global k-th smallest screening key (rank by counting; keys are distinct except sentinels)
+    for (int p0 = 0; p0 < total; p0 += 64) {
+        const int p = p0 + lane;
+        const uint64_t mine = (p < total) ? ak[p] : KEY_SENTINEL;
+        int rank = 0;
+        for (int pp = 0; pp < total; ++pp) rank += (ak[pp] < mine) ? 1 : 0;
+        if (p < total && mine != KEY_SENTINEL && rank == P.k - 1) sc[0] = (uint32_t)(mine >> 32);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const float thr = u2f(sc[0]) + band;
+
+    // exact distances of the candidates inside the band
+    for (int p0 = 0; p0 < total; p0 += 64) {
+        const int p = p0 + lane;
+        uint64_t key = KEY_SENTINEL;
+        if (p < total) {
+            const uint64_t mine = ak[p];
+            if (mine != KEY_SENTINEL && u2f((uint32_t)(mine >> 32)) <= thr) {
+                const uint32_t j = (uint32_t)(mine & 0xffffffffu);
+                const float* yr = P.Y + (size_t)j * P.ldy;
+                float acc = 0.f;
+                int c = 0;
+                if ((P.ldy & 3) == 0 && ((uintptr_t)P.Y & 15) == 0) {
+                    for (; c + 4 <= P.d; c += 4) {
+                        const f32x4 yv = *reinterpret_cast<const f32x4*>(yr + c);
+                        acc = __builtin_fmaf(xq[c], yv[0], acc);
+                        acc = __builtin_fmaf(xq[c + 1], yv[1], acc);
+                        acc = __builtin_fmaf(xq[c + 2], yv[2], acc);
+                        acc = __builtin_fmaf(xq[c + 3], yv[3], acc);
+                    }
+                }
+                for (; c < P.d; ++c) acc = __builtin_fmaf(xq[c], yr[c], acc);
+                const float cval = __builtin_fmaf(-2.0f, acc, __fadd_rn(nx, P.norms_y[j]));
+                key = mkkey(cval, j);
+            }
+        }
+        if (p < total) ek[p] = key;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    for (int p0 = 0; p0 < total; p0 += 64) {
+        const int p = p0 + lane;
+        const uint64_t mine = (p < total) ? ek[p] : KEY_SENTINEL;
+        int rank = 0;
+        for (int pp = 0; pp < total; ++pp) rank += (ek[pp] < mine) ? 1 : 0;
+        if (p < total && mine != KEY_SENTINEL && rank < P.k) {
+            float c = u2f((uint32_t)(mine >> 32));
+            if (P.metric == 1) c = sqrt_rn(fmaxf(c, 0.f));
+            P.out_d[(size_t)qi * P.k + rank] = c;
+            P.out_i[(size_t)qi * P.k + rank] = (int32_t)(uint32_t)(mine & 0xffffffffu);
+        }
+    }
+    if (lane == 0) {
+        P.flags[qi] = any_ovf ? 1 : 0;
+        if (any_ovf) atomicAdd(P.n_flagged, 1);
+    }
+}
+
+static inline int pick_ks(int d) {
+    if (d <= 32) return 2;
+    if (d <= 64) return 4;
+    if (d <= 128) return 8;
+    return 0;
+}
+
+static size_t screen_lds_bytes(int ks, int L, int nw) {
+    return (size_t)2 * ks * 2048 + (size_t)4 * 64 * sizeof(float) + (size_t)nw * 32 * L * sizeof(uint64_t);
+}
+
+// Workgroup shape and list length.  The list holds k entries plus spare slots for the candidates inside the
+// error band.  Preferred: 4 wavefronts (128 queries), two workgroups per CU (80 KiB each).  TDR_SCREEN_NW=8
+// selects 8 wavefronts (256 queries), one workgroup per CU.  Larger k: 4 wavefronts, one workgroup per CU, two
+// list entries per lane (L <= 128).
+struct ScreenCfg { int nw, L, items, wg_per_cu; };
+
+static int screen_nw_pref() {
+    static int nw = 0;
+    if (nw == 0) { const char* e = getenv("TDR_SCREEN_NW"); nw = e ? atoi(e) : 4; if (nw != 8) nw = 4; }
+    return nw;
+}
+
+static int max_list_len(int ks, int nw, size_t budget, int cap) {
+    int L = 0;
+    while (L + 1 <= cap && screen_lds_bytes(ks, L + 1, nw) <= budget) ++L;
+    return L;
+}
+
+static ScreenCfg screen_cfg(int ks, int k) {
+    const int spare_min = 8;
+    ScreenCfg c = {0, 0, 0, 0};
+    if (screen_nw_pref() == 8) {
+        const int L8 = max_list_len(ks, 8, 160 * 1024, 64);
+        if (k + spare_min <= L8) { c.nw = 8; c.L = (k + 24 < L8) ? k + 24 : L8; c.items = 1; c.wg_per_cu = 1; return c; }
+    }
+    const int L2 = max_list_len(ks, 4, 80 * 1024, 64);
+    if (k + spare_min <= L2) { c.nw = 4; c.L = (k + 24 < L2) ? k + 24 : L2; c.items = 1; c.wg_per_cu = 2; return c; }
+    const int L1 = max_list_len(ks, 4, 160 * 1024, 128);
+    if (k + spare_min <= L1) { c.nw = 4; c.L = (k + 32 < L1) ? k + 32 : L1; c.items = c.L > 64 ? 2 : 1; c.wg_per_cu = 1; return c; }
+    return c;
+}
+
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    return cus;
+}
+
+// database splits (gridDim.y) so that small query counts still fill the chip
+static int screen_splits(int64_t nq, int n_db_tiles, const ScreenCfg& c) {
+    const int64_t wgs = (nq + 32 * c.nw - 1) / (32 * c.nw);
+    const int target = 2 * device_cus() * c.wg_per_cu;
+    if (wgs >= target) return 1;
+    int64_t s = (target + wgs - 1) / wgs;
+    const int64_t max_by_tiles = n_db_tiles / 64 > 0 ? n_db_tiles / 64 : 1;
+    if (s > max_by_tiles) s = max_by_tiles;
+    if (s > 16) s = 16;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+template <int KS, int ITEMS, int NW>
+static int launch_screen(const ScreenParams& P, int n_wgs, size_t lds, hipStream_t st) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<KS, ITEMS, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((knn_screen_kernel<KS, ITEMS, NW>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(64 * NW), lds, st, P);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+template <int KS>
+static int launch_screen_ks(const ScreenParams& P, const ScreenCfg& c, int n_wgs, size_t lds, hipStream_t st) {
+    if (c.nw == 8) return launch_screen<KS, 1, 8>(P, n_wgs, lds, st);
+    if (c.items == 1) return launch_screen<KS, 1, 4>(P, n_wgs, lds, st);
+    return launch_screen<KS, 2, 4>(P, n_wgs, lds, st);
+}
+
+}  // namespace scr
+}  // namespace tdr
+
+using namespace tdr;
+using namespace tdr::scr;
+
+extern "C" {
+
+/* 1 when the two-stage (screen + rescore) search supports feature dimension d and neighbour count k. */
+int tdr_knn_screen_supported(int d, int k) {
+    const int ks = pick_ks(d);
+    if (ks == 0 || k < 1) return 0;
+    return screen_cfg(ks, k).L > 0 ? 1 : 0;
+}
+
+/* Floats of the fp16-split image of n rows of dimension d (0 if unsupported). */
+int64_t tdr_packed16_floats(int64_t n, int d) {
+    const int ks = pick_ks(d);
+    if (ks == 0 || n < 0) return 0;
+    return ((n + TILE_ROWS - 1) / TILE_ROWS) * tile16_stride_floats(ks);
+}
+
+/* meta (2 x uint32, device, caller-zeroed before the first call): meta[0] = max(meta[0], bits(max |X|)) over the
+ * n x d block; when norms != NULL also meta[1] = max(meta[1], bits(max norms[i])).  Call once per point block
+ * that will be packed with this meta (queries and database share one scale). */
+int tdr_screen_meta_f32(const float* X, int64_t n, int d, int64_t ldx, const float* norms, uint32_t* meta, void* stream) {
+    if (!X || !meta || n <= 0 || d <= 0 || ldx < d) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t total = n * d;
+    unsigned grid = (unsigned)((total + 256 * 16 - 1) / (256 * 16));
+    if (grid > 4096) grid = 4096;
+    if (grid < 1) grid = 1;
+    if (ldx == d) hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, st, X, total, meta);
+    else hipLaunchKernelGGL(absmax2d_kernel, dim3(grid), dim3(256), 0, st, X, n, d, ldx, meta);
+    TDR_CHECK_LAUNCH();
+    if (norms) {
+        unsigned g2 = (unsigned)((n + 256 * 16 - 1) / (256 * 16));
+        if (g2 > 1024) g2 = 1024;
+        if (g2 < 1) g2 = 1;
+        hipLaunchKernelGGL(absmax_kernel, dim3(g2), dim3(256), 0, st, norms, n, meta + 1);
+        TDR_CHECK_LAUNCH();
+    }
+    return TDR_OK;
+}
+
+/* fp16-split tile images of X; norms = the reference-order squared norms written by tdr_pack_rows_f32. */
+int tdr_pack16_f32(const float* X, int64_t n, int d, int64_t ldx, const float* norms, const uint32_t* meta, float* packed16,
+                   void* stream) {
+    if (!X || !norms || !meta || !packed16 || n <= 0 || d <= 0 || ldx < d) return TDR_ERR_BAD_ARG;
+    const int ks = pick_ks(d);
+    if (ks == 0) return TDR_ERR_UNSUPPORTED;
+    const int64_t tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+    const size_t shmem = (size_t)TILE_ROWS * (ks * 16 + 4) * sizeof(float);
+    hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)tiles), dim3(256), shmem, (hipStream_t)stream, X, n, d, ldx, ks, norms,
+                       meta, packed16);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+int64_t tdr_knn_screen_workspace_bytes(int64_t nq, int64_t n_db, int d, int k) {
+    const int ks = pick_ks(d);
+    if (ks == 0) return 0;
+    const ScreenCfg c = screen_cfg(ks, k);
+    if (c.L == 0) return 0;
+    const int n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
+    const int splits = screen_splits(nq, n_db_tiles, c);
+    return (int64_t)splits * nq * c.L * (int64_t)sizeof(uint64_t);
+}
+
+/*
+ * Two-stage exact kNN (sqeuclidean / euclidean).  q16 / y16: fp16-split images (tdr_pack16_f32, same meta);
+ * Xq / Y: the row-major fp32 blocks they were packed from; norms_q / norms_y: reference-order squared norms.
+ * out_d / out_i as tdr_knn_packed_f32.  flags (nq int32): 1 where the screening list overflowed -- those rows
+ * of out_d / out_i are NOT valid and must be recomputed with tdr_knn_packed_f32; *n_flagged (device int32,
+ * caller-zeroed) counts them.
+ */
+int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
+                       const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
+                       int metric, int exclude_self, const uint32_t* meta, float* out_d, int32_t* out_i, int32_t* flags,
+                       int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+    if (!q16 || !Xq || !norms_q || !y16 || !Y || !norms_y || !meta || !out_d || !out_i || !flags || !n_flagged || !ws)
+        return TDR_ERR_BAD_ARG;
+    if (nq <= 0 || n_db <= 0 || d <= 0 || ldq < d || ldy < d) return TDR_ERR_BAD_ARG;
+    if (metric != 0 && metric != 1) return TDR_ERR_UNSUPPORTED;
+    const int ks = pick_ks(d);
+    if (ks == 0) return TDR_ERR_UNSUPPORTED;
+    if (k < 1 || (int64_t)k > n_db - (exclude_self ? 1 : 0)) return TDR_ERR_BAD_ARG;
+    const ScreenCfg cfg = screen_cfg(ks, k);
+    const int L = cfg.L;
+    if (L == 0) return TDR_ERR_UNSUPPORTED;
+    if (n_db > 0x7fffffffLL) return TDR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    ScreenParams P;
+    P.qp = q16; P.yp = y16; P.meta = meta; P.nq = nq; P.q_offset = q_offset; P.n_db = n_db; P.k = k; P.L = L;
+    P.exclude_self = exclude_self;
+    P.n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
+    P.n_splits = screen_splits(nq, P.n_db_tiles, cfg);
+    P.tiles_per_split = (P.n_db_tiles + P.n_splits - 1) / P.n_splits;
+    P.dpad = ks * 16;
+    P.cand = (uint64_t*)ws;
+    const int64_t need = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
+    if (ws_bytes < need) return TDR_ERR_WORKSPACE;
+    const size_t lds = screen_lds_bytes(ks, L, cfg.nw);
+    const int wgs = (int)((nq + 32 * cfg.nw - 1) / (32 * cfg.nw));
+    int rc;
+    switch (ks) {
+        case 2: rc = launch_screen_ks<2>(P, cfg, wgs, lds, st); break;
+        case 4: rc = launch_screen_ks<4>(P, cfg, wgs, lds, st); break;
+        default: rc = launch_screen_ks<8>(P, cfg, wgs, lds, st); break;
+    }
+    if (rc != TDR_OK) return rc;
+
+    RescoreParams R;
+    R.cand = P.cand; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq;
+    R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.out_d = out_d;
+    R.out_i = out_i; R.flags = flags; R.n_flagged = n_flagged;
+    const int total = P.n_splits * L;
+    const int dq = (d + 3) & ~3;
+    const size_t rlds = (size_t)4 * ((size_t)2 * total * sizeof(uint64_t) + (size_t)dq * sizeof(float) + 16);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_rescore_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(knn_rescore_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), rlds, st, R);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+}  // extern "C"

@@ -21,9 +21,18 @@ _METRIC_ID = {"sqeuclidean": 0, "euclidean": 1, "angular": 2}
 # Value the reference adds to the diagonal when exclude_diag=True (distance/torch.py:115).
 _DIAG_ADD = 1e12
 
-# bench.py sets this to a list to collect (start_event, end_event, n_queries) around every scan launch
+# bench.py sets this to a list to collect (start_event, end_event, n_queries, kernel) around every scan launch
 # (HIP events on the launch stream); None = no instrumentation.
 PROFILE = None
+
+# Two-stage search (fp16-split screening + exact rescoring, csrc/tdr_knn_screen.hip): "auto" uses it when
+# the problem is large enough to pay for the extra packing pass, "0" never, "force" whenever it is supported.
+import os as _os
+
+SCREEN_MODE = _os.environ.get("TDR_KNN_SCREEN", "auto")
+_SCREEN_MIN_PAIRS = 1 << 26  # nq * n_db below which the one-stage kernel is used
+# counters of the last knn_packed call (tests / bench): path taken and number of overflowed queries
+LAST_KNN = {"path": None, "flagged": 0}
 
 
 class PackedPoints:
@@ -61,14 +70,106 @@ class PackedPoints:
             "tdr_pack_rows_f32",
         )
         self.device = X.device
+        self.X = X  # row-major source (kept alive: the rescoring stage of the two-stage search reads it)
+        self._img16 = None
+        self._meta = None
+
+    def screen_image(self, meta: Optional[torch.Tensor] = None):
+        """fp16-split tile images for the screening stage.  ``meta`` (2 x int32 device tensor) carries the
+        shared scale of a query/database pair; without it the block's own maximum is used and cached."""
+        L = _lib.lib()
+        own = meta is None
+        if own and self._img16 is not None:
+            return self._img16, self._meta
+        if own:
+            meta = torch.zeros(2, dtype=torch.int32, device=self.device)
+            _lib.check(L.tdr_screen_meta_f32(_lib.ptr(self.X), self.n, self.d, self.X.stride(0), _lib.ptr(self.norms),
+                                             _lib.ptr(meta), _lib.stream_ptr()), "tdr_screen_meta_f32")
+        img = torch.empty(L.tdr_packed16_floats(self.n, self.d), dtype=torch.float32, device=self.device)
+        _lib.check(L.tdr_pack16_f32(_lib.ptr(self.X), self.n, self.d, self.X.stride(0), _lib.ptr(self.norms),
+                                    _lib.ptr(meta), _lib.ptr(img), _lib.stream_ptr()), "tdr_pack16_f32")
+        if own:
+            self._img16, self._meta = img, meta
+        return img, meta
+
+
+def _use_screen(Q, Y, nq, k, metric):
+    if SCREEN_MODE == "0" or metric not in ("sqeuclidean", "euclidean"):
+        return False
+    if not _lib.lib().tdr_knn_screen_supported(Y.d, k):
+        return False
+    if SCREEN_MODE == "force":
+        return True
+    return nq * Y.n >= _SCREEN_MIN_PAIRS and Y.n >= 4096
+
+
+def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i):
+    """Two-stage search of queries Q[q0:q0+nq] against Y; rows whose screening list overflowed are redone
+    by the one-stage exact kernel.  Returns the number of such rows."""
+    L = _lib.lib()
+    dev = Y.device
+    d = Y.d
+    if Q is Y:
+        y16, meta = Y.screen_image()
+        q16 = y16
+    else:  # one scale for both blocks: max |x| over queries and database, max norm over the database
+        meta = torch.zeros(2, dtype=torch.int32, device=dev)
+        _lib.check(L.tdr_screen_meta_f32(_lib.ptr(Y.X), Y.n, d, Y.X.stride(0), _lib.ptr(Y.norms), _lib.ptr(meta),
+                                         _lib.stream_ptr()), "tdr_screen_meta_f32")
+        _lib.check(L.tdr_screen_meta_f32(_lib.ptr(Q.X), Q.n, d, Q.X.stride(0), None, _lib.ptr(meta),
+                                         _lib.stream_ptr()), "tdr_screen_meta_f32")
+        y16, _ = Y.screen_image(meta)
+        q16, _ = Q.screen_image(meta)
+    t16 = L.tdr_packed16_floats(32, d)
+    ws_bytes = L.tdr_knn_screen_workspace_bytes(nq, Y.n, d, k)
+    ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
+    flags = torch.empty(nq, dtype=torch.int32, device=dev)
+    n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
+    Xq = Q.X[q0:]
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(
+        L.tdr_knn_screen_f32(
+            _lib.ptr(q16[(q0 // 32) * t16:]), _lib.ptr(Xq), Q.X.stride(0), _lib.ptr(Q.norms[q0:]), nq, q_offset + q0,
+            _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
+            1 if exclude_self else 0, _lib.ptr(meta), _lib.ptr(out_d), _lib.ptr(out_i), _lib.ptr(flags),
+            _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
+        ),
+        "tdr_knn_screen_f32",
+    )
+    if PROFILE is not None:
+        ev1.record()
+        PROFILE.append((ev0, ev1, nq, "screen"))
+    bad = int(n_flagged.item())
+    if bad:
+        rows = flags.nonzero().squeeze(1)
+        Qf = PackedPoints(Xq[rows].contiguous())
+        kk = k + 1 if exclude_self else k
+        if kk > min(L.tdr_knn_max_k(d), Y.n):
+            raise NotImplementedError(f"[torchdr_amd] k={k}: screening overflow fallback exceeds the exact kernel's k limit.")
+        Cf, If = knn_packed(Qf, Y, kk, metric, exclude_self=False, _allow_screen=False)
+        if exclude_self:
+            # top-(k+1) without exclusion, then drop the query's own row (or the last entry when it is absent)
+            own = (rows + (q_offset + q0)).to(torch.int32)
+            is_self = If == own[:, None]
+            drop = torch.where(is_self.any(1), is_self.int().argmax(1), torch.full_like(own, k, dtype=torch.int64))
+            keep = torch.arange(kk, device=dev)[None, :] != drop[:, None]
+            Cf = Cf[keep].view(-1, k)
+            If = If[keep].view(-1, k)
+        out_d[rows] = Cf
+        out_i[rows] = If
+    return bad
 
 
 def knn_packed(
     Q: PackedPoints, Y: PackedPoints, k: int, metric: str, exclude_self: bool, q_offset: int = 0,
-    q_rows: Optional[slice] = None,
+    q_rows: Optional[slice] = None, _allow_screen: bool = True,
 ):
     """k nearest database rows of ``Y`` for the queries ``Q`` (or the row slice ``q_rows`` of Q,
-    which must start on a multiple of 32).  Returns (values (n,k) fp32 ascending, indices (n,k) int32)."""
+    which must start on a multiple of 32).  Returns (values (n,k) fp32 ascending, indices (n,k) int32).
+    Large searches take the two-stage path (fp16-split screening + exact rescoring); its results are
+    bit-identical to the one-stage kernel's."""
     L = _lib.lib()
     if Q.d != Y.d:
         raise ValueError("[TorchDR] ERROR : X and Y must have the same number of features.")
@@ -88,6 +189,12 @@ def knn_packed(
     dev = Y.device
     out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    if _allow_screen and _use_screen(Q, Y, nq, k, metric):
+        LAST_KNN["path"] = "screen"
+        LAST_KNN["flagged"] = _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i)
+        return out_d, out_i
+    if _allow_screen:
+        LAST_KNN["path"], LAST_KNN["flagged"] = "exact", 0
     ws_bytes = L.tdr_knn_workspace_bytes(nq, Y.n, k)
     ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
     tile_floats = L.tdr_packed_floats(32, d)
@@ -105,7 +212,7 @@ def knn_packed(
     )
     if PROFILE is not None:
         ev1.record()
-        PROFILE.append((ev0, ev1, nq))
+        PROFILE.append((ev0, ev1, nq, "exact"))
     return out_d, out_i
 
 
