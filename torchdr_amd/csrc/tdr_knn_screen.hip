@@ -8,7 +8,7 @@
 // keeps 22 significant bits and the scaling is exact).  For every pair |a_j - d_j| <= E_q with
 //     E_q = c_rel * ||x_q|| * max_j ||y_j|| + c_abs * (||x_q||^2 + max_j ||y_j||^2) + c_den
 // (screen_band below: fp16-split representation error 3 * 2^-22, fp32 accumulation of 3*D products in ANY
-// order, the reference's own fp32 rounding, all as worst-case bounds).  If a_(k) is the k-th smallest
+// order with a possibly truncating adder, the reference's own fp32 rounding -- all as worst-case bounds).  If a_(k) is the k-th smallest
 // screening value, the true k-th smallest distance is <= a_(k) + E_q, so every true neighbour has
 // a_j <= a_(k) + 2 E_q: the candidate set {j : a_j <= a_(k) + 2 E_q} contains the exact top-k.  The scan keeps
 // the L >= k smallest screening values per query (L - k spare slots); if the spare slots overflow (list full
@@ -39,7 +39,7 @@ __host__ __device__ __forceinline__ int64_t tile16_stride_floats(int ks) { retur
 
 // meta[0] = bits of max |x| over every element that will be packed, meta[1] = bits of max ||y||^2 (database)
 // scale s = 2^(13 - floor(log2(amax))): max |s x| in [2^13, 2^14) (fp16 max 65504; l stays normal down to
-// |s x| = 2^-3, below that its absolute error is 2^-25, accounted for by c_den)
+// |s x| = 2^-3; below that it is subnormal or flushed, accounted for by c_den)
 __device__ __forceinline__ int scale_exp(uint32_t amax_bits) {
     int ex = (int)((amax_bits >> 23) & 255u) - 127;
     if ((amax_bits & 0x7fffffffu) == 0u) ex = 13;   // all-zero data: s = 1
@@ -48,14 +48,19 @@ __device__ __forceinline__ int scale_exp(uint32_t amax_bits) {
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(e + 127) << 23); }
 
-// 2 * E_q (see the header): dpad = padded feature count, xn = ||x_q||^2, ymax2 = max ||y||^2, se = scale exponent
+// 2 * E_q (see the header): dpad = padded feature count, xn = ||x_q||^2, ymax2 = max ||y||^2, se = scale exponent.
+// Terms (u = 2^-24):  3 * 2^-22            fp16-split representation of both operands + the dropped l.l' product
+//                     2 (3 dpad + 16) u     fp32 accumulation of the 3*dpad products inside the matrix pipe, any
+//                                           order, allowing a truncating (1 ulp) adder
+//                     (dpad + 4) u          the reference's own k-ordered fp32 fma chain
+//                     8 u (xn + ymax2)      norm-sum association and the final roundings
+//                     2^-14 per element     l values below the fp16 normal range (covers a flush-to-zero pipe)
 __device__ __forceinline__ float screen_band(float xn, float ymax2, int dpad, int se) {
     const float u = 5.9604645e-08f;  // 2^-24
-    const float c_rel = 2.0f * (3.0f * 2.3841858e-07f + (3.0f * dpad + 16.0f) * u + (dpad + 4.0f) * u) * 1.01f;
+    const float c_rel = 2.0f * (3.0f * 2.3841858e-07f + 2.0f * (3.0f * dpad + 16.0f) * u + (dpad + 4.0f) * u) * 1.01f;
     const float c_abs = 8.0f * u;
-    // absolute part of the fp16 rounding of tiny elements (|s x| < 2^-3): 2^-25 per element in scaled units
     const float inv_s = pow2f(-se);
-    const float c_den = 2.0f * 2.9802322e-08f * sqrtf((float)dpad) * 1.01f * inv_s;
+    const float c_den = 2.0f * 6.1035156e-05f * sqrtf((float)dpad) * 1.01f * inv_s;
     const float nx = sqrtf(xn) * 1.0001f, ny = sqrtf(ymax2) * 1.0001f;
     const float e = c_rel * nx * ny + c_abs * (xn + ymax2) + c_den * (nx + ny);
     return 2.0f * e * 1.01f;
@@ -189,12 +194,13 @@ __device__ __forceinline__ bool coop_insert2(uint64_t* Lst, int len, int kpos, u
     return true;
 }
 
+template <int QB>
 struct SCtx {
     const ScreenParams* P;
-    uint64_t* keys;  // this wave's lists [32][L]
+    uint64_t* keys;  // this wave's lists [QB][32][L]
     int lane, q, h;
-    int64_t qt;      // query tile of this wave
-    float xn, band, m2s;
+    int64_t qt0;     // first query tile of this wave (tiles qt0 .. qt0 + QB - 1)
+    float xn[QB], band[QB], m2s;
 };
 
 // The hot filter works on the REDUCED value c' = ||y||^2 - 2 s^-2 acc (one fma per candidate) against the
@@ -204,29 +210,35 @@ __device__ __forceinline__ float reduce_tau(float tau, float xn) {
     return (tau - xn) + 2.3841858e-07f * (fabsf(tau) + xn);  // + 4u (|tau| + xn): never rejects an a <= tau
 }
 
-template <int ITEMS>
-__device__ __forceinline__ void screen_insert(const SCtx& C, const float (&dv)[16], const float (&pmin)[4], int Tprev,
-                                              float& tau_r) {
+template <int ITEMS, int QB>
+__device__ __forceinline__ void screen_insert(const SCtx<QB>& C, const float (&dv)[QB][16], const float (&pmin)[QB][4],
+                                              int Tprev, float (&tau_r)[QB]) {
     const ScreenParams& P = *C.P;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (!__any(pmin[g] <= tau_r)) continue;
+    for (int qb = 0; qb < QB; ++qb) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e;
-            unsigned long long m = __ballot(dv[r] <= tau_r);
-            while (m) {
-                const int src = __builtin_ctzll(m);
-                m &= m - 1;
-                const int sq = src & 31;
-                const int64_t j = (int64_t)Tprev * 32 + 4 * (src >> 5) + e + 8 * g;
-                if (j >= P.n_db || (P.exclude_self && j == C.qt * 32 + sq + P.q_offset)) continue;
-                const float cred = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv[r]), src));
-                const float xq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, C.xn), sq));
-                uint64_t nk, nt;
-                if (coop_insert2<ITEMS>(C.keys + (size_t)sq * P.L, P.L, P.k - 1, mkkey(cred + xq, (uint32_t)j), C.lane, nk, nt)) {
-                    if (C.q == sq)
-                        tau_r = reduce_tau(fminf(u2f((uint32_t)(nk >> 32)) + C.band, u2f((uint32_t)(nt >> 32))), C.xn);
+        for (int g = 0; g < 4; ++g) {
+            if (!__any(pmin[qb][g] <= tau_r[qb])) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                unsigned long long m = __ballot(dv[qb][r] <= tau_r[qb]);
+                while (m) {
+                    const int src = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int sq = src & 31;
+                    const int64_t j = (int64_t)Tprev * 32 + 4 * (src >> 5) + e + 8 * g;
+                    if (j >= P.n_db || (P.exclude_self && j == (C.qt0 + qb) * 32 + sq + P.q_offset)) continue;
+                    const float cred =
+                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv[qb][r]), src));
+                    const float xq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, C.xn[qb]), sq));
+                    uint64_t nk, nt;
+                    if (coop_insert2<ITEMS>(C.keys + ((size_t)qb * 32 + sq) * P.L, P.L, P.k - 1, mkkey(cred + xq, (uint32_t)j),
+                                            C.lane, nk, nt)) {
+                        if (C.q == sq)
+                            tau_r[qb] = reduce_tau(fminf(u2f((uint32_t)(nk >> 32)) + C.band[qb], u2f((uint32_t)(nt >> 32))),
+                                                   C.xn[qb]);
+                    }
                 }
             }
         }
@@ -234,50 +246,55 @@ __device__ __forceinline__ void screen_insert(const SCtx& C, const float (&dv)[1
 }
 
 // reduced screening values of one quarter (4 rows) of a finished tile
-__device__ __forceinline__ void sform_part(const SCtx& C, const f32x16& acc, const f32x4 (&yn)[4], int g, float (&dv)[16],
-                                           float (&pmin)[4]) {
-#ifdef SABL_NOEPI
-#pragma unroll
-    for (int e = 0; e < 4; ++e) dv[4 * g + e] = __builtin_inff();
-    pmin[g] = __builtin_inff();
-    return;
-#endif
+template <int QB>
+__device__ __forceinline__ void sform_part(const SCtx<QB>& C, const f32x16 (&acc)[QB], const f32x4 (&yn)[4], int g,
+                                           float (&dv)[QB][16], float (&pmin)[QB][4]) {
     const f32x4 y4 = yn[g];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dv[4 * g + e] = __builtin_fmaf(C.m2s, acc[4 * g + e], y4[e]);
-    pmin[g] = fminf(fminf(dv[4 * g], dv[4 * g + 1]), fminf(dv[4 * g + 2], dv[4 * g + 3]));
+    for (int qb = 0; qb < QB; ++qb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dv[qb][4 * g + e] = __builtin_fmaf(C.m2s, acc[qb][4 * g + e], y4[e]);
+        pmin[qb][g] = fminf(fminf(dv[qb][4 * g], dv[qb][4 * g + 1]), fminf(dv[qb][4 * g + 2], dv[qb][4 * g + 3]));
+    }
 }
 
-#if defined(SABL_NOLDSA)
-#define TDR_LDA(ptr, S) bh[(S) & (KS - 1)]
-#else
-#define TDR_LDA(ptr, S) (*reinterpret_cast<const f16x8*>(ptr))
-#endif
-// h.h' + h.l' + l.h' of one K-slice into the single accumulator chain (the fp32 accumulation of all 3*D products,
-// in whatever order, is inside screen_band's worst-case bound)
-#if defined(SABL_NOMFMA)
-#define TDR_MMA3(AH, AL, S) do { acc[0] += (float)(AH)[0] + (float)(AL)[0]; } while (0)
-#else
-#define TDR_MMA3(AH, AL, S)                                                          \
-    do {                                                                             \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bh[S], acc, 0, 0, 0);       \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bl[S], acc, 0, 0, 0);       \
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, bh[S], acc, 0, 0, 0);       \
+template <int QB>
+__device__ __forceinline__ bool any_survivor(const float (&pmin)[QB][4], const float (&tau_r)[QB]) {
+    bool hit = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+        hit |= (fminf(fminf(pmin[qb][0], pmin[qb][1]), fminf(pmin[qb][2], pmin[qb][3])) <= tau_r[qb]);
+    return __any(hit);
+}
+
+// h.h' + h.l' + l.h' of one K-slice into each query block's accumulator chain (the fp32 accumulation of all 3*D
+// products, in whatever order, is inside screen_band's worst-case bound).  With QB = 2 the two chains alternate,
+// so consecutive MFMAs are independent and share the A fragment.
+#define TDR_MMA3(AH, AL, S)                                                                             \
+    do {                                                                                                \
+        _Pragma("unroll") for (int qb = 0; qb < QB; ++qb)                                               \
+            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bh[qb][S], acc[qb], 0, 0, 0);          \
+        _Pragma("unroll") for (int qb = 0; qb < QB; ++qb)                                               \
+            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bl[qb][S], acc[qb], 0, 0, 0);          \
+        _Pragma("unroll") for (int qb = 0; qb < QB; ++qb)                                               \
+            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, bh[qb][S], acc[qb], 0, 0, 0);          \
     } while (0)
-#endif
+#define TDR_LDA(ptr) (*reinterpret_cast<const f16x8*>(ptr))
 
 // One tile step: multiply tile T (A fragments from LDS) into acc and finish tile T-1 out of `prev` between the
 // MFMA groups.  Slices are processed in double-buffered groups of GS.
-template <int KS, int ITEMS, bool HAVE_PREV>
-__device__ __forceinline__ void stile_step(const SCtx& C, const char* __restrict__ img, const f16x8 (&bh)[KS],
-                                           const f16x8 (&bl)[KS], f32x16& acc, const f32x16& prev,
-                                           const float* ynp_prev, int Tprev, float& tau_r) {
+template <int KS, int ITEMS, int QB, bool HAVE_PREV>
+__device__ __forceinline__ void stile_step(const SCtx<QB>& C, const char* __restrict__ img, const f16x8 (&bh)[QB][KS],
+                                           const f16x8 (&bl)[QB][KS], f32x16 (&acc)[QB], const f32x16 (&prev)[QB],
+                                           const float* ynp_prev, int Tprev, float (&tau_r)[QB]) {
     constexpr int GS = (KS >= 2) ? 2 : 1, NG = KS / GS;
     constexpr int PPG = (4 + NG - 1) / NG;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float dv[16];
-    float pmin[4];
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[qb][r] = 0.f;
+    float dv[QB][16];
+    float pmin[QB][4];
     // norms of the previous tile's rows first: LDS returns in order, so everything issued after them (the A
     // fragment prefetches) may stay in flight while the epilogue consumes them
     f32x4 yn[4];
@@ -289,8 +306,8 @@ __device__ __forceinline__ void stile_step(const SCtx& C, const char* __restrict
     f16x8 ah0[GS], al0[GS], ah1[GS], al1[GS];
 #pragma unroll
     for (int u = 0; u < GS; ++u) {
-        ah0[u] = TDR_LDA(ap + (2 * u) * 1024, u);
-        al0[u] = TDR_LDA(ap + (2 * u + 1) * 1024, u + 1);
+        ah0[u] = TDR_LDA(ap + (2 * u) * 1024);
+        al0[u] = TDR_LDA(ap + (2 * u + 1) * 1024);
     }
     int part = 0;
 #pragma unroll
@@ -298,15 +315,15 @@ __device__ __forceinline__ void stile_step(const SCtx& C, const char* __restrict
         if (g + 1 < NG) {
 #pragma unroll
             for (int u = 0; u < GS; ++u) {
-                ah1[u] = TDR_LDA(ap + (2 * ((g + 1) * GS + u)) * 1024, g + u);
-                al1[u] = TDR_LDA(ap + (2 * ((g + 1) * GS + u) + 1) * 1024, g + u + 1);
+                ah1[u] = TDR_LDA(ap + (2 * ((g + 1) * GS + u)) * 1024);
+                al1[u] = TDR_LDA(ap + (2 * ((g + 1) * GS + u) + 1) * 1024);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (HAVE_PREV) {
 #pragma unroll
             for (int pp = 0; pp < PPG; ++pp)
-                if (part + pp < 4) sform_part(C, prev, yn, part + pp, dv, pmin);
+                if (part + pp < 4) sform_part<QB>(C, prev, yn, part + pp, dv, pmin);
         }
         part += PPG;
 #pragma unroll
@@ -318,15 +335,15 @@ __device__ __forceinline__ void stile_step(const SCtx& C, const char* __restrict
             if (g + 2 < NG) {
 #pragma unroll
                 for (int u = 0; u < GS; ++u) {
-                    ah0[u] = TDR_LDA(ap + (2 * ((g + 2) * GS + u)) * 1024, g + u + 2);
-                    al0[u] = TDR_LDA(ap + (2 * ((g + 2) * GS + u) + 1) * 1024, g + u + 3);
+                    ah0[u] = TDR_LDA(ap + (2 * ((g + 2) * GS + u)) * 1024);
+                    al0[u] = TDR_LDA(ap + (2 * ((g + 2) * GS + u) + 1) * 1024);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (HAVE_PREV) {
 #pragma unroll
                 for (int pp = 0; pp < PPG; ++pp)
-                    if (part + pp < 4) sform_part(C, prev, yn, part + pp, dv, pmin);
+                    if (part + pp < 4) sform_part<QB>(C, prev, yn, part + pp, dv, pmin);
             }
             part += PPG;
 #pragma unroll
@@ -337,77 +354,82 @@ __device__ __forceinline__ void stile_step(const SCtx& C, const char* __restrict
         }
     }
     if (HAVE_PREV) {
-#ifdef SABL_NOINSERT
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { asm volatile("" ::"v"(pmin[g])); pmin[g] = __builtin_inff(); }
-#endif
-        if (__any(fminf(fminf(pmin[0], pmin[1]), fminf(pmin[2], pmin[3])) <= tau_r))
-            screen_insert<ITEMS>(C, dv, pmin, Tprev, tau_r);
+        if (any_survivor<QB>(pmin, tau_r)) screen_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_r);
     }
 }
 
-template <int ITEMS>
-__device__ __forceinline__ void stile_drain(const SCtx& C, const f32x16& prev, const float* ynp_prev, int Tprev,
-                                            float& tau_r) {
-    float dv[16];
-    float pmin[4];
+template <int ITEMS, int QB>
+__device__ __forceinline__ void stile_drain(const SCtx<QB>& C, const f32x16 (&prev)[QB], const float* ynp_prev, int Tprev,
+                                            float (&tau_r)[QB]) {
+    float dv[QB][16];
+    float pmin[QB][4];
     f32x4 yn[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) yn[g] = *reinterpret_cast<const f32x4*>(ynp_prev + 8 * g);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) sform_part(C, prev, yn, g, dv, pmin);
-    if (__any(fminf(fminf(pmin[0], pmin[1]), fminf(pmin[2], pmin[3])) <= tau_r)) screen_insert<ITEMS>(C, dv, pmin, Tprev, tau_r);
+    for (int g = 0; g < 4; ++g) sform_part<QB>(C, prev, yn, g, dv, pmin);
+    if (any_survivor<QB>(pmin, tau_r)) screen_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_r);
 }
 
-// NW wavefronts per workgroup (4: 128 queries, two workgroups per CU when the lists fit 80 KiB; 8: 256 queries,
-// one workgroup per CU -- the staged tile, its LDS-DMA instructions and the barrier are shared by twice the queries)
-template <int KS, int ITEMS, int NW>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && ITEMS == 1) ? 2 : 1) void knn_screen_kernel(const ScreenParams P) {
+// Workgroup = 4 wavefronts x QB query blocks of 32.  QB = 1: 128 queries, two workgroups per CU (two wavefronts
+// per SIMD) when the lists fit 80 KiB.  QB = 2: 256 queries, one workgroup per CU, one wavefront per SIMD driving
+// two MFMA chains off the same A fragments -- half the LDS reads, LDS-DMA instructions and barriers per matrix
+// instruction.
+template <int KS, int ITEMS, int QB>
+__global__ __launch_bounds__(256, (QB == 1 && ITEMS == 1) ? 2 : 1) void knn_screen_kernel(const ScreenParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NW = 4;
     constexpr int IMG_B = KS * 2048;                 // bytes of the fragment blocks of one tile
     constexpr int TILE_F = KS * 512 + 64;            // floats per tile image in HBM
     constexpr int NBLK = 2 * KS;                     // 1-KiB blocks per tile
     char* tile0 = smem_raw;
     char* tile1 = tile0 + IMG_B;
     float* nring = reinterpret_cast<float*>(tile1 + IMG_B);              // [4 slots][64 floats]
-    uint64_t* keys_all = reinterpret_cast<uint64_t*>(nring + 4 * 64);    // [NW][32][L]
+    uint64_t* keys_all = reinterpret_cast<uint64_t*>(nring + 4 * 64);    // [NW][QB][32][L]
     const int Ln = P.L;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int q = lane & 31, h = lane >> 5;
-    uint64_t* keys = keys_all + (size_t)wave * Ln * 32;
+    uint64_t* keys = keys_all + (size_t)wave * QB * Ln * 32;
 
     const int64_t n_qtiles = (P.nq + 31) / 32;
-    const int64_t qt = (int64_t)blockIdx.x * NW + wave;
-    const bool wave_active = qt < n_qtiles;
+    const int64_t qt0 = ((int64_t)blockIdx.x * NW + wave) * QB;
+    const bool wave_active = qt0 < n_qtiles;
 
     const int se = scale_exp(P.meta[0]);
-    SCtx C;
-    C.P = &P; C.keys = keys; C.lane = lane; C.q = q; C.h = h; C.qt = qt;
+    const float ymax2 = __uint_as_float(P.meta[1]);
+    SCtx<QB> C;
+    C.P = &P; C.keys = keys; C.lane = lane; C.q = q; C.h = h; C.qt0 = qt0;
     C.m2s = -2.0f * pow2f(-2 * se);
 
-    f16x8 bh[KS], bl[KS];
-    if (wave_active) {
-        const char* qimg = reinterpret_cast<const char*>(P.qp + (size_t)qt * TILE_F);
+    f16x8 bh[QB][KS], bl[QB][KS];
+    float tau_r[QB];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bh[s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s) * 1024 + lane * 16);
-            bl[s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s + 1) * 1024 + lane * 16);
+    for (int qb = 0; qb < QB; ++qb) {
+        const int64_t qt = qt0 + qb;
+        const bool blk_active = qt < n_qtiles;
+        if (blk_active) {
+            const char* qimg = reinterpret_cast<const char*>(P.qp + (size_t)qt * TILE_F);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bh[qb][s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s) * 1024 + lane * 16);
+                bl[qb][s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s + 1) * 1024 + lane * 16);
+            }
+            C.xn[qb] = reinterpret_cast<const float*>(qimg + IMG_B)[q];
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { bh[qb][s][e] = (_Float16)0.f; bl[qb][s][e] = (_Float16)0.f; }
+            C.xn[qb] = 0.f;
         }
-        C.xn = reinterpret_cast<const float*>(qimg + IMG_B)[q];
-    } else {
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { bh[s][e] = (_Float16)0.f; bl[s][e] = (_Float16)0.f; }
-        C.xn = 0.f;
+        const bool lane_valid = blk_active && (qt * 32 + q < P.nq);
+        if (!lane_valid) C.xn[qb] = 0.f;  // rows beyond nq carry +inf norms in the image
+        C.band[qb] = screen_band(C.xn[qb], ymax2, P.dpad, se);
+        tau_r[qb] = lane_valid ? __builtin_inff() : -__builtin_inff();
     }
-    const bool lane_valid = wave_active && (qt * 32 + q < P.nq);
-    if (!lane_valid) C.xn = 0.f;  // rows beyond nq carry +inf norms in the image
-    C.band = screen_band(C.xn, __uint_as_float(P.meta[1]), P.dpad, se);
-    float tau_r = lane_valid ? __builtin_inff() : -__builtin_inff();
-    for (int p = lane; p < Ln * 32; p += 64) keys[p] = KEY_SENTINEL;
+    for (int p = lane; p < QB * Ln * 32; p += 64) keys[p] = KEY_SENTINEL;
 
     const int split = blockIdx.y;
     const int t_begin = split * P.tiles_per_split;
@@ -430,47 +452,38 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && ITEMS == 1) ? 2 : 1) void knn_
     if (t_begin < t_end) stage(t_begin);
     __syncthreads();
 
-    f32x16 accA, accB;
+    f32x16 accA[QB], accB[QB];
     int T = t_begin;
 #define TDR_YN(Tx) (nring + (((Tx) - t_begin) & 3) * 64 + 4 * h)
-#ifdef SABL_NOSTAGE
-#define TDR_STAGE(Tx)
-#else
-#define TDR_STAGE(Tx) if ((Tx) < t_end) stage(Tx)
-#endif
-#ifdef SABL_NOBARRIER
-#define TDR_SYNC()
-#else
-#define TDR_SYNC() __syncthreads()
-#endif
     if (T < t_end) {
-        TDR_STAGE(T + 1);
-        if (wave_active) stile_step<KS, ITEMS, false>(C, tile0, bh, bl, accA, accA, nring, T, tau_r);
-        TDR_SYNC();
+        if (T + 1 < t_end) stage(T + 1);
+        if (wave_active) stile_step<KS, ITEMS, QB, false>(C, tile0, bh, bl, accA, accA, nring, T, tau_r);
+        __syncthreads();
         ++T;
     }
     while (T < t_end) {
         {
-            TDR_STAGE(T + 1);
-            if (wave_active) stile_step<KS, ITEMS, true>(C, tile1, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
-            TDR_SYNC();
+            if (T + 1 < t_end) stage(T + 1);
+            if (wave_active) stile_step<KS, ITEMS, QB, true>(C, tile1, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
+            __syncthreads();
             ++T;
         }
         if (T < t_end) {
-            TDR_STAGE(T + 1);
-            if (wave_active) stile_step<KS, ITEMS, true>(C, tile0, bh, bl, accA, accB, TDR_YN(T - 1), T - 1, tau_r);
-            TDR_SYNC();
+            if (T + 1 < t_end) stage(T + 1);
+            if (wave_active) stile_step<KS, ITEMS, QB, true>(C, tile0, bh, bl, accA, accB, TDR_YN(T - 1), T - 1, tau_r);
+            __syncthreads();
             ++T;
         } else {
-            accA = accB;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) accA[qb] = accB[qb];
         }
     }
-    if (wave_active && t_begin < t_end) stile_drain<ITEMS>(C, accA, TDR_YN(t_end - 1), t_end - 1, tau_r);
+    if (wave_active && t_begin < t_end) stile_drain<ITEMS, QB>(C, accA, TDR_YN(t_end - 1), t_end - 1, tau_r);
 #undef TDR_YN
 
     if (wave_active) {
-        for (int jq = 0; jq < 32; ++jq) {
-            const int64_t qi = qt * 32 + jq;
+        for (int jq = 0; jq < 32 * QB; ++jq) {
+            const int64_t qi = qt0 * 32 + jq;
             if (qi >= P.nq) break;
             for (int p = lane; p < Ln; p += 64)
                 P.cand[((size_t)split * P.nq + qi) * Ln + p] = keys[(size_t)jq * Ln + p];
@@ -601,39 +614,39 @@ static inline int pick_ks(int d) {
     return 0;
 }
 
-static size_t screen_lds_bytes(int ks, int L, int nw) {
-    return (size_t)2 * ks * 2048 + (size_t)4 * 64 * sizeof(float) + (size_t)nw * 32 * L * sizeof(uint64_t);
+static size_t screen_lds_bytes(int ks, int L, int qb) {
+    return (size_t)2 * ks * 2048 + (size_t)4 * 64 * sizeof(float) + (size_t)4 * qb * 32 * L * sizeof(uint64_t);
 }
 
 // Workgroup shape and list length.  The list holds k entries plus spare slots for the candidates inside the
-// error band.  Preferred: 4 wavefronts (128 queries), two workgroups per CU (80 KiB each).  TDR_SCREEN_NW=8
-// selects 8 wavefronts (256 queries), one workgroup per CU.  Larger k: 4 wavefronts, one workgroup per CU, two
-// list entries per lane (L <= 128).
-struct ScreenCfg { int nw, L, items, wg_per_cu; };
+// error band.  Default: QB = 1 (128 queries), two workgroups per CU (80 KiB each).  TDR_SCREEN_QB=2 selects
+// 256 queries per workgroup, one workgroup per CU.  Larger k: QB = 1, one workgroup per CU, two list entries
+// per lane (L <= 128).
+struct ScreenCfg { int qb, L, items, wg_per_cu; };
 
-static int screen_nw_pref() {
-    static int nw = 0;
-    if (nw == 0) { const char* e = getenv("TDR_SCREEN_NW"); nw = e ? atoi(e) : 4; if (nw != 8) nw = 4; }
-    return nw;
+static int screen_qb_pref() {
+    static int qb = 0;
+    if (qb == 0) { const char* e = getenv("TDR_SCREEN_QB"); qb = e ? atoi(e) : 1; if (qb != 2) qb = 1; }
+    return qb;
 }
 
-static int max_list_len(int ks, int nw, size_t budget, int cap) {
+static int max_list_len(int ks, int qb, size_t budget, int cap) {
     int L = 0;
-    while (L + 1 <= cap && screen_lds_bytes(ks, L + 1, nw) <= budget) ++L;
+    while (L + 1 <= cap && screen_lds_bytes(ks, L + 1, qb) <= budget) ++L;
     return L;
 }
 
 static ScreenCfg screen_cfg(int ks, int k) {
     const int spare_min = 8;
     ScreenCfg c = {0, 0, 0, 0};
-    if (screen_nw_pref() == 8) {
-        const int L8 = max_list_len(ks, 8, 160 * 1024, 64);
-        if (k + spare_min <= L8) { c.nw = 8; c.L = (k + 24 < L8) ? k + 24 : L8; c.items = 1; c.wg_per_cu = 1; return c; }
+    if (screen_qb_pref() == 2) {
+        const int Lq = max_list_len(ks, 2, 160 * 1024, 64);
+        if (k + spare_min <= Lq) { c.qb = 2; c.L = (k + 24 < Lq) ? k + 24 : Lq; c.items = 1; c.wg_per_cu = 1; return c; }
     }
-    const int L2 = max_list_len(ks, 4, 80 * 1024, 64);
-    if (k + spare_min <= L2) { c.nw = 4; c.L = (k + 24 < L2) ? k + 24 : L2; c.items = 1; c.wg_per_cu = 2; return c; }
-    const int L1 = max_list_len(ks, 4, 160 * 1024, 128);
-    if (k + spare_min <= L1) { c.nw = 4; c.L = (k + 32 < L1) ? k + 32 : L1; c.items = c.L > 64 ? 2 : 1; c.wg_per_cu = 1; return c; }
+    const int L2 = max_list_len(ks, 1, 80 * 1024, 64);
+    if (k + spare_min <= L2) { c.qb = 1; c.L = (k + 24 < L2) ? k + 24 : L2; c.items = 1; c.wg_per_cu = 2; return c; }
+    const int L1 = max_list_len(ks, 1, 160 * 1024, 128);
+    if (k + spare_min <= L1) { c.qb = 1; c.L = (k + 32 < L1) ? k + 32 : L1; c.items = c.L > 64 ? 2 : 1; c.wg_per_cu = 1; return c; }
     return c;
 }
 
@@ -650,7 +663,7 @@ static int device_cus() {
 
 // database splits (gridDim.y) so that small query counts still fill the chip
 static int screen_splits(int64_t nq, int n_db_tiles, const ScreenCfg& c) {
-    const int64_t wgs = (nq + 32 * c.nw - 1) / (32 * c.nw);
+    const int64_t wgs = (nq + 128 * c.qb - 1) / (128 * c.qb);
     const int target = 2 * device_cus() * c.wg_per_cu;
     if (wgs >= target) return 1;
     int64_t s = (target + wgs - 1) / wgs;
@@ -661,21 +674,21 @@ static int screen_splits(int64_t nq, int n_db_tiles, const ScreenCfg& c) {
     return (int)s;
 }
 
-template <int KS, int ITEMS, int NW>
+template <int KS, int ITEMS, int QB>
 static int launch_screen(const ScreenParams& P, int n_wgs, size_t lds, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<KS, ITEMS, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<KS, ITEMS, QB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((knn_screen_kernel<KS, ITEMS, NW>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(64 * NW), lds, st, P);
+    hipLaunchKernelGGL((knn_screen_kernel<KS, ITEMS, QB>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(256), lds, st, P);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
 
 template <int KS>
 static int launch_screen_ks(const ScreenParams& P, const ScreenCfg& c, int n_wgs, size_t lds, hipStream_t st) {
-    if (c.nw == 8) return launch_screen<KS, 1, 8>(P, n_wgs, lds, st);
-    if (c.items == 1) return launch_screen<KS, 1, 4>(P, n_wgs, lds, st);
-    return launch_screen<KS, 2, 4>(P, n_wgs, lds, st);
+    if (c.qb == 2) return launch_screen<KS, 1, 2>(P, n_wgs, lds, st);
+    if (c.items == 1) return launch_screen<KS, 1, 1>(P, n_wgs, lds, st);
+    return launch_screen<KS, 2, 1>(P, n_wgs, lds, st);
 }
 
 }  // namespace scr
@@ -780,8 +793,8 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
     P.cand = (uint64_t*)ws;
     const int64_t need = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
     if (ws_bytes < need) return TDR_ERR_WORKSPACE;
-    const size_t lds = screen_lds_bytes(ks, L, cfg.nw);
-    const int wgs = (int)((nq + 32 * cfg.nw - 1) / (32 * cfg.nw));
+    const size_t lds = screen_lds_bytes(ks, L, cfg.qb);
+    const int wgs = (int)((nq + 128 * cfg.qb - 1) / (128 * cfg.qb));
     int rc;
     switch (ks) {
         case 2: rc = launch_screen_ks<2>(P, cfg, wgs, lds, st); break;
