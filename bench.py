@@ -165,12 +165,12 @@ def main():
     scan_avg_ms = sum(scan_ms) / max(len(scan_ms), 1)
     flops = 2.0 * nq * args.n * args.d
     achieved = flops / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
-    peak = F16_MFMA_PEAK_TFLOPS if path == "screen" else FP32_MFMA_PEAK_TFLOPS
+    peak = F16_MFMA_PEAK_TFLOPS if path.startswith("screen") else FP32_MFMA_PEAK_TFLOPS
 
     # HBM-side traffic of the dominant kernel: PMC pass committed under profiles/ (separate rocprofv3 --pmc
     # runs of the same kernel on the same workload; FETCH_SIZE doubled per the gfx950 note of the guide)
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_knn_screen_pmc.json" if path == "screen" else "r01_knn_scan_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01_knn_screen_pmc.json" if path == "screen" else "r01_knn_exact_scan_pmc.json")
     if world == 1 and (args.n, args.d, args.k) == (1_000_000, 128, 30) and os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
@@ -201,7 +201,7 @@ def main():
             "knn_build_sec": scan_avg_ms * 1e-3,
             "knn_path": path,
             "roofline": {
-                "kernel": ("tdr::scr::knn_screen_kernel<8,1,4> (+ knn_rescore_kernel)" if path == "screen"
+                "kernel": ("tdr::scr::knn_screen_kernel<8,1,1> (+ knn_rescore_kernel)" if path.startswith("screen")
                            else "tdr::knn_scan_kernel<16,1,1>") if 64 < args.d <= 128 else "tdr kNN scan",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
@@ -209,7 +209,7 @@ def main():
                 "algorithmic_flops_per_launch": flops, "avg_launch_ms": scan_avg_ms,
             },
         }
-        if path == "screen":
+        if path.startswith("screen"):
             # what the matrix pipe actually executes: three f16 products per feature (h.h' + h.l' + l.h')
             out["roofline"]["executed_tflops"] = 3.0 * achieved
             out["roofline"]["executed_frac"] = 3.0 * achieved / peak

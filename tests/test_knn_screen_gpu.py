@@ -92,3 +92,49 @@ def test_screen_split_launch_small_query_count():
     X = Y[:1000].contiguous()
     (C0, I0), (C1, I1), _ = both_paths(X, 30, "sqeuclidean", False, Y=Y)
     assert torch.equal(I0, I1) and torch.equal(C0, C1)
+
+
+def test_screen_pilot_routes_unsuitable_data_to_one_stage_kernel():
+    """Large search on data whose band overflows: the pilot slice notices and the whole search runs on the
+    one-stage kernel (same results, no wasted screening pass)."""
+    from torchdr_amd.distance import base as dbase
+
+    X = (gmm(40000, 64, 1.0, seed=12) + 300.0).cuda()
+    (C0, I0), (C1, I1), flagged = both_paths_allow_pilot(X, 15)
+    assert torch.equal(I0, I1) and torch.equal(C0, C1)
+
+
+def both_paths_allow_pilot(X, k):
+    from torchdr_amd.distance import base as dbase
+
+    old = dbase.SCREEN_MODE
+    try:
+        dbase.SCREEN_MODE = "0"
+        Xp = dbase.PackedPoints(X)
+        r0 = dbase.knn_packed(Xp, Xp, k, "sqeuclidean", True)
+        dbase.SCREEN_MODE = "force"
+        Xp = dbase.PackedPoints(X)
+        r1 = dbase.knn_packed(Xp, Xp, k, "sqeuclidean", True)
+        assert dbase.LAST_KNN["path"] == "exact (pilot overflow)"
+    finally:
+        dbase.SCREEN_MODE = old
+    return r0, r1, 0
+
+
+@pytest.mark.parametrize("scale,k", [(2.0, 30), (10.0, 30), (10.0, 50)])
+def test_screen_long_list_tier_equals_exact(scale, k):
+    """tier 1 (one workgroup per CU, up to k + 72 list slots, two entries per lane) against the one-stage kernel."""
+    from torchdr_amd.distance import base as dbase
+
+    X = gmm(6000, 128, scale, seed=21).cuda()
+    old = dbase.SCREEN_MODE
+    try:
+        dbase.SCREEN_MODE = "0"
+        Xp = dbase.PackedPoints(X)
+        C0, I0 = dbase.knn_packed(Xp, Xp, k, "sqeuclidean", True)
+    finally:
+        dbase.SCREEN_MODE = old
+    C1 = torch.empty_like(C0)
+    I1 = torch.empty_like(I0)
+    dbase._knn_screen(Xp, Xp, 0, Xp.n, k, "sqeuclidean", True, 0, C1, I1, pilot=False, tier=1)
+    assert torch.equal(I0, I1) and torch.equal(C0, C1)

@@ -32,6 +32,8 @@ def run(n, d, k, scale, check=True):
         out[name + "_ms"] = round(e1.elapsed_time(e2), 3)
         if mode == "force":
             out["flagged"] = dbase.LAST_KNN["flagged"]
+            out["path"] = dbase.LAST_KNN["path"]
+            out["tier"] = dbase.LAST_KNN.get("tier")
         res[name] = (C, I)
     if check:
         out["equal"] = bool(torch.equal(res["screen"][0], res["exact"][0]) and torch.equal(res["screen"][1], res["exact"][1]))

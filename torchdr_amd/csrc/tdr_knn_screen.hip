@@ -636,17 +636,22 @@ static int max_list_len(int ks, int qb, size_t budget, int cap) {
     return L;
 }
 
-static ScreenCfg screen_cfg(int ks, int k) {
+// tier 0: the default shapes above.  tier 1: one workgroup per CU and up to 72 spare slots, for data whose error
+// band holds more candidates than tier 0 can keep (large ||x|| ||y|| relative to the neighbour spacing).
+static ScreenCfg screen_cfg(int ks, int k, int tier) {
     const int spare_min = 8;
     ScreenCfg c = {0, 0, 0, 0};
-    if (screen_qb_pref() == 2) {
-        const int Lq = max_list_len(ks, 2, 160 * 1024, 64);
-        if (k + spare_min <= Lq) { c.qb = 2; c.L = (k + 24 < Lq) ? k + 24 : Lq; c.items = 1; c.wg_per_cu = 1; return c; }
+    if (tier == 0) {
+        if (screen_qb_pref() == 2) {
+            const int Lq = max_list_len(ks, 2, 160 * 1024, 64);
+            if (k + spare_min <= Lq) { c.qb = 2; c.L = (k + 24 < Lq) ? k + 24 : Lq; c.items = 1; c.wg_per_cu = 1; return c; }
+        }
+        const int L2 = max_list_len(ks, 1, 80 * 1024, 64);
+        if (k + spare_min <= L2) { c.qb = 1; c.L = (k + 24 < L2) ? k + 24 : L2; c.items = 1; c.wg_per_cu = 2; return c; }
     }
-    const int L2 = max_list_len(ks, 1, 80 * 1024, 64);
-    if (k + spare_min <= L2) { c.qb = 1; c.L = (k + 24 < L2) ? k + 24 : L2; c.items = 1; c.wg_per_cu = 2; return c; }
     const int L1 = max_list_len(ks, 1, 160 * 1024, 128);
-    if (k + spare_min <= L1) { c.qb = 1; c.L = (k + 32 < L1) ? k + 32 : L1; c.items = c.L > 64 ? 2 : 1; c.wg_per_cu = 1; return c; }
+    const int spare = tier == 0 ? 32 : 72;
+    if (k + spare_min <= L1) { c.qb = 1; c.L = (k + spare < L1) ? k + spare : L1; c.items = c.L > 64 ? 2 : 1; c.wg_per_cu = 1; return c; }
     return c;
 }
 
@@ -703,7 +708,7 @@ extern "C" {
 int tdr_knn_screen_supported(int d, int k) {
     const int ks = pick_ks(d);
     if (ks == 0 || k < 1) return 0;
-    return screen_cfg(ks, k).L > 0 ? 1 : 0;
+    return screen_cfg(ks, k, 0).L > 0 ? 1 : 0;
 }
 
 /* Floats of the fp16-split image of n rows of dimension d (0 if unsupported). */
@@ -750,10 +755,10 @@ int tdr_pack16_f32(const float* X, int64_t n, int d, int64_t ldx, const float* n
     return TDR_OK;
 }
 
-int64_t tdr_knn_screen_workspace_bytes(int64_t nq, int64_t n_db, int d, int k) {
+int64_t tdr_knn_screen_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, int tier) {
     const int ks = pick_ks(d);
     if (ks == 0) return 0;
-    const ScreenCfg c = screen_cfg(ks, k);
+    const ScreenCfg c = screen_cfg(ks, k, tier);
     if (c.L == 0) return 0;
     const int n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
     const int splits = screen_splits(nq, n_db_tiles, c);
@@ -765,12 +770,13 @@ int64_t tdr_knn_screen_workspace_bytes(int64_t nq, int64_t n_db, int d, int k) {
  * Xq / Y: the row-major fp32 blocks they were packed from; norms_q / norms_y: reference-order squared norms.
  * out_d / out_i as tdr_knn_packed_f32.  flags (nq int32): 1 where the screening list overflowed -- those rows
  * of out_d / out_i are NOT valid and must be recomputed with tdr_knn_packed_f32; *n_flagged (device int32,
- * caller-zeroed) counts them.
+ * caller-zeroed) counts them.  tier: 0 = default list length (k + ~17..24 spare slots), 1 = long lists (up to
+ * k + 72 spare slots, one workgroup per CU) for data whose error band holds more candidates.
  */
 int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
                        const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
-                       int metric, int exclude_self, const uint32_t* meta, float* out_d, int32_t* out_i, int32_t* flags,
-                       int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+                       int metric, int exclude_self, int tier, const uint32_t* meta, float* out_d, int32_t* out_i,
+                       int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
     if (!q16 || !Xq || !norms_q || !y16 || !Y || !norms_y || !meta || !out_d || !out_i || !flags || !n_flagged || !ws)
         return TDR_ERR_BAD_ARG;
     if (nq <= 0 || n_db <= 0 || d <= 0 || ldq < d || ldy < d) return TDR_ERR_BAD_ARG;
@@ -778,7 +784,8 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
     const int ks = pick_ks(d);
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     if (k < 1 || (int64_t)k > n_db - (exclude_self ? 1 : 0)) return TDR_ERR_BAD_ARG;
-    const ScreenCfg cfg = screen_cfg(ks, k);
+    if (tier < 0 || tier > 1) return TDR_ERR_BAD_ARG;
+    const ScreenCfg cfg = screen_cfg(ks, k, tier);
     const int L = cfg.L;
     if (L == 0) return TDR_ERR_UNSUPPORTED;
     if (n_db > 0x7fffffffLL) return TDR_ERR_UNSUPPORTED;

@@ -31,6 +31,9 @@ import os as _os
 
 SCREEN_MODE = _os.environ.get("TDR_KNN_SCREEN", "auto")
 _SCREEN_MIN_PAIRS = 1 << 26  # nq * n_db below which the one-stage kernel is used
+_SCREEN_PILOT_MIN_Q = 32768   # searches with at least this many queries screen a pilot slice first
+_SCREEN_PILOT_Q = 2048
+_SCREEN_PILOT_MAX_FRAC = 0.05  # overflowed share of the pilot above which the one-stage kernel is used
 # counters of the last knn_packed call (tests / bench): path taken and number of overflowed queries
 LAST_KNN = {"path": None, "flagged": 0}
 
@@ -103,9 +106,10 @@ def _use_screen(Q, Y, nq, k, metric):
     return nq * Y.n >= _SCREEN_MIN_PAIRS and Y.n >= 4096
 
 
-def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i):
+def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, pilot=True, fallback=True, tier=0):
     """Two-stage search of queries Q[q0:q0+nq] against Y; rows whose screening list overflowed are redone
-    by the one-stage exact kernel.  Returns the number of such rows."""
+    by the one-stage exact kernel.  Returns the number of such rows, or -1 when the pilot slice says the
+    data does not suit screening (nothing written; the caller uses the one-stage kernel)."""
     L = _lib.lib()
     dev = Y.device
     d = Y.d
@@ -121,28 +125,41 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i):
         y16, _ = Y.screen_image(meta)
         q16, _ = Q.screen_image(meta)
     t16 = L.tdr_packed16_floats(32, d)
-    ws_bytes = L.tdr_knn_screen_workspace_bytes(nq, Y.n, d, k)
+    if pilot and nq >= _SCREEN_PILOT_MIN_Q:
+        # pilot: screen a small slice of the queries first; when the worst-case band swallows the spare list
+        # slots for a sizeable share of them (large ||x|| ||y|| relative to the neighbour spacing), the two-stage
+        # search would mostly fall back -- run the one-stage kernel for everything instead
+        pd = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.float32, device=dev)
+        pi = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.int32, device=dev)
+        for tier in (0, 1):  # default lists first, then the long-list shape
+            bad = _knn_screen(Q, Y, q0, _SCREEN_PILOT_Q, k, metric, exclude_self, q_offset, pd, pi, pilot=False,
+                              fallback=False, tier=tier)
+            if bad <= _SCREEN_PILOT_MAX_FRAC * _SCREEN_PILOT_Q:
+                break
+        else:
+            return -1
+    ws_bytes = L.tdr_knn_screen_workspace_bytes(nq, Y.n, d, k, tier)
     ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
     flags = torch.empty(nq, dtype=torch.int32, device=dev)
     n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
     Xq = Q.X[q0:]
-    if PROFILE is not None:
+    if PROFILE is not None and fallback:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     _lib.check(
         L.tdr_knn_screen_f32(
             _lib.ptr(q16[(q0 // 32) * t16:]), _lib.ptr(Xq), Q.X.stride(0), _lib.ptr(Q.norms[q0:]), nq, q_offset + q0,
             _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
-            1 if exclude_self else 0, _lib.ptr(meta), _lib.ptr(out_d), _lib.ptr(out_i), _lib.ptr(flags),
+            1 if exclude_self else 0, tier, _lib.ptr(meta), _lib.ptr(out_d), _lib.ptr(out_i), _lib.ptr(flags),
             _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
         ),
         "tdr_knn_screen_f32",
     )
-    if PROFILE is not None:
+    if PROFILE is not None and fallback:
         ev1.record()
-        PROFILE.append((ev0, ev1, nq, "screen"))
+        PROFILE.append((ev0, ev1, nq, "screen" if tier == 0 else "screen-long"))
     bad = int(n_flagged.item())
-    if bad:
+    if bad and fallback:
         rows = flags.nonzero().squeeze(1)
         Qf = PackedPoints(Xq[rows].contiguous())
         kk = k + 1 if exclude_self else k
@@ -159,6 +176,7 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i):
             If = If[keep].view(-1, k)
         out_d[rows] = Cf
         out_i[rows] = If
+    LAST_KNN["tier"] = tier
     return bad
 
 
@@ -190,10 +208,12 @@ def knn_packed(
     out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
     if _allow_screen and _use_screen(Q, Y, nq, k, metric):
-        LAST_KNN["path"] = "screen"
-        LAST_KNN["flagged"] = _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i)
-        return out_d, out_i
-    if _allow_screen:
+        bad = _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i)
+        if bad >= 0:
+            LAST_KNN["path"], LAST_KNN["flagged"] = "screen", bad
+            return out_d, out_i
+        LAST_KNN["path"], LAST_KNN["flagged"] = "exact (pilot overflow)", 0
+    elif _allow_screen:
         LAST_KNN["path"], LAST_KNN["flagged"] = "exact", 0
     ws_bytes = L.tdr_knn_workspace_bytes(nq, Y.n, k)
     ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
