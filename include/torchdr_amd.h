@@ -109,10 +109,11 @@ int tdr_csr_to_padded_f32(const int64_t* rowptr, const int32_t* cols, const floa
 int tdr_umap_prepare_f32(const float* vals, int64_t nnz, int max_iter, float* eps_per, float* next, void* scratch,
                          void* stream);
 /* neighbor_embedding/umap.py:236-292 + neighbor_embedding/base.py:617-649 (negatives) */
+int64_t tdr_umap_grad_workspace_bytes(int64_t n_total, int64_t n_rows, int nc);
 int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int64_t* rowptr,
                       const int32_t* cols, const float* eps_per, float* next, float a, float b, int n_iter,
                       int neg_rate, int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep,
-                      float eps, float* grad, void* stream);
+                      float eps, float* grad, int neg_slices, void* ws, int64_t ws_bytes, void* stream);
 /* gradients of neighbor_embedding/largevis.py:181-201 (kind 0), tsne.py:162-170 (kind 1, attraction only),
  * sne.py:160-168 (kind 2, attraction only) and infotsne.py:178-197 (kind 3: Student-t attraction + the row
  * log-sum-exp over the sampled negatives, rep_coef = 2 * repulsion_strength / N) */

@@ -110,6 +110,12 @@ struct UmapStepParams {
     float exag, rep;         // early_exaggeration_coeff_, repulsion_strength
     float eps;               // 1e-3
     float* grad;             // (n_rows, NC)
+    // sliced negative phase (large N): the positive pass stores the row's negative count and the slice passes
+    // accumulate the repulsion in gr_acc before the clamp
+    int32_t* nuse;           // (n_rows) or NULL = single pass
+    float* gr_acc;           // (n_rows, NC)
+    int64_t j_lo, j_hi;      // slice of negative indices handled by this pass
+    int first, last;
 };
 
 template <int NC>
@@ -125,7 +131,7 @@ __device__ __forceinline__ float sqdist(const Vec<NC>& a, const Vec<NC>& b, floa
 // flight per lane -- the kernel is bound by the latency of the random 8-byte reads of Z (8 MB at N = 1M,
 // larger than one XCD's L2), so memory-level parallelism is what buys throughput.  `cols` is read for every
 // edge (4 B) so that the gather does not wait for the activity test; eps_per only where the edge fires.
-template <int NC, int G, int U>
+template <int NC, int G, int U, bool POS_ONLY = false>
 __global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) {
     const int gl = threadIdx.x % G;
     const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
@@ -182,11 +188,19 @@ __global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) 
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) act += __shfl_xor(act, o, 64);
 
+    int n_use = act * P.neg_rate;
+    if (n_use > P.n_negatives) n_use = P.n_negatives;
+    if (POS_ONLY) {  // the negatives are evaluated by the slice passes (umap_neg_slice_kernel)
+        if (gl == 0) {
+            P.nuse[r] = n_use;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) P.grad[(size_t)r * NC + c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f);
+        }
+        return;
+    }
     float gr[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) gr[c] = 0.f;
-    int n_use = act * P.neg_rate;
-    if (n_use > P.n_negatives) n_use = P.n_negatives;
     const uint32_t rkey = neg_row_key(P.seed, P.iter, gi);
     const float m2b = -2.0f * P.b;
     for (int base = 0; base < n_use; base += U * G) {
@@ -222,6 +236,69 @@ __global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) 
             const float a_ = fminf(fmaxf(ga[c], -4.f), 4.f);
             const float r_ = fminf(fmaxf(gr[c], -4.f), 4.f);
             P.grad[(size_t)r * NC + c] = P.exag * a_ + P.rep * r_;
+        }
+    }
+}
+
+// Negative phase, one slice of the index range per launch.  At N = 1M the embedding (8 MB) does not fit an XCD's
+// 4 MB L2 and the ~43 uniformly random 8-byte gathers per row go to the fabric (random negatives cost 0.46 us per
+// 1000 rows there, 0.19 when Z fits L2, 0.07 when they are sequential).  Restricted to a slice of Z the gathers are
+// L2 hits.  Every pass regenerates the row's negatives from the counter hash (or reads the injected ones) and keeps
+// those inside [j_lo, j_hi); the partial sums meet in gr_acc and the last pass applies the clamp.  A pass is VALU
+// bound (hash + force math issue for every column slot whatever the number of live lanes: ~1050 issue cycles per
+// wavefront, 0.14 ms per 1M rows), so few, large slices win: 2 slices at N = 1M (0.96 -> 0.72 ms in
+// tools/umap_perf.py; 4 slices 1.02 ms).  Compacting the live items through LDS or pipelining rows in a persistent
+// grid did not pay (measured: the compaction costs what it saves at 16 lanes per row).
+template <int NC, int G, int U>
+__global__ __launch_bounds__(256) void umap_neg_slice_kernel(const UmapStepParams P) {
+    const int gl = threadIdx.x % G;
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (r >= P.n_rows) return;
+    const int64_t gi = P.row0 + r;
+    const Vec<NC> zi = load_z<NC>(P.Z, gi);
+    const int n_use = P.nuse[r];
+    float gr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) gr[c] = 0.f;
+    const uint32_t rkey = neg_row_key(P.seed, P.iter, gi);
+    const float m2b = -2.0f * P.b;
+    for (int base = 0; base < n_use; base += U * G) {
+        int64_t jn[U];
+        bool v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int col = base + u * G + gl;
+            v[u] = col < n_use;
+            jn[u] = gi;
+            if (v[u]) jn[u] = P.neg_inj ? P.neg_inj[(size_t)r * P.n_negatives + col] : sample_negative(rkey, gi, col, P.n_total);
+            v[u] = v[u] && jn[u] >= P.j_lo && jn[u] < P.j_hi;
+        }
+        Vec<NC> zj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            zj[u] = zi;
+            if (v[u]) zj[u] = load_z<NC>(P.Z, jn[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float df[NC];
+            const float d = sqdist<NC>(zi, zj[u], df);
+            if (v[u]) {
+                const float den = 1.0f + P.a * (d > 0.f ? fast_pow(d, P.b) : 0.f);
+                const float coef = fast_rcp((d + P.eps) * den) * m2b;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) gr[c] += coef * df[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) gr[c] = group_sum<G>(gr[c]);
+    if (gl == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float tot = (P.first ? 0.f : P.gr_acc[(size_t)r * NC + c]) + gr[c];
+            if (P.last) P.grad[(size_t)r * NC + c] += P.rep * fminf(fmaxf(tot, -4.f), 4.f);
+            else P.gr_acc[(size_t)r * NC + c] = tot;
         }
     }
 }
@@ -507,11 +584,36 @@ int tdr_umap_prepare_f32(const float* vals, int64_t nnz, int max_iter, float* ep
     return TDR_OK;
 }
 
-/* One evaluation of UMAP's closed-form gradient for rows [row0, row0 + n_rows): grad (n_rows, nc). */
+// Number of Z slices for the negative phase: 1 (single pass) while the embedding fits an XCD's L2, else
+// ceil(bytes / TDR_UMAP_SLICE_MB) (default 4 MiB slices), at most 4 -- every pass re-issues the row's whole negative
+// loop, so more passes cost more than the L2 hits return; TDR_UMAP_SLICE_MB=0 disables slicing.
+static int umap_neg_slices(int64_t n_total, int nc) {
+    static int mb = -1;
+    if (mb < 0) { const char* e = getenv("TDR_UMAP_SLICE_MB"); mb = e ? atoi(e) : 4; }
+    if (mb <= 0) return 1;
+    const int64_t bytes = n_total * nc * (int64_t)sizeof(float);
+    if (bytes <= (int64_t)3 << 20) return 1;
+    int64_t s = (bytes + ((int64_t)mb << 20) - 1) / ((int64_t)mb << 20);
+    if (s > 4) s = 4;
+    if (s < 2) s = 2;
+    return (int)s;
+}
+
+/* Workspace of tdr_umap_grad_f32 (0 when the single-pass kernel is used). */
+int64_t tdr_umap_grad_workspace_bytes(int64_t n_total, int64_t n_rows, int nc) {
+    if (n_total < 2 || n_rows <= 0 || (nc != 2 && nc != 3)) return 0;
+    if (umap_neg_slices(n_total, nc) <= 1) return 0;
+    return n_rows * (int64_t)sizeof(int32_t) + n_rows * nc * (int64_t)sizeof(float);
+}
+
+/* One evaluation of UMAP's closed-form gradient for rows [row0, row0 + n_rows): grad (n_rows, nc).
+ * neg_slices: 0 = automatic (L2-sliced negative phase for large N), 1 = single pass, > 1 = that many slices.
+ * The sliced phase needs ws >= n_rows * (4 + 4 * nc) bytes (tdr_umap_grad_workspace_bytes for the automatic
+ * choice); without it the single-pass kernel runs. */
 int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int64_t* rowptr,
                       const int32_t* cols, const float* eps_per, float* next, float a, float b, int n_iter,
                       int neg_rate, int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep,
-                      float eps, float* grad, void* stream) {
+                      float eps, float* grad, int neg_slices, void* ws, int64_t ws_bytes, void* stream) {
     if (!Z || !rowptr || !cols || !eps_per || !next || !grad || n_rows <= 0 || n_total < 2) return TDR_ERR_BAD_ARG;
     if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
     UmapStepParams P;
@@ -519,7 +621,28 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
     P.eps_per = eps_per; P.next = next; P.a = a; P.b = b; P.t1 = (float)(n_iter + 1); P.neg_rate = neg_rate;
     P.n_negatives = n_negatives; P.neg_inj = neg_inj; P.seed = seed; P.iter = (uint32_t)n_iter; P.exag = exag;
     P.rep = rep; P.eps = eps; P.grad = grad;
+    P.nuse = nullptr; P.gr_acc = nullptr; P.j_lo = 0; P.j_hi = n_total; P.first = 1; P.last = 1;
     hipStream_t st = (hipStream_t)stream;
+    int slices = neg_slices > 0 ? neg_slices : umap_neg_slices(n_total, nc);
+    if (slices > n_total) slices = (int)n_total;
+    const int64_t need = n_rows * (int64_t)sizeof(int32_t) + n_rows * nc * (int64_t)sizeof(float);
+    if (slices > 1 && ws && ws_bytes >= need && n_negatives > 0 && neg_rate > 0) {
+        P.nuse = (int32_t*)ws;
+        P.gr_acc = (float*)((char*)ws + n_rows * sizeof(int32_t));
+        int rc = (nc == 2) ? launch_group<16>(umap_grad_kernel<2, 16, 4, true>, P, n_rows, st)
+                           : launch_group<16>(umap_grad_kernel<3, 16, 4, true>, P, n_rows, st);
+        if (rc != TDR_OK) return rc;
+        const int64_t step = (n_total + slices - 1) / slices;
+        for (int sidx = 0; sidx < slices; ++sidx) {
+            P.j_lo = sidx * step;
+            P.j_hi = (sidx + 1) * step < n_total ? (sidx + 1) * step : n_total;
+            P.first = sidx == 0; P.last = sidx == slices - 1;
+            rc = (nc == 2) ? launch_group<16>(umap_neg_slice_kernel<2, 16, 4>, P, n_rows, st)
+                           : launch_group<16>(umap_neg_slice_kernel<3, 16, 4>, P, n_rows, st);
+            if (rc != TDR_OK) return rc;
+        }
+        return TDR_OK;
+    }
     // group width / unroll depth: TDR_UMAP_GEOM=0 (32x2), 1 (16x4, default), 2 (8x8) -- tuning knob
     static int geom = -1;
     if (geom < 0) { const char* g = getenv("TDR_UMAP_GEOM"); geom = g ? atoi(g) : 1; }

@@ -97,6 +97,10 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                                          device=self.device_)
         grad = self._grad_buf
         neg = self._neg_ptr_tensor()
+        if getattr(self, "_grad_ws", None) is None:  # scratch of the L2-sliced negative phase (large N only)
+            nbytes = _lib.lib().tdr_umap_grad_workspace_bytes(self.n_samples_in_, self.chunk_size_, self.n_components)
+            self._grad_ws = torch.empty(max(nbytes, 8) // 4 + 1, dtype=torch.int32, device=self.device_)
+            self._grad_ws_bytes = nbytes
         _lib.check(
             _lib.lib().tdr_umap_grad_f32(
                 _lib.ptr(self.embedding_), self.n_components, self.n_samples_in_, self.chunk_start_,
@@ -104,7 +108,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                 _lib.ptr(self.epoch_of_next_sample), float(self._a), float(self._b), int(self.n_iter_),
                 int(self.negative_sample_rate), int(self.n_negatives), _lib.ptr(neg), self._neg_seed,
                 float(self.early_exaggeration_coeff_), float(self.repulsion_strength), float(self._eps),
-                _lib.ptr(grad), _lib.stream_ptr(),
+                _lib.ptr(grad), 0, _lib.ptr(self._grad_ws), self._grad_ws_bytes, _lib.stream_ptr(),
             ),
             "tdr_umap_grad_f32",
         )
@@ -112,6 +116,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
 
     def clear_memory(self):
         super().clear_memory()
-        for attr in ("_csr", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf"):
+        for attr in ("_csr", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf", "_grad_ws"):
             if hasattr(self, attr):
                 delattr(self, attr)
