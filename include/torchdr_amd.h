@@ -60,6 +60,9 @@ int tdr_dense_dist_packed_f32(const float* qp, int64_t nq, int64_t q_offset, con
 int tdr_indexed_sqdist_f32(const float* X, int64_t nx, int d, const float* Y, int64_t ny, const int64_t* q,
                            int64_t nq, int nk, int take_sqrt, const int64_t* keys, float* out, void* stream);
 
+/* kNN consumers: eval/neighborhood_preservation.py:175-181 (per-row overlap of two neighbour lists) */
+int tdr_knn_overlap_i32(const int32_t* a, const int32_t* b, int64_t n, int K, float* out, void* stream);
+
 /* ---- K1s: two-stage exact kNN (fp16-split screening on the f16 matrix pipe + exact fp32 rescoring) ----
  * Same results, bit for bit, as tdr_knn_packed_f32 (hence as distance/torch.py:82-120 + utils/utils.py:215):
  * the screening pass only decides WHICH pairs get their reference-arithmetic distance evaluated, with a

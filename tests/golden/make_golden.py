@@ -311,11 +311,33 @@ def dense_affinity_fixture():
     save("affinity_dense", **out)
 
 
+def eval_fixture():
+    """eval metrics of the reference on a reference UMAP embedding: value parity of the metrics themselves and
+    the end-to-end quality bar for our estimators (same data, same hyper-parameters)."""
+    from torchdr import UMAP
+    from torchdr.eval import knn_label_accuracy, neighborhood_preservation
+
+    n, nc = 3000, 30
+    X = gmm(n, 32, 3.0, seed=81)
+    labels = torch.arange(n) % nc
+    torch.manual_seed(0)
+    Z = UMAP(n_neighbors=15, max_iter=300, random_state=0, backend=None, device="cpu").fit_transform(X)
+    out = {"X": X, "labels": labels, "Z_ref": Z}
+    for K in (10, 30):
+        out[f"np_K{K}"] = neighborhood_preservation(X, Z, K=K, backend=None, device="cpu")
+        out[f"np_per_sample_K{K}"] = neighborhood_preservation(X, Z, K=K, backend=None, device="cpu", return_per_sample=True)
+    out["acc_k10"] = knn_label_accuracy(Z, labels, k=10, backend=None, device="cpu")
+    out["acc_X_k10"] = knn_label_accuracy(X, labels, k=10, backend=None, device="cpu")
+    out["acc_per_sample_k10"] = knn_label_accuracy(Z, labels, k=10, backend=None, device="cpu", return_per_sample=True)
+    save("eval", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ALL = dict(knn=knn_fixtures, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
                umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne2_step=ne2_step_fixture,
-               distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture)
+               distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
+               eval=eval_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

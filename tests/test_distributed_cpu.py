@@ -117,3 +117,20 @@ def test_product_fails_loudly_without_gpu():
         pairwise_distances(torch.randn(50, 4), k=3)
     with pytest.raises(RuntimeError, match="no HIP device|no CPU"):
         UMAP(n_neighbors=5).fit_transform(torch.randn(100, 4))
+
+
+def test_eval_argument_errors_match_reference():
+    """Validation happens before any device work (eval/neighborhood_preservation.py:96-106, knn_labels.py:107-125)."""
+    import numpy as np
+    import pytest as _pt
+    from torchdr_amd.eval import knn_label_accuracy, neighborhood_preservation
+
+    X = np.zeros((10, 3), dtype=np.float32)
+    with _pt.raises(ValueError, match="same number of samples"):
+        neighborhood_preservation(X, np.zeros((9, 2), dtype=np.float32), K=3)
+    with _pt.raises(ValueError, match="must be less than number of samples"):
+        neighborhood_preservation(X, np.zeros((10, 2), dtype=np.float32), K=10)
+    with _pt.raises(ValueError, match="at least 1"):
+        knn_label_accuracy(X, np.zeros(10), k=0)
+    with _pt.raises(ValueError, match="same number of samples"):
+        knn_label_accuracy(X, np.zeros(9), k=2)

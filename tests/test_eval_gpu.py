@@ -1,0 +1,67 @@
+"""eval metrics (kNN consumers): value parity with the reference's own functions on a
+reference embedding, and the end-to-end QUALITY bar -- our UMAP on the same data with the same hyper-parameters
+must preserve neighbourhoods as well as the reference's UMAP does."""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.test_oracle_golden import load
+
+pytestmark = pytest.mark.gpu
+
+
+def test_neighborhood_preservation_matches_reference_values():
+    from torchdr_amd.eval import neighborhood_preservation
+
+    g = load("eval")
+    X, Z = g["X"].cuda(), g["Z_ref"].cuda()
+    for K in (10, 30):
+        per = neighborhood_preservation(X, Z, K=K, return_per_sample=True)
+        ref = g[f"np_per_sample_K{K}"]
+        assert per.shape == ref.shape
+        # identical neighbour sets give identical per-sample values; a tie at the K-th place may move one row
+        assert float((per.cpu() != ref).float().mean()) < 0.005
+        mean = neighborhood_preservation(X, Z, K=K)
+        assert abs(float(mean) - float(g[f"np_K{K}"])) < 1e-4
+
+
+def test_knn_label_accuracy_matches_reference_values():
+    from torchdr_amd.eval import knn_label_accuracy
+
+    g = load("eval")
+    Z, labels = g["Z_ref"].cuda(), g["labels"].cuda()
+    acc = knn_label_accuracy(Z, labels, k=10)
+    assert abs(float(acc) - float(g["acc_k10"])) < 1e-6
+    per = knn_label_accuracy(Z, labels, k=10, return_per_sample=True)
+    assert torch.allclose(per.cpu(), g["acc_per_sample_k10"], atol=1e-6)
+    # numpy in -> python float out (eval/knn_labels.py:181-188)
+    out = knn_label_accuracy(g["X"].numpy(), g["labels"].numpy(), k=10)
+    assert isinstance(out, float) and abs(out - float(g["acc_X_k10"])) < 1e-6
+
+
+def test_umap_quality_parity_with_reference_embedding():
+    """Same data, same hyper-parameters as the reference run stored in the fixture (its own RNG stream differs):
+    neighbourhood preservation of our embedding is at least the reference's, minus sampling noise."""
+    import torchdr_amd
+    from torchdr_amd.eval import knn_label_accuracy, neighborhood_preservation
+
+    g = load("eval")
+    X, labels = g["X"].cuda(), g["labels"].cuda()
+    Z = torchdr_amd.UMAP(n_neighbors=15, max_iter=300, random_state=0).fit_transform(X)
+    for K in (10, 30):
+        ours = float(neighborhood_preservation(X, Z, K=K))
+        ref = float(g[f"np_K{K}"])
+        assert ours > ref - 0.03, f"K={K}: ours {ours:.3f} vs reference {ref:.3f}"
+    assert float(knn_label_accuracy(Z, labels, k=10)) > float(g["acc_k10"]) - 0.01
+
+
+def test_overlap_kernel_against_broadcast_compare():
+    from torchdr_amd.eval.neighborhood_preservation import knn_overlap
+
+    gen = torch.Generator().manual_seed(3)
+    a = torch.stack([torch.randperm(500, generator=gen)[:100] for _ in range(257)]).to(torch.int32)
+    b = torch.stack([torch.randperm(500, generator=gen)[:100] for _ in range(257)]).to(torch.int32)
+    ref = (a[:, :, None] == b[:, None, :]).any(2).float().mean(1)
+    got = knn_overlap(a.cuda(), b.cuda()).cpu()
+    assert torch.equal(got, ref)

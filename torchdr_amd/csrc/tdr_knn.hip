@@ -630,6 +630,31 @@ __global__ __launch_bounds__(256, 2) void dense_dist_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// kNN-set overlap (eval/neighborhood_preservation.py:175-181): out[i] = |{p : a[i][p] in b[i][:]}| / K.
+// One wavefront per row; the b row sits in LDS and is read as a broadcast.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void knn_overlap_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                                                          int64_t n, int K, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t* bs = reinterpret_cast<int32_t*>(smem_raw) + (size_t)wave * K;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= n) return;
+    for (int p = lane; p < K; p += 64) bs[p] = b[(size_t)row * K + p];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int cnt = 0;
+    for (int p = lane; p < K; p += 64) {
+        const int32_t ai = a[(size_t)row * K + p];
+        bool hit = false;
+        for (int qq = 0; qq < K; ++qq) hit |= (bs[qq] == ai);
+        cnt += hit ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (lane == 0) out[row] = (float)cnt / (float)K;
+}
+
 static inline int pick_kq(int d) {
     if (d <= 32) return 4;
     if (d <= 64) return 8;
@@ -859,6 +884,16 @@ int tdr_dense_dist_packed_f32(const float* qp, int64_t nq, int64_t q_offset, con
         case 16: hipLaunchKernelGGL(dense_dist_kernel<16>, dim3(gx, gy), dim3(256), 0, st, qp, yp, nq, q_offset, n_db, metric, exclude_self, diag_add, out, ldo); break;
         default: hipLaunchKernelGGL(dense_dist_kernel<32>, dim3(gx, gy), dim3(256), 0, st, qp, yp, nq, q_offset, n_db, metric, exclude_self, diag_add, out, ldo); break;
     }
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* Fraction of the K indices of row i of a that also occur in row i of b (both (n, K) int32). */
+int tdr_knn_overlap_i32(const int32_t* a, const int32_t* b, int64_t n, int K, float* out, void* stream) {
+    if (!a || !b || !out || n <= 0 || K <= 0) return TDR_ERR_BAD_ARG;
+    if (K > 2048) return TDR_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)4 * K * sizeof(int32_t);
+    hipLaunchKernelGGL(knn_overlap_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, (hipStream_t)stream, a, b, n, K, out);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
