@@ -38,6 +38,18 @@ def _worker(rank, world, port, ret):
         assert torch.equal(csr.rowptr + b0, ref.rowptr[s:e + 1])
         assert torch.equal(csr.cols, ref.cols[b0:b1])
         assert torch.equal(csr.vals, ref.vals[b0:b1])
+        # --- the two-stage (screen + rescore) search on a row chunk whose start is not a multiple of 32: separate
+        #     query image, shared fp16 scale, self exclusion by global index
+        from torchdr_amd.distance import base as dbase
+
+        dbase.SCREEN_MODE = "force"
+        try:
+            csr_s = UMAPAffinity(n_neighbors=12, max_iter=100)(X, return_csr=True)
+            assert dbase.LAST_KNN["path"] == "screen"
+        finally:
+            dbase.SCREEN_MODE = "auto"
+        assert torch.equal(csr_s.rowptr, csr.rowptr) and torch.equal(csr_s.cols, csr.cols)
+        assert torch.equal(csr_s.vals, csr.vals)
         # --- estimators: every rank ends with the same finite embedding
         for cls, kw in ((torchdr_amd.UMAP, dict(n_neighbors=12, max_iter=40)),
                         (torchdr_amd.LargeVis, dict(perplexity=6, max_iter=25)),
