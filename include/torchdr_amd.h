@@ -128,6 +128,10 @@ int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64
 int tdr_sne_rowsum_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* R, void* stream);
 int tdr_sne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const float* R,
                           float coef, float* grad, void* stream);
+/* gradient of neighbor_embedding/pacmap.py:213-265 (near / mid-near / further pair losses) */
+int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_idx, int m_near, float w_nb,
+                        const int64_t* mid_idx, int m_mid, float w_mn, const int64_t* far_idx, int m_far, float w_fp,
+                        float* grad, void* stream);
 /* gradient pieces of neighbor_embedding/tsne.py:172-180 (dense Student-t partition function) */
 int tdr_tsne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* F, double* S,
                            void* stream);

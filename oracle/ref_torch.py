@@ -326,6 +326,25 @@ def infotsne_repulsion_grad(Z, neg, n_total, rows=None):
     return g
 
 
+def pacmap_grad(Z, near, mid, far, w_nb, w_mn, w_fp):
+    """d/dZ of PaCMAP's pair losses (neighbor_embedding/pacmap.py:213-265), q = 1 + d:
+    w_nb sum q/(10+q) over near pairs, w_mn sum q/(1e4+q) over mid-near pairs, w_fp sum 1/(1+q) over further pairs;
+    d/dd = 10 w_nb/(11+d)^2, 1e4 w_mn/(10001+d)^2, -w_fp/(2+d)^2.  Both endpoints of every pair move."""
+    g = torch.zeros_like(Z)
+    rows = torch.arange(Z.shape[0])
+    for idx, num, off, w in ((near, 10.0, 11.0, w_nb), (mid, 1.0e4, 10001.0, w_mn), (far, -1.0, 2.0, w_fp)):
+        if idx is None or w == 0:
+            continue
+        idx = idx.long()
+        diff = Z[rows][:, None, :] - Z[idx]
+        D = (diff**2).sum(-1)
+        coef = 2.0 * w * num / (off + D) ** 2
+        contrib = coef[:, :, None] * diff
+        g.index_add_(0, rows, contrib.sum(1))
+        g.index_add_(0, idx.reshape(-1), -contrib.reshape(-1, Z.shape[1]))
+    return g
+
+
 def sgd_momentum_step(Z, grad, buf, lr, momentum):
     """torch.optim.SGD (no dampening / nesterov / weight decay): buf = momentum*buf + grad
     (first step: buf = grad); Z -= lr * buf."""

@@ -332,12 +332,50 @@ def eval_fixture():
     save("eval", **out)
 
 
+def pacmap_fixture():
+    """PACMAPAffinity indices / rho and four PaCMAP steps (one per weight phase incl. the one-step lag of the
+    schedule): embedding, sampled mid-near / further tables, weights, autograd gradient, Adam-updated embedding."""
+    from torchdr import PACMAP
+    from torchdr.affinity import PACMAPAffinity
+
+    X = gmm(400, 16, 2.0, seed=91)
+    out = {"X": X}
+    aff = PACMAPAffinity(n_neighbors=10, backend=None)
+    _, idx = aff(X)
+    out["aff_idx"], out["aff_rho"] = idx, aff.rho_
+    rec = {}
+
+    class Probe(PACMAP):
+        def _training_step(self):
+            t = int(self.n_iter_)
+            if t < 4:
+                rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                rec[f"neg_{t}"] = self.neg_indices_.clone()
+                rec[f"w_{t}"] = torch.tensor([float(self.w_NB), float(self.w_MN), float(self.w_FP)])
+                if t == 0:
+                    rec["NN"] = self.NN_indices_.clone()
+            loss = super()._training_step()
+            if t < 4:
+                rec[f"mid_{t}"] = self.mid_near_indices.clone()
+                rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+            return loss
+
+    torch.manual_seed(4)
+    m = Probe(n_neighbors=10, max_iter=5, iter_per_phase=1, backend=None, init="normal", init_scaling=1.0,
+              random_state=4, device="cpu")
+    m.fit_transform(X)
+    for k_, v in rec.items():
+        out[f"pm_{k_}"] = v
+    save("pacmap", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ALL = dict(knn=knn_fixtures, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
                umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne2_step=ne2_step_fixture,
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
-               eval=eval_fixture)
+               eval=eval_fixture, pacmap=pacmap_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

@@ -163,6 +163,17 @@ def test_ne2_step_oracle(name):
         assert torch.allclose(Znew, g[f"{name}_Zafter_{t}"], rtol=1e-5, atol=1e-7)
 
 
+def test_pacmap_oracle():
+    """PaCMAP closed-form gradient vs the reference's autograd for the four captured steps (all weight phases)."""
+    g = load("pacmap")
+    for t in range(4):
+        w = g[f"pm_w_{t}"]
+        grad = R.pacmap_grad(g[f"pm_Z_{t}"], g["pm_NN"], g[f"pm_mid_{t}"], g[f"pm_neg_{t}"], float(w[0]), float(w[1]),
+                             float(w[2]))
+        ref = g[f"pm_grad_{t}"]
+        assert torch.allclose(grad, ref, rtol=1e-4, atol=2e-6 * float(ref.abs().max())), f"step {t}"
+
+
 def test_indexed_oracle():
     g = load("indexed")
     Z, q, keys = g["Z"], g["q"], g["keys"]

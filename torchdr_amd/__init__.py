@@ -6,6 +6,6 @@ from torchdr_amd.distance import pairwise_distances, pairwise_distances_indexed 
 from torchdr_amd.distributed import DistributedContext  # noqa: F401
 from torchdr_amd.affinity import (  # noqa: F401,E402
     Affinity, LogAffinity, SparseAffinity, SparseLogAffinity, EntropicAffinity, UMAPAffinity,
-    SymmetricEntropicAffinity, SinkhornAffinity,
+    SymmetricEntropicAffinity, SinkhornAffinity, PACMAPAffinity,
 )
-from torchdr_amd.neighbor_embedding import UMAP, LargeVis, TSNE, TSNEkhorn, SNE, InfoTSNE  # noqa: F401,E402
+from torchdr_amd.neighbor_embedding import UMAP, LargeVis, TSNE, TSNEkhorn, SNE, InfoTSNE, PACMAP  # noqa: F401,E402

@@ -86,3 +86,34 @@ class UMAPAffinity(SparseAffinity):
             return csr
         values, idx = csr.to_padded()
         return (values, idx) if return_indices else values
+
+
+class PACMAPAffinity(SparseAffinity):
+    """Neighbour selection of PaCMAP (reference ``affinity/knn_normalized.py:499-611``): the ``n_neighbors + 50``
+    exact nearest neighbours by squared distance, rescaled by ``rho_i * rho_j`` with ``rho_i`` the mean Euclidean
+    distance to the 4th-6th neighbours, of which the ``n_neighbors`` smallest are kept.  Returns ``(None,
+    indices)`` -- PaCMAP uses the pairs only.  The search is K1 / K1s; the per-row rescale and re-selection
+    (N x (n_neighbors + 50) elements) are device tensor ops.  Like the reference it refuses ``distributed``."""
+
+    def __init__(self, n_neighbors: float = 10, metric: str = "sqeuclidean", zero_diag: bool = True,
+                 device: str = "auto", backend=None, verbose: bool = False, compile: bool = False,
+                 distributed=False, _pre_processed: bool = False):
+        self.n_neighbors = n_neighbors
+        if distributed:
+            raise ValueError("[TorchDR] ERROR : PACMAPAffinity does not support distributed.")
+        super().__init__(metric=metric, zero_diag=zero_diag, device=device, backend=backend, verbose=verbose,
+                         sparsity=True, compile=compile, distributed=distributed, _pre_processed=_pre_processed)
+
+    def _compute_sparse_affinity(self, X: torch.Tensor, return_indices: bool = True, **kwargs):
+        n_samples_in = self._get_n_samples(X)
+        k = min(self.n_neighbors + 50, n_samples_in)
+        k = int(check_neighbor_param(k, n_samples_in))
+        C_, temp_indices = self._distance_matrix(X, k=k, return_indices=True)
+        # rows are ascending: columns 3..5 are the 4th-6th neighbours (kmin(C_, 6) of the reference :591)
+        self.rho_ = torch.sqrt(C_[:, :6])[:, 3:6].mean(dim=1).contiguous()
+        C_ = C_ / (self.rho_.unsqueeze(1) * self.rho_[temp_indices.long()])
+        local = torch.topk(C_, int(self.n_neighbors), dim=1, largest=False).indices
+        final_indices = torch.gather(temp_indices.long(), 1, local)
+        if return_indices:
+            return None, final_indices
+        return C_

@@ -536,6 +536,55 @@ __global__ __launch_bounds__(256) void sne_repulsion_kernel(const float* __restr
     }
 }
 
+// ---- PaCMAP pair losses (pacmap.py:213-265), closed-form gradient -------------------------------------------
+// Three index tables per row: near pairs  w_nb * q/(10+q), mid-near pairs  w_mn * q/(1e4+q), further pairs
+// w_fp / (1+q), with q = 1 + |z_i - z_j|^2.  d/dd of the three: 10 w_nb/(11+d)^2, 1e4 w_mn/(1e4+1+d)^2,
+// -w_fp/(2+d)^2; both endpoints of a pair receive the force (autograd through the index gather).
+struct PacmapParams {
+    const float* Z;
+    int64_t n;
+    const int64_t* near; int m_near; float w_nb;
+    const int64_t* mid;  int m_mid;  float w_mn;
+    const int64_t* far_; int m_far;  float w_fp;
+    float* grad;  // (n, NC), zero-initialised
+};
+
+template <int NC, int G>
+__global__ __launch_bounds__(256) void pacmap_grad_kernel(const PacmapParams P) {
+    const int gl = threadIdx.x % G;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (i >= P.n) return;
+    const Vec<NC> zi = load_z<NC>(P.Z, i);
+    float g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) g[c] = 0.f;
+    const int total = P.m_near + P.m_mid + P.m_far;
+    for (int p = gl; p < total; p += G) {
+        int64_t j;
+        float num, off, w;
+        if (p < P.m_near) { j = P.near[(size_t)i * P.m_near + p]; num = 10.0f; off = 11.0f; w = P.w_nb; }
+        else if (p < P.m_near + P.m_mid) { j = P.mid[(size_t)i * P.m_mid + (p - P.m_near)]; num = 1.0e4f; off = 10001.0f; w = P.w_mn; }
+        else { j = P.far_[(size_t)i * P.m_far + (p - P.m_near - P.m_mid)]; num = -1.0f; off = 2.0f; w = P.w_fp; }
+        if (w == 0.f) continue;
+        const Vec<NC> zj = load_z<NC>(P.Z, j);
+        float df[NC];
+        const float d = sqdist<NC>(zi, zj, df);
+        const float den = off + d;
+        const float coef = 2.0f * w * num / (den * den);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float t = coef * df[c];
+            g[c] += t;
+            unsafeAtomicAdd(&P.grad[(size_t)j * NC + c], -t);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        g[c] = group_sum<G>(g[c]);
+        if (gl == 0) unsafeAtomicAdd(&P.grad[(size_t)i * NC + c], g[c]);
+    }
+}
+
 // ---- SGD(momentum) step, torch.optim.SGD semantics (no dampening / nesterov / weight decay) ----------
 __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ Z, const float* __restrict__ grad,
                                                        float* __restrict__ buf, int64_t n, float lr, float momentum,
@@ -735,6 +784,22 @@ int tdr_sgd_step_f32(float* Z, const float* grad, float* buf, int64_t n, float l
     hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Z, grad, buf, n, lr, momentum, first, nan_flag, n_iter);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
+}
+
+/* Gradient of PaCMAP's three pair losses (neighbor_embedding/pacmap.py:213-265) on the (n, m_*) int64 index tables
+ * near / mid / far (mid or far may be NULL with m = 0); grad (n, nc) must be zeroed by the caller. */
+int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_idx, int m_near, float w_nb,
+                        const int64_t* mid_idx, int m_mid, float w_mn, const int64_t* far_idx, int m_far, float w_fp,
+                        float* grad, void* stream) {
+    if (!Z || !grad || n <= 0 || m_near < 0 || m_mid < 0 || m_far < 0) return TDR_ERR_BAD_ARG;
+    if ((m_near > 0 && !near_idx) || (m_mid > 0 && !mid_idx) || (m_far > 0 && !far_idx)) return TDR_ERR_BAD_ARG;
+    if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
+    PacmapParams P;
+    P.Z = Z; P.n = n; P.near = near_idx; P.m_near = m_near; P.w_nb = w_nb; P.mid = mid_idx; P.m_mid = m_mid; P.w_mn = w_mn;
+    P.far_ = far_idx; P.m_far = m_far; P.w_fp = w_fp; P.grad = grad;
+    hipStream_t st = (hipStream_t)stream;
+    if (nc == 2) return launch_group<16>(pacmap_grad_kernel<2, 16>, P, n, st);
+    return launch_group<16>(pacmap_grad_kernel<3, 16>, P, n, st);
 }
 
 }  // extern "C"

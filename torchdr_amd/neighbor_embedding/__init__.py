@@ -5,3 +5,4 @@ from .tsne import TSNE  # noqa: F401
 from .tsnekhorn import TSNEkhorn  # noqa: F401
 from .sne import SNE  # noqa: F401
 from .infotsne import InfoTSNE  # noqa: F401
+from .pacmap import PACMAP  # noqa: F401
