@@ -170,7 +170,7 @@ def main():
     # HBM-side traffic of the dominant kernel: PMC pass committed under profiles/ (separate rocprofv3 --pmc
     # runs of the same kernel on the same workload; FETCH_SIZE doubled per the gfx950 note of the guide)
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_knn_screen_pmc.json" if path == "screen" else "r01_knn_exact_scan_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r01_knn_screen_pmc.json" if path.startswith("screen") else "r01_knn_exact_scan_pmc.json")
     if world == 1 and (args.n, args.d, args.k) == (1_000_000, 128, 30) and os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path))
@@ -201,7 +201,8 @@ def main():
             "knn_build_sec": scan_avg_ms * 1e-3,
             "knn_path": path,
             "roofline": {
-                "kernel": ("tdr::scr::knn_screen_kernel<8,1,1> (+ knn_rescore_kernel)" if path.startswith("screen")
+                "kernel": (("tdr::scr::knn_screen_kernel<8,1,1,1>" if path == "screen-1term" else "tdr::scr::knn_screen_kernel<8,1,1,3>")
+                           + " (+ knn_rescore_kernel)" if path.startswith("screen")
                            else "tdr::knn_scan_kernel<16,1,1>") if 64 < args.d <= 128 else "tdr kNN scan",
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
@@ -210,9 +211,11 @@ def main():
             },
         }
         if path.startswith("screen"):
-            # what the matrix pipe actually executes: three f16 products per feature (h.h' + h.l' + l.h')
-            out["roofline"]["executed_tflops"] = 3.0 * achieved
-            out["roofline"]["executed_frac"] = 3.0 * achieved / peak
+            # what the matrix pipe actually executes: three f16 products per feature (h.h' + h.l' + l.h'), or one
+            # (h.h') on the one-term tier
+            mult = 1.0 if path == "screen-1term" else 3.0
+            out["roofline"]["executed_tflops"] = mult * achieved
+            out["roofline"]["executed_frac"] = mult * achieved / peak
             out["roofline"]["vs_fp32_mfma_peak"] = achieved / FP32_MFMA_PEAK_TFLOPS
             out["roofline"]["note"] = ("two-stage exact kNN: fp16-split screening (f16 matrix pipe) + exact fp32 rescoring of "
                                        "the survivors; results bit-identical to the one-stage fp32-MFMA kernel, whose own "

@@ -76,12 +76,14 @@ int tdr_pack16_f32(const float* X, int64_t n, int d, int64_t ldx, const float* n
                    float* packed16, void* stream);
 int64_t tdr_knn_screen_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, int tier);
 /* flags[i] = 1: the screening list of query i overflowed, its output rows are invalid and must be recomputed with
- * tdr_knn_packed_f32; *n_flagged (device int32, caller-zeroed) counts such queries.  tier 0: default list length
- * (k + ~17..24 spare slots for the error band); tier 1: up to k + 72 spare slots (one workgroup per CU). */
+ * tdr_knn_packed_f32; *n_flagged (device int32, caller-zeroed) counts such queries.  tier 0: one-term screening
+ * (h.h' only: a third of the matrix work, band ~2^-10 |x||y|; unsupported when k + 16 list slots do not fit);
+ * tier 1: three-term screening, k + ~17..24 spare slots; tier 2: three terms, up to k + 72 spare slots.
+ * predict_unsplit = 1: pilot slice -- flag what an un-sliced launch of the same search would flag. */
 int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
                        const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
-                       int metric, int exclude_self, int tier, const uint32_t* meta, float* out_d, int32_t* out_i,
-                       int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
+                       int metric, int exclude_self, int tier, int predict_unsplit, const uint32_t* meta, float* out_d,
+                       int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- K2 / K3: per-row root searches --------------------------------------------------------------
  * replace utils/root_search.py:17-77,147-198 driven by affinity/knn_normalized.py:445-465 (UMAP) and

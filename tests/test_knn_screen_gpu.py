@@ -123,7 +123,7 @@ def both_paths_allow_pilot(X, k):
 
 @pytest.mark.parametrize("scale,k", [(2.0, 30), (10.0, 30), (10.0, 50)])
 def test_screen_long_list_tier_equals_exact(scale, k):
-    """tier 1 (one workgroup per CU, up to k + 72 list slots, two entries per lane) against the one-stage kernel."""
+    """tier 2 (one workgroup per CU, up to k + 72 list slots, two entries per lane) against the one-stage kernel."""
     from torchdr_amd.distance import base as dbase
 
     X = gmm(6000, 128, scale, seed=21).cuda()
@@ -136,5 +136,26 @@ def test_screen_long_list_tier_equals_exact(scale, k):
         dbase.SCREEN_MODE = old
     C1 = torch.empty_like(C0)
     I1 = torch.empty_like(I0)
-    dbase._knn_screen(Xp, Xp, 0, Xp.n, k, "sqeuclidean", True, 0, C1, I1, pilot=False, tier=1)
+    dbase._knn_screen(Xp, Xp, 0, Xp.n, k, "sqeuclidean", True, 0, C1, I1, pilot=False, tier=2)
+    assert torch.equal(I0, I1) and torch.equal(C0, C1)
+
+
+@pytest.mark.parametrize("scale", [0.0, 2.0, 10.0])
+@pytest.mark.parametrize("d,k", [(128, 30), (64, 15), (100, 40)])
+def test_screen_one_term_tier_equals_exact(d, k, scale):
+    """tier 0 (h.h' only: a third of the matrix work, a 2^-10 |x||y| band, 62-entry lists): whatever overflows is
+    recomputed by the one-stage kernel, so the result is still bit-identical."""
+    from torchdr_amd.distance import base as dbase
+
+    X = gmm(6000, d, scale, seed=31 + d).cuda()
+    old = dbase.SCREEN_MODE
+    try:
+        dbase.SCREEN_MODE = "0"
+        Xp = dbase.PackedPoints(X)
+        C0, I0 = dbase.knn_packed(Xp, Xp, k, "sqeuclidean", True)
+    finally:
+        dbase.SCREEN_MODE = old
+    C1 = torch.empty_like(C0)
+    I1 = torch.empty_like(I0)
+    dbase._knn_screen(Xp, Xp, 0, Xp.n, k, "sqeuclidean", True, 0, C1, I1, pilot=False, tier=0)
     assert torch.equal(I0, I1) and torch.equal(C0, C1)

@@ -55,9 +55,13 @@ __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t
 //                     (dpad + 4) u          the reference's own k-ordered fp32 fma chain
 //                     8 u (xn + ymax2)      norm-sum association and the final roundings
 //                     2^-14 per element     l values below the fp16 normal range (covers a flush-to-zero pipe)
-__device__ __forceinline__ float screen_band(float xn, float ymax2, int dpad, int se) {
+// One-term screening (h.h' only, `terms` = 1) replaces the first term by 2 * 2^-11 + 2^-22 and has dpad products.
+__device__ __forceinline__ float screen_band(float xn, float ymax2, int dpad, int se, int terms) {
     const float u = 5.9604645e-08f;  // 2^-24
-    const float c_rel = 2.0f * (3.0f * 2.3841858e-07f + 2.0f * (3.0f * dpad + 16.0f) * u + (dpad + 4.0f) * u) * 1.01f;
+    // representation: three-term split 3 * 2^-22; one term (h.h' only) 2 * 2^-11 + 2^-22
+    const float c_repr = terms == 3 ? 3.0f * 2.3841858e-07f : (2.0f * 4.8828125e-04f + 2.3841858e-07f);
+    const float nprod = (float)(terms * dpad);
+    const float c_rel = 2.0f * (c_repr + 2.0f * (nprod + 16.0f) * u + (dpad + 4.0f) * u) * 1.01f;
     const float c_abs = 8.0f * u;
     const float inv_s = pow2f(-se);
     const float c_den = 2.0f * 6.1035156e-05f * sqrtf((float)dpad) * 1.01f * inv_s;
@@ -152,6 +156,7 @@ struct ScreenParams {
     int exclude_self;
     int n_db_tiles, tiles_per_split, n_splits;
     int dpad;
+    int terms;            // 3: h.h' + h.l' + l.h'; 1: h.h' only (wider band, a third of the matrix work)
     uint64_t* cand;       // (n_splits, nq, L) ascending screening keys
 };
 
@@ -274,16 +279,22 @@ __device__ __forceinline__ bool any_survivor(const float (&pmin)[QB][4], const f
     do {                                                                                                \
         _Pragma("unroll") for (int qb = 0; qb < QB; ++qb)                                               \
             acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bh[qb][S], acc[qb], 0, 0, 0);          \
-        _Pragma("unroll") for (int qb = 0; qb < QB; ++qb)                                               \
-            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bl[qb][S], acc[qb], 0, 0, 0);          \
-        _Pragma("unroll") for (int qb = 0; qb < QB; ++qb)                                               \
-            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, bh[qb][S], acc[qb], 0, 0, 0);          \
+        if (TERMS == 3) {                                                                               \
+            _Pragma("unroll") for (int qb = 0; qb < QB; ++qb)                                           \
+                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bl[qb][S], acc[qb], 0, 0, 0);      \
+            _Pragma("unroll") for (int qb = 0; qb < QB; ++qb)                                           \
+                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, bh[qb][S], acc[qb], 0, 0, 0);      \
+        }                                                                                               \
     } while (0)
+// LDS tile: TERMS == 3 keeps the {h, l} block pairs of a slice adjacent (block 2s, 2s+1); TERMS == 1 stages the h
+// blocks only, compacted (block s)
+#define TDR_AH(S) TDR_LDA(ap + ((TERMS == 3 ? 2 : 1) * (S)) * 1024)
+#define TDR_AL(S) (TERMS == 3 ? TDR_LDA(ap + (2 * (S) + 1) * 1024) : f16x8{})
 #define TDR_LDA(ptr) (*reinterpret_cast<const f16x8*>(ptr))
 
 // One tile step: multiply tile T (A fragments from LDS) into acc and finish tile T-1 out of `prev` between the
 // MFMA groups.  Slices are processed in double-buffered groups of GS.
-template <int KS, int ITEMS, int QB, bool HAVE_PREV>
+template <int KS, int ITEMS, int QB, int TERMS, bool HAVE_PREV>
 __device__ __forceinline__ void stile_step(const SCtx<QB>& C, const char* __restrict__ img, const f16x8 (&bh)[QB][KS],
                                            const f16x8 (&bl)[QB][KS], f32x16 (&acc)[QB], const f32x16 (&prev)[QB],
                                            const float* ynp_prev, int Tprev, float (&tau_r)[QB]) {
@@ -306,8 +317,8 @@ __device__ __forceinline__ void stile_step(const SCtx<QB>& C, const char* __rest
     f16x8 ah0[GS], al0[GS], ah1[GS], al1[GS];
 #pragma unroll
     for (int u = 0; u < GS; ++u) {
-        ah0[u] = TDR_LDA(ap + (2 * u) * 1024);
-        al0[u] = TDR_LDA(ap + (2 * u + 1) * 1024);
+        ah0[u] = TDR_AH(u);
+        al0[u] = TDR_AL(u);
     }
     int part = 0;
 #pragma unroll
@@ -315,8 +326,8 @@ __device__ __forceinline__ void stile_step(const SCtx<QB>& C, const char* __rest
         if (g + 1 < NG) {
 #pragma unroll
             for (int u = 0; u < GS; ++u) {
-                ah1[u] = TDR_LDA(ap + (2 * ((g + 1) * GS + u)) * 1024);
-                al1[u] = TDR_LDA(ap + (2 * ((g + 1) * GS + u) + 1) * 1024);
+                ah1[u] = TDR_AH((g + 1) * GS + u);
+                al1[u] = TDR_AL((g + 1) * GS + u);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -335,8 +346,8 @@ __device__ __forceinline__ void stile_step(const SCtx<QB>& C, const char* __rest
             if (g + 2 < NG) {
 #pragma unroll
                 for (int u = 0; u < GS; ++u) {
-                    ah0[u] = TDR_LDA(ap + (2 * ((g + 2) * GS + u)) * 1024);
-                    al0[u] = TDR_LDA(ap + (2 * ((g + 2) * GS + u) + 1) * 1024);
+                    ah0[u] = TDR_AH((g + 2) * GS + u);
+                    al0[u] = TDR_AL((g + 2) * GS + u);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -375,16 +386,17 @@ __device__ __forceinline__ void stile_drain(const SCtx<QB>& C, const f32x16 (&pr
 // per SIMD) when the lists fit 80 KiB.  QB = 2: 256 queries, one workgroup per CU, one wavefront per SIMD driving
 // two MFMA chains off the same A fragments -- half the LDS reads, LDS-DMA instructions and barriers per matrix
 // instruction.
-template <int KS, int ITEMS, int QB>
+template <int KS, int ITEMS, int QB, int TERMS>
 __global__ __launch_bounds__(256, (QB == 1 && ITEMS == 1) ? 2 : 1) void knn_screen_kernel(const ScreenParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NW = 4;
-    constexpr int IMG_B = KS * 2048;                 // bytes of the fragment blocks of one tile
+    constexpr int IMG_B = KS * 2048;                 // bytes of the fragment blocks of one tile image in HBM
+    constexpr int LDS_B = KS * 1024 * (TERMS == 3 ? 2 : 1);  // bytes of the staged copy (TERMS == 1: h blocks only)
     constexpr int TILE_F = KS * 512 + 64;            // floats per tile image in HBM
     constexpr int NBLK = 2 * KS;                     // 1-KiB blocks per tile
     char* tile0 = smem_raw;
-    char* tile1 = tile0 + IMG_B;
-    float* nring = reinterpret_cast<float*>(tile1 + IMG_B);              // [4 slots][64 floats]
+    char* tile1 = tile0 + LDS_B;
+    float* nring = reinterpret_cast<float*>(tile1 + LDS_B);              // [4 slots][64 floats]
     uint64_t* keys_all = reinterpret_cast<uint64_t*>(nring + 4 * 64);    // [NW][QB][32][L]
     const int Ln = P.L;
 
@@ -414,7 +426,8 @@ __global__ __launch_bounds__(256, (QB == 1 && ITEMS == 1) ? 2 : 1) void knn_scre
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 bh[qb][s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s) * 1024 + lane * 16);
-                bl[qb][s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s + 1) * 1024 + lane * 16);
+                if (TERMS == 3) bl[qb][s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s + 1) * 1024 + lane * 16);
+                else bl[qb][s] = f16x8{};
             }
             C.xn[qb] = reinterpret_cast<const float*>(qimg + IMG_B)[q];
         } else {
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(256, (QB == 1 && ITEMS == 1) ? 2 : 1) void knn_scre
         }
         const bool lane_valid = blk_active && (qt * 32 + q < P.nq);
         if (!lane_valid) C.xn[qb] = 0.f;  // rows beyond nq carry +inf norms in the image
-        C.band[qb] = screen_band(C.xn[qb], ymax2, P.dpad, se);
+        C.band[qb] = screen_band(C.xn[qb], ymax2, P.dpad, se, TERMS);
         tau_r[qb] = lane_valid ? __builtin_inff() : -__builtin_inff();
     }
     for (int p = lane; p < QB * Ln * 32; p += 64) keys[p] = KEY_SENTINEL;
@@ -440,11 +453,13 @@ __global__ __launch_bounds__(256, (QB == 1 && ITEMS == 1) ? 2 : 1) void knn_scre
         const int rel = T - t_begin;
         const float* src = P.yp + (size_t)T * TILE_F;
         char* dst = (rel & 1) ? tile1 : tile0;
+        constexpr int NSTG = (TERMS == 3) ? NBLK : KS;  // 1-KiB pieces to stage
 #pragma unroll
-        for (int t = 0; t < NBLK; t += NW) {
+        for (int t = 0; t < NSTG; t += NW) {
             const int blk = t + wave;
-            if (blk < NBLK)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + blk * 256 + lane * 4), (lptr_t)(dst + blk * 1024), 16, 0, 0);
+            const int sblk = (TERMS == 3) ? blk : 2 * blk;  // source block: every block, or the h block of slice blk
+            if (blk < NSTG)
+                __builtin_amdgcn_global_load_lds((gptr_t)(src + sblk * 256 + lane * 4), (lptr_t)(dst + blk * 1024), 16, 0, 0);
         }
         if (wave == NW - 1)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + NBLK * 256 + lane), (lptr_t)(nring + (rel & 3) * 64), 4, 0, 0);
@@ -457,20 +472,20 @@ __global__ __launch_bounds__(256, (QB == 1 && ITEMS == 1) ? 2 : 1) void knn_scre
 #define TDR_YN(Tx) (nring + (((Tx) - t_begin) & 3) * 64 + 4 * h)
     if (T < t_end) {
         if (T + 1 < t_end) stage(T + 1);
-        if (wave_active) stile_step<KS, ITEMS, QB, false>(C, tile0, bh, bl, accA, accA, nring, T, tau_r);
+        if (wave_active) stile_step<KS, ITEMS, QB, TERMS, false>(C, tile0, bh, bl, accA, accA, nring, T, tau_r);
         __syncthreads();
         ++T;
     }
     while (T < t_end) {
         {
             if (T + 1 < t_end) stage(T + 1);
-            if (wave_active) stile_step<KS, ITEMS, QB, true>(C, tile1, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
+            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, tile1, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
             __syncthreads();
             ++T;
         }
         if (T < t_end) {
             if (T + 1 < t_end) stage(T + 1);
-            if (wave_active) stile_step<KS, ITEMS, QB, true>(C, tile0, bh, bl, accA, accB, TDR_YN(T - 1), T - 1, tau_r);
+            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, tile0, bh, bl, accA, accB, TDR_YN(T - 1), T - 1, tau_r);
             __syncthreads();
             ++T;
         } else {
@@ -504,7 +519,8 @@ struct RescoreParams {
     const float* norms_y;  // (n_db)
     const uint32_t* meta;
     int64_t nq, ldq, ldy;
-    int d, dpad, k, L, n_splits, metric;
+    int d, dpad, k, L, n_splits, metric, terms;
+    int predict_unsplit;   // pilot runs: also flag queries whose band holds >= L candidates over ALL slices
     float* out_d;
     int32_t* out_i;
     int32_t* flags;        // (nq) 1 = overflow
@@ -534,7 +550,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     if (lane == 0) sc[0] = 0xFF800000u;
     const float nx = P.norms_q[qi];
     const int se = scale_exp(P.meta[0]);
-    const float band = screen_band(nx, __uint_as_float(P.meta[1]), P.dpad, se);
+    const float band = screen_band(nx, __uint_as_float(P.meta[1]), P.dpad, se, P.terms);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
@@ -560,12 +576,14 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     const float thr = u2f(sc[0]) + band;
 
     // exact distances of the candidates inside the band
+    int in_band = 0;
     for (int p0 = 0; p0 < total; p0 += 64) {
         const int p = p0 + lane;
         uint64_t key = KEY_SENTINEL;
         if (p < total) {
             const uint64_t mine = ak[p];
             if (mine != KEY_SENTINEL && u2f((uint32_t)(mine >> 32)) <= thr) {
+                ++in_band;
                 const uint32_t j = (uint32_t)(mine & 0xffffffffu);
                 const float* yr = P.Y + (size_t)j * P.ldy;
                 float acc = 0.f;
@@ -601,9 +619,14 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
             P.out_i[(size_t)qi * P.k + rank] = (int32_t)(uint32_t)(mine & 0xffffffffu);
         }
     }
+    // A database-sliced launch keeps L entries PER SLICE, so it overflows far less than the unsliced launch of the
+    // same search would; a pilot that stands for an unsliced run predicts from the merged band population instead.
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) in_band += __shfl_xor(in_band, o, 64);
+    const bool flag = any_ovf || (P.predict_unsplit && in_band >= P.L);
     if (lane == 0) {
-        P.flags[qi] = any_ovf ? 1 : 0;
-        if (any_ovf) atomicAdd(P.n_flagged, 1);
+        P.flags[qi] = flag ? 1 : 0;
+        if (flag) atomicAdd(P.n_flagged, 1);
     }
 }
 
@@ -614,15 +637,20 @@ static inline int pick_ks(int d) {
     return 0;
 }
 
-static size_t screen_lds_bytes(int ks, int L, int qb) {
-    return (size_t)2 * ks * 2048 + (size_t)4 * 64 * sizeof(float) + (size_t)4 * qb * 32 * L * sizeof(uint64_t);
+static size_t screen_lds_bytes(int ks, int L, int qb, int terms) {
+    return (size_t)2 * ks * 1024 * (terms == 3 ? 2 : 1) + (size_t)4 * 64 * sizeof(float) +
+           (size_t)4 * qb * 32 * L * sizeof(uint64_t);
 }
 
-// Workgroup shape and list length.  The list holds k entries plus spare slots for the candidates inside the
-// error band.  Default: QB = 1 (128 queries), two workgroups per CU (80 KiB each).  TDR_SCREEN_QB=2 selects
-// 256 queries per workgroup, one workgroup per CU.  Larger k: QB = 1, one workgroup per CU, two list entries
-// per lane (L <= 128).
-struct ScreenCfg { int qb, L, items, wg_per_cu; };
+// Workgroup shape, number of split terms and list length per tier.  The list holds k entries plus spare slots for
+// the candidates inside the error band.
+//   tier 0: ONE term (h.h' only): a third of the matrix work and half the staged bytes, band ~2^-10 ||x|| ||y||;
+//           the h-only tile leaves room for lists of up to 62 entries with two workgroups per CU.
+//   tier 1: three terms, band ~1e-4 ||x|| ||y||, k + ~17..24 spare slots, two workgroups per CU (80 KiB each);
+//           larger k: one workgroup per CU, two list entries per lane (L <= 128).
+//   tier 2: three terms, one workgroup per CU, up to k + 72 spare slots.
+// TDR_SCREEN_QB=2 (tier 1 only) selects 256 queries per workgroup, one workgroup per CU.
+struct ScreenCfg { int qb, L, items, wg_per_cu, terms; };
 
 static int screen_qb_pref() {
     static int qb = 0;
@@ -630,27 +658,30 @@ static int screen_qb_pref() {
     return qb;
 }
 
-static int max_list_len(int ks, int qb, size_t budget, int cap) {
+static int max_list_len(int ks, int qb, int terms, size_t budget, int cap) {
     int L = 0;
-    while (L + 1 <= cap && screen_lds_bytes(ks, L + 1, qb) <= budget) ++L;
+    while (L + 1 <= cap && screen_lds_bytes(ks, L + 1, qb, terms) <= budget) ++L;
     return L;
 }
 
-// tier 0: the default shapes above.  tier 1: one workgroup per CU and up to 72 spare slots, for data whose error
-// band holds more candidates than tier 0 can keep (large ||x|| ||y|| relative to the neighbour spacing).
 static ScreenCfg screen_cfg(int ks, int k, int tier) {
     const int spare_min = 8;
-    ScreenCfg c = {0, 0, 0, 0};
+    ScreenCfg c = {0, 0, 0, 0, 3};
     if (tier == 0) {
+        const int L2 = max_list_len(ks, 1, 1, 80 * 1024, 64);
+        if (k + 16 <= L2) { c.qb = 1; c.L = L2; c.items = 1; c.wg_per_cu = 2; c.terms = 1; }
+        return c;
+    }
+    if (tier == 1) {
         if (screen_qb_pref() == 2) {
-            const int Lq = max_list_len(ks, 2, 160 * 1024, 64);
+            const int Lq = max_list_len(ks, 2, 3, 160 * 1024, 64);
             if (k + spare_min <= Lq) { c.qb = 2; c.L = (k + 24 < Lq) ? k + 24 : Lq; c.items = 1; c.wg_per_cu = 1; return c; }
         }
-        const int L2 = max_list_len(ks, 1, 80 * 1024, 64);
+        const int L2 = max_list_len(ks, 1, 3, 80 * 1024, 64);
         if (k + spare_min <= L2) { c.qb = 1; c.L = (k + 24 < L2) ? k + 24 : L2; c.items = 1; c.wg_per_cu = 2; return c; }
     }
-    const int L1 = max_list_len(ks, 1, 160 * 1024, 128);
-    const int spare = tier == 0 ? 32 : 72;
+    const int L1 = max_list_len(ks, 1, 3, 160 * 1024, 128);
+    const int spare = tier == 1 ? 32 : 72;
     if (k + spare_min <= L1) { c.qb = 1; c.L = (k + spare < L1) ? k + spare : L1; c.items = c.L > 64 ? 2 : 1; c.wg_per_cu = 1; return c; }
     return c;
 }
@@ -679,21 +710,22 @@ static int screen_splits(int64_t nq, int n_db_tiles, const ScreenCfg& c) {
     return (int)s;
 }
 
-template <int KS, int ITEMS, int QB>
+template <int KS, int ITEMS, int QB, int TERMS>
 static int launch_screen(const ScreenParams& P, int n_wgs, size_t lds, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<KS, ITEMS, QB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<KS, ITEMS, QB, TERMS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((knn_screen_kernel<KS, ITEMS, QB>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((knn_screen_kernel<KS, ITEMS, QB, TERMS>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(256), lds, st, P);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
 
 template <int KS>
 static int launch_screen_ks(const ScreenParams& P, const ScreenCfg& c, int n_wgs, size_t lds, hipStream_t st) {
-    if (c.qb == 2) return launch_screen<KS, 1, 2>(P, n_wgs, lds, st);
-    if (c.items == 1) return launch_screen<KS, 1, 1>(P, n_wgs, lds, st);
-    return launch_screen<KS, 2, 1>(P, n_wgs, lds, st);
+    if (c.terms == 1) return launch_screen<KS, 1, 1, 1>(P, n_wgs, lds, st);
+    if (c.qb == 2) return launch_screen<KS, 1, 2, 3>(P, n_wgs, lds, st);
+    if (c.items == 1) return launch_screen<KS, 1, 1, 3>(P, n_wgs, lds, st);
+    return launch_screen<KS, 2, 1, 3>(P, n_wgs, lds, st);
 }
 
 }  // namespace scr
@@ -708,7 +740,7 @@ extern "C" {
 int tdr_knn_screen_supported(int d, int k) {
     const int ks = pick_ks(d);
     if (ks == 0 || k < 1) return 0;
-    return screen_cfg(ks, k, 0).L > 0 ? 1 : 0;
+    return screen_cfg(ks, k, 1).L > 0 ? 1 : 0;
 }
 
 /* Floats of the fp16-split image of n rows of dimension d (0 if unsupported). */
@@ -770,13 +802,16 @@ int64_t tdr_knn_screen_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, i
  * Xq / Y: the row-major fp32 blocks they were packed from; norms_q / norms_y: reference-order squared norms.
  * out_d / out_i as tdr_knn_packed_f32.  flags (nq int32): 1 where the screening list overflowed -- those rows
  * of out_d / out_i are NOT valid and must be recomputed with tdr_knn_packed_f32; *n_flagged (device int32,
- * caller-zeroed) counts them.  tier: 0 = default list length (k + ~17..24 spare slots), 1 = long lists (up to
- * k + 72 spare slots, one workgroup per CU) for data whose error band holds more candidates.
+ * caller-zeroed) counts them.  tier: 0 = one-term screening (h.h' only; cheapest, widest band; TDR_ERR_UNSUPPORTED when
+ * k + 16 list slots do not fit), 1 = three-term screening with k + ~17..24 spare slots, 2 = three terms and long
+ * lists (up to k + 72 spare slots, one workgroup per CU) for data whose error band holds more candidates.
+ * predict_unsplit = 1 (pilot slices): additionally flag queries whose error band holds >= L candidates over all
+ * database slices together, i.e. the ones an unsliced launch of the same search would flag.
  */
 int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
                        const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
-                       int metric, int exclude_self, int tier, const uint32_t* meta, float* out_d, int32_t* out_i,
-                       int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+                       int metric, int exclude_self, int tier, int predict_unsplit, const uint32_t* meta, float* out_d,
+                       int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
     if (!q16 || !Xq || !norms_q || !y16 || !Y || !norms_y || !meta || !out_d || !out_i || !flags || !n_flagged || !ws)
         return TDR_ERR_BAD_ARG;
     if (nq <= 0 || n_db <= 0 || d <= 0 || ldq < d || ldy < d) return TDR_ERR_BAD_ARG;
@@ -784,7 +819,7 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
     const int ks = pick_ks(d);
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     if (k < 1 || (int64_t)k > n_db - (exclude_self ? 1 : 0)) return TDR_ERR_BAD_ARG;
-    if (tier < 0 || tier > 1) return TDR_ERR_BAD_ARG;
+    if (tier < 0 || tier > 2) return TDR_ERR_BAD_ARG;
     const ScreenCfg cfg = screen_cfg(ks, k, tier);
     const int L = cfg.L;
     if (L == 0) return TDR_ERR_UNSUPPORTED;
@@ -797,10 +832,11 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
     P.n_splits = screen_splits(nq, P.n_db_tiles, cfg);
     P.tiles_per_split = (P.n_db_tiles + P.n_splits - 1) / P.n_splits;
     P.dpad = ks * 16;
+    P.terms = cfg.terms;
     P.cand = (uint64_t*)ws;
     const int64_t need = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
     if (ws_bytes < need) return TDR_ERR_WORKSPACE;
-    const size_t lds = screen_lds_bytes(ks, L, cfg.qb);
+    const size_t lds = screen_lds_bytes(ks, L, cfg.qb, cfg.terms);
     const int wgs = (int)((nq + 128 * cfg.qb - 1) / (128 * cfg.qb));
     int rc;
     switch (ks) {
@@ -812,7 +848,7 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
 
     RescoreParams R;
     R.cand = P.cand; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq;
-    R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.out_d = out_d;
+    R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.terms = cfg.terms; R.predict_unsplit = predict_unsplit; R.out_d = out_d;
     R.out_i = out_i; R.flags = flags; R.n_flagged = n_flagged;
     const int total = P.n_splits * L;
     const int dq = (d + 3) & ~3;

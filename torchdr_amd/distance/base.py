@@ -106,7 +106,7 @@ def _use_screen(Q, Y, nq, k, metric):
     return nq * Y.n >= _SCREEN_MIN_PAIRS and Y.n >= 4096
 
 
-def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, pilot=True, fallback=True, tier=0):
+def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, pilot=True, fallback=True, tier=1):
     """Two-stage search of queries Q[q0:q0+nq] against Y; rows whose screening list overflowed are redone
     by the one-stage exact kernel.  Returns the number of such rows, or -1 when the pilot slice says the
     data does not suit screening (nothing written; the caller uses the one-stage kernel)."""
@@ -131,7 +131,10 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
         # search would mostly fall back -- run the one-stage kernel for everything instead
         pd = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.float32, device=dev)
         pi = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.int32, device=dev)
-        for tier in (0, 1):  # default lists first, then the long-list shape
+        # cheapest first: one-term screening, three-term screening, three terms with long lists
+        for tier in (0, 1, 2):
+            if L.tdr_knn_screen_workspace_bytes(_SCREEN_PILOT_Q, Y.n, d, k, tier) == 0:
+                continue  # shape not available for this (d, k)
             bad = _knn_screen(Q, Y, q0, _SCREEN_PILOT_Q, k, metric, exclude_self, q_offset, pd, pi, pilot=False,
                               fallback=False, tier=tier)
             if bad <= _SCREEN_PILOT_MAX_FRAC * _SCREEN_PILOT_Q:
@@ -150,14 +153,15 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
         L.tdr_knn_screen_f32(
             _lib.ptr(q16[(q0 // 32) * t16:]), _lib.ptr(Xq), Q.X.stride(0), _lib.ptr(Q.norms[q0:]), nq, q_offset + q0,
             _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
-            1 if exclude_self else 0, tier, _lib.ptr(meta), _lib.ptr(out_d), _lib.ptr(out_i), _lib.ptr(flags),
+            1 if exclude_self else 0, tier, 0 if fallback else 1, _lib.ptr(meta), _lib.ptr(out_d), _lib.ptr(out_i),
+            _lib.ptr(flags),
             _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
         ),
         "tdr_knn_screen_f32",
     )
     if PROFILE is not None and fallback:
         ev1.record()
-        PROFILE.append((ev0, ev1, nq, "screen" if tier == 0 else "screen-long"))
+        PROFILE.append((ev0, ev1, nq, ("screen-1term", "screen", "screen-long")[tier]))
     bad = int(n_flagged.item())
     if bad and fallback:
         rows = flags.nonzero().squeeze(1)
