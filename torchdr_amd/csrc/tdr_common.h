@@ -66,27 +66,4 @@ __device__ __forceinline__ float group_min(float v) {
     return v;
 }
 
-// Philox4x32-10 counter-based generator (Salmon et al. 2011) -- stateless, one call per
-// (stream key, counter) pair; used for in-kernel negative sampling.
-__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
-                                             uint32_t k0, uint32_t k1) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
-__device__ __forceinline__ uint4 philox4x32(uint64_t seed, uint64_t ctr_lo, uint64_t ctr_hi) {
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-    uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
-    uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c0, c1, c2, c3, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    return make_uint4(c0, c1, c2, c3);
-}
-
 }  // namespace tdr

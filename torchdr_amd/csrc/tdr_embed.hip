@@ -104,7 +104,7 @@ struct UmapStepParams {
     float t1;                // n_iter + 1
     int neg_rate;            // negative_sample_rate
     int n_negatives;         // int(neg_rate * n_neighbors)
-    const int64_t* neg_inj;  // optional (n_rows, n_negatives) injected negatives, else Philox
+    const int64_t* neg_inj;  // optional (n_rows, n_negatives) injected negatives, else the counter hash
     uint64_t seed;
     uint32_t iter;
     float exag, rep;         // early_exaggeration_coeff_, repulsion_strength

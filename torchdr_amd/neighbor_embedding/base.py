@@ -181,7 +181,7 @@ def build_transposed_graph(P, NN, chunk_start, n_total, world_size):
 
 class NegativeSamplingNeighborEmbedding(NeighborEmbedding):
     """Repulsion through per-step negative samples (reference :426-649).  Negatives are drawn
-    in-kernel (Philox, keyed by seed / iteration / row / column) uniformly from all points except
+    in-kernel (counter hash keyed by seed / iteration / row / column) uniformly from all points except
     the row itself (``randint(0, N-1)`` then ``+1 if >= self``, reference :628-636); setting
     ``neg_indices_`` (tests) injects an explicit table instead.  ``discard_NNs=True`` uses the
     reference's exclusion-table scheme (:639-647) evaluated with torch ops and injected."""
