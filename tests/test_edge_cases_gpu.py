@@ -49,7 +49,7 @@ def test_argument_errors_match_reference_messages():
         pairwise_distances_indexed(X, query_indices=torch.zeros(2, 2, dtype=torch.long).cuda(),
                                    key_indices=torch.zeros(2, 2, dtype=torch.long).cuda())
     with pytest.raises(NotImplementedError, match="float32"):
-        pairwise_distances(X.double(), k=3)
+        pairwise_distances(X.half(), k=3)
     with pytest.raises(NotImplementedError, match="> 256"):
         pairwise_distances(torch.randn(40, 300).cuda(), k=3)
 
@@ -118,3 +118,22 @@ def test_indexed_distances_block_forms():
     D2 = pairwise_distances_indexed(X.cuda(), key_indices=ki.cuda(), metric="euclidean")
     assert D2.shape == (200, 80)
     assert torch.allclose(D2.cpu(), torch.cdist(X, X[ki]), atol=1e-4)
+
+
+def test_float64_inputs_are_accepted_and_returned_as_float64():
+    """numpy's default dtype: processed in float32 on the HIP path, handed back in float64 (one warning)."""
+    import warnings
+
+    import torchdr_amd
+    from torchdr_amd.distance import pairwise_distances
+
+    X32 = gmm(600, 16, 2.0, seed=17)
+    X64 = X32.double().numpy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Z = torchdr_amd.UMAP(n_neighbors=10, max_iter=30, random_state=0).fit_transform(X64)
+        C, I = pairwise_distances(torch.from_numpy(X64).cuda(), metric="sqeuclidean", k=5, exclude_diag=True,
+                                  return_indices=True)
+    assert isinstance(Z, np.ndarray) and Z.dtype == np.float64 and Z.shape == (600, 2) and np.isfinite(Z).all()
+    C32, I32 = pairwise_distances(X32.cuda(), metric="sqeuclidean", k=5, exclude_diag=True, return_indices=True)
+    assert C.dtype == torch.float64 and torch.equal(I, I32) and torch.equal(C.float(), C32)

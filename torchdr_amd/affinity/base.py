@@ -10,6 +10,8 @@ from typing import Any, Union
 
 import numpy as np
 import torch
+
+from torchdr_amd.utils.misc import as_float32
 import torch.distributed as dist
 import torch.nn as nn
 
@@ -41,7 +43,7 @@ class Affinity(nn.Module):
     def _prepare(self, X):
         if not self._pre_processed:
             X = to_torch(X)
-        return X.to(compute_device(X, self.device))
+        return as_float32(X).to(compute_device(X, self.device))  # float64 inputs are processed in float32
 
     def _compute_affinity(self, X: torch.Tensor):
         raise NotImplementedError("[TorchDR] ERROR : `_compute_affinity` method is not implemented.")

@@ -14,6 +14,7 @@ import torch
 
 from torchdr_amd import _lib
 from torchdr_amd.distributed import DistributedContext
+from torchdr_amd.utils.misc import as_float32
 
 LIST_METRICS = ["euclidean", "sqeuclidean", "angular"]
 _METRIC_ID = {"sqeuclidean": 0, "euclidean": 1, "angular": 2}
@@ -290,9 +291,16 @@ def pairwise_distances(
     if not isinstance(X, torch.Tensor):
         raise NotImplementedError("[torchdr_amd] DataLoader input is out of scope (SURVEY.md section 8f).")
 
+    self_search = Y is None or Y is X
+    if X.dtype == torch.float64:  # float64 in -> float32 kernels -> float64 out
+        out = pairwise_distances(as_float32(X), None if self_search else as_float32(Y), metric=metric, backend=backend,
+                                 exclude_diag=exclude_diag, k=k, return_indices=return_indices, device=device,
+                                 distributed_ctx=distributed_ctx)
+        if isinstance(out, tuple):
+            return out[0].to(torch.float64), out[1]
+        return out.to(torch.float64)
     X = _to_device(X, device)
     _lib.require_gpu(X, "X")
-    self_search = Y is None or Y is X
     if not self_search:
         Y = _to_device(Y, device)
         _lib.require_gpu(Y, "Y")

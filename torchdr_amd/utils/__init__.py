@@ -1,6 +1,7 @@
 """Host-side numeric glue mirroring the hot subset of ``torchdr/utils`` (reference
 ``utils/utils.py``, ``utils/wrappers.py``, ``utils/validation.py``, ``utils/sparse.py``)."""
 
+from .misc import as_float32  # noqa: F401
 from .misc import (  # noqa: F401
     bool_arg,
     seed_everything,

@@ -53,3 +53,23 @@ def compute_device(X: torch.Tensor, device="auto") -> torch.device:
     if dev.type != "cuda":
         raise RuntimeError(f"[torchdr_amd] device={device!r}: this build has no CPU compute path.")
     return dev
+
+
+_WARNED_FP64 = False
+
+
+def as_float32(X):
+    """float64 inputs (numpy's default) are accepted and PROCESSED IN float32: the HIP path is fp32 (the
+    north-star dtype); callers cast results back to the input dtype.  Warns once per process."""
+    import warnings
+
+    import torch
+
+    global _WARNED_FP64
+    if isinstance(X, torch.Tensor) and X.dtype == torch.float64:
+        if not _WARNED_FP64:
+            warnings.warn("[torchdr_amd] float64 input is processed in float32 on the HIP path "
+                          "(results are returned in float64).", stacklevel=3)
+            _WARNED_FP64 = True
+        return X.to(torch.float32)
+    return X
