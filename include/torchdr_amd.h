@@ -60,6 +60,15 @@ int tdr_dense_dist_packed_f32(const float* qp, int64_t nq, int64_t q_offset, con
 int tdr_indexed_sqdist_f32(const float* X, int64_t nx, int d, const float* Y, int64_t ny, const int64_t* q,
                            int64_t nq, int nk, int take_sqrt, const int64_t* keys, float* out, void* stream);
 
+/* General feature dimension (D > 256): the contraction is a plain library GEMM per (query chunk x database chunk)
+ * block, issued by the host; these three kernels are the rest of distance/torch.py:91-120 + utils/utils.py:215
+ * (norm expansion, self exclusion, running top-k with the canonical (distance, index) order). */
+int tdr_topk_init(uint64_t* run_keys, int64_t nq, int k, void* stream);
+int tdr_topk_merge_f32(const float* G, int64_t ldg, int64_t nq, int64_t nd, const float* xn, const float* yn,
+                       int64_t q_global0, int64_t d_global0, int k, int metric, int exclude_self, uint64_t* run_keys,
+                       void* stream);
+int tdr_topk_emit_f32(const uint64_t* run_keys, int64_t nq, int k, int metric, float* out_d, int32_t* out_i, void* stream);
+
 /* kNN consumers: eval/neighborhood_preservation.py:175-181 (per-row overlap of two neighbour lists) */
 int tdr_knn_overlap_i32(const int32_t* a, const int32_t* b, int64_t n, int K, float* out, void* stream);
 

@@ -50,8 +50,6 @@ def test_argument_errors_match_reference_messages():
                                    key_indices=torch.zeros(2, 2, dtype=torch.long).cuda())
     with pytest.raises(NotImplementedError, match="float32"):
         pairwise_distances(X.half(), k=3)
-    with pytest.raises(NotImplementedError, match="> 256"):
-        pairwise_distances(torch.randn(40, 300).cuda(), k=3)
 
 
 def test_estimator_surface():
@@ -137,3 +135,33 @@ def test_float64_inputs_are_accepted_and_returned_as_float64():
     assert isinstance(Z, np.ndarray) and Z.dtype == np.float64 and Z.shape == (600, 2) and np.isfinite(Z).all()
     C32, I32 = pairwise_distances(X32.cuda(), metric="sqeuclidean", k=5, exclude_diag=True, return_indices=True)
     assert C.dtype == torch.float64 and torch.equal(I, I32) and torch.equal(C.float(), C32)
+
+
+@pytest.mark.parametrize("d,k,metric", [(300, 10, "sqeuclidean"), (784, 30, "euclidean"), (513, 15, "angular")])
+def test_knn_general_feature_dimension(d, k, metric):
+    """D > 256 (e.g. 784-d images): library GEMM per block + HIP top-k merge.  Same neighbours as the CPU oracle up to
+    fp32 rounding of the contraction (the library's summation order is not MKL's)."""
+    import oracle
+    from torchdr_amd.distance import pairwise_distances
+
+    X = gmm(3000, d, 2.0, seed=d)
+    C, I = pairwise_distances(X.cuda(), metric=metric, k=k, exclude_diag=True, return_indices=True)
+    Co, Io = oracle.knn(X, k, metric, True)
+    assert I.dtype == torch.int32 and C.shape == (3000, k)
+    assert float((I.cpu() != Io).any(1).float().mean()) < 0.02          # rows touched by a near-tie swap
+    assert torch.allclose(C.cpu(), Co, rtol=1e-4, atol=1e-3 * float(Co.abs().mean()))
+    # cross search, no exclusion, and the dense form
+    Y = gmm(1500, d, 2.0, seed=d + 1)
+    C2, I2 = pairwise_distances(X.cuda(), Y.cuda(), metric=metric, k=5, return_indices=True)
+    Co2, Io2 = oracle.knn(X, 5, metric, False, Y=Y)
+    assert float((I2.cpu() != Io2).any(1).float().mean()) < 0.02
+    D = pairwise_distances(X[:200].cuda(), metric=metric, exclude_diag=True)
+    assert D.shape == (200, 200) and float(D.diagonal().min()) > 1e11
+
+
+def test_umap_on_784_dimensional_input():
+    import torchdr_amd
+
+    X = gmm(2000, 784, 3.0, seed=2).cuda()
+    Z = torchdr_amd.UMAP(n_neighbors=15, max_iter=100, random_state=0).fit_transform(X)
+    assert Z.shape == (2000, 2) and bool(torch.isfinite(Z).all())

@@ -655,6 +655,76 @@ __global__ __launch_bounds__(256) void knn_overlap_kernel(const int32_t* __restr
     if (lane == 0) out[row] = (float)cnt / (float)K;
 }
 
+// ---------------------------------------------------------------------------------------------
+// General feature dimension (D > 256): the contraction is a plain library GEMM on a (queries x database chunk)
+// block (the host calls rocBLAS through torch.mm); this kernel is the rest of distance/torch.py:91-120 -- forms
+// c = (||x||^2 + ||y||^2) - 2 G (or -G), excludes the query itself and folds the block into each query's running
+// ascending k-list (same 64-bit (distance, index) keys and cooperative insertion as the scan kernel).  One wavefront
+// per query row; the list lives in LDS during the launch and in `run_keys` between database chunks.
+// ---------------------------------------------------------------------------------------------
+struct TopkMergeParams {
+    const float* G;        // (nq, nd) block of X Y^T, row stride ldg
+    int64_t ldg;
+    int64_t nq, nd;
+    const float* xn;       // (nq) squared norms of the queries (unused for angular)
+    const float* yn;       // (nd) squared norms of this database chunk
+    int64_t q_global0;     // global index of query 0 (self exclusion)
+    int64_t d_global0;     // global index of database row 0 of this chunk
+    int k, metric, exclude_self;
+    uint64_t* run_keys;    // (nq, k) ascending, KEY_SENTINEL padded
+};
+
+template <int ITEMS>
+__global__ __launch_bounds__(256) void topk_merge_kernel(const TopkMergeParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= P.nq) return;
+    uint64_t* Lst = reinterpret_cast<uint64_t*>(smem_raw) + (size_t)wave * P.k;
+    for (int p = lane; p < P.k; p += 64) Lst[p] = P.run_keys[(size_t)qi * P.k + p];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float tau = u2f((uint32_t)(Lst[P.k - 1] >> 32));  // k-th best so far (+inf while the list is not full)
+    const float xq = (P.metric == 2) ? 0.f : P.xn[qi];
+    const float* g = P.G + (size_t)qi * P.ldg;
+    const int64_t self_j = P.exclude_self ? (P.q_global0 + qi - P.d_global0) : -1;
+    for (int64_t j0 = 0; j0 < P.nd; j0 += 64) {
+        const int64_t j = j0 + lane;
+        float c = __builtin_inff();
+        if (j < P.nd && j != self_j) {
+            const float gv = g[j];
+            c = (P.metric == 2) ? -gv : __builtin_fmaf(-2.0f, gv, __fadd_rn(xq, P.yn[j]));
+        }
+        unsigned long long m = __ballot(c <= tau);
+        while (m) {
+            const int src = __builtin_ctzll(m);
+            m &= m - 1;
+            const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), src));
+            uint64_t new_tail;
+            if (coop_insert<ITEMS>(Lst, P.k, mkkey(cv, (uint32_t)(P.d_global0 + j0 + src)), lane, new_tail))
+                tau = u2f((uint32_t)(new_tail >> 32));
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int p = lane; p < P.k; p += 64) P.run_keys[(size_t)qi * P.k + p] = Lst[p];
+}
+
+// run_keys -> (distance, index) outputs (sqrt for the euclidean metric)
+__global__ __launch_bounds__(256) void topk_emit_kernel(const uint64_t* __restrict__ keys, int64_t total, int metric,
+                                                        float* __restrict__ out_d, int32_t* __restrict__ out_i) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint64_t key = keys[i];
+    float c = u2f((uint32_t)(key >> 32));
+    if (metric == 1) c = sqrt_rn(fmaxf(c, 0.f));
+    out_d[i] = c;
+    out_i[i] = (int32_t)(uint32_t)(key & 0xffffffffu);
+}
+
+__global__ __launch_bounds__(256) void fill_keys_kernel(uint64_t* __restrict__ keys, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) keys[i] = KEY_SENTINEL;
+}
+
 static inline int pick_kq(int d) {
     if (d <= 32) return 4;
     if (d <= 64) return 8;
@@ -894,6 +964,44 @@ int tdr_knn_overlap_i32(const int32_t* a, const int32_t* b, int64_t n, int K, fl
     if (K > 2048) return TDR_ERR_UNSUPPORTED;
     const size_t lds = (size_t)4 * K * sizeof(int32_t);
     hipLaunchKernelGGL(knn_overlap_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, (hipStream_t)stream, a, b, n, K, out);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* General-D kNN, step 1: run_keys (nq, k) <- empty lists. */
+int tdr_topk_init(uint64_t* run_keys, int64_t nq, int k, void* stream) {
+    if (!run_keys || nq <= 0 || k <= 0) return TDR_ERR_BAD_ARG;
+    const int64_t total = nq * k;
+    hipLaunchKernelGGL(fill_keys_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, run_keys, total);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* Step 2 (per database chunk): fold G = Xq Yc^T (nq x nd, row stride ldg) into the running lists.  xn / yn: squared
+ * norms of the queries / of this chunk; q_global0 / d_global0: global indices of query 0 and of chunk row 0. */
+int tdr_topk_merge_f32(const float* G, int64_t ldg, int64_t nq, int64_t nd, const float* xn, const float* yn,
+                       int64_t q_global0, int64_t d_global0, int k, int metric, int exclude_self, uint64_t* run_keys,
+                       void* stream) {
+    if (!G || !run_keys || nq <= 0 || nd <= 0 || ldg < nd || k <= 0) return TDR_ERR_BAD_ARG;
+    if (metric < 0 || metric > 2 || (metric != 2 && (!xn || !yn))) return TDR_ERR_BAD_ARG;
+    if (k > 128) return TDR_ERR_UNSUPPORTED;
+    TopkMergeParams P;
+    P.G = G; P.ldg = ldg; P.nq = nq; P.nd = nd; P.xn = xn; P.yn = yn; P.q_global0 = q_global0; P.d_global0 = d_global0;
+    P.k = k; P.metric = metric; P.exclude_self = exclude_self; P.run_keys = run_keys;
+    const size_t lds = (size_t)4 * k * sizeof(uint64_t);
+    const dim3 grid((unsigned)((nq + 3) / 4));
+    if (k <= 64) hipLaunchKernelGGL(topk_merge_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(topk_merge_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, P);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* Step 3: lists -> out_d (nq, k) fp32 ascending, out_i (nq, k) int32. */
+int tdr_topk_emit_f32(const uint64_t* run_keys, int64_t nq, int k, int metric, float* out_d, int32_t* out_i, void* stream) {
+    if (!run_keys || !out_d || !out_i || nq <= 0 || k <= 0) return TDR_ERR_BAD_ARG;
+    const int64_t total = nq * k;
+    hipLaunchKernelGGL(topk_emit_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, run_keys,
+                       total, metric, out_d, out_i);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

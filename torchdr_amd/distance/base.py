@@ -260,6 +260,59 @@ def _to_device(X, device):
     return X
 
 
+_GENERAL_BQ = 4096    # query rows per library-GEMM block of the general-D path
+_GENERAL_BD = 65536   # database rows per block (4096 x 65536 fp32 = 1 GiB)
+
+
+def _knn_general(Xq, Y, k, metric, exclude_self, q_global0=0):
+    """Exact kNN for feature dimensions the register-resident MFMA kernels do not cover (D > 256): per
+    (query chunk x database chunk) block a plain library GEMM (``torch.mm`` = rocBLAS / hipBLASLt) forms X Y^T and
+    ``tdr_topk_merge_f32`` does the rest of the reference's op sequence (norm expansion, self exclusion, running
+    top-k in the canonical (distance, index) order).  Values agree with the reference to fp32 rounding (the
+    library's summation order is not MKL's), not bit for bit."""
+    L = _lib.lib()
+    nq, nd = Xq.shape[0], Y.shape[0]
+    if k > 128:
+        raise NotImplementedError(f"[torchdr_amd] k={k} > 128 is not supported for feature dimensions above 256.")
+    dev = Y.device
+    xn = (Xq * Xq).sum(1).contiguous()
+    yn = xn if Y is Xq else (Y * Y).sum(1).contiguous()
+    keys = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    st = _lib.stream_ptr()
+    _lib.check(L.tdr_topk_init(_lib.ptr(keys), nq, k, st), "tdr_topk_init")
+    mid = _METRIC_ID[metric]
+    for q0 in range(0, nq, _GENERAL_BQ):
+        q1 = min(q0 + _GENERAL_BQ, nq)
+        Xc = Xq[q0:q1]
+        for d0 in range(0, nd, _GENERAL_BD):
+            d1 = min(d0 + _GENERAL_BD, nd)
+            G = torch.mm(Xc, Y[d0:d1].t())
+            _lib.check(
+                L.tdr_topk_merge_f32(_lib.ptr(G), G.stride(0), q1 - q0, d1 - d0, _lib.ptr(xn[q0:q1]), _lib.ptr(yn[d0:d1]),
+                                     q_global0 + q0, d0, k, mid, 1 if exclude_self else 0, _lib.ptr(keys[q0:q1]), st),
+                "tdr_topk_merge_f32",
+            )
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    _lib.check(L.tdr_topk_emit_f32(_lib.ptr(keys), nq, k, mid, _lib.ptr(out_d), _lib.ptr(out_i), st), "tdr_topk_emit_f32")
+    LAST_KNN["path"], LAST_KNN["flagged"] = "general-D (library GEMM + top-k merge)", 0
+    return out_d, out_i
+
+
+def _dense_general(X, Y, metric, exclude_self):
+    """Dense distance matrix for D > 256 (distance/torch.py:82-116) with a library GEMM."""
+    G = torch.mm(X, Y.t())
+    if metric == "angular":
+        C = -G
+    else:
+        C = ((X * X).sum(1)[:, None] + (Y * Y).sum(1)[None, :]) - 2.0 * G
+        if metric == "euclidean":
+            C = C.clamp_(min=0).sqrt_()
+    if exclude_self:
+        C.diagonal().add_(_DIAG_ADD)
+    return C
+
+
 def pairwise_distances(
     X: torch.Tensor,
     Y: Optional[torch.Tensor] = None,
@@ -319,6 +372,10 @@ def pairwise_distances(
             )
         n = X.shape[0]
         c0, c1 = distributed_ctx.compute_chunk_bounds(n)
+        if X.shape[1] > 256:
+            Xc = X if X.stride(1) == 1 else X.contiguous()
+            C, I = _knn_general(Xc[c0:c1], Xc, int(k), metric, bool(exclude_diag), q_global0=c0)
+            return (C, I) if return_indices else C
         Yp = PackedPoints(X)
         Qp = Yp if c0 % 32 == 0 else PackedPoints(X[c0:c1])
         rows = slice(c0, c1) if Qp is Yp else None
@@ -330,9 +387,23 @@ def pairwise_distances(
         )
         return (C, I) if return_indices else C
 
+    do_exclude = bool(exclude_diag) and self_search
+    if X.shape[1] > 256:  # beyond the register-resident MFMA kernels: library GEMM + HIP top-k merge
+        if X.dtype != torch.float32:
+            raise NotImplementedError(f"[torchdr_amd] only float32 inputs are supported by the HIP distance kernels (got {X.dtype}).")
+        Xc = X if X.stride(1) == 1 else X.contiguous()
+        Yc = Xc if self_search else (Y if Y.stride(1) == 1 else Y.contiguous())
+        if Xc.shape[1] != Yc.shape[1]:
+            raise ValueError("[TorchDR] ERROR : X and Y must have the same number of features.")
+        if k is not None and k < Yc.shape[0]:
+            if do_exclude and k > Yc.shape[0] - 1:
+                raise ValueError("[TorchDR] ERROR : k must be smaller than the number of samples.")
+            C, I = _knn_general(Xc, Yc, int(k), metric, do_exclude)
+            return (C, I) if return_indices else C
+        C = _dense_general(Xc, Yc, metric, do_exclude)
+        return (C, None) if return_indices else C
     Xp = PackedPoints(X)
     Yp = Xp if self_search else PackedPoints(Y)
-    do_exclude = bool(exclude_diag) and self_search
     n_cols = Yp.n
 
     if k is not None and k < n_cols:
