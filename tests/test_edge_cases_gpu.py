@@ -165,3 +165,15 @@ def test_umap_on_784_dimensional_input():
     X = gmm(2000, 784, 3.0, seed=2).cuda()
     Z = torchdr_amd.UMAP(n_neighbors=15, max_iter=100, random_state=0).fit_transform(X)
     assert Z.shape == (2000, 2) and bool(torch.isfinite(Z).all())
+
+
+def test_knn_more_neighbours_than_the_scan_lists_hold():
+    """k = 200 at D = 128 (perplexity ~ 66): beyond the LDS-resident lists -> library GEMM + running top-k."""
+    import oracle
+    from torchdr_amd.distance import pairwise_distances
+
+    X = gmm(2500, 128, 2.0, seed=23)
+    C, I = pairwise_distances(X.cuda(), metric="sqeuclidean", k=200, exclude_diag=True, return_indices=True)
+    Co, Io = oracle.knn(X, 200, "sqeuclidean", True)
+    assert float((I.cpu() != Io).any(1).float().mean()) < 0.05
+    assert torch.allclose(C.cpu(), Co, rtol=1e-4, atol=1e-3 * float(Co.abs().mean()))

@@ -984,14 +984,15 @@ int tdr_topk_merge_f32(const float* G, int64_t ldg, int64_t nq, int64_t nd, cons
                        void* stream) {
     if (!G || !run_keys || nq <= 0 || nd <= 0 || ldg < nd || k <= 0) return TDR_ERR_BAD_ARG;
     if (metric < 0 || metric > 2 || (metric != 2 && (!xn || !yn))) return TDR_ERR_BAD_ARG;
-    if (k > 128) return TDR_ERR_UNSUPPORTED;
+    if (k > 256) return TDR_ERR_UNSUPPORTED;
     TopkMergeParams P;
     P.G = G; P.ldg = ldg; P.nq = nq; P.nd = nd; P.xn = xn; P.yn = yn; P.q_global0 = q_global0; P.d_global0 = d_global0;
     P.k = k; P.metric = metric; P.exclude_self = exclude_self; P.run_keys = run_keys;
     const size_t lds = (size_t)4 * k * sizeof(uint64_t);
     const dim3 grid((unsigned)((nq + 3) / 4));
     if (k <= 64) hipLaunchKernelGGL(topk_merge_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(topk_merge_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, P);
+    else if (k <= 128) hipLaunchKernelGGL(topk_merge_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(topk_merge_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, P);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

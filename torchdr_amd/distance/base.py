@@ -206,9 +206,9 @@ def knn_packed(
     nq = q1 - q0
     kmax = L.tdr_knn_max_k(d)
     if k > kmax:
-        raise NotImplementedError(
-            f"[torchdr_amd] k={k} exceeds the LDS-resident list capacity ({kmax}) for D={d}."
-        )
+        # more neighbours than the scan kernel's LDS-resident lists hold (e.g. perplexity > 40 at D = 128): the
+        # library-GEMM + running top-k path has no such limit up to k = 256
+        return _knn_general(Q.X[q0:q1], Y.X, k, metric, exclude_self, q_global0=q_offset + q0)
     dev = Y.device
     out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
@@ -272,8 +272,8 @@ def _knn_general(Xq, Y, k, metric, exclude_self, q_global0=0):
     library's summation order is not MKL's), not bit for bit."""
     L = _lib.lib()
     nq, nd = Xq.shape[0], Y.shape[0]
-    if k > 128:
-        raise NotImplementedError(f"[torchdr_amd] k={k} > 128 is not supported for feature dimensions above 256.")
+    if k > 256:
+        raise NotImplementedError(f"[torchdr_amd] k={k} > 256 is not supported by the running top-k kernel.")
     dev = Y.device
     xn = (Xq * Xq).sum(1).contiguous()
     yn = xn if Y is Xq else (Y * Y).sum(1).contiguous()
