@@ -83,6 +83,9 @@ int64_t tdr_packed16_floats(int64_t n, int d);
 int tdr_screen_meta_f32(const float* X, int64_t n, int d, int64_t ldx, const float* norms, uint32_t* meta, void* stream);
 int tdr_pack16_f32(const float* X, int64_t n, int d, int64_t ldx, const float* norms, const uint32_t* meta,
                    float* packed16, void* stream);
+/* as tdr_pack16_f32 for a re-ordered, padded image: image row r <- source row row_map[r] (-1 = padding row) */
+int tdr_pack16_mapped_f32(const float* X, int64_t n, int d, int64_t ldx, const float* norms, const uint32_t* meta,
+                          const int32_t* row_map, float* packed16, void* stream);
 int64_t tdr_knn_screen_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, int tier);
 /* flags[i] = 1: the screening list of query i overflowed, its output rows are invalid and must be recomputed with
  * tdr_knn_packed_f32; *n_flagged (device int32, caller-zeroed) counts such queries.  tier 0: one-term screening
@@ -93,6 +96,21 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
                        const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
                        int metric, int exclude_self, int tier, int predict_unsplit, const uint32_t* meta, float* out_d,
                        int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
+
+/* farthest-point (max-min) seeding of the coarse clustering behind the pruned search (library GEMMs do the Lloyd
+ * steps and the assignment, torchdr_amd/distance/base.py:ClusterIndex) */
+int64_t tdr_maxmin_workspace_bytes(int64_t S, int n_seeds);
+int tdr_maxmin_seeds_f32(const float* Xs, int64_t S, int d, int64_t ld, int n_seeds, int32_t* seeds, void* ws,
+                         int64_t ws_bytes, void* stream);
+/* Self search with cluster-bound pruning: the points are sorted by a coarse clustering and padded so that clusters
+ * start on tile boundaries (row_map); a workgroup visits clusters by increasing centre distance and skips every
+ * cluster whose ball cannot reach its queries' current thresholds.  Same results as tdr_knn_screen_f32 (and hence
+ * as tdr_knn_packed_f32) whatever the clustering; outputs are indexed by source row and hold source indices. */
+int tdr_knn_screen_clustered_f32(const float* x16, const float* X, int64_t ldx, const float* norms, int64_t n_img, int d, int k,
+                                 int metric, int exclude_self, int tier, const uint32_t* meta, const int32_t* row_map,
+                                 int n_clusters, const int32_t* tile_cluster, const int32_t* clus_tile_begin,
+                                 const float* clus_radius, const float* clus_dist, const int32_t* clus_order, float* out_d,
+                                 int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- K2 / K3: per-row root searches --------------------------------------------------------------
  * replace utils/root_search.py:17-77,147-198 driven by affinity/knn_normalized.py:445-465 (UMAP) and

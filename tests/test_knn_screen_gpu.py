@@ -159,3 +159,29 @@ def test_screen_one_term_tier_equals_exact(d, k, scale):
     I1 = torch.empty_like(I0)
     dbase._knn_screen(Xp, Xp, 0, Xp.n, k, "sqeuclidean", True, 0, C1, I1, pilot=False, tier=0)
     assert torch.equal(I0, I1) and torch.equal(C0, C1)
+
+
+@pytest.mark.parametrize("scale,n,d,k,tier", [(2.0, 20000, 128, 30, 1), (0.0, 9000, 64, 15, 0), (2.0, 7001, 100, 40, 1),
+                                              (4.0, 30000, 32, 10, 1)])
+def test_screen_cluster_pruned_scan_equals_exact(scale, n, d, k, tier):
+    """Cluster-bound pruning (points sorted by a coarse k-means, clusters padded to tile boundaries, clusters whose
+    ball cannot reach the thresholds skipped): results must not depend on it -- bit-identical to the one-stage kernel,
+    in the caller's row order and index space, ties broken by the caller's indices."""
+    from torchdr_amd.distance import base as dbase
+
+    base = gmm(n, d, scale, seed=41 + d)
+    X = torch.cat([base, base[:300]]).cuda()  # exact duplicates: tied distances across different clusters' tiles
+    old = (dbase.SCREEN_MODE, dbase.PRUNE_MODE)
+    try:
+        dbase.SCREEN_MODE, dbase.PRUNE_MODE = "0", "0"
+        Xp = dbase.PackedPoints(X)
+        C0, I0 = dbase.knn_packed(Xp, Xp, k, "sqeuclidean", True)
+        dbase.PRUNE_MODE = "force"
+        C1 = torch.empty_like(C0)
+        I1 = torch.empty_like(I0)
+        dbase._knn_screen(Xp, Xp, 0, Xp.n, k, "sqeuclidean", True, 0, C1, I1, pilot=False, tier=tier)
+        assert dbase.LAST_KNN["pruned"]
+    finally:
+        dbase.SCREEN_MODE, dbase.PRUNE_MODE = old
+    assert torch.equal(I0, I1), f"{int((I0 != I1).any(1).sum())} rows differ"
+    assert torch.equal(C0, C1)

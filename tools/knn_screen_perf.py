@@ -34,6 +34,7 @@ def run(n, d, k, scale, check=True):
             out["flagged"] = dbase.LAST_KNN["flagged"]
             out["path"] = dbase.LAST_KNN["path"]
             out["tier"] = dbase.LAST_KNN.get("tier")
+            out["pruned"] = dbase.LAST_KNN.get("pruned")
         res[name] = (C, I)
     if check:
         out["equal"] = bool(torch.equal(res["screen"][0], res["exact"][0]) and torch.equal(res["screen"][1], res["exact"][1]))

@@ -105,17 +105,21 @@ __global__ __launch_bounds__(256) void absmax2d_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X, int64_t n, int d, int64_t ldx, int ks,
                                                      const float* __restrict__ norms, const uint32_t* __restrict__ meta,
-                                                     float* __restrict__ out) {
+                                                     const int32_t* __restrict__ row_map, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float xs[];
     const int dimg = ks * 16;
     const int ld = dimg + 4;
     const int64_t row0 = (int64_t)blockIdx.x * TILE_ROWS;
     const int tid = threadIdx.x;
     const float s = pow2f(scale_exp(meta[0]));
+    // image row r' holds source row row_map[r'] (-1 = padding row) when a map is given (cluster-sorted order)
     for (int idx = tid; idx < TILE_ROWS * dimg; idx += 256) {
         const int r = idx / dimg, c = idx - r * dimg;
         float v = 0.f;
-        if (row0 + r < n && c < d) v = X[(size_t)(row0 + r) * ldx + c];
+        if (row0 + r < n && c < d) {
+            const int64_t src = row_map ? (int64_t)row_map[row0 + r] : row0 + r;
+            if (src >= 0) v = X[(size_t)src * ldx + c];
+        }
         xs[r * ld + c] = v * s;  // exact (power of two; inputs are finite and far from the fp32 range ends)
     }
     __syncthreads();
@@ -138,7 +142,13 @@ __global__ __launch_bounds__(256) void pack16_kernel(const float* __restrict__ X
     if (tid < 64) {
         float* nb = reinterpret_cast<float*>(img + (size_t)ks * 2048);
         float v = 0.f;
-        if (tid < 32) v = (row0 + tid < n) ? norms[row0 + tid] : __builtin_inff();
+        if (tid < 32) {
+            v = __builtin_inff();
+            if (row0 + tid < n) {
+                const int64_t src = row_map ? (int64_t)row_map[row0 + tid] : row0 + tid;
+                if (src >= 0) v = norms[src];
+            }
+        }
         nb[tid] = v;
     }
 }
@@ -158,6 +168,13 @@ struct ScreenParams {
     int dpad;
     int terms;            // 3: h.h' + h.l' + l.h'; 1: h.h' only (wider band, a third of the matrix work)
     uint64_t* cand;       // (n_splits, nq, L) ascending screening keys
+    // cluster-bound pruning (self search on cluster-sorted, tile-padded points; all NULL = visit every tile)
+    int n_clusters;
+    const int32_t* tile_cluster;    // (n_db_tiles) cluster of every 32-row tile (queries and database share the order)
+    const int32_t* clus_tile_begin; // (n_clusters + 1) first tile of each cluster
+    const float* clus_radius;       // (n_clusters) max member distance to the centre, rounded up
+    const float* clus_dist;         // (n_clusters, n_clusters) centre distances, rounded down
+    const int32_t* clus_order;      // (n_clusters, n_clusters) clusters by increasing centre distance (self first)
 };
 
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
@@ -236,6 +253,7 @@ __device__ __forceinline__ void screen_insert(const SCtx<QB>& C, const float (&d
                     if (j >= P.n_db || (P.exclude_self && j == (C.qt0 + qb) * 32 + sq + P.q_offset)) continue;
                     const float cred =
                         __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dv[qb][r]), src));
+                    if (!(cred < __builtin_inff())) continue;  // padding row (norm +inf)
                     const float xq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, C.xn[qb]), sq));
                     uint64_t nk, nt;
                     if (coop_insert2<ITEMS>(C.keys + ((size_t)qb * 32 + sq) * P.L, P.L, P.k - 1, mkkey(cred + xq, (uint32_t)j),
@@ -437,15 +455,16 @@ __global__ __launch_bounds__(256, (QB == 1 && ITEMS == 1) ? 2 : 1) void knn_scre
                 for (int e = 0; e < 8; ++e) { bh[qb][s][e] = (_Float16)0.f; bl[qb][s][e] = (_Float16)0.f; }
             C.xn[qb] = 0.f;
         }
-        const bool lane_valid = blk_active && (qt * 32 + q < P.nq);
-        if (!lane_valid) C.xn[qb] = 0.f;  // rows beyond nq carry +inf norms in the image
+        // rows beyond nq and the padding rows of a cluster-sorted image carry +inf norms: not queries
+        const bool lane_valid = blk_active && (qt * 32 + q < P.nq) && (C.xn[qb] < __builtin_inff());
+        if (!lane_valid) C.xn[qb] = 0.f;
         C.band[qb] = screen_band(C.xn[qb], ymax2, P.dpad, se, TERMS);
         tau_r[qb] = lane_valid ? __builtin_inff() : -__builtin_inff();
     }
     for (int p = lane; p < QB * Ln * 32; p += 64) keys[p] = KEY_SENTINEL;
 
     const int split = blockIdx.y;
-    const int t_begin = split * P.tiles_per_split;
+    int t_begin = split * P.tiles_per_split;  // also the origin of the tile / norm ring indices of the current range
     int t_end = t_begin + P.tiles_per_split;
     if (t_end > P.n_db_tiles) t_end = P.n_db_tiles;
 
@@ -464,36 +483,116 @@ __global__ __launch_bounds__(256, (QB == 1 && ITEMS == 1) ? 2 : 1) void knn_scre
         if (wave == NW - 1)
             __builtin_amdgcn_global_load_lds((gptr_t)(src + NBLK * 256 + lane), (lptr_t)(nring + (rel & 3) * 64), 4, 0, 0);
     };
-    if (t_begin < t_end) stage(t_begin);
-    __syncthreads();
-
     f32x16 accA[QB], accB[QB];
-    int T = t_begin;
+    // software-pipelined scan of the database tiles [r_begin, r_end): stage(T+1) flies while tile T multiplies and
+    // tile T-1 is filtered; the ring indices are relative to t_begin (set to r_begin by the caller)
 #define TDR_YN(Tx) (nring + (((Tx) - t_begin) & 3) * 64 + 4 * h)
-    if (T < t_end) {
-        if (T + 1 < t_end) stage(T + 1);
-        if (wave_active) stile_step<KS, ITEMS, QB, TERMS, false>(C, tile0, bh, bl, accA, accA, nring, T, tau_r);
+    auto scan_range = [&](int r_begin, int r_end) {
+        if (r_begin >= r_end) return;
+        t_begin = r_begin;
+        stage(r_begin);
         __syncthreads();
-        ++T;
-    }
-    while (T < t_end) {
+        int T = r_begin;
         {
-            if (T + 1 < t_end) stage(T + 1);
-            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, tile1, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
+            if (T + 1 < r_end) stage(T + 1);
+            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, false>(C, tile0, bh, bl, accA, accA, nring, T, tau_r);
             __syncthreads();
             ++T;
         }
-        if (T < t_end) {
-            if (T + 1 < t_end) stage(T + 1);
-            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, tile0, bh, bl, accA, accB, TDR_YN(T - 1), T - 1, tau_r);
-            __syncthreads();
-            ++T;
-        } else {
+        while (T < r_end) {
+            {
+                if (T + 1 < r_end) stage(T + 1);
+                if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, tile1, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
+                __syncthreads();
+                ++T;
+            }
+            if (T < r_end) {
+                if (T + 1 < r_end) stage(T + 1);
+                if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, tile0, bh, bl, accA, accB, TDR_YN(T - 1), T - 1, tau_r);
+                __syncthreads();
+                ++T;
+            } else {
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) accA[qb] = accB[qb];
+                for (int qb = 0; qb < QB; ++qb) accA[qb] = accB[qb];
+            }
+        }
+        if (wave_active) stile_drain<ITEMS, QB>(C, accA, TDR_YN(r_end - 1), r_end - 1, tau_r);
+        __syncthreads();  // the last norm-ring slot / tile buffers may be restaged by the next range
+    };
+
+    if (P.tile_cluster == nullptr) {
+        scan_range(t_begin, t_end);
+    } else {
+        // Cluster-bound pruning.  Points are sorted by cluster and clusters start on tile boundaries, so a wavefront's
+        // 32 queries lie in ONE cluster ball B(c_w, R_w).  Every member y of cluster c satisfies
+        // |x - y| >= |c_w - c_c| - R_w - R_c, hence its screening value a >= lb - E (E <= band / 2).  Clusters are
+        // visited by increasing centre distance from the first wavefront's cluster (tightens the thresholds early);
+        // one whose bound exceeds the largest current threshold of the workgroup can never contribute a candidate and is
+        // skipped -- thresholds only decrease, so the decision stays valid.  Exactness does not depend on the
+        // clustering quality, only the amount of skipped work does.
+        float* wred = reinterpret_cast<float*>(keys_all + (size_t)NW * QB * 32 * Ln);  // 16 floats behind the lists
+        unsigned long long* wmask = reinterpret_cast<unsigned long long*>(wred + 8);   // 4 ballots
+        int cw[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int64_t qtw = ((int64_t)blockIdx.x * NW + w) * QB;
+            cw[w] = (qtw < n_qtiles) ? P.tile_cluster[qtw] : -1;
+        }
+        float bmax = 0.f;  // band of the valid lanes only (invalid lanes were given ||x||^2 = 0)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) bmax = fmaxf(bmax, C.band[qb]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, o, 64));
+        // largest threshold of the workgroup in screening (a) units (tau <= tau_r + ||x||^2) and its largest band
+        auto wg_threshold = [&](float& tau_wg, float& band_wg) {
+            float tmax = -__builtin_inff();
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) tmax = fmaxf(tmax, tau_r[qb] + C.xn[qb]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, o, 64));
+            if (lane == 0) { wred[wave] = wave_active ? tmax : -__builtin_inff(); wred[4 + wave] = wave_active ? bmax : 0.f; }
+            __syncthreads();
+            tau_wg = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+            band_wg = fmaxf(fmaxf(wred[4], wred[5]), fmaxf(wred[6], wred[7]));
+            __syncthreads();
+        };
+        const int c0 = cw[0];
+        float tau_wg, band_wg;
+        wg_threshold(tau_wg, band_wg);
+        int idx0 = 0;
+        while (idx0 < P.n_clusters) {
+            // 256 clusters of the visiting order are tested at once, one per thread, against the current threshold
+            const int idx = idx0 + tid;
+            bool survive = false;
+            if (idx < P.n_clusters) {
+                const int c = P.clus_order[(size_t)c0 * P.n_clusters + idx];
+                const float rc = P.clus_radius[c];
+                float lb = __builtin_inff();
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    if (cw[w] < 0) continue;
+                    const float g = P.clus_dist[(size_t)cw[w] * P.n_clusters + c] - P.clus_radius[cw[w]] - rc;
+                    lb = fminf(lb, g > 0.f ? g * g : 0.f);
+                }
+                survive = !(lb * 0.9999f - band_wg > tau_wg);  // pruned only when NO member can enter any band
+            }
+            const unsigned long long m = __ballot(survive);
+            if (lane == 0) wmask[wave] = m;
+            __syncthreads();
+            int first = -1;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const unsigned long long mw = wmask[w];
+                if (first < 0 && mw) first = 64 * w + __builtin_ctzll(mw);
+            }
+            __syncthreads();
+            if (first < 0) { idx0 += 256; continue; }
+            const int c = P.clus_order[(size_t)c0 * P.n_clusters + idx0 + first];
+            scan_range(P.clus_tile_begin[c], P.clus_tile_begin[c + 1]);
+            wg_threshold(tau_wg, band_wg);  // thresholds only decrease: later tests get sharper
+            idx0 += first + 1;
         }
     }
-    if (wave_active && t_begin < t_end) stile_drain<ITEMS, QB>(C, accA, TDR_YN(t_end - 1), t_end - 1, tau_r);
 #undef TDR_YN
 
     if (wave_active) {
@@ -521,6 +620,7 @@ struct RescoreParams {
     int64_t nq, ldq, ldy;
     int d, dpad, k, L, n_splits, metric, terms;
     int predict_unsplit;   // pilot runs: also flag queries whose band holds >= L candidates over ALL slices
+    const int32_t* row_map; // screening index -> source row (cluster-sorted search), NULL = identity
     float* out_d;
     int32_t* out_i;
     int32_t* flags;        // (nq) 1 = overflow
@@ -541,14 +641,18 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     uint32_t* sc = reinterpret_cast<uint32_t*>(xq + dq);
     const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
     if (qi >= P.nq) return;  // no block-level barrier below: wavefronts are independent
+    // cluster-sorted search: screening position -> source row (outputs go to the source row, keys carry source indices
+    // so that the canonical (distance, index) order is the caller's)
+    const int64_t qs = P.row_map ? (int64_t)P.row_map[qi] : qi;
+    if (qs < 0) return;  // padding row
 
     for (int p = lane; p < total; p += 64) {
         const int s = p / P.L, r = p - s * P.L;
         ak[p] = P.cand[((size_t)s * P.nq + qi) * P.L + r];
     }
-    for (int c = lane; c < dq; c += 64) xq[c] = (c < P.d) ? P.Xq[(size_t)qi * P.ldq + c] : 0.f;
+    for (int c = lane; c < dq; c += 64) xq[c] = (c < P.d) ? P.Xq[(size_t)qs * P.ldq + c] : 0.f;
     if (lane == 0) sc[0] = 0xFF800000u;
-    const float nx = P.norms_q[qi];
+    const float nx = P.norms_q[qs];
     const int se = scale_exp(P.meta[0]);
     const float band = screen_band(nx, __uint_as_float(P.meta[1]), P.dpad, se, P.terms);
     __builtin_amdgcn_s_waitcnt(0);
@@ -584,7 +688,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
             const uint64_t mine = ak[p];
             if (mine != KEY_SENTINEL && u2f((uint32_t)(mine >> 32)) <= thr) {
                 ++in_band;
-                const uint32_t j = (uint32_t)(mine & 0xffffffffu);
+                const uint32_t jp = (uint32_t)(mine & 0xffffffffu);
+                const uint32_t j = P.row_map ? (uint32_t)P.row_map[jp] : jp;
                 const float* yr = P.Y + (size_t)j * P.ldy;
                 float acc = 0.f;
                 int c = 0;
@@ -615,8 +720,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
         if (p < total && mine != KEY_SENTINEL && rank < P.k) {
             float c = u2f((uint32_t)(mine >> 32));
             if (P.metric == 1) c = sqrt_rn(fmaxf(c, 0.f));
-            P.out_d[(size_t)qi * P.k + rank] = c;
-            P.out_i[(size_t)qi * P.k + rank] = (int32_t)(uint32_t)(mine & 0xffffffffu);
+            P.out_d[(size_t)qs * P.k + rank] = c;
+            P.out_i[(size_t)qs * P.k + rank] = (int32_t)(uint32_t)(mine & 0xffffffffu);
         }
     }
     // A database-sliced launch keeps L entries PER SLICE, so it overflows far less than the unsliced launch of the
@@ -625,9 +730,48 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     for (int o = 32; o > 0; o >>= 1) in_band += __shfl_xor(in_band, o, 64);
     const bool flag = any_ovf || (P.predict_unsplit && in_band >= P.L);
     if (lane == 0) {
-        P.flags[qi] = flag ? 1 : 0;
+        P.flags[qs] = flag ? 1 : 0;
         if (flag) atomicAdd(P.n_flagged, 1);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Farthest-point (max-min) seeding for the cluster index: step s adds the sample point farthest from the seeds chosen
+// so far.  One launch per step: distance of every sample point to the newest seed, running minimum, arg-max through
+// a 64-bit atomicMax on (distance bits, index) -- deterministic.  best[s] holds the winner of step s - 1.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxmin_step_kernel(const float* __restrict__ Xs, int64_t S, int d, int64_t ld,
+                                                          const unsigned long long* __restrict__ best_prev,
+                                                          float* __restrict__ mind, unsigned long long* __restrict__ best_next,
+                                                          int32_t* __restrict__ seeds, int step) {
+    extern __shared__ __attribute__((aligned(16))) float cur_row[];
+    const int64_t cur = (step == 0) ? 0 : (int64_t)(*best_prev & 0xffffffffull);
+    if (blockIdx.x == 0 && threadIdx.x == 0) seeds[step] = (int32_t)cur;
+    for (int c = threadIdx.x; c < d; c += 256) cur_row[c] = Xs[(size_t)cur * ld + c];
+    __syncthreads();
+    const int gl = threadIdx.x & 15;                                   // 16 lanes per sample row
+    unsigned long long key = 0ull;
+    // a few hundred workgroups stride over the rows: one atomic per wavefront and step stays cheap
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; i < S; i += (int64_t)gridDim.x * 16) {
+        float acc = 0.f;
+        const float* xr = Xs + (size_t)i * ld;
+        for (int c = gl; c < d; c += 16) { const float t = xr[c] - cur_row[c]; acc += t * t; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (gl == 0) {
+            const float m = fminf(step == 0 ? __builtin_inff() : mind[i], acc);
+            mind[i] = m;
+            const unsigned long long k2 = ((unsigned long long)__float_as_uint(m) << 32) | (unsigned long long)(uint32_t)i;
+            key = k2 > key ? k2 : key;  // m >= 0: its bits are monotone
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = ((unsigned long long)(uint32_t)__shfl_xor((int)(key >> 32), o, 64) << 32) |
+                                         (uint32_t)__shfl_xor((int)(key & 0xffffffffull), o, 64);
+        key = other > key ? other : key;
+    }
+    if ((threadIdx.x & 63) == 0 && key) atomicMax(best_next, key);
 }
 
 static inline int pick_ks(int d) {
@@ -639,7 +783,7 @@ static inline int pick_ks(int d) {
 
 static size_t screen_lds_bytes(int ks, int L, int qb, int terms) {
     return (size_t)2 * ks * 1024 * (terms == 3 ? 2 : 1) + (size_t)4 * 64 * sizeof(float) +
-           (size_t)4 * qb * 32 * L * sizeof(uint64_t);
+           (size_t)4 * qb * 32 * L * sizeof(uint64_t) + 128;  // + the workgroup reduction slots of the pruned scan
 }
 
 // Workgroup shape, number of split terms and list length per tier.  The list holds k entries plus spare slots for
@@ -773,16 +917,26 @@ int tdr_screen_meta_f32(const float* X, int64_t n, int d, int64_t ldx, const flo
     return TDR_OK;
 }
 
+int tdr_pack16_mapped_f32(const float* X, int64_t n, int d, int64_t ldx, const float* norms, const uint32_t* meta,
+                          const int32_t* row_map, float* packed16, void* stream);
+
 /* fp16-split tile images of X; norms = the reference-order squared norms written by tdr_pack_rows_f32. */
 int tdr_pack16_f32(const float* X, int64_t n, int d, int64_t ldx, const float* norms, const uint32_t* meta, float* packed16,
                    void* stream) {
+    return tdr_pack16_mapped_f32(X, n, d, ldx, norms, meta, nullptr, packed16, stream);
+}
+
+/* As tdr_pack16_f32 for a re-ordered, padded image: image row r holds source row row_map[r] of X (norms indexed by
+ * source row), -1 = padding row (zero features, +inf norm).  n = number of IMAGE rows. */
+int tdr_pack16_mapped_f32(const float* X, int64_t n, int d, int64_t ldx, const float* norms, const uint32_t* meta,
+                          const int32_t* row_map, float* packed16, void* stream) {
     if (!X || !norms || !meta || !packed16 || n <= 0 || d <= 0 || ldx < d) return TDR_ERR_BAD_ARG;
     const int ks = pick_ks(d);
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     const int64_t tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
     const size_t shmem = (size_t)TILE_ROWS * (ks * 16 + 4) * sizeof(float);
     hipLaunchKernelGGL(pack16_kernel, dim3((unsigned)tiles), dim3(256), shmem, (hipStream_t)stream, X, n, d, ldx, ks, norms,
-                       meta, packed16);
+                       meta, row_map, packed16);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
@@ -808,10 +962,21 @@ int64_t tdr_knn_screen_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, i
  * predict_unsplit = 1 (pilot slices): additionally flag queries whose error band holds >= L candidates over all
  * database slices together, i.e. the ones an unsliced launch of the same search would flag.
  */
-int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
-                       const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
-                       int metric, int exclude_self, int tier, int predict_unsplit, const uint32_t* meta, float* out_d,
-                       int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+struct ClusterTables {
+    int n_clusters;
+    const int32_t* row_map;
+    const int32_t* tile_cluster;
+    const int32_t* clus_tile_begin;
+    const float* clus_radius;
+    const float* clus_dist;
+    const int32_t* clus_order;
+};
+
+static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
+                           const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
+                           int metric, int exclude_self, int tier, int predict_unsplit, const uint32_t* meta, float* out_d,
+                           int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes,
+                           const ClusterTables* ct, void* stream) {
     if (!q16 || !Xq || !norms_q || !y16 || !Y || !norms_y || !meta || !out_d || !out_i || !flags || !n_flagged || !ws)
         return TDR_ERR_BAD_ARG;
     if (nq <= 0 || n_db <= 0 || d <= 0 || ldq < d || ldy < d) return TDR_ERR_BAD_ARG;
@@ -829,11 +994,15 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
     P.qp = q16; P.yp = y16; P.meta = meta; P.nq = nq; P.q_offset = q_offset; P.n_db = n_db; P.k = k; P.L = L;
     P.exclude_self = exclude_self;
     P.n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
-    P.n_splits = screen_splits(nq, P.n_db_tiles, cfg);
+    P.n_splits = ct ? 1 : screen_splits(nq, P.n_db_tiles, cfg);  // the pruned scan walks clusters, not database slices
     P.tiles_per_split = (P.n_db_tiles + P.n_splits - 1) / P.n_splits;
     P.dpad = ks * 16;
     P.terms = cfg.terms;
     P.cand = (uint64_t*)ws;
+    P.n_clusters = ct ? ct->n_clusters : 0;
+    P.tile_cluster = ct ? ct->tile_cluster : nullptr; P.clus_tile_begin = ct ? ct->clus_tile_begin : nullptr;
+    P.clus_radius = ct ? ct->clus_radius : nullptr; P.clus_dist = ct ? ct->clus_dist : nullptr;
+    P.clus_order = ct ? ct->clus_order : nullptr;
     const int64_t need = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
     if (ws_bytes < need) return TDR_ERR_WORKSPACE;
     const size_t lds = screen_lds_bytes(ks, L, cfg.qb, cfg.terms);
@@ -848,7 +1017,7 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
 
     RescoreParams R;
     R.cand = P.cand; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq;
-    R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.terms = cfg.terms; R.predict_unsplit = predict_unsplit; R.out_d = out_d;
+    R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.terms = cfg.terms; R.predict_unsplit = predict_unsplit; R.row_map = ct ? ct->row_map : nullptr; R.out_d = out_d;
     R.out_i = out_i; R.flags = flags; R.n_flagged = n_flagged;
     const int total = P.n_splits * L;
     const int dq = (d + 3) & ~3;
@@ -857,6 +1026,61 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(knn_rescore_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), rlds, st, R);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
+                       const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
+                       int metric, int exclude_self, int tier, int predict_unsplit, const uint32_t* meta, float* out_d,
+                       int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+    return knn_screen_impl(q16, Xq, ldq, norms_q, nq, q_offset, y16, Y, ldy, norms_y, n_db, d, k, metric, exclude_self, tier,
+                           predict_unsplit, meta, out_d, out_i, flags, n_flagged, ws, ws_bytes, nullptr, stream);
+}
+
+/*
+ * Self search with cluster-bound pruning.  x16: fp16-split image of the n_img cluster-sorted, tile-padded rows
+ * (tdr_pack16_mapped_f32 with row_map); X / norms: the n source rows.  row_map (n_img): image row -> source row or -1;
+ * tile_cluster (n_img / 32), clus_tile_begin (n_clusters + 1), clus_radius (n_clusters, rounded up), clus_dist
+ * (n_clusters^2 centre distances, rounded down), clus_order (n_clusters^2, clusters by increasing centre distance, self
+ * first).  out_d / out_i / flags are indexed by SOURCE row and hold source indices; results are those of
+ * tdr_knn_packed_f32 on the n source rows, whatever the clustering.  ws >= tdr_knn_screen_workspace_bytes(n_img, ...).
+ */
+int tdr_knn_screen_clustered_f32(const float* x16, const float* X, int64_t ldx, const float* norms, int64_t n_img, int d, int k,
+                                 int metric, int exclude_self, int tier, const uint32_t* meta, const int32_t* row_map,
+                                 int n_clusters, const int32_t* tile_cluster, const int32_t* clus_tile_begin,
+                                 const float* clus_radius, const float* clus_dist, const int32_t* clus_order, float* out_d,
+                                 int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+    if (!row_map || !tile_cluster || !clus_tile_begin || !clus_radius || !clus_dist || !clus_order || n_clusters <= 0)
+        return TDR_ERR_BAD_ARG;
+    if (n_img % TILE_ROWS != 0) return TDR_ERR_BAD_ARG;
+    ClusterTables ct = {n_clusters, row_map, tile_cluster, clus_tile_begin, clus_radius, clus_dist, clus_order};
+    return knn_screen_impl(x16, X, ldx, norms, n_img, 0, x16, X, ldx, norms, n_img, d, k, metric, exclude_self, tier, 0, meta,
+                           out_d, out_i, flags, n_flagged, ws, ws_bytes, &ct, stream);
+}
+
+/* Farthest-point seeding: seeds[0..n_seeds) <- indices into the (S, d) sample Xs (seed 0 = row 0, each next seed the
+ * row farthest from all previous ones).  ws: S floats + (n_seeds + 1) 64-bit words. */
+int64_t tdr_maxmin_workspace_bytes(int64_t S, int n_seeds) {
+    if (S <= 0 || n_seeds <= 0) return 0;
+    return ((S * (int64_t)sizeof(float) + 7) / 8) * 8 + (int64_t)(n_seeds + 1) * 8;
+}
+
+int tdr_maxmin_seeds_f32(const float* Xs, int64_t S, int d, int64_t ld, int n_seeds, int32_t* seeds, void* ws,
+                         int64_t ws_bytes, void* stream) {
+    if (!Xs || !seeds || !ws || S <= 0 || d <= 0 || ld < d || n_seeds <= 0 || n_seeds > S) return TDR_ERR_BAD_ARG;
+    if (ws_bytes < tdr_maxmin_workspace_bytes(S, n_seeds) || S > 0x7fffffffLL) return TDR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* mind = (float*)ws;
+    unsigned long long* best = (unsigned long long*)((char*)ws + ((S * sizeof(float) + 7) / 8) * 8);
+    hipError_t e = hipMemsetAsync(best, 0, (size_t)(n_seeds + 1) * 8, st);
+    if (e != hipSuccess) return (int)e;
+    unsigned grid = (unsigned)((S * 16 + 255) / 256);
+    if (grid > 512) grid = 512;
+    for (int s = 0; s < n_seeds; ++s) {
+        hipLaunchKernelGGL(maxmin_step_kernel, dim3(grid), dim3(256), (size_t)d * sizeof(float), st, Xs, S, d, ld, best + s, mind,
+                           best + s + 1, seeds, s);
+    }
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

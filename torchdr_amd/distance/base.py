@@ -97,6 +97,80 @@ class PackedPoints:
         return img, meta
 
 
+PRUNE_MODE = _os.environ.get("TDR_KNN_PRUNE", "auto")  # "0": never; "force": whenever supported; "auto": N >= 65536
+_PRUNE_MIN_N = 65536
+_PRUNE_MAX_SCAN_FRACTION = 0.5  # predicted share of tiles still visited above which the plain scan is used
+
+
+class ClusterIndex:
+    """Coarse clustering of a point block for the pruned self search: cluster-sorted row order padded to tile
+    boundaries (``row_map``), one ball (centre, radius) per cluster, centre distances and the visiting order.
+    Built with library GEMMs (``torch.mm``) -- the search result does not depend on it, only the amount of work
+    the scan can skip does."""
+
+    def __init__(self, P: "PackedPoints", n_clusters: Optional[int] = None, iters: int = 2):
+        X = P.X
+        dev = X.device
+        N, D = X.shape
+        C = int(n_clusters or min(2048, max(8, N // 1000)))
+        g = torch.Generator(device=dev).manual_seed(20240917)
+        S = min(N, 64 * C)
+        Xs = X[torch.randint(0, N, (S,), device=dev, generator=g)]
+        # farthest-point (max-min) seeding on the sample: one seed per well-separated group, an epsilon-net otherwise
+        # (random seeds leave merged clusters whose large balls every workgroup would have to scan), then Lloyd steps
+        L = _lib.lib()
+        seeds = torch.empty(C, dtype=torch.int32, device=dev)
+        ws_bytes = L.tdr_maxmin_workspace_bytes(S, C)
+        ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
+        _lib.check(L.tdr_maxmin_seeds_f32(_lib.ptr(Xs), S, D, Xs.stride(0), C, _lib.ptr(seeds), _lib.ptr(ws), ws_bytes,
+                                          _lib.stream_ptr()), "tdr_maxmin_seeds_f32")
+        cent = Xs[seeds.long()].clone()
+        for _ in range(iters):
+            lab = ((cent * cent).sum(1)[None, :] - 2.0 * torch.mm(Xs, cent.t())).argmin(1)
+            cnt = torch.bincount(lab, minlength=C).to(X.dtype)
+            sums = torch.zeros((C, D), dtype=X.dtype, device=dev).index_add_(0, lab, Xs)
+            cent = torch.where(cnt[:, None] > 0, sums / cnt.clamp(min=1)[:, None], cent)
+        cn = (cent * cent).sum(1)
+        labels = torch.empty(N, dtype=torch.int64, device=dev)
+        radius = torch.zeros(C, dtype=X.dtype, device=dev)
+        for r0 in range(0, N, 131072):
+            Xc = X[r0:r0 + 131072]
+            lab = (cn[None, :] - 2.0 * torch.mm(Xc, cent.t())).argmin(1)
+            labels[r0:r0 + 131072] = lab
+            radius.scatter_reduce_(0, lab, (Xc - cent[lab]).norm(dim=1), reduce="amax")
+        counts = torch.bincount(labels, minlength=C)
+        tiles = (counts + 31) // 32
+        tile_begin = torch.zeros(C + 1, dtype=torch.int64, device=dev)
+        tile_begin[1:] = tiles.cumsum(0)
+        n_img = int(tile_begin[-1].item()) * 32
+        order = torch.argsort(labels, stable=True)
+        first = torch.zeros(C + 1, dtype=torch.int64, device=dev)
+        first[1:] = counts.cumsum(0)
+        sl = labels[order]
+        dst = tile_begin[sl] * 32 + (torch.arange(N, device=dev) - first[sl])
+        row_map = torch.full((max(n_img, 32),), -1, dtype=torch.int32, device=dev)
+        row_map[dst] = order.to(torch.int32)
+        cd = (cent[:, None, :] - cent[None, :, :]).norm(dim=2) if C <= 2048 else torch.cdist(cent, cent)
+        self.n_clusters = C
+        self.n_img = n_img
+        self.row_map = row_map
+        self.tile_cluster = torch.repeat_interleave(torch.arange(C, device=dev, dtype=torch.int32), tiles).contiguous()
+        self.tile_begin = tile_begin.to(torch.int32).contiguous()
+        self.radius = (radius * (1.0 + 1e-5) + 1e-30).contiguous()   # rounded up
+        self.dist = (cd * (1.0 - 1e-5)).contiguous()                  # rounded down
+        self.order = torch.argsort(cd, dim=1).to(torch.int32).contiguous()
+        self.img16 = None
+        self.tiles = tiles
+
+    def scan_fraction(self, tau: float) -> float:
+        """Share of the database tiles a query block still has to visit when its thresholds are <= tau (squared
+        distance units): clusters c with max(0, |c_w - c_c| - R_w - R_c)^2 <= tau, averaged over the blocks."""
+        gap = (self.dist - self.radius[:, None] - self.radius[None, :]).clamp_(min=0)
+        t = self.tiles.to(gap.dtype)
+        visited = torch.mv((gap * gap <= tau).to(gap.dtype), t)
+        return float((visited * t).sum() / (t.sum() ** 2))
+
+
 def _use_screen(Q, Y, nq, k, metric):
     if SCREEN_MODE == "0" or metric not in ("sqeuclidean", "euclidean"):
         return False
@@ -126,6 +200,7 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
         y16, _ = Y.screen_image(meta)
         q16, _ = Q.screen_image(meta)
     t16 = L.tdr_packed16_floats(32, d)
+    pilot_tau = None
     if pilot and nq >= _SCREEN_PILOT_MIN_Q:
         # pilot: screen a small slice of the queries first; when the worst-case band swallows the spare list
         # slots for a sizeable share of them (large ||x|| ||y|| relative to the neighbour spacing), the two-stage
@@ -142,15 +217,55 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
                 break
         else:
             return -1
-    ws_bytes = L.tdr_knn_screen_workspace_bytes(nq, Y.n, d, k, tier)
-    ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
+        # largest k-th neighbour distance of the pilot slice: what the thresholds of a typical block settle at
+        kth = pd[:, -1]
+        pilot_tau = float((kth * kth if metric == "euclidean" else kth).max())
+    prune = (fallback and Q is Y and q0 == 0 and q_offset == 0 and nq == Y.n and PRUNE_MODE != "0"
+             and (PRUNE_MODE == "force" or Y.n >= _PRUNE_MIN_N))
+    if prune:
+        ci = getattr(Y, "_cluster_index", None)
+        if ci is None:
+            ci = Y._cluster_index = ClusterIndex(Y)
+        # worth it only when the cluster balls are far apart relative to the neighbour distances: predicted from the
+        # pilot's k-th distances (with slack for the blocks the pilot did not see)
+        if PRUNE_MODE != "force" and (pilot_tau is None or ci.scan_fraction(2.0 * pilot_tau) > _PRUNE_MAX_SCAN_FRACTION):
+            prune = False
     flags = torch.empty(nq, dtype=torch.int32, device=dev)
     n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
     Xq = Q.X[q0:]
-    if PROFILE is not None and fallback:
+    if prune:
+        # cluster-bound pruning: same results, the scan skips every cluster whose ball cannot reach the thresholds
+        if ci.img16 is None:
+            ci.img16 = torch.empty(L.tdr_packed16_floats(ci.n_img, d), dtype=torch.float32, device=dev)
+            _lib.check(L.tdr_pack16_mapped_f32(_lib.ptr(Y.X), ci.n_img, d, Y.X.stride(0), _lib.ptr(Y.norms), _lib.ptr(meta),
+                                               _lib.ptr(ci.row_map), _lib.ptr(ci.img16), _lib.stream_ptr()),
+                       "tdr_pack16_mapped_f32")
+        ws_bytes = L.tdr_knn_screen_workspace_bytes(ci.n_img, ci.n_img, d, k, tier)
+        ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
+        flags.zero_()
+        if PROFILE is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        _lib.check(
+            L.tdr_knn_screen_clustered_f32(
+                _lib.ptr(ci.img16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), ci.n_img, d, k, _METRIC_ID[metric],
+                1 if exclude_self else 0, tier, _lib.ptr(meta), _lib.ptr(ci.row_map), ci.n_clusters,
+                _lib.ptr(ci.tile_cluster), _lib.ptr(ci.tile_begin), _lib.ptr(ci.radius), _lib.ptr(ci.dist),
+                _lib.ptr(ci.order), _lib.ptr(out_d), _lib.ptr(out_i), _lib.ptr(flags), _lib.ptr(n_flagged), _lib.ptr(ws),
+                ws_bytes, _lib.stream_ptr(),
+            ),
+            "tdr_knn_screen_clustered_f32",
+        )
+        if PROFILE is not None:
+            ev1.record()
+            PROFILE.append((ev0, ev1, nq, ("screen-1term", "screen", "screen-long")[tier] + "-pruned"))
+    ws_bytes = L.tdr_knn_screen_workspace_bytes(nq, Y.n, d, k, tier)
+    ws = None if prune else torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
+    if PROFILE is not None and fallback and not prune:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _lib.check(
+    if not prune:
+      _lib.check(
         L.tdr_knn_screen_f32(
             _lib.ptr(q16[(q0 // 32) * t16:]), _lib.ptr(Xq), Q.X.stride(0), _lib.ptr(Q.norms[q0:]), nq, q_offset + q0,
             _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
@@ -159,8 +274,8 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
             _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
         ),
         "tdr_knn_screen_f32",
-    )
-    if PROFILE is not None and fallback:
+      )
+    if PROFILE is not None and fallback and not prune:
         ev1.record()
         PROFILE.append((ev0, ev1, nq, ("screen-1term", "screen", "screen-long")[tier]))
     bad = int(n_flagged.item())
@@ -182,6 +297,7 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
         out_d[rows] = Cf
         out_i[rows] = If
     LAST_KNN["tier"] = tier
+    LAST_KNN["pruned"] = bool(prune)
     return bad
 
 
