@@ -12,8 +12,11 @@ N-point problem (strong scaling): every rank holds X, searches its row chunk aga
 database, exchanges transposed edges (all-to-all-v) and all-gathers the updated rows every iteration.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the exact-kNN scan kernel (dominant): algorithmic flops 2*n_q*N*D per launch over
-                  its HIP-event duration measured inside the timed region, vs the fp32 MFMA peak;
+  roofline     -- the dominant kernel group of the step, measured with HIP events inside the timed region: the UMAP
+                  gradient evaluation (positive pass + L2-sliced negative passes; algorithmic HBM bytes per
+                  evaluation vs 8 TB/s) when the loop outweighs the kNN build, else the kNN scan (algorithmic flops
+                  2*n_q*N*D per launch vs the matrix peak of the pipe it runs on); the other one is reported as
+                  roofline_secondary;
   cpu_baseline -- the CPU oracle (row-chunked torch/MKL restatement of the reference's backend=None
                   path, oracle/ref_torch.py) timed on this box's host cores on a bounded sample.
 """
@@ -32,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense f16/bf16 matrix peak (v_mfma_f32_32x32x16_f16)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def gmm(n, d, scale, seed=42):
@@ -111,6 +115,7 @@ def main():
 
     from torchdr_amd import UMAP
     from torchdr_amd.distance import base as dbase
+    from torchdr_amd.neighbor_embedding import umap as umod
 
     X_cpu = gmm(args.n, args.d, args.scale)
     X = X_cpu.to(dev)
@@ -123,9 +128,25 @@ def main():
         torch.cuda.synchronize()
 
     keep = {}
+    # wall (HIP events) of the whole kNN-graph build = pilots + cluster index + scan + rescoring + any exact fallback
+    knn_total_events = []
+    _knn_packed = dbase.knn_packed
+
+    def _timed_knn_packed(*a, **kw):
+        if dbase.PROFILE is None or not kw.get("_allow_screen", True):
+            return _knn_packed(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = _knn_packed(*a, **kw)
+        e1.record()
+        knn_total_events.append((e0, e1))
+        return out
+
+    dbase.knn_packed = _timed_knn_packed
 
     def one_step(record):
         dbase.PROFILE = [] if record else None
+        umod.PROFILE = [] if record else None
         m = UMAP(n_neighbors=args.k, max_iter=args.max_iter, random_state=0, backend=None)
         if record:
             _orig = m.clear_memory
@@ -142,41 +163,78 @@ def main():
     for _ in range(args.warmup):
         one_step(False)
     barrier()
-    knn_events = []
+    knn_events, grad_events = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(True)
         knn_events.extend(dbase.PROFILE)
+        grad_events.extend(umod.PROFILE)
     barrier()
     elapsed = time.perf_counter() - t0
     dbase.PROFILE = None
+    umod.PROFILE = None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # kernel-level numbers for the dominant kernel (HIP events recorded on the launch stream).  Large searches
-    # take the two-stage path: the screening kernel (fp16-split products on the f16 matrix pipe, 3 MFMA products
-    # per feature) followed by the exact-rescoring kernel (~0.4 % of the time, inside the same event pair).
+    # ---- kernel-level numbers (HIP events recorded on the launch stream inside the timed region) -------------------
+    # (1) kNN build: one event pair around the scan (+ rescoring) launches.  Large searches take the two-stage path
+    #     (fp16-split screening on the f16 matrix pipe + exact fp32 rescoring), on clustered data with cluster-bound
+    #     pruning, which skips most database tiles: its rate is an EFFECTIVE one (algorithmic flops / time).
     scan_ms = [e[0].elapsed_time(e[1]) for e in knn_events]
     nq = knn_events[0][2] if knn_events else 0
     path = knn_events[0][3] if knn_events else "exact"
     scan_avg_ms = sum(scan_ms) / max(len(scan_ms), 1)
     flops = 2.0 * nq * args.n * args.d
-    achieved = flops / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
-    peak = F16_MFMA_PEAK_TFLOPS if path.startswith("screen") else FP32_MFMA_PEAK_TFLOPS
+    knn_tflops = flops / (scan_avg_ms * 1e-3) / 1e12 if scan_avg_ms > 0 else 0.0
+    tot = [e0.elapsed_time(e1) for (e0, e1) in knn_total_events]
+    knn_build_ms = sum(tot) / max(len(tot), 1) if tot else scan_avg_ms
+    knn_peak = F16_MFMA_PEAK_TFLOPS if path.startswith("screen") else FP32_MFMA_PEAK_TFLOPS
+    # (2) UMAP gradient evaluation (positive pass + negative slice passes), sampled every PROFILE_EVERY iterations.
+    #     Algorithmic HBM bytes per evaluation: the CSR stream nnz * (4 col + 4 eps_per +
+    #     4 next) + per active edge 4 (next write) + 8 (z_j) + per used negative 8 (z_j) + per row 8 + 8, with the
+    #     measured nnz and the expected 8.6 active edges / 43 used negatives per row and iteration.
+    grad_ms = [e[0].elapsed_time(e[1]) for e in grad_events]
+    grad_avg_ms = sum(grad_ms) / max(len(grad_ms), 1)
+    nnz = grad_events[0][2] if grad_events else 0
+    rows = (args.n + world - 1) // world
+    grad_bytes = 12.0 * nnz + rows * (8.6 * 12.0 + 43.0 * 8.0 + 16.0)
+    grad_gbs = grad_bytes / (grad_avg_ms * 1e-3) / 1e9 if grad_avg_ms > 0 else 0.0
 
-    # HBM-side traffic of the dominant kernel: PMC pass committed under profiles/ (separate rocprofv3 --pmc
-    # runs of the same kernel on the same workload; FETCH_SIZE doubled per the gfx950 note of the guide)
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_knn_screen_pmc.json" if path.startswith("screen") else "r01_knn_exact_scan_pmc.json")
-    if world == 1 and (args.n, args.d, args.k) == (1_000_000, 128, 30) and os.path.exists(pmc_path):
+    def pmc_traffic(name):
+        # HBM-side traffic from the PMC passes committed under profiles/ (separate rocprofv3 --pmc runs of the same
+        # kernels on the same workload; FETCH_SIZE doubled per the gfx950 note of the guide), bytes per launch group
+        f = os.path.join(ROOT, "profiles", name)
+        if world != 1 or (args.n, args.d, args.k) != (1_000_000, 128, 30) or not os.path.exists(f):
+            return None
         try:
-            pmc = json.load(open(pmc_path))
-            traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            pmc = json.load(open(f))
+            return (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
         except Exception:
-            traffic = None
+            return None
+
+    knn_pmc = {"screen": "r01_knn_screen_pmc.json", "exact": "r01_knn_exact_scan_pmc.json"}.get(path)
+    roof_knn = {
+        "kernel": {"exact": "tdr::knn_scan_kernel (fp32 MFMA)"}.get(path, "tdr::scr::knn_screen_kernel (" + path + ") + knn_rescore_kernel"),
+        "bound": "mfma", "achieved": knn_tflops, "peak": knn_peak, "unit": "TFLOP/s",
+        "frac": None if path.endswith("pruned") else knn_tflops / knn_peak,
+        "traffic": pmc_traffic(knn_pmc) if knn_pmc else None,
+        "algorithmic_flops_per_launch": flops, "avg_launch_ms": scan_avg_ms,
+        "note": ("two-stage exact kNN (fp16-split screening + exact fp32 rescoring; results bit-identical to the one-stage "
+                 "fp32-MFMA kernel)" + ("; cluster-bound pruning skips most tiles, so `achieved` is algorithmic flops / time, "
+                                        "not matrix-pipe utilisation" if path.endswith("pruned") else "")),
+    }
+    roof_grad = {
+        "kernel": "tdr::umap_grad_kernel<2,16,4,true> + tdr::umap_neg_slice_kernel<2,16,4> (one gradient evaluation)",
+        "bound": "hbm", "achieved": grad_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_gbs / HBM_PEAK_GBS,
+        "traffic": pmc_traffic("r01_umap_grad_pmc.json"),
+        "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_avg_ms, "evaluations_sampled": len(grad_ms),
+        "note": "random 8-byte gathers of the embedding + VALU-issue-bound force math dominate; see DESIGN.md section 3",
+    }
+    loop_ms = grad_avg_ms * args.max_iter
+    dominant, secondary = (roof_grad, roof_knn) if loop_ms >= scan_avg_ms else (roof_knn, roof_grad)
 
     if rank == 0:
         out = {
@@ -198,28 +256,12 @@ def main():
                             f"{args.scale}, sigma 0.5, seed 42)",
                 "parallelism": f"rows sharded over {world} GPU(s)",
             },
-            "knn_build_sec": scan_avg_ms * 1e-3,
+            "knn_build_sec": knn_build_ms * 1e-3,
+            "knn_scan_sec": scan_avg_ms * 1e-3,
             "knn_path": path,
-            "roofline": {
-                "kernel": (("tdr::scr::knn_screen_kernel<8,1,1,1>" if path == "screen-1term" else "tdr::scr::knn_screen_kernel<8,1,1,3>")
-                           + " (+ knn_rescore_kernel)" if path.startswith("screen")
-                           else "tdr::knn_scan_kernel<16,1,1>") if 64 < args.d <= 128 else "tdr kNN scan",
-                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": traffic,
-                "traffic_note": "bytes at the L2->fabric boundary per launch (incl. Infinity Cache hits), from the PMC json under profiles/",
-                "algorithmic_flops_per_launch": flops, "avg_launch_ms": scan_avg_ms,
-            },
+            "roofline": dominant,
+            "roofline_secondary": secondary,
         }
-        if path.startswith("screen"):
-            # what the matrix pipe actually executes: three f16 products per feature (h.h' + h.l' + l.h'), or one
-            # (h.h') on the one-term tier
-            mult = 1.0 if path == "screen-1term" else 3.0
-            out["roofline"]["executed_tflops"] = mult * achieved
-            out["roofline"]["executed_frac"] = mult * achieved / peak
-            out["roofline"]["vs_fp32_mfma_peak"] = achieved / FP32_MFMA_PEAK_TFLOPS
-            out["roofline"]["note"] = ("two-stage exact kNN: fp16-split screening (f16 matrix pipe) + exact fp32 rescoring of "
-                                       "the survivors; results bit-identical to the one-stage fp32-MFMA kernel, whose own "
-                                       "ceiling is the 157.3 TFLOP/s fp32 matrix peak")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(X_cpu, args.k, args.max_iter, keep)
         print(json.dumps(out), flush=True)

@@ -12,6 +12,8 @@ if [ "$1" = "pmc" ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -- \
         python $GRAFT_REPO_ROOT/tools/knn_perf.py 1000000 > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_umap_$c -- \
+        python $GRAFT_REPO_ROOT/tools/umap_perf.py 1000000 > $GRAFT_REPO_ROOT/gpurun_out/pmc_umap_$c.log 2>&1
   done
 fi
 cd $GRAFT_REPO_ROOT; f=$(ls -t gpurun_out/prof_bench/*/*kernel_stats.csv | head -1); head -6 "$f" | cut -c1-160

@@ -11,6 +11,12 @@ from torchdr_amd.neighbor_embedding.base import NegativeSamplingNeighborEmbeddin
 from torchdr_amd.utils.sparse import CSRAffinity
 
 
+# bench.py sets this to a list to collect (start_event, end_event, nnz) around every PROFILE_EVERY-th gradient
+# evaluation (HIP events on the launch stream); None = no instrumentation.
+PROFILE = None
+PROFILE_EVERY = 25
+
+
 def find_ab_params(spread, min_dist):
     """Fit a, b of 1/(1 + a x^(2b)) to the smooth-step target curve (reference :19-36: same grid,
     scipy ``curve_fit``; defaults give a = 1.5769..., b = 0.8950...)."""
@@ -101,6 +107,10 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             nbytes = _lib.lib().tdr_umap_grad_workspace_bytes(self.n_samples_in_, self.chunk_size_, self.n_components)
             self._grad_ws = torch.empty(max(nbytes, 8) // 4 + 1, dtype=torch.int32, device=self.device_)
             self._grad_ws_bytes = nbytes
+        prof = PROFILE is not None and int(self.n_iter_) % PROFILE_EVERY == 0
+        if prof:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         _lib.check(
             _lib.lib().tdr_umap_grad_f32(
                 _lib.ptr(self.embedding_), self.n_components, self.n_samples_in_, self.chunk_start_,
@@ -112,6 +122,9 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             ),
             "tdr_umap_grad_f32",
         )
+        if prof:
+            ev1.record()
+            PROFILE.append((ev0, ev1, csr.nnz))
         return grad, True
 
     def clear_memory(self):
