@@ -105,12 +105,14 @@ int tdr_maxmin_seeds_f32(const float* Xs, int64_t S, int d, int64_t ld, int n_se
 /* Self search with cluster-bound pruning: the points are sorted by a coarse clustering and padded so that clusters
  * start on tile boundaries (row_map); a workgroup visits clusters by increasing centre distance and skips every
  * cluster whose ball cannot reach its queries' current thresholds.  Same results as tdr_knn_screen_f32 (and hence
- * as tdr_knn_packed_f32) whatever the clustering; outputs are indexed by source row and hold source indices. */
+ * as tdr_knn_packed_f32) whatever the clustering; outputs are indexed by source row and hold source indices.
+ * [q_pos_begin, q_pos_end): range of the sorted order answered by this launch (0, 0 = everything). */
 int tdr_knn_screen_clustered_f32(const float* x16, const float* X, int64_t ldx, const float* norms, int64_t n_img, int d, int k,
                                  int metric, int exclude_self, int tier, const uint32_t* meta, const int32_t* row_map,
                                  int n_clusters, const int32_t* tile_cluster, const int32_t* clus_tile_begin,
-                                 const float* clus_radius, const float* clus_dist, const int32_t* clus_order, float* out_d,
-                                 int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
+                                 const float* clus_radius, const float* clus_dist, const int32_t* clus_order,
+                                 int64_t q_pos_begin, int64_t q_pos_end, float* out_d, int32_t* out_i, int32_t* flags,
+                                 int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- K2 / K3: per-row root searches --------------------------------------------------------------
  * replace utils/root_search.py:17-77,147-198 driven by affinity/knn_normalized.py:445-465 (UMAP) and

@@ -50,6 +50,28 @@ def _worker(rank, world, port, ret):
             dbase.SCREEN_MODE = "auto"
         assert torch.equal(csr_s.rowptr, csr.rowptr) and torch.equal(csr_s.cols, csr.cols)
         assert torch.equal(csr_s.vals, csr.vals)
+        # --- row-sharded search WITH cluster-bound pruning: every rank answers one range of the cluster-sorted order and
+        #     the rows travel to their owners (all-to-all-v); must equal the single-process exact result bit for bit
+        from torchdr_amd.distance import pairwise_distances
+        from torchdr_amd.distributed import DistributedContext
+
+        nb = 9001
+        Xb = gmm(nb, 32, 3.0, seed=14).cuda()
+        dbase.SCREEN_MODE, dbase.PRUNE_MODE = "force", "force"
+        try:
+            Cs, Is = pairwise_distances(Xb, metric="sqeuclidean", k=10, exclude_diag=True, return_indices=True,
+                                        distributed_ctx=DistributedContext())
+            assert dbase.LAST_KNN.get("pruned")
+        finally:
+            dbase.SCREEN_MODE, dbase.PRUNE_MODE = "auto", "auto"
+        dbase.SCREEN_MODE = "0"
+        try:
+            Ce, Ie = pairwise_distances(Xb, metric="sqeuclidean", k=10, exclude_diag=True, return_indices=True)
+        finally:
+            dbase.SCREEN_MODE = "auto"
+        b0, b1 = chunk_bounds(nb, rank, world)
+        assert Cs.shape == (b1 - b0, 10)
+        assert torch.equal(Is, Ie[b0:b1]) and torch.equal(Cs, Ce[b0:b1])
         # --- estimators: every rank ends with the same finite embedding
         for cls, kw in ((torchdr_amd.UMAP, dict(n_neighbors=12, max_iter=40)),
                         (torchdr_amd.LargeVis, dict(perplexity=6, max_iter=25)),

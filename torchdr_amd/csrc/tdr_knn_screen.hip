@@ -169,6 +169,7 @@ struct ScreenParams {
     int terms;            // 3: h.h' + h.l' + l.h'; 1: h.h' only (wider band, a third of the matrix work)
     uint64_t* cand;       // (n_splits, nq, L) ascending screening keys
     // cluster-bound pruning (self search on cluster-sorted, tile-padded points; all NULL = visit every tile)
+    int batch0;           // first query batch of this launch (a rank searches its range of the sorted order)
     int n_clusters;
     const int32_t* tile_cluster;    // (n_db_tiles) cluster of every 32-row tile (queries and database share the order)
     const int32_t* clus_tile_begin; // (n_clusters + 1) first tile of each cluster
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(256, (QB == 1 && ITEMS == 1) ? 2 : 1) void knn_scre
     uint64_t* keys = keys_all + (size_t)wave * QB * Ln * 32;
 
     const int64_t n_qtiles = (P.nq + 31) / 32;
-    const int64_t qt0 = ((int64_t)blockIdx.x * NW + wave) * QB;
+    const int64_t qt0 = (((int64_t)blockIdx.x + P.batch0) * NW + wave) * QB;
     const bool wave_active = qt0 < n_qtiles;
 
     const int se = scale_exp(P.meta[0]);
@@ -535,7 +536,7 @@ __global__ __launch_bounds__(256, (QB == 1 && ITEMS == 1) ? 2 : 1) void knn_scre
         int cw[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const int64_t qtw = ((int64_t)blockIdx.x * NW + w) * QB;
+            const int64_t qtw = (((int64_t)blockIdx.x + P.batch0) * NW + w) * QB;
             cw[w] = (qtw < n_qtiles) ? P.tile_cluster[qtw] : -1;
         }
         float bmax = 0.f;  // band of the valid lanes only (invalid lanes were given ||x||^2 = 0)
@@ -621,6 +622,7 @@ struct RescoreParams {
     int d, dpad, k, L, n_splits, metric, terms;
     int predict_unsplit;   // pilot runs: also flag queries whose band holds >= L candidates over ALL slices
     const int32_t* row_map; // screening index -> source row (cluster-sorted search), NULL = identity
+    int64_t q_begin, q_end; // screening positions handled by this launch
     float* out_d;
     int32_t* out_i;
     int32_t* flags;        // (nq) 1 = overflow
@@ -639,8 +641,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     uint64_t* ek = ak + total;
     float* xq = reinterpret_cast<float*>(ek + total);
     uint32_t* sc = reinterpret_cast<uint32_t*>(xq + dq);
-    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
-    if (qi >= P.nq) return;  // no block-level barrier below: wavefronts are independent
+    const int64_t qi = P.q_begin + (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= P.q_end) return;  // no block-level barrier below: wavefronts are independent
     // cluster-sorted search: screening position -> source row (outputs go to the source row, keys carry source indices
     // so that the canonical (distance, index) order is the caller's)
     const int64_t qs = P.row_map ? (int64_t)P.row_map[qi] : qi;
@@ -976,7 +978,7 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
                            const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
                            int metric, int exclude_self, int tier, int predict_unsplit, const uint32_t* meta, float* out_d,
                            int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes,
-                           const ClusterTables* ct, void* stream) {
+                           const ClusterTables* ct, int64_t q_pos_begin, int64_t q_pos_end, void* stream) {
     if (!q16 || !Xq || !norms_q || !y16 || !Y || !norms_y || !meta || !out_d || !out_i || !flags || !n_flagged || !ws)
         return TDR_ERR_BAD_ARG;
     if (nq <= 0 || n_db <= 0 || d <= 0 || ldq < d || ldy < d) return TDR_ERR_BAD_ARG;
@@ -1000,13 +1002,21 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     P.terms = cfg.terms;
     P.cand = (uint64_t*)ws;
     P.n_clusters = ct ? ct->n_clusters : 0;
+    P.batch0 = 0;
     P.tile_cluster = ct ? ct->tile_cluster : nullptr; P.clus_tile_begin = ct ? ct->clus_tile_begin : nullptr;
     P.clus_radius = ct ? ct->clus_radius : nullptr; P.clus_dist = ct ? ct->clus_dist : nullptr;
     P.clus_order = ct ? ct->clus_order : nullptr;
     const int64_t need = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
     if (ws_bytes < need) return TDR_ERR_WORKSPACE;
     const size_t lds = screen_lds_bytes(ks, L, cfg.qb, cfg.terms);
-    const int wgs = (int)((nq + 128 * cfg.qb - 1) / (128 * cfg.qb));
+    int wgs = (int)((nq + 128 * cfg.qb - 1) / (128 * cfg.qb));
+    int64_t q_lo = 0, q_hi = nq;
+    if (ct && q_pos_end > q_pos_begin) {  // only the query batches covering [q_pos_begin, q_pos_end) of the sorted order
+        const int64_t qpw = 128 * cfg.qb;
+        P.batch0 = (int)(q_pos_begin / qpw);
+        wgs = (int)((q_pos_end + qpw - 1) / qpw) - P.batch0;
+        q_lo = q_pos_begin; q_hi = q_pos_end < nq ? q_pos_end : nq;
+    }
     int rc;
     switch (ks) {
         case 2: rc = launch_screen_ks<2>(P, cfg, wgs, lds, st); break;
@@ -1017,7 +1027,7 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
 
     RescoreParams R;
     R.cand = P.cand; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq;
-    R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.terms = cfg.terms; R.predict_unsplit = predict_unsplit; R.row_map = ct ? ct->row_map : nullptr; R.out_d = out_d;
+    R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.terms = cfg.terms; R.predict_unsplit = predict_unsplit; R.row_map = ct ? ct->row_map : nullptr; R.q_begin = q_lo; R.q_end = q_hi; R.out_d = out_d;
     R.out_i = out_i; R.flags = flags; R.n_flagged = n_flagged;
     const int total = P.n_splits * L;
     const int dq = (d + 3) & ~3;
@@ -1025,7 +1035,7 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_rescore_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(knn_rescore_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), rlds, st, R);
+    hipLaunchKernelGGL(knn_rescore_kernel, dim3((unsigned)((q_hi - q_lo + 3) / 4)), dim3(256), rlds, st, R);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
@@ -1035,7 +1045,7 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
                        int metric, int exclude_self, int tier, int predict_unsplit, const uint32_t* meta, float* out_d,
                        int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
     return knn_screen_impl(q16, Xq, ldq, norms_q, nq, q_offset, y16, Y, ldy, norms_y, n_db, d, k, metric, exclude_self, tier,
-                           predict_unsplit, meta, out_d, out_i, flags, n_flagged, ws, ws_bytes, nullptr, stream);
+                           predict_unsplit, meta, out_d, out_i, flags, n_flagged, ws, ws_bytes, nullptr, 0, 0, stream);
 }
 
 /*
@@ -1045,18 +1055,22 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
  * (n_clusters^2 centre distances, rounded down), clus_order (n_clusters^2, clusters by increasing centre distance, self
  * first).  out_d / out_i / flags are indexed by SOURCE row and hold source indices; results are those of
  * tdr_knn_packed_f32 on the n source rows, whatever the clustering.  ws >= tdr_knn_screen_workspace_bytes(n_img, ...).
+ * [q_pos_begin, q_pos_end): positions of the sorted order whose queries this launch answers (0, 0 = all; begin a multiple
+ * of 256) -- a rank of a row-sharded search takes one contiguous range and the owners exchange the rows afterwards.
  */
 int tdr_knn_screen_clustered_f32(const float* x16, const float* X, int64_t ldx, const float* norms, int64_t n_img, int d, int k,
                                  int metric, int exclude_self, int tier, const uint32_t* meta, const int32_t* row_map,
                                  int n_clusters, const int32_t* tile_cluster, const int32_t* clus_tile_begin,
-                                 const float* clus_radius, const float* clus_dist, const int32_t* clus_order, float* out_d,
-                                 int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+                                 const float* clus_radius, const float* clus_dist, const int32_t* clus_order,
+                                 int64_t q_pos_begin, int64_t q_pos_end, float* out_d, int32_t* out_i, int32_t* flags,
+                                 int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
     if (!row_map || !tile_cluster || !clus_tile_begin || !clus_radius || !clus_dist || !clus_order || n_clusters <= 0)
         return TDR_ERR_BAD_ARG;
     if (n_img % TILE_ROWS != 0) return TDR_ERR_BAD_ARG;
+    if (q_pos_begin < 0 || q_pos_end > n_img || (q_pos_end > q_pos_begin && q_pos_begin % 256 != 0)) return TDR_ERR_BAD_ARG;
     ClusterTables ct = {n_clusters, row_map, tile_cluster, clus_tile_begin, clus_radius, clus_dist, clus_order};
     return knn_screen_impl(x16, X, ldx, norms, n_img, 0, x16, X, ldx, norms, n_img, d, k, metric, exclude_self, tier, 0, meta,
-                           out_d, out_i, flags, n_flagged, ws, ws_bytes, &ct, stream);
+                           out_d, out_i, flags, n_flagged, ws, ws_bytes, &ct, q_pos_begin, q_pos_end, stream);
 }
 
 /* Farthest-point seeding: seeds[0..n_seeds) <- indices into the (S, d) sample Xs (seed 0 = row 0, each next seed the

@@ -181,124 +181,242 @@ def _use_screen(Q, Y, nq, k, metric):
     return nq * Y.n >= _SCREEN_MIN_PAIRS and Y.n >= 4096
 
 
-def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, pilot=True, fallback=True, tier=1):
-    """Two-stage search of queries Q[q0:q0+nq] against Y; rows whose screening list overflowed are redone
-    by the one-stage exact kernel.  Returns the number of such rows, or -1 when the pilot slice says the
-    data does not suit screening (nothing written; the caller uses the one-stage kernel)."""
+_TIER_NAMES = ("screen-1term", "screen", "screen-long")
+
+
+def _screen_operands(Q, Y):
+    """fp16-split images of the query and database blocks with ONE power-of-two scale (max |x| over both, max norm over
+    the database).  Returns (q16, y16, meta)."""
     L = _lib.lib()
-    dev = Y.device
-    d = Y.d
     if Q is Y:
         y16, meta = Y.screen_image()
-        q16 = y16
-    else:  # one scale for both blocks: max |x| over queries and database, max norm over the database
-        meta = torch.zeros(2, dtype=torch.int32, device=dev)
-        _lib.check(L.tdr_screen_meta_f32(_lib.ptr(Y.X), Y.n, d, Y.X.stride(0), _lib.ptr(Y.norms), _lib.ptr(meta),
-                                         _lib.stream_ptr()), "tdr_screen_meta_f32")
-        _lib.check(L.tdr_screen_meta_f32(_lib.ptr(Q.X), Q.n, d, Q.X.stride(0), None, _lib.ptr(meta),
-                                         _lib.stream_ptr()), "tdr_screen_meta_f32")
-        y16, _ = Y.screen_image(meta)
-        q16, _ = Q.screen_image(meta)
+        return y16, y16, meta
+    dev, d = Y.device, Y.d
+    meta = torch.zeros(2, dtype=torch.int32, device=dev)
+    _lib.check(L.tdr_screen_meta_f32(_lib.ptr(Y.X), Y.n, d, Y.X.stride(0), _lib.ptr(Y.norms), _lib.ptr(meta),
+                                     _lib.stream_ptr()), "tdr_screen_meta_f32")
+    _lib.check(L.tdr_screen_meta_f32(_lib.ptr(Q.X), Q.n, d, Q.X.stride(0), None, _lib.ptr(meta),
+                                     _lib.stream_ptr()), "tdr_screen_meta_f32")
+    y16, _ = Y.screen_image(meta)
+    q16, _ = Q.screen_image(meta)
+    return q16, y16, meta
+
+
+def _screen_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier, predict_unsplit, out_d, out_i, profile):
+    """One launch of the (unpruned) two-stage search on queries Q[q0:q0+nq].  Returns (flags, n_flagged) on the device."""
+    L = _lib.lib()
+    dev, d = Y.device, Y.d
+    q16, y16, meta = ops
     t16 = L.tdr_packed16_floats(32, d)
+    ws_bytes = L.tdr_knn_screen_workspace_bytes(nq, Y.n, d, k, tier)
+    ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
+    flags = torch.empty(nq, dtype=torch.int32, device=dev)
+    n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
+    if profile:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(
+        L.tdr_knn_screen_f32(
+            _lib.ptr(q16[(q0 // 32) * t16:]), _lib.ptr(Q.X[q0:]), Q.X.stride(0), _lib.ptr(Q.norms[q0:]), nq, q_offset + q0,
+            _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
+            1 if exclude_self else 0, tier, 1 if predict_unsplit else 0, _lib.ptr(meta), _lib.ptr(out_d), _lib.ptr(out_i),
+            _lib.ptr(flags), _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
+        ),
+        "tdr_knn_screen_f32",
+    )
+    if profile:
+        ev1.record()
+        PROFILE.append((ev0, ev1, nq, _TIER_NAMES[tier]))
+    return flags, n_flagged
+
+
+def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset):
+    """Pilot: screen a 2048-query slice with each tier, cheapest first (one-term, three-term, three-term with long
+    lists), flagging what an UNSLICED launch would flag; the first tier with <= 5 % flagged wins.  Returns (tier, tau)
+    with tau the largest k-th neighbour distance (squared) of the slice, or (-1, None) when the worst-case band swallows
+    the spare list slots for a sizeable share of the queries under every tier (large ||x|| ||y|| relative to the
+    neighbour spacing): the one-stage kernel serves such data."""
+    L = _lib.lib()
+    dev, d = Y.device, Y.d
+    pd = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.float32, device=dev)
+    pi = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.int32, device=dev)
+    for tier in (0, 1, 2):
+        if L.tdr_knn_screen_workspace_bytes(_SCREEN_PILOT_Q, Y.n, d, k, tier) == 0:
+            continue  # shape not available for this (d, k)
+        _, n_flagged = _screen_launch(Q, Y, ops, q0, _SCREEN_PILOT_Q, k, metric, exclude_self, q_offset, tier, True, pd, pi,
+                                      profile=False)
+        if int(n_flagged.item()) <= _SCREEN_PILOT_MAX_FRAC * _SCREEN_PILOT_Q:
+            kth = pd[:, -1]
+            return tier, float((kth * kth if metric == "euclidean" else kth).max())
+    return -1, None
+
+
+def _screen_fallback(Q, Y, q0, k, metric, exclude_self, q_offset, rows, out_d, out_i):
+    """Recompute the flagged query rows (indices relative to q0) with the one-stage exact kernel: top-(k+1) without
+    exclusion, then drop the query's own row (or the last entry when it is absent)."""
+    L = _lib.lib()
+    dev, d = Y.device, Y.d
+    Qf = PackedPoints(Q.X[q0:][rows].contiguous())
+    kk = k + 1 if exclude_self else k
+    if kk > min(L.tdr_knn_max_k(d), Y.n):
+        raise NotImplementedError(f"[torchdr_amd] k={k}: screening overflow fallback exceeds the exact kernel's k limit.")
+    Cf, If = knn_packed(Qf, Y, kk, metric, exclude_self=False, _allow_screen=False)
+    if exclude_self:
+        own = (rows + (q_offset + q0)).to(torch.int32)
+        is_self = If == own[:, None]
+        drop = torch.where(is_self.any(1), is_self.int().argmax(1), torch.full_like(own, k, dtype=torch.int64))
+        keep = torch.arange(kk, device=dev)[None, :] != drop[:, None]
+        Cf = Cf[keep].view(-1, k)
+        If = If[keep].view(-1, k)
+    out_d[rows] = Cf
+    out_i[rows] = If
+
+
+def _cluster_index(Y, ops, build=True):
+    ci = getattr(Y, "_cluster_index", None)
+    if ci is None and build:
+        ci = Y._cluster_index = ClusterIndex(Y)
+    if ci is not None and ci.img16 is None:
+        L = _lib.lib()
+        ci.img16 = torch.empty(L.tdr_packed16_floats(ci.n_img, Y.d), dtype=torch.float32, device=Y.device)
+        _lib.check(L.tdr_pack16_mapped_f32(_lib.ptr(Y.X), ci.n_img, Y.d, Y.X.stride(0), _lib.ptr(Y.norms), _lib.ptr(ops[2]),
+                                           _lib.ptr(ci.row_map), _lib.ptr(ci.img16), _lib.stream_ptr()),
+                   "tdr_pack16_mapped_f32")
+    return ci
+
+
+def _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range=(0, 0)):
+    """Cluster-pruned self search of Y (all of it, or the queries at positions pos_range of the sorted order): rows of
+    out_d / out_i are indexed by SOURCE row.  Returns (flags indexed by source row, n_flagged)."""
+    L = _lib.lib()
+    dev, d = Y.device, Y.d
+    ws_bytes = L.tdr_knn_screen_workspace_bytes(ci.n_img, ci.n_img, d, k, tier)
+    ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
+    flags = torch.zeros(Y.n, dtype=torch.int32, device=dev)
+    n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(
+        L.tdr_knn_screen_clustered_f32(
+            _lib.ptr(ci.img16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), ci.n_img, d, k, _METRIC_ID[metric],
+            1 if exclude_self else 0, tier, _lib.ptr(ops[2]), _lib.ptr(ci.row_map), ci.n_clusters, _lib.ptr(ci.tile_cluster),
+            _lib.ptr(ci.tile_begin), _lib.ptr(ci.radius), _lib.ptr(ci.dist), _lib.ptr(ci.order), int(pos_range[0]),
+            int(pos_range[1]), _lib.ptr(out_d), _lib.ptr(out_i), _lib.ptr(flags), _lib.ptr(n_flagged), _lib.ptr(ws),
+            ws_bytes, _lib.stream_ptr(),
+        ),
+        "tdr_knn_screen_clustered_f32",
+    )
+    if PROFILE is not None:
+        ev1.record()
+        n_q = Y.n if pos_range[1] <= pos_range[0] else int(pos_range[1] - pos_range[0])
+        PROFILE.append((ev0, ev1, n_q, _TIER_NAMES[tier] + "-pruned"))
+    return flags, n_flagged
+
+
+def _want_prune(Y, n):
+    return PRUNE_MODE != "0" and (PRUNE_MODE == "force" or n >= _PRUNE_MIN_N)
+
+
+def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, pilot=True, tier=1):
+    """Two-stage search of queries Q[q0:q0+nq] against Y (tier chosen by a pilot slice for large searches; the full
+    self search of clustered data additionally prunes by cluster bounds); rows whose screening list overflowed are
+    redone by the one-stage exact kernel.  Returns the number of such rows, or -1 when the pilot says the data does not
+    suit screening (nothing written; the caller uses the one-stage kernel)."""
+    ops = _screen_operands(Q, Y)
     pilot_tau = None
     if pilot and nq >= _SCREEN_PILOT_MIN_Q:
-        # pilot: screen a small slice of the queries first; when the worst-case band swallows the spare list
-        # slots for a sizeable share of them (large ||x|| ||y|| relative to the neighbour spacing), the two-stage
-        # search would mostly fall back -- run the one-stage kernel for everything instead
-        pd = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.float32, device=dev)
-        pi = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.int32, device=dev)
-        # cheapest first: one-term screening, three-term screening, three terms with long lists
-        for tier in (0, 1, 2):
-            if L.tdr_knn_screen_workspace_bytes(_SCREEN_PILOT_Q, Y.n, d, k, tier) == 0:
-                continue  # shape not available for this (d, k)
-            bad = _knn_screen(Q, Y, q0, _SCREEN_PILOT_Q, k, metric, exclude_self, q_offset, pd, pi, pilot=False,
-                              fallback=False, tier=tier)
-            if bad <= _SCREEN_PILOT_MAX_FRAC * _SCREEN_PILOT_Q:
-                break
-        else:
+        tier, pilot_tau = _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset)
+        if tier < 0:
             return -1
-        # largest k-th neighbour distance of the pilot slice: what the thresholds of a typical block settle at
-        kth = pd[:, -1]
-        pilot_tau = float((kth * kth if metric == "euclidean" else kth).max())
-    prune = (fallback and Q is Y and q0 == 0 and q_offset == 0 and nq == Y.n and PRUNE_MODE != "0"
-             and (PRUNE_MODE == "force" or Y.n >= _PRUNE_MIN_N))
+    prune = Q is Y and q0 == 0 and q_offset == 0 and nq == Y.n and _want_prune(Y, Y.n)
     if prune:
-        ci = getattr(Y, "_cluster_index", None)
-        if ci is None:
-            ci = Y._cluster_index = ClusterIndex(Y)
+        ci = _cluster_index(Y, ops)
         # worth it only when the cluster balls are far apart relative to the neighbour distances: predicted from the
         # pilot's k-th distances (with slack for the blocks the pilot did not see)
         if PRUNE_MODE != "force" and (pilot_tau is None or ci.scan_fraction(2.0 * pilot_tau) > _PRUNE_MAX_SCAN_FRACTION):
             prune = False
-    flags = torch.empty(nq, dtype=torch.int32, device=dev)
-    n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
-    Xq = Q.X[q0:]
     if prune:
-        # cluster-bound pruning: same results, the scan skips every cluster whose ball cannot reach the thresholds
-        if ci.img16 is None:
-            ci.img16 = torch.empty(L.tdr_packed16_floats(ci.n_img, d), dtype=torch.float32, device=dev)
-            _lib.check(L.tdr_pack16_mapped_f32(_lib.ptr(Y.X), ci.n_img, d, Y.X.stride(0), _lib.ptr(Y.norms), _lib.ptr(meta),
-                                               _lib.ptr(ci.row_map), _lib.ptr(ci.img16), _lib.stream_ptr()),
-                       "tdr_pack16_mapped_f32")
-        ws_bytes = L.tdr_knn_screen_workspace_bytes(ci.n_img, ci.n_img, d, k, tier)
-        ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
-        flags.zero_()
-        if PROFILE is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-        _lib.check(
-            L.tdr_knn_screen_clustered_f32(
-                _lib.ptr(ci.img16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), ci.n_img, d, k, _METRIC_ID[metric],
-                1 if exclude_self else 0, tier, _lib.ptr(meta), _lib.ptr(ci.row_map), ci.n_clusters,
-                _lib.ptr(ci.tile_cluster), _lib.ptr(ci.tile_begin), _lib.ptr(ci.radius), _lib.ptr(ci.dist),
-                _lib.ptr(ci.order), _lib.ptr(out_d), _lib.ptr(out_i), _lib.ptr(flags), _lib.ptr(n_flagged), _lib.ptr(ws),
-                ws_bytes, _lib.stream_ptr(),
-            ),
-            "tdr_knn_screen_clustered_f32",
-        )
-        if PROFILE is not None:
-            ev1.record()
-            PROFILE.append((ev0, ev1, nq, ("screen-1term", "screen", "screen-long")[tier] + "-pruned"))
-    ws_bytes = L.tdr_knn_screen_workspace_bytes(nq, Y.n, d, k, tier)
-    ws = None if prune else torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
-    if PROFILE is not None and fallback and not prune:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    if not prune:
-      _lib.check(
-        L.tdr_knn_screen_f32(
-            _lib.ptr(q16[(q0 // 32) * t16:]), _lib.ptr(Xq), Q.X.stride(0), _lib.ptr(Q.norms[q0:]), nq, q_offset + q0,
-            _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
-            1 if exclude_self else 0, tier, 0 if fallback else 1, _lib.ptr(meta), _lib.ptr(out_d), _lib.ptr(out_i),
-            _lib.ptr(flags),
-            _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
-        ),
-        "tdr_knn_screen_f32",
-      )
-    if PROFILE is not None and fallback and not prune:
-        ev1.record()
-        PROFILE.append((ev0, ev1, nq, ("screen-1term", "screen", "screen-long")[tier]))
+        flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i)
+    else:
+        flags, n_flagged = _screen_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier, False, out_d, out_i,
+                                          profile=PROFILE is not None)
     bad = int(n_flagged.item())
-    if bad and fallback:
-        rows = flags.nonzero().squeeze(1)
-        Qf = PackedPoints(Xq[rows].contiguous())
-        kk = k + 1 if exclude_self else k
-        if kk > min(L.tdr_knn_max_k(d), Y.n):
-            raise NotImplementedError(f"[torchdr_amd] k={k}: screening overflow fallback exceeds the exact kernel's k limit.")
-        Cf, If = knn_packed(Qf, Y, kk, metric, exclude_self=False, _allow_screen=False)
-        if exclude_self:
-            # top-(k+1) without exclusion, then drop the query's own row (or the last entry when it is absent)
-            own = (rows + (q_offset + q0)).to(torch.int32)
-            is_self = If == own[:, None]
-            drop = torch.where(is_self.any(1), is_self.int().argmax(1), torch.full_like(own, k, dtype=torch.int64))
-            keep = torch.arange(kk, device=dev)[None, :] != drop[:, None]
-            Cf = Cf[keep].view(-1, k)
-            If = If[keep].view(-1, k)
-        out_d[rows] = Cf
-        out_i[rows] = If
+    if bad:
+        _screen_fallback(Q, Y, q0, k, metric, exclude_self, q_offset, flags.nonzero().squeeze(1), out_d, out_i)
     LAST_KNN["tier"] = tier
     LAST_KNN["pruned"] = bool(prune)
     return bad
+
+
+def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: bool, ctx: DistributedContext):
+    """Row-sharded self search with cluster-bound pruning.  Pruning works on the cluster-sorted order, so every rank
+    answers the queries of ONE CONTIGUOUS RANGE of that order (balanced, arbitrary source rows) and the rows are then
+    sent to the ranks that own them (all-to-all-v, the same exchange the symmetrisation uses).  The index is built by
+    rank 0 and broadcast, and the tier / prune decisions are all-reduced, so that every rank takes the same path.
+    Returns this rank's chunk (values, indices), or None when the ranks agree that pruning does not pay."""
+    import torch.distributed as dist
+
+    from torchdr_amd.parallel import allreduce_, broadcast_, exchange_rows_to_owners
+
+    L = _lib.lib()
+    dev = Y.device
+    n, W, rank = Y.n, ctx.world_size, ctx.rank
+    c0, c1 = ctx.compute_chunk_bounds(n)
+    ops = _screen_operands(Y, Y)
+    tier, tau = _choose_tier(Y, Y, ops, (c0 // 32) * 32, k, metric, exclude_self, 0)
+    vote = torch.tensor([float(tier < 0), float(max(tier, 0)), 0.0 if tau is None else tau], dtype=torch.float64, device=dev)
+    votes = [torch.empty_like(vote) for _ in range(W)]
+    if dist.get_backend() == "gloo":
+        hv = [v.cpu() for v in votes]
+        dist.all_gather(hv, vote.cpu())
+        votes = hv
+    else:
+        dist.all_gather(votes, vote)
+    if any(float(v[0]) > 0 for v in votes):
+        return None
+    tier = int(max(float(v[1]) for v in votes))
+    tau = max(float(v[2]) for v in votes)
+    # index: rank 0 builds, everybody receives identical tables
+    if rank == 0:
+        ci = ClusterIndex(Y)
+        head = torch.tensor([ci.n_clusters, ci.n_img], dtype=torch.int64, device=dev)
+    else:
+        ci = ClusterIndex.__new__(ClusterIndex)
+        head = torch.zeros(2, dtype=torch.int64, device=dev)
+    broadcast_(head)
+    C, n_img = int(head[0]), int(head[1])
+    if rank != 0:
+        ci.n_clusters, ci.n_img, ci.img16 = C, n_img, None
+        ci.row_map = torch.empty(max(n_img, 32), dtype=torch.int32, device=dev)
+        ci.tile_cluster = torch.empty(n_img // 32, dtype=torch.int32, device=dev)
+        ci.tile_begin = torch.empty(C + 1, dtype=torch.int32, device=dev)
+        ci.radius = torch.empty(C, dtype=torch.float32, device=dev)
+        ci.dist = torch.empty((C, C), dtype=torch.float32, device=dev)
+        ci.order = torch.empty((C, C), dtype=torch.int32, device=dev)
+    for t in (ci.row_map, ci.tile_cluster, ci.tile_begin, ci.radius, ci.dist, ci.order):
+        broadcast_(t)
+    if rank != 0:
+        tb = ci.tile_begin.long()
+        ci.tiles = tb[1:] - tb[:-1]
+    if PRUNE_MODE != "force" and ci.scan_fraction(2.0 * tau) > _PRUNE_MAX_SCAN_FRACTION:
+        return None  # same tables and tau on every rank: same decision
+    Y._cluster_index = ci
+    _cluster_index(Y, ops, build=False)
+    # this rank's range of the sorted order (multiples of 256 positions)
+    per = ((n_img + W - 1) // W + 255) // 256 * 256
+    p0, p1 = min(rank * per, n_img), min((rank + 1) * per, n_img)
+    out_d = torch.empty((n, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((n, k), dtype=torch.int32, device=dev)
+    rows = ci.row_map[p0:p1]
+    rows = rows[rows >= 0].long()
+    if p1 > p0:
+        flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range=(p0, p1))
+        if int(n_flagged.item()):
+            _screen_fallback(Y, Y, 0, k, metric, exclude_self, 0, rows[flags[rows] != 0], out_d, out_i)
+    Cc, Ic = exchange_rows_to_owners(rows.to(torch.int32), out_d[rows], out_i[rows], n, W, c0, c1 - c0)
+    LAST_KNN["path"], LAST_KNN["flagged"], LAST_KNN["tier"], LAST_KNN["pruned"] = "screen", 0, tier, True
+    return Cc, Ic
 
 
 def knn_packed(
@@ -493,6 +611,11 @@ def pairwise_distances(
             C, I = _knn_general(Xc[c0:c1], Xc, int(k), metric, bool(exclude_diag), q_global0=c0)
             return (C, I) if return_indices else C
         Yp = PackedPoints(X)
+        if (distributed_ctx.world_size > 1 and _want_prune(Yp, n) and _use_screen(Yp, Yp, c1 - c0, int(k), metric)
+                and n // distributed_ctx.world_size >= _SCREEN_PILOT_Q):
+            res = knn_pruned_sharded(Yp, int(k), metric, bool(exclude_diag), distributed_ctx)
+            if res is not None:
+                return res if return_indices else res[0]
         Qp = Yp if c0 % 32 == 0 else PackedPoints(X[c0:c1])
         rows = slice(c0, c1) if Qp is Yp else None
         # the reference asks Faiss for k+1 and drops column 0; excluding the query's own row

@@ -121,3 +121,33 @@ def exchange_transposed_edges(values, indices, chunk_start, n_total, world_size)
     _all_to_all_single(recv_v, send_v, rc, sc)
     # received edge (src -> dst) with dst owned here: it is entry (dst, src) of P^T
     return (recv_dst - chunk_start).to(torch.int32), recv_src, recv_v
+
+
+def exchange_rows_to_owners(row_ids, vals, idx, n_total, world_size, chunk_start, chunk_size):
+    """kNN rows computed for arbitrary global rows (``row_ids`` int32, ``vals`` (m, k) fp32, ``idx`` (m, k) int32) ->
+    the rows of this rank's chunk, in row order.  All-to-all-v by owner rank (contiguous chunks, the first
+    ``n_total % world_size`` ranks hold one extra row)."""
+    dev = vals.device
+    k = vals.shape[1]
+    owner = DistributedContext.get_rank_for_indices(row_ids.long(), n_total, world_size)
+    order = torch.argsort(owner, stable=True)
+    send_counts = torch.bincount(owner, minlength=world_size).to(torch.int64)
+    recv_counts = torch.empty_like(send_counts)
+    _all_to_all_single(recv_counts, send_counts)
+    sc, rc = send_counts.tolist(), recv_counts.tolist()
+    total = int(sum(rc))
+    s_ids, s_v, s_i = row_ids[order].contiguous(), vals[order].contiguous(), idx[order].contiguous()
+    r_ids = torch.empty(total, dtype=torch.int32, device=dev)
+    r_v = torch.empty((total, k), dtype=torch.float32, device=dev)
+    r_i = torch.empty((total, k), dtype=torch.int32, device=dev)
+    _all_to_all_single(r_ids, s_ids, rc, sc)
+    _all_to_all_single(r_v, s_v, rc, sc)
+    _all_to_all_single(r_i, s_i, rc, sc)
+    if total != chunk_size:
+        raise RuntimeError(f"[torchdr_amd] kNN row exchange: received {total} rows for a chunk of {chunk_size}.")
+    out_v = torch.empty((chunk_size, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((chunk_size, k), dtype=torch.int32, device=dev)
+    local = (r_ids.long() - chunk_start)
+    out_v[local] = r_v
+    out_i[local] = r_i
+    return out_v, out_i
