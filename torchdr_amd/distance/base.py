@@ -355,9 +355,7 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
     sent to the ranks that own them (all-to-all-v, the same exchange the symmetrisation uses).  The index is built by
     rank 0 and broadcast, and the tier / prune decisions are all-reduced, so that every rank takes the same path.
     Returns this rank's chunk (values, indices), or None when the ranks agree that pruning does not pay."""
-    import torch.distributed as dist
-
-    from torchdr_amd.parallel import allreduce_, broadcast_, exchange_rows_to_owners
+    from torchdr_amd.parallel import allreduce_max_, broadcast_, exchange_rows_to_owners
 
     L = _lib.lib()
     dev = Y.device
@@ -365,18 +363,13 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
     c0, c1 = ctx.compute_chunk_bounds(n)
     ops = _screen_operands(Y, Y)
     tier, tau = _choose_tier(Y, Y, ops, (c0 // 32) * 32, k, metric, exclude_self, 0)
+    # one decision for all ranks: any rank without a usable tier -> nobody prunes; else the most conservative tier and
+    # the largest threshold estimate (element-wise MAX all-reduce)
     vote = torch.tensor([float(tier < 0), float(max(tier, 0)), 0.0 if tau is None else tau], dtype=torch.float64, device=dev)
-    votes = [torch.empty_like(vote) for _ in range(W)]
-    if dist.get_backend() == "gloo":
-        hv = [v.cpu() for v in votes]
-        dist.all_gather(hv, vote.cpu())
-        votes = hv
-    else:
-        dist.all_gather(votes, vote)
-    if any(float(v[0]) > 0 for v in votes):
+    allreduce_max_(vote)
+    if float(vote[0]) > 0:
         return None
-    tier = int(max(float(v[1]) for v in votes))
-    tau = max(float(v[2]) for v in votes)
+    tier, tau = int(vote[1]), float(vote[2])
     # index: rank 0 builds, everybody receives identical tables
     if rank == 0:
         ci = ClusterIndex(Y)

@@ -32,6 +32,16 @@ def allreduce_(t: torch.Tensor):
     return t
 
 
+def allreduce_max_(t: torch.Tensor):
+    if _host_staged() and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MAX)
+        t.copy_(h)
+        return t
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t
+
+
 def broadcast_(t: torch.Tensor, src: int = 0):
     if _host_staged() and t.is_cuda:
         h = t.cpu()
