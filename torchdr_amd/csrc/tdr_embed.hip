@@ -116,7 +116,6 @@ struct UmapStepParams {
     float* gr_acc;           // (n_rows, NC)
     int64_t j_lo, j_hi;      // slice of negative indices handled by this pass
     int first, last;
-    int slice, n_slices;     // this pass's slice; n_slices in {2, 4}: dense multinomial split (else: filter by range)
 };
 
 template <int NC>
@@ -241,31 +240,6 @@ __global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) 
     }
 }
 
-// Number of a row's n negatives that fall into the lower of two equal halves of the index range: the population count
-// of n fair random bits, i.e. exactly Binomial(n, 1/2) -- so "split the count, then draw uniformly inside the half"
-// has the same distribution as n i.i.d. uniform draws, and every pass can generate ITS negatives densely instead of
-// generating all of them and masking the ones out of range.
-__device__ __forceinline__ int binomial_half(uint32_t key, int n) {
-    int m = 0;
-    for (int t = 0; t * 32 < n; ++t) {
-        uint32_t w = mix32(key + 0x7F4A7C15u * (uint32_t)(t + 1));
-        const int rem = n - t * 32;
-        if (rem < 32) w &= (1u << rem) - 1u;
-        m += __popc(w);
-    }
-    return m;
-}
-// negatives of slice `slice` (of n_slices = 2 or 4) for a row with n_use negatives in total
-__device__ __forceinline__ int slice_count(uint32_t rkey, int n_use, int slice, int n_slices) {
-    const int lo = binomial_half(rkey ^ 0x9E3779B9u, n_use);          // halves {0..S/2-1} | {S/2..S-1}
-    int mine = (slice < n_slices / 2) ? lo : n_use - lo;
-    if (n_slices == 4) {
-        const int q = binomial_half(rkey ^ (0x85EBCA6Bu + 0x27D4EB2Fu * (uint32_t)(slice >> 1)), mine);
-        mine = (slice & 1) ? mine - q : q;
-    }
-    return mine;
-}
-
 // Negative phase, one slice of the index range per launch.  At N = 1M the embedding (8 MB) does not fit an XCD's
 // 4 MB L2 and the ~43 uniformly random 8-byte gathers per row go to the fabric (random negatives cost 0.46 us per
 // 1000 rows there, 0.19 when Z fits L2, 0.07 when they are sequential).  Restricted to a slice of Z the gathers are
@@ -278,60 +252,37 @@ __device__ __forceinline__ int slice_count(uint32_t rkey, int n_use, int slice, 
 template <int NC, int G, int U>
 __global__ __launch_bounds__(256) void umap_neg_slice_kernel(const UmapStepParams P) {
     const int gl = threadIdx.x % G;
-    // grid-stride over the rows (a persistent grid when TDR_UMAP_PERSIST is set): whole wavefronts iterate together,
-    // rows past the end are handled as empty so that the wave-wide votes stay uniform
-    const int64_t rows_per_pass = (int64_t)gridDim.x * (256 / G);
-    const int64_t n_pad = ((P.n_rows + 256 / G - 1) / (256 / G)) * (256 / G);
-    for (int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G; r < n_pad; r += rows_per_pass) {
-    const bool valid = r < P.n_rows;
-    const int64_t gi = P.row0 + (valid ? r : 0);
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (r >= P.n_rows) return;
+    const int64_t gi = P.row0 + r;
     const Vec<NC> zi = load_z<NC>(P.Z, gi);
-    const int n_use = valid ? P.nuse[r] : 0;
+    const int n_use = P.nuse[r];
     float gr[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) gr[c] = 0.f;
     const uint32_t rkey = neg_row_key(P.seed, P.iter, gi);
     const float m2b = -2.0f * P.b;
-    // dense mode (in-kernel sampling, 2 or 4 slices): this pass draws exactly its share of the row's negatives, uniformly
-    // inside its slice of the reduced index range [0, N-1) (reference: r ~ U{0..N-2}, j = r + (r >= i)); filter mode
-    // (injected tables or other slice counts): every column is formed and the ones outside [j_lo, j_hi) are masked
-    const bool dense = P.neg_inj == nullptr && (P.n_slices == 2 || P.n_slices == 4);
-    int n_cols = n_use;
-    int64_t r_lo = 0, r_len = 0;
-    if (dense) {
-        n_cols = slice_count(rkey, n_use, P.slice, P.n_slices);
-        const int64_t step = (P.n_total - 1 + P.n_slices - 1) / P.n_slices;
-        r_lo = (int64_t)P.slice * step;
-        r_len = ((r_lo + step < P.n_total - 1) ? r_lo + step : P.n_total - 1) - r_lo;
-        if (r_len <= 0) n_cols = 0;
-    }
-    const uint32_t ckey = rkey + 0x632BE5ABu * (uint32_t)(P.slice + 1);
-    for (int base = 0; __any(base < n_cols); base += U * G) {
+    for (int base = 0; base < n_use; base += U * G) {
         int64_t jn[U];
         bool v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int col = base + u * G + gl;
-            v[u] = col < n_cols;
+            v[u] = col < n_use;
             jn[u] = gi;
-            if (v[u]) {
-                if (dense) {
-                    const uint32_t x = mix32(ckey + (uint32_t)col * 0x9E3779B9u);
-                    const int64_t rr = r_lo + (int64_t)(((uint64_t)x * (uint64_t)r_len) >> 32);
-                    jn[u] = rr + (rr >= gi ? 1 : 0);
-                } else {
-                    jn[u] = P.neg_inj ? P.neg_inj[(size_t)r * P.n_negatives + col] : sample_negative(rkey, gi, col, P.n_total);
-                    v[u] = jn[u] >= P.j_lo && jn[u] < P.j_hi;
-                }
-            }
+            if (v[u]) jn[u] = P.neg_inj ? P.neg_inj[(size_t)r * P.n_negatives + col] : sample_negative(rkey, gi, col, P.n_total);
+            v[u] = v[u] && jn[u] >= P.j_lo && jn[u] < P.j_hi;
+        }
+        Vec<NC> zj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            zj[u] = zi;
+            if (v[u]) zj[u] = load_z<NC>(P.Z, jn[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (!__any(v[u])) continue;  // column slots no row of this wavefront uses: skip the gather and the force math
-            Vec<NC> zj = zi;
-            if (v[u]) zj = load_z<NC>(P.Z, jn[u]);
             float df[NC];
-            const float d = sqdist<NC>(zi, zj, df);
+            const float d = sqdist<NC>(zi, zj[u], df);
             if (v[u]) {
                 const float den = 1.0f + P.a * (d > 0.f ? fast_pow(d, P.b) : 0.f);
                 const float coef = fast_rcp((d + P.eps) * den) * m2b;
@@ -342,7 +293,7 @@ __global__ __launch_bounds__(256) void umap_neg_slice_kernel(const UmapStepParam
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) gr[c] = group_sum<G>(gr[c]);
-    if (valid && gl == 0) {
+    if (gl == 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const float tot = (P.first ? 0.f : P.gr_acc[(size_t)r * NC + c]) + gr[c];
@@ -350,33 +301,6 @@ __global__ __launch_bounds__(256) void umap_neg_slice_kernel(const UmapStepParam
             else P.gr_acc[(size_t)r * NC + c] = tot;
         }
     }
-    }  // row loop
-}
-
-// Test hook: the negatives the dense slice passes draw for each row (same device functions), written slice after
-// slice into out (n_rows, n_use_max); unused slots = -1.  Lets the tests check the sampler's distribution.
-__global__ __launch_bounds__(256) void umap_debug_negatives_kernel(uint64_t seed, uint32_t iter, int64_t n_total, int64_t row0,
-                                                                   int64_t n_rows, const int32_t* __restrict__ nuse,
-                                                                   int n_slices, int width, int64_t* __restrict__ out) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n_rows) return;
-    const int64_t gi = row0 + r;
-    const uint32_t rkey = neg_row_key(seed, iter, gi);
-    const int n_use = nuse[r];
-    int pos = 0;
-    const int64_t step = (n_total - 1 + n_slices - 1) / n_slices;
-    for (int sl = 0; sl < n_slices; ++sl) {
-        const int cnt = slice_count(rkey, n_use, sl, n_slices);
-        const int64_t r_lo = (int64_t)sl * step;
-        const int64_t r_len = ((r_lo + step < n_total - 1) ? r_lo + step : n_total - 1) - r_lo;
-        const uint32_t ckey = rkey + 0x632BE5ABu * (uint32_t)(sl + 1);
-        for (int col = 0; col < cnt && pos < width; ++col) {
-            const uint32_t x = mix32(ckey + (uint32_t)col * 0x9E3779B9u);
-            const int64_t rr = r_lo + (int64_t)(((uint64_t)x * (uint64_t)r_len) >> 32);
-            out[(size_t)r * width + pos++] = rr + (rr >= gi ? 1 : 0);
-        }
-    }
-    for (; pos < width; ++pos) out[(size_t)r * width + pos] = -1;
 }
 
 // ---- LargeVis / TSNE sparse terms -------------------------------------------------------------------
@@ -679,11 +603,9 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ Z, co
 }
 
 template <int G, typename Prm>
-static int launch_group(void (*kern)(const Prm), const Prm& P, int64_t n_rows, hipStream_t st, int64_t max_wgs = 0) {
+static int launch_group(void (*kern)(const Prm), const Prm& P, int64_t n_rows, hipStream_t st) {
     const int rpb = 256 / G;
-    int64_t wgs = (n_rows + rpb - 1) / rpb;
-    if (max_wgs > 0 && wgs > max_wgs) wgs = max_wgs;  // grid-stride kernels only
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((n_rows + rpb - 1) / rpb)), dim3(256), 0, st, P);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TDR_OK : (int)e;
 }
@@ -720,8 +642,10 @@ static int umap_neg_slices(int64_t n_total, int nc) {
     if (mb <= 0) return 1;
     const int64_t bytes = n_total * nc * (int64_t)sizeof(float);
     if (bytes <= (int64_t)3 << 20) return 1;
-    const int64_t s = (bytes + ((int64_t)mb << 20) - 1) / ((int64_t)mb << 20);
-    return s > 2 ? 4 : 2;  // 2 or 4: the slice passes split a row's negatives by exact binomial halving
+    int64_t s = (bytes + ((int64_t)mb << 20) - 1) / ((int64_t)mb << 20);
+    if (s > 4) s = 4;
+    if (s < 2) s = 2;
+    return (int)s;
 }
 
 /* Workspace of tdr_umap_grad_f32 (0 when the single-pass kernel is used). */
@@ -746,7 +670,7 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
     P.eps_per = eps_per; P.next = next; P.a = a; P.b = b; P.t1 = (float)(n_iter + 1); P.neg_rate = neg_rate;
     P.n_negatives = n_negatives; P.neg_inj = neg_inj; P.seed = seed; P.iter = (uint32_t)n_iter; P.exag = exag;
     P.rep = rep; P.eps = eps; P.grad = grad;
-    P.nuse = nullptr; P.gr_acc = nullptr; P.j_lo = 0; P.j_hi = n_total; P.first = 1; P.last = 1; P.slice = 0; P.n_slices = 1;
+    P.nuse = nullptr; P.gr_acc = nullptr; P.j_lo = 0; P.j_hi = n_total; P.first = 1; P.last = 1;
     hipStream_t st = (hipStream_t)stream;
     int slices = neg_slices > 0 ? neg_slices : umap_neg_slices(n_total, nc);
     if (slices > n_total) slices = (int)n_total;
@@ -754,36 +678,16 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
     if (slices > 1 && ws && ws_bytes >= need && n_negatives > 0 && neg_rate > 0) {
         P.nuse = (int32_t*)ws;
         P.gr_acc = (float*)((char*)ws + n_rows * sizeof(int32_t));
-        // lanes per row x column slots per lane: TDR_UMAP_POS_GEOM / TDR_UMAP_NEG_GEOM = 0 (16x4), 1 (8x8), 2 (4x16).
-        // The slice passes are latency-bound by their short-lived wavefronts (a pass with no negatives at all costs
-        // 0.095 ms per 1M rows at 16 lanes per row), so they default to 4 lanes per row: 4x fewer wavefronts, 16
-        // gathers in flight per lane.
-        static int pg = -1, ng = -1;
-        if (pg < 0) { const char* g = getenv("TDR_UMAP_POS_GEOM"); pg = g ? atoi(g) : 0; }
-        if (ng < 0) { const char* g = getenv("TDR_UMAP_NEG_GEOM"); ng = g ? atoi(g) : 0; }
-        int rc;
-        if (nc == 2) {
-            if (pg == 1) rc = launch_group<8>(umap_grad_kernel<2, 8, 8, true>, P, n_rows, st);
-            else if (pg == 2) rc = launch_group<4>(umap_grad_kernel<2, 4, 16, true>, P, n_rows, st);
-            else rc = launch_group<16>(umap_grad_kernel<2, 16, 4, true>, P, n_rows, st);
-        } else {
-            rc = launch_group<16>(umap_grad_kernel<3, 16, 4, true>, P, n_rows, st);
-        }
+        int rc = (nc == 2) ? launch_group<16>(umap_grad_kernel<2, 16, 4, true>, P, n_rows, st)
+                           : launch_group<16>(umap_grad_kernel<3, 16, 4, true>, P, n_rows, st);
         if (rc != TDR_OK) return rc;
         const int64_t step = (n_total + slices - 1) / slices;
         for (int sidx = 0; sidx < slices; ++sidx) {
             P.j_lo = sidx * step;
             P.j_hi = (sidx + 1) * step < n_total ? (sidx + 1) * step : n_total;
-            P.first = sidx == 0; P.last = sidx == slices - 1; P.slice = sidx; P.n_slices = slices;
-            static int64_t cap = -1;  // TDR_UMAP_PERSIST = workgroups of the persistent grid (0 = one workgroup per row block)
-            if (cap < 0) { const char* g = getenv("TDR_UMAP_PERSIST"); cap = g ? atoll(g) : 0; }
-            if (nc == 2) {
-                if (ng == 1) rc = launch_group<8>(umap_neg_slice_kernel<2, 8, 8>, P, n_rows, st, cap);
-                else if (ng == 2) rc = launch_group<4>(umap_neg_slice_kernel<2, 4, 16>, P, n_rows, st, cap);
-                else rc = launch_group<16>(umap_neg_slice_kernel<2, 16, 4>, P, n_rows, st, cap);
-            } else {
-                rc = launch_group<16>(umap_neg_slice_kernel<3, 16, 4>, P, n_rows, st, cap);
-            }
+            P.first = sidx == 0; P.last = sidx == slices - 1;
+            rc = (nc == 2) ? launch_group<16>(umap_neg_slice_kernel<2, 16, 4>, P, n_rows, st)
+                           : launch_group<16>(umap_neg_slice_kernel<3, 16, 4>, P, n_rows, st);
             if (rc != TDR_OK) return rc;
         }
         return TDR_OK;
@@ -896,17 +800,6 @@ int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_i
     hipStream_t st = (hipStream_t)stream;
     if (nc == 2) return launch_group<16>(pacmap_grad_kernel<2, 16>, P, n, st);
     return launch_group<16>(pacmap_grad_kernel<3, 16>, P, n, st);
-}
-
-/* Test hook: negatives drawn by the dense slice passes of tdr_umap_grad_f32 (n_slices = 2 or 4) for rows
- * [row0, row0 + n_rows) with nuse[r] negatives each -> out (n_rows, width) int64, -1 padded. */
-int tdr_umap_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nuse,
-                             int n_slices, int width, int64_t* out, void* stream) {
-    if (!nuse || !out || n_rows <= 0 || n_total < 2 || width <= 0 || (n_slices != 2 && n_slices != 4)) return TDR_ERR_BAD_ARG;
-    hipLaunchKernelGGL(umap_debug_negatives_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       seed, (uint32_t)n_iter, n_total, row0, n_rows, nuse, n_slices, width, out);
-    TDR_CHECK_LAUNCH();
-    return TDR_OK;
 }
 
 }  // extern "C"

@@ -752,12 +752,22 @@ __global__ __launch_bounds__(256) void maxmin_step_kernel(const float* __restric
     for (int c = threadIdx.x; c < d; c += 256) cur_row[c] = Xs[(size_t)cur * ld + c];
     __syncthreads();
     const int gl = threadIdx.x & 15;                                   // 16 lanes per sample row
+    const bool vec4 = (d & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)Xs & 15) == 0;
     unsigned long long key = 0ull;
     // a few hundred workgroups stride over the rows: one atomic per wavefront and step stays cheap
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; i < S; i += (int64_t)gridDim.x * 16) {
         float acc = 0.f;
         const float* xr = Xs + (size_t)i * ld;
-        for (int c = gl; c < d; c += 16) { const float t = xr[c] - cur_row[c]; acc += t * t; }
+        if (vec4) {  // 16-byte loads: lane gl covers features 4 gl .. 4 gl + 3 of every 64-wide block
+            for (int c = gl * 4; c < d; c += 64) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+                const f32x4 w = *reinterpret_cast<const f32x4*>(cur_row + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = v[e] - w[e]; acc += t * t; }
+            }
+        } else {
+            for (int c = gl; c < d; c += 16) { const float t = xr[c] - cur_row[c]; acc += t * t; }
+        }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
         if (gl == 0) {

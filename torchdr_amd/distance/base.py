@@ -114,7 +114,7 @@ class ClusterIndex:
         N, D = X.shape
         C = int(n_clusters or min(2048, max(8, N // 1000)))
         g = torch.Generator(device=dev).manual_seed(20240917)
-        S = min(N, 64 * C)
+        S = min(N, 32 * C)
         Xs = X[torch.randint(0, N, (S,), device=dev, generator=g)]
         # farthest-point (max-min) seeding on the sample: one seed per well-separated group, an epsilon-net otherwise
         # (random seeds leave merged clusters whose large balls every workgroup would have to scan), then Lloyd steps
