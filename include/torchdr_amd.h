@@ -148,6 +148,9 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
                       const int32_t* cols, const float* eps_per, float* next, float a, float b, int n_iter,
                       int neg_rate, int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep,
                       float eps, float* grad, int neg_slices, void* ws, int64_t ws_bytes, void* stream);
+/* test hook: the negatives the dense L2-sliced negative passes draw (distribution checks of the counter-hash sampler) */
+int tdr_umap_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nuse,
+                             int n_slices, int width, int64_t* out, void* stream);
 /* gradients of neighbor_embedding/largevis.py:181-201 (kind 0), tsne.py:162-170 (kind 1, attraction only),
  * sne.py:160-168 (kind 2, attraction only) and infotsne.py:178-197 (kind 3: Student-t attraction + the row
  * log-sum-exp over the sampled negatives, rep_coef = 2 * repulsion_strength / N) */

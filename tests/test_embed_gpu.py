@@ -360,3 +360,39 @@ def test_sne_infotsne_end_to_end(cls_name):
     Z = m.fit_transform(X.cuda())
     assert Z.shape == (n, 2) and bool(torch.isfinite(Z).all())
     assert knn_preservation(X, Z.cpu(), k=10) > 0.25
+
+
+@pytest.mark.parametrize("n_slices", [2, 4])
+def test_sliced_negative_sampler_is_uniform(n_slices):
+    """The L2-sliced negative passes split a row's negatives over the index slices by exact binomial halving and draw
+    uniformly inside each slice: together that must be n_use i.i.d. uniform draws from {0..N-1} minus the row itself
+    (neighbor_embedding/base.py:628-636)."""
+    from torchdr_amd import _lib
+
+    N, rows, width = 40000, 40000, 60  # every row is a real point of the index range
+    gen = torch.Generator().manual_seed(5)
+    nuse = torch.randint(0, width + 1, (rows,), dtype=torch.int32, generator=gen).cuda()
+    nuse[:8000] = 40  # enough rows of one size for the variance check
+    out = torch.empty((rows, width), dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib().tdr_umap_debug_negatives(123456789, 7, N, 0, rows, _lib.ptr(nuse), n_slices, width, _lib.ptr(out),
+                                                   _lib.stream_ptr()), "debug_negatives")
+    out, nuse = out.cpu(), nuse.cpu().long()
+    valid = out >= 0
+    assert torch.equal(valid.sum(1), nuse)                       # every row draws exactly its n_use negatives
+    assert not bool(((out == torch.arange(rows)[:, None]) & valid).any())          # never the row itself
+    assert int(out[valid].min()) >= 0 and int(out[valid].max()) <= N - 1
+    # uniformity over the index range (chi-square over 50 bins, rows < N excluded from nothing: self removal is 1/N)
+    vals = out[valid]
+    hist = torch.bincount((vals * 50 // N).clamp(max=49), minlength=50).double()
+    expect = hist.sum() / 50
+    chi2 = float(((hist - expect) ** 2 / expect).sum())
+    assert chi2 < 100.0, chi2                                     # 49 dof: mean 49, P(chi2 > 100) ~ 2e-5
+    # split between the two halves of the range ~ Binomial(n, 1/2): the mean of the lower-half share is 1/2
+    lower = ((out < N // 2) & valid).sum(1).double()
+    share = float((lower.sum() / nuse.sum()))
+    assert abs(share - 0.5) < 0.005
+    # and its variance per row matches the binomial n/4 (a stratified split would have ~0)
+    sel = nuse == 40
+    if int(sel.sum()) > 200:
+        var = float(lower[sel].var())
+        assert 8.5 < var < 11.5, var                              # n/4 = 10 (8000 rows: sd of the estimate ~0.16)

@@ -116,6 +116,7 @@ struct UmapStepParams {
     float* gr_acc;           // (n_rows, NC)
     int64_t j_lo, j_hi;      // slice of negative indices handled by this pass
     int first, last;
+    int slice, n_slices;     // this pass's slice index; dense passes need n_slices in {2, 4}
 };
 
 template <int NC>
@@ -301,6 +302,118 @@ __global__ __launch_bounds__(256) void umap_neg_slice_kernel(const UmapStepParam
             else P.gr_acc[(size_t)r * NC + c] = tot;
         }
     }
+}
+
+// ---- dense negative slice pass --------------------------------------------------------------------------------
+// PMC on the masking pass above: 484 VALU instructions per wavefront, VALU busy 95 % -- it is VALU-issue bound, and
+// half of its column slots (all but 1/S of them) are generated only to be masked out.  The dense pass draws exactly
+// the row's share for THIS slice instead.  The share is an exact multinomial split: the number of a row's n
+// negatives falling into the lower of two equal halves of the index range is the population count of n fair random
+// bits (Binomial(n, 1/2)), applied once for 2 slices and twice for 4; inside its slice every negative is uniform.
+// "Split the count, then draw uniformly inside the part" has the same distribution as n i.i.d. uniform draws from
+// {0..N-1} minus the row itself (reference: r ~ U{0..N-2}, j = r + (r >= i); neighbor_embedding/base.py:628-636).
+__device__ __forceinline__ int binomial_half(uint32_t key, int n) {
+    int m = 0;
+    for (int t = 0; t * 32 < n; ++t) {
+        uint32_t w = mix32(key + 0x7F4A7C15u * (uint32_t)(t + 1));
+        const int rem = n - t * 32;
+        if (rem < 32) w &= (1u << rem) - 1u;
+        m += __popc(w);
+    }
+    return m;
+}
+__device__ __forceinline__ int slice_count(uint32_t rkey, int n_use, int slice, int n_slices) {
+    const int lo = binomial_half(rkey ^ 0x9E3779B9u, n_use);          // slices {0..S/2-1} | {S/2..S-1}
+    int mine = (slice < n_slices / 2) ? lo : n_use - lo;
+    if (n_slices == 4) {
+        const int q = binomial_half(rkey ^ (0x85EBCA6Bu + 0x27D4EB2Fu * (uint32_t)(slice >> 1)), mine);
+        mine = (slice & 1) ? mine - q : q;
+    }
+    return mine;
+}
+
+template <int NC, int G, int U>
+__global__ __launch_bounds__(256) void umap_neg_dense_kernel(const UmapStepParams P) {
+    const int gl = threadIdx.x % G;
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (r >= P.n_rows) return;
+    const uint32_t gi = (uint32_t)(P.row0 + r);
+    const Vec<NC> zi = load_z<NC>(P.Z, gi);
+    const uint32_t rkey = neg_row_key(P.seed, P.iter, (int64_t)gi);
+    const int n_cols = slice_count(rkey, P.nuse[r], P.slice, P.n_slices);
+    // this slice of the reduced index range [0, N-1)
+    const uint32_t nred = (uint32_t)(P.n_total - 1);
+    const uint32_t step = (nred + (uint32_t)P.n_slices - 1u) / (uint32_t)P.n_slices;
+    const uint32_t r_lo = (uint32_t)P.slice * step;
+    const uint32_t r_len = (r_lo < nred) ? ((nred - r_lo < step) ? nred - r_lo : step) : 0u;
+    const uint32_t ckey = rkey + 0x632BE5ABu * (uint32_t)(P.slice + 1) + (uint32_t)gl * 0x9E3779B9u;
+    const float m2b = -2.0f * P.b;
+    float gr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) gr[c] = 0.f;
+    if (r_len) {
+        for (int base = 0; base < n_cols; base += U * G) {
+            uint32_t jn[U];
+            bool v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int col = base + u * G + gl;
+                v[u] = col < n_cols;
+                const uint32_t x = mix32(ckey + (uint32_t)(base + u * G) * 0x9E3779B9u);
+                const uint32_t rr = r_lo + __umulhi(x, r_len);
+                jn[u] = v[u] ? rr + (rr >= gi ? 1u : 0u) : gi;
+            }
+            Vec<NC> zj[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) zj[u] = load_z<NC>(P.Z, jn[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float df[NC];
+                const float d = sqdist<NC>(zi, zj[u], df);
+                if (v[u]) {
+                    const float den = 1.0f + P.a * (d > 0.f ? fast_pow(d, P.b) : 0.f);
+                    const float coef = fast_rcp((d + P.eps) * den) * m2b;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) gr[c] += coef * df[c];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) gr[c] = group_sum<G>(gr[c]);
+    if (gl == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float tot = (P.first ? 0.f : P.gr_acc[(size_t)r * NC + c]) + gr[c];
+            if (P.last) P.grad[(size_t)r * NC + c] += P.rep * fminf(fmaxf(tot, -4.f), 4.f);
+            else P.gr_acc[(size_t)r * NC + c] = tot;
+        }
+    }
+}
+
+// Test hook: the negatives the dense slice passes draw for each row (same device functions and hashing), written slice
+// after slice into out (n_rows, width); unused slots = -1.  Lets the tests check the sampler's distribution.
+__global__ __launch_bounds__(256) void umap_debug_negatives_kernel(uint64_t seed, uint32_t iter, int64_t n_total, int64_t row0,
+                                                                   int64_t n_rows, const int32_t* __restrict__ nuse,
+                                                                   int n_slices, int width, int64_t* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t gi = (uint32_t)(row0 + r);
+    const uint32_t rkey = neg_row_key(seed, iter, (int64_t)gi);
+    const uint32_t nred = (uint32_t)(n_total - 1);
+    const uint32_t step = (nred + (uint32_t)n_slices - 1u) / (uint32_t)n_slices;
+    int pos = 0;
+    for (int sl = 0; sl < n_slices; ++sl) {
+        const int cnt = slice_count(rkey, nuse[r], sl, n_slices);
+        const uint32_t r_lo = (uint32_t)sl * step;
+        const uint32_t r_len = (r_lo < nred) ? ((nred - r_lo < step) ? nred - r_lo : step) : 0u;
+        for (int col = 0; col < cnt && pos < width && r_len; ++col) {
+            const uint32_t x = mix32(rkey + 0x632BE5ABu * (uint32_t)(sl + 1) + (uint32_t)col * 0x9E3779B9u);
+            const uint32_t rr = r_lo + __umulhi(x, r_len);
+            out[(size_t)r * width + pos++] = (int64_t)(rr + (rr >= gi ? 1u : 0u));
+        }
+    }
+    for (; pos < width; ++pos) out[(size_t)r * width + pos] = -1;
 }
 
 // ---- LargeVis / TSNE sparse terms -------------------------------------------------------------------
@@ -642,10 +755,8 @@ static int umap_neg_slices(int64_t n_total, int nc) {
     if (mb <= 0) return 1;
     const int64_t bytes = n_total * nc * (int64_t)sizeof(float);
     if (bytes <= (int64_t)3 << 20) return 1;
-    int64_t s = (bytes + ((int64_t)mb << 20) - 1) / ((int64_t)mb << 20);
-    if (s > 4) s = 4;
-    if (s < 2) s = 2;
-    return (int)s;
+    const int64_t s = (bytes + ((int64_t)mb << 20) - 1) / ((int64_t)mb << 20);
+    return s > 2 ? 4 : 2;  // 2 or 4: the dense passes split a row's negatives by exact binomial halving
 }
 
 /* Workspace of tdr_umap_grad_f32 (0 when the single-pass kernel is used). */
@@ -670,7 +781,7 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
     P.eps_per = eps_per; P.next = next; P.a = a; P.b = b; P.t1 = (float)(n_iter + 1); P.neg_rate = neg_rate;
     P.n_negatives = n_negatives; P.neg_inj = neg_inj; P.seed = seed; P.iter = (uint32_t)n_iter; P.exag = exag;
     P.rep = rep; P.eps = eps; P.grad = grad;
-    P.nuse = nullptr; P.gr_acc = nullptr; P.j_lo = 0; P.j_hi = n_total; P.first = 1; P.last = 1;
+    P.nuse = nullptr; P.gr_acc = nullptr; P.j_lo = 0; P.j_hi = n_total; P.first = 1; P.last = 1; P.slice = 0; P.n_slices = 1;
     hipStream_t st = (hipStream_t)stream;
     int slices = neg_slices > 0 ? neg_slices : umap_neg_slices(n_total, nc);
     if (slices > n_total) slices = (int)n_total;
@@ -685,9 +796,16 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
         for (int sidx = 0; sidx < slices; ++sidx) {
             P.j_lo = sidx * step;
             P.j_hi = (sidx + 1) * step < n_total ? (sidx + 1) * step : n_total;
-            P.first = sidx == 0; P.last = sidx == slices - 1;
-            rc = (nc == 2) ? launch_group<16>(umap_neg_slice_kernel<2, 16, 4>, P, n_rows, st)
-                           : launch_group<16>(umap_neg_slice_kernel<3, 16, 4>, P, n_rows, st);
+            P.first = sidx == 0; P.last = sidx == slices - 1; P.slice = sidx; P.n_slices = slices;
+            static int dense_ok = -1;  // TDR_UMAP_DENSE=0: masking passes even when the dense ones apply
+            if (dense_ok < 0) { const char* g = getenv("TDR_UMAP_DENSE"); dense_ok = g ? atoi(g) : 1; }
+            if (dense_ok && !neg_inj && (slices == 2 || slices == 4) && n_total < 0x7fffffffLL) {
+                rc = (nc == 2) ? launch_group<16>(umap_neg_dense_kernel<2, 16, 2>, P, n_rows, st)
+                               : launch_group<16>(umap_neg_dense_kernel<3, 16, 2>, P, n_rows, st);
+            } else {
+                rc = (nc == 2) ? launch_group<16>(umap_neg_slice_kernel<2, 16, 4>, P, n_rows, st)
+                               : launch_group<16>(umap_neg_slice_kernel<3, 16, 4>, P, n_rows, st);
+            }
             if (rc != TDR_OK) return rc;
         }
         return TDR_OK;
@@ -800,6 +918,17 @@ int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_i
     hipStream_t st = (hipStream_t)stream;
     if (nc == 2) return launch_group<16>(pacmap_grad_kernel<2, 16>, P, n, st);
     return launch_group<16>(pacmap_grad_kernel<3, 16>, P, n, st);
+}
+
+/* Test hook: negatives drawn by the dense slice passes of tdr_umap_grad_f32 (n_slices = 2 or 4) for rows
+ * [row0, row0 + n_rows) with nuse[r] negatives each -> out (n_rows, width) int64, -1 padded. */
+int tdr_umap_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nuse,
+                             int n_slices, int width, int64_t* out, void* stream) {
+    if (!nuse || !out || n_rows <= 0 || n_total < 2 || width <= 0 || (n_slices != 2 && n_slices != 4)) return TDR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(umap_debug_negatives_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       seed, (uint32_t)n_iter, n_total, row0, n_rows, nuse, n_slices, width, out);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
 }
 
 }  // extern "C"
