@@ -43,7 +43,7 @@ def test_umap_three_steps_vs_reference(neg_slices):
     mask = g["Isym"] >= 0
     assert torch.equal(eps_per.cpu(), g["A_padded_eps_per"][mask])
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-    ws = torch.empty(n * 3 + 16, dtype=torch.int32, device="cuda")  # scratch of the sliced negative phase
+    ws = torch.empty(n * 4 + 16, dtype=torch.int32, device="cuda")  # scratch of the sliced negative phase
     for t in range(3):
         Z = g[f"Z_{t}"].cuda().contiguous()
         nxt = g[f"next_{t}"][mask].cuda().contiguous()

@@ -22,7 +22,7 @@ Z = (torch.randn(n, 2, device="cuda") * 5).contiguous()
 grad = torch.empty((n, 2), device="cuda")
 print(json.dumps({"n": n, "nnz": nnz, "mean_deg": nnz / n}))
 
-ws = torch.empty(n * 3 + 16, dtype=torch.int32, device="cuda")
+ws = torch.empty(n * 4 + 16, dtype=torch.int32, device="cuda")
 
 
 def run(name, neg_rate, n_neg, neg_inj, iters=30, t0=100, slices=0):

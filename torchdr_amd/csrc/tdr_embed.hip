@@ -112,7 +112,7 @@ struct UmapStepParams {
     float* grad;             // (n_rows, NC)
     // sliced negative phase (large N): the positive pass stores the row's negative count and the slice passes
     // accumulate the repulsion in gr_acc before the clamp
-    int32_t* nuse;           // (n_rows) or NULL = single pass
+    int32_t* nuse;           // (n_rows, 2) row headers {n_use | slice counts << 8.., hash key} or NULL = single pass
     float* gr_acc;           // (n_rows, NC)
     int64_t j_lo, j_hi;      // slice of negative indices handled by this pass
     int first, last;
@@ -132,6 +132,26 @@ __device__ __forceinline__ float sqdist(const Vec<NC>& a, const Vec<NC>& b, floa
 // flight per lane -- the kernel is bound by the latency of the random 8-byte reads of Z (8 MB at N = 1M,
 // larger than one XCD's L2), so memory-level parallelism is what buys throughput.  `cols` is read for every
 // edge (4 B) so that the gather does not wait for the activity test; eps_per only where the edge fires.
+__device__ __forceinline__ int binomial_half(uint32_t key, int n) {
+    int m = 0;
+    for (int t = 0; t * 32 < n; ++t) {
+        uint32_t w = mix32(key + 0x7F4A7C15u * (uint32_t)(t + 1));
+        const int rem = n - t * 32;
+        if (rem < 32) w &= (1u << rem) - 1u;
+        m += __popc(w);
+    }
+    return m;
+}
+__device__ __forceinline__ int slice_count(uint32_t rkey, int n_use, int slice, int n_slices) {
+    const int lo = binomial_half(rkey ^ 0x9E3779B9u, n_use);          // slices {0..S/2-1} | {S/2..S-1}
+    int mine = (slice < n_slices / 2) ? lo : n_use - lo;
+    if (n_slices == 4) {
+        const int q = binomial_half(rkey ^ (0x85EBCA6Bu + 0x27D4EB2Fu * (uint32_t)(slice >> 1)), mine);
+        mine = (slice & 1) ? mine - q : q;
+    }
+    return mine;
+}
+
 template <int NC, int G, int U, bool POS_ONLY = false>
 __global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) {
     const int gl = threadIdx.x % G;
@@ -193,7 +213,18 @@ __global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) 
     if (n_use > P.n_negatives) n_use = P.n_negatives;
     if (POS_ONLY) {  // the negatives are evaluated by the slice passes (umap_neg_slice_kernel)
         if (gl == 0) {
-            P.nuse[r] = n_use;
+            // row header for the negative passes: n_use and the counts of slices 0..2 packed in one word (<= 150 < 256
+            // each; the last slice gets the rest), and the row's hash key -- computed here, where the VALU has slack
+            // (this pass is HBM-bound), so that the VALU-bound dense passes do not redo it
+            const uint32_t rkey = neg_row_key(P.seed, P.iter, gi);
+            uint32_t info = (uint32_t)n_use;
+            if (P.n_slices == 2 || P.n_slices == 4) {
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl)
+                    if (sl < P.n_slices - 1) info |= (uint32_t)slice_count(rkey, n_use, sl, P.n_slices) << (8 * (sl + 1));
+            }
+            P.nuse[2 * r] = (int32_t)info;
+            P.nuse[2 * r + 1] = (int32_t)rkey;
 #pragma unroll
             for (int c = 0; c < NC; ++c) P.grad[(size_t)r * NC + c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f);
         }
@@ -257,7 +288,7 @@ __global__ __launch_bounds__(256) void umap_neg_slice_kernel(const UmapStepParam
     if (r >= P.n_rows) return;
     const int64_t gi = P.row0 + r;
     const Vec<NC> zi = load_z<NC>(P.Z, gi);
-    const int n_use = P.nuse[r];
+    const int n_use = P.nuse[2 * r] & 0xff;
     float gr[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) gr[c] = 0.f;
@@ -312,26 +343,6 @@ __global__ __launch_bounds__(256) void umap_neg_slice_kernel(const UmapStepParam
 // bits (Binomial(n, 1/2)), applied once for 2 slices and twice for 4; inside its slice every negative is uniform.
 // "Split the count, then draw uniformly inside the part" has the same distribution as n i.i.d. uniform draws from
 // {0..N-1} minus the row itself (reference: r ~ U{0..N-2}, j = r + (r >= i); neighbor_embedding/base.py:628-636).
-__device__ __forceinline__ int binomial_half(uint32_t key, int n) {
-    int m = 0;
-    for (int t = 0; t * 32 < n; ++t) {
-        uint32_t w = mix32(key + 0x7F4A7C15u * (uint32_t)(t + 1));
-        const int rem = n - t * 32;
-        if (rem < 32) w &= (1u << rem) - 1u;
-        m += __popc(w);
-    }
-    return m;
-}
-__device__ __forceinline__ int slice_count(uint32_t rkey, int n_use, int slice, int n_slices) {
-    const int lo = binomial_half(rkey ^ 0x9E3779B9u, n_use);          // slices {0..S/2-1} | {S/2..S-1}
-    int mine = (slice < n_slices / 2) ? lo : n_use - lo;
-    if (n_slices == 4) {
-        const int q = binomial_half(rkey ^ (0x85EBCA6Bu + 0x27D4EB2Fu * (uint32_t)(slice >> 1)), mine);
-        mine = (slice & 1) ? mine - q : q;
-    }
-    return mine;
-}
-
 template <int NC, int G, int U>
 __global__ __launch_bounds__(256) void umap_neg_dense_kernel(const UmapStepParams P) {
     const int gl = threadIdx.x % G;
@@ -339,8 +350,14 @@ __global__ __launch_bounds__(256) void umap_neg_dense_kernel(const UmapStepParam
     if (r >= P.n_rows) return;
     const uint32_t gi = (uint32_t)(P.row0 + r);
     const Vec<NC> zi = load_z<NC>(P.Z, gi);
-    const uint32_t rkey = neg_row_key(P.seed, P.iter, (int64_t)gi);
-    const int n_cols = slice_count(rkey, P.nuse[r], P.slice, P.n_slices);
+    const uint32_t info = (uint32_t)P.nuse[2 * r];
+    const uint32_t rkey = (uint32_t)P.nuse[2 * r + 1];
+    int n_cols;
+    if (P.slice < P.n_slices - 1) n_cols = (int)((info >> (8 * (P.slice + 1))) & 0xffu);
+    else {
+        n_cols = (int)(info & 0xffu);
+        for (int sl = 0; sl < P.n_slices - 1; ++sl) n_cols -= (int)((info >> (8 * (sl + 1))) & 0xffu);
+    }
     // this slice of the reduced index range [0, N-1)
     const uint32_t nred = (uint32_t)(P.n_total - 1);
     const uint32_t step = (nred + (uint32_t)P.n_slices - 1u) / (uint32_t)P.n_slices;
@@ -763,12 +780,12 @@ static int umap_neg_slices(int64_t n_total, int nc) {
 int64_t tdr_umap_grad_workspace_bytes(int64_t n_total, int64_t n_rows, int nc) {
     if (n_total < 2 || n_rows <= 0 || (nc != 2 && nc != 3)) return 0;
     if (umap_neg_slices(n_total, nc) <= 1) return 0;
-    return n_rows * (int64_t)sizeof(int32_t) + n_rows * nc * (int64_t)sizeof(float);
+    return 2 * n_rows * (int64_t)sizeof(int32_t) + n_rows * nc * (int64_t)sizeof(float);
 }
 
 /* One evaluation of UMAP's closed-form gradient for rows [row0, row0 + n_rows): grad (n_rows, nc).
  * neg_slices: 0 = automatic (L2-sliced negative phase for large N), 1 = single pass, > 1 = that many slices.
- * The sliced phase needs ws >= n_rows * (4 + 4 * nc) bytes (tdr_umap_grad_workspace_bytes for the automatic
+ * The sliced phase needs ws >= n_rows * (8 + 4 * nc) bytes (tdr_umap_grad_workspace_bytes for the automatic
  * choice); without it the single-pass kernel runs. */
 int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int64_t* rowptr,
                       const int32_t* cols, const float* eps_per, float* next, float a, float b, int n_iter,
@@ -785,10 +802,11 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
     hipStream_t st = (hipStream_t)stream;
     int slices = neg_slices > 0 ? neg_slices : umap_neg_slices(n_total, nc);
     if (slices > n_total) slices = (int)n_total;
-    const int64_t need = n_rows * (int64_t)sizeof(int32_t) + n_rows * nc * (int64_t)sizeof(float);
+    const int64_t need = 2 * n_rows * (int64_t)sizeof(int32_t) + n_rows * nc * (int64_t)sizeof(float);
     if (slices > 1 && ws && ws_bytes >= need && n_negatives > 0 && neg_rate > 0) {
         P.nuse = (int32_t*)ws;
-        P.gr_acc = (float*)((char*)ws + n_rows * sizeof(int32_t));
+        P.n_slices = slices;
+        P.gr_acc = (float*)((char*)ws + 2 * n_rows * sizeof(int32_t));
         int rc = (nc == 2) ? launch_group<16>(umap_grad_kernel<2, 16, 4, true>, P, n_rows, st)
                            : launch_group<16>(umap_grad_kernel<3, 16, 4, true>, P, n_rows, st);
         if (rc != TDR_OK) return rc;
