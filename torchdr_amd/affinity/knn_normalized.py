@@ -1,7 +1,6 @@
 """UMAP input affinity on the GPU -- mirror of ``UMAPAffinity``
 (reference ``affinity/knn_normalized.py:335-496``)."""
 
-import math
 from typing import Union
 
 import torch

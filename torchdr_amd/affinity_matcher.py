@@ -16,7 +16,6 @@ from typing import Any, Dict, Optional, Type, Union
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from torchdr_amd import _lib
 from torchdr_amd.affinity import Affinity, SparseAffinity

@@ -3,7 +3,6 @@
 from typing import Dict, Optional, Type, Union
 
 import torch
-import torch.distributed as dist
 
 from torchdr_amd import _lib
 from torchdr_amd.affinity import EntropicAffinity

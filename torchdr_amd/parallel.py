@@ -8,7 +8,7 @@ Call sites being replaced:
         INTEGER (int32) index payload (the reference ships indices as fp32, exact only below 2^24).
 """
 
-from typing import List, Tuple
+from typing import Tuple
 
 import torch
 import torch.distributed as dist
