@@ -75,7 +75,7 @@ int tdr_knn_overlap_i32(const int32_t* a, const int32_t* b, int64_t n, int K, fl
 /* ---- K1s: two-stage exact kNN (fp16-split screening on the f16 matrix pipe + exact fp32 rescoring) ----
  * Same results, bit for bit, as tdr_knn_packed_f32 (hence as distance/torch.py:82-120 + utils/utils.py:215):
  * the screening pass only decides WHICH pairs get their reference-arithmetic distance evaluated, with a
- * worst-case error band (torchdr_amd/csrc/tdr_knn_screen.hip header).  sqeuclidean / euclidean, D <= 128. */
+ * worst-case error band (torchdr_amd/csrc/tdr_knn_screen.hip header).  sqeuclidean / euclidean, D <= 256. */
 int tdr_knn_screen_supported(int d, int k);
 int64_t tdr_packed16_floats(int64_t n, int d);
 /* meta: 2 x uint32 on the device, zeroed by the caller; accumulates max |X| (and max norms[i] when norms != NULL)

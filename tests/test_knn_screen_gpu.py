@@ -32,7 +32,7 @@ def both_paths(X, k, metric, exclude, Y=None):
 
 
 @pytest.mark.parametrize("scale", [0.0, 2.0, 10.0])
-@pytest.mark.parametrize("d,k", [(128, 30), (128, 15), (32, 30), (50, 10), (64, 45), (100, 90)])
+@pytest.mark.parametrize("d,k", [(128, 30), (128, 15), (32, 30), (50, 10), (64, 45), (100, 90), (200, 30), (256, 15)])
 def test_screen_equals_exact(d, k, scale):
     X = gmm(6000, d, scale, seed=11 + d + k).cuda()
     (C0, I0), (C1, I1), flagged = both_paths(X, k, "sqeuclidean", True)
@@ -162,7 +162,7 @@ def test_screen_one_term_tier_equals_exact(d, k, scale):
 
 
 @pytest.mark.parametrize("scale,n,d,k,tier", [(2.0, 20000, 128, 30, 1), (0.0, 9000, 64, 15, 0), (2.0, 7001, 100, 40, 1),
-                                              (4.0, 30000, 32, 10, 1)])
+                                              (4.0, 30000, 32, 10, 1), (2.0, 12000, 256, 30, 1), (1.0, 8000, 192, 20, 0)])
 def test_screen_cluster_pruned_scan_equals_exact(scale, n, d, k, tier):
     """Cluster-bound pruning (points sorted by a coarse k-means, clusters padded to tile boundaries, clusters whose
     ball cannot reach the thresholds skipped): results must not depend on it -- bit-identical to the one-stage kernel,

@@ -406,7 +406,7 @@ __device__ __forceinline__ void stile_drain(const SCtx<QB>& C, const f32x16 (&pr
 // two MFMA chains off the same A fragments -- half the LDS reads, LDS-DMA instructions and barriers per matrix
 // instruction.
 template <int KS, int ITEMS, int QB, int TERMS>
-__global__ __launch_bounds__(256, (QB == 1 && ITEMS == 1) ? 2 : 1) void knn_screen_kernel(const ScreenParams P) {
+__global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) void knn_screen_kernel(const ScreenParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NW = 4;
     constexpr int IMG_B = KS * 2048;                 // bytes of the fragment blocks of one tile image in HBM
@@ -790,6 +790,7 @@ static inline int pick_ks(int d) {
     if (d <= 32) return 2;
     if (d <= 64) return 4;
     if (d <= 128) return 8;
+    if (d <= 256) return 16;  // 32-KiB tiles and 128 query-fragment VGPRs: one workgroup per CU (one wavefront per SIMD)
     return 0;
 }
 
@@ -824,11 +825,11 @@ static ScreenCfg screen_cfg(int ks, int k, int tier) {
     const int spare_min = 8;
     ScreenCfg c = {0, 0, 0, 0, 3};
     if (tier == 0) {
-        const int L2 = max_list_len(ks, 1, 1, 80 * 1024, 64);
-        if (k + 16 <= L2) { c.qb = 1; c.L = L2; c.items = 1; c.wg_per_cu = 2; c.terms = 1; }
+        const int L2 = max_list_len(ks, 1, 1, (ks > 8 ? 160 : 80) * 1024, 64);
+        if (k + 16 <= L2) { c.qb = 1; c.L = L2; c.items = 1; c.wg_per_cu = ks > 8 ? 1 : 2; c.terms = 1; }
         return c;
     }
-    if (tier == 1) {
+    if (tier == 1 && ks <= 8) {
         if (screen_qb_pref() == 2) {
             const int Lq = max_list_len(ks, 2, 3, 160 * 1024, 64);
             if (k + spare_min <= Lq) { c.qb = 2; c.L = (k + 24 < Lq) ? k + 24 : Lq; c.items = 1; c.wg_per_cu = 1; return c; }
@@ -879,7 +880,9 @@ static int launch_screen(const ScreenParams& P, int n_wgs, size_t lds, hipStream
 template <int KS>
 static int launch_screen_ks(const ScreenParams& P, const ScreenCfg& c, int n_wgs, size_t lds, hipStream_t st) {
     if (c.terms == 1) return launch_screen<KS, 1, 1, 1>(P, n_wgs, lds, st);
-    if (c.qb == 2) return launch_screen<KS, 1, 2, 3>(P, n_wgs, lds, st);
+    if constexpr (KS <= 8) {
+        if (c.qb == 2) return launch_screen<KS, 1, 2, 3>(P, n_wgs, lds, st);
+    }
     if (c.items == 1) return launch_screen<KS, 1, 1, 3>(P, n_wgs, lds, st);
     return launch_screen<KS, 2, 1, 3>(P, n_wgs, lds, st);
 }
@@ -1031,7 +1034,8 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     switch (ks) {
         case 2: rc = launch_screen_ks<2>(P, cfg, wgs, lds, st); break;
         case 4: rc = launch_screen_ks<4>(P, cfg, wgs, lds, st); break;
-        default: rc = launch_screen_ks<8>(P, cfg, wgs, lds, st); break;
+        case 8: rc = launch_screen_ks<8>(P, cfg, wgs, lds, st); break;
+        default: rc = launch_screen_ks<16>(P, cfg, wgs, lds, st); break;
     }
     if (rc != TDR_OK) return rc;
 
