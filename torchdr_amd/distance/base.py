@@ -122,8 +122,14 @@ class ClusterIndex:
         seeds = torch.empty(C, dtype=torch.int32, device=dev)
         ws_bytes = L.tdr_maxmin_workspace_bytes(S, C)
         ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
-        _lib.check(L.tdr_maxmin_seeds_f32(_lib.ptr(Xs), S, D, Xs.stride(0), C, _lib.ptr(seeds), _lib.ptr(ws), ws_bytes,
-                                          _lib.stream_ptr()), "tdr_maxmin_seeds_f32")
+        # the C sequential seeding steps read the whole sample each: run them on a 32-d random projection (distances
+        # within ~25 %, plenty for picking well-separated seeds; the centres themselves are taken in the full space)
+        Xp = Xs
+        if D > 32:
+            R = torch.randn((D, 32), dtype=X.dtype, device=dev, generator=g) * (1.0 / 32 ** 0.5)
+            Xp = torch.mm(Xs, R)
+        _lib.check(L.tdr_maxmin_seeds_f32(_lib.ptr(Xp), S, Xp.shape[1], Xp.stride(0), C, _lib.ptr(seeds), _lib.ptr(ws),
+                                          ws_bytes, _lib.stream_ptr()), "tdr_maxmin_seeds_f32")
         cent = Xs[seeds.long()].clone()
         for _ in range(iters):
             lab = ((cent * cent).sum(1)[None, :] - 2.0 * torch.mm(Xs, cent.t())).argmin(1)
