@@ -52,6 +52,22 @@ def _worker(rank, world, port, n_rows, ret):
         g = torch.full((4, 2), float(rank + 1))
         allreduce_(g)
         assert torch.equal(g, torch.full((4, 2), float(sum(range(1, world + 1)))))
+        # kNN rows computed for arbitrary global rows travel to their owners (pruned sharded search): every rank holds
+        # the rows of an interleaved subset, afterwards each owns its contiguous chunk in row order
+        from torchdr_amd.parallel import allreduce_max_, broadcast_, exchange_rows_to_owners
+
+        k = 5
+        allC = torch.arange(n_rows * k, dtype=torch.float32).reshape(n_rows, k)
+        allI = (torch.arange(n_rows * k, dtype=torch.int64).reshape(n_rows, k) % 1000).to(torch.int32)
+        mine = torch.arange(rank, n_rows, world)                    # rows this rank "searched"
+        Cc, Ic = exchange_rows_to_owners(mine.to(torch.int32), allC[mine], allI[mine], n_rows, world, s, e - s)
+        assert torch.equal(Cc, allC[s:e]) and torch.equal(Ic, allI[s:e])
+        v = torch.tensor([float(rank == 1), float(rank), 10.0 - rank], dtype=torch.float64)
+        allreduce_max_(v)
+        assert v.tolist() == [1.0, float(world - 1), 10.0]
+        b = torch.arange(6, dtype=torch.int32) * (1 if rank == 0 else 0)
+        broadcast_(b)
+        assert b.tolist() == list(range(6))
         ret[rank] = True
     finally:
         dist.destroy_process_group()
