@@ -368,7 +368,13 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
     n, W, rank = Y.n, ctx.world_size, ctx.rank
     c0, c1 = ctx.compute_chunk_bounds(n)
     ops = _screen_operands(Y, Y)
-    tier, tau = _choose_tier(Y, Y, ops, (c0 // 32) * 32, k, metric, exclude_self, 0)
+    # rank 0 builds the cluster index while the other ranks run the pilot on their chunks (its own chunk is no more
+    # telling than theirs, so it abstains from the vote); identical tables are broadcast afterwards
+    if rank == 0 and W > 1:
+        ci = ClusterIndex(Y)
+        tier, tau = 0, None
+    else:
+        tier, tau = _choose_tier(Y, Y, ops, (c0 // 32) * 32, k, metric, exclude_self, 0)
     # one decision for all ranks: any rank without a usable tier -> nobody prunes; else the most conservative tier and
     # the largest threshold estimate (element-wise MAX all-reduce)
     vote = torch.tensor([float(tier < 0), float(max(tier, 0)), 0.0 if tau is None else tau], dtype=torch.float64, device=dev)
@@ -376,9 +382,9 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
     if float(vote[0]) > 0:
         return None
     tier, tau = int(vote[1]), float(vote[2])
-    # index: rank 0 builds, everybody receives identical tables
     if rank == 0:
-        ci = ClusterIndex(Y)
+        if W == 1:
+            ci = ClusterIndex(Y)
         head = torch.tensor([ci.n_clusters, ci.n_img], dtype=torch.int64, device=dev)
     else:
         ci = ClusterIndex.__new__(ClusterIndex)
