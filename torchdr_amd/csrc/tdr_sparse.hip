@@ -31,6 +31,41 @@ __global__ __launch_bounds__(256) void sym_rowsort_kernel(const float* __restric
     if (row >= n) return;
     const int32_t* rc = cols + (size_t)row * k;
     const float* rv = vals + (size_t)row * k;
+    if (k <= 64) {
+        // one entry per lane: duplicates are summed in original order, distinct columns ranked -- two sweeps of
+        // wave-uniform (readlane) comparisons instead of the general path's O(k^3) scalar loops
+        const bool have = lane < k;
+        const int32_t mycol = have ? rc[lane] : INT_MAX;
+        const float myval = have ? rv[lane] : 0.f;
+        bool first = have;
+        float sum = 0.f;
+        for (int q = 0; q < k; ++q) {
+            const int32_t cq = __builtin_amdgcn_readlane(mycol, q);
+            const float vq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myval), q));
+            if (have && cq == mycol) {
+                sum = __fadd_rn(sum, vq);
+                if (q < lane) first = false;
+            }
+        }
+        unsigned long long fm = __ballot(first);
+        const int uniq = __popcll(fm);
+        int rank = 0;
+        while (fm) {
+            const int q = __builtin_ctzll(fm);
+            fm &= fm - 1;
+            rank += (__builtin_amdgcn_readlane(mycol, q) < mycol) ? 1 : 0;
+        }
+        if (first) {
+            scols[(size_t)row * k + rank] = mycol;
+            svals[(size_t)row * k + rank] = sum;
+        }
+        if (lane >= uniq && lane < k) {
+            scols[(size_t)row * k + lane] = INT_MAX;
+            svals[(size_t)row * k + lane] = 0.f;
+        }
+        if (lane == 0) slen[row] = uniq;
+        return;
+    }
     int uniq_total = 0;
     for (int p0 = 0; p0 < k; p0 += 64) {
         const int p = p0 + lane;
