@@ -783,7 +783,15 @@ __global__ __launch_bounds__(256) void maxmin_step_kernel(const float* __restric
                                          (uint32_t)__shfl_xor((int)(key & 0xffffffffull), o, 64);
         key = other > key ? other : key;
     }
-    if ((threadIdx.x & 63) == 0 && key) atomicMax(best_next, key);
+    // one atomic per workgroup (the step is otherwise bound by the serialisation of the same-address atomics)
+    __shared__ unsigned long long wkey[4];
+    if ((threadIdx.x & 63) == 0) wkey[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long m = wkey[0];
+        for (int w = 1; w < 4; ++w) m = wkey[w] > m ? wkey[w] : m;
+        if (m) atomicMax(best_next, m);
+    }
 }
 
 static inline int pick_ks(int d) {
