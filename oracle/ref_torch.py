@@ -326,6 +326,19 @@ def infotsne_repulsion_grad(Z, neg, n_total, rows=None):
     return g
 
 
+def pacmap_affinity(X, n_neighbors):
+    """affinity/knn_normalized.py:574-611 (PACMAPAffinity): the n_neighbors + 50 nearest by squared distance
+    (self excluded), rho_i = mean Euclidean distance to the 4th-6th, rescale by rho_i * rho_j, keep the n_neighbors
+    smallest.  Returns (indices (n, n_neighbors) int64, rho)."""
+    n = X.shape[0]
+    k = min(n_neighbors + 50, n)
+    C, I = knn_chunked(X, k, "sqeuclidean", True)
+    rho = torch.sqrt(C[:, :6])[:, 3:6].mean(dim=1)
+    Cs = C / (rho[:, None] * rho[I.long()])
+    local = torch.topk(Cs, n_neighbors, dim=1, largest=False).indices
+    return torch.gather(I.long(), 1, local), rho
+
+
 def pacmap_grad(Z, near, mid, far, w_nb, w_mn, w_fp):
     """d/dZ of PaCMAP's pair losses (neighbor_embedding/pacmap.py:213-265), q = 1 + d:
     w_nb sum q/(10+q) over near pairs, w_mn sum q/(1e4+q) over mid-near pairs, w_fp sum 1/(1+q) over further pairs;

@@ -163,6 +163,13 @@ def test_ne2_step_oracle(name):
         assert torch.allclose(Znew, g[f"{name}_Zafter_{t}"], rtol=1e-5, atol=1e-7)
 
 
+def test_pacmap_affinity_oracle():
+    g = load("pacmap")
+    idx, rho = R.pacmap_affinity(g["X"], 10)
+    assert torch.allclose(rho, g["aff_rho"], rtol=1e-6)
+    assert torch.equal(idx.sort(1).values, g["aff_idx"].sort(1).values)
+
+
 def test_pacmap_oracle():
     """PaCMAP closed-form gradient vs the reference's autograd for the four captured steps (all weight phases)."""
     g = load("pacmap")
