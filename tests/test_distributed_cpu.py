@@ -49,6 +49,15 @@ def _worker(rank, world, port, n_rows, ret):
         full = torch.arange(n_rows * 2, dtype=torch.float32).reshape(n_rows, 2)
         out = allgather_rows(full[s:e].clone(), n_rows, world)
         assert torch.equal(out, full)
+        # in-place form (per-iteration exchange of updated rows): equal chunks -> send buffer aliases its slot
+        from torchdr_amd.parallel import allgather_rows_
+
+        for n_eq in (n_rows - n_rows % world, n_rows):               # equal chunks, then (possibly) uneven ones
+            ref = torch.arange(n_eq * 2, dtype=torch.float32).reshape(n_eq, 2)
+            s2, e2 = chunk_bounds(n_eq, rank, world)
+            mine_only = torch.full_like(ref, -1.0)
+            mine_only[s2:e2] = ref[s2:e2]
+            assert allgather_rows_(mine_only, s2, e2 - s2, world) is mine_only and torch.equal(mine_only, ref)
         g = torch.full((4, 2), float(rank + 1))
         allreduce_(g)
         assert torch.equal(g, torch.full((4, 2), float(sum(range(1, world + 1)))))

@@ -185,14 +185,14 @@ class AffinityMatcher(DRModule):
         grad, rows_only = self._compute_gradients()
         world = getattr(self, "world_size", 1)
         if world > 1 and rows_only and self._fused_sgd:
-            from torchdr_amd.parallel import allgather_rows
+            from torchdr_amd.parallel import allgather_rows_
 
             c0, c1 = self.chunk_start_, self.chunk_start_ + self.chunk_size_
             rows = self.embedding_[c0:c1]
             self._last_grad = grad
             self._last_grad_is_chunk = True
             self._sgd_kernel(rows, grad, chunk=True)
-            self.embedding_.copy_(allgather_rows(rows, self.n_samples_in_, world))
+            allgather_rows_(self.embedding_, c0, self.chunk_size_, world)
             self._lr_pos += 1
             return None
         if world > 1:

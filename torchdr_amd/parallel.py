@@ -82,6 +82,19 @@ def allgather_rows(local_rows: torch.Tensor, n_total: int, world_size: int) -> t
     return torch.cat(parts)
 
 
+def allgather_rows_(full: torch.Tensor, chunk_start: int, chunk_size: int, world_size: int) -> torch.Tensor:
+    """In-place form for the per-iteration exchange: ``full[chunk_start : chunk_start + chunk_size]`` holds this rank's
+    updated rows; on return every rank's rows are in ``full``.  With equal chunks the rank's send buffer IS its slot of
+    the receive buffer (the in-place all-gather RCCL supports: no staging copy, no scratch allocation per iteration);
+    uneven chunks or host-staged backends fall back to :func:`allgather_rows`."""
+    n = full.shape[0]
+    if n == chunk_size * world_size and full.is_contiguous() and not (_host_staged() and full.is_cuda):
+        dist.all_gather_into_tensor(full, full[chunk_start: chunk_start + chunk_size])
+        return full
+    full.copy_(allgather_rows(full[chunk_start: chunk_start + chunk_size], n, world_size))
+    return full
+
+
 def route_edges(values: torch.Tensor, indices: torch.Tensor, chunk_start: int, n_total: int, world_size: int,
                 rank: int):
     """Split this rank's edges (i -> j, v) by the owner of j.  Returns per-destination lists of
