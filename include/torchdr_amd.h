@@ -55,8 +55,8 @@ int tdr_knn_packed_f32(const float* qp, int64_t nq, int64_t q_offset, const floa
 int tdr_dense_dist_packed_f32(const float* qp, int64_t nq, int64_t q_offset, const float* yp, int64_t n_db, int d,
                               int metric, int exclude_self, float diag_add, float* out, int64_t ldo, void* stream);
 
-/* gathered distances out[i][c] = ||X[q_i] - Y[keys[i][c]]||^2 (distance/base.py:384-385); negative
- * indices wrap like PyTorch indexing. */
+/* gathered distances out[i][c] = ||X[q_i] - Y[keys[i][c]]||^2 (distance/base.py:384-385; take_sqrt = 1: its square
+ * root, :386-387; take_sqrt = 2: sum_c |x - y|, manhattan, :388-389; 3: -sum_c x y, angular, :390-391); negative indices wrap like PyTorch indexing. */
 int tdr_indexed_sqdist_f32(const float* X, int64_t nx, int d, const float* Y, int64_t ny, const int64_t* q,
                            int64_t nq, int nk, int take_sqrt, const int64_t* keys, float* out, void* stream);
 
@@ -68,6 +68,22 @@ int tdr_topk_merge_f32(const float* G, int64_t ldg, int64_t nq, int64_t nd, cons
                        int64_t q_global0, int64_t d_global0, int k, int metric, int exclude_self, uint64_t* run_keys,
                        void* stream);
 int tdr_topk_emit_f32(const uint64_t* run_keys, int64_t nq, int k, int metric, float* out_d, int32_t* out_i, void* stream);
+/* the same fold over per-query candidate lists: E (nq, nc) distances, cand (nq, nc) database indices (row stride ld,
+ * negative = skip); ranks exactly re-evaluated candidates by (distance, index) */
+int tdr_topk_merge_cand_f32(const float* E, const int32_t* cand, int64_t ld, int64_t nq, int64_t nc, int k,
+                            uint64_t* run_keys, void* stream);
+
+/* Manhattan metric (distance/torch.py:96-98, distance/base.py:368): out[i][j] = sum_c |X[i][c] - Y[j][c]| for an
+ * (nq x nd) block with row strides ldx / ldy / ldo.  kNN = this block + tdr_topk_merge_f32 with metric 3. */
+int tdr_l1_block_f32(const float* X, int64_t ldx, int64_t nq, const float* Y, int64_t ldy, int64_t nd, int d, float* out,
+                     int64_t ldo, void* stream);
+/* The same distance evaluated in the reference's own summation order (ATen's vectorised inner sum: 32 interleaved
+ * running sums, cascade every 16 rounds -- the float the CPU backend returns, distance/torch.py:98), one thread per
+ * (query, candidate): query i = row q_rows[i] of X (or row i; global id = q_global0 + that row), database row
+ * cand[i][c] (negative -> +inf) or j0 + c when cand is NULL; exclude_self: own row -> +inf.  d < 8192. */
+int tdr_l1_exact_f32(const float* X, int64_t ldx, const int64_t* q_rows, int64_t nq, int64_t q_global0, const float* Y,
+                     int64_t ldy, const int32_t* cand, int64_t ldc, int64_t nc, int64_t j0, int d, int exclude_self,
+                     float* out, int64_t ldo, void* stream);
 
 /* kNN consumers: eval/neighborhood_preservation.py:175-181 (per-row overlap of two neighbour lists) */
 int tdr_knn_overlap_i32(const int32_t* a, const int32_t* b, int64_t n, int K, float* out, void* stream);

@@ -7,6 +7,7 @@
  * What it restates (reference = /root/reference/torchdr, read-only):
  *   - distance/torch.py:82-91   X_norm = (X**2).sum(-1);  C = X_norm[:,None] + Y_norm[None,:] - 2*(X @ Y.T)
  *   - distance/torch.py:93-95   euclidean = sqrt(clamp(C, 0))
+ *   - distance/torch.py:96-98   manhattan = (X[:,None,:] - Y[None,:,:]).abs().sum(-1)
  *   - distance/torch.py:99-100  angular   = -(X @ Y.T)            (no normalisation)
  *   - distance/torch.py:111-116 self exclusion (diag += 1e12)     == "skip j == i" whenever k < N
  *   - utils/utils.py:215-216    kmin = topk(k, largest=False), indices -> int32
@@ -84,8 +85,8 @@ static void row_sum_w(const float *sq, int64_t size, int w, float *out) {
     for (int l = 0; l < w; ++l) out[l] = part[l];
 }
 
-static float sqnorm_aten(const float *x, int d, float *sq /* scratch d floats */) {
-    for (int k = 0; k < d; ++k) sq[k] = x[k] * x[k]; /* X**2 is materialised (rounded) first */
+/* ATen's sum of d contiguous floats (the order every last-dim .sum(-1) of the reference's CPU path uses) */
+static float sum_aten(const float *sq, int d) {
     const int V = 8;
     if (d >= V) {
         const int64_t vec_size = d / V;
@@ -99,6 +100,17 @@ static float sqnorm_aten(const float *x, int d, float *sq /* scratch d floats */
     float p1[1];
     row_sum_w(sq, d, 1, p1);
     return p1[0];
+}
+
+static float sqnorm_aten(const float *x, int d, float *sq /* scratch d floats */) {
+    for (int k = 0; k < d; ++k) sq[k] = x[k] * x[k]; /* X**2 is materialised (rounded) first */
+    return sum_aten(sq, d);
+}
+
+/* distance/torch.py:96-98: (x - y).abs().sum(-1) -- difference materialised (rounded), |.| exact, ATen sum order */
+static float l1_aten(const float *x, const float *y, int d, float *sq /* scratch d floats */) {
+    for (int k = 0; k < d; ++k) sq[k] = fabsf(x[k] - y[k]);
+    return sum_aten(sq, d);
 }
 
 void oracle_sqnorms_f32(const float *X, int64_t n, int d, float *out) {
@@ -142,7 +154,7 @@ static int cmp_u64(const void *a, const void *b) {
     return (x > y) - (x < y);
 }
 
-enum { METRIC_SQEUCLIDEAN = 0, METRIC_EUCLIDEAN = 1, METRIC_ANGULAR = 2 };
+enum { METRIC_SQEUCLIDEAN = 0, METRIC_EUCLIDEAN = 1, METRIC_ANGULAR = 2, METRIC_MANHATTAN = 3 };
 
 /* dot products of one query against a block of database rows, database stored transposed
  * (YT[k*ldt + j]) so the compiler vectorises over j; each acc[j] is a k-ordered FMA chain. */
@@ -164,7 +176,7 @@ static void dots_block(const float *x, const float *YT, size_t ldt, int64_t j0, 
  */
 int oracle_knn_f32(const float *X, int64_t nq, int64_t q_offset, const float *Y, int64_t n, int d, int k,
                    int metric, int exclude_self, float *out_d, int32_t *out_i, float *out_full) {
-    if (nq < 0 || n <= 0 || d <= 0 || k < 0 || metric < 0 || metric > 2) return -1;
+    if (nq < 0 || n <= 0 || d <= 0 || k < 0 || metric < 0 || metric > 3) return -1;
     if (k > 0 && k > n - (exclude_self ? 1 : 0)) return -1;
     float *xn = (float *)malloc(sizeof(float) * (size_t)(nq > 0 ? nq : 1));
     float *yn = (float *)malloc(sizeof(float) * (size_t)n);
@@ -179,6 +191,7 @@ int oracle_knn_f32(const float *X, int64_t nq, int64_t q_offset, const float *Y,
 #pragma omp parallel
     {
         float *acc = (float *)malloc(sizeof(float) * (size_t)BLK);
+        float *dif = (float *)malloc(sizeof(float) * (size_t)d);
         uint64_t *heap = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(k > 0 ? k : 1));
 #pragma omp for schedule(dynamic, 16)
         for (int64_t i = 0; i < nq; ++i) {
@@ -186,11 +199,15 @@ int oracle_knn_f32(const float *X, int64_t nq, int64_t q_offset, const float *Y,
             int filled = 0;
             for (int64_t j0 = 0; j0 < n; j0 += BLK) {
                 const int64_t nb = (n - j0 < BLK) ? (n - j0) : BLK;
-                dots_block(x, YT, (size_t)n, j0, nb, d, acc);
+                if (metric == METRIC_MANHATTAN)
+                    for (int64_t jj = 0; jj < nb; ++jj) acc[jj] = l1_aten(x, Y + (size_t)(j0 + jj) * d, d, dif);
+                else
+                    dots_block(x, YT, (size_t)n, j0, nb, d, acc);
                 for (int64_t jj = 0; jj < nb; ++jj) {
                     const int64_t j = j0 + jj;
                     float c;
-                    if (metric == METRIC_ANGULAR) c = -acc[jj];
+                    if (metric == METRIC_MANHATTAN) c = acc[jj];
+                    else if (metric == METRIC_ANGULAR) c = -acc[jj];
                     else {
                         const float s = xn[i] + yn[j];
                         const float t = 2.0f * acc[jj];
@@ -225,6 +242,7 @@ int oracle_knn_f32(const float *X, int64_t nq, int64_t q_offset, const float *Y,
             }
         }
         free(acc);
+        free(dif);
         free(heap);
     }
     free(xn); free(yn); free(YT);

@@ -26,8 +26,10 @@ def knn_chunked(X, k, metric="sqeuclidean", exclude_self=True, Y=None, chunk=409
     outC, outI = [], []
     for s in range(r0, r1, chunk):
         e = min(s + chunk, r1)
-        dot = X[s:e] @ Yd.T
-        if metric == "angular":
+        dot = None if metric == "manhattan" else X[s:e] @ Yd.T
+        if metric == "manhattan":  # distance/torch.py:96-98 (an (chunk, m, d) intermediate: keep ``chunk`` small)
+            C = (X[s:e].unsqueeze(-2) - Yd.unsqueeze(-3)).abs().sum(dim=-1)
+        elif metric == "angular":
             C = -dot
         else:
             C = xn[s:e, None] + yn[None, :] - 2 * dot

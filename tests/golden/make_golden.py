@@ -370,12 +370,48 @@ def pacmap_fixture():
     save("pacmap", **out)
 
 
+def manhattan_fixture():
+    """metric='manhattan' (distance/torch.py:96-98, distance/base.py:368, 388): kNN incl. a cascade-length feature
+    dimension and an integer-valued (heavily tied) set, cross / dense forms, the gathered forms, one affinity."""
+    out = {}
+    cases = [(600, 128, 2.0, 15, True), (500, 37, 2.0, 10, True), (300, 5, 0.0, 7, False), (250, 600, 2.0, 5, True)]
+    for i, (n, d, s, k, excl) in enumerate(cases):
+        X = gmm(n, d, s, seed=31 + i)
+        C, I = pairwise_distances(X, metric="manhattan", backend=None, exclude_diag=excl, k=k, return_indices=True)
+        Cw, _ = pairwise_distances(X, metric="manhattan", backend=None, exclude_diag=excl, k=k + 8, return_indices=True)
+        out.update({f"c{i}_n": n, f"c{i}_d": d, f"c{i}_s": s, f"c{i}_k": k, f"c{i}_excl": excl, f"c{i}_C": C, f"c{i}_I": I,
+                    f"c{i}_Cw": Cw})
+    out["n_cases"] = len(cases)
+    Xt = torch.randint(0, 3, (400, 16), generator=torch.Generator().manual_seed(35)).float()   # ties everywhere
+    Ct, It = pairwise_distances(Xt, metric="manhattan", backend=None, exclude_diag=True, k=6, return_indices=True)
+    Ctw, _ = pairwise_distances(Xt, metric="manhattan", backend=None, exclude_diag=True, k=14, return_indices=True)
+    out.update(ties_X=Xt, ties_C=Ct, ties_I=It, ties_Cw=Ctw)
+    X = gmm(300, 40, 2.0, seed=12)
+    Y = gmm(200, 40, 2.0, seed=13)
+    out["cross_C"], out["cross_I"] = pairwise_distances(X, Y, metric="manhattan", backend=None, k=10, return_indices=True)
+    out["cross_dense"] = pairwise_distances(X, Y, metric="manhattan", backend=None)
+    out["dense_excl"] = pairwise_distances(X, metric="manhattan", backend=None, exclude_diag=True)
+    g = torch.Generator().manual_seed(5)
+    keys = torch.randint(0, 300, (40, 7), generator=g)
+    keys[3, 2] = -1
+    q = torch.arange(100, 140)
+    out["keys"], out["q"] = keys, q
+    out["indexed_l1"] = pairwise_distances_indexed(X, query_indices=q, key_indices=keys, metric="manhattan")
+    out["indexed_ang"] = pairwise_distances_indexed(X, query_indices=q, key_indices=keys, metric="angular")
+    out["block_l1"] = pairwise_distances_indexed(X, query_indices=q, key_indices=torch.arange(5, 90), metric="manhattan")
+    Xa = gmm(500, 37, 2.0, seed=32)
+    aff = UMAPAffinity(n_neighbors=10, metric="manhattan", symmetrize=False, backend=None, max_iter=100)
+    P, I = aff(Xa)
+    out["umap_P"], out["umap_I"], out["umap_rho"], out["umap_eps"] = P, I, aff.rho_, aff.eps_
+    save("manhattan", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ALL = dict(knn=knn_fixtures, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
                umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne2_step=ne2_step_fixture,
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
-               eval=eval_fixture, pacmap=pacmap_fixture)
+               eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

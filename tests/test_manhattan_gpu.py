@@ -1,0 +1,138 @@
+"""metric='manhattan' on the HIP path (reference distance/torch.py:96-98, distance/base.py:368, 388) against the
+fixture generated from the real reference and against the CPU oracle.  kNN values and indices are bit-identical (the
+candidates are re-evaluated in the reference's own summation order); the dense / gathered forms are fp32 sums in
+another order and agree to 1e-5 relative."""
+
+import pytest
+import torch
+
+from tests.conftest import gmm
+from tests.test_oracle_golden import boundary_safe_rows, load
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def _knn(X, k, excl=True, Y=None):
+    from torchdr_amd.distance import pairwise_distances
+
+    C, I = pairwise_distances(X.cuda(), None if Y is None else Y.cuda(), metric="manhattan", k=k, exclude_diag=excl,
+                              return_indices=True)
+    return C.cpu(), I.cpu()
+
+
+def test_exact_order_kernel_is_the_reference_float():
+    """tdr_l1_exact_f32 (dense-column form) == the oracle's full matrix, bit for bit, across the branches of the
+    summation (scalar path, leftover items, tails, cascade)."""
+    import oracle
+    from torchdr_amd.distance.base import _l1_exact
+
+    for d in (1, 3, 4, 7, 8, 9, 31, 32, 33, 63, 100, 128, 257, 511, 512, 600, 1000, 2500):
+        X = torch.randn(70, d, generator=torch.Generator().manual_seed(d))
+        Y = torch.randn(90, d, generator=torch.Generator().manual_seed(d + 1))
+        _, _, full = oracle.knn(X, 0, "manhattan", False, Y=Y, want_full=True)
+        E = _l1_exact(X.cuda(), None, 70, 0, Y.cuda(), None, 90, 0, False)
+        assert torch.equal(E.cpu(), full), f"d={d}"
+    # unaligned rows (stride not a multiple of 4) take the scalar-load path
+    Xs = torch.randn(70, 131, generator=torch.Generator().manual_seed(0))[:, :129].cuda()
+    _, _, full = oracle.knn(Xs.cpu().contiguous(), 0, "manhattan", False, want_full=True)
+    E = _l1_exact(Xs, None, 70, 0, Xs, None, 70, 0, False)
+    assert torch.equal(E.cpu(), full)
+
+
+def test_knn_matches_the_reference_fixture_bit_for_bit():
+    from oracle import ref_torch as R
+    from torchdr_amd.distance import base as dbase
+
+    g = load("manhattan")
+    for i in range(int(g["n_cases"])):
+        n, d, k = int(g[f"c{i}_n"]), int(g[f"c{i}_d"]), int(g[f"c{i}_k"])
+        X = gmm(n, d, float(g[f"c{i}_s"]), seed=31 + i)
+        C, I = _knn(X, k, bool(g[f"c{i}_excl"]))
+        Cr, Ir = R.canonical_rows(g[f"c{i}_C"], g[f"c{i}_I"])
+        safe = boundary_safe_rows(g[f"c{i}_Cw"], k)
+        assert torch.equal(C, Cr), f"case {i}"
+        assert torch.equal(I[safe].long(), Ir[safe].long()), f"case {i}"
+        assert "manhattan" in dbase.LAST_KNN["path"]
+    # integer-valued data: exact ties everywhere -> the certificate fails and rows are re-searched in full
+    C, I = _knn(g["ties_X"], 6)
+    assert torch.equal(C, g["ties_C"]) and dbase.LAST_KNN["flagged"] > 0
+    safe = boundary_safe_rows(g["ties_Cw"], 6)
+    assert torch.equal(I[safe].long().sort(1).values, g["ties_I"][safe].long().sort(1).values)
+    # cross search
+    X, Y = gmm(300, 40, 2.0, seed=12), gmm(200, 40, 2.0, seed=13)
+    Cx, Ix = _knn(X, 10, False, Y=Y)
+    assert torch.equal(Cx, g["cross_C"]) and torch.equal(Ix.long(), g["cross_I"].long())
+
+
+@pytest.mark.parametrize("n,d,k", [(3000, 128, 30), (2000, 7, 5), (1500, 2, 12), (1200, 300, 20), (900, 50, 250)])
+def test_knn_matches_the_oracle(n, d, k):
+    import oracle
+
+    X = gmm(n, d, 2.0, seed=n + d)
+    C, I = _knn(X, k)
+    Co, Io = oracle.knn(X, k, "manhattan", True)
+    assert torch.equal(C, Co) and torch.equal(I, Io)
+
+
+def test_dense_and_gathered_forms():
+    from torchdr_amd.distance import pairwise_distances, pairwise_distances_indexed
+
+    g = load("manhattan")
+    X, Y = gmm(300, 40, 2.0, seed=12).cuda(), gmm(200, 40, 2.0, seed=13).cuda()
+    D = pairwise_distances(X, Y, metric="manhattan")
+    assert torch.allclose(D.cpu(), g["cross_dense"], rtol=RTOL, atol=0)
+    De = pairwise_distances(X, metric="manhattan", exclude_diag=True)
+    assert torch.allclose(De.cpu(), g["dense_excl"], rtol=RTOL, atol=1e-5)      # diagonal: 0 + 1e12
+    Dk, none = pairwise_distances(X, metric="manhattan", k=300, return_indices=True)  # k >= n -> dense, no indices
+    assert none is None and Dk.shape == (300, 300)
+    q, keys = g["q"].cuda(), g["keys"].cuda()
+    G1 = pairwise_distances_indexed(X, query_indices=q, key_indices=keys, metric="manhattan")
+    assert torch.allclose(G1.cpu(), g["indexed_l1"], rtol=RTOL, atol=1e-6)
+    Ga = pairwise_distances_indexed(X, query_indices=q, key_indices=keys, metric="angular")
+    assert torch.allclose(Ga.cpu(), g["indexed_ang"], rtol=1e-4, atol=1e-4)
+    B = pairwise_distances_indexed(X, query_indices=q, key_indices=torch.arange(5, 90).cuda(), metric="manhattan")
+    assert torch.allclose(B.cpu(), g["block_l1"], rtol=RTOL, atol=1e-6)
+
+
+def test_ragged_tiles_and_strided_input():
+    """Tile edges (n, m not multiples of 128, d not a multiple of 16 / 4) and a non-contiguous view."""
+    import oracle
+    from torchdr_amd.distance import pairwise_distances
+
+    for n, m, d in [(1, 1, 1), (129, 257, 17), (130, 5, 3), (300, 1000, 130)]:
+        X = torch.randn(n, d, generator=torch.Generator().manual_seed(n))
+        Y = torch.randn(m, d, generator=torch.Generator().manual_seed(m))
+        _, _, full = oracle.knn(X, 0, "manhattan", False, Y=Y, want_full=True)
+        D = pairwise_distances(X.cuda(), Y.cuda(), metric="manhattan")
+        assert D.shape == (n, m) and torch.allclose(D.cpu(), full, rtol=RTOL, atol=1e-6)
+    base = torch.randn(400, 60, generator=torch.Generator().manual_seed(0))
+    Xs = base[:, ::2]
+    C, I = pairwise_distances(Xs.cuda(), metric="manhattan", k=9, exclude_diag=True, return_indices=True)
+    Co, Io = oracle.knn(Xs.contiguous(), 9, "manhattan", True)
+    assert torch.equal(C.cpu(), Co) and torch.equal(I.cpu(), Io)
+
+
+def test_umap_affinity_and_estimators_with_manhattan_inputs():
+    import torchdr_amd
+    from torchdr_amd.affinity import UMAPAffinity
+
+    g = load("manhattan")
+    Xa = gmm(500, 37, 2.0, seed=32).cuda()
+    aff = UMAPAffinity(n_neighbors=10, metric="manhattan", symmetrize=False, max_iter=100)
+    P, I = aff(Xa)
+    assert torch.equal(I.cpu().long(), g["umap_I"].long())
+    assert torch.equal(aff.rho_.cpu(), g["umap_rho"])
+    assert torch.allclose(aff.eps_.cpu(), g["umap_eps"], rtol=RTOL, atol=0)
+    # P = exp(-(C - rho) / eps): a relative error of eps is amplified by |log P| (up to ~8 here, measured 2e-5)
+    assert torch.allclose(P.cpu(), g["umap_P"], rtol=5e-5, atol=1e-8)
+    assert torch.allclose(P.log().cpu(), g["umap_P"].log(), rtol=RTOL, atol=RTOL)
+    Z = torchdr_amd.UMAP(n_neighbors=10, metric="manhattan", max_iter=30, random_state=0).fit_transform(Xa)
+    assert Z.shape == (500, 2) and bool(torch.isfinite(Z).all())
+    Zt = torchdr_amd.TSNE(perplexity=10, metric="manhattan", max_iter=30, random_state=0).fit_transform(Xa)
+    assert Zt.shape == (500, 2) and bool(torch.isfinite(Zt).all())
+    from torchdr_amd.eval import neighborhood_preservation
+
+    s = neighborhood_preservation(Xa, Z, K=10, metric="manhattan")
+    assert 0.0 <= float(s) <= 1.0

@@ -163,6 +163,25 @@ def test_ne2_step_oracle(name):
         assert torch.allclose(Znew, g[f"{name}_Zafter_{t}"], rtol=1e-5, atol=1e-7)
 
 
+def test_manhattan_oracle_is_bit_identical_to_the_reference():
+    """metric='manhattan': the C oracle restates ATen's summation order, so values AND indices are the reference's."""
+    g = load("manhattan")
+    for i in range(int(g["n_cases"])):
+        n, d, k = int(g[f"c{i}_n"]), int(g[f"c{i}_d"]), int(g[f"c{i}_k"])
+        X = gmm(n, d, float(g[f"c{i}_s"]), seed=31 + i)
+        C, I = oracle.knn(X, k, "manhattan", bool(g[f"c{i}_excl"]))
+        Cr, Ir = R.canonical_rows(g[f"c{i}_C"], g[f"c{i}_I"])
+        safe = boundary_safe_rows(g[f"c{i}_Cw"], k)
+        assert torch.equal(C, Cr) and torch.equal(I[safe].long(), Ir[safe].long()) and safe.float().mean() > 0.95
+    Ct, It = oracle.knn(g["ties_X"], 6, "manhattan", True)       # integer data: exact ties, values still identical
+    assert torch.equal(Ct, g["ties_C"])
+    X, Y = gmm(300, 40, 2.0, seed=12), gmm(200, 40, 2.0, seed=13)
+    Cx, Ix, full = oracle.knn(X, 10, "manhattan", False, Y=Y, want_full=True)
+    assert torch.equal(full, g["cross_dense"]) and torch.equal(Cx, g["cross_C"]) and torch.equal(Ix.long(), g["cross_I"].long())
+    Ck, Ik = R.knn_chunked(X, 10, "manhattan", False, Y=Y, chunk=64)
+    assert torch.equal(Ck, g["cross_C"]) and torch.equal(Ik.long(), g["cross_I"].long())
+
+
 def test_pacmap_affinity_oracle():
     g = load("pacmap")
     idx, rho = R.pacmap_affinity(g["X"], 10)

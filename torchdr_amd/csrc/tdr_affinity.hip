@@ -325,6 +325,16 @@ __global__ __launch_bounds__(256) void indexed_sqdist_kernel(const float* __rest
     const float* x = X + (size_t)qi * d;
     const float* y = Y + (size_t)kj * d;
     float acc = 0.f;
+    if (take_sqrt == 2) {  // manhattan (distance/base.py:388)
+        for (int t = 0; t < d; ++t) acc = __fadd_rn(acc, fabsf(x[t] - y[t]));
+        out[idx] = acc;
+        return;
+    }
+    if (take_sqrt == 3) {  // angular: -<x, y> (distance/base.py:390-391)
+        for (int t = 0; t < d; ++t) acc = __fadd_rn(acc, __fmul_rn(x[t], y[t]));
+        out[idx] = -acc;
+        return;
+    }
     for (int t = 0; t < d; ++t) {
         const float df = x[t] - y[t];
         acc = __fadd_rn(acc, __fmul_rn(df, df));
@@ -397,7 +407,8 @@ int tdr_entropic_search_f32(const float* C, int64_t n, int k, float target, floa
     return launch_rows(entropic_search_kernel<64, 4>, 64, n, st, C, n, k, S, max_iter, tol, eps, log_norm, log_P);
 }
 
-/* Gathered squared (or Euclidean) distances: out (nq, nk). q/keys are int64; negative keys wrap. */
+/* Gathered distances: out (nq, nk); take_sqrt 0 = squared Euclidean, 1 = Euclidean, 2 = manhattan, 3 = angular. q/keys are int64;
+ * negative keys wrap. */
 int tdr_indexed_sqdist_f32(const float* X, int64_t nx, int d, const float* Y, int64_t ny, const int64_t* q,
                            int64_t nq, int nk, int take_sqrt, const int64_t* keys, float* out, void* stream) {
     if (!X || !Y || !q || !keys || !out || nq < 0 || nk < 0 || d <= 0) return TDR_ERR_BAD_ARG;

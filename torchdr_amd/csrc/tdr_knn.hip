@@ -672,6 +672,7 @@ struct TopkMergeParams {
     int64_t d_global0;     // global index of database row 0 of this chunk
     int k, metric, exclude_self;
     uint64_t* run_keys;    // (nq, k) ascending, KEY_SENTINEL padded
+    const int32_t* cand;   // optional (nq, nd) database index of every column (row stride ldg); entries < 0 are skipped
 };
 
 template <int ITEMS>
@@ -684,23 +685,31 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const TopkMergeParams P
     for (int p = lane; p < P.k; p += 64) Lst[p] = P.run_keys[(size_t)qi * P.k + p];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float tau = u2f((uint32_t)(Lst[P.k - 1] >> 32));  // k-th best so far (+inf while the list is not full)
-    const float xq = (P.metric == 2) ? 0.f : P.xn[qi];
+    const float xq = (P.metric >= 2) ? 0.f : P.xn[qi];
     const float* g = P.G + (size_t)qi * P.ldg;
     const int64_t self_j = P.exclude_self ? (P.q_global0 + qi - P.d_global0) : -1;
     for (int64_t j0 = 0; j0 < P.nd; j0 += 64) {
         const int64_t j = j0 + lane;
         float c = __builtin_inff();
-        if (j < P.nd && j != self_j) {
+        uint32_t id = (uint32_t)(P.d_global0 + j);
+        bool live = j < P.nd && j != self_j;
+        if (live && P.cand) {
+            const int32_t ci = P.cand[(size_t)qi * P.ldg + j];
+            live = ci >= 0;
+            id = (uint32_t)ci;
+        }
+        if (live) {
             const float gv = g[j];
-            c = (P.metric == 2) ? -gv : __builtin_fmaf(-2.0f, gv, __fadd_rn(xq, P.yn[j]));
+            c = (P.metric == 3) ? gv : (P.metric == 2) ? -gv : __builtin_fmaf(-2.0f, gv, __fadd_rn(xq, P.yn[j]));
         }
         unsigned long long m = __ballot(c <= tau);
         while (m) {
             const int src = __builtin_ctzll(m);
             m &= m - 1;
             const float cv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, c), src));
+            const uint32_t iv = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
             uint64_t new_tail;
-            if (coop_insert<ITEMS>(Lst, P.k, mkkey(cv, (uint32_t)(P.d_global0 + j0 + src)), lane, new_tail))
+            if (coop_insert<ITEMS>(Lst, P.k, mkkey(cv, iv), lane, new_tail))
                 tau = u2f((uint32_t)(new_tail >> 32));
         }
     }
@@ -777,6 +786,19 @@ static int launch_scan(const KnnParams& P, int n_wgs, size_t lds, int qb, hipStr
     if (P.k <= 64) return launch_scan_i<KQ, 1>(P, n_wgs, lds, qb, st);
     return launch_scan_i<KQ, 2>(P, n_wgs, lds, qb, st);
 }
+
+static int launch_topk_merge(const TopkMergeParams& P, void* stream) {
+    const int k = P.k;
+    const int64_t nq = P.nq;
+    const size_t lds = (size_t)4 * k * sizeof(uint64_t);
+    const dim3 grid((unsigned)((nq + 3) / 4));
+    if (k <= 64) hipLaunchKernelGGL(topk_merge_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, P);
+    else if (k <= 128) hipLaunchKernelGGL(topk_merge_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(topk_merge_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, P);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
 
 extern "C" {
 
@@ -977,24 +999,30 @@ int tdr_topk_init(uint64_t* run_keys, int64_t nq, int k, void* stream) {
     return TDR_OK;
 }
 
-/* Step 2 (per database chunk): fold G = Xq Yc^T (nq x nd, row stride ldg) into the running lists.  xn / yn: squared
- * norms of the queries / of this chunk; q_global0 / d_global0: global indices of query 0 and of chunk row 0. */
+/* Step 2 (per database chunk): fold G = Xq Yc^T (nq x nd, row stride ldg) into the running lists (metric 3, manhattan:
+ * G already holds the distances, tdr_l1_block_f32).  xn / yn: squared norms of the queries / of this chunk; q_global0 / d_global0: global indices of query 0 and of chunk row 0. */
 int tdr_topk_merge_f32(const float* G, int64_t ldg, int64_t nq, int64_t nd, const float* xn, const float* yn,
                        int64_t q_global0, int64_t d_global0, int k, int metric, int exclude_self, uint64_t* run_keys,
                        void* stream) {
     if (!G || !run_keys || nq <= 0 || nd <= 0 || ldg < nd || k <= 0) return TDR_ERR_BAD_ARG;
-    if (metric < 0 || metric > 2 || (metric != 2 && (!xn || !yn))) return TDR_ERR_BAD_ARG;
+    if (metric < 0 || metric > 3 || (metric < 2 && (!xn || !yn))) return TDR_ERR_BAD_ARG;
     if (k > 256) return TDR_ERR_UNSUPPORTED;
     TopkMergeParams P;
     P.G = G; P.ldg = ldg; P.nq = nq; P.nd = nd; P.xn = xn; P.yn = yn; P.q_global0 = q_global0; P.d_global0 = d_global0;
-    P.k = k; P.metric = metric; P.exclude_self = exclude_self; P.run_keys = run_keys;
-    const size_t lds = (size_t)4 * k * sizeof(uint64_t);
-    const dim3 grid((unsigned)((nq + 3) / 4));
-    if (k <= 64) hipLaunchKernelGGL(topk_merge_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, P);
-    else if (k <= 128) hipLaunchKernelGGL(topk_merge_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(topk_merge_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, P);
-    TDR_CHECK_LAUNCH();
-    return TDR_OK;
+    P.k = k; P.metric = metric; P.exclude_self = exclude_self; P.run_keys = run_keys; P.cand = nullptr;
+    return launch_topk_merge(P, stream);
+}
+
+/* Same fold for per-query candidate lists: E (nq, nc) distances and cand (nq, nc) database indices (both row stride
+ * ld; negative indices are skipped).  Used to rank exactly re-evaluated candidates by (distance, index). */
+int tdr_topk_merge_cand_f32(const float* E, const int32_t* cand, int64_t ld, int64_t nq, int64_t nc, int k,
+                            uint64_t* run_keys, void* stream) {
+    if (!E || !cand || !run_keys || nq <= 0 || nc <= 0 || ld < nc || k <= 0) return TDR_ERR_BAD_ARG;
+    if (k > 256) return TDR_ERR_UNSUPPORTED;
+    TopkMergeParams P;
+    P.G = E; P.ldg = ld; P.nq = nq; P.nd = nc; P.xn = nullptr; P.yn = nullptr; P.q_global0 = 0; P.d_global0 = 0;
+    P.k = k; P.metric = 3; P.exclude_self = 0; P.run_keys = run_keys; P.cand = cand;
+    return launch_topk_merge(P, stream);
 }
 
 /* Step 3: lists -> out_d (nq, k) fp32 ascending, out_i (nq, k) int32. */

@@ -16,8 +16,8 @@ from torchdr_amd import _lib
 from torchdr_amd.distributed import DistributedContext
 from torchdr_amd.utils.misc import as_float32
 
-LIST_METRICS = ["euclidean", "sqeuclidean", "angular"]
-_METRIC_ID = {"sqeuclidean": 0, "euclidean": 1, "angular": 2}
+LIST_METRICS = ["euclidean", "sqeuclidean", "manhattan", "angular"]
+_METRIC_ID = {"sqeuclidean": 0, "euclidean": 1, "angular": 2, "manhattan": 3}
 
 # Value the reference adds to the diagonal when exclude_diag=True (distance/torch.py:115).
 _DIAG_ADD = 1e12
@@ -514,8 +514,11 @@ def _knn_general(Xq, Y, k, metric, exclude_self, q_global0=0):
     if k > 256:
         raise NotImplementedError(f"[torchdr_amd] k={k} > 256 is not supported by the running top-k kernel.")
     dev = Y.device
-    xn = (Xq * Xq).sum(1).contiguous()
-    yn = xn if Y is Xq else (Y * Y).sum(1).contiguous()
+    l1 = metric == "manhattan"
+    xn = yn = None
+    if not l1:
+        xn = (Xq * Xq).sum(1).contiguous()
+        yn = xn if Y is Xq else (Y * Y).sum(1).contiguous()
     keys = torch.empty((nq, k), dtype=torch.int64, device=dev)
     st = _lib.stream_ptr()
     _lib.check(L.tdr_topk_init(_lib.ptr(keys), nq, k, st), "tdr_topk_init")
@@ -525,21 +528,116 @@ def _knn_general(Xq, Y, k, metric, exclude_self, q_global0=0):
         Xc = Xq[q0:q1]
         for d0 in range(0, nd, _GENERAL_BD):
             d1 = min(d0 + _GENERAL_BD, nd)
-            G = torch.mm(Xc, Y[d0:d1].t())
+            G = _l1_block(Xc, Y[d0:d1]) if l1 else torch.mm(Xc, Y[d0:d1].t())
             _lib.check(
-                L.tdr_topk_merge_f32(_lib.ptr(G), G.stride(0), q1 - q0, d1 - d0, _lib.ptr(xn[q0:q1]), _lib.ptr(yn[d0:d1]),
+                L.tdr_topk_merge_f32(_lib.ptr(G), G.stride(0), q1 - q0, d1 - d0, _lib.ptr(None if l1 else xn[q0:q1]),
+                                     _lib.ptr(None if l1 else yn[d0:d1]),
                                      q_global0 + q0, d0, k, mid, 1 if exclude_self else 0, _lib.ptr(keys[q0:q1]), st),
                 "tdr_topk_merge_f32",
             )
     out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
     _lib.check(L.tdr_topk_emit_f32(_lib.ptr(keys), nq, k, mid, _lib.ptr(out_d), _lib.ptr(out_i), st), "tdr_topk_emit_f32")
-    LAST_KNN["path"], LAST_KNN["flagged"] = "general-D (library GEMM + top-k merge)", 0
+    LAST_KNN["path"] = "manhattan (L1 tile kernel + top-k merge)" if l1 else "general-D (library GEMM + top-k merge)"
+    LAST_KNN["flagged"] = 0
     return out_d, out_i
 
 
+_L1_MARGIN = 8            # extra candidates kept by the tile pass for the exact re-evaluation
+_L1_EXACT_MAX_D = 8192    # tdr_l1_exact_f32 restates two cascade levels of the reference's summation
+
+
+def _l1_exact(X, q_rows, nq, q_global0, Y, cand, nc, j0, exclude_self):
+    """(nq, nc) manhattan distances in the reference's summation order (``tdr_l1_exact_f32``)."""
+    out = torch.empty((nq, nc), dtype=torch.float32, device=Y.device)
+    _lib.check(
+        _lib.lib().tdr_l1_exact_f32(_lib.ptr(X), X.stride(0), _lib.ptr(q_rows), nq, q_global0, _lib.ptr(Y), Y.stride(0),
+                                    _lib.ptr(cand), 0 if cand is None else cand.stride(0), nc, j0, X.shape[1],
+                                    1 if exclude_self else 0, _lib.ptr(out), out.stride(0), _lib.stream_ptr()),
+        "tdr_l1_exact_f32",
+    )
+    return out
+
+
+def _rank_candidates(E, cand, k):
+    """Rows of (distance, index) candidates -> the k smallest by (distance, index)."""
+    L = _lib.lib()
+    nq = E.shape[0]
+    st = _lib.stream_ptr()
+    keys = torch.empty((nq, k), dtype=torch.int64, device=E.device)
+    _lib.check(L.tdr_topk_init(_lib.ptr(keys), nq, k, st), "tdr_topk_init")
+    _lib.check(L.tdr_topk_merge_cand_f32(_lib.ptr(E), _lib.ptr(cand), E.stride(0), nq, E.shape[1], k, _lib.ptr(keys), st),
+               "tdr_topk_merge_cand_f32")
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=E.device)
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=E.device)
+    _lib.check(L.tdr_topk_emit_f32(_lib.ptr(keys), nq, k, 3, _lib.ptr(out_d), _lib.ptr(out_i), st), "tdr_topk_emit_f32")
+    return out_d, out_i
+
+
+def _knn_manhattan(Xq, Y, k, exclude_self, q_global0=0):
+    """Exact manhattan kNN whose values and indices are the reference CPU backend's (distance/torch.py:96-98, 118-120).
+
+    Two passes, like the Euclidean search: (1) the VALU tile kernel (fast, its own summation order) keeps the k + 8 best
+    per query; (2) those candidates are re-evaluated in the reference's summation order and ranked by (distance,
+    index).  Both are fp32 sums of the SAME non-negative terms fl(x - y), so they differ by at most
+    ``delta = 2.5 d 2^-24`` relatively; a point outside the candidate list has tile distance >= a_L, hence reference
+    distance >= a_L (1 - delta), while the reference's k-th distance is <= a_k (1 + delta): when
+    a_L (1 - delta) > a_k (1 + delta) nothing outside the list can enter the top k.  Rows failing that certificate
+    (heavy ties / duplicates) are re-searched against the whole database in the reference's order."""
+    nq, nd, d = Xq.shape[0], Y.shape[0], Xq.shape[1]
+    n_valid = nd - (1 if exclude_self else 0)
+    if d >= _L1_EXACT_MAX_D:  # a third cascade level in the reference's sum: tile-order values (fp32 rounding apart)
+        return _knn_general(Xq, Y, k, "manhattan", exclude_self, q_global0)
+    L = min(k + _L1_MARGIN, n_valid, 256)
+    Ca, Ia = _knn_general(Xq, Y, L, "manhattan", exclude_self, q_global0)
+    E = _l1_exact(Xq, None, nq, q_global0, Y, Ia, L, 0, False)
+    C, I = _rank_candidates(E, Ia, k)
+    n_bad = 0
+    if L < n_valid:
+        delta = 2.5 * d * 2.0 ** -24
+        bad = torch.nonzero(Ca[:, L - 1] * (1.0 - delta) <= Ca[:, k - 1] * (1.0 + delta)).reshape(-1)
+        n_bad = int(bad.numel())
+        for b0 in range(0, n_bad, 2048):
+            rows = bad[b0:b0 + 2048].contiguous()
+            m = int(rows.numel())
+            keys = torch.empty((m, k), dtype=torch.int64, device=Y.device)
+            st = _lib.stream_ptr()
+            _lib.check(_lib.lib().tdr_topk_init(_lib.ptr(keys), m, k, st), "tdr_topk_init")
+            for d0 in range(0, nd, _GENERAL_BD):
+                d1 = min(d0 + _GENERAL_BD, nd)
+                Ef = _l1_exact(Xq, rows, m, q_global0, Y, None, d1 - d0, d0, exclude_self)  # own row -> +inf
+                _lib.check(
+                    _lib.lib().tdr_topk_merge_f32(_lib.ptr(Ef), Ef.stride(0), m, d1 - d0, _lib.ptr(None), _lib.ptr(None), 0,
+                                                  d0, k, 3, 0, _lib.ptr(keys), st),
+                    "tdr_topk_merge_f32",
+                )
+            od = torch.empty((m, k), dtype=torch.float32, device=Y.device)
+            oi = torch.empty((m, k), dtype=torch.int32, device=Y.device)
+            _lib.check(_lib.lib().tdr_topk_emit_f32(_lib.ptr(keys), m, k, 3, _lib.ptr(od), _lib.ptr(oi), st), "tdr_topk_emit_f32")
+            C[rows] = od
+            I[rows] = oi
+    LAST_KNN["path"], LAST_KNN["flagged"] = "manhattan (L1 tile kernel + exact-order re-evaluation)", n_bad
+    return C, I
+
+
+def _l1_block(X, Y):
+    """(nq, nd) block of manhattan distances (distance/torch.py:96-98) by the VALU tile kernel."""
+    out = torch.empty((X.shape[0], Y.shape[0]), dtype=torch.float32, device=X.device)
+    _lib.check(
+        _lib.lib().tdr_l1_block_f32(_lib.ptr(X), X.stride(0), X.shape[0], _lib.ptr(Y), Y.stride(0), Y.shape[0], X.shape[1],
+                                    _lib.ptr(out), out.stride(0), _lib.stream_ptr()),
+        "tdr_l1_block_f32",
+    )
+    return out
+
+
 def _dense_general(X, Y, metric, exclude_self):
-    """Dense distance matrix for D > 256 (distance/torch.py:82-116) with a library GEMM."""
+    """Dense distance matrix for D > 256 (distance/torch.py:82-116) with a library GEMM; manhattan: the L1 kernel."""
+    if metric == "manhattan":
+        C = _l1_block(X, Y)
+        if exclude_self:
+            C.diagonal().add_(_DIAG_ADD)
+        return C
     G = torch.mm(X, Y.t())
     if metric == "angular":
         C = -G
@@ -611,9 +709,14 @@ def pairwise_distances(
             )
         n = X.shape[0]
         c0, c1 = distributed_ctx.compute_chunk_bounds(n)
-        if X.shape[1] > 256:
+        if X.shape[1] > 256 or metric == "manhattan":
+            if X.dtype != torch.float32:
+                raise NotImplementedError(f"[torchdr_amd] only float32 inputs are supported by the HIP distance kernels (got {X.dtype}).")
             Xc = X if X.stride(1) == 1 else X.contiguous()
-            C, I = _knn_general(Xc[c0:c1], Xc, int(k), metric, bool(exclude_diag), q_global0=c0)
+            if metric == "manhattan":
+                C, I = _knn_manhattan(Xc[c0:c1], Xc, int(k), bool(exclude_diag), q_global0=c0)
+            else:
+                C, I = _knn_general(Xc[c0:c1], Xc, int(k), metric, bool(exclude_diag), q_global0=c0)
             return (C, I) if return_indices else C
         Yp = PackedPoints(X)
         if (distributed_ctx.world_size > 1 and _want_prune(Yp, n) and _use_screen(Yp, Yp, c1 - c0, int(k), metric)
@@ -632,7 +735,7 @@ def pairwise_distances(
         return (C, I) if return_indices else C
 
     do_exclude = bool(exclude_diag) and self_search
-    if X.shape[1] > 256:  # beyond the register-resident MFMA kernels: library GEMM + HIP top-k merge
+    if X.shape[1] > 256 or metric == "manhattan":  # not on the MFMA scan kernels: (library GEMM | L1 tiles) + HIP top-k merge
         if X.dtype != torch.float32:
             raise NotImplementedError(f"[torchdr_amd] only float32 inputs are supported by the HIP distance kernels (got {X.dtype}).")
         Xc = X if X.stride(1) == 1 else X.contiguous()
@@ -642,7 +745,10 @@ def pairwise_distances(
         if k is not None and k < Yc.shape[0]:
             if do_exclude and k > Yc.shape[0] - 1:
                 raise ValueError("[TorchDR] ERROR : k must be smaller than the number of samples.")
-            C, I = _knn_general(Xc, Yc, int(k), metric, do_exclude)
+            if metric == "manhattan":
+                C, I = _knn_manhattan(Xc, Yc, int(k), do_exclude)
+            else:
+                C, I = _knn_general(Xc, Yc, int(k), metric, do_exclude)
             return (C, I) if return_indices else C
         C = _dense_general(Xc, Yc, metric, do_exclude)
         return (C, None) if return_indices else C
@@ -675,7 +781,7 @@ def pairwise_distances_indexed(
 
     The per-query-keys form (``key_indices`` 2-D, the one the embedding loop uses) runs the
     gather kernel ``tdr_indexed_sqdist_f32``: ``sum_c (x_ic - y_jc)^2`` by direct difference
-    (``base.py:384-385``).  A key index of -1 wraps to the last row, as PyTorch indexing does
+    (``base.py:384-385``; ``sum |.|`` for manhattan, ``-sum x y`` for angular, ``:388-391``).  A key index of -1 wraps to the last row, as PyTorch indexing does
     in the reference.
     """
     if Y is None:
@@ -683,7 +789,7 @@ def pairwise_distances_indexed(
     X = _to_device(X, device)
     Y = _to_device(Y, device)
     _lib.require_gpu(X, "X")
-    if metric not in ("sqeuclidean", "euclidean"):
+    if metric not in LIST_METRICS:
         raise NotImplementedError(f"Metric '{metric}' not implemented for indexed distances")
     if query_indices is not None and query_indices.dim() != 1:
         raise NotImplementedError("2D query indices not yet supported")
@@ -693,7 +799,10 @@ def pairwise_distances_indexed(
         # queries x keys block (reference base.py:357-376, torch.cdist): gather the rows, dense MFMA kernel
         Xq = X if query_indices is None else X[query_indices.to(X.device).long()]
         Yk = Y if key_indices is None else Y[key_indices.to(Y.device).long()]
-        return dense_packed(PackedPoints(Xq.float().contiguous()), PackedPoints(Yk.float().contiguous()), metric, False)
+        Xq, Yk = Xq.float().contiguous(), Yk.float().contiguous()
+        if metric == "manhattan" or Xq.shape[1] > 256:
+            return _dense_general(Xq, Yk, metric, False)
+        return dense_packed(PackedPoints(Xq), PackedPoints(Yk), metric, False)
     L = _lib.lib()
     Xc = X.contiguous().float()
     Yc = Y.contiguous().float()
@@ -710,7 +819,8 @@ def pairwise_distances_indexed(
     _lib.check(
         L.tdr_indexed_sqdist_f32(
             _lib.ptr(Xc), Xc.shape[0], Xc.shape[1], _lib.ptr(Yc), Yc.shape[0], _lib.ptr(q), nq,
-            keys.shape[1], 1 if metric == "euclidean" else 0, _lib.ptr(keys), _lib.ptr(out),
+            keys.shape[1], {"sqeuclidean": 0, "euclidean": 1, "manhattan": 2, "angular": 3}[metric], _lib.ptr(keys),
+            _lib.ptr(out),
             _lib.stream_ptr(),
         ),
         "tdr_indexed_sqdist_f32",
