@@ -4,8 +4,8 @@
 //   distance/torch.py:96-98     C = (X.unsqueeze(-2) - Y.unsqueeze(-3)).abs().sum(-1)   (an (n, m, d) intermediate there)
 //   distance/base.py:368, 388   torch.cdist(p=1) / the gathered form (the latter lives in tdr_affinity.hip)
 //
-// |x - y| does not factor into a contraction, so this is VALU work, not MFMA work: 2 instructions (v_sub, v_add |.|)
-// per (pair, feature).  A 256-thread workgroup owns a 128 x 128 tile of the output; each thread accumulates an 8 x 8
+// |x - y| does not factor into a contraction, so this is VALU work, not MFMA work: 1.5 instructions per (pair, feature)
+// (a packed subtract for two columns, then v_add with the |.| source modifier).  A 256-thread workgroup owns a 128 x 128 tile of the output; each thread accumulates an 8 x 8
 // sub-tile in registers (128 VALU instructions per 4 LDS reads of 16 B), the operands travel through LDS in
 // feature-chunks of 16, transposed so that a thread's 8 rows / 8 columns are two ds_read_b128 each.  The host feeds
 // the block to tdr_topk_merge_f32 (metric 3) for kNN, or keeps it as the dense matrix.
@@ -16,6 +16,7 @@ namespace tdr {
 constexpr int L1_T = 128;    // tile edge (queries and database rows)
 constexpr int L1_DC = 16;    // features per LDS stage
 constexpr int L1_LD = L1_T + 4;
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct L1Params {
     const float* X; int64_t ldx, nq;
@@ -79,11 +80,17 @@ __global__ __launch_bounds__(256) void l1_block_kernel(const L1Params P) {
             const float4 b0 = *reinterpret_cast<const float4*>(&Ys[dd][tx * 8]);
             const float4 b1 = *reinterpret_cast<const float4*>(&Ys[dd][tx * 8 + 4]);
             const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            const v2f b[4] = {{b0.x, b0.y}, {b0.z, b0.w}, {b1.x, b1.y}, {b1.z, b1.w}};
+            // 1.5 instructions per (pair, feature): one packed subtract per two columns, then v_add with the |.| source
+            // modifier (written as asm so that the accumulations are not re-packed behind a v_and)
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] = __fadd_rn(acc[i][j], fabsf(__fsub_rn(a[i], b[j])));
+                for (int j = 0; j < 4; ++j) {
+                    const v2f t = (v2f){a[i], a[i]} - b[j];
+                    asm("v_add_f32 %0, %0, |%1|" : "+v"(acc[i][2 * j]) : "v"(t.x));
+                    asm("v_add_f32 %0, %0, |%1|" : "+v"(acc[i][2 * j + 1]) : "v"(t.y));
+                }
         }
     }
 
