@@ -1,0 +1,58 @@
+"""DataLoader inputs on the HIP path -- mirrors the reference's tests/test_dataloader.py (same results as the tensor
+input for every batch size, the argument errors, estimators fed by a DataLoader)."""
+
+import pytest
+import torch
+from torch.utils.data import DataLoader, TensorDataset
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def sample_data():
+    return torch.randn(1000, 32, generator=torch.Generator().manual_seed(42))
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean", "angular", "manhattan"])
+@pytest.mark.parametrize("exclude_diag", [False, True])
+def test_dataloader_equals_tensor_input(sample_data, metric, exclude_diag):
+    from torchdr_amd.distance import pairwise_distances
+
+    k = 10
+    Ct, It = pairwise_distances(sample_data.cuda(), k=k, metric=metric, exclude_diag=exclude_diag, return_indices=True)
+    for bs in (50, 256, 1000):
+        dl = DataLoader(TensorDataset(sample_data), batch_size=bs, shuffle=False)
+        Cd, Id = pairwise_distances(dl, k=k, metric=metric, exclude_diag=exclude_diag, return_indices=True)
+        assert Cd.is_cuda and torch.equal(Cd, Ct) and torch.equal(Id, It)
+    assert isinstance(pairwise_distances(dl, k=k, metric=metric), torch.Tensor)       # return_indices=False
+
+
+def test_dataloader_argument_errors(sample_data):
+    from torchdr_amd.distance import pairwise_distances
+
+    dl = DataLoader(TensorDataset(sample_data), batch_size=100)
+    with pytest.raises(ValueError, match="k cannot be None"):
+        pairwise_distances(dl, k=None)
+    with pytest.raises(ValueError, match="Y must be None"):
+        pairwise_distances(dl, Y=torch.randn(100, 32), k=10)
+    with pytest.raises(ValueError, match="only supports FAISS backend"):
+        pairwise_distances(dl, k=10, backend="keops")
+    with pytest.raises(ValueError, match="DataLoader is empty"):
+        pairwise_distances(DataLoader(TensorDataset(sample_data[:0]), batch_size=10), k=3)
+
+
+def test_estimators_and_affinities_accept_a_dataloader(sample_data):
+    import torchdr_amd
+    from torchdr_amd.affinity import UMAPAffinity
+
+    # own generator: iterating a DataLoader otherwise draws its base seed from the global RNG, which the estimators
+    # seed in their constructor (reference base.py:75-79) -- the embedding would start from another state
+    dl = DataLoader(TensorDataset(sample_data), batch_size=128, shuffle=False, generator=torch.Generator().manual_seed(1))
+    P, I = UMAPAffinity(n_neighbors=10, symmetrize=False)(dl)
+    Pt, It = UMAPAffinity(n_neighbors=10, symmetrize=False)(sample_data.cuda())
+    assert torch.equal(I, It) and torch.equal(P, Pt)
+    Z = torchdr_amd.UMAP(n_neighbors=10, max_iter=40, random_state=0).fit_transform(dl)
+    Zt = torchdr_amd.UMAP(n_neighbors=10, max_iter=40, random_state=0).fit_transform(sample_data.cuda())
+    # outputs for DataLoader inputs are CPU tensors, as in the reference (utils/wrappers.py:50-54, 76-85)
+    assert isinstance(Z, torch.Tensor) and Z.device.type == "cpu" and Z.shape == (1000, 2)
+    assert torch.allclose(Z, Zt.cpu(), rtol=1e-4, atol=1e-4)

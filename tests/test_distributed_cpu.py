@@ -159,3 +159,32 @@ def test_eval_argument_errors_match_reference():
         knn_label_accuracy(X, np.zeros(10), k=0)
     with _pt.raises(ValueError, match="same number of samples"):
         knn_label_accuracy(X, np.zeros(9), k=2)
+
+
+def test_dataloader_streaming_host_logic():
+    """utils/dataloader.py without a GPU: metadata, order, tuple / numpy batches, drop_last, integer cast, errors."""
+    import numpy as np
+    import pytest
+    import torch
+    from torch.utils.data import DataLoader, TensorDataset
+
+    from torchdr_amd.distance import pairwise_distances
+    from torchdr_amd.utils import dataloader_metadata, materialize_dataloader, to_torch
+
+    X = torch.randn(1000, 32, generator=torch.Generator().manual_seed(0))
+    dl = DataLoader(TensorDataset(X, torch.arange(1000)), batch_size=256, shuffle=False)
+    assert dataloader_metadata(dl) == (1000, 32, torch.float32, torch.device("cpu"))
+    t, backend, device = to_torch(dl, return_backend_device=True)
+    assert backend == "dataloader" and device == "cpu" and torch.equal(t, X)
+    assert materialize_dataloader(DataLoader(TensorDataset(X), batch_size=300, drop_last=True)).shape == (900, 32)
+    assert torch.equal(materialize_dataloader(DataLoader(X.numpy(), batch_size=128)), X)
+    Xi = torch.arange(60).reshape(20, 3)
+    assert materialize_dataloader(DataLoader(TensorDataset(Xi), batch_size=7)).dtype == torch.float32
+    with pytest.raises(ValueError, match="DataLoader is empty"):
+        materialize_dataloader(DataLoader(TensorDataset(X[:0]), batch_size=4))
+    with pytest.raises(ValueError, match="2-D tensors"):
+        materialize_dataloader(DataLoader(TensorDataset(torch.zeros(8)), batch_size=4))
+    for kw, msg in [(dict(k=None), "k cannot be None"), (dict(k=5, Y=X), "Y must be None"),
+                    (dict(k=5, backend="keops"), "only supports FAISS backend")]:
+        with pytest.raises(ValueError, match=msg):
+            pairwise_distances(dl, **kw)

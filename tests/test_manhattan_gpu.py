@@ -136,3 +136,18 @@ def test_umap_affinity_and_estimators_with_manhattan_inputs():
 
     s = neighborhood_preservation(Xa, Z, K=10, metric="manhattan")
     assert 0.0 <= float(s) <= 1.0
+
+
+def test_row_chunk_search_as_in_the_distributed_path():
+    """Queries = a row chunk with global ids (what a rank of the sharded search runs), incl. the re-search of tied rows."""
+    from torchdr_amd.distance.base import LAST_KNN, _knn_manhattan
+
+    X = gmm(1500, 24, 2.0, seed=5).cuda()
+    Cf, If = _knn_manhattan(X, X, 12, True)
+    C, I = _knn_manhattan(X[700:1311], X, 12, True, q_global0=700)
+    assert torch.equal(C, Cf[700:1311]) and torch.equal(I, If[700:1311])
+    Xt = torch.randint(0, 3, (600, 12), generator=torch.Generator().manual_seed(1)).float().cuda()
+    Cf, If = _knn_manhattan(Xt, Xt, 5, True)
+    C, I = _knn_manhattan(Xt[200:450], Xt, 5, True, q_global0=200)
+    assert LAST_KNN["flagged"] > 0 and torch.equal(C, Cf[200:450]) and torch.equal(I, If[200:450])
+    assert bool((If != torch.arange(600, device="cuda")[:, None]).all())          # self never returned

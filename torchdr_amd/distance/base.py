@@ -14,6 +14,7 @@ import torch
 
 from torchdr_amd import _lib
 from torchdr_amd.distributed import DistributedContext
+from torchdr_amd.utils.dataloader import is_dataloader, materialize_dataloader
 from torchdr_amd.utils.misc import as_float32
 
 LIST_METRICS = ["euclidean", "sqeuclidean", "manhattan", "angular"]
@@ -678,8 +679,23 @@ def pairwise_distances(
     """
     if metric not in LIST_METRICS:
         raise ValueError(f"[TorchDR] ERROR : The '{metric}' distance is not supported.")
+    if is_dataloader(X):  # reference base.py:121-157 (batches -> one HBM-resident tensor, utils/dataloader.py)
+        if k is None:
+            raise ValueError(
+                "[TorchDR] DataLoader input requires k-NN computation. k cannot be None when X is a DataLoader."
+            )
+        if Y is not None:
+            raise ValueError(
+                "[TorchDR] DataLoader input does not support cross-distance. Y must be None when X is a DataLoader."
+            )
+        if not (backend is None or backend == "faiss" or type(backend).__name__ == "FaissConfig"):
+            raise ValueError(
+                f"[TorchDR] DataLoader input only supports FAISS backend, got backend='{backend}'. "
+                "Use backend='faiss' or backend=None."
+            )
+        X = materialize_dataloader(X, None if device == "auto" else device)
     if not isinstance(X, torch.Tensor):
-        raise NotImplementedError("[torchdr_amd] DataLoader input is out of scope (SURVEY.md section 8f).")
+        raise TypeError("[torchdr_amd] pairwise_distances expects a torch.Tensor or a DataLoader.")
 
     self_search = Y is None or Y is X
     if X.dtype == torch.float64:  # float64 in -> float32 kernels -> float64 out

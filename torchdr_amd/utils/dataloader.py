@@ -1,0 +1,64 @@
+"""DataLoader inputs (reference ``distance/base.py:121-157``, ``distance/faiss.py`` *_from_dataloader,
+``affinity_matcher.py:218-234``).
+
+The reference streams batches into a Faiss index because the point set may not fit next to its N x N intermediates.
+On an MI355X the points themselves fit (288 GB of HBM = 500 M points at D = 128) and nothing of size N^2 is ever
+formed, so the batches are streamed straight into ONE resident device tensor (the host never holds the full set)
+and the regular exact kernels run on it."""
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+
+def is_dataloader(x) -> bool:
+    return isinstance(x, DataLoader)
+
+
+def _first(batch):
+    if isinstance(batch, (list, tuple)):
+        batch = batch[0]
+    if isinstance(batch, np.ndarray):
+        batch = torch.from_numpy(batch)
+    if not isinstance(batch, torch.Tensor) or batch.dim() != 2:
+        raise ValueError("[TorchDR] DataLoader batches must be 2-D tensors (or tuples whose first item is one).")
+    return batch
+
+
+def dataloader_metadata(dl: DataLoader):
+    """(n_samples, n_features, dtype, device) from the dataset length and the first batch."""
+    try:
+        n = len(dl.dataset)
+    except TypeError:
+        n = None
+    for batch in dl:
+        b = _first(batch)
+        return n, b.shape[1], b.dtype, b.device
+    raise ValueError(
+        "[TorchDR] DataLoader is empty, cannot determine metadata. Ensure DataLoader yields at least one batch."
+    )
+
+
+def materialize_dataloader(dl: DataLoader, device=None) -> torch.Tensor:
+    """All batches, in iteration order, as one (n_samples, n_features) tensor on ``device`` (default: the current GPU
+    when there is one).  Integer batches are cast to float32 like tensor inputs."""
+    if device is None or device == "auto":
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    n, d, dtype, _ = dataloader_metadata(dl)
+    if not dtype.is_floating_point:
+        dtype = torch.float32
+    if n is None:  # iterable dataset: length unknown until exhausted
+        parts = [_first(b).to(device=device, dtype=dtype) for b in dl]
+        return torch.cat(parts)
+    out = torch.empty((n, d), dtype=dtype, device=device)
+    pos = 0
+    for batch in dl:
+        b = _first(batch)
+        if b.shape[1] != d:
+            raise ValueError(f"[TorchDR] DataLoader batches disagree on the number of features ({b.shape[1]} vs {d}).")
+        m = b.shape[0]
+        if pos + m > n:
+            raise ValueError(f"[TorchDR] DataLoader yielded more than len(dataset) = {n} samples.")
+        out[pos:pos + m].copy_(b, non_blocking=True)
+        pos += m
+    return out if pos == n else out[:pos]      # drop_last=True loaders yield fewer rows

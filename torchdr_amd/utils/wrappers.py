@@ -4,6 +4,7 @@ import functools
 
 import torch
 
+from .dataloader import is_dataloader, materialize_dataloader
 from .validation import validate_tensor
 
 try:
@@ -15,7 +16,11 @@ except ImportError:  # pragma: no cover
 def to_torch(x, return_backend_device=False):
     if pd is not None and isinstance(x, pd.DataFrame):
         x = x.values
-    if isinstance(x, torch.Tensor):
+    if is_dataloader(x):
+        # batches stream into one device-resident tensor (utils/dataloader.py); outputs come back as CPU tensors,
+        # as in the reference (wrappers.py:50-54)
+        backend, device, x_ = "dataloader", "cpu", materialize_dataloader(x)
+    elif isinstance(x, torch.Tensor):
         backend, device, x_ = "torch", x.device, x
     else:
         backend, device = "numpy", "cpu"
