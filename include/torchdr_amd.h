@@ -178,6 +178,25 @@ int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64
 int tdr_sne_rowsum_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* R, void* stream);
 int tdr_sne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const float* R,
                           float coef, float* grad, void* stream);
+/* COSNE (neighbor_embedding/cosne.py:162-193, float64 like the reference's ManifoldParameter): closed-form gradient of
+ *   -sum P log Q (kNN graph) + log sum_ij Q_ij (dense, never materialised) + lam * mean (||x||^2 - d_H(z,0)^2)^2,
+ *   Q = gamma / (d_H^2 + gamma^2), d_H^2 = arccosh(1 + 2|zi-zj|^2/((1-|zi|^2)(1-|zj|^2)) + 1e-8)^2
+ * (distance/torch.py:101-107, distance/base.py:392-398).  Pass 1 = all-pairs sums for the chunk rows (rowsum of Q +
+ * unscaled gradient sums kept in ws), pass 2 = attraction over both ends of every kNN edge + scaling by S = sum of all
+ * rowsums (device scalar, all-reduced by the caller) + norm term.  nc in 2..4. */
+int tdr_cosne_splits(int64_t n_total, int64_t n_rows);
+int64_t tdr_cosne_workspace_bytes(int64_t n_total, int64_t n_rows, int nc);
+int tdr_cosne_pairs_f64(const double* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, double gamma,
+                        double* rowsum, void* ws, int64_t ws_bytes, void* stream);
+int tdr_cosne_grad_f64(const double* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nn,
+                       const float* P_in, int k, const int64_t* t_rowptr, const int32_t* t_src, const float* t_val,
+                       const double* S, const float* x_norm, double gamma, double lam, double exag, double rep,
+                       const void* ws, int64_t ws_bytes, double* grad, void* stream);
+/* utils/radam.py:139-167 + utils/manifold.py:207-330 (PoincareBallManifold, c = 1): one RiemannianAdam step on n_rows
+ * rows, in place; step_size = lr * sqrt(1 - beta2^t) / (1 - beta1^t) from the caller; maxnorm = 1 - 1e-5 (float64). */
+int tdr_radam_poincare_f64(double* Z, const double* egrad, double* exp_avg, double* exp_avg_sq, double* rgrad,
+                           int64_t n_rows, int nc, double beta1, double beta2, double eps, double step_size,
+                           double maxnorm, int* nan_flag, int n_iter, void* stream);
 /* gradient of neighbor_embedding/pacmap.py:213-265 (near / mid-near / further pair losses) */
 int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_idx, int m_near, float w_nb,
                         const int64_t* mid_idx, int m_mid, float w_mn, const int64_t* far_idx, int m_far, float w_fp,

@@ -427,3 +427,115 @@ def tsnekhorn_grad(Z, log_P, dual, log_K):
     W = log_K.exp()  # 1/(1+d)
     M = (log_P.exp() - log_Q.exp()) * W
     return 4 * (M.sum(1, keepdim=True) * Z - M @ Z)
+
+
+# --------------------------------------------------------------------------------------------
+# COSNE -- neighbor_embedding/cosne.py:162-193 (loss), utils/manifold.py:207-330 (Poincare ball),
+# utils/radam.py:96-167 (Riemannian Adam), affinity_matcher.py:552-565 (hyperbolic init).  float64 throughout.
+# --------------------------------------------------------------------------------------------
+
+
+def cosne_loss(Z, P, NN, X_norm, gamma, lam, exag=1.0, rep=1.0, chunk_start=0):
+    """The reference's scalar loss (autograd-able): exag * CE(P, log Q on the kNN graph, gathered distances by direct
+    difference, distance/base.py:392-398) + rep * (log sum_ij Q_ij over the dense norm-expansion matrix,
+    distance/torch.py:82-107, + lam * mean_i (||x_i||^2 - d_H(z_i, 0)^2)^2)."""
+    n_rows = P.shape[0]
+    zn = (Z**2).sum(-1)
+    Zq = Z[chunk_start:chunk_start + n_rows]
+    Yk = Z[NN.long()]
+    d = torch.relu(((Zq[:, None, :] - Yk) ** 2).sum(-1))
+    den = (1 - zn[chunk_start:chunk_start + n_rows, None]) * (1 - (Yk**2).sum(-1))
+    d = torch.arccosh(1 + 2 * (d / den) + 1e-8) ** 2
+    attr = -(P * (gamma / (d + gamma**2)).log()).sum()
+    C = torch.relu(zn[:, None] + zn[None, :] - 2 * Z @ Z.T)
+    D = torch.arccosh(1 + 2 * (C / ((1 - zn)[:, None] * (1 - zn)[None, :])) + 1e-8) ** 2
+    rep_loss = (gamma / (D + gamma**2)).log().logsumexp((0, 1))
+    h = torch.arccosh(1 + 2 * (zn / (1 - zn)) + 1e-8) ** 2
+    return exag * attr + rep * (rep_loss + lam * ((X_norm - h) ** 2).mean())
+
+
+def _dd2_dzi(zi, zo):
+    """d/dz_i of d_H(z_i, z_o)^2 = arccosh(1 + 2 s / (a_i a_o) + 1e-8)^2; returns (d2, grad) for broadcastable inputs."""
+    s = ((zi - zo) ** 2).sum(-1)
+    ai, ao = 1 - (zi**2).sum(-1), 1 - (zo**2).sum(-1)
+    w = 1 + 2 * s / (ai * ao) + 1e-8
+    u = torch.arccosh(w)
+    du = 2 * u / torch.sqrt(w * w - 1)                              # d(u^2)/dw
+    dw = 4 * (zi - zo) / (ai * ao)[..., None] + (4 * s / (ai * ai * ao))[..., None] * zi
+    return u * u, du[..., None] * dw
+
+
+def cosne_grad(Z, P, NN, X_norm, gamma, lam, exag=1.0, rep=1.0):
+    """Closed-form Euclidean gradient of :func:`cosne_loss` (single process): what the HIP kernels evaluate."""
+    n, c = Z.shape
+    G = torch.zeros_like(Z)
+    # attraction: both ends of every directed edge (i -> j)
+    Zi = Z[:, None, :].expand(-1, NN.shape[1], -1)
+    Zj = Z[NN.long()]
+    d2, gi = _dd2_dzi(Zi, Zj)
+    _, gj = _dd2_dzi(Zj, Zi)
+    wgt = (P.to(Z.dtype) / (d2 + gamma**2))[..., None]
+    G += exag * (wgt * gi).sum(1)
+    G.index_add_(0, NN.reshape(-1).long(), exag * (wgt * gj).reshape(-1, c))
+    # repulsion: log sum_ij Q_ij, Q = gamma / (d2 + gamma^2), diagonal contributes to the sum only
+    D2, gI = _dd2_dzi(Z[:, None, :], Z[None, :, :])
+    Q = gamma / (D2 + gamma**2)
+    S = Q.sum()
+    dQ = -(gamma / (D2 + gamma**2) ** 2)[..., None] * gI
+    dQ[torch.arange(n), torch.arange(n)] = 0
+    G += rep * (2.0 / S) * dQ.sum(1)
+    # norm preservation
+    y = (Z**2).sum(-1)
+    w = 1 + 2 * y / (1 - y) + 1e-8
+    u = torch.arccosh(w)
+    dh = (2 * u / torch.sqrt(w * w - 1)) * (2 / (1 - y) ** 2)
+    G += rep * lam * (2.0 / n) * ((u * u - X_norm) * dh)[:, None] * (2 * Z)
+    return G
+
+
+def _lambda_x(x):
+    return 2 / (1.0 - (x**2).sum(-1, keepdim=True)).clamp_min(1e-15)
+
+
+def _mobius_add(x, y):
+    x2, y2, xy = (x**2).sum(-1, keepdim=True), (y**2).sum(-1, keepdim=True), (x * y).sum(-1, keepdim=True)
+    num = (1 + 2 * xy + y2) * x + (1 - x2) * y
+    return num / (1 + 2 * xy + x2 * y2).clamp_min(1e-15)
+
+
+def radam_poincare_step(Z, egrad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8):
+    """One RiemannianAdam step on the unit Poincare ball (c = 1, no weight decay / amsgrad), utils/radam.py:139-167.
+    ``step`` is the group's counter, which the reference increments TWICE per step.  Returns
+    (Z_new, exp_avg_new, exp_avg_sq_new, step_new, rgrad)."""
+    lam = _lambda_x(Z)
+    g = egrad / lam**2                                                    # egrad2rgrad
+    exp_avg = exp_avg * betas[0] + (1 - betas[0]) * g
+    exp_avg_sq = exp_avg_sq * betas[1] + (1 - betas[1]) * (lam**2 * (g * g).sum(-1, keepdim=True))   # inner, keepdim
+    denom = exp_avg_sq.sqrt() + eps
+    step += 1
+    step_size = lr * (1 - betas[1] ** step) ** 0.5 / (1 - betas[0] ** step)
+    u = -step_size * (exp_avg / denom)
+    un = u.norm(dim=-1, keepdim=True).clamp_min(1e-15)
+    second = (0.5 * lam * un).clamp(-15, 15).tanh() * u / un               # expmap
+    new = _mobius_add(Z, second)
+    nn_ = new.norm(dim=-1, keepdim=True).clamp_min(1e-15)                  # proj (float64: eps 1e-5)
+    maxnorm = 1 - 1e-5
+    new = torch.where(nn_ > maxnorm, new / nn_ * maxnorm, new)
+    # ptransp(point, new_point, exp_avg): gyration(new, -point, exp_avg) * lambda_point / lambda_new
+    uu, vv, ww = new, -Z, exp_avg
+    u2, v2 = (uu**2).sum(-1, keepdim=True), (vv**2).sum(-1, keepdim=True)
+    uv, uw, vw = (uu * vv).sum(-1, keepdim=True), (uu * ww).sum(-1, keepdim=True), (vv * ww).sum(-1, keepdim=True)
+    a = -uw * v2 + vw + 2 * uv * vw
+    b = -vw * u2 - uw
+    d = 1 + 2 * uv + u2 * v2
+    gyr = ww + 2 * (a * uu + b * vv) / d.clamp_min(1e-15)
+    exp_avg = gyr * lam / _lambda_x(new)
+    step += 1
+    return new, exp_avg, exp_avg_sq, step, g
+
+
+def hyperbolic_init(noise, init_scaling=0.5):
+    """affinity_matcher.py:552-565: expmap0(init_scaling * randn) on the unit ball (float64)."""
+    u = init_scaling * noise
+    un = u.norm(dim=-1, keepdim=True).clamp_min(1e-15)
+    return un.clamp(-15, 15).tanh() * u / un

@@ -406,12 +406,64 @@ def manhattan_fixture():
     save("manhattan", **out)
 
 
+def cosne_fixture():
+    """COSNE (neighbor_embedding/cosne.py:162-193 + utils/radam.py + utils/manifold.py): float64 Poincare-ball
+    trajectories of the reference.  Per recorded iteration: the state the step starts from (embedding, Adam moments,
+    step counter), the Riemannian gradient the optimizer saw (egrad2rgrad rescales ``.grad`` in place) and the state
+    after the step.  Two runs: the default ``lr='auto'`` (= N/4: every point is thrown onto the boundary of the ball in
+    one step, where the ball arithmetic is ill-conditioned) and ``lr=0.05`` (points stay interior: tight parity)."""
+    from torchdr import COSNE
+
+    X = gmm(300, 10, 2.0, seed=41)
+    keep = (0, 1, 2, 5, 19)
+    out = {"X": X}
+
+    def run(prefix, **kw):
+        rec = {}
+
+        class Rec(COSNE):
+            def _opt_state(self, tag, it):
+                st = self.optimizer_.state.get(self.embedding_, {})
+                zero = torch.zeros_like(self.embedding_.detach())
+                rec[f"EA{tag}{it}"] = st["exp_avg"].clone() if st else zero
+                rec[f"ES{tag}{it}"] = st["exp_avg_sq"].clone() if st else zero
+                rec[f"step{tag}{it}"] = int(self.optimizer_.param_groups[0].get("step", 0))
+
+            def on_training_step_start(self):
+                super().on_training_step_start()
+                it = int(self.n_iter_)
+                if it == 0:
+                    rec["P"], rec["NN"] = self.affinity_in_.clone(), self.NN_indices_.clone()
+                    rec["lr"] = float(self.lr_)
+                if it in keep:   # state the step starts from
+                    rec[f"Zb{it}"] = self.embedding_.detach().clone()
+                    self._opt_state("b", it)
+
+            def on_training_step_end(self):
+                it = int(self.n_iter_)
+                if it in keep:   # state the step produced; .grad holds the Riemannian gradient (rescaled in place)
+                    rec[f"Za{it}"] = self.embedding_.detach().clone()
+                    rec[f"R{it}"] = self.embedding_.grad.detach().clone()
+                    self._opt_state("a", it)
+                return super().on_training_step_end()
+
+        m = Rec(perplexity=10, max_iter=20, random_state=0, learning_rate_for_h_loss=0.1, gamma=2, **kw)
+        Z = m.fit_transform(X)
+        assert Z.dtype == torch.float64 and torch.equal(Z, rec["Za19"])
+        out.update({prefix + k: v for k, v in rec.items()})
+
+    run("auto_")
+    run("small_", lr=0.05)
+    save("cosne", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ALL = dict(knn=knn_fixtures, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
                umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne2_step=ne2_step_fixture,
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
-               eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture)
+               eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
+               cosne=cosne_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

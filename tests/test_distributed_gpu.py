@@ -77,7 +77,8 @@ def _worker(rank, world, port, ret):
                         (torchdr_amd.LargeVis, dict(perplexity=6, max_iter=25)),
                         (torchdr_amd.TSNE, dict(perplexity=6, max_iter=25)),
                         (torchdr_amd.SNE, dict(perplexity=6, max_iter=25)),
-                        (torchdr_amd.InfoTSNE, dict(perplexity=6, max_iter=25, n_negatives=30))):
+                        (torchdr_amd.InfoTSNE, dict(perplexity=6, max_iter=25, n_negatives=30)),
+                        (torchdr_amd.COSNE, dict(perplexity=6, max_iter=25, lr=0.05))):
             m = cls(random_state=0, **kw)
             assert m.world_size == world
             Z = m.fit_transform(X)
@@ -86,7 +87,7 @@ def _worker(rank, world, port, ret):
             gathered = [torch.empty_like(h) for _ in range(world)]
             dist.all_gather(gathered, h)
             assert torch.equal(gathered[0], gathered[1]), f"{cls.__name__}: ranks diverged"
-            if cls is torchdr_amd.SNE:  # no sampling: the sharded run must reproduce the single-process one
+            if cls in (torchdr_amd.SNE, torchdr_amd.COSNE):  # no sampling: the sharded run must reproduce the single-process one
                 Z1 = cls(random_state=0, distributed=False, **kw).fit_transform(X)
                 assert torch.allclose(Z, Z1, rtol=1e-3, atol=1e-4 * float(Z1.abs().max()))
         ret[rank] = True

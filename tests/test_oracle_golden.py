@@ -182,6 +182,31 @@ def test_manhattan_oracle_is_bit_identical_to_the_reference():
     assert torch.equal(Ck, g["cross_C"]) and torch.equal(Ik.long(), g["cross_I"].long())
 
 
+def test_cosne_oracle_vs_reference_trajectories():
+    """COSNE restatement (closed-form gradient, autograd of the restated loss, RAdam step) against the recorded float64
+    trajectories.  ``small_`` (lr 0.05, interior points): machine precision; ``auto_`` (default lr = N/4: the points sit
+    on the boundary of the ball after one step): limited by the conditioning of the ball arithmetic itself."""
+    g = load("cosne")
+    Xn = (g["X"] ** 2).sum(-1)
+    for pre, tol_g, tol_z in (("small_", 1e-13, 1e-14), ("auto_", 1e-8, 1e-4)):
+        P, NN, lr = g[pre + "P"], g[pre + "NN"], float(g[pre + "lr"])
+        for it in (0, 1, 2, 5, 19):
+            Z = g[f"{pre}Zb{it}"]
+            Gc = R.cosne_grad(Z, P, NN, Xn, 2.0, 0.1)
+            Zr = Z.clone().requires_grad_()
+            R.cosne_loss(Zr, P, NN, Xn, 2.0, 0.1).backward()
+            assert float((Zr.grad - Gc).abs().max() / Gc.abs().max()) < max(tol_g, 1e-12)
+            Zn, ea, es, step, rg = R.radam_poincare_step(Z, Gc, g[f"{pre}EAb{it}"], g[f"{pre}ESb{it}"],
+                                                         int(g[f"{pre}stepb{it}"]), lr)
+            Rg = g[f"{pre}R{it}"]
+            assert float((rg - Rg).abs().max() / Rg.abs().max()) < tol_g
+            assert float((Zn - g[f"{pre}Za{it}"]).abs().max()) < tol_z and step == int(g[f"{pre}stepa{it}"])
+            assert torch.allclose(es, g[f"{pre}ESa{it}"], rtol=1e-8, atol=0)
+    assert float(g["auto_lr"]) == 75.0                                  # lr='auto' = max(N / 4, 50)
+    Z0 = R.hyperbolic_init(torch.randn(50, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(0)))
+    assert float(Z0.norm(dim=1).max()) < 1.0
+
+
 def test_pacmap_affinity_oracle():
     g = load("pacmap")
     idx, rho = R.pacmap_affinity(g["X"], 10)

@@ -8,4 +8,4 @@ from torchdr_amd.affinity import (  # noqa: F401,E402
     Affinity, LogAffinity, SparseAffinity, SparseLogAffinity, EntropicAffinity, UMAPAffinity,
     SymmetricEntropicAffinity, SinkhornAffinity, PACMAPAffinity,
 )
-from torchdr_amd.neighbor_embedding import UMAP, LargeVis, TSNE, TSNEkhorn, SNE, InfoTSNE, PACMAP  # noqa: F401,E402
+from torchdr_amd.neighbor_embedding import UMAP, LargeVis, TSNE, TSNEkhorn, SNE, InfoTSNE, PACMAP, COSNE  # noqa: F401,E402

@@ -6,3 +6,4 @@ from .tsnekhorn import TSNEkhorn  # noqa: F401
 from .sne import SNE  # noqa: F401
 from .infotsne import InfoTSNE  # noqa: F401
 from .pacmap import PACMAP  # noqa: F401
+from .cosne import COSNE  # noqa: F401

@@ -20,3 +20,4 @@ from .sparse import CSRAffinity, symmetrize_sparse, symmetrize_to_csr  # noqa: F
 from .numeric import (  # noqa: F401
     binary_search, cross_entropy_loss, entropy, init_bounds, kmax, kmin, logsumexp_red, sum_red,
 )
+from .radam import RiemannianAdam  # noqa: F401
