@@ -818,8 +818,10 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
             static int dense_ok = -1;  // TDR_UMAP_DENSE=0: masking passes even when the dense ones apply
             if (dense_ok < 0) { const char* g = getenv("TDR_UMAP_DENSE"); dense_ok = g ? atoi(g) : 1; }
             if (dense_ok && !neg_inj && (slices == 2 || slices == 4) && n_total < 0x7fffffffLL) {
-                rc = (nc == 2) ? launch_group<16>(umap_neg_dense_kernel<2, 16, 2>, P, n_rows, st)
-                               : launch_group<16>(umap_neg_dense_kernel<3, 16, 2>, P, n_rows, st);
+                // 8 lanes per row x 2 columns per lane and round (16 x 2, 8 x 3, 8 x 4, 4 x 6, 32 x 1 measured within 2 %
+                // of each other, 32 x 1 10 % slower: the pass is bound by L2 line requests, not by lane utilisation)
+                rc = (nc == 2) ? launch_group<8>(umap_neg_dense_kernel<2, 8, 2>, P, n_rows, st)
+                               : launch_group<8>(umap_neg_dense_kernel<3, 8, 2>, P, n_rows, st);
             } else {
                 rc = (nc == 2) ? launch_group<16>(umap_neg_slice_kernel<2, 16, 4>, P, n_rows, st)
                                : launch_group<16>(umap_neg_slice_kernel<3, 16, 4>, P, n_rows, st);
