@@ -227,11 +227,11 @@ def main():
                                         "not matrix-pipe utilisation" if path.endswith("pruned") else "")),
     }
     roof_grad = {
-        "kernel": "tdr::umap_grad_kernel<2,16,4,true> + tdr::umap_neg_slice_kernel<2,16,4> (one gradient evaluation)",
+        "kernel": "tdr::umap_grad_kernel<2,16,4,true> + 2 x tdr::umap_neg_dense_kernel<2,8,2> (one gradient evaluation)",
         "bound": "hbm", "achieved": grad_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_gbs / HBM_PEAK_GBS,
         "traffic": pmc_traffic("r01_umap_grad_pmc.json"),
         "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_avg_ms, "evaluations_sampled": len(grad_ms),
-        "note": "random 8-byte gathers of the embedding + VALU-issue-bound force math dominate; see DESIGN.md section 3",
+        "note": "positive pass HBM-bound (5.2 TB/s at the L2/fabric boundary); the dense negative passes are random 8-byte L2 gathers bound by the L2 line-request rate; see DESIGN.md section 6",
     }
     loop_ms = grad_avg_ms * args.max_iter
     dominant, secondary = (roof_grad, roof_knn) if loop_ms >= scan_avg_ms else (roof_knn, roof_grad)
