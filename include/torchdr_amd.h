@@ -56,7 +56,7 @@ int tdr_dense_dist_packed_f32(const float* qp, int64_t nq, int64_t q_offset, con
                               int metric, int exclude_self, float diag_add, float* out, int64_t ldo, void* stream);
 
 /* gathered distances out[i][c] = ||X[q_i] - Y[keys[i][c]]||^2 (distance/base.py:384-385; take_sqrt = 1: its square
- * root, :386-387; take_sqrt = 2: sum_c |x - y|, manhattan, :388-389; 3: -sum_c x y, angular, :390-391); negative indices wrap like PyTorch indexing. */
+ * root, :386-387; take_sqrt = 2: sum_c |x - y|, manhattan, :388-389; 3: -sum_c x y, angular, :390-391; 4: sqhyperbolic, :392-398); negative indices wrap like PyTorch indexing. */
 int tdr_indexed_sqdist_f32(const float* X, int64_t nx, int d, const float* Y, int64_t ny, const int64_t* q,
                            int64_t nq, int nk, int take_sqrt, const int64_t* keys, float* out, void* stream);
 
@@ -68,6 +68,10 @@ int tdr_topk_merge_f32(const float* G, int64_t ldg, int64_t nq, int64_t nd, cons
                        int64_t q_global0, int64_t d_global0, int k, int metric, int exclude_self, uint64_t* run_keys,
                        void* stream);
 int tdr_topk_emit_f32(const uint64_t* run_keys, int64_t nq, int k, int metric, float* out_d, int32_t* out_i, void* stream);
+/* metric "sqhyperbolic" (distance/torch.py:101-107): kNN = tdr_topk_merge_f32 with metric 4; dense form = this in-place
+ * epilogue on the Gram block G = X Y^T */
+int tdr_hyperbolic_from_gram_f32(float* G, int64_t ld, int64_t nq, int64_t nd, const float* xn, const float* yn,
+                                 void* stream);
 /* the same fold over per-query candidate lists: E (nq, nc) distances, cand (nq, nc) database indices (row stride ld,
  * negative = skip); ranks exactly re-evaluated candidates by (distance, index) */
 int tdr_topk_merge_cand_f32(const float* E, const int32_t* cand, int64_t ld, int64_t nq, int64_t nc, int k,

@@ -35,6 +35,9 @@ def knn_chunked(X, k, metric="sqeuclidean", exclude_self=True, Y=None, chunk=409
             C = xn[s:e, None] + yn[None, :] - 2 * dot
             if metric == "euclidean":
                 C = C.clamp(min=0).sqrt()
+            elif metric == "sqhyperbolic":  # distance/torch.py:101-107
+                denom = (1 - xn[s:e])[:, None] * (1 - yn)[None, :]
+                C = torch.arccosh(1 + 2 * (torch.relu(C) / denom) + 1e-8) ** 2
         if exclude_self and Y is None:
             idx = torch.arange(s, e)
             C[idx - s, idx] = C[idx - s, idx] + 1e12

@@ -406,6 +406,34 @@ def manhattan_fixture():
     save("manhattan", **out)
 
 
+def ball_points(n, d, seed, radius=0.9):
+    """Points of the open unit ball (inputs of the sqhyperbolic metric)."""
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(n, d, generator=g)
+    r = radius * torch.rand(n, 1, generator=g) ** (1.0 / d)
+    return (v / v.norm(dim=1, keepdim=True) * r).contiguous()
+
+
+def hyperbolic_fixture():
+    """metric='sqhyperbolic' (distance/torch.py:101-107, distance/base.py:372-377, 392-398) on points of the unit ball."""
+    out = {}
+    X, Y = ball_points(400, 5, 51), ball_points(150, 5, 52)
+    out["knn_C"], out["knn_I"] = pairwise_distances(X, metric="sqhyperbolic", backend=None, exclude_diag=True, k=9,
+                                                   return_indices=True)
+    out["knn_Cw"], _ = pairwise_distances(X, metric="sqhyperbolic", backend=None, exclude_diag=True, k=17, return_indices=True)
+    out["cross_C"], out["cross_I"] = pairwise_distances(X, Y, metric="sqhyperbolic", backend=None, k=6, return_indices=True)
+    out["cross_dense"] = pairwise_distances(X, Y, metric="sqhyperbolic", backend=None)
+    out["dense_excl"] = pairwise_distances(X[:120], metric="sqhyperbolic", backend=None, exclude_diag=True)
+    g = torch.Generator().manual_seed(5)
+    keys = torch.randint(0, 400, (40, 7), generator=g)
+    keys[3, 2] = -1
+    q = torch.arange(100, 140)
+    out["keys"], out["q"] = keys, q
+    out["indexed"] = pairwise_distances_indexed(X, query_indices=q, key_indices=keys, metric="sqhyperbolic")
+    out["block"] = pairwise_distances_indexed(X, query_indices=q, key_indices=torch.arange(5, 90), metric="sqhyperbolic")
+    save("hyperbolic", X=X, Y=Y, **out)
+
+
 def cosne_fixture():
     """COSNE (neighbor_embedding/cosne.py:162-193 + utils/radam.py + utils/manifold.py): float64 Poincare-ball
     trajectories of the reference.  Per recorded iteration: the state the step starts from (embedding, Adam moments,
@@ -463,7 +491,7 @@ if __name__ == "__main__":
                umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne2_step=ne2_step_fixture,
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
-               cosne=cosne_fixture)
+               cosne=cosne_fixture, hyperbolic=hyperbolic_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

@@ -207,6 +207,14 @@ def test_cosne_oracle_vs_reference_trajectories():
     assert float(Z0.norm(dim=1).max()) < 1.0
 
 
+def test_sqhyperbolic_oracle_vs_reference_golden():
+    g = load("hyperbolic")
+    C, I = R.knn_chunked(g["X"], 9, "sqhyperbolic", True, chunk=128)
+    assert torch.equal(C, g["knn_C"]) and torch.equal(I.long(), g["knn_I"].long())
+    C, I = R.knn_chunked(g["X"], 6, "sqhyperbolic", False, Y=g["Y"], chunk=77)
+    assert torch.equal(C, g["cross_C"]) and torch.equal(I.long(), g["cross_I"].long())
+
+
 def test_pacmap_affinity_oracle():
     g = load("pacmap")
     idx, rho = R.pacmap_affinity(g["X"], 10)

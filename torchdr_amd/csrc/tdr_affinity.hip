@@ -330,6 +330,20 @@ __global__ __launch_bounds__(256) void indexed_sqdist_kernel(const float* __rest
         out[idx] = acc;
         return;
     }
+    if (take_sqrt == 4) {  // sqhyperbolic by direct difference (distance/base.py:392-398)
+        float xn = 0.f, yn = 0.f;
+        for (int t = 0; t < d; ++t) {
+            const float df = x[t] - y[t];
+            acc = __fadd_rn(acc, __fmul_rn(df, df));
+            xn = __fadd_rn(xn, __fmul_rn(x[t], x[t]));
+            yn = __fadd_rn(yn, __fmul_rn(y[t], y[t]));
+        }
+        const float den = __fmul_rn(__fsub_rn(1.0f, xn), __fsub_rn(1.0f, yn));
+        const float w = __fadd_rn(__fadd_rn(1.0f, __fmul_rn(2.0f, __fdiv_rn(fmaxf(acc, 0.f), den))), 1e-8f);
+        const float u = acoshf(w);
+        out[idx] = __fmul_rn(u, u);
+        return;
+    }
     if (take_sqrt == 3) {  // angular: -<x, y> (distance/base.py:390-391)
         for (int t = 0; t < d; ++t) acc = __fadd_rn(acc, __fmul_rn(x[t], y[t]));
         out[idx] = -acc;
@@ -407,7 +421,7 @@ int tdr_entropic_search_f32(const float* C, int64_t n, int k, float target, floa
     return launch_rows(entropic_search_kernel<64, 4>, 64, n, st, C, n, k, S, max_iter, tol, eps, log_norm, log_P);
 }
 
-/* Gathered distances: out (nq, nk); take_sqrt 0 = squared Euclidean, 1 = Euclidean, 2 = manhattan, 3 = angular. q/keys are int64;
+/* Gathered distances: out (nq, nk); take_sqrt 0 = squared Euclidean, 1 = Euclidean, 2 = manhattan, 3 = angular, 4 = sqhyperbolic. q/keys are int64;
  * negative keys wrap. */
 int tdr_indexed_sqdist_f32(const float* X, int64_t nx, int d, const float* Y, int64_t ny, const int64_t* q,
                            int64_t nq, int nk, int take_sqrt, const int64_t* keys, float* out, void* stream) {

@@ -662,6 +662,15 @@ __global__ __launch_bounds__(256) void knn_overlap_kernel(const int32_t* __restr
 // ascending k-list (same 64-bit (distance, index) keys and cooperative insertion as the scan kernel).  One wavefront
 // per query row; the list lives in LDS during the launch and in `run_keys` between database chunks.
 // ---------------------------------------------------------------------------------------------
+// distance/torch.py:101-107: arccosh(1 + 2 relu(C) / ((1 - |x|^2)(1 - |y|^2)) + 1e-8)^2 in the reference's fp32 op order
+__device__ __forceinline__ float sqhyperbolic_from(float c_sq, float xn, float yn) {
+    const float C = fmaxf(c_sq, 0.f);
+    const float den = __fmul_rn(__fsub_rn(1.0f, xn), __fsub_rn(1.0f, yn));
+    const float w = __fadd_rn(__fadd_rn(1.0f, __fmul_rn(2.0f, __fdiv_rn(C, den))), 1e-8f);
+    const float u = acoshf(w);
+    return __fmul_rn(u, u);
+}
+
 struct TopkMergeParams {
     const float* G;        // (nq, nd) block of X Y^T, row stride ldg
     int64_t ldg;
@@ -685,7 +694,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const TopkMergeParams P
     for (int p = lane; p < P.k; p += 64) Lst[p] = P.run_keys[(size_t)qi * P.k + p];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     float tau = u2f((uint32_t)(Lst[P.k - 1] >> 32));  // k-th best so far (+inf while the list is not full)
-    const float xq = (P.metric >= 2) ? 0.f : P.xn[qi];
+    const float xq = (P.metric == 2 || P.metric == 3) ? 0.f : P.xn[qi];
     const float* g = P.G + (size_t)qi * P.ldg;
     const int64_t self_j = P.exclude_self ? (P.q_global0 + qi - P.d_global0) : -1;
     for (int64_t j0 = 0; j0 < P.nd; j0 += 64) {
@@ -700,7 +709,13 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const TopkMergeParams P
         }
         if (live) {
             const float gv = g[j];
-            c = (P.metric == 3) ? gv : (P.metric == 2) ? -gv : __builtin_fmaf(-2.0f, gv, __fadd_rn(xq, P.yn[j]));
+            if (P.metric == 3) c = gv;
+            else if (P.metric == 2) c = -gv;
+            else {
+                const float yj = P.yn[j];
+                c = __builtin_fmaf(-2.0f, gv, __fadd_rn(xq, yj));
+                if (P.metric == 4) c = sqhyperbolic_from(c, xq, yj);
+            }
         }
         unsigned long long m = __ballot(c <= tau);
         while (m) {
@@ -727,6 +742,17 @@ __global__ __launch_bounds__(256) void topk_emit_kernel(const uint64_t* __restri
     if (metric == 1) c = sqrt_rn(fmaxf(c, 0.f));
     out_d[i] = c;
     out_i[i] = (int32_t)(uint32_t)(key & 0xffffffffu);
+}
+
+// Gram block -> sqhyperbolic distances, in place (dense form of distance/torch.py:101-107)
+__global__ __launch_bounds__(256) void hyperbolic_epilogue_kernel(float* __restrict__ G, int64_t ld, int64_t nq, int64_t nd,
+                                                                 const float* __restrict__ xn, const float* __restrict__ yn) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= nd || i >= nq) return;
+    const float xq = xn[i], yj = yn[j];
+    float* g = G + (size_t)i * ld + j;
+    *g = sqhyperbolic_from(__builtin_fmaf(-2.0f, *g, __fadd_rn(xq, yj)), xq, yj);
 }
 
 __global__ __launch_bounds__(256) void fill_keys_kernel(uint64_t* __restrict__ keys, int64_t total) {
@@ -1005,7 +1031,7 @@ int tdr_topk_merge_f32(const float* G, int64_t ldg, int64_t nq, int64_t nd, cons
                        int64_t q_global0, int64_t d_global0, int k, int metric, int exclude_self, uint64_t* run_keys,
                        void* stream) {
     if (!G || !run_keys || nq <= 0 || nd <= 0 || ldg < nd || k <= 0) return TDR_ERR_BAD_ARG;
-    if (metric < 0 || metric > 3 || (metric < 2 && (!xn || !yn))) return TDR_ERR_BAD_ARG;
+    if (metric < 0 || metric > 4 || ((metric < 2 || metric == 4) && (!xn || !yn))) return TDR_ERR_BAD_ARG;
     if (k > 256) return TDR_ERR_UNSUPPORTED;
     TopkMergeParams P;
     P.G = G; P.ldg = ldg; P.nq = nq; P.nd = nd; P.xn = xn; P.yn = yn; P.q_global0 = q_global0; P.d_global0 = d_global0;
@@ -1023,6 +1049,19 @@ int tdr_topk_merge_cand_f32(const float* E, const int32_t* cand, int64_t ld, int
     P.G = E; P.ldg = ld; P.nq = nq; P.nd = nc; P.xn = nullptr; P.yn = nullptr; P.q_global0 = 0; P.d_global0 = 0;
     P.k = k; P.metric = 3; P.exclude_self = 0; P.run_keys = run_keys; P.cand = cand;
     return launch_topk_merge(P, stream);
+}
+
+/* metric "sqhyperbolic" (distance/torch.py:101-107), dense form: G = X Y^T (nq x nd, row stride ld) is overwritten with
+ * arccosh(1 + 2 relu(|x|^2 + |y|^2 - 2 G) / ((1 - |x|^2)(1 - |y|^2)) + 1e-8)^2.  (kNN: tdr_topk_merge_f32, metric 4.) */
+int tdr_hyperbolic_from_gram_f32(float* G, int64_t ld, int64_t nq, int64_t nd, const float* xn, const float* yn,
+                                 void* stream) {
+    if (!G || !xn || !yn || nq < 0 || nd < 0 || ld < nd) return TDR_ERR_BAD_ARG;
+    if (nq == 0 || nd == 0) return TDR_OK;
+    if (nq > 65535) return TDR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(hyperbolic_epilogue_kernel, dim3((unsigned)((nd + 255) / 256), (unsigned)nq), dim3(256), 0,
+                       (hipStream_t)stream, G, ld, nq, nd, xn, yn);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
 }
 
 /* Step 3: lists -> out_d (nq, k) fp32 ascending, out_i (nq, k) int32. */

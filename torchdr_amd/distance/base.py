@@ -17,8 +17,9 @@ from torchdr_amd.distributed import DistributedContext
 from torchdr_amd.utils.dataloader import is_dataloader, materialize_dataloader
 from torchdr_amd.utils.misc import as_float32
 
-LIST_METRICS = ["euclidean", "sqeuclidean", "manhattan", "angular"]
-_METRIC_ID = {"sqeuclidean": 0, "euclidean": 1, "angular": 2, "manhattan": 3}
+LIST_METRICS = ["euclidean", "sqeuclidean", "manhattan", "angular", "sqhyperbolic"]
+_METRIC_ID = {"sqeuclidean": 0, "euclidean": 1, "angular": 2, "manhattan": 3, "sqhyperbolic": 4}
+_GENERAL_ONLY = ("manhattan", "sqhyperbolic")     # metrics that never take the MFMA scan kernels
 
 # Value the reference adds to the diagonal when exclude_diag=True (distance/torch.py:115).
 _DIAG_ADD = 1e12
@@ -640,6 +641,18 @@ def _dense_general(X, Y, metric, exclude_self):
             C.diagonal().add_(_DIAG_ADD)
         return C
     G = torch.mm(X, Y.t())
+    if metric == "sqhyperbolic":  # distance/torch.py:101-107
+        xn, yn = (X * X).sum(1).contiguous(), (Y * Y).sum(1).contiguous()
+        for r0 in range(0, G.shape[0], 32768):
+            r1 = min(r0 + 32768, G.shape[0])
+            _lib.check(
+                _lib.lib().tdr_hyperbolic_from_gram_f32(_lib.ptr(G[r0:r1]), G.stride(0), r1 - r0, G.shape[1],
+                                                        _lib.ptr(xn[r0:r1]), _lib.ptr(yn), _lib.stream_ptr()),
+                "tdr_hyperbolic_from_gram_f32",
+            )
+        if exclude_self:
+            G.diagonal().add_(_DIAG_ADD)
+        return G
     if metric == "angular":
         C = -G
     else:
@@ -725,7 +738,7 @@ def pairwise_distances(
             )
         n = X.shape[0]
         c0, c1 = distributed_ctx.compute_chunk_bounds(n)
-        if X.shape[1] > 256 or metric == "manhattan":
+        if X.shape[1] > 256 or metric in _GENERAL_ONLY:
             if X.dtype != torch.float32:
                 raise NotImplementedError(f"[torchdr_amd] only float32 inputs are supported by the HIP distance kernels (got {X.dtype}).")
             Xc = X if X.stride(1) == 1 else X.contiguous()
@@ -751,7 +764,7 @@ def pairwise_distances(
         return (C, I) if return_indices else C
 
     do_exclude = bool(exclude_diag) and self_search
-    if X.shape[1] > 256 or metric == "manhattan":  # not on the MFMA scan kernels: (library GEMM | L1 tiles) + HIP top-k merge
+    if X.shape[1] > 256 or metric in _GENERAL_ONLY:  # not on the MFMA scan kernels: (library GEMM | L1 tiles) + HIP top-k merge
         if X.dtype != torch.float32:
             raise NotImplementedError(f"[torchdr_amd] only float32 inputs are supported by the HIP distance kernels (got {X.dtype}).")
         Xc = X if X.stride(1) == 1 else X.contiguous()
@@ -816,7 +829,7 @@ def pairwise_distances_indexed(
         Xq = X if query_indices is None else X[query_indices.to(X.device).long()]
         Yk = Y if key_indices is None else Y[key_indices.to(Y.device).long()]
         Xq, Yk = Xq.float().contiguous(), Yk.float().contiguous()
-        if metric == "manhattan" or Xq.shape[1] > 256:
+        if metric in _GENERAL_ONLY or Xq.shape[1] > 256:
             return _dense_general(Xq, Yk, metric, False)
         return dense_packed(PackedPoints(Xq), PackedPoints(Yk), metric, False)
     L = _lib.lib()
@@ -835,7 +848,7 @@ def pairwise_distances_indexed(
     _lib.check(
         L.tdr_indexed_sqdist_f32(
             _lib.ptr(Xc), Xc.shape[0], Xc.shape[1], _lib.ptr(Yc), Yc.shape[0], _lib.ptr(q), nq,
-            keys.shape[1], {"sqeuclidean": 0, "euclidean": 1, "manhattan": 2, "angular": 3}[metric], _lib.ptr(keys),
+            keys.shape[1], {"sqeuclidean": 0, "euclidean": 1, "manhattan": 2, "angular": 3, "sqhyperbolic": 4}[metric], _lib.ptr(keys),
             _lib.ptr(out),
             _lib.stream_ptr(),
         ),
