@@ -143,6 +143,20 @@ def main():
         return out
 
     dbase.knn_packed = _timed_knn_packed
+    _knn_sharded = dbase.knn_pruned_sharded
+
+    def _timed_knn_sharded(*a, **kw):   # N > 1: pilots + index build + broadcast + pruned scan + row exchange
+        if dbase.PROFILE is None:
+            return _knn_sharded(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = _knn_sharded(*a, **kw)
+        e1.record()
+        if out is not None:
+            knn_total_events.append((e0, e1))
+        return out
+
+    dbase.knn_pruned_sharded = _timed_knn_sharded
 
     def one_step(record):
         dbase.PROFILE = [] if record else None

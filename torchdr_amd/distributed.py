@@ -38,7 +38,9 @@ def init_from_env(backend: str = None) -> bool:
         return False
     local_rank = int(os.environ["LOCAL_RANK"])
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # TDR_DIST_BACKEND=gloo: several ranks on ONE GPU (RCCL refuses duplicate devices) -- debugging / CI only,
+        # the collectives are then staged through host memory (parallel._host_staged)
+        backend = os.environ.get("TDR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
