@@ -36,3 +36,16 @@ if "c5" in which:
     m = t.TSNEkhorn(perplexity=30, max_iter=20, max_iter_affinity_in=5, init="normal", init_scaling=1.0, lr=1.0,
                     optimizer="SGD", optimizer_kwargs=None, min_grad_norm=1e-30, random_state=0)
     timed("C5 TSNEkhorn N=200k: 5 SEA iterations + 20 training steps (5 Sinkhorn passes + fused force each)", lambda: m.fit_transform(X), 1)
+if "c4" in which:
+    # C4 is the 8-GPU configuration (N=4M, D=256, k=30); on ONE MI355X it is a capacity / large-N robustness probe
+    from torchdr_amd.distance import base as dbase
+    n = 4_000_000
+    X = gmm(n, 256, 2.0).cuda()
+    C, I = timed("C4 kNN N=4M D=256 k=30 on one GPU (pairwise_distances)",
+                 lambda: pairwise_distances(X, metric="sqeuclidean", k=30, exclude_diag=True, return_indices=True), 1)
+    print(json.dumps({"knn_path": dbase.LAST_KNN.get("path"), "tier": dbase.LAST_KNN.get("tier"), "flagged": int(dbase.LAST_KNN.get("flagged", 0)),
+                      "self_returned": bool((I == torch.arange(n, device="cuda", dtype=torch.int32)[:, None]).any()),
+                      "sorted": bool((C[:, 1:] >= C[:, :-1]).all())}))
+    del C, I
+    Z = timed("C4 UMAP N=4M D=256 k=30, 200 iterations, one GPU", lambda: t.UMAP(n_neighbors=30, max_iter=200, random_state=0).fit_transform(X), 1)
+    print(json.dumps({"finite": bool(torch.isfinite(Z).all()), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))

@@ -422,7 +422,7 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
         if int(n_flagged.item()):
             _screen_fallback(Y, Y, 0, k, metric, exclude_self, 0, rows[flags[rows] != 0], out_d, out_i)
     Cc, Ic = exchange_rows_to_owners(rows.to(torch.int32), out_d[rows], out_i[rows], n, W, c0, c1 - c0)
-    LAST_KNN["path"], LAST_KNN["flagged"], LAST_KNN["tier"], LAST_KNN["pruned"] = "screen", 0, tier, True
+    LAST_KNN["path"], LAST_KNN["flagged"], LAST_KNN["tier"], LAST_KNN["pruned"] = "screen-pruned", 0, tier, True
     return Cc, Ic
 
 
@@ -456,7 +456,7 @@ def knn_packed(
     if _allow_screen and _use_screen(Q, Y, nq, k, metric):
         bad = _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i)
         if bad >= 0:
-            LAST_KNN["path"], LAST_KNN["flagged"] = "screen", bad
+            LAST_KNN["path"], LAST_KNN["flagged"] = ("screen-pruned" if LAST_KNN.get("pruned") else "screen"), bad
             return out_d, out_i
         LAST_KNN["path"], LAST_KNN["flagged"] = "exact (pilot overflow)", 0
     elif _allow_screen:
