@@ -46,6 +46,21 @@ if "c4" in which:
     print(json.dumps({"knn_path": dbase.LAST_KNN.get("path"), "tier": dbase.LAST_KNN.get("tier"), "flagged": int(dbase.LAST_KNN.get("flagged", 0)),
                       "self_returned": bool((I == torch.arange(n, device="cuda", dtype=torch.int32)[:, None]).any()),
                       "sorted": bool((C[:, 1:] >= C[:, :-1]).all())}))
+    # sampled parity at full size: 4096 random rows re-searched by the one-stage exact fp32 kernel (k + 1 without
+    # exclusion, then the row itself dropped) must give the same neighbours and distances, bit for bit
+    rows = torch.randint(0, n, (4096,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    old = dbase.SCREEN_MODE
+    dbase.SCREEN_MODE = "0"
+    try:
+        Ce, Ie = pairwise_distances(X[rows].contiguous(), X, metric="sqeuclidean", k=31, return_indices=True)
+    finally:
+        dbase.SCREEN_MODE = old
+    keep = Ie != rows[:, None].int()
+    ok_rows = keep.sum(1) == 30
+    Ie30 = Ie[ok_rows][keep[ok_rows]].reshape(-1, 30)
+    Ce30 = Ce[ok_rows][keep[ok_rows]].reshape(-1, 30)
+    print(json.dumps({"sampled_rows": int(ok_rows.sum()), "indices_equal": bool(torch.equal(Ie30, I[rows][ok_rows])),
+                      "distances_equal": bool(torch.equal(Ce30, C[rows][ok_rows]))}))
     del C, I
     Z = timed("C4 UMAP N=4M D=256 k=30, 200 iterations, one GPU", lambda: t.UMAP(n_neighbors=30, max_iter=200, random_state=0).fit_transform(X), 1)
     print(json.dumps({"finite": bool(torch.isfinite(Z).all()), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
