@@ -185,3 +185,38 @@ def test_screen_cluster_pruned_scan_equals_exact(scale, n, d, k, tier):
         dbase.SCREEN_MODE, dbase.PRUNE_MODE = old
     assert torch.equal(I0, I1), f"{int((I0 != I1).any(1).sum())} rows differ"
     assert torch.equal(C0, C1)
+
+
+def test_headline_size_search_sampled_against_the_one_stage_kernel():
+    """BASELINE's full size (N = 1M, D = 128, k = 30), default dispatch (pilot -> tier -> cluster-pruned two-stage search):
+    8192 sampled rows re-searched by the one-stage exact fp32 kernel -- itself bit-exact against the CPU oracle at the
+    sizes the oracle finishes -- give the same neighbours and distances bit for bit; every row is sorted and never
+    returns itself; the neighbour relation is the kNN graph of a metric (i in N(j) => d_ij <= d_j,k)."""
+    from torchdr_amd.distance import base as dbase
+    from torchdr_amd.distance import pairwise_distances
+
+    n, k = 1_000_000, 30
+    X = gmm(n, 128, 2.0).cuda()
+    C, I = pairwise_distances(X, metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True)
+    assert dbase.LAST_KNN["path"] == "screen-pruned" and dbase.LAST_KNN["flagged"] == 0
+    assert bool((C[:, 1:] >= C[:, :-1]).all())
+    assert not bool((I == torch.arange(n, device="cuda", dtype=torch.int32)[:, None]).any())
+    rows = torch.randint(0, n, (8192,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+    old = dbase.SCREEN_MODE
+    dbase.SCREEN_MODE = "0"
+    try:
+        Ce, Ie = pairwise_distances(X[rows].contiguous(), X, metric="sqeuclidean", k=k + 1, return_indices=True)
+    finally:
+        dbase.SCREEN_MODE = old
+    assert dbase.LAST_KNN["path"] == "exact"
+    keep = Ie != rows[:, None].int()
+    ok = keep.sum(1) == k                                   # the row itself is among its own k + 1 nearest (no duplicates)
+    assert float(ok.float().mean()) > 0.999
+    assert torch.equal(Ie[ok][keep[ok]].reshape(-1, k), I[rows][ok])
+    assert torch.equal(Ce[ok][keep[ok]].reshape(-1, k), C[rows][ok])
+    # consistency of the graph with the distances: if j lists i, then d(i, j) <= j's k-th distance, so either i lists j or
+    # i's own k-th distance is smaller still
+    j = I[rows].long()                                      # (m, k) neighbours of the sampled rows
+    dij = C[rows]
+    back = (I[j.reshape(-1)].reshape(len(rows), k, k) == rows[:, None, None].int()).any(2)
+    assert bool((back | (C[j.reshape(-1), k - 1].reshape(len(rows), k) <= dij)).all())
