@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from tests.conftest import gmm
 from tests.test_oracle_golden import load
 
 pytestmark = pytest.mark.gpu
@@ -65,3 +66,18 @@ def test_overlap_kernel_against_broadcast_compare():
     ref = (a[:, :, None] == b[:, None, :]).any(2).float().mean(1)
     got = knn_overlap(a.cuda(), b.cuda()).cpu()
     assert torch.equal(got, ref)
+
+
+def test_headline_size_umap_keeps_the_mixture_components_apart():
+    """End-to-end at BASELINE's size (N = 1M, D = 128, k = 30; 200 iterations): the 2-d embedding is finite and every
+    point's 10 nearest neighbours IN THE EMBEDDING carry its own mixture-component label (measured 1.0, like in the
+    input space) -- the whole path (pruned kNN, sigma search, symmetrisation, sliced negative sampling) at full size."""
+    import torchdr_amd
+    from torchdr_amd.eval import knn_label_accuracy
+
+    n = 1_000_000
+    X = gmm(n, 128, 2.0).cuda()
+    labels = (torch.arange(n) % 1000).cuda()          # conftest.gmm assigns component i % n_components
+    Z = torchdr_amd.UMAP(n_neighbors=30, max_iter=200, random_state=0).fit_transform(X)
+    assert Z.shape == (n, 2) and bool(torch.isfinite(Z).all())
+    assert float(knn_label_accuracy(Z, labels, k=10)) > 0.999
