@@ -132,6 +132,32 @@ def test_abi_header_matches_library():
     assert so.tdr_knn_max_k(128) >= 90
 
 
+def test_abi_argument_checks_run_before_any_device_work():
+    """Entry points validate on the host and return TDR_ERR_BAD_ARG (-1) / TDR_ERR_UNSUPPORTED (-2) without touching
+    the device: callable here, without a GPU (dummy non-null addresses are never dereferenced)."""
+    import ctypes
+
+    from torchdr_amd import _lib
+
+    L = _lib.lib()
+    p, null = ctypes.c_void_p(64), ctypes.c_void_p(0)
+    assert L.tdr_l1_block_f32(null, 8, 4, p, 8, 4, 8, p, 4, null) == -1
+    assert L.tdr_l1_block_f32(p, 4, 4, p, 8, 4, 8, p, 4, null) == -1                 # row stride < d
+    assert L.tdr_l1_exact_f32(p, 9000, null, 4, 0, p, 9000, null, 0, 4, 0, 8192, 0, p, 4, null) == -2   # third cascade level
+    assert L.tdr_l1_exact_f32(p, 8, null, 4, 0, p, 8, p, 2, 4, 0, 8, 0, p, 4, null) == -1                # ldc < nc
+    assert L.tdr_topk_merge_cand_f32(p, p, 8, 4, 8, 300, p, null) == -2              # k > 256
+    assert L.tdr_topk_merge_f32(p, 8, 4, 8, null, null, 0, 0, 5, 4, 0, p, null) == -1   # sqhyperbolic needs the norms
+    assert L.tdr_topk_merge_f32(p, 8, 4, 8, null, null, 0, 0, 5, 7, 0, p, null) == -1   # unknown metric
+    assert L.tdr_hyperbolic_from_gram_f32(p, 4, 2, 8, p, p, null) == -1              # ld < nd
+    assert L.tdr_cosne_pairs_f64(p, 5, 100, 0, 100, 2.0, p, p, 1 << 30, null) == -2  # n_components > 4
+    assert L.tdr_cosne_pairs_f64(p, 2, 100, 50, 100, 2.0, p, p, 1 << 30, null) == -1  # chunk outside the point set
+    assert L.tdr_cosne_pairs_f64(p, 2, 100, 0, 100, 2.0, p, p, 8, null) == -1        # workspace too small
+    assert L.tdr_radam_poincare_f64(p, p, p, p, null, 10, 1, 0.9, 0.999, 1e-8, 0.1, 1.0, null, 0, null) == -2
+    # host-only sizing helpers
+    assert 1 <= L.tdr_cosne_splits(1_000_000, 1_000_000) <= 64 and L.tdr_cosne_splits(300, 300) == 2
+    assert L.tdr_cosne_workspace_bytes(300, 300, 2) == 2 * 300 * 3 * 8
+
+
 def test_product_fails_loudly_without_gpu():
     from torchdr_amd import UMAP
     from torchdr_amd.distance import pairwise_distances
@@ -142,6 +168,13 @@ def test_product_fails_loudly_without_gpu():
         pairwise_distances(torch.randn(50, 4), k=3)
     with pytest.raises(RuntimeError, match="no HIP device|no CPU"):
         UMAP(n_neighbors=5).fit_transform(torch.randn(100, 4))
+    for metric in ("manhattan", "sqhyperbolic"):
+        with pytest.raises(RuntimeError, match="no CPU"):
+            pairwise_distances(torch.rand(50, 4) * 0.3, k=3, metric=metric)
+    from torchdr_amd import COSNE
+
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU"):
+        COSNE(perplexity=5, max_iter=3).fit_transform(torch.randn(100, 4))
 
 
 def test_eval_argument_errors_match_reference():
