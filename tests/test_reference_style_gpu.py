@@ -55,3 +55,24 @@ def test_array_init():
         assert silhouette_score(Z, y) > 0.2
         outs.append(Z)
     assert ((outs[0] - outs[1]) ** 2).mean() < 1e-5, "The two inits should yield similar results."
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_COSNE(dtype):
+    """torchdr/tests/test_neighbor_embedding.py:77-94, same hyper-parameters: Iris, 2000 Riemannian-Adam steps."""
+    import warnings
+
+    from sklearn.datasets import load_iris
+
+    import torchdr_amd
+
+    iris = load_iris()
+    X, y = iris.data.astype(dtype), iris.target
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = torchdr_amd.COSNE(lr=5e-2, n_components=2, max_iter=2000, random_state=0, gamma=1,
+                                  learning_rate_for_h_loss=0.01, init_scaling=0.01)
+        Z = model.fit_transform(X)
+    assert isinstance(Z, np.ndarray) and Z.shape == (X.shape[0], 2)
+    assert not np.isnan(Z).any(), "COSNE embedding has NaNs."
+    assert silhouette_score(Z, y) > 0.15, "Silhouette score should not be too low."

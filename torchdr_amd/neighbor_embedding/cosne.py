@@ -73,7 +73,9 @@ class COSNE(NeighborEmbedding):
         if isinstance(self.init, str):
             if self.init != "hyperbolic":
                 raise ValueError(f"[TorchDR] ERROR : init {self.init} not supported in {self.__class__.__name__}.")
-            u = self.init_scaling * torch.randn((n, self.n_components), device=self.device_, dtype=torch.float64)
+            # drawn from the HOST generator (16 bytes per point, once): ``random_state`` then reproduces the initial
+            # embedding of the reference's CPU backend, whose trajectories are very sensitive to it
+            u = self.init_scaling * torch.randn((n, self.n_components), dtype=torch.float64).to(self.device_)
             un = u.norm(dim=-1, keepdim=True).clamp_min(1e-15)
             emb = un.clamp(-15, 15).tanh() * u / un
         else:
