@@ -30,18 +30,22 @@ struct CosnePairsParams {
 
 // value and the two gradient coefficients of d_H^2 with respect to the FIRST point:
 //   grad = cdiff * (zi - zo) + czi * zi
+// fp64 divisions / roots are the expensive part: one reciprocal of a_i a_o, r = sqrt(w^2 - 1) formed as
+// sqrt(t (t + 2)) with t = w - 1 (no cancellation) and shared between arccosh w = log1p(t + r) and its derivative 1 / r.
 template <int NC>
-__device__ __forceinline__ double hyp_d2(const double (&zi)[NC], double ai, const double (&zo)[NC], double ao,
+__device__ __forceinline__ double hyp_d2(const double (&zi)[NC], double ai, double inv_ai, const double (&zo)[NC], double ao,
                                          double& cdiff, double& czi) {
     double s = 0.0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) { const double df = zi[c] - zo[c]; s += df * df; }
-    const double den = ai * ao;
-    const double w = 1.0 + 2.0 * (s / den) + 1e-8;
-    const double u = acosh(w);
-    const double du = 2.0 * u / sqrt(w * w - 1.0);
-    cdiff = du * 4.0 / den;
-    czi = du * 4.0 * s / (ai * den);
+    const double inv_den = 1.0 / (ai * ao);
+    const double w = 1.0 + 2.0 * (s * inv_den) + 1e-8;
+    const double t = w - 1.0;
+    const double r = sqrt(t * (t + 2.0));
+    const double u = log1p(t + r);
+    const double du = 2.0 * u / r;
+    cdiff = du * 4.0 * inv_den;
+    czi = cdiff * s * inv_ai;
     return u * u;
 }
 
@@ -54,6 +58,7 @@ __global__ __launch_bounds__(CO_TILE) void cosne_pairs_kernel(const CosnePairsPa
     double zi[NC], ai = 1.0;
 #pragma unroll
     for (int c = 0; c < NC; ++c) { zi[c] = P.Z[(size_t)gi * NC + c]; ai -= zi[c] * zi[c]; }
+    const double inv_ai = 1.0 / ai;
     double qsum = 0.0, g[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) g[c] = 0.0;
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(CO_TILE) void cosne_pairs_kernel(const CosnePairsPa
 #pragma unroll
             for (int c = 0; c < NC; ++c) zo[c] = Zs[jj][c];
             double cd, cz;
-            const double d2 = hyp_d2<NC>(zi, ai, zo, Zs[jj][NC], cd, cz);
+            const double d2 = hyp_d2<NC>(zi, ai, inv_ai, zo, Zs[jj][NC], cd, cz);
             const double inv = 1.0 / (d2 + g2);
             qsum += P.gamma * inv;
             if (t * CO_TILE + jj != gi) {                        // the diagonal only counts in the sum
@@ -117,6 +122,7 @@ __global__ __launch_bounds__(256) void cosne_finish_kernel(const CosneFinishPara
 #pragma unroll
     for (int c = 0; c < NC; ++c) { zi[c] = P.Z[(size_t)gi * NC + c]; y += zi[c] * zi[c]; }
     ai -= y;
+    const double inv_ai = 1.0 / ai;
     const double g2 = P.gamma * P.gamma;
     double att[NC];
 #pragma unroll
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(256) void cosne_finish_kernel(const CosneFinishPara
 #pragma unroll
         for (int c = 0; c < NC; ++c) { zo[c] = P.Z[(size_t)j * NC + c]; ao -= zo[c] * zo[c]; }
         double cd, cz;
-        const double d2 = hyp_d2<NC>(zi, ai, zo, ao, cd, cz);
+        const double d2 = hyp_d2<NC>(zi, ai, inv_ai, zo, ao, cd, cz);
         const double wgt = p / (d2 + g2);                        // d(-P log Q)/d(d2)
 #pragma unroll
         for (int c = 0; c < NC; ++c) att[c] += wgt * (cd * (zi[c] - zo[c]) + cz * zi[c]);
