@@ -1,0 +1,348 @@
+"""Scheduled UMAP loop (csrc/tdr_umap_sched.hip) -- the kernels bench.py times.
+
+* the schedule kernel against a step-by-step restatement of umap.py:243-247 (bit-exact counters, exact lists);
+* the gradient kernel with the reference's own negatives against the golden vectors of the real reference;
+* the gradient kernel with ITS OWN in-kernel negatives against the oracle: the negatives it draws are dumped by
+  tdr_umap_debug_negatives (same device functions) and fed to oracle.ref_torch.umap_gradients.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import gmm
+from tests.test_oracle_golden import load
+
+pytestmark = pytest.mark.gpu
+
+
+def padded_to_csr(V, J):
+    mask = J >= 0
+    rowptr = torch.zeros(V.shape[0] + 1, dtype=torch.int64)
+    rowptr[1:] = mask.sum(1).cumsum(0)
+    return rowptr, J[mask].to(torch.int32), V[mask]
+
+
+class Sched:
+    """Thin ctypes driver of plan / build / grad for the tests."""
+
+    def __init__(self, rowptr, cols, eps_per, n_total, B, S, nc=2, row0=0):
+        from torchdr_amd import _lib
+
+        self.lib, self.L = _lib, _lib.lib()
+        self.rowptr, self.cols, self.eps_per = rowptr, cols, eps_per
+        self.n_rows, self.n_total, self.B, self.S, self.nc, self.row0 = rowptr.numel() - 1, n_total, B, S, nc, row0
+        nb = (self.n_rows + 63) // 64
+        self.nb = nb
+        scratch = torch.empty(nb, dtype=torch.int64, device="cuda")
+        self.blk_base = torch.empty(nb + 1, dtype=torch.int64, device="cuda")
+        _lib.check(self.L.tdr_umap_sched_plan_f32(_lib.ptr(rowptr), _lib.ptr(eps_per), self.n_rows, B, _lib.ptr(scratch),
+                                                  _lib.ptr(self.blk_base), _lib.stream_ptr()), "plan")
+        cap = int(self.blk_base[-1].item())
+        self.list = torch.full((max(cap, 1),), -7, dtype=torch.int32, device="cuda")
+        self.off = torch.zeros(int(self.L.tdr_umap_sched_off_entries(self.n_rows, B, S)), dtype=torch.int32, device="cuda")
+        self.act = torch.zeros(B * self.n_rows, dtype=torch.int16, device="cuda")
+        self.err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self.acc = torch.empty((self.n_rows, 2 * nc), device="cuda")
+
+    def build(self, nxt, t0, n):
+        _l = self.lib
+        _l.check(self.L.tdr_umap_sched_build_f32(_l.ptr(self.rowptr), _l.ptr(self.cols), _l.ptr(self.eps_per), _l.ptr(nxt),
+                                                 self.n_rows, self.n_total, t0, n, self.S, _l.ptr(self.blk_base),
+                                                 _l.ptr(self.list), _l.ptr(self.off), _l.ptr(self.act), _l.ptr(self.err),
+                                                 _l.stream_ptr()), "build")
+        assert int(self.err.item()) == 0
+
+    def grad(self, Z, t_local, n_iter, a, b, n_neg, neg=None, seed=0, geom=0, neg_rate=5):
+        _l = self.lib
+        g = torch.empty((self.n_rows, self.nc), device="cuda")
+        _l.check(self.L.tdr_umap_sched_grad_f32(_l.ptr(Z), self.nc, self.n_total, self.row0, self.n_rows,
+                                                _l.ptr(self.blk_base), _l.ptr(self.list), _l.ptr(self.off), _l.ptr(self.act),
+                                                t_local, self.S, a, b, n_iter, neg_rate, n_neg, _l.ptr(neg), seed, 1.0, 1.0,
+                                                1e-3, _l.ptr(g), _l.ptr(self.acc), geom, _l.stream_ptr()), "sched_grad")
+        return g
+
+
+def random_graph(n, seed, hub=700):
+    gen = torch.Generator().manual_seed(seed)
+    deg = torch.randint(0, 90, (n,), generator=gen)
+    deg[5] = hub          # a hub row: many 16-edge chunks in one row group
+    deg[64:70] = 0        # empty rows at a block boundary
+    deg[n - 1] = 33
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = deg.cumsum(0)
+    nnz = int(rowptr[-1])
+    cols = torch.randint(0, n, (nnz,), generator=gen, dtype=torch.int32)
+    vals = torch.rand(nnz, generator=gen) ** 3     # many small weights -> long periods, some below the cut (inf)
+    vals[torch.rand(nnz, generator=gen) < 0.05] = 1.0
+    return rowptr, cols, vals
+
+
+def prepare(vals, max_iter):
+    from torchdr_amd import _lib
+
+    nnz = vals.numel()
+    eps_per = torch.empty(nnz, device="cuda")
+    nxt = torch.empty(nnz, device="cuda")
+    scratch = torch.zeros(2, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().tdr_umap_prepare_f32(_lib.ptr(vals), nnz, max_iter, _lib.ptr(eps_per), _lib.ptr(nxt), _lib.ptr(scratch),
+                                               _lib.stream_ptr()), "prepare")
+    return eps_per, nxt
+
+
+def layout(rowptr, cols, eps_per):
+    from torchdr_amd import _lib
+
+    cols_p, eps_p = torch.empty_like(cols), torch.empty_like(eps_per)
+    _lib.check(_lib.lib().tdr_umap_sched_layout_f32(_lib.ptr(rowptr), _lib.ptr(cols), _lib.ptr(eps_per), rowptr.numel() - 1,
+                                                    _lib.ptr(cols_p), _lib.ptr(eps_p), _lib.stream_ptr()), "layout")
+    return cols_p, eps_p
+
+
+def test_loop_layout_sorts_every_row_by_firing_period():
+    """tdr_umap_sched_layout_f32: each row's (column, epochs_per_sample) pairs, stably sorted by epochs_per_sample."""
+    n = 3000
+    rowptr, cols, vals = random_graph(n, seed=21, hub=2500)   # the hub row exceeds the sorted range: left as it is
+    eps_per, _ = prepare(vals.cuda(), 200)
+    cols_p, eps_p = layout(rowptr.cuda(), cols.cuda(), eps_per)
+    ep, cp, epp = eps_per.cpu(), cols_p.cpu(), eps_p.cpu()
+    for r in list(range(0, 80)) + [n - 1]:
+        e0, e1 = int(rowptr[r]), int(rowptr[r + 1])
+        if e1 - e0 > 2048:
+            assert torch.equal(cp[e0:e1], cols[e0:e1]) and torch.equal(epp[e0:e1], ep[e0:e1])
+            continue
+        order = torch.sort(ep[e0:e1], stable=True).indices
+        assert torch.equal(epp[e0:e1], ep[e0:e1][order])
+        assert torch.equal(cp[e0:e1], cols[e0:e1][order])
+
+
+@pytest.mark.parametrize("S", [1, 2, 4, 8])
+@pytest.mark.parametrize("B,t0", [(32, 0), (7, 37)])
+def test_schedule_is_the_step_by_step_recurrence(S, B, t0):
+    """umap.py:243-247 iterated B times on the CPU (fp32 compare and add, one firing per iteration at most) gives the
+    counters after the window and, per iteration, the set of firing edges: the kernel's `next`, `act` table and the
+    content of every (iteration, slice, row) list segment must equal them exactly (the order inside a segment only
+    permutes the force sum; it must be the same on every run)."""
+    n = 3000
+    rowptr, cols, vals = random_graph(n, seed=3 + S)
+    eps_per, nxt = prepare(vals.cuda(), 200)
+    ep_c, nx_c = eps_per.cpu(), nxt.cpu().clone()
+    # bring the counters to iteration t0 with the reference recurrence
+    for t in range(t0):
+        a = nx_c <= np.float32(t + 1)
+        nx_c[a] += ep_c[a]
+    nx0 = nx_c.clone()
+    nxt = nx_c.clone().cuda()
+    sc = Sched(rowptr.cuda(), cols.cuda(), eps_per, n, B, S)
+    sc.build(nxt, t0, B)
+    fires = []
+    for t in range(t0, t0 + B):
+        a = nx_c <= np.float32(t + 1)
+        nx_c[a] += ep_c[a]
+        fires.append(a)
+    assert torch.equal(nxt.cpu(), nx_c)
+    row_of = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+    step = (n - 1 + S - 1) // S
+    sl_of = torch.clamp(cols.long() // step, max=S - 1)
+    act = sc.act.cpu().view(B, n).long()
+    off = (sc.off.cpu().long() & 0xFFFFFFFF).view(B * S, sc.nb * 65)
+    lst, base = sc.list.cpu(), sc.blk_base.cpu()
+    for t in range(B):
+        assert torch.equal(act[t], torch.bincount(row_of[fires[t]], minlength=n))
+        for s in range(S):
+            sel = fires[t] & (sl_of == s)
+            cnt = torch.bincount(row_of[sel], minlength=sc.nb * 64).view(sc.nb, 64)
+            seg = off[t * S + s].view(sc.nb, 65)
+            assert torch.equal(seg[:, 1:] - seg[:, :-1], cnt)
+            # segment by segment (sorted: content, not order)
+            want = cols[sel].long()
+            rows_w = row_of[sel]
+            got = torch.cat([lst[int(base[rb]) + int(seg[rb, 0]): int(base[rb]) + int(seg[rb, 64])] for rb in range(sc.nb)]).long()
+            rows_g = torch.repeat_interleave(torch.arange(sc.nb * 64), cnt.view(-1))
+            assert torch.equal(torch.sort(rows_w * n + want).values, torch.sort(rows_g * n + got).values)
+    # same lists on every run
+    lst_first = sc.list.clone()
+    nxt2 = nx0.clone().cuda()
+    sc.build(nxt2, t0, B)
+    assert torch.equal(sc.list, lst_first) and torch.equal(nxt2, nxt)
+    # segments tile each block's region without gaps, in (iteration, slice) order
+    flat = off.view(B * S, sc.nb, 65)
+    assert bool((flat[0, :, 0] == 0).all())
+    assert torch.equal(flat[1:, :, 0], flat[:-1, :, 64])
+    assert bool((flat[-1, :, 64] <= base[1:] - base[:-1]).all())
+
+
+@pytest.mark.parametrize("S", [1, 2, 4])
+def test_scheduled_gradient_three_steps_vs_reference(S):
+    """The reference's own three UMAP steps (tests/golden/umap_step.npz: embedding, counters and the negatives it drew):
+    scheduled kernels with injected negatives reproduce its gradient (1e-5) and its counters (bit-exact)."""
+    g = load("umap_step")
+    a, b, T = float(g["a"]), float(g["b"]), int(g["max_iter"])
+    rowptr, cols, vals = (t.cuda() for t in padded_to_csr(g["Psym"], g["Isym"]))
+    n = g["X"].shape[0]
+    eps_per, _ = prepare(vals, T)
+    mask = g["Isym"] >= 0
+    sc = Sched(rowptr, cols, eps_per, n, 32, S)
+    for t in range(3):
+        Z = g[f"Z_{t}"].cuda().contiguous()
+        nxt = g[f"next_{t}"][mask].cuda().contiguous()
+        neg = g[f"neg_{t}"].cuda().contiguous()
+        sc.build(nxt, t, 1)
+        grad = sc.grad(Z, 0, t, a, b, neg.shape[1], neg=neg)
+        ref = g[f"grad_{t}"]
+        assert torch.allclose(grad.cpu(), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+        assert torch.equal(nxt.cpu(), g[f"nextafter_{t}"][mask])
+
+
+def csr_rows_to_padded(rowptr, cols, per_edge, rows, fill):
+    """Padded (len(rows), max_deg) views of the CSR rows `rows` (CPU tensors)."""
+    deg = (rowptr[rows + 1] - rowptr[rows])
+    K = int(deg.max())
+    NN = torch.zeros((rows.numel(), K), dtype=torch.int64)
+    out = [torch.full((rows.numel(), K), f, dtype=p.dtype) for p, f in zip(per_edge, fill)]
+    for i, r in enumerate(rows.tolist()):
+        e0, e1 = int(rowptr[r]), int(rowptr[r + 1])
+        NN[i, : e1 - e0] = cols[e0:e1].long()
+        for o, p in zip(out, per_edge):
+            o[i, : e1 - e0] = p[e0:e1]
+    return NN, out
+
+
+def oracle_check(sc, Z, nxt_before, t_local, n_iter, a, b, n_neg, seed, rows, geom=0):
+    """Production gradient (in-kernel negatives) of the rows `rows` vs the oracle evaluated on the negatives the kernel
+    draws (umap.py:236-292).  Returns the max error relative to max |g|."""
+    import oracle.ref_torch as R
+    from torchdr_amd import _lib
+
+    grad = sc.grad(Z, t_local, n_iter, a, b, n_neg, neg=None, seed=seed, geom=geom).cpu()
+    n = sc.n_rows
+    act = (sc.act.view(sc.B, n)[t_local].to(torch.int32) & 0xFFFF)
+    nuse = torch.clamp(act * 5, max=n_neg).to(torch.int32).contiguous()
+    width = max(int(nuse.max()), 1)
+    neg = torch.empty((n, width), dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib().tdr_umap_debug_negatives(seed, n_iter, sc.n_total, sc.row0, n, _lib.ptr(nuse), sc.S, width, _lib.ptr(neg),
+                                                   _lib.stream_ptr()), "debug_negatives")
+    neg = neg.cpu()[rows]
+    assert torch.equal((neg >= 0).sum(1), nuse.cpu().long()[rows])
+    neg = torch.where(neg >= 0, neg, torch.zeros_like(neg))  # unused slots: masked by the oracle's count
+    if width < n_neg:
+        neg = torch.cat([neg, torch.zeros((rows.numel(), n_neg - width), dtype=torch.int64)], 1)
+    rowptr, cols = sc.rowptr.cpu(), sc.cols.cpu()
+    NN, (ep_p, nx_p) = csr_rows_to_padded(rowptr, cols, [sc.eps_per.cpu(), nxt_before.cpu()], rows, [float("inf"), float("inf")])
+    ga, gr, act_o = R.umap_gradients(Z.cpu(), NN, ep_p, nx_p, neg, n_iter, a, b, rows=rows + sc.row0)
+    assert torch.equal(act_o.sum(1), act.cpu().long()[rows])
+    ref = ga + gr
+    err = float((grad[rows] - ref).abs().max() / ref.abs().max())
+    return err
+
+
+@pytest.mark.parametrize("S", [1, 2, 4, 8])
+@pytest.mark.parametrize("nc", [2, 3])
+def test_in_kernel_negatives_vs_oracle_fixture_graph(S, nc):
+    """The production path (counter-hash negatives drawn inside the kernel, every slice count) on the reference's own
+    affinity graph of the umap_step fixture."""
+    g = load("umap_step")
+    a, b, T = float(g["a"]), float(g["b"]), int(g["max_iter"])
+    rowptr, cols, vals = (t.cuda() for t in padded_to_csr(g["Psym"], g["Isym"]))
+    n = g["X"].shape[0]
+    eps_per, nxt = prepare(vals, T)
+    sc = Sched(rowptr, cols, eps_per, n, 32, S, nc=nc)
+    gen = torch.Generator().manual_seed(11)
+    Z = (torch.randn(n, nc, generator=gen) * 3).cuda().contiguous()
+    rows = torch.arange(n)
+    for t0 in (0, 32):
+        before = nxt.clone()
+        sc.build(nxt, t0, 32)
+        for tl in (0, 13, 31) if t0 == 0 else (5,):
+            # counters as they stood at iteration t0 + tl: replay the recurrence on the host
+            nb = before.cpu().clone()
+            ep = eps_per.cpu()
+            for t in range(t0, t0 + tl):
+                act = nb <= np.float32(t + 1)
+                nb[act] += ep[act]
+            for geom in (0, 1, 2):
+                err = oracle_check(sc, Z, nb, tl, t0 + tl, a, b, 50, 1234567 + S, rows, geom=geom)
+                assert err < 1e-5, (S, nc, t0, tl, geom, err)
+
+
+def test_in_kernel_negatives_vs_oracle_large_and_wide():
+    """N = 500k (two L2 slices by the automatic choice) with n_neighbors = 60: n_negatives = 300 > 255 (the per-step
+    kernel's 8-bit row header cannot hold it; the scheduled path has no such field).  Oracle on 4096 sampled rows."""
+    from torchdr_amd import _lib
+    from torchdr_amd.affinity import UMAPAffinity
+
+    n = 500_000
+    X = gmm(n, 32, 2.0, seed=7).cuda()
+    csr = UMAPAffinity(n_neighbors=60, max_iter=100)(X, return_csr=True)
+    del X
+    eps_per, nxt = prepare(csr.vals, 500)
+    S = int(_lib.lib().tdr_umap_sched_slices(n, 2))
+    assert S == 2
+    sc = Sched(csr.rowptr, csr.cols, eps_per, n, 32, S)
+    for t0 in (0, 32, 64):
+        before = nxt.clone()
+        sc.build(nxt, t0, 32)
+    gen = torch.Generator().manual_seed(1)
+    Z = (torch.randn(n, 2, generator=gen) * 4).cuda().contiguous()
+    rows = torch.randperm(n, generator=gen)[:4096].sort().values
+    err = oracle_check(sc, Z, before, 0, 64, 1.577, 0.895, 300, 99, rows)
+    assert err < 1e-5, err
+    # the window's other iterations agree with the per-step kernel run on the same counters with the same negatives
+    # (injected into both): 17 steps of the recurrence, then compare gradients and counters
+    L = _lib.lib()
+    nx_step = before.clone()
+    ws = torch.empty(8, dtype=torch.int32, device="cuda")
+    neg = torch.randint(0, n, (n, 300), generator=torch.Generator(device="cuda").manual_seed(2), device="cuda")
+    neg = neg + (neg >= torch.arange(n, device="cuda")[:, None]).long()
+    neg.clamp_(max=n - 1)
+    for t in range(64, 64 + 18):
+        gs = torch.empty((n, 2), device="cuda")
+        _lib.check(L.tdr_umap_grad_f32(_lib.ptr(Z), 2, n, 0, n, _lib.ptr(csr.rowptr), _lib.ptr(csr.cols), _lib.ptr(eps_per),
+                                       _lib.ptr(nx_step), 1.577, 0.895, t, 5, 300, _lib.ptr(neg), 0, 1.0, 1.0, 1e-3, _lib.ptr(gs), 1,
+                                       _lib.ptr(ws), 0, _lib.stream_ptr()), "umap_grad")
+        if t in (64, 70, 81):
+            gq = sc.grad(Z, t - 64, t, 1.577, 0.895, 300, neg=neg)
+            assert torch.allclose(gq, gs, rtol=1e-5, atol=1e-5 * float(gs.abs().max())), t
+    del neg
+
+
+def test_umap_estimator_scheduled_gradients_equal_per_step_kernel():
+    """Whole estimator on the scheduled loop; at every one of 70 steps (two window boundaries) the per-step kernel
+    (tdr_umap_grad_f32, its own copy of the epoch counters) is evaluated on the same embedding with the same injected
+    negatives: gradients agree to 1e-5 and, at the window ends, so do the epoch counters (bit for bit)."""
+    import torchdr_amd
+    from torchdr_amd import _lib
+
+    n = 4000
+    X = gmm(n, 16, 3.0, seed=4).cuda()
+    gen = torch.Generator().manual_seed(0)
+    seen = {"max_err": 0.0, "steps": 0}
+
+    class Checked(torchdr_amd.UMAP):
+        def on_training_step_start(self):
+            super().on_training_step_start()
+            r = torch.randint(0, n - 1, (n, 50), generator=gen)
+            self.neg_indices_ = (r + (r >= torch.arange(n)[:, None]).long()).cuda()
+
+        def _compute_gradients(self):
+            t = int(self.n_iter_)
+            if t == 0:
+                self._nx_step = self.epoch_of_next_sample.clone()
+            elif t % 32 == 0:   # a window has just ended: the scheduled counters stand at iteration t
+                assert torch.equal(self._nx_step, self.epoch_of_next_sample)
+            grad, rows_only = super()._compute_gradients()
+            gs = torch.empty_like(grad)
+            ws = torch.empty(8, dtype=torch.int32, device="cuda")
+            csr = self._csr
+            _lib.check(_lib.lib().tdr_umap_grad_f32(
+                _lib.ptr(self.embedding_), 2, n, 0, n, _lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols),
+                _lib.ptr(self.epochs_per_sample), _lib.ptr(self._nx_step), float(self._a), float(self._b), t, 5, 50,
+                _lib.ptr(self.neg_indices_), 0, 1.0, 1.0, 1e-3, _lib.ptr(gs), 1, _lib.ptr(ws), 0, _lib.stream_ptr()), "umap_grad")
+            err = float((grad - gs).abs().max() / gs.abs().max())
+            seen["max_err"] = max(seen["max_err"], err)
+            seen["steps"] += 1
+            return grad, rows_only
+
+    Z = Checked(n_neighbors=10, max_iter=70, random_state=0).fit_transform(X)
+    assert seen["steps"] == 70 and seen["max_err"] < 1e-5, seen
+    assert bool(torch.isfinite(Z).all())

@@ -15,8 +15,7 @@
 // counter-based hash generator keyed by (seed, iteration, row, column), only for the 5*active columns the
 // reference actually uses (it samples 150 and masks ~110 of them); an injected index table reproduces
 // the reference's per-step arithmetic exactly for the parity tests.
-#include "tdr_common.h"
-#include <stdlib.h>
+#include "tdr_embed_common.h"
 
 namespace tdr {
 
@@ -42,54 +41,6 @@ __global__ __launch_bounds__(256) void umap_prepare_kernel(const float* __restri
     next[i] = e;
 }
 
-template <int NC>
-struct Vec {
-    float v[NC];
-};
-
-template <int NC>
-__device__ __forceinline__ Vec<NC> load_z(const float* __restrict__ Z, int64_t i) {
-    Vec<NC> r;
-    if (NC == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(Z + (size_t)i * 2);
-        r.v[0] = t.x; r.v[1] = t.y;
-    } else {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) r.v[c] = Z[(size_t)i * NC + c];
-    }
-    return r;
-}
-
-// Counter-based hash generator for the negatives: three chained rounds of the "triple32" integer mixer
-// (xorshift-multiply, bias-tested avalanche) over (seed, row) -> (+iteration) -> (+column).  The first two
-// rounds are per row / per iteration and hoisted out of the column loop, so one negative costs ~10 VALU ops
-// (Philox4x32-10 costs ~90 and made the kernel instruction-bound).
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-    x ^= x >> 17; x *= 0xed5ad4bbu;
-    x ^= x >> 11; x *= 0xac4c1b51u;
-    x ^= x >> 15; x *= 0x31848babu;
-    x ^= x >> 14;
-    return x;
-}
-__device__ __forceinline__ uint32_t neg_row_key(uint64_t seed, uint32_t iter, int64_t grow) {
-    uint32_t h = mix32((uint32_t)grow ^ (uint32_t)seed);
-    h = mix32(h + (uint32_t)((uint64_t)grow >> 32) * 0x9E3779B9u + (uint32_t)(seed >> 32));
-    return mix32(h ^ (iter * 0x85EBCA6Bu + 0xC2B2AE35u));
-}
-__device__ __forceinline__ int64_t sample_negative(uint32_t row_key, int64_t grow, int col, int64_t n_total) {
-    // neighbor_embedding/base.py:628-636 : r ~ U{0..N-2}, then +1 where r >= own index.
-    // 32 random bits -> [0, N-1) by multiply-shift range reduction (bias < N / 2^32).
-    const uint32_t x = mix32(row_key + (uint32_t)col * 0x9E3779B9u);
-    int64_t r = (int64_t)(((uint64_t)x * (uint64_t)(n_total - 1)) >> 32);
-    if (r >= grow) r += 1;
-    return r;
-}
-
-// d^b through the hardware log2 / exp2 (relative error ~ |b log2 d| * 2^-23, i.e. <= ~3e-6 for the
-// distances an embedding produces) and reciprocals through v_rcp_f32 (1 ulp): the force coefficients stay
-// well inside the 1e-5 parity budget while the kernel drops from ~300 to ~80 VALU ops per edge.
-__device__ __forceinline__ float fast_pow(float d, float b) { return __builtin_amdgcn_exp2f(b * __builtin_amdgcn_logf(d)); }
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 struct UmapStepParams {
     const float* Z;          // (N, NC)
@@ -119,39 +70,12 @@ struct UmapStepParams {
     int slice, n_slices;     // this pass's slice index; dense passes need n_slices in {2, 4}
 };
 
-template <int NC>
-__device__ __forceinline__ float sqdist(const Vec<NC>& a, const Vec<NC>& b, float (&df)[NC]) {
-    float d = 0.f;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) { df[c] = a.v[c] - b.v[c]; d = __fadd_rn(d, __fmul_rn(df[c], df[c])); }
-    return d;
-}
 
 // Both loops run U group-widths per pass with every load issued before the first use: the dependent chain
 // per row is rowptr -> {next, cols} -> z_j gather -> math (3 memory levels) and U random gathers are in
 // flight per lane -- the kernel is bound by the latency of the random 8-byte reads of Z (8 MB at N = 1M,
 // larger than one XCD's L2), so memory-level parallelism is what buys throughput.  `cols` is read for every
 // edge (4 B) so that the gather does not wait for the activity test; eps_per only where the edge fires.
-__device__ __forceinline__ int binomial_half(uint32_t key, int n) {
-    int m = 0;
-    for (int t = 0; t * 32 < n; ++t) {
-        uint32_t w = mix32(key + 0x7F4A7C15u * (uint32_t)(t + 1));
-        const int rem = n - t * 32;
-        if (rem < 32) w &= (1u << rem) - 1u;
-        m += __popc(w);
-    }
-    return m;
-}
-__device__ __forceinline__ int slice_count(uint32_t rkey, int n_use, int slice, int n_slices) {
-    const int lo = binomial_half(rkey ^ 0x9E3779B9u, n_use);          // slices {0..S/2-1} | {S/2..S-1}
-    int mine = (slice < n_slices / 2) ? lo : n_use - lo;
-    if (n_slices == 4) {
-        const int q = binomial_half(rkey ^ (0x85EBCA6Bu + 0x27D4EB2Fu * (uint32_t)(slice >> 1)), mine);
-        mine = (slice & 1) ? mine - q : q;
-    }
-    return mine;
-}
-
 template <int NC, int G, int U, bool POS_ONLY = false>
 __global__ __launch_bounds__(256) void umap_grad_kernel(const UmapStepParams P) {
     const int gl = threadIdx.x % G;
@@ -418,17 +342,11 @@ __global__ __launch_bounds__(256) void umap_debug_negatives_kernel(uint64_t seed
     const uint32_t gi = (uint32_t)(row0 + r);
     const uint32_t rkey = neg_row_key(seed, iter, (int64_t)gi);
     const uint32_t nred = (uint32_t)(n_total - 1);
-    const uint32_t step = (nred + (uint32_t)n_slices - 1u) / (uint32_t)n_slices;
     int pos = 0;
     for (int sl = 0; sl < n_slices; ++sl) {
         const int cnt = slice_count(rkey, nuse[r], sl, n_slices);
-        const uint32_t r_lo = (uint32_t)sl * step;
-        const uint32_t r_len = (r_lo < nred) ? ((nred - r_lo < step) ? nred - r_lo : step) : 0u;
-        for (int col = 0; col < cnt && pos < width && r_len; ++col) {
-            const uint32_t x = mix32(rkey + 0x632BE5ABu * (uint32_t)(sl + 1) + (uint32_t)col * 0x9E3779B9u);
-            const uint32_t rr = r_lo + __umulhi(x, r_len);
-            out[(size_t)r * width + pos++] = (int64_t)(rr + (rr >= gi ? 1u : 0u));
-        }
+        for (int col = 0; col < cnt && pos < width; ++col)
+            out[(size_t)r * width + pos++] = (int64_t)slice_negative(rkey, gi, col, sl, n_slices, nred);
     }
     for (; pos < width; ++pos) out[(size_t)r * width + pos] = -1;
 }
@@ -763,16 +681,12 @@ int tdr_umap_prepare_f32(const float* vals, int64_t nnz, int max_iter, float* ep
     return TDR_OK;
 }
 
-// Number of Z slices for the negative phase: 1 (single pass) while the embedding fits an XCD's L2, else
-// ceil(bytes / TDR_UMAP_SLICE_MB) (default 4 MiB slices), at most 4 -- every pass re-issues the row's whole negative
-// loop, so more passes cost more than the L2 hits return; TDR_UMAP_SLICE_MB=0 disables slicing.
+// Number of Z slices for the negative phase: 1 (single pass) while the embedding fits an XCD's L2, else 2 or 4 slices of
+// <= 4 MiB -- every pass re-issues the row's whole negative loop, so more passes cost more than the L2 hits return.
 static int umap_neg_slices(int64_t n_total, int nc) {
-    static int mb = -1;
-    if (mb < 0) { const char* e = getenv("TDR_UMAP_SLICE_MB"); mb = e ? atoi(e) : 4; }
-    if (mb <= 0) return 1;
     const int64_t bytes = n_total * nc * (int64_t)sizeof(float);
     if (bytes <= (int64_t)3 << 20) return 1;
-    const int64_t s = (bytes + ((int64_t)mb << 20) - 1) / ((int64_t)mb << 20);
+    const int64_t s = (bytes + ((int64_t)4 << 20) - 1) / ((int64_t)4 << 20);
     return s > 2 ? 4 : 2;  // 2 or 4: the dense passes split a row's negatives by exact binomial halving
 }
 
@@ -803,7 +717,8 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
     int slices = neg_slices > 0 ? neg_slices : umap_neg_slices(n_total, nc);
     if (slices > n_total) slices = (int)n_total;
     const int64_t need = 2 * n_rows * (int64_t)sizeof(int32_t) + n_rows * nc * (int64_t)sizeof(float);
-    if (slices > 1 && ws && ws_bytes >= need && n_negatives > 0 && neg_rate > 0) {
+    // the row header packs n_use and the slice counts into 8-bit fields: larger counts take the single-pass kernel
+    if (slices > 1 && ws && ws_bytes >= need && n_negatives > 0 && n_negatives <= 255 && neg_rate > 0) {
         P.nuse = (int32_t*)ws;
         P.n_slices = slices;
         P.gr_acc = (float*)((char*)ws + 2 * n_rows * sizeof(int32_t));
@@ -815,9 +730,7 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
             P.j_lo = sidx * step;
             P.j_hi = (sidx + 1) * step < n_total ? (sidx + 1) * step : n_total;
             P.first = sidx == 0; P.last = sidx == slices - 1; P.slice = sidx; P.n_slices = slices;
-            static int dense_ok = -1;  // TDR_UMAP_DENSE=0: masking passes even when the dense ones apply
-            if (dense_ok < 0) { const char* g = getenv("TDR_UMAP_DENSE"); dense_ok = g ? atoi(g) : 1; }
-            if (dense_ok && !neg_inj && (slices == 2 || slices == 4) && n_total < 0x7fffffffLL) {
+            if (!neg_inj && (slices == 2 || slices == 4) && n_total < 0x7fffffffLL) {
                 // 8 lanes per row x 2 columns per lane and round (16 x 2, 8 x 3, 8 x 4, 4 x 6, 32 x 1 measured within 2 %
                 // of each other, 32 x 1 10 % slower: the pass is bound by L2 line requests, not by lane utilisation)
                 rc = (nc == 2) ? launch_group<8>(umap_neg_dense_kernel<2, 8, 2>, P, n_rows, st)
@@ -830,16 +743,8 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
         }
         return TDR_OK;
     }
-    // group width / unroll depth: TDR_UMAP_GEOM=0 (32x2), 1 (16x4, default), 2 (8x8) -- tuning knob
-    static int geom = -1;
-    if (geom < 0) { const char* g = getenv("TDR_UMAP_GEOM"); geom = g ? atoi(g) : 1; }
-    if (nc == 2) {
-        if (geom == 0) return launch_group<32>(umap_grad_kernel<2, 32, 2>, P, n_rows, st);
-        if (geom == 2) return launch_group<8>(umap_grad_kernel<2, 8, 8>, P, n_rows, st);
-        return launch_group<16>(umap_grad_kernel<2, 16, 4>, P, n_rows, st);
-    }
-    if (geom == 0) return launch_group<32>(umap_grad_kernel<3, 32, 2>, P, n_rows, st);
-    if (geom == 2) return launch_group<8>(umap_grad_kernel<3, 8, 8>, P, n_rows, st);
+    // 16 lanes per row x 4-deep unrolled gathers (32 x 2 and 8 x 8 measured within a few % of it)
+    if (nc == 2) return launch_group<16>(umap_grad_kernel<2, 16, 4>, P, n_rows, st);
     return launch_group<16>(umap_grad_kernel<3, 16, 4>, P, n_rows, st);
 }
 
@@ -944,7 +849,7 @@ int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_i
  * [row0, row0 + n_rows) with nuse[r] negatives each -> out (n_rows, width) int64, -1 padded. */
 int tdr_umap_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nuse,
                              int n_slices, int width, int64_t* out, void* stream) {
-    if (!nuse || !out || n_rows <= 0 || n_total < 2 || width <= 0 || (n_slices != 2 && n_slices != 4)) return TDR_ERR_BAD_ARG;
+    if (!nuse || !out || n_rows <= 0 || n_total < 2 || width <= 0 || (n_slices != 1 && n_slices != 2 && n_slices != 4 && n_slices != 8)) return TDR_ERR_BAD_ARG;
     hipLaunchKernelGGL(umap_debug_negatives_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        seed, (uint32_t)n_iter, n_total, row0, n_rows, nuse, n_slices, width, out);
     TDR_CHECK_LAUNCH();

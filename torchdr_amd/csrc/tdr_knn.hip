@@ -773,17 +773,13 @@ static inline int pick_kq(int d) {
 using namespace tdr;
 
 // Workgroup shape: 4 wavefronts x QB query blocks of 32 (QB = 1: 128 queries, 2 workgroups per CU;
-// QB = 2: 256 queries, 1 workgroup per CU, two MFMA chains per wavefront).  TDR_KNN_QB overrides.
+// QB = 2: 256 queries, 1 workgroup per CU, two MFMA chains per wavefront).
 static size_t knn_lds_bytes(int kq, int k, int qb) {
     return (size_t)2 * (kq * 256) * sizeof(float) + (size_t)4 * 64 * sizeof(float) +
            (size_t)4 * qb * k * 32 * sizeof(uint64_t);
 }
 
-static int knn_qb_pref() {
-    static int qb = 0;
-    if (qb == 0) { const char* e = getenv("TDR_KNN_QB"); qb = e ? atoi(e) : 1; if (qb != 2) qb = 1; }
-    return qb;
-}
+static int knn_qb_pref() { return 1; }  // QB = 2 measured slower (115 vs 126 TFLOP/s); kept instantiated for ablations
 
 static int knn_qb(int kq, int k) {
     int qb = knn_qb_pref();

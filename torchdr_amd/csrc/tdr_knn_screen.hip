@@ -814,14 +814,9 @@ static size_t screen_lds_bytes(int ks, int L, int qb, int terms) {
 //   tier 1: three terms, band ~1e-4 ||x|| ||y||, k + ~17..24 spare slots, two workgroups per CU (80 KiB each);
 //           larger k: one workgroup per CU, two list entries per lane (L <= 128).
 //   tier 2: three terms, one workgroup per CU, up to k + 72 spare slots.
-// TDR_SCREEN_QB=2 (tier 1 only) selects 256 queries per workgroup, one workgroup per CU.
 struct ScreenCfg { int qb, L, items, wg_per_cu, terms; };
 
-static int screen_qb_pref() {
-    static int qb = 0;
-    if (qb == 0) { const char* e = getenv("TDR_SCREEN_QB"); qb = e ? atoi(e) : 1; if (qb != 2) qb = 1; }
-    return qb;
-}
+static int screen_qb_pref() { return 1; }  // 256 queries per workgroup measured slower (786 vs 759 ms at 1M)
 
 static int max_list_len(int ks, int qb, int terms, size_t budget, int cap) {
     int L = 0;

@@ -1,0 +1,522 @@
+// K5s -- the UMAP gradient loop on per-iteration active-edge lists ("scheduled epochs").
+//
+// Replaces the same reference lines as the per-step kernels of tdr_embed.hip
+//   neighbor_embedding/umap.py:236-264   attraction over the edges whose epoch counter fires (epoch_of_next_sample)
+//   neighbor_embedding/umap.py:266-292   repulsion over 5 * (#fired edges) sampled negatives
+//   neighbor_embedding/base.py:617-649   negative sampling
+// with a different data flow.  Which edge fires at which iteration does not depend on the embedding:
+// `act = next <= n_iter + 1; next[act] += eps_per[act]` (umap.py:243-247) is a recurrence on the edge alone.  The
+// per-step kernel nevertheless streams (next, cols, eps_per) of ALL nnz edges every iteration (12 B x 49 M at N = 1M)
+// to find the ~8.6 of ~49 edges per row that fire, and writes `next` back whole.  Here a SCHEDULE kernel advances the
+// recurrence 32 iterations at a time (bit-exact: the same fp32 compare and add per iteration) and emits, per iteration
+// and per L2 slice of the embedding, the compacted column lists of the edges that fire; the gradient kernel then reads
+// ~8.6 x 4 B per row and iteration instead of ~49 x 12 B.
+//
+// Layout (one "schedule block" = 64 consecutive rows, one workgroup of the schedule kernel):
+//   blk_base (n_blocks + 1) int64   static start of every block's region in `list` (capacity bound from eps_per)
+//   list     int32                  column ids; inside a block's region the segments (t, slice, row) follow each other
+//                                   in that order, so one gradient pass (fixed t, slice) reads a contiguous run per block
+//   off      (B * S, n_blocks * 65) uint32 segment starts relative to blk_base[block]; entry 64 closes row 63
+//   act      (B, n_rows) uint16     number of edges of the row that fire at iteration t (all slices): the row draws
+//                                   min(5 * act, n_negatives) negatives (umap.py:283-288)
+// Gradient pass = one launch per slice s of the embedding (Z slice <= 4 MiB = one XCD's L2): a row group walks ONE item
+// stream made of its fired edges with column in slice s followed by its negatives drawn inside slice s (exact
+// multinomial split of the row's negative count, tdr_embed_common.h); both kinds share the d^b evaluation and differ
+// in a select.  Partial (attraction, repulsion) sums travel between the slice passes; the last pass clamps each to
+// [-4, 4] (umap.py:262,290) and writes the gradient.
+#include "tdr_embed_common.h"
+
+namespace tdr {
+
+constexpr int SCHED_RB = 64;    // rows per schedule block
+constexpr int SCHED_BMAX = 32;  // iterations per schedule window (one mask bit each)
+
+// upper bound of the firings of one edge in ANY window of B iterations: its counter advances by eps_per per firing and
+// fires at most once per iteration -> floor(B / eps_per) + 1, plus slack for the fp32 roundings of the additions and of
+// this quotient
+__device__ __forceinline__ int edge_capacity(float ep, int B) {
+    if (!(ep < __builtin_inff())) return 0;
+    const float q = (float)B / ep;
+    if (!(q < (float)B)) return B;
+    const int c = (int)q + 3;
+    return c < B ? c : B;
+}
+
+__global__ __launch_bounds__(256) void umap_sched_plan_kernel(const int64_t* __restrict__ rowptr, const float* __restrict__ eps_per,
+                                                              int64_t n_rows, int B, int64_t* __restrict__ cap) {
+    __shared__ unsigned long long part[4];
+    const int64_t rb = blockIdx.x;
+    const int64_t r0 = rb * SCHED_RB;
+    const int64_t r1 = (r0 + SCHED_RB < n_rows) ? r0 + SCHED_RB : n_rows;
+    const int64_t e0 = rowptr[r0], e1 = rowptr[r1];
+    unsigned long long c = 0;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) c += (unsigned long long)edge_capacity(eps_per[e], B);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) cap[rb] = (int64_t)(part[0] + part[1] + part[2] + part[3]);
+}
+
+// out[0..n] = exclusive scan of in[0..n) (out[n] = total); one workgroup, n is the number of schedule blocks (N / 64)
+__global__ __launch_bounds__(256) void scan_i64_kernel(const int64_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+    __shared__ long long tot[256];
+    const int tid = threadIdx.x;
+    const int64_t per = (n + 255) / 256;
+    const int64_t i0 = tid * per, i1 = (i0 + per < n) ? i0 + per : n;
+    long long s = 0;
+    for (int64_t i = i0; i < i1; ++i) s += in[i];
+    tot[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (int i = 0; i < 256; ++i) { const long long t = tot[i]; tot[i] = run; run += t; }
+        out[n] = run;
+    }
+    __syncthreads();
+    long long run = tot[tid];
+    for (int64_t i = i0; i < i1; ++i) { const long long t = in[i]; out[i] = run; run += t; }
+}
+
+struct SchedBuildParams {
+    const int64_t* rowptr;
+    const int32_t* cols;
+    const float* eps_per;
+    float* next;              // epoch_of_next_sample, advanced by B iterations
+    int64_t n_rows;
+    uint32_t slice_step;      // ceil((N - 1) / S): column j belongs to slice min(S - 1, j / slice_step)
+    int t0, B, S;             // window = iterations t0 .. t0 + B - 1 (B <= 32), S slices
+    const int64_t* blk_base;
+    int32_t* list;
+    uint32_t* off;
+    int64_t off_stride;       // n_blocks * 65
+    uint16_t* act;
+    int* err;                 // device flag: set when a block's region would overflow (never with the plan's bound)
+};
+
+// The edge's firings in the window [t0, t0 + B) as a bit mask; nx advances exactly as umap.py:243-247 does step by step.
+// `nx <= t + 1` first holds at t = ceil(nx) - 1 (or at once when the counter lags behind the iteration), so the loop
+// runs once per FIRING, not once per iteration: rarely-firing edges cost one compare.
+__device__ __forceinline__ uint32_t fire_mask(float& nx, float ep, int t0, int B) {
+    uint32_t m = 0;
+    const float tend = (float)(t0 + B);
+    int tcur = t0;
+    while (nx <= tend) {
+        int tf = (int)ceilf(nx) - 1;
+        if (tf < tcur) tf = tcur;
+        if (tf >= t0 + B) break;
+        m |= 1u << (tf - t0);
+        nx = __fadd_rn(nx, ep);
+        tcur = tf + 1;
+    }
+    return m;
+}
+
+// One workgroup = one schedule block (64 rows); a wavefront owns 16 rows and walks them 4 at a time with 16 lanes per
+// row.  Phase 1 counts the firings per (t, slice, row) in LDS, the counts are scanned into segment starts, phase 2
+// recomputes the masks (the 64 rows' edge state is ~25 KB, an L2 hit) and places every firing with a returning LDS
+// atomic on its segment's write pointer.  A row's counters are touched by one wavefront only, in program order, so the
+// placement is a function of the input alone (same lists on every run); the order inside a segment is the order the
+// LDS unit serialises the lanes of one instruction in, which only permutes the terms of the force sum.
+// Rows are laid out by tdr_umap_sched_layout_f32 with their often-firing edges first: the per-lane loops run as many
+// times as the busiest lane of the wavefront fires, so homogeneous chunks matter.
+#define CNT_STRIDE 65  // odd stride: the 16 lanes of a row group hit different (t, slice) -> different banks
+
+__global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildParams P) {
+    extern __shared__ uint32_t cnt[];  // [B * S][65]
+    __shared__ uint32_t wave_tot[4];
+    const int K = P.B * P.S;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, gl = lane & 15, gq = lane >> 4;
+    const int64_t rb = blockIdx.x;
+    const float INF = __builtin_inff();
+    for (int i = tid; i < K * CNT_STRIDE; i += 256) cnt[i] = 0;
+    __syncthreads();
+
+    for (int q = 0; q < 4; ++q) {
+        const int lr = 16 * w + 4 * q + gq;
+        const int64_t r = rb * SCHED_RB + lr;
+        int64_t e0 = 0, e1 = 0;
+        if (r < P.n_rows) { e0 = P.rowptr[r]; e1 = P.rowptr[r + 1]; }
+        const int len = (int)(e1 - e0);
+        int maxlen = len;
+        maxlen = max(maxlen, __shfl_xor(maxlen, 16, 64));
+        maxlen = max(maxlen, __shfl_xor(maxlen, 32, 64));
+        for (int c = 0; c < maxlen; c += 16) {
+            const bool valid = c + gl < len;
+            const int64_t e = e0 + c + gl;
+            float nx = valid ? P.next[e] : INF;
+            const float ep = valid ? P.eps_per[e] : INF;
+            const uint32_t col = valid ? (uint32_t)P.cols[e] : 0u;
+            uint32_t m = fire_mask(nx, ep, P.t0, P.B);
+            uint32_t s = col / P.slice_step;
+            if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
+            while (m) {
+                const int t = __ffs(m) - 1;
+                m &= m - 1;
+                atomicAdd(&cnt[(t * P.S + (int)s) * CNT_STRIDE + lr], 1u);  // a count: order-independent
+            }
+        }
+    }
+    __syncthreads();
+
+    // rows' active counts per iteration
+    for (int i = tid; i < P.B * 64; i += 256) {
+        const int t = i >> 6, lr = i & 63;
+        const int64_t r = rb * SCHED_RB + lr;
+        if (r < P.n_rows) {
+            uint32_t a = 0;
+            for (int s = 0; s < P.S; ++s) a += cnt[(t * P.S + s) * CNT_STRIDE + lr];
+            P.act[(size_t)t * P.n_rows + r] = (uint16_t)(a > 65535u ? 65535u : a);
+        }
+    }
+    // exclusive scan of the counts in (segment k = t * S + slice, row) order; wavefront w owns segments [k0, k1)
+    const int kper = (K + 3) / 4;
+    const int k0 = w * kper;
+    const int k1 = (k0 + kper < K) ? k0 + kper : K;
+    uint32_t sum = 0;
+    for (int k = k0; k < k1; ++k) sum += cnt[k * CNT_STRIDE + lane];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) wave_tot[w] = sum;
+    __syncthreads();
+    uint32_t carry = 0;
+    for (int i = 0; i < w; ++i) carry += wave_tot[i];
+    const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    const int64_t base = P.blk_base[rb];
+    const int64_t capacity64 = P.blk_base[rb + 1] - base;
+    const uint32_t capacity = capacity64 > 0xffffffffLL ? 0xffffffffu : (uint32_t)capacity64;
+    uint32_t* offp = P.off + (size_t)rb * (SCHED_RB + 1);
+    for (int k = k0; k < k1; ++k) {
+        const uint32_t v = cnt[k * CNT_STRIDE + lane];
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += up;
+        }
+        const uint32_t ex = carry + inc - v;
+        cnt[k * CNT_STRIDE + lane] = ex;  // from here on: the write pointer of segment (k, row)
+        offp[(size_t)k * P.off_stride + lane] = ex;
+        carry += __shfl(inc, 63, 64);
+        if (lane == 0) offp[(size_t)k * P.off_stride + SCHED_RB] = carry;
+    }
+    if (total > capacity && tid == 0) atomicMax(P.err, 1);
+    __syncthreads();
+
+    for (int q = 0; q < 4; ++q) {
+        const int lr = 16 * w + 4 * q + gq;
+        const int64_t r = rb * SCHED_RB + lr;
+        int64_t e0 = 0, e1 = 0;
+        if (r < P.n_rows) { e0 = P.rowptr[r]; e1 = P.rowptr[r + 1]; }
+        const int len = (int)(e1 - e0);
+        int maxlen = len;
+        maxlen = max(maxlen, __shfl_xor(maxlen, 16, 64));
+        maxlen = max(maxlen, __shfl_xor(maxlen, 32, 64));
+        for (int c = 0; c < maxlen; c += 16) {
+            const bool valid = c + gl < len;
+            const int64_t e = e0 + c + gl;
+            float nx = valid ? P.next[e] : INF;
+            const float ep = valid ? P.eps_per[e] : INF;
+            const uint32_t col = valid ? (uint32_t)P.cols[e] : 0u;
+            uint32_t m = fire_mask(nx, ep, P.t0, P.B);
+            if (m) P.next[e] = nx;
+            uint32_t s = col / P.slice_step;
+            if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
+            while (m) {
+                const int t = __ffs(m) - 1;
+                m &= m - 1;
+                const uint32_t pos = atomicAdd(&cnt[(t * P.S + (int)s) * CNT_STRIDE + lr], 1u);
+                if (pos < capacity) P.list[base + pos] = (int32_t)col;
+            }
+        }
+    }
+}
+
+// Loop layout of a row's edges: ascending eps_per (= often-firing edges first, never-firing ones last), ties by
+// position.  Rank sort per row, one wavefront per row (rows of more than 2048 edges keep their order).
+__global__ __launch_bounds__(256) void umap_sched_layout_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                                const float* __restrict__ eps_per, int64_t n_rows,
+                                                                int32_t* __restrict__ cols_out, float* __restrict__ eps_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int64_t b = rowptr[row], e = rowptr[row + 1];
+    const int len = (int)(e - b);
+    if (len > 2048) {
+        for (int p = lane; p < len; p += 64) { cols_out[b + p] = cols[b + p]; eps_out[b + p] = eps_per[b + p]; }
+        return;
+    }
+    for (int p0 = 0; p0 < len; p0 += 64) {
+        const int p = p0 + lane;
+        const bool have = p < len;
+        const float mine = have ? eps_per[b + p] : 0.f;
+        int rank = 0;
+        for (int q = 0; q < len; ++q) {
+            const float o = eps_per[b + q];
+            rank += (o < mine || (o == mine && q < p)) ? 1 : 0;
+        }
+        if (have) { cols_out[b + rank] = cols[b + p]; eps_out[b + rank] = mine; }
+    }
+}
+
+struct SchedGradParams {
+    const float* Z;
+    int64_t n_total, row0, n_rows;
+    const int64_t* blk_base;
+    const int32_t* list;
+    const uint32_t* off;
+    int64_t off_stride;
+    const uint16_t* act;
+    int t_local, S, slice;
+    float a, b;
+    int neg_rate, n_negatives;
+    const int64_t* neg_inj;   // optional (n_rows, n_negatives) injected negatives (parity tests), else the counter hash
+    uint64_t seed;
+    uint32_t iter;
+    float exag, rep, eps;
+    float* grad;              // (n_rows, NC)
+    float* acc;               // (n_rows, 2 NC) partial sums between the slice passes (S > 1)
+};
+
+// gather of one embedding row with a cache policy: POL 0 = default, 1 = non-temporal (`nt`: the line is not kept in the
+// CU's L1, whose 32 KiB cannot hold a 4 MiB slice anyway)
+template <int NC, int POL>
+__device__ __forceinline__ Vec<NC> gather_z(const float* __restrict__ Z, uint32_t j) {
+    if (POL == 0) return load_z<NC>(Z, (int64_t)j);
+    Vec<NC> r;
+    if (NC == 2) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 t = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(Z + (size_t)j * 2));
+        r.v[0] = t.x; r.v[1] = t.y;
+    } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) r.v[c] = __builtin_nontemporal_load(Z + (size_t)j * NC + c);
+    }
+    return r;
+}
+
+// One row group (G lanes) walks ONE item stream: the row's negatives drawn inside this slice first (their addresses
+// need no memory access, so their gathers leave at once), then its fired edges with column in this slice (list read,
+// skipped by the whole wavefront for the instruction slots that hold no edge).
+template <int NC, int G, int U, int POL>
+__global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradParams P) {
+    const int gl = threadIdx.x % G;
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (r >= P.n_rows) return;
+    const uint32_t gi = (uint32_t)(P.row0 + r);
+    const Vec<NC> zi = load_z<NC>(P.Z, gi);
+    const int64_t rb = r >> 6;
+    const uint32_t* ob = P.off + (size_t)(P.t_local * P.S + P.slice) * P.off_stride + rb * (SCHED_RB + 1) + (r & 63);
+    const uint32_t o0 = ob[0], o1 = ob[1];
+    const int32_t* lst = P.list + P.blk_base[rb] + o0;
+    const int npos = (int)(o1 - o0);
+    const int act = (int)P.act[(size_t)P.t_local * P.n_rows + r];
+    int n_use = act * P.neg_rate;
+    if (n_use > P.n_negatives) n_use = P.n_negatives;
+    const uint32_t rkey = neg_row_key(P.seed, P.iter, (int64_t)gi);
+    const uint32_t nred = (uint32_t)(P.n_total - 1);
+    const uint32_t step = (nred + (uint32_t)P.S - 1u) / (uint32_t)P.S;
+    const uint32_t r_lo = (uint32_t)P.slice * step;
+    const uint32_t r_len = (r_lo < nred) ? ((nred - r_lo < step) ? nred - r_lo : step) : 0u;
+    // injected negatives: every column is visited and the ones outside this slice are masked
+    int nneg = P.neg_inj ? n_use : slice_count_group<G>(rkey, n_use, P.slice, P.S, gl);
+    if (!P.neg_inj && r_len == 0u) nneg = 0;
+    const uint32_t ckey = rkey + 0x632BE5ABu * (uint32_t)(P.slice + 1);
+    const int total = nneg + npos;
+    const float two_ab = 2.0f * P.a * P.b, m2b = -2.0f * P.b;
+    float ga[NC], gr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { ga[c] = 0.f; gr[c] = 0.f; }
+    for (int base = 0; base < total; base += U * G) {
+        uint32_t jn[U];
+        bool v[U], isp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = base + u * G + gl;
+            v[u] = i < total;
+            isp[u] = i >= nneg;
+            jn[u] = gi;
+            const bool wantp = v[u] && isp[u];
+            if (__ballot(wantp)) {  // wavefront-uniform: slots that hold negatives only never wait for the list
+                if (wantp) jn[u] = (uint32_t)lst[i - nneg];
+            }
+            if (v[u] && !isp[u]) {
+                if (P.neg_inj) {
+                    const uint32_t j = (uint32_t)P.neg_inj[(size_t)r * P.n_negatives + i];
+                    uint32_t sl = j / step;
+                    if (sl > (uint32_t)(P.S - 1)) sl = (uint32_t)(P.S - 1);
+                    v[u] = sl == (uint32_t)P.slice;
+                    if (v[u]) jn[u] = j;
+                } else {
+                    const uint32_t x = mix32(ckey + (uint32_t)i * 0x9E3779B9u);
+                    const uint32_t rr = r_lo + __umulhi(x, r_len);
+                    jn[u] = rr + (rr >= gi ? 1u : 0u);
+                }
+            }
+        }
+        Vec<NC> zj[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) zj[u] = gather_z<NC, POL>(P.Z, jn[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float df[NC];
+            const float d = sqdist<NC>(zi, zj[u], df);
+            const float pb = d > 0.f ? fast_pow(d, P.b) : 0.f;
+            const float den = 1.0f + P.a * pb;
+            // attraction 2ab d^(b-1) / (1 + a d^b) (0 where d <= 0, umap.py:252-256) | repulsion -2b / ((d + eps)(1 + a d^b))
+            const float num = isp[u] ? pb * two_ab : m2b;
+            const float dd = isp[u] ? d : d + P.eps;
+            float coef = num * fast_rcp(dd * den);
+            if (!v[u] || (isp[u] && !(d > 0.f))) coef = 0.f;
+            const float ca = isp[u] ? coef : 0.f, cr = isp[u] ? 0.f : coef;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { ga[c] += ca * df[c]; gr[c] += cr * df[c]; }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { ga[c] = group_sum<G>(ga[c]); gr[c] = group_sum<G>(gr[c]); }
+    if (gl == 0) {
+        float* acc = P.acc + (size_t)r * 2 * NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float A = ga[c], R = gr[c];
+            if (P.slice > 0) { A += acc[c]; R += acc[NC + c]; }
+            if (P.slice == P.S - 1) {
+                P.grad[(size_t)r * NC + c] = P.exag * fminf(fmaxf(A, -4.f), 4.f) + P.rep * fminf(fmaxf(R, -4.f), 4.f);
+            } else {
+                acc[c] = A;
+                acc[NC + c] = R;
+            }
+        }
+    }
+}
+
+template <int NC, int G, int U, int POL>
+static int launch_sched_grad(const SchedGradParams& P, hipStream_t st) {
+    const int rpb = 256 / G;
+    hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, U, POL>), dim3((unsigned)((P.n_rows + rpb - 1) / rpb)), dim3(256), 0, st, P);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TDR_OK : (int)e;
+}
+
+// geom: lane geometry / gather policy knob (0 = default; the others are kept for ablations, tools/umap_sched_perf.py)
+template <int NC>
+static int launch_sched_grad_geom(const SchedGradParams& P, int geom, hipStream_t st) {
+    switch (geom) {
+        case 1: return launch_sched_grad<NC, 8, 2, 0>(P, st);
+        case 2: return launch_sched_grad<NC, 16, 2, 0>(P, st);
+        case 3: return launch_sched_grad<NC, 4, 8, 0>(P, st);
+        case 4: return launch_sched_grad<NC, 4, 4, 0>(P, st);
+        case 5: return launch_sched_grad<NC, 8, 4, 1>(P, st);
+        case 6: return launch_sched_grad<NC, 4, 4, 1>(P, st);
+        default: return launch_sched_grad<NC, 8, 4, 0>(P, st);
+    }
+}
+
+}  // namespace tdr
+
+using namespace tdr;
+
+extern "C" {
+
+/* Number of L2 slices of the embedding the scheduled gradient passes use: 1 while Z fits an XCD's L2 (<= 3 MiB), else
+ * the power of two (<= 8) that brings a slice to <= 4 MiB. */
+int tdr_umap_sched_slices(int64_t n_total, int nc) {
+    const int64_t bytes = n_total * nc * (int64_t)sizeof(float);
+    if (bytes <= (int64_t)3 << 20) return 1;
+    int s = 2;
+    while (s < 8 && bytes > (int64_t)s * ((int64_t)4 << 20)) s *= 2;
+    return s;
+}
+
+/* uint32 entries of the `off` table for a window of block_iters iterations and n_slices slices. */
+int64_t tdr_umap_sched_off_entries(int64_t n_rows, int block_iters, int n_slices) {
+    if (n_rows <= 0 || block_iters <= 0 || n_slices <= 0) return 0;
+    const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
+    return (int64_t)block_iters * n_slices * n_blocks * (SCHED_RB + 1);
+}
+
+/* Static plan: blk_base (n_blocks + 1, n_blocks = ceil(n_rows / 64)) = exclusive scan of the blocks' list capacities for
+ * windows of block_iters (<= 32) iterations; blk_base[n_blocks] = int32 entries `list` must hold.  scratch: n_blocks int64. */
+int tdr_umap_sched_plan_f32(const int64_t* rowptr, const float* eps_per, int64_t n_rows, int block_iters, int64_t* scratch,
+                            int64_t* blk_base, void* stream) {
+    if (!rowptr || !eps_per || !scratch || !blk_base || n_rows <= 0 || block_iters <= 0 || block_iters > SCHED_BMAX)
+        return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
+    hipLaunchKernelGGL(umap_sched_plan_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, rowptr, eps_per, n_rows, block_iters,
+                       scratch);
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(256), 0, st, (const int64_t*)scratch, n_blocks, blk_base);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* Loop layout of the edges: every row's (cols, eps_per) reordered by ascending eps_per (often-firing edges first), which
+ * makes the schedule kernel's per-lane firing loops homogeneous.  Any edge order gives the same gradient up to the
+ * order of the fp32 force sum; the CSR itself (column-sorted, utils/sparse.py semantics) is left untouched. */
+int tdr_umap_sched_layout_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, int64_t n_rows,
+                              int32_t* cols_out, float* eps_out, void* stream) {
+    if (!rowptr || !cols || !eps_per || !cols_out || !eps_out || n_rows <= 0) return TDR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(umap_sched_layout_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowptr, cols,
+                       eps_per, n_rows, cols_out, eps_out);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* Advance epoch_of_next_sample (`next`) by n_iters (<= 32) iterations starting at iteration t0 and emit the firing lists
+ * (layout: file header).  err: device int, set to 1 if a block's region would overflow. */
+int tdr_umap_sched_build_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, float* next, int64_t n_rows,
+                             int64_t n_total, int t0, int n_iters, int n_slices, const int64_t* blk_base, int32_t* list,
+                             uint32_t* off, uint16_t* act, int* err, void* stream) {
+    if (!rowptr || !cols || !eps_per || !next || !blk_base || !list || !off || !act || !err) return TDR_ERR_BAD_ARG;
+    if (n_rows <= 0 || n_total < 2 || n_total >= 0x7fffffffLL || t0 < 0 || n_iters <= 0 || n_iters > SCHED_BMAX || t0 > (1 << 24) - 64) return TDR_ERR_BAD_ARG;
+    if (n_slices != 1 && n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
+    SchedBuildParams P;
+    P.rowptr = rowptr; P.cols = cols; P.eps_per = eps_per; P.next = next; P.n_rows = n_rows;
+    const uint32_t nred = (uint32_t)(n_total - 1);
+    P.slice_step = (nred + (uint32_t)n_slices - 1u) / (uint32_t)n_slices;
+    P.t0 = t0; P.B = n_iters; P.S = n_slices; P.blk_base = blk_base; P.list = list; P.off = off;
+    const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
+    P.off_stride = n_blocks * (SCHED_RB + 1);
+    P.act = act; P.err = err;
+    const size_t lds = (size_t)n_iters * n_slices * CNT_STRIDE * sizeof(uint32_t);
+    if (lds > 32 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(umap_sched_build_kernel, dim3((unsigned)n_blocks), dim3(256), lds, (hipStream_t)stream, P);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* One evaluation of UMAP's closed-form gradient (umap.py:236-292) for rows [row0, row0 + n_rows) from the lists of
+ * tdr_umap_sched_build_f32: t_local = iteration index inside the window, n_iter = global iteration (hash counter).
+ * acc: (n_rows, 2 nc) floats (used when n_slices > 1).  geom: 0 = default lane geometry (tuning / ablation knob). */
+int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int64_t* blk_base,
+                            const int32_t* list, const uint32_t* off, const uint16_t* act, int t_local, int n_slices,
+                            float a, float b, int n_iter, int neg_rate, int n_negatives, const int64_t* neg_inj,
+                            uint64_t seed, float exag, float rep, float eps, float* grad, float* acc, int geom,
+                            void* stream) {
+    if (!Z || !blk_base || !list || !off || !act || !grad || n_rows <= 0 || n_total < 2 || n_total >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
+    if (t_local < 0 || t_local >= SCHED_BMAX || neg_rate < 0 || n_negatives < 0) return TDR_ERR_BAD_ARG;
+    if (n_slices != 1 && n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
+    if (n_slices > 1 && !acc) return TDR_ERR_BAD_ARG;
+    if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
+    SchedGradParams P;
+    P.Z = Z; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.blk_base = blk_base; P.list = list; P.off = off;
+    const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
+    P.off_stride = n_blocks * (SCHED_RB + 1);
+    P.act = act; P.t_local = t_local; P.S = n_slices; P.a = a; P.b = b; P.neg_rate = neg_rate; P.n_negatives = n_negatives;
+    P.neg_inj = neg_inj; P.seed = seed; P.iter = (uint32_t)n_iter; P.exag = exag; P.rep = rep; P.eps = eps; P.grad = grad;
+    P.acc = acc;
+    hipStream_t st = (hipStream_t)stream;
+    for (int s = 0; s < n_slices; ++s) {
+        P.slice = s;
+        const int rc = (nc == 2) ? launch_sched_grad_geom<2>(P, geom, st) : launch_sched_grad_geom<3>(P, geom, st);
+        if (rc != TDR_OK) return rc;
+    }
+    return TDR_OK;
+}
+
+}  // extern "C"

@@ -11,10 +11,20 @@ from torchdr_amd.neighbor_embedding.base import NegativeSamplingNeighborEmbeddin
 from torchdr_amd.utils.sparse import CSRAffinity
 
 
-# bench.py sets this to a list to collect (start_event, end_event, nnz) around every PROFILE_EVERY-th gradient
-# evaluation (HIP events on the launch stream); None = no instrumentation.
+# bench.py sets this to a list to collect ("grad", start_event, end_event, nnz) around every PROFILE_EVERY-th gradient
+# evaluation and ("build", start_event, end_event, n_iters) around every schedule build (HIP events on the launch
+# stream); None = no instrumentation.
 PROFILE = None
 PROFILE_EVERY = 25
+
+# scheduled loop (csrc/tdr_umap_sched.hip): the epoch counters are advanced SCHED_BLOCK_ITERS iterations at a time and
+# the gradient kernel reads per-iteration lists of the edges that fire.  SCHEDULED = False selects the per-step kernel
+# (tdr_umap_grad_f32), which streams every edge's counter each iteration; SCHED_GEOM is the lane-geometry knob of the
+# gradient kernel (tools/umap_perf.py), SCHED_SLICES overrides the automatic number of L2 slices of the embedding.
+SCHEDULED = True
+SCHED_BLOCK_ITERS = 32
+SCHED_GEOM = 0
+SCHED_SLICES = 0
 
 
 def find_ab_params(spread, min_dist):
@@ -86,15 +96,113 @@ class UMAP(NegativeSamplingNeighborEmbedding):
     def on_affinity_computation_end(self):
         super().on_affinity_computation_end()
         csr: CSRAffinity = self._csr
-        self.epochs_per_sample = torch.empty_like(csr.vals)
-        self.epoch_of_next_sample = torch.empty_like(csr.vals)
+        L = _lib.lib()
+        eps_csr = torch.empty_like(csr.vals)
+        nxt = torch.empty_like(csr.vals)
         scratch = torch.zeros(2, dtype=torch.int32, device=csr.vals.device)
         _lib.check(
-            _lib.lib().tdr_umap_prepare_f32(_lib.ptr(csr.vals), csr.nnz, int(self.max_iter),
-                                            _lib.ptr(self.epochs_per_sample), _lib.ptr(self.epoch_of_next_sample),
-                                            _lib.ptr(scratch), _lib.stream_ptr()),
+            L.tdr_umap_prepare_f32(_lib.ptr(csr.vals), csr.nnz, int(self.max_iter), _lib.ptr(eps_csr), _lib.ptr(nxt),
+                                   _lib.ptr(scratch), _lib.stream_ptr()),
             "tdr_umap_prepare_f32",
         )
+        # loop layout: each row's edges by ascending epochs_per_sample (often-firing first).  The per-edge state of the
+        # optimisation loop (epochs_per_sample, epoch_of_next_sample, _loop_cols) lives in this order; the affinity
+        # graph itself keeps the reference's column order.
+        self._loop_cols = torch.empty_like(csr.cols)
+        self.epochs_per_sample = nxt  # reuse the buffer
+        _lib.check(
+            L.tdr_umap_sched_layout_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.cols), _lib.ptr(eps_csr), csr.n,
+                                        _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample), _lib.stream_ptr()),
+            "tdr_umap_sched_layout_f32",
+        )
+        self.epoch_of_next_sample = self.epochs_per_sample.clone()  # umap.py:232
+
+    # reference attributes (affinity_matcher.py:276-286) in their padded layout, materialised on request from the CSR
+    @property
+    def affinity_in_(self):
+        if not hasattr(self, "_csr"):
+            raise AttributeError("affinity_in_")
+        return self._csr.to_padded()[0]
+
+    @property
+    def NN_indices_(self):
+        if not hasattr(self, "_csr"):
+            raise AttributeError("NN_indices_")
+        return self._csr.to_padded()[1]
+
+    def _fit_transform(self, X, y=None):
+        if self.n_components not in (2, 3):
+            raise NotImplementedError(
+                f"[torchdr_amd] UMAP: the HIP gradient kernels are built for n_components in (2, 3), got {self.n_components}."
+            )
+        return super()._fit_transform(X, y)
+
+    def _sched_setup(self):
+        """Static plan of the scheduled loop: list regions of the 64-row schedule blocks (one host read per fit)."""
+        L, csr, dev = _lib.lib(), self._csr, self.device_
+        n_rows, nc = self.chunk_size_, self.n_components
+        B = int(SCHED_BLOCK_ITERS)
+        S = int(SCHED_SLICES) or int(L.tdr_umap_sched_slices(self.n_samples_in_, nc))
+        n_blocks = (n_rows + 63) // 64
+        scratch = torch.empty(n_blocks, dtype=torch.int64, device=dev)
+        blk_base = torch.empty(n_blocks + 1, dtype=torch.int64, device=dev)
+        _lib.check(L.tdr_umap_sched_plan_f32(_lib.ptr(csr.rowptr), _lib.ptr(self.epochs_per_sample), n_rows, B,
+                                             _lib.ptr(scratch), _lib.ptr(blk_base), _lib.stream_ptr()),
+                   "tdr_umap_sched_plan_f32")
+        cap = int(blk_base[-1].item())
+        self._sched = {
+            "B": B, "S": S, "blk_base": blk_base, "t0": None, "n": 0,
+            "list": torch.empty(max(cap, 1), dtype=torch.int32, device=dev),
+            "off": torch.empty(int(L.tdr_umap_sched_off_entries(n_rows, B, S)), dtype=torch.int32, device=dev),
+            "act": torch.empty(B * n_rows, dtype=torch.int16, device=dev),
+            "err": torch.zeros(1, dtype=torch.int32, device=dev),
+            "acc": torch.empty((n_rows, 2 * nc), dtype=torch.float32, device=dev) if S > 1 else None,
+        }
+        return self._sched
+
+    def _compute_gradients_scheduled(self, grad, neg, prof=False):
+        L, csr = _lib.lib(), self._csr
+        sc = getattr(self, "_sched", None) or self._sched_setup()
+        t = int(self.n_iter_)
+        if sc["t0"] is None or not (sc["t0"] <= t < sc["t0"] + sc["n"]):
+            n = max(1, min(sc["B"], int(self.max_iter) - t))
+            if PROFILE is not None:
+                eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                eb0.record()
+            _lib.check(
+                L.tdr_umap_sched_build_f32(_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
+                                           _lib.ptr(self.epoch_of_next_sample), self.chunk_size_, self.n_samples_in_,
+                                           t, n, sc["S"], _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]),
+                                           _lib.ptr(sc["off"]), _lib.ptr(sc["act"]), _lib.ptr(sc["err"]),
+                                           _lib.stream_ptr()),
+                "tdr_umap_sched_build_f32",
+            )
+            if PROFILE is not None:
+                eb1.record()
+                PROFILE.append(("build", eb0, eb1, n))
+            sc["t0"], sc["n"] = t, n
+        if prof:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        _lib.check(
+            L.tdr_umap_sched_grad_f32(
+                _lib.ptr(self.embedding_), self.n_components, self.n_samples_in_, self.chunk_start_, self.chunk_size_,
+                _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]), _lib.ptr(sc["off"]), _lib.ptr(sc["act"]), t - sc["t0"],
+                sc["S"], float(self._a), float(self._b), t, int(self.negative_sample_rate), int(self.n_negatives),
+                _lib.ptr(neg), self._neg_seed, float(self.early_exaggeration_coeff_), float(self.repulsion_strength),
+                float(self._eps), _lib.ptr(grad), _lib.ptr(sc["acc"]), int(SCHED_GEOM), _lib.stream_ptr(),
+            ),
+            "tdr_umap_sched_grad_f32",
+        )
+        if prof:
+            ev1.record()
+            PROFILE.append(("grad", ev0, ev1, csr.nnz))
+
+    def _raise_if_nan(self):
+        super()._raise_if_nan()
+        sc = getattr(self, "_sched", None)
+        if sc is not None and int(sc["err"].item()) != 0:
+            raise RuntimeError("[torchdr_amd] UMAP: a schedule block overflowed its list region (internal error).")
 
     def _compute_gradients(self):
         csr: CSRAffinity = self._csr
@@ -103,18 +211,21 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                                          device=self.device_)
         grad = self._grad_buf
         neg = self._neg_ptr_tensor()
+        prof = PROFILE is not None and int(self.n_iter_) % PROFILE_EVERY == 0
+        if SCHEDULED and self.n_samples_in_ < 2**31 - 1:
+            self._compute_gradients_scheduled(grad, neg, prof)
+            return grad, True
+        if prof:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         if getattr(self, "_grad_ws", None) is None:  # scratch of the L2-sliced negative phase (large N only)
             nbytes = _lib.lib().tdr_umap_grad_workspace_bytes(self.n_samples_in_, self.chunk_size_, self.n_components)
             self._grad_ws = torch.empty(max(nbytes, 8) // 4 + 1, dtype=torch.int32, device=self.device_)
             self._grad_ws_bytes = nbytes
-        prof = PROFILE is not None and int(self.n_iter_) % PROFILE_EVERY == 0
-        if prof:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
         _lib.check(
             _lib.lib().tdr_umap_grad_f32(
                 _lib.ptr(self.embedding_), self.n_components, self.n_samples_in_, self.chunk_start_,
-                self.chunk_size_, _lib.ptr(csr.rowptr), _lib.ptr(csr.cols), _lib.ptr(self.epochs_per_sample),
+                self.chunk_size_, _lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
                 _lib.ptr(self.epoch_of_next_sample), float(self._a), float(self._b), int(self.n_iter_),
                 int(self.negative_sample_rate), int(self.n_negatives), _lib.ptr(neg), self._neg_seed,
                 float(self.early_exaggeration_coeff_), float(self.repulsion_strength), float(self._eps),
@@ -124,11 +235,11 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         )
         if prof:
             ev1.record()
-            PROFILE.append((ev0, ev1, csr.nnz))
+            PROFILE.append(("grad", ev0, ev1, csr.nnz))
         return grad, True
 
     def clear_memory(self):
         super().clear_memory()
-        for attr in ("_csr", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf", "_grad_ws"):
+        for attr in ("_csr", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf", "_grad_ws", "_sched", "_loop_cols"):
             if hasattr(self, attr):
                 delattr(self, attr)
