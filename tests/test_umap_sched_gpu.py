@@ -39,7 +39,7 @@ class Sched:
         _lib.check(self.L.tdr_umap_sched_plan_f32(_lib.ptr(rowptr), _lib.ptr(eps_per), self.n_rows, B, _lib.ptr(scratch),
                                                   _lib.ptr(self.blk_base), _lib.stream_ptr()), "plan")
         cap = int(self.blk_base[-1].item())
-        self.list = torch.full((max(cap, 1),), -7, dtype=torch.int32, device="cuda")
+        self.list = torch.full((cap + 64,), -7, dtype=torch.int32, device="cuda")  # + slack read by idle lanes
         self.off = torch.zeros(int(self.L.tdr_umap_sched_off_entries(self.n_rows, B, S)), dtype=torch.int32, device="cuda")
         self.act = torch.zeros(B * self.n_rows, dtype=torch.int16, device="cuda")
         self.err = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -260,7 +260,7 @@ def test_in_kernel_negatives_vs_oracle_fixture_graph(S, nc):
             for t in range(t0, t0 + tl):
                 act = nb <= np.float32(t + 1)
                 nb[act] += ep[act]
-            for geom in (0, 1, 2):
+            for geom in (0, 1, 10, 11, 13):
                 err = oracle_check(sc, Z, nb, tl, t0 + tl, a, b, 50, 1234567 + S, rows, geom=geom)
                 assert err < 1e-5, (S, nc, t0, tl, geom, err)
 

@@ -53,6 +53,34 @@ __device__ __forceinline__ float group_sum(float v) {
     for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// The same reductions on the DPP path (no LDS traffic): quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror
+// cover groups of up to 16 lanes (groups are aligned to their size); wider groups finish with shuffles.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int G>
+__device__ __forceinline__ float group_sum_dpp(float v) {
+    if (G >= 2) v += dpp_mov_f<0xB1>(v);
+    if (G >= 4) v += dpp_mov_f<0x4E>(v);
+    if (G >= 8) v += dpp_mov_f<0x141>(v);
+    if (G >= 16) v += dpp_mov_f<0x140>(v);
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ int group_sum_dpp(int v) {
+    if (G >= 2) v += dpp_mov_i<0xB1>(v);
+    if (G >= 4) v += dpp_mov_i<0x4E>(v);
+    if (G >= 8) v += dpp_mov_i<0x141>(v);
+    if (G >= 16) v += dpp_mov_i<0x140>(v);
+    if (G >= 32) v += __shfl_xor(v, 16, 64);
+    if (G >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
 template <int G>
 __device__ __forceinline__ float group_max(float v) {
 #pragma unroll

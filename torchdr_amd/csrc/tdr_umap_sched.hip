@@ -150,10 +150,15 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
             uint32_t m = fire_mask(nx, ep, P.t0, P.B);
             uint32_t s = col / P.slice_step;
             if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
-            while (m) {
-                const int t = __ffs(m) - 1;
-                m &= m - 1;
-                atomicAdd(&cnt[(t * P.S + (int)s) * CNT_STRIDE + lr], 1u);  // a count: order-independent
+            const int sbase = (int)s * CNT_STRIDE + lr;
+            while (m) {  // four firings per round: the LDS operations of a round are independent
+                int tt[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { ok[u] = m != 0u; tt[u] = ok[u] ? __ffs(m) - 1 : 0; m &= m - 1u; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u]) atomicAdd(&cnt[tt[u] * P.S * CNT_STRIDE + sbase], 1u);  // a count: order-independent
             }
         }
     }
@@ -222,11 +227,18 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
             if (m) P.next[e] = nx;
             uint32_t s = col / P.slice_step;
             if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
-            while (m) {
-                const int t = __ffs(m) - 1;
-                m &= m - 1;
-                const uint32_t pos = atomicAdd(&cnt[(t * P.S + (int)s) * CNT_STRIDE + lr], 1u);
-                if (pos < capacity) P.list[base + pos] = (int32_t)col;
+            const int sbase = (int)s * CNT_STRIDE + lr;
+            while (m) {  // four firings per round: four returning LDS atomics in flight, then four stores
+                int tt[4];
+                bool ok[4];
+                uint32_t pos[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { ok[u] = m != 0u; tt[u] = ok[u] ? __ffs(m) - 1 : 0; m &= m - 1u; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pos[u] = ok[u] ? atomicAdd(&cnt[tt[u] * P.S * CNT_STRIDE + sbase], 1u) : 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u] && pos[u] < capacity) P.list[base + pos[u]] = (int32_t)col;
             }
         }
     }
@@ -276,29 +288,43 @@ struct SchedGradParams {
     float exag, rep, eps;
     float* grad;              // (n_rows, NC)
     float* acc;               // (n_rows, 2 NC) partial sums between the slice passes (S > 1)
+    // per-pass constants of the negative split / sampler, prepared on the host (sched_pass_constants)
+    uint32_t r_lo, r_len, step;     // this slice of the reduced index range [0, N-1): start, length; ceil((N-1)/S)
+    int n_levels;                   // log2(S)
+    uint32_t lvl_xor[3];            // hash key modifier of the binomial split at each level (split_key)
+    int lvl_upper[3];               // 1: this slice lies in the upper half at that level
 };
 
-// gather of one embedding row with a cache policy: POL 0 = default, 1 = non-temporal (`nt`: the line is not kept in the
-// CU's L1, whose 32 KiB cannot hold a 4 MiB slice anyway)
-template <int NC, int POL>
-__device__ __forceinline__ Vec<NC> gather_z(const float* __restrict__ Z, uint32_t j) {
-    if (POL == 0) return load_z<NC>(Z, (int64_t)j);
-    Vec<NC> r;
-    if (NC == 2) {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        const f32x2 t = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(Z + (size_t)j * 2));
-        r.v[0] = t.x; r.v[1] = t.y;
-    } else {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) r.v[c] = __builtin_nontemporal_load(Z + (size_t)j * NC + c);
+// this slice's share of the row's n_use negatives: exact binomial halving level by level (= slice_count(),
+// tdr_embed_common.h) with the hash words spread over the G lanes of the row group and a DPP reduction
+template <int G>
+__device__ __forceinline__ int pass_negative_count(const SchedGradParams& P, uint32_t rkey, int n_use, int gl) {
+    int mine = n_use;
+    for (int l = 0; l < P.n_levels; ++l) {
+        const uint32_t key = rkey ^ P.lvl_xor[l];
+        int m = 0;
+        for (int t = gl; t * 32 < mine; t += G) {
+            uint32_t w = mix32(key + 0x7F4A7C15u * (uint32_t)(t + 1));
+            const int rem = mine - t * 32;
+            if (rem < 32) w &= (1u << rem) - 1u;
+            m += __popc(w);
+        }
+        m = group_sum_dpp<G>(m);
+        mine = P.lvl_upper[l] ? mine - m : m;
     }
-    return r;
+    return mine;
 }
 
-// One row group (G lanes) walks ONE item stream: the row's negatives drawn inside this slice first (their addresses
-// need no memory access, so their gathers leave at once), then its fired edges with column in this slice (list read,
-// skipped by the whole wavefront for the instruction slots that hold no edge).
-template <int NC, int G, int U, int POL>
+// One row group (G lanes) walks ONE item stream: the row's fired edges with column in this slice, then its negatives
+// drawn inside this slice.  PMC (N = 1M, 2 slices): ~27 % of the wavefront cycles issue, ~35 % wait for an issue slot,
+// ~38 % wait for memory, 76 G L2 requests/s (a quarter of the L2's rate) -- the pass is bound by instruction issue, so
+// the production instance (INJ = false) is branch-free: every lane evaluates both address forms and selects.
+// streamed operands (list, off, act, acc) read with the non-temporal policy: each is touched once per pass, and the
+// slice of Z the gathers hit has to stay resident in the XCD's 4 MiB L2 next to them
+template <bool NT, typename T>
+__device__ __forceinline__ T stream_load(const T* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+
+template <int NC, int G, int U, bool INJ, bool NT = false>
 __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradParams P) {
     const int gl = threadIdx.x % G;
     const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
@@ -307,22 +333,18 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
     const Vec<NC> zi = load_z<NC>(P.Z, gi);
     const int64_t rb = r >> 6;
     const uint32_t* ob = P.off + (size_t)(P.t_local * P.S + P.slice) * P.off_stride + rb * (SCHED_RB + 1) + (r & 63);
-    const uint32_t o0 = ob[0], o1 = ob[1];
+    const uint32_t o0 = stream_load<NT>(ob), o1 = stream_load<NT>(ob + 1);
     const int32_t* lst = P.list + P.blk_base[rb] + o0;
     const int npos = (int)(o1 - o0);
-    const int act = (int)P.act[(size_t)P.t_local * P.n_rows + r];
+    const int act = (int)stream_load<NT>(P.act + (size_t)P.t_local * P.n_rows + r);
     int n_use = act * P.neg_rate;
     if (n_use > P.n_negatives) n_use = P.n_negatives;
     const uint32_t rkey = neg_row_key(P.seed, P.iter, (int64_t)gi);
-    const uint32_t nred = (uint32_t)(P.n_total - 1);
-    const uint32_t step = (nred + (uint32_t)P.S - 1u) / (uint32_t)P.S;
-    const uint32_t r_lo = (uint32_t)P.slice * step;
-    const uint32_t r_len = (r_lo < nred) ? ((nred - r_lo < step) ? nred - r_lo : step) : 0u;
     // injected negatives: every column is visited and the ones outside this slice are masked
-    int nneg = P.neg_inj ? n_use : slice_count_group<G>(rkey, n_use, P.slice, P.S, gl);
-    if (!P.neg_inj && r_len == 0u) nneg = 0;
-    const uint32_t ckey = rkey + 0x632BE5ABu * (uint32_t)(P.slice + 1);
-    const int total = nneg + npos;
+    int nneg = INJ ? n_use : pass_negative_count<G>(P, rkey, n_use, gl);
+    if (!INJ && P.r_len == 0u) nneg = 0;
+    const uint32_t ckey = rkey + 0x632BE5ABu * (uint32_t)(P.slice + 1) - (uint32_t)npos * 0x9E3779B9u;
+    const int total = npos + nneg;
     const float two_ab = 2.0f * P.a * P.b, m2b = -2.0f * P.b;
     float ga[NC], gr[NC];
 #pragma unroll
@@ -334,34 +356,34 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
         for (int u = 0; u < U; ++u) {
             const int i = base + u * G + gl;
             v[u] = i < total;
-            isp[u] = i >= nneg;
-            jn[u] = gi;
-            const bool wantp = v[u] && isp[u];
-            if (__ballot(wantp)) {  // wavefront-uniform: slots that hold negatives only never wait for the list
-                if (wantp) jn[u] = (uint32_t)lst[i - nneg];
-            }
-            if (v[u] && !isp[u]) {
-                if (P.neg_inj) {
-                    const uint32_t j = (uint32_t)P.neg_inj[(size_t)r * P.n_negatives + i];
-                    uint32_t sl = j / step;
+            isp[u] = i < npos;
+            // list entry (index 0 where the slot holds no edge: the list buffer carries slack behind its last segment)
+            const uint32_t jl = (uint32_t)stream_load<NT>(lst + (isp[u] ? i : 0));
+            uint32_t jneg;
+            if (INJ) {
+                jneg = gi;
+                if (v[u] && !isp[u]) {
+                    const uint32_t j = (uint32_t)P.neg_inj[(size_t)r * P.n_negatives + (i - npos)];
+                    uint32_t sl = j / P.step;
                     if (sl > (uint32_t)(P.S - 1)) sl = (uint32_t)(P.S - 1);
                     v[u] = sl == (uint32_t)P.slice;
-                    if (v[u]) jn[u] = j;
-                } else {
-                    const uint32_t x = mix32(ckey + (uint32_t)i * 0x9E3779B9u);
-                    const uint32_t rr = r_lo + __umulhi(x, r_len);
-                    jn[u] = rr + (rr >= gi ? 1u : 0u);
+                    jneg = j;
                 }
+            } else {
+                const uint32_t x = mix32(ckey + (uint32_t)i * 0x9E3779B9u);  // column i - npos of this slice
+                const uint32_t rr = P.r_lo + __umulhi(x, P.r_len);
+                jneg = rr + (rr >= gi ? 1u : 0u);
             }
+            jn[u] = v[u] ? (isp[u] ? jl : jneg) : gi;
         }
         Vec<NC> zj[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) zj[u] = gather_z<NC, POL>(P.Z, jn[u]);
+        for (int u = 0; u < U; ++u) zj[u] = load_z<NC>(P.Z, (int64_t)jn[u]);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float df[NC];
             const float d = sqdist<NC>(zi, zj[u], df);
-            const float pb = d > 0.f ? fast_pow(d, P.b) : 0.f;
+            const float pb = fast_pow(d, P.b);  // d = 0: exp2(b * log2 0) = exp2(-inf) = 0, no branch needed
             const float den = 1.0f + P.a * pb;
             // attraction 2ab d^(b-1) / (1 + a d^b) (0 where d <= 0, umap.py:252-256) | repulsion -2b / ((d + eps)(1 + a d^b))
             const float num = isp[u] ? pb * two_ab : m2b;
@@ -374,42 +396,221 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
         }
     }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { ga[c] = group_sum<G>(ga[c]); gr[c] = group_sum<G>(gr[c]); }
+    for (int c = 0; c < NC; ++c) { ga[c] = group_sum_dpp<G>(ga[c]); gr[c] = group_sum_dpp<G>(gr[c]); }
     if (gl == 0) {
         float* acc = P.acc + (size_t)r * 2 * NC;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            float A = ga[c], R = gr[c];
-            if (P.slice > 0) { A += acc[c]; R += acc[NC + c]; }
-            if (P.slice == P.S - 1) {
-                P.grad[(size_t)r * NC + c] = P.exag * fminf(fmaxf(A, -4.f), 4.f) + P.rep * fminf(fmaxf(R, -4.f), 4.f);
+        if (P.slice > 0) {
+            if (NC == 2) {
+                typedef float f32x4v __attribute__((ext_vector_type(4)));
+                const f32x4v t = stream_load<NT>(reinterpret_cast<const f32x4v*>(acc));
+                ga[0] += t.x; ga[1] += t.y; gr[0] += t.z; gr[1] += t.w;
             } else {
-                acc[c] = A;
-                acc[NC + c] = R;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { ga[c] += acc[c]; gr[c] += acc[NC + c]; }
             }
+        }
+        if (P.slice == P.S - 1) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                P.grad[(size_t)r * NC + c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
+        } else if (NC == 2) {
+            *reinterpret_cast<float4*>(acc) = make_float4(ga[0], ga[1], gr[0], gr[1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { acc[c] = ga[c]; acc[NC + c] = gr[c]; }
         }
     }
 }
 
-template <int NC, int G, int U, int POL>
+// Software-pipelined form of the production pass.  A resident wavefront slot of the kernel above spends three dependent
+// memory round trips per row set (row header -> list -> gathers) and only the last one feeds the gather path, so the
+// header latency ADDS to the gather time (measured: 0.064 ms per pass with 4 gathers per row, 0.16 ms with 26, against
+// 0.097 ms for the gathers alone at the L2's 268 G random requests/s, tools/gather_bench.hip).  Here a workgroup walks
+// row sets with a grid stride and keeps two sets in flight: while set k gathers, the list entries of set k+1 and the
+// header of set k+2 are already on their way (loads retire in order, so waiting for the gathers of k also lands them).
+template <int NC, int G, int U>
+__global__ __launch_bounds__(256) void umap_sched_grad_pipe_kernel(const SchedGradParams P) {
+    constexpr int RW = 64 / G;   // rows per wavefront and step
+    constexpr int RBW = 4 * RW;  // rows per workgroup and step
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gl = lane % G;
+    const int64_t n_steps = (P.n_rows + RBW - 1) / RBW;
+    const uint32_t* offk = P.off + (size_t)(P.t_local * P.S + P.slice) * P.off_stride;
+    const uint16_t* actk = P.act + (size_t)P.t_local * P.n_rows;
+    const float two_ab = 2.0f * P.a * P.b, m2b = -2.0f * P.b;
+    const uint32_t skey = 0x632BE5ABu * (uint32_t)(P.slice + 1);
+
+    struct Hdr {
+        Vec<NC> zi;
+        uint32_t o0, o1, act;
+        int64_t r, base;
+    };
+    auto load_hdr = [&](int64_t step) {
+        Hdr h;
+        h.r = step * RBW + w * RW + lane / G;  // rows past the end read row 0 and store nothing
+        const int64_t rr = h.r < P.n_rows ? h.r : 0;
+        h.zi = load_z<NC>(P.Z, P.row0 + rr);
+        const uint32_t* ob = offk + (rr >> 6) * (SCHED_RB + 1) + (rr & 63);
+        h.o0 = ob[0];
+        h.o1 = ob[1];
+        h.act = actk[rr];
+        h.base = P.blk_base[rr >> 6];
+        return h;
+    };
+    struct Lst { uint32_t j[U]; };
+    auto load_list = [&](const Hdr& h) {
+        Lst l;
+        const int npos = (int)(h.o1 - h.o0);
+        const int32_t* lst = P.list + h.base + h.o0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = u * G + gl;
+            l.j[u] = (uint32_t)lst[i < npos ? i : 0];
+        }
+        return l;
+    };
+
+    int64_t step = blockIdx.x;
+    if (step >= n_steps) return;
+    const int64_t stride = gridDim.x;
+    Hdr h0 = load_hdr(step);
+    Hdr h1 = load_hdr(step + stride);
+    Lst l0 = load_list(h0);
+    for (; step < n_steps; step += stride) {
+        const Hdr h2 = load_hdr(step + 2 * stride);
+        const Lst l1 = load_list(h1);
+        // ---- row set `step`: header h0, first-round list entries l0
+        const uint32_t gi = (uint32_t)(P.row0 + (h0.r < P.n_rows ? h0.r : 0));
+        const int npos = (int)(h0.o1 - h0.o0);
+        int n_use = (int)h0.act * P.neg_rate;
+        if (n_use > P.n_negatives) n_use = P.n_negatives;
+        const uint32_t rkey = neg_row_key(P.seed, P.iter, (int64_t)gi);
+        int nneg = pass_negative_count<G>(P, rkey, n_use, gl);
+        if (P.r_len == 0u) nneg = 0;
+        const uint32_t ckey = rkey + skey - (uint32_t)npos * 0x9E3779B9u;
+        const int total = npos + nneg;
+        float ga[NC], gr[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { ga[c] = 0.f; gr[c] = 0.f; }
+        int maxtot = total;
+#pragma unroll
+        for (int o = 32; o >= G; o >>= 1) maxtot = max(maxtot, __shfl_xor(maxtot, o, 64));
+        for (int base = 0; base < maxtot; base += U * G) {
+            uint32_t jn[U];
+            bool v[U], isp[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = base + u * G + gl;
+                v[u] = i < total;
+                isp[u] = i < npos;
+                uint32_t jl = l0.j[u];
+                if (base > 0) jl = (uint32_t)P.list[h0.base + h0.o0 + (isp[u] ? i : 0)];  // rows with > U*G fired edges (hubs)
+                const uint32_t x = mix32(ckey + (uint32_t)i * 0x9E3779B9u);
+                const uint32_t rr = P.r_lo + __umulhi(x, P.r_len);
+                const uint32_t jneg = rr + (rr >= gi ? 1u : 0u);
+                jn[u] = v[u] ? (isp[u] ? jl : jneg) : gi;
+            }
+            Vec<NC> zj[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) zj[u] = load_z<NC>(P.Z, (int64_t)jn[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float df[NC];
+                const float d = sqdist<NC>(h0.zi, zj[u], df);
+                const float pb = fast_pow(d, P.b);
+                const float den = 1.0f + P.a * pb;
+                const float num = isp[u] ? pb * two_ab : m2b;
+                const float dd = isp[u] ? d : d + P.eps;
+                float coef = num * fast_rcp(dd * den);
+                if (!v[u] || (isp[u] && !(d > 0.f))) coef = 0.f;
+                const float ca = isp[u] ? coef : 0.f, cr = isp[u] ? 0.f : coef;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { ga[c] += ca * df[c]; gr[c] += cr * df[c]; }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { ga[c] = group_sum_dpp<G>(ga[c]); gr[c] = group_sum_dpp<G>(gr[c]); }
+        if (gl == 0 && h0.r < P.n_rows) {
+            float* acc = P.acc + (size_t)h0.r * 2 * NC;
+            if (P.slice > 0) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { ga[c] += acc[c]; gr[c] += acc[NC + c]; }
+            }
+            if (P.slice == P.S - 1) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    P.grad[(size_t)h0.r * NC + c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { acc[c] = ga[c]; acc[NC + c] = gr[c]; }
+            }
+        }
+        h0 = h1;
+        h1 = h2;
+        l0 = l1;
+    }
+}
+
+// host side of the per-pass constants (must mirror slice_count / slice_negative of tdr_embed_common.h)
+static void sched_pass_constants(SchedGradParams& P, int slice) {
+    const uint32_t nred = (uint32_t)(P.n_total - 1);
+    const uint32_t S = (uint32_t)P.S;
+    P.slice = slice;
+    P.step = (nred + S - 1u) / S;
+    P.r_lo = (uint32_t)slice * P.step;
+    P.r_len = (P.r_lo < nred) ? ((nred - P.r_lo < P.step) ? nred - P.r_lo : P.step) : 0u;
+    int level = 0;
+    for (int span = P.S; span > 1; span >>= 1, ++level) {
+        const uint32_t group = (uint32_t)(slice / span);
+        P.lvl_xor[level] = level == 0 ? 0x9E3779B9u
+                         : level == 1 ? 0x85EBCA6Bu + 0x27D4EB2Fu * group
+                                      : 0xC2B2AE35u + 0x165667B1u * group;
+        P.lvl_upper[level] = (slice / (span >> 1)) & 1;
+    }
+    P.n_levels = level;
+    for (; level < 3; ++level) { P.lvl_xor[level] = 0; P.lvl_upper[level] = 0; }
+}
+
+template <int NC, int G, int U, bool NT = false>
 static int launch_sched_grad(const SchedGradParams& P, hipStream_t st) {
     const int rpb = 256 / G;
-    hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, U, POL>), dim3((unsigned)((P.n_rows + rpb - 1) / rpb)), dim3(256), 0, st, P);
+    const dim3 grid((unsigned)((P.n_rows + rpb - 1) / rpb));
+    if (P.neg_inj) hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, U, true, false>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, U, false, NT>), grid, dim3(256), 0, st, P);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TDR_OK : (int)e;
 }
 
-// geom: lane geometry / gather policy knob (0 = default; the others are kept for ablations, tools/umap_sched_perf.py)
+template <int NC, int G, int U>
+static int launch_sched_grad_pipe(const SchedGradParams& P, int wgs_per_cu, hipStream_t st) {
+    if (P.neg_inj) return launch_sched_grad<NC, G, 4>(P, st);  // injected negatives: the plain kernel
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int64_t n_steps = (P.n_rows + (256 / G) - 1) / (256 / G);
+    int64_t grid = (int64_t)cus * wgs_per_cu;
+    if (grid > n_steps) grid = n_steps;
+    hipLaunchKernelGGL((umap_sched_grad_pipe_kernel<NC, G, U>), dim3((unsigned)grid), dim3(256), 0, st, P);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TDR_OK : (int)e;
+}
+
+// geom: lane geometry knob (0 = default; the others are kept for ablations, tools/umap_sched_perf.py)
 template <int NC>
 static int launch_sched_grad_geom(const SchedGradParams& P, int geom, hipStream_t st) {
     switch (geom) {
-        case 1: return launch_sched_grad<NC, 8, 2, 0>(P, st);
-        case 2: return launch_sched_grad<NC, 16, 2, 0>(P, st);
-        case 3: return launch_sched_grad<NC, 4, 8, 0>(P, st);
-        case 4: return launch_sched_grad<NC, 4, 4, 0>(P, st);
-        case 5: return launch_sched_grad<NC, 8, 4, 1>(P, st);
-        case 6: return launch_sched_grad<NC, 4, 4, 1>(P, st);
-        default: return launch_sched_grad<NC, 8, 4, 0>(P, st);
+        case 10: return launch_sched_grad_pipe<NC, 8, 4>(P, 8, st);
+        case 11: return launch_sched_grad_pipe<NC, 8, 5>(P, 8, st);
+        case 12: return launch_sched_grad_pipe<NC, 8, 4>(P, 6, st);
+        case 13: return launch_sched_grad_pipe<NC, 4, 8>(P, 6, st);
+        case 14: return launch_sched_grad_pipe<NC, 8, 5>(P, 5, st);
+        case 15: return launch_sched_grad_pipe<NC, 8, 4>(P, 16, st);
+        case 1: return launch_sched_grad<NC, 8, 2>(P, st);
+        case 2: return launch_sched_grad<NC, 16, 2>(P, st);
+        case 3: return launch_sched_grad<NC, 4, 4>(P, st);
+        case 4: return launch_sched_grad<NC, 4, 8>(P, st);
+        case 5: return launch_sched_grad<NC, 2, 8>(P, st);
+        case 6: return launch_sched_grad<NC, 8, 4, true>(P, st);
+        case 7: return launch_sched_grad<NC, 4, 4, true>(P, st);
+        default: return launch_sched_grad<NC, 8, 4>(P, st);
     }
 }
 
@@ -437,7 +638,7 @@ int64_t tdr_umap_sched_off_entries(int64_t n_rows, int block_iters, int n_slices
 }
 
 /* Static plan: blk_base (n_blocks + 1, n_blocks = ceil(n_rows / 64)) = exclusive scan of the blocks' list capacities for
- * windows of block_iters (<= 32) iterations; blk_base[n_blocks] = int32 entries `list` must hold.  scratch: n_blocks int64. */
+ * windows of block_iters (<= 32) iterations; blk_base[n_blocks] = int32 entries `list` must hold, PLUS 64 entries of slack (idle lanes of the gradient kernel read entry 0 of a segment).  scratch: n_blocks int64. */
 int tdr_umap_sched_plan_f32(const int64_t* rowptr, const float* eps_per, int64_t n_rows, int block_iters, int64_t* scratch,
                             int64_t* blk_base, void* stream) {
     if (!rowptr || !eps_per || !scratch || !blk_base || n_rows <= 0 || block_iters <= 0 || block_iters > SCHED_BMAX)
@@ -512,7 +713,7 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
     P.acc = acc;
     hipStream_t st = (hipStream_t)stream;
     for (int s = 0; s < n_slices; ++s) {
-        P.slice = s;
+        sched_pass_constants(P, s);
         const int rc = (nc == 2) ? launch_sched_grad_geom<2>(P, geom, st) : launch_sched_grad_geom<3>(P, geom, st);
         if (rc != TDR_OK) return rc;
     }

@@ -152,7 +152,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         cap = int(blk_base[-1].item())
         self._sched = {
             "B": B, "S": S, "blk_base": blk_base, "t0": None, "n": 0,
-            "list": torch.empty(max(cap, 1), dtype=torch.int32, device=dev),
+            "list": torch.empty(cap + 64, dtype=torch.int32, device=dev),  # slack: idle lanes read entry 0 of a segment
             "off": torch.empty(int(L.tdr_umap_sched_off_entries(n_rows, B, S)), dtype=torch.int32, device=dev),
             "act": torch.empty(B * n_rows, dtype=torch.int16, device=dev),
             "err": torch.zeros(1, dtype=torch.int32, device=dev),
