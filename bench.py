@@ -246,7 +246,7 @@ def main():
                                         "not matrix-pipe utilisation" if path.endswith("pruned") else "")),
     }
     roof_grad = {
-        "kernel": ("S x tdr::umap_sched_grad_kernel<2,8,4> (one pass per L2 slice of the embedding) + 1/32 of "
+        "kernel": ("S x tdr::umap_sched_grad_kernel<2,4,false> (one pass per L2 slice of the embedding) + 1/32 of "
                    "tdr::umap_sched_build_kernel (one gradient evaluation)" if umod.SCHEDULED else
                    "tdr::umap_grad_kernel<2,16,4,true> + 2 x tdr::umap_neg_dense_kernel<2,8,2> (one gradient evaluation)"),
         "bound": "hbm", "achieved": grad_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_gbs / HBM_PEAK_GBS,

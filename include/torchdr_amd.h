@@ -177,25 +177,26 @@ int tdr_umap_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t
  * the embedding, so `build` advances `next` by up to 32 iterations at once (bit-exact per iteration) and emits, per
  * iteration and per L2 slice of the embedding, the compacted columns of the edges that fire; `grad` reads those lists.
  *   plan : blk_base (ceil(n_rows/64) + 1) int64 = static list regions of the 64-row schedule blocks; the last entry is
- *          the number of int32 entries `list` needs.  scratch: ceil(n_rows/64) int64.
- *   build: off = tdr_umap_sched_off_entries(...) uint32, act = (n_iters, n_rows) uint16, err = device int (overflow flag)
+ *          the number of int32 entries `list` needs, to which the caller adds 64 entries of slack.  scratch:
+ *          ceil(n_rows/64) int64.
+ *   build: hdr = tdr_umap_sched_hdr_entries(...) 8-byte records {segment start, length | active count << 16} per
+ *          (iteration, slice, row); err = device int (1: region overflow, 2: segment > 65535 / list > 2^32 entries)
  *   grad : t_local = n_iter - t0 of the last build; acc = (n_rows, 2 nc) floats when n_slices > 1; n_slices in
- *          {1, 2, 4, 8} (tdr_umap_sched_slices = automatic choice); geom = lane geometry (0 = default). */
+ *          {1, 2, 4, 8} (tdr_umap_sched_slices = automatic choice); geom = lanes per row (0 = default). */
 int tdr_umap_sched_slices(int64_t n_total, int nc);
 /* loop layout: every row's (cols, eps_per) reordered by ascending eps_per (often-firing edges first) */
 int tdr_umap_sched_layout_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, int64_t n_rows,
                               int32_t* cols_out, float* eps_out, void* stream);
-int64_t tdr_umap_sched_off_entries(int64_t n_rows, int block_iters, int n_slices);
+int64_t tdr_umap_sched_hdr_entries(int64_t n_rows, int block_iters, int n_slices);
 int tdr_umap_sched_plan_f32(const int64_t* rowptr, const float* eps_per, int64_t n_rows, int block_iters, int64_t* scratch,
                             int64_t* blk_base, void* stream);
 int tdr_umap_sched_build_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, float* next, int64_t n_rows,
                              int64_t n_total, int t0, int n_iters, int n_slices, const int64_t* blk_base, int32_t* list,
-                             uint32_t* off, uint16_t* act, int* err, void* stream);
-int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int64_t* blk_base,
-                            const int32_t* list, const uint32_t* off, const uint16_t* act, int t_local, int n_slices,
-                            float a, float b, int n_iter, int neg_rate, int n_negatives, const int64_t* neg_inj,
-                            uint64_t seed, float exag, float rep, float eps, float* grad, float* acc, int geom,
-                            void* stream);
+                             void* hdr, int* err, void* stream);
+int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list,
+                            const void* hdr, int t_local, int n_slices, float a, float b, int n_iter, int neg_rate,
+                            int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep, float eps,
+                            float* grad, float* acc, int geom, void* stream);
 /* gradients of neighbor_embedding/largevis.py:181-201 (kind 0), tsne.py:162-170 (kind 1, attraction only),
  * sne.py:160-168 (kind 2, attraction only) and infotsne.py:178-197 (kind 3: Student-t attraction + the row
  * log-sum-exp over the sampled negatives, rep_coef = 2 * repulsion_strength / N) */

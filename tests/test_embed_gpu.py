@@ -211,10 +211,15 @@ def test_tsne_exaggeration_switch_and_schedules():
     assert np.allclose(lrs, expect, rtol=1e-6)
 
 
-def test_umap_estimator_trajectory_vs_reference():
-    """Whole-estimator parity: OUR UMAP (kNN -> sigma search -> CSR symmetrisation -> epoch counters -> 3
-    optimisation steps with the fused SGD / LR table) started from the reference's initial embedding and fed
-    the reference's own negative samples must reproduce the reference's embedding after 3 steps."""
+@pytest.mark.parametrize("teacher_forced", [True, False])
+def test_umap_estimator_trajectory_vs_reference(teacher_forced):
+    """Whole-estimator parity: OUR UMAP (kNN -> sigma search -> CSR symmetrisation -> epoch counters (one schedule window
+    serves all three steps) -> optimisation steps with the fused SGD / LR table) started from the reference's initial
+    embedding and fed the reference's own negative samples must reproduce the reference's embedding after each of its
+    first 3 steps.  teacher_forced: every step starts from the reference's embedding, so each step is held to 1e-5 on
+    its own; free-running: the 1e-7 reassociation differences of a step are amplified by the next one (the repulsion
+    -2b / ((d + 1e-3)(1 + a d^b)) of nearly coincident points has a slope of ~1e3 per unit), so step t is held to
+    1e-5 * 20^t of the embedding's range."""
     import torchdr_amd
 
     g = load("umap_step")
@@ -229,6 +234,8 @@ def test_umap_estimator_trajectory_vs_reference():
             super().on_training_step_start()
             t = int(self.n_iter_)
             self.neg_indices_ = g[f"neg_{t}"] if t < 3 else None
+            if teacher_forced and t < 3:
+                self.embedding_.copy_(g[f"Z_{t}"].to(self.device_))
 
         def on_training_step_end(self):
             super().on_training_step_end()
@@ -237,7 +244,8 @@ def test_umap_estimator_trajectory_vs_reference():
                 ref = g[f"Zafter_{t}"]
                 got = self.embedding_.detach().cpu()
                 err = float((got - ref).abs().max())
-                assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max())), f"step {t}: max |err| {err:.3e}"
+                tol = 1e-5 * (1.0 if teacher_forced else 20.0 ** t)
+                assert torch.allclose(got, ref, rtol=tol, atol=tol * float(ref.abs().max())), f"step {t}: max |err| {err:.3e}"
 
     m = Replay(n_neighbors=10, max_iter=int(g["max_iter"]), random_state=0)
     m.fit_transform(X)

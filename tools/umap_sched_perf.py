@@ -17,7 +17,7 @@ from torchdr_amd import _lib
 from torchdr_amd.affinity import UMAPAffinity
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-geoms = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,1,2,3,4,5,6").split(",")]
+geoms = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,1,2,3").split(",")]
 slices = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "2").split(",")]
 ITERS = int(os.environ.get("ITERS", "32"))
 X = gmm(n, 128, 2.0).cuda()
@@ -58,7 +58,7 @@ for S in slices:
 
     ms_build = timed(rebuild, 5) - timed(lambda: nxt.copy_(snap), 5)
     cap = int(sc.blk_base[-1].item())
-    used = int((sc.off.view(32 * S, -1)[-1].view(-1, 65)[:, 64].long() & 0xFFFFFFFF).sum())
+    used = int(sc.records(32)[1].sum())
     print(json.dumps({"slices": S, "build_ms": ms_build, "build_ms_per_iter": ms_build / 32, "list_capacity": cap,
                       "list_used": used}), flush=True)
     for geom in geoms:

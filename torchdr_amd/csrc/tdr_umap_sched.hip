@@ -16,8 +16,9 @@
 //   blk_base (n_blocks + 1) int64   static start of every block's region in `list` (capacity bound from eps_per)
 //   list     int32                  column ids; inside a block's region the segments (t, slice, row) follow each other
 //                                   in that order, so one gradient pass (fixed t, slice) reads a contiguous run per block
-//   off      (B * S, n_blocks * 65) uint32 segment starts relative to blk_base[block]; entry 64 closes row 63
-//   act      (B, n_rows) uint16     number of edges of the row that fire at iteration t (all slices): the row draws
+//   hdr      (B * S, n_rows) uint2  one record per (iteration, slice, row): .x = start of the segment in `list`
+//                                   (absolute), .y = segment length (low 16 bits) | number of edges of the row that fire
+//                                   at this iteration over all slices (high 16 bits): the row draws
 //                                   min(5 * act, n_negatives) negatives (umap.py:283-288)
 // Gradient pass = one launch per slice s of the embedding (Z slice <= 4 MiB = one XCD's L2): a row group walks ONE item
 // stream made of its fired edges with column in slice s followed by its negatives drawn inside slice s (exact
@@ -88,10 +89,9 @@ struct SchedBuildParams {
     int t0, B, S;             // window = iterations t0 .. t0 + B - 1 (B <= 32), S slices
     const int64_t* blk_base;
     int32_t* list;
-    uint32_t* off;
-    int64_t off_stride;       // n_blocks * 65
-    uint16_t* act;
-    int* err;                 // device flag: set when a block's region would overflow (never with the plan's bound)
+    uint2* hdr;               // (B * S, n_rows) segment records, see the file header
+    int* err;                 // device flag: 1 = a block's region would overflow (never with the plan's bound),
+                              // 2 = a segment longer than 65535 entries or a list beyond 2^32 entries (unsupported)
 };
 
 // The edge's firings in the window [t0, t0 + B) as a bit mask; nx advances exactly as umap.py:243-247 does step by step.
@@ -125,6 +125,7 @@ __device__ __forceinline__ uint32_t fire_mask(float& nx, float ep, int t0, int B
 __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildParams P) {
     extern __shared__ uint32_t cnt[];  // [B * S][65]
     __shared__ uint32_t wave_tot[4];
+    __shared__ uint16_t actl[SCHED_BMAX * 64];
     const int K = P.B * P.S;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, gl = lane & 15, gq = lane >> 4;
     const int64_t rb = blockIdx.x;
@@ -164,15 +165,12 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
     }
     __syncthreads();
 
-    // rows' active counts per iteration
+    // rows' active counts per iteration (all slices)
     for (int i = tid; i < P.B * 64; i += 256) {
         const int t = i >> 6, lr = i & 63;
-        const int64_t r = rb * SCHED_RB + lr;
-        if (r < P.n_rows) {
-            uint32_t a = 0;
-            for (int s = 0; s < P.S; ++s) a += cnt[(t * P.S + s) * CNT_STRIDE + lr];
-            P.act[(size_t)t * P.n_rows + r] = (uint16_t)(a > 65535u ? 65535u : a);
-        }
+        uint32_t a = 0;
+        for (int s = 0; s < P.S; ++s) a += cnt[(t * P.S + s) * CNT_STRIDE + lr];
+        actl[i] = (uint16_t)(a > 65535u ? 65535u : a);
     }
     // exclusive scan of the counts in (segment k = t * S + slice, row) order; wavefront w owns segments [k0, k1)
     const int kper = (K + 3) / 4;
@@ -190,7 +188,8 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
     const int64_t base = P.blk_base[rb];
     const int64_t capacity64 = P.blk_base[rb + 1] - base;
     const uint32_t capacity = capacity64 > 0xffffffffLL ? 0xffffffffu : (uint32_t)capacity64;
-    uint32_t* offp = P.off + (size_t)rb * (SCHED_RB + 1);
+    const int64_t row = rb * SCHED_RB + lane;
+    bool bad = base + capacity64 > 0xffffffffLL;
     for (int k = k0; k < k1; ++k) {
         const uint32_t v = cnt[k * CNT_STRIDE + lane];
         uint32_t inc = v;
@@ -201,10 +200,12 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
         }
         const uint32_t ex = carry + inc - v;
         cnt[k * CNT_STRIDE + lane] = ex;  // from here on: the write pointer of segment (k, row)
-        offp[(size_t)k * P.off_stride + lane] = ex;
+        bad = bad || v > 65535u;
+        if (row < P.n_rows)
+            P.hdr[(size_t)k * P.n_rows + row] = make_uint2((uint32_t)base + ex, (v & 0xffffu) | ((uint32_t)actl[(k / P.S) * 64 + lane] << 16));
         carry += __shfl(inc, 63, 64);
-        if (lane == 0) offp[(size_t)k * P.off_stride + SCHED_RB] = carry;
     }
+    if (bad) atomicMax(P.err, 2);
     if (total > capacity && tid == 0) atomicMax(P.err, 1);
     __syncthreads();
 
@@ -274,11 +275,8 @@ __global__ __launch_bounds__(256) void umap_sched_layout_kernel(const int64_t* _
 struct SchedGradParams {
     const float* Z;
     int64_t n_total, row0, n_rows;
-    const int64_t* blk_base;
     const int32_t* list;
-    const uint32_t* off;
-    int64_t off_stride;
-    const uint16_t* act;
+    const uint2* hdr;
     int t_local, S, slice;
     float a, b;
     int neg_rate, n_negatives;
@@ -316,28 +314,25 @@ __device__ __forceinline__ int pass_negative_count(const SchedGradParams& P, uin
 }
 
 // One row group (G lanes) walks ONE item stream: the row's fired edges with column in this slice, then its negatives
-// drawn inside this slice.  PMC (N = 1M, 2 slices): ~27 % of the wavefront cycles issue, ~35 % wait for an issue slot,
-// ~38 % wait for memory, 76 G L2 requests/s (a quarter of the L2's rate) -- the pass is bound by instruction issue, so
-// the production instance (INJ = false) is branch-free: every lane evaluates both address forms and selects.
-// streamed operands (list, off, act, acc) read with the non-temporal policy: each is touched once per pass, and the
-// slice of Z the gathers hit has to stay resident in the XCD's 4 MiB L2 next to them
-template <bool NT, typename T>
-__device__ __forceinline__ T stream_load(const T* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
-
-template <int NC, int G, int U, bool INJ, bool NT = false>
+// drawn inside this slice; lane gl owns the four consecutive items 4 gl .. 4 gl + 3 of every round of 4 G items.
+// Measured (N = 1M, 2 slices, 26 items per row and pass): the pass takes 0.16 ms against 0.097 ms for its gathers
+// alone at the L2's 268 G random requests/s (tools/gather_bench.hip), and 0.064 ms with 4 items per row -- a cost per
+// VECTOR-MEMORY INSTRUCTION of the row set, not per byte (neither fewer VALU instructions, nor narrower row groups, nor
+// a software-pipelined persistent form moved it).  Hence: one 8-byte record per row instead of four header words, one
+// 16-byte list read per lane instead of four, and a branch-free body (INJ = false: every lane evaluates both address
+// forms and selects).
+template <int NC, int G, bool INJ>
 __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradParams P) {
+    constexpr int U = 4;
     const int gl = threadIdx.x % G;
     const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     if (r >= P.n_rows) return;
     const uint32_t gi = (uint32_t)(P.row0 + r);
     const Vec<NC> zi = load_z<NC>(P.Z, gi);
-    const int64_t rb = r >> 6;
-    const uint32_t* ob = P.off + (size_t)(P.t_local * P.S + P.slice) * P.off_stride + rb * (SCHED_RB + 1) + (r & 63);
-    const uint32_t o0 = stream_load<NT>(ob), o1 = stream_load<NT>(ob + 1);
-    const int32_t* lst = P.list + P.blk_base[rb] + o0;
-    const int npos = (int)(o1 - o0);
-    const int act = (int)stream_load<NT>(P.act + (size_t)P.t_local * P.n_rows + r);
-    int n_use = act * P.neg_rate;
+    const uint2 h = P.hdr[(size_t)(P.t_local * P.S + P.slice) * P.n_rows + r];
+    const int32_t* lst = P.list + h.x;
+    const int npos = (int)(h.y & 0xffffu);
+    int n_use = (int)(h.y >> 16) * P.neg_rate;
     if (n_use > P.n_negatives) n_use = P.n_negatives;
     const uint32_t rkey = neg_row_key(P.seed, P.iter, (int64_t)gi);
     // injected negatives: every column is visited and the ones outside this slice are masked
@@ -350,15 +345,23 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
 #pragma unroll
     for (int c = 0; c < NC; ++c) { ga[c] = 0.f; gr[c] = 0.f; }
     for (int base = 0; base < total; base += U * G) {
+        const int i0 = base + gl * U;
+        // the lane's four list entries in one read (the list carries 64 entries of slack behind its last segment, so
+        // reading past a segment is harmless; positions >= npos are not used)
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x4 l4 = {0, 0, 0, 0};
+        if (__ballot(i0 < npos)) {  // wavefront-uniform: rounds made of negatives only skip the read
+            const int32_t* lp = lst + (i0 < npos ? i0 : 0);
+            __builtin_memcpy(&l4, lp, 16);
+        }
         uint32_t jn[U];
         bool v[U], isp[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = base + u * G + gl;
+            const int i = i0 + u;
             v[u] = i < total;
             isp[u] = i < npos;
-            // list entry (index 0 where the slot holds no edge: the list buffer carries slack behind its last segment)
-            const uint32_t jl = (uint32_t)stream_load<NT>(lst + (isp[u] ? i : 0));
+            const uint32_t jl = (uint32_t)l4[u];
             uint32_t jneg;
             if (INJ) {
                 jneg = gi;
@@ -401,8 +404,7 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
         float* acc = P.acc + (size_t)r * 2 * NC;
         if (P.slice > 0) {
             if (NC == 2) {
-                typedef float f32x4v __attribute__((ext_vector_type(4)));
-                const f32x4v t = stream_load<NT>(reinterpret_cast<const f32x4v*>(acc));
+                const float4 t = *reinterpret_cast<const float4*>(acc);
                 ga[0] += t.x; ga[1] += t.y; gr[0] += t.z; gr[1] += t.w;
             } else {
 #pragma unroll
@@ -410,143 +412,21 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
             }
         }
         if (P.slice == P.S - 1) {
+            float g[NC];
 #pragma unroll
-            for (int c = 0; c < NC; ++c)
-                P.grad[(size_t)r * NC + c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
+            for (int c = 0; c < NC; ++c) g[c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
+            if (NC == 2) {
+                *reinterpret_cast<float2*>(P.grad + (size_t)r * 2) = make_float2(g[0], g[1]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) P.grad[(size_t)r * NC + c] = g[c];
+            }
         } else if (NC == 2) {
             *reinterpret_cast<float4*>(acc) = make_float4(ga[0], ga[1], gr[0], gr[1]);
         } else {
 #pragma unroll
             for (int c = 0; c < NC; ++c) { acc[c] = ga[c]; acc[NC + c] = gr[c]; }
         }
-    }
-}
-
-// Software-pipelined form of the production pass.  A resident wavefront slot of the kernel above spends three dependent
-// memory round trips per row set (row header -> list -> gathers) and only the last one feeds the gather path, so the
-// header latency ADDS to the gather time (measured: 0.064 ms per pass with 4 gathers per row, 0.16 ms with 26, against
-// 0.097 ms for the gathers alone at the L2's 268 G random requests/s, tools/gather_bench.hip).  Here a workgroup walks
-// row sets with a grid stride and keeps two sets in flight: while set k gathers, the list entries of set k+1 and the
-// header of set k+2 are already on their way (loads retire in order, so waiting for the gathers of k also lands them).
-template <int NC, int G, int U>
-__global__ __launch_bounds__(256) void umap_sched_grad_pipe_kernel(const SchedGradParams P) {
-    constexpr int RW = 64 / G;   // rows per wavefront and step
-    constexpr int RBW = 4 * RW;  // rows per workgroup and step
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, gl = lane % G;
-    const int64_t n_steps = (P.n_rows + RBW - 1) / RBW;
-    const uint32_t* offk = P.off + (size_t)(P.t_local * P.S + P.slice) * P.off_stride;
-    const uint16_t* actk = P.act + (size_t)P.t_local * P.n_rows;
-    const float two_ab = 2.0f * P.a * P.b, m2b = -2.0f * P.b;
-    const uint32_t skey = 0x632BE5ABu * (uint32_t)(P.slice + 1);
-
-    struct Hdr {
-        Vec<NC> zi;
-        uint32_t o0, o1, act;
-        int64_t r, base;
-    };
-    auto load_hdr = [&](int64_t step) {
-        Hdr h;
-        h.r = step * RBW + w * RW + lane / G;  // rows past the end read row 0 and store nothing
-        const int64_t rr = h.r < P.n_rows ? h.r : 0;
-        h.zi = load_z<NC>(P.Z, P.row0 + rr);
-        const uint32_t* ob = offk + (rr >> 6) * (SCHED_RB + 1) + (rr & 63);
-        h.o0 = ob[0];
-        h.o1 = ob[1];
-        h.act = actk[rr];
-        h.base = P.blk_base[rr >> 6];
-        return h;
-    };
-    struct Lst { uint32_t j[U]; };
-    auto load_list = [&](const Hdr& h) {
-        Lst l;
-        const int npos = (int)(h.o1 - h.o0);
-        const int32_t* lst = P.list + h.base + h.o0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int i = u * G + gl;
-            l.j[u] = (uint32_t)lst[i < npos ? i : 0];
-        }
-        return l;
-    };
-
-    int64_t step = blockIdx.x;
-    if (step >= n_steps) return;
-    const int64_t stride = gridDim.x;
-    Hdr h0 = load_hdr(step);
-    Hdr h1 = load_hdr(step + stride);
-    Lst l0 = load_list(h0);
-    for (; step < n_steps; step += stride) {
-        const Hdr h2 = load_hdr(step + 2 * stride);
-        const Lst l1 = load_list(h1);
-        // ---- row set `step`: header h0, first-round list entries l0
-        const uint32_t gi = (uint32_t)(P.row0 + (h0.r < P.n_rows ? h0.r : 0));
-        const int npos = (int)(h0.o1 - h0.o0);
-        int n_use = (int)h0.act * P.neg_rate;
-        if (n_use > P.n_negatives) n_use = P.n_negatives;
-        const uint32_t rkey = neg_row_key(P.seed, P.iter, (int64_t)gi);
-        int nneg = pass_negative_count<G>(P, rkey, n_use, gl);
-        if (P.r_len == 0u) nneg = 0;
-        const uint32_t ckey = rkey + skey - (uint32_t)npos * 0x9E3779B9u;
-        const int total = npos + nneg;
-        float ga[NC], gr[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { ga[c] = 0.f; gr[c] = 0.f; }
-        int maxtot = total;
-#pragma unroll
-        for (int o = 32; o >= G; o >>= 1) maxtot = max(maxtot, __shfl_xor(maxtot, o, 64));
-        for (int base = 0; base < maxtot; base += U * G) {
-            uint32_t jn[U];
-            bool v[U], isp[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = base + u * G + gl;
-                v[u] = i < total;
-                isp[u] = i < npos;
-                uint32_t jl = l0.j[u];
-                if (base > 0) jl = (uint32_t)P.list[h0.base + h0.o0 + (isp[u] ? i : 0)];  // rows with > U*G fired edges (hubs)
-                const uint32_t x = mix32(ckey + (uint32_t)i * 0x9E3779B9u);
-                const uint32_t rr = P.r_lo + __umulhi(x, P.r_len);
-                const uint32_t jneg = rr + (rr >= gi ? 1u : 0u);
-                jn[u] = v[u] ? (isp[u] ? jl : jneg) : gi;
-            }
-            Vec<NC> zj[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) zj[u] = load_z<NC>(P.Z, (int64_t)jn[u]);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float df[NC];
-                const float d = sqdist<NC>(h0.zi, zj[u], df);
-                const float pb = fast_pow(d, P.b);
-                const float den = 1.0f + P.a * pb;
-                const float num = isp[u] ? pb * two_ab : m2b;
-                const float dd = isp[u] ? d : d + P.eps;
-                float coef = num * fast_rcp(dd * den);
-                if (!v[u] || (isp[u] && !(d > 0.f))) coef = 0.f;
-                const float ca = isp[u] ? coef : 0.f, cr = isp[u] ? 0.f : coef;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { ga[c] += ca * df[c]; gr[c] += cr * df[c]; }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { ga[c] = group_sum_dpp<G>(ga[c]); gr[c] = group_sum_dpp<G>(gr[c]); }
-        if (gl == 0 && h0.r < P.n_rows) {
-            float* acc = P.acc + (size_t)h0.r * 2 * NC;
-            if (P.slice > 0) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { ga[c] += acc[c]; gr[c] += acc[NC + c]; }
-            }
-            if (P.slice == P.S - 1) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    P.grad[(size_t)h0.r * NC + c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
-            } else {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) { acc[c] = ga[c]; acc[NC + c] = gr[c]; }
-            }
-        }
-        h0 = h1;
-        h1 = h2;
-        l0 = l1;
     }
 }
 
@@ -570,47 +450,25 @@ static void sched_pass_constants(SchedGradParams& P, int slice) {
     for (; level < 3; ++level) { P.lvl_xor[level] = 0; P.lvl_upper[level] = 0; }
 }
 
-template <int NC, int G, int U, bool NT = false>
+template <int NC, int G>
 static int launch_sched_grad(const SchedGradParams& P, hipStream_t st) {
     const int rpb = 256 / G;
     const dim3 grid((unsigned)((P.n_rows + rpb - 1) / rpb));
-    if (P.neg_inj) hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, U, true, false>), grid, dim3(256), 0, st, P);
-    else hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, U, false, NT>), grid, dim3(256), 0, st, P);
+    if (P.neg_inj) hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, true>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, false>), grid, dim3(256), 0, st, P);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TDR_OK : (int)e;
 }
 
-template <int NC, int G, int U>
-static int launch_sched_grad_pipe(const SchedGradParams& P, int wgs_per_cu, hipStream_t st) {
-    if (P.neg_inj) return launch_sched_grad<NC, G, 4>(P, st);  // injected negatives: the plain kernel
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const int64_t n_steps = (P.n_rows + (256 / G) - 1) / (256 / G);
-    int64_t grid = (int64_t)cus * wgs_per_cu;
-    if (grid > n_steps) grid = n_steps;
-    hipLaunchKernelGGL((umap_sched_grad_pipe_kernel<NC, G, U>), dim3((unsigned)grid), dim3(256), 0, st, P);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? TDR_OK : (int)e;
-}
-
-// geom: lane geometry knob (0 = default; the others are kept for ablations, tools/umap_sched_perf.py)
+// geom: lanes per row (0 = default 4: 16 items per round and row, 0.303 ms at N = 1M with 2 slices; 8 lanes 0.309,
+// 16 lanes 0.326, 2 lanes 0.319; 4 slices: 0.325 vs 0.375 with 8 lanes) -- ablation knob of tools/umap_sched_perf.py
 template <int NC>
 static int launch_sched_grad_geom(const SchedGradParams& P, int geom, hipStream_t st) {
     switch (geom) {
-        case 10: return launch_sched_grad_pipe<NC, 8, 4>(P, 8, st);
-        case 11: return launch_sched_grad_pipe<NC, 8, 5>(P, 8, st);
-        case 12: return launch_sched_grad_pipe<NC, 8, 4>(P, 6, st);
-        case 13: return launch_sched_grad_pipe<NC, 4, 8>(P, 6, st);
-        case 14: return launch_sched_grad_pipe<NC, 8, 5>(P, 5, st);
-        case 15: return launch_sched_grad_pipe<NC, 8, 4>(P, 16, st);
-        case 1: return launch_sched_grad<NC, 8, 2>(P, st);
-        case 2: return launch_sched_grad<NC, 16, 2>(P, st);
-        case 3: return launch_sched_grad<NC, 4, 4>(P, st);
-        case 4: return launch_sched_grad<NC, 4, 8>(P, st);
-        case 5: return launch_sched_grad<NC, 2, 8>(P, st);
-        case 6: return launch_sched_grad<NC, 8, 4, true>(P, st);
-        case 7: return launch_sched_grad<NC, 4, 4, true>(P, st);
-        default: return launch_sched_grad<NC, 8, 4>(P, st);
+        case 1: return launch_sched_grad<NC, 8>(P, st);
+        case 2: return launch_sched_grad<NC, 16>(P, st);
+        case 3: return launch_sched_grad<NC, 2>(P, st);
+        default: return launch_sched_grad<NC, 4>(P, st);
     }
 }
 
@@ -630,11 +488,10 @@ int tdr_umap_sched_slices(int64_t n_total, int nc) {
     return s;
 }
 
-/* uint32 entries of the `off` table for a window of block_iters iterations and n_slices slices. */
-int64_t tdr_umap_sched_off_entries(int64_t n_rows, int block_iters, int n_slices) {
+/* uint2 (8-byte) records of the `hdr` table for a window of block_iters iterations and n_slices slices. */
+int64_t tdr_umap_sched_hdr_entries(int64_t n_rows, int block_iters, int n_slices) {
     if (n_rows <= 0 || block_iters <= 0 || n_slices <= 0) return 0;
-    const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
-    return (int64_t)block_iters * n_slices * n_blocks * (SCHED_RB + 1);
+    return (int64_t)block_iters * n_slices * n_rows;
 }
 
 /* Static plan: blk_base (n_blocks + 1, n_blocks = ceil(n_rows / 64)) = exclusive scan of the blocks' list capacities for
@@ -665,21 +522,20 @@ int tdr_umap_sched_layout_f32(const int64_t* rowptr, const int32_t* cols, const 
 }
 
 /* Advance epoch_of_next_sample (`next`) by n_iters (<= 32) iterations starting at iteration t0 and emit the firing lists
- * (layout: file header).  err: device int, set to 1 if a block's region would overflow. */
+ * (layout: file header).  hdr: tdr_umap_sched_hdr_entries(...) 8-byte records.  err: device int, set to 1 if a block's
+ * region would overflow, 2 if a segment exceeds 65535 entries or the list 2^32 entries. */
 int tdr_umap_sched_build_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, float* next, int64_t n_rows,
                              int64_t n_total, int t0, int n_iters, int n_slices, const int64_t* blk_base, int32_t* list,
-                             uint32_t* off, uint16_t* act, int* err, void* stream) {
-    if (!rowptr || !cols || !eps_per || !next || !blk_base || !list || !off || !act || !err) return TDR_ERR_BAD_ARG;
+                             void* hdr, int* err, void* stream) {
+    if (!rowptr || !cols || !eps_per || !next || !blk_base || !list || !hdr || !err) return TDR_ERR_BAD_ARG;
     if (n_rows <= 0 || n_total < 2 || n_total >= 0x7fffffffLL || t0 < 0 || n_iters <= 0 || n_iters > SCHED_BMAX || t0 > (1 << 24) - 64) return TDR_ERR_BAD_ARG;
     if (n_slices != 1 && n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
     SchedBuildParams P;
     P.rowptr = rowptr; P.cols = cols; P.eps_per = eps_per; P.next = next; P.n_rows = n_rows;
     const uint32_t nred = (uint32_t)(n_total - 1);
     P.slice_step = (nred + (uint32_t)n_slices - 1u) / (uint32_t)n_slices;
-    P.t0 = t0; P.B = n_iters; P.S = n_slices; P.blk_base = blk_base; P.list = list; P.off = off;
+    P.t0 = t0; P.B = n_iters; P.S = n_slices; P.blk_base = blk_base; P.list = list; P.hdr = (uint2*)hdr; P.err = err;
     const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
-    P.off_stride = n_blocks * (SCHED_RB + 1);
-    P.act = act; P.err = err;
     const size_t lds = (size_t)n_iters * n_slices * CNT_STRIDE * sizeof(uint32_t);
     if (lds > 32 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_kernel),
@@ -694,21 +550,18 @@ int tdr_umap_sched_build_f32(const int64_t* rowptr, const int32_t* cols, const f
 /* One evaluation of UMAP's closed-form gradient (umap.py:236-292) for rows [row0, row0 + n_rows) from the lists of
  * tdr_umap_sched_build_f32: t_local = iteration index inside the window, n_iter = global iteration (hash counter).
  * acc: (n_rows, 2 nc) floats (used when n_slices > 1).  geom: 0 = default lane geometry (tuning / ablation knob). */
-int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int64_t* blk_base,
-                            const int32_t* list, const uint32_t* off, const uint16_t* act, int t_local, int n_slices,
-                            float a, float b, int n_iter, int neg_rate, int n_negatives, const int64_t* neg_inj,
-                            uint64_t seed, float exag, float rep, float eps, float* grad, float* acc, int geom,
-                            void* stream) {
-    if (!Z || !blk_base || !list || !off || !act || !grad || n_rows <= 0 || n_total < 2 || n_total >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
+int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list,
+                            const void* hdr, int t_local, int n_slices, float a, float b, int n_iter, int neg_rate,
+                            int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep, float eps,
+                            float* grad, float* acc, int geom, void* stream) {
+    if (!Z || !list || !hdr || !grad || n_rows <= 0 || n_total < 2 || n_total >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
     if (t_local < 0 || t_local >= SCHED_BMAX || neg_rate < 0 || n_negatives < 0) return TDR_ERR_BAD_ARG;
     if (n_slices != 1 && n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
     if (n_slices > 1 && !acc) return TDR_ERR_BAD_ARG;
     if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
     SchedGradParams P;
-    P.Z = Z; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.blk_base = blk_base; P.list = list; P.off = off;
-    const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
-    P.off_stride = n_blocks * (SCHED_RB + 1);
-    P.act = act; P.t_local = t_local; P.S = n_slices; P.a = a; P.b = b; P.neg_rate = neg_rate; P.n_negatives = n_negatives;
+    P.Z = Z; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.list = list; P.hdr = (const uint2*)hdr;
+    P.t_local = t_local; P.S = n_slices; P.a = a; P.b = b; P.neg_rate = neg_rate; P.n_negatives = n_negatives;
     P.neg_inj = neg_inj; P.seed = seed; P.iter = (uint32_t)n_iter; P.exag = exag; P.rep = rep; P.eps = eps; P.grad = grad;
     P.acc = acc;
     hipStream_t st = (hipStream_t)stream;

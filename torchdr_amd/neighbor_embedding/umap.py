@@ -153,8 +153,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         self._sched = {
             "B": B, "S": S, "blk_base": blk_base, "t0": None, "n": 0,
             "list": torch.empty(cap + 64, dtype=torch.int32, device=dev),  # slack: idle lanes read entry 0 of a segment
-            "off": torch.empty(int(L.tdr_umap_sched_off_entries(n_rows, B, S)), dtype=torch.int32, device=dev),
-            "act": torch.empty(B * n_rows, dtype=torch.int16, device=dev),
+            "hdr": torch.empty(2 * int(L.tdr_umap_sched_hdr_entries(n_rows, B, S)), dtype=torch.int32, device=dev),
             "err": torch.zeros(1, dtype=torch.int32, device=dev),
             "acc": torch.empty((n_rows, 2 * nc), dtype=torch.float32, device=dev) if S > 1 else None,
         }
@@ -173,8 +172,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                 L.tdr_umap_sched_build_f32(_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
                                            _lib.ptr(self.epoch_of_next_sample), self.chunk_size_, self.n_samples_in_,
                                            t, n, sc["S"], _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]),
-                                           _lib.ptr(sc["off"]), _lib.ptr(sc["act"]), _lib.ptr(sc["err"]),
-                                           _lib.stream_ptr()),
+                                           _lib.ptr(sc["hdr"]), _lib.ptr(sc["err"]), _lib.stream_ptr()),
                 "tdr_umap_sched_build_f32",
             )
             if PROFILE is not None:
@@ -187,8 +185,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         _lib.check(
             L.tdr_umap_sched_grad_f32(
                 _lib.ptr(self.embedding_), self.n_components, self.n_samples_in_, self.chunk_start_, self.chunk_size_,
-                _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]), _lib.ptr(sc["off"]), _lib.ptr(sc["act"]), t - sc["t0"],
-                sc["S"], float(self._a), float(self._b), t, int(self.negative_sample_rate), int(self.n_negatives),
+                _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), t - sc["t0"], sc["S"], float(self._a), float(self._b), t, int(self.negative_sample_rate), int(self.n_negatives),
                 _lib.ptr(neg), self._neg_seed, float(self.early_exaggeration_coeff_), float(self.repulsion_strength),
                 float(self._eps), _lib.ptr(grad), _lib.ptr(sc["acc"]), int(SCHED_GEOM), _lib.stream_ptr(),
             ),
@@ -202,7 +199,8 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         super()._raise_if_nan()
         sc = getattr(self, "_sched", None)
         if sc is not None and int(sc["err"].item()) != 0:
-            raise RuntimeError("[torchdr_amd] UMAP: a schedule block overflowed its list region (internal error).")
+            raise RuntimeError("[torchdr_amd] UMAP: schedule build failed (list region overflow, a segment beyond 65535 "
+                               "entries or a list beyond 2^32 entries); set neighbor_embedding.umap.SCHEDULED = False.")
 
     def _compute_gradients(self):
         csr: CSRAffinity = self._csr
