@@ -158,6 +158,23 @@ int tdr_sym_fill_f32(int64_t n, int k, int64_t row_offset, int mode, const int32
 int tdr_csr_to_padded_f32(const int64_t* rowptr, const int32_t* cols, const float* vals, int64_t n, int64_t width,
                           float* pv, int64_t* pi, void* stream);
 
+/* ---- K0: the steps either side of the path inside fit_transform (csrc/tdr_prep.hip) ---------------------------- */
+/* utils/validation.py:308 (torch.isfinite(X).all()): *count (device uint64, caller-zeroed) += number of inf / nan entries */
+int tdr_nonfinite_count_f32(const float* X, int64_t n, int d, int64_t ldx, void* count, void* stream);
+/* base.py:132-148 (torch.unique(X, dim=0, return_inverse=True)): rep (n) int32 = smallest index of a row equal to row i;
+ * counters (2 x uint32, device) = {rows duplicating an earlier row, rows whose 64-bit hash collided with a different
+ * row (rep is then not reliable: use an exact method)}.  ws: tdr_dedup_workspace_bytes(n). */
+int64_t tdr_dedup_workspace_bytes(int64_t n);
+int tdr_dedup_rows_f32(const float* X, int64_t n, int d, int64_t ldx, int32_t* rep, void* counters, void* ws, int64_t ws_bytes,
+                       void* stream);
+/* spectral_embedding/pca.py:151-184: column means (d fp32) and the Gram matrix of the centred block (d x d fp64) on the
+ * fp32 matrix pipe (d <= 256), and the projection E (n, nc <= 4) = (X - mean) V. */
+int64_t tdr_pca_gram_workspace_floats(int64_t n, int d);
+int tdr_pca_gram_f32(const float* X, int64_t n, int d, int64_t ldx, float* mean, double* G, float* ws, int64_t ws_floats,
+                     void* stream);
+int tdr_pca_project_f32(const float* X, int64_t n, int d, int64_t ldx, const float* mean, const float* V, int nc, float* E,
+                        void* stream);
+
 /* ---- K5 / K6 / K9: embedding loop ----------------------------------------------------------------- */
 /* neighbor_embedding/umap.py:215-234 */
 int tdr_umap_prepare_f32(const float* vals, int64_t nnz, int max_iter, float* eps_per, float* next, void* scratch,

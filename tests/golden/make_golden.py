@@ -485,13 +485,45 @@ def cosne_fixture():
     save("cosne", **out)
 
 
+def c1_tsne_fixture():
+    """BASELINE config C1 at full size: TSNE on the 5000 x 50 Gaussian mixture, perplexity 30, backend=None (CPU):
+    the reference's first two optimisation steps (embedding before / gradient / after, lr, momentum, exaggeration) and
+    the entropic bandwidths.  X itself is regenerated by the test (tests.conftest.gmm, same seed)."""
+    from torchdr import TSNE
+
+    X = gmm(5000, 50, 2.0, seed=42)
+    rec = {}
+
+    class Probe(TSNE):
+        def _training_step(self):
+            t = int(self.n_iter_)
+            if t < 2:
+                rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                rec[f"lr_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["lr"]))
+                rec[f"mom_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["momentum"]))
+                rec[f"exag_{t}"] = torch.tensor(float(self.early_exaggeration_coeff_))
+                if t == 0:
+                    rec["eps"] = self.affinity_in.eps_.detach().clone()
+                    rec["NN_head"] = self.NN_indices_[:, :8].to(torch.int32).clone()
+            loss = super()._training_step()
+            if t < 2:
+                rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+                rec[f"loss_{t}"] = loss.detach().clone()
+            return loss
+
+    torch.manual_seed(3)
+    Probe(perplexity=30, max_iter=3, backend=None, random_state=3).fit_transform(X)
+    save("c1_tsne", **rec)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ALL = dict(knn=knn_fixtures, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
                umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne2_step=ne2_step_fixture,
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
-               cosne=cosne_fixture, hyperbolic=hyperbolic_fixture)
+               cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

@@ -1,0 +1,88 @@
+"""K0 (csrc/tdr_prep.hip): the steps either side of the hot path inside fit_transform -- isfinite scan
+(utils/validation.py:308), duplicate rows (base.py:132-148, torch.unique(dim=0)), PCA initialisation
+(spectral_embedding/pca.py:151-184) -- against their torch formulations."""
+
+import pytest
+import torch
+
+from tests.conftest import gmm
+
+pytestmark = pytest.mark.gpu
+
+
+def test_nonfinite_scan_counts_what_isfinite_rejects():
+    from torchdr_amd.utils.validation import count_nonfinite, validate_tensor
+
+    gen = torch.Generator().manual_seed(0)
+    for n, d in ((1, 1), (7, 3), (1000, 127), (4097, 128), (33, 1025)):
+        X = torch.randn(n, d, generator=gen)
+        bad = torch.rand(n, d, generator=gen) < 0.01
+        X[bad] = float("inf")
+        X[torch.rand(n, d, generator=gen) < 0.005] = float("nan")
+        X[torch.rand(n, d, generator=gen) < 0.005] = -float("inf")
+        want = int((~torch.isfinite(X)).sum())
+        assert count_nonfinite(X.cuda()) == want
+        wide = torch.zeros(n, d + 5)
+        wide[:, :d] = X
+        assert count_nonfinite(wide.cuda()[:, :d]) == want          # row stride > d
+        assert count_nonfinite(X.cuda().T) == want                    # non-unit inner stride: counted by torch
+    ok = torch.randn(100, 8).cuda()
+    assert validate_tensor(ok) is ok
+    ok[17, 3] = float("nan")
+    with pytest.raises(ValueError, match="infinite"):
+        validate_tensor(ok)
+
+
+def test_duplicate_rows_are_found_like_torch_unique():
+    from torchdr_amd.base import unique_rows
+
+    gen = torch.Generator().manual_seed(1)
+    X = torch.randn(5000, 24, generator=gen)
+    X[100:140] = X[:40]                 # duplicates of earlier rows
+    X[4000] = X[4999] = X[2500]         # a triple
+    X[7, 3] = 0.0
+    X[3000] = X[7]
+    X[3000, 3] = -0.0                   # equal by value (-0.0 == 0.0), different bits
+    Xu, inv = unique_rows(X.cuda())
+    ref_u, ref_inv = torch.unique(X, dim=0, return_inverse=True)
+    assert Xu.shape[0] == ref_u.shape[0] == 5000 - 39 - 2 - 1   # row 107 stopped duplicating row 7 when X[7, 3] changed
+    assert bool((Xu[inv].cpu() == X).all())   # re-expansion gives back every row (by value: -0.0 == 0.0)
+    # same partition into groups of equal rows as torch.unique, and first occurrences keep their order
+    same_ref = ref_inv[:, None] == ref_inv[None, :100]
+    same_got = inv.cpu()[:, None] == inv.cpu()[None, :100]
+    assert torch.equal(same_ref, same_got)
+    first = torch.tensor([int((inv.cpu() == g).nonzero()[0]) for g in range(0, Xu.shape[0], 97)])
+    assert bool((first[1:] > first[:-1]).all())
+    # no duplicates: the input itself comes back
+    Y = torch.randn(3000, 16, generator=gen).cuda()
+    Yu, none = unique_rows(Y)
+    assert none is None and Yu.data_ptr() == Y.data_ptr()
+
+
+def test_pca_initialisation_matches_the_torch_formulation():
+    from torchdr_amd import _lib
+    from torchdr_amd.affinity_matcher import pca_scores
+
+    for n, d in ((5000, 50), (20000, 128), (3000, 200), (1000, 256), (500, 7)):
+        X = gmm(n, d, 2.0, seed=n).cuda()
+        L = _lib.lib()
+        mean = torch.empty(d, device="cuda")
+        G = torch.empty((d, d), dtype=torch.float64, device="cuda")
+        wsf = int(L.tdr_pca_gram_workspace_floats(n, d))
+        ws = torch.empty(wsf, device="cuda")
+        _lib.check(L.tdr_pca_gram_f32(_lib.ptr(X), n, d, X.stride(0), _lib.ptr(mean), _lib.ptr(G), _lib.ptr(ws), wsf,
+                                      _lib.stream_ptr()), "gram")
+        Xd = X.double()
+        mu = Xd.mean(0)
+        Gd = (Xd - mu).T @ (Xd - mu)
+        assert torch.allclose(mean.double(), mu, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(G, Gd, rtol=1e-4, atol=1e-4 * float(Gd.abs().max()))
+        assert torch.equal(G, G.T.contiguous()) or torch.allclose(G, G.T, rtol=1e-6)
+        # scores: same subspace and signs as the SVD route of the reference (pca.py:169-178, svd_flip u-based)
+        E = pca_scores(X, 2)
+        U, S, Vt = torch.linalg.svd(Xd - mu, full_matrices=False)
+        ref = U[:, :2] * S[:2]
+        idx = ref.abs().argmax(0)
+        sg = torch.sign(ref[idx, torch.arange(2, device="cuda")])
+        ref = ref * sg
+        assert torch.allclose(E.double(), ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max())), (n, d)

@@ -356,15 +356,34 @@ def pca_scores(X: torch.Tensor, n_components: int) -> torch.Tensor:
     """PCA scores U*S of the centred data with the reference's sign convention
     (spectral_embedding/pca.py:169-178 + utils/utils.py:292-298 ``svd_flip``, u-based).
 
-    Computed from the D x D covariance eigen-decomposition (one GEMM + a tiny eigh) instead of a
-    thin SVD of the N x D block: same subspace and signs, O(N D^2) on the GPU.  Initialisation
-    only -- the scores are rescaled to std 1e-4 right after (A.5)."""
-    mean = X.mean(0, keepdim=True)
-    Xc = X - mean
-    cov = Xc.T @ Xc
-    evals, evecs = torch.linalg.eigh(cov.double())
-    V = evecs[:, -n_components:].flip(1).to(X.dtype)  # top components, descending
-    E = Xc @ V
+    Computed from the D x D covariance eigen-decomposition instead of a thin SVD of the N x D block: column means and
+    the Gram matrix of the centred block by ``tdr_pca_gram_f32`` (fp32 matrix pipe, deterministic fp64 combination), a
+    D x D ``eigh`` (the one library call left: a tiny dense eigenproblem), and the projection by
+    ``tdr_pca_project_f32``.  Same subspace and signs, O(N D^2) on the GPU.  Initialisation only -- the scores are
+    rescaled to std 1e-4 right after (A.5).  D > 256 or more than 4 components use torch ops."""
+    n, d = X.shape
+    if d > 256 or n_components > 4 or not X.is_cuda or X.dtype != torch.float32:
+        mean = X.mean(0, keepdim=True)
+        Xc = X - mean
+        cov = Xc.T @ Xc
+        evals, evecs = torch.linalg.eigh(cov.double())
+        V = evecs[:, -n_components:].flip(1).to(X.dtype)
+        E = Xc @ V
+    else:
+        if X.stride(1) != 1:
+            X = X.contiguous()
+        L = _lib.lib()
+        mean = torch.empty(d, dtype=torch.float32, device=X.device)
+        G = torch.empty((d, d), dtype=torch.float64, device=X.device)
+        ws_floats = int(L.tdr_pca_gram_workspace_floats(n, d))
+        ws = torch.empty(ws_floats, dtype=torch.float32, device=X.device)
+        _lib.check(L.tdr_pca_gram_f32(_lib.ptr(X), n, d, X.stride(0), _lib.ptr(mean), _lib.ptr(G), _lib.ptr(ws), ws_floats,
+                                      _lib.stream_ptr()), "tdr_pca_gram_f32")
+        evals, evecs = torch.linalg.eigh(G)
+        V = evecs[:, -n_components:].flip(1).to(torch.float32).contiguous()  # top components, descending
+        E = torch.empty((n, n_components), dtype=torch.float32, device=X.device)
+        _lib.check(L.tdr_pca_project_f32(_lib.ptr(X), n, d, X.stride(0), _lib.ptr(mean), _lib.ptr(V), n_components, _lib.ptr(E),
+                                         _lib.stream_ptr()), "tdr_pca_project_f32")
     idx = E.abs().argmax(0)
     signs = torch.sign(E[idx, torch.arange(E.shape[1], device=E.device)])
     signs = torch.where(signs == 0, torch.ones_like(signs), signs)

@@ -12,6 +12,41 @@ from sklearn.base import BaseEstimator
 from torchdr_amd.utils import handle_input_output, seed_everything, set_logger
 
 
+def unique_rows(X: torch.Tensor, device="auto"):
+    """Duplicate-row removal of ``fit_transform`` (reference base.py:133: ``torch.unique(X, dim=0, return_inverse=True)``).
+    Returns ``(X_unique, inverse)`` with ``inverse = None`` when every row is unique (the common case: X is returned as it
+    is, on the compute device).  Duplicates are FOUND by 64-bit row hashes in an open-addressing table plus an exact
+    row compare (``tdr_dedup_rows_f32``: one pass over X instead of the lexicographic merge sort of the N x D block);
+    the unique rows keep their original order (the reference's sorted order only relabels the points: the embedding is
+    re-expanded through ``inverse`` either way).  A 64-bit hash collision between different rows (probability ~N^2/2^65)
+    falls back to the exact sort."""
+    from torchdr_amd import _lib
+    from torchdr_amd.utils import compute_device
+
+    if X.dim() != 2 or X.dtype != torch.float32 or X.shape[0] < 2:
+        return X, None
+    X = X.to(compute_device(X, device))
+    if X.stride(1) != 1:
+        X = X.contiguous()
+    n, d = X.shape
+    L = _lib.lib()
+    ws_bytes = int(L.tdr_dedup_workspace_bytes(n))
+    ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=X.device)
+    rep = torch.empty(n, dtype=torch.int32, device=X.device)
+    counters = torch.zeros(2, dtype=torch.int32, device=X.device)
+    _lib.check(L.tdr_dedup_rows_f32(_lib.ptr(X), n, d, X.stride(0), _lib.ptr(rep), _lib.ptr(counters), _lib.ptr(ws), ws_bytes,
+                                    _lib.stream_ptr()), "tdr_dedup_rows_f32")
+    n_dup, n_collide = (int(v) for v in counters.tolist())
+    if n_collide:
+        X_unique, inverse = torch.unique(X, dim=0, return_inverse=True)
+        return (X_unique, inverse) if X_unique.shape[0] < n else (X, None)
+    if n_dup == 0:
+        return X, None
+    keep = rep == torch.arange(n, dtype=torch.int32, device=X.device)
+    new_index = keep.long().cumsum(0) - 1
+    return X[keep], new_index[rep.long()]
+
+
 class DRModule(BaseEstimator, nn.Module, ABC):
     def __init__(self, n_components: int = 2, device: str = "auto", backend=None, verbose: bool = False,
                  random_state: Optional[float] = None, compile: bool = False, process_duplicates: bool = True,
@@ -42,18 +77,15 @@ class DRModule(BaseEstimator, nn.Module, ABC):
         (reference base.py:132-148)."""
         in_dtype = X.dtype
         X = as_float32(X)  # float64 in -> computed in float32 -> float64 out
+        inverse = None
         if self.process_duplicates:
-            X_unique, inverse = torch.unique(X, dim=0, return_inverse=True)
-            if X_unique.shape[0] < X.shape[0]:
+            X, inverse = unique_rows(X, self.device)
+            if inverse is not None:
                 self.logger.info(
-                    f"Detected {X.shape[0] - X_unique.shape[0]} duplicate samples, performing DR on unique data."
+                    f"Detected {inverse.numel() - X.shape[0]} duplicate samples, performing DR on unique data."
                 )
-                emb = self._fit_transform(X_unique, y=y)
-                self.embedding_ = emb[inverse.to(emb.device)]
-            else:
-                self.embedding_ = self._fit_transform(X, y=y)
-        else:
-            self.embedding_ = self._fit_transform(X, y=y)
+        emb = self._fit_transform(X, y=y)
+        self.embedding_ = emb if inverse is None else emb[inverse.to(emb.device)]
         if in_dtype == torch.float64:
             self.embedding_ = self.embedding_.to(torch.float64)
         self.is_fitted_ = True

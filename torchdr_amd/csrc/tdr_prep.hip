@@ -1,0 +1,306 @@
+// K0 -- the steps either side of the hot path inside fit_transform, on the device:
+//   utils/validation.py:308           torch.isfinite(X).all()                -> nonfinite_count_kernel
+//   base.py:132-148                   torch.unique(X, dim=0, return_inverse) -> row hashes + open-addressing table + exact
+//                                                                               row compare (the lexicographic merge sort
+//                                                                               of the N x D block is not needed to FIND
+//                                                                               duplicates)
+//   spectral_embedding/pca.py:151-184 PCA initialisation: column means, the D x D Gram matrix of the centred block on
+//                                     the fp32 matrix pipe, projection on the leading eigenvectors (the D x D
+//                                     eigen-decomposition itself stays a library call on a tiny matrix)
+#include "tdr_common.h"
+
+namespace tdr {
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
+// ---- isfinite scan: number of inf / nan entries of an (n, d) block -------------------------------------------------
+__global__ __launch_bounds__(256) void nonfinite_count_kernel(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                              unsigned long long* __restrict__ count) {
+    unsigned bad = 0;
+    if (ldx == d && (((uintptr_t)X) & 15) == 0) {  // dense block: 16-byte reads over the flat range
+        const int64_t total = n * (int64_t)d, n4 = total >> 2;
+        const uint4* X4 = reinterpret_cast<const uint4*>(X);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            const uint4 v = X4[i];
+            bad += ((v.x & 0x7f800000u) == 0x7f800000u) + ((v.y & 0x7f800000u) == 0x7f800000u) +
+                   ((v.z & 0x7f800000u) == 0x7f800000u) + ((v.w & 0x7f800000u) == 0x7f800000u);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (total & 3))
+            bad += (__float_as_uint(X[(n4 << 2) + threadIdx.x]) & 0x7f800000u) == 0x7f800000u;
+    } else {
+        const int64_t total = n * (int64_t)d;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+            const int64_t r = i / d;
+            bad += (__float_as_uint(X[r * ldx + (i - r * d)]) & 0x7f800000u) == 0x7f800000u;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, (unsigned long long)bad);
+}
+
+// ---- duplicate rows ---------------------------------------------------------------------------------------------------
+// 64-bit hash of every row (one wavefront per row): position-keyed mixes of the element bits, summed.  -0.0 hashes as
+// +0.0 (torch.unique compares values); the result is never 0 (0 marks an empty table slot).
+__global__ __launch_bounds__(256) void row_hash_kernel(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                       uint64_t* __restrict__ hash) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    uint64_t h = 0;
+    for (int c = lane; c < d; c += 64) {
+        const float x = X[row * ldx + c];
+        const uint32_t b = (x == 0.f) ? 0u : __float_as_uint(x);
+        h += mix64(((uint64_t)(uint32_t)c << 32 | b) + 0x9E3779B97F4A7C15ull);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h += __shfl_xor(h, o, 64);
+    h = mix64(h);
+    if (lane == 0) hash[row] = h ? h : 1ull;
+}
+
+// insert every row's hash into an open-addressing table (linear probing); the slot remembers the smallest row index
+__global__ __launch_bounds__(256) void dedup_insert_kernel(const uint64_t* __restrict__ hash, int64_t n,
+                                                           unsigned long long* __restrict__ table, int* __restrict__ slot_rep,
+                                                           int log2size, int* __restrict__ slot_of) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long h = hash[i];
+    const uint64_t mask = ((uint64_t)1 << log2size) - 1;
+    uint64_t slot = (h * 0x9E3779B97F4A7C15ull) >> (64 - log2size);
+    for (;;) {
+        const unsigned long long prev = atomicCAS(&table[slot], 0ull, h);
+        if (prev == 0ull || prev == h) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicMin(&slot_rep[slot], (int)i);
+    slot_of[i] = (int)slot;
+}
+
+// rep[i] = smallest row index whose row equals row i (i itself for first occurrences).  A row whose hash slot is led
+// by a DIFFERENT row (a 64-bit collision) is counted in counters[1]; the caller then falls back to the exact sort.
+__global__ __launch_bounds__(256) void dedup_resolve_kernel(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                            const int* __restrict__ slot_of, const int* __restrict__ slot_rep,
+                                                            int* __restrict__ rep, unsigned* __restrict__ counters) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = slot_rep[slot_of[i]];
+    if (r == (int)i) { rep[i] = (int)i; return; }
+    bool same = true;
+    for (int c = 0; c < d && same; ++c) same = X[i * ldx + c] == X[(int64_t)r * ldx + c];
+    rep[i] = same ? r : (int)i;
+    atomicAdd(&counters[same ? 0 : 1], 1u);
+}
+
+// ---- PCA initialisation ---------------------------------------------------------------------------------------------
+// column sums of a row strip per workgroup (thread = column, fp32 over <= rows_per_wg rows), combined in fixed order
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                             int64_t rows_per_wg, float* __restrict__ partial) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < n) ? r0 + rows_per_wg : n;
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += X[r * ldx + c];
+        partial[(size_t)blockIdx.x * d + c] = s;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int n_wg, int d, double inv_n,
+                                                           float* __restrict__ mean) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= d) return;
+    double s = 0.0;
+    for (int w = 0; w < n_wg; ++w) s += (double)partial[(size_t)w * d + c];
+    mean[c] = (float)(s * inv_n);
+}
+
+// Gram matrix of the centred block, G = sum_k (x_k - mean)(x_k - mean)^T, per workgroup over its row strip: DT
+// wavefronts, wavefront w owns the 32-row band m0 = 32 w of G (DT accumulator tiles); strips of 32 rows go through LDS
+// and v_mfma_f32_32x32x2_f32 contracts two rows per instruction (A[m][k] = xc[k][m0 + m], B[k][n] = xc[k][n0 + n]).
+template <int DT>
+__global__ __launch_bounds__(64 * DT) void gram_partial_kernel(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                               const float* __restrict__ mean, int64_t rows_per_wg,
+                                                               float* __restrict__ partial) {
+    constexpr int W = 32 * DT;
+    __shared__ float tile[32 * W];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    f32x16 acc[DT];
+#pragma unroll
+    for (int j = 0; j < DT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < n) ? r0 + rows_per_wg : n;
+    for (int64_t rt = r0; rt < r1; rt += 32) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 32 * W; e += 64 * DT) {
+            const int rr = e / W, c = e - rr * W;
+            const int64_t row = rt + rr;
+            tile[e] = (row < r1 && c < d) ? X[row * ldx + c] - mean[c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const float a = tile[(2 * s + h) * W + 32 * w + i];
+#pragma unroll
+            for (int j = 0; j < DT; ++j) {
+                const float b = tile[(2 * s + h) * W + 32 * j + i];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * W * W;
+#pragma unroll
+    for (int j = 0; j < DT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[(size_t)m * W + 32 * j + i] = acc[j][r];
+        }
+}
+__global__ __launch_bounds__(256) void gram_final_kernel(const float* __restrict__ partial, int n_wg, int W, int d,
+                                                         double* __restrict__ G) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= d * d) return;
+    const int m = e / d, c = e - m * d;
+    double s = 0.0;
+    for (int w = 0; w < n_wg; ++w) s += (double)partial[(size_t)w * W * W + (size_t)m * W + c];
+    G[e] = s;
+}
+
+// scores E = (X - mean) V for nc <= 4 components, one wavefront per row
+__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                      const float* __restrict__ mean, const float* __restrict__ V, int nc,
+                                                      float* __restrict__ E) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane; c < d; c += 64) {
+        const float x = X[row * ldx + c] - mean[c];
+        for (int k = 0; k < nc; ++k) s[k] += x * V[(size_t)c * nc + k];
+    }
+    for (int k = 0; k < nc; ++k) {
+        const float t = wave_sum(s[k]);
+        if (lane == 0) E[row * nc + k] = t;
+    }
+}
+
+}  // namespace tdr
+
+using namespace tdr;
+
+extern "C" {
+
+/* utils/validation.py:308: *count (device uint64, caller-zeroed) += number of inf / nan entries of the (n, d) block. */
+int tdr_nonfinite_count_f32(const float* X, int64_t n, int d, int64_t ldx, void* count, void* stream) {
+    if (!X || !count || n <= 0 || d <= 0 || ldx < d) return TDR_ERR_BAD_ARG;
+    int64_t blocks = (n * (int64_t)d / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(nonfinite_count_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, X, n, d, ldx,
+                       (unsigned long long*)count);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* workspace of tdr_dedup_rows_f32 in bytes */
+int64_t tdr_dedup_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    int log2size = 4;
+    while (((int64_t)1 << log2size) < 2 * n) ++log2size;
+    return n * 8 + ((int64_t)1 << log2size) * (8 + 4) + n * 4;
+}
+
+/* base.py:132-148 (torch.unique(dim=0)): rep (n) int32 = smallest index of a row equal to row i; counters (2 x uint32,
+ * device) = {rows that duplicate an earlier row, rows whose 64-bit hash collided with a different row (then rep is not
+ * reliable and the caller must use an exact method)}.  n < 2^31. */
+int tdr_dedup_rows_f32(const float* X, int64_t n, int d, int64_t ldx, int32_t* rep, void* counters, void* ws, int64_t ws_bytes,
+                       void* stream) {
+    if (!X || !rep || !counters || !ws || n <= 0 || d <= 0 || ldx < d || n >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
+    if (ws_bytes < tdr_dedup_workspace_bytes(n)) return TDR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int log2size = 4;
+    while (((int64_t)1 << log2size) < 2 * n) ++log2size;
+    const int64_t slots = (int64_t)1 << log2size;
+    uint64_t* hash = (uint64_t*)ws;
+    unsigned long long* table = (unsigned long long*)(hash + n);
+    int* slot_rep = (int*)(table + slots);
+    int* slot_of = slot_rep + slots;
+    hipError_t e = hipMemsetAsync(table, 0, slots * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(slot_rep, 0x7f, slots * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 8, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(row_hash_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, X, n, d, ldx, hash);
+    hipLaunchKernelGGL(dedup_insert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint64_t*)hash, n, table,
+                       slot_rep, log2size, slot_of);
+    hipLaunchKernelGGL(dedup_resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, n, d, ldx,
+                       (const int*)slot_of, (const int*)slot_rep, rep, (unsigned*)counters);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* workspace (floats) of tdr_pca_gram_f32 */
+int64_t tdr_pca_gram_workspace_floats(int64_t n, int d) {
+    if (n <= 0 || d <= 0 || d > 256) return 0;
+    const int W = 32 * ((d + 31) / 32);
+    int64_t n_wg = (n + 4095) / 4096;
+    if (n_wg > 512) n_wg = 512;
+    return n_wg * ((int64_t)W * W + d);
+}
+
+/* spectral_embedding/pca.py:151-160: mean (d) fp32 = column means, G (d, d) fp64 = Gram matrix of the centred block
+ * (deterministic: fixed partition into row strips, partial results combined in order).  d <= 256. */
+int tdr_pca_gram_f32(const float* X, int64_t n, int d, int64_t ldx, float* mean, double* G, float* ws, int64_t ws_floats,
+                     void* stream) {
+    if (!X || !mean || !G || !ws || n <= 0 || d <= 0 || ldx < d) return TDR_ERR_BAD_ARG;
+    if (d > 256) return TDR_ERR_UNSUPPORTED;
+    if (ws_floats < tdr_pca_gram_workspace_floats(n, d)) return TDR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int DT = (d + 31) / 32, W = 32 * DT;
+    int64_t n_wg = (n + 4095) / 4096;
+    if (n_wg > 512) n_wg = 512;
+    int64_t rows_per_wg = (n + n_wg - 1) / n_wg;
+    rows_per_wg = (rows_per_wg + 31) / 32 * 32;
+    n_wg = (n + rows_per_wg - 1) / rows_per_wg;
+    float* part_g = ws;
+    float* part_s = ws + n_wg * (int64_t)W * W;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, X, n, d, ldx, rows_per_wg, part_s);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, (const float*)part_s, (int)n_wg, d,
+                       1.0 / (double)n, mean);
+#define TDR_GRAM(DTV)                                                                                                    \
+    hipLaunchKernelGGL(gram_partial_kernel<DTV>, dim3((unsigned)n_wg), dim3(64 * DTV), 0, st, X, n, d, ldx, (const float*)mean, \
+                       rows_per_wg, part_g)
+    switch (DT) {
+        case 1: TDR_GRAM(1); break;
+        case 2: TDR_GRAM(2); break;
+        case 3: TDR_GRAM(3); break;
+        case 4: TDR_GRAM(4); break;
+        case 5: TDR_GRAM(5); break;
+        case 6: TDR_GRAM(6); break;
+        case 7: TDR_GRAM(7); break;
+        default: TDR_GRAM(8); break;
+    }
+#undef TDR_GRAM
+    hipLaunchKernelGGL(gram_final_kernel, dim3((unsigned)((d * d + 255) / 256)), dim3(256), 0, st, (const float*)part_g, (int)n_wg, W,
+                       d, G);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* spectral_embedding/pca.py:171-178: E (n, nc) = (X - mean) V, V (d, nc) row-major, nc <= 4. */
+int tdr_pca_project_f32(const float* X, int64_t n, int d, int64_t ldx, const float* mean, const float* V, int nc, float* E,
+                        void* stream) {
+    if (!X || !mean || !V || !E || n <= 0 || d <= 0 || ldx < d || nc <= 0) return TDR_ERR_BAD_ARG;
+    if (nc > 4) return TDR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(project_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X, n, d, ldx, mean, V, nc, E);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+}  // extern "C"
