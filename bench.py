@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--max-iter", type=int, default=1000)
     ap.add_argument("--scale", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loop", choices=["auto", "graph", "c", "python"], default="auto",
+                    help="UMAP loop driver: replayed HIP graphs (default), plain launches from the C loop object, or one Python iteration per step")
     args = ap.parse_args()
 
     from torchdr_amd.distributed import init_from_env
@@ -117,6 +119,9 @@ def main():
     from torchdr_amd.distance import base as dbase
     from torchdr_amd.neighbor_embedding import umap as umod
 
+    if args.loop != "auto":
+        umod.LOOP_RUNNER = args.loop != "python"
+        umod.LOOP_GRAPH = args.loop == "graph"
     X_cpu = gmm(args.n, args.d, args.scale)
     X = X_cpu.to(dev)
     torch.cuda.synchronize()
@@ -161,6 +166,7 @@ def main():
     def one_step(record):
         dbase.PROFILE = [] if record else None
         umod.PROFILE = [] if record else None
+        umod.LOOP_PROFILE = [] if record else None
         m = UMAP(n_neighbors=args.k, max_iter=args.max_iter, random_state=0, backend=None)
         if record:
             _orig = m.clear_memory
@@ -177,16 +183,18 @@ def main():
     for _ in range(args.warmup):
         one_step(False)
     barrier()
-    knn_events, grad_events = [], []
+    knn_events, grad_events, loop_events = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(True)
         knn_events.extend(dbase.PROFILE)
         grad_events.extend(umod.PROFILE)
+        loop_events.extend(umod.LOOP_PROFILE)
     barrier()
     elapsed = time.perf_counter() - t0
     dbase.PROFILE = None
     umod.PROFILE = None
+    umod.LOOP_PROFILE = None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if distributed:
@@ -212,12 +220,22 @@ def main():
     #     measured nnz and the expected 8.6 active edges / 43 used negatives per row and iteration.
     #     Scheduled loop: one evaluation = S slice passes of umap_sched_grad_kernel + 1/n_iters of a schedule build
     #     (umap_sched_build_kernel advances the epoch counters 32 iterations at a time); every build is timed.
-    grad_ms = [e[1].elapsed_time(e[2]) for e in grad_events if e[0] == "grad"]
-    build_ms = [e[1].elapsed_time(e[2]) / e[3] for e in grad_events if e[0] == "build"]
-    build_avg_ms = sum(build_ms) / max(len(build_ms), 1)      # amortised per iteration
-    grad_only_ms = sum(grad_ms) / max(len(grad_ms), 1)
-    grad_avg_ms = grad_only_ms + build_avg_ms
-    nnz = next((e[3] for e in grad_events if e[0] == "grad"), 0)
+    #     Loop runner (default): HIP events around every segment of the loop (a segment = the iterations between two
+    #     convergence checks, ~check_interval of them, executed as replayed window graphs): one "evaluation" = one whole
+    #     iteration = 1/n of its window's schedule build + S gradient passes + the SGD step.
+    if loop_events:
+        seg = [(e[0].elapsed_time(e[1]), e[2]) for e in loop_events if e[2] > 1]
+        grad_avg_ms = sum(t for t, _ in seg) / max(sum(n for _, n in seg), 1)
+        grad_only_ms, build_avg_ms, n_sampled = None, None, sum(n for _, n in seg)
+        nnz = loop_events[0][3]
+    else:
+        grad_ms = [e[1].elapsed_time(e[2]) for e in grad_events if e[0] == "grad"]
+        build_ms = [e[1].elapsed_time(e[2]) / e[3] for e in grad_events if e[0] == "build"]
+        build_avg_ms = sum(build_ms) / max(len(build_ms), 1)      # amortised per iteration
+        grad_only_ms = sum(grad_ms) / max(len(grad_ms), 1)
+        grad_avg_ms = grad_only_ms + build_avg_ms
+        n_sampled = len(grad_ms)
+        nnz = next((e[3] for e in grad_events if e[0] == "grad"), 0)
     rows = (args.n + world - 1) // world
     grad_bytes = 12.0 * nnz + rows * (8.6 * 12.0 + 43.0 * 8.0 + 16.0)
     grad_gbs = grad_bytes / (grad_avg_ms * 1e-3) / 1e9 if grad_avg_ms > 0 else 0.0
@@ -246,12 +264,12 @@ def main():
                                         "not matrix-pipe utilisation" if path.endswith("pruned") else "")),
     }
     roof_grad = {
-        "kernel": ("S x tdr::umap_sched_grad_kernel<2,4,false> (one pass per L2 slice of the embedding) + 1/32 of "
-                   "tdr::umap_sched_build_kernel (one gradient evaluation)" if umod.SCHEDULED else
+        "kernel": ("one UMAP iteration = S x tdr::umap_sched_grad_kernel<2,4,false> (one pass per L2 slice of the embedding) "
+                   "+ tdr::sgd_table_step_kernel + 1/32 of tdr::umap_sched_build_kernel" if umod.SCHEDULED else
                    "tdr::umap_grad_kernel<2,16,4,true> + 2 x tdr::umap_neg_dense_kernel<2,8,2> (one gradient evaluation)"),
         "bound": "hbm", "achieved": grad_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_gbs / HBM_PEAK_GBS,
         "traffic": pmc_traffic("r02_umap_sched_pmc.json" if umod.SCHEDULED else "r01_umap_grad_pmc.json"),
-        "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_avg_ms, "evaluations_sampled": len(grad_ms),
+        "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_avg_ms, "evaluations_sampled": n_sampled,
         "grad_passes_ms": grad_only_ms, "schedule_build_ms_per_iteration": build_avg_ms,
         "note": ("algorithmic bytes = SURVEY 8d's per-step edge stream (12 B x nnz + gathers); the scheduled loop reads "
                  "per-iteration firing lists instead (~8.6 x 4 B per row), so what bounds the passes is the L2 gather "

@@ -214,6 +214,25 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
                             const void* hdr, int t_local, int n_slices, float a, float b, int n_iter, int neg_rate,
                             int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep, float eps,
                             float* grad, float* acc, int geom, void* stream);
+/* The optimisation loop of affinity_matcher.py:288-352 for UMAP's closed-form step + torch.optim.SGD behind one handle
+ * (csrc/tdr_umap_sched.hip): windows of <= block_iters iterations (schedule build + per iteration n_slices gradient
+ * passes + the SGD step [+ a row all-gather]) are captured into HIP graphs and replayed; the iteration base lives in
+ * device memory.  lr_table: max_iter device floats; norm2: ceil(max_iter / check_interval) device floats, caller-zeroed
+ * (squared gradient norm at the iterations the reference inspects, :331-349); nan_flag: device int (first NaN iteration
+ * + 1, :315); snap: optional (n_rows, nc) copy of the stepped rows taken at those iterations (lets a host that runs whole
+ * windows ahead return the state at which the reference stops, :343-349); scratch: >= 4 bytes of device memory; gather: optional `int (*)(void* ctx, float* Z, int nc, void* stream)`
+ * run after every step (tdr_ctx_allgather_rows of a tdr_ctx_create context), NULL = single process. */
+typedef struct tdr_umap_loop_desc {
+    float* Z; int nc; int64_t n_total, row0, n_rows;
+    const int64_t* rowptr; const int32_t* cols; const float* eps_per; float* next;
+    const int64_t* blk_base; int32_t* list; void* hdr; int* err; float* acc; float* grad; float* mom_buf;
+    float a, b; int neg_rate, n_negatives; uint64_t seed; float exag, rep, eps; int n_slices, block_iters;
+    const float* lr_table; int max_iter; float momentum; int first_iter; int check_interval; float* norm2; float* snap; int* nan_flag;
+    void* scratch; void* gather; void* gather_ctx; int geom;
+} tdr_umap_loop_desc;
+int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d);
+int tdr_umap_loop_run(void* loop, int it0, int n_iters, int use_graph, void* stream);
+int tdr_umap_loop_destroy(void* loop);
 /* gradients of neighbor_embedding/largevis.py:181-201 (kind 0), tsne.py:162-170 (kind 1, attraction only),
  * sne.py:160-168 (kind 2, attraction only) and infotsne.py:178-197 (kind 3: Student-t attraction + the row
  * log-sum-exp over the sampled negatives, rep_coef = 2 * repulsion_strength / N) */

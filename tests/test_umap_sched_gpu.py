@@ -351,3 +351,79 @@ def test_umap_estimator_scheduled_gradients_equal_per_step_kernel():
     Z = Checked(n_neighbors=10, max_iter=70, random_state=0).fit_transform(X)
     assert seen["steps"] == 70 and seen["max_err"] < 1e-5, seen
     assert bool(torch.isfinite(Z).all())
+
+
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_loop_runner_equals_the_call_by_call_sequence(use_graph):
+    """tdr_umap_loop_run (whole windows enqueued at once, replayed as HIP graphs, iteration base in device memory)
+    against the same windows issued call by call (build, S gradient passes, tdr_sgd_step_f32): bit-identical embedding
+    and epoch counters after 70 iterations (windows 32 + 32 + 6), squared gradient norms at the inspected iterations."""
+    import ctypes
+
+    from torchdr_amd import _lib
+
+    L = _lib.lib()
+    n, T, ci = 20000, 70, 25
+    gen = torch.Generator().manual_seed(3)
+    rowptr, cols, vals = random_graph(n, seed=9, hub=300)
+    eps_csr, _ = prepare(vals.cuda(), 200)
+    cols_p, eps_p = layout(rowptr.cuda(), cols.cuda(), eps_csr)
+    rowptr = rowptr.cuda()
+    lr = torch.linspace(1.0, 0.0, T + 1)[:T].contiguous()
+    Z0 = (torch.randn(n, 2, generator=gen) * 3).cuda()
+    a, b, seed, S = 1.577, 0.895, 4242, 2
+
+    # call by call
+    sc = Sched(rowptr, cols_p, eps_p, n, 32, S)
+    Z, nxt = Z0.clone(), eps_p.clone()
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    norms, snaps = {}, {}
+    for t0 in range(0, T, 32):
+        nw = min(32, T - t0)
+        sc.build(nxt, t0, nw)
+        for tl in range(nw):
+            g = sc.grad(Z, tl, t0 + tl, a, b, 150, neg=None, seed=seed)
+            if (t0 + tl) % ci == 0:
+                norms[(t0 + tl) // ci] = float((g.double() ** 2).sum())
+            _lib.check(L.tdr_sgd_step_f32(_lib.ptr(Z), _lib.ptr(g), None, Z.numel(), float(lr[t0 + tl]), 0.0, 0, _lib.ptr(flag),
+                                          t0 + tl, _lib.stream_ptr()), "sgd")
+            if (t0 + tl) % ci == 0:
+                snaps[t0 + tl] = Z.clone()
+    # loop object
+    sc2 = Sched(rowptr, cols_p, eps_p, n, 32, S)
+    Z2, nxt2 = Z0.clone(), eps_p.clone()
+    grad = torch.empty((n, 2), device="cuda")
+    lr_d, norm2 = lr.cuda(), torch.zeros(T // ci + 2, device="cuda")
+    flag2, scratch = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(16, dtype=torch.int32, device="cuda")
+    d = _lib.UmapLoopDesc()
+    d.Z, d.nc, d.n_total, d.row0, d.n_rows = _lib.ptr(Z2), 2, n, 0, n
+    d.rowptr, d.cols, d.eps_per, d.next = _lib.ptr(rowptr), _lib.ptr(cols_p), _lib.ptr(eps_p), _lib.ptr(nxt2)
+    d.blk_base, d.list, d.hdr, d.err = _lib.ptr(sc2.blk_base), _lib.ptr(sc2.list), _lib.ptr(sc2.hdr), _lib.ptr(sc2.err)
+    d.acc, d.grad, d.mom_buf = _lib.ptr(sc2.acc), _lib.ptr(grad), None
+    d.a, d.b, d.neg_rate, d.n_negatives, d.seed = a, b, 5, 150, seed
+    d.exag, d.rep, d.eps, d.n_slices, d.block_iters = 1.0, 1.0, 1e-3, S, 32
+    d.lr_table, d.max_iter, d.momentum, d.first_iter, d.check_interval = _lib.ptr(lr_d), T, 0.0, 0, ci
+    snap = torch.zeros((n, 2), device="cuda")
+    d.norm2, d.snap, d.nan_flag, d.scratch, d.gather, d.gather_ctx, d.geom = (_lib.ptr(norm2), _lib.ptr(snap), _lib.ptr(flag2), _lib.ptr(scratch),
+                                                                               None, None, 0)
+    h = ctypes.c_void_p()
+    _lib.check(L.tdr_umap_loop_create(ctypes.byref(h), ctypes.byref(d)), "create")
+    side = torch.cuda.Stream()       # graphs cannot be captured on the legacy default stream
+    side.wait_stream(torch.cuda.current_stream())
+    try:
+        with torch.cuda.stream(side):
+            _lib.check(L.tdr_umap_loop_run(h, 0, 64, use_graph, _lib.stream_ptr()), "run")   # two replays of the 32-window
+            _lib.check(L.tdr_umap_loop_run(h, 64, 6, use_graph, _lib.stream_ptr()), "run")
+        torch.cuda.synchronize()
+        assert torch.equal(Z2, Z) and torch.equal(nxt2, nxt)
+        assert torch.equal(snap, snaps[(T - 1) // ci * ci])     # embedding right after the last inspected iteration
+        for k, v in norms.items():
+            assert abs(float(norm2[k]) - v) <= 1e-5 * v
+        # on the default stream a capture request degrades to plain launches instead of failing
+        _lib.check(L.tdr_umap_loop_run(h, 0, 1, 1, None), "run on the default stream")
+        torch.cuda.synchronize()
+    finally:
+        L.tdr_umap_loop_destroy(h)
+    assert int(sc2.err.item()) == 0 and int(flag2.item()) == 0
+    # argument errors
+    assert L.tdr_umap_loop_run(None, 0, 1, 0, None) == -1

@@ -105,3 +105,16 @@ def ptr(t):
 
 def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class UmapLoopDesc(ctypes.Structure):
+    """``tdr_umap_loop_desc`` of include/torchdr_amd.h (field order and types must match the header)."""
+    _fields_ = [
+        ("Z", c_ptr), ("nc", c_i32), ("n_total", c_i64), ("row0", c_i64), ("n_rows", c_i64),
+        ("rowptr", c_ptr), ("cols", c_ptr), ("eps_per", c_ptr), ("next", c_ptr),
+        ("blk_base", c_ptr), ("list", c_ptr), ("hdr", c_ptr), ("err", c_ptr), ("acc", c_ptr), ("grad", c_ptr), ("mom_buf", c_ptr),
+        ("a", c_f32), ("b", c_f32), ("neg_rate", c_i32), ("n_negatives", c_i32), ("seed", c_u64),
+        ("exag", c_f32), ("rep", c_f32), ("eps", c_f32), ("n_slices", c_i32), ("block_iters", c_i32),
+        ("lr_table", c_ptr), ("max_iter", c_i32), ("momentum", c_f32), ("first_iter", c_i32), ("check_interval", c_i32),
+        ("norm2", c_ptr), ("snap", c_ptr), ("nan_flag", c_ptr), ("scratch", c_ptr), ("gather", c_ptr), ("gather_ctx", c_ptr), ("geom", c_i32),
+    ]

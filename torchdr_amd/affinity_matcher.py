@@ -146,7 +146,13 @@ class AffinityMatcher(DRModule):
         del X
 
         self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self.device_)
-        grad_norm = float("nan")
+        self._run_training_loop()
+        self._raise_if_nan()
+        self.clear_memory()
+        return self.embedding_
+
+    def _run_training_loop(self):
+        """Reference :288-352: step, hooks, and every ``check_interval`` iterations the NaN / convergence checks."""
         for step in range(self.max_iter):
             self.n_iter_.fill_(step)
             self.on_training_step_start()
@@ -154,20 +160,29 @@ class AffinityMatcher(DRModule):
             self.on_training_step_end()
             if step % self.check_interval == 0:
                 self._raise_if_nan()
-                grad_norm = self._grad_norm()
-                if self.verbose:
-                    self.logger.info(
-                        f"[{step}/{self.max_iter}] Grad norm: {grad_norm:.2e} | LR: {self._current_lr():.2e}"
-                    )
-                if grad_norm < self.min_grad_norm:
-                    if self.verbose:
-                        self.logger.info(f"Convergence reached at iter {step} with grad norm: {grad_norm:.2e}.")
+                if self._converged(step, self._grad_norm()):
                     break
-        self._raise_if_nan()
-        self.clear_memory()
-        return self.embedding_
+
+    def _converged(self, step: int, grad_norm: float) -> bool:
+        if self.verbose:
+            self.logger.info(f"[{step}/{self.max_iter}] Grad norm: {grad_norm:.2e} | LR: {self._current_lr():.2e}")
+        if grad_norm < self.min_grad_norm:
+            if self.verbose:
+                self.logger.info(f"Convergence reached at iter {step} with grad norm: {grad_norm:.2e}.")
+            return True
+        return False
 
     def _raise_if_nan(self):
+        if not getattr(self, "_fused_sgd", True):
+            # torch.optim path: nothing wrote the flag -- scan the embedding here (every check_interval iterations)
+            if bool(torch.isnan(self.embedding_.detach()).any()):
+                self._nan_flag.fill_(int(self.n_iter_) + 1)
+        if getattr(self, "world_size", 1) > 1:
+            # a rank steps only its own rows: agree on the flag so that all ranks raise together instead of one raising
+            # while the others wait in the next collective
+            from torchdr_amd.parallel import allreduce_max_
+
+            allreduce_max_(self._nan_flag)
         it = int(self._nan_flag.item())
         if it != 0:
             raise ValueError(f"[TorchDR] ERROR AffinityMatcher : NaNs in the embeddings at iter {it - 1}.")

@@ -26,6 +26,7 @@
 // in a select.  Partial (attraction, repulsion) sums travel between the slice passes; the last pass clamps each to
 // [-4, 4] (umap.py:262,290) and writes the gradient.
 #include "tdr_embed_common.h"
+#include "../../include/torchdr_amd.h"
 
 namespace tdr {
 
@@ -87,6 +88,7 @@ struct SchedBuildParams {
     int64_t n_rows;
     uint32_t slice_step;      // ceil((N - 1) / S): column j belongs to slice min(S - 1, j / slice_step)
     int t0, B, S;             // window = iterations t0 .. t0 + B - 1 (B <= 32), S slices
+    const int* iter_base;     // optional device int added to t0 (graph replays: one captured window serves every window)
     const int64_t* blk_base;
     int32_t* list;
     uint2* hdr;               // (B * S, n_rows) segment records, see the file header
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, gl = lane & 15, gq = lane >> 4;
     const int64_t rb = blockIdx.x;
     const float INF = __builtin_inff();
+    const int t0 = P.t0 + (P.iter_base ? *P.iter_base : 0);
     for (int i = tid; i < K * CNT_STRIDE; i += 256) cnt[i] = 0;
     __syncthreads();
 
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
             float nx = valid ? P.next[e] : INF;
             const float ep = valid ? P.eps_per[e] : INF;
             const uint32_t col = valid ? (uint32_t)P.cols[e] : 0u;
-            uint32_t m = fire_mask(nx, ep, P.t0, P.B);
+            uint32_t m = fire_mask(nx, ep, t0, P.B);
             uint32_t s = col / P.slice_step;
             if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
             const int sbase = (int)s * CNT_STRIDE + lr;
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
             float nx = valid ? P.next[e] : INF;
             const float ep = valid ? P.eps_per[e] : INF;
             const uint32_t col = valid ? (uint32_t)P.cols[e] : 0u;
-            uint32_t m = fire_mask(nx, ep, P.t0, P.B);
+            uint32_t m = fire_mask(nx, ep, t0, P.B);
             if (m) P.next[e] = nx;
             uint32_t s = col / P.slice_step;
             if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
@@ -283,6 +286,7 @@ struct SchedGradParams {
     const int64_t* neg_inj;   // optional (n_rows, n_negatives) injected negatives (parity tests), else the counter hash
     uint64_t seed;
     uint32_t iter;
+    const int* iter_base;     // optional device int added to iter (graph replays)
     float exag, rep, eps;
     float* grad;              // (n_rows, NC)
     float* acc;               // (n_rows, 2 NC) partial sums between the slice passes (S > 1)
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
     const int npos = (int)(h.y & 0xffffu);
     int n_use = (int)(h.y >> 16) * P.neg_rate;
     if (n_use > P.n_negatives) n_use = P.n_negatives;
-    const uint32_t rkey = neg_row_key(P.seed, P.iter, (int64_t)gi);
+    const uint32_t rkey = neg_row_key(P.seed, P.iter + (P.iter_base ? (uint32_t)*P.iter_base : 0u), (int64_t)gi);
     // injected negatives: every column is visited and the ones outside this slice are masked
     int nneg = INJ ? n_use : pass_negative_count<G>(P, rkey, n_use, gl);
     if (!INJ && P.r_len == 0u) nneg = 0;
@@ -472,6 +476,91 @@ static int launch_sched_grad_geom(const SchedGradParams& P, int geom, hipStream_
     }
 }
 
+// ---- the optimisation loop as one object ------------------------------------------------------------------------------
+// SGD step of the loop runner: torch.optim.SGD semantics (affinity_matcher.py:427) with the learning rate read from a
+// device table at the global iteration (device iteration base + offset), the NaN flag of check_NaNs (:315), and -- at
+// the iterations the reference inspects the gradient (n_iter % check_interval == 0, :331-349) -- the squared gradient
+// norm accumulated into norm2[n_iter / check_interval] and the stepped rows copied to `snap`, so that a host that runs
+// whole windows ahead can still return exactly the state of the iteration at which the reference would have stopped.
+__global__ __launch_bounds__(256) void sgd_table_step_kernel(float* __restrict__ Z, const float* __restrict__ grad,
+                                                             float* __restrict__ buf, int64_t n, const float* __restrict__ lr_table,
+                                                             const int* __restrict__ iter_base, int iter_off, float momentum,
+                                                             int first_iter, int check_interval, float* __restrict__ norm2,
+                                                             float* __restrict__ snap, int* __restrict__ nan_flag) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int it = *iter_base + iter_off;
+    float g = i < n ? grad[i] : 0.f;
+    const bool inspected = check_interval > 0 && it % check_interval == 0;
+    if (inspected) {
+        float q = g * g;
+        q = wave_sum(q);
+        if ((threadIdx.x & 63) == 0 && q != 0.f) atomicAdd(&norm2[it / check_interval], q);
+    }
+    if (i >= n) return;
+    if (momentum != 0.f) {
+        const bool first = it == first_iter;
+        const float bprev = first ? 0.f : buf[i];
+        g = first ? g : __fadd_rn(__fmul_rn(bprev, momentum), g);
+        buf[i] = g;
+    }
+    const float z = fmaf(-lr_table[it], g, Z[i]);
+    Z[i] = z;
+    if (inspected && snap) snap[i] = z;  // the state the reference returns if it stops here (:343-349)
+    if (z != z) atomicCAS(nan_flag, 0, it + 1);
+}
+
+typedef int (*tdr_collective_fn)(void* ctx, float* Z, int nc, void* stream);  // all-gather of the rows every rank stepped
+
+struct UmapLoop {
+    // static description of the problem (device pointers are the caller's)
+    float* Z; int nc; int64_t n_total, row0, n_rows;
+    const int64_t* rowptr; const int32_t* cols; const float* eps_per; float* next;
+    const int64_t* blk_base; int32_t* list; uint2* hdr; int* err; float* acc; float* grad; float* mom_buf;
+    float a, b; int neg_rate, n_negatives; uint64_t seed; float exag, rep, eps; int S, B;
+    const float* lr_table; int max_iter; float momentum; int first_iter; int check_interval; float* norm2; float* snap; int* nan_flag;
+    int* iter_base;                 // device int (caller's scratch)
+    tdr_collective_fn gather; void* gather_ctx;
+    int geom;
+    // captured windows: graph_len[i] iterations each
+    hipGraphExec_t graphs[2]; int graph_len[2];
+};
+
+// enqueue one window: schedule build for iterations [base + 0, base + n) and n x (S gradient passes + SGD step [+ row
+// all-gather]); `base` lives in L->iter_base on the device, so the SAME enqueued sequence serves any window
+static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st) {
+    SchedBuildParams Bp;
+    Bp.rowptr = L->rowptr; Bp.cols = L->cols; Bp.eps_per = L->eps_per; Bp.next = L->next; Bp.n_rows = L->n_rows;
+    const uint32_t nred = (uint32_t)(L->n_total - 1);
+    Bp.slice_step = (nred + (uint32_t)L->S - 1u) / (uint32_t)L->S;
+    Bp.t0 = 0; Bp.iter_base = L->iter_base; Bp.B = n; Bp.S = L->S; Bp.blk_base = L->blk_base; Bp.list = L->list; Bp.hdr = L->hdr;
+    Bp.err = L->err;
+    const int64_t n_blocks = (L->n_rows + SCHED_RB - 1) / SCHED_RB;
+    const size_t lds = (size_t)n * L->S * CNT_STRIDE * sizeof(uint32_t);
+    hipLaunchKernelGGL(umap_sched_build_kernel, dim3((unsigned)n_blocks), dim3(256), lds, st, Bp);
+    SchedGradParams G;
+    G.Z = L->Z; G.n_total = L->n_total; G.row0 = L->row0; G.n_rows = L->n_rows; G.list = L->list; G.hdr = L->hdr; G.S = L->S;
+    G.a = L->a; G.b = L->b; G.neg_rate = L->neg_rate; G.n_negatives = L->n_negatives; G.neg_inj = nullptr; G.seed = L->seed;
+    G.iter_base = L->iter_base; G.exag = L->exag; G.rep = L->rep; G.eps = L->eps; G.grad = L->grad; G.acc = L->acc;
+    const int64_t n_el = L->n_rows * L->nc;
+    for (int t = 0; t < n; ++t) {
+        G.t_local = t; G.iter = (uint32_t)t;
+        for (int s = 0; s < L->S; ++s) {
+            sched_pass_constants(G, s);
+            const int rc = (L->nc == 2) ? launch_sched_grad_geom<2>(G, L->geom, st) : launch_sched_grad_geom<3>(G, L->geom, st);
+            if (rc != TDR_OK) return rc;
+        }
+        hipLaunchKernelGGL(sgd_table_step_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st,
+                           L->Z + L->row0 * L->nc, (const float*)L->grad, L->mom_buf, n_el, L->lr_table, (const int*)L->iter_base, t,
+                           L->momentum, L->first_iter, L->check_interval, L->norm2, L->snap, L->nan_flag);
+        if (L->gather) {
+            const int rc = L->gather(L->gather_ctx, L->Z, L->nc, (void*)st);
+            if (rc != TDR_OK) return rc;
+        }
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TDR_OK : (int)e;
+}
+
 }  // namespace tdr
 
 using namespace tdr;
@@ -534,7 +623,7 @@ int tdr_umap_sched_build_f32(const int64_t* rowptr, const int32_t* cols, const f
     P.rowptr = rowptr; P.cols = cols; P.eps_per = eps_per; P.next = next; P.n_rows = n_rows;
     const uint32_t nred = (uint32_t)(n_total - 1);
     P.slice_step = (nred + (uint32_t)n_slices - 1u) / (uint32_t)n_slices;
-    P.t0 = t0; P.B = n_iters; P.S = n_slices; P.blk_base = blk_base; P.list = list; P.hdr = (uint2*)hdr; P.err = err;
+    P.t0 = t0; P.iter_base = nullptr; P.B = n_iters; P.S = n_slices; P.blk_base = blk_base; P.list = list; P.hdr = (uint2*)hdr; P.err = err;
     const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
     const size_t lds = (size_t)n_iters * n_slices * CNT_STRIDE * sizeof(uint32_t);
     if (lds > 32 * 1024) {
@@ -562,7 +651,7 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
     SchedGradParams P;
     P.Z = Z; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.list = list; P.hdr = (const uint2*)hdr;
     P.t_local = t_local; P.S = n_slices; P.a = a; P.b = b; P.neg_rate = neg_rate; P.n_negatives = n_negatives;
-    P.neg_inj = neg_inj; P.seed = seed; P.iter = (uint32_t)n_iter; P.exag = exag; P.rep = rep; P.eps = eps; P.grad = grad;
+    P.neg_inj = neg_inj; P.seed = seed; P.iter = (uint32_t)n_iter; P.iter_base = nullptr; P.exag = exag; P.rep = rep; P.eps = eps; P.grad = grad;
     P.acc = acc;
     hipStream_t st = (hipStream_t)stream;
     for (int s = 0; s < n_slices; ++s) {
@@ -570,6 +659,104 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
         const int rc = (nc == 2) ? launch_sched_grad_geom<2>(P, geom, st) : launch_sched_grad_geom<3>(P, geom, st);
         if (rc != TDR_OK) return rc;
     }
+    return TDR_OK;
+}
+
+/* ---- the whole optimisation loop behind one handle -------------------------------------------------------------------
+ * affinity_matcher.py:288-352 (the training loop) for UMAP's closed-form step with torch.optim.SGD: every window of up to
+ * `block_iters` iterations is ONE enqueued sequence (schedule build, then per iteration S gradient passes + the SGD step
+ * [+ the all-gather of the rows this rank stepped]) whose iteration base lives in device memory, captured once into a HIP
+ * graph and replayed for every window of the same length -- the host issues one graph launch per window instead of
+ * ~4 kernel launches per iteration.
+ *   desc: device pointers of the problem (see tdr_umap_loop_desc); lr_table: max_iter floats on the device (the learning
+ *   rate of every iteration); norm2: ceil(max_iter / check_interval) floats, caller-zeroed (squared gradient norms at the
+ *   iterations the reference inspects); scratch: >= 4 bytes of device memory (the iteration base).
+ *   gather / gather_ctx: optional collective run after every step (tdr_ctx_allgather_rows of a tdr_ctx), NULL = none. */
+int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
+    if (!out || !d || !d->Z || !d->rowptr || !d->cols || !d->eps_per || !d->next || !d->blk_base || !d->list || !d->hdr || !d->err ||
+        !d->grad || !d->lr_table || !d->norm2 || !d->nan_flag || !d->scratch) return TDR_ERR_BAD_ARG;
+    if (d->n_rows <= 0 || d->n_total < 2 || d->n_total >= 0x7fffffffLL || d->block_iters <= 0 || d->block_iters > SCHED_BMAX) return TDR_ERR_BAD_ARG;
+    if (d->n_slices != 1 && d->n_slices != 2 && d->n_slices != 4 && d->n_slices != 8) return TDR_ERR_BAD_ARG;
+    if (d->n_slices > 1 && !d->acc) return TDR_ERR_BAD_ARG;
+    if (d->momentum != 0.f && !d->mom_buf) return TDR_ERR_BAD_ARG;
+    if (d->nc != 2 && d->nc != 3) return TDR_ERR_UNSUPPORTED;
+    UmapLoop* L = new UmapLoop();
+    L->Z = d->Z; L->nc = d->nc; L->n_total = d->n_total; L->row0 = d->row0; L->n_rows = d->n_rows; L->rowptr = d->rowptr;
+    L->cols = d->cols; L->eps_per = d->eps_per; L->next = d->next; L->blk_base = d->blk_base; L->list = d->list;
+    L->hdr = (uint2*)d->hdr; L->err = d->err; L->acc = d->acc; L->grad = d->grad; L->mom_buf = d->mom_buf; L->a = d->a; L->b = d->b;
+    L->neg_rate = d->neg_rate; L->n_negatives = d->n_negatives; L->seed = d->seed; L->exag = d->exag; L->rep = d->rep; L->eps = d->eps;
+    L->S = d->n_slices; L->B = d->block_iters; L->lr_table = d->lr_table; L->max_iter = d->max_iter; L->momentum = d->momentum;
+    L->first_iter = d->first_iter; L->check_interval = d->check_interval; L->norm2 = d->norm2; L->snap = d->snap; L->nan_flag = d->nan_flag;
+    L->iter_base = (int*)d->scratch; L->gather = (tdr_collective_fn)d->gather; L->gather_ctx = d->gather_ctx; L->geom = d->geom;
+    L->graphs[0] = L->graphs[1] = nullptr; L->graph_len[0] = L->graph_len[1] = 0;
+    const size_t lds = (size_t)L->B * L->S * CNT_STRIDE * sizeof(uint32_t);
+    if (lds > 32 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { delete L; return (int)e; }
+    }
+    *out = L;
+    return TDR_OK;
+}
+
+/* Run iterations [it0, it0 + n_iters) (n_iters >= 1; it0 + n_iters <= max_iter).  use_graph != 0: windows are captured
+ * into HIP graphs on first use (at most two distinct window lengths are kept) and replayed; 0: plain launches. */
+int tdr_umap_loop_run(void* loop, int it0, int n_iters, int use_graph, void* stream) {
+    UmapLoop* L = (UmapLoop*)loop;
+    if (!L || it0 < 0 || n_iters <= 0 || it0 + n_iters > L->max_iter) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int it = it0;
+    while (it < it0 + n_iters) {
+        const int n = (it0 + n_iters - it < L->B) ? it0 + n_iters - it : L->B;
+        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)L->iter_base, it, 1, st);
+        if (e != hipSuccess) return (int)e;
+        int slot = -1;
+        if (use_graph) {
+            for (int i = 0; i < 2; ++i)
+                if (L->graphs[i] && L->graph_len[i] == n) slot = i;
+            if (slot < 0) {
+                int free_slot = !L->graphs[0] ? 0 : (!L->graphs[1] ? 1 : -1);
+                if (free_slot >= 0) {
+                    hipGraph_t g = nullptr;
+                    e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+                    if (e != hipSuccess) {  // e.g. the legacy default stream cannot be captured: plain launches from now on
+                        (void)hipGetLastError();
+                        use_graph = 0;
+                        const int rc0 = umap_loop_enqueue_window(L, n, st);
+                        if (rc0 != TDR_OK) return rc0;
+                        it += n;
+                        continue;
+                    }
+                    const int rc = umap_loop_enqueue_window(L, n, st);
+                    e = hipStreamEndCapture(st, &g);
+                    if (rc != TDR_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+                    if (e != hipSuccess) return (int)e;
+                    hipGraphExec_t ge = nullptr;
+                    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(g);
+                    if (e != hipSuccess) return (int)e;
+                    L->graphs[free_slot] = ge; L->graph_len[free_slot] = n; slot = free_slot;
+                }
+            }
+        }
+        if (slot >= 0) {
+            e = hipGraphLaunch(L->graphs[slot], st);
+            if (e != hipSuccess) return (int)e;
+        } else {
+            const int rc = umap_loop_enqueue_window(L, n, st);
+            if (rc != TDR_OK) return rc;
+        }
+        it += n;
+    }
+    return TDR_OK;
+}
+
+int tdr_umap_loop_destroy(void* loop) {
+    UmapLoop* L = (UmapLoop*)loop;
+    if (!L) return TDR_ERR_BAD_ARG;
+    for (int i = 0; i < 2; ++i)
+        if (L->graphs[i]) (void)hipGraphExecDestroy(L->graphs[i]);
+    delete L;
     return TDR_OK;
 }
 

@@ -755,7 +755,10 @@ def pairwise_distances(
                 C, I = _knn_general(Xc[c0:c1], Xc, int(k), metric, bool(exclude_diag), q_global0=c0)
             return (C, I) if return_indices else C
         Yp = PackedPoints(X)
-        if (distributed_ctx.world_size > 1 and _want_prune(Yp, n) and _use_screen(Yp, Yp, c1 - c0, int(k), metric)
+        # every rank must take the same branch (the sharded search is collective): decide from rank-independent
+        # quantities only (n // W, never this rank's own c1 - c0, which differs by one row across ranks)
+        if (distributed_ctx.world_size > 1 and _want_prune(Yp, n)
+                and _use_screen(Yp, Yp, n // distributed_ctx.world_size, int(k), metric)
                 and n // distributed_ctx.world_size >= _SCREEN_PILOT_Q):
             res = knn_pruned_sharded(Yp, int(k), metric, bool(exclude_diag), distributed_ctx)
             if res is not None:

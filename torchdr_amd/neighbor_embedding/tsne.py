@@ -33,6 +33,11 @@ class TSNE(NeighborEmbedding):
         self.metric = metric
         self.perplexity = perplexity
         self.max_iter_affinity = max_iter_affinity
+        if not sparsity:
+            raise NotImplementedError(
+                "[torchdr_amd] sparsity=False (dense N x N input affinity) is not part of the accelerated path; the "
+                "kNN-sparse affinity (sparsity=True, the reference's default) is."
+            )
         self.sparsity = sparsity
         affinity_in = EntropicAffinity(perplexity=perplexity, metric=metric, max_iter=max_iter_affinity,
                                        device=device, backend=backend, verbose=verbose, sparsity=sparsity,

@@ -22,6 +22,17 @@ PROFILE_EVERY = 25
 # (tdr_umap_grad_f32), which streams every edge's counter each iteration; SCHED_GEOM is the lane-geometry knob of the
 # gradient kernel (tools/umap_perf.py), SCHED_SLICES overrides the automatic number of L2 slices of the embedding.
 SCHEDULED = True
+# LOOP_RUNNER: run the whole optimisation loop through tdr_umap_loop_* (one ctypes call per window of <= 32 iterations,
+# windows replayed as HIP graphs when LOOP_GRAPH) when the estimator's step is the stock one (no overridden hooks, no
+# injected negatives, fused SGD, no early exaggeration).  "auto": only where the host would otherwise bound the loop,
+# i.e. row-sharded runs with an on-stream RCCL context (an iteration there is a few tens of microseconds of kernels);
+# on one GPU an iteration is ~0.37 ms of kernels at N = 1M and the ~50 us of Python per iteration are hidden -- measured
+# (bench.py --loop): python 475.7 ms / step, C loop 486.4, graphs 496.3 (capture + 129-node replays cost more than the
+# launches they save).  True: whenever eligible; False: never.
+LOOP_RUNNER = "auto"
+LOOP_GRAPH = True
+# bench.py sets this to a list to collect (start_event, end_event, n_iterations) per loop-runner segment
+LOOP_PROFILE = None
 SCHED_BLOCK_ITERS = 32
 SCHED_GEOM = 0
 SCHED_SLICES = 0
@@ -194,6 +205,113 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         if prof:
             ev1.record()
             PROFILE.append(("grad", ev0, ev1, csr.nnz))
+
+    # ---- whole-loop runner ---------------------------------------------------------------------------------------------
+    def _loop_runner_eligible(self) -> bool:
+        from torchdr_amd.affinity_matcher import AffinityMatcher
+        from torchdr_amd.neighbor_embedding.base import NegativeSamplingNeighborEmbedding, NeighborEmbedding
+
+        if not (SCHEDULED and LOOP_RUNNER) or not self._fused_sgd or self.n_samples_in_ >= 2**31 - 1:
+            return False
+        if self.world_size > 1 and getattr(self, "_rccl_ctx", None) is None:
+            return False
+        if LOOP_RUNNER == "auto" and self.world_size == 1:
+            return False
+        if self.neg_indices_ is not None or self._exclusion is not None or self.early_exaggeration_coeff_ > 1:
+            return False
+        cls = type(self)
+        stock = (
+            ("on_training_step_start", NegativeSamplingNeighborEmbedding), ("on_training_step_end", NeighborEmbedding),
+            ("_training_step", AffinityMatcher), ("_optimizer_step", AffinityMatcher), ("_sgd_kernel", AffinityMatcher),
+            ("_compute_gradients", UMAP), ("_compute_gradients_scheduled", UMAP), ("_grad_norm", AffinityMatcher),
+        )
+        return all(getattr(cls, name) is getattr(owner, name) for name, owner in stock)
+
+    def _run_training_loop(self):
+        if not self._loop_runner_eligible():
+            return super()._run_training_loop()
+        import ctypes
+
+        L, csr, dev = _lib.lib(), self._csr, self.device_
+        sc = getattr(self, "_sched", None) or self._sched_setup()
+        T, ci, nc = int(self.max_iter), int(self.check_interval), self.n_components
+        if getattr(self, "_grad_buf", None) is None:
+            self._grad_buf = torch.empty((self.chunk_size_, nc), dtype=torch.float32, device=dev)
+        mom = float(self._sgd_momentum)
+        keep = {
+            "lr": torch.tensor(self._lr_table[:T] + [0.0] * max(0, T - len(self._lr_table)), dtype=torch.float32, device=dev),
+            "norm2": torch.zeros(T // max(ci, 1) + 2, dtype=torch.float32, device=dev),
+            "scratch": torch.zeros(16, dtype=torch.int32, device=dev),
+            "mom": torch.zeros_like(self._grad_buf) if mom != 0.0 else None,
+            "snap": torch.empty_like(self._grad_buf),
+        }
+        d = _lib.UmapLoopDesc()
+        d.Z, d.nc, d.n_total, d.row0, d.n_rows = _lib.ptr(self.embedding_), nc, self.n_samples_in_, self.chunk_start_, self.chunk_size_
+        d.rowptr, d.cols, d.eps_per, d.next = (_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
+                                               _lib.ptr(self.epoch_of_next_sample))
+        d.blk_base, d.list, d.hdr, d.err = _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), _lib.ptr(sc["err"])
+        d.acc, d.grad, d.mom_buf = _lib.ptr(sc["acc"]), _lib.ptr(self._grad_buf), _lib.ptr(keep["mom"])
+        d.a, d.b, d.neg_rate, d.n_negatives, d.seed = float(self._a), float(self._b), int(self.negative_sample_rate), int(self.n_negatives), self._neg_seed
+        d.exag, d.rep, d.eps = float(self.early_exaggeration_coeff_), float(self.repulsion_strength), float(self._eps)
+        d.n_slices, d.block_iters = sc["S"], min(sc["B"], max(ci, 1))
+        d.lr_table, d.max_iter, d.momentum, d.first_iter, d.check_interval = _lib.ptr(keep["lr"]), T, mom, 0, ci
+        d.norm2, d.snap, d.nan_flag, d.scratch = (_lib.ptr(keep["norm2"]), _lib.ptr(keep["snap"]), _lib.ptr(self._nan_flag),
+                                                  _lib.ptr(keep["scratch"]))
+        ctx = getattr(self, "_rccl_ctx", None)
+        d.gather, d.gather_ctx = (ctx.gather_fn, ctx.handle) if ctx is not None else (None, None)
+        d.geom = int(SCHED_GEOM)
+        handle = ctypes.c_void_p()
+        _lib.check(L.tdr_umap_loop_create(ctypes.byref(handle), ctypes.byref(d)), "tdr_umap_loop_create")
+        # graphs cannot be captured on the legacy default stream: the loop runs on a side stream ordered after the
+        # caller's stream, and the caller's stream waits for it at the end
+        outer = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev) if LOOP_GRAPH else outer
+        side.wait_stream(outer)
+        try:
+            with torch.cuda.stream(side):
+                self._loop_segments(L, handle, keep, T, ci, csr)
+            sc["t0"], sc["n"] = None, 0
+            self._last_grad, self._last_grad_is_chunk = self._grad_buf, True
+        finally:
+            outer.wait_stream(side)
+            L.tdr_umap_loop_destroy(handle)
+
+    def _loop_segments(self, L, handle, keep, T, ci, csr):
+        """Whole windows (<= min(32, check_interval) iterations, so at most one inspected iteration each) run ahead of
+        the host; after a window that holds an inspected iteration s (s % check_interval == 0) the host reads the NaN
+        flag and |grad|(s) and, if the reference would have stopped at s (:343-349), restores the rows from the
+        snapshot the step kernel took right after step s."""
+        B = min(self._sched["B"], max(ci, 1))
+        for w0 in range(0, T, B):
+            n = min(B, T - w0)
+            if LOOP_PROFILE is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _lib.check(L.tdr_umap_loop_run(handle, w0, n, 1 if LOOP_GRAPH else 0, _lib.stream_ptr()), "tdr_umap_loop_run")
+            if LOOP_PROFILE is not None:
+                e1.record()
+                LOOP_PROFILE.append((e0, e1, n, csr.nnz))
+            self.n_iter_.fill_(w0 + n - 1)
+            self._lr_pos = w0 + n
+            s = -(-w0 // ci) * ci        # first inspected iteration >= w0
+            if s < w0 + n:
+                self._raise_if_nan()
+                sq = keep["norm2"][s // ci].reshape(1).clone()
+                if self.world_size > 1:
+                    from torchdr_amd.parallel import allreduce_
+
+                    allreduce_(sq)
+                self._lr_pos = s + 1
+                if self._converged(s, float(sq.sqrt().item())):
+                    c0 = self.chunk_start_
+                    self.embedding_[c0:c0 + self.chunk_size_].copy_(keep["snap"])
+                    if self.world_size > 1:
+                        from torchdr_amd.parallel import allgather_rows_
+
+                        allgather_rows_(self.embedding_, c0, self.chunk_size_, self.world_size)
+                    self.n_iter_.fill_(s)
+                    return
+                self._lr_pos = w0 + n
 
     def _raise_if_nan(self):
         super()._raise_if_nan()
