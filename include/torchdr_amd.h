@@ -158,6 +158,17 @@ int tdr_sym_fill_f32(int64_t n, int k, int64_t row_offset, int mode, const int32
 int tdr_csr_to_padded_f32(const int64_t* rowptr, const int32_t* cols, const float* vals, int64_t n, int64_t width,
                           float* pv, int64_t* pi, void* stream);
 
+/* ---- multi-GPU context: an RCCL communicator behind the C ABI (csrc/tdr_ctx.hip) ----------------------------------
+ * One process per GPU.  The collectives are enqueued on the caller's stream (no host synchronisation; capturable into the
+ * HIP graphs of tdr_umap_loop_*).  librccl is dlopen'ed from rccl_path ("" = "librccl.so"), normally the copy PyTorch
+ * loaded.  Replaces affinity_matcher.py:395-413 (zero-padded all-reduce of the stepped rows -> in-place all-gather) and
+ * :425 (gradient all-reduce).  RCCL errors are returned as 1000 + ncclResult_t. */
+int tdr_ctx_unique_id(const char* rccl_path, void* out128);
+int tdr_ctx_create(void** ctx, int rank, int world, const void* unique_id128, const char* rccl_path, int64_t n_total);
+int tdr_ctx_allgather_rows(void* ctx, float* Z, int nc, void* stream);
+int tdr_ctx_allreduce_f32(void* ctx, float* buf, int64_t count, void* stream);
+int tdr_ctx_destroy(void* ctx);
+
 /* ---- K0: the steps either side of the path inside fit_transform (csrc/tdr_prep.hip) ---------------------------- */
 /* utils/validation.py:308 (torch.isfinite(X).all()): *count (device uint64, caller-zeroed) += number of inf / nan entries */
 int tdr_nonfinite_count_f32(const float* X, int64_t n, int d, int64_t ldx, void* count, void* stream);

@@ -77,6 +77,15 @@ def _worker(rank, world, port, n_rows, ret):
         b = torch.arange(6, dtype=torch.int32) * (1 if rank == 0 else 0)
         broadcast_(b)
         assert b.tolist() == list(range(6))
+        # row-sharded INPUT: every rank passes its shard, gets the full block back (one all-gather of the shards)
+        from torchdr_amd.parallel import gather_row_shards
+
+        Xfull = torch.arange(n_rows * 3, dtype=torch.float32).reshape(n_rows, 3)
+        assert torch.equal(gather_row_shards(Xfull[s:e].clone()), Xfull)
+        if n_rows % world:   # shards that do not follow the chunk rule are refused, on every rank alike
+            wrong = Xfull[: n_rows // world] if rank == 0 else Xfull[n_rows // world:]
+            with pytest.raises(ValueError, match="chunk rule"):
+                gather_row_shards(wrong.clone())
         ret[rank] = True
     finally:
         dist.destroy_process_group()

@@ -90,9 +90,77 @@ def _worker(rank, world, port, ret):
             if cls in (torchdr_amd.SNE, torchdr_amd.COSNE):  # no sampling: the sharded run must reproduce the single-process one
                 Z1 = cls(random_state=0, distributed=False, **kw).fit_transform(X)
                 assert torch.allclose(Z, Z1, rtol=1e-3, atol=1e-4 * float(Z1.abs().max()))
+        # --- row-sharded INPUT (sharded_input=True): each rank hands over ITS rows only; same embedding as the
+        #     replicated-input run, bit for bit (the shards are all-gathered first, then the same code runs)
+        Zr = torchdr_amd.UMAP(n_neighbors=12, max_iter=20, random_state=0).fit_transform(X)
+        Zs = torchdr_amd.UMAP(n_neighbors=12, max_iter=20, random_state=0, sharded_input=True).fit_transform(X[s:e].clone())
+        assert Zs.shape == (n, 2) and torch.equal(Zs, Zr)
         ret[rank] = True
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_context_single_rank():
+    """tdr_ctx_*: librccl opened with dlopen, communicator of ONE rank on this GPU (what a 1-GPU box can run): the
+    in-place row all-gather and the all-reduce are identities, on a side stream and inside a captured HIP graph of the
+    UMAP loop object, whose result must equal the run without a context."""
+    import ctypes
+
+    from tests.test_umap_sched_gpu import Sched, layout, prepare, random_graph
+    from torchdr_amd import _lib
+    from torchdr_amd.parallel import RcclContext
+
+    n = 20000
+    ctx = RcclContext.create(n, torch.device("cuda", 0), rank=0, world=1)
+    if ctx is None:
+        pytest.skip("librccl could not be opened in this environment")
+    try:
+        Z = torch.randn(n, 2, device="cuda")
+        Z0 = Z.clone()
+        ctx.allgather_rows_(Z)
+        g = torch.arange(10, dtype=torch.float32, device="cuda")
+        ctx.allreduce_(g)
+        torch.cuda.synchronize()
+        assert torch.equal(Z, Z0) and torch.equal(g.cpu(), torch.arange(10, dtype=torch.float32))
+        # loop object with the context's all-gather after every step, replayed as a graph
+        L = _lib.lib()
+        rowptr, cols, vals = random_graph(n, seed=9, hub=300)
+        eps_csr, _ = prepare(vals.cuda(), 200)
+        cols_p, eps_p = layout(rowptr.cuda(), cols.cuda(), eps_csr)
+        rowptr = rowptr.cuda()
+        T = 40
+        lr = torch.linspace(1.0, 0.0, T + 1)[:T].contiguous().cuda()
+        outs = []
+        for use_ctx in (False, True):
+            sc = Sched(rowptr, cols_p, eps_p, n, 32, 2)
+            Zl, nxt = Z0.clone(), eps_p.clone()
+            grad, norm2 = torch.empty((n, 2), device="cuda"), torch.zeros(8, device="cuda")
+            flag, scratch = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(16, dtype=torch.int32, device="cuda")
+            d = _lib.UmapLoopDesc()
+            d.Z, d.nc, d.n_total, d.row0, d.n_rows = _lib.ptr(Zl), 2, n, 0, n
+            d.rowptr, d.cols, d.eps_per, d.next = _lib.ptr(rowptr), _lib.ptr(cols_p), _lib.ptr(eps_p), _lib.ptr(nxt)
+            d.blk_base, d.list, d.hdr, d.err = _lib.ptr(sc.blk_base), _lib.ptr(sc.list), _lib.ptr(sc.hdr), _lib.ptr(sc.err)
+            d.acc, d.grad, d.mom_buf = _lib.ptr(sc.acc), _lib.ptr(grad), None
+            d.a, d.b, d.neg_rate, d.n_negatives, d.seed = 1.577, 0.895, 5, 150, 77
+            d.exag, d.rep, d.eps, d.n_slices, d.block_iters = 1.0, 1.0, 1e-3, 2, 32
+            d.lr_table, d.max_iter, d.momentum, d.first_iter, d.check_interval = _lib.ptr(lr), T, 0.0, 0, 50
+            d.norm2, d.snap, d.nan_flag, d.scratch = _lib.ptr(norm2), None, _lib.ptr(flag), _lib.ptr(scratch)
+            d.gather, d.gather_ctx, d.geom = (ctx.gather_fn, ctx.handle, 0) if use_ctx else (None, None, 0)
+            h = ctypes.c_void_p()
+            _lib.check(L.tdr_umap_loop_create(ctypes.byref(h), ctypes.byref(d)), "create")
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            try:
+                with torch.cuda.stream(side):
+                    _lib.check(L.tdr_umap_loop_run(h, 0, T, 1, _lib.stream_ptr()), "run")
+                torch.cuda.synchronize()
+            finally:
+                L.tdr_umap_loop_destroy(h)
+            assert int(flag.item()) == 0 and int(sc.err.item()) == 0
+            outs.append(Zl)
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        ctx.destroy()
 
 
 def test_two_rank_sharded_path_on_one_gpu():

@@ -207,7 +207,11 @@ class AffinityMatcher(DRModule):
             self._last_grad = grad
             self._last_grad_is_chunk = True
             self._sgd_kernel(rows, grad, chunk=True)
-            allgather_rows_(self.embedding_, c0, self.chunk_size_, world)
+            ctx = getattr(self, "_rccl_ctx", None)
+            if ctx is not None:
+                ctx.allgather_rows_(self.embedding_)   # on-stream RCCL through the C library
+            else:
+                allgather_rows_(self.embedding_, c0, self.chunk_size_, world)
             self._lr_pos += 1
             return None
         if world > 1:

@@ -77,6 +77,11 @@ class DRModule(BaseEstimator, nn.Module, ABC):
         (reference base.py:132-148)."""
         in_dtype = X.dtype
         X = as_float32(X)  # float64 in -> computed in float32 -> float64 out
+        if getattr(self, "sharded_input", False) and getattr(self, "world_size", 1) > 1:
+            # X is this rank's row shard: one all-gather of the shards, then the replicated-input path
+            from torchdr_amd.parallel import gather_row_shards
+
+            X = gather_row_shards(X)
         inverse = None
         if self.process_duplicates:
             X, inverse = unique_rows(X, self.device)

@@ -13,6 +13,11 @@ from torchdr_amd.affinity import Affinity
 from torchdr_amd.affinity_matcher import AffinityMatcher
 
 
+# per-iteration exchange through an RCCL communicator owned by the C library (tdr_ctx_*: collectives enqueued on the
+# compute stream, graph-capturable) when the process group runs on RCCL; False keeps every collective in torch.distributed
+RCCL_CONTEXT = True
+
+
 class NeighborEmbedding(AffinityMatcher):
     _lr_as_tensor = False
 
@@ -31,6 +36,9 @@ class NeighborEmbedding(AffinityMatcher):
         self.early_exaggeration_iter = early_exaggeration_iter if early_exaggeration_iter is not None else 0
         self.early_exaggeration_coeff = early_exaggeration_coeff if early_exaggeration_coeff is not None else 1
         self.repulsion_strength = repulsion_strength
+        # extension of the reference's surface: fit_transform receives this rank's ROW SHARD (chunk rule of
+        # DistributedContext) instead of the full block on every rank; the shards are all-gathered over RCCL first
+        self.sharded_input = bool(kwargs.pop("sharded_input", False))
         if "learning_rate" in kwargs:  # sklearn-style aliases (reference :170-173)
             lr = kwargs.pop("learning_rate")
         if "early_exaggeration" in kwargs:
@@ -138,6 +146,18 @@ class NeighborEmbedding(AffinityMatcher):
         else:
             self.chunk_start_ = 0
             self.chunk_size_ = self.n_samples_in_
+        self._rccl_ctx = None
+        if self.world_size > 1 and RCCL_CONTEXT and dist.get_backend() == "nccl" and torch.cuda.is_available():
+            from torchdr_amd.parallel import RcclContext
+
+            self._rccl_ctx = RcclContext.create(self.n_samples_in_, self.device_)
+
+    def clear_memory(self):
+        super().clear_memory()
+        ctx = getattr(self, "_rccl_ctx", None)
+        if ctx is not None:
+            ctx.destroy()
+            self._rccl_ctx = None
 
     @property
     def chunk_indices_(self):

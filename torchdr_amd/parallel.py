@@ -174,3 +174,135 @@ def exchange_rows_to_owners(row_ids, vals, idx, n_total, world_size, chunk_start
     out_v[local] = r_v
     out_i[local] = r_i
     return out_v, out_i
+
+
+def gather_row_shards(X_local: torch.Tensor) -> torch.Tensor:
+    """Row-sharded input (north star: "the point set shards by rows ... with RCCL all-gather"): every rank passes ITS rows,
+    in rank order, and gets the full (N, D) block back -- one all-gather of the shards over xGMI, after which the
+    search runs exactly as on a replicated input (queries = own chunk, database = all N).  Shards must follow the
+    reference's chunk rule (``distributed/__init__.py:209-219``: contiguous, the first ``N mod W`` ranks hold one extra
+    row) so that the rank's shard IS its chunk of every later stage."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if X_local.dim() != 2:
+        raise ValueError("[TorchDR] ERROR : a row shard must be a 2-D block.")
+    staged = _host_staged() and X_local.is_cuda
+    dev = torch.device("cpu") if staged or not X_local.is_cuda else X_local.device
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    sizes[rank] = X_local.shape[0]
+    dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
+    sizes = sizes.tolist()
+    n = int(sum(sizes))
+    for r, m in enumerate(sizes):
+        s, e = chunk_bounds(n, r, world)
+        if m != e - s:
+            raise ValueError(
+                f"[TorchDR] ERROR : row shards must follow the chunk rule of DistributedContext.compute_chunk_bounds "
+                f"(rank {r} holds {m} rows, expected {e - s} of {n})."
+            )
+    max_rows = max(sizes)
+    loc = X_local.contiguous()
+    if staged:
+        loc = loc.cpu()
+    if loc.shape[0] < max_rows:
+        loc = torch.cat([loc, loc.new_zeros((max_rows - loc.shape[0], loc.shape[1]))])
+    out = loc.new_empty((world * max_rows, loc.shape[1]))
+    dist.all_gather_into_tensor(out, loc)
+    if any(m != max_rows for m in sizes):
+        out = torch.cat([out[r * max_rows: r * max_rows + m] for r, m in enumerate(sizes)])
+    return out.to(X_local.device)
+
+
+class RcclContext:
+    """``tdr_ctx_*``: an RCCL communicator owned by the C library, whose collectives are enqueued on the caller's stream
+    (capturable into the HIP graphs of the UMAP loop object).  Rank 0 draws the unique id and the bytes travel through
+    the already initialised ``torch.distributed`` group.  ``create`` returns None instead of raising when RCCL cannot be
+    opened or the self-check against ``torch.distributed`` fails: callers then keep the Python-level collectives."""
+
+    def __init__(self, handle, n_total):
+        import ctypes
+
+        from torchdr_amd import _lib
+
+        self.handle = handle
+        self.n_total = n_total
+        self.gather_fn = ctypes.cast(_lib.lib().tdr_ctx_allgather_rows, ctypes.c_void_p)
+
+    @staticmethod
+    def rccl_path() -> bytes:
+        import os
+
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        return cand.encode() if os.path.exists(cand) else b""
+
+    @classmethod
+    def create(cls, n_total: int, device, rank=None, world=None, broadcast=None):
+        import ctypes
+
+        from torchdr_amd import _lib
+
+        L = _lib.lib()
+        rank = dist.get_rank() if rank is None else rank
+        world = dist.get_world_size() if world is None else world
+        path = cls.rccl_path()
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            if L.tdr_ctx_unique_id(path, buf) != 0:
+                uid.fill_(255)   # "unavailable" marker, broadcast like a real id so that every rank gives up together
+            else:
+                uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if world > 1:
+            if broadcast is not None:
+                uid = broadcast(uid)
+            else:
+                t = uid.to(device) if dist.get_backend() == "nccl" else uid
+                dist.broadcast(t, src=0)
+                uid = t.cpu()
+        if bool((uid == 255).all()):
+            return None
+        handle = ctypes.c_void_p()
+        raw = bytes(uid.numpy().tobytes())
+        with torch.cuda.device(device):
+            rc = L.tdr_ctx_create(ctypes.byref(handle), rank, world, raw, path, n_total)
+        if rc != 0:
+            return None
+        ctx = cls(handle, n_total)
+        if not ctx._self_check(device, rank, world):
+            ctx.destroy()
+            return None
+        return ctx
+
+    def _self_check(self, device, rank, world) -> bool:
+        """An all-gather of 3 columns through the context must place every rank's rows where chunk_bounds says."""
+        from torchdr_amd import _lib
+
+        Z = torch.full((self.n_total, 3), -1.0, dtype=torch.float32, device=device)
+        s, e = chunk_bounds(self.n_total, rank, world)
+        Z[s:e] = float(rank + 1)
+        if _lib.lib().tdr_ctx_allgather_rows(self.handle, _lib.ptr(Z), 3, _lib.stream_ptr()) != 0:
+            return False
+        want = torch.empty(self.n_total, dtype=torch.float32, device=device)
+        for r in range(world):
+            a, b = chunk_bounds(self.n_total, r, world)
+            want[a:b] = float(r + 1)
+        return bool((Z == want[:, None]).all())
+
+    def allgather_rows_(self, Z: torch.Tensor):
+        from torchdr_amd import _lib
+
+        _lib.check(_lib.lib().tdr_ctx_allgather_rows(self.handle, _lib.ptr(Z), Z.shape[1], _lib.stream_ptr()),
+                   "tdr_ctx_allgather_rows")
+        return Z
+
+    def allreduce_(self, t: torch.Tensor):
+        from torchdr_amd import _lib
+
+        _lib.check(_lib.lib().tdr_ctx_allreduce_f32(self.handle, _lib.ptr(t), t.numel(), _lib.stream_ptr()), "tdr_ctx_allreduce_f32")
+        return t
+
+    def destroy(self):
+        from torchdr_amd import _lib
+
+        if self.handle is not None:
+            _lib.lib().tdr_ctx_destroy(self.handle)
+            self.handle = None
