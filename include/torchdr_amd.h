@@ -122,6 +122,20 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
 int64_t tdr_maxmin_workspace_bytes(int64_t S, int n_seeds);
 int tdr_maxmin_seeds_f32(const float* Xs, int64_t S, int d, int64_t ld, int n_seeds, int32_t* seeds, void* ws,
                          int64_t ws_bytes, void* stream);
+/* Coarse cluster index of the pruned self search, built with the package's own kernels (csrc/tdr_cluster.hip; the
+ * search result never depends on it, only the number of skipped tiles does): stratified sample, farthest-point seeding
+ * of C clusters by ONE workgroup on the sample's exact distance matrix (tdr_dense_dist_packed_f32), Lloyd updates
+ * (assignments come from tdr_knn_packed_f32 with k = 1), radii / centre distances by direct differences with outward
+ * rounding, padded cluster-sorted layout. */
+int tdr_cluster_sample_i32(int64_t n, int S, uint32_t seed, int32_t* sample_idx, void* stream);
+int tdr_cluster_maxmin_capacity(void);
+int tdr_cluster_maxmin_f32(const float* D2, int64_t ld, int S, int C, int32_t* seeds, void* stream);
+int tdr_gather_rows_f32(const float* X, int64_t ldx, int d, const int32_t* idx, const int32_t* idx2, int64_t m, float* out,
+                        void* stream);
+int tdr_cluster_update_f32(const float* Xs, int64_t S, int d, const int32_t* labels, int C, float* cent, void* ws, void* stream);
+int tdr_cluster_tables_f32(const float* X, int64_t n, int d, int64_t ldx, const int32_t* labels, const float* cent, int C,
+                           float* radius, int32_t* tile_begin, int32_t* tiles, int32_t* tile_cluster, int32_t* row_map,
+                           int64_t* n_img, float* dist, int32_t* order, void* ws, void* stream);
 /* Self search with cluster-bound pruning: the points are sorted by a coarse clustering and padded so that clusters
  * start on tile boundaries (row_map); a workgroup visits clusters by increasing centre distance and skips every
  * cluster whose ball cannot reach its queries' current thresholds.  Same results as tdr_knn_screen_f32 (and hence

@@ -76,3 +76,40 @@ for S in slices:
 
     print(json.dumps({"slices": S, "variant": "no_negatives", "grad_ms": timed(step_pos, 16)}), flush=True)
     del sc
+
+# ---- host cost of the loop object: wall time of the tdr_umap_loop_run CALL (no synchronisation) per iteration --------
+import ctypes
+import time
+
+L = _lib.lib()
+S = slices[0]
+sc = Sched(csr.rowptr, cols, eps_per, n, 32, S)
+T = 320
+lr = torch.linspace(1.0, 0.0, T + 1)[:T].contiguous().cuda()
+nxt = nxt0.clone()
+grad, norm2 = torch.empty((n, 2), device="cuda"), torch.zeros(64, device="cuda")
+flag, scratch = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(16, dtype=torch.int32, device="cuda")
+d = _lib.UmapLoopDesc()
+d.Z, d.nc, d.n_total, d.row0, d.n_rows = _lib.ptr(Z), 2, n, 0, n
+d.rowptr, d.cols, d.eps_per, d.next = _lib.ptr(csr.rowptr), _lib.ptr(cols), _lib.ptr(eps_per), _lib.ptr(nxt)
+d.blk_base, d.list, d.hdr, d.err = _lib.ptr(sc.blk_base), _lib.ptr(sc.list), _lib.ptr(sc.hdr), _lib.ptr(sc.err)
+d.acc, d.grad, d.mom_buf = _lib.ptr(sc.acc), _lib.ptr(grad), None
+d.a, d.b, d.neg_rate, d.n_negatives, d.seed = 1.577, 0.895, 5, 150, 77
+d.exag, d.rep, d.eps, d.n_slices, d.block_iters = 1.0, 1.0, 1e-3, S, 32
+d.lr_table, d.max_iter, d.momentum, d.first_iter, d.check_interval = _lib.ptr(lr), T, 0.0, 0, 50
+d.norm2, d.snap, d.nan_flag, d.scratch, d.gather, d.gather_ctx, d.geom = _lib.ptr(norm2), None, _lib.ptr(flag), _lib.ptr(scratch), None, None, 0
+h = ctypes.c_void_p()
+_lib.check(L.tdr_umap_loop_create(ctypes.byref(h), ctypes.byref(d)), "create")
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    for mode, name in ((1, "graph"), (0, "launches")):
+        _lib.check(L.tdr_umap_loop_run(h, 0, 32, mode, _lib.stream_ptr()), "warm")   # capture / first use
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _lib.check(L.tdr_umap_loop_run(h, 32, 288, mode, _lib.stream_ptr()), "run")
+        t_host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        print(json.dumps({"loop_object": name, "host_us_per_iteration": t_host / 288 * 1e6, "gpu_ms_per_iteration": t_all / 288 * 1e3}),
+              flush=True)
+L.tdr_umap_loop_destroy(h)

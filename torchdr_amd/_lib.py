@@ -53,6 +53,8 @@ def parse_header(path=HEADER_PATH):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         argtypes = []
         for a in [x.strip() for x in args.replace("\n", " ").split(",") if x.strip()]:
+            if a == "void":
+                continue
             if "*" in a:
                 argtypes.append(c_ptr)
             else:

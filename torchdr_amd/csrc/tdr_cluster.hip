@@ -1,0 +1,286 @@
+// Coarse cluster index of the pruned exact self search (DESIGN.md "Cluster-bound pruning"), built with the package's own
+// kernels.  The search result never depends on this index -- only the number of tiles the scan may skip does -- so the
+// index is free to be approximate (sampling, projected seeding, unordered cluster members); its BOUNDS are not: radii are
+// rounded up and centre distances down from direct-difference evaluations.
+//
+// Stages (host: torchdr_amd/distance/base.py:ClusterIndex):
+//   1. sample      S = 16 C (<= 16384) stratified rows, gathered in full dimension
+//   2. seeding     farthest-point (max-min) selection of C seeds on the EXACT squared distances of the sample: the S x S
+//                  matrix comes from the dense MFMA kernel (tdr_dense_dist_packed_f32, 17-70 GFLOP), then ONE workgroup
+//                  walks it -- a step reads the newest seed's row (<= 64 KiB, contiguous), updates the running
+//                  min-distances it keeps in registers and takes a workgroup arg-max: no launches, no grid barrier (the
+//                  previous version launched one kernel per seed: 1000 launches, 10.4 ms of an N = 1M fit; a 16-d
+//                  random projection small enough for registers was tried first and mis-seeds ~1 % of the blobs, which
+//                  costs the pruned scan 5x)
+//   3. Lloyd       nearest centre of the sample / of all N points through the exact kNN kernel with k = 1 (K1), centroid
+//                  sums by atomics
+//   4. bounds      radius_c = max |x - c| over the members (direct difference, rounded up), centre distance matrix
+//                  (direct difference, rounded down), visiting order = per-row rank sort of the centre distances
+//   5. layout      members of a cluster contiguous, every cluster padded to a multiple of 32 rows (row_map, -1 = padding)
+#include "tdr_common.h"
+
+namespace tdr {
+
+__device__ __forceinline__ uint32_t cmix32(uint32_t x) {
+    x ^= x >> 17; x *= 0xed5ad4bbu; x ^= x >> 11; x *= 0xac4c1b51u; x ^= x >> 15; x *= 0x31848babu; x ^= x >> 14;
+    return x;
+}
+
+constexpr int CL_PP = 16;    // sample points per thread of the seeding workgroup
+constexpr int CL_TH = 1024;  // threads of the seeding workgroup
+
+// ---- 1. stratified sample: stratum s covers rows [s n / S, (s + 1) n / S); one hashed row of it -----------------------
+__global__ __launch_bounds__(256) void cluster_sample_kernel(int64_t n, int S, uint32_t seed, int32_t* __restrict__ sample_idx) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= S) return;
+    const int64_t lo = (int64_t)s * n / S, hi = (int64_t)(s + 1) * n / S;
+    sample_idx[s] = (int32_t)(lo + (hi > lo ? (int64_t)(cmix32(seed ^ (uint32_t)s * 0x9E3779B9u) % (uint32_t)(hi - lo)) : 0));
+}
+
+// ---- 2. max-min seeding on the sample's distance matrix, one workgroup ------------------------------------------------
+__global__ __launch_bounds__(CL_TH) void cluster_maxmin_kernel(const float* __restrict__ D2, int64_t ld, int S, int C,
+                                                              int32_t* __restrict__ seeds) {
+    __shared__ unsigned long long wbest[CL_TH / 64];
+    __shared__ int winner;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float mind[CL_PP];
+#pragma unroll
+    for (int p = 0; p < CL_PP; ++p) mind[p] = (p * CL_TH + tid) < S ? 3.0e38f : -1.0f;
+    int cur = 0;  // first seed: sample point 0
+    for (int step = 0; step < C; ++step) {
+        if (tid == 0) seeds[step] = cur;
+        const float* row = D2 + (size_t)cur * ld;
+        float best = -2.0f;
+        int bi = 0;
+#pragma unroll
+        for (int p = 0; p < CL_PP; ++p) {
+            const int i = p * CL_TH + tid;
+            if (i < S) mind[p] = fminf(mind[p], row[i]);
+            if (mind[p] > best) { best = mind[p]; bi = i; }
+        }
+        // workgroup arg-max of (min-distance, index): clamped at 0, so the bit patterns order like the values
+        unsigned long long key = ((unsigned long long)__float_as_uint(fmaxf(best, 0.f)) << 32) | (unsigned)(0x7fffffff - bi);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o, 64);
+            key = other > key ? other : key;
+        }
+        if (lane == 0) wbest[w] = key;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long k = wbest[0];
+            for (int i = 1; i < CL_TH / 64; ++i) k = wbest[i] > k ? wbest[i] : k;
+            winner = 0x7fffffff - (int)(unsigned)(k & 0xffffffffu);
+        }
+        __syncthreads();
+        cur = winner;
+    }
+}
+
+// ---- gather rows: out[i] = X[idx[i]] (optionally through a second index: X[idx[idx2[i]]]) ---------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ X, int64_t ldx, int d,
+                                                          const int32_t* __restrict__ idx, const int32_t* __restrict__ idx2,
+                                                          int64_t m, float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * d) return;
+    const int64_t i = e / d;
+    const int c = (int)(e - i * d);
+    const int64_t row = idx[idx2 ? idx2[i] : i];
+    out[e] = X[row * ldx + c];
+}
+
+// ---- 3. Lloyd update: sums[label] += x, cnt[label] += 1 (one wavefront per point), then cent = sums / cnt -----------------
+__global__ __launch_bounds__(256) void centroid_accumulate_kernel(const float* __restrict__ Xs, int64_t S, int d,
+                                                                  const int32_t* __restrict__ labels, float* __restrict__ sums,
+                                                                  int32_t* __restrict__ cnt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= S) return;
+    const int l = labels[s];
+    for (int c = lane; c < d; c += 64) unsafeAtomicAdd(&sums[(size_t)l * d + c], Xs[s * d + c]);
+    if (lane == 0) atomicAdd(&cnt[l], 1);
+}
+__global__ __launch_bounds__(256) void centroid_finalize_kernel(const float* __restrict__ sums, const int32_t* __restrict__ cnt,
+                                                                int C, int d, float* __restrict__ cent) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= C * d) return;
+    const int n = cnt[e / d];
+    if (n > 0) cent[e] = sums[e] / (float)n;  // an empty cluster keeps its centre
+}
+
+// ---- 4. bounds ----------------------------------------------------------------------------------------------------------
+// radius[label] = max |x - c_label| (direct difference) and the cluster sizes; one wavefront per point
+__global__ __launch_bounds__(256) void cluster_radius_kernel(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
+                                                             const int32_t* __restrict__ labels, const float* __restrict__ cent,
+                                                             unsigned* __restrict__ radius_bits, int32_t* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int l = labels[r];
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float t = X[r * ldx + c] - cent[(size_t)l * d + c];
+        s += t * t;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        atomicMax(&radius_bits[l], __float_as_uint(sqrtf(s)));  // >= 0: bit order = value order
+        atomicAdd(&counts[l], 1);
+    }
+}
+// radius *= 1 + 1e-5 (+ tiny): the bound has to dominate the rounding of the sums above
+__global__ void radius_round_up_kernel(float* __restrict__ radius, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) radius[c] = radius[c] * (1.0f + 1e-5f) + 1e-30f;
+}
+
+// centre distance matrix (direct difference, rounded down) and, per row, the clusters by increasing centre distance
+// (rank sort in LDS; C <= 4096)
+__global__ __launch_bounds__(256) void centre_tables_kernel(const float* __restrict__ cent, int C, int d, float* __restrict__ dist,
+                                                            int32_t* __restrict__ order) {
+    extern __shared__ float row[];  // C distances
+    const int a = blockIdx.x;
+    for (int b = threadIdx.x; b < C; b += 256) {
+        float s = 0.f;
+        for (int c = 0; c < d; ++c) {
+            const float t = cent[(size_t)a * d + c] - cent[(size_t)b * d + c];
+            s += t * t;
+        }
+        row[b] = sqrtf(s);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < C; b += 256) {
+        const float mine = row[b];
+        int rank = 0;
+        for (int q = 0; q < C; ++q) {
+            const float o = row[q];
+            rank += (o < mine || (o == mine && q < b)) ? 1 : 0;
+        }
+        order[(size_t)a * C + rank] = b;
+        dist[(size_t)a * C + b] = mine * (1.0f - 1e-5f);
+    }
+}
+
+// ---- 5. layout ------------------------------------------------------------------------------------------------------------
+// one workgroup: tiles_c = ceil(count_c / 32), tile_begin = exclusive scan, tile_cluster[t] = c, *n_img = 32 * total tiles
+__global__ __launch_bounds__(256) void cluster_tiles_kernel(const int32_t* __restrict__ counts, int C, int32_t* __restrict__ tile_begin,
+                                                            int32_t* __restrict__ tiles, int32_t* __restrict__ tile_cluster,
+                                                            int64_t* __restrict__ n_img) {
+    __shared__ int tot[256];
+    const int tid = threadIdx.x;
+    const int per = (C + 255) / 256;
+    const int c0 = tid * per, c1 = (c0 + per < C) ? c0 + per : C;
+    int s = 0;
+    for (int c = c0; c < c1; ++c) s += (counts[c] + 31) / 32;
+    tot[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) { const int t = tot[i]; tot[i] = run; run += t; }
+        tile_begin[C] = run;
+        *n_img = (int64_t)run * 32;
+    }
+    __syncthreads();
+    int run = tot[tid];
+    for (int c = c0; c < c1; ++c) {
+        const int t = (counts[c] + 31) / 32;
+        tile_begin[c] = run;
+        tiles[c] = t;
+        for (int i = 0; i < t; ++i) tile_cluster[run + i] = c;
+        run += t;
+    }
+}
+// row_map[tile_begin[label] * 32 + position] = row (positions handed out by an atomic cursor per cluster)
+__global__ __launch_bounds__(256) void cluster_scatter_kernel(const int32_t* __restrict__ labels, int64_t n,
+                                                              const int32_t* __restrict__ tile_begin, int32_t* __restrict__ cursor,
+                                                              int32_t* __restrict__ row_map) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int l = labels[r];
+    const int pos = atomicAdd(&cursor[l], 1);
+    row_map[(size_t)tile_begin[l] * 32 + pos] = (int32_t)r;
+}
+
+}  // namespace tdr
+
+using namespace tdr;
+
+extern "C" {
+
+/* 1. indices of S stratified sample rows of an n-row block. */
+int tdr_cluster_sample_i32(int64_t n, int S, uint32_t seed, int32_t* sample_idx, void* stream) {
+    if (!sample_idx || n <= 0 || S <= 0 || n >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(cluster_sample_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n, S, seed, sample_idx);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* largest sample the seeding workgroup handles */
+int tdr_cluster_maxmin_capacity(void) { return CL_PP * CL_TH; }
+
+/* 2. C farthest-point seeds (indices into the sample) from the sample's S x S squared-distance matrix D2 (row stride ld);
+ * S <= tdr_cluster_maxmin_capacity(). */
+int tdr_cluster_maxmin_f32(const float* D2, int64_t ld, int S, int C, int32_t* seeds, void* stream) {
+    if (!D2 || !seeds || S <= 0 || C <= 0 || C > S || ld < S) return TDR_ERR_BAD_ARG;
+    if (S > CL_PP * CL_TH) return TDR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cluster_maxmin_kernel, dim3(1), dim3(CL_TH), 0, (hipStream_t)stream, D2, ld, S, C, seeds);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* out (m, d) = X[idx[idx2 ? idx2[i] : i]] */
+int tdr_gather_rows_f32(const float* X, int64_t ldx, int d, const int32_t* idx, const int32_t* idx2, int64_t m, float* out,
+                        void* stream) {
+    if (!X || !idx || !out || m <= 0 || d <= 0 || ldx < d) return TDR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((m * d + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X, ldx, d, idx,
+                       idx2, m, out);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* 3. one Lloyd update on the sample: cent (C, d) <- mean of the sample points labelled c (clusters without points keep
+ * their centre).  ws: C * d floats + C int32. */
+int tdr_cluster_update_f32(const float* Xs, int64_t S, int d, const int32_t* labels, int C, float* cent, void* ws, void* stream) {
+    if (!Xs || !labels || !cent || !ws || S <= 0 || d <= 0 || C <= 0) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    float* sums = (float*)ws;
+    int32_t* cnt = (int32_t*)(sums + (size_t)C * d);
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)C * d * 4 + (size_t)C * 4, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(centroid_accumulate_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, Xs, S, d, labels, sums, cnt);
+    hipLaunchKernelGGL(centroid_finalize_kernel, dim3((unsigned)((C * d + 255) / 256)), dim3(256), 0, st, (const float*)sums,
+                       (const int32_t*)cnt, C, d, cent);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* 4 + 5. everything that follows the assignment of all n points (labels): radii (rounded up), cluster sizes, the padded
+ * cluster-sorted layout (row_map: n + 32 C int32, -1 = padding; tile_cluster: (n + 32 C) / 32 int32; tile_begin: C + 1;
+ * tiles: C; *n_img = rows of the padded image), centre distances (C x C, rounded down) and visiting order (C x C).
+ * ws: 2 * C int32. */
+int tdr_cluster_tables_f32(const float* X, int64_t n, int d, int64_t ldx, const int32_t* labels, const float* cent, int C,
+                           float* radius, int32_t* tile_begin, int32_t* tiles, int32_t* tile_cluster, int32_t* row_map,
+                           int64_t* n_img, float* dist, int32_t* order, void* ws, void* stream) {
+    if (!X || !labels || !cent || !radius || !tile_begin || !tiles || !tile_cluster || !row_map || !n_img || !dist || !order || !ws)
+        return TDR_ERR_BAD_ARG;
+    if (n <= 0 || d <= 0 || ldx < d || C <= 0 || n >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
+    if (C > 4096) return TDR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* counts = (int32_t*)ws;
+    int32_t* cursor = counts + C;
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)2 * C * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(radius, 0, (size_t)C * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(row_map, 0xFF, (size_t)(n + 32 * (int64_t)C) * 4, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(cluster_radius_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, X, n, d, ldx, labels, cent,
+                       (unsigned*)radius, counts);
+    hipLaunchKernelGGL(radius_round_up_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, radius, C);
+    hipLaunchKernelGGL(cluster_tiles_kernel, dim3(1), dim3(256), 0, st, (const int32_t*)counts, C, tile_begin, tiles, tile_cluster, n_img);
+    hipLaunchKernelGGL(cluster_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, labels, n,
+                       (const int32_t*)tile_begin, cursor, row_map);
+    hipLaunchKernelGGL(centre_tables_kernel, dim3((unsigned)C), dim3(256), (size_t)C * sizeof(float), st, cent, C, d, dist, order);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+}  // extern "C"

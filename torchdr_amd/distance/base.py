@@ -107,75 +107,68 @@ _PRUNE_MAX_SCAN_FRACTION = 0.5  # predicted share of tiles still visited above w
 class ClusterIndex:
     """Coarse clustering of a point block for the pruned self search: cluster-sorted row order padded to tile
     boundaries (``row_map``), one ball (centre, radius) per cluster, centre distances and the visiting order.
-    Built with library GEMMs (``torch.mm``) -- the search result does not depend on it, only the amount of work
-    the scan can skip does."""
+    Built by the package's own kernels (``csrc/tdr_cluster.hip``; nearest-centre assignments are the exact kNN kernel
+    with k = 1) -- the search result does not depend on it, only the amount of work the scan can skip does."""
 
     def __init__(self, P: "PackedPoints", n_clusters: Optional[int] = None, iters: int = 2):
         X = P.X
         dev = X.device
         N, D = X.shape
+        L = _lib.lib()
         # more than 2048 balls measured slower at N = 4M (3.5 s vs 2.7 s): Gaussian blobs in high dimension are not
         # resolved further by splitting them -- the sub-balls overlap and all of them are scanned anyway
         C = int(n_clusters or min(2048, max(8, N // 1000)))
-        g = torch.Generator(device=dev).manual_seed(20240917)
-        S = min(N, 32 * C)
-        Xs = X[torch.randint(0, N, (S,), device=dev, generator=g)]
-        # farthest-point (max-min) seeding on the sample: one seed per well-separated group, an epsilon-net otherwise
-        # (random seeds leave merged clusters whose large balls every workgroup would have to scan), then Lloyd steps
-        L = _lib.lib()
+        S = int(min(N, 16 * C, L.tdr_cluster_maxmin_capacity()))
+        C = min(C, S)
+        st = _lib.stream_ptr()
+        # 1-2. stratified sample; farthest-point seeds on its exact distance matrix (dense MFMA kernel + one workgroup):
+        # one seed per well-separated group, an epsilon-net otherwise (random seeds leave merged clusters whose large
+        # balls every workgroup would have to scan)
+        sample_idx = torch.empty(S, dtype=torch.int32, device=dev)
+        _lib.check(L.tdr_cluster_sample_i32(N, S, 20240917, _lib.ptr(sample_idx), st), "tdr_cluster_sample_i32")
+        Xs = torch.empty((S, D), dtype=torch.float32, device=dev)
+        _lib.check(L.tdr_gather_rows_f32(_lib.ptr(X), X.stride(0), D, _lib.ptr(sample_idx), None, S, _lib.ptr(Xs), st), "tdr_gather_rows_f32")
+        Ps = PackedPoints(Xs)
+        D2 = dense_packed(Ps, Ps, "sqeuclidean", False)
         seeds = torch.empty(C, dtype=torch.int32, device=dev)
-        ws_bytes = L.tdr_maxmin_workspace_bytes(S, C)
-        ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
-        # the C sequential seeding steps read the whole sample each: run them on a 32-d random projection (distances
-        # within ~25 %, plenty for picking well-separated seeds; the centres themselves are taken in the full space)
-        Xp = Xs
-        if D > 32:
-            R = torch.randn((D, 32), dtype=X.dtype, device=dev, generator=g) * (1.0 / 32 ** 0.5)
-            Xp = torch.mm(Xs, R)
-        _lib.check(L.tdr_maxmin_seeds_f32(_lib.ptr(Xp), S, Xp.shape[1], Xp.stride(0), C, _lib.ptr(seeds), _lib.ptr(ws),
-                                          ws_bytes, _lib.stream_ptr()), "tdr_maxmin_seeds_f32")
-        cent = Xs[seeds.long()].clone()
+        _lib.check(L.tdr_cluster_maxmin_f32(_lib.ptr(D2), D2.stride(0), S, C, _lib.ptr(seeds), st), "tdr_cluster_maxmin_f32")
+        del D2
+        cent = torch.empty((C, D), dtype=torch.float32, device=dev)
+        _lib.check(L.tdr_gather_rows_f32(_lib.ptr(X), X.stride(0), D, _lib.ptr(sample_idx), _lib.ptr(seeds), C, _lib.ptr(cent), st),
+                   "tdr_gather_rows_f32")
+        # 3. Lloyd steps on the sample, then the assignment of all N points: nearest centre = exact kNN with k = 1
+        ws = torch.empty(C * D + C + 2 * C, dtype=torch.int32, device=dev)
         for _ in range(iters):
-            lab = ((cent * cent).sum(1)[None, :] - 2.0 * torch.mm(Xs, cent.t())).argmin(1)
-            cnt = torch.bincount(lab, minlength=C).to(X.dtype)
-            sums = torch.zeros((C, D), dtype=X.dtype, device=dev).index_add_(0, lab, Xs)
-            cent = torch.where(cnt[:, None] > 0, sums / cnt.clamp(min=1)[:, None], cent)
-        cn = (cent * cent).sum(1)
-        labels = torch.empty(N, dtype=torch.int64, device=dev)
-        radius = torch.zeros(C, dtype=X.dtype, device=dev)
-        for r0 in range(0, N, 131072):
-            Xc = X[r0:r0 + 131072]
-            lab = (cn[None, :] - 2.0 * torch.mm(Xc, cent.t())).argmin(1)
-            labels[r0:r0 + 131072] = lab
-            radius.scatter_reduce_(0, lab, (Xc - cent[lab]).norm(dim=1), reduce="amax")
-        counts = torch.bincount(labels, minlength=C)
-        tiles = (counts + 31) // 32
-        tile_begin = torch.zeros(C + 1, dtype=torch.int64, device=dev)
-        tile_begin[1:] = tiles.cumsum(0)
-        n_img = int(tile_begin[-1].item()) * 32
-        order = torch.argsort(labels, stable=True)
-        first = torch.zeros(C + 1, dtype=torch.int64, device=dev)
-        first[1:] = counts.cumsum(0)
-        sl = labels[order]
-        dst = tile_begin[sl] * 32 + (torch.arange(N, device=dev) - first[sl])
-        row_map = torch.full((max(n_img, 32),), -1, dtype=torch.int32, device=dev)
-        row_map[dst] = order.to(torch.int32)
-        # centre distances by DIRECT difference (a GEMM-based cdist loses digits by cancellation exactly where the bounds
-        # matter, for nearby centres), in row chunks of <= 1 GiB
-        cd = torch.empty((C, C), dtype=X.dtype, device=dev)
-        rows_per = max(1, (1 << 28) // max(C * D, 1))
-        for r0 in range(0, C, rows_per):
-            cd[r0:r0 + rows_per] = (cent[r0:r0 + rows_per, None, :] - cent[None, :, :]).norm(dim=2)
+            _, lab = knn_packed(Ps, PackedPoints(cent), 1, "sqeuclidean", exclude_self=False, _allow_screen=False)
+            _lib.check(L.tdr_cluster_update_f32(_lib.ptr(Xs), S, D, _lib.ptr(lab), C, _lib.ptr(cent), _lib.ptr(ws), st),
+                       "tdr_cluster_update_f32")
+        _, labels = knn_packed(P, PackedPoints(cent), 1, "sqeuclidean", exclude_self=False, _allow_screen=False)
+        # 4-5. radii (rounded up), padded cluster-sorted layout, centre distances (rounded down), visiting order
+        cap = N + 32 * C
+        radius = torch.empty(C, dtype=torch.float32, device=dev)
+        tile_begin = torch.empty(C + 1, dtype=torch.int32, device=dev)
+        tiles = torch.empty(C, dtype=torch.int32, device=dev)
+        tile_cluster = torch.empty(cap // 32, dtype=torch.int32, device=dev)
+        row_map = torch.empty(cap, dtype=torch.int32, device=dev)
+        n_img = torch.zeros(1, dtype=torch.int64, device=dev)
+        cd = torch.empty((C, C), dtype=torch.float32, device=dev)
+        order = torch.empty((C, C), dtype=torch.int32, device=dev)
+        _lib.check(
+            L.tdr_cluster_tables_f32(_lib.ptr(X), N, D, X.stride(0), _lib.ptr(labels), _lib.ptr(cent), C, _lib.ptr(radius),
+                                     _lib.ptr(tile_begin), _lib.ptr(tiles), _lib.ptr(tile_cluster), _lib.ptr(row_map),
+                                     _lib.ptr(n_img), _lib.ptr(cd), _lib.ptr(order), _lib.ptr(ws), st),
+            "tdr_cluster_tables_f32",
+        )
         self.n_clusters = C
-        self.n_img = n_img
-        self.row_map = row_map
-        self.tile_cluster = torch.repeat_interleave(torch.arange(C, device=dev, dtype=torch.int32), tiles).contiguous()
-        self.tile_begin = tile_begin.to(torch.int32).contiguous()
-        self.radius = (radius * (1.0 + 1e-5) + 1e-30).contiguous()   # rounded up
-        self.dist = (cd * (1.0 - 1e-5)).contiguous()                  # rounded down
-        self.order = torch.argsort(cd, dim=1).to(torch.int32).contiguous()
+        self.n_img = max(int(n_img.item()), 32)
+        self.row_map = row_map[: self.n_img]
+        self.tile_cluster = tile_cluster[: self.n_img // 32]
+        self.tile_begin = tile_begin
+        self.radius = radius     # rounded up in the kernel
+        self.dist = cd           # rounded down in the kernel
+        self.order = order
         self.img16 = None
-        self.tiles = tiles
+        self.tiles = tiles.to(torch.int64)
 
     def scan_fraction(self, tau: float) -> float:
         """Share of the database tiles a query block still has to visit when its thresholds are <= tau (squared
@@ -472,7 +465,8 @@ def knn_packed(
     ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
     tile_floats = L.tdr_packed_floats(32, d)
     qdata = Q.data[(q0 // 32) * tile_floats:]
-    if PROFILE is not None:
+    prof = PROFILE is not None and _allow_screen   # internal searches (cluster index: k = 1 vs the centres) are not the kNN build's scan
+    if prof:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     _lib.check(
@@ -483,7 +477,7 @@ def knn_packed(
         ),
         "tdr_knn_packed_f32",
     )
-    if PROFILE is not None:
+    if prof:
         ev1.record()
         PROFILE.append((ev0, ev1, nq, "exact"))
     return out_d, out_i
