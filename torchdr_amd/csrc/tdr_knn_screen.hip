@@ -865,7 +865,10 @@ static int screen_splits(int64_t nq, int n_db_tiles, const ScreenCfg& c) {
     int64_t s = (target + wgs - 1) / wgs;
     const int64_t max_by_tiles = n_db_tiles / 64 > 0 ? n_db_tiles / 64 : 1;
     if (s > max_by_tiles) s = max_by_tiles;
-    if (s > 16) s = 16;
+    // the rescoring kernel keeps 2 x splits x L keys per wavefront in LDS: 4 wavefronts x 16 B x splits x L <= ~144 KiB
+    const int64_t max_by_lds = (144 * 1024) / (64 * (int64_t)(c.L > 0 ? c.L : 1));
+    if (s > max_by_lds) s = max_by_lds;
+    if (s > 32) s = 32;
     if (s < 1) s = 1;
     return (int)s;
 }

@@ -35,7 +35,7 @@ import os as _os
 SCREEN_MODE = _os.environ.get("TDR_KNN_SCREEN", "auto")
 _SCREEN_MIN_PAIRS = 1 << 26  # nq * n_db below which the one-stage kernel is used
 _SCREEN_PILOT_MIN_Q = 32768   # searches with at least this many queries screen a pilot slice first
-_SCREEN_PILOT_Q = 2048
+_SCREEN_PILOT_Q = 1024   # 8 query groups x 32 database slices = 256 workgroups: 3.2 ms per tier at N = 1M (2048 queries x 16 slices: 6.5 ms)
 _SCREEN_PILOT_MAX_FRAC = 0.05  # overflowed share of the pilot above which the one-stage kernel is used
 # counters of the last knn_packed call (tests / bench): path taken and number of overflowed queries
 LAST_KNN = {"path": None, "flagged": 0}
@@ -118,7 +118,7 @@ class ClusterIndex:
         # more than 2048 balls measured slower at N = 4M (3.5 s vs 2.7 s): Gaussian blobs in high dimension are not
         # resolved further by splitting them -- the sub-balls overlap and all of them are scanned anyway
         C = int(n_clusters or min(2048, max(8, N // 1000)))
-        S = int(min(N, 16 * C, L.tdr_cluster_maxmin_capacity()))
+        S = int(min(N, 8 * C, L.tdr_cluster_maxmin_capacity()))
         C = min(C, S)
         st = _lib.stream_ptr()
         # 1-2. stratified sample; farthest-point seeds on its exact distance matrix (dense MFMA kernel + one workgroup):
