@@ -91,6 +91,48 @@ def cpu_baseline(X_cpu, k, max_iter, model):
     }
 
 
+def knn_variants(X, args, dbase):
+    """Context for `knn_build_sec` (outside the timed region): how much of it is the data.  The pruned search skips the
+    tiles whose cluster balls cannot reach a query's threshold -- on the benchmark's 1000-blob mixture that is ~99.9 % of
+    them -- so the same exact search is also timed without pruning (two-stage: fp16-split screening on the f16 matrix
+    pipe + exact rescoring), as the one-stage fp32-MFMA scan, and on structureless data of the same shape (centre
+    scale 0: one Gaussian), where pruning cannot help."""
+    from torchdr_amd.distance import pairwise_distances
+
+    def timed(Xd, prune, screen):
+        old = dbase.PRUNE_MODE, dbase.SCREEN_MODE
+        dbase.PRUNE_MODE, dbase.SCREEN_MODE = prune, screen
+        try:
+            best = 1e9
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pairwise_distances(Xd, metric="sqeuclidean", k=args.k, exclude_diag=True, return_indices=True)
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            return best, dbase.LAST_KNN.get("path")
+        finally:
+            dbase.PRUNE_MODE, dbase.SCREEN_MODE = old
+
+    flops = 2.0 * args.n * args.n * args.d
+    out = {}
+    t, path = timed(X, "0", "auto")
+    out["knn_unpruned_sec"] = t
+    out["knn_unpruned_path"] = path
+    out["knn_unpruned_algorithmic_tflops"] = flops / t / 1e12
+    out["knn_unpruned_frac_of_f16_peak"] = flops / t / 1e12 / F16_MFMA_PEAK_TFLOPS
+    t, path = timed(X, "0", "0")
+    out["knn_one_stage_sec"] = t
+    out["knn_one_stage_frac_of_fp32_mfma_peak"] = flops / t / 1e12 / FP32_MFMA_PEAK_TFLOPS
+    X0 = gmm(args.n, args.d, 0.0).to(X.device)
+    t, path = timed(X0, "auto", "auto")
+    out["knn_structureless_sec"] = t
+    out["knn_structureless_path"] = path
+    out["note"] = ("wall seconds of pairwise_distances(k=%d) incl. packing and pilots, best of 2, outside the timed region; "
+                   "structureless = the same generator with centre scale 0" % args.k)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +144,8 @@ def main():
     ap.add_argument("--max-iter", type=int, default=1000)
     ap.add_argument("--scale", type=float, default=2.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-knn-variants", action="store_true",
+                    help="skip the untimed kNN context figures (unpruned two-stage, one-stage fp32, structureless data)")
     ap.add_argument("--loop", choices=["auto", "graph", "c", "python"], default="auto",
                     help="UMAP loop driver: replayed HIP graphs (default), plain launches from the C loop object, or one Python iteration per step")
     args = ap.parse_args()
@@ -304,6 +348,8 @@ def main():
             "roofline": dominant,
             "roofline_secondary": secondary,
         }
+        if not args.no_knn_variants and world == 1:
+            out["knn_context"] = knn_variants(X, args, dbase)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(X_cpu, args.k, args.max_iter, keep)
         print(json.dumps(out), flush=True)

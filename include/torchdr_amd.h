@@ -305,6 +305,10 @@ int tdr_fill_f32(float* p, int64_t n, float v, void* stream);
  * affinity/entropic.py:37-42,518-565 (_log_Pse, row entropy / logsumexp of the dual-ascent loop) */
 int tdr_sea_rowstats_f32(const float* packed, int64_t n, int d, const float* side, int exclude_diag, float diag_add,
                          float* psum, float* ent, void* stream);
+/* affinity/entropic.py:728-734 on the input points, matrix-free: lse[i] = LSE_j(log K_ij + f_j), log K = -C / eps
+ * (student != 0: -log(1 + C) / eps); the caller forms the symmetric Sinkhorn update f <- 0.5 (f - lse). */
+int tdr_sinkhorn_lse_f32(const float* packed, int64_t n, int d, const float* f, float inv_eps, int student, int exclude_diag,
+                         float diag_add, float* lse, void* stream);
 /* gradient of neighbor_embedding/tsnekhorn.py:210-230 w.r.t. the embedding (duals detached) */
 int tdr_khorn_grad_f32(const float* packed, int64_t n, int d, const float* side, float log_n, float* grad, void* stream);
 /* affinity/entropic.py:733-740: one symmetric log-domain Sinkhorn update, student kernel on the embedding */

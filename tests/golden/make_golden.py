@@ -485,6 +485,25 @@ def cosne_fixture():
     save("cosne", **out)
 
 
+def sinkhorn_fixture():
+    """SinkhornAffinity on INPUT points (entropic.py:693-755): Gaussian base kernel (the class default) and the student
+    base kernel on an 8-d input, cold and warm started: duals, iteration counts, a few rows of log P."""
+    from torchdr.affinity import SinkhornAffinity
+
+    X = gmm(300, 8, 1.5, seed=77)
+    out = {"X": X}
+    for name, kw in (("gauss", dict(eps=5.0, base_kernel="gaussian")), ("gauss_nozd", dict(eps=20.0, base_kernel="gaussian", zero_diag=False)),
+                     ("student", dict(eps=2.0, base_kernel="student"))):
+        aff = SinkhornAffinity(tol=1e-5, max_iter=300, backend=None, **kw)
+        logP = aff(X, log=True)
+        out[f"{name}_dual"], out[f"{name}_n_iter"], out[f"{name}_logP_rows"] = aff.dual_.clone(), torch.tensor(aff.n_iter_), logP[:6].clone()
+    aff = SinkhornAffinity(eps=5.0, tol=1e-5, max_iter=3, backend=None)
+    init = torch.linspace(-1, 1, 300)
+    aff._compute_log_affinity(X, init_dual=init.clone())
+    out["warm_init"], out["warm_dual"] = init, aff.dual_.clone()
+    save("sinkhorn", **out)
+
+
 def c1_tsne_fixture():
     """BASELINE config C1 at full size: TSNE on the 5000 x 50 Gaussian mixture, perplexity 30, backend=None (CPU):
     the reference's first two optimisation steps (embedding before / gradient / after, lr, momentum, exaggeration) and
@@ -523,7 +542,7 @@ if __name__ == "__main__":
                umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne2_step=ne2_step_fixture,
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
-               cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture)
+               cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

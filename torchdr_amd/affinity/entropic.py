@@ -271,10 +271,35 @@ def sinkhorn_student_dual(Z: torch.Tensor, init_dual, max_iter: int, tol: float,
     return f, k
 
 
+def sinkhorn_input_dual(X: torch.Tensor, eps: float, init_dual, max_iter: int, tol: float, zero_diag: bool, student: bool):
+    """Symmetric Sinkhorn fixed point on the INPUT points (reference ``entropic.py:693-755``), matrix-free: every
+    iteration is one pass of the MFMA pair scan (``tdr_sinkhorn_lse_f32``: distances tile by tile, streaming row
+    log-sum-exp), nothing of size N x N exists.  Returns (packed points, dual, n_iter)."""
+    _lib.require_gpu(X, "X")
+    packed = PackedPoints(X.detach().float())
+    n = X.shape[0]
+    f = torch.zeros(n, dtype=torch.float32, device=X.device) if init_dual is None else init_dual.clone().float()
+    lse = torch.empty_like(f)
+    L = _lib.lib()
+    k = 0
+    for k in range(max_iter):
+        _lib.check(L.tdr_sinkhorn_lse_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(f), 1.0 / float(eps), 1 if student else 0,
+                                          1 if zero_diag else 0, 1e12, _lib.ptr(lse), _lib.stream_ptr()), "tdr_sinkhorn_lse_f32")
+        red = -lse
+        f = 0.5 * (f + red)
+        check_NaNs(f, msg=f"ERROR Affinity: NaN at iter {k}.")
+        if float(torch.norm(f - red)) < tol:   # tested AFTER the averaging update (:735-740)
+            break
+    return packed, f, k
+
+
 class SinkhornAffinity(LogAffinity):
-    r"""Doubly stochastic affinity by symmetric log-domain Sinkhorn (reference ``entropic.py:580-755``).
-    The accelerated path covers what TSNEkhorn uses: ``base_kernel="student"``, ``eps=1`` on a 2-D / 3-D
-    embedding, no gradient tracking; other settings raise ``NotImplementedError``."""
+    r"""Doubly stochastic affinity by symmetric log-domain Sinkhorn (reference ``entropic.py:580-755``):
+    :math:`P = \exp(f_i + f_j - C_{ij}/\varepsilon)/N` (``base_kernel="gaussian"``, the class default) or with
+    :math:`\log(1 + C)` in place of :math:`C` (``"student"``).  On a 2-D / 3-D input with the student kernel and
+    ``eps = 1`` (what TSNEkhorn evaluates on the embedding every step) the update is the LDS-tiled all-pairs kernel;
+    any other input runs the matrix-free MFMA pair scan.  ``with_grad=True`` (autograd through the iterations) is not
+    available: there is no autograd graph on the HIP path."""
 
     def __init__(self, eps: float = 1.0, tol: float = 1e-5, max_iter: int = 1000, base_kernel: str = "gaussian",
                  metric: str = "sqeuclidean", zero_diag: bool = True, device: str = "auto", backend=None,
@@ -289,13 +314,17 @@ class SinkhornAffinity(LogAffinity):
         self.with_grad = with_grad
 
     def fit_dual(self, X: torch.Tensor, init_dual=None):
-        if self.base_kernel != "student" or self.eps != 1.0 or self.with_grad or X.shape[1] not in (2, 3) \
-                or self.metric != "sqeuclidean":
-            raise NotImplementedError(
-                "[torchdr_amd] SinkhornAffinity: only base_kernel='student', eps=1, with_grad=False on a "
-                "2-D/3-D input is accelerated (the TSNEkhorn configuration)."
-            )
-        dual, k = sinkhorn_student_dual(X, init_dual, self.max_iter, self.tol, self.zero_diag)
+        if self.with_grad:
+            raise NotImplementedError("[torchdr_amd] SinkhornAffinity(with_grad=True): the HIP path has no autograd graph.")
+        if self.base_kernel not in ("gaussian", "student"):
+            raise ValueError(f"[TorchDR] ERROR : base_kernel {self.base_kernel} not supported in SinkhornAffinity.")
+        if self.metric != "sqeuclidean":
+            raise NotImplementedError("[torchdr_amd] SinkhornAffinity supports metric='sqeuclidean'.")
+        if self.base_kernel == "student" and self.eps == 1.0 and X.shape[1] in (2, 3):
+            dual, k = sinkhorn_student_dual(X, init_dual, self.max_iter, self.tol, self.zero_diag)
+        else:
+            _, dual, k = sinkhorn_input_dual(X, self.eps, init_dual, self.max_iter, self.tol, self.zero_diag,
+                                             self.base_kernel == "student")
         self.register_buffer("dual_", dual, persistent=False)
         self.n_iter_ = k
         return dual
@@ -305,9 +334,9 @@ class SinkhornAffinity(LogAffinity):
         if n > _DENSE_LIMIT:
             raise MemoryError(f"[torchdr_amd] dense Sinkhorn output for N={n} is not materialised; use fit_dual.")
         dual = self.fit_dual(X, init_dual)
-        Xc = X.detach().float()
-        D = ((Xc[:, None, :] - Xc[None, :, :]) ** 2).sum(-1)
-        if self.zero_diag:
-            D = D + torch.diag(torch.full((n,), 1e12, device=X.device))
-        log_K = -(1 + D).log()
+        packed = PackedPoints(X.detach().float())
+        C = dense_packed(packed, packed, "sqeuclidean", self.zero_diag)
+        if self.base_kernel == "student":
+            C = (1 + C).log()
+        log_K = -C / self.eps
         return dual[:, None] + dual[None, :] + log_K - math.log(n)

@@ -20,7 +20,15 @@ import torch
 from torchdr_amd import _lib
 from torchdr_amd.affinity import Affinity, SparseAffinity
 from torchdr_amd.base import DRModule
-from torchdr_amd.utils import compute_device, to_torch
+from torchdr_amd.utils import check_nonnegativity, compute_device, cross_entropy_loss, to_torch
+
+
+def square_loss(P, Q):
+    """utils/utils.py:127-147: sum of squared differences."""
+    return ((P - Q) ** 2).sum()
+
+
+LOSS_DICT = {"square_loss": square_loss, "cross_entropy_loss": cross_entropy_loss}
 
 
 _LR_TABLE_CACHE = {}
@@ -88,6 +96,8 @@ class AffinityMatcher(DRModule):
         self.max_iter = max_iter
         self.scheduler = scheduler
         self.scheduler_kwargs = scheduler_kwargs
+        if loss_fn not in LOSS_DICT:
+            raise ValueError(f"[TorchDR] ERROR : Loss function {loss_fn} not supported.")
         self.loss_fn = loss_fn
         self.kwargs_loss = kwargs_loss
         self.init = init
@@ -128,13 +138,23 @@ class AffinityMatcher(DRModule):
             )
 
         self.on_affinity_computation_start()
-        if self.affinity_in == "precomputed":
-            raise NotImplementedError('[torchdr_amd] affinity_in="precomputed" is not part of the accelerated path.')
-        if self.verbose:
-            self.logger.info(
-                f"----- Computing the input affinity matrix with {self.affinity_in.__class__.__name__} -----"
-            )
-        self._compute_affinity_in(X)
+        if self.affinity_in == "precomputed":   # reference :259-271
+            if self.verbose:
+                self.logger.info("----- Using precomputed affinity matrix -----")
+            if self.n_features_in_ != self.n_samples_in_:
+                raise ValueError(
+                    '[TorchDR] ERROR : When affinity_in="precomputed" the input '
+                    "X in fit must be a tensor of lazy tensor of shape "
+                    "(n_samples, n_samples)."
+                )
+            check_nonnegativity(X)
+            self.register_buffer("affinity_in_", X, persistent=False)
+        else:
+            if self.verbose:
+                self.logger.info(
+                    f"----- Computing the input affinity matrix with {self.affinity_in.__class__.__name__} -----"
+                )
+            self._compute_affinity_in(X)
         self.on_affinity_computation_end()
 
         if self.verbose:
@@ -197,6 +217,8 @@ class AffinityMatcher(DRModule):
         Multi-GPU, rows-only + fused SGD: each rank steps ITS rows and the updated rows are all-gathered
         (1/W of the reference's zero-padded gradient all-reduce, :395-413, and no full-size optimizer pass);
         otherwise the gradient is all-gathered / all-reduced (:425) and every rank steps the full embedding."""
+        if type(self)._compute_gradients is AffinityMatcher._compute_gradients:
+            return self._autograd_training_step()
         grad, rows_only = self._compute_gradients()
         world = getattr(self, "world_size", 1)
         if world > 1 and rows_only and self._fused_sgd:
@@ -240,6 +262,51 @@ class AffinityMatcher(DRModule):
 
     def _compute_gradients(self):
         raise NotImplementedError("[TorchDR] ERROR : _compute_gradients method must be implemented.")
+
+    # ---- autograd mode (reference :418-425) ---------------------------------------------------------------------------
+    def _autograd_training_step(self):
+        """A subclass that defines a LOSS instead of closed-form gradients (``_compute_loss``, or for neighbour
+        embeddings ``_compute_attractive_loss`` / ``_compute_repulsive_loss``) is differentiated by PyTorch autograd on
+        the device tensors, exactly as the reference does; the optimizer step then runs as for the kernel-produced
+        gradients.  The estimators shipped here never take this path (they all carry closed forms)."""
+        emb = self.embedding_
+        if not emb.requires_grad:
+            emb.requires_grad_(True)
+        emb.grad = None
+        loss = self._compute_loss()
+        loss.backward()
+        grad = emb.grad.detach()
+        if getattr(self, "world_size", 1) > 1:
+            from torchdr_amd.parallel import allreduce_
+
+            allreduce_(grad)  # :425
+        self._last_grad, self._last_grad_is_chunk = grad, False
+        if self._fused_sgd:
+            emb.requires_grad_(False)
+            self._sgd_kernel(emb, grad.contiguous())
+        else:
+            lr = self._current_lr()
+            for g in self.optimizer_.param_groups:
+                g["lr"] = lr
+            self.optimizer_.step()
+            self.optimizer_.zero_grad(set_to_none=True)
+        self._lr_pos += 1
+        return loss
+
+    def _compute_loss(self):
+        """Reference :433-459: ``loss_fn(affinity_in_, affinity_out(embedding_))``; ``affinity_out`` has to be
+        differentiable (an Affinity written with torch ops -- the HIP affinities of this package have no autograd)."""
+        if self.affinity_out is None:
+            raise ValueError("[TorchDR] ERROR : affinity_out is not set. Set it or implement _compute_loss method.")
+        from torchdr_amd.affinity import LogAffinity
+
+        kwargs_affinity_out = dict(self.kwargs_affinity_out or {})
+        kwargs_loss = dict(self.kwargs_loss or {})
+        if self.loss_fn == "cross_entropy_loss" and isinstance(self.affinity_out, LogAffinity):
+            kwargs_affinity_out.setdefault("log", True)
+            kwargs_loss.setdefault("log", True)
+        Q = self.affinity_out(self.embedding_, **kwargs_affinity_out)
+        return LOSS_DICT[self.loss_fn](self.affinity_in_, Q, **kwargs_loss)
 
     def _current_lr(self) -> float:
         return self._lr_table[min(self._lr_pos, len(self._lr_table) - 1)]

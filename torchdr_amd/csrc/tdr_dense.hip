@@ -64,6 +64,28 @@ struct SeaStats {
     }
 };
 
+// Symmetric Sinkhorn on a Gaussian base kernel (entropic.py:728-734): row log-sum-exp of log K_ij + f_j with
+// log K = -C / eps (student base: -log(1 + C) / eps); out0[i] = LSE_j(...).  side = (f).
+struct SinkLse {
+    static constexpr int SIDE = 1;
+    float m, s;
+    __device__ __forceinline__ void init(const float*) { m = -__builtin_inff(); s = 0.f; }
+    __device__ __forceinline__ void add(float c, const float* sj, const PairScanParams& P) {
+        const float base = P.c1 != 0.f ? __logf(1.0f + c) : c;   // c1 != 0: student base kernel
+        const float lp = sj[0] - base * P.c0;                     // c0 = 1 / eps
+        if (lp > m) { s *= __expf(m - lp); m = lp; }
+        s += __expf(lp - m);
+    }
+    __device__ __forceinline__ void merge(const SinkLse& o) {
+        const float mm = fmaxf(m, o.m);
+        const float a = (m == -__builtin_inff()) ? 0.f : __expf(m - mm);
+        const float b = (o.m == -__builtin_inff()) ? 0.f : __expf(o.m - mm);
+        s = s * a + o.s * b; m = mm;
+    }
+    __device__ __forceinline__ void shfl_from(const SinkLse& x, int src) { m = __shfl(x.m, src, 64); s = __shfl(x.s, src, 64); }
+    __device__ __forceinline__ void store(int64_t row, const PairScanParams& P) const { P.out0[row] = m + logf(s); }
+};
+
 // TSNEkhorn force: g_i = 4 * sum_j (P_ij - Q_ij) w_ij (z_i - z_j), w = 1/(1+|z_i-z_j|^2),
 //   P_ij = exp((mu_i+mu_j-2C_ij)/(e_i+e_j) - log N),  Q_ij = E_i E_j w_ij / N  with E = exp(dual)
 //   (the diagonal term vanishes with z_i - z_i).  side = (mu, e, z0, z1, E); out0 = grad (n, 2).
@@ -387,6 +409,19 @@ int tdr_sea_rowstats_f32(const float* packed, int64_t n, int d, const float* sid
     P.side = side; P.qside = side; P.c0 = 0.f; P.c1 = 0.f; P.diag_add = diag_add; P.exclude_diag = exclude_diag;
     P.out0 = psum; P.out1 = ent;
     return launch_pair_scan<SeaStats>(P, d, (hipStream_t)stream);
+}
+
+/* One reduction of the symmetric Sinkhorn fixed point on the INPUT points (entropic.py:728-734, matrix-free):
+ *   lse[i] = LSE_j(log K_ij + f_j),  log K = -C / eps (student != 0: -log(1 + C) / eps), C = squared distances of the packed
+ *   points with diag_add on the diagonal when exclude_diag.  The caller forms f <- 0.5 (f - lse). */
+int tdr_sinkhorn_lse_f32(const float* packed, int64_t n, int d, const float* f, float inv_eps, int student, int exclude_diag,
+                         float diag_add, float* lse, void* stream) {
+    if (!packed || !f || !lse || n <= 0 || !(inv_eps > 0.f)) return TDR_ERR_BAD_ARG;
+    PairScanParams P;
+    P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
+    P.side = f; P.qside = f; P.c0 = inv_eps; P.c1 = student ? 1.0f : 0.f; P.diag_add = diag_add; P.exclude_diag = exclude_diag;
+    P.out0 = lse; P.out1 = nullptr;
+    return launch_pair_scan<SinkLse>(P, d, (hipStream_t)stream);
 }
 
 /* TSNEkhorn embedding gradient (n, 2): 4 sum_j (P_ij - Q_ij)/(1+d_ij) (z_i - z_j).

@@ -74,6 +74,18 @@ class NeighborEmbedding(AffinityMatcher):
         self.early_exaggeration_coeff_ = self.early_exaggeration_coeff
         return super()._fit_transform(X, y)
 
+    # --- loss hooks of the autograd mode (reference :207-231); the estimators of this package override
+    #     _compute_gradients with closed forms and never evaluate these -------------------------------
+    def _compute_attractive_loss(self):
+        raise NotImplementedError("[TorchDR] ERROR : _compute_attractive_loss method must be implemented.")
+
+    def _compute_repulsive_loss(self):
+        raise NotImplementedError("[TorchDR] ERROR : _compute_repulsive_loss method must be implemented.")
+
+    def _compute_loss(self):
+        return (self.early_exaggeration_coeff_ * self._compute_attractive_loss()
+                + self.repulsion_strength * self._compute_repulsive_loss())
+
     # --- early exaggeration (reference :282-295) ------------------------------------------------
     def on_training_step_end(self):
         if self.early_exaggeration_coeff_ > 1 and int(self.n_iter_) == self.early_exaggeration_iter:
