@@ -183,6 +183,23 @@ int tdr_ctx_allgather_rows(void* ctx, float* Z, int nc, void* stream);
 int tdr_ctx_allreduce_f32(void* ctx, float* buf, int64_t count, void* stream);
 int tdr_ctx_destroy(void* ctx);
 
+/* ---- float64 twins of the affinity side (csrc/tdr_f64.hip): the reference computes in its input's dtype ---------------
+ * K1 on the fp64 matrix pipe (v_mfma_f64_16x16x4_f64), K2 / K3 root searches, the gathered distances and the values of the
+ * symmetrised graph on the pattern built by the float32 pipeline.  metric: 0 sqeuclidean, 1 euclidean, 2 angular.
+ * tdr_knn_f64: k > 0 -> (nq, k) smallest distances ascending by (distance, index) + indices; k == 0 -> dense (nq, n_db)
+ * matrix into out_d (row stride ldo).  ws: (nq + n_db) doubles.  tdr_knn_f64_lds_bytes == 0: shape unsupported. */
+int64_t tdr_knn_f64_lds_bytes(int d, int k);
+int tdr_knn_f64(const double* Xq, int64_t nq, int64_t ldq, int64_t q_global0, const double* Y, int64_t n_db, int64_t ldy, int d, int k,
+                int metric, int exclude_self, double diag_add, double* out_d, int32_t* out_i, int64_t ldo, double* ws, void* stream);
+int tdr_umap_search_f64(const double* C, int64_t n, int k, double target, int max_iter, double tol, double* rho, double* eps,
+                        double* P, void* stream);
+int tdr_entropic_search_f64(const double* C, int64_t n, int k, double target, double log_n, int max_iter, double tol, int use_bounds,
+                            double tN, double perplexity, double p1, double* eps, double* lognorm, double* logP, void* stream);
+int tdr_indexed_sqdist_f64(const double* X, int64_t nx, int d, const double* Y, int64_t ny, const int64_t* q, int64_t nq, int nk, int mode,
+                           const int64_t* keys, double* out, void* stream);
+int tdr_sym_values_f64(const int64_t* rowptr, const int32_t* cols, int64_t n, const int32_t* nn, const double* P, int k,
+                       int64_t row_offset, int mode, double* vals, void* stream);
+
 /* ---- K0: the steps either side of the path inside fit_transform (csrc/tdr_prep.hip) ---------------------------- */
 /* utils/validation.py:308 (torch.isfinite(X).all()): *count (device uint64, caller-zeroed) += number of inf / nan entries */
 int tdr_nonfinite_count_f32(const float* X, int64_t n, int d, int64_t ldx, void* count, void* stream);

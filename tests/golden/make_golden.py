@@ -485,6 +485,31 @@ def cosne_fixture():
     save("cosne", **out)
 
 
+def affinity64_fixture():
+    """float64 inputs (the reference computes in the input's dtype, tests/test_affinity.py:54-60): kNN, both root-search
+    affinities, the symmetrised UMAP graph and gathered distances, all in float64."""
+    X = gmm(600, 16, 2.0, seed=64).double()
+    out = {"X": X}
+    C, I = pairwise_distances(X, metric="sqeuclidean", backend=None, exclude_diag=True, k=15, return_indices=True)
+    out["knn_C"], out["knn_I"] = C, I
+    Ce = pairwise_distances(X[:50], X[100:300], metric="euclidean", backend=None)
+    out["cross_euclid"] = Ce
+    ea = EntropicAffinity(perplexity=5, backend=None)
+    lp, idx = ea(X, log=True, return_indices=True)
+    out["ent_logP"], out["ent_idx"], out["ent_eps"] = lp, idx, ea.eps_
+    ua = UMAPAffinity(n_neighbors=10, backend=None)
+    P, J = ua(X, return_indices=True)
+    out["umap_P"], out["umap_J"], out["umap_rho"], out["umap_eps"] = P, J, ua.rho_, ua.eps_
+    q = torch.arange(0, 600, 7)
+    keys = torch.randint(0, 600, (q.numel(), 5), generator=torch.Generator().manual_seed(1))
+    keys[3, 2] = -1
+    out["idx_q"], out["idx_keys"] = q, keys
+    out["idx_D"] = pairwise_distances_indexed(X, query_indices=q, key_indices=keys)
+    for v in (C, lp, P, out["idx_D"], Ce):
+        assert v.dtype == torch.float64
+    save("affinity64", **out)
+
+
 def sinkhorn_fixture():
     """SinkhornAffinity on INPUT points (entropic.py:693-755): Gaussian base kernel (the class default) and the student
     base kernel on an 8-d input, cold and warm started: duals, iteration counts, a few rows of log P."""
@@ -542,7 +567,7 @@ if __name__ == "__main__":
                umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne2_step=ne2_step_fixture,
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
-               cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture)
+               cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

@@ -43,7 +43,11 @@ class Affinity(nn.Module):
     def _prepare(self, X):
         if not self._pre_processed:
             X = to_torch(X)
-        return as_float32(X).to(compute_device(X, self.device))  # float64 inputs are processed in float32
+        # float64 inputs keep their dtype where the float64 kernels cover the affinity (kNN-sparse entropic / UMAP
+        # affinities, csrc/tdr_f64.hip), as the reference computes in its input's dtype; everything else runs in float32
+        if X.dtype == torch.float64 and getattr(self, "_float64_kernels", False) and not getattr(self, "is_multi_gpu", False):
+            return X.to(compute_device(X, self.device))
+        return as_float32(X).to(compute_device(X, self.device))
 
     def _compute_affinity(self, X: torch.Tensor):
         raise NotImplementedError("[TorchDR] ERROR : `_compute_affinity` method is not implemented.")

@@ -69,6 +69,8 @@ def entropic_search(C: torch.Tensor, perplexity: int, n_total: int, max_iter: in
     """eps_i with H(softmax(-C_i/eps_i)) = log(perp) + 1; returns (eps, log_norm, log_P) with
     log_P = -C/eps - LSE - log(n_total)  (entropic.py:272-310, K2 ``tdr_entropic_search_f32``)."""
     _lib.require_gpu(C, "C")
+    if C.dtype == torch.float64:
+        return _entropic_search_f64(C.contiguous(), perplexity, n_total, max_iter, use_bounds)
     C = C.contiguous().float()
     n, k = C.shape
     eps = torch.empty(n, dtype=torch.float32, device=C.device)
@@ -89,10 +91,57 @@ def entropic_search(C: torch.Tensor, perplexity: int, n_total: int, max_iter: in
     return eps, log_norm, log_P
 
 
+def _entropic_search_f64(C, perplexity, n_total, max_iter, use_bounds):
+    """float64 twin of :func:`entropic_search` (``tdr_entropic_search_f64``); the scalar p1 root of the bounds is found in
+    float64 on the host (entropic.py:51-115)."""
+    import math
+
+    n, k = C.shape
+    tN, perp = float(n), float(perplexity)
+    p1 = 0.5
+    if use_bounds:
+        max_val = min(math.sqrt(2.0 * tN), perp)
+        f = lambda x: math.log(max_val) - 2.0 * (1.0 - x) * math.log(tN / (2.0 * (1.0 - x)))  # noqa: E731
+        b, e = 0.75, 1.0 - 1e-6
+        # scalar form of root_search.py:17-77 (bounds given, no bracketing needed beyond the reference's two loops)
+        for _ in range(1000):
+            if not f(b) > 0:
+                break
+            e, b = min(e, b), b * 0.5
+        for _ in range(1000):
+            if not f(e) < 0:
+                break
+            b, e = max(b, e), e * 2.0
+        fb, m = f(b), (b + e) * 0.5
+        fm = f(m)
+        for _ in range(1000):
+            if not abs(fm) >= 1e-6:
+                break
+            if fm * fb > 0:
+                b, fb = m, fm
+            else:
+                e = m
+            m = (b + e) * 0.5
+            fm = f(m)
+        p1 = m
+    eps = torch.empty(n, dtype=torch.float64, device=C.device)
+    log_norm = torch.empty(n, dtype=torch.float64, device=C.device)
+    log_P = torch.empty_like(C)
+    _lib.check(
+        _lib.lib().tdr_entropic_search_f64(_lib.ptr(C), n, k, math.log(perp) + 1.0, math.log(float(n_total)), int(max_iter), _TOL,
+                                           1 if use_bounds else 0, tN, perp, p1, _lib.ptr(eps), _lib.ptr(log_norm), _lib.ptr(log_P),
+                                           _lib.stream_ptr()),
+        "tdr_entropic_search_f64",
+    )
+    return eps, log_norm, log_P
+
+
 class EntropicAffinity(SparseLogAffinity):
     r"""Entropic affinity of SNE / t-SNE: per-row bandwidth :math:`\varepsilon_i` such that the row
     entropy equals :math:`\log(\mathrm{perplexity}) + 1`; rows sum to :math:`1/n`.
     Constructor arguments as in the reference (``entropic.py:196-228``)."""
+
+    _float64_kernels = True   # float64 inputs are computed in float64 (csrc/tdr_f64.hip)
 
     def __init__(self, perplexity: float = 30, max_iter: int = 1000, sparsity: bool = True,
                  metric: str = "sqeuclidean", zero_diag: bool = True, device: str = "auto",

@@ -17,6 +17,14 @@ def umap_sigma_search(C: torch.Tensor, n_neighbors, max_iter: int):
     """rho_i = min_j C_ij; eps_i with sum_j exp(-(C_ij - rho_i)/eps_i) = log2(n_neighbors); P = exp(.).
     (knn_normalized.py:445-465, K3 ``tdr_umap_search_f32``.)"""
     _lib.require_gpu(C, "C")
+    if C.dtype == torch.float64:
+        C = C.contiguous()
+        n, k = C.shape
+        rho, eps, P = torch.empty(n, dtype=torch.float64, device=C.device), torch.empty(n, dtype=torch.float64, device=C.device), torch.empty_like(C)
+        target = float(torch.log2(torch.tensor(n_neighbors, dtype=torch.float64)))
+        _lib.check(_lib.lib().tdr_umap_search_f64(_lib.ptr(C), n, k, target, int(max_iter), _TOL, _lib.ptr(rho), _lib.ptr(eps),
+                                                  _lib.ptr(P), _lib.stream_ptr()), "tdr_umap_search_f64")
+        return rho, eps, P
     C = C.contiguous().float()
     n, k = C.shape
     rho = torch.empty(n, dtype=torch.float32, device=C.device)
@@ -36,6 +44,8 @@ class UMAPAffinity(SparseAffinity):
     :math:`\sum_j P_{ij} = \log_2(\mathrm{n\_neighbors})`, symmetrised as
     :math:`P + P^\top - P \circ P^\top`.  Constructor arguments as in the reference
     (``knn_normalized.py:385-415``)."""
+
+    _float64_kernels = True   # float64 inputs are computed in float64 (csrc/tdr_f64.hip)
 
     def __init__(self, n_neighbors: float = 30, max_iter: int = 1000, sparsity: bool = True,
                  metric: str = "sqeuclidean", zero_diag: bool = True, device: str = "auto",

@@ -483,6 +483,50 @@ def knn_packed(
     return out_d, out_i
 
 
+_F64_METRIC = {"sqeuclidean": 0, "euclidean": 1, "angular": 2}
+
+
+def _pairwise_f64(X, Y, metric, exclude_diag, k, return_indices, device, distributed_ctx):
+    """float64 inputs on the float64 kernels (``tdr_knn_f64``: fp64 matrix pipe + in-kernel top-k, or the dense matrix),
+    as the reference computes in the dtype of its input.  Returns NotImplemented when no float64 kernel covers the call."""
+    if metric not in _F64_METRIC or X.shape[1] > 256 or (distributed_ctx is not None and distributed_ctx.is_initialized):
+        return NotImplemented
+    L = _lib.lib()
+    X = _to_device(X, device)
+    _lib.require_gpu(X, "X")
+    self_search = Y is None
+    Yd = X if self_search else _to_device(Y, device).to(torch.float64)
+    if X.shape[1] != Yd.shape[1]:
+        raise ValueError("[TorchDR] ERROR : X and Y must have the same number of features.")
+    Xc = X if X.stride(1) == 1 else X.contiguous()
+    Yc = Xc if self_search else (Yd if Yd.stride(1) == 1 else Yd.contiguous())
+    nq, d = Xc.shape
+    n_db = Yc.shape[0]
+    do_exclude = bool(exclude_diag) and self_search
+    kk = int(k) if (k is not None and k < n_db) else 0
+    if kk and do_exclude and kk > n_db - 1:
+        raise ValueError("[TorchDR] ERROR : k must be smaller than the number of samples.")
+    if L.tdr_knn_f64_lds_bytes(d, kk) == 0:
+        return NotImplemented
+    ws = torch.empty(nq + n_db, dtype=torch.float64, device=Xc.device)
+    if kk:
+        out_d = torch.empty((nq, kk), dtype=torch.float64, device=Xc.device)
+        out_i = torch.empty((nq, kk), dtype=torch.int32, device=Xc.device)
+        ldo = kk
+    else:
+        out_d = torch.empty((nq, n_db), dtype=torch.float64, device=Xc.device)
+        out_i, ldo = None, n_db
+    _lib.check(
+        L.tdr_knn_f64(_lib.ptr(Xc), nq, Xc.stride(0), 0, _lib.ptr(Yc), n_db, Yc.stride(0), d, kk, _F64_METRIC[metric],
+                      1 if do_exclude else 0, _DIAG_ADD, _lib.ptr(out_d), _lib.ptr(out_i), ldo, _lib.ptr(ws), _lib.stream_ptr()),
+        "tdr_knn_f64",
+    )
+    LAST_KNN["path"], LAST_KNN["flagged"] = "f64", 0
+    if return_indices:
+        return out_d, out_i
+    return out_d
+
+
 def dense_packed(Q: PackedPoints, Y: PackedPoints, metric: str, exclude_self: bool, q_offset: int = 0):
     L = _lib.lib()
     out = torch.empty((Q.n, Y.n), dtype=torch.float32, device=Y.device)
@@ -712,7 +756,11 @@ def pairwise_distances(
         raise TypeError("[torchdr_amd] pairwise_distances expects a torch.Tensor or a DataLoader.")
 
     self_search = Y is None or Y is X
-    if X.dtype == torch.float64:  # float64 in -> float32 kernels -> float64 out
+    if X.dtype == torch.float64:
+        res = _pairwise_f64(X, None if self_search else Y, metric, exclude_diag, k, return_indices, device, distributed_ctx)
+        if res is not NotImplemented:
+            return res
+        # shapes / metrics without a float64 kernel (d > 256, manhattan, sqhyperbolic, row-sharded): float32 arithmetic
         out = pairwise_distances(as_float32(X), None if self_search else as_float32(Y), metric=metric, backend=backend,
                                  exclude_diag=exclude_diag, k=k, return_indices=return_indices, device=device,
                                  distributed_ctx=distributed_ctx)
@@ -837,8 +885,9 @@ def pairwise_distances_indexed(
             return _dense_general(Xq, Yk, metric, False)
         return dense_packed(PackedPoints(Xq), PackedPoints(Yk), metric, False)
     L = _lib.lib()
-    Xc = X.contiguous().float()
-    Yc = Y.contiguous().float()
+    f64 = X.dtype == torch.float64 and metric != "sqhyperbolic"
+    Xc = X.contiguous() if f64 else X.contiguous().float()
+    Yc = Y.contiguous().to(torch.float64) if f64 else Y.contiguous().float()
     keys = key_indices.to(device=X.device, dtype=torch.int64).contiguous()
     nq = keys.shape[0]
     if query_indices is None:
@@ -848,6 +897,12 @@ def pairwise_distances_indexed(
         assert keys.shape[0] == len(q), (
             f"key_indices first dim {keys.shape[0]} must match number of queries {len(q)}"
         )
+    if f64:   # float64 inputs: float64 arithmetic, as the reference's gather-and-subtract does (distance/base.py:384-391)
+        out = torch.empty(keys.shape, dtype=torch.float64, device=X.device)
+        _lib.check(L.tdr_indexed_sqdist_f64(_lib.ptr(Xc), Xc.shape[0], Xc.shape[1], _lib.ptr(Yc), Yc.shape[0], _lib.ptr(q), nq,
+                                            keys.shape[1], {"sqeuclidean": 0, "euclidean": 1, "manhattan": 2, "angular": 3}[metric],
+                                            _lib.ptr(keys), _lib.ptr(out), _lib.stream_ptr()), "tdr_indexed_sqdist_f64")
+        return out
     out = torch.empty(keys.shape, dtype=torch.float32, device=X.device)
     _lib.check(
         L.tdr_indexed_sqdist_f32(

@@ -29,6 +29,14 @@ class CSRAffinity:
         """(values (n, max_deg), indices int64 (n, max_deg)) padded with (0, -1): the layout the
         reference returns (``pack_to_rowwise``, sparse.py:89-135)."""
         width = self.max_degree()
+        if self.vals.dtype == torch.float64:   # float64 graph (float64 input): indices by the kernel, values placed by torch
+            _, pi = CSRAffinity(self.rowptr, self.cols, self.vals.float(), self.row_offset, self.n_total).to_padded()
+            pv = torch.zeros((self.n, width), dtype=torch.float64, device=self.vals.device)
+            deg = self.rowptr[1:] - self.rowptr[:-1]
+            rows = torch.repeat_interleave(torch.arange(self.n, device=self.vals.device), deg)
+            slot = torch.arange(self.nnz, device=self.vals.device) - self.rowptr[:-1][rows]
+            pv[rows, slot] = self.vals
+            return pv, pi
         pv = torch.empty((self.n, width), dtype=torch.float32, device=self.vals.device)
         pi = torch.empty((self.n, width), dtype=torch.int64, device=self.vals.device)
         _lib.check(
@@ -84,6 +92,15 @@ def symmetrize_to_csr(values, indices, mode="sum_minus_prod", row_offset=0, n_to
                            _lib.ptr(ovals), st),
         "tdr_sym_fill_f32",
     )
+    if values.dtype == torch.float64:
+        # float64 input: the pattern above came from float(values); the float64 values P + P^T - P o P^T are evaluated on
+        # it from the float64 block (tdr_sym_values_f64).  Row-sharded runs carry float32 transposed edges: float32 only.
+        if n_ext:
+            raise NotImplementedError("[torchdr_amd] float64 symmetrisation is single-process.")
+        v64 = torch.empty(nnz, dtype=torch.float64, device=dev)
+        _lib.check(L.tdr_sym_values_f64(_lib.ptr(rowptr), _lib.ptr(ocols), n, _lib.ptr(cols), _lib.ptr(values.contiguous()), k, row_offset,
+                                        _MODE[mode], _lib.ptr(v64), st), "tdr_sym_values_f64")
+        ovals = v64
     return CSRAffinity(rowptr, ocols, ovals, row_offset=row_offset, n_total=n_total if n_total else n)
 
 
