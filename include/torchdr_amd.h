@@ -50,6 +50,16 @@ int tdr_knn_max_k(int d);
 int tdr_knn_packed_f32(const float* qp, int64_t nq, int64_t q_offset, const float* yp, int64_t n_db, int d, int k,
                        int metric, int exclude_self, float* out_d, int32_t* out_i, void* ws, int64_t ws_bytes,
                        void* stream);
+/* D > 256 (distance/torch.py:82-120 at e.g. 784 features): the same tile images with the feature dimension padded to a
+ * multiple of 32, and a K-chunked scan (a wavefront accumulates 4 database tiles per pass over its queries' features)
+ * with the running top-k fused; same contract as tdr_knn_packed_f32, workspace from tdr_knn_workspace_bytes.  Every
+ * distance is one k-ordered fp32 fma chain over the row (MKL splits contractions beyond K ~ 380, so parity with the CPU
+ * reference is to fp32 rounding there). */
+int64_t tdr_packed_floats_wide(int64_t n, int d);
+int tdr_pack_rows_wide_f32(const float* X, int64_t n, int d, int64_t ldx, float* packed, float* norms_out, void* stream);
+int tdr_knn_wide_max_k(void);
+int tdr_knn_wide_f32(const float* qp, int64_t nq, int64_t q_offset, const float* yp, int64_t n_db, int d, int k, int metric,
+                     int exclude_self, float* out_d, int32_t* out_i, void* ws, int64_t ws_bytes, void* stream);
 
 /* dense nq x n_db matrix (k=None path, distance/torch.py:91-116); diag_add (1e12) on C[i][q_offset+i]. */
 int tdr_dense_dist_packed_f32(const float* qp, int64_t nq, int64_t q_offset, const float* yp, int64_t n_db, int d,

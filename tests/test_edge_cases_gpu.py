@@ -144,15 +144,18 @@ def test_float64_inputs_are_accepted_and_returned_as_float64():
     assert torch.allclose(C.cpu(), ref, rtol=1e-10, atol=1e-10)
 
 
-@pytest.mark.parametrize("d,k,metric", [(300, 10, "sqeuclidean"), (784, 30, "euclidean"), (513, 15, "angular")])
+@pytest.mark.parametrize("d,k,metric", [(300, 10, "sqeuclidean"), (784, 30, "euclidean"), (513, 15, "angular"), (2048, 100, "sqeuclidean")])
 def test_knn_general_feature_dimension(d, k, metric):
-    """D > 256 (e.g. 784-d images): library GEMM per block + HIP top-k merge.  Same neighbours as the CPU oracle up to
-    fp32 rounding of the contraction (the library's summation order is not MKL's)."""
+    """D > 256 (e.g. 784-d images): K-chunked MFMA scan with the running top-k fused (tdr_knn_wide_f32).  Same
+    neighbours as the CPU oracle up to fp32 rounding of the contraction: the kernel's k-ordered fma chain is MKL's
+    order only for K <= ~380 (MKL splits longer contractions), so this path is tolerance-parity by construction."""
     import oracle
+    from torchdr_amd.distance import base as dbase
     from torchdr_amd.distance import pairwise_distances
 
     X = gmm(3000, d, 2.0, seed=d)
     C, I = pairwise_distances(X.cuda(), metric=metric, k=k, exclude_diag=True, return_indices=True)
+    assert dbase.LAST_KNN["path"].startswith("wide")
     Co, Io = oracle.knn(X, k, metric, True)
     assert I.dtype == torch.int32 and C.shape == (3000, k)
     assert float((I.cpu() != Io).any(1).float().mean()) < 0.02          # rows touched by a near-tie swap
@@ -164,6 +167,32 @@ def test_knn_general_feature_dimension(d, k, metric):
     assert float((I2.cpu() != Io2).any(1).float().mean()) < 0.02
     D = pairwise_distances(X[:200].cuda(), metric=metric, exclude_diag=True)
     assert D.shape == (200, 200) and float(D.diagonal().min()) > 1e11
+    # the library-GEMM form of the same search (kept for comparison) agrees with the scan
+    dbase.WIDE_SCAN = False
+    try:
+        Cg, Ig = pairwise_distances(X.cuda(), metric=metric, k=k, exclude_diag=True, return_indices=True)
+    finally:
+        dbase.WIDE_SCAN = True
+    assert float((I != Ig).float().mean()) < 0.005 and torch.allclose(C, Cg, rtol=1e-4, atol=1e-3 * float(Co.abs().mean()))   # near-tie swaps only
+
+
+def test_knn_wide_ragged_shapes_and_database_slices():
+    """Wide scan on shapes that exercise the short last tile group, a query count that is not a multiple of 32, the
+    sliced-database launch of small query sets and a row-chunked (distributed-style) query offset."""
+    import oracle
+    from torchdr_amd.distance import base as dbase
+
+    X = gmm(4133, 300, 2.0, seed=77)
+    Xc = X.cuda()
+    Co, Io = oracle.knn(X, 12, "sqeuclidean", True)
+    C, I = dbase._knn_wide(Xc, Xc, 12, "sqeuclidean", True)
+    assert float((I.cpu() != Io).any(1).float().mean()) < 0.02
+    assert torch.allclose(C.cpu(), Co, rtol=1e-4, atol=1e-3 * float(Co.abs().mean()))
+    # a chunk of 77 queries starting at row 1000 (self exclusion by global index), database sliced over the grid
+    Cq, Iq = dbase._knn_wide(Xc[1000:1077].contiguous(), Xc, 12, "sqeuclidean", True, q_global0=1000)
+    assert float((Iq.cpu() != Io[1000:1077]).any(1).float().mean()) < 0.05
+    assert torch.allclose(Cq.cpu(), Co[1000:1077], rtol=1e-4, atol=1e-3 * float(Co.abs().mean()))
+    assert not bool((Iq.cpu() == torch.arange(1000, 1077)[:, None]).any())
 
 
 def test_umap_on_784_dimensional_input():

@@ -178,6 +178,7 @@ struct KnnParams {
     float* out_d;         // (nq, k)      when n_splits == 1
     int32_t* out_i;       // (nq, k)
     uint64_t* ws_keys;    // (n_splits, nq, k) partial keys when n_splits > 1
+    int kq;               // wide kernel only: 8-dim blocks per tile image (run-time)
 };
 
 // HBM -> LDS staging of one tile image by LDS-DMA (global_load_lds: no VGPR round trip, no ds_write pass).
@@ -760,6 +761,191 @@ __global__ __launch_bounds__(256) void fill_keys_kernel(uint64_t* __restrict__ k
     if (i < total) keys[i] = KEY_SENTINEL;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Wide rows (D > 256): the query block no longer fits the register file, so the contraction is
+// K-chunked.  A wavefront still owns 32 queries and a lane ONE query (same filter / k-list
+// machinery as knn_scan_kernel), but it accumulates a GROUP of WIDE_TG database tiles at once:
+// per K step of WIDE_KC blocks (32 dims) it reads its query fragment once (4 x 16 B per lane,
+// from L2 / the infinity cache) and multiplies it into the WIDE_TG accumulators with A fragments
+// taken from a double-buffered LDS ring the four wavefronts stage together by LDS-DMA.  After the
+// last K step the group's 4 x 32 x 32 candidate values are formed, filtered against the lane's
+// k-th best and merged -- the N x N block never exists in memory (the library-GEMM form of
+// distance/torch.py:91 wrote 1 GiB blocks of X Y^T that a second kernel re-read).
+// Each output element is one k-ordered fma chain over the whole row, as in the D <= 256 kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr int WIDE_TG = 4;  // database tiles accumulated together (= wavefronts: wave w stages tile w of the group)
+constexpr int WIDE_KC = 4;  // 8-dim blocks per K step
+
+__global__ __launch_bounds__(256) void pack_wide_kernel(const float* __restrict__ X, int64_t n, int d, int64_t ldx, int kq,
+                                                        float* __restrict__ out, float* __restrict__ norms_out) {
+    __shared__ float xs[TILE_ROWS][264];
+    const int64_t row0 = (int64_t)blockIdx.x * TILE_ROWS;
+    const int tid = threadIdx.x;
+    float* img = out + (size_t)blockIdx.x * tile_stride_floats(kq);
+    for (int c0 = 0; c0 < kq * 8; c0 += 256) {
+        for (int idx = tid; idx < TILE_ROWS * 256; idx += 256) {
+            const int r = idx >> 8, c = idx & 255;
+            float v = 0.f;
+            if (row0 + r < n && c0 + c < d) v = X[(size_t)(row0 + r) * ldx + c0 + c];
+            xs[r][c] = v;
+        }
+        __syncthreads();
+        const int t0 = c0 / 8;
+        const int nblk = (kq - t0 < 32) ? kq - t0 : 32;
+        for (int idx = tid; idx < nblk * 64; idx += 256) {
+            const int t = idx >> 6, l = idx & 63, h = l >> 5, i = l & 31;
+            const float* xr = &xs[i][8 * t + h];
+            f32x4 v = {xr[0], xr[2], xr[4], xr[6]};
+            *reinterpret_cast<f32x4*>(img + (size_t)(t0 + t) * 256 + l * 4) = v;
+        }
+        __syncthreads();
+    }
+    // norms: 8 lanes per row in ATen's AVX2 order (as pack_rows_kernel), read from the source rows
+    {
+        const int i = tid >> 3, l = tid & 7;
+        const bool valid = (row0 + i) < n;
+        const float* xr = X + (size_t)(valid ? row0 + i : 0) * ldx;
+        const int vec = d / 8;
+        const float p = aten_row_sum_sq(xr + l, vec, 8);
+        float fin = 0.f;
+        if (l == 0)
+            for (int k = vec * 8; k < d; ++k) fin = __fadd_rn(fin, __fmul_rn(xr[k], xr[k]));
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float ps = __shfl(p, (tid & 56) + s, 64);
+            fin = __fadd_rn(fin, ps);
+        }
+        if (l == 0) {
+            img[(size_t)kq * 256 + i] = valid ? fin : __builtin_inff();
+            img[(size_t)kq * 256 + 32 + i] = 0.f;
+            if (valid && norms_out) norms_out[row0 + i] = fin;
+        }
+    }
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(256, 2) void knn_wide_kernel(const KnnParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NW = 4, TG = WIDE_TG, KC = WIDE_KC;
+    constexpr int BUF_F = TG * KC * 256;
+    float* buf0 = reinterpret_cast<float*>(smem_raw);
+    float* buf1 = buf0 + BUF_F;
+    float* nring = buf1 + BUF_F;                                          // [2 groups][TG tiles][64 floats]
+    uint64_t* keys_all = reinterpret_cast<uint64_t*>(nring + 2 * TG * 64);  // [NW waves][32 queries][k] ascending
+    const int k = P.k, kq = P.kq;
+    const int64_t TILE_F = tile_stride_floats(kq);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane & 31, h = lane >> 5;
+    uint64_t* keys = keys_all + (size_t)wave * k * 32;
+    const int64_t n_qtiles = (P.nq + 31) / 32;
+    const int64_t qt0 = (int64_t)blockIdx.x * NW + wave;
+    const bool wave_active = qt0 < n_qtiles;
+    const float* qimg = P.qp + (size_t)(wave_active ? qt0 : 0) * TILE_F;
+
+    ScanCtx<1> C;
+    float tau_d[1];
+    C.xn[0] = wave_active ? qimg[(size_t)kq * 256 + q] : 0.f;
+    tau_d[0] = (wave_active && qt0 * 32 + q < P.nq) ? __builtin_inff() : -__builtin_inff();
+    for (int p = lane; p < k * 32; p += 64) keys[p] = KEY_SENTINEL;
+    C.P = &P; C.keys = keys; C.k = k; C.lane = lane; C.q = q; C.h = h; C.qt0 = qt0;
+    C.angular = (P.metric == 2);
+
+    const int split = blockIdx.y;
+    const int t_begin = split * P.tiles_per_split;
+    int t_end = t_begin + P.tiles_per_split;
+    if (t_end > P.n_db_tiles) t_end = P.n_db_tiles;
+    const int spg = kq / KC;  // K steps per group
+    const int n_groups = (t_end > t_begin) ? (t_end - t_begin + TG - 1) / TG : 0;
+    const int total = n_groups * spg;
+
+    auto stage = [&](int step) {
+        const int g = step / spg, c = step - g * spg;
+        int T = t_begin + g * TG + wave;
+        if (T >= t_end) T = t_end - 1;  // short last group: a copy of the last tile, never merged
+        const float* src = P.yp + (size_t)T * TILE_F;
+        float* dst = ((step & 1) ? buf1 : buf0) + wave * KC * 256;
+#pragma unroll
+        for (int u = 0; u < KC; ++u)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)(c * KC + u) * 256 + lane * 4), (lptr_t)(dst + u * 256), 16, 0, 0);
+        if (c == 0)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)kq * 256 + lane), (lptr_t)(nring + ((g & 1) * TG + wave) * 64), 4, 0, 0);
+    };
+    f32x4 bcur[KC], bnext[KC];
+    auto load_b = [&](int c, f32x4 (&b)[KC]) {
+#pragma unroll
+        for (int u = 0; u < KC; ++u) b[u] = *reinterpret_cast<const f32x4*>(qimg + (size_t)(c * KC + u) * 256 + lane * 4);
+    };
+    if (total > 0) { stage(0); load_b(0, bcur); }
+    __syncthreads();
+
+    f32x16 acc[TG];
+    int g = 0, c = 0;
+    for (int step = 0; step < total; ++step) {
+        if (step + 1 < total) {
+            stage(step + 1);
+            load_b((c + 1 == spg) ? 0 : c + 1, bnext);
+        }
+        if (c == 0) {
+#pragma unroll
+            for (int j = 0; j < TG; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        }
+        const float* ap = ((step & 1) ? buf1 : buf0) + lane * 4;
+#pragma unroll
+        for (int j = 0; j < TG; ++j) {
+            f32x4 a[KC];
+#pragma unroll
+            for (int u = 0; u < KC; ++u) a[u] = *reinterpret_cast<const f32x4*>(ap + (j * KC + u) * 256);
+#pragma unroll
+            for (int u = 0; u < KC; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], bcur[u][e], acc[j], 0, 0, 0);
+        }
+        if (c == spg - 1) {
+            if (wave_active) {
+#pragma unroll
+                for (int j = 0; j < TG; ++j) {
+                    const int T = t_begin + g * TG + j;
+                    if (T < t_end) {
+                        f32x16 one[1];
+                        one[0] = acc[j];
+                        float dv[1][16], pmin[1][4];
+                        const float* ynp = nring + ((g & 1) * TG + j) * 64 + 4 * h;
+#pragma unroll
+                        for (int part = 0; part < 4; ++part) form_part<1>(C, one, ynp, part, dv, pmin);
+                        if (any_survivor<1>(pmin, tau_d)) scan_insert<ITEMS, 1>(C, dv, pmin, T, tau_d);
+                    }
+                }
+            }
+            c = 0; ++g;
+        } else {
+            ++c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < KC; ++u) bcur[u] = bnext[u];
+    }
+
+    if (wave_active) {
+        for (int jq = 0; jq < 32; ++jq) {
+            const int64_t qi = qt0 * 32 + jq;
+            if (qi >= P.nq) break;
+            for (int p = lane; p < k; p += 64) {
+                const uint64_t mine = keys[(size_t)jq * k + p];
+                if (P.n_splits > 1) {
+                    P.ws_keys[((size_t)split * P.nq + qi) * k + p] = mine;
+                } else {
+                    float cc = u2f((uint32_t)(mine >> 32));
+                    if (P.metric == 1) cc = sqrt_rn(fmaxf(cc, 0.f));
+                    P.out_d[(size_t)qi * k + p] = cc;
+                    P.out_i[(size_t)qi * k + p] = (int32_t)(uint32_t)(mine & 0xffffffffu);
+                }
+            }
+        }
+    }
+}
+
 static inline int pick_kq(int d) {
     if (d <= 32) return 4;
     if (d <= 64) return 8;
@@ -973,6 +1159,92 @@ int tdr_knn_packed_f32(const float* qp, int64_t nq, int64_t q_offset, const floa
             if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((q_count + 3) / 4)), dim3(256), mlds, st,
                                (const uint64_t*)ws, q_count, k, P.n_splits, metric, P.out_d, P.out_i);
+            TDR_CHECK_LAUNCH();
+        }
+    }
+    return TDR_OK;
+}
+
+
+/* ---- wide rows (D > 256): K-chunked scan, csrc/tdr_knn.hip knn_wide_kernel ----------------------------------------- */
+static inline int wide_kq(int d) { return d > 256 ? ((d + 31) / 32) * 4 : 0; }
+static size_t knn_wide_lds_bytes(int k) {
+    return (size_t)2 * WIDE_TG * WIDE_KC * 256 * sizeof(float) + (size_t)2 * WIDE_TG * 64 * sizeof(float) +
+           (size_t)4 * k * 32 * sizeof(uint64_t);
+}
+
+/* floats of the packed image of n rows of dimension d > 256 (0 otherwise) */
+int64_t tdr_packed_floats_wide(int64_t n, int d) {
+    const int kq = wide_kq(d);
+    if (kq == 0 || n < 0) return 0;
+    return ((n + TILE_ROWS - 1) / TILE_ROWS) * tile_stride_floats(kq);
+}
+
+int tdr_pack_rows_wide_f32(const float* X, int64_t n, int d, int64_t ldx, float* packed, float* norms_out, void* stream) {
+    if (!X || !packed || n <= 0 || d <= 0 || ldx < d) return TDR_ERR_BAD_ARG;
+    const int kq = wide_kq(d);
+    if (kq == 0) return TDR_ERR_UNSUPPORTED;
+    const int64_t tiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+    hipLaunchKernelGGL(pack_wide_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, X, n, d, ldx, kq, packed, norms_out);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* largest k of tdr_knn_wide_f32 (LDS budget of a workgroup) */
+int tdr_knn_wide_max_k(void) {
+    int k = 0;
+    while (knn_wide_lds_bytes(k + 1) <= 160 * 1024) ++k;
+    return k < 128 ? k : 128;
+}
+
+/* kNN of wide packed queries against a wide packed database (tdr_pack_rows_wide_f32 images); same contract as
+ * tdr_knn_packed_f32 (workspace: tdr_knn_workspace_bytes). */
+int tdr_knn_wide_f32(const float* qp, int64_t nq, int64_t q_offset, const float* yp, int64_t n_db, int d, int k, int metric,
+                     int exclude_self, float* out_d, int32_t* out_i, void* ws, int64_t ws_bytes, void* stream) {
+    if (!qp || !yp || !out_d || !out_i || nq <= 0 || n_db <= 0 || d <= 0) return TDR_ERR_BAD_ARG;
+    if (metric < 0 || metric > 2) return TDR_ERR_BAD_ARG;
+    const int kq = wide_kq(d);
+    if (kq == 0) return TDR_ERR_UNSUPPORTED;
+    if (k < 1 || (int64_t)k > n_db - (exclude_self ? 1 : 0)) return TDR_ERR_BAD_ARG;
+    if (k > tdr_knn_wide_max_k() || n_db > 0x7fffffffLL) return TDR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
+    const KnnPlan pl = make_plan(nq, n_db_tiles, 1);
+    const size_t lds = knn_wide_lds_bytes(k);
+    const int64_t tile_f = tile_stride_floats(kq);
+    for (int part = 0; part < 2; ++part) {
+        const int64_t wgs = part == 0 ? pl.main_wgs : pl.tail_wgs;
+        if (wgs == 0) continue;
+        const int64_t q_begin = part == 0 ? 0 : pl.main_wgs * 128;
+        const int64_t q_count = part == 0 ? (pl.tail_wgs ? pl.main_wgs * 128 : nq) : nq - q_begin;
+        KnnParams P;
+        P.qp = qp + (q_begin / 32) * tile_f; P.yp = yp; P.nq = q_count; P.q_offset = q_offset + q_begin; P.n_db = n_db;
+        P.k = k; P.metric = metric; P.exclude_self = exclude_self; P.n_db_tiles = n_db_tiles; P.kq = kq;
+        P.n_splits = part == 0 ? 1 : pl.tail_splits;
+        P.tiles_per_split = (P.n_db_tiles + P.n_splits - 1) / P.n_splits;
+        P.tiles_per_split = ((P.tiles_per_split + WIDE_TG - 1) / WIDE_TG) * WIDE_TG;  // whole groups per slice
+        P.out_d = out_d + q_begin * k; P.out_i = out_i + q_begin * k; P.ws_keys = (uint64_t*)ws;
+        if (P.n_splits > 1) {
+            const int64_t need = (int64_t)P.n_splits * q_count * k * (int64_t)sizeof(uint64_t);
+            if (!ws || ws_bytes < need) return TDR_ERR_WORKSPACE;
+        }
+        hipError_t e;
+        if (k <= 64) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(knn_wide_kernel<1>, dim3((unsigned)wgs, (unsigned)P.n_splits), dim3(256), lds, st, P);
+        } else {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(knn_wide_kernel<2>, dim3((unsigned)wgs, (unsigned)P.n_splits), dim3(256), lds, st, P);
+        }
+        TDR_CHECK_LAUNCH();
+        if (P.n_splits > 1) {
+            const size_t mlds = (size_t)4 * P.n_splits * k * sizeof(uint64_t);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)((q_count + 3) / 4)), dim3(256), mlds, st, (const uint64_t*)ws, q_count, k,
+                               P.n_splits, metric, P.out_d, P.out_i);
             TDR_CHECK_LAUNCH();
         }
     }

@@ -20,6 +20,7 @@ from torchdr_amd.utils.misc import as_float32
 LIST_METRICS = ["euclidean", "sqeuclidean", "manhattan", "angular", "sqhyperbolic"]
 _METRIC_ID = {"sqeuclidean": 0, "euclidean": 1, "angular": 2, "manhattan": 3, "sqhyperbolic": 4}
 _GENERAL_ONLY = ("manhattan", "sqhyperbolic")     # metrics that never take the MFMA scan kernels
+WIDE_SCAN = True   # D > 256: K-chunked MFMA scan (False = library GEMM + top-k merge, kept for comparison)
 
 # Value the reference adds to the diagonal when exclude_diag=True (distance/torch.py:115).
 _DIAG_ADD = 1e12
@@ -546,18 +547,67 @@ def _to_device(X, device):
     return X
 
 
+class WidePackedPoints:
+    """Tile images of a point block with more than 256 features (``tdr_pack_rows_wide_f32``): same layout as
+    ``PackedPoints`` with the feature dimension padded to a multiple of 32."""
+
+    def __init__(self, X: torch.Tensor):
+        _lib.require_gpu(X, "X")
+        if X.dtype != torch.float32:
+            raise NotImplementedError(f"[torchdr_amd] only float32 inputs are supported by the HIP distance kernels (got {X.dtype}).")
+        if X.stride(1) != 1:
+            X = X.contiguous()
+        L = _lib.lib()
+        self.n, self.d = X.shape
+        self.data = torch.empty(L.tdr_packed_floats_wide(self.n, self.d), dtype=torch.float32, device=X.device)
+        self.norms = torch.empty(self.n, dtype=torch.float32, device=X.device)
+        _lib.check(L.tdr_pack_rows_wide_f32(_lib.ptr(X), self.n, self.d, X.stride(0), _lib.ptr(self.data), _lib.ptr(self.norms),
+                                            _lib.stream_ptr()), "tdr_pack_rows_wide_f32")
+        self.device, self.X = X.device, X
+
+
+def _knn_wide(Xq, Y, k, metric, exclude_self, q_global0=0):
+    """Exact kNN for D > 256 (sqeuclidean / euclidean / angular) on the K-chunked MFMA scan (``tdr_knn_wide_f32``):
+    the reference's op sequence (distance/torch.py:82-120 + utils/utils.py:215) with the running top-k fused -- no
+    block of X Y^T is ever written.  Every distance is one k-ordered fp32 fma chain over the row, which is what MKL
+    computes for K <= ~380; beyond that MKL splits the contraction, so parity with the CPU reference is to fp32
+    rounding, not bit for bit.  Returns None when k exceeds the kernel's LDS-resident lists."""
+    L = _lib.lib()
+    if k > min(int(L.tdr_knn_wide_max_k()), Y.shape[0]):
+        return None
+    Yp = WidePackedPoints(Y)
+    Qp = Yp if Xq is Y else WidePackedPoints(Xq)
+    nq, nd, d = Qp.n, Yp.n, Yp.d
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=Yp.device)
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=Yp.device)
+    ws_bytes = int(L.tdr_knn_workspace_bytes(nq, nd, k))
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=Yp.device)
+    _lib.check(
+        L.tdr_knn_wide_f32(_lib.ptr(Qp.data), nq, q_global0, _lib.ptr(Yp.data), nd, d, k, _METRIC_ID[metric],
+                           1 if exclude_self else 0, _lib.ptr(out_d), _lib.ptr(out_i), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
+        "tdr_knn_wide_f32",
+    )
+    LAST_KNN["path"], LAST_KNN["flagged"] = "wide (K-chunked MFMA scan)", 0
+    return out_d, out_i
+
+
 _GENERAL_BQ = 4096    # query rows per library-GEMM block of the general-D path
 _GENERAL_BD = 65536   # database rows per block (4096 x 65536 fp32 = 1 GiB)
 
 
 def _knn_general(Xq, Y, k, metric, exclude_self, q_global0=0):
-    """Exact kNN for feature dimensions the register-resident MFMA kernels do not cover (D > 256): per
-    (query chunk x database chunk) block a plain library GEMM (``torch.mm`` = rocBLAS / hipBLASLt) forms X Y^T and
-    ``tdr_topk_merge_f32`` does the rest of the reference's op sequence (norm expansion, self exclusion, running
-    top-k in the canonical (distance, index) order).  Values agree with the reference to fp32 rounding (the
-    library's summation order is not MKL's), not bit for bit."""
+    """Exact kNN outside the LDS-resident lists of the scan kernels (k beyond their capacity, sqhyperbolic, and the
+    manhattan tile pass): per (query chunk x database chunk) block a plain library GEMM (``torch.mm`` = rocBLAS /
+    hipBLASLt) forms X Y^T and ``tdr_topk_merge_f32`` does the rest of the reference's op sequence (norm expansion,
+    self exclusion, running top-k in the canonical (distance, index) order).  Values agree with the reference to fp32
+    rounding (the library's summation order is not MKL's), not bit for bit.  D > 256 with an MFMA metric goes to
+    ``_knn_wide`` first."""
     L = _lib.lib()
     nq, nd = Xq.shape[0], Y.shape[0]
+    if metric in ("sqeuclidean", "euclidean", "angular") and Y.shape[1] > 256 and WIDE_SCAN:
+        res = _knn_wide(Xq, Y, k, metric, exclude_self, q_global0)
+        if res is not None:
+            return res
     if k > 256:
         raise NotImplementedError(f"[torchdr_amd] k={k} > 256 is not supported by the running top-k kernel.")
     dev = Y.device
