@@ -98,11 +98,50 @@ __global__ __launch_bounds__(256) void dedup_resolve_kernel(const float* __restr
 }
 
 // ---- PCA initialisation ---------------------------------------------------------------------------------------------
-// column sums of a row strip per workgroup (thread = column, fp32 over <= rows_per_wg rows), combined in fixed order
+// column sums of a row strip per workgroup (fp32 over <= rows_per_wg rows), combined in fixed order.  Vector form
+// (d and ldx multiples of 4, 16-byte aligned rows): thread = (float4 column, row lane), 256 / (d / 4) row lanes walk
+// the strip interleaved with four loads in flight each; the lanes' sums meet in LDS in lane order.  Scalar form:
+// thread = column.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t n, int d, int64_t ldx,
-                                                             int64_t rows_per_wg, float* __restrict__ partial) {
+                                                             int64_t rows_per_wg, int vec, float* __restrict__ partial) {
+    __shared__ float red[256 * 4];
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
     const int64_t r1 = (r0 + rows_per_wg < n) ? r0 + rows_per_wg : n;
+    if (vec) {
+        const int nv = d / 4;          // float4 columns (<= 64)
+        const int lanes = 256 / nv;    // row lanes
+        const int c = threadIdx.x % nv, rl = threadIdx.x / nv;
+        float4 s[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < lanes) {
+            int64_t r = r0 + rl;
+            for (; r + 3 * lanes < r1; r += 4 * lanes) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 v = *reinterpret_cast<const float4*>(X + (r + (int64_t)u * lanes) * ldx + 4 * c);
+                    s[u].x += v.x; s[u].y += v.y; s[u].z += v.z; s[u].w += v.w;
+                }
+            }
+            for (; r < r1; r += lanes) {
+                const float4 v = *reinterpret_cast<const float4*>(X + r * ldx + 4 * c);
+                s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+            }
+        }
+        const float4 t = make_float4((s[0].x + s[1].x) + (s[2].x + s[3].x), (s[0].y + s[1].y) + (s[2].y + s[3].y),
+                                     (s[0].z + s[1].z) + (s[2].z + s[3].z), (s[0].w + s[1].w) + (s[2].w + s[3].w));
+        *reinterpret_cast<float4*>(red + threadIdx.x * 4) = t;
+        __syncthreads();
+        if (threadIdx.x < nv) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int l = 0; l < lanes; ++l) {
+                const float4 v = *reinterpret_cast<const float4*>(red + (l * nv + threadIdx.x) * 4);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * d + 4 * threadIdx.x) = a;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < d; c += 256) {
         float s = 0.f;
         for (int64_t r = r0; r < r1; ++r) s += X[r * ldx + c];
@@ -249,8 +288,8 @@ int tdr_dedup_rows_f32(const float* X, int64_t n, int d, int64_t ldx, int32_t* r
 int64_t tdr_pca_gram_workspace_floats(int64_t n, int d) {
     if (n <= 0 || d <= 0 || d > 256) return 0;
     const int W = 32 * ((d + 31) / 32);
-    int64_t n_wg = (n + 4095) / 4096;
-    if (n_wg > 512) n_wg = 512;
+    int64_t n_wg = (n + 1023) / 1024;
+    if (n_wg > 1024) n_wg = 1024;
     return n_wg * ((int64_t)W * W + d);
 }
 
@@ -263,14 +302,15 @@ int tdr_pca_gram_f32(const float* X, int64_t n, int d, int64_t ldx, float* mean,
     if (ws_floats < tdr_pca_gram_workspace_floats(n, d)) return TDR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int DT = (d + 31) / 32, W = 32 * DT;
-    int64_t n_wg = (n + 4095) / 4096;
-    if (n_wg > 512) n_wg = 512;
+    int64_t n_wg = (n + 1023) / 1024;  // several workgroups per CU hide each other's load latency
+    if (n_wg > 1024) n_wg = 1024;
     int64_t rows_per_wg = (n + n_wg - 1) / n_wg;
     rows_per_wg = (rows_per_wg + 31) / 32 * 32;
     n_wg = (n + rows_per_wg - 1) / rows_per_wg;
     float* part_g = ws;
     float* part_s = ws + n_wg * (int64_t)W * W;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, X, n, d, ldx, rows_per_wg, part_s);
+    const int vec = (d % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)part_s & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)n_wg), dim3(256), 0, st, X, n, d, ldx, rows_per_wg, vec, part_s);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, st, (const float*)part_s, (int)n_wg, d,
                        1.0 / (double)n, mean);
 #define TDR_GRAM(DTV)                                                                                                    \

@@ -111,9 +111,13 @@ __device__ __forceinline__ int bsearch_row(const int32_t* __restrict__ c, int le
 // row j receives one extra entry.  `ext_*`: edges received from other ranks, already transposed
 // (ext_row = local row that RECEIVES, ext_col = global source), counted unconditionally when the
 // receiving row lacks that column.
-__global__ __launch_bounds__(256) void sym_count_kernel(const int32_t* __restrict__ scols, const int32_t* __restrict__ slen,
-                                                        int64_t n, int k, int64_t row_offset,
-                                                        int32_t* __restrict__ incnt) {
+// The visit of row j (a random 128-byte line or two of scols, one of svals) is the expensive part of an edge: it is
+// made ONCE, here, and the transposed value P_ji (or VT_MISSING) is left in `vt` for the fill pass, which then reads
+// nothing at random.
+constexpr uint32_t VT_MISSING = 0xFFC0DEADu;  // a NaN pattern no arithmetic produces: row j has no entry for column i
+__global__ __launch_bounds__(256) void sym_count_kernel(const float* __restrict__ svals, const int32_t* __restrict__ scols,
+                                                        const int32_t* __restrict__ slen, int64_t n, int k, int64_t row_offset,
+                                                        int32_t* __restrict__ incnt, uint32_t* __restrict__ vt) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n * k) return;
     const int64_t i = idx / k;
@@ -121,9 +125,11 @@ __global__ __launch_bounds__(256) void sym_count_kernel(const int32_t* __restric
     if (p >= slen[i]) return;
     const int64_t j = scols[idx];
     const int64_t lj = j - row_offset;
-    if (lj < 0 || lj >= n) return;  // transpose belongs to another rank
+    if (lj < 0 || lj >= n) { vt[idx] = 0u; return; }  // transpose belongs to another rank (arrives as an ext edge)
     const int32_t gi = (int32_t)(i + row_offset);
-    if (bsearch_row(scols + (size_t)lj * k, slen[lj], gi) < 0) atomicAdd(&incnt[lj], 1);
+    const int pos = bsearch_row(scols + (size_t)lj * k, slen[lj], gi);
+    if (pos < 0) { atomicAdd(&incnt[lj], 1); vt[idx] = VT_MISSING; }
+    else vt[idx] = __builtin_bit_cast(uint32_t, svals[(size_t)lj * k + pos]);
 }
 
 __global__ __launch_bounds__(256) void sym_count_ext_kernel(const int32_t* __restrict__ scols, const int32_t* __restrict__ slen,
@@ -215,8 +221,8 @@ __device__ __forceinline__ float combine(float vP, float vPT, int mode) {
 __global__ __launch_bounds__(256) void sym_fill_kernel(const float* __restrict__ svals, const int32_t* __restrict__ scols,
                                                        const int32_t* __restrict__ slen, int64_t n, int k,
                                                        int64_t row_offset, int mode, const int64_t* __restrict__ rowptr,
-                                                       int32_t* __restrict__ cursor, int32_t* __restrict__ tcols,
-                                                       float* __restrict__ tvals) {
+                                                       int32_t* __restrict__ cursor, const uint32_t* __restrict__ vtw,
+                                                       int32_t* __restrict__ tcols, float* __restrict__ tvals) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n * k) return;
     const int64_t i = idx / k;
@@ -225,17 +231,15 @@ __global__ __launch_bounds__(256) void sym_fill_kernel(const float* __restrict__
     const int32_t j = scols[idx];
     const float v = svals[idx];
     const int64_t lj = (int64_t)j - row_offset;
-    float vt = 0.f;  // P_ji when row j is local and has column i; remote transposes arrive via ext edges
+    const uint32_t w = vtw[idx];  // P_ji found by the count pass (0 for remote rows: their transposes arrive via ext edges)
+    float vt = 0.f;
     const int32_t gi = (int32_t)(i + row_offset);
-    bool local = (lj >= 0 && lj < n);
-    if (local) {
-        const int pos = bsearch_row(scols + (size_t)lj * k, slen[lj], gi);
-        if (pos >= 0) vt = svals[(size_t)lj * k + pos];
-        else {
-            const int64_t dst = rowptr[lj] + slen[lj] + atomicAdd(&cursor[lj], 1);
-            tcols[dst] = gi;
-            tvals[dst] = combine(0.f, v, mode);
-        }
+    if (w == VT_MISSING) {
+        const int64_t dst = rowptr[lj] + slen[lj] + atomicAdd(&cursor[lj], 1);
+        tcols[dst] = gi;
+        tvals[dst] = combine(0.f, v, mode);
+    } else {
+        vt = __builtin_bit_cast(float, w);
     }
     const int64_t dst = rowptr[i] + p;
     tcols[dst] = j;
@@ -275,12 +279,25 @@ __global__ __launch_bounds__(256) void sym_finalize_kernel(const int64_t* __rest
     if (row >= n) return;
     const int64_t b = rowptr[row], e = rowptr[row + 1];
     const int len = (int)(e - b);
+    if (len <= 64) {  // the row sits in one register per lane; every entry is broadcast once through the scalar unit
+        const bool have = lane < len;
+        const int32_t mine = have ? tcols[b + lane] : INT_MAX;
+        const float v = have ? tvals[b + lane] : 0.f;
+        int rank = 0;
+        for (int q = 0; q < len; ++q) rank += (__builtin_amdgcn_readlane(mine, q) < mine) ? 1 : 0;
+        if (have) { cols[b + rank] = mine; vals[b + rank] = v; }
+        return;
+    }
     for (int p0 = 0; p0 < len; p0 += 64) {
         const int p = p0 + lane;
         const bool have = p < len;
         const int32_t mine = have ? tcols[b + p] : INT_MAX;
         int rank = 0;
-        for (int q = 0; q < len; ++q) rank += (tcols[b + q] < mine) ? 1 : 0;
+        for (int q0 = 0; q0 < len; q0 += 64) {
+            const int32_t theirs = (q0 + lane < len) ? tcols[b + q0 + lane] : INT_MAX;
+            const int nq = (len - q0 < 64) ? len - q0 : 64;
+            for (int q = 0; q < nq; ++q) rank += (__builtin_amdgcn_readlane(theirs, q) < mine) ? 1 : 0;
+        }
         if (have) { cols[b + rank] = mine; vals[b + rank] = tvals[b + p]; }
     }
 }
@@ -315,6 +332,7 @@ int64_t tdr_sym_workspace_bytes(int64_t n, int k) {
     b += n * 4;      // cursor
     b += nb * 8;     // block sums
     b += 16;         // total (int64) + max_deg (int32)
+    b += n * k * 4;  // transposed values found by the count pass
     return b + 256;
 }
 
@@ -339,13 +357,14 @@ int tdr_sym_count_f32(const float* vals, const int32_t* cols, int64_t n, int k, 
     w = (char*)(((uintptr_t)w + 7) & ~(uintptr_t)7);
     int64_t* block_sums = (int64_t*)w; w += nb * 8;
     int64_t* total = (int64_t*)w; w += 8;
-    int32_t* max_deg = (int32_t*)w;
+    int32_t* max_deg = (int32_t*)w; w += 8;
+    uint32_t* vt = (uint32_t*)w;
     hipError_t e = hipMemsetAsync(incnt, 0, (size_t)n * 8, st);  // incnt + cursor
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(total, 0, 16, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(sym_rowsort_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, vals, cols, n, k, svals, scols, slen);
-    hipLaunchKernelGGL(sym_count_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, scols, slen, n, k, row_offset, incnt);
+    hipLaunchKernelGGL(sym_count_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, svals, scols, slen, n, k, row_offset, incnt, vt);
     if (n_ext > 0) {
         if (!ext_row || !ext_col) return TDR_ERR_BAD_ARG;
         hipLaunchKernelGGL(sym_count_ext_kernel, dim3((unsigned)((n_ext + 255) / 256)), dim3(256), 0, st, scols, slen, k, ext_row, ext_col, n_ext, incnt);
@@ -370,8 +389,12 @@ int tdr_sym_fill_f32(int64_t n, int k, int64_t row_offset, int mode, const int32
     int32_t* scols = (int32_t*)w; w += n * k * 4;
     int32_t* slen = (int32_t*)w; w += n * 4;
     w += n * 4;  // incnt
-    int32_t* cursor = (int32_t*)w;
-    hipLaunchKernelGGL(sym_fill_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, svals, scols, slen, n, k, row_offset, mode, rowptr, cursor, tcols, tvals);
+    int32_t* cursor = (int32_t*)w; w += n * 4;
+    const int64_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    w = (char*)(((uintptr_t)w + 7) & ~(uintptr_t)7);
+    w += nb * 8 + 16;  // block sums, total + max_deg
+    const uint32_t* vt = (const uint32_t*)w;
+    hipLaunchKernelGGL(sym_fill_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, svals, scols, slen, n, k, row_offset, mode, rowptr, cursor, vt, tcols, tvals);
     if (n_ext > 0) {
         if (!ext_row || !ext_col || !ext_val) return TDR_ERR_BAD_ARG;
         hipLaunchKernelGGL(sym_fill_ext_kernel, dim3((unsigned)((n_ext + 255) / 256)), dim3(256), 0, st, svals, scols, slen, k, mode, rowptr, cursor, ext_row, ext_col, ext_val, n_ext, tcols, tvals);

@@ -249,7 +249,9 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
 }
 
 // Loop layout of a row's edges: ascending eps_per (= often-firing edges first, never-firing ones last), ties by
-// position.  Rank sort per row, one wavefront per row (rows of more than 2048 edges keep their order).
+// position.  Rank sort per row, one wavefront per row: the row's periods sit in registers (lane p holds entries p,
+// p + 64, ...) and every entry is broadcast once through the scalar unit (v_readlane); rows of more than 2048 edges
+// keep their order.
 __global__ __launch_bounds__(256) void umap_sched_layout_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                                 const float* __restrict__ eps_per, int64_t n_rows,
                                                                 int32_t* __restrict__ cols_out, float* __restrict__ eps_out) {
@@ -262,14 +264,30 @@ __global__ __launch_bounds__(256) void umap_sched_layout_kernel(const int64_t* _
         for (int p = lane; p < len; p += 64) { cols_out[b + p] = cols[b + p]; eps_out[b + p] = eps_per[b + p]; }
         return;
     }
+    if (len <= 64) {  // the common case: one entry per lane
+        const bool have = lane < len;
+        const float mine = have ? eps_per[b + lane] : __builtin_inff();
+        const int32_t col = have ? cols[b + lane] : 0;
+        int rank = 0;
+        for (int q = 0; q < len; ++q) {
+            const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), q));
+            rank += (o < mine || (o == mine && q < lane)) ? 1 : 0;
+        }
+        if (have) { cols_out[b + rank] = col; eps_out[b + rank] = mine; }
+        return;
+    }
     for (int p0 = 0; p0 < len; p0 += 64) {
         const int p = p0 + lane;
         const bool have = p < len;
         const float mine = have ? eps_per[b + p] : 0.f;
         int rank = 0;
-        for (int q = 0; q < len; ++q) {
-            const float o = eps_per[b + q];
-            rank += (o < mine || (o == mine && q < p)) ? 1 : 0;
+        for (int q0 = 0; q0 < len; q0 += 64) {
+            const float theirs = (q0 + lane < len) ? eps_per[b + q0 + lane] : __builtin_inff();
+            const int nq = (len - q0 < 64) ? len - q0 : 64;
+            for (int q = 0; q < nq; ++q) {
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, theirs), q));
+                rank += (o < mine || (o == mine && q0 + q < p)) ? 1 : 0;
+            }
         }
         if (have) { cols_out[b + rank] = cols[b + p]; eps_out[b + rank] = mine; }
     }

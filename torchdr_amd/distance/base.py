@@ -20,6 +20,7 @@ from torchdr_amd.utils.misc import as_float32
 LIST_METRICS = ["euclidean", "sqeuclidean", "manhattan", "angular", "sqhyperbolic"]
 _METRIC_ID = {"sqeuclidean": 0, "euclidean": 1, "angular": 2, "manhattan": 3, "sqhyperbolic": 4}
 _GENERAL_ONLY = ("manhattan", "sqhyperbolic")     # metrics that never take the MFMA scan kernels
+PILOT_CONCURRENT = True   # pilot tiers and the cluster-index build on concurrent streams (False: one after the other)
 WIDE_SCAN = True   # D > 256: K-chunked MFMA scan (False = library GEMM + top-k merge, kept for comparison)
 
 # Value the reference adds to the diagonal when exclude_diag=True (distance/torch.py:115).
@@ -239,21 +240,61 @@ def _screen_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier, p
     return flags, n_flagged
 
 
-def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset):
-    """Pilot: screen a 2048-query slice with each tier, cheapest first (one-term, three-term, three-term with long
-    lists), flagging what an UNSLICED launch would flag; the first tier with <= 5 % flagged wins.  Returns (tier, tau)
-    with tau the largest k-th neighbour distance (squared) of the slice, or (-1, None) when the worst-case band swallows
-    the spare list slots for a sizeable share of the queries under every tier (large ||x|| ||y|| relative to the
-    neighbour spacing): the one-stage kernel serves such data."""
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev, n):
+    """Cached side streams of a device (pilot searches and the cluster-index build run next to each other)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    have = _SIDE_STREAMS.setdefault(key, [])
+    while len(have) < n:
+        have.append(torch.cuda.Stream(device=dev))
+    return have[:n]
+
+
+def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset, side_work=None):
+    """Pilot: screen a 1024-query slice with the tiers (one-term, three-term, three-term with long lists), flagging what
+    an UNSLICED launch would flag; the cheapest tier with <= 5 % flagged wins.  Returns (tier, tau) with tau the largest
+    k-th neighbour distance (squared) of the slice, or (-1, None) when the worst-case band swallows the spare list slots
+    for a sizeable share of the queries under every tier (large ||x|| ||y|| relative to the neighbour spacing): the
+    one-stage kernel serves such data.
+    A pilot launch is 256 workgroups (one per CU) of ~5 ms, so the first two tiers run CONCURRENTLY on two streams, and
+    ``side_work`` (the cluster-index build, a chain of small kernels plus one single-workgroup seeding kernel) on a
+    third; all are joined before the one host read of the flag counters."""
     L = _lib.lib()
     dev, d = Y.device, Y.d
-    pd = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.float32, device=dev)
-    pi = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.int32, device=dev)
-    for tier in (0, 1, 2):
-        if L.tdr_knn_screen_workspace_bytes(_SCREEN_PILOT_Q, Y.n, d, k, tier) == 0:
-            continue  # shape not available for this (d, k)
+    tiers = [t for t in (0, 1, 2) if L.tdr_knn_screen_workspace_bytes(_SCREEN_PILOT_Q, Y.n, d, k, t) != 0]
+    main = torch.cuda.current_stream(dev)
+    side = _side_streams(dev, 2)
+    for sd in side:
+        sd.wait_stream(main)
+
+    def launch(tier):
+        pd = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.float32, device=dev)
+        pi = torch.empty((_SCREEN_PILOT_Q, k), dtype=torch.int32, device=dev)
         _, n_flagged = _screen_launch(Q, Y, ops, q0, _SCREEN_PILOT_Q, k, metric, exclude_self, q_offset, tier, True, pd, pi,
                                       profile=False)
+        return pd, n_flagged
+
+    runs = {}
+    if len(tiers) >= 2 and PILOT_CONCURRENT:
+        with torch.cuda.stream(side[0]):
+            runs[tiers[0]] = launch(tiers[0])
+        runs[tiers[1]] = launch(tiers[1])
+    elif tiers:
+        runs[tiers[0]] = launch(tiers[0])
+    if side_work is not None:
+        if PILOT_CONCURRENT:
+            with torch.cuda.stream(side[1]):
+                side_work()
+        else:
+            side_work()
+    for sd in side:
+        main.wait_stream(sd)
+    for tier in tiers:
+        if tier not in runs:
+            runs[tier] = launch(tier)
+        pd, n_flagged = runs[tier]
         if int(n_flagged.item()) <= _SCREEN_PILOT_MAX_FRAC * _SCREEN_PILOT_Q:
             kth = pd[:, -1]
             return tier, float((kth * kth if metric == "euclidean" else kth).max())
@@ -334,11 +375,13 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
     suit screening (nothing written; the caller uses the one-stage kernel)."""
     ops = _screen_operands(Q, Y)
     pilot_tau = None
+    prune = Q is Y and q0 == 0 and q_offset == 0 and nq == Y.n and _want_prune(Y, Y.n)
     if pilot and nq >= _SCREEN_PILOT_MIN_Q:
-        tier, pilot_tau = _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset)
+        # the index build does not depend on the pilot's outcome: it runs next to it
+        tier, pilot_tau = _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset,
+                                       side_work=(lambda: _cluster_index(Y, ops)) if prune else None)
         if tier < 0:
             return -1
-    prune = Q is Y and q0 == 0 and q_offset == 0 and nq == Y.n and _want_prune(Y, Y.n)
     if prune:
         ci = _cluster_index(Y, ops)
         # worth it only when the cluster balls are far apart relative to the neighbour distances: predicted from the
