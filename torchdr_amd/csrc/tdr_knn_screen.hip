@@ -233,8 +233,9 @@ __device__ __forceinline__ float reduce_tau(float tau, float xn) {
     return (tau - xn) + 2.3841858e-07f * (fabsf(tau) + xn);  // + 4u (|tau| + xn): never rejects an a <= tau
 }
 
+// one candidate at a time: the cheaper form while survivors are rare (steady state of a long scan)
 template <int ITEMS, int QB>
-__device__ __forceinline__ void screen_insert(const SCtx<QB>& C, const float (&dv)[QB][16], const float (&pmin)[QB][4],
+__device__ __forceinline__ void screen_insert_serial(const SCtx<QB>& C, const float (&dv)[QB][16], const float (&pmin)[QB][4],
                                               int Tprev, float (&tau_r)[QB]) {
     const ScreenParams& P = *C.P;
 #pragma unroll
@@ -269,6 +270,119 @@ __device__ __forceinline__ void screen_insert(const SCtx<QB>& C, const float (&d
     }
 }
 
+// Survivors of one finished tile -> the queries' lists.  A lane holds 16 candidate values of ONE query (two lanes per
+// query: the tile's rows 4h + (r & 3) + 8 (r >> 2)).  Per query with at least one survivor the wavefront MERGES all of
+// that query's survivors (<= 32) into its ascending list in one pass:
+//   collect  the survivors' keys are pulled out of the owning lanes' registers through the scalar unit
+//            (v_readlane, select on the lane id) into lanes 0 .. nb-1;
+//   rank     every list entry counts the survivors below it (its shift), every survivor counts the list entries
+//            (ballot + popcount) and the other survivors below it (its position) -- one u64 compare per (entry,
+//            survivor) pair and no dependent shuffle chains;
+//   place    entries and survivors are scattered to their final positions (LDS), entries pushed past the end fall off.
+// The result is the L smallest of (list + survivors), exactly what inserting them one by one produces, at
+// ~(300 + 56 nb) cycles per query instead of ~450 per survivor: on clustered data a query meets most of its candidates
+// in the first tiles of its own cluster, where nearly every row still beats the threshold.
+template <int ITEMS, int QB>
+__device__ __forceinline__ void screen_insert_merge(const SCtx<QB>& C, const float (&dv)[QB][16], const float (&pmin)[QB][4],
+                                              int Tprev, float (&tau_r)[QB]) {
+    const ScreenParams& P = *C.P;
+    const int L = P.L;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int64_t jb = (int64_t)Tprev * 32 + 4 * C.h;
+        const int64_t jself = (C.qt0 + qb) * 32 + C.q + P.q_offset;
+        // opaque copies: nothing below may be speculated above the (rarely taken) branch that leads here
+        float tq = tau_r[qb], xq = C.xn[qb];
+        asm volatile("" : "+v"(tq), "+v"(xq));
+        uint32_t hi[16];
+        uint32_t smask = 0;  // bit r: this lane's candidate r survives (one VGPR instead of 16 ballots in SGPRs)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t j = jb + (r & 3) + 8 * (r >> 2);
+            // padding rows carry +inf norms; rows beyond the database and the query's own row are not candidates
+            const bool ok = dv[qb][r] <= tq && dv[qb][r] < __builtin_inff() && j < P.n_db && !(P.exclude_self && j == jself);
+            smask |= ok ? (1u << r) : 0u;
+            hi[r] = f2u(dv[qb][r] + xq);  // the full screening value a = c' + ||x||^2 is what the lists hold
+        }
+        const unsigned long long any = __ballot(smask != 0u);
+        uint32_t qmask = (uint32_t)any | (uint32_t)(any >> 32);
+        while (qmask) {
+            const int sq = __builtin_amdgcn_readfirstlane(__builtin_ctz(qmask));
+            qmask &= qmask - 1u;
+            uint64_t* Lst = C.keys + ((size_t)qb * 32 + sq) * L;
+            uint64_t cur[ITEMS];
+#pragma unroll
+            for (int t = 0; t < ITEMS; ++t) {
+                const int p = C.lane + 64 * t;
+                cur[t] = (p < L) ? Lst[p] : KEY_SENTINEL;
+            }
+            // collect
+            uint32_t Bhi = (uint32_t)(KEY_SENTINEL >> 32), Blo = 0xffffffffu;
+            int nb = 0;
+            const uint32_t m2[2] = {(uint32_t)__builtin_amdgcn_readlane((int)smask, sq),
+                                    (uint32_t)__builtin_amdgcn_readlane((int)smask, sq + 32)};
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    if ((m2[hh] >> r) & 1u) {
+                        const uint32_t kh = (uint32_t)__builtin_amdgcn_readlane((int)hi[r], sq + 32 * hh);
+                        const uint32_t kl = (uint32_t)(Tprev * 32 + 4 * hh + (r & 3) + 8 * (r >> 2));
+                        const bool mine = C.lane == nb;  // lane nb receives survivor nb
+                        Bhi = mine ? kh : Bhi;
+                        Blo = mine ? kl : Blo;
+                        ++nb;
+                    }
+                }
+            }
+            // rank
+            const uint64_t Bv = ((uint64_t)Bhi << 32) | (uint64_t)Blo;
+            int cntS = 0, rankB = 0;
+            int shift[ITEMS];
+#pragma unroll
+            for (int t = 0; t < ITEMS; ++t) shift[t] = 0;
+            for (int t2 = 0; t2 < nb; ++t2) {
+                const uint64_t bk = readlane_u64(Bv, t2);
+                int c = 0;
+#pragma unroll
+                for (int t = 0; t < ITEMS; ++t) {
+                    const bool lt = cur[t] < bk;
+                    c += __popcll(__ballot(lt));
+                    shift[t] += lt ? 0 : 1;
+                }
+                cntS = (C.lane == t2) ? c : cntS;
+                rankB += (bk < Bv) ? 1 : 0;
+            }
+            // place
+#pragma unroll
+            for (int t = 0; t < ITEMS; ++t) {
+                const int p = C.lane + 64 * t;
+                const int np = p + shift[t];
+                if (p < L && np < L && shift[t] > 0) Lst[np] = cur[t];
+            }
+            if (C.lane < nb) {
+                const int pos = rankB + cntS;
+                if (pos < L) Lst[pos] = Bv;
+            }
+            // the query's new threshold (LDS operations of a wavefront complete in order: these reads see the writes)
+            const uint64_t nk = Lst[P.k - 1], nt = Lst[L - 1];
+            if (C.q == sq)
+                tau_r[qb] = reduce_tau(fminf(u2f((uint32_t)(nk >> 32)) + C.band[qb], u2f((uint32_t)(nt >> 32))), C.xn[qb]);
+        }
+    }
+}
+
+// few lanes with a survivor in the wavefront's tile (the steady state of a long scan): one candidate at a time
+// (~450 cycles each); many (a query's first tiles, clustered data): merged per query (~800 cycles of preparation per
+// tile + ~(300 + 56 nb) per query).  `lanes` = number of lanes that hold at least one survivor.
+constexpr int MERGE_MIN_LANES = 8;
+template <int ITEMS, int QB>
+__device__ __forceinline__ void screen_insert(const SCtx<QB>& C, const float (&dv)[QB][16], const float (&pmin)[QB][4],
+                                              int Tprev, float (&tau_r)[QB], int lanes) {
+    if (__builtin_expect(lanes >= MERGE_MIN_LANES, 0)) screen_insert_merge<ITEMS, QB>(C, dv, pmin, Tprev, tau_r);  // laid out of line
+    else screen_insert_serial<ITEMS, QB>(C, dv, pmin, Tprev, tau_r);
+}
+
 // reduced screening values of one quarter (4 rows) of a finished tile
 template <int QB>
 __device__ __forceinline__ void sform_part(const SCtx<QB>& C, const f32x16 (&acc)[QB], const f32x4 (&yn)[4], int g,
@@ -282,13 +396,14 @@ __device__ __forceinline__ void sform_part(const SCtx<QB>& C, const f32x16 (&acc
     }
 }
 
+// number of lanes with at least one candidate at or below their threshold
 template <int QB>
-__device__ __forceinline__ bool any_survivor(const float (&pmin)[QB][4], const float (&tau_r)[QB]) {
+__device__ __forceinline__ int survivor_lanes(const float (&pmin)[QB][4], const float (&tau_r)[QB]) {
     bool hit = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
         hit |= (fminf(fminf(pmin[qb][0], pmin[qb][1]), fminf(pmin[qb][2], pmin[qb][3])) <= tau_r[qb]);
-    return __any(hit);
+    return __popcll(__ballot(hit));
 }
 
 // h.h' + h.l' + l.h' of one K-slice into each query block's accumulator chain (the fp32 accumulation of all 3*D
@@ -384,7 +499,8 @@ __device__ __forceinline__ void stile_step(const SCtx<QB>& C, const char* __rest
         }
     }
     if (HAVE_PREV) {
-        if (any_survivor<QB>(pmin, tau_r)) screen_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_r);
+        const int lanes = survivor_lanes<QB>(pmin, tau_r);
+        if (lanes) screen_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_r, lanes);
     }
 }
 
@@ -398,7 +514,8 @@ __device__ __forceinline__ void stile_drain(const SCtx<QB>& C, const f32x16 (&pr
     for (int g = 0; g < 4; ++g) yn[g] = *reinterpret_cast<const f32x4*>(ynp_prev + 8 * g);
 #pragma unroll
     for (int g = 0; g < 4; ++g) sform_part<QB>(C, prev, yn, g, dv, pmin);
-    if (any_survivor<QB>(pmin, tau_r)) screen_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_r);
+    const int lanes = survivor_lanes<QB>(pmin, tau_r);
+    if (lanes) screen_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_r, lanes);
 }
 
 // Workgroup = 4 wavefronts x QB query blocks of 32.  QB = 1: 128 queries, two workgroups per CU (two wavefronts
@@ -500,44 +617,38 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
             __syncthreads();
             ++T;
         }
+        // ONE copy of the steady-state step (the kernel is ~100 KB of code against a 64 KB instruction cache): the
+        // finished tile always sits in accA, the running one in accB, swapped by 16 register moves per tile
         while (T < r_end) {
-            {
-                if (T + 1 < r_end) stage(T + 1);
-                if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, tile1, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
-                __syncthreads();
-                ++T;
-            }
-            if (T < r_end) {
-                if (T + 1 < r_end) stage(T + 1);
-                if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, tile0, bh, bl, accA, accB, TDR_YN(T - 1), T - 1, tau_r);
-                __syncthreads();
-                ++T;
-            } else {
+            if (T + 1 < r_end) stage(T + 1);
+            const char* img = ((T - t_begin) & 1) ? tile1 : tile0;
+            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, img, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
+            __syncthreads();
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) accA[qb] = accB[qb];
-            }
+            for (int qb = 0; qb < QB; ++qb) accA[qb] = accB[qb];
+            ++T;
         }
         if (wave_active) stile_drain<ITEMS, QB>(C, accA, TDR_YN(r_end - 1), r_end - 1, tau_r);
         __syncthreads();  // the last norm-ring slot / tile buffers may be restaged by the next range
     };
 
-    if (P.tile_cluster == nullptr) {
-        scan_range(t_begin, t_end);
-    } else {
-        // Cluster-bound pruning.  Points are sorted by cluster and clusters start on tile boundaries, so a wavefront's
-        // 32 queries lie in ONE cluster ball B(c_w, R_w).  Every member y of cluster c satisfies
-        // |x - y| >= |c_w - c_c| - R_w - R_c, hence its screening value a >= lb - E (E <= band / 2).  Clusters are
-        // visited by increasing centre distance from the first wavefront's cluster (tightens the thresholds early);
-        // one whose bound exceeds the largest current threshold of the workgroup can never contribute a candidate and is
-        // skipped -- thresholds only decrease, so the decision stays valid.  Exactness does not depend on the
-        // clustering quality, only the amount of skipped work does.
+    {
+        // Range driver (ONE call site of scan_range: the scan body is most of the kernel's code).  Without cluster tables:
+        // the slice [t_begin, t_end).  With them, cluster-bound pruning: points are sorted by cluster and clusters start
+        // on tile boundaries, so a wavefront's 32 queries lie in ONE cluster ball B(c_w, R_w).  Every member y of
+        // cluster c satisfies |x - y| >= |c_w - c_c| - R_w - R_c, hence its screening value a >= lb - E (E <= band / 2).
+        // Clusters are visited by increasing centre distance from the first wavefront's cluster (tightens the
+        // thresholds early); one whose bound exceeds the largest current threshold of the workgroup can never
+        // contribute a candidate and is skipped -- thresholds only decrease, so the decision stays valid.  Exactness
+        // does not depend on the clustering quality, only the amount of skipped work does.
+        const bool pruned = P.tile_cluster != nullptr;
         float* wred = reinterpret_cast<float*>(keys_all + (size_t)NW * QB * 32 * Ln);  // 16 floats behind the lists
         unsigned long long* wmask = reinterpret_cast<unsigned long long*>(wred + 8);   // 4 ballots
         int cw[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const int64_t qtw = (((int64_t)blockIdx.x + P.batch0) * NW + w) * QB;
-            cw[w] = (qtw < n_qtiles) ? P.tile_cluster[qtw] : -1;
+            cw[w] = (pruned && qtw < n_qtiles) ? P.tile_cluster[qtw] : -1;
         }
         float bmax = 0.f;  // band of the valid lanes only (invalid lanes were given ||x||^2 = 0)
 #pragma unroll
@@ -558,40 +669,53 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
             __syncthreads();
         };
         const int c0 = cw[0];
-        float tau_wg, band_wg;
-        wg_threshold(tau_wg, band_wg);
+        float tau_wg = 0.f, band_wg = 0.f;
         int idx0 = 0;
-        while (idx0 < P.n_clusters) {
-            // 256 clusters of the visiting order are tested at once, one per thread, against the current threshold
-            const int idx = idx0 + tid;
-            bool survive = false;
-            if (idx < P.n_clusters) {
-                const int c = P.clus_order[(size_t)c0 * P.n_clusters + idx];
-                const float rc = P.clus_radius[c];
-                float lb = __builtin_inff();
+        bool more = true;
+        while (more) {
+            int rb = t_begin, re = t_end;
+            if (!pruned) {
+                more = false;
+            } else {
+                wg_threshold(tau_wg, band_wg);  // thresholds only decrease: later tests get sharper
+                bool found = false;
+                while (idx0 < P.n_clusters) {
+                    // 256 clusters of the visiting order are tested at once, one per thread, against the current threshold
+                    const int idx = idx0 + tid;
+                    bool survive = false;
+                    if (idx < P.n_clusters) {
+                        const int c = P.clus_order[(size_t)c0 * P.n_clusters + idx];
+                        const float rc = P.clus_radius[c];
+                        float lb = __builtin_inff();
 #pragma unroll
-                for (int w = 0; w < NW; ++w) {
-                    if (cw[w] < 0) continue;
-                    const float g = P.clus_dist[(size_t)cw[w] * P.n_clusters + c] - P.clus_radius[cw[w]] - rc;
-                    lb = fminf(lb, g > 0.f ? g * g : 0.f);
+                        for (int w = 0; w < NW; ++w) {
+                            if (cw[w] < 0) continue;
+                            const float g = P.clus_dist[(size_t)cw[w] * P.n_clusters + c] - P.clus_radius[cw[w]] - rc;
+                            lb = fminf(lb, g > 0.f ? g * g : 0.f);
+                        }
+                        survive = !(lb * 0.9999f - band_wg > tau_wg);  // pruned only when NO member can enter any band
+                    }
+                    const unsigned long long m = __ballot(survive);
+                    if (lane == 0) wmask[wave] = m;
+                    __syncthreads();
+                    int first = -1;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const unsigned long long mw = wmask[w];
+                        if (first < 0 && mw) first = 64 * w + __builtin_ctzll(mw);
+                    }
+                    __syncthreads();
+                    if (first < 0) { idx0 += 256; continue; }
+                    const int c = P.clus_order[(size_t)c0 * P.n_clusters + idx0 + first];
+                    rb = P.clus_tile_begin[c];
+                    re = P.clus_tile_begin[c + 1];
+                    idx0 += first + 1;
+                    found = true;
+                    break;
                 }
-                survive = !(lb * 0.9999f - band_wg > tau_wg);  // pruned only when NO member can enter any band
+                if (!found) break;
             }
-            const unsigned long long m = __ballot(survive);
-            if (lane == 0) wmask[wave] = m;
-            __syncthreads();
-            int first = -1;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const unsigned long long mw = wmask[w];
-                if (first < 0 && mw) first = 64 * w + __builtin_ctzll(mw);
-            }
-            __syncthreads();
-            if (first < 0) { idx0 += 256; continue; }
-            const int c = P.clus_order[(size_t)c0 * P.n_clusters + idx0 + first];
-            scan_range(P.clus_tile_begin[c], P.clus_tile_begin[c + 1]);
-            wg_threshold(tau_wg, band_wg);  // thresholds only decrease: later tests get sharper
-            idx0 += first + 1;
+            scan_range(rb, re);
         }
     }
 #undef TDR_YN
