@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void umap_neg_dense_kernel(const UmapStepParam
             for (int u = 0; u < U; ++u) {
                 const int col = base + u * G + gl;
                 v[u] = col < n_cols;
-                const uint32_t x = mix32(ckey + (uint32_t)(base + u * G) * 0x9E3779B9u);
+                const uint32_t x = mix32_item(ckey + (uint32_t)(base + u * G) * 0x9E3779B9u);  // = slice_negative()
                 const uint32_t rr = r_lo + __umulhi(x, r_len);
                 jn[u] = v[u] ? rr + (rr >= gi ? 1u : 0u) : gi;
             }

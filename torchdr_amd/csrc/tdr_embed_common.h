@@ -34,6 +34,16 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 14;
     return x;
 }
+// Two-multiply mixer ("lowbias32" constants) for the per-negative hash of the sliced samplers: its input is the row key
+// -- already three rounds of mix32 over (seed, row, iteration) -- plus a Weyl step per column, so one more strong round
+// is not needed, and a 32-bit integer multiply is a quarter-rate instruction (16 SIMD cycles per wavefront): the scheduled
+// gradient pass spends 48 of them per wavefront on the sampler.
+__device__ __forceinline__ uint32_t mix32_item(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
 __device__ __forceinline__ uint32_t neg_row_key(uint64_t seed, uint32_t iter, int64_t grow) {
     uint32_t h = mix32((uint32_t)grow ^ (uint32_t)seed);
     h = mix32(h + (uint32_t)((uint64_t)grow >> 32) * 0x9E3779B9u + (uint32_t)(seed >> 32));
@@ -119,7 +129,7 @@ __device__ __forceinline__ uint32_t slice_negative(uint32_t rkey, uint32_t gi, i
     const uint32_t step = (nred + (uint32_t)n_slices - 1u) / (uint32_t)n_slices;
     const uint32_t r_lo = (uint32_t)slice * step;
     const uint32_t r_len = (r_lo < nred) ? ((nred - r_lo < step) ? nred - r_lo : step) : 0u;
-    const uint32_t x = mix32(rkey + 0x632BE5ABu * (uint32_t)(slice + 1) + (uint32_t)col * 0x9E3779B9u);
+    const uint32_t x = mix32_item(rkey + 0x632BE5ABu * (uint32_t)(slice + 1) + (uint32_t)col * 0x9E3779B9u);
     const uint32_t rr = r_lo + __umulhi(x, r_len);
     return rr + (rr >= gi ? 1u : 0u);
 }

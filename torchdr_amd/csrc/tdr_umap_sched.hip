@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
                     jneg = j;
                 }
             } else {
-                const uint32_t x = mix32(ckey + (uint32_t)i * 0x9E3779B9u);  // column i - npos of this slice
+                const uint32_t x = mix32_item(ckey + (uint32_t)i * 0x9E3779B9u);  // column i - npos of this slice
                 const uint32_t rr = P.r_lo + __umulhi(x, P.r_len);
                 jneg = rr + (rr >= gi ? 1u : 0u);
             }
