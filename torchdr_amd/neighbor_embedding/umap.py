@@ -264,8 +264,12 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         _lib.check(L.tdr_umap_loop_create(ctypes.byref(handle), ctypes.byref(d)), "tdr_umap_loop_create")
         # graphs cannot be captured on the legacy default stream: the loop runs on a side stream ordered after the
         # caller's stream, and the caller's stream waits for it at the end
+        # windows that contain RCCL calls are enqueued as plain launches: captured collectives have never run on hardware
+        # here, and at the ~100 us an iteration takes when the rows are sharded the 8 us of host work per iteration of the
+        # plain form are hidden anyway
+        self._loop_graph = bool(LOOP_GRAPH) and ctx is None
         outer = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(device=dev) if LOOP_GRAPH else outer
+        side = torch.cuda.Stream(device=dev) if self._loop_graph else outer
         side.wait_stream(outer)
         try:
             with torch.cuda.stream(side):
@@ -287,7 +291,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             if LOOP_PROFILE is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            _lib.check(L.tdr_umap_loop_run(handle, w0, n, 1 if LOOP_GRAPH else 0, _lib.stream_ptr()), "tdr_umap_loop_run")
+            _lib.check(L.tdr_umap_loop_run(handle, w0, n, 1 if self._loop_graph else 0, _lib.stream_ptr()), "tdr_umap_loop_run")
             if LOOP_PROFILE is not None:
                 e1.record()
                 LOOP_PROFILE.append((e0, e1, n, csr.nnz))

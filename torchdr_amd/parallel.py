@@ -264,11 +264,17 @@ class RcclContext:
         raw = bytes(uid.numpy().tobytes())
         with torch.cuda.device(device):
             rc = L.tdr_ctx_create(ctypes.byref(handle), rank, world, raw, path, n_total)
-        if rc != 0:
-            return None
-        ctx = cls(handle, n_total)
-        if not ctx._self_check(device, rank, world):
-            ctx.destroy()
+        ctx = cls(handle, n_total) if rc == 0 else None
+        ok = ctx is not None and ctx._self_check(device, rank, world)
+        if world > 1 and broadcast is None:
+            # every rank keeps the context or none does (a rank that fell back alone would wait in a torch.distributed
+            # collective the others never enter)
+            flag = torch.tensor([1.0 if ok else 0.0], device=device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item() > 0)
+        if not ok:
+            if ctx is not None:
+                ctx.destroy()
             return None
         return ctx
 
