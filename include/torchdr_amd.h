@@ -157,6 +157,14 @@ int tdr_knn_screen_clustered_f32(const float* x16, const float* X, int64_t ldx, 
                                  const float* clus_radius, const float* clus_dist, const int32_t* clus_order,
                                  int64_t q_pos_begin, int64_t q_pos_end, float* out_d, int32_t* out_i, int32_t* flags,
                                  int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
+/* Approximate IVF-style self search on the same cluster index (distance/faiss.py:331-349: nlist = n_clusters, nprobe):
+ * a workgroup scans its own clusters and then the nearest ones, nprobe scans in all; candidates are rescored exactly.
+ * out_d / out_i must be pre-filled by the caller (+inf / -1): rows with fewer than k candidates keep that tail. */
+int tdr_knn_ivf_f32(const float* x16, const float* X, int64_t ldx, const float* norms, int64_t n_img, int d, int k, int metric,
+                    int exclude_self, int tier, const uint32_t* meta, const int32_t* row_map, int n_clusters,
+                    const int32_t* tile_cluster, const int32_t* clus_tile_begin, const float* clus_radius, const float* clus_dist,
+                    const int32_t* clus_order, int nprobe, float* out_d, int32_t* out_i, int32_t* flags, int32_t* n_flagged,
+                    void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- K2 / K3: per-row root searches --------------------------------------------------------------
  * replace utils/root_search.py:17-77,147-198 driven by affinity/knn_normalized.py:445-465 (UMAP) and

@@ -176,6 +176,7 @@ struct ScreenParams {
     const float* clus_radius;       // (n_clusters) max member distance to the centre, rounded up
     const float* clus_dist;         // (n_clusters, n_clusters) centre distances, rounded down
     const int32_t* clus_order;      // (n_clusters, n_clusters) clusters by increasing centre distance (self first)
+    int max_visit;                  // approximate (IVF-style) search: clusters a workgroup may scan at most; 0 = exact
 };
 
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
@@ -672,14 +673,65 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
         float tau_wg = 0.f, band_wg = 0.f;
         int idx0 = 0;
         bool more = true;
+        // approximate mode (max_visit > 0, the IVF search of distance/faiss.py:331-349 on the cluster index): clusters are
+        // taken by increasing distance of their centre to the NEAREST of the wavefronts' own centres: the own clusters
+        // (distance 0) first, then max_visit - 1 others.  The candidates are the first max_visit entries of every wavefront's
+        // visiting order (their union contains the max_visit nearest by that key); "next" = the smallest (key, cluster)
+        // above the last one taken, so no visited set is kept.  Clusters the exact bound excludes are never taken.
+        int visited = 0;
+        unsigned long long prev = 0ull;  // (key bits << 32 | cluster) + 1 of the last cluster taken
         while (more) {
             int rb = t_begin, re = t_end;
             if (!pruned) {
                 more = false;
             } else {
-                wg_threshold(tau_wg, band_wg);  // thresholds only decrease: later tests get sharper
                 bool found = false;
-                while (idx0 < P.n_clusters) {
+                wg_threshold(tau_wg, band_wg);  // thresholds only decrease: later tests get sharper
+                if (P.max_visit > 0) {
+                    unsigned long long best = ~0ull;
+                    const int ncand = P.max_visit < P.n_clusters ? P.max_visit : P.n_clusters;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        if (cw[w] < 0) continue;
+                        for (int i = tid; i < ncand; i += 256) {
+                            const int c = P.clus_order[(size_t)cw[w] * P.n_clusters + i];
+                            const float rc = P.clus_radius[c];
+                            float key = __builtin_inff(), lb = __builtin_inff();
+#pragma unroll
+                            for (int w2 = 0; w2 < NW; ++w2) {
+                                if (cw[w2] < 0) continue;
+                                const float dc = P.clus_dist[(size_t)cw[w2] * P.n_clusters + c];
+                                key = fminf(key, dc);
+                                const float g = dc - P.clus_radius[cw[w2]] - rc;
+                                lb = fminf(lb, g > 0.f ? g * g : 0.f);
+                            }
+                            const unsigned long long kc = (((unsigned long long)__float_as_uint(fmaxf(key, 0.f)) << 32) | (uint32_t)c) + 1ull;
+                            if (kc > prev && kc < best && !(lb * 0.9999f - band_wg > tau_wg)) best = kc;
+                        }
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const unsigned long long other = __shfl_xor(best, o, 64);
+                        best = other < best ? other : best;
+                    }
+                    if (lane == 0) wmask[wave] = best;
+                    __syncthreads();
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) best = wmask[w] < best ? wmask[w] : best;
+                    __syncthreads();
+                    if (best == ~0ull) break;
+                    // the wavefronts' own clusters (key 0) are always scanned -- a query's own list is Faiss's nprobe = 1 --
+                    // and count as ONE scan together; max_visit - 1 further clusters follow
+                    const bool own_cluster = ((best - 1ull) >> 32) == 0ull;
+                    if (!own_cluster && visited >= P.max_visit - 1) break;
+                    if (own_cluster) --visited;  // undone below by the common increment
+                    prev = best;
+                    const int c = (int)(uint32_t)((best - 1ull) & 0xffffffffull);
+                    rb = P.clus_tile_begin[c];
+                    re = P.clus_tile_begin[c + 1];
+                    found = true;
+                }
+                while (!found && idx0 < P.n_clusters) {
                     // 256 clusters of the visiting order are tested at once, one per thread, against the current threshold
                     const int idx = idx0 + tid;
                     bool survive = false;
@@ -711,9 +763,9 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
                     re = P.clus_tile_begin[c + 1];
                     idx0 += first + 1;
                     found = true;
-                    break;
                 }
                 if (!found) break;
+                ++visited;
             }
             scan_range(rb, re);
         }
@@ -1115,6 +1167,7 @@ struct ClusterTables {
     const float* clus_radius;
     const float* clus_dist;
     const int32_t* clus_order;
+    int max_visit;
 };
 
 static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
@@ -1149,6 +1202,7 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     P.tile_cluster = ct ? ct->tile_cluster : nullptr; P.clus_tile_begin = ct ? ct->clus_tile_begin : nullptr;
     P.clus_radius = ct ? ct->clus_radius : nullptr; P.clus_dist = ct ? ct->clus_dist : nullptr;
     P.clus_order = ct ? ct->clus_order : nullptr;
+    P.max_visit = ct ? ct->max_visit : 0;
     const int64_t need = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
     if (ws_bytes < need) return TDR_ERR_WORKSPACE;
     const size_t lds = screen_lds_bytes(ks, L, cfg.qb, cfg.terms);
@@ -1212,9 +1266,28 @@ int tdr_knn_screen_clustered_f32(const float* x16, const float* X, int64_t ldx, 
         return TDR_ERR_BAD_ARG;
     if (n_img % TILE_ROWS != 0) return TDR_ERR_BAD_ARG;
     if (q_pos_begin < 0 || q_pos_end > n_img || (q_pos_end > q_pos_begin && q_pos_begin % 256 != 0)) return TDR_ERR_BAD_ARG;
-    ClusterTables ct = {n_clusters, row_map, tile_cluster, clus_tile_begin, clus_radius, clus_dist, clus_order};
+    ClusterTables ct = {n_clusters, row_map, tile_cluster, clus_tile_begin, clus_radius, clus_dist, clus_order, 0};
     return knn_screen_impl(x16, X, ldx, norms, n_img, 0, x16, X, ldx, norms, n_img, d, k, metric, exclude_self, tier, 0, meta,
                            out_d, out_i, flags, n_flagged, ws, ws_bytes, &ct, q_pos_begin, q_pos_end, stream);
+}
+
+/* Approximate (IVF-style) self search on the same cluster index: distance/faiss.py:331-349 (`IndexIVFFlat`, nlist =
+ * n_clusters, nprobe).  Same arguments as tdr_knn_screen_clustered_f32; a workgroup (128 consecutive rows of the sorted
+ * order) scans its wavefronts' own clusters (together they are probe 1) and then the nprobe - 1 clusters whose centres are
+ * nearest to ANY of those (clusters the exact search would skip by its bound are never taken).  Candidates are rescored exactly, so
+ * every returned distance is the reference's value for that pair; neighbours that live in unvisited clusters are missed.
+ * Rows with fewer than k candidates leave the tail of out_d / out_i as the caller initialised it (+inf / -1). */
+int tdr_knn_ivf_f32(const float* x16, const float* X, int64_t ldx, const float* norms, int64_t n_img, int d, int k, int metric,
+                    int exclude_self, int tier, const uint32_t* meta, const int32_t* row_map, int n_clusters,
+                    const int32_t* tile_cluster, const int32_t* clus_tile_begin, const float* clus_radius, const float* clus_dist,
+                    const int32_t* clus_order, int nprobe, float* out_d, int32_t* out_i, int32_t* flags, int32_t* n_flagged,
+                    void* ws, int64_t ws_bytes, void* stream) {
+    if (!row_map || !tile_cluster || !clus_tile_begin || !clus_radius || !clus_dist || !clus_order || n_clusters <= 0 || nprobe < 1)
+        return TDR_ERR_BAD_ARG;
+    if (n_img % TILE_ROWS != 0) return TDR_ERR_BAD_ARG;
+    ClusterTables ct = {n_clusters, row_map, tile_cluster, clus_tile_begin, clus_radius, clus_dist, clus_order, nprobe};
+    return knn_screen_impl(x16, X, ldx, norms, n_img, 0, x16, X, ldx, norms, n_img, d, k, metric, exclude_self, tier, 0, meta,
+                           out_d, out_i, flags, n_flagged, ws, ws_bytes, &ct, 0, 0, stream);
 }
 
 /* Farthest-point seeding: seeds[0..n_seeds) <- indices into the (S, d) sample Xs (seed 0 = row 0, each next seed the

@@ -6,3 +6,4 @@ from .base import (  # noqa: F401
     pairwise_distances,
     pairwise_distances_indexed,
 )
+from .faiss import FaissConfig  # noqa: F401

@@ -401,6 +401,62 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
     return bad
 
 
+def _ivf_request(backend, self_search, k, n, d, metric):
+    """(nlist, nprobe) when `backend` asks for an approximate index and the search is one the IVF kernel serves (full self
+    search with k, sqeuclidean / euclidean, D <= 256, k within the screening lists), else None -> the exact search, which
+    is a valid answer to any approximate request."""
+    if backend is None or not getattr(backend, "index_type", "Flat") in ("IVF", "IVFPQ"):
+        return None
+    if not self_search or k is None or k >= n or metric not in ("sqeuclidean", "euclidean"):
+        return None
+    if d > 256 or not _lib.lib().tdr_knn_screen_supported(d, int(k)) or n < 4096:
+        return None
+    nlist = max(1, min(int(getattr(backend, "nlist", 100)), n // 64, int(_lib.lib().tdr_cluster_maxmin_capacity())))
+    return nlist, max(1, min(int(getattr(backend, "nprobe", 1)), nlist))
+
+
+def _knn_ivf(Y: "PackedPoints", k: int, metric: str, exclude_self: bool, nlist: int, nprobe: int):
+    """Approximate self search (distance/faiss.py:331-349, ``IndexIVFFlat``): ``nlist`` clusters from the package's own
+    index builder, ``nprobe`` cluster scans per block of 128 queries of the cluster-sorted order (``tdr_knn_ivf_f32``).
+    Distances are exact for every returned pair; rows that find fewer than k candidates keep (+inf, -1) in the tail, as
+    Faiss returns them."""
+    L = _lib.lib()
+    dev, d = Y.device, Y.d
+    ops = _screen_operands(Y, Y)
+    tier = 1
+    if Y.n >= _SCREEN_PILOT_MIN_Q:
+        tier, _ = _choose_tier(Y, Y, ops, 0, k, metric, exclude_self, 0)
+        if tier < 0:   # data the screening stage cannot serve: exact one-stage search
+            return knn_packed(Y, Y, k, metric, exclude_self, _allow_screen=False)
+    cache = Y.__dict__.setdefault("_ivf_index", {})
+    ci = cache.get(nlist)
+    if ci is None:
+        ci = cache[nlist] = ClusterIndex(Y, n_clusters=nlist)
+    if ci.img16 is None:
+        ci.img16 = torch.empty(L.tdr_packed16_floats(ci.n_img, d), dtype=torch.float32, device=dev)
+        _lib.check(L.tdr_pack16_mapped_f32(_lib.ptr(Y.X), ci.n_img, d, Y.X.stride(0), _lib.ptr(Y.norms), _lib.ptr(ops[2]),
+                                           _lib.ptr(ci.row_map), _lib.ptr(ci.img16), _lib.stream_ptr()), "tdr_pack16_mapped_f32")
+    out_d = torch.full((Y.n, k), float("inf"), dtype=torch.float32, device=dev)
+    out_i = torch.full((Y.n, k), -1, dtype=torch.int32, device=dev)
+    ws_bytes = L.tdr_knn_screen_workspace_bytes(ci.n_img, ci.n_img, d, k, tier)
+    ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
+    flags = torch.zeros(Y.n, dtype=torch.int32, device=dev)
+    n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(
+        L.tdr_knn_ivf_f32(_lib.ptr(ci.img16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), ci.n_img, d, k, _METRIC_ID[metric],
+                          1 if exclude_self else 0, tier, _lib.ptr(ops[2]), _lib.ptr(ci.row_map), ci.n_clusters,
+                          _lib.ptr(ci.tile_cluster), _lib.ptr(ci.tile_begin), _lib.ptr(ci.radius), _lib.ptr(ci.dist), _lib.ptr(ci.order),
+                          int(nprobe), _lib.ptr(out_d), _lib.ptr(out_i), _lib.ptr(flags), _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes,
+                          _lib.stream_ptr()),
+        "tdr_knn_ivf_f32",
+    )
+    bad = int(n_flagged.item())
+    if bad:  # spare list slots overflowed: those rows are searched exactly
+        _screen_fallback(Y, Y, 0, k, metric, exclude_self, 0, flags.nonzero().squeeze(1), out_d, out_i)
+    LAST_KNN["path"], LAST_KNN["flagged"], LAST_KNN["tier"], LAST_KNN["pruned"] = f"ivf (nlist={ci.n_clusters}, nprobe={nprobe})", bad, tier, False
+    return out_d, out_i
+
+
 def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: bool, ctx: DistributedContext):
     """Row-sharded self search with cluster-bound pruning.  Pruning works on the cluster-sorted order, so every rank
     answers the queries of ONE CONTIGUOUS RANGE of that order (balanced, arbitrary source rows) and the rows are then
@@ -933,7 +989,11 @@ def pairwise_distances(
     if k is not None and k < n_cols:
         if do_exclude and k > n_cols - 1:
             raise ValueError("[TorchDR] ERROR : k must be smaller than the number of samples.")
-        C, I = knn_packed(Xp, Yp, int(k), metric, do_exclude)
+        ivf = _ivf_request(backend, self_search, k, n_cols, Xp.d, metric)
+        if ivf is not None:   # FaissConfig(index_type="IVF" / "IVFPQ"): approximate search on the cluster index
+            C, I = _knn_ivf(Yp, int(k), metric, do_exclude, *ivf)
+        else:
+            C, I = knn_packed(Xp, Yp, int(k), metric, do_exclude)
         return (C, I) if return_indices else C
 
     C = dense_packed(Xp, Yp, metric, do_exclude)
