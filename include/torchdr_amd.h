@@ -60,6 +60,8 @@ int tdr_pack_rows_wide_f32(const float* X, int64_t n, int d, int64_t ldx, float*
 int tdr_knn_wide_max_k(void);
 int tdr_knn_wide_f32(const float* qp, int64_t nq, int64_t q_offset, const float* yp, int64_t n_db, int d, int k, int metric,
                      int exclude_self, float* out_d, int32_t* out_i, void* ws, int64_t ws_bytes, void* stream);
+int tdr_dense_dist_wide_f32(const float* qp, int64_t nq, int64_t q_offset, const float* yp, int64_t n_db, int d, int metric,
+                            int exclude_self, float diag_add, float* out, int64_t ldo, void* stream);
 
 /* dense nq x n_db matrix (k=None path, distance/torch.py:91-116); diag_add (1e12) on C[i][q_offset+i]. */
 int tdr_dense_dist_packed_f32(const float* qp, int64_t nq, int64_t q_offset, const float* yp, int64_t n_db, int d,

@@ -167,6 +167,15 @@ def test_knn_general_feature_dimension(d, k, metric):
     assert float((I2.cpu() != Io2).any(1).float().mean()) < 0.02
     D = pairwise_distances(X[:200].cuda(), metric=metric, exclude_diag=True)
     assert D.shape == (200, 200) and float(D.diagonal().min()) > 1e11
+    # the dense form (wide tile kernel) against float64 arithmetic, and a ragged cross block
+    Xd, Yd = X[:333].double(), Y[:77].double()
+    Dc = pairwise_distances(X[:333].cuda(), Y[:77].cuda(), metric=metric).cpu().double()
+    if metric == "angular":
+        ref = -(Xd @ Yd.T)
+    else:
+        ref = torch.cdist(Xd, Yd) ** 2
+        ref = ref.sqrt() if metric == "euclidean" else ref
+    assert Dc.shape == (333, 77) and torch.allclose(Dc, ref, rtol=1e-4, atol=1e-3 * float(ref.abs().mean()))
     # the library-GEMM form of the same search (kept for comparison) agrees with the scan
     dbase.WIDE_SCAN = False
     try:

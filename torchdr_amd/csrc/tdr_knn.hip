@@ -824,6 +824,52 @@ __global__ __launch_bounds__(256) void pack_wide_kernel(const float* __restrict_
     }
 }
 
+// dense distance tiles for wide rows: dense_dist_kernel with a run-time number of 8-feature blocks
+__global__ __launch_bounds__(256, 2) void dense_wide_kernel(const float* __restrict__ qp, const float* __restrict__ yp, int64_t nq,
+                                                            int64_t q_offset, int64_t n_db, int kq, int metric, int exclude_self,
+                                                            float diag_add, float* __restrict__ out, int64_t ldo) {
+    const int64_t TILE_F = tile_stride_floats(kq);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane & 31, h = lane >> 5;
+    const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
+    if (qt >= (nq + 31) / 32) return;
+    const int64_t T = blockIdx.y;
+    const float* qimg = qp + (size_t)qt * TILE_F;
+    const float* img = yp + (size_t)T * TILE_F;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t0 = 0; t0 < kq; t0 += 4) {  // kq is a multiple of 4
+        f32x4 a[4], bq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const f32x4*>(img + (size_t)(t0 + u) * 256 + lane * 4);
+            bq[u] = *reinterpret_cast<const f32x4*>(qimg + (size_t)(t0 + u) * 256 + lane * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], bq[u][e], acc, 0, 0, 0);
+    }
+    const float xn = qimg[(size_t)kq * 256 + q];
+    const int64_t gq = qt * 32 + q;
+    if (gq >= nq) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int64_t j = T * 32 + i;
+        if (j >= n_db) continue;
+        float c;
+        if (metric == 2) c = -acc[r];
+        else {
+            c = __fsub_rn(__fadd_rn(xn, img[(size_t)kq * 256 + i]), __fmul_rn(2.0f, acc[r]));
+            if (metric == 1) c = sqrt_rn(fmaxf(c, 0.f));
+        }
+        if (exclude_self && j == gq + q_offset) c = __fadd_rn(c, diag_add);
+        out[(size_t)gq * ldo + j] = c;
+    }
+}
+
 template <int ITEMS>
 __global__ __launch_bounds__(256, 2) void knn_wide_kernel(const KnnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1248,6 +1294,22 @@ int tdr_knn_wide_f32(const float* qp, int64_t nq, int64_t q_offset, const float*
             TDR_CHECK_LAUNCH();
         }
     }
+    return TDR_OK;
+}
+
+/* Dense nq x n_db distance matrix from WIDE packed operands (D > 256; row stride ldo floats). */
+int tdr_dense_dist_wide_f32(const float* qp, int64_t nq, int64_t q_offset, const float* yp, int64_t n_db, int d, int metric,
+                            int exclude_self, float diag_add, float* out, int64_t ldo, void* stream) {
+    if (!qp || !yp || !out || nq <= 0 || n_db <= 0 || ldo < n_db) return TDR_ERR_BAD_ARG;
+    if (metric < 0 || metric > 2) return TDR_ERR_BAD_ARG;
+    const int kq = wide_kq(d);
+    if (kq == 0) return TDR_ERR_UNSUPPORTED;
+    const unsigned gx = (unsigned)(((nq + 31) / 32 + 3) / 4);
+    const unsigned gy = (unsigned)((n_db + 31) / 32);
+    if (gy > 65535u) return TDR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dense_wide_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, qp, yp, nq, q_offset, n_db, kq, metric,
+                       exclude_self, diag_add, out, ldo);
+    TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
 

@@ -828,12 +828,24 @@ def _l1_block(X, Y):
 
 
 def _dense_general(X, Y, metric, exclude_self):
-    """Dense distance matrix for D > 256 (distance/torch.py:82-116) with a library GEMM; manhattan: the L1 kernel."""
+    """Dense distance matrix outside the register-resident kernels (distance/torch.py:82-116): D > 256 on the wide tile
+    kernel, sqhyperbolic with a library GEMM, manhattan on the L1 kernel."""
     if metric == "manhattan":
         C = _l1_block(X, Y)
         if exclude_self:
             C.diagonal().add_(_DIAG_ADD)
         return C
+    if metric in ("sqeuclidean", "euclidean", "angular") and X.shape[1] > 256 and WIDE_SCAN and Y.shape[0] <= 65535 * 32:
+        # the wide tile images and one fp32-MFMA tile kernel (no library GEMM)
+        Yp = WidePackedPoints(Y)
+        Qp = Yp if X is Y else WidePackedPoints(X)
+        out = torch.empty((Qp.n, Yp.n), dtype=torch.float32, device=Yp.device)
+        _lib.check(
+            _lib.lib().tdr_dense_dist_wide_f32(_lib.ptr(Qp.data), Qp.n, 0, _lib.ptr(Yp.data), Yp.n, Yp.d, _METRIC_ID[metric],
+                                               1 if exclude_self else 0, _DIAG_ADD, _lib.ptr(out), out.stride(0), _lib.stream_ptr()),
+            "tdr_dense_dist_wide_f32",
+        )
+        return out
     G = torch.mm(X, Y.t())
     if metric == "sqhyperbolic":  # distance/torch.py:101-107
         xn, yn = (X * X).sum(1).contiguous(), (Y * Y).sum(1).contiguous()
