@@ -88,6 +88,7 @@ struct SchedBuildParams {
     int64_t n_rows;
     uint32_t slice_step;      // ceil((N - 1) / S): column j belongs to slice min(S - 1, j / slice_step)
     int t0, B, S;             // window = iterations t0 .. t0 + B - 1 (B <= 32), S slices
+    int stash;                // 1: keep the first chunks' (mask, column | slice << 29) in registers (needs N <= 2^29)
     const int* iter_base;     // optional device int added to t0 (graph replays: one captured window serves every window)
     const int64_t* blk_base;
     int32_t* list;
@@ -116,14 +117,16 @@ __device__ __forceinline__ uint32_t fire_mask(float& nx, float ep, int t0, int B
 
 // One workgroup = one schedule block (64 rows); a wavefront owns 16 rows and walks them 4 at a time with 16 lanes per
 // row.  Phase 1 counts the firings per (t, slice, row) in LDS, the counts are scanned into segment starts, phase 2
-// recomputes the masks (the 64 rows' edge state is ~25 KB, an L2 hit) and places every firing with a returning LDS
-// atomic on its segment's write pointer.  A row's counters are touched by one wavefront only, in program order, so the
+// places every firing with a returning LDS atomic on its segment's write pointer: from registers for the first 32
+// edges of a row (kept from phase 1), by recomputing the masks for the rest (the 64 rows' edge state is ~25 KB, an L2
+// hit).  A row's counters are touched by one wavefront only, in program order, so the
 // placement is a function of the input alone (same lists on every run); the order inside a segment is the order the
 // LDS unit serialises the lanes of one instruction in, which only permutes the terms of the force sum.
 // Rows are laid out by tdr_umap_sched_layout_f32 with their often-firing edges first: the per-lane loops run as many
 // times as the busiest lane of the wavefront fires, so homogeneous chunks matter.
 #define CNT_STRIDE 65  // odd stride: the 16 lanes of a row group hit different (t, slice) -> different banks
 
+template <int STASH>
 __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildParams P) {
     extern __shared__ uint32_t cnt[];  // [B * S][65]
     __shared__ uint32_t wave_tot[4];
@@ -136,6 +139,11 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
     for (int i = tid; i < K * CNT_STRIDE; i += 256) cnt[i] = 0;
     __syncthreads();
 
+    // (mask, column | slice) of the first STASH chunks of every row stay in registers for phase 2: the rows are laid out
+    // with their often-firing edges first, so these chunks carry most of the firings -- and most of the cost of
+    // advancing the counters, which phase 2 would otherwise repeat
+    uint32_t m_st[4 * STASH], cs_st[4 * STASH];
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int lr = 16 * w + 4 * q + gq;
         const int64_t r = rb * SCHED_RB + lr;
@@ -145,15 +153,18 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
         int maxlen = len;
         maxlen = max(maxlen, __shfl_xor(maxlen, 16, 64));
         maxlen = max(maxlen, __shfl_xor(maxlen, 32, 64));
-        for (int c = 0; c < maxlen; c += 16) {
+        auto count_chunk = [&](int c, uint32_t& m_out, uint32_t& cs_out, bool keep) {
             const bool valid = c + gl < len;
             const int64_t e = e0 + c + gl;
             float nx = valid ? P.next[e] : INF;
             const float ep = valid ? P.eps_per[e] : INF;
             const uint32_t col = valid ? (uint32_t)P.cols[e] : 0u;
             uint32_t m = fire_mask(nx, ep, t0, P.B);
+            if (keep && m) P.next[e] = nx;  // phase 2 does not visit this edge again
             uint32_t s = col / P.slice_step;
             if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
+            m_out = m;
+            cs_out = col | (s << 29);  // kept form only (stash = 1 requires column ids below 2^29)
             const int sbase = (int)s * CNT_STRIDE + lr;
             while (m) {  // four firings per round: the LDS operations of a round are independent
                 int tt[4];
@@ -164,6 +175,15 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
                 for (int u = 0; u < 4; ++u)
                     if (ok[u]) atomicAdd(&cnt[tt[u] * P.S * CNT_STRIDE + sbase], 1u);  // a count: order-independent
             }
+        };
+#pragma unroll
+        for (int ci = 0; ci < STASH; ++ci) {
+            m_st[q * STASH + ci] = 0u; cs_st[q * STASH + ci] = 0u;
+            if (16 * ci < maxlen) count_chunk(16 * ci, m_st[q * STASH + ci], cs_st[q * STASH + ci], P.stash != 0);
+        }
+        for (int c = 16 * STASH; c < maxlen; c += 16) {
+            uint32_t mm, cc;
+            count_chunk(c, mm, cc, false);
         }
     }
     __syncthreads();
@@ -212,6 +232,7 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
     if (total > capacity && tid == 0) atomicMax(P.err, 1);
     __syncthreads();
 
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int lr = 16 * w + 4 * q + gq;
         const int64_t r = rb * SCHED_RB + lr;
@@ -221,16 +242,7 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
         int maxlen = len;
         maxlen = max(maxlen, __shfl_xor(maxlen, 16, 64));
         maxlen = max(maxlen, __shfl_xor(maxlen, 32, 64));
-        for (int c = 0; c < maxlen; c += 16) {
-            const bool valid = c + gl < len;
-            const int64_t e = e0 + c + gl;
-            float nx = valid ? P.next[e] : INF;
-            const float ep = valid ? P.eps_per[e] : INF;
-            const uint32_t col = valid ? (uint32_t)P.cols[e] : 0u;
-            uint32_t m = fire_mask(nx, ep, t0, P.B);
-            if (m) P.next[e] = nx;
-            uint32_t s = col / P.slice_step;
-            if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
+        auto place = [&](uint32_t m, uint32_t col, uint32_t s) {
             const int sbase = (int)s * CNT_STRIDE + lr;
             while (m) {  // four firings per round: four returning LDS atomics in flight, then four stores
                 int tt[4];
@@ -244,6 +256,24 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
                 for (int u = 0; u < 4; ++u)
                     if (ok[u] && pos[u] < capacity) P.list[base + pos[u]] = (int32_t)col;
             }
+        };
+        int c_first = 0;
+        if (P.stash) {
+#pragma unroll
+            for (int ci = 0; ci < STASH; ++ci) place(m_st[q * STASH + ci], cs_st[q * STASH + ci] & 0x1fffffffu, cs_st[q * STASH + ci] >> 29);
+            c_first = 16 * STASH;
+        }
+        for (int c = c_first; c < maxlen; c += 16) {
+            const bool valid = c + gl < len;
+            const int64_t e = e0 + c + gl;
+            float nx = valid ? P.next[e] : INF;
+            const float ep = valid ? P.eps_per[e] : INF;
+            const uint32_t col = valid ? (uint32_t)P.cols[e] : 0u;
+            const uint32_t m = fire_mask(nx, ep, t0, P.B);
+            if (m) P.next[e] = nx;
+            uint32_t s = col / P.slice_step;
+            if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
+            place(m, col, s);
         }
     }
 }
@@ -494,6 +524,29 @@ static int launch_sched_grad_geom(const SchedGradParams& P, int geom, hipStream_
     }
 }
 
+// launch the schedule kernel (stash depth: chunks of 16 edges per row kept in registers between the two phases)
+static int launch_sched_build(const SchedBuildParams& P0, hipStream_t st, bool set_attr) {
+    SchedBuildParams P = P0;
+    const int64_t n_blocks = (P.n_rows + SCHED_RB - 1) / SCHED_RB;
+    const size_t lds = (size_t)P.B * P.S * CNT_STRIDE * sizeof(uint32_t);
+    // depth 2 measured best at N = 1M (2.02 ms per window; 0: 2.29, 1: 2.16, 3: 2.04 -- registers cost occupancy)
+    const int depth = P.stash ? 2 : 0;
+#define TDR_BUILD(D)                                                                                                  \
+    do {                                                                                                              \
+        if (set_attr && lds > 32 * 1024) {                                                                            \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_kernel<D>),            \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+            if (e != hipSuccess) return (int)e;                                                                       \
+        }                                                                                                             \
+        hipLaunchKernelGGL(umap_sched_build_kernel<D>, dim3((unsigned)n_blocks), dim3(256), lds, st, P);              \
+    } while (0)
+    if (depth == 0) TDR_BUILD(1);  // column ids beyond 2^29: the depth-1 instance with stash = 0 keeps nothing
+    else TDR_BUILD(2);
+#undef TDR_BUILD
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TDR_OK : (int)e;
+}
+
 // ---- the optimisation loop as one object ------------------------------------------------------------------------------
 // SGD step of the loop runner: torch.optim.SGD semantics (affinity_matcher.py:427) with the learning rate read from a
 // device table at the global iteration (device iteration base + offset), the NaN flag of check_NaNs (:315), and -- at
@@ -550,11 +603,11 @@ static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st) {
     Bp.rowptr = L->rowptr; Bp.cols = L->cols; Bp.eps_per = L->eps_per; Bp.next = L->next; Bp.n_rows = L->n_rows;
     const uint32_t nred = (uint32_t)(L->n_total - 1);
     Bp.slice_step = (nred + (uint32_t)L->S - 1u) / (uint32_t)L->S;
+    Bp.stash = L->n_total <= (1LL << 29) ? 1 : 0;
     Bp.t0 = 0; Bp.iter_base = L->iter_base; Bp.B = n; Bp.S = L->S; Bp.blk_base = L->blk_base; Bp.list = L->list; Bp.hdr = L->hdr;
     Bp.err = L->err;
-    const int64_t n_blocks = (L->n_rows + SCHED_RB - 1) / SCHED_RB;
-    const size_t lds = (size_t)n * L->S * CNT_STRIDE * sizeof(uint32_t);
-    hipLaunchKernelGGL(umap_sched_build_kernel, dim3((unsigned)n_blocks), dim3(256), lds, st, Bp);
+    const int rcb = launch_sched_build(Bp, st, false);
+    if (rcb != TDR_OK) return rcb;
     SchedGradParams G;
     G.Z = L->Z; G.n_total = L->n_total; G.row0 = L->row0; G.n_rows = L->n_rows; G.list = L->list; G.hdr = L->hdr; G.S = L->S;
     G.a = L->a; G.b = L->b; G.neg_rate = L->neg_rate; G.n_negatives = L->n_negatives; G.neg_inj = nullptr; G.seed = L->seed;
@@ -641,17 +694,9 @@ int tdr_umap_sched_build_f32(const int64_t* rowptr, const int32_t* cols, const f
     P.rowptr = rowptr; P.cols = cols; P.eps_per = eps_per; P.next = next; P.n_rows = n_rows;
     const uint32_t nred = (uint32_t)(n_total - 1);
     P.slice_step = (nred + (uint32_t)n_slices - 1u) / (uint32_t)n_slices;
+    P.stash = n_total <= (1LL << 29) ? 1 : 0;
     P.t0 = t0; P.iter_base = nullptr; P.B = n_iters; P.S = n_slices; P.blk_base = blk_base; P.list = list; P.hdr = (uint2*)hdr; P.err = err;
-    const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
-    const size_t lds = (size_t)n_iters * n_slices * CNT_STRIDE * sizeof(uint32_t);
-    if (lds > 32 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(umap_sched_build_kernel, dim3((unsigned)n_blocks), dim3(256), lds, (hipStream_t)stream, P);
-    TDR_CHECK_LAUNCH();
-    return TDR_OK;
+    return launch_sched_build(P, (hipStream_t)stream, true);
 }
 
 /* One evaluation of UMAP's closed-form gradient (umap.py:236-292) for rows [row0, row0 + n_rows) from the lists of
@@ -708,9 +753,12 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
     L->iter_base = (int*)d->scratch; L->gather = (tdr_collective_fn)d->gather; L->gather_ctx = d->gather_ctx; L->geom = d->geom;
     L->graphs[0] = L->graphs[1] = nullptr; L->graph_len[0] = L->graph_len[1] = 0;
     const size_t lds = (size_t)L->B * L->S * CNT_STRIDE * sizeof(uint32_t);
-    if (lds > 32 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_kernel),
+    if (lds > 32 * 1024) {  // raised here, outside graph capture, for every instance the launcher may pick
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_kernel<1>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_kernel<2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { delete L; return (int)e; }
     }
     *out = L;
