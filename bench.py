@@ -155,7 +155,7 @@ def main():
     distributed = init_from_env()
     rank = dist.get_rank() if distributed else 0
     world = dist.get_world_size() if distributed else 1
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -42,7 +42,7 @@ def init_from_env(backend: str = None) -> bool:
         # the collectives are then staged through host memory (parallel._host_staged)
         backend = os.environ.get("TDR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())  # more ranks than GPUs only in the gloo debugging mode
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group(backend=backend)
     return True
@@ -63,6 +63,7 @@ class DistributedContext:
             self.world_size = dist.get_world_size()
             self.local_rank = int(os.environ.get("LOCAL_RANK", 0))
             if torch.cuda.is_available():
+                self.local_rank %= torch.cuda.device_count()
                 torch.cuda.set_device(self.local_rank)
         else:
             self.rank = 0

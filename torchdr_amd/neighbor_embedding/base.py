@@ -136,6 +136,7 @@ class NeighborEmbedding(AffinityMatcher):
             self.is_multi_gpu = self.world_size > 1
             local_rank = int(os.environ.get("LOCAL_RANK", 0))
             if torch.cuda.is_available():
+                local_rank %= torch.cuda.device_count()  # more ranks than GPUs only in the gloo debugging mode
                 torch.cuda.set_device(local_rank)
             if self.device == "cpu":
                 raise ValueError("[TorchDR] Distributed mode requires GPU (device cannot be 'cpu')")
