@@ -136,7 +136,7 @@ def knn_variants(X, args, dbase):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--npoints", dest="n", type=int, default=1_000_000)
     ap.add_argument("--dim", dest="d", type=int, default=128)
