@@ -169,3 +169,47 @@ def test_two_rank_sharded_path_on_one_gpu():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world))
+
+
+def _worker_c4(rank, world, port, ret):
+    """BASELINE config C4's shape (D = 256, k = 30, rows sharded over 8 ranks) at a size one GPU can host 8 times."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torchdr_amd
+        from tests.conftest import gmm
+        from torchdr_amd.affinity import UMAPAffinity
+        from torchdr_amd.distributed import chunk_bounds
+
+        n = 8003   # 8003 = 8 * 1000 + 3: three ranks own one row more, no chunk starts on a multiple of 32
+        X = gmm(n, 256, 2.0, seed=44).cuda()
+        s, e = chunk_bounds(n, rank, world)
+        csr = UMAPAffinity(n_neighbors=30, max_iter=100)(X, return_csr=True)
+        ref = UMAPAffinity(n_neighbors=30, max_iter=100, distributed=False)(X, return_csr=True)
+        b0, b1 = int(ref.rowptr[s]), int(ref.rowptr[e])
+        assert csr.n == e - s and csr.row_offset == s
+        assert torch.equal(csr.rowptr + b0, ref.rowptr[s:e + 1]) and torch.equal(csr.cols, ref.cols[b0:b1])
+        assert torch.equal(csr.vals, ref.vals[b0:b1])
+        Zr = torchdr_amd.UMAP(n_neighbors=30, max_iter=60, random_state=0).fit_transform(X)
+        assert Zr.shape == (n, 2) and bool(torch.isfinite(Zr).all())
+        h = Zr.detach().cpu()
+        gathered = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(gathered, h)
+        assert all(torch.equal(gathered[0], g) for g in gathered[1:]), "ranks diverged"
+        Zs = torchdr_amd.UMAP(n_neighbors=30, max_iter=60, random_state=0, sharded_input=True).fit_transform(X[s:e].clone())
+        assert torch.equal(Zs, Zr)
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_sharded_umap_on_one_gpu():
+    """C4's parallel layout (8 row shards, uneven chunks) end to end: per-rank affinity rows equal the single-process
+    graph bit for bit, every rank ends with the same embedding, row-sharded input gives the same result."""
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_c4, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))
