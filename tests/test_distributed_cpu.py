@@ -230,3 +230,25 @@ def test_dataloader_streaming_host_logic():
                     (dict(k=5, backend="keops"), "only supports FAISS backend")]:
         with pytest.raises(ValueError, match=msg):
             pairwise_distances(dl, **kw)
+
+
+def test_faiss_config_and_approximate_search_routing():
+    """Host logic of the approximate search: `FaissConfig` mirrors the reference's constructor (distance/faiss.py:174-201),
+    and only a full self search with k that the IVF kernel serves is routed to it -- everything else is answered exactly."""
+    from torchdr_amd.distance import FaissConfig
+    from torchdr_amd.distance.base import _ivf_request
+
+    cfg = FaissConfig(index_type="IVF", nlist=256, nprobe=8, temp_memory=2.0, device=1, some_faiss_option=3)
+    assert cfg.approximate and cfg.nlist == 256 and cfg.nprobe == 8 and cfg.faiss_kwargs == {"some_faiss_option": 3}
+    assert "IVF" in repr(cfg) and not FaissConfig().approximate
+    with pytest.raises(ValueError):
+        FaissConfig(index_type="HNSW")
+    assert _ivf_request(cfg, True, 15, 50_000, 64, "sqeuclidean") == (256, 8)
+    assert _ivf_request(FaissConfig(index_type="IVFPQ", nlist=100000, nprobe=500000), True, 15, 50_000, 64, "euclidean") == (781, 781)
+    for args in ((None, True, 15, 50_000, 64, "sqeuclidean"), ("faiss", True, 15, 50_000, 64, "sqeuclidean"),
+                 (FaissConfig(), True, 15, 50_000, 64, "sqeuclidean"),      # Flat = exact
+                 (cfg, False, 15, 50_000, 64, "sqeuclidean"),               # cross search
+                 (cfg, True, None, 50_000, 64, "sqeuclidean"),              # dense form
+                 (cfg, True, 15, 50_000, 64, "angular"), (cfg, True, 15, 50_000, 300, "sqeuclidean"),
+                 (cfg, True, 15, 2000, 64, "sqeuclidean")):
+        assert _ivf_request(*args) is None, args
