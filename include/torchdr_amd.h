@@ -261,7 +261,9 @@ int tdr_umap_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t
  *   build: hdr = tdr_umap_sched_hdr_entries(...) 8-byte records {segment start, length | active count << 16} per
  *          (iteration, slice, row); err = device int (1: region overflow, 2: segment > 65535 / list > 2^32 entries)
  *   grad : t_local = n_iter - t0 of the last build; acc = (n_rows, 2 nc) floats when n_slices > 1; n_slices in
- *          {1, 2, 4, 8} (tdr_umap_sched_slices = automatic choice); geom = lanes per row (0 = default). */
+ *          {1, 2, 4, 8} (tdr_umap_sched_slices = automatic choice); geom: low 4 bits = lanes per row (0 = default), bit 4
+ *          (16) = all slices in ONE launch spread over the XCDs (workgroup b takes slice (b % 8) / (8 / n_slices)) plus a
+ *          combine kernel -- acc then holds n_slices planes of (n_rows, 2 nc) floats; same gradient bit for bit. */
 int tdr_umap_sched_slices(int64_t n_total, int nc);
 /* loop layout: every row's (cols, eps_per) reordered by ascending eps_per (often-firing edges first) */
 int tdr_umap_sched_layout_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, int64_t n_rows,

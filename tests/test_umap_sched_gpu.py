@@ -42,7 +42,7 @@ class Sched:
         self.list = torch.full((cap + 64,), -7, dtype=torch.int32, device="cuda")  # + slack read by idle lanes
         self.hdr = torch.zeros((int(self.L.tdr_umap_sched_hdr_entries(self.n_rows, B, S)), 2), dtype=torch.int32, device="cuda")
         self.err = torch.zeros(1, dtype=torch.int32, device="cuda")
-        self.acc = torch.empty((self.n_rows, 2 * nc), device="cuda")
+        self.acc = torch.empty((S * self.n_rows, 2 * nc), device="cuda")   # S planes: enough for the joint launch (geom & 16)
 
     def build(self, nxt, t0, n):
         _l = self.lib
@@ -268,6 +268,29 @@ def test_in_kernel_negatives_vs_oracle_fixture_graph(S, nc):
             for geom in (0, 1, 2, 3):
                 err = oracle_check(sc, Z, nb, tl, t0 + tl, a, b, 50, 1234567 + S, rows, geom=geom)
                 assert err < 1e-5, (S, nc, t0, tl, geom, err)
+
+
+@pytest.mark.parametrize("S", [2, 4, 8])
+@pytest.mark.parametrize("nc", [2, 3])
+def test_joint_slice_launch_is_bit_identical(S, nc):
+    """geom & 16: all slices in ONE launch (workgroup b takes slice (b % 8) / (8 / S), i.e. one slice per XCD group) plus
+    the combine kernel -- the same gradient, bit for bit, as one launch per slice (same partial sums, added in the same
+    order), for every lane geometry, with injected and with in-kernel negatives."""
+    n = 5000
+    rowptr, cols, vals = random_graph(n, seed=31 + S)
+    eps_per, nxt = prepare(vals.cuda(), 200)
+    sc = Sched(rowptr.cuda(), cols.cuda(), eps_per, n, 32, S, nc=nc)
+    sc.build(nxt, 0, 32)
+    gen = torch.Generator().manual_seed(5)
+    Z = (torch.randn(n, nc, generator=gen) * 3).cuda().contiguous()
+    neg = torch.randint(0, n - 1, (n, 40), generator=gen)
+    neg = (neg + (neg >= torch.arange(n)[:, None]).long()).cuda()
+    for tl in (0, 17):
+        for geom in (0, 1):
+            for inj in (None, neg):
+                a = sc.grad(Z, tl, tl, 1.577, 0.895, 40, neg=inj, seed=99, geom=geom)
+                b = sc.grad(Z, tl, tl, 1.577, 0.895, 40, neg=inj, seed=99, geom=geom | 16)
+                assert torch.equal(a, b), (S, nc, tl, geom, inj is None)
 
 
 def test_in_kernel_negatives_vs_oracle_large_and_wide():

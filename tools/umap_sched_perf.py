@@ -17,7 +17,7 @@ from torchdr_amd import _lib
 from torchdr_amd.affinity import UMAPAffinity
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-geoms = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,1,2,3").split(",")]
+geoms = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,1,2,3").split(",")]   # + 16: joint slice launch
 slices = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "2").split(",")]
 ITERS = int(os.environ.get("ITERS", "32"))
 X = gmm(n, 128, 2.0).cuda()

@@ -343,15 +343,21 @@ struct SchedGradParams {
     int n_levels;                   // log2(S)
     uint32_t lvl_xor[3];            // hash key modifier of the binomial split at each level (split_key)
     int lvl_upper[3];               // 1: this slice lies in the upper half at that level
+    // joint launch: ALL slices in one grid, workgroup b on XCD b % 8 (round-robin dispatch) takes slice (b % 8) / (8 / S),
+    // so every XCD's L2 still holds one slice; partial sums go to plane `slice` of acc and a combine kernel finishes
+    int joint;
+    uint32_t j_r_lo[8], j_r_len[8], j_lvl_xor[8][3];
+    int j_lvl_upper[8][3];
 };
 
 // this slice's share of the row's n_use negatives: exact binomial halving level by level (= slice_count(),
 // tdr_embed_common.h) with the hash words spread over the G lanes of the row group and a DPP reduction
 template <int G>
-__device__ __forceinline__ int pass_negative_count(const SchedGradParams& P, uint32_t rkey, int n_use, int gl) {
+__device__ __forceinline__ int pass_negative_count(int n_levels, const uint32_t (&lvl_xor)[3], const int (&lvl_upper)[3], uint32_t rkey,
+                                                   int n_use, int gl) {
     int mine = n_use;
-    for (int l = 0; l < P.n_levels; ++l) {
-        const uint32_t key = rkey ^ P.lvl_xor[l];
+    for (int l = 0; l < n_levels; ++l) {
+        const uint32_t key = rkey ^ lvl_xor[l];
         int m = 0;
         for (int t = gl; t * 32 < mine; t += G) {
             uint32_t w = mix32(key + 0x7F4A7C15u * (uint32_t)(t + 1));
@@ -360,7 +366,7 @@ __device__ __forceinline__ int pass_negative_count(const SchedGradParams& P, uin
             m += __popc(w);
         }
         m = group_sum_dpp<G>(m);
-        mine = P.lvl_upper[l] ? mine - m : m;
+        mine = lvl_upper[l] ? mine - m : m;
     }
     return mine;
 }
@@ -377,20 +383,32 @@ template <int NC, int G, bool INJ>
 __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradParams P) {
     constexpr int U = 4;
     const int gl = threadIdx.x % G;
-    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    int slice = P.slice;
+    int64_t blk = blockIdx.x;
+    uint32_t r_lo = P.r_lo, r_len = P.r_len, lvl_xor[3] = {P.lvl_xor[0], P.lvl_xor[1], P.lvl_xor[2]};
+    int lvl_upper[3] = {P.lvl_upper[0], P.lvl_upper[1], P.lvl_upper[2]};
+    if (P.joint) {
+        const int xcd = blockIdx.x & 7, per = 8 / P.S;
+        slice = xcd / per;
+        blk = (int64_t)(blockIdx.x >> 3) * per + (xcd % per);
+        r_lo = P.j_r_lo[slice]; r_len = P.j_r_len[slice];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) { lvl_xor[l] = P.j_lvl_xor[slice][l]; lvl_upper[l] = P.j_lvl_upper[slice][l]; }
+    }
+    const int64_t r = (blk * 256 + threadIdx.x) / G;
     if (r >= P.n_rows) return;
     const uint32_t gi = (uint32_t)(P.row0 + r);
     const Vec<NC> zi = load_z<NC>(P.Z, gi);
-    const uint2 h = P.hdr[(size_t)(P.t_local * P.S + P.slice) * P.n_rows + r];
+    const uint2 h = P.hdr[(size_t)(P.t_local * P.S + slice) * P.n_rows + r];
     const int32_t* lst = P.list + h.x;
     const int npos = (int)(h.y & 0xffffu);
     int n_use = (int)(h.y >> 16) * P.neg_rate;
     if (n_use > P.n_negatives) n_use = P.n_negatives;
     const uint32_t rkey = neg_row_key(P.seed, P.iter + (P.iter_base ? (uint32_t)*P.iter_base : 0u), (int64_t)gi);
     // injected negatives: every column is visited and the ones outside this slice are masked
-    int nneg = INJ ? n_use : pass_negative_count<G>(P, rkey, n_use, gl);
-    if (!INJ && P.r_len == 0u) nneg = 0;
-    const uint32_t ckey = rkey + 0x632BE5ABu * (uint32_t)(P.slice + 1) - (uint32_t)npos * 0x9E3779B9u;
+    int nneg = INJ ? n_use : pass_negative_count<G>(P.n_levels, lvl_xor, lvl_upper, rkey, n_use, gl);
+    if (!INJ && r_len == 0u) nneg = 0;
+    const uint32_t ckey = rkey + 0x632BE5ABu * (uint32_t)(slice + 1) - (uint32_t)npos * 0x9E3779B9u;
     const int total = npos + nneg;
     const float two_ab = 2.0f * P.a * P.b, m2b = -2.0f * P.b;
     float ga[NC], gr[NC];
@@ -421,12 +439,12 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
                     const uint32_t j = (uint32_t)P.neg_inj[(size_t)r * P.n_negatives + (i - npos)];
                     uint32_t sl = j / P.step;
                     if (sl > (uint32_t)(P.S - 1)) sl = (uint32_t)(P.S - 1);
-                    v[u] = sl == (uint32_t)P.slice;
+                    v[u] = sl == (uint32_t)slice;
                     jneg = j;
                 }
             } else {
                 const uint32_t x = mix32_item(ckey + (uint32_t)i * 0x9E3779B9u);  // column i - npos of this slice
-                const uint32_t rr = P.r_lo + __umulhi(x, P.r_len);
+                const uint32_t rr = r_lo + __umulhi(x, r_len);
                 jneg = rr + (rr >= gi ? 1u : 0u);
             }
             jn[u] = v[u] ? (isp[u] ? jl : jneg) : gi;
@@ -452,7 +470,15 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) { ga[c] = group_sum_dpp<G>(ga[c]); gr[c] = group_sum_dpp<G>(gr[c]); }
-    if (gl == 0) {
+    if (gl == 0 && P.joint) {  // this slice's partial sums; umap_sched_combine_kernel adds the planes in slice order
+        float* acc = P.acc + ((size_t)slice * P.n_rows + r) * 2 * NC;
+        if (NC == 2) {
+            *reinterpret_cast<float4*>(acc) = make_float4(ga[0], ga[1], gr[0], gr[1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { acc[c] = ga[c]; acc[NC + c] = gr[c]; }
+        }
+    } else if (gl == 0) {
         float* acc = P.acc + (size_t)r * 2 * NC;
         if (P.slice > 0) {
             if (NC == 2) {
@@ -482,6 +508,25 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
     }
 }
 
+// joint launch: gradient = exag * clamp(sum of the attraction planes) + rep * clamp(sum of the repulsion planes), the planes
+// added in slice order (the association of the per-slice launches: bit-identical results)
+template <int NC>
+__global__ __launch_bounds__(256) void umap_sched_combine_kernel(const float* __restrict__ acc, int S, int64_t n_rows, float exag,
+                                                                 float rep, float* __restrict__ grad) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    float ga[NC], gr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { ga[c] = acc[(size_t)r * 2 * NC + c]; gr[c] = acc[(size_t)r * 2 * NC + NC + c]; }
+    for (int s = 1; s < S; ++s) {
+        const float* a = acc + ((size_t)s * n_rows + r) * 2 * NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { ga[c] = a[c] + ga[c]; gr[c] = a[NC + c] + gr[c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) grad[(size_t)r * NC + c] = exag * fminf(fmaxf(ga[c], -4.f), 4.f) + rep * fminf(fmaxf(gr[c], -4.f), 4.f);
+}
+
 // host side of the per-pass constants (must mirror slice_count / slice_negative of tdr_embed_common.h)
 static void sched_pass_constants(SchedGradParams& P, int slice) {
     const uint32_t nred = (uint32_t)(P.n_total - 1);
@@ -505,7 +550,9 @@ static void sched_pass_constants(SchedGradParams& P, int slice) {
 template <int NC, int G>
 static int launch_sched_grad(const SchedGradParams& P, hipStream_t st) {
     const int rpb = 256 / G;
-    const dim3 grid((unsigned)((P.n_rows + rpb - 1) / rpb));
+    int64_t blocks = (P.n_rows + rpb - 1) / rpb;
+    if (P.joint) { const int per = 8 / P.S; blocks = ((blocks + per - 1) / per) * 8; }
+    const dim3 grid((unsigned)blocks);
     if (P.neg_inj) hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, true>), grid, dim3(256), 0, st, P);
     else hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, false>), grid, dim3(256), 0, st, P);
     hipError_t e = hipGetLastError();
@@ -545,6 +592,33 @@ static int launch_sched_build(const SchedBuildParams& P0, hipStream_t st, bool s
 #undef TDR_BUILD
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TDR_OK : (int)e;
+}
+
+// all slice passes of one evaluation: one launch per slice (geom < 16), or -- geom & 16, S > 1 -- ONE joint launch with the
+// slices spread over the XCDs and a combine kernel; acc must then hold S planes of (n_rows, 2 nc) floats
+template <int NC>
+static int launch_sched_grad_all(SchedGradParams& P, int geom, hipStream_t st) {
+    P.joint = 0;
+    if ((geom & 16) && P.S > 1) {
+        for (int s = 0; s < P.S; ++s) {
+            sched_pass_constants(P, s);
+            P.j_r_lo[s] = P.r_lo; P.j_r_len[s] = P.r_len;
+            for (int l = 0; l < 3; ++l) { P.j_lvl_xor[s][l] = P.lvl_xor[l]; P.j_lvl_upper[s][l] = P.lvl_upper[l]; }
+        }
+        P.joint = 1;
+        const int rc = launch_sched_grad_geom<NC>(P, geom & 15, st);
+        if (rc != TDR_OK) return rc;
+        hipLaunchKernelGGL(umap_sched_combine_kernel<NC>, dim3((unsigned)((P.n_rows + 255) / 256)), dim3(256), 0, st, (const float*)P.acc,
+                           P.S, P.n_rows, P.exag, P.rep, P.grad);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? TDR_OK : (int)e;
+    }
+    for (int s = 0; s < P.S; ++s) {
+        sched_pass_constants(P, s);
+        const int rc = launch_sched_grad_geom<NC>(P, geom & 15, st);
+        if (rc != TDR_OK) return rc;
+    }
+    return TDR_OK;
 }
 
 // ---- the optimisation loop as one object ------------------------------------------------------------------------------
@@ -615,11 +689,8 @@ static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st) {
     const int64_t n_el = L->n_rows * L->nc;
     for (int t = 0; t < n; ++t) {
         G.t_local = t; G.iter = (uint32_t)t;
-        for (int s = 0; s < L->S; ++s) {
-            sched_pass_constants(G, s);
-            const int rc = (L->nc == 2) ? launch_sched_grad_geom<2>(G, L->geom, st) : launch_sched_grad_geom<3>(G, L->geom, st);
-            if (rc != TDR_OK) return rc;
-        }
+        const int rcg = (L->nc == 2) ? launch_sched_grad_all<2>(G, L->geom, st) : launch_sched_grad_all<3>(G, L->geom, st);
+        if (rcg != TDR_OK) return rcg;
         hipLaunchKernelGGL(sgd_table_step_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st,
                            L->Z + L->row0 * L->nc, (const float*)L->grad, L->mom_buf, n_el, L->lr_table, (const int*)L->iter_base, t,
                            L->momentum, L->first_iter, L->check_interval, L->norm2, L->snap, L->nan_flag);
@@ -701,7 +772,9 @@ int tdr_umap_sched_build_f32(const int64_t* rowptr, const int32_t* cols, const f
 
 /* One evaluation of UMAP's closed-form gradient (umap.py:236-292) for rows [row0, row0 + n_rows) from the lists of
  * tdr_umap_sched_build_f32: t_local = iteration index inside the window, n_iter = global iteration (hash counter).
- * acc: (n_rows, 2 nc) floats (used when n_slices > 1).  geom: 0 = default lane geometry (tuning / ablation knob). */
+ * acc: (n_rows, 2 nc) floats (used when n_slices > 1).  geom: low 4 bits = lane geometry (0 = default; tuning knob);
+ * bit 4 (16) = all slices in ONE launch spread over the XCDs + a combine kernel: acc then holds n_slices planes of
+ * (n_rows, 2 nc) floats. */
 int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list,
                             const void* hdr, int t_local, int n_slices, float a, float b, int n_iter, int neg_rate,
                             int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep, float eps,
@@ -717,12 +790,7 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
     P.neg_inj = neg_inj; P.seed = seed; P.iter = (uint32_t)n_iter; P.iter_base = nullptr; P.exag = exag; P.rep = rep; P.eps = eps; P.grad = grad;
     P.acc = acc;
     hipStream_t st = (hipStream_t)stream;
-    for (int s = 0; s < n_slices; ++s) {
-        sched_pass_constants(P, s);
-        const int rc = (nc == 2) ? launch_sched_grad_geom<2>(P, geom, st) : launch_sched_grad_geom<3>(P, geom, st);
-        if (rc != TDR_OK) return rc;
-    }
-    return TDR_OK;
+    return (nc == 2) ? launch_sched_grad_all<2>(P, geom, st) : launch_sched_grad_all<3>(P, geom, st);
 }
 
 /* ---- the whole optimisation loop behind one handle -------------------------------------------------------------------

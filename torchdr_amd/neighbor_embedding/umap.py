@@ -19,8 +19,9 @@ PROFILE_EVERY = 25
 
 # scheduled loop (csrc/tdr_umap_sched.hip): the epoch counters are advanced SCHED_BLOCK_ITERS iterations at a time and
 # the gradient kernel reads per-iteration lists of the edges that fire.  SCHEDULED = False selects the per-step kernel
-# (tdr_umap_grad_f32), which streams every edge's counter each iteration; SCHED_GEOM is the lane-geometry knob of the
-# gradient kernel (tools/umap_perf.py), SCHED_SLICES overrides the automatic number of L2 slices of the embedding.
+# (tdr_umap_grad_f32), which streams every edge's counter each iteration; SCHED_GEOM: low 4 bits = lane geometry of the
+# gradient kernel (tools/umap_sched_perf.py), bit 4 = all L2 slices in ONE launch spread over the XCDs (0.295 vs 0.304 ms per
+# iteration at N = 1M, bit-identical gradients); SCHED_SLICES overrides the automatic number of L2 slices of the embedding.
 SCHEDULED = True
 # LOOP_RUNNER: run the whole optimisation loop through tdr_umap_loop_* (one ctypes call per window of <= 32 iterations,
 # windows replayed as HIP graphs when LOOP_GRAPH) when the estimator's step is the stock one (no overridden hooks, no
@@ -34,7 +35,7 @@ LOOP_GRAPH = True
 # bench.py sets this to a list to collect (start_event, end_event, n_iterations) per loop-runner segment
 LOOP_PROFILE = None
 SCHED_BLOCK_ITERS = 32
-SCHED_GEOM = 0
+SCHED_GEOM = 16
 SCHED_SLICES = 0
 
 
@@ -166,7 +167,8 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             "list": torch.empty(cap + 64, dtype=torch.int32, device=dev),  # slack: idle lanes read entry 0 of a segment
             "hdr": torch.empty(2 * int(L.tdr_umap_sched_hdr_entries(n_rows, B, S)), dtype=torch.int32, device=dev),
             "err": torch.zeros(1, dtype=torch.int32, device=dev),
-            "acc": torch.empty((n_rows, 2 * nc), dtype=torch.float32, device=dev) if S > 1 else None,
+            # partial sums between the slice passes; the joint launch (SCHED_GEOM & 16) keeps one plane per slice
+            "acc": torch.empty(((S if int(SCHED_GEOM) & 16 else 1) * n_rows, 2 * nc), dtype=torch.float32, device=dev) if S > 1 else None,
         }
         return self._sched
 
