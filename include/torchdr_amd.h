@@ -263,7 +263,8 @@ int tdr_umap_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t
  *   grad : t_local = n_iter - t0 of the last build; acc = (n_rows, 2 nc) floats when n_slices > 1; n_slices in
  *          {1, 2, 4, 8} (tdr_umap_sched_slices = automatic choice); geom: low 4 bits = lanes per row (0 = default), bit 4
  *          (16) = all slices in ONE launch spread over the XCDs (workgroup b takes slice (b % 8) / (8 / n_slices)) plus a
- *          combine kernel -- acc then holds n_slices planes of (n_rows, 2 nc) floats; same gradient bit for bit. */
+ *          combine kernel -- acc then holds n_slices planes of (n_rows, 2 nc) floats; same gradient bit for bit; bit 5 (32):
+ *          see tdr_umap_sched_step_f32. */
 int tdr_umap_sched_slices(int64_t n_total, int nc);
 /* loop layout: every row's (cols, eps_per) reordered by ascending eps_per (often-firing edges first) */
 int tdr_umap_sched_layout_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, int64_t n_rows,
@@ -278,6 +279,11 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
                             const void* hdr, int t_local, int n_slices, float a, float b, int n_iter, int neg_rate,
                             int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep, float eps,
                             float* grad, float* acc, int geom, void* stream);
+/* geom & 32 (with 16): the joint launch leaves the per-slice planes in acc and this call finishes the iteration: combine
+ * (clamps of umap.py:262,290) -> grad (n_rows, nc), then the torch.optim.SGD(momentum) step of tdr_sgd_step_f32 on the rows
+ * Z (n_rows, nc), in one kernel with the same bits as the two. */
+int tdr_umap_sched_step_f32(const float* acc, int n_slices, int nc, int64_t n_rows, float exag, float rep, float* grad, float* Z,
+                            float* buf, float lr, float momentum, int first, int* nan_flag, int n_iter, void* stream);
 /* The optimisation loop of affinity_matcher.py:288-352 for UMAP's closed-form step + torch.optim.SGD behind one handle
  * (csrc/tdr_umap_sched.hip): windows of <= block_iters iterations (schedule build + per iteration n_slices gradient
  * passes + the SGD step [+ a row all-gather]) are captured into HIP graphs and replayed; the iteration base lives in

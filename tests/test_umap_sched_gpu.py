@@ -450,3 +450,26 @@ def test_loop_runner_equals_the_call_by_call_sequence(use_graph):
     assert int(sc2.err.item()) == 0 and int(flag2.item()) == 0
     # argument errors
     assert L.tdr_umap_loop_run(None, 0, 1, 0, None) == -1
+
+
+@pytest.mark.parametrize("momentum", [0.0, 0.6])
+def test_fused_combine_and_sgd_step_changes_nothing(momentum):
+    """Stock estimator: the joint gradient launch leaves the per-slice planes and tdr_umap_sched_step_f32 combines them and
+    steps the rows in one kernel.  A subclass with an (empty) end-of-step hook takes the form with the separate combine
+    kernel and tdr_sgd_step_f32.  Same embedding bit for bit, with and without momentum, across two schedule windows."""
+    import torchdr_amd
+    from torchdr_amd.neighbor_embedding import umap as umod
+
+    n = 400_000          # two L2 slices at nc = 2 (the joint launch needs more than one)
+    X = gmm(n, 16, 3.0, seed=6).cuda()
+
+    class Hooked(torchdr_amd.UMAP):
+        def on_training_step_end(self):
+            super().on_training_step_end()
+
+    kw = dict(n_neighbors=10, max_iter=45, random_state=0, optimizer_kwargs={"momentum": momentum} if momentum else "auto")
+    m = torchdr_amd.UMAP(**kw)
+    Za = m.fit_transform(X)
+    Zb = Hooked(**kw).fit_transform(X)
+    assert int(umod._lib.lib().tdr_umap_sched_slices(n, 2)) == 2
+    assert torch.equal(Za, Zb) and bool(torch.isfinite(Za).all())

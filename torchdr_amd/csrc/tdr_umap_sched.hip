@@ -527,6 +527,41 @@ __global__ __launch_bounds__(256) void umap_sched_combine_kernel(const float* __
     for (int c = 0; c < NC; ++c) grad[(size_t)r * NC + c] = exag * fminf(fmaxf(ga[c], -4.f), 4.f) + rep * fminf(fmaxf(gr[c], -4.f), 4.f);
 }
 
+// combine + torch.optim.SGD step in one pass over the rows (same arithmetic as umap_sched_combine_kernel followed by
+// sgd_step_kernel of tdr_embed.hip): saves a launch and the round trip of the gradient through memory
+template <int NC>
+__global__ __launch_bounds__(256) void umap_sched_combine_sgd_kernel(const float* __restrict__ acc, int S, int64_t n_rows, float exag,
+                                                                     float rep, float* __restrict__ grad, float* __restrict__ Z,
+                                                                     float* __restrict__ buf, float lr, float momentum, int first,
+                                                                     int* __restrict__ nan_flag, int iter) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_rows) return;
+    float ga[NC], gr[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { ga[c] = acc[(size_t)r * 2 * NC + c]; gr[c] = acc[(size_t)r * 2 * NC + NC + c]; }
+    for (int s = 1; s < S; ++s) {
+        const float* a = acc + ((size_t)s * n_rows + r) * 2 * NC;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { ga[c] = a[c] + ga[c]; gr[c] = a[NC + c] + gr[c]; }
+    }
+    bool nan = false;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int64_t i = r * NC + c;
+        float g = exag * fminf(fmaxf(ga[c], -4.f), 4.f) + rep * fminf(fmaxf(gr[c], -4.f), 4.f);
+        grad[i] = g;
+        if (momentum != 0.f) {
+            const float bprev = first ? 0.f : buf[i];
+            g = first ? g : __fadd_rn(__fmul_rn(bprev, momentum), g);
+            buf[i] = g;
+        }
+        const float z = fmaf(-lr, g, Z[i]);
+        Z[i] = z;
+        nan = nan || z != z;
+    }
+    if (nan) atomicCAS(nan_flag, 0, iter + 1);
+}
+
 // host side of the per-pass constants (must mirror slice_count / slice_negative of tdr_embed_common.h)
 static void sched_pass_constants(SchedGradParams& P, int slice) {
     const uint32_t nred = (uint32_t)(P.n_total - 1);
@@ -608,6 +643,7 @@ static int launch_sched_grad_all(SchedGradParams& P, int geom, hipStream_t st) {
         P.joint = 1;
         const int rc = launch_sched_grad_geom<NC>(P, geom & 15, st);
         if (rc != TDR_OK) return rc;
+        if (geom & 32) return TDR_OK;  // the caller finishes with tdr_umap_sched_step_f32 (combine + SGD step)
         hipLaunchKernelGGL(umap_sched_combine_kernel<NC>, dim3((unsigned)((P.n_rows + 255) / 256)), dim3(256), 0, st, (const float*)P.acc,
                            P.S, P.n_rows, P.exag, P.rep, P.grad);
         hipError_t e = hipGetLastError();
@@ -774,7 +810,7 @@ int tdr_umap_sched_build_f32(const int64_t* rowptr, const int32_t* cols, const f
  * tdr_umap_sched_build_f32: t_local = iteration index inside the window, n_iter = global iteration (hash counter).
  * acc: (n_rows, 2 nc) floats (used when n_slices > 1).  geom: low 4 bits = lane geometry (0 = default; tuning knob);
  * bit 4 (16) = all slices in ONE launch spread over the XCDs + a combine kernel: acc then holds n_slices planes of
- * (n_rows, 2 nc) floats. */
+ * (n_rows, 2 nc) floats; bit 5 (32, with bit 4) = leave the planes in acc: tdr_umap_sched_step_f32 combines and steps. */
 int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list,
                             const void* hdr, int t_local, int n_slices, float a, float b, int n_iter, int neg_rate,
                             int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep, float eps,
@@ -791,6 +827,24 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
     P.acc = acc;
     hipStream_t st = (hipStream_t)stream;
     return (nc == 2) ? launch_sched_grad_all<2>(P, geom, st) : launch_sched_grad_all<3>(P, geom, st);
+}
+
+/* Finish a joint evaluation (tdr_umap_sched_grad_f32 with geom & 48 == 48): gradient = exag * clamp(attraction) + rep *
+ * clamp(repulsion) from the n_slices planes of acc (umap.py:262,290), written to grad (n_rows, nc), then the
+ * torch.optim.SGD(momentum) step of tdr_sgd_step_f32 on the rows Z (n_rows, nc) -- one kernel, same bits as the two. */
+int tdr_umap_sched_step_f32(const float* acc, int n_slices, int nc, int64_t n_rows, float exag, float rep, float* grad, float* Z,
+                            float* buf, float lr, float momentum, int first, int* nan_flag, int n_iter, void* stream) {
+    if (!acc || !grad || !Z || !nan_flag || n_rows <= 0) return TDR_ERR_BAD_ARG;
+    if (n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
+    if (momentum != 0.f && !buf) return TDR_ERR_BAD_ARG;
+    if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)((n_rows + 255) / 256));
+    if (nc == 2) hipLaunchKernelGGL(umap_sched_combine_sgd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, acc, n_slices, n_rows, exag, rep,
+                                    grad, Z, buf, lr, momentum, first, nan_flag, n_iter);
+    else hipLaunchKernelGGL(umap_sched_combine_sgd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, acc, n_slices, n_rows, exag, rep, grad,
+                            Z, buf, lr, momentum, first, nan_flag, n_iter);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
 }
 
 /* ---- the whole optimisation loop behind one handle -------------------------------------------------------------------

@@ -195,18 +195,52 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         if prof:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
+        geom = int(SCHED_GEOM)
+        # joint launch + stock fused-SGD step: the gradient kernel leaves the per-slice planes and ONE kernel combines
+        # them and steps the rows (`_sgd_kernel` below); anything that looks at the gradient in between keeps the form
+        # with its own combine kernel
+        self._sched_deferred = bool((geom & 16) and sc["S"] > 1 and self._fused_sgd and self._stock_step())
+        if self._sched_deferred:
+            geom |= 32
         _lib.check(
             L.tdr_umap_sched_grad_f32(
                 _lib.ptr(self.embedding_), self.n_components, self.n_samples_in_, self.chunk_start_, self.chunk_size_,
                 _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), t - sc["t0"], sc["S"], float(self._a), float(self._b), t, int(self.negative_sample_rate), int(self.n_negatives),
                 _lib.ptr(neg), self._neg_seed, float(self.early_exaggeration_coeff_), float(self.repulsion_strength),
-                float(self._eps), _lib.ptr(grad), _lib.ptr(sc["acc"]), int(SCHED_GEOM), _lib.stream_ptr(),
+                float(self._eps), _lib.ptr(grad), _lib.ptr(sc["acc"]), geom, _lib.stream_ptr(),
             ),
             "tdr_umap_sched_grad_f32",
         )
         if prof:
             ev1.record()
             PROFILE.append(("grad", ev0, ev1, csr.nnz))
+
+    def _stock_step(self) -> bool:
+        """Nothing between the gradient evaluation and the optimizer step is overridden (hooks, step, gradient)."""
+        from torchdr_amd.affinity_matcher import AffinityMatcher
+        from torchdr_amd.neighbor_embedding.base import NeighborEmbedding
+
+        cls = type(self)
+        stock = (("on_training_step_end", NeighborEmbedding), ("_training_step", AffinityMatcher), ("_optimizer_step", AffinityMatcher),
+                 ("_sgd_kernel", UMAP), ("_compute_gradients", UMAP), ("_compute_gradients_scheduled", UMAP))
+        return all(getattr(cls, name) is getattr(owner, name) for name, owner in stock)
+
+    def _sgd_kernel(self, Z, grad, chunk=False):
+        if not getattr(self, "_sched_deferred", False):
+            return super()._sgd_kernel(Z, grad, chunk=chunk)
+        self._sched_deferred = False
+        sc = self._sched
+        mom = float(self._sgd_momentum)
+        first = 0
+        if mom != 0.0 and self._momentum_buf is None:
+            self._momentum_buf, first = torch.empty_like(Z), 1
+        _lib.check(
+            _lib.lib().tdr_umap_sched_step_f32(_lib.ptr(sc["acc"]), sc["S"], self.n_components, self.chunk_size_,
+                                               float(self.early_exaggeration_coeff_), float(self.repulsion_strength), _lib.ptr(grad),
+                                               _lib.ptr(Z), _lib.ptr(self._momentum_buf), self._current_lr(), mom, first,
+                                               _lib.ptr(self._nan_flag), int(self.n_iter_), _lib.stream_ptr()),
+            "tdr_umap_sched_step_f32",
+        )
 
     # ---- whole-loop runner ---------------------------------------------------------------------------------------------
     def _loop_runner_eligible(self) -> bool:
@@ -224,7 +258,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         cls = type(self)
         stock = (
             ("on_training_step_start", NegativeSamplingNeighborEmbedding), ("on_training_step_end", NeighborEmbedding),
-            ("_training_step", AffinityMatcher), ("_optimizer_step", AffinityMatcher), ("_sgd_kernel", AffinityMatcher),
+            ("_training_step", AffinityMatcher), ("_optimizer_step", AffinityMatcher), ("_sgd_kernel", UMAP),
             ("_compute_gradients", UMAP), ("_compute_gradients_scheduled", UMAP), ("_grad_norm", AffinityMatcher),
         )
         return all(getattr(cls, name) is getattr(owner, name) for name, owner in stock)
