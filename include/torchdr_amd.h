@@ -129,11 +129,6 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
                        int metric, int exclude_self, int tier, int predict_unsplit, const uint32_t* meta, float* out_d,
                        int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
 
-/* farthest-point (max-min) seeding of the coarse clustering behind the pruned search (library GEMMs do the Lloyd
- * steps and the assignment, torchdr_amd/distance/base.py:ClusterIndex) */
-int64_t tdr_maxmin_workspace_bytes(int64_t S, int n_seeds);
-int tdr_maxmin_seeds_f32(const float* Xs, int64_t S, int d, int64_t ld, int n_seeds, int32_t* seeds, void* ws,
-                         int64_t ws_bytes, void* stream);
 /* Coarse cluster index of the pruned self search, built with the package's own kernels (csrc/tdr_cluster.hip; the
  * search result never depends on it, only the number of skipped tiles does): stratified sample, farthest-point seeding
  * of C clusters by ONE workgroup on the sample's exact distance matrix (tdr_dense_dist_packed_f32), Lloyd updates

@@ -913,63 +913,6 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Farthest-point (max-min) seeding for the cluster index: step s adds the sample point farthest from the seeds chosen
-// so far.  One launch per step: distance of every sample point to the newest seed, running minimum, arg-max through
-// a 64-bit atomicMax on (distance bits, index) -- deterministic.  best[s] holds the winner of step s - 1.
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxmin_step_kernel(const float* __restrict__ Xs, int64_t S, int d, int64_t ld,
-                                                          const unsigned long long* __restrict__ best_prev,
-                                                          float* __restrict__ mind, unsigned long long* __restrict__ best_next,
-                                                          int32_t* __restrict__ seeds, int step) {
-    extern __shared__ __attribute__((aligned(16))) float cur_row[];
-    const int64_t cur = (step == 0) ? 0 : (int64_t)(*best_prev & 0xffffffffull);
-    if (blockIdx.x == 0 && threadIdx.x == 0) seeds[step] = (int32_t)cur;
-    for (int c = threadIdx.x; c < d; c += 256) cur_row[c] = Xs[(size_t)cur * ld + c];
-    __syncthreads();
-    const int gl = threadIdx.x & 15;                                   // 16 lanes per sample row
-    const bool vec4 = (d & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)Xs & 15) == 0;
-    unsigned long long key = 0ull;
-    // a few hundred workgroups stride over the rows: one atomic per wavefront and step stays cheap
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; i < S; i += (int64_t)gridDim.x * 16) {
-        float acc = 0.f;
-        const float* xr = Xs + (size_t)i * ld;
-        if (vec4) {  // 16-byte loads: lane gl covers features 4 gl .. 4 gl + 3 of every 64-wide block
-            for (int c = gl * 4; c < d; c += 64) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
-                const f32x4 w = *reinterpret_cast<const f32x4*>(cur_row + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float t = v[e] - w[e]; acc += t * t; }
-            }
-        } else {
-            for (int c = gl; c < d; c += 16) { const float t = xr[c] - cur_row[c]; acc += t * t; }
-        }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (gl == 0) {
-            const float m = fminf(step == 0 ? __builtin_inff() : mind[i], acc);
-            mind[i] = m;
-            const unsigned long long k2 = ((unsigned long long)__float_as_uint(m) << 32) | (unsigned long long)(uint32_t)i;
-            key = k2 > key ? k2 : key;  // m >= 0: its bits are monotone
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = ((unsigned long long)(uint32_t)__shfl_xor((int)(key >> 32), o, 64) << 32) |
-                                         (uint32_t)__shfl_xor((int)(key & 0xffffffffull), o, 64);
-        key = other > key ? other : key;
-    }
-    // one atomic per workgroup (the step is otherwise bound by the serialisation of the same-address atomics)
-    __shared__ unsigned long long wkey[4];
-    if ((threadIdx.x & 63) == 0) wkey[threadIdx.x >> 6] = key;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long m = wkey[0];
-        for (int w = 1; w < 4; ++w) m = wkey[w] > m ? wkey[w] : m;
-        if (m) atomicMax(best_next, m);
-    }
-}
-
 static inline int pick_ks(int d) {
     if (d <= 32) return 2;
     if (d <= 64) return 4;
@@ -1288,32 +1231,6 @@ int tdr_knn_ivf_f32(const float* x16, const float* X, int64_t ldx, const float* 
     ClusterTables ct = {n_clusters, row_map, tile_cluster, clus_tile_begin, clus_radius, clus_dist, clus_order, nprobe};
     return knn_screen_impl(x16, X, ldx, norms, n_img, 0, x16, X, ldx, norms, n_img, d, k, metric, exclude_self, tier, 0, meta,
                            out_d, out_i, flags, n_flagged, ws, ws_bytes, &ct, 0, 0, stream);
-}
-
-/* Farthest-point seeding: seeds[0..n_seeds) <- indices into the (S, d) sample Xs (seed 0 = row 0, each next seed the
- * row farthest from all previous ones).  ws: S floats + (n_seeds + 1) 64-bit words. */
-int64_t tdr_maxmin_workspace_bytes(int64_t S, int n_seeds) {
-    if (S <= 0 || n_seeds <= 0) return 0;
-    return ((S * (int64_t)sizeof(float) + 7) / 8) * 8 + (int64_t)(n_seeds + 1) * 8;
-}
-
-int tdr_maxmin_seeds_f32(const float* Xs, int64_t S, int d, int64_t ld, int n_seeds, int32_t* seeds, void* ws,
-                         int64_t ws_bytes, void* stream) {
-    if (!Xs || !seeds || !ws || S <= 0 || d <= 0 || ld < d || n_seeds <= 0 || n_seeds > S) return TDR_ERR_BAD_ARG;
-    if (ws_bytes < tdr_maxmin_workspace_bytes(S, n_seeds) || S > 0x7fffffffLL) return TDR_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    float* mind = (float*)ws;
-    unsigned long long* best = (unsigned long long*)((char*)ws + ((S * sizeof(float) + 7) / 8) * 8);
-    hipError_t e = hipMemsetAsync(best, 0, (size_t)(n_seeds + 1) * 8, st);
-    if (e != hipSuccess) return (int)e;
-    unsigned grid = (unsigned)((S * 16 + 255) / 256);
-    if (grid > 512) grid = 512;
-    for (int s = 0; s < n_seeds; ++s) {
-        hipLaunchKernelGGL(maxmin_step_kernel, dim3(grid), dim3(256), (size_t)d * sizeof(float), st, Xs, S, d, ld, best + s, mind,
-                           best + s + 1, seeds, s);
-    }
-    TDR_CHECK_LAUNCH();
-    return TDR_OK;
 }
 
 }  // extern "C"
