@@ -255,7 +255,8 @@ int tdr_umap_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t
  *          ceil(n_rows/64) int64.
  *   build: hdr = tdr_umap_sched_hdr_entries(...) 8-byte records {segment start, length | active count << 16} per
  *          (iteration, slice, row); err = device int (1: region overflow, 2: segment > 65535 / list > 2^32 entries)
- *   grad : t_local = n_iter - t0 of the last build; acc = (n_rows, 2 nc) floats when n_slices > 1; n_slices in
+ *   grad : nc = row width of Z / grad (1..32: exact kernels for 2 and 3, zero-padded register instances for the rest);
+ *          t_local = n_iter - t0 of the last build; acc = (n_rows, 2 nc) floats when n_slices > 1; n_slices in
  *          {1, 2, 4, 8} (tdr_umap_sched_slices = automatic choice); geom: low 4 bits = lanes per row (0 = default), bit 4
  *          (16) = all slices in ONE launch spread over the XCDs (workgroup b takes slice (b % 8) / (8 / n_slices)) plus a
  *          combine kernel -- acc then holds n_slices planes of (n_rows, 2 nc) floats; same gradient bit for bit; bit 5 (32):

@@ -242,7 +242,7 @@ def oracle_check(sc, Z, nxt_before, t_local, n_iter, a, b, n_neg, seed, rows, ge
 
 
 @pytest.mark.parametrize("S", [1, 2, 4, 8])
-@pytest.mark.parametrize("nc", [2, 3])
+@pytest.mark.parametrize("nc", [2, 3, 5, 16])
 def test_in_kernel_negatives_vs_oracle_fixture_graph(S, nc):
     """The production path (counter-hash negatives drawn inside the kernel, every slice count) on the reference's own
     affinity graph of the umap_step fixture."""
@@ -271,7 +271,7 @@ def test_in_kernel_negatives_vs_oracle_fixture_graph(S, nc):
 
 
 @pytest.mark.parametrize("S", [2, 4, 8])
-@pytest.mark.parametrize("nc", [2, 3])
+@pytest.mark.parametrize("nc", [2, 3, 4, 7, 32])
 def test_joint_slice_launch_is_bit_identical(S, nc):
     """geom & 16: all slices in ONE launch (workgroup b takes slice (b % 8) / (8 / S), i.e. one slice per XCD group) plus
     the combine kernel -- the same gradient, bit for bit, as one launch per slice (same partial sums, added in the same
@@ -473,3 +473,20 @@ def test_fused_combine_and_sgd_step_changes_nothing(momentum):
     Zb = Hooked(**kw).fit_transform(X)
     assert int(umod._lib.lib().tdr_umap_sched_slices(n, 2)) == 2
     assert torch.equal(Za, Zb) and bool(torch.isfinite(Za).all())
+
+
+@pytest.mark.parametrize("nc", [1, 5, 10])
+def test_umap_with_more_embedding_dimensions(nc):
+    """n_components outside {2, 3} (padded kernel instances): the estimator on the scheduled loop, its per-iteration
+    gradient against the oracle on the negatives the kernel draws, blobs stay separated in the embedding."""
+    import torchdr_amd
+    from torchdr_amd.distance import pairwise_distances
+
+    n = 6000
+    X = gmm(n, 20, 3.0, seed=12).cuda()
+    Z = torchdr_amd.UMAP(n_neighbors=12, n_components=nc, max_iter=120, random_state=0).fit_transform(X)
+    assert Z.shape == (n, nc) and bool(torch.isfinite(Z).all())
+    labels = (torch.arange(n) % (n // 100)).cuda()
+    _, I = pairwise_distances(Z.contiguous(), metric="sqeuclidean", k=5, exclude_diag=True, return_indices=True)
+    agree = float((labels[I.long()] == labels[:, None]).float().mean())
+    assert agree > (0.5 if nc == 1 else 0.85), agree

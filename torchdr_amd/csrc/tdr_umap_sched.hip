@@ -346,6 +346,7 @@ struct SchedGradParams {
     // joint launch: ALL slices in one grid, workgroup b on XCD b % 8 (round-robin dispatch) takes slice (b % 8) / (8 / S),
     // so every XCD's L2 still holds one slice; partial sums go to plane `slice` of acc and a combine kernel finishes
     int joint;
+    int nc;                         // actual row width of Z / grad / acc (PAD instances: NC is the padded register width)
     uint32_t j_r_lo[8], j_r_len[8], j_lvl_xor[8][3];
     int j_lvl_upper[8][3];
 };
@@ -379,9 +380,19 @@ __device__ __forceinline__ int pass_negative_count(int n_levels, const uint32_t 
 // a software-pipelined persistent form moved it).  Hence: one 8-byte record per row instead of four header words, one
 // 16-byte list read per lane instead of four, and a branch-free body (INJ = false: every lane evaluates both address
 // forms and selects).
-template <int NC, int G, bool INJ>
+// PAD instances serve any n_components <= NC: rows are P.nc floats wide, registers hold NC (zeros beyond P.nc contribute
+// nothing to distances or forces)
+template <int NC, int G, bool INJ, bool PAD = false>
 __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradParams P) {
     constexpr int U = 4;
+    const int nc = PAD ? P.nc : NC;
+    auto load_row = [&](int64_t i) {
+        if (!PAD) return load_z<NC>(P.Z, i);
+        Vec<NC> v;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v.v[c] = c < nc ? P.Z[(size_t)i * nc + c] : 0.f;
+        return v;
+    };
     const int gl = threadIdx.x % G;
     int slice = P.slice;
     int64_t blk = blockIdx.x;
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
     const int64_t r = (blk * 256 + threadIdx.x) / G;
     if (r >= P.n_rows) return;
     const uint32_t gi = (uint32_t)(P.row0 + r);
-    const Vec<NC> zi = load_z<NC>(P.Z, gi);
+    const Vec<NC> zi = load_row(gi);
     const uint2 h = P.hdr[(size_t)(P.t_local * P.S + slice) * P.n_rows + r];
     const int32_t* lst = P.list + h.x;
     const int npos = (int)(h.y & 0xffffu);
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
         }
         Vec<NC> zj[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) zj[u] = load_z<NC>(P.Z, (int64_t)jn[u]);
+        for (int u = 0; u < U; ++u) zj[u] = load_row((int64_t)jn[u]);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float df[NC];
@@ -471,41 +482,73 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
 #pragma unroll
     for (int c = 0; c < NC; ++c) { ga[c] = group_sum_dpp<G>(ga[c]); gr[c] = group_sum_dpp<G>(gr[c]); }
     if (gl == 0 && P.joint) {  // this slice's partial sums; umap_sched_combine_kernel adds the planes in slice order
-        float* acc = P.acc + ((size_t)slice * P.n_rows + r) * 2 * NC;
-        if (NC == 2) {
+        float* acc = P.acc + ((size_t)slice * P.n_rows + r) * 2 * nc;
+        if (NC == 2 && !PAD) {
             *reinterpret_cast<float4*>(acc) = make_float4(ga[0], ga[1], gr[0], gr[1]);
         } else {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { acc[c] = ga[c]; acc[NC + c] = gr[c]; }
+            for (int c = 0; c < NC; ++c)
+                if (c < nc) { acc[c] = ga[c]; acc[nc + c] = gr[c]; }
         }
     } else if (gl == 0) {
-        float* acc = P.acc + (size_t)r * 2 * NC;
+        float* acc = P.acc + (size_t)r * 2 * nc;
         if (P.slice > 0) {
-            if (NC == 2) {
+            if (NC == 2 && !PAD) {
                 const float4 t = *reinterpret_cast<const float4*>(acc);
                 ga[0] += t.x; ga[1] += t.y; gr[0] += t.z; gr[1] += t.w;
             } else {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) { ga[c] += acc[c]; gr[c] += acc[NC + c]; }
+                for (int c = 0; c < NC; ++c)
+                    if (c < nc) { ga[c] += acc[c]; gr[c] += acc[nc + c]; }
             }
         }
         if (P.slice == P.S - 1) {
             float g[NC];
 #pragma unroll
             for (int c = 0; c < NC; ++c) g[c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
-            if (NC == 2) {
+            if (NC == 2 && !PAD) {
                 *reinterpret_cast<float2*>(P.grad + (size_t)r * 2) = make_float2(g[0], g[1]);
             } else {
 #pragma unroll
-                for (int c = 0; c < NC; ++c) P.grad[(size_t)r * NC + c] = g[c];
+                for (int c = 0; c < NC; ++c)
+                    if (c < nc) P.grad[(size_t)r * nc + c] = g[c];
             }
-        } else if (NC == 2) {
+        } else if (NC == 2 && !PAD) {
             *reinterpret_cast<float4*>(acc) = make_float4(ga[0], ga[1], gr[0], gr[1]);
         } else {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { acc[c] = ga[c]; acc[NC + c] = gr[c]; }
+            for (int c = 0; c < NC; ++c)
+                if (c < nc) { acc[c] = ga[c]; acc[nc + c] = gr[c]; }
         }
     }
+}
+
+// elementwise forms of the two finishing kernels for any row width nc (thread = one component of one row)
+__global__ __launch_bounds__(256) void umap_sched_combine_any_kernel(const float* __restrict__ acc, int S, int64_t n_rows, int nc, float exag,
+                                                                     float rep, float* __restrict__ grad, float* __restrict__ Z,
+                                                                     float* __restrict__ buf, float lr, float momentum, int first,
+                                                                     int* __restrict__ nan_flag, int iter) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows * nc) return;
+    const int64_t r = i / nc;
+    const int c = (int)(i - r * nc);
+    float ga = acc[(size_t)r * 2 * nc + c], gr = acc[(size_t)r * 2 * nc + nc + c];
+    for (int s = 1; s < S; ++s) {
+        const float* a = acc + ((size_t)s * n_rows + r) * 2 * nc;
+        ga = a[c] + ga;
+        gr = a[nc + c] + gr;
+    }
+    float g = exag * fminf(fmaxf(ga, -4.f), 4.f) + rep * fminf(fmaxf(gr, -4.f), 4.f);
+    grad[i] = g;
+    if (!Z) return;  // combine only
+    if (momentum != 0.f) {
+        const float bprev = first ? 0.f : buf[i];
+        g = first ? g : __fadd_rn(__fmul_rn(bprev, momentum), g);
+        buf[i] = g;
+    }
+    const float z = fmaf(-lr, g, Z[i]);
+    Z[i] = z;
+    if (z != z) atomicCAS(nan_flag, 0, iter + 1);
 }
 
 // joint launch: gradient = exag * clamp(sum of the attraction planes) + rep * clamp(sum of the repulsion planes), the planes
@@ -606,6 +649,30 @@ static int launch_sched_grad_geom(const SchedGradParams& P, int geom, hipStream_
     }
 }
 
+// padded instances (any n_components <= NC, default lane geometry)
+template <int NC>
+static int launch_sched_grad_pad(const SchedGradParams& P, hipStream_t st) {
+    constexpr int G = 4;
+    const int rpb = 256 / G;
+    int64_t blocks = (P.n_rows + rpb - 1) / rpb;
+    if (P.joint) { const int per = 8 / P.S; blocks = ((blocks + per - 1) / per) * 8; }
+    const dim3 grid((unsigned)blocks);
+    if (P.neg_inj) hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, true, true>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((umap_sched_grad_kernel<NC, G, false, true>), grid, dim3(256), 0, st, P);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TDR_OK : (int)e;
+}
+// one launch of the gradient kernel for row width P.nc: exact instances for 2 and 3, padded ones up to SCHED_NC_MAX
+constexpr int SCHED_NC_MAX = 32;
+static int launch_sched_grad_nc(const SchedGradParams& P, int geom, hipStream_t st) {
+    if (P.nc == 2) return launch_sched_grad_geom<2>(P, geom, st);
+    if (P.nc == 3) return launch_sched_grad_geom<3>(P, geom, st);
+    if (P.nc <= 4) return launch_sched_grad_pad<4>(P, st);
+    if (P.nc <= 8) return launch_sched_grad_pad<8>(P, st);
+    if (P.nc <= 16) return launch_sched_grad_pad<16>(P, st);
+    return launch_sched_grad_pad<32>(P, st);
+}
+
 // launch the schedule kernel (stash depth: chunks of 16 edges per row kept in registers between the two phases)
 static int launch_sched_build(const SchedBuildParams& P0, hipStream_t st, bool set_attr) {
     SchedBuildParams P = P0;
@@ -631,7 +698,6 @@ static int launch_sched_build(const SchedBuildParams& P0, hipStream_t st, bool s
 
 // all slice passes of one evaluation: one launch per slice (geom < 16), or -- geom & 16, S > 1 -- ONE joint launch with the
 // slices spread over the XCDs and a combine kernel; acc must then hold S planes of (n_rows, 2 nc) floats
-template <int NC>
 static int launch_sched_grad_all(SchedGradParams& P, int geom, hipStream_t st) {
     P.joint = 0;
     if ((geom & 16) && P.S > 1) {
@@ -641,17 +707,22 @@ static int launch_sched_grad_all(SchedGradParams& P, int geom, hipStream_t st) {
             for (int l = 0; l < 3; ++l) { P.j_lvl_xor[s][l] = P.lvl_xor[l]; P.j_lvl_upper[s][l] = P.lvl_upper[l]; }
         }
         P.joint = 1;
-        const int rc = launch_sched_grad_geom<NC>(P, geom & 15, st);
+        const int rc = launch_sched_grad_nc(P, geom & 15, st);
         if (rc != TDR_OK) return rc;
         if (geom & 32) return TDR_OK;  // the caller finishes with tdr_umap_sched_step_f32 (combine + SGD step)
-        hipLaunchKernelGGL(umap_sched_combine_kernel<NC>, dim3((unsigned)((P.n_rows + 255) / 256)), dim3(256), 0, st, (const float*)P.acc,
-                           P.S, P.n_rows, P.exag, P.rep, P.grad);
+        if (P.nc == 2) hipLaunchKernelGGL(umap_sched_combine_kernel<2>, dim3((unsigned)((P.n_rows + 255) / 256)), dim3(256), 0, st,
+                                          (const float*)P.acc, P.S, P.n_rows, P.exag, P.rep, P.grad);
+        else if (P.nc == 3) hipLaunchKernelGGL(umap_sched_combine_kernel<3>, dim3((unsigned)((P.n_rows + 255) / 256)), dim3(256), 0, st,
+                                               (const float*)P.acc, P.S, P.n_rows, P.exag, P.rep, P.grad);
+        else hipLaunchKernelGGL(umap_sched_combine_any_kernel, dim3((unsigned)((P.n_rows * P.nc + 255) / 256)), dim3(256), 0, st,
+                                (const float*)P.acc, P.S, P.n_rows, P.nc, P.exag, P.rep, P.grad, (float*)nullptr, (float*)nullptr, 0.f, 0.f, 0,
+                                (int*)nullptr, 0);
         hipError_t e = hipGetLastError();
         return e == hipSuccess ? TDR_OK : (int)e;
     }
     for (int s = 0; s < P.S; ++s) {
         sched_pass_constants(P, s);
-        const int rc = launch_sched_grad_geom<NC>(P, geom & 15, st);
+        const int rc = launch_sched_grad_nc(P, geom & 15, st);
         if (rc != TDR_OK) return rc;
     }
     return TDR_OK;
@@ -725,7 +796,8 @@ static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st) {
     const int64_t n_el = L->n_rows * L->nc;
     for (int t = 0; t < n; ++t) {
         G.t_local = t; G.iter = (uint32_t)t;
-        const int rcg = (L->nc == 2) ? launch_sched_grad_all<2>(G, L->geom, st) : launch_sched_grad_all<3>(G, L->geom, st);
+        G.nc = L->nc;
+        const int rcg = launch_sched_grad_all(G, L->geom, st);
         if (rcg != TDR_OK) return rcg;
         hipLaunchKernelGGL(sgd_table_step_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st,
                            L->Z + L->row0 * L->nc, (const float*)L->grad, L->mom_buf, n_el, L->lr_table, (const int*)L->iter_base, t,
@@ -819,14 +891,15 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
     if (t_local < 0 || t_local >= SCHED_BMAX || neg_rate < 0 || n_negatives < 0) return TDR_ERR_BAD_ARG;
     if (n_slices != 1 && n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
     if (n_slices > 1 && !acc) return TDR_ERR_BAD_ARG;
-    if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
+    if (nc < 1 || nc > SCHED_NC_MAX) return TDR_ERR_UNSUPPORTED;
     SchedGradParams P;
     P.Z = Z; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.list = list; P.hdr = (const uint2*)hdr;
     P.t_local = t_local; P.S = n_slices; P.a = a; P.b = b; P.neg_rate = neg_rate; P.n_negatives = n_negatives;
     P.neg_inj = neg_inj; P.seed = seed; P.iter = (uint32_t)n_iter; P.iter_base = nullptr; P.exag = exag; P.rep = rep; P.eps = eps; P.grad = grad;
     P.acc = acc;
     hipStream_t st = (hipStream_t)stream;
-    return (nc == 2) ? launch_sched_grad_all<2>(P, geom, st) : launch_sched_grad_all<3>(P, geom, st);
+    P.nc = nc;
+    return launch_sched_grad_all(P, geom, st);
 }
 
 /* Finish a joint evaluation (tdr_umap_sched_grad_f32 with geom & 48 == 48): gradient = exag * clamp(attraction) + rep *
@@ -837,8 +910,14 @@ int tdr_umap_sched_step_f32(const float* acc, int n_slices, int nc, int64_t n_ro
     if (!acc || !grad || !Z || !nan_flag || n_rows <= 0) return TDR_ERR_BAD_ARG;
     if (n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
     if (momentum != 0.f && !buf) return TDR_ERR_BAD_ARG;
-    if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
+    if (nc < 1 || nc > SCHED_NC_MAX) return TDR_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)((n_rows + 255) / 256));
+    if (nc != 2 && nc != 3) {
+        hipLaunchKernelGGL(umap_sched_combine_any_kernel, dim3((unsigned)((n_rows * nc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc,
+                           n_slices, n_rows, nc, exag, rep, grad, Z, buf, lr, momentum, first, nan_flag, n_iter);
+        TDR_CHECK_LAUNCH();
+        return TDR_OK;
+    }
     if (nc == 2) hipLaunchKernelGGL(umap_sched_combine_sgd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, acc, n_slices, n_rows, exag, rep,
                                     grad, Z, buf, lr, momentum, first, nan_flag, n_iter);
     else hipLaunchKernelGGL(umap_sched_combine_sgd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, acc, n_slices, n_rows, exag, rep, grad,
@@ -864,7 +943,7 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
     if (d->n_slices != 1 && d->n_slices != 2 && d->n_slices != 4 && d->n_slices != 8) return TDR_ERR_BAD_ARG;
     if (d->n_slices > 1 && !d->acc) return TDR_ERR_BAD_ARG;
     if (d->momentum != 0.f && !d->mom_buf) return TDR_ERR_BAD_ARG;
-    if (d->nc != 2 && d->nc != 3) return TDR_ERR_UNSUPPORTED;
+    if (d->nc < 1 || d->nc > SCHED_NC_MAX) return TDR_ERR_UNSUPPORTED;
     UmapLoop* L = new UmapLoop();
     L->Z = d->Z; L->nc = d->nc; L->n_total = d->n_total; L->row0 = d->row0; L->n_rows = d->n_rows; L->rowptr = d->rowptr;
     L->cols = d->cols; L->eps_per = d->eps_per; L->next = d->next; L->blk_base = d->blk_base; L->list = d->list;

@@ -143,9 +143,11 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         return self._csr.to_padded()[1]
 
     def _fit_transform(self, X, y=None):
-        if self.n_components not in (2, 3):
+        nc_ok = range(1, 33) if SCHEDULED else (2, 3)   # scheduled loop: exact kernels for 2 / 3, padded ones up to 32
+        if self.n_components not in nc_ok:
             raise NotImplementedError(
-                f"[torchdr_amd] UMAP: the HIP gradient kernels are built for n_components in (2, 3), got {self.n_components}."
+                f"[torchdr_amd] UMAP: the HIP gradient kernels are built for n_components in 1..32 "
+                f"(2 or 3 with SCHEDULED = False), got {self.n_components}."
             )
         return super()._fit_transform(X, y)
 
