@@ -374,12 +374,15 @@ __device__ __forceinline__ int pass_negative_count(int n_levels, const uint32_t 
 
 // One row group (G lanes) walks ONE item stream: the row's fired edges with column in this slice, then its negatives
 // drawn inside this slice; lane gl owns the four consecutive items 4 gl .. 4 gl + 3 of every round of 4 G items.
-// Measured (N = 1M, 2 slices, 26 items per row and pass): the pass takes 0.16 ms against 0.097 ms for its gathers
-// alone at the L2's 268 G random requests/s (tools/gather_bench.hip), and 0.064 ms with 4 items per row -- a cost per
-// VECTOR-MEMORY INSTRUCTION of the row set, not per byte (neither fewer VALU instructions, nor narrower row groups, nor
-// a software-pipelined persistent form moved it).  Hence: one 8-byte record per row instead of four header words, one
-// 16-byte list read per lane instead of four, and a branch-free body (INJ = false: every lane evaluates both address
-// forms and selects).
+// What bounds it (N = 1M, 2 slices, 26 items per row and slice; DESIGN.md section 3, profiles/r02_umap_sched_ablation.json):
+// the vector ALUs and the L2 at once.  691 vector instructions per wavefront and slice (a wave64 instruction holds a
+// 16-lane SIMD for 4 cycles, 16 for 32-bit integer multiplies and transcendentals) keep the ALUs ~80 % busy; the 26 M
+// random 8-byte gathers per slice keep the L2 ~85 % busy (its request rate, 128 channels x clock, is the ceiling: 268 G/s
+// in tools/gather_bench.hip at 2.1 GHz, ~180 G/s at the 1.43 GHz the chip holds under this kernel).  Removing either
+// alone (ablations) leaves the other: 0.310 -> 0.266 (no random gathers) / 0.301 (no hash, pow, rcp) / 0.223 ms (both).
+// Hence the shape: one 8-byte record per row instead of four header words, one 16-byte list read per lane instead of
+// four, a branch-free body (INJ = false: every lane evaluates both address forms and selects), a two-multiply item
+// hash, and all slices in ONE launch spread over the XCDs (see the joint fields of SchedGradParams).
 // PAD instances serve any n_components <= NC: rows are P.nc floats wide, registers hold NC (zeros beyond P.nc contribute
 // nothing to distances or forces)
 template <int NC, int G, bool INJ, bool PAD = false>
