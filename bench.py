@@ -308,9 +308,10 @@ def main():
                                         "not matrix-pipe utilisation" if path.endswith("pruned") else "")),
     }
     roof_grad = {
-        "kernel": ("one UMAP iteration = tdr::umap_sched_grad_kernel<2,4,false> (ONE launch over both L2 slices of the embedding, "
-                   "slices spread over the XCDs) + tdr::umap_sched_combine_kernel + tdr::sgd_step_kernel + 1/32 of "
-                   "tdr::umap_sched_build_kernel" if umod.SCHEDULED else
+        "kernel": ("tdr::umap_sched_grad_kernel<2,4,false> (ONE launch per iteration over both L2 slices of the embedding, slices "
+                   "spread over the XCDs; HIP events around every 25th launch) + 1/32 of tdr::umap_sched_build_kernel (every "
+                   "build timed); the combine + SGD-step kernel that follows (tdr::umap_sched_combine_sgd_kernel, ~11 us in the "
+                   "rocprof CSV) is outside the event pairs" if umod.SCHEDULED else
                    "tdr::umap_grad_kernel<2,16,4,true> + 2 x tdr::umap_neg_dense_kernel<2,8,2> (one gradient evaluation)"),
         "bound": "hbm", "achieved": grad_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_gbs / HBM_PEAK_GBS,
         "traffic": pmc_traffic("r02_umap_sched_pmc.json" if umod.SCHEDULED else "r01_umap_grad_pmc.json"),
