@@ -164,13 +164,19 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                                              _lib.ptr(scratch), _lib.ptr(blk_base), _lib.stream_ptr()),
                    "tdr_umap_sched_plan_f32")
         cap = int(blk_base[-1].item())
+        # the joint launch relies on workgroups going round-robin over EIGHT XCDs that each cache one slice: only on the
+        # whole device (256 CUs); on a partitioned one (e.g. one XCD per device) the slices go one launch at a time
+        geom = int(SCHED_GEOM)
+        if torch.cuda.get_device_properties(dev).multi_processor_count < 256:
+            geom &= 15
         self._sched = {
             "B": B, "S": S, "blk_base": blk_base, "t0": None, "n": 0,
             "list": torch.empty(cap + 64, dtype=torch.int32, device=dev),  # slack: idle lanes read entry 0 of a segment
             "hdr": torch.empty(2 * int(L.tdr_umap_sched_hdr_entries(n_rows, B, S)), dtype=torch.int32, device=dev),
             "err": torch.zeros(1, dtype=torch.int32, device=dev),
-            # partial sums between the slice passes; the joint launch (SCHED_GEOM & 16) keeps one plane per slice
-            "acc": torch.empty(((S if int(SCHED_GEOM) & 16 else 1) * n_rows, 2 * nc), dtype=torch.float32, device=dev) if S > 1 else None,
+            "geom": geom,
+            # partial sums between the slice passes; the joint launch (geom & 16) keeps one plane per slice
+            "acc": torch.empty(((S if geom & 16 else 1) * n_rows, 2 * nc), dtype=torch.float32, device=dev) if S > 1 else None,
         }
         return self._sched
 
@@ -197,7 +203,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         if prof:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        geom = int(SCHED_GEOM)
+        geom = sc["geom"]
         # joint launch + stock fused-SGD step: the gradient kernel leaves the per-slice planes and ONE kernel combines
         # them and steps the rows (`_sgd_kernel` below); anything that looks at the gradient in between keeps the form
         # with its own combine kernel
@@ -297,7 +303,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                                                   _lib.ptr(keep["scratch"]))
         ctx = getattr(self, "_rccl_ctx", None)
         d.gather, d.gather_ctx = (ctx.gather_fn, ctx.handle) if ctx is not None else (None, None)
-        d.geom = int(SCHED_GEOM)
+        d.geom = sc["geom"]
         handle = ctypes.c_void_p()
         _lib.check(L.tdr_umap_loop_create(ctypes.byref(handle), ctypes.byref(d)), "tdr_umap_loop_create")
         # graphs cannot be captured on the legacy default stream: the loop runs on a side stream ordered after the
