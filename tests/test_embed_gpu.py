@@ -404,3 +404,69 @@ def test_sliced_negative_sampler_is_uniform(n_slices):
     if int(sel.sum()) > 200:
         var = float(lower[sel].var())
         assert 8.5 < var < 11.5, var                              # n/4 = 10 (8000 rows: sd of the estimate ~0.16)
+
+
+@pytest.mark.parametrize("nc", [1, 4, 5, 16, 32])
+def test_ne_gradient_kernels_at_other_embedding_widths(nc):
+    """n_components outside {2, 3} run on zero-padded register instances of the same kernels: every closed-form gradient
+    (LargeVis / TSNE / SNE / InfoTSNE attraction and repulsion, PaCMAP) against the oracle's torch restatement."""
+    import oracle.ref_torch as R
+    from torchdr_amd import _lib
+    from torchdr_amd.neighbor_embedding.base import build_transposed_graph
+
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(100 + nc)
+    n, k, n_neg = 700, 9, 7
+    Z = (torch.randn(n, nc, generator=gen) * 1.5 / max(nc / 2.0, 1.0) ** 0.5).contiguous()   # pair distances O(1) at every width
+    NN = torch.stack([torch.randperm(n - 1, generator=gen)[:k] for _ in range(n)])
+    NN = (NN + (NN >= torch.arange(n)[:, None]).long()).to(torch.int32)
+    P = torch.rand(n, k, generator=gen)
+    neg = R.sample_negatives(n, torch.arange(n), n_neg, generator=gen)
+    Zc, NNc, Pc, negc = Z.cuda(), NN.cuda().contiguous(), P.cuda().contiguous(), neg.cuda().contiguous()
+
+    def ne(kind, rep_coef, with_neg, pull):
+        tg = build_transposed_graph(Pc, NNc, 0, n, 1) if pull else (None, None, None)
+        grad = torch.zeros((n, nc), device="cuda")
+        _lib.check(L.tdr_ne_grad_f32(_lib.ptr(Zc), nc, n, 0, n, _lib.ptr(NNc), _lib.ptr(Pc), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]),
+                                     _lib.ptr(tg[2]), kind, 1.0, rep_coef, n_neg if with_neg else 0, _lib.ptr(negc) if with_neg else None,
+                                     0, 0, _lib.ptr(grad), _lib.stream_ptr()), "ne_grad")
+        return grad
+
+    def close(a, b):
+        return torch.allclose(a.cpu(), b, rtol=2e-4, atol=2e-6 * float(b.abs().max()))
+
+    for pull in (False, True):
+        assert close(ne(0, 2.0 / n, True, pull), R.ne_attraction_grad(Z, NN, P, "largevis") + R.largevis_repulsion_grad(Z, neg, n))
+        assert close(ne(1, 0.0, False, pull), R.ne_attraction_grad(Z, NN, P, "tsne"))
+        assert close(ne(2, 0.0, False, pull), R.ne_attraction_grad(Z, NN, P, "sne"))
+        assert close(ne(3, 2.0 / n, True, pull), R.ne_attraction_grad(Z, NN, P, "infotsne") + R.infotsne_repulsion_grad(Z, neg, n))
+    # dense repulsions
+    F = torch.empty((n, nc), device="cuda")
+    S = torch.zeros(1, dtype=torch.float64, device="cuda")
+    _lib.check(L.tdr_tsne_repulsion_f32(_lib.ptr(Zc), nc, n, 0, n, _lib.ptr(F), _lib.ptr(S), _lib.stream_ptr()), "tsne_rep")
+    g = torch.zeros((n, nc), device="cuda")
+    _lib.check(L.tdr_add_scaled_f32(_lib.ptr(g), _lib.ptr(F), _lib.ptr(S), -4.0, n * nc, _lib.stream_ptr()), "add_scaled")
+    ref, Sref = R.tsne_repulsion_grad(Z)
+    assert close(g, ref) and abs(float(S.item()) - float(Sref)) < 1e-4 * float(Sref)
+    Rs = torch.empty(n, device="cuda")
+    _lib.check(L.tdr_sne_rowsum_f32(_lib.ptr(Zc), nc, n, 0, n, _lib.ptr(Rs), _lib.stream_ptr()), "sne_rowsum")
+    g = torch.zeros((n, nc), device="cuda")
+    _lib.check(L.tdr_sne_repulsion_f32(_lib.ptr(Zc), nc, n, 0, n, _lib.ptr(Rs), -2.0 / n, _lib.ptr(g), _lib.stream_ptr()), "sne_rep")
+    assert close(g, R.sne_repulsion_grad(Z))
+    # PaCMAP pair losses
+    near, mid, far = (torch.randint(0, n, (n, m), generator=gen) for m in (6, 3, 4))
+    g = torch.zeros((n, nc), device="cuda")
+    near_c, mid_c, far_c = near.cuda(), mid.cuda(), far.cuda()
+    _lib.check(L.tdr_pacmap_grad_f32(_lib.ptr(Zc), nc, n, _lib.ptr(near_c), 6, 2.0, _lib.ptr(mid_c), 3, 3.0,
+                                     _lib.ptr(far_c), 4, 1.0, _lib.ptr(g), _lib.stream_ptr()), "pacmap")
+    assert close(g, R.pacmap_grad(Z, near, mid, far, 2.0, 3.0, 1.0))
+
+
+@pytest.mark.parametrize("cls_name,kw", [("LargeVis", dict(perplexity=8)), ("TSNE", dict(perplexity=8)), ("SNE", dict(perplexity=8)),
+                                         ("InfoTSNE", dict(perplexity=8)), ("PACMAP", dict(n_neighbors=8))])
+def test_estimators_with_five_components(cls_name, kw):
+    import torchdr_amd
+
+    X = gmm(1500, 12, 3.0, seed=21).cuda()
+    Z = getattr(torchdr_amd, cls_name)(n_components=5, max_iter=60, random_state=0, **kw).fit_transform(X)
+    assert Z.shape == (1500, 5) and bool(torch.isfinite(Z).all())

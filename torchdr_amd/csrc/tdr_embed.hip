@@ -371,15 +371,17 @@ struct NeStepParams {
     const int64_t* t_rowptr; // (n_rows + 1) or NULL
     const int32_t* t_src;    // global source row of each in-edge
     const float* t_val;      // P of each in-edge
+    int nc;                  // row width of Z / grad (PAD instances)
 };
 
-template <int NC, int G>
+template <int NC, int G, bool PAD = false>
 __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
+    const int nc = PAD ? S.nc : NC;  // row width in memory (PAD: NC is the padded register width)
     const int gl = threadIdx.x % G;
     const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     if (r >= S.n_rows) return;
     const int64_t gi = S.row0 + r;
-    const Vec<NC> zi = load_z<NC>(S.Z, gi);
+    const Vec<NC> zi = load_zp<NC, PAD>(S.Z, gi, nc);
     float g[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) g[c] = 0.f;
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
     for (int p = gl; p < S.k; p += G) {
         const int64_t j = S.nn[(size_t)r * S.k + p];
         const float pij = S.P[(size_t)r * S.k + p];
-        const Vec<NC> zj = load_z<NC>(S.Z, j);
+        const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
         float df[NC];
         float d = 0.f;
 #pragma unroll
@@ -401,14 +403,14 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
         for (int c = 0; c < NC; ++c) {
             const float t = w * df[c];
             g[c] += t;
-            if (!pull) unsafeAtomicAdd(&S.grad[(size_t)j * NC + c], -t);
+            if (!pull && c < nc) unsafeAtomicAdd(&S.grad[(size_t)j * nc + c], -t);
         }
     }
     if (pull) {
         // in-edges s -> i carry -w (z_s - z_i) = +w (z_i - z_s): the same expression as an out-edge
         const int64_t e1 = S.t_rowptr[r + 1];
         for (int64_t e = S.t_rowptr[r] + gl; e < e1; e += G) {
-            const Vec<NC> zs = load_z<NC>(S.Z, S.t_src[e]);
+            const Vec<NC> zs = load_zp<NC, PAD>(S.Z, S.t_src[e], nc);
             float df[NC];
             float d = 0.f;
 #pragma unroll
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
             int64_t j;
             if (S.neg_inj) j = S.neg_inj[(size_t)r * S.n_neg + col];
             else j = sample_negative(rkey, gi, col, S.n_total);
-            const Vec<NC> zj = load_z<NC>(S.Z, j);
+            const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
             float d = 0.f;
 #pragma unroll
             for (int c = 0; c < NC; ++c) { const float t = zi.v[c] - zj.v[c]; d += t * t; }
@@ -440,7 +442,7 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
         int64_t j;
         if (S.neg_inj) j = S.neg_inj[(size_t)r * S.n_neg + col];
         else j = sample_negative(rkey, gi, col, S.n_total);
-        const Vec<NC> zj = load_z<NC>(S.Z, j);
+        const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
         float df[NC];
         float d = 0.f;
 #pragma unroll
@@ -456,26 +458,27 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
         for (int c = 0; c < NC; ++c) {
             const float t = w * df[c];
             g[c] += t;
-            unsafeAtomicAdd(&S.grad[(size_t)j * NC + c], -t);
+            if (c < nc) unsafeAtomicAdd(&S.grad[(size_t)j * nc + c], -t);
         }
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         g[c] = group_sum<G>(g[c]);
-        if (gl == 0) unsafeAtomicAdd(&S.grad[(size_t)gi * NC + c], g[c]);
+        if (gl == 0 && c < nc) unsafeAtomicAdd(&S.grad[(size_t)gi * nc + c], g[c]);
     }
 }
 
 // ---- TSNE dense repulsion (tsne.py:172-180): S = sum_ij w_ij, F_i = sum_j (z_i - z_j) w_ij^2 ---------
-template <int NC>
+template <int NC, bool PAD = false>
 __global__ __launch_bounds__(256) void tsne_repulsion_kernel(const float* __restrict__ Z, int64_t n_total, int64_t row0,
-                                                             int64_t n_rows, float* __restrict__ F, double* __restrict__ S) {
+                                                             int64_t n_rows, float* __restrict__ F, double* __restrict__ S, int nc_) {
+    const int nc = PAD ? nc_ : NC;
     __shared__ float tile[256 * NC];
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool have = r < n_rows;
     Vec<NC> zi;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) zi.v[c] = have ? Z[(size_t)(row0 + r) * NC + c] : 0.f;
+    for (int c = 0; c < NC; ++c) zi.v[c] = (have && c < nc) ? Z[(size_t)(row0 + r) * nc + c] : 0.f;
     float f[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) f[c] = 0.f;
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256) void tsne_repulsion_kernel(const float* __rest
         __syncthreads();
         const int64_t j = j0 + threadIdx.x;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) tile[threadIdx.x * NC + c] = (j < n_total) ? Z[(size_t)j * NC + c] : 0.f;
+        for (int c = 0; c < NC; ++c) tile[threadIdx.x * NC + c] = (j < n_total && c < nc) ? Z[(size_t)j * nc + c] : 0.f;
         __syncthreads();
         const int lim = (int)((n_total - j0 < 256) ? (n_total - j0) : 256);
         for (int t = 0; t < lim; ++t) {
@@ -501,7 +504,8 @@ __global__ __launch_bounds__(256) void tsne_repulsion_kernel(const float* __rest
     }
     if (have) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) F[(size_t)r * NC + c] = f[c];
+        for (int c = 0; c < NC; ++c)
+            if (c < nc) F[(size_t)r * nc + c] = f[c];
     } else s = 0.f;
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) atomicAdd(S, (double)s);
@@ -518,21 +522,22 @@ __global__ __launch_bounds__(256) void add_scaled_kernel(float* __restrict__ gra
 
 // ---- SNE dense repulsion (sne.py:170-179): (1/N) sum_i log sum_j exp(-d_ij), diagonal included -------
 // pass 1: R_i = sum_j exp(-d_ij) for the rows of this chunk
-template <int NC>
+template <int NC, bool PAD = false>
 __global__ __launch_bounds__(256) void sne_rowsum_kernel(const float* __restrict__ Z, int64_t n_total, int64_t row0,
-                                                         int64_t n_rows, float* __restrict__ R) {
+                                                         int64_t n_rows, float* __restrict__ R, int nc_) {
+    const int nc = PAD ? nc_ : NC;
     __shared__ float tile[256 * NC];
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool have = r < n_rows;
     Vec<NC> zi;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) zi.v[c] = have ? Z[(size_t)(row0 + r) * NC + c] : 0.f;
+    for (int c = 0; c < NC; ++c) zi.v[c] = (have && c < nc) ? Z[(size_t)(row0 + r) * nc + c] : 0.f;
     float s = 0.f;
     for (int64_t j0 = 0; j0 < n_total; j0 += 256) {
         __syncthreads();
         const int64_t j = j0 + threadIdx.x;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) tile[threadIdx.x * NC + c] = (j < n_total) ? Z[(size_t)j * NC + c] : 0.f;
+        for (int c = 0; c < NC; ++c) tile[threadIdx.x * NC + c] = (j < n_total && c < nc) ? Z[(size_t)j * nc + c] : 0.f;
         __syncthreads();
         const int lim = (int)((n_total - j0 < 256) ? (n_total - j0) : 256);
         for (int t = 0; t < lim; ++t) {
@@ -546,16 +551,17 @@ __global__ __launch_bounds__(256) void sne_rowsum_kernel(const float* __restrict
 }
 
 // pass 2: grad_i += coef * sum_j exp(-d_ij) (1/R_i + 1/R_j) (z_i - z_j)   (R: all n_total rows)
-template <int NC>
+template <int NC, bool PAD = false>
 __global__ __launch_bounds__(256) void sne_repulsion_kernel(const float* __restrict__ Z, int64_t n_total, int64_t row0,
                                                             int64_t n_rows, const float* __restrict__ R, float coef,
-                                                            float* __restrict__ grad) {
+                                                            float* __restrict__ grad, int nc_) {
+    const int nc = PAD ? nc_ : NC;
     __shared__ float tile[256 * (NC + 1)];
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool have = r < n_rows;
     Vec<NC> zi;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) zi.v[c] = have ? Z[(size_t)(row0 + r) * NC + c] : 0.f;
+    for (int c = 0; c < NC; ++c) zi.v[c] = (have && c < nc) ? Z[(size_t)(row0 + r) * nc + c] : 0.f;
     const float inv_ri = have ? 1.0f / R[row0 + r] : 0.f;
     float f[NC];
 #pragma unroll
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(256) void sne_repulsion_kernel(const float* __restr
         __syncthreads();
         const int64_t j = j0 + threadIdx.x;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) tile[threadIdx.x * (NC + 1) + c] = (j < n_total) ? Z[(size_t)j * NC + c] : 0.f;
+        for (int c = 0; c < NC; ++c) tile[threadIdx.x * (NC + 1) + c] = (j < n_total && c < nc) ? Z[(size_t)j * nc + c] : 0.f;
         tile[threadIdx.x * (NC + 1) + NC] = (j < n_total) ? 1.0f / R[j] : 0.f;
         __syncthreads();
         const int lim = (int)((n_total - j0 < 256) ? (n_total - j0) : 256);
@@ -580,7 +586,8 @@ __global__ __launch_bounds__(256) void sne_repulsion_kernel(const float* __restr
     }
     if (have) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) grad[(size_t)(row0 + r) * NC + c] += coef * f[c];
+        for (int c = 0; c < NC; ++c)
+            if (c < nc) grad[(size_t)(row0 + r) * nc + c] += coef * f[c];
     }
 }
 
@@ -594,15 +601,17 @@ struct PacmapParams {
     const int64_t* near; int m_near; float w_nb;
     const int64_t* mid;  int m_mid;  float w_mn;
     const int64_t* far_; int m_far;  float w_fp;
-    float* grad;  // (n, NC), zero-initialised
+    float* grad;  // (n, nc), zero-initialised
+    int nc;       // row width (PAD instances)
 };
 
-template <int NC, int G>
+template <int NC, int G, bool PAD = false>
 __global__ __launch_bounds__(256) void pacmap_grad_kernel(const PacmapParams P) {
+    const int nc = PAD ? P.nc : NC;
     const int gl = threadIdx.x % G;
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
     if (i >= P.n) return;
-    const Vec<NC> zi = load_z<NC>(P.Z, i);
+    const Vec<NC> zi = load_zp<NC, PAD>(P.Z, i, nc);
     float g[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) g[c] = 0.f;
@@ -614,7 +623,7 @@ __global__ __launch_bounds__(256) void pacmap_grad_kernel(const PacmapParams P) 
         else if (p < P.m_near + P.m_mid) { j = P.mid[(size_t)i * P.m_mid + (p - P.m_near)]; num = 1.0e4f; off = 10001.0f; w = P.w_mn; }
         else { j = P.far_[(size_t)i * P.m_far + (p - P.m_near - P.m_mid)]; num = -1.0f; off = 2.0f; w = P.w_fp; }
         if (w == 0.f) continue;
-        const Vec<NC> zj = load_z<NC>(P.Z, j);
+        const Vec<NC> zj = load_zp<NC, PAD>(P.Z, j, nc);
         float df[NC];
         const float d = sqdist<NC>(zi, zj, df);
         const float den = off + d;
@@ -623,13 +632,13 @@ __global__ __launch_bounds__(256) void pacmap_grad_kernel(const PacmapParams P) 
         for (int c = 0; c < NC; ++c) {
             const float t = coef * df[c];
             g[c] += t;
-            unsafeAtomicAdd(&P.grad[(size_t)j * NC + c], -t);
+            if (c < nc) unsafeAtomicAdd(&P.grad[(size_t)j * nc + c], -t);
         }
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         g[c] = group_sum<G>(g[c]);
-        if (gl == 0) unsafeAtomicAdd(&P.grad[(size_t)i * NC + c], g[c]);
+        if (gl == 0 && c < nc) unsafeAtomicAdd(&P.grad[(size_t)i * nc + c], g[c]);
     }
 }
 
@@ -757,17 +766,23 @@ int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64
                     float exag, float rep_coef, int n_neg, const int64_t* neg_inj, uint64_t seed, int n_iter,
                     float* grad, void* stream) {
     if (!Z || !nn || !P_ || !grad || n_rows <= 0 || k <= 0 || n_total < 2) return TDR_ERR_BAD_ARG;
-    if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
+    if (nc < 1 || nc > 32) return TDR_ERR_UNSUPPORTED;
     if (kind < 0 || kind > 3) return TDR_ERR_BAD_ARG;
     NeStepParams S;
+    S.nc = nc;
     S.Z = Z; S.n_total = n_total; S.row0 = row0; S.n_rows = n_rows; S.nn = nn; S.P = P_; S.k = k; S.kind = kind;
     S.exag = exag; S.rep_coef = rep_coef; S.n_neg = n_neg; S.neg_inj = neg_inj; S.seed = seed;
     S.iter = (uint32_t)n_iter; S.grad = grad;
     if (t_rowptr && (!t_src || !t_val)) return TDR_ERR_BAD_ARG;
     S.t_rowptr = t_rowptr; S.t_src = t_src; S.t_val = t_val;
     hipStream_t st = (hipStream_t)stream;
+    // exact instances for 2 and 3 components, zero-padded register instances for any other width up to 32
     if (nc == 2) return launch_group<16>(ne_grad_kernel<2, 16>, S, n_rows, st);
-    return launch_group<16>(ne_grad_kernel<3, 16>, S, n_rows, st);
+    if (nc == 3) return launch_group<16>(ne_grad_kernel<3, 16>, S, n_rows, st);
+    if (nc <= 4) return launch_group<16>(ne_grad_kernel<4, 16, true>, S, n_rows, st);
+    if (nc <= 8) return launch_group<16>(ne_grad_kernel<8, 16, true>, S, n_rows, st);
+    if (nc <= 16) return launch_group<16>(ne_grad_kernel<16, 16, true>, S, n_rows, st);
+    return launch_group<16>(ne_grad_kernel<32, 16, true>, S, n_rows, st);
 }
 
 /* TSNE dense repulsion for rows [row0, row0+n_rows): F (n_rows, nc) = sum_j (z_i - z_j)/(1+d)^2 and
@@ -777,8 +792,12 @@ int tdr_tsne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0
     if (!Z || !F || !S || n_rows <= 0) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((n_rows + 255) / 256);
-    if (nc == 2) hipLaunchKernelGGL(tsne_repulsion_kernel<2>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S);
-    else if (nc == 3) hipLaunchKernelGGL(tsne_repulsion_kernel<3>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S);
+    if (nc == 2) hipLaunchKernelGGL(tsne_repulsion_kernel<2>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
+    else if (nc == 3) hipLaunchKernelGGL(tsne_repulsion_kernel<3>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
+    else if (nc >= 1 && nc <= 4) hipLaunchKernelGGL((tsne_repulsion_kernel<4, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
+    else if (nc <= 8 && nc >= 1) hipLaunchKernelGGL((tsne_repulsion_kernel<8, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
+    else if (nc <= 16 && nc >= 1) hipLaunchKernelGGL((tsne_repulsion_kernel<16, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
+    else if (nc <= 32 && nc >= 1) hipLaunchKernelGGL((tsne_repulsion_kernel<32, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
     else return TDR_ERR_UNSUPPORTED;
     TDR_CHECK_LAUNCH();
     return TDR_OK;
@@ -789,8 +808,12 @@ int tdr_sne_rowsum_f32(const float* Z, int nc, int64_t n_total, int64_t row0, in
     if (!Z || !R || n_rows <= 0) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((n_rows + 255) / 256);
-    if (nc == 2) hipLaunchKernelGGL(sne_rowsum_kernel<2>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R);
-    else if (nc == 3) hipLaunchKernelGGL(sne_rowsum_kernel<3>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R);
+    if (nc == 2) hipLaunchKernelGGL(sne_rowsum_kernel<2>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, nc);
+    else if (nc == 3) hipLaunchKernelGGL(sne_rowsum_kernel<3>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, nc);
+    else if (nc >= 1 && nc <= 4) hipLaunchKernelGGL((sne_rowsum_kernel<4, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, nc);
+    else if (nc <= 8 && nc >= 1) hipLaunchKernelGGL((sne_rowsum_kernel<8, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, nc);
+    else if (nc <= 16 && nc >= 1) hipLaunchKernelGGL((sne_rowsum_kernel<16, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, nc);
+    else if (nc <= 32 && nc >= 1) hipLaunchKernelGGL((sne_rowsum_kernel<32, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, nc);
     else return TDR_ERR_UNSUPPORTED;
     TDR_CHECK_LAUNCH();
     return TDR_OK;
@@ -803,8 +826,12 @@ int tdr_sne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0,
     if (!Z || !R || !grad || n_rows <= 0) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((n_rows + 255) / 256);
-    if (nc == 2) hipLaunchKernelGGL(sne_repulsion_kernel<2>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad);
-    else if (nc == 3) hipLaunchKernelGGL(sne_repulsion_kernel<3>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad);
+    if (nc == 2) hipLaunchKernelGGL(sne_repulsion_kernel<2>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad, nc);
+    else if (nc == 3) hipLaunchKernelGGL(sne_repulsion_kernel<3>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad, nc);
+    else if (nc >= 1 && nc <= 4) hipLaunchKernelGGL((sne_repulsion_kernel<4, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad, nc);
+    else if (nc <= 8 && nc >= 1) hipLaunchKernelGGL((sne_repulsion_kernel<8, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad, nc);
+    else if (nc <= 16 && nc >= 1) hipLaunchKernelGGL((sne_repulsion_kernel<16, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad, nc);
+    else if (nc <= 32 && nc >= 1) hipLaunchKernelGGL((sne_repulsion_kernel<32, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad, nc);
     else return TDR_ERR_UNSUPPORTED;
     TDR_CHECK_LAUNCH();
     return TDR_OK;
@@ -836,13 +863,18 @@ int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_i
                         float* grad, void* stream) {
     if (!Z || !grad || n <= 0 || m_near < 0 || m_mid < 0 || m_far < 0) return TDR_ERR_BAD_ARG;
     if ((m_near > 0 && !near_idx) || (m_mid > 0 && !mid_idx) || (m_far > 0 && !far_idx)) return TDR_ERR_BAD_ARG;
-    if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
+    if (nc < 1 || nc > 32) return TDR_ERR_UNSUPPORTED;
     PacmapParams P;
+    P.nc = nc;
     P.Z = Z; P.n = n; P.near = near_idx; P.m_near = m_near; P.w_nb = w_nb; P.mid = mid_idx; P.m_mid = m_mid; P.w_mn = w_mn;
     P.far_ = far_idx; P.m_far = m_far; P.w_fp = w_fp; P.grad = grad;
     hipStream_t st = (hipStream_t)stream;
     if (nc == 2) return launch_group<16>(pacmap_grad_kernel<2, 16>, P, n, st);
-    return launch_group<16>(pacmap_grad_kernel<3, 16>, P, n, st);
+    if (nc == 3) return launch_group<16>(pacmap_grad_kernel<3, 16>, P, n, st);
+    if (nc <= 4) return launch_group<16>(pacmap_grad_kernel<4, 16, true>, P, n, st);
+    if (nc <= 8) return launch_group<16>(pacmap_grad_kernel<8, 16, true>, P, n, st);
+    if (nc <= 16) return launch_group<16>(pacmap_grad_kernel<16, 16, true>, P, n, st);
+    return launch_group<16>(pacmap_grad_kernel<32, 16, true>, P, n, st);
 }
 
 /* Test hook: negatives drawn by the dense slice passes of tdr_umap_grad_f32 (n_slices = 2 or 4) for rows

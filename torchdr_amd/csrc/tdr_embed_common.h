@@ -23,6 +23,17 @@ __device__ __forceinline__ Vec<NC> load_z(const float* __restrict__ Z, int64_t i
     return r;
 }
 
+// row i of a block whose rows are `nc` floats wide into NC >= nc registers (zeros beyond nc contribute nothing to
+// distances or forces): the PAD instances of the gradient kernels serve any embedding width up to NC
+template <int NC, bool PAD>
+__device__ __forceinline__ Vec<NC> load_zp(const float* __restrict__ Z, int64_t i, int nc) {
+    if (!PAD) return load_z<NC>(Z, i);
+    Vec<NC> r;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) r.v[c] = c < nc ? Z[(size_t)i * nc + c] : 0.f;
+    return r;
+}
+
 // Counter-based hash generator for the negatives: three chained rounds of the "triple32" integer mixer
 // (xorshift-multiply, bias-tested avalanche) over (seed, row) -> (+iteration) -> (+column).  The first two
 // rounds are per row / per iteration and hoisted out of the column loop, so one negative costs ~10 VALU ops
