@@ -346,6 +346,10 @@ int tdr_fill_f32(float* p, int64_t n, float v, void* stream);
  * affinity/entropic.py:37-42,518-565 (_log_Pse, row entropy / logsumexp of the dual-ascent loop) */
 int tdr_sea_rowstats_f32(const float* packed, int64_t n, int d, const float* side, int exclude_diag, float diag_add,
                          float* psum, float* ent, void* stream);
+/* the same with energy[i] = sum_j exp(lp_ij) C_ij: the dual objective of the LBFGS path (entropic.py:483-491) is
+ * -sum(energy) - <e, target - ent> + <mu, psum - 1> */
+int tdr_sea_rowstats3_f32(const float* packed, int64_t n, int d, const float* side, int exclude_diag, float diag_add,
+                          float* psum, float* ent, float* energy, void* stream);
 /* affinity/entropic.py:728-734 on the input points, matrix-free: lse[i] = LSE_j(log K_ij + f_j), log K = -C / eps
  * (student != 0: -log(1 + C) / eps); the caller forms the symmetric Sinkhorn update f <- 0.5 (f - lse). */
 int tdr_sinkhorn_lse_f32(const float* packed, int64_t n, int d, const float* f, float inv_eps, int student, int exclude_diag,

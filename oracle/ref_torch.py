@@ -406,6 +406,20 @@ def sea_affinity(C, perplexity, lr=1e-1, max_iter=100, tol=1e-3, eps_square=True
     return eps, mu, log_P - math.log(n), k
 
 
+def sea_dual_objective(C, eps, mu, perplexity, eps_square=True):
+    """The closure of SymmetricEntropicAffinity(optimizer="LBFGS") (affinity/entropic.py:483-491): negative Lagrangian
+    -sum(P C) - <e, target - H> + <mu, rowsum - 1> with log P = (mu_i + mu_j - 2 C_ij) / (e_i + e_j), e = eps^2 or eps.
+    Returns (loss, H, rowsum); its gradients are H - target (times 2 eps when squared) and rowsum - 1."""
+    e = eps**2 if eps_square else eps
+    log_P = (mu[:, None] + mu[None, :] - 2 * C) / (e[:, None] + e[None, :])
+    P = log_P.exp()
+    H = -(P * (log_P - 1)).sum(1)
+    rowsum = P.sum(1)
+    target = math.log(perplexity) + 1
+    loss = -(P * C).sum() - torch.inner(e, target - H) + torch.inner(mu, rowsum - 1)
+    return loss, H, rowsum
+
+
 def sinkhorn_student(Z, init_dual=None, max_iter=5, tol=1e-5, zero_diag=True):
     n = Z.shape[0]
     D = torch.cdist(Z, Z) ** 2 if False else ((Z[:, None, :] - Z[None, :, :]) ** 2).sum(-1)

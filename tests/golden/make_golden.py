@@ -529,6 +529,35 @@ def sinkhorn_fixture():
     save("sinkhorn", **out)
 
 
+def sea_lbfgs_fixture():
+    """The objective SymmetricEntropicAffinity(optimizer="LBFGS") hands to torch.optim.LBFGS (entropic.py:483-491): loss
+    and autograd gradients of the reference's own closure expression at given duals, with and without the squared
+    parameterisation of eps, with and without the diagonal.  (The reference's LBFGS RUN is not recorded: with its
+    defaults it ends in NaN duals or overflows inside the line search on this kind of data; the objective is what can be
+    pinned.)"""
+    from torchdr.affinity.entropic import _log_Pse
+    from torchdr.utils import entropy
+
+    X = gmm(256, 16, 2.0, seed=61)
+    out = {"X": X}
+    gen = torch.Generator().manual_seed(7)
+    target = torch.log(torch.tensor(10.0)) + 1
+    for name, eps_square, zero_diag in (("sq", True, True), ("lin", False, False)):
+        C = pairwise_distances(X, metric="sqeuclidean", backend=None, exclude_diag=zero_diag)
+        if isinstance(C, tuple):
+            C = C[0]
+        eps = (0.8 + 0.4 * torch.rand(256, generator=gen)).requires_grad_(True)
+        mu = (0.5 * torch.randn(256, generator=gen)).requires_grad_(True)
+        _eps = eps**2 if eps_square else eps
+        log_P = _log_Pse(C, _eps, mu, eps_square=False)
+        H = entropy(log_P, log=True, dim=1)
+        loss = -(log_P.exp() * C).sum(0).sum() - torch.inner(_eps, target - H) + torch.inner(mu, log_P.logsumexp(1).squeeze().expm1())
+        loss.backward()
+        out.update({f"{name}_eps": eps.detach(), f"{name}_mu": mu.detach(), f"{name}_loss": loss.detach(), f"{name}_grad_eps": eps.grad,
+                    f"{name}_grad_mu": mu.grad, f"{name}_H": H.detach(), f"{name}_rowsum": log_P.logsumexp(1).exp().detach()})
+    save("sea_lbfgs", **out)
+
+
 def c1_tsne_fixture():
     """BASELINE config C1 at full size: TSNE on the 5000 x 50 Gaussian mixture, perplexity 30, backend=None (CPU):
     the reference's first two optimisation steps (embedding before / gradient / after, lr, momentum, exaggeration) and
@@ -567,7 +596,8 @@ if __name__ == "__main__":
                umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne2_step=ne2_step_fixture,
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
-               cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture)
+               cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture,
+               sea_lbfgs=sea_lbfgs_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

@@ -306,3 +306,28 @@ def test_numeric_helpers_cpu():
     assert torch.allclose(entropy(P.log(), log=True), entropy(P, log=False), atol=1e-6)
     assert sum_red(P, 1).shape == (4, 1) and logsumexp_red(P.log(), 1).shape == (4, 1)
     assert torch.allclose(cross_entropy_loss(P, P.log(), log=True), cross_entropy_loss(P, P))
+
+
+def test_sea_lbfgs_objective_matches_reference_autograd():
+    """oracle.ref_torch.sea_dual_objective against the reference's own closure expression and its AUTOGRAD gradients
+    (tests/golden/sea_lbfgs.npz): loss, row statistics, and the closed-form gradients H - target (x 2 eps) / rowsum - 1."""
+    import math
+
+    import oracle.ref_torch as R
+
+    g = load("sea_lbfgs")
+    X = g["X"].double()
+    for name, sq, zd in (("sq", True, True), ("lin", False, False)):
+        C = torch.cdist(X, X) ** 2
+        if zd:
+            C = C + torch.diag(torch.full((X.shape[0],), 1e12, dtype=torch.float64))
+        eps, mu = g[f"{name}_eps"].double(), g[f"{name}_mu"].double()
+        loss, H, rowsum = R.sea_dual_objective(C, eps, mu, 10.0, eps_square=sq)
+        assert abs(float(loss) - float(g[f"{name}_loss"])) < 2e-4 * abs(float(g[f"{name}_loss"]))
+        assert torch.allclose(H.float(), g[f"{name}_H"], rtol=1e-4, atol=1e-4)
+        assert torch.allclose(rowsum.float(), g[f"{name}_rowsum"], rtol=1e-4, atol=5e-5)
+        ge = H - (math.log(10.0) + 1)
+        ge = 2 * eps * ge if sq else ge
+        assert torch.allclose(ge.float(), g[f"{name}_grad_eps"], rtol=1e-4, atol=1e-4)
+        # the fixture is the reference in fp32: row sums of ~2 carry ~2e-5 of rounding
+        assert torch.allclose((rowsum - 1).float(), g[f"{name}_grad_mu"], rtol=1e-4, atol=5e-5)

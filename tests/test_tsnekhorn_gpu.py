@@ -107,3 +107,42 @@ def test_tsnekhorn_estimator():
     assert int(m2.n_iter_) == 0
     with pytest.raises(ValueError, match="does not support distributed"):
         torchdr_amd.TSNEkhorn(distributed=True)
+
+
+def test_sea_lbfgs_objective_and_run():
+    """optimizer="LBFGS" (entropic.py:473-508).  (1) The matrix-free closure -- three row statistics of
+    tdr_sea_rowstats3_f32 -- gives the reference's loss and autograd gradients at the fixture's duals (1e-4).  (2) A run
+    from the reference's starting point lowers the dual residuals and returns finite duals; the dense log-affinity is
+    built from the FINAL duals, as the reference does on this path."""
+    import math
+
+    from torchdr_amd.affinity import SymmetricEntropicAffinity
+    from torchdr_amd.affinity.entropic import sea_rowstats
+    from torchdr_amd.distance import PackedPoints
+
+    g = load("sea_lbfgs")
+    X = g["X"].cuda()
+    packed = PackedPoints(X)
+    target = math.log(10.0) + 1
+    for name, sq, zd in (("sq", True, True), ("lin", False, False)):
+        eps, mu = g[f"{name}_eps"].cuda(), g[f"{name}_mu"].cuda()
+        e = eps ** 2 if sq else eps
+        P_sum, H, energy = sea_rowstats(packed, mu, e, zd, energy=True)
+        loss = -energy.sum() - torch.inner(e, target - H) + torch.inner(mu, P_sum - 1)
+        assert abs(float(loss) - float(g[f"{name}_loss"])) < 3e-4 * abs(float(g[f"{name}_loss"]))
+        ge = (2 * eps * (H - target)) if sq else (H - target)
+        assert torch.allclose(ge.cpu(), g[f"{name}_grad_eps"], rtol=2e-4, atol=2e-4)
+        assert torch.allclose((P_sum - 1).cpu(), g[f"{name}_grad_mu"], rtol=2e-4, atol=1e-4)
+    # a run: residuals at the start (eps = mu = 1) against the residuals of the returned duals
+    sea = SymmetricEntropicAffinity(perplexity=10, optimizer="LBFGS", lr=1e-3, max_iter=40, tol=1e-4)
+    one = torch.ones(256, device="cuda")
+    P0, H0 = sea_rowstats(packed, one, one, True)
+    r0 = float((P0 - 1).norm() + (H0 - target).norm())
+    sea.fit_duals(X)
+    mu, e = sea.dual_side()
+    assert bool(torch.isfinite(mu).all()) and bool(torch.isfinite(e).all()) and int(sea.n_iter_) > 1
+    P1, H1 = sea_rowstats(packed, mu, e, True)
+    r1 = float((P1 - 1).norm() + (H1 - target).norm())
+    assert r1 < r0, (r0, r1)
+    logP = sea(X, log=True)
+    assert logP.shape == (256, 256) and bool(torch.isfinite(logP[~torch.eye(256, dtype=torch.bool, device="cuda")]).all())

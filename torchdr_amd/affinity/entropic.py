@@ -188,12 +188,21 @@ from torchdr_amd.utils import check_NaNs  # noqa: E402
 _DENSE_LIMIT = 30000  # largest N for which the dense (N, N) API output is materialised
 
 
-def sea_rowstats(packed: PackedPoints, mu: torch.Tensor, e: torch.Tensor, zero_diag: bool):
-    """(P_sum, H) of the implicit matrix exp((mu_i+mu_j-2C_ij)/(e_i+e_j)) -- K7 ``tdr_sea_rowstats_f32``."""
+def sea_rowstats(packed: PackedPoints, mu: torch.Tensor, e: torch.Tensor, zero_diag: bool, energy: bool = False):
+    """(P_sum, H) of the implicit matrix exp((mu_i+mu_j-2C_ij)/(e_i+e_j)) -- K7 ``tdr_sea_rowstats_f32``; with
+    ``energy`` also sum_j P_ij C_ij (the third term of the dual objective, ``tdr_sea_rowstats3_f32``)."""
     n = packed.n
     side = torch.stack([mu, e], dim=1).contiguous()
     psum = torch.empty(n, dtype=torch.float32, device=mu.device)
     ent = torch.empty(n, dtype=torch.float32, device=mu.device)
+    if energy:
+        en = torch.empty(n, dtype=torch.float32, device=mu.device)
+        _lib.check(
+            _lib.lib().tdr_sea_rowstats3_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), 1 if zero_diag else 0,
+                                             1e12, _lib.ptr(psum), _lib.ptr(ent), _lib.ptr(en), _lib.stream_ptr()),
+            "tdr_sea_rowstats3_f32",
+        )
+        return psum, ent, en
     _lib.check(
         _lib.lib().tdr_sea_rowstats_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), 1 if zero_diag else 0,
                                         1e12, _lib.ptr(psum), _lib.ptr(ent), _lib.stream_ptr()),
@@ -210,8 +219,8 @@ class SymmetricEntropicAffinity(LogAffinity):
     The dual loop is **matrix-free**: every iteration recomputes the pairwise distances tile by tile on
     the MFMA pipe and reduces them to the two row statistics the gradients need (no N x N buffer).
     ``fit_duals`` runs just that (what ``TSNEkhorn`` uses); calling the object returns the dense
-    log-affinity like the reference does, for N up to ``_DENSE_LIMIT``.  Only the first-order optimizers
-    path (``optimizer != "LBFGS"``, reference :518-571) is implemented."""
+    log-affinity like the reference does, for N up to ``_DENSE_LIMIT``.  First-order optimizers (reference :518-571)
+    and LBFGS (:473-508) both run on the same row statistics."""
 
     def __init__(self, perplexity: float = 30, lr: float = 1e-1, eps_square: bool = True, tol: float = 1e-3,
                  max_iter: int = 500, check_interval: int = 50, optimizer: str = "Adam",
@@ -231,8 +240,6 @@ class SymmetricEntropicAffinity(LogAffinity):
     def fit_duals(self, X: torch.Tensor) -> PackedPoints:
         if self.metric != "sqeuclidean":
             raise NotImplementedError("[torchdr_amd] SymmetricEntropicAffinity supports metric='sqeuclidean'.")
-        if self.optimizer == "LBFGS":
-            raise NotImplementedError("[torchdr_amd] SymmetricEntropicAffinity: LBFGS is not implemented.")
         n = X.shape[0]
         packed = PackedPoints(X)
         perplexity = check_neighbor_param(self.perplexity, n)
@@ -241,6 +248,8 @@ class SymmetricEntropicAffinity(LogAffinity):
         mu = torch.ones(n, dtype=torch.float32, device=X.device)
         self.register_buffer("eps_", eps, persistent=False)
         self.register_buffer("mu_", mu, persistent=False)
+        if self.optimizer == "LBFGS":
+            return self._fit_duals_lbfgs(packed, target)
         optimizer = getattr(torch.optim, self.optimizer)([self.eps_, self.mu_], lr=self.lr)
         k = 0
         for k in range(self.max_iter):
@@ -273,6 +282,46 @@ class SymmetricEntropicAffinity(LogAffinity):
                         self.logger.info(f"Convergence reached at iter {k}.")
                     break
         self.n_iter_ = k
+        return packed
+
+    def _fit_duals_lbfgs(self, packed: PackedPoints, target: torch.Tensor) -> PackedPoints:
+        """Reference :473-508: ``torch.optim.LBFGS`` (strong Wolfe line search) on the negative Lagrangian.  The reference
+        differentiates the loss by autograd; here the closure evaluates loss and gradient from three matrix-free row
+        statistics.  The gradient is exact, not an approximation: log P is the minimiser of the Lagrangian for the given
+        duals, so the terms that go through P cancel pair by pair ((i, j) against (j, i)) and what is left is
+        d/d mu = P_sum - 1, d/d e = H - target (times 2 eps when eps is squared) -- the same expressions the reference
+        uses for its first-order optimizers (:529-534)."""
+        optimizer = torch.optim.LBFGS([self.eps_, self.mu_], lr=self.lr, max_iter=self.max_iter, tolerance_grad=self.tol,
+                                      line_search_fn="strong_wolfe")
+        evals = {"n": 0}
+
+        def closure():
+            with torch.no_grad():
+                e = self.eps_ ** 2 if self.eps_square else self.eps_
+                P_sum, H, energy = sea_rowstats(packed, self.mu_, e, self.zero_diag, energy=True)
+                loss = -energy.sum() - torch.inner(e, target - H) + torch.inner(self.mu_, P_sum - 1)
+                grad_eps = H - target
+                if self.eps_square:
+                    grad_eps = 2 * self.eps_ * grad_eps
+                self.eps_.grad = grad_eps
+                self.mu_.grad = P_sum - 1
+                evals["n"] += 1
+            return loss
+
+        self.eps_.requires_grad_(True)
+        self.mu_.requires_grad_(True)
+        try:
+            optimizer.step(closure)
+        finally:
+            self.eps_.requires_grad_(False)
+            self.mu_.requires_grad_(False)
+            self.eps_.grad = None
+            self.mu_.grad = None
+        check_NaNs([self.eps_, self.mu_],
+                   msg="[TorchDR] ERROR Affinity: NaN in dual variables, consider decreasing the learning rate.")
+        e = self.eps_ ** 2 if self.eps_square else self.eps_
+        self._dual_snapshot = (self.mu_.clone(), e.clone())   # the reference returns log P of the FINAL duals here (:506-508)
+        self.n_iter_ = evals["n"]
         return packed
 
     def dual_side(self):

@@ -28,6 +28,7 @@ struct PairScanParams {
     int exclude_diag;
     float* out0;           // per-row outputs
     float* out1;
+    float* out2;           // optional third output (SeaStats: sum_j P_ij C_ij), may be NULL
 };
 
 // ---- epilogues ---------------------------------------------------------------------------------------
@@ -35,32 +36,34 @@ struct PairScanParams {
 // H_i = -sum_j exp(lp_ij) (lp_ij - 1)   (entropic.py:522-525; P is NOT normalised inside the entropy).
 struct SeaStats {
     static constexpr int SIDE = 2;  // mu, e (= eps^2 or eps)
-    float mu_i, e_i, m, s, t;
-    __device__ __forceinline__ void init(const float* qs) { mu_i = qs[0]; e_i = qs[1]; m = -__builtin_inff(); s = 0.f; t = 0.f; }
+    float mu_i, e_i, m, s, t, u;   // u = sum_j exp(lp_ij - m) C_ij (the energy term of the dual objective, entropic.py:487)
+    __device__ __forceinline__ void init(const float* qs) { mu_i = qs[0]; e_i = qs[1]; m = -__builtin_inff(); s = 0.f; t = 0.f; u = 0.f; }
     __device__ __forceinline__ void add(float c, const float* sj, const PairScanParams&) {
         const float lp = (mu_i + sj[0] - 2.0f * c) * __builtin_amdgcn_rcpf(e_i + sj[1]);
         if (lp > m) {  // rescale running sums to the new maximum
             const float sc = __expf(m - lp);
-            s *= sc; t *= sc; m = lp;
+            s *= sc; t *= sc; u *= sc; m = lp;
         }
         const float p = __expf(lp - m);
         s += p;
         t = fmaf(p, lp, t);
+        u = (p > 0.f) ? fmaf(p, c, u) : u;   // the excluded diagonal carries c = 1e12 and p = 0
     }
     __device__ __forceinline__ void merge(const SeaStats& o) {
         const float mm = fmaxf(m, o.m);
         const float a = (m == -__builtin_inff()) ? 0.f : __expf(m - mm);
         const float b = (o.m == -__builtin_inff()) ? 0.f : __expf(o.m - mm);
-        s = s * a + o.s * b; t = t * a + o.t * b; m = mm;
+        s = s * a + o.s * b; t = t * a + o.t * b; u = u * a + o.u * b; m = mm;
     }
     __device__ __forceinline__ void shfl_from(const SeaStats& x, int src) {
-        m = __shfl(x.m, src, 64); s = __shfl(x.s, src, 64); t = __shfl(x.t, src, 64); mu_i = x.mu_i; e_i = x.e_i;
+        m = __shfl(x.m, src, 64); s = __shfl(x.s, src, 64); t = __shfl(x.t, src, 64); u = __shfl(x.u, src, 64); mu_i = x.mu_i; e_i = x.e_i;
     }
     __device__ __forceinline__ void store(int64_t row, const PairScanParams& P) const {
         const float em = expf(m);
         const float S = em * s, T = em * t;
         P.out0[row] = S;
         P.out1[row] = -(T - S);
+        if (P.out2) P.out2[row] = em * u;
     }
 };
 
@@ -407,7 +410,19 @@ int tdr_sea_rowstats_f32(const float* packed, int64_t n, int d, const float* sid
     PairScanParams P;
     P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
     P.side = side; P.qside = side; P.c0 = 0.f; P.c1 = 0.f; P.diag_add = diag_add; P.exclude_diag = exclude_diag;
-    P.out0 = psum; P.out1 = ent;
+    P.out0 = psum; P.out1 = ent; P.out2 = nullptr;
+    return launch_pair_scan<SeaStats>(P, d, (hipStream_t)stream);
+}
+
+/* The same with the third row statistic energy[i] = sum_j exp(lp_ij) C_ij: the dual objective of entropic.py:483-491
+ * (the LBFGS path) is -sum(energy) - <e, target - ent> + <mu, psum - 1>. */
+int tdr_sea_rowstats3_f32(const float* packed, int64_t n, int d, const float* side, int exclude_diag, float diag_add,
+                          float* psum, float* ent, float* energy, void* stream) {
+    if (!packed || !side || !psum || !ent || !energy || n <= 0) return TDR_ERR_BAD_ARG;
+    PairScanParams P;
+    P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
+    P.side = side; P.qside = side; P.c0 = 0.f; P.c1 = 0.f; P.diag_add = diag_add; P.exclude_diag = exclude_diag;
+    P.out0 = psum; P.out1 = ent; P.out2 = energy;
     return launch_pair_scan<SeaStats>(P, d, (hipStream_t)stream);
 }
 
@@ -420,7 +435,7 @@ int tdr_sinkhorn_lse_f32(const float* packed, int64_t n, int d, const float* f, 
     PairScanParams P;
     P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
     P.side = f; P.qside = f; P.c0 = inv_eps; P.c1 = student ? 1.0f : 0.f; P.diag_add = diag_add; P.exclude_diag = exclude_diag;
-    P.out0 = lse; P.out1 = nullptr;
+    P.out0 = lse; P.out1 = nullptr; P.out2 = nullptr;
     return launch_pair_scan<SinkLse>(P, d, (hipStream_t)stream);
 }
 
@@ -431,7 +446,7 @@ int tdr_khorn_grad_f32(const float* packed, int64_t n, int d, const float* side,
     PairScanParams P;
     P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
     P.side = side; P.qside = side; P.c0 = log_n; P.c1 = 1.0f / (float)n; P.diag_add = 0.f; P.exclude_diag = 0;
-    P.out0 = grad; P.out1 = nullptr;
+    P.out0 = grad; P.out1 = nullptr; P.out2 = nullptr;
     return launch_pair_scan<KhornForce>(P, d, (hipStream_t)stream);
 }
 
