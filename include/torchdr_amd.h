@@ -356,6 +356,9 @@ int tdr_sinkhorn_lse_f32(const float* packed, int64_t n, int d, const float* f, 
                          float diag_add, float* lse, void* stream);
 /* gradient of neighbor_embedding/tsnekhorn.py:210-230 w.r.t. the embedding (duals detached) */
 int tdr_khorn_grad_f32(const float* packed, int64_t n, int d, const float* side, float log_n, float* grad, void* stream);
+/* the same for an (n, nc) embedding, nc = 2 or 3; side: (n, 3 + nc) row-major (mu, e, z_0 .. z_{nc-1}, exp(dual)) */
+int tdr_khorn_grad_nc_f32(const float* packed, int64_t n, int d, const float* side, int nc, float log_n, float* grad,
+                          void* stream);
 /* affinity/entropic.py:733-740: one symmetric log-domain Sinkhorn update, student kernel on the embedding */
 int tdr_sinkhorn_pass_f32(const float* Z, int nc, const float* f, const float* Ef, float fmax, int64_t n, int zero_diag,
                           float diag_add, float* f_new, float* resid2, void* stream);

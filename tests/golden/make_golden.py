@@ -558,6 +558,67 @@ def sea_lbfgs_fixture():
     save("sea_lbfgs", **out)
 
 
+def dense_ne_fixture():
+    """sparsity=False: TSNE / SNE / LargeVis / InfoTSNE on the DENSE (N, N) entropic affinity (NN_indices_ is None, the
+    attraction runs over all pairs: tsne.py:162-170, sne.py:163-172, largevis.py:192-201, infotsne.py:179-188); two
+    optimisation steps each, negatives recorded for the two samplers."""
+    from torchdr import SNE, TSNE, InfoTSNE, LargeVis
+
+    X = gmm(300, 16, 2.0, seed=57)
+    out = {"X": X}
+    for name, cls, kw in (("tsne", TSNE, dict(perplexity=8)), ("sne", SNE, dict(perplexity=6)),
+                          ("largevis", LargeVis, dict(perplexity=5)),
+                          ("infotsne", InfoTSNE, dict(perplexity=7, n_negatives=40))):
+        rec = {}
+
+        class Probe(cls):
+            def _training_step(self):
+                t = int(self.n_iter_)
+                if t < 2:
+                    rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                    if hasattr(self, "neg_indices_"):
+                        rec[f"neg_{t}"] = self.neg_indices_.clone()
+                    if t == 0:
+                        assert self.NN_indices_ is None and self.affinity_in_.shape == (300, 300)
+                loss = super()._training_step()
+                if t < 2:
+                    rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                    rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+                return loss
+
+        torch.manual_seed(4)
+        Probe(max_iter=4, backend=None, init="normal", random_state=4, sparsity=False, **kw).fit_transform(X)
+        for k_, v in rec.items():
+            out[f"{name}_{k_}"] = v
+    save("dense_ne", **out)
+
+
+def tsnekhorn3_fixture():
+    """TSNEkhorn with n_components = 3 (tsnekhorn.py:210-230): two optimisation steps of the reference on the data of
+    the `tsnekhorn` fixture -- embedding before, Sinkhorn dual, autograd gradient, embedding after."""
+    from torchdr import TSNEkhorn
+
+    X = gmm(256, 16, 2.0, seed=61)
+    rec = {}
+
+    class Probe(TSNEkhorn):
+        def _training_step(self):
+            t = int(self.n_iter_)
+            if t < 2:
+                rec[f"Z_{t}"] = self.embedding_.detach().clone()
+            loss = super()._training_step()
+            if t < 2:
+                rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                rec[f"dual_{t}"] = self.dual_sinkhorn_.detach().clone()
+                rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+            return loss
+
+    torch.manual_seed(3)
+    Probe(perplexity=10, n_components=3, max_iter=3, max_iter_affinity_in=30, init="normal", init_scaling=1.0,
+          min_grad_norm=1e-12, lr=1.0, optimizer="SGD", optimizer_kwargs=None, backend=None, random_state=3).fit_transform(X)
+    save("tsnekhorn3", **rec)
+
+
 def c1_tsne_fixture():
     """BASELINE config C1 at full size: TSNE on the 5000 x 50 Gaussian mixture, perplexity 30, backend=None (CPU):
     the reference's first two optimisation steps (embedding before / gradient / after, lr, momentum, exaggeration) and
@@ -597,7 +658,7 @@ if __name__ == "__main__":
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
                cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture,
-               sea_lbfgs=sea_lbfgs_fixture)
+               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

@@ -470,3 +470,61 @@ def test_estimators_with_five_components(cls_name, kw):
     X = gmm(1500, 12, 3.0, seed=21).cuda()
     Z = getattr(torchdr_amd, cls_name)(n_components=5, max_iter=60, random_state=0, **kw).fit_transform(X)
     assert Z.shape == (1500, 5) and bool(torch.isfinite(Z).all())
+
+
+# ---- sparsity=False: the dense (N, N) input affinity ------------------------------------------------------------
+@pytest.mark.parametrize("name", ["tsne", "sne", "largevis", "infotsne"])
+def test_dense_affinity_estimators_vs_reference(name):
+    """sparsity=False against the real reference (tests/golden/dense_ne.npz): NN_indices_ is None, the attraction runs
+    over all N^2 pairs (tsne.py:162-170 and siblings with key_indices=None); two optimisation steps from the
+    reference's starting embedding, the two samplers with the reference's negatives injected."""
+    import torchdr_amd
+
+    g = load("dense_ne")
+    X = g["X"].cuda()
+    cls, kw = {"tsne": (torchdr_amd.TSNE, dict(perplexity=8)), "sne": (torchdr_amd.SNE, dict(perplexity=6)),
+               "largevis": (torchdr_amd.LargeVis, dict(perplexity=5)),
+               "infotsne": (torchdr_amd.InfoTSNE, dict(perplexity=7, n_negatives=40))}[name]
+    seen = {}
+
+    class Replay(cls):
+        def _init_embedding(self, X_):
+            self.embedding_ = g[f"{name}_Z_0"].to(self.device_).contiguous()
+            return self.embedding_
+
+        def on_training_step_start(self):
+            super().on_training_step_start()
+            t = int(self.n_iter_)
+            if t == 0:
+                seen["nn_none"] = self.NN_indices_ is None
+                seen["P_shape"] = tuple(self.affinity_in_.shape)
+            if name in ("largevis", "infotsne"):
+                self.neg_indices_ = g[f"{name}_neg_{t}"] if t < 2 else None
+
+        def _optimizer_step(self, grad):
+            t = int(self.n_iter_)
+            if t < 2:
+                seen[f"grad_{t}"] = grad.detach().cpu().clone()
+            super()._optimizer_step(grad)
+
+        def on_training_step_end(self):
+            super().on_training_step_end()
+            t = int(self.n_iter_)
+            if t < 2:
+                seen[t] = self.embedding_.detach().cpu().clone()
+
+    Replay(max_iter=4, random_state=4, sparsity=False, **kw).fit_transform(X)
+    assert seen["nn_none"] and seen["P_shape"] == (300, 300)
+    for t in range(2):
+        ref = g[f"{name}_grad_{t}"]
+        assert torch.allclose(seen[f"grad_{t}"], ref, rtol=1e-4, atol=2e-5 * float(ref.abs().max())), f"{name} grad {t}"
+        ref = g[f"{name}_Zafter_{t}"]
+        assert torch.allclose(seen[t], ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max())), f"{name} step {t}"
+
+
+def test_dense_affinity_cannot_discard_neighbours():
+    import torchdr_amd
+
+    X = gmm(300, 8, 2.0, seed=5).cuda()
+    with pytest.raises(ValueError, match="discard_NNs"):
+        torchdr_amd.LargeVis(perplexity=5, max_iter=2, sparsity=False, discard_NNs=True).fit_transform(X)

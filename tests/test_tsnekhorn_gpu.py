@@ -146,3 +146,44 @@ def test_sea_lbfgs_objective_and_run():
     assert r1 < r0, (r0, r1)
     logP = sea(X, log=True)
     assert logP.shape == (256, 256) and bool(torch.isfinite(logP[~torch.eye(256, dtype=torch.bool, device="cuda")]).all())
+
+
+def test_tsnekhorn_three_components_vs_reference():
+    """n_components = 3 (tests/golden/tsnekhorn3.npz): the estimator replayed from the reference's starting embedding --
+    Sinkhorn duals, gradients and embeddings of the first two steps."""
+    import torchdr_amd
+
+    g = load("tsnekhorn3")
+    X = gmm(256, 16, 2.0, seed=61).cuda()
+    seen = {}
+
+    class Replay(torchdr_amd.TSNEkhorn):
+        def _init_embedding(self, X_):
+            self.embedding_ = g["Z_0"].to(self.device_).contiguous()
+            return self.embedding_
+
+        def _optimizer_step(self, grad):
+            t = int(self.n_iter_)
+            if t < 2:
+                seen[f"grad_{t}"] = grad.detach().cpu().clone()
+                seen[f"dual_{t}"] = self.dual_sinkhorn_.detach().cpu().clone()
+            super()._optimizer_step(grad)
+
+        def on_training_step_end(self):
+            super().on_training_step_end()
+            t = int(self.n_iter_)
+            if t < 2:
+                seen[t] = self.embedding_.detach().cpu().clone()
+
+    Z = Replay(perplexity=10, n_components=3, max_iter=3, max_iter_affinity_in=30, init="normal", init_scaling=1.0,
+               min_grad_norm=1e-12, lr=1.0, optimizer="SGD", optimizer_kwargs=None, random_state=3).fit_transform(X)
+    assert Z.shape == (256, 3)
+    for t in range(2):
+        assert torch.allclose(seen[f"dual_{t}"], g[f"dual_{t}"], rtol=1e-4, atol=1e-5), t
+        ref = g[f"grad_{t}"]
+        assert torch.allclose(seen[f"grad_{t}"], ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max())), t
+        ref = g[f"Zafter_{t}"]   # lr = 1: the step carries the gradient's tolerance
+        atol = 2e-3 * float(g[f"grad_{t}"].abs().max()) + 1e-5 * float(ref.abs().max())
+        assert torch.allclose(seen[t], ref, rtol=1e-4, atol=atol), t
+    with pytest.raises(NotImplementedError):
+        torchdr_amd.TSNEkhorn(n_components=4)

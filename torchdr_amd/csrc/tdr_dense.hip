@@ -91,26 +91,45 @@ struct SinkLse {
 
 // TSNEkhorn force: g_i = 4 * sum_j (P_ij - Q_ij) w_ij (z_i - z_j), w = 1/(1+|z_i-z_j|^2),
 //   P_ij = exp((mu_i+mu_j-2C_ij)/(e_i+e_j) - log N),  Q_ij = E_i E_j w_ij / N  with E = exp(dual)
-//   (the diagonal term vanishes with z_i - z_i).  side = (mu, e, z0, z1, E); out0 = grad (n, 2).
+//   (the diagonal term vanishes with z_i - z_i).  side = (mu, e, z[NC], E); out0 = grad (n, NC).
+//   (the side block of a tile is staged by one load per thread: 32 * SIDE <= 256, so NC <= 5)
+template <int NC>
 struct KhornForce {
-    static constexpr int SIDE = 5;
-    float mu_i, e_i, z0, z1, E_i, g0, g1;
-    __device__ __forceinline__ void init(const float* qs) { mu_i = qs[0]; e_i = qs[1]; z0 = qs[2]; z1 = qs[3]; E_i = qs[4]; g0 = 0.f; g1 = 0.f; }
+    static constexpr int SIDE = 3 + NC;
+    float mu_i, e_i, z[NC], E_i, g[NC];
+    __device__ __forceinline__ void init(const float* qs) {
+        mu_i = qs[0]; e_i = qs[1]; E_i = qs[2 + NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { z[c] = qs[2 + c]; g[c] = 0.f; }
+    }
     __device__ __forceinline__ void add(float c, const float* sj, const PairScanParams& P) {
         const float lp = (mu_i + sj[0] - 2.0f * c) * __builtin_amdgcn_rcpf(e_i + sj[1]) - P.c0;  // c0 = log N
         const float p = __expf(lp);
-        const float d0 = z0 - sj[2], d1 = z1 - sj[3];
-        const float w = __builtin_amdgcn_rcpf(1.0f + d0 * d0 + d1 * d1);
-        const float q = E_i * sj[4] * w * P.c1;  // c1 = 1/N
+        float df[NC], d2 = 1.0f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) df[k] = z[k] - sj[2 + k];
+        if (NC == 2) d2 = 1.0f + df[0] * df[0] + df[1] * df[1];
+        else {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) d2 = fmaf(df[k], df[k], d2);
+        }
+        const float w = __builtin_amdgcn_rcpf(d2);
+        const float q = E_i * sj[2 + NC] * w * P.c1;  // c1 = 1/N
         const float coef = (p - q) * w;
-        g0 = fmaf(coef, d0, g0);
-        g1 = fmaf(coef, d1, g1);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) g[k] = fmaf(coef, df[k], g[k]);
     }
-    __device__ __forceinline__ void merge(const KhornForce& o) { g0 += o.g0; g1 += o.g1; }
-    __device__ __forceinline__ void shfl_from(const KhornForce& x, int src) { g0 = __shfl(x.g0, src, 64); g1 = __shfl(x.g1, src, 64); }
+    __device__ __forceinline__ void merge(const KhornForce& o) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) g[k] += o.g[k];
+    }
+    __device__ __forceinline__ void shfl_from(const KhornForce& x, int src) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) g[k] = __shfl(x.g[k], src, 64);
+    }
     __device__ __forceinline__ void store(int64_t row, const PairScanParams& P) const {
-        P.out0[row * 2 + 0] = 4.0f * g0;
-        P.out0[row * 2 + 1] = 4.0f * g1;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) P.out0[row * NC + k] = 4.0f * g[k];
     }
 };
 
@@ -439,15 +458,23 @@ int tdr_sinkhorn_lse_f32(const float* packed, int64_t n, int d, const float* f, 
     return launch_pair_scan<SinkLse>(P, d, (hipStream_t)stream);
 }
 
-/* TSNEkhorn embedding gradient (n, 2): 4 sum_j (P_ij - Q_ij)/(1+d_ij) (z_i - z_j).
- * side: (n, 5) row-major (mu, e, z0, z1, exp(dual)); log_n = log(n). */
-int tdr_khorn_grad_f32(const float* packed, int64_t n, int d, const float* side, float log_n, float* grad, void* stream) {
+/* TSNEkhorn embedding gradient (n, nc), nc = 2 or 3: 4 sum_j (P_ij - Q_ij)/(1+d_ij) (z_i - z_j).
+ * side: (n, 3 + nc) row-major (mu, e, z_0 .. z_{nc-1}, exp(dual)); log_n = log(n). */
+int tdr_khorn_grad_nc_f32(const float* packed, int64_t n, int d, const float* side, int nc, float log_n, float* grad,
+                          void* stream) {
     if (!packed || !side || !grad || n <= 0) return TDR_ERR_BAD_ARG;
+    if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
     PairScanParams P;
     P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
     P.side = side; P.qside = side; P.c0 = log_n; P.c1 = 1.0f / (float)n; P.diag_add = 0.f; P.exclude_diag = 0;
     P.out0 = grad; P.out1 = nullptr; P.out2 = nullptr;
-    return launch_pair_scan<KhornForce>(P, d, (hipStream_t)stream);
+    if (nc == 2) return launch_pair_scan<KhornForce<2>>(P, d, (hipStream_t)stream);
+    return launch_pair_scan<KhornForce<3>>(P, d, (hipStream_t)stream);
+}
+
+/* The two-component form (side: (n, 5)). */
+int tdr_khorn_grad_f32(const float* packed, int64_t n, int d, const float* side, float log_n, float* grad, void* stream) {
+    return tdr_khorn_grad_nc_f32(packed, n, d, side, 2, log_n, grad, stream);
 }
 
 /* One symmetric Sinkhorn update on the embedding Z (n, nc), student kernel, eps = 1:

@@ -159,6 +159,15 @@ class NeighborEmbedding(AffinityMatcher):
         else:
             self.chunk_start_ = 0
             self.chunk_size_ = self.n_samples_in_
+        # Dense input affinity (sparsity=False): NN_indices_ is None as in the reference, whose attraction then runs over
+        # all pairs (pairwise_distances_indexed with key_indices=None, e.g. tsne.py:162-170).  The edge kernels see the
+        # same thing as a rectangular graph of width N whose row i lists 0..N-1.
+        # (read from the buffer dict: UMAP exposes both names as lazily materialised properties)
+        self._nn_table = self._buffers.get("NN_indices_")
+        P = self._buffers.get("affinity_in_")
+        if self._nn_table is None and torch.is_tensor(P) and P.dim() == 2 and P.shape[1] == self.n_samples_in_:
+            cols = torch.arange(self.n_samples_in_, dtype=torch.int32, device=P.device)
+            self._nn_table = cols.unsqueeze(0).expand(P.shape[0], -1).contiguous()
         self._rccl_ctx = None
         if self.world_size > 1 and RCCL_CONTEXT and dist.get_backend() == "nccl" and torch.cuda.is_available():
             from torchdr_amd.parallel import RcclContext
@@ -167,6 +176,7 @@ class NeighborEmbedding(AffinityMatcher):
 
     def clear_memory(self):
         super().clear_memory()
+        self._nn_table = None
         ctx = getattr(self, "_rccl_ctx", None)
         if ctx is not None:
             ctx.destroy()
@@ -246,6 +256,9 @@ class NegativeSamplingNeighborEmbedding(NeighborEmbedding):
         self._exclusion = None
         if self.discard_NNs:
             nn_rows = self._nn_for_exclusion()
+            if nn_rows is None:
+                raise ValueError("[TorchDR] ERROR : discard_NNs=True needs the neighbour table of a sparse affinity "
+                                 "(sparsity=True).")
             self_idx = self.chunk_indices_.unsqueeze(1)
             excl = torch.cat([self_idx, nn_rows.to(self_idx.dtype)], dim=1)
             self._exclusion = excl.sort(dim=1).values

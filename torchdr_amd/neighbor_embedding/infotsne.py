@@ -33,11 +33,6 @@ class InfoTSNE(NegativeSamplingNeighborEmbedding):
         self.metric = metric
         self.perplexity = perplexity
         self.max_iter_affinity = max_iter_affinity
-        if not sparsity:
-            raise NotImplementedError(
-                "[torchdr_amd] sparsity=False (dense N x N input affinity) is not part of the accelerated path; the "
-                "kNN-sparse affinity (sparsity=True, the reference's default) is."
-            )
         self.sparsity = sparsity
         affinity_in = EntropicAffinity(perplexity=perplexity, metric=metric, max_iter=max_iter_affinity,
                                        device=device, backend=backend, verbose=verbose, sparsity=sparsity,
@@ -53,7 +48,7 @@ class InfoTSNE(NegativeSamplingNeighborEmbedding):
 
     def on_affinity_computation_end(self):
         super().on_affinity_computation_end()
-        self._tgraph = build_transposed_graph(self.affinity_in_, self.NN_indices_, self.chunk_start_,
+        self._tgraph = build_transposed_graph(self.affinity_in_, self._nn_table, self.chunk_start_,
                                               self.n_samples_in_, self.world_size)
 
     def _compute_gradients(self):
@@ -63,7 +58,7 @@ class InfoTSNE(NegativeSamplingNeighborEmbedding):
         neg = self._neg_ptr_tensor()
         _lib.check(
             _lib.lib().tdr_ne_grad_f32(
-                _lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_, _lib.ptr(self.NN_indices_),
+                _lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_, _lib.ptr(self._nn_table),
                 _lib.ptr(P), P.shape[1], _lib.ptr(self._tgraph[0]), _lib.ptr(self._tgraph[1]),
                 _lib.ptr(self._tgraph[2]), 3, float(self.early_exaggeration_coeff_),
                 float(self.repulsion_strength) * 2.0 / n, int(self.n_negatives), _lib.ptr(neg), self._neg_seed,

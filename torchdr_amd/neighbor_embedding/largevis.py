@@ -31,11 +31,6 @@ class LargeVis(NegativeSamplingNeighborEmbedding):
         self.metric = metric
         self.perplexity = perplexity
         self.max_iter_affinity = max_iter_affinity
-        if not sparsity:
-            raise NotImplementedError(
-                "[torchdr_amd] sparsity=False (dense N x N input affinity) is not part of the accelerated path; the "
-                "kNN-sparse affinity (sparsity=True, the reference's default) is."
-            )
         self.sparsity = sparsity
         affinity_in = EntropicAffinity(perplexity=perplexity, metric=metric, max_iter=max_iter_affinity,
                                        device=device, backend=backend, verbose=verbose, sparsity=sparsity,
@@ -51,13 +46,13 @@ class LargeVis(NegativeSamplingNeighborEmbedding):
 
     def on_affinity_computation_end(self):
         super().on_affinity_computation_end()
-        self._tgraph = build_transposed_graph(self.affinity_in_, self.NN_indices_, self.chunk_start_,
+        self._tgraph = build_transposed_graph(self.affinity_in_, self._nn_table, self.chunk_start_,
                                               self.n_samples_in_, self.world_size)
 
     def _compute_gradients(self):
         n, nc = self.n_samples_in_, self.n_components
         grad = torch.zeros((n, nc), dtype=torch.float32, device=self.device_)
-        nn = self.NN_indices_
+        nn = self._nn_table
         P = self.affinity_in_
         neg = self._neg_ptr_tensor()
         _lib.check(

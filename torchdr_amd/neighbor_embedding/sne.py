@@ -34,11 +34,6 @@ class SNE(NeighborEmbedding):
         self.metric = metric
         self.perplexity = perplexity
         self.max_iter_affinity = max_iter_affinity
-        if not sparsity:
-            raise NotImplementedError(
-                "[torchdr_amd] sparsity=False (dense N x N input affinity) is not part of the accelerated path; the "
-                "kNN-sparse affinity (sparsity=True, the reference's default) is."
-            )
         self.sparsity = sparsity
         affinity_in = EntropicAffinity(perplexity=perplexity, metric=metric, max_iter=max_iter_affinity,
                                        device=device, backend=backend, verbose=verbose, sparsity=sparsity,
@@ -53,7 +48,7 @@ class SNE(NeighborEmbedding):
 
     def on_affinity_computation_end(self):
         super().on_affinity_computation_end()
-        self._tgraph = build_transposed_graph(self.affinity_in_, self.NN_indices_, self.chunk_start_,
+        self._tgraph = build_transposed_graph(self.affinity_in_, self._nn_table, self.chunk_start_,
                                               self.n_samples_in_, self.world_size)
 
     def clear_memory(self):
@@ -69,7 +64,7 @@ class SNE(NeighborEmbedding):
         P = self.affinity_in_
         _lib.check(
             L.tdr_ne_grad_f32(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
-                              _lib.ptr(self.NN_indices_), _lib.ptr(P), P.shape[1], _lib.ptr(self._tgraph[0]),
+                              _lib.ptr(self._nn_table), _lib.ptr(P), P.shape[1], _lib.ptr(self._tgraph[0]),
                               _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]), 2,
                               float(self.early_exaggeration_coeff_), 0.0, 0, None, 0, int(self.n_iter_),
                               _lib.ptr(grad), st),

@@ -42,9 +42,9 @@ class TSNEkhorn(NeighborEmbedding):
         self.tol_affinity_in = tol_affinity_in
         self.unrolling = bool_arg(unrolling)
         self.symmetric_affinity = bool_arg(symmetric_affinity)
-        if self.unrolling or not self.symmetric_affinity or n_components != 2:
+        if self.unrolling or not self.symmetric_affinity or n_components not in (2, 3):
             raise NotImplementedError(
-                "[torchdr_amd] TSNEkhorn: unrolling=True, symmetric_affinity=False and n_components != 2 "
+                "[torchdr_amd] TSNEkhorn: unrolling=True, symmetric_affinity=False and n_components outside {2, 3} "
                 "are not part of the accelerated path."
             )
         affinity_in = SymmetricEntropicAffinity(perplexity=perplexity, lr=lr_affinity_in,
@@ -70,12 +70,13 @@ class TSNEkhorn(NeighborEmbedding):
         Z = self.embedding_.detach()
         dual = self.affinity_out.fit_dual(Z, init_dual=self.dual_sinkhorn_)  # 5 warm-started passes (:214-216)
         self.dual_sinkhorn_ = dual.detach()
-        side = torch.stack([self._mu, self._e, Z[:, 0], Z[:, 1], dual.exp()], dim=1).contiguous()
-        grad = torch.empty((n, 2), dtype=torch.float32, device=self.device_)
+        nc = self.n_components
+        side = torch.cat([self._mu[:, None], self._e[:, None], Z, dual.exp()[:, None]], dim=1).contiguous()
+        grad = torch.empty((n, nc), dtype=torch.float32, device=self.device_)
         _lib.check(
-            _lib.lib().tdr_khorn_grad_f32(_lib.ptr(self._packed.data), n, self._packed.d, _lib.ptr(side),
-                                          math.log(n), _lib.ptr(grad), _lib.stream_ptr()),
-            "tdr_khorn_grad_f32",
+            _lib.lib().tdr_khorn_grad_nc_f32(_lib.ptr(self._packed.data), n, self._packed.d, _lib.ptr(side), nc,
+                                             math.log(n), _lib.ptr(grad), _lib.stream_ptr()),
+            "tdr_khorn_grad_nc_f32",
         )
         return grad, False
 
