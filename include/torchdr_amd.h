@@ -186,6 +186,11 @@ int tdr_sym_fill_f32(int64_t n, int k, int64_t row_offset, int mode, const int32
 /* CSR -> padded (n, width) with (0, -1) fill (pack_to_rowwise, utils/sparse.py:89-135). */
 int tdr_csr_to_padded_f32(const int64_t* rowptr, const int32_t* cols, const float* vals, int64_t n, int64_t width,
                           float* pv, int64_t* pi, void* stream);
+/* Renumbered copy of a square CSR graph (no reference counterpart: the embedding loop of UMAP numbers the points in the
+ * cluster-sorted order of the kNN stage so that a row's neighbours share cache lines): new row j = old row perm[j], column
+ * c -> inv[c] with inv[perm[j]] = j; new_rowptr (n + 1) = running sum of the permuted degrees. */
+int tdr_csr_permute_f32(const int64_t* rowptr, const int32_t* cols, const float* vals, int64_t n, const int32_t* perm,
+                        const int32_t* inv, const int64_t* new_rowptr, int32_t* new_cols, float* new_vals, void* stream);
 
 /* ---- multi-GPU context: an RCCL communicator behind the C ABI (csrc/tdr_ctx.hip) ----------------------------------
  * One process per GPU.  The collectives are enqueued on the caller's stream (no host synchronisation; capturable into the

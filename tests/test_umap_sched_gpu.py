@@ -291,6 +291,10 @@ def test_joint_slice_launch_is_bit_identical(S, nc):
                 a = sc.grad(Z, tl, tl, 1.577, 0.895, 40, neg=inj, seed=99, geom=geom)
                 b = sc.grad(Z, tl, tl, 1.577, 0.895, 40, neg=inj, seed=99, geom=geom | 16)
                 assert torch.equal(a, b), (S, nc, tl, geom, inj is None)
+                if geom == 0:   # geom & 64: a workgroup's rows dealt to its row groups by active count -- same rows, same sums
+                    c = sc.grad(Z, tl, tl, 1.577, 0.895, 40, neg=inj, seed=99, geom=64)
+                    d = sc.grad(Z, tl, tl, 1.577, 0.895, 40, neg=inj, seed=99, geom=16 | 64)
+                    assert torch.equal(a, c) and torch.equal(a, d), (S, nc, tl, inj is None)
 
 
 def test_in_kernel_negatives_vs_oracle_large_and_wide():
@@ -490,3 +494,74 @@ def test_umap_with_more_embedding_dimensions(nc):
     _, I = pairwise_distances(Z.contiguous(), metric="sqeuclidean", k=5, exclude_diag=True, return_indices=True)
     agree = float((labels[I.long()] == labels[:, None]).float().mean())
     assert agree > (0.5 if nc == 1 else 0.85), agree
+
+
+# ---- the loop's row numbering (cluster-sorted order of the kNN stage) ---------------------------------------------------
+def test_csr_permute_kernel_vs_torch():
+    from torchdr_amd import _lib
+
+    n = 3000
+    rowptr, cols, vals = random_graph(n, seed=77)
+    rowptr, cols, vals = rowptr.cuda(), cols.cuda(), vals.cuda()
+    gen = torch.Generator().manual_seed(3)
+    perm = torch.randperm(n, generator=gen).cuda()
+    inv = torch.empty(n, dtype=torch.int64, device="cuda")
+    inv[perm] = torch.arange(n, device="cuda")
+    deg = (rowptr[1:] - rowptr[:-1])[perm]
+    new_rowptr = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    new_rowptr[1:] = deg.cumsum(0)
+    nc, nv = torch.empty_like(cols), torch.empty_like(vals)
+    p32, i32 = perm.to(torch.int32).contiguous(), inv.to(torch.int32).contiguous()
+    _lib.check(_lib.lib().tdr_csr_permute_f32(_lib.ptr(rowptr), _lib.ptr(cols), _lib.ptr(vals), n, _lib.ptr(p32), _lib.ptr(i32),
+                                              _lib.ptr(new_rowptr), _lib.ptr(nc), _lib.ptr(nv), _lib.stream_ptr()), "permute")
+    erow = torch.repeat_interleave(torch.arange(n, device="cuda"), deg)
+    src = rowptr[perm][erow] + (torch.arange(erow.numel(), device="cuda") - new_rowptr[erow])
+    assert torch.equal(nc.long(), inv[cols[src].long()]) and torch.equal(nv, vals[src])
+
+
+def test_umap_loop_in_cluster_order_is_the_same_fit():
+    """RELABEL: the loop numbers the points in the kNN stage's cluster-sorted order.  (1) It is the fit of the rows handed
+    over in that order (same graph, same initial embedding, same negatives -- the sampler is keyed by loop row numbers),
+    returned in the caller's order: compared with an unrelabelled fit of X[order].  (2) Same random_state, same embedding,
+    bit for bit, on every run (the order itself is canonical)."""
+    import torchdr_amd
+    from torchdr_amd.distance import base as dbase
+    from torchdr_amd.neighbor_embedding import umap as U
+
+    n = 20000
+    X = gmm(n, 32, 2.0, seed=3).cuda()
+    init = torch.randn(n, 2, generator=torch.Generator().manual_seed(1)).cuda()
+    old_mode, old_rel = dbase.PRUNE_MODE, U.RELABEL
+    try:
+        dbase.PRUNE_MODE = "force"
+        U.RELABEL = True
+        # three iterations: the clamped forces make the dynamics sign-driven (a row whose force sum is near zero flips by
+        # 8 lr on a last-bit difference), so longer runs of the two fits drift apart
+        kw = dict(n_neighbors=15, max_iter=3, random_state=0)
+        m1 = torchdr_amd.UMAP(init=init, **kw)
+        Z1 = m1.fit_transform(X)
+        order = m1.loop_order_
+        assert order is not None and torch.equal(order.sort().values, torch.arange(n, device="cuda"))
+        m1b = torchdr_amd.UMAP(init=init, **kw)
+        assert torch.equal(m1b.fit_transform(X), Z1) and torch.equal(m1b.loop_order_, order)
+        U.RELABEL = False
+        m2 = torchdr_amd.UMAP(init=init[order].contiguous(), **kw)
+        Z2 = m2.fit_transform(X[order].contiguous())
+        assert m2.loop_order_ is None
+    finally:
+        dbase.PRUNE_MODE, U.RELABEL = old_mode, old_rel
+    # same arithmetic up to the order in which a row's edges are listed (ties of the layout sort) and summed
+    err = (Z1[order] - Z2).abs().max(1).values / Z2.abs().max()
+    assert float(err.median()) < 1e-5 and float((err > 1e-3).float().mean()) < 0.01, (float(err.median()), float(err.quantile(0.99)), float(err.max()))
+    # a subclass that looks at rows during the optimisation keeps the caller's numbering
+    class Watching(torchdr_amd.UMAP):
+        def on_training_step_end(self):
+            super().on_training_step_end()
+
+    try:
+        dbase.PRUNE_MODE = "force"
+        w = Watching(init=init, **kw)
+        w.fit_transform(X)
+        assert w.loop_order_ is None
+    finally:
+        dbase.PRUNE_MODE = old_mode

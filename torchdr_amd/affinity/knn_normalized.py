@@ -73,7 +73,12 @@ class UMAPAffinity(SparseAffinity):
             return (P, None) if return_indices else P
         if self.verbose:
             self.logger.info(f"Sparsity mode enabled, computing {n_neighbors} nearest neighbors...")
+        from torchdr_amd.distance import base as _dbase
+
+        _dbase.LAST_KNN["cluster_order"] = None
         C_, indices = self._distance_matrix(X, k=int(n_neighbors), return_indices=True)
+        # single-GPU pruned search: the cluster-sorted row order it worked in (UMAP renumbers its loop in that order)
+        self._row_order = _dbase.LAST_KNN.get("cluster_order") if not self.is_multi_gpu else None
         rho, eps, P = umap_sigma_search(C_, n_neighbors, self.max_iter)
         self.register_buffer("rho_", rho, persistent=False)
         self.register_buffer("eps_", eps, persistent=False)

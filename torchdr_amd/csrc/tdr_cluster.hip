@@ -13,7 +13,7 @@
 //                  random projection small enough for registers was tried first and mis-seeds ~1 % of the blobs, which
 //                  costs the pruned scan 5x)
 //   3. Lloyd       nearest centre of the sample / of all N points through the exact kNN kernel with k = 1 (K1), centroid
-//                  sums by atomics
+//                  sums in sample order (one workgroup per cluster)
 //   4. bounds      radius_c = max |x - c| over the members (direct difference, rounded up), centre distance matrix
 //                  (direct difference, rounded down), visiting order = per-row rank sort of the centre distances
 //   5. layout      members of a cluster contiguous, every cluster padded to a multiple of 32 rows (row_map, -1 = padding)
@@ -89,23 +89,36 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     out[e] = X[row * ldx + c];
 }
 
-// ---- 3. Lloyd update: sums[label] += x, cnt[label] += 1 (one wavefront per point), then cent = sums / cnt -----------------
-__global__ __launch_bounds__(256) void centroid_accumulate_kernel(const float* __restrict__ Xs, int64_t S, int d,
-                                                                  const int32_t* __restrict__ labels, float* __restrict__ sums,
-                                                                  int32_t* __restrict__ cnt) {
-    const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= S) return;
-    const int l = labels[s];
-    for (int c = lane; c < d; c += 64) unsafeAtomicAdd(&sums[(size_t)l * d + c], Xs[s * d + c]);
-    if (lane == 0) atomicAdd(&cnt[l], 1);
-}
-__global__ __launch_bounds__(256) void centroid_finalize_kernel(const float* __restrict__ sums, const int32_t* __restrict__ cnt,
-                                                                int C, int d, float* __restrict__ cent) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= C * d) return;
-    const int n = cnt[e / d];
-    if (n > 0) cent[e] = sums[e] / (float)n;  // an empty cluster keeps its centre
+// ---- 3. Lloyd update: cent[l] = mean of the sample points labelled l.  One workgroup per cluster, one thread per feature
+// column, members added in sample order: the centres -- and with them the assignments and the cluster-sorted order that
+// callers renumber their points by -- are the same on every run (atomics would make the last bits depend on arrival order).
+// The labels pass through LDS 16384 at a time; the membership test is uniform across the workgroup.
+constexpr int CL_LAB = 16384;
+__global__ __launch_bounds__(256) void centroid_update_kernel(const float* __restrict__ Xs, int64_t S, int d,
+                                                              const int32_t* __restrict__ labels, float* __restrict__ cent) {
+    __shared__ short lab[CL_LAB];
+    const int l = blockIdx.x;
+    for (int c0 = 0; c0 < d; c0 += 256) {
+        const int c = c0 + threadIdx.x;
+        float sum = 0.f;
+        int n = 0;
+        for (int64_t s0 = 0; s0 < S; s0 += CL_LAB) {
+            const int m = (int)((S - s0 < CL_LAB) ? S - s0 : CL_LAB);
+            __syncthreads();
+            for (int s = threadIdx.x; s < m; s += 256) lab[s] = (short)labels[s0 + s];
+            __syncthreads();
+            if (c < d) {
+#pragma unroll 4
+                for (int s = 0; s < m; ++s) {
+                    if (lab[s] == (short)l) {
+                        sum += Xs[(size_t)(s0 + s) * d + c];
+                        ++n;
+                    }
+                }
+            }
+        }
+        if (c < d && n > 0) cent[(size_t)l * d + c] = sum / (float)n;  // an empty cluster keeps its centre
+    }
 }
 
 // ---- 4. bounds ----------------------------------------------------------------------------------------------------------
@@ -241,15 +254,10 @@ int tdr_gather_rows_f32(const float* X, int64_t ldx, int d, const int32_t* idx, 
 /* 3. one Lloyd update on the sample: cent (C, d) <- mean of the sample points labelled c (clusters without points keep
  * their centre).  ws: C * d floats + C int32. */
 int tdr_cluster_update_f32(const float* Xs, int64_t S, int d, const int32_t* labels, int C, float* cent, void* ws, void* stream) {
-    if (!Xs || !labels || !cent || !ws || S <= 0 || d <= 0 || C <= 0) return TDR_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    float* sums = (float*)ws;
-    int32_t* cnt = (int32_t*)(sums + (size_t)C * d);
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)C * d * 4 + (size_t)C * 4, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(centroid_accumulate_kernel, dim3((unsigned)((S + 3) / 4)), dim3(256), 0, st, Xs, S, d, labels, sums, cnt);
-    hipLaunchKernelGGL(centroid_finalize_kernel, dim3((unsigned)((C * d + 255) / 256)), dim3(256), 0, st, (const float*)sums,
-                       (const int32_t*)cnt, C, d, cent);
+    if (!Xs || !labels || !cent || S <= 0 || d <= 0 || C <= 0) return TDR_ERR_BAD_ARG;
+    if (C > 32767) return TDR_ERR_UNSUPPORTED;
+    (void)ws;  // kept in the signature: the update needs no scratch any more
+    hipLaunchKernelGGL(centroid_update_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, Xs, S, d, labels, cent);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

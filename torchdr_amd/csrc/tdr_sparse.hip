@@ -314,6 +314,23 @@ __global__ __launch_bounds__(256) void csr_to_padded_kernel(const int64_t* __res
     else { pv[idx] = 0.f; pi[idx] = -1; }
 }
 
+// Renumbered copy of a square CSR graph: new row j is old row perm[j], every column c becomes inv[c] (inv[perm[j]] = j);
+// new_rowptr is the running sum of the permuted degrees (the caller's).  16 lanes per row.
+__global__ __launch_bounds__(256) void csr_permute_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                          const float* __restrict__ vals, int64_t n, const int32_t* __restrict__ perm,
+                                                          const int32_t* __restrict__ inv, const int64_t* __restrict__ new_rowptr,
+                                                          int32_t* __restrict__ new_cols, float* __restrict__ new_vals) {
+    const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    if (j >= n) return;
+    const int64_t o = perm[j];
+    const int64_t src = rowptr[o], len = rowptr[o + 1] - src, dst = new_rowptr[j];
+    for (int64_t e = l; e < len; e += 16) {
+        new_cols[dst + e] = inv[cols[src + e]];
+        new_vals[dst + e] = vals[src + e];
+    }
+}
+
 }  // namespace tdr
 
 using namespace tdr;
@@ -409,6 +426,14 @@ int tdr_csr_to_padded_f32(const int64_t* rowptr, const int32_t* cols, const floa
     if (!rowptr || !pv || !pi || n <= 0 || width < 0) return TDR_ERR_BAD_ARG;
     if (width == 0) return TDR_OK;
     hipLaunchKernelGGL(csr_to_padded_kernel, dim3((unsigned)((n * width + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rowptr, cols, vals, n, width, pv, pi);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+int tdr_csr_permute_f32(const int64_t* rowptr, const int32_t* cols, const float* vals, int64_t n, const int32_t* perm,
+                        const int32_t* inv, const int64_t* new_rowptr, int32_t* new_cols, float* new_vals, void* stream) {
+    if (!rowptr || !cols || !vals || !perm || !inv || !new_rowptr || !new_cols || !new_vals || n <= 0) return TDR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(csr_permute_kernel, dim3((unsigned)((n * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rowptr, cols, vals,
+                       n, perm, inv, new_rowptr, new_cols, new_vals);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

@@ -346,6 +346,7 @@ struct SchedGradParams {
     // joint launch: ALL slices in one grid, workgroup b on XCD b % 8 (round-robin dispatch) takes slice (b % 8) / (8 / S),
     // so every XCD's L2 still holds one slice; partial sums go to plane `slice` of acc and a combine kernel finishes
     int joint;
+    int sort_rows;                  // 1: the 64 rows of a workgroup are dealt to its row groups in order of their active counts
     int nc;                         // actual row width of Z / grad / acc (PAD instances: NC is the padded register width)
     uint32_t j_r_lo[8], j_r_len[8], j_lvl_xor[8][3];
     int j_lvl_upper[8][3];
@@ -409,11 +410,45 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
 #pragma unroll
         for (int l = 0; l < 3; ++l) { lvl_xor[l] = P.j_lvl_xor[slice][l]; lvl_upper[l] = P.j_lvl_upper[slice][l]; }
     }
-    const int64_t r = (blk * 256 + threadIdx.x) / G;
-    if (r >= P.n_rows) return;
+    int64_t r = (blk * 256 + threadIdx.x) / G;
+    uint2 h;
+    if (G == 4 && P.sort_rows) {
+        // A wavefront runs as many rounds as the busiest of its 16 rows (a row has 5 negatives per fired edge: ~26 items
+        // per slice, sigma ~9, a round is 16 items).  Counting sort of the workgroup's 64 rows by active count: rows with
+        // similar item counts share a wavefront.  Which row group evaluates a row does not enter its result.
+        __shared__ int s_hist[64];
+        __shared__ uint2 s_hdr[64];
+        __shared__ int s_row[64];
+        const int slot = threadIdx.x >> 2, lane = threadIdx.x & 63;
+        const bool have = r < P.n_rows;
+        uint2 h0 = make_uint2(0u, 0u);
+        if (have) h0 = P.hdr[(size_t)(P.t_local * P.S + slice) * P.n_rows + r];
+        int key = have ? (int)(h0.y >> 16) : 63;
+        key = key > 62 && have ? 62 : key;
+        if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
+        __syncthreads();
+        int within = 0;
+        if (gl == 0) within = atomicAdd(&s_hist[key], 1);
+        __syncthreads();
+        const int cnt = s_hist[lane];
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        const int rank = __shfl(incl - cnt, key, 64) + within;
+        if (gl == 0) { s_hdr[rank] = h0; s_row[rank] = slot; }
+        __syncthreads();
+        r = blk * 64 + s_row[slot];
+        h = s_hdr[slot];
+        if (r >= P.n_rows) return;
+    } else {
+        if (r >= P.n_rows) return;
+        h = P.hdr[(size_t)(P.t_local * P.S + slice) * P.n_rows + r];
+    }
     const uint32_t gi = (uint32_t)(P.row0 + r);
     const Vec<NC> zi = load_row(gi);
-    const uint2 h = P.hdr[(size_t)(P.t_local * P.S + slice) * P.n_rows + r];
     const int32_t* lst = P.list + h.x;
     const int npos = (int)(h.y & 0xffffu);
     int n_use = (int)(h.y >> 16) * P.neg_rate;
@@ -703,6 +738,7 @@ static int launch_sched_build(const SchedBuildParams& P0, hipStream_t st, bool s
 // slices spread over the XCDs and a combine kernel; acc must then hold S planes of (n_rows, 2 nc) floats
 static int launch_sched_grad_all(SchedGradParams& P, int geom, hipStream_t st) {
     P.joint = 0;
+    P.sort_rows = (geom & 64) ? 1 : 0;
     if ((geom & 16) && P.S > 1) {
         for (int s = 0; s < P.S; ++s) {
             sched_pass_constants(P, s);

@@ -398,6 +398,9 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
         _screen_fallback(Q, Y, q0, k, metric, exclude_self, q_offset, flags.nonzero().squeeze(1), out_d, out_i)
     LAST_KNN["tier"] = tier
     LAST_KNN["pruned"] = bool(prune)
+    # the cluster-sorted row order of a pruned self search (source row of every position, -1 in the padding; cluster of
+    # every 32 positions): callers that go on to gather rows by neighbour index (the UMAP loop) renumber the points in it
+    LAST_KNN["cluster_order"] = (ci.row_map, ci.tile_cluster) if prune else None
     return bad
 
 
@@ -454,6 +457,7 @@ def _knn_ivf(Y: "PackedPoints", k: int, metric: str, exclude_self: bool, nlist: 
     if bad:  # spare list slots overflowed: those rows are searched exactly
         _screen_fallback(Y, Y, 0, k, metric, exclude_self, 0, flags.nonzero().squeeze(1), out_d, out_i)
     LAST_KNN["path"], LAST_KNN["flagged"], LAST_KNN["tier"], LAST_KNN["pruned"] = f"ivf (nlist={ci.n_clusters}, nprobe={nprobe})", bad, tier, False
+    LAST_KNN["cluster_order"] = (ci.row_map, ci.tile_cluster)
     return out_d, out_i
 
 
@@ -553,6 +557,8 @@ def knn_packed(
     dev = Y.device
     out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    if _allow_screen:
+        LAST_KNN["cluster_order"] = None
     if _allow_screen and _use_screen(Q, Y, nq, k, metric):
         bad = _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i)
         if bad >= 0:
