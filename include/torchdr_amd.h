@@ -265,7 +265,8 @@ int tdr_umap_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t
  *          {1, 2, 4, 8} (tdr_umap_sched_slices = automatic choice); geom: low 4 bits = lanes per row (0 = default), bit 4
  *          (16) = all slices in ONE launch spread over the XCDs (workgroup b takes slice (b % 8) / (8 / n_slices)) plus a
  *          combine kernel -- acc then holds n_slices planes of (n_rows, 2 nc) floats; same gradient bit for bit; bit 5 (32):
- *          see tdr_umap_sched_step_f32. */
+ *          see tdr_umap_sched_step_f32; bit 6 (64): with 4 lanes per row, the 64 rows of a workgroup are dealt to its
+ *          wavefronts in order of their active counts (fewer masked rounds; same gradient bit for bit). */
 int tdr_umap_sched_slices(int64_t n_total, int nc);
 /* loop layout: every row's (cols, eps_per) reordered by ascending eps_per (often-firing edges first) */
 int tdr_umap_sched_layout_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, int64_t n_rows,

@@ -220,3 +220,30 @@ def test_headline_size_search_sampled_against_the_one_stage_kernel():
     dij = C[rows]
     back = (I[j.reshape(-1)].reshape(len(rows), k, k) == rows[:, None, None].int()).any(2)
     assert bool((back | (C[j.reshape(-1), k - 1].reshape(len(rows), k) <= dij)).all())
+
+
+def test_cluster_index_is_the_same_on_every_run():
+    """The Lloyd update sums a cluster's members in sample order (no atomics): centres equal the per-label means, and two
+    builds of the index give the same labels bit for bit -- callers renumber their points by this order (UMAP's loop)."""
+    from torchdr_amd import _lib
+    from torchdr_amd.distance.base import ClusterIndex, PackedPoints
+
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(4)
+    S, d, C = 5000, 48, 37
+    Xs = torch.randn(S, d, generator=gen).cuda()
+    labels = torch.randint(0, C - 1, (S,), generator=gen).to(torch.int32).cuda()   # cluster C - 1 stays empty
+    cent0 = torch.randn(C, d, generator=gen).cuda()
+    cent = cent0.clone()
+    ws = torch.empty(C * d + 3 * C, dtype=torch.int32, device="cuda")
+    _lib.check(L.tdr_cluster_update_f32(_lib.ptr(Xs), S, d, _lib.ptr(labels), C, _lib.ptr(cent), _lib.ptr(ws), _lib.stream_ptr()), "update")
+    ref = torch.stack([Xs[labels == c].double().mean(0) for c in range(C - 1)])
+    assert torch.allclose(cent[:-1].double(), ref, rtol=1e-5, atol=1e-6)
+    assert torch.equal(cent[-1], cent0[-1])
+    cent2 = cent0.clone()
+    _lib.check(L.tdr_cluster_update_f32(_lib.ptr(Xs), S, d, _lib.ptr(labels), C, _lib.ptr(cent2), _lib.ptr(ws), _lib.stream_ptr()), "update")
+    assert torch.equal(cent, cent2)
+    X = gmm(60000, 32, 2.0, seed=12).cuda()
+    a, b = ClusterIndex(PackedPoints(X)), ClusterIndex(PackedPoints(X))
+    assert a.n_img == b.n_img and torch.equal(a.tile_cluster, b.tile_cluster) and torch.equal(a.radius, b.radius)
+    assert torch.equal(a.row_map.sort().values, b.row_map.sort().values)

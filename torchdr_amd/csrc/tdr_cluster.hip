@@ -92,32 +92,43 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // ---- 3. Lloyd update: cent[l] = mean of the sample points labelled l.  One workgroup per cluster, one thread per feature
 // column, members added in sample order: the centres -- and with them the assignments and the cluster-sorted order that
 // callers renumber their points by -- are the same on every run (atomics would make the last bits depend on arrival order).
-// The labels pass through LDS 16384 at a time; the membership test is uniform across the workgroup.
-constexpr int CL_LAB = 16384;
+// The workgroup tests 256 labels at a time (one ballot per wavefront, double-buffered in LDS: one barrier per chunk) and
+// walks the set bits in order; a cluster has ~8 members among the 8 C samples, so most chunks cost the test alone.
 __global__ __launch_bounds__(256) void centroid_update_kernel(const float* __restrict__ Xs, int64_t S, int d,
                                                               const int32_t* __restrict__ labels, float* __restrict__ cent) {
-    __shared__ short lab[CL_LAB];
-    const int l = blockIdx.x;
-    for (int c0 = 0; c0 < d; c0 += 256) {
-        const int c = c0 + threadIdx.x;
-        float sum = 0.f;
-        int n = 0;
-        for (int64_t s0 = 0; s0 < S; s0 += CL_LAB) {
-            const int m = (int)((S - s0 < CL_LAB) ? S - s0 : CL_LAB);
+    __shared__ unsigned long long wmask[2][4];
+    const int l = blockIdx.x, w = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < d; c0 += 1024) {
+        float sum[4] = {0.f, 0.f, 0.f, 0.f};
+        int n = 0, it = 0;
+        for (int64_t s0 = 0; s0 < S; s0 += 256, ++it) {
+            const int64_t s = s0 + threadIdx.x;
+            const bool hit = s < S && labels[s] == l;
+            const unsigned long long m = __ballot(hit);
+            if ((threadIdx.x & 63) == 0) wmask[it & 1][w] = m;
             __syncthreads();
-            for (int s = threadIdx.x; s < m; s += 256) lab[s] = (short)labels[s0 + s];
-            __syncthreads();
-            if (c < d) {
-#pragma unroll 4
-                for (int s = 0; s < m; ++s) {
-                    if (lab[s] == (short)l) {
-                        sum += Xs[(size_t)(s0 + s) * d + c];
-                        ++n;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                unsigned long long mm = wmask[it & 1][ww];
+                while (mm) {
+                    const int bpos = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    const float* row = Xs + (size_t)(s0 + ww * 64 + bpos) * d;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = c0 + q * 256 + threadIdx.x;
+                        if (c < d) sum[q] += row[c];
                     }
+                    ++n;
                 }
             }
         }
-        if (c < d && n > 0) cent[(size_t)l * d + c] = sum / (float)n;  // an empty cluster keeps its centre
+        __syncthreads();  // the next column group starts over with buffer 0
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + q * 256 + threadIdx.x;
+            if (c < d && n > 0) cent[(size_t)l * d + c] = sum[q] / (float)n;  // an empty cluster keeps its centre
+        }
     }
 }
 
@@ -255,7 +266,6 @@ int tdr_gather_rows_f32(const float* X, int64_t ldx, int d, const int32_t* idx, 
  * their centre).  ws: C * d floats + C int32. */
 int tdr_cluster_update_f32(const float* Xs, int64_t S, int d, const int32_t* labels, int C, float* cent, void* ws, void* stream) {
     if (!Xs || !labels || !cent || S <= 0 || d <= 0 || C <= 0) return TDR_ERR_BAD_ARG;
-    if (C > 32767) return TDR_ERR_UNSUPPORTED;
     (void)ws;  // kept in the signature: the update needs no scratch any more
     hipLaunchKernelGGL(centroid_update_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, Xs, S, d, labels, cent);
     TDR_CHECK_LAUNCH();
