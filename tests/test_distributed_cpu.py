@@ -252,3 +252,50 @@ def test_faiss_config_and_approximate_search_routing():
                  (cfg, True, 15, 50_000, 64, "angular"), (cfg, True, 15, 50_000, 300, "sqeuclidean"),
                  (cfg, True, 15, 2000, 64, "sqeuclidean")):
         assert _ivf_request(*args) is None, args
+
+
+def test_umap_renumbers_its_loop_only_when_nobody_watches():
+    """Host logic of UMAP's cluster-order numbering: eligible for the stock class on one rank with a float32 graph of all
+    rows; any overridden hook, a neighbour-exclusion table, injected negatives, row shards or a float64 graph keep the
+    caller's numbering.  Without an order from the kNN stage `_relabel` hands back the graph it was given."""
+    import torch
+
+    import torchdr_amd
+    from torchdr_amd.utils.sparse import CSRAffinity
+
+    def graph(dtype=torch.float32, n_total=None):
+        return CSRAffinity(torch.tensor([0, 1, 2, 3]), torch.tensor([1, 2, 0], dtype=torch.int32), torch.ones(3, dtype=dtype),
+                           n_total=n_total)
+
+    def prepared(cls=torchdr_amd.UMAP, **kw):
+        m = cls(n_neighbors=2, max_iter=3, **kw)
+        m._csr, m.n_samples_in_, m.world_size = graph(), 3, 1
+        return m
+
+    assert prepared()._relabel_eligible()
+    assert not prepared(discard_NNs=True)._relabel_eligible()
+    m = prepared()
+    m.neg_indices_ = torch.zeros((3, 10), dtype=torch.int64)
+    assert not m._relabel_eligible()
+    m = prepared()
+    m.world_size = 2
+    assert not m._relabel_eligible()
+    m = prepared()
+    m._csr = graph(torch.float64)
+    assert not m._relabel_eligible()
+    m = prepared()
+    m._csr = graph(n_total=6)     # a row shard of a larger graph
+    assert not m._relabel_eligible()
+
+    class Watching(torchdr_amd.UMAP):
+        def on_training_step_end(self):
+            super().on_training_step_end()
+
+    class OwnInit(torchdr_amd.UMAP):
+        def _init_embedding(self, X):
+            return super()._init_embedding(X)
+
+    assert not prepared(Watching)._relabel_eligible() and not prepared(OwnInit)._relabel_eligible()
+    m = prepared()
+    m.affinity_in._row_order = None
+    assert m._relabel() is m._csr and m.loop_order_ is None
