@@ -112,7 +112,10 @@ class ClusterIndex:
     Built by the package's own kernels (``csrc/tdr_cluster.hip``; nearest-centre assignments are the exact kNN kernel
     with k = 1) -- the search result does not depend on it, only the amount of work the scan can skip does."""
 
-    def __init__(self, P: "PackedPoints", n_clusters: Optional[int] = None, iters: int = 2):
+    def __init__(self, P: "PackedPoints", n_clusters: Optional[int] = None, iters: int = 2, defer: bool = False):
+        """``defer``: enqueue the build and return; ``finish()`` (the one host read, of the padded image's row count) is
+        called later -- the pruned search enqueues its pilot launches in between, so that the single-workgroup seeding
+        kernel is already running when the pilots fill the register files of every CU."""
         X = P.X
         dev = X.device
         N, D = X.shape
@@ -162,15 +165,25 @@ class ClusterIndex:
             "tdr_cluster_tables_f32",
         )
         self.n_clusters = C
-        self.n_img = max(int(n_img.item()), 32)
-        self.row_map = row_map[: self.n_img]
-        self.tile_cluster = tile_cluster[: self.n_img // 32]
         self.tile_begin = tile_begin
         self.radius = radius     # rounded up in the kernel
         self.dist = cd           # rounded down in the kernel
         self.order = order
         self.img16 = None
+        self._pending = (n_img, row_map, tile_cluster, tiles)
+        if not defer:
+            self.finish()
+
+    def finish(self):
+        if self._pending is None:
+            return self
+        n_img, row_map, tile_cluster, tiles = self._pending
+        self._pending = None
+        self.n_img = max(int(n_img.item()), 32)
+        self.row_map = row_map[: self.n_img]
+        self.tile_cluster = tile_cluster[: self.n_img // 32]
         self.tiles = tiles.to(torch.int64)
+        return self
 
     def scan_fraction(self, tau: float) -> float:
         """Share of the database tiles a query block still has to visit when its thresholds are <= tau (squared
@@ -277,18 +290,26 @@ def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset, side_work=Non
         return pd, n_flagged
 
     runs = {}
+    side_start, side_finish = side_work if side_work is not None else (None, None)
+    if side_start is not None and PILOT_CONCURRENT:
+        # first in: its single-workgroup seeding kernel (4 ms of dependent steps) must hold a CU before the pilots'
+        # workgroups take every register file (two pilots = 2 x 256 registers per lane on every SIMD); enqueued after
+        # them, the whole chain waited for the pilots to drain (19 ms -> ~14 ms until the main scan can start)
+        with torch.cuda.stream(side[1]):
+            side_start()
     if len(tiers) >= 2 and PILOT_CONCURRENT:
         with torch.cuda.stream(side[0]):
             runs[tiers[0]] = launch(tiers[0])
         runs[tiers[1]] = launch(tiers[1])
     elif tiers:
         runs[tiers[0]] = launch(tiers[0])
-    if side_work is not None:
+    if side_finish is not None:
         if PILOT_CONCURRENT:
             with torch.cuda.stream(side[1]):
-                side_work()
+                side_finish()
         else:
-            side_work()
+            side_start()
+            side_finish()
     for sd in side:
         main.wait_stream(sd)
     for tier in tiers:
@@ -322,10 +343,20 @@ def _screen_fallback(Q, Y, q0, k, metric, exclude_self, q_offset, rows, out_d, o
     out_i[rows] = If
 
 
+def _cluster_index_start(Y):
+    """Enqueue the index build (no host read yet); `_cluster_index` completes it."""
+    ci = getattr(Y, "_cluster_index", None)
+    if ci is None:
+        ci = Y._cluster_index = ClusterIndex(Y, defer=True)
+    return ci
+
+
 def _cluster_index(Y, ops, build=True):
     ci = getattr(Y, "_cluster_index", None)
     if ci is None and build:
         ci = Y._cluster_index = ClusterIndex(Y)
+    if ci is not None:
+        ci.finish()
     if ci is not None and ci.img16 is None:
         L = _lib.lib()
         ci.img16 = torch.empty(L.tdr_packed16_floats(ci.n_img, Y.d), dtype=torch.float32, device=Y.device)
@@ -379,7 +410,7 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
     if pilot and nq >= _SCREEN_PILOT_MIN_Q:
         # the index build does not depend on the pilot's outcome: it runs next to it
         tier, pilot_tau = _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset,
-                                       side_work=(lambda: _cluster_index(Y, ops)) if prune else None)
+                                       side_work=((lambda: _cluster_index_start(Y)), (lambda: _cluster_index(Y, ops))) if prune else None)
         if tier < 0:
             return -1
     if prune:
