@@ -78,7 +78,9 @@ class UMAPAffinity(SparseAffinity):
         _dbase.LAST_KNN["cluster_order"] = None
         C_, indices = self._distance_matrix(X, k=int(n_neighbors), return_indices=True)
         # single-GPU pruned search: the cluster-sorted row order it worked in (UMAP renumbers its loop in that order)
-        self._row_order = _dbase.LAST_KNN.get("cluster_order") if not self.is_multi_gpu else None
+        # (taken out of the record: it is this call's, and the record must not keep device memory alive)
+        order = _dbase.LAST_KNN.pop("cluster_order", None)
+        self._row_order = order if not self.is_multi_gpu else None
         rho, eps, P = umap_sigma_search(C_, n_neighbors, self.max_iter)
         self.register_buffer("rho_", rho, persistent=False)
         self.register_buffer("eps_", eps, persistent=False)
