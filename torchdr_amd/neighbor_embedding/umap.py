@@ -134,6 +134,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         self._perm = None
         self.loop_order_ = None     # kept after the fit: caller's row of every loop row, or None when the loop ran unrelabelled
         order = getattr(self.affinity_in, "_row_order", None)
+        self.affinity_in._row_order = None
         if order is None or not self._relabel_eligible():
             return self._csr
         csr, n, dev = self._csr, self._csr.n, self._csr.vals.device
