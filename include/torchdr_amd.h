@@ -236,6 +236,10 @@ int tdr_pca_gram_f32(const float* X, int64_t n, int d, int64_t ldx, float* mean,
                      void* stream);
 int tdr_pca_project_f32(const float* X, int64_t n, int d, int64_t ldx, const float* mean, const float* V, int nc, float* E,
                         void* stream);
+/* the d x d eigenproblem between the two (spectral_embedding/pca.py:169-178 uses a thin SVD of the centred block): one-sided
+ * Jacobi in one workgroup, no host read -- evals (d) descending, evecs (d, d) row-major with column r the eigenvector of
+ * evals[r]; G symmetric positive semi-definite, d <= 256; ws = 2 d^2 doubles. */
+int tdr_eigh_jacobi_f64(const double* G, int d, double* evals, double* evecs, double* ws, void* stream);
 
 /* ---- K5 / K6 / K9: embedding loop ----------------------------------------------------------------- */
 /* neighbor_embedding/umap.py:215-234 */

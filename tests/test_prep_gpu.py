@@ -86,3 +86,45 @@ def test_pca_initialisation_matches_the_torch_formulation():
         sg = torch.sign(ref[idx, torch.arange(2, device="cuda")])
         ref = ref * sg
         assert torch.allclose(E.double(), ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max())), (n, d)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 7, 50, 128, 129, 256])
+def test_jacobi_eigh_vs_lapack(d):
+    """tdr_eigh_jacobi_f64 (the D x D eigenproblem of the PCA initialisation) against LAPACK in float64 on the host:
+    eigenvalues descending to 1e-12 of the largest, eigenvector residual |G V - V diag(lambda)| and orthogonality at the
+    same level; a rank-deficient Gram matrix (more features than samples) included."""
+    from torchdr_amd import _lib
+
+    gen = torch.Generator().manual_seed(d)
+    n = 40 if d in (50, 129) else 2000          # 40 < d: rank-deficient
+    X = torch.randn(n, d, generator=gen, dtype=torch.float64) * (torch.rand(d, generator=gen, dtype=torch.float64) * 3 + 0.1)
+    X = X - X.mean(0)
+    G = (X.T @ X).contiguous()
+    Gd = G.cuda()
+    evals = torch.empty(d, dtype=torch.float64, device="cuda")
+    evecs = torch.empty((d, d), dtype=torch.float64, device="cuda")
+    ws = torch.empty(2 * d * d, dtype=torch.float64, device="cuda")
+    _lib.check(_lib.lib().tdr_eigh_jacobi_f64(_lib.ptr(Gd), d, _lib.ptr(evals), _lib.ptr(evecs), _lib.ptr(ws), _lib.stream_ptr()),
+               "tdr_eigh_jacobi_f64")
+    ev, V = evals.cpu(), evecs.cpu()
+    ref = torch.linalg.eigvalsh(G).flip(0).clamp_min(0)
+    scale = float(ref[0])
+    assert bool((ev[:-1] >= ev[1:]).all())
+    assert float((ev - ref).abs().max()) < 1e-12 * scale
+    assert float((G @ V - V * ev[None, :]).abs().max()) < 1e-11 * scale
+    assert float((V.T @ V - torch.eye(d, dtype=torch.float64)).abs().max()) < 1e-11
+
+
+def test_pca_scores_same_with_either_eigensolver():
+    from torchdr_amd import affinity_matcher as am
+
+    X = gmm(20000, 64, 2.0, seed=9).cuda()
+    old = am.PCA_EIGH
+    try:
+        am.PCA_EIGH = "jacobi"
+        a = am.pca_scores(X, 2)
+        am.PCA_EIGH = "library"
+        b = am.pca_scores(X, 2)
+    finally:
+        am.PCA_EIGH = old
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))

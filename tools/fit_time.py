@@ -1,6 +1,6 @@
 """GPU probe: wall time of the headline fit (UMAP N = 1M D = 128 k = 30, 1000 iterations) without bench.py's context legs.
 
-    python tools/fit_time.py [N] [reps]        env RELABEL=0/1, GEOM=<int> override the module defaults
+    python tools/fit_time.py [N] [reps]        env RELABEL=0/1, GEOM=<int>, PREFETCH=0/1, EIGH=jacobi/library override the module defaults
 """
 import json
 import os
@@ -21,6 +21,12 @@ if "RELABEL" in os.environ:
     U.RELABEL = os.environ["RELABEL"] == "1"
 if "GEOM" in os.environ:
     U.SCHED_GEOM = int(os.environ["GEOM"])
+from torchdr_amd import affinity_matcher as AM
+
+if "PREFETCH" in os.environ:
+    AM.PCA_PREFETCH = os.environ["PREFETCH"] == "1"
+if "EIGH" in os.environ:
+    AM.PCA_EIGH = os.environ["EIGH"]
 X = gmm(n, 128, 2.0).cuda()
 ts = []
 for r in range(reps + 1):
@@ -30,5 +36,5 @@ for r in range(reps + 1):
     Z = m.fit_transform(X)
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
-print(json.dumps({"n": n, "relabel": U.RELABEL, "geom": U.SCHED_GEOM, "relabelled": m.loop_order_ is not None,
+print(json.dumps({"n": n, "prefetch": AM.PCA_PREFETCH, "eigh": AM.PCA_EIGH, "relabel": U.RELABEL, "geom": U.SCHED_GEOM, "relabelled": m.loop_order_ is not None,
                   "ms_per_fit": ts[1:], "finite": bool(torch.isfinite(Z).all())}))

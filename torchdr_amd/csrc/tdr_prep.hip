@@ -230,6 +230,96 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
     }
 }
 
+// ---- eigen-decomposition of the D x D Gram matrix (PCA initialisation, spectral_embedding/pca.py:169-178) ------------------
+// One-sided Jacobi (Hestenes) in ONE workgroup: the columns of W (= G at the start) are orthogonalised by plane rotations,
+// the same rotations accumulate in V.  For a symmetric positive semi-definite G the limit is W = V diag(lambda): column
+// norms = eigenvalues, V = eigenvectors (relative accuracy ~1e-14 after 6-9 sweeps at D <= 256).  A sweep is D' - 1
+// rounds of D' / 2 disjoint column pairs (round-robin tournament), a pair is worked by `lp` lanes of one wavefront
+// (three dot products, a butterfly reduction that leaves identical bits in every lane, two column updates in W and V);
+// rounds are separated by a workgroup barrier.  No host read anywhere: the decomposition can run on a side stream under
+// the kNN search (the library `eigh` reads its status word back).  W and V live in the caller's workspace (L2-resident).
+constexpr int EIG_TH = 1024;
+constexpr int EIG_MAX_D = 256;
+__global__ __launch_bounds__(EIG_TH) void eigh_jacobi_kernel(const double* __restrict__ G, int d, double* W, double* V,
+                                                             double* __restrict__ evals, double* __restrict__ evecs, int max_sweeps,
+                                                             double tol) {
+    __shared__ int rotated;
+    __shared__ double sig[EIG_MAX_D];
+    __shared__ int perm[EIG_MAX_D];
+    const int tid = threadIdx.x;
+    const int dp = d + (d & 1), n_pairs = dp / 2, m = dp - 1;
+    int lp = 64;
+    while (lp * n_pairs > EIG_TH) lp >>= 1;  // n_pairs <= 128: at least 8 lanes per pair
+    const int pair = tid / lp, l = tid % lp;
+    for (int e = tid; e < d * d; e += EIG_TH) {
+        W[e] = G[e];  // symmetric: column-major = row-major
+        V[e] = (e / d == e % d) ? 1.0 : 0.0;
+    }
+    __threadfence_block();  // one workgroup = one CU = one L1: workgroup scope is enough, no L2 write-back per round
+    __syncthreads();
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (tid == 0) rotated = 0;
+        __syncthreads();
+        for (int r = 0; r < m; ++r) {
+            if (pair < n_pairs) {
+                int a, b;
+                if (pair == 0) { a = dp - 1; b = r; }
+                else { a = (r + pair) % m; b = (r - pair + m) % m; }
+                const int p = a < b ? a : b, q = a < b ? b : a;
+                if (q < d) {  // odd d: the pair with the phantom column rests
+                    double* wp = W + (size_t)p * d;
+                    double* wq = W + (size_t)q * d;
+                    double al = 0.0, be = 0.0, ga = 0.0;
+                    for (int i = l; i < d; i += lp) {
+                        const double x = wp[i], y = wq[i];
+                        al = fma(x, x, al); be = fma(y, y, be); ga = fma(x, y, ga);
+                    }
+                    for (int o = lp >> 1; o > 0; o >>= 1) {
+                        al += __shfl_xor(al, o, 64); be += __shfl_xor(be, o, 64); ga += __shfl_xor(ga, o, 64);
+                    }
+                    const double ab = al * be;
+                    if (ab != 0.0 && fabs(ga) > tol * sqrt(ab)) {
+                        const double z = (be - al) / (2.0 * ga);
+                        const double t = (z < 0.0 ? -1.0 : 1.0) / (fabs(z) + sqrt(1.0 + z * z));
+                        const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+                        double* vp = V + (size_t)p * d;
+                        double* vq = V + (size_t)q * d;
+                        for (int i = l; i < d; i += lp) {
+                            const double x = wp[i], y = wq[i];
+                            wp[i] = c * x - sn * y; wq[i] = sn * x + c * y;
+                            const double u = vp[i], v = vq[i];
+                            vp[i] = c * u - sn * v; vq[i] = sn * u + c * v;
+                        }
+                        if (l == 0) rotated = 1;
+                    }
+                }
+            }
+            __threadfence_block();  // one workgroup = one CU = one L1: workgroup scope is enough, no L2 write-back per round
+            __syncthreads();
+        }
+        const int any = rotated;
+        __syncthreads();
+        if (!any) break;
+    }
+    for (int j = tid; j < d; j += EIG_TH) {
+        double s2 = 0.0;
+        for (int i = 0; i < d; ++i) { const double x = W[(size_t)j * d + i]; s2 = fma(x, x, s2); }
+        sig[j] = sqrt(s2);
+    }
+    __syncthreads();
+    for (int j = tid; j < d; j += EIG_TH) {  // descending, ties by column
+        int rank = 0;
+        for (int k = 0; k < d; ++k) rank += (sig[k] > sig[j] || (sig[k] == sig[j] && k < j)) ? 1 : 0;
+        evals[rank] = sig[j];
+        perm[rank] = j;
+    }
+    __syncthreads();
+    for (int e = tid; e < d * d; e += EIG_TH) {  // evecs (d, d) row-major: column r = eigenvector of the r-th largest eigenvalue
+        const int i = e / d, r = e % d;
+        evecs[e] = V[(size_t)perm[r] * d + i];
+    }
+}
+
 }  // namespace tdr
 
 using namespace tdr;
@@ -339,6 +429,16 @@ int tdr_pca_project_f32(const float* X, int64_t n, int d, int64_t ldx, const flo
     if (!X || !mean || !V || !E || n <= 0 || d <= 0 || ldx < d || nc <= 0) return TDR_ERR_BAD_ARG;
     if (nc > 4) return TDR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(project_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X, n, d, ldx, mean, V, nc, E);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+/* Eigen-decomposition of a symmetric positive semi-definite d x d matrix (d <= 256) without a host read: evals (d)
+ * descending, evecs (d, d) row-major with column r the eigenvector of evals[r]; ws = 2 d^2 doubles. */
+int tdr_eigh_jacobi_f64(const double* G, int d, double* evals, double* evecs, double* ws, void* stream) {
+    if (!G || !evals || !evecs || !ws || d <= 0) return TDR_ERR_BAD_ARG;
+    if (d > EIG_MAX_D) return TDR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(eigh_jacobi_kernel, dim3(1), dim3(EIG_TH), 0, (hipStream_t)stream, G, d, ws, ws + (size_t)d * d, evals, evecs, 40,
+                       1e-15);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
