@@ -299,3 +299,12 @@ def test_umap_renumbers_its_loop_only_when_nobody_watches():
     m = prepared()
     m.affinity_in._row_order = None
     assert m._relabel() is m._csr and m.loop_order_ is None
+
+
+def test_cluster_index_from_broadcast_tables_needs_no_host_read():
+    """Row-sharded pruned search: ranks other than 0 assemble their ClusterIndex from broadcast tables
+    (`ClusterIndex.__new__`), so `finish()` -- the deferred host read of a locally built index -- must be a no-op there."""
+    from torchdr_amd.distance.base import ClusterIndex
+
+    ci = ClusterIndex.__new__(ClusterIndex)
+    assert ci.finish() is ci

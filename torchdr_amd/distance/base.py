@@ -112,6 +112,8 @@ class ClusterIndex:
     Built by the package's own kernels (``csrc/tdr_cluster.hip``; nearest-centre assignments are the exact kNN kernel
     with k = 1) -- the search result does not depend on it, only the amount of work the scan can skip does."""
 
+    _pending = None   # instances assembled from broadcast tables (row-sharded search) have nothing left to read
+
     def __init__(self, P: "PackedPoints", n_clusters: Optional[int] = None, iters: int = 2, defer: bool = False):
         """``defer``: enqueue the build and return; ``finish()`` (the one host read, of the padded image's row count) is
         called later -- the pruned search enqueues its pilot launches in between, so that the single-workgroup seeding
