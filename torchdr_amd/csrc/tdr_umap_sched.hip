@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
     uint2 h;
     if (G == 4 && P.sort_rows) {
         // A wavefront runs as many rounds as the busiest of its 16 rows (a row has 5 negatives per fired edge: ~26 items
-        // per slice, sigma ~9, a round is 16 items).  Counting sort of the workgroup's 64 rows by active count: rows with
+        // per slice, sigma ~13, a round is 16 items: 4.0 rounds per wavefront in order, 2.9 dealt -- tools/round_model.py).  Counting sort of the workgroup's 64 rows by active count: rows with
         // similar item counts share a wavefront.  Which row group evaluates a row does not enter its result.
         __shared__ int s_hist[64];
         __shared__ uint2 s_hdr[64];
