@@ -38,7 +38,8 @@ nxt = eps_per.copy()
 rng = np.random.default_rng(0)
 own_slice = cols * S // n
 # "local": the loop in cluster order -- practically every fired edge stays in the row's own slice
-stats = {"plain": [], "dealt": [], "work": [], "plain_local": [], "dealt_local": []}
+stats = {"plain": [], "dealt": [], "work": [], "plain_local": [], "dealt_local": [], "dealt_pool256": [], "dealt_round8": [],
+         "dealt_exact_key": []}
 row_slice = np.arange(n) * S // n
 for t in range(iters):
     act = nxt <= t + 1
@@ -62,6 +63,15 @@ for t in range(iters):
         stats["plain"].append(plain.mean())
         stats["dealt"].append(dealt.mean())
         stats["work"].append(((npos + nneg)[:m] / 16.0).mean())
+        # variants (what a next step could buy): a pool of 256 rows, rounds of 8 items (in units of 16), the exact item count as key
+        m4 = n // 256 * 256
+        it = (npos + nneg)
+        o4 = np.argsort(fired[:m4].reshape(-1, 256), axis=1, kind="stable")
+        stats["dealt_pool256"].append(np.take_along_axis(rounds[:m4].reshape(-1, 256), o4, 1).reshape(-1, 16, 16).max(2).mean())
+        r8 = (-(-it // 8))[:m].reshape(-1, 64)
+        stats["dealt_round8"].append(np.take_along_axis(r8, order, 1).reshape(-1, 4, 16).max(2).mean() / 2.0)
+        oe = np.argsort(it[:m].reshape(-1, 64), axis=1, kind="stable")
+        stats["dealt_exact_key"].append(np.take_along_axis(blocks, oe, 1).reshape(-1, 4, 16).max(2).mean())
         loc = -(-(np.where(row_slice == s, fired, 0) + nneg) // 16)[:m].reshape(-1, 64)
         stats["plain_local"].append(loc.reshape(-1, 4, 16).max(2).mean())
         stats["dealt_local"].append(np.take_along_axis(loc, order, 1).reshape(-1, 4, 16).max(2).mean())
