@@ -308,3 +308,15 @@ def test_cluster_index_from_broadcast_tables_needs_no_host_read():
 
     ci = ClusterIndex.__new__(ClusterIndex)
     assert ci.finish() is ci
+
+
+def test_top_level_names_of_the_path():
+    """`from torchdr import X` keeps working for every in-scope name of the reference's package root (`torchdr/__init__.py`)."""
+    import torchdr_amd
+
+    for name in ("Affinity", "LogAffinity", "SparseAffinity", "SparseLogAffinity", "EntropicAffinity", "UMAPAffinity",
+                 "SymmetricEntropicAffinity", "SinkhornAffinity", "PACMAPAffinity", "AffinityMatcher", "DRModule",
+                 "NeighborEmbedding", "NegativeSamplingNeighborEmbedding", "UMAP", "LargeVis", "TSNE", "TSNEkhorn", "SNE",
+                 "InfoTSNE", "PACMAP", "COSNE", "pairwise_distances", "eval", "knn_label_accuracy",
+                 "neighborhood_preservation"):
+        assert hasattr(torchdr_amd, name), name

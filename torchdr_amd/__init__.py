@@ -9,3 +9,8 @@ from torchdr_amd.affinity import (  # noqa: F401,E402
     SymmetricEntropicAffinity, SinkhornAffinity, PACMAPAffinity,
 )
 from torchdr_amd.neighbor_embedding import UMAP, LargeVis, TSNE, TSNEkhorn, SNE, InfoTSNE, PACMAP, COSNE  # noqa: F401,E402
+from torchdr_amd.base import DRModule  # noqa: F401,E402
+from torchdr_amd.affinity_matcher import AffinityMatcher  # noqa: F401,E402
+from torchdr_amd.neighbor_embedding.base import NeighborEmbedding, NegativeSamplingNeighborEmbedding  # noqa: F401,E402
+from torchdr_amd import eval  # noqa: F401,E402,A004
+from torchdr_amd.eval import knn_label_accuracy, neighborhood_preservation  # noqa: F401,E402
