@@ -320,3 +320,16 @@ def test_top_level_names_of_the_path():
                  "InfoTSNE", "PACMAP", "COSNE", "pairwise_distances", "eval", "knn_label_accuracy",
                  "neighborhood_preservation"):
         assert hasattr(torchdr_amd, name), name
+
+
+def test_distributed_context_faiss_config():
+    """`DistributedContext.get_faiss_config` (reference distributed/__init__.py:269-309): the caller's settings on the local GPU."""
+    from torchdr_amd.distance import FaissConfig
+    from torchdr_amd.distributed import DistributedContext
+
+    ctx = DistributedContext(force_enable=True)
+    ctx.rank, ctx.world_size, ctx.local_rank = 3, 8, 3
+    assert ctx.get_faiss_config().device == 3 and ctx.get_faiss_config().index_type == "Flat"
+    cfg = ctx.get_faiss_config(FaissConfig(index_type="IVF", nlist=64, nprobe=4, temp_memory=2.0, device=0, use_float16=True))
+    assert (cfg.device, cfg.index_type, cfg.nlist, cfg.nprobe, cfg.temp_memory) == (3, "IVF", 64, 4, 2.0)
+    assert cfg.faiss_kwargs == {"use_float16": True}

@@ -85,6 +85,16 @@ class DistributedContext:
         ranks = torch.where(indices < split, indices // (base + 1), rem + (indices - split) // base)
         return torch.clamp(ranks, 0, world_size - 1)
 
+    def get_faiss_config(self, base_config=None):
+        """``FaissConfig`` for this rank's GPU (reference ``distributed/__init__.py:269-309``): the caller's settings with
+        the device replaced by the local rank."""
+        from torchdr_amd.distance import FaissConfig
+
+        if base_config is None:
+            return FaissConfig(device=self.local_rank)
+        return FaissConfig(temp_memory=base_config.temp_memory, device=self.local_rank, index_type=base_config.index_type,
+                           nprobe=base_config.nprobe, nlist=base_config.nlist, **base_config.faiss_kwargs)
+
     def __repr__(self):
         if self.is_initialized:
             return (

@@ -19,7 +19,7 @@ def set_logger(name: str, verbose: bool = False) -> logging.Logger:
     return logger
 
 
-def seed_everything(seed=None, fast=True, deterministic=False):
+def seed_everything(seed, fast=True, deterministic=False):
     """Seed python / numpy / torch generators (utils.py:51-97); returns the seed used."""
     if seed is None:
         seed = int(torch.randint(0, 2**31 - 1, (1,)).item())

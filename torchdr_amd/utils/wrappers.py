@@ -42,14 +42,14 @@ def restore_original_format(x, backend="torch", device="cpu"):
 
 
 def handle_input_output(_func=None, *, accept_sparse=False, ensure_min_samples=1, ensure_min_features=1,
-                        ensure_2d=True, **check_kwargs):
+                        ensure_2d=True, **check_array_kwargs):
     def deco(func):
         @functools.wraps(func)
         def wrapper(self, X, *args, **kwargs):
             X_, backend, device = to_torch(X, return_backend_device=True)
             X_ = validate_tensor(
                 X_, accept_sparse=accept_sparse, ensure_min_samples=ensure_min_samples,
-                ensure_min_features=ensure_min_features, ensure_2d=ensure_2d, **check_kwargs,
+                ensure_min_features=ensure_min_features, ensure_2d=ensure_2d, **check_array_kwargs,
             )
             out = func(self, X_, *args, **kwargs)
             return restore_original_format(out, backend=backend, device=device)
