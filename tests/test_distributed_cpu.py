@@ -333,3 +333,77 @@ def test_distributed_context_faiss_config():
     cfg = ctx.get_faiss_config(FaissConfig(index_type="IVF", nlist=64, nprobe=4, temp_memory=2.0, device=0, use_float16=True))
     assert (cfg.device, cfg.index_type, cfg.nlist, cfg.nprobe, cfg.temp_memory) == (3, "IVF", 64, 4, 2.0)
     assert cfg.faiss_kwargs == {"use_float16": True}
+
+
+def test_training_step_modes_follow_the_reference():
+    """`AffinityMatcher._training_step` (reference affinity_matcher.py:354-430): closed-form gradients when the class brings
+    its own `_compute_gradients` (tuple contract of this package, or the reference's bare tensor of chunk rows) or sets
+    `_use_closed_form_gradients` and fills the attractive / repulsive hooks (neighbor_embedding/base.py:236-254); autograd
+    of the loss otherwise.  Host logic only: torch.optim.Adam on CPU tensors stands in for the step kernels."""
+    import torch
+
+    from torchdr_amd.neighbor_embedding.base import NeighborEmbedding
+
+    def armed(cls):
+        m = object.__new__(cls)
+        torch.nn.Module.__init__(m)
+        m.embedding_ = torch.ones(6, 2)
+        m.optimizer_ = torch.optim.SGD([m.embedding_], lr=1.0)
+        m._fused_sgd, m._lr_table, m._lr_pos = False, [0.5, 0.5], 0
+        m.early_exaggeration_coeff_, m.repulsion_strength = 2.0, 3.0
+        m.n_iter_ = torch.tensor(0)
+        m.chunk_size_ = 6
+        return m
+
+    class Hooks(NeighborEmbedding):
+        _use_closed_form_gradients = True
+
+        def _compute_attractive_gradients(self):
+            return torch.full((6, 2), 1.0)
+
+        def _compute_repulsive_gradients(self):
+            return torch.full((6, 2), -0.5)
+
+    m = armed(Hooks)
+    assert m._training_step() is None and m._lr_pos == 1
+    assert torch.allclose(m.embedding_, torch.full((6, 2), 1.0 - 0.5 * (2.0 * 1.0 + 3.0 * -0.5)))
+
+    class Bare(NeighborEmbedding):
+        def _compute_gradients(self):
+            return torch.full((6, 2), 4.0)
+
+    m = armed(Bare)
+    m._training_step()
+    assert torch.allclose(m.embedding_, torch.full((6, 2), -1.0))
+
+    class Tup(NeighborEmbedding):
+        def _compute_gradients(self):
+            return torch.full((6, 2), 2.0), False
+
+    m = armed(Tup)
+    m._training_step()
+    assert torch.allclose(m.embedding_, torch.zeros(6, 2))
+
+    class Loss(NeighborEmbedding):
+        def _compute_attractive_loss(self):
+            return (self.embedding_ ** 2).sum()
+
+        def _compute_repulsive_loss(self):
+            return self.embedding_.sum() * 0.0
+
+    m = armed(Loss)
+    loss = m._training_step()
+    assert float(loss.detach()) == 2.0 * 12.0 and torch.allclose(m.embedding_.detach(), torch.full((6, 2), 1.0 - 0.5 * 4.0))
+
+    class Unfilled(NeighborEmbedding):
+        _use_closed_form_gradients = True
+
+    with pytest.raises(NotImplementedError, match="_compute_attractive_gradients"):
+        armed(Unfilled)._training_step()
+
+    class Wrong(NeighborEmbedding):
+        def _compute_gradients(self):
+            return torch.zeros(5, 2)
+
+    with pytest.raises(RuntimeError, match="Gradient size mismatch"):
+        armed(Wrong)._training_step()

@@ -236,9 +236,26 @@ class AffinityMatcher(DRModule):
         Multi-GPU, rows-only + fused SGD: each rank steps ITS rows and the updated rows are all-gathered
         (1/W of the reference's zero-padded gradient all-reduce, :395-413, and no full-size optimizer pass);
         otherwise the gradient is all-gathered / all-reduced (:425) and every rank steps the full embedding."""
-        if type(self)._compute_gradients is AffinityMatcher._compute_gradients:
+        # closed-form gradients (reference :381-413) when the class provides them -- an own `_compute_gradients`, or
+        # `_use_closed_form_gradients = True` with the base class's combination of the attractive / repulsive hooks --
+        # else autograd of the loss (:414-425)
+        own = not getattr(type(self)._compute_gradients, "_is_base", False)
+        if not (own or getattr(self, "_use_closed_form_gradients", False)):
             return self._autograd_training_step()
-        grad, rows_only = self._compute_gradients()
+        out = self._compute_gradients()
+        if isinstance(out, tuple):
+            grad, rows_only = out
+        else:   # the reference's contract: a bare tensor holding the gradient rows of this rank's chunk (:384-413)
+            grad, rows_only = out, True
+            if grad is None:        # :383 `if gradients is not None`
+                self._lr_pos += 1
+                return None
+            if grad.shape[0] != getattr(self, "chunk_size_", grad.shape[0]):
+                raise RuntimeError(
+                    f"Gradient size mismatch in distributed mode: expected {self.chunk_size_} gradients for chunk but "
+                    f"_compute_gradients() returned {grad.shape[0]}"
+                )
+            grad = grad.detach().to(torch.float32).contiguous()
         world = getattr(self, "world_size", 1)
         if world > 1 and rows_only and self._fused_sgd:
             from torchdr_amd.parallel import allgather_rows_
@@ -281,6 +298,8 @@ class AffinityMatcher(DRModule):
 
     def _compute_gradients(self):
         raise NotImplementedError("[TorchDR] ERROR : _compute_gradients method must be implemented.")
+
+    _compute_gradients._is_base = True
 
     # ---- autograd mode (reference :418-425) ---------------------------------------------------------------------------
     def _autograd_training_step(self):

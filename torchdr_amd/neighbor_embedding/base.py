@@ -86,6 +86,27 @@ class NeighborEmbedding(AffinityMatcher):
         return (self.early_exaggeration_coeff_ * self._compute_attractive_loss()
                 + self.repulsion_strength * self._compute_repulsive_loss())
 
+    # closed-form mode of the reference (:236-254): a subclass with `_use_closed_form_gradients = True` supplies the two
+    # gradient terms (rows of its chunk) as torch tensors; the estimators of this package override `_compute_gradients`
+    # itself with their HIP kernels
+    def _compute_gradients(self):
+        return (self.early_exaggeration_coeff_ * self._compute_attractive_gradients()
+                + self.repulsion_strength * self._compute_repulsive_gradients())
+
+    _compute_gradients._is_base = True
+
+    def _compute_attractive_gradients(self):
+        raise NotImplementedError(
+            "[TorchDR] ERROR : _compute_attractive_gradients method must be implemented "
+            "when _use_closed_form_gradients is True."
+        )
+
+    def _compute_repulsive_gradients(self):
+        raise NotImplementedError(
+            "[TorchDR] ERROR : _compute_repulsive_gradients method must be implemented "
+            "when _use_closed_form_gradients is True."
+        )
+
     # --- early exaggeration (reference :282-295) ------------------------------------------------
     def on_training_step_end(self):
         if self.early_exaggeration_coeff_ > 1 and int(self.n_iter_) == self.early_exaggeration_iter:
