@@ -56,6 +56,16 @@ class Affinity(nn.Module):
         return pairwise_distances(X=X, metric=self.metric, backend=self.backend, exclude_diag=self.zero_diag, k=k,
                                   return_indices=return_indices, device=self.device)
 
+    def _get_compute_device(self, X):
+        """Reference affinity/base.py:139-160 (tensor or DataLoader input), on this build's HIP device."""
+        from torchdr_amd.utils import dataloader_metadata, is_dataloader
+
+        if is_dataloader(X):
+            if self.device == "auto":
+                return compute_device(torch.empty(0, device=dataloader_metadata(X)[3]), "auto")
+            return compute_device(None, self.device)
+        return compute_device(X, self.device)
+
     def _get_n_samples(self, X):
         return X.shape[0]
 

@@ -109,6 +109,10 @@ class DRModule(BaseEstimator, nn.Module, ABC):
     def _fit_transform(self, X: torch.Tensor, y: Optional[Any] = None) -> torch.Tensor:
         raise NotImplementedError("[TorchDR] ERROR : _fit_transform method is not implemented.")
 
+    def _get_compute_device(self, X):
+        """Reference base.py:215-217, with this build's rule that compute happens on a HIP device (utils.compute_device)."""
+        return compute_device(X, self.device)
+
     def clear_memory(self):
         for name in list(getattr(self, "_non_persistent_buffers_set", [])):
             if hasattr(self, name):
