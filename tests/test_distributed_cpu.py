@@ -407,3 +407,19 @@ def test_training_step_modes_follow_the_reference():
 
     with pytest.raises(RuntimeError, match="Gradient size mismatch"):
         armed(Wrong)._training_step()
+
+
+def test_get_compute_device_hook():
+    """`_get_compute_device` of estimators and affinities (reference base.py:215-217, affinity/base.py:139-160): an explicit
+    device is returned as given; "auto" needs a HIP device in this build and says so on a host without one."""
+    import torch
+
+    import torchdr_amd
+    from torchdr_amd.affinity import EntropicAffinity
+
+    X = torch.zeros(3, 2)
+    assert str(torchdr_amd.UMAP(device="cuda:0")._get_compute_device(X)) == "cuda:0"
+    assert str(EntropicAffinity(device="cuda:0")._get_compute_device(X)) == "cuda:0"
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            torchdr_amd.UMAP()._get_compute_device(X)

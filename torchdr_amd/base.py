@@ -9,7 +9,7 @@ from torchdr_amd.utils.misc import as_float32
 import torch.nn as nn
 from sklearn.base import BaseEstimator
 
-from torchdr_amd.utils import handle_input_output, seed_everything, set_logger
+from torchdr_amd.utils import compute_device, handle_input_output, seed_everything, set_logger
 
 
 def unique_rows(X: torch.Tensor, device="auto"):
