@@ -423,3 +423,21 @@ def test_get_compute_device_hook():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no HIP device"):
             torchdr_amd.UMAP()._get_compute_device(X)
+
+
+def test_utils_names_the_path_imports():
+    """The names the reference's in-scope modules import from `torchdr.utils` resolve here too (host helpers)."""
+    import torch
+
+    from torchdr_amd.utils import (DistributedContext, compile_if_requested, cross_entropy_loss, matrix_transpose,  # noqa: F401
+                                   square_loss, sum_matrix_vector, sum_red, symmetrize_sparse)
+
+    M = torch.arange(6.0).reshape(2, 3)
+    assert torch.equal(sum_matrix_vector(M, torch.tensor([10.0, 20.0])), M + torch.tensor([[10.0], [20.0]]))
+    assert torch.equal(sum_matrix_vector(M, torch.tensor([1.0, 2.0, 3.0]), transpose=True), M + torch.tensor([[1.0, 2.0, 3.0]]))
+    assert matrix_transpose(M).shape == (3, 2) and float(square_loss(M, M + 1)) == 6.0
+
+    def f(x):
+        return x + 1
+
+    assert compile_if_requested(f) is f

@@ -20,12 +20,7 @@ import torch
 from torchdr_amd import _lib
 from torchdr_amd.affinity import Affinity, SparseAffinity
 from torchdr_amd.base import DRModule
-from torchdr_amd.utils import check_nonnegativity, compute_device, cross_entropy_loss, to_torch
-
-
-def square_loss(P, Q):
-    """utils/utils.py:127-147: sum of squared differences."""
-    return ((P - Q) ** 2).sum()
+from torchdr_amd.utils import check_nonnegativity, compute_device, cross_entropy_loss, square_loss, to_torch
 
 
 LOSS_DICT = {"square_loss": square_loss, "cross_entropy_loss": cross_entropy_loss}

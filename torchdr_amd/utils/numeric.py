@@ -112,3 +112,20 @@ def binary_search(f: Callable, n: int, begin=1.0, end=1.0, max_iter: int = 100, 
         m = (b + e) * 0.5
         f_m = f(m)
     return m
+
+
+def square_loss(P, Q):
+    """Sum of squared differences (reference ``utils/utils.py:127-147``)."""
+    return ((P - Q) ** 2).sum()
+
+
+def sum_matrix_vector(M, v, transpose=False):
+    """``M + v[:, None]`` (``transpose=False``) or ``M + v[None, :]`` (reference ``utils/utils.py:444-470``)."""
+    return M + (v.unsqueeze(-2) if transpose else v.unsqueeze(-1))
+
+
+def matrix_transpose(arg):
+    """Swap the last two axes (reference ``utils/utils.py:526-551``)."""
+    if not isinstance(arg, torch.Tensor):
+        raise ValueError(f"[TorchDR] ERROR : Unsupported input type for matrix_transpose: {type(arg)}.")
+    return arg.transpose(-1, -2)
