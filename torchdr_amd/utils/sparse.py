@@ -107,3 +107,20 @@ def symmetrize_to_csr(values, indices, mode="sum_minus_prod", row_offset=0, n_to
 def symmetrize_sparse(values, indices, mode="sum_minus_prod"):
     """Drop-in for ``torchdr.utils.sparse.symmetrize_sparse`` (sparse.py:170-206): padded output."""
     return symmetrize_to_csr(values, indices, mode).to_padded()
+
+
+def distributed_symmetrize_sparse(values, indices, chunk_start: int, chunk_size: int, n_total: int, mode="sum_minus_prod"):
+    """Drop-in for ``torchdr.utils.sparse.distributed_symmetrize_sparse`` (sparse.py:209-342): this rank's (chunk_size, k)
+    block -> its rows of ``P + P^T - P o P^T`` (or ``P + P^T``), padded.  Transposed edges whose row lives on another rank
+    travel by one all-to-all-v (``parallel.exchange_transposed_edges``) and enter the symmetrisation kernels as extra
+    edges -- the composition ``UMAPAffinity`` uses on row-sharded runs."""
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        raise RuntimeError("distributed_symmetrize requires torch.distributed to be initialized")
+    if values.shape[0] != chunk_size:
+        raise ValueError(f"[TorchDR] ERROR : values has {values.shape[0]} rows, chunk_size is {chunk_size}.")
+    from torchdr_amd.parallel import exchange_transposed_edges
+
+    ext = exchange_transposed_edges(values, indices, chunk_start, n_total, dist.get_world_size())
+    return symmetrize_to_csr(values, indices, mode, row_offset=chunk_start, n_total=n_total, ext=ext).to_padded()
