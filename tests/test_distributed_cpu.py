@@ -441,3 +441,24 @@ def test_utils_names_the_path_imports():
         return x + 1
 
     assert compile_if_requested(f) is f
+
+
+def test_backend_named_distance_entry_points():
+    """`pairwise_distances_torch` / `_faiss` / `_faiss_from_dataloader` (reference distance/torch.py:21, faiss.py:225,477):
+    the reference's argument order and errors in front of the one HIP search."""
+    import torch
+
+    from torchdr_amd.distance import (LIST_METRICS_FAISS, LIST_METRICS_TORCH, pairwise_distances_faiss,
+                                      pairwise_distances_faiss_from_dataloader, pairwise_distances_torch)
+
+    assert "manhattan" in LIST_METRICS_TORCH and LIST_METRICS_FAISS == ["euclidean", "sqeuclidean", "angular"]
+    X = torch.zeros(4, 2)
+    with pytest.raises(ValueError, match="metrics are supported for FAISS"):
+        pairwise_distances_faiss(X, 2, metric="manhattan")
+    with pytest.raises(ValueError, match="metrics are supported for FAISS"):
+        pairwise_distances_faiss_from_dataloader(torch.utils.data.DataLoader(X, batch_size=2), 2, metric="manhattan")
+    with pytest.raises(ValueError, match="not supported"):
+        pairwise_distances_torch(X, metric="nope")
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="HIP device"):   # no CPU compute path behind any of the names
+            pairwise_distances_torch(X, k=2)
