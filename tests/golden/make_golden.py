@@ -619,6 +619,39 @@ def tsnekhorn3_fixture():
     save("tsnekhorn3", **rec)
 
 
+def signatures_fixture():
+    """Constructor / function signatures of the in-scope public surface of the reference: parameter names in order and the
+    repr of every default (tests/golden/signatures.json) -- what `from torchdr import X; X(**kwargs)` code relies on."""
+    import inspect
+    import json
+
+    import torchdr.affinity as RA
+    import torchdr.distance as RD
+    import torchdr.eval as RE
+
+    def sig(obj):
+        ps = inspect.signature(obj).parameters
+        return [[k, None if v.default is inspect._empty else repr(v.default)] for k, v in ps.items()
+                if k not in ("self", "kwargs")]
+
+    out = {}
+    for n in ("UMAP", "TSNE", "LargeVis", "SNE", "InfoTSNE", "PACMAP", "COSNE", "TSNEkhorn", "AffinityMatcher", "NeighborEmbedding",
+              "NegativeSamplingNeighborEmbedding"):
+        out[n] = sig(getattr(torchdr, n).__init__)
+    for n in ("EntropicAffinity", "UMAPAffinity", "SymmetricEntropicAffinity", "SinkhornAffinity", "PACMAPAffinity"):
+        out["affinity." + n] = sig(getattr(RA, n).__init__)
+    for n in ("pairwise_distances", "pairwise_distances_indexed", "pairwise_distances_torch", "pairwise_distances_faiss",
+              "pairwise_distances_faiss_from_dataloader"):
+        out["distance." + n] = sig(getattr(RD, n))
+    out["distance.FaissConfig"] = sig(RD.FaissConfig.__init__)
+    for n in ("neighborhood_preservation", "knn_label_accuracy"):
+        out["eval." + n] = sig(getattr(RE, n))
+    path = os.path.join(HERE, "signatures.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("signatures:", len(out), "entries")
+
+
 def c1_tsne_fixture():
     """BASELINE config C1 at full size: TSNE on the 5000 x 50 Gaussian mixture, perplexity 30, backend=None (CPU):
     the reference's first two optimisation steps (embedding before / gradient / after, lr, momentum, exaggeration) and
@@ -658,7 +691,7 @@ if __name__ == "__main__":
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
                cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture,
-               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture)
+               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, signatures=signatures_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

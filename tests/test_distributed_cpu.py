@@ -462,3 +462,38 @@ def test_backend_named_distance_entry_points():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="HIP device"):   # no CPU compute path behind any of the names
             pairwise_distances_torch(X, k=2)
+
+
+def test_public_signatures_match_the_reference():
+    """Every in-scope constructor / function takes the reference's parameters, in the reference's order, with the
+    reference's defaults (tests/golden/signatures.json, written by make_golden.py from the real package)."""
+    import inspect
+    import json
+    import os
+
+    import torchdr_amd
+    import torchdr_amd.affinity as AA
+    import torchdr_amd.distance as AD
+    import torchdr_amd.eval as AE
+
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "signatures.json")))
+
+    def sig(obj):
+        ps = inspect.signature(obj).parameters
+        return [[k, None if v.default is inspect._empty else repr(v.default)] for k, v in ps.items() if k not in ("self", "kwargs")]
+
+    for name, want in ref.items():
+        if name.startswith("affinity."):
+            obj = getattr(AA, name.split(".", 1)[1]).__init__
+        elif name == "distance.FaissConfig":
+            obj = AD.FaissConfig.__init__
+        elif name.startswith("distance."):
+            obj = getattr(AD, name.split(".", 1)[1])
+        elif name.startswith("eval."):
+            obj = getattr(AE, name.split(".", 1)[1])
+        else:
+            obj = getattr(torchdr_amd, name).__init__
+        got = sig(obj)
+        assert [k for k, _ in got] == [k for k, _ in want], (name, got, want)
+        for (k, dg), (_, dw) in zip(got, want):
+            assert dg == dw, (name, k, dg, dw)
