@@ -241,8 +241,19 @@ def test_faiss_config_and_approximate_search_routing():
     cfg = FaissConfig(index_type="IVF", nlist=256, nprobe=8, temp_memory=2.0, device=1, some_faiss_option=3)
     assert cfg.approximate and cfg.nlist == 256 and cfg.nprobe == 8 and cfg.faiss_kwargs == {"some_faiss_option": 3}
     assert "IVF" in repr(cfg) and not FaissConfig().approximate
-    with pytest.raises(ValueError):
-        FaissConfig(index_type="HNSW")
+    # as in the reference (tests/test_utils.py:193-207): any string constructs, the SEARCH reports it; an unknown metric
+    # under a faiss backend gets the Faiss backend's message
+    import torch
+
+    from torchdr_amd.distance import pairwise_distances
+
+    bad = FaissConfig(index_type="HNSW")
+    with pytest.raises(ValueError, match="Index type.*not supported"):
+        pairwise_distances(torch.randn(50, 10), k=5, backend=bad)
+    with pytest.raises(ValueError, match="Only.*euclidean.*sqeuclidean.*angular"):
+        pairwise_distances(torch.randn(50, 10), k=5, backend="faiss", metric="cosine")
+    with pytest.raises(ValueError, match="The 'cosine' distance is not supported"):
+        pairwise_distances(torch.randn(50, 10), k=5, backend=None, metric="cosine")
     assert _ivf_request(cfg, True, 15, 50_000, 64, "sqeuclidean") == (256, 8)
     assert _ivf_request(FaissConfig(index_type="IVFPQ", nlist=100000, nprobe=500000), True, 15, 50_000, 64, "euclidean") == (781, 781)
     for args in ((None, True, 15, 50_000, 64, "sqeuclidean"), ("faiss", True, 15, 50_000, 64, "sqeuclidean"),

@@ -936,8 +936,13 @@ def pairwise_distances(
     distances is unspecified, so that is the only place results can differ from the
     reference's CPU backend (parity protocol).
     """
+    faiss_like = backend == "faiss" or type(backend).__name__ == "FaissConfig"
     if metric not in LIST_METRICS:
+        if faiss_like:   # the message of the reference's Faiss backend (distance/faiss.py:297-300)
+            raise ValueError("[TorchDR] Only ['euclidean', 'sqeuclidean', 'angular'] metrics are supported for FAISS.")
         raise ValueError(f"[TorchDR] ERROR : The '{metric}' distance is not supported.")
+    if hasattr(backend, "check_index_type"):
+        backend.check_index_type()
     if is_dataloader(X):  # reference base.py:121-157 (batches -> one HBM-resident tensor, utils/dataloader.py)
         if k is None:
             raise ValueError(

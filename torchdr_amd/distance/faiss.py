@@ -14,12 +14,19 @@ _INDEX_TYPES = ("Flat", "IVF", "IVFPQ")
 class FaissConfig:
     def __init__(self, temp_memory: Union[str, float] = "auto", device: int = 0, index_type: str = "Flat", nprobe: int = 1,
                  nlist: int = 100, M: int = 16, nbits: int = 8, **kwargs):
-        if index_type not in _INDEX_TYPES:
-            raise ValueError(f"[TorchDR] ERROR : index_type must be one of {_INDEX_TYPES}, got {index_type!r}.")
         self.temp_memory, self.device = temp_memory, device
         self.index_type, self.nprobe, self.nlist = index_type, int(nprobe), int(nlist)
         self.M, self.nbits = M, nbits
         self.faiss_kwargs = dict(kwargs)
+
+    def check_index_type(self):
+        """The reference accepts any string at construction and reports it when the index is built
+        (``distance/faiss.py:350-354``); the search entry points call this."""
+        if self.index_type not in _INDEX_TYPES:
+            raise ValueError(
+                f"[TorchDR] ERROR : Index type '{self.index_type}' is not supported. "
+                "Supported types are 'Flat', 'IVF', and 'IVFPQ'."
+            )
 
     @property
     def approximate(self) -> bool:
