@@ -74,8 +74,9 @@ def test_ivfpq_request_and_unsupported_shapes_fall_back_gracefully():
                                 backend=FaissConfig(index_type="IVF", nlist=64, nprobe=2))
     C5, I5 = pairwise_distances(X, metric="angular", k=5, exclude_diag=True, return_indices=True)
     assert torch.equal(I4, I5)
-    with pytest.raises(ValueError):
-        FaissConfig(index_type="HNSW")
+    with pytest.raises(ValueError, match="Index type.*not supported"):   # reported by the search, as in the reference
+        pairwise_distances(X, metric="sqeuclidean", k=5, exclude_diag=True, return_indices=True,
+                           backend=FaissConfig(index_type="HNSW"))
 
 
 def test_umap_with_an_ivf_backend():
