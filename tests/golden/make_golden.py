@@ -652,6 +652,43 @@ def signatures_fixture():
     print("signatures:", len(out), "entries")
 
 
+def manifold_fixture():
+    """utils/manifold.py: every operation of PoincareBallManifold (and the non-trivial ones of EuclideanManifold) on random
+    float64 inputs at curvatures 1 and 0.7 -- points inside the ball, a few near its boundary, tangent vectors, a matrix."""
+    from torchdr.utils.manifold import EuclideanManifold, PoincareBallManifold
+
+    gen = torch.Generator().manual_seed(11)
+    out = {}
+    for tag, c in (("c1", 1.0), ("c07", 0.7)):
+        B = PoincareBallManifold()
+        x = torch.randn(40, 3, generator=gen, dtype=torch.float64)
+        x = x / x.norm(dim=1, keepdim=True) * torch.rand(40, 1, generator=gen, dtype=torch.float64) * 0.95 / c ** 0.5
+        x[:4] = x[:4] / x[:4].norm(dim=1, keepdim=True) * (1 - 1e-7) / c ** 0.5       # near the boundary
+        y = torch.randn(40, 3, generator=gen, dtype=torch.float64)
+        y = y / y.norm(dim=1, keepdim=True) * torch.rand(40, 1, generator=gen, dtype=torch.float64) * 0.9 / c ** 0.5
+        u = torch.randn(40, 3, generator=gen, dtype=torch.float64) * 0.3
+        v = torch.randn(40, 3, generator=gen, dtype=torch.float64) * 0.3
+        m = torch.randn(3, 3, generator=gen, dtype=torch.float64)
+        far = x * 1.7
+        out.update({f"{tag}_x": x, f"{tag}_y": y, f"{tag}_u": u, f"{tag}_v": v, f"{tag}_m": m, f"{tag}_far": far})
+        out.update({
+            f"{tag}_sqdist": B.sqdist(x, y, c), f"{tag}_egrad2rgrad": B.egrad2rgrad(x, u.clone(), c), f"{tag}_proj": B.proj(far, c),
+            f"{tag}_proj32": B.proj(far.float(), c), f"{tag}_expmap": B.expmap(u, y, c), f"{tag}_logmap": B.logmap(y, x, c),
+            f"{tag}_expmap0": B.expmap0(u * 20, c), f"{tag}_logmap0": B.logmap0(x, c), f"{tag}_mobius_add": B.mobius_add(x, y, c),
+            f"{tag}_mobius_matvec": B.mobius_matvec(m, y, c), f"{tag}_inner": B.inner(y, c, u, v), f"{tag}_inner_self": B.inner(y, c, u, keepdim=True),
+            f"{tag}_ptransp": B.ptransp(y, x, u, c), f"{tag}_ptransp0": B.ptransp0(y, u, c), f"{tag}_lambda": B._lambda_x(x, c),
+            f"{tag}_hyperboloid": B.to_hyperboloid(y, c),
+        })
+        z = y.clone().requires_grad_(True)
+        B.sqdist(x, z, c).sum().backward()
+        out[f"{tag}_sqdist_grad"] = z.grad
+    E = EuclideanManifold()
+    out["euc_sqdist"] = E.sqdist(x, y, 1.0)
+    out["euc_ptransp0"] = E.ptransp0(x, u, 1.0)
+    out["euc_normalize"] = E.normalize((x * 3).clone())
+    save("manifold", **out)
+
+
 def c1_tsne_fixture():
     """BASELINE config C1 at full size: TSNE on the 5000 x 50 Gaussian mixture, perplexity 30, backend=None (CPU):
     the reference's first two optimisation steps (embedding before / gradient / after, lr, momentum, exaggeration) and
@@ -691,7 +728,7 @@ if __name__ == "__main__":
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
                cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture,
-               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, signatures=signatures_fixture)
+               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, signatures=signatures_fixture, manifold=manifold_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

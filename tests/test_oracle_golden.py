@@ -331,3 +331,38 @@ def test_sea_lbfgs_objective_matches_reference_autograd():
         assert torch.allclose(ge.float(), g[f"{name}_grad_eps"], rtol=1e-4, atol=1e-4)
         # the fixture is the reference in fp32: row sums of ~2 carry ~2e-5 of rounding
         assert torch.allclose((rowsum - 1).float(), g[f"{name}_grad_mu"], rtol=1e-4, atol=5e-5)
+
+
+def test_manifold_operations_vs_reference():
+    """torchdr_amd.utils.manifold (host-side ball arithmetic for code that works with a COSNE embedding) against every
+    operation of the reference's PoincareBallManifold / EuclideanManifold on random float64 inputs, two curvatures, points
+    near the boundary included (tests/golden/manifold.npz)."""
+    from torchdr_amd.utils import EuclideanManifold, ManifoldParameter, PoincareBallManifold
+
+    g = load("manifold")
+    B = PoincareBallManifold()
+    for tag, c in (("c1", 1.0), ("c07", 0.7)):
+        x, y, u, v, m, far = (g[f"{tag}_{k}"] for k in ("x", "y", "u", "v", "m", "far"))
+        got = {
+            "sqdist": B.sqdist(x, y, c), "egrad2rgrad": B.egrad2rgrad(x, u.clone(), c), "proj": B.proj(far, c),
+            "proj32": B.proj(far.float(), c), "expmap": B.expmap(u, y, c), "logmap": B.logmap(y, x, c),
+            "expmap0": B.expmap0(u * 20, c), "logmap0": B.logmap0(x, c), "mobius_add": B.mobius_add(x, y, c),
+            "mobius_matvec": B.mobius_matvec(m, y, c), "inner": B.inner(y, c, u, v), "inner_self": B.inner(y, c, u, keepdim=True),
+            "ptransp": B.ptransp(y, x, u, c), "ptransp0": B.ptransp0(y, u, c), "lambda": B._lambda_x(x, c),
+            "hyperboloid": B.to_hyperboloid(y, c),
+        }
+        for k, val in got.items():
+            ref = g[f"{tag}_{k}"]
+            assert val.dtype == ref.dtype and val.shape == ref.shape, (tag, k)
+            tol = 1e-6 if k == "proj32" else 1e-12
+            assert torch.allclose(val, ref, rtol=tol, atol=tol * float(ref.abs().max())), (tag, k, float((val - ref).abs().max()))
+        z = y.clone().requires_grad_(True)
+        B.sqdist(x, z, c).sum().backward()
+        ref = g[f"{tag}_sqdist_grad"]
+        assert torch.allclose(z.grad, ref, rtol=1e-9, atol=1e-9 * float(ref.abs().max())), tag
+    E = EuclideanManifold()
+    x, y, u = g["c07_x"], g["c07_y"], g["c07_u"]
+    assert torch.equal(E.sqdist(x, y, 1.0), g["euc_sqdist"]) and torch.equal(E.ptransp0(x, u, 1.0), g["euc_ptransp0"])
+    assert torch.allclose(E.normalize((x * 3).clone()), g["euc_normalize"], rtol=1e-12)
+    p = ManifoldParameter(x.clone(), True, B, 0.7)
+    assert p.requires_grad and p.c == 0.7 and p.manifold is B and "PoincareBall" in repr(p)

@@ -22,4 +22,5 @@ from .numeric import (  # noqa: F401
     sum_matrix_vector, sum_red,
 )
 from .radam import RiemannianAdam  # noqa: F401
+from .manifold import EuclideanManifold, Manifold, ManifoldParameter, PoincareBallManifold  # noqa: F401
 from torchdr_amd.distributed import DistributedContext  # noqa: F401,E402
