@@ -508,3 +508,18 @@ def test_public_signatures_match_the_reference():
         assert [k for k, _ in got] == [k for k, _ in want], (name, got, want)
         for (k, dg), (_, dw) in zip(got, want):
             assert dg == dw, (name, k, dg, dw)
+
+
+def test_host_root_searches():
+    """`binary_search` / `false_position` (utils/root_search.py:17-143) for arbitrary callables: both bracket by halving /
+    doubling and stop at |f| < 1e-6."""
+    import torch
+
+    import torchdr_amd
+    from torchdr_amd.utils import binary_search, false_position
+
+    t = torch.linspace(0.5, 30, 64, dtype=torch.float64)
+    for search in (binary_search, false_position):
+        r = search(lambda x: x ** 3 - t, 64, dtype=torch.float64)
+        assert float((r ** 3 - t).abs().max()) < 1e-6
+    assert torchdr_amd.false_position is false_position and torchdr_amd.binary_search is binary_search

@@ -14,3 +14,4 @@ from torchdr_amd.affinity_matcher import AffinityMatcher  # noqa: F401,E402
 from torchdr_amd.neighbor_embedding.base import NeighborEmbedding, NegativeSamplingNeighborEmbedding  # noqa: F401,E402
 from torchdr_amd import eval  # noqa: F401,E402,A004
 from torchdr_amd.eval import knn_label_accuracy, neighborhood_preservation  # noqa: F401,E402
+from torchdr_amd.utils import binary_search, false_position  # noqa: F401,E402

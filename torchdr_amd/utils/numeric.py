@@ -114,6 +114,33 @@ def binary_search(f: Callable, n: int, begin=1.0, end=1.0, max_iter: int = 100, 
     return m
 
 
+def false_position(f: Callable, n: int, begin=1.0, end=1.0, max_iter: int = 100, dtype=torch.float32,
+                   device="cpu") -> torch.Tensor:
+    """Batched regula falsi for an increasing batched function (root_search.py:81-143): the secant through the bracket
+    ends replaces the midpoint of `binary_search`; the end whose value has the sign of f(m) moves to m.  Host helper for
+    arbitrary callables -- the affinities run their searches inside the HIP kernels."""
+    tol = torch.tensor(_TOL, dtype=dtype, device=device)
+    b, e = init_bounds(f, n, begin, end, max_iter=max_iter, dtype=dtype, device=device)
+    f_b, f_e = f(b), f(e)
+
+    def secant():
+        return b - (b - e) / (f_b - f_e) * f_b
+
+    m = secant()
+    f_m = f(m)
+    for _ in range(max_iter):
+        active = f_m.abs() >= tol
+        if not active.any():
+            break
+        same = f_m * f_b > 0
+        lower, upper = active & same, active & ~same
+        b, f_b = torch.where(lower, m, b), torch.where(lower, f_m, f_b)
+        e, f_e = torch.where(upper, m, e), torch.where(upper, f_m, f_e)
+        m = secant()
+        f_m = f(m)
+    return m
+
+
 def square_loss(P, Q):
     """Sum of squared differences (reference ``utils/utils.py:127-147``)."""
     return ((P - Q) ** 2).sum()
