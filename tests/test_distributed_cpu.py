@@ -101,6 +101,17 @@ def test_exchange_steps_world_size_2(n_rows):
     assert all(ret.get(r) for r in range(world))
 
 
+def test_exchange_steps_world_size_3_uneven():
+    """The same exchanges over three ranks with chunks of 200 / 200 / 199 rows (the eight-rank layout of BASELINE C4 has
+    such a short last chunk)."""
+    world = 3
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, 599, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))
+
+
 def test_route_edges_partition():
     """route_edges is a pure partition of the edge list (no communication)."""
     from torchdr_amd.distributed import DistributedContext
