@@ -1,0 +1,110 @@
+"""Host-side API behaviour the reference's own unit tests pin down, re-run here without a GPU
+(``torchdr/tests/test_utils.py:1188-1246`` validate_tensor / to_torch, ``test_affinity_matcher.py:14-137, 340-395``
+constructor and configuration errors)."""
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_validate_tensor_and_to_torch():
+    from torchdr_amd.utils import to_torch, validate_tensor
+
+    with pytest.raises(ValueError, match="validate_tensor expects a torch.Tensor"):
+        validate_tensor(np.random.randn(10, 5))
+    X = torch.randn(10, 5)
+    assert validate_tensor(X) is X
+    assert validate_tensor(torch.randn(10), ensure_2d=True).shape == (10, 1)
+    with pytest.raises(ValueError):
+        validate_tensor(torch.randn(1, 1), ensure_min_samples=2)
+    with pytest.raises(ValueError):
+        validate_tensor(torch.randn(1, 1), ensure_min_features=2)
+    Xs = torch.randn(10, 5).to_sparse()
+    with pytest.raises(ValueError):
+        validate_tensor(Xs, accept_sparse=False)
+    assert validate_tensor(Xs, accept_sparse=True).is_sparse
+    with pytest.raises(ValueError, match="complex tensors are not supported"):
+        validate_tensor(torch.randn(10, 5, dtype=torch.cfloat))
+    with pytest.raises(ValueError, match="infinite values"):
+        validate_tensor(torch.tensor([1.0, float("inf")]))
+    Xn = np.random.randn(10, 5)
+    Xt, backend, device = to_torch(Xn, return_backend_device=True)
+    assert isinstance(Xt, torch.Tensor) and backend == "numpy" and device == "cpu" and torch.equal(Xt, torch.from_numpy(Xn))
+    Xt, backend, device = to_torch(X, return_backend_device=True)
+    assert backend == "torch" and device == X.device
+
+
+def test_affinity_matcher_argument_errors():
+    from torchdr_amd import AffinityMatcher
+    from torchdr_amd.affinity import EntropicAffinity
+
+    aff = EntropicAffinity()
+    with pytest.raises(ValueError):
+        AffinityMatcher(affinity_in=aff, affinity_out=aff, loss_fn="invalid_loss")
+    with pytest.raises(ValueError):
+        AffinityMatcher(affinity_in=aff, affinity_out="invalid_affinity")
+    with pytest.raises(ValueError):
+        AffinityMatcher(affinity_in=None, affinity_out=aff)
+    with pytest.raises(ValueError, match="affinity_out must be an Affinity instance"):
+        AffinityMatcher(affinity_in=aff, affinity_out=42)
+    m = AffinityMatcher(affinity_in=aff, affinity_out=aff, scheduler="invalid_scheduler")
+    m.optimizer_, m.lr_ = torch.optim.SGD([torch.zeros(1, requires_grad=True)], lr=1.0), 1.0
+    with pytest.raises(ValueError):
+        m._configure_scheduler()
+    for bad in ("InvalidOptimizer", dict):
+        m = AffinityMatcher(affinity_in=aff, affinity_out=aff, optimizer=bad)
+        m.embedding_, m.lr_ = torch.zeros(3, 2), 1.0
+        with pytest.raises(ValueError):
+            m._configure_optimizer()
+    m = AffinityMatcher(affinity_in=aff, affinity_out=aff, init="invalid_init")
+    m.device_ = "cpu"
+    with pytest.raises(ValueError):
+        m._init_embedding(torch.rand(5, 2))
+    with pytest.raises(ValueError, match="affinity_out is not set"):
+        AffinityMatcher(affinity_in=aff, affinity_out=None)._compute_loss()
+
+
+def test_matcher_configuration_steps_one_by_one():
+    """The reference's unit tests drive the private configuration steps in isolation on host tensors
+    (test_affinity_matcher.py:89-246): every init kind, `_set_params`, optimizers and schedulers by name / class / kwargs
+    leave real torch objects in `optimizer_` / `scheduler_`."""
+    from torch.optim import SGD
+    from torch.optim.lr_scheduler import ExponentialLR, StepLR
+
+    from torchdr_amd import AffinityMatcher
+    from torchdr_amd.affinity import EntropicAffinity
+
+    aff = EntropicAffinity()
+    X = torch.rand(5, 2)
+    for init in ("normal", "random", "pca", torch.ones(5, 2), np.ones((5, 2))):
+        m = AffinityMatcher(affinity_in=aff, affinity_out=aff, init=init)
+        m._init_embedding(X)
+        assert m.embedding_.shape == (5, 2)
+    m = AffinityMatcher(affinity_in=aff, affinity_out=aff, lr="auto", verbose=True)
+    m._set_learning_rate()
+    assert m.lr_ == 1.0
+    with pytest.raises(ValueError):
+        AffinityMatcher(affinity_in=aff, affinity_out=aff)._configure_scheduler()
+
+    def configured(**kw):
+        m = AffinityMatcher(affinity_in=aff, affinity_out=aff, **kw)
+        m._init_embedding(torch.rand(5, 2))
+        assert m._set_params()[0]["params"] is m.embedding_
+        m._set_learning_rate()
+        m._configure_optimizer()
+        return m
+
+    assert isinstance(configured(optimizer="Adam").optimizer_, torch.optim.Adam)
+    assert isinstance(configured(optimizer=SGD).optimizer_, SGD)
+    m = configured(optimizer="SGD", optimizer_kwargs={"momentum": 0.9})
+    assert isinstance(m.optimizer_, SGD) and m.optimizer_.param_groups[0]["momentum"] == 0.9 and m._fused_sgd
+    m = configured(scheduler="StepLR", scheduler_kwargs={"step_size": 10})
+    m._configure_scheduler()
+    assert isinstance(m.scheduler_, StepLR)
+    m = configured(scheduler=ExponentialLR, scheduler_kwargs={"gamma": 0.9}, max_iter=4)
+    m._configure_scheduler()
+    assert isinstance(m.scheduler_, ExponentialLR)
+    assert m._lr_table == pytest.approx([1.0, 0.9, 0.81, 0.729])     # the table the loop reads
+    m = configured()
+    m._configure_scheduler()
+    assert m.scheduler_ is None

@@ -352,6 +352,9 @@ class AffinityMatcher(DRModule):
             first = 1
         else:
             first = 0
+        holder = getattr(self, "optimizer_", None)
+        if isinstance(holder, torch.optim.Optimizer):
+            holder.param_groups[0]["lr"] = self._current_lr()
         _lib.check(
             _lib.lib().tdr_sgd_step_f32(_lib.ptr(Z), _lib.ptr(grad), _lib.ptr(self._momentum_buf), Z.numel(),
                                         self._current_lr(), mom, first, _lib.ptr(self._nan_flag), int(self.n_iter_),
@@ -387,10 +390,11 @@ class AffinityMatcher(DRModule):
     def _init_embedding(self, X):
         """Reference :493-573 (A.5): Z0 = init_scaling * E / std(E[:, 0])."""
         n = X.shape[0]
+        dev = getattr(self, "device_", None) or X.device    # callable on its own, as in the reference's unit tests
         if isinstance(self.init, (torch.Tensor, np.ndarray)):
-            emb = to_torch(self.init).to(device=self.device_, dtype=X.dtype)
+            emb = to_torch(self.init).to(device=dev, dtype=X.dtype)
         elif self.init in ("normal", "random"):
-            emb = torch.randn((n, self.n_components), device=self.device_, dtype=X.dtype)
+            emb = torch.randn((n, self.n_components), device=dev, dtype=X.dtype)
         elif self.init == "pca":
             pre, self._pca_prefetch = getattr(self, "_pca_prefetch", None), None
             if pre is not None:
@@ -404,6 +408,11 @@ class AffinityMatcher(DRModule):
             raise ValueError(f"[TorchDR] ERROR : init {self.init} not supported in {self.__class__.__name__}.")
         self.embedding_ = (self.init_scaling * emb / emb[:, 0].std()).contiguous()
         return self.embedding_
+
+    def _set_params(self):
+        """Reference :577-583 (there is no encoder on this path: the embedding itself is what is optimised)."""
+        self.params_ = [{"params": self.embedding_}]
+        return self.params_
 
     def _set_learning_rate(self):
         if self.lr == "auto":
@@ -433,8 +442,11 @@ class AffinityMatcher(DRModule):
         self._fused_sgd = optimizer_class is torch.optim.SGD and set(kwargs) <= {"momentum"}
         self._momentum_buf = None
         if self._fused_sgd:
+            # the step itself is the fused kernel (`_sgd_kernel`); `optimizer_` stays a genuine torch.optim.SGD over the
+            # embedding -- hyper-parameters and the current learning rate can be read from it as from the reference's --
+            # whose `step` is never called
             self._sgd_momentum = kwargs.get("momentum", 0.0)
-            self.optimizer_ = None  # the fused kernel is the optimizer
+            self.optimizer_ = optimizer_class([self.embedding_], lr=float(self.lr_), **kwargs)
         else:
             self.embedding_.requires_grad_(True)
             self.optimizer_ = optimizer_class([self.embedding_], lr=float(self.lr_), **kwargs)
@@ -443,6 +455,10 @@ class AffinityMatcher(DRModule):
     def _configure_scheduler(self, n_iter: Optional[int] = None):
         """Resolve the scheduler class (reference :625-657) and tabulate the learning rates it produces."""
         n_iter = n_iter or self.max_iter
+        if not hasattr(self, "optimizer_"):
+            raise ValueError(
+                "[TorchDR] ERROR : optimizer not set. Please call _configure_optimizer before _configure_scheduler."
+            )
         scheduler_class = None
         if self.scheduler is not None:
             if isinstance(self.scheduler, str):
@@ -459,7 +475,13 @@ class AffinityMatcher(DRModule):
                         "torch.optim.lr_scheduler) or a subclass of torch.optim.lr_scheduler.LRScheduler."
                     )
                 scheduler_class = self.scheduler
-        self.scheduler_ = scheduler_class
+        # the learning rates come from the table below (the same scheduler class stepping a throw-away optimizer, memoised);
+        # `scheduler_` is an instance bound to `optimizer_`, as in the reference, and is never stepped
+        opt = getattr(self, "optimizer_", None)
+        if scheduler_class is not None and isinstance(opt, torch.optim.Optimizer):
+            self.scheduler_ = scheduler_class(opt, **(self.scheduler_kwargs or {}))
+        else:
+            self.scheduler_ = None if scheduler_class is None else scheduler_class
         self._lr_table = lr_schedule_table(scheduler_class, self.scheduler_kwargs, self.lr_, self._lr_as_tensor,
                                            int(self.max_iter))
         self._lr_pos = 0
