@@ -689,6 +689,40 @@ def manifold_fixture():
     save("manifold", **out)
 
 
+def radam_fixture():
+    """utils/radam.py: trajectories of the reference's RiemannianAdam (a torch.optim.Adam subclass) -- a ManifoldParameter on
+    the Poincare ball (c = 0.8) and a plain tensor with amsgrad + weight decay -- five steps each on fixed quadratic losses:
+    points, both moments and the group's step counter after every step."""
+    from torchdr.utils import ManifoldParameter, PoincareBallManifold, RiemannianAdam
+
+    gen = torch.Generator().manual_seed(21)
+    out = {}
+    x0 = torch.randn(12, 3, generator=gen, dtype=torch.float64) * 0.2
+    tgt = torch.randn(12, 3, generator=gen, dtype=torch.float64) * 0.3
+    out.update(ball_init=x0, ball_target=tgt)
+    p = ManifoldParameter(x0.clone(), True, PoincareBallManifold(), 0.8)
+    opt = RiemannianAdam([p], lr=0.05, stabilize=4)
+    for t in range(5):
+        opt.zero_grad()
+        ((p - tgt) ** 2).sum().backward()
+        opt.step()
+        st = opt.state[p]
+        out.update({f"ball_x{t}": p.detach().clone(), f"ball_m1_{t}": st["exp_avg"].clone(), f"ball_m2_{t}": st["exp_avg_sq"].clone(),
+                    f"ball_step{t}": torch.tensor(opt.param_groups[0]["step"])})
+    y0 = torch.randn(6, 4, generator=gen, dtype=torch.float64)
+    out["flat_init"] = y0
+    q = y0.clone().requires_grad_(True)
+    opt = RiemannianAdam([q], lr=0.01, betas=(0.8, 0.99), eps=1e-6, weight_decay=1e-2, amsgrad=True)
+    for t in range(5):
+        opt.zero_grad()
+        (q ** 4).sum().backward()
+        opt.step()
+        st = opt.state[q]
+        out.update({f"flat_x{t}": q.detach().clone(), f"flat_m1_{t}": st["exp_avg"].clone(), f"flat_m2_{t}": st["exp_avg_sq"].clone(),
+                    f"flat_max{t}": st["max_exp_avg_sq"].clone()})
+    save("radam", **out)
+
+
 def c1_tsne_fixture():
     """BASELINE config C1 at full size: TSNE on the 5000 x 50 Gaussian mixture, perplexity 30, backend=None (CPU):
     the reference's first two optimisation steps (embedding before / gradient / after, lr, momentum, exaggeration) and
@@ -728,7 +762,7 @@ if __name__ == "__main__":
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
                cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture,
-               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, signatures=signatures_fixture, manifold=manifold_fixture)
+               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, signatures=signatures_fixture, manifold=manifold_fixture, radam=radam_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

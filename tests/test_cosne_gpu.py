@@ -90,14 +90,14 @@ def test_gradient_against_autograd_of_the_restated_loss():
 @pytest.mark.parametrize("pre,atol", [("small_", 1e-12), ("auto_", 1e-4)])
 def test_radam_step_matches_the_reference_state(pre, atol):
     from oracle import ref_torch as R
-    from torchdr_amd.utils import RiemannianAdam
+    from torchdr_amd.utils.radam import PoincareAdamKernel
 
     g = load("cosne")
     lr = float(g[pre + "lr"])
     for it in KEEP:
         Z = g[f"{pre}Zb{it}"]
         egrad = g[f"{pre}R{it}"] * R._lambda_x(Z) ** 2            # undo the in-place rescale: the Euclidean gradient
-        opt = RiemannianAdam(lr=lr)
+        opt = PoincareAdamKernel(lr=lr)
         opt.exp_avg, opt.exp_avg_sq = g[f"{pre}EAb{it}"].cuda(), g[f"{pre}ESb{it}"].cuda()
         opt.step_count = int(g[f"{pre}stepb{it}"])
         rows = Z.cuda().contiguous()

@@ -366,3 +366,42 @@ def test_manifold_operations_vs_reference():
     assert torch.allclose(E.normalize((x * 3).clone()), g["euc_normalize"], rtol=1e-12)
     p = ManifoldParameter(x.clone(), True, B, 0.7)
     assert p.requires_grad and p.c == 0.7 and p.manifold is B and "PoincareBall" in repr(p)
+
+
+def test_riemannian_adam_optimizer_vs_reference():
+    """torchdr_amd.utils.RiemannianAdam (the torch.optim.Adam subclass user code imports; COSNE itself steps with the HIP
+    kernel) against five-step trajectories of the reference's: a ManifoldParameter on the ball with stabilisation, a plain
+    tensor with amsgrad and weight decay (tests/golden/radam.npz); plus the behaviours its unit tests pin
+    (tests/test_utils.py:262-586): defaults, the twice-per-step counter, sparse gradients refused, closures."""
+    from torchdr_amd.utils import ManifoldParameter, PoincareBallManifold, RiemannianAdam
+
+    g = load("radam")
+    p = ManifoldParameter(g["ball_init"].clone(), True, PoincareBallManifold(), 0.8)
+    opt = RiemannianAdam([p], lr=0.05, stabilize=4)
+    for t in range(5):
+        opt.zero_grad()
+        ((p - g["ball_target"]) ** 2).sum().backward()
+        opt.step()
+        st = opt.state[p]
+        for got, key in ((p.detach(), f"ball_x{t}"), (st["exp_avg"], f"ball_m1_{t}"), (st["exp_avg_sq"], f"ball_m2_{t}")):
+            assert torch.allclose(got, g[key], rtol=1e-12, atol=1e-14), (key, float((got - g[key]).abs().max()))
+        assert opt.param_groups[0]["step"] == int(g[f"ball_step{t}"]) == 2 * (t + 1)
+    q = g["flat_init"].clone().requires_grad_(True)
+    opt = RiemannianAdam([q], lr=0.01, betas=(0.8, 0.99), eps=1e-6, weight_decay=1e-2, amsgrad=True)
+    for t in range(5):
+        opt.zero_grad()
+        (q ** 4).sum().backward()
+        opt.step()
+        st = opt.state[q]
+        for got, key in ((q.detach(), f"flat_x{t}"), (st["exp_avg"], f"flat_m1_{t}"), (st["exp_avg_sq"], f"flat_m2_{t}"),
+                         (st["max_exp_avg_sq"], f"flat_max{t}")):
+            assert torch.allclose(got, g[key], rtol=1e-12, atol=1e-14), key
+    w = torch.randn(5, 3, requires_grad=True)
+    o = RiemannianAdam([w])
+    grp = o.param_groups[0]
+    assert (grp["lr"], grp["betas"], grp["eps"], grp["weight_decay"], grp["amsgrad"], o._stabilize) == (1e-3, (0.9, 0.999), 1e-8, 0, False, None)
+    assert o.step(lambda: torch.tensor(3.0)) == 3.0 and "step" in grp        # a parameter without a gradient is skipped
+    w.grad = torch.sparse_coo_tensor(torch.tensor([[0], [0]]), torch.tensor([1.0]), (5, 3))
+    with pytest.raises(RuntimeError, match="does not support sparse gradients"):
+        o.step()
+    o.stabilize_group(grp)     # plain tensors and untouched parameters: nothing to do, no error

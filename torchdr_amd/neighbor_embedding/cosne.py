@@ -7,7 +7,7 @@ import torch
 from torchdr_amd import _lib
 from torchdr_amd.affinity import EntropicAffinity
 from torchdr_amd.neighbor_embedding.base import NeighborEmbedding, build_transposed_graph
-from torchdr_amd.utils.radam import RiemannianAdam
+from torchdr_amd.utils.radam import PoincareAdamKernel, RiemannianAdam
 
 
 class COSNE(NeighborEmbedding):
@@ -96,7 +96,7 @@ class COSNE(NeighborEmbedding):
         kw = dict(self.optimizer_kwargs or {})
         self._fused_sgd = False
         self._momentum_buf = None
-        self._radam = RiemannianAdam(lr=float(self.lr_), **kw)
+        self._radam = PoincareAdamKernel(lr=float(self.lr_), **kw)
         self.optimizer_ = self._radam
         return self.optimizer_
 

@@ -21,6 +21,6 @@ from .numeric import (  # noqa: F401
     binary_search, cross_entropy_loss, entropy, false_position, init_bounds, kmax, kmin, logsumexp_red, matrix_transpose, square_loss,
     sum_matrix_vector, sum_red,
 )
-from .radam import RiemannianAdam  # noqa: F401
+from .radam import PoincareAdamKernel, RiemannianAdam  # noqa: F401
 from .manifold import EuclideanManifold, Manifold, ManifoldParameter, PoincareBallManifold  # noqa: F401
 from torchdr_amd.distributed import DistributedContext  # noqa: F401,E402
