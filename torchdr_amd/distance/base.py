@@ -943,6 +943,8 @@ def pairwise_distances(
         raise ValueError(f"[TorchDR] ERROR : The '{metric}' distance is not supported.")
     if hasattr(backend, "check_index_type"):
         backend.check_index_type()
+    if k is not None and not isinstance(k, int):   # a 0-d tensor or a numpy integer (reference tests/test_utils.py:165-174)
+        k = int(k)
     if is_dataloader(X):  # reference base.py:121-157 (batches -> one HBM-resident tensor, utils/dataloader.py)
         if k is None:
             raise ValueError(
