@@ -108,3 +108,22 @@ def test_matcher_configuration_steps_one_by_one():
     m = configured()
     m._configure_scheduler()
     assert m.scheduler_ is None
+
+
+def test_dataloader_order_and_ivfpq_configuration_errors():
+    """Reference tests/test_dataloader.py:274-281 (a shuffling loader is refused: neighbour indices refer to iteration order)
+    and :381-389 (IVFPQ with M that does not divide the feature dimension)."""
+    from torch.utils.data import DataLoader, TensorDataset
+
+    from torchdr_amd.distance import FaissConfig, pairwise_distances
+    from torchdr_amd.utils import materialize_dataloader
+
+    X = torch.randn(300, 8)
+    with pytest.raises(ValueError, match="shuffle=False"):
+        materialize_dataloader(DataLoader(TensorDataset(X), batch_size=100, shuffle=True))
+    with pytest.raises(ValueError, match="shuffle=False"):
+        pairwise_distances(DataLoader(TensorDataset(X), batch_size=100, shuffle=True), k=10, return_indices=True)
+    assert torch.equal(materialize_dataloader(DataLoader(TensorDataset(X), batch_size=64, shuffle=False), device="cpu"), X)
+    with pytest.raises(ValueError, match="must be divisible by M"):
+        pairwise_distances(torch.randn(500, 33), k=10, backend=FaissConfig(index_type="IVFPQ", nlist=50, nprobe=10, M=8, nbits=8),
+                           return_indices=True)

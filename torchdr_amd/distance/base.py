@@ -945,6 +945,15 @@ def pairwise_distances(
         backend.check_index_type()
     if k is not None and not isinstance(k, int):   # a 0-d tensor or a numpy integer (reference tests/test_utils.py:165-174)
         k = int(k)
+    if getattr(backend, "index_type", None) == "IVFPQ" and isinstance(X, torch.Tensor) and X.dim() == 2:
+        # there are no sub-quantisers here (an IVFPQ request is served uncompressed), but a configuration Faiss would
+        # refuse is refused in the same words (distance/faiss.py:341-347)
+        d_feat, M = X.shape[1], int(getattr(backend, "M", 16))
+        if M <= 0 or d_feat % M != 0:
+            raise ValueError(
+                f"[TorchDR] ERROR : Vector dimension {d_feat} must be divisible by M={M} for IVFPQ. "
+                f"Choose M from divisors of {d_feat}."
+            )
     if is_dataloader(X):  # reference base.py:121-157 (batches -> one HBM-resident tensor, utils/dataloader.py)
         if k is None:
             raise ValueError(

@@ -39,9 +39,39 @@ def dataloader_metadata(dl: DataLoader):
     )
 
 
+def _iterates_in_order(sampler) -> bool:
+    from torch.utils.data import BatchSampler, RandomSampler, SequentialSampler
+
+    if isinstance(sampler, BatchSampler):
+        return _iterates_in_order(sampler.sampler)
+    if isinstance(sampler, RandomSampler):
+        return False
+    if isinstance(sampler, SequentialSampler):
+        return True
+    return not getattr(sampler, "shuffle", False)
+
+
+def check_dataloader_order(dl: DataLoader):
+    """Neighbour indices refer to the order the loader yields its rows in, so that order has to be the dataset's
+    (reference ``distance/faiss.py:60-110``: a shuffling sampler is refused, an unknown one draws a warning)."""
+    sampler = getattr(dl, "sampler", None)
+    if sampler is None:
+        import warnings
+
+        warnings.warn("[TorchDR] Could not verify DataLoader has shuffle=False. Ensure deterministic iteration for correct "
+                      "k-NN results.")
+        return
+    if not _iterates_in_order(sampler):
+        raise ValueError(
+            "[TorchDR] DataLoader must have shuffle=False for deterministic iteration. Current sampler: "
+            f"{type(sampler).__name__}. k-NN indices will be incorrect with shuffled data."
+        )
+
+
 def materialize_dataloader(dl: DataLoader, device=None) -> torch.Tensor:
     """All batches, in iteration order, as one (n_samples, n_features) tensor on ``device`` (default: the current GPU
     when there is one).  Integer batches are cast to float32 like tensor inputs."""
+    check_dataloader_order(dl)
     if device is None or device == "auto":
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     n, d, dtype, _ = dataloader_metadata(dl)
