@@ -123,7 +123,13 @@ def test_dataloader_order_and_ivfpq_configuration_errors():
         materialize_dataloader(DataLoader(TensorDataset(X), batch_size=100, shuffle=True))
     with pytest.raises(ValueError, match="shuffle=False"):
         pairwise_distances(DataLoader(TensorDataset(X), batch_size=100, shuffle=True), k=10, return_indices=True)
-    assert torch.equal(materialize_dataloader(DataLoader(TensorDataset(X), batch_size=64, shuffle=False), device="cpu"), X)
+    from torchdr_amd.distance.faiss import get_dataloader_metadata
+
+    dl = DataLoader(TensorDataset(X), batch_size=64, shuffle=False)
+    assert get_dataloader_metadata(dl) is None
+    assert torch.equal(materialize_dataloader(dl, device="cpu"), X)
+    meta = get_dataloader_metadata(dl)      # reference tests/test_dataloader.py:243-330
+    assert (meta["n_samples"], meta["n_features"], meta["dtype"]) == (300, 8, torch.float32)
     with pytest.raises(ValueError, match="must be divisible by M"):
         pairwise_distances(torch.randn(500, 33), k=10, backend=FaissConfig(index_type="IVFPQ", nlist=50, nprobe=10, M=8, nbits=8),
                            return_indices=True)

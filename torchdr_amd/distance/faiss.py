@@ -36,3 +36,10 @@ class FaissConfig:
         extra = f", M={self.M}, nbits={self.nbits}" if self.index_type == "IVFPQ" else ""
         return (f"FaissConfig(temp_memory={self.temp_memory!r}, device={self.device}, index_type={self.index_type!r}, "
                 f"nprobe={self.nprobe}, nlist={self.nlist}{extra})")
+
+
+def get_dataloader_metadata(dataloader):
+    """Reference ``distance/faiss.py:27-41`` (the name lives in this module there)."""
+    from torchdr_amd.utils.dataloader import get_dataloader_metadata as _get
+
+    return _get(dataloader)

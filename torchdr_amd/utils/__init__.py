@@ -15,7 +15,7 @@ from .validation import (  # noqa: F401
     validate_tensor,
 )
 from .wrappers import compile_if_requested, handle_input_output, restore_original_format, to_torch  # noqa: F401
-from .dataloader import dataloader_metadata, is_dataloader, materialize_dataloader  # noqa: F401
+from .dataloader import dataloader_metadata, get_dataloader_metadata, is_dataloader, materialize_dataloader  # noqa: F401
 from .sparse import CSRAffinity, distributed_symmetrize_sparse, symmetrize_sparse, symmetrize_to_csr  # noqa: F401
 from .numeric import (  # noqa: F401
     binary_search, cross_entropy_loss, entropy, false_position, init_bounds, kmax, kmin, logsumexp_red, matrix_transpose, square_loss,

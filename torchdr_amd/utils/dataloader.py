@@ -68,17 +68,34 @@ def check_dataloader_order(dl: DataLoader):
         )
 
 
+_METADATA = "_tdr_metadata"      # kept on the loader object itself: no global table that outlives it
+
+
+def get_dataloader_metadata(dl: DataLoader):
+    """{'n_samples', 'n_features', 'dtype', 'device'} of a loader that has been through `materialize_dataloader`, else None
+    (reference ``distance/faiss.py:27-41``)."""
+    return getattr(dl, _METADATA, None)
+
+
 def materialize_dataloader(dl: DataLoader, device=None) -> torch.Tensor:
     """All batches, in iteration order, as one (n_samples, n_features) tensor on ``device`` (default: the current GPU
     when there is one).  Integer batches are cast to float32 like tensor inputs."""
     check_dataloader_order(dl)
     if device is None or device == "auto":
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-    n, d, dtype, _ = dataloader_metadata(dl)
+    n, d, dtype, src_device = dataloader_metadata(dl)
     if not dtype.is_floating_point:
         dtype = torch.float32
+
+    def remember(rows):
+        try:
+            setattr(dl, _METADATA, {"n_samples": int(rows), "n_features": int(d), "dtype": dtype, "device": src_device})
+        except Exception:   # a loader class that refuses new attributes: nothing cached
+            pass
+
     if n is None:  # iterable dataset: length unknown until exhausted
         parts = [_first(b).to(device=device, dtype=dtype) for b in dl]
+        remember(sum(p.shape[0] for p in parts))
         return torch.cat(parts)
     out = torch.empty((n, d), dtype=dtype, device=device)
     pos = 0
@@ -91,4 +108,5 @@ def materialize_dataloader(dl: DataLoader, device=None) -> torch.Tensor:
             raise ValueError(f"[TorchDR] DataLoader yielded more than len(dataset) = {n} samples.")
         out[pos:pos + m].copy_(b, non_blocking=True)
         pos += m
+    remember(pos)
     return out if pos == n else out[:pos]      # drop_last=True loaders yield fewer rows
