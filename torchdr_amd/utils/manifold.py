@@ -24,11 +24,15 @@ def _len(a):
     return a.norm(dim=-1, p=2, keepdim=True).clamp_min(_FLOOR)
 
 
-def _tanh(t):
-    return t.clamp(-_TANH_CLIP, _TANH_CLIP).tanh()
+def tanh(x, clamp=_TANH_CLIP):
+    """tanh of the argument clipped to +-clamp (reference :206-225)."""
+    return x.clamp(-clamp, clamp).tanh()
 
 
-class _Artanh(torch.autograd.Function):
+_tanh = tanh
+
+
+class Artanh(torch.autograd.Function):
     """0.5 (log(1 + x) - log(1 - x)) evaluated in float64 on the clipped argument; derivative 1 / (1 - x^2)."""
 
     @staticmethod
@@ -45,7 +49,7 @@ class _Artanh(torch.autograd.Function):
 
 
 def artanh(x):
-    return _Artanh.apply(x)
+    return Artanh.apply(x)
 
 
 class Manifold:
