@@ -2,14 +2,24 @@
 (BASELINE.json `metric`), synthetic Gaussian-mixture data, on N GPUs of one node.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus 8 --steps 3 --warmup 1          # starts its own 8 ranks (one per GPU, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus 8 --steps 3 --warmup 1
+        --master-port P bench.py --gpus 8 --steps 3 --warmup 1   # ... or joins the ranks torchrun started
+
+``--gpus N`` with no rank in the environment re-executes this script N times, one process per GPU (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set as torchrun would), backend ``nccl`` (= RCCL) when the node has N devices; with fewer
+devices than ranks (a one-GPU development box) the ranks share devices over ``gloo`` and the line says so
+(``"devices_shared": true`` -- control flow only, the timing means nothing then).
 
 A "step" = one complete ``UMAP(...).fit_transform(X)`` (dedup + isfinite scan + pack + exact kNN + sigma
 search + symmetrisation + PCA init + ``max_iter`` optimisation iterations) over the SAME N points, with X
 already resident in HBM when the timed region starts.  Multi-GPU runs shard the rows of the same
 N-point problem (strong scaling): every rank holds X, searches its row chunk against the full
-database, exchanges transposed edges (all-to-all-v) and all-gathers the updated rows every iteration.
+database, exchanges transposed edges (all-to-all-v) and all-gathers the updated rows every iteration.  At N > 1 every
+rank holds ITS ROW SHARD of X when the timed region starts (``sharded_input=True``; ``--replicated-input`` hands every
+rank the full block instead) and the line carries ``phases_ms`` (shard gather, kNN pieces, exchanges, symmetrisation,
+init, loop -- HIP events, max over ranks), ``allgather_us`` (one per-iteration row exchange, timed on its own after the
+run), ``rccl_context`` and ``hbm_peak_gb`` per rank.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel group of the step, measured with HIP events inside the timed region: the UMAP
@@ -47,20 +57,48 @@ def gmm(n, d, scale, seed=42):
     return (centers[labels] + 0.5 * torch.randn(n, d, generator=g)).contiguous()
 
 
-def cpu_baseline(X_cpu, k, max_iter, model):
-    """Bounded CPU sample of the same workload with the oracle (kind "port")."""
+def cpu_baseline(X_cpu, k, max_iter, model, budget_s=60.0):
+    """CPU oracle on a bounded sample of the same workload (kind "port"): every stage of the fit,
+    each on the sample stated in `sample`, each extrapolated by the printed factor.  The kNN and loop samples grow until
+    section 8d's size (16 chunks of 4096 query rows; 20 iterations on 200k rows) or the time budget is reached."""
     from oracle import ref_torch as R
 
     n, d = X_cpu.shape
     threads = torch.get_num_threads()
-    rows = min(n, 2 * 4096)
+    notes = []
+    # (1) kNN: row chunks of 4096 queries against the full database
+    t_used, rows = 0.0, 0
+    while rows < min(n, 16 * 4096) and (rows == 0 or t_used < budget_s):
+        t0 = time.perf_counter()
+        R.knn_chunked(X_cpu, k, "sqeuclidean", True, chunk=4096, rows=(rows, min(rows + 4096, n)))
+        t_used += time.perf_counter() - t0
+        rows = min(rows + 4096, n)
+    f_knn = n / rows
+    t_knn = t_used * f_knn
+    notes.append(f"kNN: {rows // 4096} chunks x 4096 query rows vs the full database {t_used:.1f}s, x{f_knn:.1f} -> {t_knn:.0f}s")
+    # (2) sigma search + symmetrisation on a row sample of the GPU-built kNN distances is not available here (the fit
+    #     keeps the graph, not the distances): both run on the oracle's own kNN of a 20k-row subproblem, scaled by rows
+    sub = min(n, 20000)
+    Cs, Is = R.knn_chunked(X_cpu[:sub].contiguous(), k, "sqeuclidean", True)
     t0 = time.perf_counter()
-    R.knn_chunked(X_cpu, k, "sqeuclidean", True, chunk=4096, rows=(0, rows))
-    t_knn_rows = time.perf_counter() - t0
-    t_knn = t_knn_rows * n / rows
-    # optimisation loop: the oracle's padded-gather step on a row sample of the GPU-built graph
+    P, _, _ = R.umap_affinity(Cs, k, 100)
+    t_sig_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    R.symmetrize_sparse(P, Is.long(), "sum_minus_prod")
+    t_sym_s = time.perf_counter() - t0
+    t_sig, t_sym = t_sig_s * n / sub, t_sym_s * n / sub
+    notes.append(f"sigma search / symmetrisation: {sub} rows {t_sig_s:.2f}s / {t_sym_s:.2f}s, x{n / sub:.0f} -> {t_sig:.0f}s / {t_sym:.0f}s")
+    # (3) PCA initialisation (spectral_embedding/pca.py:151-184: thin SVD of the centred block), 200k rows
+    ps = min(n, 200000)
+    t0 = time.perf_counter()
+    Xc = X_cpu[:ps] - X_cpu[:ps].mean(0, keepdim=True)
+    torch.linalg.svd(Xc, full_matrices=False)
+    t_pca_s = time.perf_counter() - t0
+    t_pca = t_pca_s * n / ps
+    notes.append(f"PCA init: SVD of {ps} rows {t_pca_s:.1f}s, x{n / ps:.0f} -> {t_pca:.0f}s")
+    # (4) optimisation loop: the oracle's padded-gather step on a row sample of the GPU-built graph
     csr = model["csr"]
-    sample = min(csr.n, 20000)
+    sample = min(csr.n, 200000)
     rp = csr.rowptr[: sample + 1].cpu()
     deg = (rp[1:] - rp[:-1])
     width = int(deg.max())
@@ -74,20 +112,23 @@ def cpu_baseline(X_cpu, k, max_iter, model):
     A[r_idx, slot] = vals
     eps_per, nxt = R.umap_prepare(A, max_iter)
     Z = torch.randn(n, 2) * 1e-4
-    iters = 5
-    t0 = time.perf_counter()
-    for t in range(iters):
-        rows_t = torch.arange(sample)
+    rows_t = torch.arange(sample)
+    iters, t_used = 0, 0.0
+    while iters < 20 and (iters < 3 or t_used < budget_s / 2):
+        t0 = time.perf_counter()
         neg = R.sample_negatives(n, rows_t, 150)
-        R.umap_gradients(Z, NN, eps_per, nxt, neg, t, model["a"], model["b"], rows=rows_t)
-    t_loop = (time.perf_counter() - t0) / iters * (n / sample) * max_iter
-    total = t_knn + t_loop
+        R.umap_gradients(Z, NN, eps_per, nxt, neg, iters, model["a"], model["b"], rows=rows_t)
+        t_used += time.perf_counter() - t0
+        iters += 1
+    f_loop = (n / sample) * max_iter / iters
+    t_loop = t_used * f_loop
+    notes.append(f"loop: {iters} iterations on {sample} rows (padded width {width}, 150 negatives) {t_used:.1f}s, "
+                 f"x{n / sample:.0f} rows x{max_iter / iters:.0f} iterations -> {t_loop:.0f}s")
+    total = t_knn + t_sig + t_sym + t_pca + t_loop
     return {
         "value": n / total, "unit": "samples/sec", "cores": threads, "kind": "port",
-        "sample": (f"kNN: {rows} of {n} query rows vs full database ({t_knn_rows:.1f}s, x{n / rows:.0f} extrapolated "
-                   f"-> {t_knn:.0f}s); loop: {iters} iterations on {sample} rows extrapolated to {n} rows x "
-                   f"{max_iter} iterations -> {t_loop:.0f}s; sigma search / symmetrisation / init not included"),
-        "knn_build_sec_est": t_knn,
+        "sample": "; ".join(notes) + f"; every factor is a linear extrapolation; {threads} torch threads",
+        "knn_build_sec_est": t_knn, "total_sec_est": total,
     }
 
 
@@ -133,6 +174,54 @@ def knn_variants(X, args, dbase):
     return out
 
 
+def knn_uniform(args, dev, dbase):
+    """The reference's own "random (uniform)" benchmark set (benchmarks/faiss/run_benchmark.py:143-145: seed 42,
+    ``torch.randn(n, d)``, k = 15; published: Faiss Flat 10.16 s on one B200, BENCHMARK_RESULTS.md:22): the exact search
+    where no structure helps -- nothing is pruned, the screening kernel scans every tile."""
+    from torchdr_amd.distance import pairwise_distances
+
+    torch.manual_seed(42)
+    Xu = torch.randn(args.n, args.d).to(dev)
+    best = 1e9
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pairwise_distances(Xu, metric="sqeuclidean", k=15, exclude_diag=True, return_indices=True)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    flops = 2.0 * args.n * args.n * args.d
+    return {"sec": best, "k": 15, "path": dbase.LAST_KNN.get("path"), "tier": dbase.LAST_KNN.get("tier"),
+            "algorithmic_tflops": flops / best / 1e12, "frac_of_f16_peak": flops / best / 1e12 / F16_MFMA_PEAK_TFLOPS,
+            "reference_published_sec": 10.16, "reference_hardware": "1x NVIDIA B200, Faiss GpuIndexFlatL2 through torchdr.pairwise_distances",
+            "note": "exact kNN of seed-42 randn(N, D), k = 15, wall incl. packing and pilots, best of 2, outside the timed region"}
+
+
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` with no rank in the environment: start the N ranks ourselves (what
+    `python -m torch.distributed.run --nproc-per-node N` would do), one process per GPU over RCCL.  Rank 0's stdout is this
+    process's stdout, so the ONE JSON line comes through unchanged."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    n_dev = torch.cuda.device_count()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n_ranks),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    if n_dev < n_ranks:   # fewer devices than ranks: RCCL refuses duplicate devices -> gloo, host-staged collectives
+        env["TDR_DIST_BACKEND"] = "gloo"
+    procs = []
+    for r in range(n_ranks):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = pr.wait() or rc
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,7 +237,13 @@ def main():
                     help="skip the untimed kNN context figures (unpruned two-stage, one-stage fp32, structureless data)")
     ap.add_argument("--loop", choices=["auto", "graph", "c", "python"], default="auto",
                     help="UMAP loop driver: replayed HIP graphs (default), plain launches from the C loop object, or one Python iteration per step")
+    ap.add_argument("--replicated-input", action="store_true",
+                    help="N > 1: every rank is handed the full block (the reference's calling convention) instead of its row shard")
+    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of CPU work the kNN sample of cpu_baseline may take")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "LOCAL_RANK" not in os.environ:
+        self_launch(args.gpus)
 
     from torchdr_amd.distributed import init_from_env
 
@@ -166,8 +261,17 @@ def main():
     if args.loop != "auto":
         umod.LOOP_RUNNER = args.loop != "python"
         umod.LOOP_GRAPH = args.loop == "graph"
+    from torchdr_amd.distributed import chunk_bounds
+    from torchdr_amd.utils import phases
+
     X_cpu = gmm(args.n, args.d, args.scale)
-    X = X_cpu.to(dev)
+    sharded = world > 1 and not args.replicated_input
+    if sharded:     # this rank's row shard is what is resident when the clock starts
+        s0, s1 = chunk_bounds(args.n, rank, world)
+        X = X_cpu[s0:s1].to(dev)
+    else:
+        X = X_cpu.to(dev)
+    devices_shared = world > torch.cuda.device_count()
     torch.cuda.synchronize()
 
     def barrier():
@@ -211,13 +315,16 @@ def main():
         dbase.PROFILE = [] if record else None
         umod.PROFILE = [] if record else None
         umod.LOOP_PROFILE = [] if record else None
-        m = UMAP(n_neighbors=args.k, max_iter=args.max_iter, random_state=0, backend=None)
+        m = UMAP(n_neighbors=args.k, max_iter=args.max_iter, random_state=0, backend=None, sharded_input=sharded)
         if record:
+            keep["rccl_context"] = None
             _orig = m.clear_memory
 
             def _keep_then_clear():
                 keep["csr"] = m._csr
                 keep["a"], keep["b"] = m._a, m._b
+                keep["rccl_context"] = getattr(m, "_rccl_ctx", None) is not None
+                keep["loop_order"] = getattr(m, "loop_order_", None) is not None
                 _orig()
 
             m.clear_memory = _keep_then_clear
@@ -228,6 +335,8 @@ def main():
         one_step(False)
     barrier()
     knn_events, grad_events, loop_events = [], [], []
+    torch.cuda.reset_peak_memory_stats(dev)
+    phases.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(True)
@@ -236,14 +345,48 @@ def main():
         loop_events.extend(umod.LOOP_PROFILE)
     barrier()
     elapsed = time.perf_counter() - t0
+    phase_ms = {k_: v / args.steps for k_, v in phases.stop().items()}
     dbase.PROFILE = None
     umod.PROFILE = None
     umod.LOOP_PROFILE = None
 
+    from torchdr_amd.parallel import allreduce_max_
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if distributed:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce_max_(t)
     elapsed = float(t.item())
+    hbm_peak = torch.tensor([0.0] * world, dtype=torch.float64, device=dev)
+    hbm_peak[rank] = torch.cuda.max_memory_allocated(dev) / 1e9
+    names = sorted(phase_ms)
+    ph = torch.tensor([phase_ms[k_] for k_ in names], dtype=torch.float64, device=dev)
+    allgather_us = None
+    if distributed:
+        allreduce_max_(hbm_peak)
+        allreduce_max_(ph)      # every rank records the same phase names (same code path)
+        # one per-iteration row exchange of the (N, 2) embedding, on its own: the transport the loop used
+        from torchdr_amd.parallel import RcclContext, allgather_rows_
+
+        Zt = torch.zeros((args.n, 2), dtype=torch.float32, device=dev)
+        c0, c1 = chunk_bounds(args.n, rank, world)
+        ctx = RcclContext.create(args.n, dev) if (keep.get("rccl_context") and dist.get_backend() == "nccl") else None
+        reps = 50
+        for timed in (False, True):
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                if ctx is not None:
+                    ctx.allgather_rows_(Zt)
+                else:
+                    allgather_rows_(Zt, c0, c1 - c0, world)
+            torch.cuda.synchronize()
+            allgather_us = (time.perf_counter() - t1) / reps * 1e6
+        if ctx is not None:
+            ctx.destroy()
+        ag = torch.tensor([allgather_us], dtype=torch.float64, device=dev)
+        allreduce_max_(ag)
+        allgather_us = float(ag.item())
+    phase_ms = dict(zip(names, [round(v, 3) for v in ph.tolist()]))
 
     # ---- kernel-level numbers (HIP events recorded on the launch stream inside the timed region) -------------------
     # (1) kNN build: one event pair around the scan (+ rescoring) launches.  Large searches take the two-stage path
@@ -342,18 +485,29 @@ def main():
                 "workload": f"UMAP fit_transform N={args.n} D={args.d} k={args.k} max_iter={args.max_iter} "
                             f"n_components=2 init=pca, Gaussian mixture (min(1000,N/100) clusters, centre scale "
                             f"{args.scale}, sigma 0.5, seed 42)",
-                "parallelism": f"rows sharded over {world} GPU(s)",
+                "parallelism": f"rows sharded over {world} GPU(s)" + ("" if world == 1 else
+                               (", row-sharded input" if sharded else ", replicated input")),
             },
+            "phases_ms": phase_ms,
+            "hbm_peak_gb": [round(v, 2) for v in hbm_peak.tolist()],
             "knn_build_sec": knn_build_ms * 1e-3,
             "knn_scan_sec": scan_avg_ms * 1e-3,
             "knn_path": path,
             "roofline": dominant,
             "roofline_secondary": secondary,
         }
+        if world > 1:
+            out["backend"] = dist.get_backend()
+            out["devices_shared"] = bool(devices_shared)
+            out["rccl_context"] = bool(keep.get("rccl_context"))
+            out["loop_in_cluster_order"] = bool(keep.get("loop_order"))
+            out["allgather_us"] = allgather_us
+            out["allgather_ms_per_fit"] = None if allgather_us is None else allgather_us * args.max_iter * 1e-3
         if not args.no_knn_variants and world == 1:
             out["knn_context"] = knn_variants(X, args, dbase)
+            out["knn_uniform"] = knn_uniform(args, dev, dbase)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(X_cpu, args.k, args.max_iter, keep)
+            out["cpu_baseline"] = cpu_baseline(X_cpu, args.k, args.max_iter, keep, budget_s=args.cpu_budget)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

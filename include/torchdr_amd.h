@@ -140,9 +140,14 @@ int tdr_cluster_maxmin_f32(const float* D2, int64_t ld, int S, int C, int32_t* s
 int tdr_gather_rows_f32(const float* X, int64_t ldx, int d, const int32_t* idx, const int32_t* idx2, int64_t m, float* out,
                         void* stream);
 int tdr_cluster_update_f32(const float* Xs, int64_t S, int d, const int32_t* labels, int C, float* cent, void* ws, void* stream);
+/* the layout is a stable counting sort (members of a cluster by ascending row): every rank of a row-sharded fit builds the
+ * SAME index by itself.  perm / inv / ppos (nullable together, n int32 each): the cluster-sorted order without padding
+ * (position -> row, row -> position, position -> position in the padded layout). */
+int64_t tdr_cluster_tables_workspace_bytes(int64_t n, int C);
 int tdr_cluster_tables_f32(const float* X, int64_t n, int d, int64_t ldx, const int32_t* labels, const float* cent, int C,
                            float* radius, int32_t* tile_begin, int32_t* tiles, int32_t* tile_cluster, int32_t* row_map,
-                           int64_t* n_img, float* dist, int32_t* order, void* ws, void* stream);
+                           int64_t* n_img, float* dist, int32_t* order, int32_t* perm, int32_t* inv, int32_t* ppos, void* ws,
+                           int64_t ws_bytes, void* stream);
 /* Self search with cluster-bound pruning: the points are sorted by a coarse clustering and padded so that clusters
  * start on tile boundaries (row_map); a workgroup visits clusters by increasing centre distance and skips every
  * cluster whose ball cannot reach its queries' current thresholds.  Same results as tdr_knn_screen_f32 (and hence

@@ -198,9 +198,21 @@ def test_c4_point_set_on_one_gpu():
     from torchdr_amd.distance import pairwise_distances
 
     n, k = 4_000_000, 30
-    X = gmm(n, 256, 2.0).cuda()
+    Xh = gmm(n, 256, 2.0)
+    X = Xh.cuda()
     torch.cuda.reset_peak_memory_stats()
     C, I = pairwise_distances(X, metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True)
+    # the CPU oracle at full size: 128 sampled rows against all 4M points, bit for bit
+    import oracle
+
+    orows = torch.randint(0, n, (128,), generator=torch.Generator().manual_seed(12))
+    Co, Io = oracle.knn(Xh[orows].contiguous(), k + 1, "sqeuclidean", exclude_self=False, Y=Xh)
+    keep_o = Io != orows[:, None].int()
+    ok_o = keep_o.sum(1) == k
+    assert int(ok_o.sum()) >= 120
+    assert torch.equal(Io[ok_o][keep_o[ok_o]].reshape(-1, k), I[orows.cuda()][ok_o.cuda()].cpu())
+    assert torch.equal(Co[ok_o][keep_o[ok_o]].reshape(-1, k), C[orows.cuda()][ok_o.cuda()].cpu())
+    del Xh
     assert bool((C[:, 1:] >= C[:, :-1]).all())
     assert not bool((I == torch.arange(n, device="cuda", dtype=torch.int32)[:, None]).any())
     rows = torch.randint(0, n, (4096,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))

@@ -14,11 +14,13 @@ from tests.test_distributed_cpu import _free_port
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, backend="gloo"):
+    # gloo: every rank on device 0 (host-staged collectives); nccl (= RCCL): one device per rank
+    local = rank if backend == "nccl" else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+                      LOCAL_RANK=str(local))
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         import torchdr_amd
         from tests.conftest import gmm
@@ -62,6 +64,19 @@ def _worker(rank, world, port, ret):
             Cs, Is = pairwise_distances(Xb, metric="sqeuclidean", k=10, exclude_diag=True, return_indices=True,
                                         distributed_ctx=DistributedContext())
             assert dbase.LAST_KNN.get("pruned")
+            # --- the same search with the ranks KEEPING their range of the cluster-sorted order (what a row-sharded UMAP
+            #     asks for): rows and neighbour indices are positions of the order; mapped back through (perm, inv) they
+            #     are the exact result.  perm is the same on every rank (each built the index itself).
+            info = {"want_loop_order": True}
+            Cl, Il = dbase._pairwise(Xb, None, "sqeuclidean", None, True, 10, True, "auto", DistributedContext(), info)
+            assert info.get("loop_order") and info["cluster_order"] is not None
+            perm_l, inv_l = info["cluster_order"]
+            hp = perm_l.cpu()
+            gp = [torch.empty_like(hp) for _ in range(world)]
+            dist.all_gather(gp, hp)
+            assert all(torch.equal(gp[0], g) for g in gp[1:]), "cluster order differs between ranks"
+            assert torch.equal(perm_l.long().sort().values, torch.arange(nb, device="cuda"))
+            assert torch.equal(inv_l[perm_l.long()].long(), torch.arange(nb, device="cuda"))
         finally:
             dbase.SCREEN_MODE, dbase.PRUNE_MODE = "auto", "auto"
         dbase.SCREEN_MODE = "0"
@@ -72,6 +87,8 @@ def _worker(rank, world, port, ret):
         b0, b1 = chunk_bounds(nb, rank, world)
         assert Cs.shape == (b1 - b0, 10)
         assert torch.equal(Is, Ie[b0:b1]) and torch.equal(Cs, Ce[b0:b1])
+        mine = perm_l[b0:b1].long()     # caller's rows of this rank's positions
+        assert torch.equal(Cl, Ce[mine]) and torch.equal(perm_l[Il.long()], Ie[mine])
         # --- estimators: every rank ends with the same finite embedding
         for cls, kw in ((torchdr_amd.UMAP, dict(n_neighbors=12, max_iter=40)),
                         (torchdr_amd.LargeVis, dict(perplexity=6, max_iter=25)),
@@ -90,6 +107,24 @@ def _worker(rank, world, port, ret):
             if cls in (torchdr_amd.SNE, torchdr_amd.COSNE):  # no sampling: the sharded run must reproduce the single-process one
                 Z1 = cls(random_state=0, distributed=False, **kw).fit_transform(X)
                 assert torch.allclose(Z, Z1, rtol=1e-3, atol=1e-4 * float(Z1.abs().max()))
+            if cls is torchdr_amd.UMAP:
+                # one negative-sampling seed for all ranks, keyed by global row: the sharded fit IS the single-process fit
+                Z1 = cls(random_state=0, distributed=False, **kw).fit_transform(X)
+                assert torch.equal(Z, Z1), float((Z - Z1).abs().max())
+        # --- UMAP with the pruned search: ranks keep their range of the cluster-sorted order, the loop runs in that
+        #     numbering on every rank (no kNN row exchange, no index broadcast) -- and is still the single-process fit,
+        #     bit for bit, in the caller's order
+        dbase.SCREEN_MODE, dbase.PRUNE_MODE = "force", "force"
+        try:
+            mu = torchdr_amd.UMAP(n_neighbors=10, max_iter=40, random_state=0)
+            Zp = mu.fit_transform(Xb)
+            assert mu.loop_order_ is not None and dbase.LAST_KNN.get("pruned")
+            m1 = torchdr_amd.UMAP(n_neighbors=10, max_iter=40, random_state=0, distributed=False)
+            Zp1 = m1.fit_transform(Xb)
+            assert m1.loop_order_ is not None and torch.equal(m1.loop_order_, mu.loop_order_)
+        finally:
+            dbase.SCREEN_MODE, dbase.PRUNE_MODE = "auto", "auto"
+        assert torch.equal(Zp, Zp1), float((Zp - Zp1).abs().max())
         # --- row-sharded INPUT (sharded_input=True): each rank hands over ITS rows only; same embedding as the
         #     replicated-input run, bit for bit (the shards are all-gathered first, then the same code runs)
         Zr = torchdr_amd.UMAP(n_neighbors=12, max_iter=20, random_state=0).fit_transform(X)
@@ -169,6 +204,88 @@ def test_two_rank_sharded_path_on_one_gpu():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world))
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
+def test_two_rank_sharded_path_over_rccl():
+    """The same checks with backend nccl (= RCCL over xGMI), one device per rank: chunked / pruned / loop-order searches,
+    the edge all-to-all of the symmetrisation, every estimator (UMAP through the C loop object with `tdr_ctx_allgather_rows`
+    enqueued on the compute stream, uneven chunks: grouped broadcasts), row-sharded input -- all against the
+    single-process results."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), ret, "nccl"), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))
+
+
+def _worker_rccl_even(rank, world, port, ret):
+    """Even chunks over RCCL: the in-place ncclAllGather form of the per-iteration exchange, LargeVis / TSNE gradient
+    all-reduce, and the UMAP loop in cluster order at a size where the default dispatch prunes."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        import torchdr_amd
+        from tests.conftest import gmm
+        from torchdr_amd.distance import base as dbase
+
+        n = 70000 - 70000 % world
+        X = gmm(n, 32, 2.0, seed=5).cuda()
+        m = torchdr_amd.UMAP(n_neighbors=15, max_iter=60, random_state=0)
+        Z = m.fit_transform(X)
+        assert m.world_size == world and dbase.LAST_KNN.get("pruned") and m.loop_order_ is not None
+        Z1 = torchdr_amd.UMAP(n_neighbors=15, max_iter=60, random_state=0, distributed=False).fit_transform(X)
+        assert torch.equal(Z, Z1), float((Z - Z1).abs().max())
+        s, e = n * rank // world, n * (rank + 1) // world
+        Zs = torchdr_amd.UMAP(n_neighbors=15, max_iter=60, random_state=0, sharded_input=True).fit_transform(X[s:e].clone())
+        assert torch.equal(Zs, Z)
+        for cls, kw in ((torchdr_amd.LargeVis, dict(perplexity=6, max_iter=25)), (torchdr_amd.TSNE, dict(perplexity=6, max_iter=25))):
+            Zc = cls(random_state=0, **kw).fit_transform(X[:6000].contiguous())
+            assert bool(torch.isfinite(Zc).all())
+            h = Zc.detach().clone()
+            g = [torch.empty_like(h) for _ in range(world)]
+            dist.all_gather(g, h)
+            assert all(torch.equal(g[0], t) for t in g[1:]), f"{cls.__name__}: ranks diverged"
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank")
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_even_chunks_over_rccl(world):
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_rccl_even, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no rank in the environment (the driver's invocation) starts two ranks itself --
+    over RCCL when the node has two devices, else sharing the device over gloo -- and prints ONE line with n_gpus = 2 and
+    the per-phase split."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--npoints", "70000", "--steps", "1",
+                          "--warmup", "1", "--max-iter", "100", "--no-cpu-baseline", "--no-knn-variants"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["scaling"] == "strong"
+    assert rec["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+    assert rec["devices_shared"] == (torch.cuda.device_count() < 2)
+    assert rec["loop_in_cluster_order"] and len(rec["hbm_peak_gb"]) == 2
+    for name in ("shard gather (all-gather of X)", "knn: pruned scan + rescoring", "symmetrise: edge exchange (all-to-all)", "loop"):
+        assert name in rec["phases_ms"], sorted(rec["phases_ms"])
 
 
 def _worker_c4(rank, world, port, ret):

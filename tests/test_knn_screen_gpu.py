@@ -189,16 +189,28 @@ def test_screen_cluster_pruned_scan_equals_exact(scale, n, d, k, tier):
 
 def test_headline_size_search_sampled_against_the_one_stage_kernel():
     """BASELINE's full size (N = 1M, D = 128, k = 30), default dispatch (pilot -> tier -> cluster-pruned two-stage search):
-    8192 sampled rows re-searched by the one-stage exact fp32 kernel -- itself bit-exact against the CPU oracle at the
+    256 sampled rows searched by the CPU oracle against the whole set, and 8192 sampled rows re-searched by the one-stage exact fp32 kernel -- itself bit-exact against the CPU oracle at the
     sizes the oracle finishes -- give the same neighbours and distances bit for bit; every row is sorted and never
     returns itself; the neighbour relation is the kNN graph of a metric (i in N(j) => d_ij <= d_j,k)."""
     from torchdr_amd.distance import base as dbase
     from torchdr_amd.distance import pairwise_distances
 
     n, k = 1_000_000, 30
-    X = gmm(n, 128, 2.0).cuda()
+    Xh = gmm(n, 128, 2.0)
+    X = Xh.cuda()
     C, I = pairwise_distances(X, metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True)
     assert dbase.LAST_KNN["path"] == "screen-pruned" and dbase.LAST_KNN["flagged"] == 0
+    # the CPU oracle itself at full size: 256 sampled rows against all 1M points (top k + 1 without exclusion, own row
+    # dropped) -- distances and indices bit for bit
+    import oracle
+
+    orows = torch.randint(0, n, (256,), generator=torch.Generator().manual_seed(11))
+    Co, Io = oracle.knn(Xh[orows].contiguous(), k + 1, "sqeuclidean", exclude_self=False, Y=Xh)
+    keep_o = Io != orows[:, None].int()
+    ok_o = keep_o.sum(1) == k
+    assert int(ok_o.sum()) >= 250
+    assert torch.equal(Io[ok_o][keep_o[ok_o]].reshape(-1, k), I[orows.cuda()][ok_o.cuda()].cpu())
+    assert torch.equal(Co[ok_o][keep_o[ok_o]].reshape(-1, k), C[orows.cuda()][ok_o.cuda()].cpu())
     assert bool((C[:, 1:] >= C[:, :-1]).all())
     assert not bool((I == torch.arange(n, device="cuda", dtype=torch.int32)[:, None]).any())
     rows = torch.randint(0, n, (8192,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))

@@ -103,7 +103,7 @@ def layout(rowptr, cols, eps_per):
 
 
 def test_loop_layout_sorts_every_row_by_firing_period():
-    """tdr_umap_sched_layout_f32: each row's (column, epochs_per_sample) pairs, stably sorted by epochs_per_sample."""
+    """tdr_umap_sched_layout_f32: each row's (column, epochs_per_sample) pairs, sorted by (epochs_per_sample, column)."""
     n = 3000
     rowptr, cols, vals = random_graph(n, seed=21, hub=2500)   # the hub row exceeds the sorted range: left as it is
     eps_per, _ = prepare(vals.cuda(), 200)
@@ -114,7 +114,9 @@ def test_loop_layout_sorts_every_row_by_firing_period():
         if e1 - e0 > 2048:
             assert torch.equal(cp[e0:e1], cols[e0:e1]) and torch.equal(epp[e0:e1], ep[e0:e1])
             continue
-        order = torch.sort(ep[e0:e1], stable=True).indices
+        # by (epochs_per_sample, column, position)
+        by_col = torch.sort(cols[e0:e1], stable=True).indices
+        order = by_col[torch.sort(ep[e0:e1][by_col], stable=True).indices]
         assert torch.equal(epp[e0:e1], ep[e0:e1][order])
         assert torch.equal(cp[e0:e1], cols[e0:e1][order])
 

@@ -16,6 +16,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from torchdr_amd.distance import pairwise_distances
+from torchdr_amd.distance.base import _pairwise
 from torchdr_amd.distributed import DistributedContext
 from torchdr_amd.utils import bool_arg, compute_device, set_logger, to_torch
 
@@ -143,11 +144,12 @@ class SparseAffinity(Affinity):
     def _compute_sparse_affinity(self, X: torch.Tensor, return_indices: bool = True, **kwargs):
         raise NotImplementedError("[TorchDR] ERROR : `_compute_sparse_affinity` method is not implemented.")
 
-    def _distance_matrix(self, X: torch.Tensor, k: int = None, return_indices: bool = False):
-        result = pairwise_distances(
-            X=X, metric=self.metric, backend=self.backend, exclude_diag=self.zero_diag, k=k,
-            return_indices=return_indices, device=self.device,
-            distributed_ctx=self.dist_ctx if self.distributed else None,
+    def _distance_matrix(self, X: torch.Tensor, k: int = None, return_indices: bool = False, info: dict = None):
+        """``info``: record shared with the search (``distance.base._pairwise``): the cluster-sorted row order of a pruned
+        self search comes back in it, and a row-sharded caller may ask for its rows in that numbering."""
+        result = _pairwise(
+            X, None, self.metric, self.backend, self.zero_diag, k, return_indices, self.device,
+            self.dist_ctx if self.distributed else None, info,
         )
         if self.distributed and self.dist_ctx is not None:
             c0, c1 = self.dist_ctx.compute_chunk_bounds(self._get_n_samples(X))

@@ -73,15 +73,21 @@ class UMAPAffinity(SparseAffinity):
             return (P, None) if return_indices else P
         if self.verbose:
             self.logger.info(f"Sparsity mode enabled, computing {n_neighbors} nearest neighbors...")
-        from torchdr_amd.distance import base as _dbase
+        from torchdr_amd.utils.phases import phase
 
-        _dbase.LAST_KNN["cluster_order"] = None
-        C_, indices = self._distance_matrix(X, k=int(n_neighbors), return_indices=True)
-        # single-GPU pruned search: the cluster-sorted row order it worked in (UMAP renumbers its loop in that order)
-        # (taken out of the record: it is this call's, and the record must not keep device memory alive)
-        order = _dbase.LAST_KNN.pop("cluster_order", None)
-        self._row_order = order if not self.is_multi_gpu else None
-        rho, eps, P = umap_sigma_search(C_, n_neighbors, self.max_iter)
+        # the cluster-sorted row order a pruned search worked in comes back in `info` (UMAP numbers the points of its loop
+        # in that order).  Row-sharded: a UMAP that can run in that numbering says so (`_accept_loop_order`), and the rank
+        # then KEEPS the rows of its range of the order instead of exchanging them -- rows and neighbour indices of
+        # everything below are positions of the order (`_rows_in_loop_order`).
+        info = {"want_loop_order": bool(self.is_multi_gpu and getattr(self, "_accept_loop_order", False))}
+        with phase("knn"):
+            C_, indices = self._distance_matrix(X, k=int(n_neighbors), return_indices=True, info=info)
+        self._row_order = info.get("cluster_order")
+        self._rows_in_loop_order = bool(info.get("loop_order"))
+        if self.is_multi_gpu and not self._rows_in_loop_order:
+            self._row_order = None
+        with phase("sigma search"):
+            rho, eps, P = umap_sigma_search(C_, n_neighbors, self.max_iter)
         self.register_buffer("rho_", rho, persistent=False)
         self.register_buffer("eps_", eps, persistent=False)
 
@@ -92,11 +98,14 @@ class UMAPAffinity(SparseAffinity):
         if self.is_multi_gpu:
             from torchdr_amd.parallel import exchange_transposed_edges
 
-            ext = exchange_transposed_edges(P, indices, self.chunk_start_, n_samples_in, self.world_size)
-            csr = symmetrize_to_csr(P, indices, "sum_minus_prod", row_offset=self.chunk_start_,
-                                    n_total=n_samples_in, ext=ext)
+            with phase("symmetrise: edge exchange (all-to-all)"):
+                ext = exchange_transposed_edges(P, indices, self.chunk_start_, n_samples_in, self.world_size)
+            with phase("symmetrise"):
+                csr = symmetrize_to_csr(P, indices, "sum_minus_prod", row_offset=self.chunk_start_,
+                                        n_total=n_samples_in, ext=ext)
         else:
-            csr = symmetrize_to_csr(P, indices, "sum_minus_prod", n_total=n_samples_in)
+            with phase("symmetrise"):
+                csr = symmetrize_to_csr(P, indices, "sum_minus_prod", n_total=n_samples_in)
         self._csr_ = csr
         if return_csr:
             return csr

@@ -132,6 +132,8 @@ class AffinityMatcher(DRModule):
                 f"[torchdr_amd] only float32 inputs are supported by the HIP path (got {X.dtype})."
             )
 
+        from torchdr_amd.utils.phases import phase
+
         self._start_pca_prefetch(X)
         self.on_affinity_computation_start()
         if self.affinity_in == "precomputed":   # reference :259-271
@@ -151,19 +153,22 @@ class AffinityMatcher(DRModule):
                     f"----- Computing the input affinity matrix with {self.affinity_in.__class__.__name__} -----"
                 )
             self._compute_affinity_in(X)
-        self.on_affinity_computation_end()
+        with phase("loop layout (epoch counters, exclusion tables, RCCL context)"):
+            self.on_affinity_computation_end()
 
         if self.verbose:
             self.logger.info("----- Optimizing the embedding -----")
-        self._init_embedding(X)
-        self._set_learning_rate()
-        self._configure_optimizer()
-        self._configure_scheduler()
+        with phase("init embedding"):
+            self._init_embedding(X)
+            self._set_learning_rate()
+            self._configure_optimizer()
+            self._configure_scheduler()
         del X
 
         self._nan_flag = torch.zeros(1, dtype=torch.int32, device=self.device_)
-        self._run_training_loop()
-        self._raise_if_nan()
+        with phase("loop"):
+            self._run_training_loop()
+            self._raise_if_nan()
         self.clear_memory()
         return self.embedding_
 

@@ -80,11 +80,16 @@ class DRModule(BaseEstimator, nn.Module, ABC):
         if getattr(self, "sharded_input", False) and getattr(self, "world_size", 1) > 1:
             # X is this rank's row shard: one all-gather of the shards, then the replicated-input path
             from torchdr_amd.parallel import gather_row_shards
+            from torchdr_amd.utils.phases import phase
 
-            X = gather_row_shards(X)
+            with phase("shard gather (all-gather of X)"):
+                X = gather_row_shards(X)
         inverse = None
         if self.process_duplicates:
-            X, inverse = unique_rows(X, self.device)
+            from torchdr_amd.utils.phases import phase
+
+            with phase("input checks (dedup)"):
+                X, inverse = unique_rows(X, self.device)
             if inverse is not None:
                 self.logger.info(
                     f"Detected {inverse.numel() - X.shape[0]} duplicate samples, performing DR on unique data."

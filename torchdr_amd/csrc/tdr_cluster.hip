@@ -1,6 +1,6 @@
 // Coarse cluster index of the pruned exact self search (DESIGN.md "Cluster-bound pruning"), built with the package's own
 // kernels.  The search result never depends on this index -- only the number of tiles the scan may skip does -- so the
-// index is free to be approximate (sampling, projected seeding, unordered cluster members); its BOUNDS are not: radii are
+// index is free to be approximate (sampling, projected seeding); its BOUNDS are not: radii are
 // rounded up and centre distances down from direct-difference evaluations.
 //
 // Stages (host: torchdr_amd/distance/base.py:ClusterIndex):
@@ -16,7 +16,8 @@
 //                  sums in sample order (one workgroup per cluster)
 //   4. bounds      radius_c = max |x - c| over the members (direct difference, rounded up), centre distance matrix
 //                  (direct difference, rounded down), visiting order = per-row rank sort of the centre distances
-//   5. layout      members of a cluster contiguous, every cluster padded to a multiple of 32 rows (row_map, -1 = padding)
+//   5. layout      members of a cluster contiguous and in ascending row order (stable counting sort: deterministic), every
+//                  cluster padded to a multiple of 32 rows (row_map, -1 = padding); + the compact order perm / inv
 #include "tdr_common.h"
 
 namespace tdr {
@@ -189,40 +190,111 @@ __global__ __launch_bounds__(256) void centre_tables_kernel(const float* __restr
 // one workgroup: tiles_c = ceil(count_c / 32), tile_begin = exclusive scan, tile_cluster[t] = c, *n_img = 32 * total tiles
 __global__ __launch_bounds__(256) void cluster_tiles_kernel(const int32_t* __restrict__ counts, int C, int32_t* __restrict__ tile_begin,
                                                             int32_t* __restrict__ tiles, int32_t* __restrict__ tile_cluster,
-                                                            int64_t* __restrict__ n_img) {
+                                                            int64_t* __restrict__ n_img, int32_t* __restrict__ row_begin) {
     __shared__ int tot[256];
+    __shared__ int rtot[256];
     const int tid = threadIdx.x;
     const int per = (C + 255) / 256;
     const int c0 = tid * per, c1 = (c0 + per < C) ? c0 + per : C;
-    int s = 0;
-    for (int c = c0; c < c1; ++c) s += (counts[c] + 31) / 32;
+    int s = 0, rs = 0;
+    for (int c = c0; c < c1; ++c) { s += (counts[c] + 31) / 32; rs += counts[c]; }
     tot[tid] = s;
+    rtot[tid] = rs;
     __syncthreads();
     if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < 256; ++i) { const int t = tot[i]; tot[i] = run; run += t; }
+        int run = 0, rrun = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int t = tot[i]; tot[i] = run; run += t;
+            const int rt = rtot[i]; rtot[i] = rrun; rrun += rt;
+        }
         tile_begin[C] = run;
+        row_begin[C] = rrun;
         *n_img = (int64_t)run * 32;
     }
     __syncthreads();
-    int run = tot[tid];
+    int run = tot[tid], rrun = rtot[tid];
     for (int c = c0; c < c1; ++c) {
         const int t = (counts[c] + 31) / 32;
         tile_begin[c] = run;
+        row_begin[c] = rrun;
         tiles[c] = t;
         for (int i = 0; i < t; ++i) tile_cluster[run + i] = c;
         run += t;
+        rrun += counts[c];
     }
 }
-// row_map[tile_begin[label] * 32 + position] = row (positions handed out by an atomic cursor per cluster)
-__global__ __launch_bounds__(256) void cluster_scatter_kernel(const int32_t* __restrict__ labels, int64_t n,
-                                                              const int32_t* __restrict__ tile_begin, int32_t* __restrict__ cursor,
-                                                              int32_t* __restrict__ row_map) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
-    const int l = labels[r];
-    const int pos = atomicAdd(&cursor[l], 1);
-    row_map[(size_t)tile_begin[l] * 32 + pos] = (int32_t)r;
+// Stable layout: the members of a cluster in ASCENDING ROW ORDER -- the same on every run and on every rank of a row-sharded
+// fit (each rank builds the index itself instead of receiving it; an atomic cursor per cluster would hand out positions in
+// arrival order).  A counting sort by label in three steps: the rows are cut into NB <= 2048 runs of `rps` consecutive rows,
+// one wavefront per run; (1) H[c][b] = members of cluster c in run b, (2) exclusive scan of every H[c][.], (3) a run walks
+// its rows 64 at a time: lanes holding the same label rank themselves by lane (ballots), the group's first lane advances
+// H[c][b] with ONE returning atomic and the others take its value -- a run is touched by one wavefront only, in order.
+// Also emits the compact cluster-sorted order (perm: position -> row, inv: row -> position, ppos: position -> padded position).
+__global__ __launch_bounds__(256) void cluster_hist_kernel(const int32_t* __restrict__ labels, int64_t n, int rps, int NB,
+                                                           int32_t* __restrict__ H) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= NB) return;
+    const int64_t r1 = ((int64_t)(b + 1) * rps < n) ? (int64_t)(b + 1) * rps : n;
+    for (int64_t r = (int64_t)b * rps + lane; r < r1; r += 64) atomicAdd(&H[(size_t)labels[r] * NB + b], 1);
+}
+// one wavefront per cluster: H[c][.] <- exclusive prefix sums over the runs
+__global__ __launch_bounds__(256) void cluster_hist_scan_kernel(int32_t* __restrict__ H, int C, int NB) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    int32_t* h = H + (size_t)c * NB;
+    const int per = (NB + 63) / 64;
+    const int b0 = lane * per, b1 = (b0 + per < NB) ? b0 + per : NB;
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += h[b];
+    int incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    int run = incl - s;
+    for (int b = b0; b < b1; ++b) { const int t = h[b]; h[b] = run; run += t; }
+}
+__global__ __launch_bounds__(256) void cluster_scatter_kernel(const int32_t* __restrict__ labels, int64_t n, int rps, int NB,
+                                                              const int32_t* __restrict__ tile_begin, const int32_t* __restrict__ row_begin,
+                                                              int32_t* __restrict__ H, int32_t* __restrict__ row_map,
+                                                              int32_t* __restrict__ perm, int32_t* __restrict__ inv,
+                                                              int32_t* __restrict__ ppos) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= NB) return;
+    const int64_t r1 = ((int64_t)(b + 1) * rps < n) ? (int64_t)(b + 1) * rps : n;
+    for (int64_t r0 = (int64_t)b * rps; r0 < r1; r0 += 64) {
+        const int64_t r = r0 + lane;
+        const bool valid = r < r1;
+        const int l = valid ? labels[r] : -1 - lane;   // idle lanes: labels of their own
+        int rank = 0, size = 1, leader = lane;
+        unsigned long long rem = __ballot(true);
+        while (rem) {
+            const int ld = __builtin_amdgcn_readfirstlane(__builtin_ctzll(rem));
+            const int lbl = __builtin_amdgcn_readlane(l, ld);
+            const unsigned long long m = __ballot(l == lbl);
+            if (l == lbl) {
+                rank = __popcll(m & ((1ull << lane) - 1ull));
+                size = __popcll(m);
+                leader = ld;
+            }
+            rem &= ~m;
+        }
+        int old = 0;
+        if (valid && lane == leader) old = atomicAdd(&H[(size_t)l * NB + b], size);
+        old = __shfl(old, leader, 64);
+        if (valid) {
+            const int pos = old + rank;
+            const int pp = tile_begin[l] * 32 + pos;
+            row_map[pp] = (int32_t)r;
+            if (perm) {
+                const int cp = row_begin[l] + pos;
+                perm[cp] = (int32_t)r;
+                inv[r] = cp;
+                ppos[cp] = pp;
+            }
+        }
+    }
 }
 
 }  // namespace tdr
@@ -272,30 +344,57 @@ int tdr_cluster_update_f32(const float* Xs, int64_t S, int d, const int32_t* lab
     return TDR_OK;
 }
 
+static inline void cluster_runs(int64_t n, int* rps, int* NB) {
+    int64_t per = (n + 2047) / 2048;
+    per = (per + 63) / 64 * 64;
+    if (per < 1024) per = 1024;
+    *rps = (int)per;
+    *NB = (int)((n + per - 1) / per);
+}
+
+/* bytes of the scratch block tdr_cluster_tables_f32 needs */
+int64_t tdr_cluster_tables_workspace_bytes(int64_t n, int C) {
+    if (n <= 0 || C <= 0) return 0;
+    int rps, NB;
+    cluster_runs(n, &rps, &NB);
+    return ((int64_t)2 * C + 1 + (int64_t)C * NB) * 4;
+}
+
 /* 4 + 5. everything that follows the assignment of all n points (labels): radii (rounded up), cluster sizes, the padded
  * cluster-sorted layout (row_map: n + 32 C int32, -1 = padding; tile_cluster: (n + 32 C) / 32 int32; tile_begin: C + 1;
  * tiles: C; *n_img = rows of the padded image), centre distances (C x C, rounded down) and visiting order (C x C).
- * ws: 2 * C int32. */
+ * The members of a cluster are laid out by ascending row (deterministic).  perm / inv / ppos (n int32 each, all or none):
+ * the same order without padding: position -> row, row -> position, position -> position in the padded layout.  ws: tdr_cluster_tables_workspace_bytes(n, C). */
 int tdr_cluster_tables_f32(const float* X, int64_t n, int d, int64_t ldx, const int32_t* labels, const float* cent, int C,
                            float* radius, int32_t* tile_begin, int32_t* tiles, int32_t* tile_cluster, int32_t* row_map,
-                           int64_t* n_img, float* dist, int32_t* order, void* ws, void* stream) {
+                           int64_t* n_img, float* dist, int32_t* order, int32_t* perm, int32_t* inv, int32_t* ppos, void* ws,
+                           int64_t ws_bytes, void* stream) {
     if (!X || !labels || !cent || !radius || !tile_begin || !tiles || !tile_cluster || !row_map || !n_img || !dist || !order || !ws)
         return TDR_ERR_BAD_ARG;
-    if (n <= 0 || d <= 0 || ldx < d || C <= 0 || n >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
+    if (n <= 0 || d <= 0 || ldx < d || C <= 0 || n >= 0x7fffffffLL || (perm == nullptr) != (inv == nullptr) ||
+        (perm == nullptr) != (ppos == nullptr))
+        return TDR_ERR_BAD_ARG;
     if (C > 4096) return TDR_ERR_UNSUPPORTED;
+    if (ws_bytes < tdr_cluster_tables_workspace_bytes(n, C)) return TDR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    int rps, NB;
+    cluster_runs(n, &rps, &NB);
     int32_t* counts = (int32_t*)ws;
-    int32_t* cursor = counts + C;
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)2 * C * 4, st);
+    int32_t* row_begin = counts + C;
+    int32_t* H = row_begin + C + 1;
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)tdr_cluster_tables_workspace_bytes(n, C), st);
     if (e == hipSuccess) e = hipMemsetAsync(radius, 0, (size_t)C * 4, st);
     if (e == hipSuccess) e = hipMemsetAsync(row_map, 0xFF, (size_t)(n + 32 * (int64_t)C) * 4, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(cluster_radius_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, X, n, d, ldx, labels, cent,
                        (unsigned*)radius, counts);
     hipLaunchKernelGGL(radius_round_up_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, radius, C);
-    hipLaunchKernelGGL(cluster_tiles_kernel, dim3(1), dim3(256), 0, st, (const int32_t*)counts, C, tile_begin, tiles, tile_cluster, n_img);
-    hipLaunchKernelGGL(cluster_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, labels, n,
-                       (const int32_t*)tile_begin, cursor, row_map);
+    hipLaunchKernelGGL(cluster_tiles_kernel, dim3(1), dim3(256), 0, st, (const int32_t*)counts, C, tile_begin, tiles, tile_cluster, n_img,
+                       row_begin);
+    hipLaunchKernelGGL(cluster_hist_kernel, dim3((unsigned)((NB + 3) / 4)), dim3(256), 0, st, labels, n, rps, NB, H);
+    hipLaunchKernelGGL(cluster_hist_scan_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, st, H, C, NB);
+    hipLaunchKernelGGL(cluster_scatter_kernel, dim3((unsigned)((NB + 3) / 4)), dim3(256), 0, st, labels, n, rps, NB,
+                       (const int32_t*)tile_begin, (const int32_t*)row_begin, H, row_map, perm, inv, ppos);
     hipLaunchKernelGGL(centre_tables_kernel, dim3((unsigned)C), dim3(256), (size_t)C * sizeof(float), st, cent, C, d, dist, order);
     TDR_CHECK_LAUNCH();
     return TDR_OK;

@@ -278,8 +278,9 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
     }
 }
 
-// Loop layout of a row's edges: ascending eps_per (= often-firing edges first, never-firing ones last), ties by
-// position.  Rank sort per row, one wavefront per row: the row's periods sit in registers (lane p holds entries p,
+// Loop layout of a row's edges: ascending eps_per (= often-firing edges first, never-firing ones last), ties by column
+// id, then position -- the order does not depend on how the CSR row was arranged, so a row-sharded fit (rows symmetrised
+// in the loop's numbering) and a single-process one (rows permuted into it) sum a row's forces in the same order.  Rank sort per row, one wavefront per row: the row's periods sit in registers (lane p holds entries p,
 // p + 64, ...) and every entry is broadcast once through the scalar unit (v_readlane); rows of more than 2048 edges
 // keep their order.
 __global__ __launch_bounds__(256) void umap_sched_layout_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(256) void umap_sched_layout_kernel(const int64_t* _
         int rank = 0;
         for (int q = 0; q < len; ++q) {
             const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), q));
-            rank += (o < mine || (o == mine && q < lane)) ? 1 : 0;
+            const int32_t oc = __builtin_amdgcn_readlane(col, q);
+            rank += (o < mine || (o == mine && (oc < col || (oc == col && q < lane)))) ? 1 : 0;
         }
         if (have) { cols_out[b + rank] = col; eps_out[b + rank] = mine; }
         return;
@@ -310,16 +312,19 @@ __global__ __launch_bounds__(256) void umap_sched_layout_kernel(const int64_t* _
         const int p = p0 + lane;
         const bool have = p < len;
         const float mine = have ? eps_per[b + p] : 0.f;
+        const int32_t col = have ? cols[b + p] : 0;
         int rank = 0;
         for (int q0 = 0; q0 < len; q0 += 64) {
             const float theirs = (q0 + lane < len) ? eps_per[b + q0 + lane] : __builtin_inff();
+            const int32_t tcol = (q0 + lane < len) ? cols[b + q0 + lane] : 0;
             const int nq = (len - q0 < 64) ? len - q0 : 64;
             for (int q = 0; q < nq; ++q) {
                 const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, theirs), q));
-                rank += (o < mine || (o == mine && q0 + q < p)) ? 1 : 0;
+                const int32_t oc = __builtin_amdgcn_readlane(tcol, q);
+                rank += (o < mine || (o == mine && (oc < col || (oc == col && q0 + q < p)))) ? 1 : 0;
             }
         }
-        if (have) { cols_out[b + rank] = cols[b + p]; eps_out[b + rank] = mine; }
+        if (have) { cols_out[b + rank] = col; eps_out[b + rank] = mine; }
     }
 }
 
@@ -352,8 +357,13 @@ struct SchedGradParams {
     int j_lvl_upper[8][3];
 };
 
-// this slice's share of the row's n_use negatives: exact binomial halving level by level (= slice_count(),
-// tdr_embed_common.h) with the hash words spread over the G lanes of the row group and a DPP reduction
+// this slice's share of the row's n_use negatives: binomial halving level by level (= slice_count(),
+// tdr_embed_common.h) with the hash words spread over the G lanes of the row group and a DPP reduction.  Every level
+// flips FAIR coins, which is the exact multinomial split when the S slices of the reduced index range [0, N - 1) are
+// equally long; the last slice is up to S - 1 indices shorter (step = ceil((N - 1) / S)), so its points are drawn with
+// probability 1 / (S len_last) instead of 1 / (N - 1): a relative bias of at most S / N (8e-6 at the smallest N that has
+// two slices), far below the sampling noise of 150 draws per row.  S > 1 only when Z exceeds one L2 (N >= 512 k rows of
+// two floats), so an empty last slice (N - 1 < S) cannot occur there; it is guarded (nneg = 0) for direct callers.
 template <int G>
 __device__ __forceinline__ int pass_negative_count(int n_levels, const uint32_t (&lvl_xor)[3], const int (&lvl_upper)[3], uint32_t rkey,
                                                    int n_use, int gl) {

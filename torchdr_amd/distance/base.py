@@ -144,7 +144,7 @@ class ClusterIndex:
         _lib.check(L.tdr_gather_rows_f32(_lib.ptr(X), X.stride(0), D, _lib.ptr(sample_idx), _lib.ptr(seeds), C, _lib.ptr(cent), st),
                    "tdr_gather_rows_f32")
         # 3. Lloyd steps on the sample, then the assignment of all N points: nearest centre = exact kNN with k = 1
-        ws = torch.empty(C * D + C + 2 * C, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(int(L.tdr_cluster_tables_workspace_bytes(N, C)) // 4, C * D + 3 * C) + 1, dtype=torch.int32, device=dev)
         for _ in range(iters):
             _, lab = knn_packed(Ps, PackedPoints(cent), 1, "sqeuclidean", exclude_self=False, _allow_screen=False)
             _lib.check(L.tdr_cluster_update_f32(_lib.ptr(Xs), S, D, _lib.ptr(lab), C, _lib.ptr(cent), _lib.ptr(ws), st),
@@ -160,10 +160,16 @@ class ClusterIndex:
         n_img = torch.zeros(1, dtype=torch.int64, device=dev)
         cd = torch.empty((C, C), dtype=torch.float32, device=dev)
         order = torch.empty((C, C), dtype=torch.int32, device=dev)
+        # compact cluster-sorted order (members of a cluster by ascending row: the same on every run and every rank):
+        # perm[position] = row, inv[row] = position
+        self.perm = torch.empty(N, dtype=torch.int32, device=dev)
+        self.inv = torch.empty(N, dtype=torch.int32, device=dev)
+        self.ppos = torch.empty(N, dtype=torch.int32, device=dev)   # position -> position in the padded layout
         _lib.check(
             L.tdr_cluster_tables_f32(_lib.ptr(X), N, D, X.stride(0), _lib.ptr(labels), _lib.ptr(cent), C, _lib.ptr(radius),
                                      _lib.ptr(tile_begin), _lib.ptr(tiles), _lib.ptr(tile_cluster), _lib.ptr(row_map),
-                                     _lib.ptr(n_img), _lib.ptr(cd), _lib.ptr(order), _lib.ptr(ws), st),
+                                     _lib.ptr(n_img), _lib.ptr(cd), _lib.ptr(order), _lib.ptr(self.perm), _lib.ptr(self.inv),
+                                     _lib.ptr(self.ppos), _lib.ptr(ws), ws.numel() * 4, st),
             "tdr_cluster_tables_f32",
         )
         self.n_clusters = C
@@ -185,6 +191,15 @@ class ClusterIndex:
         self.row_map = row_map[: self.n_img]
         self.tile_cluster = tile_cluster[: self.n_img // 32]
         self.tiles = tiles.to(torch.int64)
+        return self
+
+    def record_stream(self, stream):
+        """The tables may have been allocated while a side stream was current (the build runs next to the pilots); the
+        search that follows uses them on `stream`: tell the caching allocator, so that freeing them cannot hand the
+        memory to a later side-stream allocation while kernels of `stream` still read it."""
+        for t in vars(self).values():
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(stream)
         return self
 
     def scan_fraction(self, tau: float) -> float:
@@ -315,6 +330,12 @@ def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset, side_work=Non
             side_finish()
     for sd in side:
         main.wait_stream(sd)
+    for pd, n_flagged in runs.values():   # allocated under a side stream, read on the main one
+        pd.record_stream(main)
+        n_flagged.record_stream(main)
+    ci_built = getattr(Y, "_cluster_index", None)
+    if ci_built is not None:
+        ci_built.record_stream(main)
     for tier in tiers:
         if tier not in runs:
             runs[tier] = launch(tier)
@@ -360,6 +381,7 @@ def _cluster_index(Y, ops, build=True):
         ci = Y._cluster_index = ClusterIndex(Y)
     if ci is not None:
         ci.finish()
+        ci.record_stream(torch.cuda.current_stream(Y.device))
     if ci is not None and ci.img16 is None:
         L = _lib.lib()
         ci.img16 = torch.empty(L.tdr_packed16_floats(ci.n_img, Y.d), dtype=torch.float32, device=Y.device)
@@ -402,7 +424,7 @@ def _want_prune(Y, n):
     return PRUNE_MODE != "0" and (PRUNE_MODE == "force" or n >= _PRUNE_MIN_N)
 
 
-def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, pilot=True, tier=1):
+def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, pilot=True, tier=1, info=None):
     """Two-stage search of queries Q[q0:q0+nq] against Y (tier chosen by a pilot slice for large searches; the full
     self search of clustered data additionally prunes by cluster bounds); rows whose screening list overflowed are
     redone by the one-stage exact kernel.  Returns the number of such rows, or -1 when the pilot says the data does not
@@ -432,9 +454,11 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
         _screen_fallback(Q, Y, q0, k, metric, exclude_self, q_offset, flags.nonzero().squeeze(1), out_d, out_i)
     LAST_KNN["tier"] = tier
     LAST_KNN["pruned"] = bool(prune)
-    # the cluster-sorted row order of a pruned self search (source row of every position, -1 in the padding; cluster of
-    # every 32 positions): callers that go on to gather rows by neighbour index (the UMAP loop) renumber the points in it
-    LAST_KNN["cluster_order"] = (ci.row_map, ci.tile_cluster) if prune else None
+    # the cluster-sorted row order of a pruned self search (perm: position -> source row, inv: row -> position; members
+    # of a cluster by ascending row): callers that go on to gather rows by neighbour index (the UMAP loop) renumber the
+    # points in it.  Handed to the caller through its `info` record, not through module state.
+    if info is not None:
+        info["cluster_order"] = (ci.perm, ci.inv) if prune else None
     return bad
 
 
@@ -448,15 +472,21 @@ def _ivf_request(backend, self_search, k, n, d, metric):
         return None
     if d > 256 or not _lib.lib().tdr_knn_screen_supported(d, int(k)) or n < 4096:
         return None
-    nlist = max(1, min(int(getattr(backend, "nlist", 100)), n // 64, int(_lib.lib().tdr_cluster_maxmin_capacity())))
+    # the index builder's limits: the seeding workgroup's sample capacity and the 4096 clusters of the table kernel
+    # (a larger nlist is served with 4096 lists and proportionally fewer probes would be wrong: keep nprobe as given)
+    nlist = max(1, min(int(getattr(backend, "nlist", 100)), n // 64, int(_lib.lib().tdr_cluster_maxmin_capacity()), _IVF_MAX_LISTS))
     return nlist, max(1, min(int(getattr(backend, "nprobe", 1)), nlist))
 
 
-def _knn_ivf(Y: "PackedPoints", k: int, metric: str, exclude_self: bool, nlist: int, nprobe: int):
+_IVF_MAX_LISTS = 4096   # tdr_cluster_tables_f32 (per-cluster LDS rank sort of the centre distances)
+
+
+def _knn_ivf(Y: "PackedPoints", k: int, metric: str, exclude_self: bool, nlist: int, nprobe: int, info=None):
     """Approximate self search (distance/faiss.py:331-349, ``IndexIVFFlat``): ``nlist`` clusters from the package's own
     index builder, ``nprobe`` cluster scans per block of 128 queries of the cluster-sorted order (``tdr_knn_ivf_f32``).
-    Distances are exact for every returned pair; rows that find fewer than k candidates keep (+inf, -1) in the tail, as
-    Faiss returns them."""
+    Distances are exact for every returned pair.  Rows that find fewer than k candidates in the lists they probed (small
+    or singleton clusters at low ``nprobe``; Faiss pads such rows with -1) are searched exactly instead: the affinity and
+    symmetrisation stages downstream index the embedding with these columns and must never see -1 / +inf."""
     L = _lib.lib()
     dev, d = Y.device, Y.d
     ops = _screen_operands(Y, Y)
@@ -487,86 +517,85 @@ def _knn_ivf(Y: "PackedPoints", k: int, metric: str, exclude_self: bool, nlist: 
                           _lib.stream_ptr()),
         "tdr_knn_ivf_f32",
     )
-    bad = int(n_flagged.item())
-    if bad:  # spare list slots overflowed: those rows are searched exactly
-        _screen_fallback(Y, Y, 0, k, metric, exclude_self, 0, flags.nonzero().squeeze(1), out_d, out_i)
+    # spare list slots overflowed, or fewer than k candidates found: those rows are searched exactly
+    redo = ((flags != 0) | (out_i[:, k - 1] < 0)).nonzero().squeeze(1)
+    bad = int(redo.numel())
+    if bad:
+        _screen_fallback(Y, Y, 0, k, metric, exclude_self, 0, redo, out_d, out_i)
     LAST_KNN["path"], LAST_KNN["flagged"], LAST_KNN["tier"], LAST_KNN["pruned"] = f"ivf (nlist={ci.n_clusters}, nprobe={nprobe})", bad, tier, False
-    LAST_KNN["cluster_order"] = (ci.row_map, ci.tile_cluster)
+    if info is not None:
+        info["cluster_order"] = (ci.perm, ci.inv)
     return out_d, out_i
 
 
-def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: bool, ctx: DistributedContext):
+def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: bool, ctx: DistributedContext,
+                       loop_order: bool = False, info: Optional[dict] = None):
     """Row-sharded self search with cluster-bound pruning.  Pruning works on the cluster-sorted order, so every rank
-    answers the queries of ONE CONTIGUOUS RANGE of that order (balanced, arbitrary source rows) and the rows are then
-    sent to the ranks that own them (all-to-all-v, the same exchange the symmetrisation uses).  The index is built by
-    rank 0 and broadcast, and the tier / prune decisions are all-reduced, so that every rank takes the same path.
-    Returns this rank's chunk (values, indices), or None when the ranks agree that pruning does not pay."""
-    from torchdr_amd.parallel import allreduce_max_, broadcast_, exchange_rows_to_owners
+    answers the queries of ONE CONTIGUOUS RANGE of that order (the chunk rule applied to positions: balanced, arbitrary
+    source rows).  Every rank builds the SAME cluster index by itself, next to the pilot search of its own chunk -- the
+    index kernels are deterministic (stable layout, ordered Lloyd sums), so nothing is built on one rank and broadcast;
+    the pilots' votes are combined by one MAX all-reduce, after which every decision is a function of identical inputs.
 
-    L = _lib.lib()
+    ``loop_order=False``: the rows then travel to the ranks that own them in the CALLER's numbering (all-to-all-v, the
+    exchange the symmetrisation uses); returns this rank's chunk (values, indices).
+    ``loop_order=True``: no exchange -- the rank KEEPS its range.  Returned row j is position ``chunk_start + j`` of the
+    cluster-sorted order and neighbour indices are positions too; ``info["cluster_order"] = (perm, inv)`` maps positions
+    to the caller's rows and back.  The estimator runs every later stage (sigma search, symmetrisation, loop) in that
+    numbering, where a rank's neighbours are almost all its own rows, and un-permutes the embedding at the end.
+
+    Returns None when the ranks agree that pruning does not pay."""
+    from torchdr_amd.parallel import allreduce_max_, exchange_rows_to_owners
+    from torchdr_amd.utils.phases import phase
+
     dev = Y.device
     n, W, rank = Y.n, ctx.world_size, ctx.rank
     c0, c1 = ctx.compute_chunk_bounds(n)
-    ops = _screen_operands(Y, Y)
-    # rank 0 builds the cluster index while the other ranks run the pilot on their chunks (its own chunk is no more
-    # telling than theirs, so it abstains from the vote); identical tables are broadcast afterwards
-    if rank == 0 and W > 1:
-        ci = ClusterIndex(Y)
-        tier, tau = 0, None
-    else:
-        tier, tau = _choose_tier(Y, Y, ops, (c0 // 32) * 32, k, metric, exclude_self, 0)
+    with phase("knn: pilots + cluster index"):
+        ops = _screen_operands(Y, Y)
+        q0 = max(0, min((c0 // 32) * 32, ((n - _SCREEN_PILOT_Q) // 32) * 32))
+        tier, tau = _choose_tier(Y, Y, ops, q0, k, metric, exclude_self, 0,
+                                 side_work=((lambda: _cluster_index_start(Y)), (lambda: _cluster_index(Y, ops))))
     # one decision for all ranks: any rank without a usable tier -> nobody prunes; else the most conservative tier and
     # the largest threshold estimate (element-wise MAX all-reduce)
     vote = torch.tensor([float(tier < 0), float(max(tier, 0)), 0.0 if tau is None else tau], dtype=torch.float64, device=dev)
-    allreduce_max_(vote)
+    with phase("knn: vote (all-reduce)"):
+        allreduce_max_(vote)
     if float(vote[0]) > 0:
         return None
     tier, tau = int(vote[1]), float(vote[2])
-    if rank == 0:
-        if W == 1:
-            ci = ClusterIndex(Y)
-        head = torch.tensor([ci.n_clusters, ci.n_img], dtype=torch.int64, device=dev)
-    else:
-        ci = ClusterIndex.__new__(ClusterIndex)
-        head = torch.zeros(2, dtype=torch.int64, device=dev)
-    broadcast_(head)
-    C, n_img = int(head[0]), int(head[1])
-    if rank != 0:
-        ci.n_clusters, ci.n_img, ci.img16 = C, n_img, None
-        ci.row_map = torch.empty(max(n_img, 32), dtype=torch.int32, device=dev)
-        ci.tile_cluster = torch.empty(n_img // 32, dtype=torch.int32, device=dev)
-        ci.tile_begin = torch.empty(C + 1, dtype=torch.int32, device=dev)
-        ci.radius = torch.empty(C, dtype=torch.float32, device=dev)
-        ci.dist = torch.empty((C, C), dtype=torch.float32, device=dev)
-        ci.order = torch.empty((C, C), dtype=torch.int32, device=dev)
-    for t in (ci.row_map, ci.tile_cluster, ci.tile_begin, ci.radius, ci.dist, ci.order):
-        broadcast_(t)
-    if rank != 0:
-        tb = ci.tile_begin.long()
-        ci.tiles = tb[1:] - tb[:-1]
+    ci = _cluster_index(Y, ops)
     if PRUNE_MODE != "force" and ci.scan_fraction(2.0 * tau) > _PRUNE_MAX_SCAN_FRACTION:
         return None  # same tables and tau on every rank: same decision
-    Y._cluster_index = ci
-    _cluster_index(Y, ops, build=False)
-    # this rank's range of the sorted order (multiples of 256 positions)
-    per = ((n_img + W - 1) // W + 255) // 256 * 256
-    p0, p1 = min(rank * per, n_img), min((rank + 1) * per, n_img)
+    # this rank's positions [c0, c1) of the compact sorted order -> the range of the padded layout that holds them
+    # (begin rounded down to a query batch; the few extra rows are answered twice, by this rank and by its neighbour)
+    pp = ci.ppos[torch.tensor([c0, c1 - 1], device=dev)].tolist()
+    p0, p1 = (pp[0] // 256) * 256, pp[1] + 1
     out_d = torch.empty((n, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((n, k), dtype=torch.int32, device=dev)
-    rows = ci.row_map[p0:p1]
-    rows = rows[rows >= 0].long()
-    if p1 > p0:
+    rows = ci.perm[c0:c1].long()
+    with phase("knn: pruned scan + rescoring"):
         flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range=(p0, p1))
         if int(n_flagged.item()):
-            _screen_fallback(Y, Y, 0, k, metric, exclude_self, 0, rows[flags[rows] != 0], out_d, out_i)
-    Cc, Ic = exchange_rows_to_owners(rows.to(torch.int32), out_d[rows], out_i[rows], n, W, c0, c1 - c0)
+            mine = rows[flags[rows] != 0]
+            if mine.numel():
+                _screen_fallback(Y, Y, 0, k, metric, exclude_self, 0, mine, out_d, out_i)
     LAST_KNN["path"], LAST_KNN["flagged"], LAST_KNN["tier"], LAST_KNN["pruned"] = "screen-pruned", 0, tier, True
+    if loop_order:
+        with phase("knn: renumber"):
+            Cc = out_d[rows]
+            Ic = ci.inv[out_i[rows].long()]
+        if info is not None:
+            info["cluster_order"] = (ci.perm, ci.inv)
+            info["loop_order"] = True
+        return Cc, Ic
+    with phase("knn: rows to owners (all-to-all)"):
+        Cc, Ic = exchange_rows_to_owners(rows.to(torch.int32), out_d[rows], out_i[rows], n, W, c0, c1 - c0)
     return Cc, Ic
 
 
 def knn_packed(
     Q: PackedPoints, Y: PackedPoints, k: int, metric: str, exclude_self: bool, q_offset: int = 0,
-    q_rows: Optional[slice] = None, _allow_screen: bool = True,
+    q_rows: Optional[slice] = None, _allow_screen: bool = True, info: Optional[dict] = None,
 ):
     """k nearest database rows of ``Y`` for the queries ``Q`` (or the row slice ``q_rows`` of Q,
     which must start on a multiple of 32).  Returns (values (n,k) fp32 ascending, indices (n,k) int32).
@@ -591,10 +620,8 @@ def knn_packed(
     dev = Y.device
     out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
-    if _allow_screen:
-        LAST_KNN["cluster_order"] = None
     if _allow_screen and _use_screen(Q, Y, nq, k, metric):
-        bad = _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i)
+        bad = _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, info=info)
         if bad >= 0:
             LAST_KNN["path"], LAST_KNN["flagged"] = ("screen-pruned" if LAST_KNN.get("pruned") else "screen"), bad
             return out_d, out_i
@@ -923,6 +950,8 @@ def pairwise_distances(
 ):
     r"""Compute pairwise distances (or the k smallest per row) between two point sets.
 
+    (Body: :func:`_pairwise`, which additionally takes the ``info`` record the affinity classes use.)
+
     Same contract as the reference (``distance/base.py:22-249``, ``distance/torch.py:21-125``):
     ``C_ij = (||x_i||^2 + ||y_j||^2) - 2 x_i.y_j`` in fp32 (``sqeuclidean``, not clamped),
     ``sqrt(clamp(C, 0))`` (``euclidean``), ``-x_i.y_j`` (``angular``); when ``Y`` is None / is X
@@ -936,6 +965,14 @@ def pairwise_distances(
     distances is unspecified, so that is the only place results can differ from the
     reference's CPU backend (parity protocol).
     """
+    return _pairwise(X, Y, metric, backend, exclude_diag, k, return_indices, device, distributed_ctx, None)
+
+
+def _pairwise(X, Y, metric, backend, exclude_diag, k, return_indices, device, distributed_ctx, info):
+    """:func:`pairwise_distances` with an ``info`` record (dict or None) between the search and the affinity class that
+    called it -- in: ``want_loop_order`` (a row-sharded UMAP accepts its rows in the cluster-sorted numbering); out:
+    ``cluster_order`` = (perm, inv) of a pruned / approximate self search, ``loop_order`` = True when the returned rows
+    ARE in that numbering.  (Replaces the module-level record round 2 passed this through.)"""
     faiss_like = backend == "faiss" or type(backend).__name__ == "FaissConfig"
     if metric not in LIST_METRICS:
         if faiss_like:   # the message of the reference's Faiss backend (distance/faiss.py:297-300)
@@ -1019,7 +1056,8 @@ def pairwise_distances(
         if (distributed_ctx.world_size > 1 and _want_prune(Yp, n)
                 and _use_screen(Yp, Yp, n // distributed_ctx.world_size, int(k), metric)
                 and n // distributed_ctx.world_size >= _SCREEN_PILOT_Q):
-            res = knn_pruned_sharded(Yp, int(k), metric, bool(exclude_diag), distributed_ctx)
+            res = knn_pruned_sharded(Yp, int(k), metric, bool(exclude_diag), distributed_ctx,
+                                     loop_order=bool(info and info.get("want_loop_order")), info=info)
             if res is not None:
                 return res if return_indices else res[0]
         Qp = Yp if c0 % 32 == 0 else PackedPoints(X[c0:c1])
@@ -1059,9 +1097,9 @@ def pairwise_distances(
             raise ValueError("[TorchDR] ERROR : k must be smaller than the number of samples.")
         ivf = _ivf_request(backend, self_search, k, n_cols, Xp.d, metric)
         if ivf is not None:   # FaissConfig(index_type="IVF" / "IVFPQ"): approximate search on the cluster index
-            C, I = _knn_ivf(Yp, int(k), metric, do_exclude, *ivf)
+            C, I = _knn_ivf(Yp, int(k), metric, do_exclude, *ivf, info=info)
         else:
-            C, I = knn_packed(Xp, Yp, int(k), metric, do_exclude)
+            C, I = knn_packed(Xp, Yp, int(k), metric, do_exclude, info=info)
         return (C, I) if return_indices else C
 
     C = dense_packed(Xp, Yp, metric, do_exclude)

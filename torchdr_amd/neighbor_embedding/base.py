@@ -209,10 +209,14 @@ class NeighborEmbedding(AffinityMatcher):
 
     def _init_embedding(self, X: torch.Tensor):
         super()._init_embedding(X)
-        if self.world_size > 1:
+        if self.world_size > 1 and not (isinstance(self.init, str) and self.init == "pca"):
+            # reference :421.  init="pca" needs no exchange: every rank holds the full block and the PCA kernels are
+            # deterministic (ordered fp64 combination of the Gram tiles, one-workgroup Jacobi) -- same bits on every rank
             from torchdr_amd.parallel import broadcast_
+            from torchdr_amd.utils.phases import phase
 
-            broadcast_(self.embedding_, src=0)  # reference :421
+            with phase("init: broadcast"):
+                broadcast_(self.embedding_, src=0)
         return self.embedding_
 
 
@@ -273,7 +277,15 @@ class NegativeSamplingNeighborEmbedding(NeighborEmbedding):
 
     def on_affinity_computation_end(self):
         super().on_affinity_computation_end()
-        self._neg_seed = int(torch.randint(0, 2**62, (1,)).item()) + 7919 * self.rank
+        # ONE seed for all ranks (rank 0's): the sampler is keyed by (seed, iteration, GLOBAL row, column), so every row has
+        # its own stream whichever rank evaluates it, and a row-sharded fit draws exactly the negatives of the
+        # single-process fit with the same random_state
+        seed = torch.randint(0, 2**62, (1,))
+        if self.world_size > 1:
+            from torchdr_amd.parallel import broadcast_
+
+            seed = broadcast_(seed.to(self.device_), src=0).cpu()
+        self._neg_seed = int(seed.item())
         self._exclusion = None
         if self.discard_NNs:
             nn_rows = self._nn_for_exclusion()

@@ -108,15 +108,28 @@ class UMAP(NegativeSamplingNeighborEmbedding):
 
     # the affinity stays in CSR on the device (the reference's padded (N, max_deg) layout is 5-8x larger)
     def _compute_affinity_in(self, X):
+        # row-sharded: a fit whose loop may run in the cluster-sorted numbering tells the affinity so BEFORE the search --
+        # each rank then keeps the rows of its range of that order (no row exchange, neighbours mostly rank-local).  The
+        # test uses nothing rank-dependent: every rank takes the same branch.
+        self.affinity_in._accept_loop_order = bool(self.world_size > 1 and self._relabel_eligible_static())
         self._csr = self.affinity_in(X, return_indices=True, return_csr=True)
 
     def _relabel_eligible(self) -> bool:
+        if not self._relabel_eligible_static():
+            return False
+        if getattr(self.affinity_in, "_rows_in_loop_order", False):
+            return True     # row-sharded: the affinity already IS in the order
+        return self.world_size == 1 and self._csr.vals.dtype == torch.float32 and self._csr.n == self._csr.n_total
+
+    def _relabel_eligible_static(self) -> bool:
+        """What can be said before the affinity exists: the switches, and that nothing outside this class looks at rows
+        during the optimisation."""
         from torchdr_amd.affinity_matcher import AffinityMatcher
         from torchdr_amd.neighbor_embedding.base import NegativeSamplingNeighborEmbedding, NeighborEmbedding
 
-        if not (RELABEL and SCHEDULED) or self.world_size > 1 or self.discard_NNs or self.neg_indices_ is not None:
+        if not (RELABEL and SCHEDULED) or self.discard_NNs or self.neg_indices_ is not None:
             return False
-        if self._csr.vals.dtype != torch.float32 or self._csr.n != self._csr.n_total or self.n_samples_in_ >= 2**31 - 1:
+        if self.n_samples_in_ >= 2**31 - 1:
             return False
         cls = type(self)
         stock = (
@@ -130,33 +143,31 @@ class UMAP(NegativeSamplingNeighborEmbedding):
 
     def _relabel(self):
         """The loop's copy of the graph, numbered in the kNN stage's cluster-sorted order (``tdr_csr_permute_f32``);
-        ``self._perm[j]`` = caller's row of loop row j.  Returns the graph the loop runs on."""
+        ``self._perm[j]`` = caller's row of loop row j.  Returns the graph the loop runs on.  The order comes from the
+        cluster index (members of a cluster by ascending row: the same on every run and on every rank -- the loop's
+        numbering, and with it the negative sampler, must not depend on arrival order).  Row-sharded fits receive their
+        affinity rows in that numbering already (``UMAPAffinity._rows_in_loop_order``): only the map is kept."""
         self._perm = None
         self.loop_order_ = None     # kept after the fit: caller's row of every loop row, or None when the loop ran unrelabelled
         order = getattr(self.affinity_in, "_row_order", None)
         self.affinity_in._row_order = None
         if order is None or not self._relabel_eligible():
+            if getattr(self.affinity_in, "_rows_in_loop_order", False):
+                raise RuntimeError("[torchdr_amd] UMAP: the affinity rows are in cluster order but the loop cannot run in it.")
             return self._csr
-        csr, n, dev = self._csr, self._csr.n, self._csr.vals.device
-        row_map, tile_cluster = order
-        keep = row_map >= 0
-        if int(keep.sum()) != n:
+        perm, inv = order
+        csr, n, dev = self._csr, self._csr.n_total, self._csr.vals.device
+        if perm.numel() != n:
             return csr
-        # members of a cluster by ascending row (the index hands out positions inside a cluster in arrival order, which
-        # differs from run to run; the loop's numbering -- and with it the negative sampler -- must not)
-        key = (tile_cluster.to(torch.int64).repeat_interleave(32)[keep] << 32) | row_map[keep].to(torch.int64)
-        perm64 = key.sort().values & 0xFFFFFFFF
-        perm = perm64
-        inv = torch.empty(n, dtype=torch.int32, device=dev)
-        inv[perm64] = torch.arange(n, dtype=torch.int32, device=dev)
+        self._perm = self.loop_order_ = perm.to(torch.int64)
+        if getattr(self.affinity_in, "_rows_in_loop_order", False):
+            return csr
         rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-        torch.cumsum((csr.rowptr[1:] - csr.rowptr[:-1])[perm64], 0, out=rowptr[1:])
+        torch.cumsum((csr.rowptr[1:] - csr.rowptr[:-1])[self._perm], 0, out=rowptr[1:])
         cols, vals = torch.empty_like(csr.cols), torch.empty_like(csr.vals)
-        perm = perm.to(torch.int32).contiguous()
         _lib.check(_lib.lib().tdr_csr_permute_f32(_lib.ptr(csr.rowptr), _lib.ptr(csr.cols), _lib.ptr(csr.vals), n, _lib.ptr(perm),
                                                   _lib.ptr(inv), _lib.ptr(rowptr), _lib.ptr(cols), _lib.ptr(vals), _lib.stream_ptr()),
                    "tdr_csr_permute_f32")
-        self._perm = self.loop_order_ = perm64
         return CSRAffinity(rowptr, cols, vals, row_offset=0, n_total=n)
 
     def _init_embedding(self, X):
@@ -170,6 +181,9 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         return idx
 
     def on_affinity_computation_end(self):
+        # plans and buffers of a previous fit (kept until clear_memory, which a fit that raised never reached) are sized
+        # for THAT graph: never reuse them
+        self._sched, self._grad_buf, self._sched_deferred, self._grad_ws = None, None, False, None
         super().on_affinity_computation_end()
         csr: CSRAffinity = self._relabel()
         self._csr_loop = csr
