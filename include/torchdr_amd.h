@@ -75,6 +75,7 @@ int tdr_indexed_sqdist_f32(const float* X, int64_t nx, int d, const float* Y, in
 /* General feature dimension (D > 256): the contraction is a plain library GEMM per (query chunk x database chunk)
  * block, issued by the host; these three kernels are the rest of distance/torch.py:91-120 + utils/utils.py:215
  * (norm expansion, self exclusion, running top-k with the canonical (distance, index) order). */
+int tdr_topk_max_k(void);
 int tdr_topk_init(uint64_t* run_keys, int64_t nq, int k, void* stream);
 int tdr_topk_merge_f32(const float* G, int64_t ldg, int64_t nq, int64_t nd, const float* xn, const float* yn,
                        int64_t q_global0, int64_t d_global0, int k, int metric, int exclude_self, uint64_t* run_keys,

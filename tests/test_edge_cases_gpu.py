@@ -212,13 +212,55 @@ def test_umap_on_784_dimensional_input():
     assert Z.shape == (2000, 2) and bool(torch.isfinite(Z).all())
 
 
-def test_knn_more_neighbours_than_the_scan_lists_hold():
-    """k = 200 at D = 128 (perplexity ~ 66): beyond the LDS-resident lists -> library GEMM + running top-k."""
+@pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean", "angular"])
+@pytest.mark.parametrize("k,d", [(200, 128), (300, 128), (300, 50), (700, 24)])
+def test_knn_more_neighbours_than_the_scan_lists_hold(metric, k, d):
+    """k beyond the LDS-resident lists (perplexity 100 -> k = 300, affinity/entropic.py:259): blocks of the exact distance
+    matrix from the dense fp32-MFMA kernel + running top-k merge.  Distances AND indices equal the CPU oracle's bit for bit
+    (euclidean: the squared distances are ranked and ATen's vectorised sqrt is not correctly rounded -- values to 2e-7,
+    as everywhere else)."""
     import oracle
+    from torchdr_amd.distance import base as dbase
     from torchdr_amd.distance import pairwise_distances
 
-    X = gmm(2500, 128, 2.0, seed=23)
-    C, I = pairwise_distances(X.cuda(), metric="sqeuclidean", k=200, exclude_diag=True, return_indices=True)
-    Co, Io = oracle.knn(X, 200, "sqeuclidean", True)
-    assert float((I.cpu() != Io).any(1).float().mean()) < 0.05
-    assert torch.allclose(C.cpu(), Co, rtol=1e-4, atol=1e-3 * float(Co.abs().mean()))
+    X = gmm(2500, d, 2.0, seed=23)
+    C, I = pairwise_distances(X.cuda(), metric=metric, k=k, exclude_diag=True, return_indices=True)
+    assert dbase.LAST_KNN["path"].startswith("dense MFMA blocks")
+    Co, Io = oracle.knn(X, k, metric, True)
+    assert torch.equal(I.cpu(), Io)
+    if metric == "euclidean":
+        assert torch.allclose(C.cpu(), Co, rtol=2e-7, atol=0)
+    else:
+        assert torch.equal(C.cpu(), Co)
+
+
+def test_knn_large_k_cross_set_ragged_and_chunked():
+    """The same path on a cross search with ragged sizes, several query / database blocks and a row-sharded query chunk."""
+    import oracle
+    from torchdr_amd.distance import base as dbase
+    from torchdr_amd.distance import pairwise_distances
+
+    old = dbase._GENERAL_BQ, dbase._GENERAL_BD
+    dbase._GENERAL_BQ, dbase._GENERAL_BD = 512, 2048
+    try:
+        X, Y = gmm(1301, 40, 2.0, seed=3), gmm(5003, 40, 2.0, seed=4)
+        C, I = pairwise_distances(X.cuda(), Y.cuda(), metric="sqeuclidean", k=260, return_indices=True)
+        Co, Io = oracle.knn(X, 260, "sqeuclidean", False, Y=Y)
+        assert torch.equal(I.cpu(), Io) and torch.equal(C.cpu(), Co)
+        # self search, k = 300, queries = rows [1024, 2200) of the set (a rank's chunk): own row excluded by global index
+        Xp = dbase.PackedPoints(Y.cuda())
+        Cc, Ic = dbase.knn_packed(Xp, Xp, 300, "sqeuclidean", True, q_rows=slice(1024, 2200))
+        Cs, Is = oracle.knn(Y[1024:2200].contiguous(), 300, "sqeuclidean", True, Y=Y, q_offset=1024)
+        assert torch.equal(Ic.cpu(), Is) and torch.equal(Cc.cpu(), Cs)
+    finally:
+        dbase._GENERAL_BQ, dbase._GENERAL_BD = old
+
+
+def test_tsne_perplexity_100_runs():
+    """TSNE(perplexity=100) asks for k = 300 neighbours (entropic.py:259), which round 2 refused."""
+    import torchdr_amd
+
+    X = gmm(3000, 32, 2.0, seed=8).cuda()
+    m = torchdr_amd.TSNE(perplexity=100, max_iter=30, random_state=0)
+    Z = m.fit_transform(X)
+    assert Z.shape == (3000, 2) and bool(torch.isfinite(Z).all())

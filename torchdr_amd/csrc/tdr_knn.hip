@@ -1041,6 +1041,8 @@ static int launch_scan(const KnnParams& P, int n_wgs, size_t lds, int qb, hipStr
     return launch_scan_i<KQ, 2>(P, n_wgs, lds, qb, st);
 }
 
+constexpr int TOPK_MERGE_MAX_K = 1024;   // 16 list entries per lane, 4 x 8 KiB of LDS per workgroup
+
 static int launch_topk_merge(const TopkMergeParams& P, void* stream) {
     const int k = P.k;
     const int64_t nq = P.nq;
@@ -1048,7 +1050,9 @@ static int launch_topk_merge(const TopkMergeParams& P, void* stream) {
     const dim3 grid((unsigned)((nq + 3) / 4));
     if (k <= 64) hipLaunchKernelGGL(topk_merge_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, P);
     else if (k <= 128) hipLaunchKernelGGL(topk_merge_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(topk_merge_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, P);
+    else if (k <= 256) hipLaunchKernelGGL(topk_merge_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, P);
+    else if (k <= 512) hipLaunchKernelGGL(topk_merge_kernel<8>, grid, dim3(256), lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(topk_merge_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, P);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
@@ -1346,6 +1350,9 @@ int tdr_knn_overlap_i32(const int32_t* a, const int32_t* b, int64_t n, int K, fl
     return TDR_OK;
 }
 
+/* largest k of the running top-k lists (tdr_topk_merge_f32 / tdr_topk_merge_cand_f32) */
+int tdr_topk_max_k(void) { return TOPK_MERGE_MAX_K; }
+
 /* General-D kNN, step 1: run_keys (nq, k) <- empty lists. */
 int tdr_topk_init(uint64_t* run_keys, int64_t nq, int k, void* stream) {
     if (!run_keys || nq <= 0 || k <= 0) return TDR_ERR_BAD_ARG;
@@ -1362,7 +1369,7 @@ int tdr_topk_merge_f32(const float* G, int64_t ldg, int64_t nq, int64_t nd, cons
                        void* stream) {
     if (!G || !run_keys || nq <= 0 || nd <= 0 || ldg < nd || k <= 0) return TDR_ERR_BAD_ARG;
     if (metric < 0 || metric > 4 || ((metric < 2 || metric == 4) && (!xn || !yn))) return TDR_ERR_BAD_ARG;
-    if (k > 256) return TDR_ERR_UNSUPPORTED;
+    if (k > TOPK_MERGE_MAX_K) return TDR_ERR_UNSUPPORTED;
     TopkMergeParams P;
     P.G = G; P.ldg = ldg; P.nq = nq; P.nd = nd; P.xn = xn; P.yn = yn; P.q_global0 = q_global0; P.d_global0 = d_global0;
     P.k = k; P.metric = metric; P.exclude_self = exclude_self; P.run_keys = run_keys; P.cand = nullptr;
@@ -1374,7 +1381,7 @@ int tdr_topk_merge_f32(const float* G, int64_t ldg, int64_t nq, int64_t nd, cons
 int tdr_topk_merge_cand_f32(const float* E, const int32_t* cand, int64_t ld, int64_t nq, int64_t nc, int k,
                             uint64_t* run_keys, void* stream) {
     if (!E || !cand || !run_keys || nq <= 0 || nc <= 0 || ld < nc || k <= 0) return TDR_ERR_BAD_ARG;
-    if (k > 256) return TDR_ERR_UNSUPPORTED;
+    if (k > TOPK_MERGE_MAX_K) return TDR_ERR_UNSUPPORTED;
     TopkMergeParams P;
     P.G = E; P.ldg = ld; P.nq = nq; P.nd = nc; P.xn = nullptr; P.yn = nullptr; P.q_global0 = 0; P.d_global0 = 0;
     P.k = k; P.metric = 3; P.exclude_self = 0; P.run_keys = run_keys; P.cand = cand;

@@ -614,9 +614,9 @@ def knn_packed(
     nq = q1 - q0
     kmax = L.tdr_knn_max_k(d)
     if k > kmax:
-        # more neighbours than the scan kernel's LDS-resident lists hold (e.g. perplexity > 40 at D = 128): the
-        # library-GEMM + running top-k path has no such limit up to k = 256
-        return _knn_general(Q.X[q0:q1], Y.X, k, metric, exclude_self, q_global0=q_offset + q0)
+        # more neighbours than the scan kernels' LDS-resident lists hold (e.g. perplexity > 40 at D = 128): blocks of the
+        # exact distance matrix from the dense MFMA kernel + the running top-k merge -- same bits as the scan kernels
+        return _knn_dense_merge(Q, Y, q0, q1, k, metric, exclude_self, q_offset)
     dev = Y.device
     out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
@@ -757,6 +757,47 @@ def _knn_wide(Xq, Y, k, metric, exclude_self, q_global0=0):
     return out_d, out_i
 
 
+def _knn_dense_merge(Q: "PackedPoints", Y: "PackedPoints", q0: int, q1: int, k: int, metric: str, exclude_self: bool, q_offset: int):
+    """Exact kNN with k beyond the scan kernels' lists (``TSNE(perplexity=100)`` asks for k = 300,
+    affinity/entropic.py:259; utils/utils.py:203-216 has no limit): per (4096 queries x 65536 rows) block the dense
+    fp32-MFMA kernel (``tdr_dense_dist_packed_f32``: the k-ordered fma chain and the reference's epilogue, the arithmetic
+    of the scan kernels and of the CPU oracle) writes the distances and ``tdr_topk_merge_f32`` (value passthrough) folds
+    them into the running lists in the canonical (distance, index) order.  Distances AND indices are bit-identical to the
+    scan kernels' and the oracle's -- the library-GEMM form this replaces agreed to fp32 rounding only.  k <= 1024."""
+    L = _lib.lib()
+    dev, d = Y.device, Y.d
+    nq, nd = q1 - q0, Y.n
+    if k > int(L.tdr_topk_max_k()):
+        raise NotImplementedError(f"[torchdr_amd] k={k} > {int(L.tdr_topk_max_k())} neighbours is not supported by the running top-k kernel.")
+    st = _lib.stream_ptr()
+    keys = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    _lib.check(L.tdr_topk_init(_lib.ptr(keys), nq, k, st), "tdr_topk_init")
+    tile = int(L.tdr_packed_floats(32, d))
+    mid = _METRIC_ID[metric]
+    dense_metric = 0 if mid == 1 else mid       # euclidean: ranked on the squared values, square root at the end
+    bq = min(_GENERAL_BQ, (nq + 31) // 32 * 32)
+    G = torch.empty((bq, min(_GENERAL_BD, (nd + 31) // 32 * 32)), dtype=torch.float32, device=dev)
+    for c0 in range(0, nq, _GENERAL_BQ):
+        c1 = min(c0 + _GENERAL_BQ, nq)
+        for d0 in range(0, nd, _GENERAL_BD):
+            d1 = min(d0 + _GENERAL_BD, nd)
+            _lib.check(
+                L.tdr_dense_dist_packed_f32(_lib.ptr(Q.data[((q0 + c0) // 32) * tile:]), c1 - c0, 0, _lib.ptr(Y.data[(d0 // 32) * tile:]),
+                                            d1 - d0, d, dense_metric, 0, _DIAG_ADD, _lib.ptr(G), G.stride(0), st),
+                "tdr_dense_dist_packed_f32",
+            )
+            _lib.check(
+                L.tdr_topk_merge_f32(_lib.ptr(G), G.stride(0), c1 - c0, d1 - d0, None, None, q_offset + q0 + c0, d0, k, 3,
+                                     1 if exclude_self else 0, _lib.ptr(keys[c0:c1]), st),
+                "tdr_topk_merge_f32",
+            )
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    _lib.check(L.tdr_topk_emit_f32(_lib.ptr(keys), nq, k, mid, _lib.ptr(out_d), _lib.ptr(out_i), st), "tdr_topk_emit_f32")
+    LAST_KNN["path"], LAST_KNN["flagged"] = "dense MFMA blocks + top-k merge", 0
+    return out_d, out_i
+
+
 _GENERAL_BQ = 4096    # query rows per library-GEMM block of the general-D path
 _GENERAL_BD = 65536   # database rows per block (4096 x 65536 fp32 = 1 GiB)
 
@@ -774,8 +815,8 @@ def _knn_general(Xq, Y, k, metric, exclude_self, q_global0=0):
         res = _knn_wide(Xq, Y, k, metric, exclude_self, q_global0)
         if res is not None:
             return res
-    if k > 256:
-        raise NotImplementedError(f"[torchdr_amd] k={k} > 256 is not supported by the running top-k kernel.")
+    if k > int(L.tdr_topk_max_k()):
+        raise NotImplementedError(f"[torchdr_amd] k={k} > {int(L.tdr_topk_max_k())} is not supported by the running top-k kernel.")
     dev = Y.device
     l1 = metric == "manhattan"
     xn = yn = None
@@ -851,7 +892,7 @@ def _knn_manhattan(Xq, Y, k, exclude_self, q_global0=0):
     n_valid = nd - (1 if exclude_self else 0)
     if d >= _L1_EXACT_MAX_D:  # a third cascade level in the reference's sum: tile-order values (fp32 rounding apart)
         return _knn_general(Xq, Y, k, "manhattan", exclude_self, q_global0)
-    L = min(k + _L1_MARGIN, n_valid, 256)
+    L = min(k + _L1_MARGIN, n_valid, int(_lib.lib().tdr_topk_max_k()))
     Ca, Ia = _knn_general(Xq, Y, L, "manhattan", exclude_self, q_global0)
     E = _l1_exact(Xq, None, nq, q_global0, Y, Ia, L, 0, False)
     C, I = _rank_candidates(E, Ia, k)
