@@ -379,6 +379,24 @@ int tdr_khorn_grad_nc_f32(const float* packed, int64_t n, int d, const float* si
 int tdr_sinkhorn_pass_f32(const float* Z, int nc, const float* f, const float* Ef, float fmax, int64_t n, int zero_diag,
                           float diag_add, float* f_new, float* resid2, void* stream);
 
+/* ---- float64 embedding loop (csrc/tdr_embed_f64.hip) ------------------------------------------------------------------
+ * The reference computes in the dtype of its input and runs every neighbour-embedding method in float32 and float64
+ * (tests/test_neighbor_embedding.py:34,55-74): float64 twins of tdr_umap_prepare_f32 / tdr_umap_grad_f32 (per-step form,
+ * umap.py:215-292), tdr_ne_grad_f32 (largevis.py:181-201, tsne.py:162-170, sne.py, infotsne.py), tdr_tsne_repulsion_f32 /
+ * tdr_add_scaled_f32 (tsne.py:172-180) and tdr_sgd_step_f32 (affinity_matcher.py:427-429); same argument meaning. */
+int tdr_umap_prepare_f64(const double* vals, int64_t nnz, int max_iter, double* eps_per, double* next, void* scratch, void* stream);
+int tdr_umap_grad_f64(const double* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int64_t* rowptr,
+                      const int32_t* cols, const double* eps_per, double* next, double a, double b, int n_iter, int neg_rate,
+                      int n_negatives, const int64_t* neg_inj, uint64_t seed, double exag, double rep, double eps, double* grad,
+                      void* stream);
+int tdr_ne_grad_f64(const double* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nn, const double* P_,
+                    int k, const int64_t* t_rowptr, const int32_t* t_src, const double* t_val, int kind, double exag,
+                    double rep_coef, int n_neg, const int64_t* neg_inj, uint64_t seed, int n_iter, double* grad, void* stream);
+int tdr_tsne_repulsion_f64(const double* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, double* F, double* S, void* stream);
+int tdr_add_scaled_f64(double* grad, const double* F, const double* S, double coef, int64_t n, void* stream);
+int tdr_sgd_step_f64(double* Z, const double* grad, double* buf, int64_t n, double lr, double momentum, int first, int* nan_flag,
+                     int n_iter, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

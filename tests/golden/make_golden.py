@@ -202,6 +202,76 @@ def ne_step_fixture():
     save("ne_step", **out)
 
 
+def ne_step64_fixture():
+    """float64 inputs: the reference computes everything in its input's dtype (tests/test_neighbor_embedding.py:34,55-74 run
+    every method in float32 and float64) -- kNN, affinity, the epoch counters of UMAP, the embedding and the optimizer state
+    are float64.  Three UMAP steps and two LargeVis / TSNE steps of the real reference on float64 data."""
+    from torchdr import TSNE, UMAP, LargeVis
+
+    out = {}
+    X = gmm(500, 16, 2.0, seed=41).double()
+    rec = {}
+
+    class ProbeU(UMAP):
+        def on_affinity_computation_end(self):
+            super().on_affinity_computation_end()
+            rec["eps_per"] = self.epochs_per_sample.clone()
+            rec["NN"] = self.NN_indices_.clone()
+
+        def _training_step(self):
+            t = int(self.n_iter_)
+            if t < 3:
+                rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                rec[f"neg_{t}"] = self.neg_indices_.clone()
+                rec[f"next_{t}"] = self.epoch_of_next_sample.clone()
+                rec[f"lr_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["lr"]), dtype=torch.float64)
+            o = super()._training_step()
+            if t < 3:
+                rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+                rec[f"nextafter_{t}"] = self.epoch_of_next_sample.clone()
+            return o
+
+    torch.manual_seed(0)
+    m = ProbeU(n_neighbors=10, max_iter=20, backend=None, init="normal", random_state=0)
+    m.fit_transform(X)
+    assert rec["Z_0"].dtype == torch.float64 and rec["eps_per"].dtype == torch.float64
+    Ps, Is = UMAPAffinity(n_neighbors=10, backend=None, max_iter=100)(X)
+    out.update({f"umap_{k_}": v for k_, v in rec.items()})
+    out.update(umap_X=X, umap_Psym=Ps, umap_Isym=Is, umap_a=torch.tensor(m._a, dtype=torch.float64),
+               umap_b=torch.tensor(m._b, dtype=torch.float64))
+    X2 = gmm(400, 16, 2.0, seed=51).double()
+    out["ne_X"] = X2
+    for name, cls, kw in (("largevis", LargeVis, dict(perplexity=5)), ("tsne", TSNE, dict(perplexity=8))):
+        rec = {}
+
+        class Probe(cls):
+            def _training_step(self):
+                t = int(self.n_iter_)
+                if t < 2:
+                    rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                    if hasattr(self, "neg_indices_"):
+                        rec[f"neg_{t}"] = self.neg_indices_.clone()
+                    rec[f"lr_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["lr"]), dtype=torch.float64)
+                    rec[f"mom_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["momentum"]), dtype=torch.float64)
+                    rec[f"exag_{t}"] = torch.tensor(float(self.early_exaggeration_coeff_), dtype=torch.float64)
+                    if t == 0:
+                        rec["P"] = self.affinity_in_.clone()
+                        rec["NN"] = self.NN_indices_.clone()
+                loss = super()._training_step()
+                if t < 2:
+                    rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                    rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+                return loss
+
+        torch.manual_seed(1)
+        Probe(max_iter=4, backend=None, init="normal", random_state=1, **kw).fit_transform(X2)
+        assert rec["Z_0"].dtype == torch.float64 and rec["P"].dtype == torch.float64
+        for k_, v in rec.items():
+            out[f"{name}_{k_}"] = v
+    save("ne_step64", **out)
+
+
 def ne2_step_fixture():
     """SNE / InfoTSNE (the SURVEY section 8f "next" estimators): autograd gradient + momentum step."""
     from torchdr import SNE, InfoTSNE
@@ -758,7 +828,7 @@ def c1_tsne_fixture():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ALL = dict(knn=knn_fixtures, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
-               umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne2_step=ne2_step_fixture,
+               umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne_step64=ne_step64_fixture, ne2_step=ne2_step_fixture,
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
                cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture,

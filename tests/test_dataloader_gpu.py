@@ -56,3 +56,23 @@ def test_estimators_and_affinities_accept_a_dataloader(sample_data):
     # outputs for DataLoader inputs are CPU tensors, as in the reference (utils/wrappers.py:50-54, 76-85)
     assert isinstance(Z, torch.Tensor) and Z.device.type == "cpu" and Z.shape == (1000, 2)
     assert torch.allclose(Z, Zt.cpu(), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("bs,drop_last", [(50, False), (77, False), (1000, False), (96, True), (2048, False)])
+def test_batches_are_packed_as_they_arrive(sample_data, bs, drop_last):
+    """`pairwise_distances(dataloader)` streams every batch into its rows of the resident block and packs the MFMA tiles
+    it completes at once (`PackedPoints.from_batches`): the images and norms equal those of the concatenated block bit for
+    bit, whatever the batch size (tiles that straddle two batches, a ragged last tile, `drop_last`)."""
+    from torchdr_amd.distance.base import PackedPoints
+    from torchdr_amd.utils.dataloader import stream_dataloader_packed
+
+    dl = DataLoader(TensorDataset(sample_data), batch_size=bs, shuffle=False, drop_last=drop_last)
+    X, packed = stream_dataloader_packed(dl, "cuda", "sqeuclidean")
+    n = (len(sample_data) // bs) * bs if drop_last else len(sample_data)
+    assert packed is not None and packed.n == n and packed.X is X and X.shape == (n, 32)
+    ref = PackedPoints(sample_data[:n].cuda())
+    assert torch.equal(X, sample_data[:n].cuda()) and torch.equal(packed.norms, ref.norms)
+    assert torch.equal(packed.data[: ref.data.numel()], ref.data)
+    # metrics / shapes without fp32 tile images fall back to the resident block alone
+    X2, p2 = stream_dataloader_packed(dl, "cuda", "manhattan")
+    assert p2 is None and torch.equal(X2, X)

@@ -273,6 +273,9 @@ def test_bench_starts_its_own_ranks():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    # at this size the index has 70 clusters for 700 blobs and the default dispatch would (rightly) not prune: force the
+    # pruned, cluster-ordered path the headline size takes
+    env.update(TDR_KNN_PRUNE="force", TDR_KNN_SCREEN="force")
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--npoints", "70000", "--steps", "1",
                           "--warmup", "1", "--max-iter", "100", "--no-cpu-baseline", "--no-knn-variants"],
                          env=env, capture_output=True, text=True, timeout=600)

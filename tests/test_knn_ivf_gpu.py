@@ -96,3 +96,77 @@ def test_umap_with_an_ivf_backend():
     _, I = pairwise_distances(Z, metric="sqeuclidean", k=5, exclude_diag=True, return_indices=True)
     agree = float((labels[I.long()] == labels[:, None]).float().mean())
     assert agree > 0.8, agree
+
+
+def test_ivf_nlist_beyond_the_index_builder_is_clamped():
+    """FaissConfig(nlist=8192) (the reference's docs recommend 4096..16384 for large sets) used to reach the table
+    kernel with more clusters than it builds; it is served with the builder's 4096 lists."""
+    from torchdr_amd.distance import FaissConfig, pairwise_distances
+    from torchdr_amd.distance import base as dbase
+
+    n, k = 300_000, 10
+    X = gmm(n, 16, 2.0, seed=6).cuda()
+    C, I = pairwise_distances(X, metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True,
+                              backend=FaissConfig(index_type="IVF", nlist=8192, nprobe=16))
+    assert "nlist=4096" in dbase.LAST_KNN["path"]
+    assert bool((I >= 0).all()) and bool(torch.isfinite(C).all())
+
+
+def test_ivf_rows_with_too_few_candidates_are_searched_exactly():
+    """nprobe = 1 on many small lists leaves rows with fewer than k candidates; Faiss pads them with -1, which
+    the affinity / symmetrisation stages would index the embedding with.  Such rows are searched exactly: no -1, no inf,
+    and they equal the exact search's rows."""
+    from torchdr_amd.distance import FaissConfig, pairwise_distances
+
+    n, k = 30000, 40
+    X = gmm(n, 8, 1.0, seed=2).cuda()
+    Ce, Ie = pairwise_distances(X, metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True)
+    C, I = pairwise_distances(X, metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True,
+                              backend=FaissConfig(index_type="IVF", nlist=468, nprobe=1))    # ~64 rows per list < k + 1 for many
+    assert bool((I >= 0).all()) and bool(torch.isfinite(C).all())
+    assert bool((C[:, 1:] >= C[:, :-1]).all())
+    import torchdr_amd
+
+    Z = torchdr_amd.UMAP(n_neighbors=k, max_iter=30, random_state=0, backend=FaissConfig(index_type="IVF", nlist=468, nprobe=1)).fit_transform(X)
+    assert bool(torch.isfinite(Z).all())
+
+
+def test_ivf_search_at_ten_million_points():
+    """SURVEY 8f.4 motivates the approximate search by N >= 10M (reference: IVF nlist 16384 nprobe 81, 54.7 s at 99.9 % recall on
+    a B200, BENCHMARK_RESULTS.md:35).  N = 10M x 128 on one MI355X: 4096 lists (the builder's maximum), recall against 2048
+    sampled rows searched exactly (one-stage fp32 kernel against all 10M points); every returned distance exact."""
+    import time
+
+    from torchdr_amd.distance import FaissConfig, pairwise_distances
+    from torchdr_amd.distance import base as dbase
+
+    n, d, k = 10_000_000, 128, 15
+    g = torch.Generator().manual_seed(42)
+    centers = torch.randn(1000, d, generator=g) * 2.0
+    X = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    for s in range(0, n, 1_000_000):       # generated in slices: the host never holds the 5 GB block
+        lab = torch.arange(s, s + 1_000_000) % 1000
+        X[s:s + 1_000_000] = (centers[lab] + 0.5 * torch.randn(1_000_000, d, generator=g)).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    C, I = pairwise_distances(X, metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True,
+                              backend=FaissConfig(index_type="IVF", nlist=4096, nprobe=8))
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    assert dbase.LAST_KNN["path"].startswith("ivf") and bool((I >= 0).all())
+    rows = torch.randint(0, n, (2048,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    old = dbase.SCREEN_MODE
+    dbase.SCREEN_MODE = "0"
+    try:
+        Ce, Ie = pairwise_distances(X[rows].contiguous(), X, metric="sqeuclidean", k=k + 1, return_indices=True)
+    finally:
+        dbase.SCREEN_MODE = old
+    keep = Ie != rows[:, None].int()
+    ok = keep.sum(1) == k
+    Ie_k, Ce_k = Ie[ok][keep[ok]].reshape(-1, k), Ce[ok][keep[ok]].reshape(-1, k)
+    rec = recall(I[rows][ok].cpu(), Ie_k.cpu())
+    print({"ivf_10m_sec": round(sec, 2), "recall": round(rec, 4)})
+    assert rec > 0.99, rec
+    hit = I[rows][ok] == Ie_k           # where the same neighbour sits in the same slot, the distance is the exact one
+    assert torch.equal(C[rows][ok][hit], Ce_k[hit])
+    assert sec < 30.0

@@ -122,6 +122,32 @@ def test_umap_step_oracle():
     assert torch.allclose(lr, 1 - torch.arange(T, dtype=torch.float64) / T, atol=1e-6)
 
 
+def test_float64_steps_oracle():
+    """The oracle's restatements are dtype-generic: on the float64 fixture (the reference run on float64 data) they hold
+    to float64 accuracy -- counters bit for bit, gradients and steps at 1e-10."""
+    g = load("ne_step64")
+    a, b = float(g["umap_a"]), float(g["umap_b"])
+    eps_per, _ = R.umap_prepare(g["umap_Psym"], 20)
+    assert eps_per.dtype == torch.float64 and torch.equal(eps_per, g["umap_eps_per"])
+    for t in range(3):
+        nxt = g[f"umap_next_{t}"].clone()
+        ga, gr, _ = R.umap_gradients(g[f"umap_Z_{t}"], g["umap_NN"], eps_per, nxt, g[f"umap_neg_{t}"], t, a, b)
+        assert torch.allclose(ga + gr, g[f"umap_grad_{t}"], rtol=1e-10, atol=1e-12)
+        assert torch.equal(nxt, g[f"umap_nextafter_{t}"])
+    n = g["ne_X"].shape[0]
+    for name in ("largevis", "tsne"):
+        P, NN = g[f"{name}_P"], g[f"{name}_NN"]
+        buf = None
+        for t in range(2):
+            Z = g[f"{name}_Z_{t}"]
+            grad = float(g[f"{name}_exag_{t}"]) * R.ne_attraction_grad(Z, NN, P, name)
+            grad = grad + (R.largevis_repulsion_grad(Z, g[f"{name}_neg_{t}"], n) if name == "largevis" else R.tsne_repulsion_grad(Z)[0])
+            ref = g[f"{name}_grad_{t}"]
+            assert torch.allclose(grad, ref, rtol=1e-9, atol=1e-11 * float(ref.abs().max()))
+            Znew, buf = R.sgd_momentum_step(Z, ref, buf, float(g[f"{name}_lr_{t}"]), float(g[f"{name}_mom_{t}"]))
+            assert torch.allclose(Znew, g[f"{name}_Zafter_{t}"], rtol=1e-10, atol=1e-12)
+
+
 @pytest.mark.parametrize("name", ["largevis", "tsne"])
 def test_ne_step_oracle(name):
     g = load("ne_step")

@@ -85,6 +85,11 @@ def lib():
     return _lib
 
 
+def fn(name: str, dtype):
+    """Entry point `name`_f32 / `name`_f64 for a tensor dtype (the float64 twins of the embedding loop)."""
+    return getattr(lib(), name + ("_f64" if dtype == torch.float64 else "_f32"))
+
+
 def check(status, what):
     if status == 0:
         return

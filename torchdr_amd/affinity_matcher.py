@@ -127,10 +127,11 @@ class AffinityMatcher(DRModule):
         self.n_samples_in_, self.n_features_in_ = X.shape
         self.device_ = compute_device(X, self.device)
         X = X.to(self.device_)
-        if X.dtype != torch.float32:
+        if X.dtype != torch.float32 and not (X.dtype == torch.float64 and getattr(self, "_float64_loop", False)):
             raise NotImplementedError(
-                f"[torchdr_amd] only float32 inputs are supported by the HIP path (got {X.dtype})."
+                f"[torchdr_amd] only float32 inputs are supported by the HIP path of {type(self).__name__} (got {X.dtype})."
             )
+        self._dtype = X.dtype
 
         from torchdr_amd.utils.phases import phase
 
@@ -255,7 +256,7 @@ class AffinityMatcher(DRModule):
                     f"Gradient size mismatch in distributed mode: expected {self.chunk_size_} gradients for chunk but "
                     f"_compute_gradients() returned {grad.shape[0]}"
                 )
-            grad = grad.detach().to(torch.float32).contiguous()
+            grad = grad.detach().to(getattr(self, "_dtype", torch.float32)).contiguous()
         world = getattr(self, "world_size", 1)
         if world > 1 and rows_only and self._fused_sgd:
             from torchdr_amd.parallel import allgather_rows_
@@ -361,10 +362,10 @@ class AffinityMatcher(DRModule):
         if isinstance(holder, torch.optim.Optimizer):
             holder.param_groups[0]["lr"] = self._current_lr()
         _lib.check(
-            _lib.lib().tdr_sgd_step_f32(_lib.ptr(Z), _lib.ptr(grad), _lib.ptr(self._momentum_buf), Z.numel(),
-                                        self._current_lr(), mom, first, _lib.ptr(self._nan_flag), int(self.n_iter_),
-                                        _lib.stream_ptr()),
-            "tdr_sgd_step_f32",
+            _lib.fn("tdr_sgd_step", Z.dtype)(_lib.ptr(Z), _lib.ptr(grad), _lib.ptr(self._momentum_buf), Z.numel(),
+                                             self._current_lr(), mom, first, _lib.ptr(self._nan_flag), int(self.n_iter_),
+                                             _lib.stream_ptr()),
+            "tdr_sgd_step",
         )
 
     def _optimizer_step(self, grad):

@@ -23,6 +23,15 @@ def unique_rows(X: torch.Tensor, device="auto"):
     from torchdr_amd import _lib
     from torchdr_amd.utils import compute_device
 
+    if X.dim() == 2 and X.dtype == torch.float64 and X.shape[0] >= 2:
+        # float64 rows that are equal are equal after rounding to float32: the hash pass on the rounded block finds every
+        # candidate; only when it reports duplicates (or collisions) is the float64 block itself sorted
+        X = X.to(compute_device(X, device))
+        _, inv32 = unique_rows(X.to(torch.float32), device)
+        if inv32 is None:
+            return X, None
+        X_unique, inverse = torch.unique(X, dim=0, return_inverse=True)
+        return (X_unique, inverse) if X_unique.shape[0] < X.shape[0] else (X, None)
     if X.dim() != 2 or X.dtype != torch.float32 or X.shape[0] < 2:
         return X, None
     X = X.to(compute_device(X, device))
@@ -76,7 +85,12 @@ class DRModule(BaseEstimator, nn.Module, ABC):
         """Fit and return the embedding.  Duplicate rows are embedded once and re-expanded
         (reference base.py:132-148)."""
         in_dtype = X.dtype
-        X = as_float32(X)  # float64 in -> computed in float32 -> float64 out
+        # float64 in: estimators with float64 kernels for the whole path (`_float64_loop`: UMAP, LargeVis, TSNE, InfoTSNE;
+        # single process, D <= 256) compute in float64 like the reference (which computes in its input's dtype); the
+        # others compute in float32 and hand float64 back
+        if not (X.dtype == torch.float64 and getattr(self, "_float64_loop", False) and getattr(self, "world_size", 1) == 1
+                and X.dim() == 2 and X.shape[1] <= 256 and getattr(self, "metric", "sqeuclidean") in ("sqeuclidean", "euclidean", "angular")):
+            X = as_float32(X)
         if getattr(self, "sharded_input", False) and getattr(self, "world_size", 1) > 1:
             # X is this rank's row shard: one all-gather of the shards, then the replicated-input path
             from torchdr_amd.parallel import gather_row_shards

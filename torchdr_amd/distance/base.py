@@ -82,6 +82,53 @@ class PackedPoints:
         self._img16 = None
         self._meta = None
 
+    @classmethod
+    def from_batches(cls, batches, n: int, d: int, device, dtype=torch.float32):
+        """Point block assembled from a stream of row batches (DataLoader input, distance/faiss.py:477-591 streams its
+        batches into the index the same way): every batch is copied into its rows of the resident block and the tiles it
+        completes are packed at once (``tdr_pack_rows_f32`` on the tile range, enqueued while the loader prepares the next
+        batch) -- when the last batch has arrived the tile images and norms exist; no second pass over the N x D block.
+        ``n`` = upper bound of the row count (``len(dataset)``); a loader that yields fewer rows (``drop_last``) gives a
+        shorter block.  Same images, bit for bit, as ``PackedPoints(X)`` of the concatenated batches."""
+        L = _lib.lib()
+        nfl = L.tdr_packed_floats(n, d)
+        if nfl == 0 or dtype != torch.float32:
+            return None
+        self = cls.__new__(cls)
+        X = torch.empty((n, d), dtype=torch.float32, device=device)
+        self.data = torch.empty(nfl, dtype=torch.float32, device=device)
+        self.norms = torch.empty(n, dtype=torch.float32, device=device)
+        tile = int(L.tdr_packed_floats(32, d))
+        pos = done = 0
+
+        def pack(r0, r1):
+            _lib.check(L.tdr_pack_rows_f32(_lib.ptr(X[r0:]), r1 - r0, d, X.stride(0), _lib.ptr(self.data[(r0 // 32) * tile:]),
+                                           _lib.ptr(self.norms[r0:]), _lib.stream_ptr()), "tdr_pack_rows_f32")
+
+        for b in batches:
+            m = b.shape[0]
+            if b.shape[1] != d:
+                raise ValueError(f"[TorchDR] DataLoader batches disagree on the number of features ({b.shape[1]} vs {d}).")
+            if pos + m > n:
+                raise ValueError(f"[TorchDR] DataLoader yielded more than len(dataset) = {n} samples.")
+            X[pos:pos + m].copy_(b, non_blocking=True)
+            pos += m
+            full = (pos // 32) * 32
+            if full > done:
+                pack(done, full)
+                done = full
+        if pos > done:
+            pack(done, pos)
+        if pos == 0:
+            raise ValueError("[TorchDR] DataLoader is empty, cannot determine metadata. Ensure DataLoader yields at least one batch.")
+        self.n, self.d = pos, d
+        self.X = X if pos == n else X[:pos]
+        self.norms = self.norms[:pos]
+        self.device = X.device
+        self._img16 = None
+        self._meta = None
+        return self
+
     def screen_image(self, meta: Optional[torch.Tensor] = None):
         """fp16-split tile images for the screening stage.  ``meta`` (2 x int32 device tensor) carries the
         shared scale of a query/database pair; without it the block's own maximum is used and cached."""
@@ -1046,7 +1093,11 @@ def _pairwise(X, Y, metric, backend, exclude_diag, k, return_indices, device, di
                 f"[TorchDR] DataLoader input only supports FAISS backend, got backend='{backend}'. "
                 "Use backend='faiss' or backend=None."
             )
-        X = materialize_dataloader(X, None if device == "auto" else device)
+        from torchdr_amd.utils.dataloader import stream_dataloader_packed
+
+        X, packed_stream = stream_dataloader_packed(X, None if device == "auto" else device, metric)
+    else:
+        packed_stream = None
     if not isinstance(X, torch.Tensor):
         raise TypeError("[torchdr_amd] pairwise_distances expects a torch.Tensor or a DataLoader.")
 
@@ -1129,7 +1180,7 @@ def _pairwise(X, Y, metric, backend, exclude_diag, k, return_indices, device, di
             return (C, I) if return_indices else C
         C = _dense_general(Xc, Yc, metric, do_exclude)
         return (C, None) if return_indices else C
-    Xp = PackedPoints(X)
+    Xp = packed_stream if packed_stream is not None and packed_stream.X is X else PackedPoints(X)
     Yp = Xp if self_search else PackedPoints(Y)
     n_cols = Yp.n
 

@@ -17,6 +17,8 @@ class LargeVis(NegativeSamplingNeighborEmbedding):
     Defaults as the reference: ``lr="auto"`` (= max(N/4, 50)), SGD momentum 0.8, ``LinearLR`` with
     torch's default arguments (lr ramps 1/3 -> 1 over the first 5 steps)."""
 
+    _float64_loop = True   # float64 inputs are embedded in float64 (csrc/tdr_embed_f64.hip)
+
     def __init__(self, perplexity: float = 30, n_components: int = 2, lr: Union[float, str] = "auto",
                  optimizer: Union[str, Type[torch.optim.Optimizer]] = "SGD",
                  optimizer_kwargs: Union[Dict, str] = "auto",
@@ -51,19 +53,19 @@ class LargeVis(NegativeSamplingNeighborEmbedding):
 
     def _compute_gradients(self):
         n, nc = self.n_samples_in_, self.n_components
-        grad = torch.zeros((n, nc), dtype=torch.float32, device=self.device_)
-        nn = self._nn_table
         P = self.affinity_in_
+        grad = torch.zeros((n, nc), dtype=P.dtype, device=self.device_)
+        nn = self._nn_table
         neg = self._neg_ptr_tensor()
         _lib.check(
-            _lib.lib().tdr_ne_grad_f32(
+            _lib.fn("tdr_ne_grad", P.dtype)(
                 _lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_, _lib.ptr(nn), _lib.ptr(P),
                 P.shape[1], _lib.ptr(self._tgraph[0]), _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]), 0,
                 float(self.early_exaggeration_coeff_), float(self.repulsion_strength) * 2.0 / n,
                 int(self.n_negatives), _lib.ptr(neg), self._neg_seed, int(self.n_iter_), _lib.ptr(grad),
                 _lib.stream_ptr(),
             ),
-            "tdr_ne_grad_f32",
+            "tdr_ne_grad",
         )
         return grad, False
 

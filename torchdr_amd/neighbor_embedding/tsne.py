@@ -19,6 +19,8 @@ class TSNE(NeighborEmbedding):
     every rank, ``tsne.py:178-179``).  Early exaggeration 12 for 250 iterations, ``lr="auto"``,
     SGD momentum 0.5 -> 0.8 with the optimizer rebuilt at the switch."""
 
+    _float64_loop = True   # float64 inputs are embedded in float64 (csrc/tdr_embed_f64.hip; n_components <= 16)
+
     def __init__(self, perplexity: float = 30, n_components: int = 2, lr: Union[float, str] = "auto",
                  optimizer: Union[str, Type[torch.optim.Optimizer]] = "SGD",
                  optimizer_kwargs: Union[Dict, str] = "auto",
@@ -59,22 +61,23 @@ class TSNE(NeighborEmbedding):
         L = _lib.lib()
         n, nc = self.n_samples_in_, self.n_components
         st = _lib.stream_ptr()
-        grad = torch.zeros((n, nc), dtype=torch.float32, device=self.device_)
         P = self.affinity_in_
+        dt = P.dtype
+        grad = torch.zeros((n, nc), dtype=dt, device=self.device_)
         _lib.check(
-            L.tdr_ne_grad_f32(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
+            _lib.fn("tdr_ne_grad", dt)(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
                               _lib.ptr(self._nn_table), _lib.ptr(P), P.shape[1], _lib.ptr(self._tgraph[0]),
                               _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]), 1,
                               float(self.early_exaggeration_coeff_), 0.0, 0, None, 0, int(self.n_iter_),
                               _lib.ptr(grad), st),
-            "tdr_ne_grad_f32",
+            "tdr_ne_grad",
         )
-        F = torch.empty((self.chunk_size_, nc), dtype=torch.float32, device=self.device_)
+        F = torch.empty((self.chunk_size_, nc), dtype=dt, device=self.device_)
         S = torch.zeros(1, dtype=torch.float64, device=self.device_)
         _lib.check(
-            L.tdr_tsne_repulsion_f32(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
-                                     _lib.ptr(F), _lib.ptr(S), st),
-            "tdr_tsne_repulsion_f32",
+            _lib.fn("tdr_tsne_repulsion", dt)(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
+                                              _lib.ptr(F), _lib.ptr(S), st),
+            "tdr_tsne_repulsion",
         )
         if self.world_size > 1:
             from torchdr_amd.parallel import allreduce_
@@ -82,8 +85,8 @@ class TSNE(NeighborEmbedding):
             allreduce_(S)
         rows = grad[self.chunk_start_: self.chunk_start_ + self.chunk_size_]
         _lib.check(
-            L.tdr_add_scaled_f32(_lib.ptr(rows), _lib.ptr(F), _lib.ptr(S), -4.0 * float(self.repulsion_strength),
-                                 rows.numel(), st),
-            "tdr_add_scaled_f32",
+            _lib.fn("tdr_add_scaled", dt)(_lib.ptr(rows), _lib.ptr(F), _lib.ptr(S), -4.0 * float(self.repulsion_strength),
+                                          rows.numel(), st),
+            "tdr_add_scaled",
         )
         return grad, False

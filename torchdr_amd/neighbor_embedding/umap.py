@@ -68,7 +68,10 @@ class UMAP(NegativeSamplingNeighborEmbedding):
     """UMAP with the reference's constructor (``umap.py:129-160``) and semantics (appendix A.3 of
     SURVEY.md): squared-Euclidean kNN, sigma search, fuzzy-union symmetrisation, per-edge epoch
     counters, 5 negatives per active edge, forces clamped to [-4, 4], plain SGD with a linear
-    1 -> 0 learning-rate ramp."""
+    1 -> 0 learning-rate ramp.  float64 inputs run in float64 end to end (per-step kernel
+    ``tdr_umap_grad_f64``; the scheduled loop is the float32 path)."""
+
+    _float64_loop = True
 
     def __init__(self, n_neighbors: float = 30, n_components: int = 2, min_dist: float = 0.1, spread: float = 1.0,
                  a: Optional[float] = None, b: Optional[float] = None, lr: float = 1e0,
@@ -188,6 +191,17 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         csr: CSRAffinity = self._relabel()
         self._csr_loop = csr
         L = _lib.lib()
+        if csr.vals.dtype == torch.float64:
+            # float64 graph (float64 input): the epoch counters are float64 like the reference's (umap.py:215-234 in the
+            # affinity's dtype) and the loop is the per-step float64 kernel, which reads the CSR as it is
+            self.epochs_per_sample = torch.empty_like(csr.vals)
+            self.epoch_of_next_sample = torch.empty_like(csr.vals)
+            scratch = torch.zeros(2, dtype=torch.int64, device=csr.vals.device)
+            _lib.check(L.tdr_umap_prepare_f64(_lib.ptr(csr.vals), csr.nnz, int(self.max_iter), _lib.ptr(self.epochs_per_sample),
+                                              _lib.ptr(self.epoch_of_next_sample), _lib.ptr(scratch), _lib.stream_ptr()),
+                       "tdr_umap_prepare_f64")
+            self._loop_cols = csr.cols
+            return
         eps_csr = torch.empty_like(csr.vals)
         nxt = torch.empty_like(csr.vals)
         scratch = torch.zeros(2, dtype=torch.int32, device=csr.vals.device)
@@ -343,6 +357,8 @@ class UMAP(NegativeSamplingNeighborEmbedding):
 
         if not (SCHEDULED and LOOP_RUNNER) or not self._fused_sgd or self.n_samples_in_ >= 2**31 - 1:
             return False
+        if self._csr_loop.vals.dtype != torch.float32:
+            return False
         if self.world_size > 1 and getattr(self, "_rccl_ctx", None) is None:
             return False
         if LOOP_RUNNER == "auto" and self.world_size == 1:
@@ -457,10 +473,23 @@ class UMAP(NegativeSamplingNeighborEmbedding):
     def _compute_gradients(self):
         csr: CSRAffinity = self._csr_loop
         if self.world_size > 1 or getattr(self, "_grad_buf", None) is None:
-            self._grad_buf = torch.empty((self.chunk_size_, self.n_components), dtype=torch.float32,
+            self._grad_buf = torch.empty((self.chunk_size_, self.n_components), dtype=csr.vals.dtype,
                                          device=self.device_)
         grad = self._grad_buf
         neg = self._neg_ptr_tensor()
+        if csr.vals.dtype == torch.float64:
+            _lib.check(
+                _lib.lib().tdr_umap_grad_f64(
+                    _lib.ptr(self.embedding_), self.n_components, self.n_samples_in_, self.chunk_start_, self.chunk_size_,
+                    _lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
+                    _lib.ptr(self.epoch_of_next_sample), float(self._a), float(self._b), int(self.n_iter_),
+                    int(self.negative_sample_rate), int(self.n_negatives), _lib.ptr(neg), self._neg_seed,
+                    float(self.early_exaggeration_coeff_), float(self.repulsion_strength), float(self._eps), _lib.ptr(grad),
+                    _lib.stream_ptr(),
+                ),
+                "tdr_umap_grad_f64",
+            )
+            return grad, True
         prof = PROFILE is not None and int(self.n_iter_) % PROFILE_EVERY == 0
         if SCHEDULED and self.n_samples_in_ < 2**31 - 1:
             self._compute_gradients_scheduled(grad, neg, prof)

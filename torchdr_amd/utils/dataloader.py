@@ -110,3 +110,28 @@ def materialize_dataloader(dl: DataLoader, device=None) -> torch.Tensor:
         pos += m
     remember(pos)
     return out if pos == n else out[:pos]      # drop_last=True loaders yield fewer rows
+
+
+def stream_dataloader_packed(dl: DataLoader, device=None, metric: str = "sqeuclidean"):
+    """``pairwise_distances(dataloader, k=...)``: the batches go straight into the search's own layout -- each batch is
+    copied into its rows of the resident block and the MFMA tile images / norms of the tiles it completes are packed at
+    once (``PackedPoints.from_batches``), instead of materialising the block and packing it in a second pass.  Returns
+    ``(X, packed)``; ``packed`` is None where the search does not use the fp32 tile images (D > 256, manhattan /
+    sqhyperbolic, non-float32 batches, iterable datasets of unknown length): the block is then materialised only."""
+    from torchdr_amd.distance.base import PackedPoints
+
+    check_dataloader_order(dl)
+    if device is None or device == "auto":
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    n, d, dtype, src_device = dataloader_metadata(dl)
+    if not dtype.is_floating_point:
+        dtype = torch.float32
+    if (n is None or d > 256 or dtype != torch.float32 or metric not in ("sqeuclidean", "euclidean", "angular")
+            or torch.device(device).type != "cuda"):
+        return materialize_dataloader(dl, device), None
+    packed = PackedPoints.from_batches((_first(b) for b in dl), n, d, torch.device(device))
+    try:
+        setattr(dl, _METADATA, {"n_samples": int(packed.n), "n_features": int(d), "dtype": dtype, "device": src_device})
+    except Exception:
+        pass
+    return packed.X, packed
