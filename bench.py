@@ -81,7 +81,7 @@ def cpu_baseline(X_cpu, k, max_iter, model, budget_s=60.0):
     sub = min(n, 20000)
     Cs, Is = R.knn_chunked(X_cpu[:sub].contiguous(), k, "sqeuclidean", True)
     t0 = time.perf_counter()
-    P, _, _ = R.umap_affinity(Cs, k, 100)
+    _, _, P = R.umap_affinity(Cs, k, 100)
     t_sig_s = time.perf_counter() - t0
     t0 = time.perf_counter()
     R.symmetrize_sparse(P, Is.long(), "sum_minus_prod")

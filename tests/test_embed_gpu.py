@@ -528,3 +528,40 @@ def test_dense_affinity_cannot_discard_neighbours():
     X = gmm(300, 8, 2.0, seed=5).cuda()
     with pytest.raises(ValueError, match="discard_NNs"):
         torchdr_amd.LargeVis(perplexity=5, max_iter=2, sparsity=False, discard_NNs=True).fit_transform(X)
+
+
+@pytest.mark.parametrize("cls_name,kw", [("LargeVis", dict(perplexity=5)), ("TSNE", dict(perplexity=6)), ("InfoTSNE", dict(perplexity=6, n_negatives=20))])
+def test_rectangular_graph_estimators_run_their_loop_in_cluster_order(cls_name, kw):
+    """LargeVis / TSNE / InfoTSNE after a pruned kNN search: the loop numbers the points in the search's cluster-sorted order
+    (a row's neighbour gathers hit the L1 / L2).  It IS the fit of the rows handed over in that order -- compared with an
+    unrelabelled fit of X[order] -- returned in the caller's order, and the same on every run."""
+    import torchdr_amd
+    from torchdr_amd.distance import base as dbase
+    from torchdr_amd.neighbor_embedding import umap as U
+
+    cls = getattr(torchdr_amd, cls_name)
+    n = 20000
+    X = gmm(n, 32, 2.0, seed=3).cuda()
+    init = torch.randn(n, 2, generator=torch.Generator().manual_seed(1)).cuda()
+    old_mode, old_rel = dbase.PRUNE_MODE, U.RELABEL
+    try:
+        dbase.PRUNE_MODE = "force"
+        U.RELABEL = True
+        args = dict(max_iter=3, random_state=0, init=init, **kw)
+        m1 = cls(**args)
+        Z1 = m1.fit_transform(X)
+        order = m1.loop_order_
+        assert order is not None and torch.equal(order.sort().values, torch.arange(n, device="cuda"))
+        m1b = cls(**args)
+        Z1b = m1b.fit_transform(X)
+        assert torch.equal(m1b.loop_order_, order)
+        if cls_name == "TSNE":      # no atomics on its path: bit-identical runs
+            assert torch.equal(Z1b, Z1)
+        U.RELABEL = False
+        m2 = cls(**dict(args, init=init[order].contiguous()))
+        Z2 = m2.fit_transform(X[order].contiguous())
+        assert m2.loop_order_ is None
+    finally:
+        dbase.PRUNE_MODE, U.RELABEL = old_mode, old_rel
+    err = (Z1[order] - Z2).abs().max(1).values / Z2.abs().max()
+    assert float(err.median()) < 1e-5 and float((err > 1e-3).float().mean()) < 0.01, (float(err.median()), float(err.max()))

@@ -169,7 +169,10 @@ class EntropicAffinity(SparseLogAffinity):
         if self.verbose:
             self.logger.info(f"Sparsity mode enabled, computing {k} nearest neighbors...")
         k = check_neighbor_param(torch.tensor(k), torch.tensor(n_samples_in))
-        C_, indices = self._distance_matrix(X, k=int(k), return_indices=True)
+        info = {}
+        C_, indices = self._distance_matrix(X, k=int(k), return_indices=True, info=info)
+        # the cluster-sorted row order a pruned search worked in (estimators number the points of their loop in it)
+        self._row_order = info.get("cluster_order") if not self.is_multi_gpu else None
         eps, log_norm, log_P = entropic_search(
             C_, int(perplexity), n_samples_in, self.max_iter, use_bounds=not self.is_multi_gpu
         )

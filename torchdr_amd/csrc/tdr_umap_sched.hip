@@ -125,6 +125,11 @@ __device__ __forceinline__ uint32_t fire_mask(float& nx, float ep, int t0, int B
 // Rows are laid out by tdr_umap_sched_layout_f32 with their often-firing edges first: the per-lane loops run as many
 // times as the busiest lane of the wavefront fires, so homogeneous chunks matter.
 #define CNT_STRIDE 65  // odd stride: the 16 lanes of a row group hit different (t, slice) -> different banks
+// scratch builds only (tools/sched_build_ablate.py): bit 0 stop after phase 1, bit 1 no counting atomics, bit 2 no row
+// records, bit 3 no list stores, bit 4 no phase 2
+#ifndef TDR_SCHED_ABLATE
+#define TDR_SCHED_ABLATE 0
+#endif
 
 template <int STASH>
 __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildParams P) {
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
                 for (int u = 0; u < 4; ++u) { ok[u] = m != 0u; tt[u] = ok[u] ? __ffs(m) - 1 : 0; m &= m - 1u; }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (ok[u]) atomicAdd(&cnt[tt[u] * P.S * CNT_STRIDE + sbase], 1u);  // a count: order-independent
+                    if (ok[u] && !(TDR_SCHED_ABLATE & 2)) atomicAdd(&cnt[tt[u] * P.S * CNT_STRIDE + sbase], 1u);  // a count: order-independent
             }
         };
 #pragma unroll
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
         }
     }
     __syncthreads();
+    if (TDR_SCHED_ABLATE & 1) return;
 
     // rows' active counts per iteration (all slices)
     for (int i = tid; i < P.B * 64; i += 256) {
@@ -224,13 +230,14 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
         const uint32_t ex = carry + inc - v;
         cnt[k * CNT_STRIDE + lane] = ex;  // from here on: the write pointer of segment (k, row)
         bad = bad || v > 65535u;
-        if (row < P.n_rows)
+        if (row < P.n_rows && !(TDR_SCHED_ABLATE & 4))
             P.hdr[(size_t)k * P.n_rows + row] = make_uint2((uint32_t)base + ex, (v & 0xffffu) | ((uint32_t)actl[(k / P.S) * 64 + lane] << 16));
         carry += __shfl(inc, 63, 64);
     }
     if (bad) atomicMax(P.err, 2);
     if (total > capacity && tid == 0) atomicMax(P.err, 1);
     __syncthreads();
+    if (TDR_SCHED_ABLATE & 16) return;
 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
                 for (int u = 0; u < 4; ++u) pos[u] = ok[u] ? atomicAdd(&cnt[tt[u] * P.S * CNT_STRIDE + sbase], 1u) : 0xffffffffu;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (ok[u] && pos[u] < capacity) P.list[base + pos[u]] = (int32_t)col;
+                    if (ok[u] && pos[u] < capacity && !(TDR_SCHED_ABLATE & 8)) P.list[base + pos[u]] = (int32_t)col;
             }
         };
         int c_first = 0;

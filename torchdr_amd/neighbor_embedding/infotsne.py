@@ -19,6 +19,7 @@ class InfoTSNE(NegativeSamplingNeighborEmbedding):
     exaggeration 12 for 250 iterations, 300 negatives, ``lr="auto"``, SGD momentum 0.5 -> 0.8,
     ``LinearLR`` with torch's default arguments."""
 
+    _relabel_rect = True   # single GPU, pruned search: the loop runs in the kNN stage's cluster-sorted numbering
     _float64_loop = True   # float64 inputs are embedded in float64 (csrc/tdr_embed_f64.hip)
 
     def __init__(self, perplexity: float = 30, n_components: int = 2, lr: Union[float, str] = "auto",

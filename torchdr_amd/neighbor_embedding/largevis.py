@@ -17,6 +17,7 @@ class LargeVis(NegativeSamplingNeighborEmbedding):
     Defaults as the reference: ``lr="auto"`` (= max(N/4, 50)), SGD momentum 0.8, ``LinearLR`` with
     torch's default arguments (lr ramps 1/3 -> 1 over the first 5 steps)."""
 
+    _relabel_rect = True   # single GPU, pruned search: the loop runs in the kNN stage's cluster-sorted numbering
     _float64_loop = True   # float64 inputs are embedded in float64 (csrc/tdr_embed_f64.hip)
 
     def __init__(self, perplexity: float = 30, n_components: int = 2, lr: Union[float, str] = "auto",

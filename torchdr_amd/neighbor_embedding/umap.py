@@ -139,7 +139,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             ("on_training_step_start", NegativeSamplingNeighborEmbedding), ("on_training_step_end", NeighborEmbedding),
             ("_training_step", AffinityMatcher), ("_optimizer_step", AffinityMatcher), ("_sgd_kernel", UMAP),
             ("_compute_gradients", UMAP), ("_compute_gradients_scheduled", UMAP), ("_grad_norm", AffinityMatcher),
-            ("_init_embedding", UMAP), ("_run_training_loop", UMAP), ("_loop_segments", UMAP), ("_fit_transform", UMAP),
+            ("_init_embedding", NeighborEmbedding), ("_run_training_loop", UMAP), ("_loop_segments", UMAP), ("_fit_transform", UMAP),
             ("on_affinity_computation_end", UMAP), ("_compute_affinity_in", UMAP), ("_converged", AffinityMatcher),
         )
         return all(getattr(cls, name) is getattr(owner, name) for name, owner in stock)
@@ -150,8 +150,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         cluster index (members of a cluster by ascending row: the same on every run and on every rank -- the loop's
         numbering, and with it the negative sampler, must not depend on arrival order).  Row-sharded fits receive their
         affinity rows in that numbering already (``UMAPAffinity._rows_in_loop_order``): only the map is kept."""
-        self._perm = None
-        self.loop_order_ = None     # kept after the fit: caller's row of every loop row, or None when the loop ran unrelabelled
         order = getattr(self.affinity_in, "_row_order", None)
         self.affinity_in._row_order = None
         if order is None or not self._relabel_eligible():
@@ -172,12 +170,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                                                   _lib.ptr(inv), _lib.ptr(rowptr), _lib.ptr(cols), _lib.ptr(vals), _lib.stream_ptr()),
                    "tdr_csr_permute_f32")
         return CSRAffinity(rowptr, cols, vals, row_offset=0, n_total=n)
-
-    def _init_embedding(self, X):
-        emb = super()._init_embedding(X)
-        if getattr(self, "_perm", None) is not None:   # rows of the initial embedding in the loop's numbering
-            self.embedding_ = emb.index_select(0, self._perm).contiguous()
-        return self.embedding_
 
     def _nn_for_exclusion(self):
         _, idx = self._csr.to_padded()
@@ -242,14 +234,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                 f"[torchdr_amd] UMAP: the HIP gradient kernels are built for n_components in 1..32 "
                 f"(2 or 3 with SCHEDULED = False), got {self.n_components}."
             )
-        Z = super()._fit_transform(X, y)
-        perm = getattr(self, "_perm", None)
-        if perm is not None:    # back to the caller's row order
-            out = torch.empty_like(Z)
-            out.index_copy_(0, perm, Z)
-            self.embedding_ = Z = out
-            self._perm = None
-        return Z
+        return super()._fit_transform(X, y)    # NeighborEmbedding: un-permutes a loop that ran in cluster order
 
     def _sched_setup(self):
         """Static plan of the scheduled loop: list regions of the 64-row schedule blocks (one host read per fit)."""
