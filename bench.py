@@ -369,7 +369,7 @@ def main():
 
         Zt = torch.zeros((args.n, 2), dtype=torch.float32, device=dev)
         c0, c1 = chunk_bounds(args.n, rank, world)
-        ctx = RcclContext.create(args.n, dev) if (keep.get("rccl_context") and dist.get_backend() == "nccl") else None
+        ctx = RcclContext.shared(args.n, dev) if (keep.get("rccl_context") and dist.get_backend() == "nccl") else None
         reps = 50
         for timed in (False, True):
             barrier()
@@ -381,8 +381,6 @@ def main():
                     allgather_rows_(Zt, c0, c1 - c0, world)
             torch.cuda.synchronize()
             allgather_us = (time.perf_counter() - t1) / reps * 1e6
-        if ctx is not None:
-            ctx.destroy()
         ag = torch.tensor([allgather_us], dtype=torch.float64, device=dev)
         allreduce_max_(ag)
         allgather_us = float(ag.item())
@@ -510,7 +508,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(X_cpu, args.k, args.max_iter, keep, budget_s=args.cpu_budget)
         print(json.dumps(out), flush=True)
     if distributed:
+        from torchdr_amd.parallel import RcclContext
+
         dist.barrier()
+        RcclContext.destroy_shared()
         dist.destroy_process_group()
 
 

@@ -205,6 +205,7 @@ int tdr_csr_permute_f32(const int64_t* rowptr, const int32_t* cols, const float*
  * :425 (gradient all-reduce).  RCCL errors are returned as 1000 + ncclResult_t. */
 int tdr_ctx_unique_id(const char* rccl_path, void* out128);
 int tdr_ctx_create(void** ctx, int rank, int world, const void* unique_id128, const char* rccl_path, int64_t n_total);
+int tdr_ctx_set_rows(void* ctx, int64_t n_total);
 int tdr_ctx_allgather_rows(void* ctx, float* Z, int nc, void* stream);
 int tdr_ctx_allreduce_f32(void* ctx, float* buf, int64_t count, void* stream);
 int tdr_ctx_destroy(void* ctx);

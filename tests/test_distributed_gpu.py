@@ -132,6 +132,9 @@ def _worker(rank, world, port, ret, backend="gloo"):
         assert Zs.shape == (n, 2) and torch.equal(Zs, Zr)
         ret[rank] = True
     finally:
+        from torchdr_amd.parallel import RcclContext
+
+        RcclContext.destroy_shared()    # the process's communicator (one per process, shared by every fit)
         dist.destroy_process_group()
 
 
@@ -249,6 +252,9 @@ def _worker_rccl_even(rank, world, port, ret):
             assert all(torch.equal(g[0], t) for t in g[1:]), f"{cls.__name__}: ranks diverged"
         ret[rank] = True
     finally:
+        from torchdr_amd.parallel import RcclContext
+
+        RcclContext.destroy_shared()    # the process's communicator (one per process, shared by every fit)
         dist.destroy_process_group()
 
 
@@ -322,6 +328,9 @@ def _worker_c4(rank, world, port, ret):
         assert torch.equal(Zs, Zr)
         ret[rank] = True
     finally:
+        from torchdr_amd.parallel import RcclContext
+
+        RcclContext.destroy_shared()    # the process's communicator (one per process, shared by every fit)
         dist.destroy_process_group()
 
 

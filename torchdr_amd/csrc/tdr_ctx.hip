@@ -101,6 +101,15 @@ int tdr_ctx_create(void** ctx, int rank, int world, const void* unique_id128, co
     return TDR_OK;
 }
 
+/* Re-target the communicator at an embedding of n_total rows (the chunk rule is applied to it by the collectives below):
+ * creating an RCCL communicator costs tens of milliseconds, so ONE is kept per process and reused by every fit. */
+int tdr_ctx_set_rows(void* ctx, int64_t n_total) {
+    TdrCtx* c = (TdrCtx*)ctx;
+    if (!c || n_total <= 0) return TDR_ERR_BAD_ARG;
+    c->n_total = n_total;
+    return TDR_OK;
+}
+
 /* In-place all-gather of the row chunks of Z (n_total, nc): on entry rows [start_r, start_r + rows_r) of every rank r
  * hold what rank r computed; on return every rank holds all rows.  Equal chunks: one ncclAllGather whose send buffer is
  * the rank's own slot of the receive buffer; uneven chunks: one grouped ncclBroadcast per rank.  Enqueued on `stream`.

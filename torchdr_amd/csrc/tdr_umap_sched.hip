@@ -32,6 +32,7 @@ namespace tdr {
 
 constexpr int SCHED_RB = 64;    // rows per schedule block
 constexpr int SCHED_BMAX = 32;  // iterations per schedule window (one mask bit each)
+constexpr int SCHED_DENSE_MIN = 3;  // a register-resident chunk is counted / placed bit-sliced when some lane fires this often
 
 // upper bound of the firings of one edge in ANY window of B iterations: its counter advances by eps_per per firing and
 // fires at most once per iteration -> floor(B / eps_per) + 1, plus slack for the fp32 roundings of the additions and of
@@ -115,6 +116,79 @@ __device__ __forceinline__ uint32_t fire_mask(float& nx, float ep, int t0, int B
     return m;
 }
 
+// ---- bit-sliced counting over a 16-lane row group -------------------------------------------------------------------
+// A lane's firing mask holds one bit per iteration of the window.  "How many lanes of the row group fire at iteration t"
+// (segment sizes) and "how many lanes below me fire at t" (positions inside a segment) are sums of 1-bit values over the
+// 16 lanes -- for all 32 iterations AT ONCE when the sums are kept bit-sliced: plane p of a value holds bit p of the count
+// of every iteration.  Adding two bit-sliced numbers is a ripple of full adders on 32-bit words (xor / majority), moving
+// a number to another lane one DPP instruction per plane.  ~50 vector instructions give all 32 totals (or all 32 prefix
+// counts) of a row group, with no LDS traffic; the per-firing LDS atomics they replace hit the SAME counter from up to 16
+// lanes at once (the often-firing edges of a row fire together) and serialised in the LDS unit: counting alone took 0.7 of
+// the 1.9 ms of a window (profiles/r03_sched_build_ablation.json).
+template <int CTRL>
+__device__ __forceinline__ uint32_t dppu(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+
+#define TDR_FA(x, y, c, sum, carry)      \
+    do {                                 \
+        const uint32_t xy__ = (x) ^ (y); \
+        sum = xy__ ^ (c);                \
+        carry = ((x) & (y)) | ((c) & xy__); \
+    } while (0)
+
+// totals over the row group of a 1-bit-per-iteration value: every lane of the group gets the 5 planes (counts 0..16)
+__device__ __forceinline__ void bs_total16(uint32_t m, uint32_t (&T)[5]) {
+    uint32_t b = dppu<0xB1>(m);                       // pairs
+    const uint32_t s0 = m ^ b, s1 = m & b;
+    uint32_t b0 = dppu<0x4E>(s0), b1 = dppu<0x4E>(s1);  // quads: 2-bit + 2-bit
+    const uint32_t r0 = s0 ^ b0, c0 = s0 & b0;
+    uint32_t r1, r2;
+    TDR_FA(s1, b1, c0, r1, r2);
+    b0 = dppu<0x141>(r0); b1 = dppu<0x141>(r1); uint32_t b2 = dppu<0x141>(r2);   // half rows: 3-bit + 3-bit
+    const uint32_t u0 = r0 ^ b0, k0 = r0 & b0;
+    uint32_t u1, k1, u2, u3;
+    TDR_FA(r1, b1, k0, u1, k1);
+    TDR_FA(r2, b2, k1, u2, u3);
+    b0 = dppu<0x140>(u0); b1 = dppu<0x140>(u1); b2 = dppu<0x140>(u2); const uint32_t b3 = dppu<0x140>(u3);   // row: 4-bit + 4-bit
+    uint32_t q1, q2, q3;
+    T[0] = u0 ^ b0; q1 = u0 & b0;
+    TDR_FA(u1, b1, q1, T[1], q2);
+    TDR_FA(u2, b2, q2, T[2], q3);
+    TDR_FA(u3, b3, q3, T[3], T[4]);
+}
+// exclusive prefix over the lanes of the row group (lane i: how many lanes j < i of its group have the bit set), 4 planes
+__device__ __forceinline__ void bs_rank16(uint32_t m, uint32_t (&E)[4]) {
+    uint32_t b = dppu<0x111>(m);                       // row_shr:1 (zeros shifted in)
+    const uint32_t s0 = m ^ b, s1 = m & b;
+    uint32_t b0 = dppu<0x112>(s0), b1 = dppu<0x112>(s1);
+    const uint32_t r0 = s0 ^ b0, c0 = s0 & b0;
+    uint32_t r1, r2;
+    TDR_FA(s1, b1, c0, r1, r2);
+    b0 = dppu<0x114>(r0); b1 = dppu<0x114>(r1); uint32_t b2 = dppu<0x114>(r2);
+    const uint32_t u0 = r0 ^ b0, k0 = r0 & b0;
+    uint32_t u1, k1, u2, u3;
+    TDR_FA(r1, b1, k0, u1, k1);
+    TDR_FA(r2, b2, k1, u2, u3);
+    b0 = dppu<0x118>(u0); b1 = dppu<0x118>(u1); b2 = dppu<0x118>(u2); const uint32_t b3 = dppu<0x118>(u3);
+    uint32_t i0, i1, i2, i3, q1, q2, q3, q4;
+    i0 = u0 ^ b0; q1 = u0 & b0;
+    TDR_FA(u1, b1, q1, i1, q2);
+    TDR_FA(u2, b2, q2, i2, q3);
+    TDR_FA(u3, b3, q3, i3, q4);
+    (void)q4;                                          // inclusive count 16 -> exclusive 15: plane 4 is not needed
+    // exclusive = inclusive - own bit (borrow ripple)
+    E[0] = i0 ^ m; uint32_t w = ~i0 & m;
+    E[1] = i1 ^ w; w = ~i1 & w;
+    E[2] = i2 ^ w; w = ~i2 & w;
+    E[3] = i3 ^ w;
+}
+template <int NP>
+__device__ __forceinline__ uint32_t bs_get(const uint32_t (&V)[NP], int t) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int p2 = 0; p2 < NP; ++p2) c |= ((V[p2] >> t) & 1u) << p2;
+    return c;
+}
+
 // One workgroup = one schedule block (64 rows); a wavefront owns 16 rows and walks them 4 at a time with 16 lanes per
 // row.  Phase 1 counts the firings per (t, slice, row) in LDS, the counts are scanned into segment starts, phase 2
 // places every firing with a returning LDS atomic on its segment's write pointer: from registers for the first 32
@@ -158,6 +232,22 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
         int maxlen = len;
         maxlen = max(maxlen, __shfl_xor(maxlen, 16, 64));
         maxlen = max(maxlen, __shfl_xor(maxlen, 32, 64));
+        // segment sizes / write pointers of a chunk whose lanes fire often: bit-sliced totals per slice, lane gl adds the
+        // counts of iterations gl and gl + 16 (64 distinct LDS words per instruction: no conflicts)
+        auto add_totals = [&](uint32_t m, uint32_t s, int lr_) {
+            for (int sg = 0; sg < P.S; ++sg) {
+                const uint32_t ms = (s == (uint32_t)sg) ? m : 0u;
+                if (__ballot(ms != 0u) == 0ull) continue;
+                uint32_t T[5];
+                bs_total16(ms, T);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int t = gl + 16 * hh;
+                    const uint32_t c = (t < P.B) ? bs_get<5>(T, t) : 0u;
+                    if (c && !(TDR_SCHED_ABLATE & 2)) atomicAdd(&cnt[(t * P.S + sg) * CNT_STRIDE + lr_], c);
+                }
+            }
+        };
         auto count_chunk = [&](int c, uint32_t& m_out, uint32_t& cs_out, bool keep) {
             const bool valid = c + gl < len;
             const int64_t e = e0 + c + gl;
@@ -171,6 +261,10 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
             m_out = m;
             cs_out = col | (s << 29);  // kept form only (stash = 1 requires column ids below 2^29)
             const int sbase = (int)s * CNT_STRIDE + lr;
+            if (keep && __any(__popc(m) >= SCHED_DENSE_MIN)) {   // wavefront-uniform; phase 2 takes the same decision
+                add_totals(m, s, lr);
+                return;
+            }
             while (m) {  // four firings per round: the LDS operations of a round are independent
                 int tt[4];
                 bool ok[4];
@@ -264,10 +358,56 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
                     if (ok[u] && pos[u] < capacity && !(TDR_SCHED_ABLATE & 8)) P.list[base + pos[u]] = (int32_t)col;
             }
         };
+        // the same for a chunk whose lanes fire often: a firing's position = the segment's write pointer (plain LDS read:
+        // lanes reading one word are served by a broadcast) + the number of lanes below it that fire into the same segment
+        // (bit-sliced prefix count); the pointers advance by the chunk's totals afterwards.  LDS operations of a wavefront
+        // complete in order and a row's counters belong to one wavefront, so the reads see the pointers as the previous
+        // chunk left them.
+        auto place_dense = [&](uint32_t m, uint32_t col, uint32_t s) {
+            uint32_t E[4] = {0u, 0u, 0u, 0u};
+            for (int sg = 0; sg < P.S; ++sg) {
+                const uint32_t ms = (s == (uint32_t)sg) ? m : 0u;
+                if (__ballot(ms != 0u) == 0ull) continue;
+                uint32_t X[4];
+                bs_rank16(ms, X);
+                if (s == (uint32_t)sg) { E[0] = X[0]; E[1] = X[1]; E[2] = X[2]; E[3] = X[3]; }
+            }
+            const int sbase = (int)s * CNT_STRIDE + lr;
+            uint32_t mm = m;
+            while (mm) {
+                int tt[4];
+                bool ok[4];
+                uint32_t pos[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { ok[u] = mm != 0u; tt[u] = ok[u] ? __ffs(mm) - 1 : 0; mm &= mm - 1u; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) pos[u] = ok[u] ? cnt[tt[u] * P.S * CNT_STRIDE + sbase] + bs_get<4>(E, tt[u]) : 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (ok[u] && pos[u] < capacity && !(TDR_SCHED_ABLATE & 8)) P.list[base + pos[u]] = (int32_t)col;
+            }
+            // advance the write pointers by this chunk's totals (same code as the counting pass)
+            for (int sg = 0; sg < P.S; ++sg) {
+                const uint32_t ms = (s == (uint32_t)sg) ? m : 0u;
+                if (__ballot(ms != 0u) == 0ull) continue;
+                uint32_t T[5];
+                bs_total16(ms, T);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int t = gl + 16 * hh;
+                    const uint32_t c = (t < P.B) ? bs_get<5>(T, t) : 0u;
+                    if (c) atomicAdd(&cnt[(t * P.S + sg) * CNT_STRIDE + lr], c);
+                }
+            }
+        };
         int c_first = 0;
         if (P.stash) {
 #pragma unroll
-            for (int ci = 0; ci < STASH; ++ci) place(m_st[q * STASH + ci], cs_st[q * STASH + ci] & 0x1fffffffu, cs_st[q * STASH + ci] >> 29);
+            for (int ci = 0; ci < STASH; ++ci) {
+                const uint32_t mm = m_st[q * STASH + ci], cc = cs_st[q * STASH + ci];
+                if (__any(__popc(mm) >= SCHED_DENSE_MIN)) place_dense(mm, cc & 0x1fffffffu, cc >> 29);
+                else place(mm, cc & 0x1fffffffu, cc >> 29);
+            }
             c_first = 16 * STASH;
         }
         for (int c = c_first; c < maxlen; c += 16) {

@@ -242,15 +242,12 @@ class NeighborEmbedding(AffinityMatcher):
         if self.world_size > 1 and RCCL_CONTEXT and dist.get_backend() == "nccl" and torch.cuda.is_available():
             from torchdr_amd.parallel import RcclContext
 
-            self._rccl_ctx = RcclContext.create(self.n_samples_in_, self.device_)
+            self._rccl_ctx = RcclContext.shared(self.n_samples_in_, self.device_)   # one communicator per process
 
     def clear_memory(self):
         super().clear_memory()
         self._nn_table = None
-        ctx = getattr(self, "_rccl_ctx", None)
-        if ctx is not None:
-            ctx.destroy()
-            self._rccl_ctx = None
+        self._rccl_ctx = None    # the communicator itself is the process's (RcclContext.shared): not destroyed per fit
 
     @property
     def chunk_indices_(self):

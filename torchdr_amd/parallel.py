@@ -278,6 +278,32 @@ class RcclContext:
             return None
         return ctx
 
+    # ONE communicator per process and device, shared by every fit: ncclCommInitRank costs tens of milliseconds (bootstrap,
+    # topology, channel set-up) -- per fit it would be most of a row-sharded fit_transform at 8 GPUs
+    _shared = {}
+
+    @classmethod
+    def shared(cls, n_total: int, device):
+        """The process's communicator on `device`, re-targeted at an embedding of `n_total` rows; created (collectively:
+        every rank reaches its first call in the same fit) on first use.  None when RCCL is unavailable."""
+        from torchdr_amd import _lib
+
+        key = (torch.device(device).index, dist.get_world_size(), dist.get_rank())
+        if key not in cls._shared:
+            cls._shared[key] = cls.create(n_total, device)
+        ctx = cls._shared[key]
+        if ctx is not None and ctx.n_total != n_total:
+            _lib.check(_lib.lib().tdr_ctx_set_rows(ctx.handle, n_total), "tdr_ctx_set_rows")
+            ctx.n_total = n_total
+        return ctx
+
+    @classmethod
+    def destroy_shared(cls):
+        for ctx in cls._shared.values():
+            if ctx is not None:
+                ctx.destroy()
+        cls._shared.clear()
+
     def _self_check(self, device, rank, world) -> bool:
         """An all-gather of 3 columns through the context must place every rank's rows where chunk_bounds says."""
         from torchdr_amd import _lib
