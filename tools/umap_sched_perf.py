@@ -27,8 +27,7 @@ if os.environ.get("RELABEL", "0") == "1":
     # points renumbered in the cluster-sorted order of the kNN stage's index: a row's neighbours get nearby numbers
     from torchdr_amd.distance.base import ClusterIndex, PackedPoints
 
-    rm = ClusterIndex(PackedPoints(X)).row_map.to(torch.int64)
-    perm = rm[rm >= 0]
+    perm = ClusterIndex(PackedPoints(X)).perm.to(torch.int64)    # the production numbering (members of a cluster by ascending row)
     assert perm.numel() == n
     inv = torch.empty(n, dtype=torch.int64, device="cuda")
     inv[perm] = torch.arange(n, device="cuda")
@@ -40,7 +39,7 @@ if os.environ.get("RELABEL", "0") == "1":
     cols_ = inv[cols_[src].to(torch.int64)].to(torch.int32).contiguous()
     vals_ = vals_[src].contiguous()
     rowptr_ = new_rowptr
-    del rm, perm, inv, deg, erow, src
+    del perm, inv, deg, erow, src
     far = (cols_.to(torch.int64) - torch.repeat_interleave(torch.arange(n, device="cuda"), rowptr_[1:] - rowptr_[:-1])).abs()
     print(json.dumps({"relabel": True, "edges_within_1024": float((far < 1024).float().mean()),
                       "edges_within_4096": float((far < 4096).float().mean())}), flush=True)

@@ -118,13 +118,16 @@ __device__ __forceinline__ uint32_t fire_mask(float& nx, float ep, int t0, int B
 
 // ---- bit-sliced counting over a 16-lane row group -------------------------------------------------------------------
 // A lane's firing mask holds one bit per iteration of the window.  "How many lanes of the row group fire at iteration t"
-// (segment sizes) and "how many lanes below me fire at t" (positions inside a segment) are sums of 1-bit values over the
-// 16 lanes -- for all 32 iterations AT ONCE when the sums are kept bit-sliced: plane p of a value holds bit p of the count
-// of every iteration.  Adding two bit-sliced numbers is a ripple of full adders on 32-bit words (xor / majority), moving
-// a number to another lane one DPP instruction per plane.  ~50 vector instructions give all 32 totals (or all 32 prefix
-// counts) of a row group, with no LDS traffic; the per-firing LDS atomics they replace hit the SAME counter from up to 16
-// lanes at once (the often-firing edges of a row fire together) and serialised in the LDS unit: counting alone took 0.7 of
-// the 1.9 ms of a window (profiles/r03_sched_build_ablation.json).
+// (the segment sizes) is a sum of 1-bit values over the 16 lanes -- for all 32 iterations AT ONCE when the sums are kept
+// bit-sliced: plane p of a value holds bit p of the count of every iteration.  Adding two bit-sliced numbers is a ripple of
+// full adders on 32-bit words (xor / majority), moving a number to another lane one DPP instruction per plane: ~50 vector
+// instructions give all 32 totals of a row group, with no LDS traffic, where the per-firing loop runs as many rounds as the
+// busiest lane fires (up to 32) and its LDS atomics hit the SAME counter from up to 16 lanes at once.  Used for the
+// counting pass of the register-resident chunks (phase 1: 1.008 -> 0.935 ms of a 1.9 ms window).  The placement pass keeps
+// the returning atomics: the bit-sliced prefix-count form (position = pointer + number of lanes below that fire into the
+// same segment) was built, passed the same tests and measured SLOWER (1.99 vs 1.91 ms per window): the kernel is bound by
+// vector instructions (11.6 k per wavefront, 62 % of the SIMD cycles; profiles/r03_sched_build_pmc.json), and extracting a
+// 4-plane rank per firing costs more instructions than the atomic it replaces.
 template <int CTRL>
 __device__ __forceinline__ uint32_t dppu(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
 
@@ -154,32 +157,6 @@ __device__ __forceinline__ void bs_total16(uint32_t m, uint32_t (&T)[5]) {
     TDR_FA(u1, b1, q1, T[1], q2);
     TDR_FA(u2, b2, q2, T[2], q3);
     TDR_FA(u3, b3, q3, T[3], T[4]);
-}
-// exclusive prefix over the lanes of the row group (lane i: how many lanes j < i of its group have the bit set), 4 planes
-__device__ __forceinline__ void bs_rank16(uint32_t m, uint32_t (&E)[4]) {
-    uint32_t b = dppu<0x111>(m);                       // row_shr:1 (zeros shifted in)
-    const uint32_t s0 = m ^ b, s1 = m & b;
-    uint32_t b0 = dppu<0x112>(s0), b1 = dppu<0x112>(s1);
-    const uint32_t r0 = s0 ^ b0, c0 = s0 & b0;
-    uint32_t r1, r2;
-    TDR_FA(s1, b1, c0, r1, r2);
-    b0 = dppu<0x114>(r0); b1 = dppu<0x114>(r1); uint32_t b2 = dppu<0x114>(r2);
-    const uint32_t u0 = r0 ^ b0, k0 = r0 & b0;
-    uint32_t u1, k1, u2, u3;
-    TDR_FA(r1, b1, k0, u1, k1);
-    TDR_FA(r2, b2, k1, u2, u3);
-    b0 = dppu<0x118>(u0); b1 = dppu<0x118>(u1); b2 = dppu<0x118>(u2); const uint32_t b3 = dppu<0x118>(u3);
-    uint32_t i0, i1, i2, i3, q1, q2, q3, q4;
-    i0 = u0 ^ b0; q1 = u0 & b0;
-    TDR_FA(u1, b1, q1, i1, q2);
-    TDR_FA(u2, b2, q2, i2, q3);
-    TDR_FA(u3, b3, q3, i3, q4);
-    (void)q4;                                          // inclusive count 16 -> exclusive 15: plane 4 is not needed
-    // exclusive = inclusive - own bit (borrow ripple)
-    E[0] = i0 ^ m; uint32_t w = ~i0 & m;
-    E[1] = i1 ^ w; w = ~i1 & w;
-    E[2] = i2 ^ w; w = ~i2 & w;
-    E[3] = i3 ^ w;
 }
 template <int NP>
 __device__ __forceinline__ uint32_t bs_get(const uint32_t (&V)[NP], int t) {
@@ -358,56 +335,10 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
                     if (ok[u] && pos[u] < capacity && !(TDR_SCHED_ABLATE & 8)) P.list[base + pos[u]] = (int32_t)col;
             }
         };
-        // the same for a chunk whose lanes fire often: a firing's position = the segment's write pointer (plain LDS read:
-        // lanes reading one word are served by a broadcast) + the number of lanes below it that fire into the same segment
-        // (bit-sliced prefix count); the pointers advance by the chunk's totals afterwards.  LDS operations of a wavefront
-        // complete in order and a row's counters belong to one wavefront, so the reads see the pointers as the previous
-        // chunk left them.
-        auto place_dense = [&](uint32_t m, uint32_t col, uint32_t s) {
-            uint32_t E[4] = {0u, 0u, 0u, 0u};
-            for (int sg = 0; sg < P.S; ++sg) {
-                const uint32_t ms = (s == (uint32_t)sg) ? m : 0u;
-                if (__ballot(ms != 0u) == 0ull) continue;
-                uint32_t X[4];
-                bs_rank16(ms, X);
-                if (s == (uint32_t)sg) { E[0] = X[0]; E[1] = X[1]; E[2] = X[2]; E[3] = X[3]; }
-            }
-            const int sbase = (int)s * CNT_STRIDE + lr;
-            uint32_t mm = m;
-            while (mm) {
-                int tt[4];
-                bool ok[4];
-                uint32_t pos[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { ok[u] = mm != 0u; tt[u] = ok[u] ? __ffs(mm) - 1 : 0; mm &= mm - 1u; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) pos[u] = ok[u] ? cnt[tt[u] * P.S * CNT_STRIDE + sbase] + bs_get<4>(E, tt[u]) : 0xffffffffu;
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (ok[u] && pos[u] < capacity && !(TDR_SCHED_ABLATE & 8)) P.list[base + pos[u]] = (int32_t)col;
-            }
-            // advance the write pointers by this chunk's totals (same code as the counting pass)
-            for (int sg = 0; sg < P.S; ++sg) {
-                const uint32_t ms = (s == (uint32_t)sg) ? m : 0u;
-                if (__ballot(ms != 0u) == 0ull) continue;
-                uint32_t T[5];
-                bs_total16(ms, T);
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    const int t = gl + 16 * hh;
-                    const uint32_t c = (t < P.B) ? bs_get<5>(T, t) : 0u;
-                    if (c) atomicAdd(&cnt[(t * P.S + sg) * CNT_STRIDE + lr], c);
-                }
-            }
-        };
         int c_first = 0;
         if (P.stash) {
 #pragma unroll
-            for (int ci = 0; ci < STASH; ++ci) {
-                const uint32_t mm = m_st[q * STASH + ci], cc = cs_st[q * STASH + ci];
-                if (__any(__popc(mm) >= SCHED_DENSE_MIN)) place_dense(mm, cc & 0x1fffffffu, cc >> 29);
-                else place(mm, cc & 0x1fffffffu, cc >> 29);
-            }
+            for (int ci = 0; ci < STASH; ++ci) place(m_st[q * STASH + ci], cs_st[q * STASH + ci] & 0x1fffffffu, cs_st[q * STASH + ci] >> 29);
             c_first = 16 * STASH;
         }
         for (int c = c_first; c < maxlen; c += 16) {
