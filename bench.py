@@ -455,7 +455,7 @@ def main():
                    "rocprof CSV) is outside the event pairs" if umod.SCHEDULED else
                    "tdr::umap_grad_kernel<2,16,4,true> + 2 x tdr::umap_neg_dense_kernel<2,8,2> (one gradient evaluation)"),
         "bound": "hbm", "achieved": grad_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_gbs / HBM_PEAK_GBS,
-        "traffic": pmc_traffic("r02_umap_sched_pmc.json" if umod.SCHEDULED else "r01_umap_grad_pmc.json"),
+        "traffic": pmc_traffic("r03_umap_sched_pmc.json" if umod.SCHEDULED else "r01_umap_grad_pmc.json"),
         "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_avg_ms, "evaluations_sampled": n_sampled,
         "grad_passes_ms": grad_only_ms, "schedule_build_ms_per_iteration": build_avg_ms,
         "note": ("algorithmic bytes = SURVEY 8d's per-step edge stream (12 B x nnz + gathers); the scheduled loop reads "

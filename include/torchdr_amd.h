@@ -350,6 +350,15 @@ int tdr_radam_poincare_f64(double* Z, const double* egrad, double* exp_avg, doub
 int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_idx, int m_near, float w_nb,
                         const int64_t* mid_idx, int m_mid, float w_mn, const int64_t* far_idx, int m_far, float w_fp,
                         float* grad, void* stream);
+/* tdr_ne_grad_f32 with the negatives drawn as keyed permutations of the rows (kinds 0 = LargeVis, 3 = InfoTSNE): a row pulls
+ * its own draws j = P(i) AND the draws that hit it (i' = P^-1(i)) -- no atomics on the far endpoints.  Per row the draws are
+ * uniform and independent across columns / iterations like neighbor_embedding/base.py:628-636; within one column they are
+ * distinct across rows.  Needs the transposed graph.  rowsum_ws: kind 3 only, n_total floats; kind 3 takes all rows at once. */
+int tdr_ne_grad_perm_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nn,
+                         const float* P_, int k, const int64_t* t_rowptr, const int32_t* t_src, const float* t_val, int kind,
+                         float exag, float rep_coef, int n_neg, uint64_t seed, int n_iter, float* rowsum_ws, float* grad,
+                         void* stream);
+int tdr_perm_negatives_debug(uint64_t seed, int n_iter, int64_t n_total, int n_neg, int64_t* fwd, int64_t* inv, void* stream);
 /* gradient pieces of neighbor_embedding/tsne.py:172-180 (dense Student-t partition function) */
 int tdr_tsne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* F, double* S,
                            void* stream);

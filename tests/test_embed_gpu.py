@@ -565,3 +565,79 @@ def test_rectangular_graph_estimators_run_their_loop_in_cluster_order(cls_name, 
         dbase.PRUNE_MODE, U.RELABEL = old_mode, old_rel
     err = (Z1[order] - Z2).abs().max(1).values / Z2.abs().max()
     assert float(err.median()) < 1e-5 and float((err > 1e-3).float().mean()) < 0.01, (float(err.median()), float(err.max()))
+
+
+# ---- permutation sampler (LargeVis / InfoTSNE negatives pulled by both endpoints) ---------------------------------------------
+@pytest.mark.parametrize("n", [401, 5000, 70001])
+def test_permutation_sampler_properties(n):
+    """tdr_perm_negatives_debug: column c of iteration t is a permutation of the rows (every row is drawn exactly once), the
+    inverse table inverts it, a row's draws over columns and iterations are uniform (chi-square over 64 bins) and do not
+    repeat a pattern between neighbouring rows or columns."""
+    from torchdr_amd import _lib
+
+    L = _lib.lib()
+    n_neg, iters = 6, 4
+    fw, iv = [], []
+    for t in range(iters):
+        f = torch.empty((n, n_neg), dtype=torch.int64, device="cuda")
+        i = torch.empty((n, n_neg), dtype=torch.int64, device="cuda")
+        _lib.check(L.tdr_perm_negatives_debug(12345, t, n, n_neg, _lib.ptr(f), _lib.ptr(i), _lib.stream_ptr()), "perm_debug")
+        fw.append(f.cpu())
+        iv.append(i.cpu())
+    ar = torch.arange(n)
+    for f, i in zip(fw, iv):
+        for c in range(n_neg):
+            assert torch.equal(f[:, c].sort().values, ar)                  # a permutation of the rows
+            assert torch.equal(i[f[:, c], c], ar) and torch.equal(f[i[:, c], c], ar)   # and its inverse
+    allf = torch.stack(fw, 0)                                               # (iters, n, n_neg)
+    # different columns / iterations are different permutations
+    assert float((allf[0, :, 0] == allf[0, :, 1]).float().mean()) < 0.01 and float((allf[0, :, 0] == allf[1, :, 0]).float().mean()) < 0.01
+    # a row's 24 draws spread uniformly: chi-square of all draws of a block of rows over 64 bins of the index range
+    rows = slice(0, min(n, 2000))
+    draws = allf[:, rows, :].reshape(-1)
+    counts = torch.bincount((draws * 64 // n).clamp(max=63), minlength=64).double()
+    expected = torch.bincount((ar * 64 // n).clamp(max=63), minlength=64).double() * draws.numel() / n
+    chi2 = float(((counts - expected) ** 2 / expected).sum())
+    assert chi2 < 63 + 6 * (2 * 63) ** 0.5, chi2
+    # neighbouring rows do not map to neighbouring (or equally spaced) rows
+    diff = (allf[0, 1:, 0] - allf[0, :-1, 0]) % n
+    assert diff.unique().numel() > 0.5 * min(n, 5000)
+    # self draws are rare (1 / n per draw)
+    assert float((allf == ar[None, :, None]).float().mean()) < 5.0 / n + 1e-3
+
+
+@pytest.mark.parametrize("kind,name", [(0, "largevis"), (3, "tsne")])
+def test_permutation_gradient_equals_the_scatter_form_on_the_same_negatives(kind, name):
+    """tdr_ne_grad_perm_f32 pulls, for every row, its own draws and the draws that hit it; tdr_ne_grad_f32 fed the SAME draws
+    as an injected table scatters the far endpoints' shares with atomics.  Same pairs, same weights (InfoTSNE: the drawing
+    row's normaliser): the gradients agree to the rounding of the sums."""
+    from torchdr_amd import _lib
+    from torchdr_amd.neighbor_embedding.base import build_transposed_graph
+
+    g = load("ne_step")
+    L = _lib.lib()
+    NN, P = g[f"{name}_NN"].cuda().contiguous(), g[f"{name}_P"].cuda().contiguous()
+    n, k = NN.shape
+    Z = (g[f"{name}_Z_1"] * 3e3).cuda().contiguous()      # spread the points: distances of order one
+    tg = build_transposed_graph(P, NN, 0, n, 1)
+    n_neg, seed, it = 7, 991, 5
+    fwd = torch.empty((n, n_neg), dtype=torch.int64, device="cuda")
+    inv = torch.empty((n, n_neg), dtype=torch.int64, device="cuda")
+    _lib.check(L.tdr_perm_negatives_debug(seed, it, n, n_neg, _lib.ptr(fwd), _lib.ptr(inv), _lib.stream_ptr()), "perm_debug")
+    ws = torch.empty(n, dtype=torch.float32, device="cuda")
+    g1 = torch.zeros((n, 2), device="cuda")
+    _lib.check(L.tdr_ne_grad_perm_f32(_lib.ptr(Z), 2, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]),
+                                      kind, 1.0, 0.37, n_neg, seed, it, _lib.ptr(ws), _lib.ptr(g1), _lib.stream_ptr()), "perm")
+    g2 = torch.zeros((n, 2), device="cuda")
+    _lib.check(L.tdr_ne_grad_f32(_lib.ptr(Z), 2, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]),
+                                 kind, 1.0, 0.37, n_neg, _lib.ptr(fwd), 0, it, _lib.ptr(g2), _lib.stream_ptr()), "scatter")
+    assert float(g2.abs().max()) > 0
+    assert torch.allclose(g1, g2, rtol=2e-5, atol=2e-6 * float(g2.abs().max())), float((g1 - g2).abs().max() / g2.abs().max())
+    # the oracle's closed form on the same table
+    from oracle import ref_torch as R
+
+    Zc, fc = Z.cpu(), fwd.cpu()
+    attr = R.ne_attraction_grad(Zc, NN.cpu(), P.cpu(), "largevis" if kind == 0 else "tsne")
+    rep = (R.largevis_repulsion_grad(Zc, fc, n) if kind == 0 else R.infotsne_repulsion_grad(Zc, fc, n)) * (0.37 / (2.0 / n))
+    ref = attr + rep
+    assert torch.allclose(g1.cpu(), ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))

@@ -372,7 +372,33 @@ struct NeStepParams {
     const int32_t* t_src;    // global source row of each in-edge
     const float* t_val;      // P of each in-edge
     int nc;                  // row width of Z / grad (PAD instances)
+    int perm_neg;            // 1: negatives are keyed permutations of the rows and BOTH shares of every pair are pulled
+                             // (tdr_embed_common.h: permutation sampler); kinds 0 and 3, no injected table
+    const float* rowsum;     // kind 3 with perm_neg: (n_total) row normalisers sum_n q of EVERY row (ne_rowsum_kernel)
 };
+
+// InfoTSNE with the permutation sampler, pass 1: rowsum[i] = sum over row i's own draws of q = 1 / (1 + d)
+template <int NC, int G, bool PAD = false>
+__global__ __launch_bounds__(256) void ne_rowsum_kernel(const NeStepParams S, float* __restrict__ out) {
+    const int nc = PAD ? S.nc : NC;
+    const int gl = threadIdx.x % G;
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (r >= S.n_rows) return;
+    const int64_t gi = S.row0 + r;
+    const Vec<NC> zi = load_zp<NC, PAD>(S.Z, gi, nc);
+    float s = 0.f;
+    for (int col = gl; col < S.n_neg; col += G) {
+        const PermKey K = perm_key(S.seed, S.iter, col, S.n_total);
+        const uint32_t j = perm_fwd((uint32_t)gi, K);
+        const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const float t = zi.v[c] - zj.v[c]; d += t * t; }
+        s += 1.0f / (1.0f + d);     // a self draw (probability 1/N) counts q = 1, as the pair (i, i) would
+    }
+    s = group_sum<G>(s);
+    if (gl == 0) out[gi] = s;
+}
 
 template <int NC, int G, bool PAD = false>
 __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
@@ -419,6 +445,37 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) g[c] += w * df[c];
         }
+    }
+    if (S.perm_neg) {
+        // permutation sampler: item 2c = this row's own draw of column c, item 2c + 1 = the row whose draw of column c hit
+        // this row; both are  +w (z_i - z_other)  on THIS row -- nothing is sent to the other endpoint
+        const float own_inv = (S.kind == 3) ? 1.0f / S.rowsum[gi] : 0.f;
+        for (int it = gl; it < 2 * S.n_neg; it += G) {
+            const PermKey K = perm_key(S.seed, S.iter, it >> 1, S.n_total);
+            const bool inward = (it & 1) != 0;
+            const uint32_t j = inward ? perm_inv((uint32_t)gi, K) : perm_fwd((uint32_t)gi, K);
+            if ((int64_t)j == gi) continue;
+            const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
+            float df[NC];
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d += df[c] * df[c]; }
+            float w;
+            if (S.kind == 3) {
+                const float q = 1.0f / (1.0f + d);
+                w = -S.rep_coef * q * q * (inward ? 1.0f / S.rowsum[j] : own_inv);   // the DRAWING row's normaliser
+            } else {
+                w = -S.rep_coef / ((1.0f + d) * (2.0f + d));
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) g[c] += w * df[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            g[c] = group_sum<G>(g[c]);
+            if (gl == 0 && c < nc) unsafeAtomicAdd(&S.grad[(size_t)gi * nc + c], g[c]);
+        }
+        return;
     }
     const uint32_t rkey = neg_row_key(S.seed, S.iter, gi);
     // InfoTSNE (kind 3): the repulsion is the row's log-sum over its negatives of q = 1/(1+d); its
@@ -659,6 +716,17 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ Z, co
     if (z != z) atomicCAS(nan_flag, 0, iter + 1);  // first iteration that produced a NaN (+1)
 }
 
+__global__ __launch_bounds__(256) void perm_debug_kernel(uint64_t seed, uint32_t iter, int64_t n_total, int n_neg,
+                                                         int64_t* __restrict__ fwd, int64_t* __restrict__ inv) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_total * n_neg) return;
+    const int64_t i = e / n_neg;
+    const int c = (int)(e - i * n_neg);
+    const PermKey K = perm_key(seed, iter, c, n_total);
+    fwd[e] = perm_fwd((uint32_t)i, K);
+    inv[e] = perm_inv((uint32_t)i, K);
+}
+
 template <int G, typename Prm>
 static int launch_group(void (*kern)(const Prm), const Prm& P, int64_t n_rows, hipStream_t st) {
     const int rpb = 256 / G;
@@ -757,6 +825,29 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
     return launch_group<16>(umap_grad_kernel<3, 16, 4>, P, n_rows, st);
 }
 
+static int ne_grad_launch(NeStepParams& S, float* rowsum, hipStream_t st) {
+    const int nc = S.nc;
+    const int64_t n_rows = S.n_rows;
+    if (rowsum) {   // InfoTSNE with the permutation sampler, pass 1: every row's normaliser over its own draws
+        const int rpb = 256 / 16;
+        const dim3 grid((unsigned)((n_rows + rpb - 1) / rpb));
+        if (nc == 2) hipLaunchKernelGGL((ne_rowsum_kernel<2, 16>), grid, dim3(256), 0, st, S, rowsum);
+        else if (nc == 3) hipLaunchKernelGGL((ne_rowsum_kernel<3, 16>), grid, dim3(256), 0, st, S, rowsum);
+        else if (nc <= 4) hipLaunchKernelGGL((ne_rowsum_kernel<4, 16, true>), grid, dim3(256), 0, st, S, rowsum);
+        else if (nc <= 8) hipLaunchKernelGGL((ne_rowsum_kernel<8, 16, true>), grid, dim3(256), 0, st, S, rowsum);
+        else if (nc <= 16) hipLaunchKernelGGL((ne_rowsum_kernel<16, 16, true>), grid, dim3(256), 0, st, S, rowsum);
+        else hipLaunchKernelGGL((ne_rowsum_kernel<32, 16, true>), grid, dim3(256), 0, st, S, rowsum);
+        TDR_CHECK_LAUNCH();
+    }
+    // exact instances for 2 and 3 components, zero-padded register instances for any other width up to 32
+    if (nc == 2) return launch_group<16>(ne_grad_kernel<2, 16>, S, n_rows, st);
+    if (nc == 3) return launch_group<16>(ne_grad_kernel<3, 16>, S, n_rows, st);
+    if (nc <= 4) return launch_group<16>(ne_grad_kernel<4, 16, true>, S, n_rows, st);
+    if (nc <= 8) return launch_group<16>(ne_grad_kernel<8, 16, true>, S, n_rows, st);
+    if (nc <= 16) return launch_group<16>(ne_grad_kernel<16, 16, true>, S, n_rows, st);
+    return launch_group<16>(ne_grad_kernel<32, 16, true>, S, n_rows, st);
+}
+
 /* Sparse attraction (+ LargeVis negative-sample repulsion) gradient; grad (N, nc) must be zeroed by the
  * caller.  Both endpoints of every edge receive their share: with the transposed graph (t_rowptr / t_src /
  * t_val = in-edges of rows [row0, row0+n_rows)) each row pulls its in-edges itself and only the negative
@@ -770,19 +861,47 @@ int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64
     if (kind < 0 || kind > 3) return TDR_ERR_BAD_ARG;
     NeStepParams S;
     S.nc = nc;
+    S.perm_neg = 0; S.rowsum = nullptr;
     S.Z = Z; S.n_total = n_total; S.row0 = row0; S.n_rows = n_rows; S.nn = nn; S.P = P_; S.k = k; S.kind = kind;
     S.exag = exag; S.rep_coef = rep_coef; S.n_neg = n_neg; S.neg_inj = neg_inj; S.seed = seed;
     S.iter = (uint32_t)n_iter; S.grad = grad;
     if (t_rowptr && (!t_src || !t_val)) return TDR_ERR_BAD_ARG;
     S.t_rowptr = t_rowptr; S.t_src = t_src; S.t_val = t_val;
-    hipStream_t st = (hipStream_t)stream;
-    // exact instances for 2 and 3 components, zero-padded register instances for any other width up to 32
-    if (nc == 2) return launch_group<16>(ne_grad_kernel<2, 16>, S, n_rows, st);
-    if (nc == 3) return launch_group<16>(ne_grad_kernel<3, 16>, S, n_rows, st);
-    if (nc <= 4) return launch_group<16>(ne_grad_kernel<4, 16, true>, S, n_rows, st);
-    if (nc <= 8) return launch_group<16>(ne_grad_kernel<8, 16, true>, S, n_rows, st);
-    if (nc <= 16) return launch_group<16>(ne_grad_kernel<16, 16, true>, S, n_rows, st);
-    return launch_group<16>(ne_grad_kernel<32, 16, true>, S, n_rows, st);
+    return ne_grad_launch(S, nullptr, (hipStream_t)stream);
+}
+
+/* The same gradient with the negatives drawn as keyed PERMUTATIONS of the rows (kinds 0 = LargeVis, 3 = InfoTSNE): column c
+ * of iteration t is j = P_{t,c}(i), so the row that drew j is P^{-1}(j) and a row pulls both its own draws and the draws that
+ * hit it -- no atomics for the far endpoints (tdr_embed_common.h, "permutation sampler").  Each row's draws are uniform over
+ * the rows and independent across columns / iterations, as neighbor_embedding/base.py:628-636 draws them; across the rows of
+ * one column they are distinct.  Needs the transposed graph (the neighbour edges are pulled too).  rowsum_ws: kind 3 only,
+ * n_total floats of scratch (the row normalisers of every row); all rows in one call (row0 = 0, n_rows = n_total). */
+int tdr_ne_grad_perm_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nn,
+                         const float* P_, int k, const int64_t* t_rowptr, const int32_t* t_src, const float* t_val, int kind,
+                         float exag, float rep_coef, int n_neg, uint64_t seed, int n_iter, float* rowsum_ws, float* grad,
+                         void* stream) {
+    if (!Z || !nn || !P_ || !grad || !t_rowptr || !t_src || !t_val || n_rows <= 0 || k <= 0 || n_total < 2) return TDR_ERR_BAD_ARG;
+    if (nc < 1 || nc > 32 || n_total > 0x7fffffffLL) return TDR_ERR_UNSUPPORTED;
+    if ((kind != 0 && kind != 3) || n_neg <= 0) return TDR_ERR_BAD_ARG;
+    if (kind == 3 && (!rowsum_ws || row0 != 0 || n_rows != n_total)) return TDR_ERR_BAD_ARG;
+    NeStepParams S;
+    S.nc = nc;
+    S.perm_neg = 1; S.rowsum = kind == 3 ? rowsum_ws : nullptr;
+    S.Z = Z; S.n_total = n_total; S.row0 = row0; S.n_rows = n_rows; S.nn = nn; S.P = P_; S.k = k; S.kind = kind;
+    S.exag = exag; S.rep_coef = rep_coef; S.n_neg = n_neg; S.neg_inj = nullptr; S.seed = seed;
+    S.iter = (uint32_t)n_iter; S.grad = grad;
+    S.t_rowptr = t_rowptr; S.t_src = t_src; S.t_val = t_val;
+    return ne_grad_launch(S, kind == 3 ? rowsum_ws : nullptr, (hipStream_t)stream);
+}
+
+/* Test hook: the permutation sampler's draws -- fwd[i][c] = P_{t,c}(i) and inv[i][c] = P_{t,c}^{-1}(i), (n_total, n_neg) int64. */
+int tdr_perm_negatives_debug(uint64_t seed, int n_iter, int64_t n_total, int n_neg, int64_t* fwd, int64_t* inv, void* stream) {
+    if (!fwd || !inv || n_total < 2 || n_total > 0x7fffffffLL || n_neg <= 0) return TDR_ERR_BAD_ARG;
+    const int64_t total = n_total * n_neg;
+    hipLaunchKernelGGL(perm_debug_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       (uint32_t)n_iter, n_total, n_neg, fwd, inv);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
 }
 
 /* TSNE dense repulsion for rows [row0, row0+n_rows): F (n_rows, nc) = sum_j (z_i - z_j)/(1+d)^2 and

@@ -69,6 +69,57 @@ __device__ __forceinline__ int64_t sample_negative(uint32_t row_key, int64_t gro
     return r;
 }
 
+// ---- permutation sampler (LargeVis / InfoTSNE negatives, pull form) ------------------------------------------------------
+// The reference draws, per row i and column c, a uniform j != i (neighbor_embedding/base.py:628-636) and autograd sends the
+// pair's force to BOTH endpoints.  With a hash sampler the far endpoint's share has to be scattered with atomics (10 M
+// device-scope fp32 atomics per LargeVis iteration at N = 1M: 0.5 of its 0.54 ms).  Here column c of iteration t is a keyed
+// pseudo-random PERMUTATION of the rows, j = P_{t,c}(i): every row's draws are still uniform over the rows and independent
+// across columns and iterations (the per-row law of the reference's sampler; i = j happens with probability 1/N and
+// contributes nothing), and the row that drew j is P^{-1}(j) -- so a row PULLS both its own draws and the draws that hit
+// it, and nothing is scattered.  What differs from independent draws is the joint law across rows of one column (no two
+// rows draw the same j): every row is the far endpoint of exactly n_negatives pairs instead of Poisson(n_negatives).
+// P = three rounds of (odd multiply + keyed add mod 2^b, xorshift by ceil(b/2)) on b = ceil(log2 N) bits with cycle walking
+// into [0, N); each step is invertible (the xorshift is an involution at that shift).
+struct PermKey {
+    uint32_t a1, a2, a3, mask, n;
+    int s;
+};
+constexpr uint32_t PERM_M1 = 0x9E3779B1u, PERM_M2 = 0x85EBCA6Bu;
+constexpr uint32_t inv_odd_u32(uint32_t a) {
+    uint32_t x = a;                       // a * a = 1 mod 8: 3 correct bits, doubled by every Newton step
+    x *= 2u - a * x; x *= 2u - a * x; x *= 2u - a * x; x *= 2u - a * x;
+    return x;
+}
+constexpr uint32_t PERM_I1 = inv_odd_u32(PERM_M1), PERM_I2 = inv_odd_u32(PERM_M2);
+__device__ __forceinline__ PermKey perm_key(uint64_t seed, uint32_t iter, int col, int64_t n_total) {
+    PermKey K;
+    uint32_t h = mix32((uint32_t)seed ^ (0x9E3779B9u * (uint32_t)(col + 1)));
+    h = mix32(h + (uint32_t)(seed >> 32) + iter * 0x85EBCA6Bu);
+    K.a1 = h; K.a2 = mix32(h ^ 0xC2B2AE35u); K.a3 = mix32(h + 0x27D4EB2Fu);
+    int b = 32 - __clz((uint32_t)(n_total - 1));
+    if (b < 2) b = 2;
+    K.mask = b >= 32 ? 0xffffffffu : ((1u << b) - 1u);
+    K.s = (b + 1) >> 1;
+    K.n = (uint32_t)n_total;
+    return K;
+}
+__device__ __forceinline__ uint32_t perm_fwd(uint32_t x, const PermKey& K) {
+    do {
+        x = (x * PERM_M1 + K.a1) & K.mask; x ^= x >> K.s;
+        x = (x * PERM_M2 + K.a2) & K.mask; x ^= x >> K.s;
+        x = (x * PERM_M1 + K.a3) & K.mask; x ^= x >> K.s;
+    } while (x >= K.n);
+    return x;
+}
+__device__ __forceinline__ uint32_t perm_inv(uint32_t x, const PermKey& K) {
+    do {
+        x ^= x >> K.s; x = ((x - K.a3) * PERM_I1) & K.mask;
+        x ^= x >> K.s; x = ((x - K.a2) * PERM_I2) & K.mask;
+        x ^= x >> K.s; x = ((x - K.a1) * PERM_I1) & K.mask;
+    } while (x >= K.n);
+    return x;
+}
+
 // d^b through the hardware log2 / exp2 (relative error ~ |b log2 d| * 2^-23, i.e. <= ~3e-6 for the
 // distances an embedding produces) and reciprocals through v_rcp_f32 (1 ulp): the force coefficients stay
 // well inside the 1e-5 parity budget while the kernel drops from ~300 to ~80 VALU ops per edge.

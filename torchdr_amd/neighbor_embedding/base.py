@@ -16,6 +16,9 @@ from torchdr_amd.affinity_matcher import AffinityMatcher
 # per-iteration exchange through an RCCL communicator owned by the C library (tdr_ctx_*: collectives enqueued on the
 # compute stream, graph-capturable) when the process group runs on RCCL; False keeps every collective in torch.distributed
 RCCL_CONTEXT = True
+# LargeVis / InfoTSNE on one GPU: negatives drawn as keyed permutations of the rows, both shares of a pair pulled by the rows
+# themselves (tdr_ne_grad_perm_f32: no far-endpoint atomics; csrc/tdr_embed_common.h).  False = the hash sampler + atomics.
+PERM_NEGATIVES = True
 
 
 class NeighborEmbedding(AffinityMatcher):

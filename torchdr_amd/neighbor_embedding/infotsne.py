@@ -56,9 +56,25 @@ class InfoTSNE(NegativeSamplingNeighborEmbedding):
 
     def _compute_gradients(self):
         n, nc = self.n_samples_in_, self.n_components
+        from torchdr_amd.neighbor_embedding import base as _nb
+
         P = self.affinity_in_
         grad = torch.zeros((n, nc), dtype=P.dtype, device=self.device_)
         neg = self._neg_ptr_tensor()
+        if neg is None and _nb.PERM_NEGATIVES and self.world_size == 1 and P.dtype == torch.float32 and self.n_negatives > 0:
+            # one GPU, no injected table: permutation sampler -- pass 1 every row's normaliser over its own draws, pass 2 each
+            # row pulls its own draws and the draws that hit it (600 M fp32 atomics per iteration at N = 1M otherwise)
+            ws = torch.empty(n, dtype=torch.float32, device=self.device_)
+            _lib.check(
+                _lib.lib().tdr_ne_grad_perm_f32(
+                    _lib.ptr(self.embedding_), nc, n, 0, n, _lib.ptr(self._nn_table), _lib.ptr(P), P.shape[1],
+                    _lib.ptr(self._tgraph[0]), _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]), 3,
+                    float(self.early_exaggeration_coeff_), float(self.repulsion_strength) * 2.0 / n, int(self.n_negatives),
+                    self._neg_seed, int(self.n_iter_), _lib.ptr(ws), _lib.ptr(grad), _lib.stream_ptr(),
+                ),
+                "tdr_ne_grad_perm_f32",
+            )
+            return grad, False
         _lib.check(
             _lib.fn("tdr_ne_grad", P.dtype)(
                 _lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_, _lib.ptr(self._nn_table),
