@@ -4,7 +4,7 @@ dominant kernel measured by HIP events on the launch stream inside the run:
     python tools/config_roofline.py c3     # LargeVis N = 1M, D = 128, kNN width 15 (perplexity 5), 500 iterations
     python tools/config_roofline.py c5     # symmetric entropic affinity N = 200k, D = 64, perplexity 30: dual iterations
 
-C3, `tdr::ne_grad_kernel` (one launch per iteration): algorithmic bytes per SURVEY.md section 8d K6 =
+C3, `tdr::ne_grad_kernel` through `tdr_ne_grad_perm_f32` (one launch per iteration): algorithmic bytes per SURVEY.md section 8d K6 =
 N k (4 idx + 4 P + 8 z_j + 8 far-endpoint update) + N n_neg (8 + 8) + 2 N (8 z + 8 momentum) = 0.472 GB at k = 15,
 against the 8 TB/s HBM peak.  C5, `tdr::pair_scan_kernel<.., SeaStats>` (one launch per dual iteration): 2 N^2 D flop
 (5.12e12) against the fp32 matrix peak 157.3 TFLOP/s; the N^2 = 4e10 exponentials are reported beside it (`exp_per_s`).
@@ -67,7 +67,7 @@ def c3(width=15, steps=2):
     X = gmm(n, d, 2.0).cuda()
     perp = width // 3
     t.LargeVis(perplexity=perp, max_iter=20, random_state=0).fit_transform(X)   # warm-up
-    tm = Timed("tdr_ne_grad_f32", every=10)
+    tm = Timed("tdr_ne_grad_perm_f32", every=10)     # one GPU: permutation sampler, both shares of every negative pair pulled
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -80,7 +80,7 @@ def c3(width=15, steps=2):
     line(f"samples/sec (fit_transform), LargeVis N=1M D=128 kNN width {width}, {iters} iterations", n / wall, "samples/sec", wall * 1e3, steps,
          f"BASELINE config C3: LargeVis fit_transform N={n} D={d} perplexity={perp} (kNN width {width}) n_negatives={n_neg} "
          f"max_iter={iters}, Gaussian mixture (1000 clusters, centre scale 2, sigma 0.5, seed 42)",
-         {"kernel": "tdr::ne_grad_kernel<2,16> (kind 0: LargeVis attraction pull-form + 5 negatives per row with fp32 atomics), one launch per iteration",
+         {"kernel": "tdr::ne_grad_kernel<2,16> (kind 0: LargeVis attraction and the 5 negatives per row, both endpoints' shares pulled: permutation sampler, no far-endpoint atomics), one launch per iteration",
           "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
           "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": ms, "launches_sampled": cnt,
           "note": "SURVEY 8d K6 bytes; traffic: see profiles/r03_c3_pmc.json (separate rocprofv3 --pmc passes)"},
