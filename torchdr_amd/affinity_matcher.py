@@ -178,7 +178,7 @@ class AffinityMatcher(DRModule):
         reads anything back) are enqueued on a side stream now and run under the kNN search; `_init_embedding` waits for
         that stream.  3.5 ms of the N = 1M fit."""
         self._pca_prefetch = None
-        if not (PCA_PREFETCH and PCA_EIGH == "jacobi" and isinstance(self.init, str) and self.init == "pca"):
+        if not (_opt("PCA_PREFETCH") and _opt("PCA_EIGH") == "jacobi" and isinstance(self.init, str) and self.init == "pca"):
             return
         if not X.is_cuda or X.dtype != torch.float32 or X.shape[1] > 256 or self.n_components > 4:
             return
@@ -513,6 +513,13 @@ PCA_EIGH = "jacobi"
 PCA_PREFETCH = True
 _PREFETCH_STREAMS = {}
 
+def _opt(name):
+    """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
+    from torchdr_amd import config
+
+    return config.get(name, globals())
+
+
 
 def pca_scores(X: torch.Tensor, n_components: int) -> torch.Tensor:
     """PCA scores U*S of the centred data with the reference's sign convention
@@ -541,7 +548,7 @@ def pca_scores(X: torch.Tensor, n_components: int) -> torch.Tensor:
         ws = torch.empty(ws_floats, dtype=torch.float32, device=X.device)
         _lib.check(L.tdr_pca_gram_f32(_lib.ptr(X), n, d, X.stride(0), _lib.ptr(mean), _lib.ptr(G), _lib.ptr(ws), ws_floats,
                                       _lib.stream_ptr()), "tdr_pca_gram_f32")
-        if PCA_EIGH == "jacobi":    # one workgroup, no host read (csrc/tdr_prep.hip)
+        if _opt("PCA_EIGH") == "jacobi":    # one workgroup, no host read (csrc/tdr_prep.hip)
             evals = torch.empty(d, dtype=torch.float64, device=X.device)
             evecs = torch.empty((d, d), dtype=torch.float64, device=X.device)
             ews = torch.empty(2 * d * d, dtype=torch.float64, device=X.device)

@@ -18,6 +18,13 @@ from torchdr_amd.utils.dataloader import is_dataloader, materialize_dataloader
 from torchdr_amd.utils.misc import as_float32
 
 LIST_METRICS = ["euclidean", "sqeuclidean", "manhattan", "angular", "sqhyperbolic"]
+
+def _opt(name):
+    """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
+    from torchdr_amd import config
+
+    return config.get(name, globals())
+
 _METRIC_ID = {"sqeuclidean": 0, "euclidean": 1, "angular": 2, "manhattan": 3, "sqhyperbolic": 4}
 _GENERAL_ONLY = ("manhattan", "sqhyperbolic")     # metrics that never take the MFMA scan kernels
 PILOT_CONCURRENT = True   # pilot tiers and the cluster-index build on concurrent streams (False: one after the other)
@@ -259,11 +266,11 @@ class ClusterIndex:
 
 
 def _use_screen(Q, Y, nq, k, metric):
-    if SCREEN_MODE == "0" or metric not in ("sqeuclidean", "euclidean"):
+    if _opt("SCREEN_MODE") == "0" or metric not in ("sqeuclidean", "euclidean"):
         return False
     if not _lib.lib().tdr_knn_screen_supported(Y.d, k):
         return False
-    if SCREEN_MODE == "force":
+    if _opt("SCREEN_MODE") == "force":
         return True
     return nq * Y.n >= _SCREEN_MIN_PAIRS and Y.n >= 4096
 
@@ -355,21 +362,21 @@ def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset, side_work=Non
 
     runs = {}
     side_start, side_finish = side_work if side_work is not None else (None, None)
-    if side_start is not None and PILOT_CONCURRENT:
+    if side_start is not None and _opt("PILOT_CONCURRENT"):
         # first in: its single-workgroup seeding kernel (4 ms of dependent steps) must hold a CU before the pilots'
         # workgroups take every register file (two pilots = 2 x 256 registers per lane on every SIMD); enqueued after
         # them, the whole chain waited for the pilots to drain (kernel trace at N = 1M: the main scan starts 17.4 ms into the
         # fit instead of 19.8 ms; pilots, chain and pilot rescoring now share the device and end together)
         with torch.cuda.stream(side[1]):
             side_start()
-    if len(tiers) >= 2 and PILOT_CONCURRENT:
+    if len(tiers) >= 2 and _opt("PILOT_CONCURRENT"):
         with torch.cuda.stream(side[0]):
             runs[tiers[0]] = launch(tiers[0])
         runs[tiers[1]] = launch(tiers[1])
     elif tiers:
         runs[tiers[0]] = launch(tiers[0])
     if side_finish is not None:
-        if PILOT_CONCURRENT:
+        if _opt("PILOT_CONCURRENT"):
             with torch.cuda.stream(side[1]):
                 side_finish()
         else:
@@ -468,7 +475,7 @@ def _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_
 
 
 def _want_prune(Y, n):
-    return PRUNE_MODE != "0" and (PRUNE_MODE == "force" or n >= _PRUNE_MIN_N)
+    return _opt("PRUNE_MODE") != "0" and (_opt("PRUNE_MODE") == "force" or n >= _PRUNE_MIN_N)
 
 
 def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, pilot=True, tier=1, info=None):
@@ -489,7 +496,7 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
         ci = _cluster_index(Y, ops)
         # worth it only when the cluster balls are far apart relative to the neighbour distances: predicted from the
         # pilot's k-th distances (with slack for the blocks the pilot did not see)
-        if PRUNE_MODE != "force" and (pilot_tau is None or ci.scan_fraction(2.0 * pilot_tau) > _PRUNE_MAX_SCAN_FRACTION):
+        if _opt("PRUNE_MODE") != "force" and (pilot_tau is None or ci.scan_fraction(2.0 * pilot_tau) > _PRUNE_MAX_SCAN_FRACTION):
             prune = False
     if prune:
         flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i)
@@ -611,7 +618,7 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
         return None
     tier, tau = int(vote[1]), float(vote[2])
     ci = _cluster_index(Y, ops)
-    if PRUNE_MODE != "force" and ci.scan_fraction(2.0 * tau) > _PRUNE_MAX_SCAN_FRACTION:
+    if _opt("PRUNE_MODE") != "force" and ci.scan_fraction(2.0 * tau) > _PRUNE_MAX_SCAN_FRACTION:
         return None  # same tables and tau on every rank: same decision
     # this rank's positions [c0, c1) of the compact sorted order -> the range of the padded layout that holds them
     # (begin rounded down to a query batch; the few extra rows are answered twice, by this rank and by its neighbour)
@@ -858,7 +865,7 @@ def _knn_general(Xq, Y, k, metric, exclude_self, q_global0=0):
     ``_knn_wide`` first."""
     L = _lib.lib()
     nq, nd = Xq.shape[0], Y.shape[0]
-    if metric in ("sqeuclidean", "euclidean", "angular") and Y.shape[1] > 256 and WIDE_SCAN:
+    if metric in ("sqeuclidean", "euclidean", "angular") and Y.shape[1] > 256 and _opt("WIDE_SCAN"):
         res = _knn_wide(Xq, Y, k, metric, exclude_self, q_global0)
         if res is not None:
             return res
@@ -990,7 +997,7 @@ def _dense_general(X, Y, metric, exclude_self):
         if exclude_self:
             C.diagonal().add_(_DIAG_ADD)
         return C
-    if metric in ("sqeuclidean", "euclidean", "angular") and X.shape[1] > 256 and WIDE_SCAN and Y.shape[0] <= 65535 * 32:
+    if metric in ("sqeuclidean", "euclidean", "angular") and X.shape[1] > 256 and _opt("WIDE_SCAN") and Y.shape[0] <= 65535 * 32:
         # the wide tile images and one fp32-MFMA tile kernel (no library GEMM)
         Yp = WidePackedPoints(Y)
         Qp = Yp if X is Y else WidePackedPoints(X)

@@ -20,6 +20,13 @@ RCCL_CONTEXT = True
 # themselves (tdr_ne_grad_perm_f32: no far-endpoint atomics; csrc/tdr_embed_common.h).  False = the hash sampler + atomics.
 PERM_NEGATIVES = True
 
+def _opt(name):
+    """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
+    from torchdr_amd import config
+
+    return config.get(name, globals())
+
+
 
 class NeighborEmbedding(AffinityMatcher):
     _lr_as_tensor = False
@@ -99,7 +106,7 @@ class NeighborEmbedding(AffinityMatcher):
     def _rect_relabel_eligible(self) -> bool:
         from torchdr_amd.neighbor_embedding import umap as _umap
 
-        if not (_umap.RELABEL and self._relabel_rect) or self.world_size > 1:
+        if not (_umap._opt("RELABEL") and self._relabel_rect) or self.world_size > 1:
             return False
         if getattr(self, "discard_NNs", False) or getattr(self, "neg_indices_", None) is not None:
             return False
@@ -242,7 +249,7 @@ class NeighborEmbedding(AffinityMatcher):
             cols = torch.arange(self.n_samples_in_, dtype=torch.int32, device=P.device)
             self._nn_table = cols.unsqueeze(0).expand(P.shape[0], -1).contiguous()
         self._rccl_ctx = None
-        if self.world_size > 1 and RCCL_CONTEXT and dist.get_backend() == "nccl" and torch.cuda.is_available():
+        if self.world_size > 1 and _opt("RCCL_CONTEXT") and dist.get_backend() == "nccl" and torch.cuda.is_available():
             from torchdr_amd.parallel import RcclContext
 
             self._rccl_ctx = RcclContext.shared(self.n_samples_in_, self.device_)   # one communicator per process

@@ -61,7 +61,7 @@ class InfoTSNE(NegativeSamplingNeighborEmbedding):
         P = self.affinity_in_
         grad = torch.zeros((n, nc), dtype=P.dtype, device=self.device_)
         neg = self._neg_ptr_tensor()
-        if neg is None and _nb.PERM_NEGATIVES and self.world_size == 1 and P.dtype == torch.float32 and self.n_negatives > 0:
+        if neg is None and _nb._opt("PERM_NEGATIVES") and self.world_size == 1 and P.dtype == torch.float32 and self.n_negatives > 0:
             # one GPU, no injected table: permutation sampler -- pass 1 every row's normaliser over its own draws, pass 2 each
             # row pulls its own draws and the draws that hit it (600 M fp32 atomics per iteration at N = 1M otherwise)
             ws = torch.empty(n, dtype=torch.float32, device=self.device_)

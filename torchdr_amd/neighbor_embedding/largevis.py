@@ -60,7 +60,7 @@ class LargeVis(NegativeSamplingNeighborEmbedding):
         grad = torch.zeros((n, nc), dtype=P.dtype, device=self.device_)
         nn = self._nn_table
         neg = self._neg_ptr_tensor()
-        if neg is None and _nb.PERM_NEGATIVES and self.world_size == 1 and P.dtype == torch.float32 and self.n_negatives > 0:
+        if neg is None and _nb._opt("PERM_NEGATIVES") and self.world_size == 1 and P.dtype == torch.float32 and self.n_negatives > 0:
             # one GPU, no injected table: permutation sampler, every pair's two shares pulled (no atomics)
             _lib.check(
                 _lib.lib().tdr_ne_grad_perm_f32(

@@ -47,6 +47,13 @@ SCHED_SLICES = 0
 # the loop's row numbers, so the random stream differs from an unrelabelled run (same distribution).
 RELABEL = True
 
+def _opt(name):
+    """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
+    from torchdr_amd import config
+
+    return config.get(name, globals())
+
+
 
 def find_ab_params(spread, min_dist):
     """Fit a, b of 1/(1 + a x^(2b)) to the smooth-step target curve (reference :19-36: same grid,
@@ -130,7 +137,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         from torchdr_amd.affinity_matcher import AffinityMatcher
         from torchdr_amd.neighbor_embedding.base import NegativeSamplingNeighborEmbedding, NeighborEmbedding
 
-        if not (RELABEL and SCHEDULED) or self.discard_NNs or self.neg_indices_ is not None:
+        if not (_opt("RELABEL") and _opt("SCHEDULED")) or self.discard_NNs or self.neg_indices_ is not None:
             return False
         if self.n_samples_in_ >= 2**31 - 1:
             return False
@@ -228,7 +235,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         return self._csr.to_padded()[1]
 
     def _fit_transform(self, X, y=None):
-        nc_ok = range(1, 33) if SCHEDULED else (2, 3)   # scheduled loop: exact kernels for 2 / 3, padded ones up to 32
+        nc_ok = range(1, 33) if _opt("SCHEDULED") else (2, 3)   # scheduled loop: exact kernels for 2 / 3, padded ones up to 32
         if self.n_components not in nc_ok:
             raise NotImplementedError(
                 f"[torchdr_amd] UMAP: the HIP gradient kernels are built for n_components in 1..32 "
@@ -240,8 +247,8 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         """Static plan of the scheduled loop: list regions of the 64-row schedule blocks (one host read per fit)."""
         L, csr, dev = _lib.lib(), self._csr_loop, self.device_
         n_rows, nc = self.chunk_size_, self.n_components
-        B = int(SCHED_BLOCK_ITERS)
-        S = int(SCHED_SLICES) or int(L.tdr_umap_sched_slices(self.n_samples_in_, nc))
+        B = int(_opt("SCHED_BLOCK_ITERS"))
+        S = int(_opt("SCHED_SLICES")) or int(L.tdr_umap_sched_slices(self.n_samples_in_, nc))
         n_blocks = (n_rows + 63) // 64
         scratch = torch.empty(n_blocks, dtype=torch.int64, device=dev)
         blk_base = torch.empty(n_blocks + 1, dtype=torch.int64, device=dev)
@@ -251,7 +258,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         cap = int(blk_base[-1].item())
         # the joint launch relies on workgroups going round-robin over EIGHT XCDs that each cache one slice: only on the
         # whole device (256 CUs); on a partitioned one (e.g. one XCD per device) the slices go one launch at a time
-        geom = int(SCHED_GEOM)
+        geom = int(_opt("SCHED_GEOM"))
         if torch.cuda.get_device_properties(dev).multi_processor_count < 256:
             geom &= 15
         self._sched = {
@@ -340,13 +347,13 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         from torchdr_amd.affinity_matcher import AffinityMatcher
         from torchdr_amd.neighbor_embedding.base import NegativeSamplingNeighborEmbedding, NeighborEmbedding
 
-        if not (SCHEDULED and LOOP_RUNNER) or not self._fused_sgd or self.n_samples_in_ >= 2**31 - 1:
+        if not (_opt("SCHEDULED") and _opt("LOOP_RUNNER")) or not self._fused_sgd or self.n_samples_in_ >= 2**31 - 1:
             return False
         if self._csr_loop.vals.dtype != torch.float32:
             return False
         if self.world_size > 1 and getattr(self, "_rccl_ctx", None) is None:
             return False
-        if LOOP_RUNNER == "auto" and self.world_size == 1:
+        if _opt("LOOP_RUNNER") == "auto" and self.world_size == 1:
             return False
         if self.neg_indices_ is not None or self._exclusion is not None or self.early_exaggeration_coeff_ > 1:
             return False
@@ -398,7 +405,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         # windows that contain RCCL calls are enqueued as plain launches: captured collectives have never run on hardware
         # here, and at the ~100 us an iteration takes when the rows are sharded the 8 us of host work per iteration of the
         # plain form are hidden anyway
-        self._loop_graph = bool(LOOP_GRAPH) and ctx is None
+        self._loop_graph = bool(_opt("LOOP_GRAPH")) and ctx is None
         outer = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev) if self._loop_graph else outer
         side.wait_stream(outer)
@@ -476,7 +483,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             )
             return grad, True
         prof = PROFILE is not None and int(self.n_iter_) % PROFILE_EVERY == 0
-        if SCHEDULED and self.n_samples_in_ < 2**31 - 1:
+        if _opt("SCHEDULED") and self.n_samples_in_ < 2**31 - 1:
             self._compute_gradients_scheduled(grad, neg, prof)
             return grad, True
         if prof:
