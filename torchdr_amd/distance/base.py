@@ -336,9 +336,11 @@ def _side_streams(dev, n):
     return have[:n]
 
 
-def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset, side_work=None):
+def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset, side_work=None, scan_frac_of=None):
     """Pilot: screen a 1024-query slice with the tiers (one-term, three-term, three-term with long lists), flagging what
-    an UNSLICED launch would flag; the cheapest tier with <= 5 % flagged wins.  Returns (tier, tau) with tau the largest
+    an UNSLICED launch would flag; among the tiers with <= 5 % flagged the one with the smallest estimated total time wins
+    (`_pick_tier`; ``scan_frac_of``: callable tau -> predicted scan share of a pruned search, evaluated after the side work
+    -- the cluster index -- is complete).  Returns (tier, tau) with tau the largest
     k-th neighbour distance (squared) of the slice, or (-1, None) when the worst-case band swallows the spare list slots
     for a sizeable share of the queries under every tier (large ||x|| ||y|| relative to the neighbour spacing): the
     one-stage kernel serves such data.
@@ -390,14 +392,49 @@ def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset, side_work=Non
     ci_built = getattr(Y, "_cluster_index", None)
     if ci_built is not None:
         ci_built.record_stream(main)
+    # every tier that keeps the flagged share <= 5 %: (tier, flagged share, tau).  The first two pilots have both run
+    # already; the long-list tier is only tried when neither passes.
+    cands = []
     for tier in tiers:
         if tier not in runs:
+            if cands:
+                break
             runs[tier] = launch(tier)
         pd, n_flagged = runs[tier]
-        if int(n_flagged.item()) <= _SCREEN_PILOT_MAX_FRAC * _SCREEN_PILOT_Q:
+        f = int(n_flagged.item()) / float(_SCREEN_PILOT_Q)
+        if f <= _SCREEN_PILOT_MAX_FRAC:
             kth = pd[:, -1]
-            return tier, float((kth * kth if metric == "euclidean" else kth).max())
-    return -1, None
+            cands.append((tier, f, float((kth * kth if metric == "euclidean" else kth).max())))
+    LAST_KNN["tier_candidates"] = [(t, round(f, 4)) for t, f, _ in cands]
+    if not cands:
+        return -1, None
+    tier, _, tau = _pick_tier(cands, Q.n if Q is not Y else Y.n, Y.n, d, scan_frac_of)
+    return tier, tau
+
+
+# matrix work of a tier relative to the one-term tier, and the two rates of the cost model (effective flop/s of the
+# one-term screening scan and of the one-stage exact kernel at the headline size)
+_TIER_REL_COST = {0: 1.0, 1: 1.9, 2: 2.3}
+_SCREEN_RATE, _EXACT_RATE = 6.2e14, 1.26e14
+
+
+def _pick_tier(cands, nq, n_db, d, scan_frac_of=None):
+    """Cheapest tier by estimated time = scan + exact re-search of the rows it will flag.  A flagged row costs a full
+    one-stage scan of the database (n_db * d * 2 flop at the fp32 matrix rate): at N = 1M every per cent of flagged rows is
+    20 ms -- next to nothing against an unpruned scan (0.4-0.8 s), but several times a PRUNED scan (15-40 ms), where the
+    cheapest-tier-that-passes rule of round 2 picked the one-term tier for k = 15 and paid 50 ms for its 2 % of flagged rows
+    (kNN build 84 ms; 30 ms with the three-term tier).  ``scan_frac_of(tau)``: predicted share of the tiles a pruned scan
+    still visits, or None when the scan will not be pruned."""
+    best = None
+    for tier, f, tau in cands:
+        pairs = float(nq) * float(n_db) * d * 2.0
+        frac = 1.0
+        if scan_frac_of is not None:
+            frac = min(1.0, max(float(scan_frac_of(2.0 * tau)), 0.02))     # a pruned scan never costs less than its fixed part
+        cost = pairs * _TIER_REL_COST[tier] * frac / _SCREEN_RATE + f * pairs / _EXACT_RATE
+        if best is None or cost < best[0]:
+            best = (cost, tier, f, tau)
+    return best[1], best[2], best[3]
 
 
 def _screen_fallback(Q, Y, q0, k, metric, exclude_self, q_offset, rows, out_d, out_i):
@@ -419,6 +456,17 @@ def _screen_fallback(Q, Y, q0, k, metric, exclude_self, q_offset, rows, out_d, o
         If = If[keep].view(-1, k)
     out_d[rows] = Cf
     out_i[rows] = If
+
+
+def _pruned_share(Y, tau):
+    """Predicted share of the tiles a pruned scan of Y still visits at threshold tau (1.0 when the index says pruning will
+    not be used: the plain scan then runs)."""
+    ci = getattr(Y, "_cluster_index", None)
+    if ci is None:
+        return 1.0
+    ci.finish()
+    share = ci.scan_fraction(tau)
+    return share if (_opt("PRUNE_MODE") == "force" or share <= _PRUNE_MAX_SCAN_FRACTION) else 1.0
 
 
 def _cluster_index_start(Y):
@@ -489,7 +537,8 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
     if pilot and nq >= _SCREEN_PILOT_MIN_Q:
         # the index build does not depend on the pilot's outcome: it runs next to it
         tier, pilot_tau = _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset,
-                                       side_work=((lambda: _cluster_index_start(Y)), (lambda: _cluster_index(Y, ops))) if prune else None)
+                                       side_work=((lambda: _cluster_index_start(Y)), (lambda: _cluster_index(Y, ops))) if prune else None,
+                                       scan_frac_of=(lambda tau: _pruned_share(Y, tau)) if prune else None)
         if tier < 0:
             return -1
     if prune:
@@ -608,7 +657,8 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
         ops = _screen_operands(Y, Y)
         q0 = max(0, min((c0 // 32) * 32, ((n - _SCREEN_PILOT_Q) // 32) * 32))
         tier, tau = _choose_tier(Y, Y, ops, q0, k, metric, exclude_self, 0,
-                                 side_work=((lambda: _cluster_index_start(Y)), (lambda: _cluster_index(Y, ops))))
+                                 side_work=((lambda: _cluster_index_start(Y)), (lambda: _cluster_index(Y, ops))),
+                                 scan_frac_of=lambda t: _pruned_share(Y, t))
     # one decision for all ranks: any rank without a usable tier -> nobody prunes; else the most conservative tier and
     # the largest threshold estimate (element-wise MAX all-reduce)
     vote = torch.tensor([float(tier < 0), float(max(tier, 0)), 0.0 if tau is None else tau], dtype=torch.float64, device=dev)
