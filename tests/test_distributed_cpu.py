@@ -165,7 +165,8 @@ def test_abi_argument_checks_run_before_any_device_work():
     assert L.tdr_l1_block_f32(p, 4, 4, p, 8, 4, 8, p, 4, null) == -1                 # row stride < d
     assert L.tdr_l1_exact_f32(p, 9000, null, 4, 0, p, 9000, null, 0, 4, 0, 8192, 0, p, 4, null) == -2   # third cascade level
     assert L.tdr_l1_exact_f32(p, 8, null, 4, 0, p, 8, p, 2, 4, 0, 8, 0, p, 4, null) == -1                # ldc < nc
-    assert L.tdr_topk_merge_cand_f32(p, p, 8, 4, 8, 300, p, null) == -2              # k > 256
+    assert L.tdr_topk_merge_cand_f32(p, p, 8, 4, 8, 1300, p, null) == -2             # k > tdr_topk_max_k() = 1024
+    assert L.tdr_topk_max_k() == 1024
     assert L.tdr_topk_merge_f32(p, 8, 4, 8, null, null, 0, 0, 5, 4, 0, p, null) == -1   # sqhyperbolic needs the norms
     assert L.tdr_topk_merge_f32(p, 8, 4, 8, null, null, 0, 0, 5, 7, 0, p, null) == -1   # unknown metric
     assert L.tdr_hyperbolic_from_gram_f32(p, 4, 2, 8, p, p, null) == -1              # ld < nd

@@ -67,6 +67,8 @@ class NeighborEmbedding(AffinityMatcher):
                          init=init, init_scaling=init_scaling, device=device, backend=backend, verbose=verbose,
                          random_state=random_state, check_interval=check_interval, compile=compile, **kwargs)
         self._setup_distributed(distributed)
+        self._perm = None
+        self.loop_order_ = None     # after a fit: caller's row of every loop row, or None when the loop ran in the caller's numbering
 
     # --- fit ------------------------------------------------------------------------------------
     def _check_n_neighbors(self, n):
