@@ -13,7 +13,7 @@ from tests.conftest import gmm
 pytestmark = pytest.mark.gpu
 
 RZ = 16384          # red-zone elements of 4 bytes on each side
-PATTERN = 0x5A5AA5A5 - (1 << 32)
+PATTERN = 0x5A5AA5A5
 
 
 class Arena:

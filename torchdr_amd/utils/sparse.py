@@ -64,6 +64,11 @@ def symmetrize_to_csr(values, indices, mode="sum_minus_prod", row_offset=0, n_to
     vals = values.contiguous().float()
     cols = indices.to(torch.int32).contiguous()
     n, k = vals.shape
+    if k > 256:
+        raise NotImplementedError(
+            f"[torchdr_amd] symmetrize_sparse: the row-local symmetrisation kernels hold up to 256 entries per row (got {k}); "
+            "UMAP with more than 256 neighbours is not supported."
+        )
     dev = vals.device
     ws_bytes = L.tdr_sym_workspace_bytes(n, k)
     ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
