@@ -386,6 +386,10 @@ struct SchedEllParams {
     int* err;
 };
 
+constexpr int ELL_U = 8;   // slots in flight per wavefront: the walk is a chain of dependent global loads (one per slot), and a
+                           // block is one wavefront -- without this a CU has ~9 loads in flight and the kernel is bound by
+                           // memory LATENCY (9.5 ms per window measured; 1.85 ms for the edge-per-lane kernel)
+
 __global__ __launch_bounds__(64) void umap_sched_build_ell_kernel(const SchedEllParams P) {
     extern __shared__ uint32_t cnt[];  // [B * S][64]: column `lane` = the counters / write pointers of that lane's row
     const int lane = threadIdx.x;
@@ -397,28 +401,38 @@ __global__ __launch_bounds__(64) void umap_sched_build_ell_kernel(const SchedEll
     const int W = (int)((P.ell_base[rb + 1] - e0) >> 6);
     const int32_t rinfo = P.ell_row[rb * 64 + lane];
     const int lrow = rinfo & 0xff, deg = rinfo >> 8;
+    const float INF = __builtin_inff();
 
     // phase 1: advance the counters, keep the masks, count the firings per (iteration, slice) of the lane's row
-    for (int slot = 0; slot < W; ++slot) {
-        const bool valid = slot < deg;
-        if (!__ballot(valid)) break;     // lanes are sorted by degree: nothing left in this block
-        const int64_t idx = e0 + (int64_t)slot * 64 + lane;
-        uint32_t m = 0u, s = 0u;
-        if (valid) {
-            float nx = P.next[idx];
-            const float ep = P.eps[idx];
-            const uint32_t col = (uint32_t)P.cols[idx];
-            m = fire_mask(nx, ep, t0, P.B);
-            if (m) P.next[idx] = nx;
-            P.mask[idx] = m;
-            s = col / P.slice_step;
-            if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
+    for (int slot0 = 0; slot0 < W; slot0 += ELL_U) {
+        float nx[ELL_U], ep[ELL_U];
+        uint32_t col[ELL_U];
+#pragma unroll
+        for (int u = 0; u < ELL_U; ++u) {
+            const bool valid = slot0 + u < deg;
+            const int64_t idx = e0 + (int64_t)(slot0 + u) * 64 + lane;
+            nx[u] = valid ? P.next[idx] : INF;
+            ep[u] = valid ? P.eps[idx] : INF;
+            col[u] = valid ? (uint32_t)P.cols[idx] : 0u;
         }
-        const int sbase = (int)s * 64 + lane;
-        while (m) {
-            const int t = __ffs(m) - 1;
-            m &= m - 1u;
-            atomicAdd(&cnt[t * P.S * 64 + sbase], 1u);   // the lane's own column: never contended
+#pragma unroll
+        for (int u = 0; u < ELL_U; ++u) {
+            if (slot0 + u >= W) break;       // wavefront-uniform
+            const bool valid = slot0 + u < deg;
+            const int64_t idx = e0 + (int64_t)(slot0 + u) * 64 + lane;
+            float nxu = nx[u];
+            uint32_t m = fire_mask(nxu, ep[u], t0, P.B);     // invalid lanes: counter +inf, no firing
+            if (m) P.next[idx] = nxu;
+            if (valid) P.mask[idx] = m;
+            if (!__ballot(m != 0u)) continue;
+            uint32_t s = col[u] / P.slice_step;
+            if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
+            const int sbase = (int)s * 64 + lane;
+            while (m) {
+                const int t = __ffs(m) - 1;
+                m &= m - 1u;
+                atomicAdd(&cnt[t * P.S * 64 + sbase], 1u);   // the lane's own column: never contended
+            }
         }
     }
 
@@ -434,11 +448,15 @@ __global__ __launch_bounds__(64) void umap_sched_build_ell_kernel(const SchedEll
     bool bad = base + capacity64 > 0xffffffffLL;
     uint32_t carry = 0;
     for (int t = 0; t < P.B; ++t) {
-        uint32_t v[8];
+        uint32_t v[4] = {0u, 0u, 0u, 0u};    // slices x window <= 128 and window <= 32: at most 4 slices at full windows
         uint32_t act = 0;
-        for (int sg = 0; sg < P.S; ++sg) { v[sg] = cnt[(t * P.S + sg) * 64 + own]; act += v[sg]; }
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg)
+            if (sg < P.S) { v[sg] = cnt[(t * P.S + sg) * 64 + own]; act += v[sg]; }
         if (act > 65535u) act = 65535u;
-        for (int sg = 0; sg < P.S; ++sg) {
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            if (sg >= P.S) break;
             const int k = t * P.S + sg;
             uint32_t inc = v[sg];
 #pragma unroll
@@ -457,24 +475,28 @@ __global__ __launch_bounds__(64) void umap_sched_build_ell_kernel(const SchedEll
     if (carry > capacity && lane == 0) atomicMax(P.err, 1);
 
     // phase 2: place every firing at its row's write pointer
-    for (int slot = 0; slot < W; ++slot) {
-        const bool valid = slot < deg;
-        if (!__ballot(valid)) break;
-        const int64_t idx = e0 + (int64_t)slot * 64 + lane;
-        uint32_t m = valid ? P.mask[idx] : 0u;
-        if (!__ballot(m != 0u)) continue;
-        uint32_t col = 0u, s = 0u;
-        if (m) {
-            col = (uint32_t)P.cols[idx];
-            s = col / P.slice_step;
-            if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
+    for (int slot0 = 0; slot0 < W; slot0 += ELL_U) {
+        uint32_t mk[ELL_U], col[ELL_U];
+#pragma unroll
+        for (int u = 0; u < ELL_U; ++u) {
+            const bool valid = slot0 + u < deg;
+            const int64_t idx = e0 + (int64_t)(slot0 + u) * 64 + lane;
+            mk[u] = valid ? P.mask[idx] : 0u;
+            col[u] = valid ? (uint32_t)P.cols[idx] : 0u;
         }
-        const int sbase = (int)s * 64 + lane;
-        while (m) {
-            const int t = __ffs(m) - 1;
-            m &= m - 1u;
-            const uint32_t pos = atomicAdd(&cnt[t * P.S * 64 + sbase], 1u);
-            if (pos < capacity) P.list[base + pos] = (int32_t)col;
+#pragma unroll
+        for (int u = 0; u < ELL_U; ++u) {
+            uint32_t m = mk[u];
+            if (!__ballot(m != 0u)) continue;
+            uint32_t s = col[u] / P.slice_step;
+            if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
+            const int sbase = (int)s * 64 + lane;
+            while (m) {
+                const int t = __ffs(m) - 1;
+                m &= m - 1u;
+                const uint32_t pos = atomicAdd(&cnt[t * P.S * 64 + sbase], 1u);
+                if (pos < capacity) P.list[base + pos] = (int32_t)col[u];
+            }
         }
     }
 }
@@ -1255,7 +1277,7 @@ int tdr_umap_sched_build_ell_f32(const int64_t* ell_base, const int32_t* ell_row
     if (!ell_base || !ell_row || !ell_cols || !ell_eps || !ell_next || !ell_mask || !blk_base || !list || !hdr || !err) return TDR_ERR_BAD_ARG;
     if (n_rows <= 0 || n_total < 2 || n_total >= 0x7fffffffLL || t0 < 0 || n_iters <= 0 || n_iters > SCHED_BMAX || t0 > (1 << 24) - 64) return TDR_ERR_BAD_ARG;
     if (n_slices != 1 && n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
-    if (n_slices * n_iters > 128) return TDR_ERR_UNSUPPORTED;
+    if (n_slices * n_iters > 128 || n_slices > 4) return TDR_ERR_UNSUPPORTED;
     SchedEllParams P;
     P.ell_base = ell_base; P.ell_row = ell_row; P.cols = ell_cols; P.eps = ell_eps; P.next = ell_next; P.mask = (uint32_t*)ell_mask;
     P.n_rows = n_rows;
