@@ -16,6 +16,14 @@ X = gmm(n, 128, 2.0).cuda()
 csr = UMAPAffinity(n_neighbors=30, max_iter=100)(X, return_csr=True)
 ci = ClusterIndex(PackedPoints(X))
 perm, inv = ci.perm, ci.inv
+WIN = int(os.environ.get("DEG_WINDOW", "0"))
+if WIN:   # refine the cluster-sorted order: inside windows of WIN consecutive positions, rows by descending degree
+    deg0 = (csr.rowptr[1:] - csr.rowptr[:-1])[perm.long()]
+    key = (torch.arange(n, device="cuda") // WIN) * 8192 + (8191 - deg0.clamp(max=8191))
+    order = torch.sort(key, stable=True).indices
+    perm = perm[order].contiguous()
+    inv = torch.empty_like(perm)
+    inv[perm.long()] = torch.arange(n, dtype=torch.int32, device="cuda")
 rowptr = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
 torch.cumsum((csr.rowptr[1:] - csr.rowptr[:-1])[perm.long()], 0, out=rowptr[1:])
 cols, vals = torch.empty_like(csr.cols), torch.empty_like(csr.vals)
