@@ -297,18 +297,6 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
  * Z (n_rows, nc), in one kernel with the same bits as the two. */
 int tdr_umap_sched_step_f32(const float* acc, int n_slices, int nc, int64_t n_rows, float exag, float rep, float* grad, float* Z,
                             float* buf, float lr, float momentum, int first, int* nan_flag, int n_iter, void* stream);
-/* Row-per-lane schedule build on a block-ELL copy of the loop state (a lane owns a row, the wavefront walks the rows' edges
- * rank by rank: lanes of one instruction fire about equally often; counters and write pointers are lane-private).  Same
- * outputs as tdr_umap_sched_build_f32.  plan -> (host reads ell_base[n_blocks], *max_deg) -> pack -> build per window;
- * unpack returns the counters to CSR loop order. */
-int tdr_umap_sched_ell_plan(const int64_t* rowptr, int64_t n_rows, int64_t* entries, int64_t* ell_base, int* max_deg, void* stream);
-int tdr_umap_sched_ell_pack_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, int64_t n_rows, const int64_t* ell_base,
-                                int32_t* ell_row, int32_t* ell_cols, float* ell_eps, float* ell_next, void* stream);
-int tdr_umap_sched_ell_unpack_f32(const int64_t* rowptr, int64_t n_rows, const int64_t* ell_base, const int32_t* ell_row,
-                                  const float* ell_vals, float* out, void* stream);
-int tdr_umap_sched_build_ell_f32(const int64_t* ell_base, const int32_t* ell_row, const int32_t* ell_cols, const float* ell_eps,
-                                 float* ell_next, void* ell_mask, int64_t n_rows, int64_t n_total, int t0, int n_iters, int n_slices,
-                                 const int64_t* blk_base, int32_t* list, void* hdr, int* err, void* stream);
 /* The optimisation loop of affinity_matcher.py:288-352 for UMAP's closed-form step + torch.optim.SGD behind one handle
  * (csrc/tdr_umap_sched.hip): windows of <= block_iters iterations (schedule build + per iteration n_slices gradient
  * passes + the SGD step [+ a row all-gather]) are captured into HIP graphs and replayed; the iteration base lives in
@@ -324,8 +312,6 @@ typedef struct tdr_umap_loop_desc {
     float a, b; int neg_rate, n_negatives; uint64_t seed; float exag, rep, eps; int n_slices, block_iters;
     const float* lr_table; int max_iter; float momentum; int first_iter; int check_interval; float* norm2; float* snap; int* nan_flag;
     void* scratch; void* gather; void* gather_ctx; int geom;
-    /* optional block-ELL copy of the loop state (tdr_umap_sched_ell_*): the windows then use the row-per-lane schedule build */
-    const int64_t* ell_base; const int32_t* ell_row; const int32_t* ell_cols; const float* ell_eps; float* ell_next; void* ell_mask;
 } tdr_umap_loop_desc;
 int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d);
 int tdr_umap_loop_run(void* loop, int it0, int n_iters, int use_graph, void* stream);

@@ -567,118 +567,3 @@ def test_umap_loop_in_cluster_order_is_the_same_fit():
         assert w.loop_order_ is None
     finally:
         dbase.PRUNE_MODE = old_mode
-
-
-# ---- row-per-lane schedule build on the block-ELL state -------------------------------------------------------------------
-class SchedEll(Sched):
-    """`Sched` with the loop state in block-ELL form: plan / pack once, `tdr_umap_sched_build_ell_f32` per window; the counters
-    are gathered back into the caller's CSR tensor after every build (so the CSR-based checks apply unchanged)."""
-
-    def __init__(self, rowptr, cols, eps_per, n_total, B, S, nc=2, row0=0):
-        super().__init__(rowptr, cols, eps_per, n_total, B, S, nc, row0)
-        _l, L = self.lib, self.L
-        nb = self.nb
-        entries = torch.empty(nb, dtype=torch.int64, device="cuda")
-        self.ell_base = torch.empty(nb + 1, dtype=torch.int64, device="cuda")
-        md = torch.zeros(1, dtype=torch.int32, device="cuda")
-        _l.check(L.tdr_umap_sched_ell_plan(_l.ptr(rowptr), self.n_rows, _l.ptr(entries), _l.ptr(self.ell_base), _l.ptr(md), _l.stream_ptr()), "ell_plan")
-        n_ell = int(self.ell_base[-1].item())
-        self.max_deg = int(md.item())
-        self.ell_row = torch.empty(nb * 64, dtype=torch.int32, device="cuda")
-        self.ell_cols = torch.empty(n_ell, dtype=torch.int32, device="cuda")
-        self.ell_eps = torch.empty(n_ell, dtype=torch.float32, device="cuda")
-        self.ell_next = torch.empty(n_ell, dtype=torch.float32, device="cuda")
-        self.ell_mask = torch.empty(n_ell, dtype=torch.int32, device="cuda")
-        self._packed_for = None
-
-    def _pack(self, nxt):
-        """ELL state from the CSR counters `nxt` (pack copies the periods; the counters go in through a second pack call)."""
-        _l, L = self.lib, self.L
-        _l.check(L.tdr_umap_sched_ell_pack_f32(_l.ptr(self.rowptr), _l.ptr(self.cols), _l.ptr(nxt), self.n_rows, _l.ptr(self.ell_base),
-                                               _l.ptr(self.ell_row), _l.ptr(self.ell_cols), _l.ptr(self.ell_next), _l.ptr(self.ell_eps),
-                                               _l.stream_ptr()), "ell_pack(next)")      # eps slot <- counters (overwritten below), next slot <- counters
-        tmp = self.ell_eps.clone()        # = the counters in ELL order
-        _l.check(L.tdr_umap_sched_ell_pack_f32(_l.ptr(self.rowptr), _l.ptr(self.cols), _l.ptr(self.eps_per), self.n_rows, _l.ptr(self.ell_base),
-                                               _l.ptr(self.ell_row), _l.ptr(self.ell_cols), _l.ptr(self.ell_eps), _l.ptr(self.ell_next),
-                                               _l.stream_ptr()), "ell_pack(eps)")
-        self.ell_next.copy_(tmp)
-
-    def build(self, nxt, t0, n):
-        _l, L = self.lib, self.L
-        self._pack(nxt)
-        _l.check(L.tdr_umap_sched_build_ell_f32(_l.ptr(self.ell_base), _l.ptr(self.ell_row), _l.ptr(self.ell_cols), _l.ptr(self.ell_eps),
-                                                _l.ptr(self.ell_next), _l.ptr(self.ell_mask), self.n_rows, self.n_total, t0, n, self.S,
-                                                _l.ptr(self.blk_base), _l.ptr(self.list), _l.ptr(self.hdr), _l.ptr(self.err), _l.stream_ptr()),
-                 "build_ell")
-        assert int(self.err.item()) == 0
-        _l.check(L.tdr_umap_sched_ell_unpack_f32(_l.ptr(self.rowptr), self.n_rows, _l.ptr(self.ell_base), _l.ptr(self.ell_row),
-                                                 _l.ptr(self.ell_next), _l.ptr(nxt), _l.stream_ptr()), "ell_unpack")
-
-
-@pytest.mark.parametrize("S", [1, 2, 4])
-@pytest.mark.parametrize("B,t0", [(32, 0), (7, 37), (32, 64)])
-def test_ell_schedule_equals_the_edge_per_lane_schedule(S, B, t0):
-    """tdr_umap_sched_build_ell_f32 (a lane owns a row, block-ELL state) against tdr_umap_sched_build_f32 (a lane owns an edge):
-    identical counters, identical row records (start, length, active count of every (iteration, slice, row) segment -- hence the
-    same tiling of every block's region) and the same set of columns in every segment; same lists on every run.  Graph with a
-    700-edge hub row, empty rows at a block boundary and a ragged last block."""
-    if S * B > 128:
-        pytest.skip("the ELL kernel holds a row's (iteration, slice) table in one LDS column: slices x window <= 128")
-    n = 3000 + 21
-    rowptr, cols, vals = random_graph(n, seed=5 + S, hub=700)
-    eps_per, nxt0 = prepare(vals.cuda(), 200)
-    ep_c, nx_c = eps_per.cpu(), nxt0.cpu().clone()
-    for t in range(t0):
-        a = nx_c <= np.float32(t + 1)
-        nx_c[a] += ep_c[a]
-    cols_p, eps_p = layout(rowptr.cuda(), cols.cuda(), eps_per)
-    # counters in the loop order of the layout: re-derive them from the laid-out periods (same recurrence, same start)
-    nx_l = eps_p.cpu().clone()
-    epl = eps_p.cpu()
-    for t in range(t0):
-        a = nx_l <= np.float32(t + 1)
-        nx_l[a] += epl[a]
-    a_ref = Sched(rowptr.cuda(), cols_p, eps_p, n, B, S)
-    b_ell = SchedEll(rowptr.cuda(), cols_p, eps_p, n, B, S)
-    assert b_ell.max_deg == 700
-    na, nb_ = nx_l.clone().cuda(), nx_l.clone().cuda()
-    a_ref.build(na, t0, B)
-    b_ell.build(nb_, t0, B)
-    assert torch.equal(na, nb_)
-    sa, la, aa = a_ref.records(B)
-    sb, lb, ab = b_ell.records(B)
-    assert torch.equal(la, lb) and torch.equal(aa, ab) and torch.equal(sa, sb)
-    la_, lb_ = a_ref.list.cpu().long(), b_ell.list.cpu().long()
-    for k in range(B * S):
-        idx = torch.repeat_interleave(sa[k], la[k]) + (torch.arange(int(la[k].sum())) - torch.repeat_interleave(la[k].cumsum(0) - la[k], la[k]))
-        rows_g = torch.repeat_interleave(torch.arange(n), la[k])
-        assert torch.equal(torch.sort(rows_g * n + la_[idx]).values, torch.sort(rows_g * n + lb_[idx]).values)
-    first = b_ell.list.clone()
-    nb2 = nx_l.clone().cuda()
-    b_ell.build(nb2, t0, B)
-    assert torch.equal(b_ell.list, first) and torch.equal(nb2, nb_)
-
-
-def test_umap_fit_is_the_same_with_either_schedule_kernel():
-    """Whole estimator with SCHED_ELL on / off: same counters, same row records, same set of columns per segment -- only the
-    order inside a segment differs, i.e. the order in which a row's forces are added.  Three iterations (the clamped forces
-    make longer runs drift apart on last-bit differences, as for the cluster-order numbering)."""
-    import torchdr_amd
-    from torchdr_amd import config
-
-    X = gmm(6000, 16, 2.0, seed=12).cuda()
-    init = torch.randn(6000, 2, generator=torch.Generator().manual_seed(2)).cuda()
-    out, nxt = {}, {}
-    for ell in (True, False):
-        with config.options(SCHED_ELL=ell):
-            class Keep(torchdr_amd.UMAP):
-                def clear_memory(self_inner):
-                    nxt[ell] = self_inner.epoch_of_next_sample.clone()
-                    super().clear_memory()
-
-            Keep.__module__ = "torchdr_amd.tests"
-            m = Keep(n_neighbors=12, max_iter=3, random_state=0, init=init)
-            out[ell] = m.fit_transform(X)
-    assert torch.equal(nxt[True], nxt[False])
-    err = (out[True] - out[False]).abs().max(1).values / out[False].abs().max()
-    assert float(err.median()) < 1e-5 and float((err > 1e-3).float().mean()) < 0.01, (float(err.median()), float(err.max()))

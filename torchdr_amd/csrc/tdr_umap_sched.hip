@@ -356,208 +356,6 @@ __global__ __launch_bounds__(256) void umap_sched_build_kernel(const SchedBuildP
     }
 }
 
-// ---- row-per-lane schedule build on a block-ELL copy of the loop state ---------------------------------------------
-// The kernel above gives a lane one EDGE of a 16-edge chunk and runs its per-firing loops as long as the busiest of the 64
-// lanes fires: a row's strongest edge fires in every iteration of the window, its sixteenth in a sixth of them -- ~40 % of
-// the lanes do something in a given round, and the kernel is bound by vector instructions (11.6 k per 16 rows,
-// profiles/r03_sched_build_pmc.json).  Here a lane owns a ROW and the wavefront walks the rows' edges rank by rank (a
-// row's edges are sorted by firing period): the 64 lanes of an instruction hold edges of the SAME rank of 64 different
-// rows, which fire about equally often, and everything a firing touches is private to the lane -- its row's counters are
-// its own column of the LDS table (plain adds, no same-address atomics), its row's write pointers likewise.  For the loads
-// to coalesce the loop state of a 64-row block is kept slot-major ("block-ELL": entry (slot, lane) at base + 64 slot + lane,
-// width = the block's largest degree); the lanes of a block take its rows by DESCENDING degree, so the padded part of a
-// slot is a suffix of lanes that is masked off and never touches memory.  Firing masks go to a scratch array between the
-// two phases (one coalesced word per edge) instead of being recomputed.  One wavefront = one block = one workgroup: no
-// barriers.  Same lists (as sets per segment), row records and counters as the kernel above.
-struct SchedEllParams {
-    const int64_t* ell_base;   // (n_blocks + 1) first entry of every block; entries of block b = 64 * width_b
-    const int32_t* ell_row;    // (n_blocks * 64) lane -> local row (low 8 bits) | degree << 8; rows beyond n_rows: degree 0
-    const int32_t* cols;       // ELL arrays
-    const float* eps;
-    float* next;
-    uint32_t* mask;            // scratch, same shape
-    int64_t n_rows;
-    uint32_t slice_step;
-    int t0, B, S;
-    const int* iter_base;
-    const int64_t* blk_base;
-    int32_t* list;
-    uint2* hdr;
-    int* err;
-};
-
-constexpr int ELL_U = 8;   // slots in flight per wavefront: the walk is a chain of dependent global loads (one per slot), and a
-                           // block is one wavefront -- without this a CU has ~9 loads in flight and the kernel is bound by
-                           // memory LATENCY (9.5 ms per window measured; 1.85 ms for the edge-per-lane kernel)
-
-__global__ __launch_bounds__(64) void umap_sched_build_ell_kernel(const SchedEllParams P) {
-    extern __shared__ uint32_t cnt[];  // [B * S][64]: column `lane` = the counters / write pointers of that lane's row
-    const int lane = threadIdx.x;
-    const int64_t rb = blockIdx.x;
-    const int K = P.B * P.S;
-    const int t0 = P.t0 + (P.iter_base ? *P.iter_base : 0);
-    for (int k = 0; k < K; ++k) cnt[k * 64 + lane] = 0u;
-    const int64_t e0 = P.ell_base[rb];
-    const int W = (int)((P.ell_base[rb + 1] - e0) >> 6);
-    const int32_t rinfo = P.ell_row[rb * 64 + lane];
-    const int lrow = rinfo & 0xff, deg = rinfo >> 8;
-    const float INF = __builtin_inff();
-
-    // phase 1: advance the counters, keep the masks, count the firings per (iteration, slice) of the lane's row
-    for (int slot0 = 0; slot0 < W; slot0 += ELL_U) {
-        float nx[ELL_U], ep[ELL_U];
-        uint32_t col[ELL_U];
-#pragma unroll
-        for (int u = 0; u < ELL_U; ++u) {
-            const bool valid = slot0 + u < deg;
-            const int64_t idx = e0 + (int64_t)(slot0 + u) * 64 + lane;
-            nx[u] = valid ? P.next[idx] : INF;
-            ep[u] = valid ? P.eps[idx] : INF;
-            col[u] = valid ? (uint32_t)P.cols[idx] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < ELL_U; ++u) {
-            if (slot0 + u >= W) break;       // wavefront-uniform
-            const bool valid = slot0 + u < deg;
-            const int64_t idx = e0 + (int64_t)(slot0 + u) * 64 + lane;
-            float nxu = nx[u];
-            uint32_t m = fire_mask(nxu, ep[u], t0, P.B);     // invalid lanes: counter +inf, no firing
-            if (m) P.next[idx] = nxu;
-            if (valid) P.mask[idx] = m;
-            if (!__ballot(m != 0u)) continue;
-            uint32_t s = col[u] / P.slice_step;
-            if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
-            const int sbase = (int)s * 64 + lane;
-            while (m) {
-                const int t = __ffs(m) - 1;
-                m &= m - 1u;
-                atomicAdd(&cnt[t * P.S * 64 + sbase], 1u);   // the lane's own column: never contended
-            }
-        }
-    }
-
-    // row records and write pointers: exclusive scan of the counts in (iteration, slice, row) order.  The scan runs over
-    // ROWS (lane r <-> local row r) while the counters sit in the column of the lane that owns the row.
-    __shared__ int owner_of_row[64];
-    owner_of_row[lrow] = lane;
-    const int own = owner_of_row[lane];      // LDS operations of a wavefront complete in order: the writes are visible
-    const int64_t base = P.blk_base[rb];
-    const int64_t capacity64 = P.blk_base[rb + 1] - base;
-    const uint32_t capacity = capacity64 > 0xffffffffLL ? 0xffffffffu : (uint32_t)capacity64;
-    const int64_t row = rb * 64 + lane;
-    bool bad = base + capacity64 > 0xffffffffLL;
-    uint32_t carry = 0;
-    for (int t = 0; t < P.B; ++t) {
-        uint32_t v[4] = {0u, 0u, 0u, 0u};    // slices x window <= 128 and window <= 32: at most 4 slices at full windows
-        uint32_t act = 0;
-#pragma unroll
-        for (int sg = 0; sg < 4; ++sg)
-            if (sg < P.S) { v[sg] = cnt[(t * P.S + sg) * 64 + own]; act += v[sg]; }
-        if (act > 65535u) act = 65535u;
-#pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-            if (sg >= P.S) break;
-            const int k = t * P.S + sg;
-            uint32_t inc = v[sg];
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = __shfl_up(inc, o, 64);
-                if (lane >= o) inc += up;
-            }
-            const uint32_t ex = carry + inc - v[sg];
-            cnt[k * 64 + own] = ex;
-            bad = bad || v[sg] > 65535u;
-            if (row < P.n_rows) P.hdr[(size_t)k * P.n_rows + row] = make_uint2((uint32_t)base + ex, (v[sg] & 0xffffu) | (act << 16));
-            carry += __shfl(inc, 63, 64);
-        }
-    }
-    if (bad) atomicMax(P.err, 2);
-    if (carry > capacity && lane == 0) atomicMax(P.err, 1);
-
-    // phase 2: place every firing at its row's write pointer
-    for (int slot0 = 0; slot0 < W; slot0 += ELL_U) {
-        uint32_t mk[ELL_U], col[ELL_U];
-#pragma unroll
-        for (int u = 0; u < ELL_U; ++u) {
-            const bool valid = slot0 + u < deg;
-            const int64_t idx = e0 + (int64_t)(slot0 + u) * 64 + lane;
-            mk[u] = valid ? P.mask[idx] : 0u;
-            col[u] = valid ? (uint32_t)P.cols[idx] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < ELL_U; ++u) {
-            uint32_t m = mk[u];
-            if (!__ballot(m != 0u)) continue;
-            uint32_t s = col[u] / P.slice_step;
-            if (s > (uint32_t)(P.S - 1)) s = (uint32_t)(P.S - 1);
-            const int sbase = (int)s * 64 + lane;
-            while (m) {
-                const int t = __ffs(m) - 1;
-                m &= m - 1u;
-                const uint32_t pos = atomicAdd(&cnt[t * P.S * 64 + sbase], 1u);
-                if (pos < capacity) P.list[base + pos] = (int32_t)col[u];
-            }
-        }
-    }
-}
-
-// widths of the blocks: largest degree among the 64 rows (one wavefront per block)
-__global__ __launch_bounds__(256) void umap_ell_width_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows, int64_t n_blocks,
-                                                             int64_t* __restrict__ entries, int* __restrict__ max_deg) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= n_blocks) return;
-    const int64_t r = b * 64 + lane;
-    int d = r < n_rows ? (int)(rowptr[r + 1] - rowptr[r]) : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) d = max(d, __shfl_xor(d, o, 64));
-    if (lane == 0) { entries[b] = (int64_t)d * 64; atomicMax(max_deg, d); }
-}
-
-// CSR loop state (rows' edges in loop order) -> block-ELL; lanes take the rows of a block by descending degree
-__global__ __launch_bounds__(256) void umap_ell_pack_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                                                            const float* __restrict__ eps, int64_t n_rows, int64_t n_blocks,
-                                                            const int64_t* __restrict__ ell_base, int32_t* __restrict__ ell_row,
-                                                            int32_t* __restrict__ ecols, float* __restrict__ eeps, float* __restrict__ enext) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= n_blocks) return;
-    const int64_t r = b * 64 + lane;
-    const int64_t e_begin = r < n_rows ? rowptr[r] : 0;
-    const int d = r < n_rows ? (int)(rowptr[r + 1] - e_begin) : 0;
-    int rank = 0;   // position of this row among the block's rows by (degree descending, row ascending)
-    for (int q = 0; q < 64; ++q) {
-        const int dq = __builtin_amdgcn_readlane(d, q);
-        rank += (dq > d || (dq == d && q < lane)) ? 1 : 0;
-    }
-    ell_row[b * 64 + rank] = lane | (d << 8);
-    const int64_t e0 = ell_base[b];
-    const float INF = __builtin_inff();
-    for (int slot = 0; slot < d; ++slot) {
-        const int64_t dst = e0 + (int64_t)slot * 64 + rank;
-        const float ep = eps[e_begin + slot];
-        ecols[dst] = cols[e_begin + slot];
-        eeps[dst] = ep;
-        enext[dst] = ep;
-    }
-    (void)INF;
-}
-
-// block-ELL values (e.g. the counters) -> CSR loop order
-__global__ __launch_bounds__(256) void umap_ell_unpack_kernel(const int64_t* __restrict__ rowptr, int64_t n_rows, int64_t n_blocks,
-                                                              const int64_t* __restrict__ ell_base, const int32_t* __restrict__ ell_row,
-                                                              const float* __restrict__ evals, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= n_blocks) return;
-    const int32_t rinfo = ell_row[b * 64 + lane];
-    const int lrow = rinfo & 0xff, d = rinfo >> 8;
-    const int64_t r = b * 64 + lrow;
-    if (r >= n_rows) return;
-    const int64_t e_begin = rowptr[r], e0 = ell_base[b];
-    for (int slot = 0; slot < d; ++slot) out[e_begin + slot] = evals[e0 + (int64_t)slot * 64 + lane];
-}
-
 // Loop layout of a row's edges: ascending eps_per (= often-firing edges first, never-firing ones last), ties by column
 // id, then position -- the order does not depend on how the CSR row was arranged, so a row-sharded fit (rows symmetrised
 // in the loop's numbering) and a single-process one (rows permuted into it) sum a row's forces in the same order.  Rank sort per row, one wavefront per row: the row's periods sit in registers (lane p holds entries p,
@@ -1024,19 +822,6 @@ static int launch_sched_build(const SchedBuildParams& P0, hipStream_t st, bool s
     return e == hipSuccess ? TDR_OK : (int)e;
 }
 
-static int launch_sched_build_ell(const SchedEllParams& P, hipStream_t st, bool set_attr) {
-    const int64_t n_blocks = (P.n_rows + SCHED_RB - 1) / SCHED_RB;
-    const size_t lds = (size_t)P.B * P.S * 64 * sizeof(uint32_t);
-    if (set_attr && lds > 32 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_ell_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(umap_sched_build_ell_kernel, dim3((unsigned)n_blocks), dim3(64), lds, st, P);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? TDR_OK : (int)e;
-}
-
 // all slice passes of one evaluation: one launch per slice (geom < 16), or -- geom & 16, S > 1 -- ONE joint launch with the
 // slices spread over the XCDs and a combine kernel; acc must then hold S planes of (n_rows, 2 nc) floats
 static int launch_sched_grad_all(SchedGradParams& P, int geom, hipStream_t st) {
@@ -1115,8 +900,6 @@ struct UmapLoop {
     int* iter_base;                 // device int (caller's scratch)
     tdr_collective_fn gather; void* gather_ctx;
     int geom;
-    // block-ELL copy of the loop state (row-per-lane schedule build); ell_base == nullptr: the CSR form above
-    const int64_t* ell_base; const int32_t* ell_row; const int32_t* ell_cols; const float* ell_eps; float* ell_next; uint32_t* ell_mask;
     // captured windows: graph_len[i] iterations each
     hipGraphExec_t graphs[2]; int graph_len[2];
 };
@@ -1131,16 +914,7 @@ static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st) {
     Bp.stash = L->n_total <= (1LL << 29) ? 1 : 0;
     Bp.t0 = 0; Bp.iter_base = L->iter_base; Bp.B = n; Bp.S = L->S; Bp.blk_base = L->blk_base; Bp.list = L->list; Bp.hdr = L->hdr;
     Bp.err = L->err;
-    int rcb;
-    if (L->ell_base) {
-        SchedEllParams Ep;
-        Ep.ell_base = L->ell_base; Ep.ell_row = L->ell_row; Ep.cols = L->ell_cols; Ep.eps = L->ell_eps; Ep.next = L->ell_next;
-        Ep.mask = L->ell_mask; Ep.n_rows = L->n_rows; Ep.slice_step = Bp.slice_step; Ep.t0 = 0; Ep.iter_base = L->iter_base;
-        Ep.B = n; Ep.S = L->S; Ep.blk_base = L->blk_base; Ep.list = L->list; Ep.hdr = L->hdr; Ep.err = L->err;
-        rcb = launch_sched_build_ell(Ep, st, false);
-    } else {
-        rcb = launch_sched_build(Bp, st, false);
-    }
+    const int rcb = launch_sched_build(Bp, st, false);
     if (rcb != TDR_OK) return rcb;
     SchedGradParams G;
     G.Z = L->Z; G.n_total = L->n_total; G.row0 = L->row0; G.n_rows = L->n_rows; G.list = L->list; G.hdr = L->hdr; G.S = L->S;
@@ -1231,62 +1005,6 @@ int tdr_umap_sched_build_f32(const int64_t* rowptr, const int32_t* cols, const f
     return launch_sched_build(P, (hipStream_t)stream, true);
 }
 
-/* ---- block-ELL form of the loop state (row-per-lane schedule build; file header of the kernel) ---------------------------
- * Step 1: entries (n_blocks int64 scratch) and ell_base (n_blocks + 1) from the rows' degrees; *max_deg (device int, zeroed
- * here) = largest degree.  The host reads ell_base[n_blocks] (entries to allocate per ELL array) and *max_deg. */
-int tdr_umap_sched_ell_plan(const int64_t* rowptr, int64_t n_rows, int64_t* entries, int64_t* ell_base, int* max_deg, void* stream) {
-    if (!rowptr || !entries || !ell_base || !max_deg || n_rows <= 0) return TDR_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
-    hipError_t e = hipMemsetAsync(max_deg, 0, sizeof(int), st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(umap_ell_width_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, st, rowptr, n_rows, n_blocks, entries, max_deg);
-    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(256), 0, st, (const int64_t*)entries, n_blocks, ell_base);
-    TDR_CHECK_LAUNCH();
-    return TDR_OK;
-}
-
-/* Step 2: loop state in CSR loop order (tdr_umap_sched_layout_f32) -> block-ELL: ell_row (n_blocks * 64: lane -> local row |
- * degree << 8, lanes by descending degree), ell_cols / ell_eps / ell_next (ell_base[n_blocks] entries each; next = eps). */
-int tdr_umap_sched_ell_pack_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, int64_t n_rows, const int64_t* ell_base,
-                                int32_t* ell_row, int32_t* ell_cols, float* ell_eps, float* ell_next, void* stream) {
-    if (!rowptr || !cols || !eps_per || !ell_base || !ell_row || !ell_cols || !ell_eps || !ell_next || n_rows <= 0) return TDR_ERR_BAD_ARG;
-    const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
-    hipLaunchKernelGGL(umap_ell_pack_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowptr, cols, eps_per,
-                       n_rows, n_blocks, ell_base, ell_row, ell_cols, ell_eps, ell_next);
-    TDR_CHECK_LAUNCH();
-    return TDR_OK;
-}
-
-/* block-ELL values (the counters) back to CSR loop order: out (nnz). */
-int tdr_umap_sched_ell_unpack_f32(const int64_t* rowptr, int64_t n_rows, const int64_t* ell_base, const int32_t* ell_row,
-                                  const float* ell_vals, float* out, void* stream) {
-    if (!rowptr || !ell_base || !ell_row || !ell_vals || !out || n_rows <= 0) return TDR_ERR_BAD_ARG;
-    const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
-    hipLaunchKernelGGL(umap_ell_unpack_kernel, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowptr, n_rows,
-                       n_blocks, ell_base, ell_row, ell_vals, out);
-    TDR_CHECK_LAUNCH();
-    return TDR_OK;
-}
-
-/* tdr_umap_sched_build_f32 on the block-ELL state: same row records, same lists (per segment, as sets), same counters.
- * ell_mask: scratch of ell_base[n_blocks] words.  n_slices * n_iters <= 128 (the counters of a row are a column of LDS). */
-int tdr_umap_sched_build_ell_f32(const int64_t* ell_base, const int32_t* ell_row, const int32_t* ell_cols, const float* ell_eps,
-                                 float* ell_next, void* ell_mask, int64_t n_rows, int64_t n_total, int t0, int n_iters, int n_slices,
-                                 const int64_t* blk_base, int32_t* list, void* hdr, int* err, void* stream) {
-    if (!ell_base || !ell_row || !ell_cols || !ell_eps || !ell_next || !ell_mask || !blk_base || !list || !hdr || !err) return TDR_ERR_BAD_ARG;
-    if (n_rows <= 0 || n_total < 2 || n_total >= 0x7fffffffLL || t0 < 0 || n_iters <= 0 || n_iters > SCHED_BMAX || t0 > (1 << 24) - 64) return TDR_ERR_BAD_ARG;
-    if (n_slices != 1 && n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
-    if (n_slices * n_iters > 128 || n_slices > 4) return TDR_ERR_UNSUPPORTED;
-    SchedEllParams P;
-    P.ell_base = ell_base; P.ell_row = ell_row; P.cols = ell_cols; P.eps = ell_eps; P.next = ell_next; P.mask = (uint32_t*)ell_mask;
-    P.n_rows = n_rows;
-    const uint32_t nred = (uint32_t)(n_total - 1);
-    P.slice_step = (nred + (uint32_t)n_slices - 1u) / (uint32_t)n_slices;
-    P.t0 = t0; P.iter_base = nullptr; P.B = n_iters; P.S = n_slices; P.blk_base = blk_base; P.list = list; P.hdr = (uint2*)hdr; P.err = err;
-    return launch_sched_build_ell(P, (hipStream_t)stream, true);
-}
-
 /* One evaluation of UMAP's closed-form gradient (umap.py:236-292) for rows [row0, row0 + n_rows) from the lists of
  * tdr_umap_sched_build_f32: t_local = iteration index inside the window, n_iter = global iteration (hash counter).
  * acc: (n_rows, 2 nc) floats (used when n_slices > 1).  geom: low 4 bits = lane geometry (0 = default; tuning knob);
@@ -1362,14 +1080,6 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
     L->first_iter = d->first_iter; L->check_interval = d->check_interval; L->norm2 = d->norm2; L->snap = d->snap; L->nan_flag = d->nan_flag;
     L->iter_base = (int*)d->scratch; L->gather = (tdr_collective_fn)d->gather; L->gather_ctx = d->gather_ctx; L->geom = d->geom;
     L->graphs[0] = L->graphs[1] = nullptr; L->graph_len[0] = L->graph_len[1] = 0;
-    L->ell_base = d->ell_base; L->ell_row = d->ell_row; L->ell_cols = d->ell_cols; L->ell_eps = d->ell_eps; L->ell_next = d->ell_next;
-    L->ell_mask = (uint32_t*)d->ell_mask;
-    if (L->ell_base && (!L->ell_row || !L->ell_cols || !L->ell_eps || !L->ell_next || !L->ell_mask)) { delete L; return TDR_ERR_BAD_ARG; }
-    if (L->ell_base && (size_t)L->B * L->S * 64 * sizeof(uint32_t) > 32 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_ell_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)L->B * L->S * 64 * sizeof(uint32_t)));
-        if (e != hipSuccess) { delete L; return (int)e; }
-    }
     const size_t lds = (size_t)L->B * L->S * CNT_STRIDE * sizeof(uint32_t);
     if (lds > 32 * 1024) {  // raised here, outside graph capture, for every instance the launcher may pick
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_kernel<1>),

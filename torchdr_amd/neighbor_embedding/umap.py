@@ -46,12 +46,6 @@ SCHED_SLICES = 0
 # together with the row sort above.  The embedding is returned in the caller's order; the negative sampler is keyed by
 # the loop's row numbers, so the random stream differs from an unrelabelled run (same distribution).
 RELABEL = True
-# SCHED_ELL: keep the loop state (columns, periods, counters of every edge) in a block-ELL layout -- 64 rows per block,
-# slot-major, lanes = rows by descending degree -- and build the schedule row-per-lane (tdr_umap_sched_build_ell_f32): the 64
-# lanes of an instruction then hold edges of the same rank of 64 rows, which fire about equally often, and a row's counters
-# and write pointers are private to its lane.  Used when the window's (iteration, slice) table of a row fits an LDS column
-# (slices x window <= 128) and no row has more than 2048 edges; False = the edge-per-lane kernel on the CSR state.
-SCHED_ELL = True
 
 def _opt(name):
     """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
@@ -227,27 +221,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         )
         self.epoch_of_next_sample = self.epochs_per_sample.clone()  # umap.py:232
 
-    # `epoch_of_next_sample` (umap.py:232) in CSR loop order.  With the block-ELL schedule (SCHED_ELL) the live counters are the
-    # ELL array; reading the attribute gathers them back (tdr_umap_sched_ell_unpack_f32), so what a caller sees is always current.
-    @property
-    def epoch_of_next_sample(self):
-        nxt = self.__dict__.get("_next_csr")
-        sc = self.__dict__.get("_sched")
-        ell = sc.get("ell") if isinstance(sc, dict) else None
-        if nxt is not None and ell is not None:
-            _lib.check(_lib.lib().tdr_umap_sched_ell_unpack_f32(_lib.ptr(self._csr_loop.rowptr), self.chunk_size_, _lib.ptr(ell["base"]),
-                                                                _lib.ptr(ell["row"]), _lib.ptr(ell["next"]), _lib.ptr(nxt), _lib.stream_ptr()),
-                       "tdr_umap_sched_ell_unpack_f32")
-        return nxt
-
-    @epoch_of_next_sample.setter
-    def epoch_of_next_sample(self, value):
-        self.__dict__["_next_csr"] = value
-
-    @epoch_of_next_sample.deleter
-    def epoch_of_next_sample(self):
-        self.__dict__.pop("_next_csr", None)
-
     # reference attributes (affinity_matcher.py:276-286) in their padded layout, materialised on request from the CSR
     @property
     def affinity_in_(self):
@@ -282,24 +255,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         _lib.check(L.tdr_umap_sched_plan_f32(_lib.ptr(csr.rowptr), _lib.ptr(self.epochs_per_sample), n_rows, B,
                                              _lib.ptr(scratch), _lib.ptr(blk_base), _lib.stream_ptr()),
                    "tdr_umap_sched_plan_f32")
-        ell = None
-        if _opt("SCHED_ELL") and S * B <= 128 and csr.vals.dtype == torch.float32:
-            ell_entries = torch.empty(n_blocks, dtype=torch.int64, device=dev)
-            ell_base = torch.empty(n_blocks + 1, dtype=torch.int64, device=dev)
-            ell_maxdeg = torch.zeros(1, dtype=torch.int32, device=dev)
-            _lib.check(L.tdr_umap_sched_ell_plan(_lib.ptr(csr.rowptr), n_rows, _lib.ptr(ell_entries), _lib.ptr(ell_base), _lib.ptr(ell_maxdeg),
-                                                 _lib.stream_ptr()), "tdr_umap_sched_ell_plan")
-            cap, n_ell, max_deg = (int(v) for v in torch.stack([blk_base[-1], ell_base[-1], ell_maxdeg[0].to(torch.int64)]).tolist())
-            if max_deg <= 2048 and n_ell > 0:
-                ell = {"base": ell_base, "row": torch.empty(n_blocks * 64, dtype=torch.int32, device=dev),
-                       "cols": torch.empty(n_ell, dtype=torch.int32, device=dev), "eps": torch.empty(n_ell, dtype=torch.float32, device=dev),
-                       "next": torch.empty(n_ell, dtype=torch.float32, device=dev), "mask": torch.empty(n_ell, dtype=torch.int32, device=dev)}
-                # the counters as they stand now (a fresh fit: = the periods; the pack kernel copies eps, then the current values)
-                _lib.check(L.tdr_umap_sched_ell_pack_f32(_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample), n_rows,
-                                                         _lib.ptr(ell_base), _lib.ptr(ell["row"]), _lib.ptr(ell["cols"]), _lib.ptr(ell["eps"]),
-                                                         _lib.ptr(ell["next"]), _lib.stream_ptr()), "tdr_umap_sched_ell_pack_f32")
-        else:
-            cap = int(blk_base[-1].item())
+        cap = int(blk_base[-1].item())
         # the joint launch relies on workgroups going round-robin over EIGHT XCDs that each cache one slice: only on the
         # whole device (256 CUs); on a partitioned one (e.g. one XCD per device) the slices go one launch at a time
         geom = int(_opt("SCHED_GEOM"))
@@ -313,7 +269,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             "geom": geom,
             # partial sums between the slice passes; the joint launch (geom & 16) keeps one plane per slice
             "acc": torch.empty(((S if geom & 16 else 1) * n_rows, 2 * nc), dtype=torch.float32, device=dev) if S > 1 else None,
-            "ell": ell,
         }
         return self._sched
 
@@ -326,23 +281,13 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             if PROFILE is not None:
                 eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 eb0.record()
-            ell = sc["ell"]
-            if ell is not None:
-                _lib.check(
-                    L.tdr_umap_sched_build_ell_f32(_lib.ptr(ell["base"]), _lib.ptr(ell["row"]), _lib.ptr(ell["cols"]), _lib.ptr(ell["eps"]),
-                                                   _lib.ptr(ell["next"]), _lib.ptr(ell["mask"]), self.chunk_size_, self.n_samples_in_, t, n,
-                                                   sc["S"], _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]),
-                                                   _lib.ptr(sc["err"]), _lib.stream_ptr()),
-                    "tdr_umap_sched_build_ell_f32",
-                )
-            else:
-                _lib.check(
-                    L.tdr_umap_sched_build_f32(_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
-                                               _lib.ptr(self._next_csr), self.chunk_size_, self.n_samples_in_,
-                                               t, n, sc["S"], _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]),
-                                               _lib.ptr(sc["hdr"]), _lib.ptr(sc["err"]), _lib.stream_ptr()),
-                    "tdr_umap_sched_build_f32",
-                )
+            _lib.check(
+                L.tdr_umap_sched_build_f32(_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
+                                           _lib.ptr(self.epoch_of_next_sample), self.chunk_size_, self.n_samples_in_,
+                                           t, n, sc["S"], _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]),
+                                           _lib.ptr(sc["hdr"]), _lib.ptr(sc["err"]), _lib.stream_ptr()),
+                "tdr_umap_sched_build_f32",
+            )
             if PROFILE is not None:
                 eb1.record()
                 PROFILE.append(("build", eb0, eb1, n))
@@ -441,11 +386,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         d = _lib.UmapLoopDesc()
         d.Z, d.nc, d.n_total, d.row0, d.n_rows = _lib.ptr(self.embedding_), nc, self.n_samples_in_, self.chunk_start_, self.chunk_size_
         d.rowptr, d.cols, d.eps_per, d.next = (_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
-                                               _lib.ptr(self._next_csr))
-        if sc["ell"] is not None:
-            ell = sc["ell"]
-            d.ell_base, d.ell_row, d.ell_cols, d.ell_eps, d.ell_next, d.ell_mask = (
-                _lib.ptr(ell["base"]), _lib.ptr(ell["row"]), _lib.ptr(ell["cols"]), _lib.ptr(ell["eps"]), _lib.ptr(ell["next"]), _lib.ptr(ell["mask"]))
+                                               _lib.ptr(self.epoch_of_next_sample))
         d.blk_base, d.list, d.hdr, d.err = _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), _lib.ptr(sc["err"])
         d.acc, d.grad, d.mom_buf = _lib.ptr(sc["acc"]), _lib.ptr(self._grad_buf), _lib.ptr(keep["mom"])
         d.a, d.b, d.neg_rate, d.n_negatives, d.seed = float(self._a), float(self._b), int(self.negative_sample_rate), int(self.n_negatives), self._neg_seed
@@ -570,7 +511,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
 
     def clear_memory(self):
         super().clear_memory()
-        self.__dict__.pop("_next_csr", None)    # (the attribute `epoch_of_next_sample` is a property over it)
-        for attr in ("_csr", "_csr_loop", "epochs_per_sample", "_exclusion", "_grad_buf", "_grad_ws", "_sched", "_loop_cols"):
+        for attr in ("_csr", "_csr_loop", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf", "_grad_ws", "_sched", "_loop_cols"):
             if hasattr(self, attr):
                 delattr(self, attr)
