@@ -382,12 +382,25 @@ int tdr_sinkhorn_lse_f32(const float* packed, int64_t n, int d, const float* f, 
                          float diag_add, float* lse, void* stream);
 /* gradient of neighbor_embedding/tsnekhorn.py:210-230 w.r.t. the embedding (duals detached) */
 int tdr_khorn_grad_f32(const float* packed, int64_t n, int d, const float* side, float log_n, float* grad, void* stream);
-/* the same for an (n, nc) embedding, nc = 2 or 3; side: (n, 3 + nc) row-major (mu, e, z_0 .. z_{nc-1}, exp(dual)) */
+/* the same for an (n, nc) embedding, nc in {2, 3, 4, 8, 16, 32} (other widths: pad z with zero columns up to the next one);
+ * side: (n, 3 + nc) row-major (mu, e, z_0 .. z_{nc-1}, exp(dual)) */
 int tdr_khorn_grad_nc_f32(const float* packed, int64_t n, int d, const float* side, int nc, float log_n, float* grad,
                           void* stream);
-/* affinity/entropic.py:733-740: one symmetric log-domain Sinkhorn update, student kernel on the embedding */
+/* TSNEkhorn(unrolling=True), neighbor_embedding/tsnekhorn.py:134,224-227: gradient of CE(P, log Q) with autograd THROUGH the
+ * <= 5 Sinkhorn updates (affinity/entropic.py:729-736 with with_grad=True), in closed form:
+ *   4 sum_j [P_ij + w_ij sum_k (a^k_i b^k_j + a^k_j b^k_i)] w_ij (z_i - z_j),  w = 1/(1+d_ij);
+ * side: (n, 2 + nc + 10) row-major (mu, e, z_0 .. z_{nc-1}, a^1..a^5, b^1..b^5) -- a^k = adjoint of update k / (4 s^k),
+ * b^k = exp(f^{k-1} - max), zero for updates that did not run. */
+int tdr_khorn_grad_unrolled_f32(const float* packed, int64_t n, int d, const float* side, int nc, float log_n, float* grad,
+                                void* stream);
+/* affinity/entropic.py:733-740: one symmetric log-domain Sinkhorn update, student kernel on the embedding
+ * (nc in {2, 3, 4, 8, 16, 32}) */
 int tdr_sinkhorn_pass_f32(const float* Z, int nc, const float* f, const float* Ef, float fmax, int64_t n, int zero_diag,
                           float diag_add, float* f_new, float* resid2, void* stream);
+/* out_j = sum_i v_i / (1 + |z_i - z_j|^2): the mat-vec of the adjoint of that update (what autograd runs backwards through
+ * affinity/entropic.py:735 when with_grad=True); the diagonal term is weighted 1 / (1 + diag_add) when zero_diag */
+int tdr_student_matvec_f32(const float* Z, int nc, const float* v, int64_t n, int zero_diag, float diag_add, float* out,
+                           void* stream);
 
 /* ---- float64 embedding loop (csrc/tdr_embed_f64.hip) ------------------------------------------------------------------
  * The reference computes in the dtype of its input and runs every neighbour-embedding method in float32 and float64

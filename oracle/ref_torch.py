@@ -446,6 +446,61 @@ def tsnekhorn_grad(Z, log_P, dual, log_K):
     return 4 * (M.sum(1, keepdim=True) * Z - M @ Z)
 
 
+def tsnekhorn_unrolled_grad(Z, log_P, init_dual=None, max_iter=5, tol=1e-5, zero_diag=True):
+    """TSNEkhorn(unrolling=True) (neighbor_embedding/tsnekhorn.py:134, 183, 224-227): loss = CE(P, log Q) alone, log Q =
+    f_i + f_j + log K - log n with f the result of the <= max_iter Sinkhorn updates of affinity/entropic.py:733-743 started
+    from the DETACHED warm start and run under autograd (with_grad=True).  Restated with torch autograd on dense matrices,
+    exactly as the reference evaluates it.  Returns (gradient w.r.t. Z, dual, n_iter)."""
+    n = Z.shape[0]
+    Zg = Z.detach().clone().requires_grad_(True)
+    D = ((Zg[:, None, :] - Zg[None, :, :]) ** 2).sum(-1)
+    if zero_diag:
+        D = D + torch.diag(torch.full((n,), 1e12, dtype=Z.dtype))
+    log_K = -(1 + D).log()
+    dual = torch.zeros(n, dtype=Z.dtype) if init_dual is None else init_dual.detach().clone()
+    k = 0
+    for k in range(max_iter):
+        red = -(log_K + dual[:, None]).logsumexp(0)
+        dual = 0.5 * (dual + red)
+        if torch.norm(dual - red) < tol:
+            break
+    log_Q = dual[:, None] + dual[None, :] + log_K - math.log(n)
+    loss = -(log_P.exp() * log_Q).sum()
+    (g,) = torch.autograd.grad(loss, Zg)
+    return g, dual.detach(), k
+
+
+def tsnekhorn_unrolled_grad_closed(Z, log_P, init_dual=None, max_iter=5, tol=1e-5, zero_diag=True):
+    """The same gradient without autograd -- the formulation the HIP path evaluates (csrc/tdr_dense.hip, KhornForceUnrolled):
+    adjoints g^K = -(rowsum P + colsum P), g^{k-1} = (g^k - S^k^T g^k) / 2 with S^k the softmax update k reduces, and
+    grad_i = sum_j [4 P_ij + w_ij sum_k (a^k_i b^k_j + a^k_j b^k_i)] w_ij (z_i - z_j), a^k = g^k / s^k, b^k = exp(f^{k-1} - max)."""
+    n = Z.shape[0]
+    D = ((Z[:, None, :] - Z[None, :, :]) ** 2).sum(-1)
+    if zero_diag:
+        D = D + torch.diag(torch.full((n,), 1e12, dtype=Z.dtype))
+    W = 1 / (1 + D)
+    f = torch.zeros(n, dtype=Z.dtype) if init_dual is None else init_dual.clone()
+    rec = []
+    for _ in range(max_iter):
+        fmax = f.max()
+        Ef = (f - fmax).exp()
+        s = W @ Ef
+        red = -(fmax + s.log())
+        f = 0.5 * (f + red)
+        rec.append((Ef, s))
+        if torch.norm(f - red) < tol:
+            break
+    P = log_P.exp()
+    g = -(P.sum(1) + P.sum(0))
+    bil = torch.zeros_like(W)
+    for Ef, s in reversed(rec):
+        a = g / s
+        bil = bil + a[:, None] * Ef[None, :] + Ef[:, None] * a[None, :]
+        g = 0.5 * (g - Ef * (W @ a))
+    coef = (4 * P + W * bil) * W
+    return coef.sum(1, keepdim=True) * Z - coef @ Z, f
+
+
 # --------------------------------------------------------------------------------------------
 # COSNE -- neighbor_embedding/cosne.py:162-193 (loss), utils/manifold.py:207-330 (Poincare ball),
 # utils/radam.py:96-167 (Riemannian Adam), affinity_matcher.py:552-565 (hyperbolic init).  float64 throughout.

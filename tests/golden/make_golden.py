@@ -689,6 +689,40 @@ def tsnekhorn3_fixture():
     save("tsnekhorn3", **rec)
 
 
+def tsnekhorn_unrolled_fixture():
+    """TSNEkhorn(unrolling=True) (tsnekhorn.py:134, 224-227: autograd through the 5 Sinkhorn updates) and TSNEkhorn with
+    n_components = 4: two optimisation steps of the reference each, on the data of the `tsnekhorn` fixture -- embedding
+    before, Sinkhorn dual, autograd gradient, embedding after; plus the reference's log P for the oracle check."""
+    from torchdr import TSNEkhorn
+
+    X = gmm(256, 16, 2.0, seed=61)
+    out = {"X": X}
+    for name, kw in (("u2", dict(unrolling=True)), ("u3", dict(unrolling=True, n_components=3)), ("n4", dict(n_components=4)),
+                     ("u5", dict(unrolling=True, n_components=5))):
+        rec = {}
+
+        class Probe(TSNEkhorn):
+            def _training_step(self):
+                t = int(self.n_iter_)
+                if t < 2:
+                    rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                loss = super()._training_step()
+                if t < 2:
+                    rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                    rec[f"dual_{t}"] = self.dual_sinkhorn_.detach().clone()
+                    rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+                if t == 0 and name == "u2":
+                    out["log_P"] = self.affinity_in_.detach().log().clone()
+                return loss
+
+        torch.manual_seed(3)
+        Probe(perplexity=10, max_iter=3, max_iter_affinity_in=30, init="normal", init_scaling=1.0, min_grad_norm=1e-12, lr=1.0,
+              optimizer="SGD", optimizer_kwargs=None, backend=None, random_state=3, **kw).fit_transform(X)
+        for k_, v in rec.items():
+            out[f"{name}_{k_}"] = v
+    save("tsnekhorn_unrolled", **out)
+
+
 def signatures_fixture():
     """Constructor / function signatures of the in-scope public surface of the reference: parameter names in order and the
     repr of every default (tests/golden/signatures.json) -- what `from torchdr import X; X(**kwargs)` code relies on."""
@@ -832,7 +866,7 @@ if __name__ == "__main__":
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
                cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture,
-               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, signatures=signatures_fixture, manifold=manifold_fixture, radam=radam_fixture)
+               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, tsnekhorn_unrolled=tsnekhorn_unrolled_fixture, signatures=signatures_fixture, manifold=manifold_fixture, radam=radam_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

@@ -313,6 +313,33 @@ def test_tsnekhorn_oracle():
         assert torch.allclose(grad, ref, rtol=1e-3, atol=1e-5 * float(ref.abs().max()))
 
 
+def test_tsnekhorn_unrolled_oracle():
+    """TSNEkhorn(unrolling=True): the oracle's autograd restatement and its closed form (the formulation the HIP path
+    evaluates) against the reference's own autograd gradients, 2 / 3 / 5 components, two warm-started steps each."""
+    g = load("tsnekhorn_unrolled")
+    log_P = g["log_P"]
+    for name in ("u2", "u3", "u5"):
+        init = None
+        for t in range(2):
+            Z, ref = g[f"{name}_Z_{t}"], g[f"{name}_grad_{t}"]
+            grad, dual, _ = R.tsnekhorn_unrolled_grad(Z, log_P, init, 5, 1e-5)
+            assert torch.allclose(dual, g[f"{name}_dual_{t}"], rtol=1e-5, atol=1e-6)
+            assert torch.allclose(grad, ref, rtol=1e-4, atol=1e-6 * float(ref.abs().max()))
+            gc, dc = R.tsnekhorn_unrolled_grad_closed(Z.double(), log_P.double(), None if init is None else init.double(), 5, 1e-5)
+            assert torch.allclose(dc.float(), dual, rtol=1e-5, atol=1e-6)
+            assert torch.allclose(gc.float(), ref, rtol=1e-4, atol=2e-6 * float(ref.abs().max()))
+            assert torch.allclose(Z - grad, g[f"{name}_Zafter_{t}"], rtol=1e-5, atol=1e-6)   # SGD, lr = 1
+            init = dual
+    # four components, duals detached (the closed form of tsnekhorn.py:210-230 at a width without an exact instance)
+    init = None
+    for t in range(2):
+        Z = g[f"n4_Z_{t}"]
+        dual, log_K, _ = R.sinkhorn_student(Z, init, 5, 1e-5)
+        init = dual
+        ref = g[f"n4_grad_{t}"]
+        assert torch.allclose(R.tsnekhorn_grad(Z, log_P, dual, log_K), ref, rtol=1e-3, atol=1e-5 * float(ref.abs().max()))
+
+
 def test_numeric_helpers_cpu():
     """API-parity helpers (utils/utils.py, utils/root_search.py): the reference's own unit checks
     (test_utils.py:45-82: roots of x^2 - 1)."""

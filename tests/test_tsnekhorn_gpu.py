@@ -61,8 +61,11 @@ def test_sinkhorn_student_vs_reference():
     sk2 = SinkhornAffinity(base_kernel="student", max_iter=1000, tol=1e-5)
     Q = sk2(g["sk_Z"].cuda())
     assert torch.allclose(Q.sum(1).cpu(), torch.full((256,), 1 / 256), rtol=1e-3)
-    with pytest.raises(NotImplementedError):   # autograd through the iterations: no autograd graph on the HIP path
-        SinkhornAffinity(base_kernel="student", with_grad=True)(g["sk_Z"].cuda())
+    # with_grad=True: same numbers; an input that requires grad is refused (no autograd graph on the HIP path)
+    skg = SinkhornAffinity(base_kernel="student", max_iter=5, with_grad=True)
+    assert torch.equal(skg(g["sk_Z"].cuda(), log=True, init_dual=g["sk_init"].cuda()), logQ)
+    with pytest.raises(NotImplementedError):
+        skg(g["sk_Z"].cuda().requires_grad_(True))
     # the Gaussian base kernel (class default) runs the matrix-free pair scan: tests/test_matcher_modes_gpu.py
 
 
@@ -92,6 +95,131 @@ def test_tsnekhorn_gradient_and_steps_vs_reference_autograd():
         assert torch.allclose(grad.cpu(), ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()))
 
 
+def _khorn_side(X):
+    import torchdr_amd
+
+    sea = torchdr_amd.SymmetricEntropicAffinity(perplexity=10, lr=1e-1, max_iter=30, tol=1e-3, zero_diag=False)
+    packed = sea.fit_duals(X)
+    mu, e = sea.dual_side()
+    return packed, mu, e
+
+
+@pytest.mark.parametrize("name", ["u2", "u3", "u5"])
+def test_tsnekhorn_unrolled_gradient_vs_reference_autograd(name):
+    """TSNEkhorn(unrolling=True) (tsnekhorn.py:134, 224-227): the reference back-propagates through the 5 Sinkhorn updates;
+    here the recorded passes + 5 adjoint mat-vecs + the bilinear force kernel, against the reference's autograd gradient of
+    two warm-started steps (2 / 3 components exact instances, 5 zero-padded to 8)."""
+    from torchdr_amd import _lib
+    from torchdr_amd.affinity.entropic import pad_embedding, sea_rowstats, sinkhorn_student_adjoint, sinkhorn_student_dual
+
+    g = load("tsnekhorn_unrolled")
+    X = g["X"].cuda()
+    n = X.shape[0]
+    packed, mu, e = _khorn_side(X)
+    S, _ = sea_rowstats(packed, mu, e, False)
+    assert torch.allclose((S / n).cpu(), g["log_P"].exp().sum(1), rtol=2e-4)
+    init = None
+    for t in range(2):
+        Z = g[f"{name}_Z_{t}"].cuda()
+        nc = Z.shape[1]
+        Zp = pad_embedding(Z)
+        rec = []
+        dual, k = sinkhorn_student_dual(Zp, init, 5, 1e-5, True, record=rec)
+        init = dual
+        assert k == 4 and len(rec) == 5
+        assert torch.allclose(dual.cpu(), g[f"{name}_dual_{t}"], rtol=1e-5, atol=2e-6)
+        A, B = sinkhorn_student_adjoint(Zp, rec, -(2.0 / n) * S, True)
+        side = torch.cat([mu[:, None], e[:, None], Zp, 0.25 * A, B], dim=1).contiguous()
+        grad = torch.empty((n, Zp.shape[1]), device="cuda")
+        _lib.check(_lib.lib().tdr_khorn_grad_unrolled_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), Zp.shape[1],
+                                                          float(np.log(n)), _lib.ptr(grad), _lib.stream_ptr()), "khorn unrolled")
+        ref = g[f"{name}_grad_{t}"]
+        assert torch.allclose(grad[:, :nc].cpu(), ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()))
+        assert float(grad[:, nc:].abs().max()) == 0.0 if Zp.shape[1] > nc else True
+
+
+def test_tsnekhorn_unrolled_matches_the_oracle_at_3000_points():
+    """Many tiles / several workgroups: the HIP unrolled gradient against the oracle's dense float64 closed form."""
+    import oracle.ref_torch as R
+    import torchdr_amd
+    from torchdr_amd import _lib
+    from torchdr_amd.affinity.entropic import sea_rowstats, sinkhorn_student_adjoint, sinkhorn_student_dual
+
+    n = 3000
+    X = gmm(n, 32, 3.0, seed=12)
+    sea = torchdr_amd.SymmetricEntropicAffinity(perplexity=20, lr=1e-1, max_iter=15, tol=1e-3, zero_diag=False)
+    packed = sea.fit_duals(X.cuda())
+    mu, e = sea.dual_side()
+    gen = torch.Generator().manual_seed(5)
+    Z = torch.randn(n, 2, generator=gen) * 4
+    f0 = torch.randn(n, generator=gen) * 0.2
+    import oracle
+    _, _, C = oracle.knn(X, 0, "sqeuclidean", False, want_full=True)
+    mu64, e64 = mu.cpu().double(), e.cpu().double()
+    log_P = (mu64[:, None] + mu64[None, :] - 2 * C.double()) / (e64[:, None] + e64[None, :]) - np.log(n)
+    ref, f_ref = R.tsnekhorn_unrolled_grad_closed(Z.double(), log_P, f0.double(), 5, 1e-5)
+    rec = []
+    dual, _ = sinkhorn_student_dual(Z.cuda(), f0.cuda(), 5, 1e-5, True, record=rec)
+    assert torch.allclose(dual.cpu().double(), f_ref, rtol=1e-5, atol=1e-5)
+    S, _ = sea_rowstats(packed, mu, e, False)
+    A, B = sinkhorn_student_adjoint(Z.cuda(), rec, -(2.0 / n) * S, True)
+    side = torch.cat([mu[:, None], e[:, None], Z.cuda(), 0.25 * A, B], dim=1).contiguous()
+    grad = torch.empty((n, 2), device="cuda")
+    _lib.check(_lib.lib().tdr_khorn_grad_unrolled_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), 2, float(np.log(n)),
+                                                      _lib.ptr(grad), _lib.stream_ptr()), "khorn unrolled")
+    assert torch.allclose(grad.cpu().double(), ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()))
+
+
+def test_tsnekhorn_four_components_vs_reference():
+    """n_components = 4 (no exact instance below 32 other than 2 / 3: the register instance of width 4), duals detached."""
+    from torchdr_amd import _lib
+    from torchdr_amd.affinity.entropic import sinkhorn_student_dual
+
+    g = load("tsnekhorn_unrolled")
+    X = g["X"].cuda()
+    n = X.shape[0]
+    packed, mu, e = _khorn_side(X)
+    init = None
+    for t in range(2):
+        Z = g[f"n4_Z_{t}"].cuda().contiguous()
+        dual, _ = sinkhorn_student_dual(Z, init, 5, 1e-5, True)
+        init = dual
+        assert torch.allclose(dual.cpu(), g[f"n4_dual_{t}"], rtol=1e-5, atol=2e-6)
+        side = torch.cat([mu[:, None], e[:, None], Z, dual.exp()[:, None]], dim=1).contiguous()
+        grad = torch.empty((n, 4), device="cuda")
+        _lib.check(_lib.lib().tdr_khorn_grad_nc_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), 4, float(np.log(n)),
+                                                    _lib.ptr(grad), _lib.stream_ptr()), "khorn")
+        ref = g[f"n4_grad_{t}"]
+        assert torch.allclose(grad.cpu(), ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("kw,name", [(dict(unrolling=True), "u2"), (dict(unrolling=True, n_components=5), "u5"), (dict(n_components=4), "n4")])
+def test_tsnekhorn_estimator_steps_vs_reference(kw, name):
+    """The estimator itself, two SGD steps from the reference's starting embedding (unrolled / padded widths)."""
+    import torchdr_amd
+
+    g = load("tsnekhorn_unrolled")
+    rec = {}
+
+    class Probe(torchdr_amd.TSNEkhorn):
+        def _init_embedding(self, X):
+            super()._init_embedding(X)
+            self.embedding_.data.copy_(g[f"{name}_Z_0"].to(self.embedding_.device))
+
+        def _training_step(self):
+            t = int(self.n_iter_)
+            out = super()._training_step()
+            if t < 2:
+                rec[t] = self.embedding_.detach().clone()
+            return out
+
+    Probe(perplexity=10, max_iter=3, max_iter_affinity_in=30, init="normal", init_scaling=1.0, min_grad_norm=1e-12, lr=1.0,
+          optimizer="SGD", optimizer_kwargs=None, random_state=3, **kw).fit_transform(g["X"].cuda())
+    for t in range(2):
+        ref = g[f"{name}_Zafter_{t}"]
+        assert torch.allclose(rec[t].cpu(), ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max())), t
+
+
 def test_tsnekhorn_estimator():
     import torchdr_amd
 
@@ -107,6 +235,12 @@ def test_tsnekhorn_estimator():
     assert int(m2.n_iter_) == 0
     with pytest.raises(ValueError, match="does not support distributed"):
         torchdr_amd.TSNEkhorn(distributed=True)
+    with pytest.raises(NotImplementedError, match="fails at its first loss evaluation"):   # so does the reference (RuntimeError)
+        torchdr_amd.TSNEkhorn(symmetric_affinity=False)
+    Zu = torchdr_amd.TSNEkhorn(perplexity=10, max_iter=20, max_iter_affinity_in=20, init="normal", init_scaling=1.0, lr=1.0,
+                               optimizer="SGD", optimizer_kwargs=None, min_grad_norm=1e-12, random_state=0, unrolling=True,
+                               n_components=1).fit_transform(X.cuda())
+    assert Zu.shape == (1500, 1) and torch.isfinite(Zu).all()
 
 
 def test_sea_lbfgs_objective_and_run():
@@ -186,4 +320,4 @@ def test_tsnekhorn_three_components_vs_reference():
         atol = 2e-3 * float(g[f"grad_{t}"].abs().max()) + 1e-5 * float(ref.abs().max())
         assert torch.allclose(seen[t], ref, rtol=1e-4, atol=atol), t
     with pytest.raises(NotImplementedError):
-        torchdr_amd.TSNEkhorn(n_components=4)
+        torchdr_amd.TSNEkhorn(n_components=33)

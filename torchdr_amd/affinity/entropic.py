@@ -346,11 +346,29 @@ class SymmetricEntropicAffinity(LogAffinity):
         return log_P
 
 
-def sinkhorn_student_dual(Z: torch.Tensor, init_dual, max_iter: int, tol: float, zero_diag: bool = True):
-    """Symmetric Sinkhorn fixed point on the embedding (student kernel, eps = 1): reference
-    ``entropic.py:728-748``.  Returns (dual, n_iter)."""
-    _lib.require_gpu(Z, "Z")
+_EMBED_WIDTHS = (2, 3, 4, 8, 16, 32)    # register instances of the embedding-side kernels (tdr_dense.hip)
+
+
+def pad_embedding(Z: torch.Tensor):
+    """(n, nc) -> contiguous fp32 (n, w), w the next kernel width, zero columns added (they change no distance)."""
     Zc = Z.detach().contiguous().float()
+    nc = Zc.shape[1]
+    if nc > _EMBED_WIDTHS[-1]:
+        raise NotImplementedError(f"[torchdr_amd] embedding widths above {_EMBED_WIDTHS[-1]} are not part of the accelerated path.")
+    w = next(x for x in _EMBED_WIDTHS if x >= nc)
+    if w == nc:
+        return Zc
+    Zp = torch.zeros((Zc.shape[0], w), dtype=torch.float32, device=Zc.device)
+    Zp[:, :nc] = Zc
+    return Zp
+
+
+def sinkhorn_student_dual(Z: torch.Tensor, init_dual, max_iter: int, tol: float, zero_diag: bool = True, record=None):
+    """Symmetric Sinkhorn fixed point on the embedding (student kernel, eps = 1): reference
+    ``entropic.py:728-748``.  Returns (dual, n_iter).  ``record``: a list that receives, per update that ran,
+    (Ef, 1 / s) with Ef = exp(f_before - max) and s_i = sum_j Ef_j / (1 + d_ij) -- what the adjoint of the update needs."""
+    _lib.require_gpu(Z, "Z")
+    Zc = pad_embedding(Z)
     n, nc = Zc.shape
     f = torch.zeros(n, dtype=torch.float32, device=Z.device) if init_dual is None else init_dual.clone().float()
     f_new = torch.empty_like(f)
@@ -366,10 +384,36 @@ def sinkhorn_student_dual(Z: torch.Tensor, init_dual, max_iter: int, tol: float,
                                     1e12, _lib.ptr(f_new), _lib.ptr(resid2), _lib.stream_ptr()),
             "tdr_sinkhorn_pass_f32",
         )
-        f, f_new = f_new, f
+        if record is not None:      # f_new = (f - fmax - log s) / 2  =>  1 / s = exp(2 f_new - f + fmax)
+            record.append((Ef, (2.0 * f_new - f + fmax).exp()))
+            f, f_new = f_new, torch.empty_like(f)
+        else:
+            f, f_new = f_new, f
         if float(resid2.sqrt()) < tol:
             break
     return f, k
+
+
+def sinkhorn_student_adjoint(Z: torch.Tensor, record, g_final: torch.Tensor, zero_diag: bool = True, n_terms: int = 5):
+    """Reverse sweep through the recorded updates f^k = (f^{k-1} - LSE_j(log K_ij + f^{k-1}_j)) / 2 (reference
+    ``entropic.py:733-736`` under ``with_grad=True``): with S^k_ij = Ef^k_j w_ij / s^k_i the softmax update k reduces,
+    the adjoints are g^{k-1} = (g^k - S^k^T g^k) / 2 -- one Student-kernel mat-vec each (``tdr_student_matvec_f32``) -- and
+    the gradient w.r.t. log K_ij is -(1/2) sum_k g^k_i S^k_ij.  Returns (A, B), both (n, n_terms): A[:, k] = g^k / s^k,
+    B[:, k] = Ef^k (zero columns for updates that did not run), so that sum_k g^k_i S^k_ij = w_ij sum_k A_ik B_jk."""
+    Zc = pad_embedding(Z)
+    n, nc = Zc.shape
+    A = torch.zeros((n, n_terms), dtype=torch.float32, device=Z.device)
+    B = torch.zeros((n, n_terms), dtype=torch.float32, device=Z.device)
+    g = g_final.float().contiguous()
+    t = torch.empty_like(g)
+    L = _lib.lib()
+    for col, (Ef, inv_s) in enumerate(reversed(record)):
+        a = (g * inv_s).contiguous()
+        A[:, col], B[:, col] = a, Ef
+        _lib.check(L.tdr_student_matvec_f32(_lib.ptr(Zc), nc, _lib.ptr(a), n, 1 if zero_diag else 0, 1e12, _lib.ptr(t),
+                                            _lib.stream_ptr()), "tdr_student_matvec_f32")
+        g = 0.5 * (g - Ef * t)
+    return A, B
 
 
 def sinkhorn_input_dual(X: torch.Tensor, eps: float, init_dual, max_iter: int, tol: float, zero_diag: bool, student: bool):
@@ -399,8 +443,10 @@ class SinkhornAffinity(LogAffinity):
     :math:`P = \exp(f_i + f_j - C_{ij}/\varepsilon)/N` (``base_kernel="gaussian"``, the class default) or with
     :math:`\log(1 + C)` in place of :math:`C` (``"student"``).  On a 2-D / 3-D input with the student kernel and
     ``eps = 1`` (what TSNEkhorn evaluates on the embedding every step) the update is the LDS-tiled all-pairs kernel;
-    any other input runs the matrix-free MFMA pair scan.  ``with_grad=True`` (autograd through the iterations) is not
-    available: there is no autograd graph on the HIP path."""
+    any other input runs the matrix-free MFMA pair scan.  ``with_grad=True``: the duals and the returned values are the
+    same numbers; there is no autograd graph on the HIP path, so an input that requires grad is refused here --
+    ``TSNEkhorn(unrolling=True)``, the reference's one user of the flag, differentiates the updates in closed form
+    (``sinkhorn_student_adjoint``)."""
 
     def __init__(self, eps: float = 1.0, tol: float = 1e-5, max_iter: int = 1000, base_kernel: str = "gaussian",
                  metric: str = "sqeuclidean", zero_diag: bool = True, device: str = "auto", backend=None,
@@ -415,13 +461,14 @@ class SinkhornAffinity(LogAffinity):
         self.with_grad = with_grad
 
     def fit_dual(self, X: torch.Tensor, init_dual=None):
-        if self.with_grad:
-            raise NotImplementedError("[torchdr_amd] SinkhornAffinity(with_grad=True): the HIP path has no autograd graph.")
+        if self.with_grad and X.requires_grad:
+            raise NotImplementedError("[torchdr_amd] SinkhornAffinity(with_grad=True) on an input that requires grad: the HIP "
+                                      "path has no autograd graph (TSNEkhorn(unrolling=True) uses the closed-form adjoint).")
         if self.base_kernel not in ("gaussian", "student"):
             raise ValueError(f"[TorchDR] ERROR : base_kernel {self.base_kernel} not supported in SinkhornAffinity.")
         if self.metric != "sqeuclidean":
             raise NotImplementedError("[torchdr_amd] SinkhornAffinity supports metric='sqeuclidean'.")
-        if self.base_kernel == "student" and self.eps == 1.0 and X.shape[1] in (2, 3):
+        if self.base_kernel == "student" and self.eps == 1.0 and X.shape[1] <= 3:
             dual, k = sinkhorn_student_dual(X, init_dual, self.max_iter, self.tol, self.zero_diag)
         else:
             _, dual, k = sinkhorn_input_dual(X, self.eps, init_dual, self.max_iter, self.tol, self.zero_diag,

@@ -92,7 +92,7 @@ struct SinkLse {
 // TSNEkhorn force: g_i = 4 * sum_j (P_ij - Q_ij) w_ij (z_i - z_j), w = 1/(1+|z_i-z_j|^2),
 //   P_ij = exp((mu_i+mu_j-2C_ij)/(e_i+e_j) - log N),  Q_ij = E_i E_j w_ij / N  with E = exp(dual)
 //   (the diagonal term vanishes with z_i - z_i).  side = (mu, e, z[NC], E); out0 = grad (n, NC).
-//   (the side block of a tile is staged by one load per thread: 32 * SIDE <= 256, so NC <= 5)
+//   Instances for NC = 2, 3 and the zero-padded widths 4 / 8 / 16 / 32 (the caller pads z; padded components add nothing).
 template <int NC>
 struct KhornForce {
     static constexpr int SIDE = 3 + NC;
@@ -124,6 +124,55 @@ struct KhornForce {
         for (int k = 0; k < NC; ++k) g[k] += o.g[k];
     }
     __device__ __forceinline__ void shfl_from(const KhornForce& x, int src) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) g[k] = __shfl(x.g[k], src, 64);
+    }
+    __device__ __forceinline__ void store(int64_t row, const PairScanParams& P) const {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) P.out0[row * NC + k] = 4.0f * g[k];
+    }
+};
+
+// TSNEkhorn force with `unrolling=True` (tsnekhorn.py:134, 224-227: loss = CE(P, log Q) alone, autograd THROUGH the K <= 5
+// symmetric Sinkhorn updates of entropic.py:733-736 that produce the dual from the detached warm start).  In closed form:
+// with w = 1/(1+d), Ef^k = exp(f^{k-1} - max f^{k-1}), s^k_i = sum_j Ef^k_j w_ij (what update k reduces),
+// S^k_ij = w_ij Ef^k_j / s^k_i its softmax, and the adjoints  g^K = -(rowsum P + colsum P),  g^{k-1} = (g^k - S^k^T g^k) / 2,
+//   grad_i = sum_j [ 4 P_ij + w_ij sum_k (g^k_i S^k_ij + g^k_j S^k_ji) / w_ij ] w_ij (z_i - z_j)
+//          = 4 sum_j [ P_ij + w_ij sum_k (a^k_i b^k_j + a^k_j b^k_i) ] w_ij (z_i - z_j),   a^k = g^k / (4 s^k),  b^k = Ef^k
+// -- the Q term of KhornForce replaced by a rank-2K bilinear form of per-point vectors (the caller runs the K forward
+// updates and the K adjoint mat-vecs, tdr_student_matvec_f32, and pads a / b with zeros when the updates stopped early).
+// side = (mu, e, z[NC], a[5], b[5]).
+template <int NC>
+struct KhornForceUnrolled {
+    static constexpr int KU = 5;
+    static constexpr int SIDE = 2 + NC + 2 * KU;
+    float mu_i, e_i, z[NC], a[KU], b[KU], g[NC];
+    __device__ __forceinline__ void init(const float* qs) {
+        mu_i = qs[0]; e_i = qs[1];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { z[c] = qs[2 + c]; g[c] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < KU; ++k) { a[k] = qs[2 + NC + k]; b[k] = qs[2 + NC + KU + k]; }
+    }
+    __device__ __forceinline__ void add(float c, const float* sj, const PairScanParams& P) {
+        const float lp = (mu_i + sj[0] - 2.0f * c) * __builtin_amdgcn_rcpf(e_i + sj[1]) - P.c0;  // c0 = log N
+        const float p = __expf(lp);
+        float df[NC], d2 = 1.0f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { df[k] = z[k] - sj[2 + k]; d2 = fmaf(df[k], df[k], d2); }
+        const float w = __builtin_amdgcn_rcpf(d2);
+        float bil = 0.f;
+#pragma unroll
+        for (int k = 0; k < KU; ++k) bil = fmaf(a[k], sj[2 + NC + KU + k], fmaf(sj[2 + NC + k], b[k], bil));
+        const float coef = fmaf(w, bil, p) * w;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) g[k] = fmaf(coef, df[k], g[k]);
+    }
+    __device__ __forceinline__ void merge(const KhornForceUnrolled& o) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) g[k] += o.g[k];
+    }
+    __device__ __forceinline__ void shfl_from(const KhornForceUnrolled& x, int src) {
 #pragma unroll
         for (int k = 0; k < NC; ++k) g[k] = __shfl(x.g[k], src, 64);
     }
@@ -263,7 +312,8 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
     const int n_tiles = P.n_db_tiles;
     // stage(T): image -> tile[T & 1] and norms -> nring[T & 3] by LDS-DMA; side scalars -> sring[T & 3] (the
     // caller stores `sreg` right before the barrier, when the DMA has long landed)
-    float sreg = 0.f;
+    constexpr int SREG = (SIDE_SLOT + 255) / 256;   // side scalars of a tile held per thread between the load and the store
+    float sreg[SREG];
     auto stage = [&](int T) {
         const float* src = P.yp + (size_t)T * TILE_F;
         float* dst = (T & 1) ? tile1 : tile0;
@@ -275,13 +325,21 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
         }
         if (wave == 3)
             __builtin_amdgcn_global_load_lds((dgptr_t)(src + KQ * 256 + lane), (dlptr_t)(nring + (T & 3) * 64), 4, 0, 0);
-        if (tid < SIDE_SLOT) {
-            const int64_t idx = (int64_t)T * SIDE_SLOT + tid;
-            sreg = (idx < P.n_db * SIDE) ? P.side[idx] : 0.f;
+#pragma unroll
+        for (int u = 0; u < SREG; ++u) {
+            const int o = u * 256 + tid;
+            if (o < SIDE_SLOT) {
+                const int64_t idx = (int64_t)T * SIDE_SLOT + o;
+                sreg[u] = (idx < P.n_db * SIDE) ? P.side[idx] : 0.f;
+            }
         }
     };
     auto stage_side_store = [&](int T) {
-        if (tid < SIDE_SLOT) sring[(T & 3) * SIDE_SLOT + tid] = sreg;
+#pragma unroll
+        for (int u = 0; u < SREG; ++u) {
+            const int o = u * 256 + tid;
+            if (o < SIDE_SLOT) sring[(T & 3) * SIDE_SLOT + o] = sreg[u];
+        }
     };
     if (n_tiles > 0) { stage(0); stage_side_store(0); }
     __syncthreads();
@@ -341,6 +399,31 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
 //   red_j = -LSE_i(log K_ij + f_i),  log K_ij = -log(1 + d_ij) / eps,  d_ii += 1e12 when zero_diag
 // With eps == 1:  red_j = -( fmax + log sum_i exp(f_i - fmax) / (1 + d_ij) )  -- no per-pair transcendental.
 // out[j] = 0.5 * (f_j + red_j)  (the averaged update), resid2 += (out[j] - red_j)^2  (convergence test :738).
+// s_j = sum_i v_i / (1 + |z_j - z_i|^2) for the thread's row j (all 256 threads of the workgroup take part in the staging)
+template <int NC>
+__device__ __forceinline__ float student_weighted_sum(const float* __restrict__ Z, const float* __restrict__ v, int64_t n,
+                                                      int64_t j, const float (&zj)[NC], int zero_diag, float diag_add,
+                                                      float* tile) {
+    float s = 0.f;
+    for (int64_t i0 = 0; i0 < n; i0 += 256) {
+        __syncthreads();
+        const int64_t i = i0 + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) tile[threadIdx.x * (NC + 1) + c] = (i < n) ? Z[(size_t)i * NC + c] : 0.f;
+        tile[threadIdx.x * (NC + 1) + NC] = (i < n) ? v[i] : 0.f;
+        __syncthreads();
+        const int lim = (int)((n - i0 < 256) ? (n - i0) : 256);
+        for (int t = 0; t < lim; ++t) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const float df = zj[c] - tile[t * (NC + 1) + c]; d = fmaf(df, df, d); }
+            if (zero_diag && (i0 + t) == j) d += diag_add;
+            s = fmaf(tile[t * (NC + 1) + NC], __builtin_amdgcn_rcpf(1.0f + d), s);
+        }
+    }
+    return s;
+}
+
 template <int NC>
 __global__ __launch_bounds__(256) void sinkhorn_pass_kernel(const float* __restrict__ Z, const float* __restrict__ f,
                                                             const float* __restrict__ Ef, float fmax, int64_t n,
@@ -352,23 +435,7 @@ __global__ __launch_bounds__(256) void sinkhorn_pass_kernel(const float* __restr
     float zj[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) zj[c] = have ? Z[(size_t)j * NC + c] : 0.f;
-    float s = 0.f;
-    for (int64_t i0 = 0; i0 < n; i0 += 256) {
-        __syncthreads();
-        const int64_t i = i0 + threadIdx.x;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) tile[threadIdx.x * (NC + 1) + c] = (i < n) ? Z[(size_t)i * NC + c] : 0.f;
-        tile[threadIdx.x * (NC + 1) + NC] = (i < n) ? Ef[i] : 0.f;
-        __syncthreads();
-        const int lim = (int)((n - i0 < 256) ? (n - i0) : 256);
-        for (int t = 0; t < lim; ++t) {
-            float d = 0.f;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) { const float df = zj[c] - tile[t * (NC + 1) + c]; d = fmaf(df, df, d); }
-            if (zero_diag && (i0 + t) == j) d += diag_add;
-            s = fmaf(tile[t * (NC + 1) + NC], __builtin_amdgcn_rcpf(1.0f + d), s);
-        }
-    }
+    const float s = student_weighted_sum<NC>(Z, Ef, n, j, zj, zero_diag, diag_add, tile);
     float r2 = 0.f;
     if (have) {
         const float red = -(fmax + logf(s));
@@ -379,6 +446,20 @@ __global__ __launch_bounds__(256) void sinkhorn_pass_kernel(const float* __restr
     }
     r2 = wave_sum(r2);
     if ((threadIdx.x & 63) == 0 && r2 != 0.f) atomicAdd(resid2, r2);
+}
+
+// out_j = sum_i v_i / (1 + d_ij): the Student-kernel mat-vec of the adjoint Sinkhorn updates (v may be negative)
+template <int NC>
+__global__ __launch_bounds__(256) void student_matvec_kernel(const float* __restrict__ Z, const float* __restrict__ v, int64_t n,
+                                                             int zero_diag, float diag_add, float* __restrict__ out) {
+    __shared__ float tile[256 * (NC + 1)];
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = j < n;
+    float zj[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) zj[c] = have ? Z[(size_t)j * NC + c] : 0.f;
+    const float s = student_weighted_sum<NC>(Z, v, n, j, zj, zero_diag, diag_add, tile);
+    if (have) out[j] = s;
 }
 
 static inline int dense_pick_kq(int d) {
@@ -458,18 +539,45 @@ int tdr_sinkhorn_lse_f32(const float* packed, int64_t n, int d, const float* f, 
     return launch_pair_scan<SinkLse>(P, d, (hipStream_t)stream);
 }
 
-/* TSNEkhorn embedding gradient (n, nc), nc = 2 or 3: 4 sum_j (P_ij - Q_ij)/(1+d_ij) (z_i - z_j).
+/* TSNEkhorn embedding gradient (n, nc): 4 sum_j (P_ij - Q_ij)/(1+d_ij) (z_i - z_j).  nc in {2, 3, 4, 8, 16, 32} (wider
+ * instances serve any width below them: the caller pads z with zeros and drops the padded gradient columns).
  * side: (n, 3 + nc) row-major (mu, e, z_0 .. z_{nc-1}, exp(dual)); log_n = log(n). */
 int tdr_khorn_grad_nc_f32(const float* packed, int64_t n, int d, const float* side, int nc, float log_n, float* grad,
                           void* stream) {
     if (!packed || !side || !grad || n <= 0) return TDR_ERR_BAD_ARG;
-    if (nc != 2 && nc != 3) return TDR_ERR_UNSUPPORTED;
     PairScanParams P;
     P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
     P.side = side; P.qside = side; P.c0 = log_n; P.c1 = 1.0f / (float)n; P.diag_add = 0.f; P.exclude_diag = 0;
     P.out0 = grad; P.out1 = nullptr; P.out2 = nullptr;
-    if (nc == 2) return launch_pair_scan<KhornForce<2>>(P, d, (hipStream_t)stream);
-    return launch_pair_scan<KhornForce<3>>(P, d, (hipStream_t)stream);
+    switch (nc) {
+        case 2: return launch_pair_scan<KhornForce<2>>(P, d, (hipStream_t)stream);
+        case 3: return launch_pair_scan<KhornForce<3>>(P, d, (hipStream_t)stream);
+        case 4: return launch_pair_scan<KhornForce<4>>(P, d, (hipStream_t)stream);
+        case 8: return launch_pair_scan<KhornForce<8>>(P, d, (hipStream_t)stream);
+        case 16: return launch_pair_scan<KhornForce<16>>(P, d, (hipStream_t)stream);
+        case 32: return launch_pair_scan<KhornForce<32>>(P, d, (hipStream_t)stream);
+        default: return TDR_ERR_UNSUPPORTED;
+    }
+}
+
+/* The same for TSNEkhorn(unrolling=True) (tsnekhorn.py:224-227; KhornForceUnrolled above): 4 sum_j [P_ij + w_ij sum_k
+ * (a^k_i b^k_j + a^k_j b^k_i)] w_ij (z_i - z_j).  side: (n, 2 + nc + 10) row-major (mu, e, z_0 .. z_{nc-1}, a^1..a^5, b^1..b^5). */
+int tdr_khorn_grad_unrolled_f32(const float* packed, int64_t n, int d, const float* side, int nc, float log_n, float* grad,
+                                void* stream) {
+    if (!packed || !side || !grad || n <= 0) return TDR_ERR_BAD_ARG;
+    PairScanParams P;
+    P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
+    P.side = side; P.qside = side; P.c0 = log_n; P.c1 = 0.f; P.diag_add = 0.f; P.exclude_diag = 0;
+    P.out0 = grad; P.out1 = nullptr; P.out2 = nullptr;
+    switch (nc) {
+        case 2: return launch_pair_scan<KhornForceUnrolled<2>>(P, d, (hipStream_t)stream);
+        case 3: return launch_pair_scan<KhornForceUnrolled<3>>(P, d, (hipStream_t)stream);
+        case 4: return launch_pair_scan<KhornForceUnrolled<4>>(P, d, (hipStream_t)stream);
+        case 8: return launch_pair_scan<KhornForceUnrolled<8>>(P, d, (hipStream_t)stream);
+        case 16: return launch_pair_scan<KhornForceUnrolled<16>>(P, d, (hipStream_t)stream);
+        case 32: return launch_pair_scan<KhornForceUnrolled<32>>(P, d, (hipStream_t)stream);
+        default: return TDR_ERR_UNSUPPORTED;
+    }
 }
 
 /* The two-component form (side: (n, 5)). */
@@ -485,9 +593,39 @@ int tdr_sinkhorn_pass_f32(const float* Z, int nc, const float* f, const float* E
     if (!Z || !f || !Ef || !f_new || !resid2 || n <= 0) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((n + 255) / 256);
-    if (nc == 2) hipLaunchKernelGGL(sinkhorn_pass_kernel<2>, dim3(grid), dim3(256), 0, st, Z, f, Ef, fmax, n, zero_diag, diag_add, f_new, resid2);
-    else if (nc == 3) hipLaunchKernelGGL(sinkhorn_pass_kernel<3>, dim3(grid), dim3(256), 0, st, Z, f, Ef, fmax, n, zero_diag, diag_add, f_new, resid2);
-    else return TDR_ERR_UNSUPPORTED;
+#define TDR_SK(NCV) hipLaunchKernelGGL(sinkhorn_pass_kernel<NCV>, dim3(grid), dim3(256), 0, st, Z, f, Ef, fmax, n, zero_diag, diag_add, f_new, resid2)
+    switch (nc) {
+        case 2: TDR_SK(2); break;
+        case 3: TDR_SK(3); break;
+        case 4: TDR_SK(4); break;
+        case 8: TDR_SK(8); break;
+        case 16: TDR_SK(16); break;
+        case 32: TDR_SK(32); break;
+        default: return TDR_ERR_UNSUPPORTED;
+    }
+#undef TDR_SK
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* out_j = sum_i v_i / (1 + |z_i - z_j|^2) over the embedding Z (n, nc), the diagonal term weighted 1 / (1 + diag_add) when
+ * zero_diag: the Student-kernel mat-vec of the adjoint Sinkhorn updates (entropic.py:733-736 differentiated; v signed). */
+int tdr_student_matvec_f32(const float* Z, int nc, const float* v, int64_t n, int zero_diag, float diag_add, float* out,
+                           void* stream) {
+    if (!Z || !v || !out || n <= 0) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+#define TDR_MV(NCV) hipLaunchKernelGGL(student_matvec_kernel<NCV>, dim3(grid), dim3(256), 0, st, Z, v, n, zero_diag, diag_add, out)
+    switch (nc) {
+        case 2: TDR_MV(2); break;
+        case 3: TDR_MV(3); break;
+        case 4: TDR_MV(4); break;
+        case 8: TDR_MV(8); break;
+        case 16: TDR_MV(16); break;
+        case 32: TDR_MV(32); break;
+        default: return TDR_ERR_UNSUPPORTED;
+    }
+#undef TDR_MV
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

@@ -6,7 +6,8 @@ from typing import Dict, Optional, Type, Union
 import torch
 
 from torchdr_amd import _lib
-from torchdr_amd.affinity.entropic import SinkhornAffinity, SymmetricEntropicAffinity
+from torchdr_amd.affinity.entropic import (SinkhornAffinity, SymmetricEntropicAffinity, pad_embedding, sea_rowstats,
+                                           sinkhorn_student_adjoint, sinkhorn_student_dual)
 from torchdr_amd.neighbor_embedding.base import NeighborEmbedding
 from torchdr_amd.utils import bool_arg
 
@@ -17,9 +18,18 @@ class TSNEkhorn(NeighborEmbedding):
 
     Fully matrix-free: the input affinity lives as its duals :math:`(\varepsilon, \mu)` and the packed
     point images; every training step recomputes :math:`P_{ij}` tile by tile on the MFMA pipe inside the
-    fused force kernel (``tdr_khorn_grad_f32``), after 5 warm-started Sinkhorn passes on the embedding
-    (``tdr_sinkhorn_pass_f32``).  ``unrolling`` (autograd through the Sinkhorn loop) and the non-symmetric
-    input affinity are not part of the accelerated path."""
+    fused force kernel (``tdr_khorn_grad_nc_f32``), after 5 warm-started Sinkhorn passes on the embedding
+    (``tdr_sinkhorn_pass_f32``).  Any ``n_components`` up to 32 (zero-padded register instances).
+
+    ``unrolling=True`` (reference ``tsnekhorn.py:134, 183, 224-227``: the loss is :math:`\mathrm{CE}(P, \log Q)` alone and
+    autograd runs THROUGH the 5 Sinkhorn updates) is differentiated in closed form: the forward passes record
+    :math:`(e^{f^{k-1}}, 1/s^k)`, a reverse sweep of 5 Student-kernel mat-vecs gives the adjoints
+    (``affinity.entropic.sinkhorn_student_adjoint``), and the force kernel ``tdr_khorn_grad_unrolled_f32`` carries them as a
+    rank-10 bilinear form in place of the :math:`Q` term -- still nothing of size :math:`N^2`.
+
+    ``symmetric_affinity=False`` is refused: the reference's own path fails at its first loss evaluation (the sparse
+    ``(n, k)`` entropic affinity is multiplied with the dense ``(n, n)`` log Q: "The size of tensor a (k) must match the size of
+    tensor b (n)"), so there is no behaviour to reproduce."""
 
     def __init__(self, perplexity: float = 30, n_components: int = 2, lr: Union[float, str] = "auto",
                  optimizer: Union[str, Type[torch.optim.Optimizer]] = "SGD",
@@ -42,11 +52,13 @@ class TSNEkhorn(NeighborEmbedding):
         self.tol_affinity_in = tol_affinity_in
         self.unrolling = bool_arg(unrolling)
         self.symmetric_affinity = bool_arg(symmetric_affinity)
-        if self.unrolling or not self.symmetric_affinity or n_components not in (2, 3):
+        if not self.symmetric_affinity:
             raise NotImplementedError(
-                "[torchdr_amd] TSNEkhorn: unrolling=True, symmetric_affinity=False and n_components outside {2, 3} "
-                "are not part of the accelerated path."
+                "[torchdr_amd] TSNEkhorn(symmetric_affinity=False): the reference's own path fails at its first loss evaluation "
+                "(sparse (n, k) affinity against the dense (n, n) log Q); there is no behaviour to reproduce."
             )
+        if n_components > 32:
+            raise NotImplementedError("[torchdr_amd] TSNEkhorn: n_components above 32 is not part of the accelerated path.")
         affinity_in = SymmetricEntropicAffinity(perplexity=perplexity, lr=lr_affinity_in,
                                                 eps_square=eps_square_affinity_in, metric=metric,
                                                 tol=tol_affinity_in, max_iter=max_iter_affinity_in, device=device,
@@ -64,24 +76,39 @@ class TSNEkhorn(NeighborEmbedding):
         self._packed = self.affinity_in.fit_duals(X)
         self._mu, self._e = self.affinity_in.dual_side()
         self.dual_sinkhorn_ = None
+        self._p_marginals = None
 
     def _compute_gradients(self):
         n = self.n_samples_in_
-        Z = self.embedding_.detach()
-        dual = self.affinity_out.fit_dual(Z, init_dual=self.dual_sinkhorn_)  # 5 warm-started passes (:214-216)
-        self.dual_sinkhorn_ = dual.detach()
         nc = self.n_components
-        side = torch.cat([self._mu[:, None], self._e[:, None], Z, dual.exp()[:, None]], dim=1).contiguous()
-        grad = torch.empty((n, nc), dtype=torch.float32, device=self.device_)
-        _lib.check(
-            _lib.lib().tdr_khorn_grad_nc_f32(_lib.ptr(self._packed.data), n, self._packed.d, _lib.ptr(side), nc,
-                                             math.log(n), _lib.ptr(grad), _lib.stream_ptr()),
-            "tdr_khorn_grad_nc_f32",
-        )
-        return grad, False
+        Zp = pad_embedding(self.embedding_)
+        w = Zp.shape[1]
+        out = self.affinity_out
+        rec = [] if self.unrolling else None
+        # 5 warm-started passes from the detached dual of the previous step (:214-216)
+        dual, k = sinkhorn_student_dual(Zp, self.dual_sinkhorn_, out.max_iter, out.tol, out.zero_diag, record=rec)
+        out.register_buffer("dual_", dual, persistent=False)
+        out.n_iter_ = k
+        self.dual_sinkhorn_ = dual.detach()
+        grad = torch.empty((n, w), dtype=torch.float32, device=self.device_)
+        L = _lib.lib()
+        if not self.unrolling:
+            side = torch.cat([self._mu[:, None], self._e[:, None], Zp, dual.exp()[:, None]], dim=1).contiguous()
+            _lib.check(L.tdr_khorn_grad_nc_f32(_lib.ptr(self._packed.data), n, self._packed.d, _lib.ptr(side), w, math.log(n),
+                                               _lib.ptr(grad), _lib.stream_ptr()), "tdr_khorn_grad_nc_f32")
+        else:
+            if self._p_marginals is None:    # d loss / d f_i = -(sum_j P_ij + sum_j P_ji); P is fixed during the fit
+                S, _ = sea_rowstats(self._packed, self._mu, self._e, False)
+                self._p_marginals = (2.0 / n) * S
+            A, B = sinkhorn_student_adjoint(Zp, rec, -self._p_marginals, out.zero_diag)
+            side = torch.cat([self._mu[:, None], self._e[:, None], Zp, 0.25 * A, B], dim=1).contiguous()
+            _lib.check(L.tdr_khorn_grad_unrolled_f32(_lib.ptr(self._packed.data), n, self._packed.d, _lib.ptr(side), w,
+                                                     math.log(n), _lib.ptr(grad), _lib.stream_ptr()),
+                       "tdr_khorn_grad_unrolled_f32")
+        return (grad if w == nc else grad[:, :nc].contiguous()), False
 
     def clear_memory(self):
         super().clear_memory()
-        for attr in ("_packed", "_mu", "_e", "dual_sinkhorn_"):
+        for attr in ("_packed", "_mu", "_e", "dual_sinkhorn_", "_p_marginals"):
             if hasattr(self, attr):
                 delattr(self, attr)
