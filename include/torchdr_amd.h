@@ -368,31 +368,37 @@ int tdr_sgd_step_f32(float* Z, const float* grad, float* buf, int64_t n, float l
                      int* nan_flag, int n_iter, void* stream);
 int tdr_fill_f32(float* p, int64_t n, float v, void* stream);
 
+/* Optional workspace of the matrix-free pair scans below (ws / ws_bytes; NULL = none): with a buffer of
+ * tdr_pair_scan_workspace_bytes(n, n_state) bytes the database is split into segments so that the launch fills the chip
+ * evenly (unsplit, N = 200k is 1.5 rounds of workgroups); per-segment statistics are folded in segment order by a second
+ * kernel.  n_state: floats of running statistics per row -- 4 for the row statistics, 2 for the log-sum-exp, the instance
+ * width nc for the forces.  0 = a scan of this size is not split. */
+int64_t tdr_pair_scan_workspace_bytes(int64_t n, int n_state);
 /* ---- K7 / K8: matrix-free dense affinities (TSNEkhorn) ------------------------------------------------
  * affinity/entropic.py:37-42,518-565 (_log_Pse, row entropy / logsumexp of the dual-ascent loop) */
 int tdr_sea_rowstats_f32(const float* packed, int64_t n, int d, const float* side, int exclude_diag, float diag_add,
-                         float* psum, float* ent, void* stream);
+                         float* psum, float* ent, void* ws, int64_t ws_bytes, void* stream);
 /* the same with energy[i] = sum_j exp(lp_ij) C_ij: the dual objective of the LBFGS path (entropic.py:483-491) is
  * -sum(energy) - <e, target - ent> + <mu, psum - 1> */
 int tdr_sea_rowstats3_f32(const float* packed, int64_t n, int d, const float* side, int exclude_diag, float diag_add,
-                          float* psum, float* ent, float* energy, void* stream);
+                          float* psum, float* ent, float* energy, void* ws, int64_t ws_bytes, void* stream);
 /* affinity/entropic.py:728-734 on the input points, matrix-free: lse[i] = LSE_j(log K_ij + f_j), log K = -C / eps
  * (student != 0: -log(1 + C) / eps); the caller forms the symmetric Sinkhorn update f <- 0.5 (f - lse). */
 int tdr_sinkhorn_lse_f32(const float* packed, int64_t n, int d, const float* f, float inv_eps, int student, int exclude_diag,
-                         float diag_add, float* lse, void* stream);
+                         float diag_add, float* lse, void* ws, int64_t ws_bytes, void* stream);
 /* gradient of neighbor_embedding/tsnekhorn.py:210-230 w.r.t. the embedding (duals detached) */
 int tdr_khorn_grad_f32(const float* packed, int64_t n, int d, const float* side, float log_n, float* grad, void* stream);
 /* the same for an (n, nc) embedding, nc in {2, 3, 4, 8, 16, 32} (other widths: pad z with zero columns up to the next one);
  * side: (n, 3 + nc) row-major (mu, e, z_0 .. z_{nc-1}, exp(dual)) */
 int tdr_khorn_grad_nc_f32(const float* packed, int64_t n, int d, const float* side, int nc, float log_n, float* grad,
-                          void* stream);
+                          void* ws, int64_t ws_bytes, void* stream);
 /* TSNEkhorn(unrolling=True), neighbor_embedding/tsnekhorn.py:134,224-227: gradient of CE(P, log Q) with autograd THROUGH the
  * <= 5 Sinkhorn updates (affinity/entropic.py:729-736 with with_grad=True), in closed form:
  *   4 sum_j [P_ij + w_ij sum_k (a^k_i b^k_j + a^k_j b^k_i)] w_ij (z_i - z_j),  w = 1/(1+d_ij);
  * side: (n, 2 + nc + 10) row-major (mu, e, z_0 .. z_{nc-1}, a^1..a^5, b^1..b^5) -- a^k = adjoint of update k / (4 s^k),
  * b^k = exp(f^{k-1} - max), zero for updates that did not run. */
 int tdr_khorn_grad_unrolled_f32(const float* packed, int64_t n, int d, const float* side, int nc, float log_n, float* grad,
-                                void* stream);
+                                void* ws, int64_t ws_bytes, void* stream);
 /* affinity/entropic.py:733-740: one symmetric log-domain Sinkhorn update, student kernel on the embedding
  * (nc in {2, 3, 4, 8, 16, 32}) */
 int tdr_sinkhorn_pass_f32(const float* Z, int nc, const float* f, const float* Ef, float fmax, int64_t n, int zero_diag,

@@ -49,6 +49,55 @@ def test_sea_rowstats_vs_oracle_medium():
     assert torch.allclose(H.cpu().double(), H_ref, rtol=2e-5, atol=1e-4)
 
 
+def test_split_pair_scan_equals_the_unsplit_scan():
+    """With the optional workspace the database is scanned in segments by separate workgroups and the per-segment statistics
+    are folded in order: same numbers up to the association of the fp32 sums (row statistics, log-sum-exp, forces)."""
+    from torchdr_amd import _lib
+    from torchdr_amd.affinity.entropic import pair_scan_workspace
+    from torchdr_amd.distance import PackedPoints
+
+    n = 20000
+    X = gmm(n, 64, 2.0, seed=3).cuda()
+    packed = PackedPoints(X)
+    gen = torch.Generator().manual_seed(1)
+    mu = (torch.rand(n, generator=gen) * 2 - 1).cuda()
+    e = (torch.rand(n, generator=gen) * 20 + 40).cuda()
+    L = _lib.lib()
+    assert int(L.tdr_pair_scan_workspace_bytes(3000, 4)) == 0 and int(L.tdr_pair_scan_workspace_bytes(n, 4)) > 0
+    side = torch.stack([mu, e], dim=1).contiguous()
+    out = {}
+    for split in (False, True):
+        ws, nb, keep = pair_scan_workspace(n, 4, X.device) if split else (None, 0, None)
+        S, H, En = (torch.empty(n, device="cuda") for _ in range(3))
+        _lib.check(L.tdr_sea_rowstats3_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), 1, 1e12, _lib.ptr(S), _lib.ptr(H),
+                                           _lib.ptr(En), ws, nb, _lib.stream_ptr()), "rowstats3")
+        f = (mu * 0.3).contiguous()
+        lse = torch.empty(n, device="cuda")
+        ws2, nb2, keep2 = pair_scan_workspace(n, 2, X.device) if split else (None, 0, None)
+        _lib.check(L.tdr_sinkhorn_lse_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(f), 0.05, 0, 1, 1e12, _lib.ptr(lse), ws2, nb2,
+                                          _lib.stream_ptr()), "lse")
+        Z = torch.randn(n, 3, generator=torch.Generator().manual_seed(2)).cuda() * 3
+        side3 = torch.cat([mu[:, None], e[:, None], Z, (0.1 * mu).exp()[:, None]], dim=1).contiguous()
+        grad = torch.empty((n, 3), device="cuda")
+        ws3, nb3, keep3 = pair_scan_workspace(n, 3, X.device) if split else (None, 0, None)
+        _lib.check(L.tdr_khorn_grad_nc_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side3), 3, float(np.log(n)), _lib.ptr(grad),
+                                           ws3, nb3, _lib.stream_ptr()), "khorn")
+        torch.cuda.synchronize()
+        out[split] = (S, H, En, lse, grad)
+    for name_, a_, b_ in zip(("rowsum", "entropy", "energy", "lse", "force"), out[False], out[True]):
+        if name_ == "force":     # signed terms that cancel: the tolerance of the force tests below
+            assert torch.allclose(a_, b_, rtol=2e-3, atol=2e-5 * float(a_.abs().max()))
+            continue
+        rel = float(((a_ - b_).abs() / (a_.abs() + 1e-6 * float(a_.abs().max()))).max())
+        assert rel < 5e-5, (name_, rel)      # fp32 sums of 20 000 positive terms in two associations
+    # a buffer that is too small is ignored (unsplit scan, bit-equal to no buffer)
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    S2, H2 = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    _lib.check(L.tdr_sea_rowstats_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), 1, 1e12, _lib.ptr(S2), _lib.ptr(H2),
+                                      _lib.ptr(small), 1024, _lib.stream_ptr()), "rowstats")
+    assert torch.equal(S2, out[False][0]) and torch.equal(H2, out[False][1])
+
+
 def test_sinkhorn_student_vs_reference():
     from torchdr_amd.affinity import SinkhornAffinity
 
@@ -132,7 +181,7 @@ def test_tsnekhorn_unrolled_gradient_vs_reference_autograd(name):
         side = torch.cat([mu[:, None], e[:, None], Zp, 0.25 * A, B], dim=1).contiguous()
         grad = torch.empty((n, Zp.shape[1]), device="cuda")
         _lib.check(_lib.lib().tdr_khorn_grad_unrolled_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), Zp.shape[1],
-                                                          float(np.log(n)), _lib.ptr(grad), _lib.stream_ptr()), "khorn unrolled")
+                                                          float(np.log(n)), _lib.ptr(grad), None, 0, _lib.stream_ptr()), "khorn unrolled")
         ref = g[f"{name}_grad_{t}"]
         assert torch.allclose(grad[:, :nc].cpu(), ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()))
         assert float(grad[:, nc:].abs().max()) == 0.0 if Zp.shape[1] > nc else True
@@ -166,7 +215,7 @@ def test_tsnekhorn_unrolled_matches_the_oracle_at_3000_points():
     side = torch.cat([mu[:, None], e[:, None], Z.cuda(), 0.25 * A, B], dim=1).contiguous()
     grad = torch.empty((n, 2), device="cuda")
     _lib.check(_lib.lib().tdr_khorn_grad_unrolled_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), 2, float(np.log(n)),
-                                                      _lib.ptr(grad), _lib.stream_ptr()), "khorn unrolled")
+                                                      _lib.ptr(grad), None, 0, _lib.stream_ptr()), "khorn unrolled")
     assert torch.allclose(grad.cpu().double(), ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()))
 
 
@@ -188,7 +237,7 @@ def test_tsnekhorn_four_components_vs_reference():
         side = torch.cat([mu[:, None], e[:, None], Z, dual.exp()[:, None]], dim=1).contiguous()
         grad = torch.empty((n, 4), device="cuda")
         _lib.check(_lib.lib().tdr_khorn_grad_nc_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), 4, float(np.log(n)),
-                                                    _lib.ptr(grad), _lib.stream_ptr()), "khorn")
+                                                    _lib.ptr(grad), None, 0, _lib.stream_ptr()), "khorn")
         ref = g[f"n4_grad_{t}"]
         assert torch.allclose(grad.cpu(), ref, rtol=2e-3, atol=2e-5 * float(ref.abs().max()))
 

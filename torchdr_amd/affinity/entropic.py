@@ -191,6 +191,16 @@ from torchdr_amd.utils import check_NaNs  # noqa: E402
 _DENSE_LIMIT = 30000  # largest N for which the dense (N, N) API output is materialised
 
 
+def pair_scan_workspace(n: int, n_state: int, device):
+    """(pointer, bytes) of the optional split workspace of a pair scan (``tdr_pair_scan_workspace_bytes``) plus the tensor
+    that owns it (stream-ordered: allocated and released on the current stream by the caching allocator)."""
+    nbytes = int(_lib.lib().tdr_pair_scan_workspace_bytes(n, n_state))
+    if nbytes <= 0:
+        return None, 0, None
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return _lib.ptr(buf), nbytes, buf
+
+
 def sea_rowstats(packed: PackedPoints, mu: torch.Tensor, e: torch.Tensor, zero_diag: bool, energy: bool = False):
     """(P_sum, H) of the implicit matrix exp((mu_i+mu_j-2C_ij)/(e_i+e_j)) -- K7 ``tdr_sea_rowstats_f32``; with
     ``energy`` also sum_j P_ij C_ij (the third term of the dual objective, ``tdr_sea_rowstats3_f32``)."""
@@ -198,17 +208,18 @@ def sea_rowstats(packed: PackedPoints, mu: torch.Tensor, e: torch.Tensor, zero_d
     side = torch.stack([mu, e], dim=1).contiguous()
     psum = torch.empty(n, dtype=torch.float32, device=mu.device)
     ent = torch.empty(n, dtype=torch.float32, device=mu.device)
+    ws, ws_bytes, _keep = pair_scan_workspace(n, 4, mu.device)
     if energy:
         en = torch.empty(n, dtype=torch.float32, device=mu.device)
         _lib.check(
             _lib.lib().tdr_sea_rowstats3_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), 1 if zero_diag else 0,
-                                             1e12, _lib.ptr(psum), _lib.ptr(ent), _lib.ptr(en), _lib.stream_ptr()),
+                                             1e12, _lib.ptr(psum), _lib.ptr(ent), _lib.ptr(en), ws, ws_bytes, _lib.stream_ptr()),
             "tdr_sea_rowstats3_f32",
         )
         return psum, ent, en
     _lib.check(
         _lib.lib().tdr_sea_rowstats_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), 1 if zero_diag else 0,
-                                        1e12, _lib.ptr(psum), _lib.ptr(ent), _lib.stream_ptr()),
+                                        1e12, _lib.ptr(psum), _lib.ptr(ent), ws, ws_bytes, _lib.stream_ptr()),
         "tdr_sea_rowstats_f32",
     )
     return psum, ent
@@ -427,9 +438,11 @@ def sinkhorn_input_dual(X: torch.Tensor, eps: float, init_dual, max_iter: int, t
     lse = torch.empty_like(f)
     L = _lib.lib()
     k = 0
+    ws, ws_bytes, _keep = pair_scan_workspace(n, 2, X.device)
     for k in range(max_iter):
         _lib.check(L.tdr_sinkhorn_lse_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(f), 1.0 / float(eps), 1 if student else 0,
-                                          1 if zero_diag else 0, 1e12, _lib.ptr(lse), _lib.stream_ptr()), "tdr_sinkhorn_lse_f32")
+                                          1 if zero_diag else 0, 1e12, _lib.ptr(lse), ws, ws_bytes, _lib.stream_ptr()),
+                   "tdr_sinkhorn_lse_f32")
         red = -lse
         f = 0.5 * (f + red)
         check_NaNs(f, msg=f"ERROR Affinity: NaN at iter {k}.")

@@ -29,6 +29,11 @@ struct PairScanParams {
     float* out0;           // per-row outputs
     float* out1;
     float* out2;           // optional third output (SeaStats: sum_j P_ij C_ij), may be NULL
+    // database split (launch_pair_scan): workgroup b scans segment b / n_qblocks of the tiles for query block b % n_qblocks and
+    // saves its running statistics to part[(seg * nq + row) * NSTATE ..]; pair_scan_merge_kernel folds the segments in order
+    int n_seg, tiles_per_seg;
+    int64_t n_qblocks;
+    float* part;
 };
 
 // ---- epilogues ---------------------------------------------------------------------------------------
@@ -58,6 +63,9 @@ struct SeaStats {
     __device__ __forceinline__ void shfl_from(const SeaStats& x, int src) {
         m = __shfl(x.m, src, 64); s = __shfl(x.s, src, 64); t = __shfl(x.t, src, 64); u = __shfl(x.u, src, 64); mu_i = x.mu_i; e_i = x.e_i;
     }
+    static constexpr int NSTATE = 4;
+    __device__ __forceinline__ void save(float* p) const { p[0] = m; p[1] = s; p[2] = t; p[3] = u; }
+    __device__ __forceinline__ void load(const float* p) { m = p[0]; s = p[1]; t = p[2]; u = p[3]; }
     __device__ __forceinline__ void store(int64_t row, const PairScanParams& P) const {
         const float em = expf(m);
         const float S = em * s, T = em * t;
@@ -86,6 +94,9 @@ struct SinkLse {
         s = s * a + o.s * b; m = mm;
     }
     __device__ __forceinline__ void shfl_from(const SinkLse& x, int src) { m = __shfl(x.m, src, 64); s = __shfl(x.s, src, 64); }
+    static constexpr int NSTATE = 2;
+    __device__ __forceinline__ void save(float* p) const { p[0] = m; p[1] = s; }
+    __device__ __forceinline__ void load(const float* p) { m = p[0]; s = p[1]; }
     __device__ __forceinline__ void store(int64_t row, const PairScanParams& P) const { P.out0[row] = m + logf(s); }
 };
 
@@ -126,6 +137,15 @@ struct KhornForce {
     __device__ __forceinline__ void shfl_from(const KhornForce& x, int src) {
 #pragma unroll
         for (int k = 0; k < NC; ++k) g[k] = __shfl(x.g[k], src, 64);
+    }
+    static constexpr int NSTATE = NC;
+    __device__ __forceinline__ void save(float* p) const {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) p[k] = g[k];
+    }
+    __device__ __forceinline__ void load(const float* p) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) g[k] = p[k];
     }
     __device__ __forceinline__ void store(int64_t row, const PairScanParams& P) const {
 #pragma unroll
@@ -175,6 +195,15 @@ struct KhornForceUnrolled {
     __device__ __forceinline__ void shfl_from(const KhornForceUnrolled& x, int src) {
 #pragma unroll
         for (int k = 0; k < NC; ++k) g[k] = __shfl(x.g[k], src, 64);
+    }
+    static constexpr int NSTATE = NC;
+    __device__ __forceinline__ void save(float* p) const {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) p[k] = g[k];
+    }
+    __device__ __forceinline__ void load(const float* p) {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) g[k] = p[k];
     }
     __device__ __forceinline__ void store(int64_t row, const PairScanParams& P) const {
 #pragma unroll
@@ -282,7 +311,9 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 31, h = lane >> 5;
     const int64_t n_qtiles = (P.nq + 31) / 32;
-    const int64_t qt = (int64_t)blockIdx.x * 4 + wave;
+    const int seg = (int)((int64_t)blockIdx.x / P.n_qblocks);        // segment-major: concurrent workgroups stream the same tiles
+    const int64_t qblock = (int64_t)blockIdx.x - (int64_t)seg * P.n_qblocks;
+    const int64_t qt = qblock * 4 + wave;
     const bool wave_active = qt < n_qtiles;
     const int64_t gq = qt * 32 + q;
     const bool lane_valid = wave_active && gq < P.nq;
@@ -309,7 +340,8 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
         for (int t = 0; t < 4 * KQ; ++t) b[t] = 0.f;
     }
 
-    const int n_tiles = P.n_db_tiles;
+    const int T0 = seg * P.tiles_per_seg;
+    const int n_tiles = (T0 + P.tiles_per_seg < P.n_db_tiles) ? T0 + P.tiles_per_seg : P.n_db_tiles;   // this segment: [T0, n_tiles)
     // stage(T): image -> tile[T & 1] and norms -> nring[T & 3] by LDS-DMA; side scalars -> sring[T & 3] (the
     // caller stores `sreg` right before the barrier, when the DMA has long landed)
     constexpr int SREG = (SIDE_SLOT + 255) / 256;   // side scalars of a tile held per thread between the load and the store
@@ -341,16 +373,16 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
             if (o < SIDE_SLOT) sring[(T & 3) * SIDE_SLOT + o] = sreg[u];
         }
     };
-    if (n_tiles > 0) { stage(0); stage_side_store(0); }
+    if (n_tiles > T0) { stage(T0); stage_side_store(T0); }
     __syncthreads();
 
     f32x16 accA, accB;
-    int T = 0;
+    int T = T0;
     if (T < n_tiles) {
         const bool nx = T + 1 < n_tiles;
         if (nx) stage(T + 1);
         if (wave_active)
-            pair_tile_step<KQ, Epi, false>(epi, P, tile0, b, accA, accA, nring, sring, lane, h, xn, 0, gq);
+            pair_tile_step<KQ, Epi, false>(epi, P, (T & 1) ? tile1 : tile0, b, accA, accA, nring, sring, lane, h, xn, 0, gq);
         if (nx) stage_side_store(T + 1);
         __syncthreads();
         ++T;
@@ -381,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
             accA = accB;
         }
     }
-    if (wave_active && n_tiles > 0) {
+    if (wave_active && n_tiles > T0) {
         const int Tl = n_tiles - 1;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -391,8 +423,25 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
         Epi other;
         other.shfl_from(epi, lane ^ 32);
         epi.merge(other);
-        if (h == 0 && lane_valid) epi.store(gq, P);
+        if (h == 0 && lane_valid) {
+            if (P.n_seg == 1) epi.store(gq, P);
+            else epi.save(P.part + ((size_t)seg * P.nq + gq) * Epi::NSTATE);
+        }
     }
+}
+
+// folds the per-segment statistics of a row in segment order (a fixed association: the result does not depend on scheduling)
+template <class Epi>
+__global__ __launch_bounds__(256) void pair_scan_merge_kernel(const PairScanParams P) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= P.nq) return;
+    Epi epi, other;
+    epi.load(P.part + (size_t)row * Epi::NSTATE);
+    for (int sgm = 1; sgm < P.n_seg; ++sgm) {
+        other.load(P.part + ((size_t)sgm * P.nq + row) * Epi::NSTATE);
+        epi.merge(other);
+    }
+    epi.store(row, P);
 }
 
 // ---- Sinkhorn pass on the 2-D / 3-D embedding (student kernel), entropic.py:733-740 --------------------
@@ -470,13 +519,34 @@ static inline int dense_pick_kq(int d) {
     return 0;
 }
 
+// Database split of a pair scan.  A workgroup serves 128 rows against the tiles it is given; unsplit, N = 200k is 1563
+// workgroups for 1024 resident ones (4 per CU): 1.5 rounds, a quarter of the launch with the chip mostly idle -- and below
+// N = 32k the grid does not cover the CUs at all.  Split into segments of >= 64 tiles so that there are >= ~16 k workgroups.
+static inline int pair_scan_segments(int64_t nq, int n_tiles) {
+    const int64_t n_qb = (nq + 127) / 128;
+    int64_t s = (16384 + n_qb - 1) / n_qb;
+    if (s > n_tiles / 64) s = n_tiles / 64;
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : (int)s;
+}
+
 template <class Epi>
-static int launch_pair_scan(const PairScanParams& P, int d, hipStream_t st) {
+static int launch_pair_scan(PairScanParams P, int d, hipStream_t st, void* ws, int64_t ws_bytes) {
     const int kq = dense_pick_kq(d);
     if (kq == 0) return TDR_ERR_UNSUPPORTED;
+    P.n_qblocks = (P.nq + 127) / 128;
+    P.n_seg = 1; P.tiles_per_seg = P.n_db_tiles; P.part = nullptr;
+    {
+        const int want = pair_scan_segments(P.nq, P.n_db_tiles);
+        if (want > 1 && ws && ws_bytes >= (int64_t)want * P.nq * Epi::NSTATE * (int64_t)sizeof(float)) {
+            P.tiles_per_seg = (P.n_db_tiles + want - 1) / want;
+            P.n_seg = (P.n_db_tiles + P.tiles_per_seg - 1) / P.tiles_per_seg;
+            P.part = (float*)ws;
+        }
+    }
     const size_t lds = (size_t)2 * (kq * 256) * sizeof(float) + (size_t)4 * 64 * sizeof(float) +
                        (size_t)4 * 32 * Epi::SIDE * sizeof(float);
-    const unsigned grid = (unsigned)((P.nq + 127) / 128);
+    const unsigned grid = (unsigned)(P.n_qblocks * P.n_seg);
 #define TDR_LAUNCH(KQV)                                                                                          \
     {                                                                                                            \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pair_scan_kernel<KQV, Epi>),            \
@@ -491,6 +561,8 @@ static int launch_pair_scan(const PairScanParams& P, int d, hipStream_t st) {
         default: TDR_LAUNCH(32) break;
     }
 #undef TDR_LAUNCH
+    if (P.n_seg > 1)
+        hipLaunchKernelGGL((pair_scan_merge_kernel<Epi>), dim3((unsigned)((P.nq + 255) / 256)), dim3(256), 0, st, P);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TDR_OK : (int)e;
 }
@@ -501,61 +573,71 @@ using namespace tdr;
 
 extern "C" {
 
+/* Bytes of the optional workspace of the pair scans below for n points and `n_state` floats of running statistics per row
+ * (row statistics 4, log-sum-exp 2, forces: the instance width nc): with it the database is split into segments so that
+ * the launch fills the chip evenly (pair_scan_segments); 0 = the scan of this size is not split.  NULL / a smaller buffer
+ * runs the unsplit scan. */
+int64_t tdr_pair_scan_workspace_bytes(int64_t n, int n_state) {
+    if (n <= 0 || n_state <= 0) return 0;
+    const int want = pair_scan_segments(n, (int)((n + 31) / 32));
+    return want > 1 ? (int64_t)want * n * n_state * (int64_t)sizeof(float) : 0;
+}
+
 /* SEA row statistics over the implicit N x N matrix lp_ij = (mu_i + mu_j - 2 C_ij)/(e_i + e_j):
  *   psum[i] = sum_j exp(lp_ij),  ent[i] = -sum_j exp(lp_ij)(lp_ij - 1).
  * packed: tile images of X (tdr_pack_rows_f32); side: (n, 2) row-major (mu, e) with e = eps^2 or eps. */
 int tdr_sea_rowstats_f32(const float* packed, int64_t n, int d, const float* side, int exclude_diag, float diag_add,
-                         float* psum, float* ent, void* stream) {
+                         float* psum, float* ent, void* ws, int64_t ws_bytes, void* stream) {
     if (!packed || !side || !psum || !ent || n <= 0) return TDR_ERR_BAD_ARG;
     PairScanParams P;
     P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
     P.side = side; P.qside = side; P.c0 = 0.f; P.c1 = 0.f; P.diag_add = diag_add; P.exclude_diag = exclude_diag;
     P.out0 = psum; P.out1 = ent; P.out2 = nullptr;
-    return launch_pair_scan<SeaStats>(P, d, (hipStream_t)stream);
+    return launch_pair_scan<SeaStats>(P, d, (hipStream_t)stream, ws, ws_bytes);
 }
 
 /* The same with the third row statistic energy[i] = sum_j exp(lp_ij) C_ij: the dual objective of entropic.py:483-491
  * (the LBFGS path) is -sum(energy) - <e, target - ent> + <mu, psum - 1>. */
 int tdr_sea_rowstats3_f32(const float* packed, int64_t n, int d, const float* side, int exclude_diag, float diag_add,
-                          float* psum, float* ent, float* energy, void* stream) {
+                          float* psum, float* ent, float* energy, void* ws, int64_t ws_bytes, void* stream) {
     if (!packed || !side || !psum || !ent || !energy || n <= 0) return TDR_ERR_BAD_ARG;
     PairScanParams P;
     P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
     P.side = side; P.qside = side; P.c0 = 0.f; P.c1 = 0.f; P.diag_add = diag_add; P.exclude_diag = exclude_diag;
     P.out0 = psum; P.out1 = ent; P.out2 = energy;
-    return launch_pair_scan<SeaStats>(P, d, (hipStream_t)stream);
+    return launch_pair_scan<SeaStats>(P, d, (hipStream_t)stream, ws, ws_bytes);
 }
 
 /* One reduction of the symmetric Sinkhorn fixed point on the INPUT points (entropic.py:728-734, matrix-free):
  *   lse[i] = LSE_j(log K_ij + f_j),  log K = -C / eps (student != 0: -log(1 + C) / eps), C = squared distances of the packed
  *   points with diag_add on the diagonal when exclude_diag.  The caller forms f <- 0.5 (f - lse). */
 int tdr_sinkhorn_lse_f32(const float* packed, int64_t n, int d, const float* f, float inv_eps, int student, int exclude_diag,
-                         float diag_add, float* lse, void* stream) {
+                         float diag_add, float* lse, void* ws, int64_t ws_bytes, void* stream) {
     if (!packed || !f || !lse || n <= 0 || !(inv_eps > 0.f)) return TDR_ERR_BAD_ARG;
     PairScanParams P;
     P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
     P.side = f; P.qside = f; P.c0 = inv_eps; P.c1 = student ? 1.0f : 0.f; P.diag_add = diag_add; P.exclude_diag = exclude_diag;
     P.out0 = lse; P.out1 = nullptr; P.out2 = nullptr;
-    return launch_pair_scan<SinkLse>(P, d, (hipStream_t)stream);
+    return launch_pair_scan<SinkLse>(P, d, (hipStream_t)stream, ws, ws_bytes);
 }
 
 /* TSNEkhorn embedding gradient (n, nc): 4 sum_j (P_ij - Q_ij)/(1+d_ij) (z_i - z_j).  nc in {2, 3, 4, 8, 16, 32} (wider
  * instances serve any width below them: the caller pads z with zeros and drops the padded gradient columns).
  * side: (n, 3 + nc) row-major (mu, e, z_0 .. z_{nc-1}, exp(dual)); log_n = log(n). */
 int tdr_khorn_grad_nc_f32(const float* packed, int64_t n, int d, const float* side, int nc, float log_n, float* grad,
-                          void* stream) {
+                          void* ws, int64_t ws_bytes, void* stream) {
     if (!packed || !side || !grad || n <= 0) return TDR_ERR_BAD_ARG;
     PairScanParams P;
     P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
     P.side = side; P.qside = side; P.c0 = log_n; P.c1 = 1.0f / (float)n; P.diag_add = 0.f; P.exclude_diag = 0;
     P.out0 = grad; P.out1 = nullptr; P.out2 = nullptr;
     switch (nc) {
-        case 2: return launch_pair_scan<KhornForce<2>>(P, d, (hipStream_t)stream);
-        case 3: return launch_pair_scan<KhornForce<3>>(P, d, (hipStream_t)stream);
-        case 4: return launch_pair_scan<KhornForce<4>>(P, d, (hipStream_t)stream);
-        case 8: return launch_pair_scan<KhornForce<8>>(P, d, (hipStream_t)stream);
-        case 16: return launch_pair_scan<KhornForce<16>>(P, d, (hipStream_t)stream);
-        case 32: return launch_pair_scan<KhornForce<32>>(P, d, (hipStream_t)stream);
+        case 2: return launch_pair_scan<KhornForce<2>>(P, d, (hipStream_t)stream, ws, ws_bytes);
+        case 3: return launch_pair_scan<KhornForce<3>>(P, d, (hipStream_t)stream, ws, ws_bytes);
+        case 4: return launch_pair_scan<KhornForce<4>>(P, d, (hipStream_t)stream, ws, ws_bytes);
+        case 8: return launch_pair_scan<KhornForce<8>>(P, d, (hipStream_t)stream, ws, ws_bytes);
+        case 16: return launch_pair_scan<KhornForce<16>>(P, d, (hipStream_t)stream, ws, ws_bytes);
+        case 32: return launch_pair_scan<KhornForce<32>>(P, d, (hipStream_t)stream, ws, ws_bytes);
         default: return TDR_ERR_UNSUPPORTED;
     }
 }
@@ -563,26 +645,26 @@ int tdr_khorn_grad_nc_f32(const float* packed, int64_t n, int d, const float* si
 /* The same for TSNEkhorn(unrolling=True) (tsnekhorn.py:224-227; KhornForceUnrolled above): 4 sum_j [P_ij + w_ij sum_k
  * (a^k_i b^k_j + a^k_j b^k_i)] w_ij (z_i - z_j).  side: (n, 2 + nc + 10) row-major (mu, e, z_0 .. z_{nc-1}, a^1..a^5, b^1..b^5). */
 int tdr_khorn_grad_unrolled_f32(const float* packed, int64_t n, int d, const float* side, int nc, float log_n, float* grad,
-                                void* stream) {
+                                void* ws, int64_t ws_bytes, void* stream) {
     if (!packed || !side || !grad || n <= 0) return TDR_ERR_BAD_ARG;
     PairScanParams P;
     P.qp = packed; P.yp = packed; P.nq = n; P.q_offset = 0; P.n_db = n; P.n_db_tiles = (int)((n + 31) / 32);
     P.side = side; P.qside = side; P.c0 = log_n; P.c1 = 0.f; P.diag_add = 0.f; P.exclude_diag = 0;
     P.out0 = grad; P.out1 = nullptr; P.out2 = nullptr;
     switch (nc) {
-        case 2: return launch_pair_scan<KhornForceUnrolled<2>>(P, d, (hipStream_t)stream);
-        case 3: return launch_pair_scan<KhornForceUnrolled<3>>(P, d, (hipStream_t)stream);
-        case 4: return launch_pair_scan<KhornForceUnrolled<4>>(P, d, (hipStream_t)stream);
-        case 8: return launch_pair_scan<KhornForceUnrolled<8>>(P, d, (hipStream_t)stream);
-        case 16: return launch_pair_scan<KhornForceUnrolled<16>>(P, d, (hipStream_t)stream);
-        case 32: return launch_pair_scan<KhornForceUnrolled<32>>(P, d, (hipStream_t)stream);
+        case 2: return launch_pair_scan<KhornForceUnrolled<2>>(P, d, (hipStream_t)stream, ws, ws_bytes);
+        case 3: return launch_pair_scan<KhornForceUnrolled<3>>(P, d, (hipStream_t)stream, ws, ws_bytes);
+        case 4: return launch_pair_scan<KhornForceUnrolled<4>>(P, d, (hipStream_t)stream, ws, ws_bytes);
+        case 8: return launch_pair_scan<KhornForceUnrolled<8>>(P, d, (hipStream_t)stream, ws, ws_bytes);
+        case 16: return launch_pair_scan<KhornForceUnrolled<16>>(P, d, (hipStream_t)stream, ws, ws_bytes);
+        case 32: return launch_pair_scan<KhornForceUnrolled<32>>(P, d, (hipStream_t)stream, ws, ws_bytes);
         default: return TDR_ERR_UNSUPPORTED;
     }
 }
 
 /* The two-component form (side: (n, 5)). */
 int tdr_khorn_grad_f32(const float* packed, int64_t n, int d, const float* side, float log_n, float* grad, void* stream) {
-    return tdr_khorn_grad_nc_f32(packed, n, d, side, 2, log_n, grad, stream);
+    return tdr_khorn_grad_nc_f32(packed, n, d, side, 2, log_n, grad, nullptr, 0, stream);
 }
 
 /* One symmetric Sinkhorn update on the embedding Z (n, nc), student kernel, eps = 1:

@@ -6,7 +6,7 @@ from typing import Dict, Optional, Type, Union
 import torch
 
 from torchdr_amd import _lib
-from torchdr_amd.affinity.entropic import (SinkhornAffinity, SymmetricEntropicAffinity, pad_embedding, sea_rowstats,
+from torchdr_amd.affinity.entropic import (SinkhornAffinity, SymmetricEntropicAffinity, pad_embedding, pair_scan_workspace, sea_rowstats,
                                            sinkhorn_student_adjoint, sinkhorn_student_dual)
 from torchdr_amd.neighbor_embedding.base import NeighborEmbedding
 from torchdr_amd.utils import bool_arg
@@ -91,11 +91,12 @@ class TSNEkhorn(NeighborEmbedding):
         out.n_iter_ = k
         self.dual_sinkhorn_ = dual.detach()
         grad = torch.empty((n, w), dtype=torch.float32, device=self.device_)
+        ws, ws_bytes, _keep = pair_scan_workspace(n, w, self.device_)
         L = _lib.lib()
         if not self.unrolling:
             side = torch.cat([self._mu[:, None], self._e[:, None], Zp, dual.exp()[:, None]], dim=1).contiguous()
             _lib.check(L.tdr_khorn_grad_nc_f32(_lib.ptr(self._packed.data), n, self._packed.d, _lib.ptr(side), w, math.log(n),
-                                               _lib.ptr(grad), _lib.stream_ptr()), "tdr_khorn_grad_nc_f32")
+                                               _lib.ptr(grad), ws, ws_bytes, _lib.stream_ptr()), "tdr_khorn_grad_nc_f32")
         else:
             if self._p_marginals is None:    # d loss / d f_i = -(sum_j P_ij + sum_j P_ji); P is fixed during the fit
                 S, _ = sea_rowstats(self._packed, self._mu, self._e, False)
@@ -103,7 +104,7 @@ class TSNEkhorn(NeighborEmbedding):
             A, B = sinkhorn_student_adjoint(Zp, rec, -self._p_marginals, out.zero_diag)
             side = torch.cat([self._mu[:, None], self._e[:, None], Zp, 0.25 * A, B], dim=1).contiguous()
             _lib.check(L.tdr_khorn_grad_unrolled_f32(_lib.ptr(self._packed.data), n, self._packed.d, _lib.ptr(side), w,
-                                                     math.log(n), _lib.ptr(grad), _lib.stream_ptr()),
+                                                     math.log(n), _lib.ptr(grad), ws, ws_bytes, _lib.stream_ptr()),
                        "tdr_khorn_grad_unrolled_f32")
         return (grad if w == nc else grad[:, :nc].contiguous()), False
 
