@@ -448,20 +448,22 @@ __global__ __launch_bounds__(256) void pair_scan_merge_kernel(const PairScanPara
 //   red_j = -LSE_i(log K_ij + f_i),  log K_ij = -log(1 + d_ij) / eps,  d_ii += 1e12 when zero_diag
 // With eps == 1:  red_j = -( fmax + log sum_i exp(f_i - fmax) / (1 + d_ij) )  -- no per-pair transcendental.
 // out[j] = 0.5 * (f_j + red_j)  (the averaged update), resid2 += (out[j] - red_j)^2  (convergence test :738).
-// s_j = sum_i v_i / (1 + |z_j - z_i|^2) for the thread's row j (all 256 threads of the workgroup take part in the staging)
-template <int NC>
+// s_j = sum_i v_i / (1 + |z_j - z_i|^2) for the thread's row j (all BS threads of the workgroup take part in the staging).
+// BS = 256, or 64 when 256-row workgroups would be too few to load the CUs evenly (N = 200k: 782 workgroups on 256 CUs is
+// 3.05 per CU -- a quarter of the launch runs with most CUs idle; 3125 single-wavefront workgroups leave a 6 % tail).
+template <int NC, int BS>
 __device__ __forceinline__ float student_weighted_sum(const float* __restrict__ Z, const float* __restrict__ v, int64_t n,
                                                       int64_t j, const float (&zj)[NC], int zero_diag, float diag_add,
                                                       float* tile) {
     float s = 0.f;
-    for (int64_t i0 = 0; i0 < n; i0 += 256) {
+    for (int64_t i0 = 0; i0 < n; i0 += BS) {
         __syncthreads();
         const int64_t i = i0 + threadIdx.x;
 #pragma unroll
         for (int c = 0; c < NC; ++c) tile[threadIdx.x * (NC + 1) + c] = (i < n) ? Z[(size_t)i * NC + c] : 0.f;
         tile[threadIdx.x * (NC + 1) + NC] = (i < n) ? v[i] : 0.f;
         __syncthreads();
-        const int lim = (int)((n - i0 < 256) ? (n - i0) : 256);
+        const int lim = (int)((n - i0 < BS) ? (n - i0) : BS);
         for (int t = 0; t < lim; ++t) {
             float d = 0.f;
 #pragma unroll
@@ -473,18 +475,18 @@ __device__ __forceinline__ float student_weighted_sum(const float* __restrict__ 
     return s;
 }
 
-template <int NC>
-__global__ __launch_bounds__(256) void sinkhorn_pass_kernel(const float* __restrict__ Z, const float* __restrict__ f,
-                                                            const float* __restrict__ Ef, float fmax, int64_t n,
-                                                            int zero_diag, float diag_add, float* __restrict__ f_new,
-                                                            float* __restrict__ resid2) {
-    __shared__ float tile[256 * (NC + 1)];
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+template <int NC, int BS>
+__global__ __launch_bounds__(BS) void sinkhorn_pass_kernel(const float* __restrict__ Z, const float* __restrict__ f,
+                                                           const float* __restrict__ Ef, float fmax, int64_t n,
+                                                           int zero_diag, float diag_add, float* __restrict__ f_new,
+                                                           float* __restrict__ resid2) {
+    __shared__ float tile[BS * (NC + 1)];
+    const int64_t j = (int64_t)blockIdx.x * BS + threadIdx.x;
     const bool have = j < n;
     float zj[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) zj[c] = have ? Z[(size_t)j * NC + c] : 0.f;
-    const float s = student_weighted_sum<NC>(Z, Ef, n, j, zj, zero_diag, diag_add, tile);
+    const float s = student_weighted_sum<NC, BS>(Z, Ef, n, j, zj, zero_diag, diag_add, tile);
     float r2 = 0.f;
     if (have) {
         const float red = -(fmax + logf(s));
@@ -498,18 +500,21 @@ __global__ __launch_bounds__(256) void sinkhorn_pass_kernel(const float* __restr
 }
 
 // out_j = sum_i v_i / (1 + d_ij): the Student-kernel mat-vec of the adjoint Sinkhorn updates (v may be negative)
-template <int NC>
-__global__ __launch_bounds__(256) void student_matvec_kernel(const float* __restrict__ Z, const float* __restrict__ v, int64_t n,
-                                                             int zero_diag, float diag_add, float* __restrict__ out) {
-    __shared__ float tile[256 * (NC + 1)];
-    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+template <int NC, int BS>
+__global__ __launch_bounds__(BS) void student_matvec_kernel(const float* __restrict__ Z, const float* __restrict__ v, int64_t n,
+                                                            int zero_diag, float diag_add, float* __restrict__ out) {
+    __shared__ float tile[BS * (NC + 1)];
+    const int64_t j = (int64_t)blockIdx.x * BS + threadIdx.x;
     const bool have = j < n;
     float zj[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) zj[c] = have ? Z[(size_t)j * NC + c] : 0.f;
-    const float s = student_weighted_sum<NC>(Z, v, n, j, zj, zero_diag, diag_add, tile);
+    const float s = student_weighted_sum<NC, BS>(Z, v, n, j, zj, zero_diag, diag_add, tile);
     if (have) out[j] = s;
 }
+
+// single-wavefront workgroups until 256-row ones number >= 16 per CU
+static inline bool student_small_blocks(int64_t n) { return (n + 255) / 256 < 16 * 256; }
 
 static inline int dense_pick_kq(int d) {
     if (d <= 32) return 4;
@@ -674,8 +679,13 @@ int tdr_sinkhorn_pass_f32(const float* Z, int nc, const float* f, const float* E
                           float diag_add, float* f_new, float* resid2, void* stream) {
     if (!Z || !f || !Ef || !f_new || !resid2 || n <= 0) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)((n + 255) / 256);
-#define TDR_SK(NCV) hipLaunchKernelGGL(sinkhorn_pass_kernel<NCV>, dim3(grid), dim3(256), 0, st, Z, f, Ef, fmax, n, zero_diag, diag_add, f_new, resid2)
+    const bool small = student_small_blocks(n);
+    const unsigned grid = (unsigned)(small ? (n + 63) / 64 : (n + 255) / 256);
+#define TDR_SK(NCV)                                                                                                         \
+    {                                                                                                                       \
+        if (small) hipLaunchKernelGGL((sinkhorn_pass_kernel<NCV, 64>), dim3(grid), dim3(64), 0, st, Z, f, Ef, fmax, n, zero_diag, diag_add, f_new, resid2); \
+        else hipLaunchKernelGGL((sinkhorn_pass_kernel<NCV, 256>), dim3(grid), dim3(256), 0, st, Z, f, Ef, fmax, n, zero_diag, diag_add, f_new, resid2);    \
+    }
     switch (nc) {
         case 2: TDR_SK(2); break;
         case 3: TDR_SK(3); break;
@@ -696,8 +706,13 @@ int tdr_student_matvec_f32(const float* Z, int nc, const float* v, int64_t n, in
                            void* stream) {
     if (!Z || !v || !out || n <= 0) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)((n + 255) / 256);
-#define TDR_MV(NCV) hipLaunchKernelGGL(student_matvec_kernel<NCV>, dim3(grid), dim3(256), 0, st, Z, v, n, zero_diag, diag_add, out)
+    const bool small = student_small_blocks(n);
+    const unsigned grid = (unsigned)(small ? (n + 63) / 64 : (n + 255) / 256);
+#define TDR_MV(NCV)                                                                                                         \
+    {                                                                                                                       \
+        if (small) hipLaunchKernelGGL((student_matvec_kernel<NCV, 64>), dim3(grid), dim3(64), 0, st, Z, v, n, zero_diag, diag_add, out); \
+        else hipLaunchKernelGGL((student_matvec_kernel<NCV, 256>), dim3(grid), dim3(256), 0, st, Z, v, n, zero_diag, diag_add, out);    \
+    }
     switch (nc) {
         case 2: TDR_MV(2); break;
         case 3: TDR_MV(3); break;
