@@ -14,7 +14,7 @@ import torch
 
 from torchdr_amd import _lib
 from torchdr_amd.distributed import DistributedContext
-from torchdr_amd.utils.dataloader import is_dataloader, materialize_dataloader
+from torchdr_amd.utils.dataloader import is_dataloader
 from torchdr_amd.utils.misc import as_float32
 
 LIST_METRICS = ["euclidean", "sqeuclidean", "manhattan", "angular", "sqhyperbolic"]
