@@ -217,11 +217,26 @@ typedef __attribute__((address_space(3))) void* dlptr_t;
 // One tile step, software pipelined like the kNN scan (tdr_knn.hip): the MFMA chain of tile T runs with the
 // row reduction of tile T-1 (held in `accp`) placed BETWEEN its MFMAs, so the exp-heavy epilogue executes in
 // the shadow of the 64-cycle matrix instructions.  Quarter `g` of the previous tile = its rows 8g+4h .. +3.
+// `edge` (uniform over the wavefront): the tile holds the diagonal of one of the wavefront's rows or database rows beyond
+// n_db -- every other tile takes the lean loop (no 64-bit index compare, no diagonal select, no bounds mask per pair; the
+// epilogue's vector instructions share the issue port with the MFMAs and bound the scan together with them).
 template <class Epi>
 __device__ __forceinline__ void reduce_part(Epi& epi, const PairScanParams& P, const f32x16& accp, const float* ynp,
-                                            const float* sd, int g, int h, float xn, int64_t row_base, int64_t gq) {
+                                            const float* sd, int g, int h, float xn, int64_t row_base, int64_t gq, bool edge) {
     constexpr int SIDE = Epi::SIDE;
     const f32x4 y4 = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
+    if (!edge) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = e + 8 * g + 4 * h;  // database row inside the tile
+            const float c = __builtin_fmaf(-2.0f, accp[4 * g + e], __fadd_rn(xn, y4[e]));
+            float sj[SIDE];
+#pragma unroll
+            for (int s_ = 0; s_ < SIDE; ++s_) sj[s_] = sd[i * SIDE + s_];
+            epi.add(c, sj, P);
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
@@ -242,7 +257,7 @@ template <int KQ, class Epi, bool HAVE_PREV>
 __device__ __forceinline__ void pair_tile_step(Epi& epi, const PairScanParams& P, const float* __restrict__ img,
                                                const float (&b)[4 * KQ], f32x16& acc, const f32x16& accp,
                                                const float* ynp_prev, const float* sd_prev, int lane, int h, float xn,
-                                               int64_t row_base_prev, int64_t gq) {
+                                               int64_t row_base_prev, int64_t gq, bool edge_prev) {
     constexpr int GQ = (KQ >= 4) ? 4 : KQ, NG = KQ / GQ;
     constexpr int PARTS_PER_GROUP = (4 + NG - 1) / NG;
 #pragma unroll
@@ -262,7 +277,7 @@ __device__ __forceinline__ void pair_tile_step(Epi& epi, const PairScanParams& P
         if (HAVE_PREV) {
 #pragma unroll
             for (int pp = 0; pp < PARTS_PER_GROUP; ++pp)
-                if (part + pp < 4) reduce_part<Epi>(epi, P, accp, ynp_prev, sd_prev, part + pp, h, xn, row_base_prev, gq);
+                if (part + pp < 4) reduce_part<Epi>(epi, P, accp, ynp_prev, sd_prev, part + pp, h, xn, row_base_prev, gq, edge_prev);
         }
         part += PARTS_PER_GROUP;
 #pragma unroll
@@ -282,7 +297,7 @@ __device__ __forceinline__ void pair_tile_step(Epi& epi, const PairScanParams& P
             if (HAVE_PREV) {
 #pragma unroll
                 for (int pp = 0; pp < PARTS_PER_GROUP; ++pp)
-                    if (part + pp < 4) reduce_part<Epi>(epi, P, accp, ynp_prev, sd_prev, part + pp, h, xn, row_base_prev, gq);
+                    if (part + pp < 4) reduce_part<Epi>(epi, P, accp, ynp_prev, sd_prev, part + pp, h, xn, row_base_prev, gq, edge_prev);
             }
             part += PARTS_PER_GROUP;
 #pragma unroll
@@ -297,8 +312,14 @@ __device__ __forceinline__ void pair_tile_step(Epi& epi, const PairScanParams& P
     }
 }
 
+// Four workgroups per CU (<= 128 VGPRs) for the statistics scans at D <= 64 -- measured at N = 200k, D = 64 (SeaStats):
+// 60.4 ms per launch at three wavefronts per SIMD, 58.0 ms at four (two spilled registers); the force functors carry the
+// embedding coordinates and would spill heavily, they stay at two.
+#ifndef TDR_PAIR_MINBLK
+#define TDR_PAIR_MINBLK 4
+#endif
 template <int KQ, class Epi>
-__global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams P) {
+__global__ __launch_bounds__(256, (KQ <= 8 && Epi::SIDE <= 2) ? TDR_PAIR_MINBLK : 2) void pair_scan_kernel(const PairScanParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int TILE_F = KQ * 256 + 64;
     constexpr int IMG_F = KQ * 256;
@@ -376,13 +397,19 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
     if (n_tiles > T0) { stage(T0); stage_side_store(T0); }
     __syncthreads();
 
+    // tiles that need the careful epilogue: the last one when n_db is ragged, and the one(s) holding the wavefront's diagonal
+    const int64_t dq0 = qt * 32 + P.q_offset;
+    auto is_edge = [&](int Tp) -> bool {
+        const int64_t r0 = (int64_t)Tp * 32;
+        return (r0 + 32 > P.n_db) || (P.exclude_diag && r0 < dq0 + 32 && r0 + 32 > dq0);
+    };
     f32x16 accA, accB;
     int T = T0;
     if (T < n_tiles) {
         const bool nx = T + 1 < n_tiles;
         if (nx) stage(T + 1);
         if (wave_active)
-            pair_tile_step<KQ, Epi, false>(epi, P, (T & 1) ? tile1 : tile0, b, accA, accA, nring, sring, lane, h, xn, 0, gq);
+            pair_tile_step<KQ, Epi, false>(epi, P, (T & 1) ? tile1 : tile0, b, accA, accA, nring, sring, lane, h, xn, 0, gq, false);
         if (nx) stage_side_store(T + 1);
         __syncthreads();
         ++T;
@@ -394,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
             if (wave_active)
                 pair_tile_step<KQ, Epi, true>(epi, P, (T & 1) ? tile1 : tile0, b, accB, accA,
                                               nring + ((T - 1) & 3) * 64 + 4 * h, sring + ((T - 1) & 3) * SIDE_SLOT, lane, h,
-                                              xn, (int64_t)(T - 1) * 32 + 4 * h, gq);
+                                              xn, (int64_t)(T - 1) * 32 + 4 * h, gq, is_edge(T - 1));
             if (nx) stage_side_store(T + 1);
             __syncthreads();
             ++T;
@@ -405,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
             if (wave_active)
                 pair_tile_step<KQ, Epi, true>(epi, P, (T & 1) ? tile1 : tile0, b, accA, accB,
                                               nring + ((T - 1) & 3) * 64 + 4 * h, sring + ((T - 1) & 3) * SIDE_SLOT, lane, h,
-                                              xn, (int64_t)(T - 1) * 32 + 4 * h, gq);
+                                              xn, (int64_t)(T - 1) * 32 + 4 * h, gq, is_edge(T - 1));
             if (nx) stage_side_store(T + 1);
             __syncthreads();
             ++T;
@@ -418,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void pair_scan_kernel(const PairScanParams 
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             reduce_part<Epi>(epi, P, accA, nring + (Tl & 3) * 64 + 4 * h, sring + (Tl & 3) * SIDE_SLOT, g, h, xn,
-                             (int64_t)Tl * 32 + 4 * h, gq);
+                             (int64_t)Tl * 32 + 4 * h, gq, is_edge(Tl));
         // combine the two lanes (h = 0, 1) that share a row
         Epi other;
         other.shfl_from(epi, lane ^ 32);
