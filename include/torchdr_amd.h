@@ -362,6 +362,12 @@ int tdr_perm_negatives_debug(uint64_t seed, int n_iter, int64_t n_total, int n_n
 /* gradient pieces of neighbor_embedding/tsne.py:172-180 (dense Student-t partition function) */
 int tdr_tsne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* F, double* S,
                            void* stream);
+/* the same with the columns spread over several workgroups per row block (a 256-row block against all columns is one
+ * workgroup: N = 50k is 196 workgroups for 256 CUs): `ws` of tdr_tsne_repulsion_workspace_bytes() bytes holds the
+ * per-segment partial forces, added in segment order; NULL / too small / 0 bytes needed: the unsplit launch */
+int64_t tdr_tsne_repulsion_workspace_bytes(int64_t n_total, int64_t n_rows, int nc);
+int tdr_tsne_repulsion_split_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* F, double* S,
+                                 void* ws, int64_t ws_bytes, void* stream);
 int tdr_add_scaled_f32(float* grad, const float* F, const double* S, float coef, int64_t n, void* stream);
 /* torch.optim.SGD step of affinity_matcher.py:427 (+ the NaN guard of :315) */
 int tdr_sgd_step_f32(float* Z, const float* grad, float* buf, int64_t n, float lr, float momentum, int first,

@@ -641,3 +641,38 @@ def test_permutation_gradient_equals_the_scatter_form_on_the_same_negatives(kind
     rep = (R.largevis_repulsion_grad(Zc, fc, n) if kind == 0 else R.infotsne_repulsion_grad(Zc, fc, n)) * (0.37 / (2.0 / n))
     ref = attr + rep
     assert torch.allclose(g1.cpu(), ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("n,nc", [(20_000, 2), (33_333, 3), (9_000, 5)])
+def test_tsne_repulsion_with_column_segments_equals_the_unsplit_launch(n, nc):
+    """tdr_tsne_repulsion_split_f32 cuts the columns into segments (several workgroups per row block) and adds the per-segment
+    forces in order; the segment cut depends on N only, so a row chunk (what a rank of a sharded fit evaluates) gives the
+    same bits as the corresponding rows of the full launch."""
+    from torchdr_amd import _lib
+
+    L = _lib.lib()
+    Z = (torch.randn(n, nc, generator=torch.Generator().manual_seed(2)) * 6).cuda().contiguous()
+    nb = int(L.tdr_tsne_repulsion_workspace_bytes(n, n, nc))
+    assert nb > 0 and int(L.tdr_tsne_repulsion_workspace_bytes(1000, 1000, 2)) == 0
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    F0, F1 = torch.empty((n, nc), device="cuda"), torch.empty((n, nc), device="cuda")
+    S0, S1 = torch.zeros(1, dtype=torch.float64, device="cuda"), torch.zeros(1, dtype=torch.float64, device="cuda")
+    _lib.check(L.tdr_tsne_repulsion_f32(_lib.ptr(Z), nc, n, 0, n, _lib.ptr(F0), _lib.ptr(S0), _lib.stream_ptr()), "rep")
+    _lib.check(L.tdr_tsne_repulsion_split_f32(_lib.ptr(Z), nc, n, 0, n, _lib.ptr(F1), _lib.ptr(S1), _lib.ptr(ws), nb, _lib.stream_ptr()), "split")
+    assert abs(float(S0) - float(S1)) < 1e-6 * float(S0)
+    assert torch.allclose(F0, F1, rtol=1e-4, atol=2e-6 * float(F0.abs().max()))
+    # a row chunk of a sharded fit: same bits as the rows of the full launch
+    r0, nr = 4096 + 77, n // 3
+    Fc = torch.empty((nr, nc), device="cuda")
+    Sc = torch.zeros(1, dtype=torch.float64, device="cuda")
+    wsc = torch.empty(int(L.tdr_tsne_repulsion_workspace_bytes(n, nr, nc)), dtype=torch.uint8, device="cuda")
+    _lib.check(L.tdr_tsne_repulsion_split_f32(_lib.ptr(Z), nc, n, r0, nr, _lib.ptr(Fc), _lib.ptr(Sc), _lib.ptr(wsc), wsc.numel(),
+                                              _lib.stream_ptr()), "split chunk")
+    assert torch.equal(Fc, F1[r0:r0 + nr])
+    # against the closed form in float64
+    Zd = Z.double().cpu()
+    sub = torch.arange(0, n, max(n // 200, 1))
+    D = ((Zd[sub, None, :] - Zd[None, :, :]) ** 2).sum(-1)
+    W = 1 / (1 + D)
+    ref = ((W ** 2)[:, :, None] * (Zd[sub, None, :] - Zd[None, :, :])).sum(1)
+    assert torch.allclose(F1.cpu().double()[sub], ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))

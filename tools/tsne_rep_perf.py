@@ -13,15 +13,22 @@ from torchdr_amd import _lib  # noqa: E402
 if len(sys.argv) > 1:
     _lib.LIB_PATH = os.path.join(ROOT, sys.argv[1])
 L = _lib.lib()
+SPLIT = os.environ.get("SPLIT", "1") != "0"
 out = {}
-for n, nc in ((50_000, 2), (100_000, 2), (200_000, 2), (100_000, 3)):
+for n, nc in ((5_000, 2), (20_000, 2), (50_000, 2), (100_000, 2), (200_000, 2), (100_000, 3)):
     Z = (torch.randn(n, nc, generator=torch.Generator().manual_seed(0)) * 10).cuda().contiguous()
     F = torch.empty((n, nc), device="cuda")
     S = torch.zeros(1, dtype=torch.float64, device="cuda")
 
+    nb = int(L.tdr_tsne_repulsion_workspace_bytes(n, n, nc)) if (SPLIT and hasattr(L, "tdr_tsne_repulsion_workspace_bytes")) else 0
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device="cuda")
+
     def run():
         S.zero_()
-        _lib.check(L.tdr_tsne_repulsion_f32(_lib.ptr(Z), nc, n, 0, n, _lib.ptr(F), _lib.ptr(S), _lib.stream_ptr()), "rep")
+        if nb:
+            _lib.check(L.tdr_tsne_repulsion_split_f32(_lib.ptr(Z), nc, n, 0, n, _lib.ptr(F), _lib.ptr(S), _lib.ptr(ws), nb, _lib.stream_ptr()), "rep")
+        else:
+            _lib.check(L.tdr_tsne_repulsion_f32(_lib.ptr(Z), nc, n, 0, n, _lib.ptr(F), _lib.ptr(S), _lib.stream_ptr()), "rep")
 
     run()
     torch.cuda.synchronize()

@@ -535,7 +535,13 @@ typedef float ne_f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NC, bool PAD = false>
 __global__ __launch_bounds__(256) void tsne_repulsion_kernel(const float* __restrict__ Z, int64_t n_total, int64_t row0,
-                                                             int64_t n_rows, float* __restrict__ F, double* __restrict__ S, int nc_) {
+                                                             int64_t n_rows, float* __restrict__ F, double* __restrict__ S, int nc_,
+                                                             int64_t cols_per_seg) {
+    // blockIdx.y = column segment (tdr_tsne_repulsion_split_f32): this workgroup sums over columns [j_lo, j_hi) and writes
+    // its rows' partial forces to plane blockIdx.y of F (n_seg planes of n_rows x nc; one plane = the result when unsplit)
+    const int64_t j_lo = (int64_t)blockIdx.y * cols_per_seg;
+    const int64_t j_hi = (j_lo + cols_per_seg < n_total) ? j_lo + cols_per_seg : n_total;
+    F += (size_t)blockIdx.y * n_rows * (PAD ? nc_ : NC);
     const int nc = PAD ? nc_ : NC;
     __shared__ __attribute__((aligned(16))) float tile[256 * NC];
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -549,14 +555,14 @@ __global__ __launch_bounds__(256) void tsne_repulsion_kernel(const float* __rest
         f2[c] = ne_f32x2{0.f, 0.f};
     }
     ne_f32x2 s2 = ne_f32x2{0.f, 0.f};
-    for (int64_t j0 = 0; j0 < n_total; j0 += 256) {
+    for (int64_t j0 = j_lo; j0 < j_hi; j0 += 256) {
         __syncthreads();
         const int64_t j = j0 + threadIdx.x;
         float* rec = tile + (threadIdx.x >> 1) * (2 * NC) + (threadIdx.x & 1);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) rec[2 * c] = (j < n_total && c < nc) ? Z[(size_t)j * nc + c] : 0.f;
+        for (int c = 0; c < NC; ++c) rec[2 * c] = (j < j_hi && c < nc) ? Z[(size_t)j * nc + c] : 0.f;
         __syncthreads();
-        const int lim = (int)((n_total - j0 < 256) ? (n_total - j0) : 256);
+        const int lim = (int)((j_hi - j0 < 256) ? (j_hi - j0) : 256);
         const int pairs = lim >> 1;
         for (int p = 0; p < pairs; ++p) {
             const ne_f32x2* q = reinterpret_cast<const ne_f32x2*>(tile + p * (2 * NC));
@@ -593,6 +599,16 @@ __global__ __launch_bounds__(256) void tsne_repulsion_kernel(const float* __rest
     } else s = 0.f;
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) atomicAdd(S, (double)s);
+}
+
+// out[i] = planes[0][i] + planes[1][i] + ... in plane order
+__global__ __launch_bounds__(256) void sum_planes_kernel(const float* __restrict__ planes, int n_planes, int64_t cnt,
+                                                         float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cnt) return;
+    float a = planes[i];
+    for (int p = 1; p < n_planes; ++p) a += planes[(size_t)p * cnt + i];
+    out[i] = a;
 }
 
 // grad[row0 + r] += coef / S * F[r]
@@ -963,20 +979,63 @@ int tdr_perm_negatives_debug(uint64_t seed, int n_iter, int64_t n_total, int n_n
     return TDR_OK;
 }
 
+// column segments of the dense TSNE repulsion: >= ~4096 workgroups, segments of >= 1024 columns (multiples of the 256-column tile)
+// (a function of n_total alone: a rank that holds a row chunk cuts the columns where the single-process launch does, so the
+// sums keep their association whatever the sharding)
+static inline int tsne_rep_segments(int64_t n_total) {
+    const int64_t row_blocks = (n_total + 255) / 256;
+    int64_t s = (4096 + row_blocks - 1) / row_blocks;
+    if (s > n_total / 1024) s = n_total / 1024;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : (int)s;
+}
+
+static int tsne_repulsion_launch(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* F, double* S,
+                                 int n_seg, hipStream_t st) {
+    const int64_t cols = n_seg > 1 ? (((n_total + n_seg - 1) / n_seg + 255) / 256) * 256 : n_total;
+    const dim3 grid((unsigned)((n_rows + 255) / 256), (unsigned)(n_seg > 1 ? (n_total + cols - 1) / cols : 1));
+    if (nc == 2) hipLaunchKernelGGL(tsne_repulsion_kernel<2>, grid, dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc, cols);
+    else if (nc == 3) hipLaunchKernelGGL(tsne_repulsion_kernel<3>, grid, dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc, cols);
+    else if (nc >= 1 && nc <= 4) hipLaunchKernelGGL((tsne_repulsion_kernel<4, true>), grid, dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc, cols);
+    else if (nc <= 8 && nc >= 1) hipLaunchKernelGGL((tsne_repulsion_kernel<8, true>), grid, dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc, cols);
+    else if (nc <= 16 && nc >= 1) hipLaunchKernelGGL((tsne_repulsion_kernel<16, true>), grid, dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc, cols);
+    else if (nc <= 32 && nc >= 1) hipLaunchKernelGGL((tsne_repulsion_kernel<32, true>), grid, dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc, cols);
+    else return TDR_ERR_UNSUPPORTED;
+    TDR_CHECK_LAUNCH();
+    return (int)grid.y;     // > 0: the number of planes written
+}
+
 /* TSNE dense repulsion for rows [row0, row0+n_rows): F (n_rows, nc) = sum_j (z_i - z_j)/(1+d)^2 and
  * *S (double, device, caller-zeroed) += sum_ij 1/(1+d_ij). */
 int tdr_tsne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* F, double* S,
                            void* stream) {
     if (!Z || !F || !S || n_rows <= 0) return TDR_ERR_BAD_ARG;
+    const int rc = tsne_repulsion_launch(Z, nc, n_total, row0, n_rows, F, S, 1, (hipStream_t)stream);
+    return rc > 0 ? TDR_OK : rc;
+}
+
+/* Bytes of the workspace with which tdr_tsne_repulsion_split_f32 spreads the columns over several workgroups per row block
+ * (0 = the launch of this size is not split).  A row block of 256 rows against all columns is one workgroup: N = 50k is 196
+ * workgroups for 256 CUs, N = 100k 1.5 per CU. */
+int64_t tdr_tsne_repulsion_workspace_bytes(int64_t n_total, int64_t n_rows, int nc) {
+    if (n_total <= 0 || n_rows <= 0 || nc < 1) return 0;
+    const int n_seg = tsne_rep_segments(n_total);
+    return n_seg > 1 ? (int64_t)n_seg * n_rows * nc * (int64_t)sizeof(float) : 0;
+}
+
+/* The same result as tdr_tsne_repulsion_f32 with the columns cut into segments (blockIdx.y), each writing its partial forces to
+ * a plane of `ws`; the planes are added in segment order (a fixed association).  ws NULL / too small: the unsplit launch. */
+int tdr_tsne_repulsion_split_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* F, double* S,
+                                 void* ws, int64_t ws_bytes, void* stream) {
+    if (!Z || !F || !S || n_rows <= 0) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned grid = (unsigned)((n_rows + 255) / 256);
-    if (nc == 2) hipLaunchKernelGGL(tsne_repulsion_kernel<2>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
-    else if (nc == 3) hipLaunchKernelGGL(tsne_repulsion_kernel<3>, dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
-    else if (nc >= 1 && nc <= 4) hipLaunchKernelGGL((tsne_repulsion_kernel<4, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
-    else if (nc <= 8 && nc >= 1) hipLaunchKernelGGL((tsne_repulsion_kernel<8, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
-    else if (nc <= 16 && nc >= 1) hipLaunchKernelGGL((tsne_repulsion_kernel<16, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
-    else if (nc <= 32 && nc >= 1) hipLaunchKernelGGL((tsne_repulsion_kernel<32, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, F, S, nc);
-    else return TDR_ERR_UNSUPPORTED;
+    const int n_seg = tsne_rep_segments(n_total);
+    if (n_seg <= 1 || !ws || ws_bytes < (int64_t)n_seg * n_rows * nc * (int64_t)sizeof(float))
+        return tdr_tsne_repulsion_f32(Z, nc, n_total, row0, n_rows, F, S, stream);
+    const int planes = tsne_repulsion_launch(Z, nc, n_total, row0, n_rows, (float*)ws, S, n_seg, st);
+    if (planes <= 0) return planes;
+    const int64_t cnt = n_rows * nc;
+    hipLaunchKernelGGL(sum_planes_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (const float*)ws, planes, cnt, F);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

@@ -75,11 +75,18 @@ class TSNE(NeighborEmbedding):
         )
         F = torch.empty((self.chunk_size_, nc), dtype=dt, device=self.device_)
         S = torch.zeros(1, dtype=torch.float64, device=self.device_)
-        _lib.check(
-            _lib.fn("tdr_tsne_repulsion", dt)(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
-                                              _lib.ptr(F), _lib.ptr(S), st),
-            "tdr_tsne_repulsion",
-        )
+        ws_bytes = int(L.tdr_tsne_repulsion_workspace_bytes(n, self.chunk_size_, nc)) if dt == torch.float32 else 0
+        if ws_bytes > 0:    # columns spread over several workgroups per row block (N <= ~1M: a row block alone is too coarse)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device_)
+            _lib.check(L.tdr_tsne_repulsion_split_f32(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
+                                                      _lib.ptr(F), _lib.ptr(S), _lib.ptr(ws), ws_bytes, st),
+                       "tdr_tsne_repulsion_split_f32")
+        else:
+            _lib.check(
+                _lib.fn("tdr_tsne_repulsion", dt)(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
+                                                  _lib.ptr(F), _lib.ptr(S), st),
+                "tdr_tsne_repulsion",
+            )
         if self.world_size > 1:
             from torchdr_amd.parallel import allreduce_
 
