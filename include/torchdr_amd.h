@@ -405,14 +405,17 @@ int tdr_khorn_grad_nc_f32(const float* packed, int64_t n, int d, const float* si
  * b^k = exp(f^{k-1} - max), zero for updates that did not run. */
 int tdr_khorn_grad_unrolled_f32(const float* packed, int64_t n, int d, const float* side, int nc, float log_n, float* grad,
                                 void* ws, int64_t ws_bytes, void* stream);
+/* optional workspace of the two all-pairs passes on the embedding below (ws / ws_bytes; NULL = none): the columns are then
+ * spread over several workgroups per block of 256 rows and the per-segment sums added in order; 0 = not split at this size */
+int64_t tdr_student_workspace_bytes(int64_t n);
 /* affinity/entropic.py:733-740: one symmetric log-domain Sinkhorn update, student kernel on the embedding
  * (nc in {2, 3, 4, 8, 16, 32}) */
 int tdr_sinkhorn_pass_f32(const float* Z, int nc, const float* f, const float* Ef, float fmax, int64_t n, int zero_diag,
-                          float diag_add, float* f_new, float* resid2, void* stream);
+                          float diag_add, float* f_new, float* resid2, void* ws, int64_t ws_bytes, void* stream);
 /* out_j = sum_i v_i / (1 + |z_i - z_j|^2): the mat-vec of the adjoint of that update (what autograd runs backwards through
  * affinity/entropic.py:735 when with_grad=True); the diagonal term is weighted 1 / (1 + diag_add) when zero_diag */
 int tdr_student_matvec_f32(const float* Z, int nc, const float* v, int64_t n, int zero_diag, float diag_add, float* out,
-                           void* stream);
+                           void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- float64 embedding loop (csrc/tdr_embed_f64.hip) ------------------------------------------------------------------
  * The reference computes in the dtype of its input and runs every neighbour-embedding method in float32 and float64

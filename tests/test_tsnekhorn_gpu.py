@@ -98,6 +98,46 @@ def test_split_pair_scan_equals_the_unsplit_scan():
     assert torch.equal(S2, out[False][0]) and torch.equal(H2, out[False][1])
 
 
+@pytest.mark.parametrize("nc", [2, 3, 8])
+def test_split_passes_on_the_embedding_equal_the_unsplit_ones(nc):
+    """Sinkhorn update and adjoint mat-vec on the embedding with the columns spread over several workgroups per row block
+    (workspace given) against the one-workgroup-per-row-block launches, and against a float64 evaluation on sampled rows."""
+    from torchdr_amd import _lib
+
+    L = _lib.lib()
+    n = 20_011
+    gen = torch.Generator().manual_seed(3)
+    Z = (torch.randn(n, nc, generator=gen) * 3).cuda().contiguous()
+    f = (torch.randn(n, generator=gen) * 0.3).cuda()
+    v = torch.randn(n, generator=gen).cuda()
+    fmax = float(f.max())
+    Ef = (f - fmax).exp()
+    nb = int(L.tdr_student_workspace_bytes(n))
+    assert nb > 0 and int(L.tdr_student_workspace_bytes(1500)) == 0
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    res = {}
+    for split in (False, True):
+        fn, r2, out = torch.empty(n, device="cuda"), torch.zeros(1, device="cuda"), torch.empty(n, device="cuda")
+        w, b_ = (_lib.ptr(ws), nb) if split else (None, 0)
+        _lib.check(L.tdr_sinkhorn_pass_f32(_lib.ptr(Z), nc, _lib.ptr(f), _lib.ptr(Ef), fmax, n, 1, 1e12, _lib.ptr(fn), _lib.ptr(r2), w, b_,
+                                           _lib.stream_ptr()), "pass")
+        _lib.check(L.tdr_student_matvec_f32(_lib.ptr(Z), nc, _lib.ptr(v), n, 1, 1e12, _lib.ptr(out), w, b_, _lib.stream_ptr()), "matvec")
+        torch.cuda.synchronize()
+        res[split] = (fn, r2, out)
+    assert torch.allclose(res[False][0], res[True][0], rtol=1e-5, atol=1e-5), float((res[False][0] - res[True][0]).abs().max())
+    assert abs(float(res[False][1]) - float(res[True][1])) < 1e-4 * float(res[False][1])
+    scale = float(res[False][2].abs().max())
+    assert torch.allclose(res[False][2], res[True][2], rtol=1e-4, atol=5e-5 * scale)   # 20 000 signed terms that cancel
+    sub = torch.arange(0, n, 97)
+    Zd = Z.double().cpu()
+    W = 1 / (1 + ((Zd[sub, None, :] - Zd[None, :, :]) ** 2).sum(-1))
+    W[torch.arange(len(sub)), sub] = 0      # zero_diag: the diagonal term is weighted 1 / (1 + 1e12)
+    ref = W @ v.double().cpu()
+    assert torch.allclose(res[True][2].cpu().double()[sub], ref, rtol=1e-4, atol=5e-5 * scale)
+    red = -(fmax + (W @ Ef.double().cpu()).log())
+    assert torch.allclose(res[True][0].cpu().double()[sub], 0.5 * (f.double().cpu()[sub] + red), rtol=1e-5, atol=1e-5)
+
+
 def test_sinkhorn_student_vs_reference():
     from torchdr_amd.affinity import SinkhornAffinity
 

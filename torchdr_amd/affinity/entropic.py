@@ -385,6 +385,8 @@ def sinkhorn_student_dual(Z: torch.Tensor, init_dual, max_iter: int, tol: float,
     f_new = torch.empty_like(f)
     resid2 = torch.zeros(1, dtype=torch.float32, device=Z.device)
     L = _lib.lib()
+    ws_bytes = int(L.tdr_student_workspace_bytes(n))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=Z.device)
     k = 0
     for k in range(max_iter):
         fmax = float(f.max())
@@ -392,7 +394,7 @@ def sinkhorn_student_dual(Z: torch.Tensor, init_dual, max_iter: int, tol: float,
         resid2.zero_()
         _lib.check(
             L.tdr_sinkhorn_pass_f32(_lib.ptr(Zc), nc, _lib.ptr(f), _lib.ptr(Ef), fmax, n, 1 if zero_diag else 0,
-                                    1e12, _lib.ptr(f_new), _lib.ptr(resid2), _lib.stream_ptr()),
+                                    1e12, _lib.ptr(f_new), _lib.ptr(resid2), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()),
             "tdr_sinkhorn_pass_f32",
         )
         if record is not None:      # f_new = (f - fmax - log s) / 2  =>  1 / s = exp(2 f_new - f + fmax)
@@ -418,11 +420,13 @@ def sinkhorn_student_adjoint(Z: torch.Tensor, record, g_final: torch.Tensor, zer
     g = g_final.float().contiguous()
     t = torch.empty_like(g)
     L = _lib.lib()
+    ws_bytes = int(L.tdr_student_workspace_bytes(n))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=Z.device)
     for col, (Ef, inv_s) in enumerate(reversed(record)):
         a = (g * inv_s).contiguous()
         A[:, col], B[:, col] = a, Ef
         _lib.check(L.tdr_student_matvec_f32(_lib.ptr(Zc), nc, _lib.ptr(a), n, 1 if zero_diag else 0, 1e12, _lib.ptr(t),
-                                            _lib.stream_ptr()), "tdr_student_matvec_f32")
+                                            _lib.ptr(ws), ws_bytes, _lib.stream_ptr()), "tdr_student_matvec_f32")
         g = 0.5 * (g - Ef * t)
     return A, B
 

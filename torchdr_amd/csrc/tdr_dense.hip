@@ -487,22 +487,22 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int NC, int BS>
 __device__ __forceinline__ float student_weighted_sum(const float* __restrict__ Z, const float* __restrict__ v, int64_t n,
                                                       int64_t j, const float (&zj)[NC], int zero_diag, float diag_add,
-                                                      float* tile) {
+                                                      float* tile, int64_t i_lo, int64_t i_hi) {
     constexpr int REC = 2 * (NC + 1);      // floats per column pair
     float s = 0.f;
     f32x2 zz[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) zz[c] = f32x2{zj[c], zj[c]};
     const int64_t own0 = (int64_t)blockIdx.x * BS;
-    for (int64_t i0 = 0; i0 < n; i0 += BS) {
+    for (int64_t i0 = i_lo; i0 < i_hi; i0 += BS) {   // i_lo: a multiple of BS
         __syncthreads();
         const int64_t i = i0 + threadIdx.x;
         float* rec = tile + (threadIdx.x >> 1) * REC + (threadIdx.x & 1);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) rec[2 * c] = (i < n) ? Z[(size_t)i * NC + c] : 0.f;
-        rec[2 * NC] = (i < n) ? v[i] : 0.f;
+        for (int c = 0; c < NC; ++c) rec[2 * c] = (i < i_hi) ? Z[(size_t)i * NC + c] : 0.f;
+        rec[2 * NC] = (i < i_hi) ? v[i] : 0.f;
         __syncthreads();
-        const int lim = (int)((n - i0 < BS) ? (n - i0) : BS);
+        const int lim = (int)((i_hi - i0 < BS) ? (i_hi - i0) : BS);
         if (zero_diag && i0 == own0) {     // the tile with this workgroup's own rows: one column at a time, diagonal weighted
             for (int t = 0; t < lim; ++t) {
                 const float* q = tile + (t >> 1) * REC + (t & 1);
@@ -535,13 +535,13 @@ __global__ __launch_bounds__(BS) void sinkhorn_pass_kernel(const float* __restri
                                                            const float* __restrict__ Ef, float fmax, int64_t n,
                                                            int zero_diag, float diag_add, float* __restrict__ f_new,
                                                            float* __restrict__ resid2) {
-    __shared__ float tile[BS * (NC + 1)];
+    __shared__ __attribute__((aligned(16))) float tile[BS * (NC + 1)];
     const int64_t j = (int64_t)blockIdx.x * BS + threadIdx.x;
     const bool have = j < n;
     float zj[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) zj[c] = have ? Z[(size_t)j * NC + c] : 0.f;
-    const float s = student_weighted_sum<NC, BS>(Z, Ef, n, j, zj, zero_diag, diag_add, tile);
+    const float s = student_weighted_sum<NC, BS>(Z, Ef, n, j, zj, zero_diag, diag_add, tile, 0, n);
     float r2 = 0.f;
     if (have) {
         const float red = -(fmax + logf(s));
@@ -554,22 +554,104 @@ __global__ __launch_bounds__(BS) void sinkhorn_pass_kernel(const float* __restri
     if ((threadIdx.x & 63) == 0 && r2 != 0.f) atomicAdd(resid2, r2);
 }
 
-// out_j = sum_i v_i / (1 + d_ij): the Student-kernel mat-vec of the adjoint Sinkhorn updates (v may be negative)
+// out_j = sum_i v_i / (1 + d_ij): the Student-kernel mat-vec of the adjoint Sinkhorn updates (v may be negative).
+// blockIdx.y = column segment [y * cols_per_seg, ..): the partial sum goes to plane y of `out` (one plane when unsplit).
 template <int NC, int BS>
 __global__ __launch_bounds__(BS) void student_matvec_kernel(const float* __restrict__ Z, const float* __restrict__ v, int64_t n,
-                                                            int zero_diag, float diag_add, float* __restrict__ out) {
-    __shared__ float tile[BS * (NC + 1)];
+                                                            int zero_diag, float diag_add, float* __restrict__ out,
+                                                            int64_t cols_per_seg) {
+    __shared__ __attribute__((aligned(16))) float tile[BS * (NC + 1)];
     const int64_t j = (int64_t)blockIdx.x * BS + threadIdx.x;
     const bool have = j < n;
     float zj[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) zj[c] = have ? Z[(size_t)j * NC + c] : 0.f;
-    const float s = student_weighted_sum<NC, BS>(Z, v, n, j, zj, zero_diag, diag_add, tile);
-    if (have) out[j] = s;
+    const int64_t i_lo = (int64_t)blockIdx.y * cols_per_seg;
+    const int64_t i_hi = (i_lo + cols_per_seg < n) ? i_lo + cols_per_seg : n;
+    const float s = student_weighted_sum<NC, BS>(Z, v, n, j, zj, zero_diag, diag_add, tile, i_lo, i_hi);
+    if (have) out[(size_t)blockIdx.y * n + j] = s;
 }
 
-// single-wavefront workgroups until 256-row ones number >= 16 per CU
+// the Sinkhorn update from per-segment partial sums (added in segment order)
+__global__ __launch_bounds__(256) void sinkhorn_finish_kernel(const float* __restrict__ planes, int n_planes,
+                                                              const float* __restrict__ f, float fmax, int64_t n,
+                                                              float* __restrict__ f_new, float* __restrict__ resid2) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float r2 = 0.f;
+    if (j < n) {
+        float s = planes[j];
+        for (int p = 1; p < n_planes; ++p) s += planes[(size_t)p * n + j];
+        const float red = -(fmax + logf(s));
+        const float fn = 0.5f * (f[j] + red);
+        f_new[j] = fn;
+        const float df = fn - red;
+        r2 = df * df;
+    }
+    r2 = wave_sum(r2);
+    if ((threadIdx.x & 63) == 0 && r2 != 0.f) atomicAdd(resid2, r2);
+}
+
+__global__ __launch_bounds__(256) void sum_planes_f32_kernel(const float* __restrict__ planes, int n_planes, int64_t cnt,
+                                                             float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= cnt) return;
+    float a = planes[i];
+    for (int p = 1; p < n_planes; ++p) a += planes[(size_t)p * cnt + i];
+    out[i] = a;
+}
+
+// single-wavefront workgroups until 256-row ones number >= 16 per CU (unsplit launches)
 static inline bool student_small_blocks(int64_t n) { return (n + 255) / 256 < 16 * 256; }
+
+// column segments of the all-pairs passes on the embedding: >= ~4096 workgroups of 256 rows, segments of >= 1024 columns
+static inline int student_segments(int64_t n) {
+    const int64_t row_blocks = (n + 255) / 256;
+    int64_t s = (4096 + row_blocks - 1) / row_blocks;
+    if (s > n / 1024) s = n / 1024;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : (int)s;
+}
+
+// launches the (possibly segmented) mat-vec into `out` (n_seg planes of n floats); returns the number of planes or an error < 0
+static int student_matvec_launch(const float* Z, int nc, const float* v, int64_t n, int zero_diag, float diag_add, float* out,
+                                 int n_seg, hipStream_t st) {
+    if (n_seg <= 1) {
+        const bool small = student_small_blocks(n);
+        const unsigned grid = (unsigned)(small ? (n + 63) / 64 : (n + 255) / 256);
+#define TDR_MV(NCV)                                                                                                         \
+    {                                                                                                                       \
+        if (small) hipLaunchKernelGGL((student_matvec_kernel<NCV, 64>), dim3(grid), dim3(64), 0, st, Z, v, n, zero_diag, diag_add, out, n); \
+        else hipLaunchKernelGGL((student_matvec_kernel<NCV, 256>), dim3(grid), dim3(256), 0, st, Z, v, n, zero_diag, diag_add, out, n);    \
+    }
+        switch (nc) {
+            case 2: TDR_MV(2); break;
+            case 3: TDR_MV(3); break;
+            case 4: TDR_MV(4); break;
+            case 8: TDR_MV(8); break;
+            case 16: TDR_MV(16); break;
+            case 32: TDR_MV(32); break;
+            default: return TDR_ERR_UNSUPPORTED;
+        }
+#undef TDR_MV
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 1 : -(int)e - 1000;
+    }
+    const int64_t cols = (((n + n_seg - 1) / n_seg + 255) / 256) * 256;
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)((n + cols - 1) / cols));
+#define TDR_MV(NCV) hipLaunchKernelGGL((student_matvec_kernel<NCV, 256>), grid, dim3(256), 0, st, Z, v, n, zero_diag, diag_add, out, cols)
+    switch (nc) {
+        case 2: TDR_MV(2); break;
+        case 3: TDR_MV(3); break;
+        case 4: TDR_MV(4); break;
+        case 8: TDR_MV(8); break;
+        case 16: TDR_MV(16); break;
+        case 32: TDR_MV(32); break;
+        default: return TDR_ERR_UNSUPPORTED;
+    }
+#undef TDR_MV
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? (int)grid.y : -(int)e - 1000;
+}
 
 static inline int dense_pick_kq(int d) {
     if (d <= 32) return 4;
@@ -727,13 +809,31 @@ int tdr_khorn_grad_f32(const float* packed, int64_t n, int d, const float* side,
     return tdr_khorn_grad_nc_f32(packed, n, d, side, 2, log_n, grad, nullptr, 0, stream);
 }
 
+/* Bytes of the optional workspace of the two all-pairs passes on the embedding below: with it the columns are spread over
+ * several workgroups per block of 256 rows (one workgroup per row block is too coarse below ~1M rows: N = 200k is 3 per CU);
+ * 0 = a pass of this size is not split. */
+int64_t tdr_student_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    const int n_seg = student_segments(n);
+    return n_seg > 1 ? (int64_t)n_seg * n * (int64_t)sizeof(float) : 0;
+}
+
 /* One symmetric Sinkhorn update on the embedding Z (n, nc), student kernel, eps = 1:
  *   f_new = 0.5 (f + red), red_j = -LSE_i(-log(1 + d_ij) + f_i);  *resid2 (device, caller-zeroed) += |f_new - red|^2.
- * Ef = exp(f - fmax) precomputed by the caller (fmax = max f). */
+ * Ef = exp(f - fmax) precomputed by the caller (fmax = max f).  ws / ws_bytes: tdr_student_workspace_bytes (NULL: unsplit). */
 int tdr_sinkhorn_pass_f32(const float* Z, int nc, const float* f, const float* Ef, float fmax, int64_t n, int zero_diag,
-                          float diag_add, float* f_new, float* resid2, void* stream) {
+                          float diag_add, float* f_new, float* resid2, void* ws, int64_t ws_bytes, void* stream) {
     if (!Z || !f || !Ef || !f_new || !resid2 || n <= 0) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    const int n_seg = student_segments(n);
+    if (n_seg > 1 && ws && ws_bytes >= (int64_t)n_seg * n * (int64_t)sizeof(float)) {
+        const int planes = student_matvec_launch(Z, nc, Ef, n, zero_diag, diag_add, (float*)ws, n_seg, st);
+        if (planes <= 0) return planes == TDR_ERR_UNSUPPORTED ? planes : -planes - 1000;
+        hipLaunchKernelGGL(sinkhorn_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, planes, f,
+                           fmax, n, f_new, resid2);
+        TDR_CHECK_LAUNCH();
+        return TDR_OK;
+    }
     const bool small = student_small_blocks(n);
     const unsigned grid = (unsigned)(small ? (n + 63) / 64 : (n + 255) / 256);
 #define TDR_SK(NCV)                                                                                                         \
@@ -756,29 +856,22 @@ int tdr_sinkhorn_pass_f32(const float* Z, int nc, const float* f, const float* E
 }
 
 /* out_j = sum_i v_i / (1 + |z_i - z_j|^2) over the embedding Z (n, nc), the diagonal term weighted 1 / (1 + diag_add) when
- * zero_diag: the Student-kernel mat-vec of the adjoint Sinkhorn updates (entropic.py:733-736 differentiated; v signed). */
+ * zero_diag: the Student-kernel mat-vec of the adjoint Sinkhorn updates (entropic.py:733-736 differentiated; v signed).
+ * ws / ws_bytes: tdr_student_workspace_bytes (NULL: unsplit). */
 int tdr_student_matvec_f32(const float* Z, int nc, const float* v, int64_t n, int zero_diag, float diag_add, float* out,
-                           void* stream) {
+                           void* ws, int64_t ws_bytes, void* stream) {
     if (!Z || !v || !out || n <= 0) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const bool small = student_small_blocks(n);
-    const unsigned grid = (unsigned)(small ? (n + 63) / 64 : (n + 255) / 256);
-#define TDR_MV(NCV)                                                                                                         \
-    {                                                                                                                       \
-        if (small) hipLaunchKernelGGL((student_matvec_kernel<NCV, 64>), dim3(grid), dim3(64), 0, st, Z, v, n, zero_diag, diag_add, out); \
-        else hipLaunchKernelGGL((student_matvec_kernel<NCV, 256>), dim3(grid), dim3(256), 0, st, Z, v, n, zero_diag, diag_add, out);    \
+    const int n_seg = student_segments(n);
+    if (n_seg > 1 && ws && ws_bytes >= (int64_t)n_seg * n * (int64_t)sizeof(float)) {
+        const int planes = student_matvec_launch(Z, nc, v, n, zero_diag, diag_add, (float*)ws, n_seg, st);
+        if (planes <= 0) return planes == TDR_ERR_UNSUPPORTED ? planes : -planes - 1000;
+        hipLaunchKernelGGL(sum_planes_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)ws, planes, n, out);
+        TDR_CHECK_LAUNCH();
+        return TDR_OK;
     }
-    switch (nc) {
-        case 2: TDR_MV(2); break;
-        case 3: TDR_MV(3); break;
-        case 4: TDR_MV(4); break;
-        case 8: TDR_MV(8); break;
-        case 16: TDR_MV(16); break;
-        case 32: TDR_MV(32); break;
-        default: return TDR_ERR_UNSUPPORTED;
-    }
-#undef TDR_MV
-    TDR_CHECK_LAUNCH();
+    const int planes = student_matvec_launch(Z, nc, v, n, zero_diag, diag_add, out, 1, st);
+    if (planes <= 0) return planes == TDR_ERR_UNSUPPORTED ? planes : -planes - 1000;
     return TDR_OK;
 }
 
