@@ -138,6 +138,11 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
 int tdr_cluster_sample_i32(int64_t n, int S, uint32_t seed, int32_t* sample_idx, void* stream);
 int tdr_cluster_maxmin_capacity(void);
 int tdr_cluster_maxmin_f32(const float* D2, int64_t ld, int S, int C, int32_t* seeds, void* stream);
+/* the same with the number of seeds read off the data: up to c_max seeds, ended at the first step t >= c_min at which the
+ * max-min squared distance falls below `drop` x the previous one (every well-separated group holds a seed); no such step:
+ * c_min seeds.  *n_seeds: device int32; seeds: c_max entries */
+int tdr_cluster_maxmin_adaptive_f32(const float* D2, int64_t ld, int S, int c_min, int c_max, float drop, int32_t* seeds,
+                                    int32_t* n_seeds, void* stream);
 int tdr_gather_rows_f32(const float* X, int64_t ldx, int d, const int32_t* idx, const int32_t* idx2, int64_t m, float* out,
                         void* stream);
 int tdr_cluster_update_f32(const float* Xs, int64_t S, int d, const int32_t* labels, int C, float* cent, void* ws, void* stream);

@@ -259,3 +259,32 @@ def test_cluster_index_is_the_same_on_every_run():
     a, b = ClusterIndex(PackedPoints(X)), ClusterIndex(PackedPoints(X))
     assert a.n_img == b.n_img and torch.equal(a.tile_cluster, b.tile_cluster) and torch.equal(a.radius, b.radius)
     assert torch.equal(a.row_map.sort().values, b.row_map.sort().values)
+
+
+def test_cluster_index_reads_the_number_of_groups_off_the_data():
+    """No cluster count asked for: the farthest-point seeding goes on past the default (N / 1000) and stops where the max-min
+    distance collapses -- one ball per well-separated group.  200k points in 700 blobs: 700 balls, not the default 200 (whose
+    balls each swallow three or four blobs, so that nothing can be pruned); the pruned search then runs and is bit-equal to
+    the exact one.  Data without groups (one Gaussian): the default count."""
+    from torchdr_amd.distance import base as dbase
+    from torchdr_amd.distance.base import ClusterIndex, PackedPoints
+
+    n, d, blobs = 200_000, 64, 700
+    g = torch.Generator().manual_seed(21)
+    centres = torch.randn(blobs, d, generator=g) * 2.0
+    X = (centres[torch.arange(n) % blobs] + 0.5 * torch.randn(n, d, generator=g)).cuda()
+    ci = ClusterIndex(PackedPoints(X))
+    assert ci.n_clusters == blobs
+    assert ClusterIndex(PackedPoints(X), n_clusters=300).n_clusters == 300          # an explicit count is taken as it is
+    flat = torch.randn(n, d, generator=g).cuda()
+    assert ClusterIndex(PackedPoints(flat)).n_clusters == n // 1000
+    C, I = dbase.pairwise_distances(X, metric="sqeuclidean", k=15, exclude_diag=True, return_indices=True)
+    assert dbase.LAST_KNN["path"].endswith("pruned"), dbase.LAST_KNN
+    rows = torch.arange(0, n, 401, device="cuda")
+    P = PackedPoints(X)
+    Ce, Ie = dbase.knn_packed(PackedPoints(X[rows].contiguous()), P, 16, "sqeuclidean", False, _allow_screen=False)
+    keep = Ie != rows[:, None].int()
+    ok = keep.sum(1) == 15
+    assert float(ok.float().mean()) > 0.999
+    assert torch.equal(Ie[ok][keep[ok]].reshape(-1, 15), I[rows][ok])
+    assert torch.equal(Ce[ok][keep[ok]].reshape(-1, 15), C[rows][ok])

@@ -39,10 +39,18 @@ __global__ __launch_bounds__(256) void cluster_sample_kernel(int64_t n, int S, u
 }
 
 // ---- 2. max-min seeding on the sample's distance matrix, one workgroup ------------------------------------------------
+// Adaptive form (c_min < C, n_out != NULL): the max-min distance delta_t of the t-th seed is non-increasing; on data made of
+// well-separated groups it collapses once every group holds a seed (the next farthest point lies INSIDE a group).  The loop
+// stops at the first step t >= c_min whose delta falls below `drop` x the previous one and reports t seeds: one ball per
+// group, whatever the number of groups between c_min and C.  No such step: c_min seeds (the fixed default).
 __global__ __launch_bounds__(CL_TH) void cluster_maxmin_kernel(const float* __restrict__ D2, int64_t ld, int S, int C,
-                                                              int32_t* __restrict__ seeds) {
+                                                              int32_t* __restrict__ seeds, int c_min, float drop,
+                                                              int32_t* __restrict__ n_out) {
     __shared__ unsigned long long wbest[CL_TH / 64];
     __shared__ int winner;
+    __shared__ int stop_at;
+    if (threadIdx.x == 0) stop_at = -1;
+    float prev_delta = 3.0e38f;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float mind[CL_PP];
 #pragma unroll
@@ -72,10 +80,15 @@ __global__ __launch_bounds__(CL_TH) void cluster_maxmin_kernel(const float* __re
             unsigned long long k = wbest[0];
             for (int i = 1; i < CL_TH / 64; ++i) k = wbest[i] > k ? wbest[i] : k;
             winner = 0x7fffffff - (int)(unsigned)(k & 0xffffffffu);
+            const float delta = __uint_as_float((unsigned)(k >> 32));     // max-min distance of the NEXT seed
+            if (n_out && step + 1 >= c_min && step > 0 && delta < drop * prev_delta) stop_at = step + 1;
+            prev_delta = delta;
         }
         __syncthreads();
         cur = winner;
+        if (stop_at >= 0) break;
     }
+    if (tid == 0 && n_out) *n_out = stop_at >= 0 ? stop_at : c_min;
 }
 
 // ---- gather rows: out[i] = X[idx[i]] (optionally through a second index: X[idx[idx2[i]]]) ---------------------------------
@@ -319,7 +332,23 @@ int tdr_cluster_maxmin_capacity(void) { return CL_PP * CL_TH; }
 int tdr_cluster_maxmin_f32(const float* D2, int64_t ld, int S, int C, int32_t* seeds, void* stream) {
     if (!D2 || !seeds || S <= 0 || C <= 0 || C > S || ld < S) return TDR_ERR_BAD_ARG;
     if (S > CL_PP * CL_TH) return TDR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(cluster_maxmin_kernel, dim3(1), dim3(CL_TH), 0, (hipStream_t)stream, D2, ld, S, C, seeds);
+    hipLaunchKernelGGL(cluster_maxmin_kernel, dim3(1), dim3(CL_TH), 0, (hipStream_t)stream, D2, ld, S, C, seeds, C, 0.f,
+                       (int32_t*)nullptr);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* The same seeding with the number of seeds read off the data: up to c_max farthest-point seeds; the first step t >= c_min
+ * at which the max-min (squared) distance falls below `drop` x the previous one ends the loop with t seeds -- the point
+ * where every well-separated group holds a seed -- else c_min seeds.  *n_seeds (device int32) receives the count; seeds
+ * has room for c_max entries. */
+int tdr_cluster_maxmin_adaptive_f32(const float* D2, int64_t ld, int S, int c_min, int c_max, float drop, int32_t* seeds,
+                                    int32_t* n_seeds, void* stream) {
+    if (!D2 || !seeds || !n_seeds || S <= 0 || c_min <= 0 || c_max < c_min || c_max > S || ld < S || !(drop > 0.f && drop < 1.f))
+        return TDR_ERR_BAD_ARG;
+    if (S > CL_PP * CL_TH) return TDR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cluster_maxmin_kernel, dim3(1), dim3(CL_TH), 0, (hipStream_t)stream, D2, ld, S, c_max, seeds, c_min, drop,
+                       n_seeds);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

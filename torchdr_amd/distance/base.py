@@ -156,6 +156,7 @@ class PackedPoints:
 
 
 PRUNE_MODE = _os.environ.get("TDR_KNN_PRUNE", "auto")  # "0": never; "force": whenever supported; "auto": N >= 65536
+_SEED_DROP = 0.25    # adaptive seeding: a max-min SQUARED distance below a quarter of the previous one ends the seeding
 _PRUNE_MIN_N = 65536
 _PRUNE_MAX_SCAN_FRACTION = 0.5  # predicted share of tiles still visited above which the plain scan is used
 
@@ -179,8 +180,13 @@ class ClusterIndex:
         # more than 2048 balls measured slower at N = 4M (3.5 s vs 2.7 s): Gaussian blobs in high dimension are not
         # resolved further by splitting them -- the sub-balls overlap and all of them are scanned anyway
         C = int(n_clusters or min(2048, max(8, N // 1000)))
-        S = int(min(N, 8 * C, L.tdr_cluster_maxmin_capacity()))
-        C = min(C, S)
+        # no count asked for: the seeding may go on past the default up to c_max seeds and stops where the max-min distance
+        # collapses -- one ball per well-separated group when the data has between C and c_max of them (N = 500k in 1000
+        # blobs: the default of 500 balls merges blobs in pairs, nothing can be pruned and the search is 7x slower than at
+        # N = 1M, where the default happens to equal the number of blobs)
+        c_max = C if n_clusters else int(min(2048, max(C, N // 64)))
+        S = int(min(N, max(8 * C, min(8192, 8 * c_max)), L.tdr_cluster_maxmin_capacity()))
+        C, c_max = min(C, S), min(c_max, S)
         st = _lib.stream_ptr()
         # 1-2. stratified sample; farthest-point seeds on its exact distance matrix (dense MFMA kernel + one workgroup):
         # one seed per well-separated group, an epsilon-net otherwise (random seeds leave merged clusters whose large
@@ -191,9 +197,37 @@ class ClusterIndex:
         _lib.check(L.tdr_gather_rows_f32(_lib.ptr(X), X.stride(0), D, _lib.ptr(sample_idx), None, S, _lib.ptr(Xs), st), "tdr_gather_rows_f32")
         Ps = PackedPoints(Xs)
         D2 = dense_packed(Ps, Ps, "sqeuclidean", False)
-        seeds = torch.empty(C, dtype=torch.int32, device=dev)
-        _lib.check(L.tdr_cluster_maxmin_f32(_lib.ptr(D2), D2.stride(0), S, C, _lib.ptr(seeds), st), "tdr_cluster_maxmin_f32")
+        seeds = torch.empty(c_max, dtype=torch.int32, device=dev)
+        n_seeds = None
+        if c_max > C:
+            n_seeds = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(L.tdr_cluster_maxmin_adaptive_f32(_lib.ptr(D2), D2.stride(0), S, C, c_max, _SEED_DROP, _lib.ptr(seeds),
+                                                         _lib.ptr(n_seeds), st), "tdr_cluster_maxmin_adaptive_f32")
+        else:
+            _lib.check(L.tdr_cluster_maxmin_f32(_lib.ptr(D2), D2.stride(0), S, C, _lib.ptr(seeds), st), "tdr_cluster_maxmin_f32")
         del D2
+        # the rest of the build needs the seed count on the host when it was left to the data: with `defer` it is run by
+        # finish(), AFTER the caller has enqueued its pilot searches (the read waits for the seeding kernel, the pilots
+        # run meanwhile)
+        self._seeded = (P, Xs, Ps, sample_idx, seeds, n_seeds, C, S, iters)
+        self._seed_event = torch.cuda.Event()
+        self._seed_event.record()       # finish() may run under another stream than this one
+        if not (defer and n_seeds is not None):
+            self._build_rest()
+        if not defer:
+            self.finish()
+
+    def _build_rest(self):
+        P, Xs, Ps, sample_idx, seeds, n_seeds, C, S, iters = self._seeded
+        self._seeded = None
+        X = P.X
+        dev = X.device
+        N, D = X.shape
+        L = _lib.lib()
+        st = _lib.stream_ptr()
+        torch.cuda.current_stream(dev).wait_event(self._seed_event)
+        if n_seeds is not None:
+            C = int(n_seeds.item())     # the host read: the seeding kernel has finished when it returns
         cent = torch.empty((C, D), dtype=torch.float32, device=dev)
         _lib.check(L.tdr_gather_rows_f32(_lib.ptr(X), X.stride(0), D, _lib.ptr(sample_idx), _lib.ptr(seeds), C, _lib.ptr(cent), st),
                    "tdr_gather_rows_f32")
@@ -233,10 +267,12 @@ class ClusterIndex:
         self.order = order
         self.img16 = None
         self._pending = (n_img, row_map, tile_cluster, tiles)
-        if not defer:
-            self.finish()
+
+    _seeded = None
 
     def finish(self):
+        if self._seeded is not None:
+            self._build_rest()
         if self._pending is None:
             return self
         n_img, row_map, tile_cluster, tiles = self._pending
