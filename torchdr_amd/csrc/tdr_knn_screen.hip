@@ -669,7 +669,6 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
             band_wg = fmaxf(fmaxf(wred[4], wred[5]), fmaxf(wred[6], wred[7]));
             __syncthreads();
         };
-        const int c0 = cw[0];
         float tau_wg = 0.f, band_wg = 0.f;
         int idx0 = 0;
         bool more = true;
@@ -680,6 +679,27 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
         // above the last one taken, so no visited set is kept.  Clusters the exact bound excludes are never taken.
         int visited = 0;
         unsigned long long prev = 0ull;  // (key bits << 32 | cluster) + 1 of the last cluster taken
+        // exact mode: the distinct own clusters of the wavefronts, a cursor into the visiting order of each, whose turn it is
+        int own[NW], idxj[NW], n_own = 0, rr = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { own[w] = 0; idxj[w] = 0; }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            bool fresh = cw[w] >= 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NW; ++w2) fresh = fresh && !(w2 < w && cw[w2] == cw[w]);
+            if (fresh) {
+#pragma unroll
+                for (int t = 0; t < NW; ++t)
+                    if (t == n_own) own[t] = cw[w];
+                ++n_own;
+            }
+        }
+        unsigned* vis = reinterpret_cast<unsigned*>(wmask + 4);     // 4096 bits: clusters scanned by this workgroup
+        if (pruned) {
+            if (tid < 128) vis[tid] = 0u;
+            __syncthreads();
+        }
         while (more) {
             int rb = t_begin, re = t_end;
             if (!pruned) {
@@ -731,12 +751,31 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
                     re = P.clus_tile_begin[c + 1];
                     found = true;
                 }
-                while (!found && idx0 < P.n_clusters) {
+                // Exact mode.  A workgroup's four query tiles may lie in up to four clusters, and the layout order of the
+                // clusters says nothing about where they are in space: walking only the visiting order of the first
+                // wavefront's cluster, a tile of another cluster met its own neighbourhood after hundreds of clusters, and until
+                // then its thresholds -- those of arbitrary rows -- let nothing be pruned for the whole workgroup (N = 700k in
+                // 1000 blobs of 22 tiles: a fifth of the workgroups straddle two blobs, 47 ms against 18 ms at N = 1M where
+                // blobs are 8 workgroups each).  So the visiting orders of ALL the distinct own clusters are walked in turn
+                // (each starts with the cluster itself), a bitmap in LDS keeps a cluster from being scanned twice.
+                while (!found && P.max_visit <= 0) {
+                    int j = -1;
+#pragma unroll
+                    for (int t = 0; t < NW; ++t) {
+                        const int jj = (rr + t) % NW;
+                        if (j < 0 && jj < n_own && idxj[jj] < P.n_clusters) j = jj;
+                    }
+                    if (j < 0) break;
+                    rr = (j + 1) % NW;
+                    int cj = own[0], ij = idxj[0];
+#pragma unroll
+                    for (int t = 1; t < NW; ++t)
+                        if (t == j) { cj = own[t]; ij = idxj[t]; }
                     // 256 clusters of the visiting order are tested at once, one per thread, against the current threshold
-                    const int idx = idx0 + tid;
+                    const int idx = ij + tid;
                     bool survive = false;
                     if (idx < P.n_clusters) {
-                        const int c = P.clus_order[(size_t)c0 * P.n_clusters + idx];
+                        const int c = P.clus_order[(size_t)cj * P.n_clusters + idx];
                         const float rc = P.clus_radius[c];
                         float lb = __builtin_inff();
 #pragma unroll
@@ -745,7 +784,8 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
                             const float g = P.clus_dist[(size_t)cw[w] * P.n_clusters + c] - P.clus_radius[cw[w]] - rc;
                             lb = fminf(lb, g > 0.f ? g * g : 0.f);
                         }
-                        survive = !(lb * 0.9999f - band_wg > tau_wg);  // pruned only when NO member can enter any band
+                        // pruned only when NO member can enter any band; scanned already: not again (duplicates in the lists)
+                        survive = !((vis[c >> 5] >> (c & 31)) & 1u) && !(lb * 0.9999f - band_wg > tau_wg);
                     }
                     const unsigned long long m = __ballot(survive);
                     if (lane == 0) wmask[wave] = m;
@@ -757,11 +797,15 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
                         if (first < 0 && mw) first = 64 * w + __builtin_ctzll(mw);
                     }
                     __syncthreads();
-                    if (first < 0) { idx0 += 256; continue; }
-                    const int c = P.clus_order[(size_t)c0 * P.n_clusters + idx0 + first];
+                    const int adv = first < 0 ? 256 : first + 1;
+#pragma unroll
+                    for (int t = 0; t < NW; ++t)
+                        if (t == j) idxj[t] += adv;
+                    if (first < 0) continue;
+                    const int c = P.clus_order[(size_t)cj * P.n_clusters + ij + first];
+                    if (tid == 0) vis[c >> 5] |= 1u << (c & 31);     // read again only after the barriers of the scan below
                     rb = P.clus_tile_begin[c];
                     re = P.clus_tile_begin[c + 1];
-                    idx0 += first + 1;
                     found = true;
                 }
                 if (!found) break;
@@ -923,7 +967,7 @@ static inline int pick_ks(int d) {
 
 static size_t screen_lds_bytes(int ks, int L, int qb, int terms) {
     return (size_t)2 * ks * 1024 * (terms == 3 ? 2 : 1) + (size_t)4 * 64 * sizeof(float) +
-           (size_t)4 * qb * 32 * L * sizeof(uint64_t) + 128;  // + the workgroup reduction slots of the pruned scan
+           (size_t)4 * qb * 32 * L * sizeof(uint64_t) + 128 + 512;  // + the workgroup reduction slots and the scanned-cluster bitmap of the pruned scan
 }
 
 // Workgroup shape, number of split terms and list length per tier.  The list holds k entries plus spare slots for
@@ -1205,6 +1249,7 @@ int tdr_knn_screen_clustered_f32(const float* x16, const float* X, int64_t ldx, 
                                  const float* clus_radius, const float* clus_dist, const int32_t* clus_order,
                                  int64_t q_pos_begin, int64_t q_pos_end, float* out_d, int32_t* out_i, int32_t* flags,
                                  int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+    if (n_clusters > 4096) return TDR_ERR_UNSUPPORTED;     // the scanned-cluster bitmap of a workgroup (LDS) and the index builder's limit
     if (!row_map || !tile_cluster || !clus_tile_begin || !clus_radius || !clus_dist || !clus_order || n_clusters <= 0)
         return TDR_ERR_BAD_ARG;
     if (n_img % TILE_ROWS != 0) return TDR_ERR_BAD_ARG;
@@ -1225,6 +1270,7 @@ int tdr_knn_ivf_f32(const float* x16, const float* X, int64_t ldx, const float* 
                     const int32_t* tile_cluster, const int32_t* clus_tile_begin, const float* clus_radius, const float* clus_dist,
                     const int32_t* clus_order, int nprobe, float* out_d, int32_t* out_i, int32_t* flags, int32_t* n_flagged,
                     void* ws, int64_t ws_bytes, void* stream) {
+    if (n_clusters > 4096) return TDR_ERR_UNSUPPORTED;
     if (!row_map || !tile_cluster || !clus_tile_begin || !clus_radius || !clus_dist || !clus_order || n_clusters <= 0 || nprobe < 1)
         return TDR_ERR_BAD_ARG;
     if (n_img % TILE_ROWS != 0) return TDR_ERR_BAD_ARG;
