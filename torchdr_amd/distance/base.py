@@ -505,6 +505,20 @@ def _pruned_share(Y, tau):
     return share if (_opt("PRUNE_MODE") == "force" or share <= _PRUNE_MAX_SCAN_FRACTION) else 1.0
 
 
+def _cluster_index_early(Y):
+    """Enqueue the first stage of the index build (sample, its distance matrix, the single-workgroup seeding kernel) on the
+    side stream NOW -- before the caller packs the screening image and launches its pilots.  The two pilot launches take every
+    register file of the chip for ~5 ms; a seeding kernel enqueued with them waited for a CU (kernel trace: its tiny
+    pack kernel sat 4.9 ms in the queue and the build ended 1.1 ms later than it had before the build was split in two)."""
+    if not _opt("PILOT_CONCURRENT") or getattr(Y, "_cluster_index", None) is not None:
+        return
+    dev = Y.device
+    side = _side_streams(dev, 2)[1]
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        _cluster_index_start(Y)
+
+
 def _cluster_index_start(Y):
     """Enqueue the index build (no host read yet); `_cluster_index` completes it."""
     ci = getattr(Y, "_cluster_index", None)
@@ -567,9 +581,11 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
     self search of clustered data additionally prunes by cluster bounds); rows whose screening list overflowed are
     redone by the one-stage exact kernel.  Returns the number of such rows, or -1 when the pilot says the data does not
     suit screening (nothing written; the caller uses the one-stage kernel)."""
+    prune = Q is Y and q0 == 0 and q_offset == 0 and nq == Y.n and _want_prune(Y, Y.n)
+    if prune and pilot and nq >= _SCREEN_PILOT_MIN_Q:
+        _cluster_index_early(Y)
     ops = _screen_operands(Q, Y)
     pilot_tau = None
-    prune = Q is Y and q0 == 0 and q_offset == 0 and nq == Y.n and _want_prune(Y, Y.n)
     if pilot and nq >= _SCREEN_PILOT_MIN_Q:
         # the index build does not depend on the pilot's outcome: it runs next to it
         tier, pilot_tau = _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset,
@@ -690,6 +706,7 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
     n, W, rank = Y.n, ctx.world_size, ctx.rank
     c0, c1 = ctx.compute_chunk_bounds(n)
     with phase("knn: pilots + cluster index"):
+        _cluster_index_early(Y)
         ops = _screen_operands(Y, Y)
         q0 = max(0, min((c0 // 32) * 32, ((n - _SCREEN_PILOT_Q) // 32) * 32))
         tier, tau = _choose_tier(Y, Y, ops, q0, k, metric, exclude_self, 0,
