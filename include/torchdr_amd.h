@@ -165,6 +165,21 @@ int tdr_knn_screen_clustered_f32(const float* x16, const float* X, int64_t ldx, 
                                  const float* clus_radius, const float* clus_dist, const int32_t* clus_order,
                                  int64_t q_pos_begin, int64_t q_pos_end, float* out_d, int32_t* out_i, int32_t* flags,
                                  int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
+/* tdr_knn_screen_clustered_f32 with a per-tile table: tile_cdist (n_img / 32, n_clusters) = for every 32-row tile of the sorted
+ * order a LOWER bound of the distance from any of its rows to every cluster centre (tdr_cluster_tile_cdist_f32).  A cluster is
+ * skipped when |x - c| - R_c of the workgroup's own query rows already exceeds their thresholds: sharper than the ball-to-ball
+ * bound, clusters whose balls overlap are still told apart.  Same results bit for bit. */
+int tdr_knn_screen_clustered_tb_f32(const float* x16, const float* X, int64_t ldx, const float* norms, int64_t n_img, int d, int k,
+                                    int metric, int exclude_self, int tier, const uint32_t* meta, const int32_t* row_map,
+                                    int n_clusters, const int32_t* tile_cluster, const int32_t* clus_tile_begin,
+                                    const float* clus_radius, const float* clus_dist, const int32_t* clus_order,
+                                    const float* tile_cdist, int64_t q_pos_begin, int64_t q_pos_end, float* out_d, int32_t* out_i,
+                                    int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
+/* rows of that table from a block of exact squared distances d2 (rows, C) of consecutive rows of the padded sorted order to the
+ * C centres: out (rows / 32, C) = sqrt(max(0, min over the tile's valid rows of d2 - (d + 16) 2^-23 (|x|^2 + |c|^2))) rounded
+ * down; row_map (rows): source row or -1; xn (rows), cn (C): squared norms */
+int tdr_cluster_tile_cdist_f32(const float* d2, int64_t ld, int64_t rows, int C, int d, const int32_t* row_map, const float* xn,
+                               const float* cn, float* out, void* stream);
 /* Approximate IVF-style self search on the same cluster index (distance/faiss.py:331-349: nlist = n_clusters, nprobe):
  * a workgroup scans its own clusters and then the nearest ones, nprobe scans in all; candidates are rescored exactly.
  * out_d / out_i must be pre-filled by the caller (+inf / -1): rows with fewer than k candidates keep that tail. */

@@ -288,3 +288,45 @@ def test_cluster_index_reads_the_number_of_groups_off_the_data():
     assert float(ok.float().mean()) > 0.999
     assert torch.equal(Ie[ok][keep[ok]].reshape(-1, 15), I[rows][ok])
     assert torch.equal(Ce[ok][keep[ok]].reshape(-1, 15), C[rows][ok])
+
+
+@pytest.mark.parametrize("n,d,scale,k", [(120_000, 64, 1.0, 15), (150_000, 128, 1.1, 30)])
+def test_tile_bounds_prune_overlapping_balls_and_equal_exact(n, d, scale, k):
+    """Blobs whose balls overlap (centre distance ~ 1.4 sqrt(d), radius ~ 0.6 sqrt(d)): the ball-to-ball bound keeps every
+    cluster, the per-tile table (|x - c| - R_c from the tile's own rows) does not.  The table is a LOWER bound of every row's
+    distance to every centre; the search with it returns the same rows as the exact kernel."""
+    from torchdr_amd import config
+    from torchdr_amd.distance import base as dbase
+    from torchdr_amd.distance.base import PackedPoints
+
+    X = gmm(n, d, scale, seed=5).cuda()
+    with config.options(TILE_BOUNDS="force"):
+        P = PackedPoints(X)
+        C, I = dbase.knn_packed(P, P, k, "sqeuclidean", True)
+    assert dbase.LAST_KNN["tile_bounds"] and dbase.LAST_KNN["pruned"], dbase.LAST_KNN
+    ci = P._cluster_index
+    T = ci.tile_cdist
+    # the table against float64 distances of sampled tiles
+    tiles = torch.arange(0, T.shape[0], max(T.shape[0] // 40, 1), device="cuda")
+    cent = ci.centres.double()
+    for t in tiles.tolist():
+        rows = ci.row_map[t * 32:(t + 1) * 32]
+        rows = rows[rows >= 0].long()
+        if rows.numel() == 0:
+            assert bool(torch.isinf(T[t]).all())
+            continue
+        true_min = torch.cdist(X[rows].double(), cent).min(0).values
+        assert bool((T[t].double() <= true_min * (1 + 1e-7)).all())
+        assert bool((T[t].double() >= true_min * (1 - 1e-3) - 1e-3).all())      # and not needlessly loose
+    # results: sampled rows against the one-stage kernel
+    rows = torch.arange(0, n, 157, device="cuda")
+    Ce, Ie = dbase.knn_packed(PackedPoints(X[rows].contiguous()), PackedPoints(X), k + 1, "sqeuclidean", False, _allow_screen=False)
+    keep = Ie != rows[:, None].int()
+    ok = keep.sum(1) == k
+    assert float(ok.float().mean()) > 0.999
+    assert torch.equal(Ie[ok][keep[ok]].reshape(-1, k), I[rows][ok])
+    assert torch.equal(Ce[ok][keep[ok]].reshape(-1, k), C[rows][ok])
+    # and the whole result against the search without the table
+    with config.options(TILE_BOUNDS=False):
+        C0, I0 = dbase.knn_packed(PackedPoints(X), PackedPoints(X), k, "sqeuclidean", True) if False else dbase.pairwise_distances(X, metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True)
+    assert torch.equal(C0, C) and torch.equal(I0, I)

@@ -91,6 +91,28 @@ __global__ __launch_bounds__(CL_TH) void cluster_maxmin_kernel(const float* __re
     if (tid == 0 && n_out) *n_out = stop_at >= 0 ? stop_at : c_min;
 }
 
+// ---- per-tile lower bound of the distance to every centre (tdr_cluster_tile_cdist_f32) -----------------------------------
+__global__ __launch_bounds__(256) void tile_cdist_kernel(const float* __restrict__ d2, int64_t ld, int C, float eps,
+                                                         const int32_t* __restrict__ row_map, const float* __restrict__ xn,
+                                                         const float* __restrict__ cn, float* __restrict__ out) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const float cnc = cn[c];
+    float best = __builtin_inff();
+    for (int i = 0; i < 32; ++i) {
+        if (row_map[r0 + i] < 0) continue;
+        const float v = d2[(size_t)(r0 + i) * ld + c] - eps * (xn[r0 + i] + cnc);
+        best = fminf(best, v);
+    }
+    float t = best;
+    if (best < __builtin_inff()) {
+        t = sqrtf(fmaxf(best, 0.f));     // round to nearest; the factor below takes it down by more than an ulp
+        t = t * 0.999999f;
+    }
+    out[(size_t)blockIdx.x * C + c] = t;
+}
+
 // ---- gather rows: out[i] = X[idx[i]] (optionally through a second index: X[idx[idx2[i]]]) ---------------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ X, int64_t ldx, int d,
                                                           const int32_t* __restrict__ idx, const int32_t* __restrict__ idx2,
@@ -349,6 +371,21 @@ int tdr_cluster_maxmin_adaptive_f32(const float* D2, int64_t ld, int S, int c_mi
     if (S > CL_PP * CL_TH) return TDR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(cluster_maxmin_kernel, dim3(1), dim3(CL_TH), 0, (hipStream_t)stream, D2, ld, S, c_max, seeds, c_min, drop,
                        n_seeds);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* Per-tile lower bounds of the distance to every cluster centre, from a block of exact squared distances:
+ * d2 (rows, C; row stride ld) = squared distances of `rows` consecutive rows of the padded cluster-sorted order (rows a multiple
+ * of 32) to the C centres, as the dense kernel gives them (norm expansion, fp32); row_map (rows): source row or -1 (padding,
+ * ignored); xn (rows) / cn (C): squared norms of the rows / centres.  out (rows / 32, C): for every tile and centre
+ * sqrt(max(0, min over its valid rows of d2 - eps (|x|^2 + |c|^2))), rounded down -- eps = (d + 16) 2^-23 covers the rounding
+ * of the expansion, so the value never exceeds the true distance of any row of the tile; tiles of padding only get +inf. */
+int tdr_cluster_tile_cdist_f32(const float* d2, int64_t ld, int64_t rows, int C, int d, const int32_t* row_map, const float* xn,
+                               const float* cn, float* out, void* stream) {
+    if (!d2 || !row_map || !xn || !cn || !out || rows <= 0 || rows % 32 != 0 || C <= 0 || ld < C || d <= 0) return TDR_ERR_BAD_ARG;
+    const dim3 grid((unsigned)(rows / 32), (unsigned)((C + 255) / 256));
+    hipLaunchKernelGGL(tile_cdist_kernel, grid, dim3(256), 0, (hipStream_t)stream, d2, ld, C, (float)(d + 16) * 1.1920929e-07f, row_map, xn, cn, out);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

@@ -177,6 +177,8 @@ struct ScreenParams {
     const float* clus_dist;         // (n_clusters, n_clusters) centre distances, rounded down
     const int32_t* clus_order;      // (n_clusters, n_clusters) clusters by increasing centre distance (self first)
     int max_visit;                  // approximate (IVF-style) search: clusters a workgroup may scan at most; 0 = exact
+    const float* tile_cdist;        // optional (n_db_tiles, n_clusters): lower bound of min over the tile's rows of |x - c_c| --
+                                    // the bound |x - y| >= |x - c_c| - R_c of the tile's own rows replaces the ball-to-ball bound
 };
 
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
@@ -646,10 +648,12 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
         float* wred = reinterpret_cast<float*>(keys_all + (size_t)NW * QB * 32 * Ln);  // 16 floats behind the lists
         unsigned long long* wmask = reinterpret_cast<unsigned long long*>(wred + 8);   // 4 ballots
         int cw[NW];
+        int64_t qtile[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const int64_t qtw = (((int64_t)blockIdx.x + P.batch0) * NW + w) * QB;
             cw[w] = (pruned && qtw < n_qtiles) ? P.tile_cluster[qtw] : -1;
+            qtile[w] = qtw;
         }
         float bmax = 0.f;  // band of the valid lanes only (invalid lanes were given ||x||^2 = 0)
 #pragma unroll
@@ -781,7 +785,15 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
 #pragma unroll
                         for (int w = 0; w < NW; ++w) {
                             if (cw[w] < 0) continue;
-                            const float g = P.clus_dist[(size_t)cw[w] * P.n_clusters + c] - P.clus_radius[cw[w]] - rc;
+                            // ball to ball: |x - y| >= |c_w - c_c| - R_w - R_c; with the per-tile table, from the tile's own
+                            // rows: |x - y| >= min_x |x - c_c| - R_c (no R_w, and |x - c_c| ~ sqrt(|c_w - c_c|^2 + |x - c_w|^2)
+                            // in high dimension: prunes where the balls themselves overlap)
+                            float g = P.clus_dist[(size_t)cw[w] * P.n_clusters + c] - P.clus_radius[cw[w]] - rc;
+                            if (P.tile_cdist) {
+#pragma unroll
+                                for (int qb = 0; qb < QB; ++qb)
+                                    g = fmaxf(g, P.tile_cdist[(size_t)(qtile[w] + qb) * P.n_clusters + c] - rc);
+                            }
                             lb = fminf(lb, g > 0.f ? g * g : 0.f);
                         }
                         // pruned only when NO member can enter any band; scanned already: not again (duplicates in the lists)
@@ -1155,6 +1167,7 @@ struct ClusterTables {
     const float* clus_dist;
     const int32_t* clus_order;
     int max_visit;
+    const float* tile_cdist;
 };
 
 static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
@@ -1190,6 +1203,7 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     P.clus_radius = ct ? ct->clus_radius : nullptr; P.clus_dist = ct ? ct->clus_dist : nullptr;
     P.clus_order = ct ? ct->clus_order : nullptr;
     P.max_visit = ct ? ct->max_visit : 0;
+    P.tile_cdist = ct ? ct->tile_cdist : nullptr;
     const int64_t need = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
     if (ws_bytes < need) return TDR_ERR_WORKSPACE;
     const size_t lds = screen_lds_bytes(ks, L, cfg.qb, cfg.terms);
@@ -1254,7 +1268,29 @@ int tdr_knn_screen_clustered_f32(const float* x16, const float* X, int64_t ldx, 
         return TDR_ERR_BAD_ARG;
     if (n_img % TILE_ROWS != 0) return TDR_ERR_BAD_ARG;
     if (q_pos_begin < 0 || q_pos_end > n_img || (q_pos_end > q_pos_begin && q_pos_begin % 256 != 0)) return TDR_ERR_BAD_ARG;
-    ClusterTables ct = {n_clusters, row_map, tile_cluster, clus_tile_begin, clus_radius, clus_dist, clus_order, 0};
+    ClusterTables ct = {n_clusters, row_map, tile_cluster, clus_tile_begin, clus_radius, clus_dist, clus_order, 0, nullptr};
+    return knn_screen_impl(x16, X, ldx, norms, n_img, 0, x16, X, ldx, norms, n_img, d, k, metric, exclude_self, tier, 0, meta,
+                           out_d, out_i, flags, n_flagged, ws, ws_bytes, &ct, q_pos_begin, q_pos_end, stream);
+}
+
+/* The same search with a per-tile table: tile_cdist (n_img / 32, n_clusters) holds, for every 32-row tile of the sorted
+ * order, a LOWER bound of the distance (not squared) from any of its rows to every cluster centre
+ * (tdr_cluster_tile_cdist_f32).  A cluster is then skipped when no row of the workgroup's query tiles can have a member
+ * of it inside its band by |x - y| >= |x - c| - R_c -- sharper than the ball-to-ball bound (no query-side radius, and in high
+ * dimension |x - c| ~ sqrt(|c_w - c|^2 + |x - c_w|^2)): clusters whose balls overlap are still told apart.  Results are the
+ * same rows bit for bit; only the amount of skipped work differs. */
+int tdr_knn_screen_clustered_tb_f32(const float* x16, const float* X, int64_t ldx, const float* norms, int64_t n_img, int d, int k,
+                                    int metric, int exclude_self, int tier, const uint32_t* meta, const int32_t* row_map,
+                                    int n_clusters, const int32_t* tile_cluster, const int32_t* clus_tile_begin,
+                                    const float* clus_radius, const float* clus_dist, const int32_t* clus_order,
+                                    const float* tile_cdist, int64_t q_pos_begin, int64_t q_pos_end, float* out_d, int32_t* out_i,
+                                    int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+    if (n_clusters > 4096) return TDR_ERR_UNSUPPORTED;
+    if (!row_map || !tile_cluster || !clus_tile_begin || !clus_radius || !clus_dist || !clus_order || n_clusters <= 0)
+        return TDR_ERR_BAD_ARG;
+    if (n_img % TILE_ROWS != 0) return TDR_ERR_BAD_ARG;
+    if (q_pos_begin < 0 || q_pos_end > n_img || (q_pos_end > q_pos_begin && q_pos_begin % 256 != 0)) return TDR_ERR_BAD_ARG;
+    ClusterTables ct = {n_clusters, row_map, tile_cluster, clus_tile_begin, clus_radius, clus_dist, clus_order, 0, tile_cdist};
     return knn_screen_impl(x16, X, ldx, norms, n_img, 0, x16, X, ldx, norms, n_img, d, k, metric, exclude_self, tier, 0, meta,
                            out_d, out_i, flags, n_flagged, ws, ws_bytes, &ct, q_pos_begin, q_pos_end, stream);
 }
@@ -1274,7 +1310,7 @@ int tdr_knn_ivf_f32(const float* x16, const float* X, int64_t ldx, const float* 
     if (!row_map || !tile_cluster || !clus_tile_begin || !clus_radius || !clus_dist || !clus_order || n_clusters <= 0 || nprobe < 1)
         return TDR_ERR_BAD_ARG;
     if (n_img % TILE_ROWS != 0) return TDR_ERR_BAD_ARG;
-    ClusterTables ct = {n_clusters, row_map, tile_cluster, clus_tile_begin, clus_radius, clus_dist, clus_order, nprobe};
+    ClusterTables ct = {n_clusters, row_map, tile_cluster, clus_tile_begin, clus_radius, clus_dist, clus_order, nprobe, nullptr};
     return knn_screen_impl(x16, X, ldx, norms, n_img, 0, x16, X, ldx, norms, n_img, d, k, metric, exclude_self, tier, 0, meta,
                            out_d, out_i, flags, n_flagged, ws, ws_bytes, &ct, 0, 0, stream);
 }

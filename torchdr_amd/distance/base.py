@@ -156,6 +156,8 @@ class PackedPoints:
 
 
 PRUNE_MODE = _os.environ.get("TDR_KNN_PRUNE", "auto")  # "0": never; "force": whenever supported; "auto": N >= 65536
+TILE_BOUNDS = True   # per-tile bounds as the second chance of a pruned search (ClusterIndex.tile_table); "force": always take it
+_TILE_MAX_SCAN_FRACTION = 0.97
 _SEED_DROP = 0.25    # adaptive seeding: a max-min SQUARED distance below a quarter of the previous one ends the seeding
 _PRUNE_MIN_N = 65536
 _PRUNE_MAX_SCAN_FRACTION = 0.5  # predicted share of tiles still visited above which the plain scan is used
@@ -261,6 +263,8 @@ class ClusterIndex:
             "tdr_cluster_tables_f32",
         )
         self.n_clusters = C
+        self.centres = cent
+        self.tile_cdist = None
         self.tile_begin = tile_begin
         self.radius = radius     # rounded up in the kernel
         self.dist = cd           # rounded down in the kernel
@@ -299,6 +303,44 @@ class ClusterIndex:
         t = self.tiles.to(gap.dtype)
         visited = torch.mv((gap * gap <= tau).to(gap.dtype), t)
         return float((visited * t).sum() / (t.sum() ** 2))
+
+
+    # ---- per-tile bounds: the second chance of data whose balls overlap ---------------------------------------------------
+    def tile_table(self, P: "PackedPoints"):
+        """(n_img / 32, C) lower bounds of the distance from any row of a tile of the sorted order to every centre
+        (``tdr_cluster_tile_cdist_f32`` on blocks of the exact distance matrix rows x centres from the dense MFMA kernel).  With it
+        the scan skips a cluster when |x - c| - R_c of the workgroup's OWN rows exceeds their thresholds -- no query-side radius,
+        and in high dimension |x - c| ~ sqrt(|c_w - c|^2 + |x - c_w|^2): blobs whose balls overlap (centre distance 16, radius
+        6.6, k-th neighbour at 8: the ball-to-ball bound keeps every cluster) are still told apart (the tile bound keeps 11 %)."""
+        if self.tile_cdist is not None:
+            return self.tile_cdist
+        self.finish()
+        L = _lib.lib()
+        dev, d, C = P.device, P.d, self.n_clusters
+        PC = PackedPoints(self.centres)
+        T = torch.empty((self.n_img // 32, C), dtype=torch.float32, device=dev)
+        chunk = 32768
+        for r0 in range(0, self.n_img, chunk):
+            rm = self.row_map[r0:r0 + chunk]
+            Pq = PackedPoints(P.X.index_select(0, rm.clamp(min=0).long()))
+            D2 = dense_packed(Pq, PC, "sqeuclidean", False)
+            _lib.check(L.tdr_cluster_tile_cdist_f32(_lib.ptr(D2), D2.stride(0), rm.numel(), C, d, _lib.ptr(rm), _lib.ptr(Pq.norms),
+                                                    _lib.ptr(PC.norms), _lib.ptr(T[r0 // 32:]), _lib.stream_ptr()),
+                       "tdr_cluster_tile_cdist_f32")
+        self.tile_cdist = T
+        return T
+
+    def scan_fraction_tiles(self, tau: float) -> float:
+        """Predicted share of the database tiles a query tile still visits under the per-tile bound at threshold tau (squared
+        units), from ~512 tiles spread over the sorted order."""
+        T = self.tile_cdist
+        step = max(T.shape[0] // 512, 1)
+        sub = T[::step]
+        sub = sub[torch.isfinite(sub[:, 0])]
+        gap = (sub - self.radius[None, :]).clamp_(min=0)
+        t = self.tiles.to(gap.dtype)
+        visited = torch.mv((gap * gap <= tau).to(gap.dtype), t)
+        return float(visited.mean() / t.sum())
 
 
 def _use_screen(Q, Y, nq, k, metric):
@@ -543,7 +585,7 @@ def _cluster_index(Y, ops, build=True):
     return ci
 
 
-def _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range=(0, 0)):
+def _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range=(0, 0), tile_cdist=None):
     """Cluster-pruned self search of Y (all of it, or the queries at positions pos_range of the sorted order): rows of
     out_d / out_i are indexed by SOURCE row.  Returns (flags indexed by source row, n_flagged)."""
     L = _lib.lib()
@@ -556,14 +598,15 @@ def _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     _lib.check(
-        L.tdr_knn_screen_clustered_f32(
+        L.tdr_knn_screen_clustered_tb_f32(
             _lib.ptr(ci.img16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), ci.n_img, d, k, _METRIC_ID[metric],
             1 if exclude_self else 0, tier, _lib.ptr(ops[2]), _lib.ptr(ci.row_map), ci.n_clusters, _lib.ptr(ci.tile_cluster),
-            _lib.ptr(ci.tile_begin), _lib.ptr(ci.radius), _lib.ptr(ci.dist), _lib.ptr(ci.order), int(pos_range[0]),
+            _lib.ptr(ci.tile_begin), _lib.ptr(ci.radius), _lib.ptr(ci.dist), _lib.ptr(ci.order),
+            None if tile_cdist is None else _lib.ptr(tile_cdist), int(pos_range[0]),
             int(pos_range[1]), _lib.ptr(out_d), _lib.ptr(out_i), _lib.ptr(flags), _lib.ptr(n_flagged), _lib.ptr(ws),
             ws_bytes, _lib.stream_ptr(),
         ),
-        "tdr_knn_screen_clustered_f32",
+        "tdr_knn_screen_clustered_tb_f32",
     )
     if PROFILE is not None:
         ev1.record()
@@ -586,6 +629,7 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
         _cluster_index_early(Y)
     ops = _screen_operands(Q, Y)
     pilot_tau = None
+    tile_tab = None
     if pilot and nq >= _SCREEN_PILOT_MIN_Q:
         # the index build does not depend on the pilot's outcome: it runs next to it
         tier, pilot_tau = _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset,
@@ -598,9 +642,20 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
         # worth it only when the cluster balls are far apart relative to the neighbour distances: predicted from the
         # pilot's k-th distances (with slack for the blocks the pilot did not see)
         if _opt("PRUNE_MODE") != "force" and (pilot_tau is None or ci.scan_fraction(2.0 * pilot_tau) > _PRUNE_MAX_SCAN_FRACTION):
+            # the balls overlap too much for the ball-to-ball bound.  Second chance: the per-tile table (a few ms of dense
+            # distances rows x centres) and its own prediction
             prune = False
+            if pilot_tau is not None and _opt("TILE_BOUNDS"):
+                tile_tab = ci.tile_table(Y)
+                # pilot_tau is the LARGEST k-th distance of the pilot rows and a workgroup prunes with its own, smaller,
+                # thresholds, so the prediction is pessimistic -- measured at N = 1M, D = 128 (unpruned -> tile bounds, ms):
+                # prediction 0.34: 497 -> 158; 0.70 (D = 64): 429 -> 242; 0.96 (N = 300k): 88 -> 59; 1.00 (blobs that
+                # overlap entirely): 483 -> 448; 0.998 (ONE Gaussian): 460 -> 514.  Taken whenever anything is predicted to go.
+                prune = _opt("TILE_BOUNDS") == "force" or ci.scan_fraction_tiles(pilot_tau) <= _TILE_MAX_SCAN_FRACTION
+                if not prune:
+                    tile_tab = None
     if prune:
-        flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i)
+        flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, tile_cdist=tile_tab)
     else:
         flags, n_flagged = _screen_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier, False, out_d, out_i,
                                           profile=PROFILE is not None)
@@ -609,6 +664,7 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
         _screen_fallback(Q, Y, q0, k, metric, exclude_self, q_offset, flags.nonzero().squeeze(1), out_d, out_i)
     LAST_KNN["tier"] = tier
     LAST_KNN["pruned"] = bool(prune)
+    LAST_KNN["tile_bounds"] = tile_tab is not None
     # the cluster-sorted row order of a pruned self search (perm: position -> source row, inv: row -> position; members
     # of a cluster by ascending row): callers that go on to gather rows by neighbour index (the UMAP loop) renumber the
     # points in it.  Handed to the caller through its `info` record, not through module state.
@@ -721,8 +777,15 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
         return None
     tier, tau = int(vote[1]), float(vote[2])
     ci = _cluster_index(Y, ops)
+    tile_tab = None
     if _opt("PRUNE_MODE") != "force" and ci.scan_fraction(2.0 * tau) > _PRUNE_MAX_SCAN_FRACTION:
-        return None  # same tables and tau on every rank: same decision
+        # same tables and tau on every rank: same decision.  Second chance as in the single-process search: the per-tile
+        # bounds (every rank builds the same table -- a few ms -- and reads the same prediction off it)
+        if not _opt("TILE_BOUNDS"):
+            return None
+        tile_tab = ci.tile_table(Y)
+        if not (_opt("TILE_BOUNDS") == "force" or ci.scan_fraction_tiles(tau) <= _TILE_MAX_SCAN_FRACTION):
+            return None
     # this rank's positions [c0, c1) of the compact sorted order -> the range of the padded layout that holds them
     # (begin rounded down to a query batch; the few extra rows are answered twice, by this rank and by its neighbour)
     pp = ci.ppos[torch.tensor([c0, c1 - 1], device=dev)].tolist()
@@ -731,7 +794,8 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
     out_i = torch.empty((n, k), dtype=torch.int32, device=dev)
     rows = ci.perm[c0:c1].long()
     with phase("knn: pruned scan + rescoring"):
-        flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range=(p0, p1))
+        flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range=(p0, p1),
+                                          tile_cdist=tile_tab)
         if int(n_flagged.item()):
             mine = rows[flags[rows] != 0]
             if mine.numel():
