@@ -133,3 +133,28 @@ def test_dataloader_order_and_ivfpq_configuration_errors():
     with pytest.raises(ValueError, match="must be divisible by M"):
         pairwise_distances(torch.randn(500, 33), k=10, backend=FaissConfig(index_type="IVFPQ", nlist=50, nprobe=10, M=8, nbits=8),
                            return_indices=True)
+
+
+def test_embedding_padding_and_new_switches_cpu():
+    """Host helpers of round 3 that need no device: the zero-padding of embeddings to the next kernel width, and the scoped
+    switch of the per-tile bounds."""
+    import torch
+
+    from torchdr_amd import config
+    from torchdr_amd.affinity.entropic import pad_embedding
+    from torchdr_amd.distance import base as dbase
+
+    for nc, w in ((1, 2), (2, 2), (3, 3), (4, 4), (5, 8), (9, 16), (17, 32), (32, 32)):
+        Z = torch.randn(7, nc, dtype=torch.float64)
+        P = pad_embedding(Z)
+        assert P.shape == (7, w) and P.dtype == torch.float32 and P.is_contiguous()
+        assert torch.equal(P[:, :nc], Z.float()) and float(P[:, nc:].abs().sum()) == 0.0
+    with pytest.raises(NotImplementedError):
+        pad_embedding(torch.zeros(3, 33))
+    assert dbase._opt("TILE_BOUNDS") is True
+    with config.options(TILE_BOUNDS="force"):
+        assert dbase._opt("TILE_BOUNDS") == "force"
+        with config.options(TILE_BOUNDS=False):
+            assert dbase._opt("TILE_BOUNDS") is False
+        assert dbase._opt("TILE_BOUNDS") == "force"
+    assert dbase._opt("TILE_BOUNDS") is True
