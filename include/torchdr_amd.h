@@ -366,6 +366,13 @@ int tdr_cosne_grad_f64(const double* Z, int nc, int64_t n_total, int64_t row0, i
 int tdr_radam_poincare_f64(double* Z, const double* egrad, double* exp_avg, double* exp_avg_sq, double* rgrad,
                            int64_t n_rows, int nc, double beta1, double beta2, double eps, double step_size,
                            double maxnorm, int* nan_flag, int n_iter, void* stream);
+/* neighbor_embedding/pacmap.py:213-239, the mid-near pairs of one iteration for all rows and slots in one launch: 6 candidates
+ * j = r + (r >= i), r uniform in [1, n - 2] (counter hash keyed by seed / iteration / row / slot / candidate), ranked by their
+ * input-space distance to x_i (mode 0 squared or plain Euclidean, 2 manhattan, 3 angular), the second nearest kept.
+ * X (n, d) row stride ldx; out (n, n_mid) int64: emit_index 0 = the POSITION (0..5) of that candidate among the six, which is what
+ * the reference stores and uses (its `topk(...).indices[:, 1]`), 1 = the candidate's row (test hook) */
+int tdr_pacmap_mid_near_f32(const float* X, int64_t ldx, int d, int64_t n, int n_mid, int mode, uint64_t seed, int n_iter,
+                            int emit_index, int64_t* out, void* stream);
 /* gradient of neighbor_embedding/pacmap.py:213-265 (near / mid-near / further pair losses) */
 int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_idx, int m_near, float w_nb,
                         const int64_t* mid_idx, int m_mid, float w_mn, const int64_t* far_idx, int m_far, float w_fp,

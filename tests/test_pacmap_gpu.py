@@ -96,3 +96,49 @@ def test_pacmap_end_to_end():
     Z = torchdr_amd.PACMAP(n_neighbors=10, random_state=0).fit_transform(X)
     assert Z.shape == (n, 2) and bool(torch.isfinite(Z).all())
     assert float(knn_label_accuracy(Z, labels, k=10)) > 0.9
+
+
+@pytest.mark.parametrize("metric,mode", [("sqeuclidean", 0), ("manhattan", 2), ("angular", 3)])
+def test_mid_near_kernel_samples_what_the_reference_samples(metric, mode):
+    """tdr_pacmap_mid_near_f32 (pacmap.py:213-239 in one launch), through its test hook that emits the picked ROW: every pick is one of six candidates that are uniform over
+    the rows the reference can draw (1 .. n - 1, the row itself excluded), and it is the SECOND nearest of them in the input
+    space -- checked by recomputing the six candidates' distances from the same hash on the host side of the test: the
+    distribution of the pick's rank among fresh uniform rows matches the second order statistic of six."""
+    from torchdr_amd import _lib
+
+    n, d, n_mid = 20_000, 24, 5
+    X = gmm(n, d, 2.0, seed=3).cuda().contiguous()
+    L = _lib.lib()
+    out = torch.empty((n, n_mid), dtype=torch.int64, device="cuda")
+    _lib.check(L.tdr_pacmap_mid_near_f32(_lib.ptr(X), X.stride(0), d, n, n_mid, mode, 1234567, 7, 1, _lib.ptr(out), _lib.stream_ptr()), "mid")
+    out2 = torch.empty_like(out)
+    _lib.check(L.tdr_pacmap_mid_near_f32(_lib.ptr(X), X.stride(0), d, n, n_mid, mode, 1234567, 7, 1, _lib.ptr(out2), _lib.stream_ptr()), "mid")
+    assert torch.equal(out, out2)                                              # a function of (seed, iteration, row, slot)
+    rows = torch.arange(n, device="cuda")[:, None]
+    assert int(out.min()) >= 1 and int(out.max()) <= n - 1 and not bool((out == rows).any())
+    # uniform over the admissible rows: chi-square of 20 equal bins
+    hist = torch.histc(out.float(), bins=20, min=1, max=n - 1)
+    exp = out.numel() / 20
+    assert float(((hist - exp) ** 2 / exp).sum()) < 60
+    # second order statistic of six: the share of uniformly drawn rows that are nearer than the pick has mean 2/7
+    def dist(a, b):
+        if mode == 0:
+            return ((a - b) ** 2).sum(-1)
+        if mode == 2:
+            return (a - b).abs().sum(-1)
+        return -(a * b).sum(-1)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    probe = torch.randint(1, n, (n, 64), device="cuda", generator=g)
+    dp = dist(X[:, None, :], X[probe])                                         # (n, 64)
+    dpick = dist(X, X[out[:, 0]])
+    share = (dp < dpick[:, None]).float().mean()
+    assert abs(float(share) - 2.0 / 7.0) < 0.01, float(share)
+    # another iteration / seed draws other pairs
+    _lib.check(L.tdr_pacmap_mid_near_f32(_lib.ptr(X), X.stride(0), d, n, n_mid, mode, 1234567, 8, 1, _lib.ptr(out2), _lib.stream_ptr()), "mid")
+    assert float((out2 == out).float().mean()) < 0.01
+    # production form: the POSITION of that candidate among the six (the reference's `topk(...).indices[:, 1]`): 0..5, uniform
+    pos = torch.empty_like(out)
+    _lib.check(L.tdr_pacmap_mid_near_f32(_lib.ptr(X), X.stride(0), d, n, n_mid, mode, 1234567, 7, 0, _lib.ptr(pos), _lib.stream_ptr()), "mid")
+    assert int(pos.min()) == 0 and int(pos.max()) == 5
+    h6 = torch.bincount(pos.reshape(-1), minlength=6).float()
+    assert float(((h6 - pos.numel() / 6) ** 2 / (pos.numel() / 6)).sum()) < 30

@@ -723,6 +723,59 @@ __global__ __launch_bounds__(256) void sne_repulsion_kernel(const float* __restr
     }
 }
 
+// ---- PaCMAP mid-near sampling (pacmap.py:213-239): one 16-lane group per (row, slot) -----------------------------------------
+// The lanes of a group split the feature dimension; each accumulates its share of the 6 candidate distances, the group adds
+// them up (DPP row reductions) and every lane picks the second smallest.  The reference does this with six gathers of
+// (n, 6, d) blocks, a distance kernel and a top-k per slot and iteration.
+__global__ __launch_bounds__(256) void pacmap_mid_near_kernel(const float* __restrict__ X, int64_t ldx, int d, int64_t n, int n_mid,
+                                                              int mode, uint64_t seed, uint32_t iter, int emit_index,
+                                                              int64_t* __restrict__ out) {
+    const int gl = threadIdx.x & 15;
+    const int64_t item = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    if (item >= n * n_mid) return;
+    const int64_t i = item / n_mid;
+    const int slot = (int)(item - i * n_mid);
+    const uint32_t key = neg_row_key(seed ^ 0x5bd1e9955bd1e995ull, iter, i) + 0x9E3779B9u * (uint32_t)(slot + 1);
+    int64_t cand[6];
+    const float* xi = X + (size_t)i * ldx;
+    float acc[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const uint32_t h = mix32(key + 0x85EBCA6Bu * (uint32_t)(c + 1));
+        const int64_t r = 1 + (int64_t)(((uint64_t)h * (uint64_t)(n - 2)) >> 32);      // [1, n - 2]
+        cand[c] = r + (r >= i ? 1 : 0);
+        acc[c] = 0.f;
+    }
+    for (int f = gl; f < d; f += 16) {
+        const float a = xi[f];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const float b = X[(size_t)cand[c] * ldx + f];
+            if (mode == 0) { const float t = a - b; acc[c] = fmaf(t, t, acc[c]); }
+            else if (mode == 2) acc[c] += fabsf(a - b);
+            else acc[c] = fmaf(-a, b, acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) acc[c] = group_sum<16>(acc[c]);
+    if (gl == 0) {
+        int rank1 = -1;        // second of the ascending order; ties keep the earlier candidate first
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            int below = 0;
+#pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2) below += (acc[c2] < acc[c] || (acc[c2] == acc[c] && c2 < c)) ? 1 : 0;
+            if (below == 1) rank1 = c;
+        }
+        int64_t pick = cand[0];
+#pragma unroll
+        for (int c = 1; c < 6; ++c) pick = (rank1 == c) ? cand[c] : pick;
+        // the reference stores `topk(...).indices[:, 1]`: the POSITION of the second nearest among the six, not its row
+        // (pacmap.py:236-239) -- reproduced; emit_index is the test hook that shows which row that was
+        out[item] = emit_index ? pick : (int64_t)rank1;
+    }
+}
+
 // ---- PaCMAP pair losses (pacmap.py:213-265), closed-form gradient -------------------------------------------
 // Three index tables per row: near pairs  w_nb * q/(10+q), mid-near pairs  w_mn * q/(1e4+q), further pairs
 // w_fp / (1+q), with q = 1 + |z_i - z_j|^2.  d/dd of the three: 10 w_nb/(11+d)^2, 1e4 w_mn/(1e4+1+d)^2,
@@ -1089,6 +1142,24 @@ int tdr_sgd_step_f32(float* Z, const float* grad, float* buf, int64_t n, float l
     if (!Z || !grad || !nan_flag || n <= 0) return TDR_ERR_BAD_ARG;
     if (momentum != 0.f && !buf) return TDR_ERR_BAD_ARG;
     hipLaunchKernelGGL(sgd_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Z, grad, buf, n, lr, momentum, first, nan_flag, n_iter);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* PaCMAP mid-near pairs (neighbor_embedding/pacmap.py:213-239), one launch for all rows and slots: for row i and slot s draw
+ * 6 candidates j = r + (r >= i), r uniform in [1, n - 2] (the reference's `randint(1, n - 1)` + shift past the row itself),
+ * rank them by their INPUT-space distance to x_i and keep the second nearest.  mode 0: squared / plain Euclidean (same
+ * ranking), 2: manhattan, 3: angular (-dot).  Candidates come from the counter hash keyed by (seed, iteration, row, slot,
+ * candidate); ties between candidates keep the earlier one, as a stable ascending sort would.  out (n, n_mid) int64:
+ * emit_index = 0: the POSITION (0..5) of that candidate among the six -- what the reference's `topk(...).indices[:, 1]` stores
+ * and then uses as a row index (pacmap.py:236-239; reproduced for result parity); 1: the candidate's row (test hook). */
+int tdr_pacmap_mid_near_f32(const float* X, int64_t ldx, int d, int64_t n, int n_mid, int mode, uint64_t seed, int n_iter,
+                            int emit_index, int64_t* out, void* stream) {
+    if (!X || !out || n < 8 || n >= 0x7fffffffLL || n_mid <= 0 || d <= 0 || ldx < d) return TDR_ERR_BAD_ARG;
+    if (mode != 0 && mode != 2 && mode != 3) return TDR_ERR_UNSUPPORTED;
+    const int64_t items = n * n_mid;
+    hipLaunchKernelGGL(pacmap_mid_near_kernel, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, (hipStream_t)stream, X, ldx, d, n,
+                       n_mid, mode, seed, (uint32_t)n_iter, emit_index, out);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

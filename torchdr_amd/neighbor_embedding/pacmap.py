@@ -76,6 +76,16 @@ class PACMAP(NegativeSamplingNeighborEmbedding):
         if n - 1 < 6:
             raise ValueError("[TorchDR] ERROR : Not enough points to sample 6 mid-near points.")
         dev = self.device_
+        mode = {"sqeuclidean": 0, "euclidean": 0, "manhattan": 2, "angular": 3}.get(self.metric)
+        if mode is not None and self.X_.dtype == torch.float32 and self.X_.is_cuda and n >= 8:
+            # one launch: candidates from the counter hash, their input-space distances, the POSITION of the second nearest
+            # among the six (what `topk(...).indices[:, 1]` below stores -- the reference's quirk, class docstring)
+            X = self.X_ if self.X_.stride(1) == 1 else self.X_.contiguous()
+            out = torch.empty((n, self.n_mid_near), dtype=torch.int64, device=dev)
+            _lib.check(_lib.lib().tdr_pacmap_mid_near_f32(_lib.ptr(X), X.stride(0), X.shape[1], n, self.n_mid_near, mode,
+                                                          int(self._neg_seed), int(self.n_iter_), 0, _lib.ptr(out), _lib.stream_ptr()),
+                       "tdr_pacmap_mid_near_f32")
+            return out
         self_idx = torch.arange(n, device=dev).unsqueeze(1)
         out = torch.empty((n, self.n_mid_near), dtype=torch.int64, device=dev)
         for i in range(self.n_mid_near):
