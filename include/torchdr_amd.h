@@ -377,6 +377,10 @@ int tdr_pacmap_mid_near_f32(const float* X, int64_t ldx, int d, int64_t n, int n
 int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_idx, int m_near, float w_nb,
                         const int64_t* mid_idx, int m_mid, float w_mn, const int64_t* far_idx, int m_far, float w_fp,
                         float* grad, void* stream);
+/* measurement / test switch of tdr_ne_grad_perm_f32: 1 = never split the launch into the two halves of the index range (one
+ * visit per row), 0 (default) = split where the negatives dominate a row (>= 64 items) and the gathered tables exceed an XCD's
+ * L2; returns the previous value */
+int tdr_ne_grad_perm_halves(int mode);
 /* tdr_ne_grad_f32 with the negatives drawn as keyed permutations of the rows (kinds 0 = LargeVis, 3 = InfoTSNE): a row pulls
  * its own draws j = P(i) AND the draws that hit it (i' = P^-1(i)) -- no atomics on the far endpoints.  Per row the draws are
  * uniform and independent across columns / iterations like neighbor_embedding/base.py:628-636; within one column they are

@@ -676,3 +676,42 @@ def test_tsne_repulsion_with_column_segments_equals_the_unsplit_launch(n, nc):
     W = 1 / (1 + D)
     ref = ((W ** 2)[:, :, None] * (Zd[sub, None, :] - Zd[None, :, :])).sum(1)
     assert torch.allclose(F1.cpu().double()[sub], ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("kind,nc,n_neg", [(3, 2, 40), (3, 3, 64), (0, 2, 32)])
+def test_two_half_launch_of_the_permutation_gradient_equals_the_single_visit(kind, nc, n_neg):
+    """Many negatives per row and tables beyond an XCD's L2: tdr_ne_grad_perm_f32 visits every row twice in one launch, once
+    per half of the index range (a visit's negative endpoints -- and InfoTSNE's normalisers -- come from one half); switched
+    off (tdr_ne_grad_perm_halves) the same call visits rows once.  Same items, a row's sums split in two partial sums; odd
+    N (unequal halves); the two-half form is reproducible bit for bit."""
+    from torchdr_amd import _lib
+    from torchdr_amd.neighbor_embedding.base import build_transposed_graph
+
+    L = _lib.lib()
+    n, k = 450_001, 6
+    gen = torch.Generator().manual_seed(4)
+    NN = ((torch.arange(n)[:, None] + torch.randint(1, 2000, (n, k), generator=gen)) % n).to(torch.int32).cuda().contiguous()
+    P = (torch.rand(n, k, generator=gen) / n).cuda().contiguous()
+    Z = (torch.randn(n, nc, generator=gen) * 4).cuda().contiguous()
+    tg = build_transposed_graph(P, NN, 0, n, 1)
+
+    def run():
+        ws = torch.empty(n, dtype=torch.float32, device="cuda")
+        g = torch.zeros((n, nc), device="cuda")
+        _lib.check(L.tdr_ne_grad_perm_f32(_lib.ptr(Z), nc, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]),
+                                          _lib.ptr(tg[2]), kind, 1.0, 2.0 / n, n_neg, 77, 3, _lib.ptr(ws), _lib.ptr(g), _lib.stream_ptr()), "perm")
+        torch.cuda.synchronize()
+        return g, ws
+
+    old = L.tdr_ne_grad_perm_halves(1)
+    try:
+        one, ws1 = run()
+    finally:
+        L.tdr_ne_grad_perm_halves(old)
+    two, ws2 = run()
+    assert float(one.abs().max()) > 0
+    if kind == 3:
+        assert torch.allclose(ws1, ws2, rtol=1e-5)
+    assert torch.allclose(one, two, rtol=1e-4, atol=2e-6 * float(one.abs().max())), float((one - two).abs().max() / one.abs().max())
+    again, _ = run()
+    assert torch.equal(again, two)

@@ -375,14 +375,34 @@ struct NeStepParams {
     int perm_neg;            // 1: negatives are keyed permutations of the rows and BOTH shares of every pair are pulled
                              // (tdr_embed_common.h: permutation sampler); kinds 0 and 3, no injected table
     const float* rowsum;     // kind 3 with perm_neg: (n_total) row normalisers sum_n q of EVERY row (ne_rowsum_kernel)
+    int neg_halves;          // perm_neg, many negatives per row (InfoTSNE: 2 x 300 items): ONE launch in which every row is visited
+                             // by two workgroups, one per half of the index range; a visit takes the row's negative items whose
+                             // OTHER endpoint lies in its half (and, when the row itself does, its neighbour edges).  Workgroups
+                             // go round the 8 XCDs, XCDs 0-3 take the lower half, 4-7 the upper: an XCD gathers from half of
+                             // the embedding and of the normaliser table (6 MB instead of 12 MB at N = 1M against 4 MB of L2).
+                             // The two partial sums of a row meet by atomic adds onto zero: 0 + a + b in either order.
 };
+
+// the half of the index range a workgroup of a two-half launch serves, and its row block
+__device__ __forceinline__ void ne_half_of_block(const NeStepParams& S, int64_t& blk, int64_t& j_lo, int64_t& j_hi) {
+    blk = blockIdx.x; j_lo = 0; j_hi = S.n_total;
+    if (S.neg_halves == 2) {
+        const int x = (int)(blockIdx.x & 7u);
+        blk = (int64_t)(blockIdx.x >> 3) * 4 + (x & 3);
+        const int64_t half = (S.n_total + 1) >> 1;
+        j_lo = (x >> 2) ? half : 0;
+        j_hi = (x >> 2) ? S.n_total : half;
+    }
+}
 
 // InfoTSNE with the permutation sampler, pass 1: rowsum[i] = sum over row i's own draws of q = 1 / (1 + d)
 template <int NC, int G, bool PAD = false>
 __global__ __launch_bounds__(256) void ne_rowsum_kernel(const NeStepParams S, float* __restrict__ out) {
     const int nc = PAD ? S.nc : NC;
     const int gl = threadIdx.x % G;
-    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    int64_t blk, j_lo, j_hi;
+    ne_half_of_block(S, blk, j_lo, j_hi);
+    const int64_t r = (blk * 256 + threadIdx.x) / G;
     if (r >= S.n_rows) return;
     const int64_t gi = S.row0 + r;
     const Vec<NC> zi = load_zp<NC, PAD>(S.Z, gi, nc);
@@ -390,6 +410,7 @@ __global__ __launch_bounds__(256) void ne_rowsum_kernel(const NeStepParams S, fl
     for (int col = gl; col < S.n_neg; col += G) {
         const PermKey K = perm_key(S.seed, S.iter, col, S.n_total);
         const uint32_t j = perm_fwd((uint32_t)gi, K);
+        if ((int64_t)j < j_lo || (int64_t)j >= j_hi) continue;
         const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
         float d = 0.f;
 #pragma unroll
@@ -397,16 +418,22 @@ __global__ __launch_bounds__(256) void ne_rowsum_kernel(const NeStepParams S, fl
         s += 1.0f / (1.0f + d);     // a self draw (probability 1/N) counts q = 1, as the pair (i, i) would
     }
     s = group_sum<G>(s);
-    if (gl == 0) out[gi] = s;
+    if (gl == 0) {
+        if (S.neg_halves == 2) unsafeAtomicAdd(&out[gi], s);     // onto zero: the two visits' sums in either order
+        else out[gi] = s;
+    }
 }
 
 template <int NC, int G, bool PAD = false>
 __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
     const int nc = PAD ? S.nc : NC;  // row width in memory (PAD: NC is the padded register width)
     const int gl = threadIdx.x % G;
-    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    int64_t blk, j_lo, j_hi;
+    ne_half_of_block(S, blk, j_lo, j_hi);
+    const int64_t r = (blk * 256 + threadIdx.x) / G;
     if (r >= S.n_rows) return;
     const int64_t gi = S.row0 + r;
+    const bool own_half = gi >= j_lo && gi < j_hi;      // this visit also takes the row's neighbour edges
     const Vec<NC> zi = load_zp<NC, PAD>(S.Z, gi, nc);
     float g[NC];
 #pragma unroll
@@ -416,7 +443,7 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
     const bool pull = S.t_rowptr != nullptr;
     // out-edges i -> j : +w (z_i - z_j) on i, and -w (z_i - z_j) on j (pushed with atomics unless j's own row
     // pulls it from the transposed graph)
-    for (int p = gl; p < S.k; p += G) {
+    for (int p = gl; own_half && p < S.k; p += G) {
         const int64_t j = S.nn[(size_t)r * S.k + p];
         const float pij = S.P[(size_t)r * S.k + p];
         const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
@@ -432,7 +459,7 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
             if (!pull && c < nc) unsafeAtomicAdd(&S.grad[(size_t)j * nc + c], -t);
         }
     }
-    if (pull) {
+    if (pull && own_half) {
         // in-edges s -> i carry -w (z_s - z_i) = +w (z_i - z_s): the same expression as an out-edge
         const int64_t e1 = S.t_rowptr[r + 1];
         for (int64_t e = S.t_rowptr[r] + gl; e < e1; e += G) {
@@ -454,7 +481,7 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
             const PermKey K = perm_key(S.seed, S.iter, it >> 1, S.n_total);
             const bool inward = (it & 1) != 0;
             const uint32_t j = inward ? perm_inv((uint32_t)gi, K) : perm_fwd((uint32_t)gi, K);
-            if ((int64_t)j == gi) continue;
+            if ((int64_t)j == gi || (int64_t)j < j_lo || (int64_t)j >= j_hi) continue;
             const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
             float df[NC];
             float d = 0.f;
@@ -953,12 +980,19 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
     return launch_group<16>(umap_grad_kernel<3, 16, 4>, P, n_rows, st);
 }
 
+static int g_ne_halves_mode = 0;   // 0 = by size, 1 = never (tdr_ne_grad_perm_halves: measurements and the equality test)
+
 static int ne_grad_launch(NeStepParams& S, float* rowsum, hipStream_t st) {
     const int nc = S.nc;
     const int64_t n_rows = S.n_rows;
+    const int64_t blocks1 = (n_rows + 15) / 16;
+    const int64_t grid_rows = S.neg_halves == 2 ? ((blocks1 + 3) / 4) * 8 : blocks1;     // two visits per (padded) row block
     if (rowsum) {   // InfoTSNE with the permutation sampler, pass 1: every row's normaliser over its own draws
-        const int rpb = 256 / 16;
-        const dim3 grid((unsigned)((n_rows + rpb - 1) / rpb));
+        if (S.neg_halves == 2) {
+            hipError_t e0 = hipMemsetAsync(rowsum, 0, (size_t)S.n_total * sizeof(float), st);
+            if (e0 != hipSuccess) return (int)e0;
+        }
+        const dim3 grid((unsigned)grid_rows);
         if (nc == 2) hipLaunchKernelGGL((ne_rowsum_kernel<2, 16>), grid, dim3(256), 0, st, S, rowsum);
         else if (nc == 3) hipLaunchKernelGGL((ne_rowsum_kernel<3, 16>), grid, dim3(256), 0, st, S, rowsum);
         else if (nc <= 4) hipLaunchKernelGGL((ne_rowsum_kernel<4, 16, true>), grid, dim3(256), 0, st, S, rowsum);
@@ -966,6 +1000,16 @@ static int ne_grad_launch(NeStepParams& S, float* rowsum, hipStream_t st) {
         else if (nc <= 16) hipLaunchKernelGGL((ne_rowsum_kernel<16, 16, true>), grid, dim3(256), 0, st, S, rowsum);
         else hipLaunchKernelGGL((ne_rowsum_kernel<32, 16, true>), grid, dim3(256), 0, st, S, rowsum);
         TDR_CHECK_LAUNCH();
+    }
+    if (S.neg_halves == 2) {
+#define TDR_NE2(K) { hipLaunchKernelGGL(K, dim3((unsigned)grid_rows), dim3(256), 0, st, S); hipError_t e = hipGetLastError(); return e == hipSuccess ? TDR_OK : (int)e; }
+        if (nc == 2) TDR_NE2((ne_grad_kernel<2, 16>))
+        if (nc == 3) TDR_NE2((ne_grad_kernel<3, 16>))
+        if (nc <= 4) TDR_NE2((ne_grad_kernel<4, 16, true>))
+        if (nc <= 8) TDR_NE2((ne_grad_kernel<8, 16, true>))
+        if (nc <= 16) TDR_NE2((ne_grad_kernel<16, 16, true>))
+        TDR_NE2((ne_grad_kernel<32, 16, true>))
+#undef TDR_NE2
     }
     // exact instances for 2 and 3 components, zero-padded register instances for any other width up to 32
     if (nc == 2) return launch_group<16>(ne_grad_kernel<2, 16>, S, n_rows, st);
@@ -989,7 +1033,7 @@ int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64
     if (kind < 0 || kind > 3) return TDR_ERR_BAD_ARG;
     NeStepParams S;
     S.nc = nc;
-    S.perm_neg = 0; S.rowsum = nullptr;
+    S.perm_neg = 0; S.rowsum = nullptr; S.neg_halves = 1;
     S.Z = Z; S.n_total = n_total; S.row0 = row0; S.n_rows = n_rows; S.nn = nn; S.P = P_; S.k = k; S.kind = kind;
     S.exag = exag; S.rep_coef = rep_coef; S.n_neg = n_neg; S.neg_inj = neg_inj; S.seed = seed;
     S.iter = (uint32_t)n_iter; S.grad = grad;
@@ -1015,11 +1059,24 @@ int tdr_ne_grad_perm_f32(const float* Z, int nc, int64_t n_total, int64_t row0, 
     NeStepParams S;
     S.nc = nc;
     S.perm_neg = 1; S.rowsum = kind == 3 ? rowsum_ws : nullptr;
+    // two halves where the negatives dominate the row (>= 64 items) and the gathered tables do not fit an XCD's 4 MB of L2:
+    // InfoTSNE's 2 x 300 items, 30 iterations at N = 500k / 700k / 1M: 122 / 229 / 413 -> 110 / 202 / 245 ms; at N = 300k
+    // (3.6 MB) 64 -> 102 ms, hence the threshold.  LargeVis (2 x 5 items against ~30 edge items): 0.236 -> 0.288 ms at N = 1M.
+    S.neg_halves = (g_ne_halves_mode != 1 && row0 == 0 && n_rows == n_total && 2 * n_neg >= 64 &&
+                    (int64_t)n_total * (nc + (kind == 3 ? 1 : 0)) * (int64_t)sizeof(float) > (11ll << 19)) ? 2 : 1;   // 5.5 MB
     S.Z = Z; S.n_total = n_total; S.row0 = row0; S.n_rows = n_rows; S.nn = nn; S.P = P_; S.k = k; S.kind = kind;
     S.exag = exag; S.rep_coef = rep_coef; S.n_neg = n_neg; S.neg_inj = nullptr; S.seed = seed;
     S.iter = (uint32_t)n_iter; S.grad = grad;
     S.t_rowptr = t_rowptr; S.t_src = t_src; S.t_val = t_val;
     return ne_grad_launch(S, kind == 3 ? rowsum_ws : nullptr, (hipStream_t)stream);
+}
+
+/* Measurement / test switch: 1 = tdr_ne_grad_perm_f32 never splits its launch into the two halves of the index range, 0 (default)
+ * = by size.  Returns the previous value. */
+int tdr_ne_grad_perm_halves(int mode) {
+    const int old = g_ne_halves_mode;
+    g_ne_halves_mode = mode == 1 ? 1 : 0;
+    return old;
 }
 
 /* Test hook: the permutation sampler's draws -- fwd[i][c] = P_{t,c}(i) and inv[i][c] = P_{t,c}^{-1}(i), (n_total, n_neg) int64. */
