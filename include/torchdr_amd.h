@@ -308,6 +308,23 @@ int tdr_umap_sched_plan_f32(const int64_t* rowptr, const float* eps_per, int64_t
 int tdr_umap_sched_build_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, float* next, int64_t n_rows,
                              int64_t n_total, int t0, int n_iters, int n_slices, const int64_t* blk_base, int32_t* list,
                              void* hdr, int* err, void* stream);
+/* Round 4: the schedule build on GROUP-ORDERED loop state (csrc/tdr_umap_sched.hip, umap_sched_build2_kernel).  `group`
+ * sorts the edges of every 16 consecutive rows (row-major, rows already in (period, column) order: `layout`) stably by
+ * firing-period class -> cols_g / eps_g (nnz), rs_g (nnz bytes: local row | slice << 4), order_g (nnz int32: row-major
+ * position relative to the group's first edge); `ungroup` moves per-edge values (epoch_of_next_sample) back to the
+ * row-major order; `plan_groups` = `plan` with 16-row regions (grp_base: ceil(n_rows/16) + 1 int64, scratch:
+ * ceil(n_rows/16) int64); `build_groups` = `build` on that state: one wavefront per group with equally busy lanes, the
+ * list written through an LDS stage (stage = entries, 0 = default) with coalesced stores.  Same records, same counters
+ * (bit-exact umap.py:243-247); a segment lists the row's firing edges in (period, column) order. */
+int tdr_umap_sched_group_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, int64_t n_rows, int64_t n_total,
+                             int n_slices, int32_t* cols_g, float* eps_g, uint8_t* rs_g, int32_t* order_g, int* err, void* stream);
+int tdr_umap_sched_ungroup_f32(const int64_t* rowptr, const int32_t* order_g, const float* vals_g, int64_t n_rows, float* vals_rm,
+                               void* stream);
+int tdr_umap_sched_plan_groups_f32(const int64_t* rowptr, const float* eps_per, int64_t n_rows, int block_iters, int64_t* scratch,
+                                   int64_t* grp_base, void* stream);
+int tdr_umap_sched_build_groups_f32(const int64_t* rowptr, const int32_t* cols_g, const float* eps_g, const uint8_t* rs_g, float* next_g,
+                                    int64_t n_rows, int t0, int n_iters, int n_slices, const int64_t* grp_base, int32_t* list,
+                                    void* hdr, int* err, int stage, void* stream);
 int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list,
                             const void* hdr, int t_local, int n_slices, float a, float b, int n_iter, int neg_rate,
                             int n_negatives, const int64_t* neg_inj, uint64_t seed, float exag, float rep, float eps,
@@ -332,6 +349,7 @@ typedef struct tdr_umap_loop_desc {
     float a, b; int neg_rate, n_negatives; uint64_t seed; float exag, rep, eps; int n_slices, block_iters;
     const float* lr_table; int max_iter; float momentum; int first_iter; int check_interval; float* norm2; float* snap; int* nan_flag;
     void* scratch; void* gather; void* gather_ctx; int geom;
+    const uint8_t* rs;   /* non-NULL: cols / eps_per / next are group-ordered (tdr_umap_sched_group_f32), blk_base = grp_base */
 } tdr_umap_loop_desc;
 int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d);
 int tdr_umap_loop_run(void* loop, int it0, int n_iters, int use_graph, void* stream);

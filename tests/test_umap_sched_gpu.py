@@ -572,3 +572,201 @@ def test_umap_loop_in_cluster_order_is_the_same_fit():
         assert w.loop_order_ is None
     finally:
         dbase.PRUNE_MODE = old_mode
+
+
+# ---- round 4: the schedule build on group-ordered loop state ------------------------------------------------------------
+def period_class_np(ep):
+    b = ep.numpy().view(np.uint32).astype(np.int64)
+    k = np.where(b < 0x3F800000, 0, (b - 0x3F800000) >> 21)
+    return torch.from_numpy(np.minimum(k, 63))
+
+
+def group(rowptr, cols, eps_per, n_total, S):
+    from torchdr_amd import _lib
+
+    nnz = cols.numel()
+    cols_g, eps_g = torch.empty_like(cols), torch.empty_like(eps_per)
+    rs_g = torch.empty(nnz, dtype=torch.uint8, device="cuda")
+    order_g = torch.empty(nnz, dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().tdr_umap_sched_group_f32(_lib.ptr(rowptr), _lib.ptr(cols), _lib.ptr(eps_per), rowptr.numel() - 1, n_total, S,
+                                                   _lib.ptr(cols_g), _lib.ptr(eps_g), _lib.ptr(rs_g), _lib.ptr(order_g), _lib.ptr(err),
+                                                   _lib.stream_ptr()), "group")
+    assert int(err.item()) == 0
+    return cols_g, eps_g, rs_g, order_g
+
+
+class GroupSched(Sched):
+    """plan / build on group-ordered state (16-row regions); grad and records are the base class's."""
+
+    def __init__(self, rowptr, cols_rm, eps_rm, n_total, B, S, nc=2, row0=0, stage=0):
+        from torchdr_amd import _lib
+
+        self.lib, self.L = _lib, _lib.lib()
+        self.rowptr = rowptr
+        self.cols, self.eps_per = cols_rm, eps_rm      # row-major (oracle_check reads them)
+        self.n_rows, self.n_total, self.B, self.S, self.nc, self.row0, self.stage = rowptr.numel() - 1, n_total, B, S, nc, row0, stage
+        self.cols_g, self.eps_g, self.rs_g, self.order_g = group(rowptr, cols_rm, eps_rm, n_total, S)
+        nb = (self.n_rows + 15) // 16
+        self.nb = nb
+        scratch = torch.empty(nb, dtype=torch.int64, device="cuda")
+        self.blk_base = torch.empty(nb + 1, dtype=torch.int64, device="cuda")
+        _lib.check(self.L.tdr_umap_sched_plan_groups_f32(_lib.ptr(rowptr), _lib.ptr(self.eps_g), self.n_rows, B, _lib.ptr(scratch),
+                                                         _lib.ptr(self.blk_base), _lib.stream_ptr()), "plan_groups")
+        cap = int(self.blk_base[-1].item())
+        self.list = torch.full((cap + 64,), -7, dtype=torch.int32, device="cuda")
+        self.hdr = torch.zeros((int(self.L.tdr_umap_sched_hdr_entries(self.n_rows, B, S)), 2), dtype=torch.int32, device="cuda")
+        self.err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        self.acc = torch.empty((S * self.n_rows, 2 * nc), device="cuda")
+        g0 = rowptr[:-1:16]
+        e0 = torch.repeat_interleave(g0, torch.cat([g0[1:], rowptr[-1:]]) - g0)
+        self.abs_order = e0 + self.order_g.long()       # row-major edge of every group-ordered entry
+
+    def to_group(self, v_rm):
+        return v_rm[self.abs_order].contiguous()
+
+    def to_rows(self, v_g):
+        _l = self.lib
+        out = torch.empty_like(v_g)
+        _l.check(self.L.tdr_umap_sched_ungroup_f32(_l.ptr(self.rowptr), _l.ptr(self.order_g), _l.ptr(v_g), self.n_rows, _l.ptr(out),
+                                                   _l.stream_ptr()), "ungroup")
+        return out
+
+    def build(self, nxt_g, t0, n):
+        _l = self.lib
+        _l.check(self.L.tdr_umap_sched_build_groups_f32(_l.ptr(self.rowptr), _l.ptr(self.cols_g), _l.ptr(self.eps_g), _l.ptr(self.rs_g),
+                                                        _l.ptr(nxt_g), self.n_rows, t0, n, self.S, _l.ptr(self.blk_base), _l.ptr(self.list),
+                                                        _l.ptr(self.hdr), _l.ptr(self.err), self.stage, _l.stream_ptr()), "build_groups")
+        assert int(self.err.item()) == 0
+
+
+@pytest.mark.parametrize("S", [1, 2, 8])
+def test_group_order_is_a_stable_sort_by_period_class(S):
+    n = 3000
+    rowptr, cols, vals = random_graph(n, seed=40 + S, hub=1500)
+    eps_per, _ = prepare(vals.cuda(), 200)
+    cols_p, eps_p = layout(rowptr.cuda(), cols.cuda(), eps_per)
+    cols_g, eps_g, rs_g, order_g = (t.cpu() for t in group(rowptr.cuda(), cols_p, eps_p, n, S))
+    cp, epp = cols_p.cpu(), eps_p.cpu()
+    step = (n - 1 + S - 1) // S
+    for g in range((n + 15) // 16):
+        e0, e1 = int(rowptr[16 * g]), int(rowptr[min(16 * g + 16, n)])
+        o = order_g[e0:e1].long()
+        assert torch.equal(o.sort().values, torch.arange(e1 - e0))                   # a permutation of the group's edges
+        assert torch.equal(cols_g[e0:e1], cp[e0:e1][o]) and torch.equal(eps_g[e0:e1], epp[e0:e1][o])
+        cls = period_class_np(eps_g[e0:e1])
+        assert bool((cls[1:] >= cls[:-1]).all())                                      # classes ascending
+        same = cls[1:] == cls[:-1]
+        assert bool((o[1:][same] > o[:-1][same]).all())                               # stable inside a class
+        row_of = torch.searchsorted(rowptr[16 * g + 1: min(16 * g + 16, n) + 1].contiguous(), e0 + o, right=True)
+        assert torch.equal((rs_g[e0:e1] & 15).long(), row_of)
+        assert torch.equal((rs_g[e0:e1] >> 4).long(), torch.clamp(cols_g[e0:e1].long() // step, max=S - 1))
+    # values travel back to the row-major order
+    gs = GroupSched(rowptr.cuda(), cols_p, eps_p, n, 32, S)
+    v = torch.rand(cols.numel(), device="cuda")
+    assert torch.equal(gs.to_rows(gs.to_group(v)), v)
+
+
+@pytest.mark.parametrize("S", [1, 2, 4, 8])
+@pytest.mark.parametrize("B,t0", [(32, 0), (7, 37), (20, 11)])
+def test_grouped_schedule_is_the_step_by_step_recurrence(S, B, t0):
+    """tdr_umap_sched_build_groups_f32 against the CPU iteration of umap.py:243-247: counters bit-equal, (length, active
+    count) of every record, and every (iteration, slice, row) segment equal IN ORDER to the row's firing edges in their
+    (period, column) order -- the order a row-sharded fit and a single-process fit must share.  A hub row of 1500 edges
+    puts one group beyond the register-resident chunks; a small LDS stage sends many entries down the direct-store path:
+    same lists."""
+    n = 3000
+    rowptr, cols, vals = random_graph(n, seed=3 + S, hub=1500)
+    eps_per, _ = prepare(vals.cuda(), 200)
+    cols_p, eps_p = layout(rowptr.cuda(), cols.cuda(), eps_per)
+    ep_c, cp = eps_p.cpu(), cols_p.cpu()
+    nx_c = ep_c.clone()
+    for t in range(t0):
+        a = nx_c <= np.float32(t + 1)
+        nx_c[a] += ep_c[a]
+    nx0 = nx_c.clone()
+    gs = GroupSched(rowptr.cuda(), cols_p, eps_p, n, B, S)
+    nxt_g = gs.to_group(nx0.cuda())
+    gs.build(nxt_g, t0, B)
+    fires = []
+    for t in range(t0, t0 + B):
+        a = nx_c <= np.float32(t + 1)
+        nx_c[a] += ep_c[a]
+        fires.append(a)
+    assert torch.equal(gs.to_rows(nxt_g).cpu(), nx_c)
+    row_of = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+    step = (n - 1 + S - 1) // S
+    sl_of = torch.clamp(cp.long() // step, max=S - 1)
+    start, length, act = gs.records(B)
+    lst, base = gs.list.cpu().long(), gs.blk_base.cpu()
+    for t in range(B):
+        want_act = torch.bincount(row_of[fires[t]], minlength=n)
+        for s in range(S):
+            k = t * S + s
+            assert torch.equal(act[k], want_act)
+            sel = fires[t] & (sl_of == s)
+            assert torch.equal(length[k], torch.bincount(row_of[sel], minlength=n))
+            idx = torch.repeat_interleave(start[k], length[k]) + (torch.arange(int(length[k].sum())) -
+                                                                   torch.repeat_interleave(length[k].cumsum(0) - length[k], length[k]))
+            rows_g = torch.repeat_interleave(torch.arange(n), length[k])
+            assert torch.equal(torch.sort(row_of[sel] * n + cp[sel].long()).values, torch.sort(rows_g * n + lst[idx]).values)
+            # order inside a segment: by (rank of this firing among the edge's firings of the 8-iteration run, the row's
+            # own edge order) -- a key made of the edge alone
+            rank = torch.zeros(cp.numel(), dtype=torch.long)
+            for tq in range(t - t % 8, t):
+                rank += fires[tq].long()
+            e_sel = torch.nonzero(sel).flatten()
+            key = (row_of[e_sel] * 16 + rank[e_sel]) * cp.numel() + e_sel
+            assert torch.equal(lst[idx], cp[e_sel[torch.argsort(key)]].long()), (t, s)
+    # segments tile each 16-row region without gaps, in (iteration, slice, row) order
+    nb = gs.nb
+    pad = nb * 16 - n
+    st = torch.cat([start, start[:, -1:].expand(-1, pad) + length[:, -1:].expand(-1, pad)], 1).view(B * S, nb, 16)
+    ln = torch.cat([length, torch.zeros((B * S, pad), dtype=torch.long)], 1).view(B * S, nb, 16)
+    assert torch.equal(st[:, :, 1:], st[:, :, :-1] + ln[:, :, :-1])
+    assert torch.equal(st[0, :, 0], base[:-1])
+    assert torch.equal(st[1:, :, 0], st[:-1, :, 15] + ln[:-1, :, 15])
+    assert bool((st[-1, :, 15] + ln[-1, :, 15] <= base[1:]).all())
+    # the stage size does not enter the result
+    used = int((st[-1, -1, 15] + ln[-1, -1, 15]))
+    for stage in (512, 4096):
+        gs2 = GroupSched(rowptr.cuda(), cols_p, eps_p, n, B, S, stage=stage)
+        nxt2 = gs2.to_group(nx0.cuda())
+        gs2.build(nxt2, t0, B)
+        assert torch.equal(nxt2, nxt_g) and torch.equal(gs2.hdr, gs.hdr) and torch.equal(gs2.list[:used], gs.list[:used])
+    # the row-chunk kernel on the same graph: same counters, same records up to the region layout, same segment content
+    sc = Sched(rowptr.cuda(), cols_p, eps_p, n, B, S)
+    nxt_r = nx0.clone().cuda()
+    sc.build(nxt_r, t0, B)
+    assert torch.equal(nxt_r.cpu(), nx_c)
+    s2, l2, a2 = sc.records(B)
+    assert torch.equal(l2, length) and torch.equal(a2, act)
+
+
+def test_grouped_schedule_does_not_depend_on_the_group_composition():
+    """Rows [r0, n) handed over as a graph of their own (what a rank of a row-sharded fit holds): the groups are cut
+    elsewhere, every row's segments list the same columns in the same order."""
+    n, S, B = 2000, 2, 32
+    rowptr, cols, vals = random_graph(n, seed=77, hub=400)
+    eps_per, _ = prepare(vals.cuda(), 200)
+    cols_p, eps_p = layout(rowptr.cuda(), cols.cuda(), eps_per)
+    full = GroupSched(rowptr.cuda(), cols_p, eps_p, n, B, S)
+    nx = full.to_group(eps_p.clone())
+    full.build(nx, 0, B)
+    st_f, ln_f, _ = full.records(B)
+    lst_f = full.list.cpu().long()
+    for r0 in (5, 23):
+        e0 = int(rowptr[r0])
+        rp = (rowptr[r0:] - e0).cuda()
+        part = GroupSched(rp, cols_p[e0:].contiguous(), eps_p[e0:].contiguous(), n, B, S)
+        nxp = part.to_group(eps_p[e0:].clone())
+        part.build(nxp, 0, B)
+        st_p, ln_p, _ = part.records(B)
+        lst_p = part.list.cpu().long()
+        assert torch.equal(ln_p, ln_f[:, r0:])
+        for k in (0, 1, 17, 40, 63):
+            for r in range(0, n - r0, 7):
+                a, b = int(st_p[k, r]), int(st_f[k, r0 + r])
+                m = int(ln_p[k, r])
+                assert torch.equal(lst_p[a:a + m], lst_f[b:b + m]), (r0, k, r)
+        assert torch.equal(part.to_rows(nxp), full.to_rows(nx)[e0:])

@@ -46,11 +46,11 @@ __device__ __forceinline__ int edge_capacity(float ep, int B) {
 }
 
 __global__ __launch_bounds__(256) void umap_sched_plan_kernel(const int64_t* __restrict__ rowptr, const float* __restrict__ eps_per,
-                                                              int64_t n_rows, int B, int64_t* __restrict__ cap) {
+                                                              int64_t n_rows, int B, int rows_per_block, int64_t* __restrict__ cap) {
     __shared__ unsigned long long part[4];
     const int64_t rb = blockIdx.x;
-    const int64_t r0 = rb * SCHED_RB;
-    const int64_t r1 = (r0 + SCHED_RB < n_rows) ? r0 + SCHED_RB : n_rows;
+    const int64_t r0 = rb * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < n_rows) ? r0 + rows_per_block : n_rows;
     const int64_t e0 = rowptr[r0], e1 = rowptr[r1];
     unsigned long long c = 0;
     for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) c += (unsigned long long)edge_capacity(eps_per[e], B);
@@ -403,6 +403,333 @@ __global__ __launch_bounds__(256) void umap_sched_layout_kernel(const int64_t* _
             }
         }
         if (have) { cols_out[b + rank] = col; eps_out[b + rank] = mine; }
+    }
+}
+
+// ---- the schedule build on GROUP-ORDERED loop state (round 4) ----------------------------------------------------------
+// What bounds the row-chunk kernel above (profiles/r03_sched_build_pmc.json, r03_sched_build_ablation.json): its per-firing
+// loops run as many rounds as the busiest lane of the wavefront fires (a row's 16 hottest edges sit in one 16-lane group:
+// ~40 % of the lanes do work), and its list stores are 275 M scattered 4-byte requests per window (0.72 of the 1.9 ms).
+// Here the loop state of every GROUP of 16 consecutive rows is laid out once per fit in order of the firing period
+// (tdr_umap_sched_group_f32: a stable counting sort of the group's edges by period class, 4 classes per octave, rows
+// pre-sorted by (period, column) -- so a row's edges keep their (period, column) order among themselves whatever the
+// other rows of the group are), one wavefront owns one group, and
+//   * a lane's edge and its 63 neighbours fire (nearly) equally often: the recurrence / counting / placement loops run
+//     with most lanes busy;
+//   * the group's list region is filled through an LDS stage, 8 iterations (one contiguous run of the region: segments
+//     follow each other in (iteration, slice, row) order) at a time, and flushed with coalesced stores; entries beyond
+//     the stage go straight to memory;
+//   * nothing is shared between wavefronts: no workgroup barrier, the scan of the segment sizes is a wavefront scan.
+// A row's counters are touched by one wavefront only, in program order, lanes of one LDS instruction in lane order, so a
+// segment lists the row's firing edges in (period, column) order on every run and for every composition of the group
+// (a row-sharded fit cuts the groups elsewhere and still sums a row's forces in the same order).
+// Records and lists have the format of the row-chunk kernel with 16-row blocks (grp_base instead of blk_base).
+constexpr int G2_ROWS = 16;    // rows per group (one wavefront)
+constexpr int G2_STRIDE = 17;  // counters of one (iteration, slice): 16 rows, odd stride
+constexpr int G2_STASH = 16;   // 64-edge chunks whose (mask, column, row | slice) stay in registers between the phases
+constexpr int G2_TC = 8;       // iterations per staged run
+constexpr int G2_STAGE_DEFAULT = 1024;  // staged list entries (LDS, >= 512); the mean run is 16 rows x 8.6 firings x 8 iterations = 1100
+
+// firing period -> class: 4 per octave (epochs_per_sample = max weight / weight >= 1); 2^15.5 and beyond, incl. the
+// never-firing edges (inf), share class 63.  Monotone in the period.
+__device__ __forceinline__ int period_class(float ep) {
+    const uint32_t b = __float_as_uint(ep);
+    if (b < 0x3F800000u) return 0;
+    const uint32_t k = (b - 0x3F800000u) >> 21;
+    return k > 63u ? 63 : (int)k;
+}
+
+// One wavefront per group: stable counting sort of the group's edges (row-major, every row already in (period, column)
+// order) by period class.  Outputs in group order: column, period, (local row | slice << 4), and the edge's position in
+// the row-major order relative to the group's first edge (to move per-edge state between the two orders).
+__global__ __launch_bounds__(64) void umap_sched_group_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                              const float* __restrict__ eps_per, int64_t n_rows, uint32_t slice_step,
+                                                              int S, int32_t* __restrict__ cols_g, float* __restrict__ eps_g,
+                                                              uint8_t* __restrict__ rs_g, int32_t* __restrict__ order_g,
+                                                              int* __restrict__ err) {
+    __shared__ int hist[64];
+    __shared__ int rpl[17];
+    const int lane = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * G2_ROWS;
+    const int nr = (int)((n_rows - r0 < G2_ROWS) ? n_rows - r0 : G2_ROWS);
+    const int64_t e0 = rowptr[r0], e1 = rowptr[r0 + nr];
+    if (e1 - e0 > 0x7fffffffLL - 64) {
+        if (lane == 0) atomicMax(err, 2);
+        return;
+    }
+    const int ne = (int)(e1 - e0);
+    if (lane <= 16) rpl[lane] = (int)(rowptr[r0 + (lane < nr ? lane : nr)] - e0);
+    hist[lane] = 0;
+    __syncthreads();
+    for (int c = 0; c < ne; c += 64)
+        if (c + lane < ne) atomicAdd(&hist[period_class(eps_per[e0 + c + lane])], 1);  // a count: order-independent
+    __syncthreads();
+    // lane b keeps the write position of class b
+    const int cntb = hist[lane];
+    int incl = cntb;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    int binpos = incl - cntb;
+    for (int c = 0; c < ne; c += 64) {
+        const int i = c + lane;
+        const bool valid = i < ne;
+        const float ep = valid ? eps_per[e0 + i] : 0.f;
+        const int32_t col = valid ? cols[e0 + i] : 0;
+        const int cls = valid ? period_class(ep) : -1;
+        unsigned long long rem = __ballot(valid);
+        int dst = 0;
+        while (rem) {  // one round per distinct class of the chunk; lanes of a class keep their order (stable)
+            const int l0 = __ffsll((long long)rem) - 1;
+            const int c0 = __builtin_amdgcn_readlane(cls, l0);
+            const unsigned long long mk = __ballot(cls == c0);
+            const int base = __builtin_amdgcn_readlane(binpos, c0);
+            if (cls == c0) dst = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (lane == c0) binpos += __popcll(mk);
+            rem &= ~mk;
+        }
+        if (valid) {
+            int lr = 0;
+#pragma unroll
+            for (int q = 1; q <= 16; ++q) lr += (rpl[q] <= i) ? 1 : 0;
+            uint32_t s = (uint32_t)col / slice_step;
+            if (s > (uint32_t)(S - 1)) s = (uint32_t)(S - 1);
+            cols_g[e0 + dst] = col;
+            eps_g[e0 + dst] = ep;
+            rs_g[e0 + dst] = (uint8_t)(lr | (int)(s << 4));
+            order_g[e0 + dst] = i;
+        }
+    }
+}
+
+// per-edge values from group order back to the row-major order (inspection / parity: epoch_of_next_sample)
+__global__ __launch_bounds__(64) void umap_sched_ungroup_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ order_g,
+                                                                const float* __restrict__ vals_g, int64_t n_rows,
+                                                                float* __restrict__ vals_rm) {
+    const int64_t r0 = (int64_t)blockIdx.x * G2_ROWS;
+    const int64_t r1 = (r0 + G2_ROWS < n_rows) ? r0 + G2_ROWS : n_rows;
+    const int64_t e0 = rowptr[r0], e1 = rowptr[r1];
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 64) vals_rm[e0 + order_g[e]] = vals_g[e];
+}
+
+struct SchedBuild2Params {
+    const int64_t* rowptr;
+    const int32_t* cols;      // group order (tdr_umap_sched_group_f32)
+    const float* eps_per;
+    const uint8_t* rs;        // local row | slice << 4
+    float* next;              // epoch_of_next_sample in group order, advanced by B iterations
+    int64_t n_rows;
+    int t0, B, S;
+    int stage;                // LDS stage entries
+    const int* iter_base;
+    const int64_t* grp_base;  // (n_groups + 1) static list regions (tdr_umap_sched_plan_groups_f32)
+    int32_t* list;
+    uint2* hdr;
+    int* err;
+};
+
+template <int WAVES>   // wavefronts per SIMD the register allocation aims at (launch_sched_build2)
+__global__ __launch_bounds__(64, WAVES) void umap_sched_build2_kernel(const SchedBuild2Params P) {
+    extern __shared__ uint32_t sm2[];  // cnt [B * S][17] | stage [P.stage >= 512] (the rows' active counts until phase 2)
+    __shared__ uint32_t tb[SCHED_BMAX / G2_TC + 2];
+    const int K = P.B * P.S, KS = P.S * G2_STRIDE;
+    uint32_t* cnt = sm2;
+    uint32_t* stage = sm2 + ((K * G2_STRIDE + 3) & ~3);
+    uint32_t* actl = stage;
+    const int lane = threadIdx.x;
+    const int64_t g = blockIdx.x;
+    const int64_t r0 = g * G2_ROWS;
+    const int nr = (int)((P.n_rows - r0 < G2_ROWS) ? P.n_rows - r0 : G2_ROWS);
+    const int64_t e0 = P.rowptr[r0], e1 = P.rowptr[r0 + nr];
+    const float INF = __builtin_inff();
+    const int t0 = P.t0 + (P.iter_base ? *P.iter_base : 0);
+    if (e1 - e0 > 0x7fffffffLL - 64) {
+        if (lane == 0) atomicMax(P.err, 2);
+        return;
+    }
+    const int ne = (int)(e1 - e0);
+    for (int i = lane; i < K * G2_STRIDE; i += 64) cnt[i] = 0;
+    __syncthreads();
+
+    // fire_mask() with the count of every firing added to its (iteration, slice, row) counter as it is found (a count:
+    // order-independent); idx = slice * 17 + local row
+    auto fire_count = [&](float& nx, float ep, int idx) {
+        uint32_t m = 0;
+        const float tend = (float)(t0 + P.B);
+        int tcur = t0;
+        while (nx <= tend) {
+            int tf = (int)ceilf(nx) - 1;
+            if (tf < tcur) tf = tcur;
+            if (tf >= t0 + P.B) break;
+            m |= 1u << (tf - t0);
+            atomicAdd(&cnt[(tf - t0) * KS + idx], 1u);
+            nx = __fadd_rn(nx, ep);
+            tcur = tf + 1;
+        }
+        return m;
+    };
+    // phase 1: advance the counters, count the firings per (iteration, slice, row).  ALL loads of the register-resident
+    // chunks are issued before the first counter is written back: a store to `next` orders every later load of `next`
+    // behind it, and chunk-by-chunk the wavefront would sit out one memory latency per chunk (12 per group).
+    uint32_t m_st[G2_STASH], c_st[G2_STASH], rs_st[G2_STASH / 4];
+    {
+        float nxv[G2_STASH], epv[G2_STASH];
+        uint32_t rbv[G2_STASH];
+#pragma unroll
+        for (int ci = 0; ci < G2_STASH; ++ci) {
+            const bool valid = ci * 64 + lane < ne;
+            const int64_t e = e0 + ci * 64 + lane;
+            nxv[ci] = valid ? P.next[e] : INF;
+            epv[ci] = valid ? P.eps_per[e] : INF;
+            rbv[ci] = valid ? (uint32_t)P.rs[e] : 0u;
+            c_st[ci] = valid ? (uint32_t)P.cols[e] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < G2_STASH / 4; ++q)
+            rs_st[q] = rbv[4 * q] | (rbv[4 * q + 1] << 8) | (rbv[4 * q + 2] << 16) | (rbv[4 * q + 3] << 24);
+#pragma unroll
+        for (int ci = 0; ci < G2_STASH; ++ci) {
+            m_st[ci] = 0u;
+            if (ci * 64 < ne) {
+                float nx = nxv[ci];
+                const uint32_t m = fire_count(nx, epv[ci], (int)(rbv[ci] >> 4) * G2_STRIDE + (int)(rbv[ci] & 15u));
+                if (m) P.next[e0 + ci * 64 + lane] = nx;
+                m_st[ci] = m;
+            }
+        }
+    }
+    for (int c = G2_STASH * 64; c < ne; c += 64) {  // groups of more than 1024 edges: the tail is advanced again in phase 3
+        const bool valid = c + lane < ne;
+        const int64_t e = e0 + c + lane;
+        float nx = valid ? P.next[e] : INF;
+        const float ep = valid ? P.eps_per[e] : INF;
+        const uint32_t rb = valid ? (uint32_t)P.rs[e] : 0u;
+        (void)fire_count(nx, ep, (int)(rb >> 4) * G2_STRIDE + (int)(rb & 15u));
+    }
+    __syncthreads();
+
+    // rows' active counts per iteration (all slices)
+    for (int i = lane; i < P.B * G2_ROWS; i += 64) {
+        const int t = i >> 4, lr = i & 15;
+        uint32_t a = 0;
+        for (int s = 0; s < P.S; ++s) a += cnt[(t * P.S + s) * G2_STRIDE + lr];
+        actl[i] = a > 65535u ? 65535u : a;
+    }
+    __syncthreads();
+    // exclusive scan of the counts in (segment k = t * S + slice, row) order, four segments per step; records
+    const int64_t gbase = P.grp_base[g];
+    const int64_t capacity64 = P.grp_base[g + 1] - gbase;
+    const uint32_t capacity = capacity64 > 0xffffffffLL ? 0xffffffffu : (uint32_t)capacity64;
+    bool bad = gbase + capacity64 > 0xffffffffLL;
+    const int n_runs = (P.B + G2_TC - 1) / G2_TC;
+    uint32_t carry = 0;
+    for (int k4 = 0; k4 < K; k4 += 4) {
+        const int k = k4 + (lane >> 4), lr = lane & 15;
+        const uint32_t v = k < K ? cnt[k * G2_STRIDE + lr] : 0u;
+        // inclusive scan inside the 16-lane DPP row (= one segment index), rows chained through the scalar unit
+        uint32_t inc = v;
+        inc += dppu<0x111>(inc);
+        inc += dppu<0x112>(inc);
+        inc += dppu<0x114>(inc);
+        inc += dppu<0x118>(inc);
+        const uint32_t t0r = (uint32_t)__builtin_amdgcn_readlane((int)inc, 15), t1r = (uint32_t)__builtin_amdgcn_readlane((int)inc, 31);
+        const uint32_t t2r = (uint32_t)__builtin_amdgcn_readlane((int)inc, 47), t3r = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+        const int qrow = lane >> 4;
+        const uint32_t below = qrow == 0 ? 0u : (qrow == 1 ? t0r : (qrow == 2 ? t0r + t1r : t0r + t1r + t2r));
+        const uint32_t ex = carry + below + inc - v;
+        bad = bad || v > 65535u;
+        if (k < K) {
+            cnt[k * G2_STRIDE + lr] = ex;  // from here on: the write pointer of segment (k, row)
+            if (lr < nr) P.hdr[(size_t)k * P.n_rows + r0 + lr] = make_uint2((uint32_t)gbase + ex, (v & 0xffffu) | (actl[(k / P.S) * G2_ROWS + lr] << 16));
+            if (lr == 0 && k % (G2_TC * P.S) == 0) tb[k / (G2_TC * P.S)] = ex;
+        }
+        carry += t0r + t1r + t2r + t3r;
+    }
+    if (lane == 0) tb[n_runs] = carry;
+    if (bad) atomicMax(P.err, 2);
+    if (carry > capacity && lane == 0) atomicMax(P.err, 1);
+    __syncthreads();
+
+    // phase 2: place the firings, one run of G2_TC iterations at a time, through the LDS stage.  Inside a run the firings
+    // are taken RANK-OUTER: pass p places, for every lane, the p-th firing of its edge in this run.  A segment then lists
+    // a row's edges by (rank of the firing in the edge's own mask, period, column) -- a key made of the edge alone, so the
+    // order does not depend on which chunk or lane the edge sits in (i.e. on the other rows of the group).
+    for (int j = 0; j < n_runs; ++j) {
+        const uint32_t sbase = tb[j], send = tb[j + 1];
+        const int tlo = j * G2_TC;
+        const uint32_t runmask = 0xffu << tlo;
+        auto put = [&](uint32_t pos, uint32_t col) {
+            const uint32_t rel = pos - sbase;
+            if (rel < (uint32_t)P.stage) stage[rel] = col;
+            else if (pos < capacity) P.list[gbase + pos] = (int32_t)col;
+        };
+        uint32_t live = 0xfu;   // wavefront-uniform: chunk groups that may still hold firings of this run
+        for (int pass = 0; pass < G2_TC; ++pass) {
+            bool any = false;
+            // every atomic of the pass is issued before the first position is used (LDS returns in order)
+            uint32_t pos[G2_STASH];
+            uint32_t has = 0u;   // wavefront-uniform: chunk groups that placed something
+#pragma unroll
+            for (int cg = 0; cg < G2_STASH; cg += 4) {
+                if (cg * 64 >= ne || !(live & (1u << (cg >> 2)))) continue;
+                uint32_t bits[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bits[u] = m_st[cg + u] & runmask;
+                if (__ballot((bits[0] | bits[1] | bits[2] | bits[3]) != 0u) == 0ull) { live &= ~(1u << (cg >> 2)); continue; }
+                has |= 1u << (cg >> 2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    pos[cg + u] = 0xffffffffu;
+                    if (bits[u]) {
+                        const uint32_t rb = (rs_st[(cg + u) >> 2] >> (8 * ((cg + u) & 3))) & 0xffu;
+                        const int t = __ffs(bits[u]) - 1;
+                        m_st[cg + u] &= m_st[cg + u] - 1u;  // earlier runs are used up: the lowest set bit is this one
+                        pos[cg + u] = atomicAdd(&cnt[t * KS + (int)(rb >> 4) * G2_STRIDE + (int)(rb & 15u)], 1u);
+                    }
+                }
+            }
+            any = has != 0u;
+#pragma unroll
+            for (int cg = 0; cg < G2_STASH; cg += 4) {
+                if (!(has & (1u << (cg >> 2)))) continue;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (pos[cg + u] != 0xffffffffu) put(pos[cg + u], c_st[cg + u]);
+            }
+            for (int c = G2_STASH * 64; c < ne; c += 64) {  // beyond the register-resident chunks: the mask is formed again
+                const bool valid = c + lane < ne;
+                const int64_t e = e0 + c + lane;
+                float nx = valid ? P.next[e] : INF;
+                const float ep = valid ? P.eps_per[e] : INF;
+                uint32_t m = fire_mask(nx, ep, t0, P.B) & runmask;
+                for (int q = 0; q < pass; ++q) m &= m - 1u;
+                if (__ballot(m != 0u) == 0ull) continue;
+                any = true;
+                if (m) {
+                    const uint32_t rb = (uint32_t)P.rs[e];
+                    const int t = __ffs(m) - 1;
+                    put(atomicAdd(&cnt[t * KS + (int)(rb >> 4) * G2_STRIDE + (int)(rb & 15u)], 1u), (uint32_t)P.cols[e]);
+                }
+            }
+            if (!any) break;
+        }
+        __syncthreads();
+        uint32_t n_st = send - sbase;
+        if (n_st > (uint32_t)P.stage) n_st = (uint32_t)P.stage;
+        if (sbase >= capacity) n_st = 0;
+        else if (n_st > capacity - sbase) n_st = capacity - sbase;
+        for (uint32_t i = lane; i < n_st; i += 64) P.list[gbase + sbase + i] = (int32_t)stage[i];
+        __syncthreads();
+    }
+    // the counters of the chunks beyond the register-resident ones (phase 1 left them as they were)
+    for (int c = G2_STASH * 64; c < ne; c += 64) {
+        if (c + lane < ne) {
+            const int64_t e = e0 + c + lane;
+            float nx = P.next[e];
+            if (fire_mask(nx, P.eps_per[e], t0, P.B)) P.next[e] = nx;
+        }
     }
 }
 
@@ -822,6 +1149,32 @@ static int launch_sched_build(const SchedBuildParams& P0, hipStream_t st, bool s
     return e == hipSuccess ? TDR_OK : (int)e;
 }
 
+// launch the group-ordered schedule kernel: one wavefront per group of 16 rows
+static size_t sched_build2_lds(int B, int S, int stage) { return ((size_t)((B * S * G2_STRIDE + 3) & ~3) + (size_t)stage) * sizeof(uint32_t); }
+static int launch_sched_build2(const SchedBuild2Params& P0, hipStream_t st, bool set_attr) {
+    SchedBuild2Params P = P0;
+    const int variant = (P.stage >> 16) & 15;   // tuning knob of tools/sched_build2_perf.py: register budget of the kernel
+    P.stage &= 0xffff;
+    if (P.stage == 0) P.stage = G2_STAGE_DEFAULT;
+    const int64_t n_groups = (P.n_rows + G2_ROWS - 1) / G2_ROWS;
+    const size_t lds = sched_build2_lds(P.B, P.S, P.stage);
+#define TDR_BUILD2(W)                                                                                                 \
+    do {                                                                                                              \
+        if (set_attr && lds > 32 * 1024) {                                                                            \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build2_kernel<W>),           \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
+            if (e != hipSuccess) return (int)e;                                                                       \
+        }                                                                                                             \
+        hipLaunchKernelGGL(umap_sched_build2_kernel<W>, dim3((unsigned)n_groups), dim3(64), lds, st, P);              \
+    } while (0)
+    if (variant == 6) TDR_BUILD2(6);
+    else if (variant == 4) TDR_BUILD2(4);
+    else TDR_BUILD2(5);   // 96 registers (8 spilled): 1.10 ms per window at N = 1M; 4 -> 126 registers 1.19, 6 -> 80 (39 spilled) 1.65
+#undef TDR_BUILD2
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TDR_OK : (int)e;
+}
+
 // all slice passes of one evaluation: one launch per slice (geom < 16), or -- geom & 16, S > 1 -- ONE joint launch with the
 // slices spread over the XCDs and a combine kernel; acc must then hold S planes of (n_rows, 2 nc) floats
 static int launch_sched_grad_all(SchedGradParams& P, int geom, hipStream_t st) {
@@ -900,6 +1253,7 @@ struct UmapLoop {
     int* iter_base;                 // device int (caller's scratch)
     tdr_collective_fn gather; void* gather_ctx;
     int geom;
+    const uint8_t* rs;              // non-null: group-ordered loop state (cols / eps_per / next / blk_base of tdr_umap_sched_group_f32 / _plan_groups_f32)
     // captured windows: graph_len[i] iterations each
     hipGraphExec_t graphs[2]; int graph_len[2];
 };
@@ -907,6 +1261,14 @@ struct UmapLoop {
 // enqueue one window: schedule build for iterations [base + 0, base + n) and n x (S gradient passes + SGD step [+ row
 // all-gather]); `base` lives in L->iter_base on the device, so the SAME enqueued sequence serves any window
 static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st) {
+    if (L->rs) {
+        SchedBuild2Params B2;
+        B2.rowptr = L->rowptr; B2.cols = L->cols; B2.eps_per = L->eps_per; B2.rs = L->rs; B2.next = L->next; B2.n_rows = L->n_rows;
+        B2.t0 = 0; B2.B = n; B2.S = L->S; B2.stage = G2_STAGE_DEFAULT; B2.iter_base = L->iter_base; B2.grp_base = L->blk_base;
+        B2.list = L->list; B2.hdr = L->hdr; B2.err = L->err;
+        const int rc2 = launch_sched_build2(B2, st, false);
+        if (rc2 != TDR_OK) return rc2;
+    }
     SchedBuildParams Bp;
     Bp.rowptr = L->rowptr; Bp.cols = L->cols; Bp.eps_per = L->eps_per; Bp.next = L->next; Bp.n_rows = L->n_rows;
     const uint32_t nred = (uint32_t)(L->n_total - 1);
@@ -914,7 +1276,7 @@ static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st) {
     Bp.stash = L->n_total <= (1LL << 29) ? 1 : 0;
     Bp.t0 = 0; Bp.iter_base = L->iter_base; Bp.B = n; Bp.S = L->S; Bp.blk_base = L->blk_base; Bp.list = L->list; Bp.hdr = L->hdr;
     Bp.err = L->err;
-    const int rcb = launch_sched_build(Bp, st, false);
+    const int rcb = L->rs ? TDR_OK : launch_sched_build(Bp, st, false);
     if (rcb != TDR_OK) return rcb;
     SchedGradParams G;
     G.Z = L->Z; G.n_total = L->n_total; G.row0 = L->row0; G.n_rows = L->n_rows; G.list = L->list; G.hdr = L->hdr; G.S = L->S;
@@ -969,7 +1331,7 @@ int tdr_umap_sched_plan_f32(const int64_t* rowptr, const float* eps_per, int64_t
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_blocks = (n_rows + SCHED_RB - 1) / SCHED_RB;
     hipLaunchKernelGGL(umap_sched_plan_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, rowptr, eps_per, n_rows, block_iters,
-                       scratch);
+                       SCHED_RB, scratch);
     hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(256), 0, st, (const int64_t*)scratch, n_blocks, blk_base);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
@@ -1003,6 +1365,64 @@ int tdr_umap_sched_build_f32(const int64_t* rowptr, const int32_t* cols, const f
     P.stash = n_total <= (1LL << 29) ? 1 : 0;
     P.t0 = t0; P.iter_base = nullptr; P.B = n_iters; P.S = n_slices; P.blk_base = blk_base; P.list = list; P.hdr = (uint2*)hdr; P.err = err;
     return launch_sched_build(P, (hipStream_t)stream, true);
+}
+
+/* Group order of the loop state (round 4; see umap_sched_build2_kernel): the edges of every group of 16 consecutive rows,
+ * given row-major with every row in (period, column) order (tdr_umap_sched_layout_f32), sorted stably by period class.
+ * cols_g / eps_g (nnz), rs_g (nnz bytes: local row | slice << 4 for n_slices slices of n_total points), order_g (nnz int32:
+ * the edge's row-major position relative to its group's first edge).  err: device int, 2 = a group beyond 2^31 edges. */
+int tdr_umap_sched_group_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, int64_t n_rows, int64_t n_total,
+                             int n_slices, int32_t* cols_g, float* eps_g, uint8_t* rs_g, int32_t* order_g, int* err, void* stream) {
+    if (!rowptr || !cols || !eps_per || !cols_g || !eps_g || !rs_g || !order_g || !err || n_rows <= 0 || n_total < 2 || n_total >= 0x7fffffffLL)
+        return TDR_ERR_BAD_ARG;
+    if (n_slices != 1 && n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
+    const uint32_t nred = (uint32_t)(n_total - 1);
+    const uint32_t slice_step = (nred + (uint32_t)n_slices - 1u) / (uint32_t)n_slices;
+    hipLaunchKernelGGL(umap_sched_group_kernel, dim3((unsigned)((n_rows + G2_ROWS - 1) / G2_ROWS)), dim3(64), 0, (hipStream_t)stream, rowptr, cols,
+                       eps_per, n_rows, slice_step, n_slices, cols_g, eps_g, rs_g, order_g, err);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* vals_rm[e] = the group-ordered per-edge value of row-major edge e (e.g. epoch_of_next_sample for inspection). */
+int tdr_umap_sched_ungroup_f32(const int64_t* rowptr, const int32_t* order_g, const float* vals_g, int64_t n_rows, float* vals_rm,
+                               void* stream) {
+    if (!rowptr || !order_g || !vals_g || !vals_rm || n_rows <= 0) return TDR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(umap_sched_ungroup_kernel, dim3((unsigned)((n_rows + G2_ROWS - 1) / G2_ROWS)), dim3(64), 0, (hipStream_t)stream, rowptr,
+                       order_g, vals_g, n_rows, vals_rm);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* Static plan of the group-ordered build: grp_base (n_groups + 1, n_groups = ceil(n_rows / 16)), as tdr_umap_sched_plan_f32
+ * with 16-row blocks (eps_per in either order: a group's capacity is a sum over its edges).  scratch: n_groups int64. */
+int tdr_umap_sched_plan_groups_f32(const int64_t* rowptr, const float* eps_per, int64_t n_rows, int block_iters, int64_t* scratch,
+                                   int64_t* grp_base, void* stream) {
+    if (!rowptr || !eps_per || !scratch || !grp_base || n_rows <= 0 || block_iters <= 0 || block_iters > SCHED_BMAX)
+        return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_groups = (n_rows + G2_ROWS - 1) / G2_ROWS;
+    hipLaunchKernelGGL(umap_sched_plan_kernel, dim3((unsigned)n_groups), dim3(256), 0, st, rowptr, eps_per, n_rows, block_iters,
+                       G2_ROWS, scratch);
+    hipLaunchKernelGGL(scan_i64_kernel, dim3(1), dim3(256), 0, st, (const int64_t*)scratch, n_groups, grp_base);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* tdr_umap_sched_build_f32 on group-ordered state: same records and lists (regions per 16-row group), `next_g` advanced
+ * bit-exactly; a segment lists the row's firing edges in (period, column) order.  stage: LDS stage entries (0 = default). */
+int tdr_umap_sched_build_groups_f32(const int64_t* rowptr, const int32_t* cols_g, const float* eps_g, const uint8_t* rs_g, float* next_g,
+                                    int64_t n_rows, int t0, int n_iters, int n_slices, const int64_t* grp_base, int32_t* list,
+                                    void* hdr, int* err, int stage, void* stream) {
+    if (!rowptr || !cols_g || !eps_g || !rs_g || !next_g || !grp_base || !list || !hdr || !err) return TDR_ERR_BAD_ARG;
+    if (n_rows <= 0 || t0 < 0 || n_iters <= 0 || n_iters > SCHED_BMAX || t0 > (1 << 24) - 64) return TDR_ERR_BAD_ARG;
+    if (n_slices != 1 && n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
+    if ((stage & 0xffff) != 0 && ((stage & 0xffff) < 512 || (stage & 0xffff) > 24576)) return TDR_ERR_BAD_ARG;
+    SchedBuild2Params P;
+    P.rowptr = rowptr; P.cols = cols_g; P.eps_per = eps_g; P.rs = rs_g; P.next = next_g; P.n_rows = n_rows;
+    P.t0 = t0; P.B = n_iters; P.S = n_slices; P.stage = stage; P.iter_base = nullptr; P.grp_base = grp_base;
+    P.list = list; P.hdr = (uint2*)hdr; P.err = err;
+    return launch_sched_build2(P, (hipStream_t)stream, true);
 }
 
 /* One evaluation of UMAP's closed-form gradient (umap.py:236-292) for rows [row0, row0 + n_rows) from the lists of
@@ -1079,6 +1499,7 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
     L->S = d->n_slices; L->B = d->block_iters; L->lr_table = d->lr_table; L->max_iter = d->max_iter; L->momentum = d->momentum;
     L->first_iter = d->first_iter; L->check_interval = d->check_interval; L->norm2 = d->norm2; L->snap = d->snap; L->nan_flag = d->nan_flag;
     L->iter_base = (int*)d->scratch; L->gather = (tdr_collective_fn)d->gather; L->gather_ctx = d->gather_ctx; L->geom = d->geom;
+    L->rs = d->rs;
     L->graphs[0] = L->graphs[1] = nullptr; L->graph_len[0] = L->graph_len[1] = 0;
     const size_t lds = (size_t)L->B * L->S * CNT_STRIDE * sizeof(uint32_t);
     if (lds > 32 * 1024) {  // raised here, outside graph capture, for every instance the launcher may pick
@@ -1087,6 +1508,11 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build_kernel<2>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { delete L; return (int)e; }
+    }
+    if (L->rs && sched_build2_lds(L->B, L->S, G2_STAGE_DEFAULT) > 32 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build2_kernel<5>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sched_build2_lds(L->B, L->S, G2_STAGE_DEFAULT));
         if (e != hipSuccess) { delete L; return (int)e; }
     }
     *out = L;

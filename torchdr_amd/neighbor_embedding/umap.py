@@ -46,6 +46,13 @@ SCHED_SLICES = 0
 # together with the row sort above.  The embedding is returned in the caller's order; the negative sampler is keyed by
 # the loop's row numbers, so the random stream differs from an unrelabelled run (same distribution).
 RELABEL = True
+# GROUPED: the scheduled loop keeps its per-edge state (columns, epochs_per_sample, epoch_of_next_sample) in GROUP order --
+# the edges of every 16 consecutive rows sorted by firing-period class (tdr_umap_sched_group_f32) -- and builds the firing
+# lists with tdr_umap_sched_build_groups_f32 (one wavefront per group, equally busy lanes, coalesced list stores).  The
+# row-major arrays stay what they were (`epochs_per_sample`, `_loop_cols`); `epoch_of_next_sample` is brought back to the
+# row-major order when it is read.  False: the row-chunk kernel of rounds 2-3 (tdr_umap_sched_build_f32).
+GROUPED = True
+SCHED_STAGE = 0      # LDS stage entries of the grouped build (0 = library default)
 
 def _opt(name):
     """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
@@ -116,6 +123,37 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                          random_state=random_state, check_interval=check_interval, discard_NNs=discard_NNs,
                          compile=compile, n_negatives=self.n_negatives, distributed=distributed, **kwargs)
 
+    # epoch_of_next_sample (umap.py:232,247) in the row-major loop order.  While the grouped build owns the counters
+    # (self._g), they live in group order and are brought back here when somebody looks.
+    @property
+    def epoch_of_next_sample(self):
+        if "_next_rm" not in self.__dict__:
+            raise AttributeError("epoch_of_next_sample")
+        g = self.__dict__.get("_g")
+        if g is not None and g["dirty"]:
+            _lib.check(_lib.lib().tdr_umap_sched_ungroup_f32(_lib.ptr(self._csr_loop.rowptr), _lib.ptr(g["order"]), _lib.ptr(g["next"]),
+                                                              self._csr_loop.n, _lib.ptr(self._next_rm), _lib.stream_ptr()),
+                       "tdr_umap_sched_ungroup_f32")
+            g["dirty"] = False
+        return self._next_rm
+
+    @epoch_of_next_sample.setter
+    def epoch_of_next_sample(self, value):
+        self._next_rm = value
+        if self.__dict__.get("_g") is not None:   # a caller replaced the counters: the grouped copy follows
+            g = self._g
+            g0 = self._csr_loop.rowptr[:-1:16]
+            e0 = torch.repeat_interleave(g0, torch.cat([g0[1:], self._csr_loop.rowptr[-1:]]) - g0)
+            g["next"] = value[e0 + g["order"].long()].contiguous()
+            g["dirty"] = False
+
+    @epoch_of_next_sample.deleter
+    def epoch_of_next_sample(self):
+        self.__dict__.pop("_next_rm", None)
+
+    def _sched_slices(self) -> int:
+        return int(_opt("SCHED_SLICES")) or int(_lib.lib().tdr_umap_sched_slices(self.n_samples_in_, self.n_components))
+
     # the affinity stays in CSR on the device (the reference's padded (N, max_deg) layout is 5-8x larger)
     def _compute_affinity_in(self, X):
         # row-sharded: a fit whose loop may run in the cluster-sorted numbering tells the affinity so BEFORE the search --
@@ -185,7 +223,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
     def on_affinity_computation_end(self):
         # plans and buffers of a previous fit (kept until clear_memory, which a fit that raised never reached) are sized
         # for THAT graph: never reuse them
-        self._sched, self._grad_buf, self._sched_deferred, self._grad_ws = None, None, False, None
+        self._sched, self._grad_buf, self._sched_deferred, self._grad_ws, self._g = None, None, False, None, None
         super().on_affinity_computation_end()
         csr: CSRAffinity = self._relabel()
         self._csr_loop = csr
@@ -220,6 +258,20 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             "tdr_umap_sched_layout_f32",
         )
         self.epoch_of_next_sample = self.epochs_per_sample.clone()  # umap.py:232
+        if _opt("GROUPED") and _opt("SCHEDULED") and self.n_samples_in_ < 2**31 - 1 and self.n_components <= 32:
+            dev, nnz = csr.vals.device, csr.nnz
+            g = {"cols": torch.empty_like(csr.cols), "eps": torch.empty_like(csr.vals),
+                 "rs": torch.empty(nnz, dtype=torch.uint8, device=dev), "order": torch.empty(nnz, dtype=torch.int32, device=dev),
+                 "S": self._sched_slices(), "dirty": False}
+            sc = self._sched_err = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(
+                L.tdr_umap_sched_group_f32(_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample), csr.n,
+                                           self.n_samples_in_, g["S"], _lib.ptr(g["cols"]), _lib.ptr(g["eps"]), _lib.ptr(g["rs"]),
+                                           _lib.ptr(g["order"]), _lib.ptr(sc), _lib.stream_ptr()),
+                "tdr_umap_sched_group_f32",
+            )
+            g["next"] = g["eps"].clone()          # umap.py:232 in group order
+            self._g = g
 
     # reference attributes (affinity_matcher.py:276-286) in their padded layout, materialised on request from the CSR
     @property
@@ -248,12 +300,17 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         L, csr, dev = _lib.lib(), self._csr_loop, self.device_
         n_rows, nc = self.chunk_size_, self.n_components
         B = int(_opt("SCHED_BLOCK_ITERS"))
-        S = int(_opt("SCHED_SLICES")) or int(L.tdr_umap_sched_slices(self.n_samples_in_, nc))
-        n_blocks = (n_rows + 63) // 64
+        S = self._sched_slices()
+        g = getattr(self, "_g", None)
+        if g is not None and g["S"] != S:
+            raise RuntimeError("[torchdr_amd] UMAP: the number of L2 slices changed between the loop layout and the schedule plan.")
+        rows_per_block = 16 if g is not None else 64
+        n_blocks = (n_rows + rows_per_block - 1) // rows_per_block
         scratch = torch.empty(n_blocks, dtype=torch.int64, device=dev)
         blk_base = torch.empty(n_blocks + 1, dtype=torch.int64, device=dev)
-        _lib.check(L.tdr_umap_sched_plan_f32(_lib.ptr(csr.rowptr), _lib.ptr(self.epochs_per_sample), n_rows, B,
-                                             _lib.ptr(scratch), _lib.ptr(blk_base), _lib.stream_ptr()),
+        plan = L.tdr_umap_sched_plan_groups_f32 if g is not None else L.tdr_umap_sched_plan_f32
+        _lib.check(plan(_lib.ptr(csr.rowptr), _lib.ptr(self.epochs_per_sample), n_rows, B,
+                        _lib.ptr(scratch), _lib.ptr(blk_base), _lib.stream_ptr()),
                    "tdr_umap_sched_plan_f32")
         cap = int(blk_base[-1].item())
         # the joint launch relies on workgroups going round-robin over EIGHT XCDs that each cache one slice: only on the
@@ -281,13 +338,24 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             if PROFILE is not None:
                 eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 eb0.record()
-            _lib.check(
-                L.tdr_umap_sched_build_f32(_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
-                                           _lib.ptr(self.epoch_of_next_sample), self.chunk_size_, self.n_samples_in_,
-                                           t, n, sc["S"], _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]),
-                                           _lib.ptr(sc["hdr"]), _lib.ptr(sc["err"]), _lib.stream_ptr()),
-                "tdr_umap_sched_build_f32",
-            )
+            g = getattr(self, "_g", None)
+            if g is not None:
+                _lib.check(
+                    L.tdr_umap_sched_build_groups_f32(_lib.ptr(csr.rowptr), _lib.ptr(g["cols"]), _lib.ptr(g["eps"]), _lib.ptr(g["rs"]),
+                                                      _lib.ptr(g["next"]), self.chunk_size_, t, n, sc["S"], _lib.ptr(sc["blk_base"]),
+                                                      _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), _lib.ptr(sc["err"]),
+                                                      int(_opt("SCHED_STAGE")), _lib.stream_ptr()),
+                    "tdr_umap_sched_build_groups_f32",
+                )
+                g["dirty"] = True
+            else:
+                _lib.check(
+                    L.tdr_umap_sched_build_f32(_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
+                                               _lib.ptr(self.epoch_of_next_sample), self.chunk_size_, self.n_samples_in_,
+                                               t, n, sc["S"], _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]),
+                                               _lib.ptr(sc["hdr"]), _lib.ptr(sc["err"]), _lib.stream_ptr()),
+                    "tdr_umap_sched_build_f32",
+                )
             if PROFILE is not None:
                 eb1.record()
                 PROFILE.append(("build", eb0, eb1, n))
@@ -385,8 +453,14 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         }
         d = _lib.UmapLoopDesc()
         d.Z, d.nc, d.n_total, d.row0, d.n_rows = _lib.ptr(self.embedding_), nc, self.n_samples_in_, self.chunk_start_, self.chunk_size_
-        d.rowptr, d.cols, d.eps_per, d.next = (_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
-                                               _lib.ptr(self.epoch_of_next_sample))
+        g = getattr(self, "_g", None)
+        if g is not None:
+            d.rowptr, d.cols, d.eps_per, d.next, d.rs = (_lib.ptr(csr.rowptr), _lib.ptr(g["cols"]), _lib.ptr(g["eps"]), _lib.ptr(g["next"]),
+                                                         _lib.ptr(g["rs"]))
+            g["dirty"] = True
+        else:
+            d.rowptr, d.cols, d.eps_per, d.next = (_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
+                                                   _lib.ptr(self.epoch_of_next_sample))
         d.blk_base, d.list, d.hdr, d.err = _lib.ptr(sc["blk_base"]), _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), _lib.ptr(sc["err"])
         d.acc, d.grad, d.mom_buf = _lib.ptr(sc["acc"]), _lib.ptr(self._grad_buf), _lib.ptr(keep["mom"])
         d.a, d.b, d.neg_rate, d.n_negatives, d.seed = float(self._a), float(self._b), int(self.negative_sample_rate), int(self.n_negatives), self._neg_seed
@@ -458,6 +532,9 @@ class UMAP(NegativeSamplingNeighborEmbedding):
     def _raise_if_nan(self):
         super()._raise_if_nan()
         sc = getattr(self, "_sched", None)
+        ge = getattr(self, "_sched_err", None)
+        if ge is not None and int(ge.item()) != 0:
+            raise RuntimeError("[torchdr_amd] UMAP: a group of 16 rows holds more than 2^31 edges; set neighbor_embedding.umap.GROUPED = False.")
         if sc is not None and int(sc["err"].item()) != 0:
             raise RuntimeError("[torchdr_amd] UMAP: schedule build failed (list region overflow, a segment beyond 65535 "
                                "entries or a list beyond 2^32 entries); set neighbor_embedding.umap.SCHEDULED = False.")
@@ -511,6 +588,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
 
     def clear_memory(self):
         super().clear_memory()
+        self.__dict__.pop("_g", None)
         for attr in ("_csr", "_csr_loop", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf", "_grad_ws", "_sched", "_loop_cols"):
             if hasattr(self, attr):
                 delattr(self, attr)
