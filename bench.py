@@ -127,7 +127,9 @@ def cpu_baseline(X_cpu, k, max_iter, model, budget_s=60.0):
     total = t_knn + t_sig + t_sym + t_pca + t_loop
     return {
         "value": n / total, "unit": "samples/sec", "cores": threads, "kind": "port",
-        "sample": "; ".join(notes) + f"; every factor is a linear extrapolation; {threads} torch threads",
+        "sample": "; ".join(notes) + f"; every factor is a linear extrapolation; {threads} torch threads; SURVEY 8d asks for 16 kNN "
+                  f"chunks and 20 loop iterations -- the samples stop at --cpu-budget = {budget_s:.0f} s of CPU work (the task statement "
+                  "bounds the baseline at 10-30 s), raise it to complete them",
         "knn_build_sec_est": t_knn, "total_sec_est": total,
     }
 
@@ -196,6 +198,106 @@ def knn_uniform(args, dev, dbase):
             "note": "exact kNN of seed-42 randn(N, D), k = 15, wall incl. packing and pilots, best of 2, outside the timed region"}
 
 
+class _TimedEntry:
+    """Wrap one entry point of the ctypes library with HIP events on the current stream (every `every`-th call)."""
+
+    def __init__(self, name, every=1):
+        from torchdr_amd import _lib
+
+        self.L, self.name, self.every = _lib.lib(), name, every
+        self.fn = getattr(self.L, name)
+        self.events, self.calls = [], 0
+        setattr(self.L, name, self)
+
+    def __call__(self, *a):
+        self.calls += 1
+        if self.calls % self.every:
+            return self.fn(*a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = self.fn(*a)
+        e1.record()
+        self.events.append((e0, e1))
+        return rc
+
+    def close(self):
+        setattr(self.L, self.name, self.fn)
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.events]
+        return sum(ms) / max(len(ms), 1), len(ms)
+
+
+def config_c3(dev, width=15, steps=1, iters=500):
+    """BASELINE config C3 (outside the timed region): LargeVis N = 1M, D = 128, kNN width 15, 500 iterations.  `roofline` =
+    tdr::ne_grad_kernel (one launch per iteration), algorithmic bytes per SURVEY.md section 8d K6 = N k (4 idx + 4 P + 8 z_j
+    + 8 far-endpoint update) + N n_neg (8 + 8) + 2 N (8 z + 8 momentum) against the HBM peak.  Both negative samplers are
+    timed: the permutation sampler of the one-GPU default (every row the far endpoint of exactly n_neg pairs; pull form, no
+    atomics) and the reference's law (independent uniform draws, base.py:628-636; hash sampler + far-endpoint atomics)."""
+    import torchdr_amd as t
+    from torchdr_amd import config
+
+    n, d, n_neg = 1_000_000, 128, 5
+    X = gmm(n, d, 2.0).to(dev)
+    perp = width // 3
+    nbytes = n * width * (4 + 4 + 8 + 8) + n * n_neg * (8 + 8) + 2 * n * (8 + 8)
+    out = {}
+    for name, perm, entry in (("permutation", True, "tdr_ne_grad_perm_f32"), ("independent", False, "tdr_ne_grad_f32")):
+        with config.options(PERM_NEGATIVES=perm):
+            t.LargeVis(perplexity=perp, max_iter=20, random_state=0).fit_transform(X)   # warm-up
+            tm = _TimedEntry(entry, every=10)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                t.LargeVis(perplexity=perp, max_iter=iters, random_state=0).fit_transform(X)
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / steps
+            ms, cnt = tm.close()
+        out[name] = {"ms_per_fit": wall * 1e3, "samples_per_sec": n / wall, "grad_launch_ms": ms, "launches_sampled": cnt,
+                     "hbm_gbs": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    best = out["permutation"]
+    return {
+        "workload": f"BASELINE config C3: LargeVis fit_transform N={n} D={d} perplexity={perp} (kNN width {width}) n_negatives={n_neg} "
+                    f"max_iter={iters}, Gaussian mixture (1000 clusters, centre scale 2, sigma 0.5, seed 42)",
+        "ms": best["ms_per_fit"], "samples_per_sec": best["samples_per_sec"],
+        "roofline": {"kernel": "tdr::ne_grad_kernel<2,16> (kind 0: LargeVis attraction + 5 negatives per row), one launch per iteration",
+                     "bound": "hbm", "achieved": best["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": best["frac"],
+                     "traffic": None, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": best["grad_launch_ms"],
+                     "launches_sampled": best["launches_sampled"]},
+        "samplers": out,
+    }
+
+
+def config_c5(dev, steps=12):
+    """BASELINE config C5 (outside the timed region): symmetric entropic affinity N = 200k, D = 64, perplexity 30 -- the dual
+    iterations of affinity/entropic.py:518-565.  `roofline` = tdr::pair_scan_kernel<8, SeaStats> (one launch per dual
+    iteration): 2 N^2 D flop against the fp32 matrix peak; the N^2 exponentials are reported beside it."""
+    import torchdr_amd as t
+
+    n, d = 200_000, 64
+    X = gmm(n, d, 2.0).to(dev)
+    sea = t.SymmetricEntropicAffinity(perplexity=30, lr=1e-1, max_iter=2, zero_diag=False, verbose=False)
+    sea.fit_duals(X)    # warm-up
+    tm = _TimedEntry("tdr_sea_rowstats_f32")
+    sea = t.SymmetricEntropicAffinity(perplexity=30, lr=1e-1, max_iter=steps, tol=0.0, zero_diag=False, verbose=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sea.fit_duals(X)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms, cnt = tm.close()
+    flops = 2.0 * n * n * d
+    tf = flops / (ms * 1e-3) / 1e12
+    return {
+        "workload": f"BASELINE config C5 (input affinity of TSNEkhorn): SymmetricEntropicAffinity.fit_duals N={n} D={d} perplexity=30, "
+                    f"Adam lr 0.1, {cnt} dual iterations, matrix-free",
+        "ms": wall / max(cnt, 1) * 1e3, "iterations_per_sec": cnt / wall,
+        "roofline": {"kernel": "tdr::pair_scan_kernel<KQ=8, SeaStats> (fp32 MFMA distance tiles + streaming row statistics), one launch per dual iteration",
+                     "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "algorithmic_flops_per_launch": flops, "avg_launch_ms": ms, "launches_sampled": cnt,
+                     "exp_per_s": n * float(n) / (ms * 1e-3)},
+    }
+
+
 def self_launch(n_ranks):
     """`python bench.py --gpus N` with no rank in the environment: start the N ranks ourselves (what
     `python -m torch.distributed.run --nproc-per-node N` would do), one process per GPU over RCCL.  Rank 0's stdout is this
@@ -235,6 +337,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn-variants", action="store_true",
                     help="skip the untimed kNN context figures (unpruned two-stage, one-stage fp32, structureless data)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the untimed BASELINE configs C3 (LargeVis 1M) and C5 (SEA 200k)")
     ap.add_argument("--loop", choices=["auto", "graph", "c", "python"], default="auto",
                     help="UMAP loop driver: replayed HIP graphs (default), plain launches from the C loop object, or one Python iteration per step")
     ap.add_argument("--replicated-input", action="store_true",
@@ -449,13 +552,15 @@ def main():
                                         "not matrix-pipe utilisation" if path.endswith("pruned") else "")),
     }
     roof_grad = {
-        "kernel": ("tdr::umap_sched_grad_kernel<2,4,false> (ONE launch per iteration over both L2 slices of the embedding, slices "
-                   "spread over the XCDs; HIP events around every 25th launch) + 1/32 of tdr::umap_sched_build_kernel (every "
-                   "build timed); the combine + SGD-step kernel that follows (tdr::umap_sched_combine_sgd_kernel, ~11 us in the "
-                   "rocprof CSV) is outside the event pairs" if umod.SCHEDULED else
+        "kernel": ("one whole UMAP iteration: tdr::umap_sched_grad_kernel<2,4,false> (ONE launch over both L2 slices of the embedding, "
+                   "slices spread over the XCDs) + tdr::umap_sched_combine_sgd_kernel (clamps + SGD step) -- HIP events around "
+                   "every 25th iteration's two launches -- + 1/32 of tdr::umap_sched_build2_kernel (group-ordered schedule build, "
+                   "every build timed)" if umod.SCHEDULED else
                    "tdr::umap_grad_kernel<2,16,4,true> + 2 x tdr::umap_neg_dense_kernel<2,8,2> (one gradient evaluation)"),
         "bound": "hbm", "achieved": grad_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_gbs / HBM_PEAK_GBS,
-        "traffic": pmc_traffic("r03_umap_sched_pmc.json" if umod.SCHEDULED else "r01_umap_grad_pmc.json"),
+        "traffic": pmc_traffic("r04_umap_sched_pmc.json" if umod.SCHEDULED else "r01_umap_grad_pmc.json"),
+        "traffic_source": "profiles/r04_umap_sched_pmc.json: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the same "
+                          "three kernels at this shape, per iteration; not re-measured inside this run",
         "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_avg_ms, "evaluations_sampled": n_sampled,
         "grad_passes_ms": grad_only_ms, "schedule_build_ms_per_iteration": build_avg_ms,
         "note": ("algorithmic bytes = SURVEY 8d's per-step edge stream (12 B x nnz + gathers); the scheduled loop reads "
@@ -504,6 +609,12 @@ def main():
         if not args.no_knn_variants and world == 1:
             out["knn_context"] = knn_variants(X, args, dbase)
             out["knn_uniform"] = knn_uniform(args, dev, dbase)
+        if not args.no_configs and world == 1:
+            del X
+            torch.cuda.empty_cache()
+            out["configs"] = {"c3": config_c3(dev), "c5": config_c5(dev),
+                              "note": "BASELINE.json configs[2] and configs[4], run once each after the timed region; per-kernel roofline "
+                                      "by HIP events around the C-ABI entry point on the launch stream"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(X_cpu, args.k, args.max_iter, keep, budget_s=args.cpu_budget)
         print(json.dumps(out), flush=True)

@@ -859,6 +859,152 @@ def c1_tsne_fixture():
     save("c1_tsne", **rec)
 
 
+def grad_in_float64(est):
+    """The reference's OWN loss at the estimator's current state, evaluated in float64: a deep copy of the estimator with
+    every floating tensor (embedding, affinities, Sinkhorn duals ...) cast up, `_compute_loss()` and autograd.  Same
+    inputs as the float32 step the fixture records, none of its rounding: what separates the float32 autograd noise of
+    the reference from the error of a float32 kernel.  The random generator is restored afterwards (PaCMAP samples inside
+    its loss), the estimator itself is left untouched."""
+    import copy
+    from collections import OrderedDict
+
+    def up(v):
+        if torch.is_tensor(v) and v.is_floating_point():
+            return v.detach().double()
+        return v
+
+    def shallow_double(obj):
+        c = copy.copy(obj)
+        c.__dict__ = {k: up(v) for k, v in obj.__dict__.items()}
+        if isinstance(obj, torch.nn.Module):
+            c._parameters = OrderedDict((k, None if v is None else torch.nn.Parameter(up(v))) for k, v in obj._parameters.items())
+            c._buffers = OrderedDict((k, up(v)) for k, v in obj._buffers.items())
+            c._modules = OrderedDict(obj._modules)
+        return c
+
+    with torch.random.fork_rng():
+        m = shallow_double(est)
+        for name in ("affinity_out", "affinity_in"):
+            obj = getattr(est, name, None)
+            if obj is not None:
+                if name in m.__dict__:
+                    m.__dict__[name] = shallow_double(obj)
+                else:
+                    m._modules[name] = shallow_double(obj)
+        emb = m.embedding_.detach().double().requires_grad_(True)
+        if "embedding_" in m._parameters:
+            m._parameters["embedding_"] = torch.nn.Parameter(emb)
+        else:
+            m.__dict__["embedding_"] = emb
+        loss = m._compute_loss()
+        loss.backward()
+        assert m.embedding_.grad.dtype == torch.float64
+        return m.embedding_.grad.detach().clone()
+
+
+def grad64_fixture():
+    """float64 twins of the gradients held by ne_step / ne2_step / dense_ne / tsnekhorn / tsnekhorn3 / tsnekhorn_unrolled /
+    c1_tsne / pacmap: the same estimators run again (same data, seeds and arguments as the functions above), and before
+    every recorded step `grad_in_float64` evaluates the reference's loss in float64 AT THE FLOAT32 STATE of that step.
+    Every run checks that its float32 gradient is the one the original fixture holds (same state, bit for bit)."""
+    from torchdr import PACMAP, SNE, TSNE, InfoTSNE, LargeVis, TSNEkhorn
+
+    out = {}
+
+    def run(fixture, prefix, cls, n_steps, seed, X, kw, key="grad", exact=True):
+        have = np.load(os.path.join(HERE, fixture + ".npz"))
+        rec = {}
+
+        class Probe(cls):
+            def _training_step(self):
+                t = int(self.n_iter_)
+                if t < n_steps:
+                    rec[t] = grad_in_float64(self)
+                loss = super()._training_step()
+                if t < n_steps:
+                    g32 = self.embedding_.grad.detach().numpy()
+                    want = have[f"{prefix}{key}_{t}"]
+                    if exact:
+                        assert np.array_equal(g32, want), (fixture, prefix, t)
+                    else:   # 5000 points: the threaded reductions of the initialisation do not repeat bit for bit
+                        dev = float(np.abs(g32 - want).max() / np.abs(want).max())
+                        print(f"  {fixture}/{prefix}{t}: this run's float32 gradient vs the stored one: {dev:.2e} of max |g|")
+                        assert dev < 1e-6, (fixture, prefix, t, dev)
+                return loss
+
+        torch.manual_seed(seed)
+        Probe(**kw).fit_transform(X)
+        for t, g in rec.items():
+            out[f"{fixture}/{prefix}grad64_{t}"] = g
+            g32 = torch.from_numpy(have[f"{prefix}{key}_{t}"]).double()
+            print(f"  {fixture}/{prefix}{t}: reference float32 autograd vs float64: {float((g32 - g).abs().max() / g.abs().max()):.2e} of max |g|")
+
+    X = gmm(400, 16, 2.0, seed=51)
+    for name, cls, kw in (("largevis", LargeVis, dict(perplexity=5)), ("tsne", TSNE, dict(perplexity=8))):
+        run("ne_step", name + "_", cls, 2, 1, X, dict(max_iter=4, backend=None, init="normal", random_state=1, **kw))
+    X = gmm(400, 16, 2.0, seed=53)
+    for name, cls, kw in (("sne", SNE, dict(perplexity=6)), ("infotsne", InfoTSNE, dict(perplexity=7, n_negatives=40))):
+        run("ne2_step", name + "_", cls, 2, 2, X, dict(max_iter=4, backend=None, init="normal", init_scaling=1.0, random_state=2, **kw))
+    X = gmm(300, 16, 2.0, seed=57)
+    for name, cls, kw in (("tsne", TSNE, dict(perplexity=8)), ("sne", SNE, dict(perplexity=6)), ("largevis", LargeVis, dict(perplexity=5)),
+                          ("infotsne", InfoTSNE, dict(perplexity=7, n_negatives=40))):
+        run("dense_ne", name + "_", cls, 2, 4, X, dict(max_iter=4, backend=None, init="normal", random_state=4, sparsity=False, **kw))
+    X = gmm(256, 16, 2.0, seed=61)
+    tk = dict(perplexity=10, max_iter=3, max_iter_affinity_in=30, init="normal", init_scaling=1.0, min_grad_norm=1e-12, lr=1.0,
+              optimizer="SGD", optimizer_kwargs=None, backend=None, random_state=3)
+    run("tsnekhorn", "tk_", TSNEkhorn, 2, 3, X, tk)
+    run("tsnekhorn3", "", TSNEkhorn, 2, 3, X, dict(tk, n_components=3))
+    for name, kw in (("u2", dict(unrolling=True)), ("u3", dict(unrolling=True, n_components=3)), ("n4", dict(n_components=4)),
+                     ("u5", dict(unrolling=True, n_components=5))):
+        run("tsnekhorn_unrolled", name + "_", TSNEkhorn, 2, 3, X, dict(tk, **kw))
+    X = gmm(400, 16, 2.0, seed=91)
+    run("pacmap", "pm_", PACMAP, 4, 4, X, dict(n_neighbors=10, max_iter=5, iter_per_phase=1, backend=None, init="normal", init_scaling=1.0,
+                                               random_state=4, device="cpu"))
+    X = gmm(5000, 50, 2.0, seed=42)
+    run("c1_tsne", "", TSNE, 2, 3, X, dict(perplexity=30, max_iter=3, backend=None, random_state=3), exact=False)
+    # C1 end to end in float64: the affinity (kNN, entropic bisection) computed in float64 as well, the embedding of each
+    # recorded step set to the float32 fixture's -- how far the reference's OWN float32 pipeline (bisection stopped at its
+    # tolerance, float32 P) is from the float64 one at the gradient
+    have = np.load(os.path.join(HERE, "c1_tsne.npz"))
+    rec = {}
+
+    class Probe64(TSNE):
+        def _training_step(self):
+            t = int(self.n_iter_)
+            if t < 2:
+                with torch.no_grad():
+                    self.embedding_.copy_(torch.from_numpy(have[f"Z_{t}"]).double())
+            loss = super()._training_step()
+            if t < 2:
+                rec[t] = self.embedding_.grad.detach().clone()
+            return loss
+
+    torch.manual_seed(3)
+    Probe64(perplexity=30, max_iter=3, backend=None, random_state=3).fit_transform(X.double())
+    for t, g in rec.items():
+        assert g.dtype == torch.float64
+        out[f"c1_tsne/grad64_pipeline_{t}"] = g
+        g32 = torch.from_numpy(have[f"grad_{t}"]).double()
+        print(f"  c1_tsne/{t}: reference float32 PIPELINE (affinity + gradient) vs the float64 pipeline: "
+              f"{float((g32 - g).abs().max() / g.abs().max()):.2e} of max |g|")
+    # the symmetric entropic affinity of the `tsnekhorn` fixture on the same points in float64 (30 Adam steps on the duals)
+    from torchdr.affinity import SymmetricEntropicAffinity
+
+    have = np.load(os.path.join(HERE, "tsnekhorn.npz"))
+    X = gmm(256, 16, 2.0, seed=61)
+    sea = SymmetricEntropicAffinity(perplexity=10, lr=1e-1, max_iter=30, tol=1e-3, zero_diag=False, backend=None)
+    logP = sea(X.double(), log=True)
+    assert logP.dtype == torch.float64
+    out.update({"tsnekhorn/sea64_logP": logP, "tsnekhorn/sea64_eps": sea.eps_.detach(), "tsnekhorn/sea64_mu": sea.mu_.detach(),
+                "tsnekhorn/sea64_n_iter": torch.tensor(int(sea.n_iter_))})
+    d32 = torch.from_numpy(have["sea_logP"]).double()
+    print(f"  tsnekhorn/sea: reference float32 log P vs float64: max abs {float((d32 - logP).abs().max()):.2e}, "
+          f"P relative to max P {float((d32.exp() - logP.exp()).abs().max() / logP.exp().max()):.2e}; "
+          f"iterations {int(have['sea_n_iter'])} / {int(sea.n_iter_)}; eps rel {float((torch.from_numpy(have['sea_eps']).double() - sea.eps_).abs().max() / sea.eps_.abs().max()):.2e}")
+    save("grad64", **out)
+
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ALL = dict(knn=knn_fixtures, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
@@ -866,7 +1012,7 @@ if __name__ == "__main__":
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
                cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture,
-               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, tsnekhorn_unrolled=tsnekhorn_unrolled_fixture, signatures=signatures_fixture, manifold=manifold_fixture, radam=radam_fixture)
+               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, tsnekhorn_unrolled=tsnekhorn_unrolled_fixture, signatures=signatures_fixture, manifold=manifold_fixture, radam=radam_fixture, grad64=grad64_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.conftest import gmm
+from tests.conftest import gmm, grade32, grade64
 from tests.test_oracle_golden import load
 
 pytestmark = pytest.mark.gpu
@@ -54,6 +54,7 @@ def test_c1_tsne_5k_first_steps_vs_reference():
             if t < 2:
                 ref = g[f"grad_{t}"]
                 seen[f"grad_err_{t}"] = float((grad.cpu() - ref).abs().max() / ref.abs().max())
+                seen[f"grad64_{t}"] = grad.detach().cpu().clone()
             super()._optimizer_step(grad)
 
         def on_training_step_end(self):
@@ -68,8 +69,17 @@ def test_c1_tsne_5k_first_steps_vs_reference():
     # the 8 nearest neighbours of every point (kNN width is 90): identical wherever distances do not tie exactly
     assert float((seen["nn"] == g["NN_head"]).float().mean()) > 0.9999
     for t in range(2):
-        assert seen[f"grad_err_{t}"] < 1e-4, seen
-        assert seen[f"z_err_{t}"] < 1e-4, seen
+        # the estimator on ITS OWN graph: the entropic bisection stops at its tolerance, and two roots inside it give
+        # P's whose gradients differ by this much -- the reference's own float32 pipeline is 4.1e-5 / 9.4e-6 of max |g|
+        # away from its float64 pipeline at these two steps (make_golden.py grad64 prints it); the kernels alone are graded
+        # at 1e-5 against float64 on the reference's P (tests/test_embed_gpu.py: 2e-7)
+        g32_own = seen.pop(f"grad64_{t}")
+        # measured (MI355X, round 4): 4.0e-5 / 9.3e-6 against the float64 gradient on the REFERENCE's float32 affinity -- which is
+        # itself 4.1e-5 / 9.4e-6 away from the float64 pipeline -- and 8.9e-6 / 6.2e-6 against the float64 pipeline
+        grade64(f"c1_tsne/{t}/vs_float64_gradient_on_the_reference_float32_affinity", g32_own, load("grad64")[f"c1_tsne/grad64_{t}"], (6e-5, 1.5e-5)[t])
+        grade64(f"c1_tsne/{t}/vs_float64_pipeline", g32_own, load("grad64")[f"c1_tsne/grad64_pipeline_{t}"], 1e-5)
+        assert seen[f"grad_err_{t}"] < (6e-5, 1.5e-5)[t], seen      # vs the reference's float32 gradient: see above
+        assert seen[f"z_err_{t}"] < (6e-5, 1.5e-5)[t], seen         # the step carries the gradient (initial embedding ~1e-4)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -184,7 +194,7 @@ def test_c3_largevis_1m_500_iterations():
     touch = sel[srcn] | sel[dstn]
     add(srcn[touch], dstn[touch], lambda d: -(2.0 / n) / ((1.0 + d) * (2.0 + d)))          # A.4 repulsion
     got = keep["grad"].cpu().double()[rows]
-    assert float((got - g).abs().max() / g.abs().max()) < 1e-4
+    grade64("c3_largevis_1m/sampled_gradient_vs_float64_closed_form", got, g, 1e-5)
     del R
 
 
@@ -266,7 +276,11 @@ def test_c5_tsnekhorn_200k_symmetric_entropic_rows_vs_fp64():
     # fp32 tile sums over 200k columns (the N = 3000 case of tests/test_tsnekhorn_gpu.py holds 2e-5)
     err_s = float(((S.cpu().double()[rows] - S_ref) / S_ref).abs().max())
     err_h = float(((H.cpu().double()[rows] - H_ref) / H_ref.abs().clamp(min=1.0)).abs().max())
-    assert err_s < 3e-4 and err_h < 3e-4, (err_s, err_h)
+    from tests.conftest import AUDIT
+    # per-ROW relative error of float32 sums over 200 000 columns (tile sums combined in order): measured 1.6e-5 / 1.05e-5
+    AUDIT["c5_sea_200k/row_sum_relative_per_row"] = {"err_vs_float64": err_s, "budget": 3e-5}
+    AUDIT["c5_sea_200k/row_entropy_relative_per_row"] = {"err_vs_float64": err_h, "budget": 3e-5}
+    assert err_s < 3e-5 and err_h < 3e-5, (err_s, err_h)
     sea = torchdr_amd.SymmetricEntropicAffinity(perplexity=30, lr=1e-1, max_iter=5, zero_diag=False)
     sea.fit_duals(X)
     assert bool(torch.isfinite(sea.eps_).all()) and bool(torch.isfinite(sea.mu_).all())

@@ -75,7 +75,7 @@ want = nxt.clone()
 hdr_rc = sc.hdr.clone()
 del sc
 
-for stage in (768, 1024, 1536, 768 | 5 << 16, 1024 | 5 << 16, 1536 | 5 << 16, 768 | 4 << 16, 1024 | 4 << 16, 1536 | 4 << 16, 2048 | 4 << 16):
+for stage in (1024, 512 | 1 << 20, 768 | 1 << 20, 1024 | 1 << 20, 768 | 4 << 16 | 1 << 20):
     gs = GroupSched(rowptr, cols, eps_per, n, 32, S, stage=stage)
     ng = gs.to_group(eps_per)
     for t0 in (0, 32, 64):
@@ -88,6 +88,6 @@ for stage in (768, 1024, 1536, 768 | 5 << 16, 1024 | 5 << 16, 1536 | 5 << 16, 76
 
     ms = timed(rebuild_g) - t_copy
     ok = bool(torch.equal(gs.to_rows(ng), want)) and bool(torch.equal(gs.hdr[:, 1], hdr_rc[:, 1]))
-    print(json.dumps({"kernel": "group-ordered (r04)", "stage": stage & 0xffff, "waves_variant": stage >> 16, "build_ms": ms, "per_iteration_us": ms / 32 * 1e3,
+    print(json.dumps({"kernel": "group-ordered (r04)", "stage": stage & 0xffff, "waves_variant": (stage >> 16) & 15, "tc4": stage >> 20, "build_ms": ms, "per_iteration_us": ms / 32 * 1e3,
                       "same_counters_and_records": ok, "list_capacity": int(gs.blk_base[-1])}), flush=True)
     del gs

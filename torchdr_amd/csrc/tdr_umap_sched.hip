@@ -530,10 +530,10 @@ struct SchedBuild2Params {
     int* err;
 };
 
-template <int WAVES>   // wavefronts per SIMD the register allocation aims at (launch_sched_build2)
+template <int WAVES, int TC>   // WAVES: wavefronts per SIMD the register allocation aims at; TC: iterations per staged run
 __global__ __launch_bounds__(64, WAVES) void umap_sched_build2_kernel(const SchedBuild2Params P) {
     extern __shared__ uint32_t sm2[];  // cnt [B * S][17] | stage [P.stage >= 512] (the rows' active counts until phase 2)
-    __shared__ uint32_t tb[SCHED_BMAX / G2_TC + 2];
+    __shared__ uint32_t tb[SCHED_BMAX / TC + 2];
     const int K = P.B * P.S, KS = P.S * G2_STRIDE;
     uint32_t* cnt = sm2;
     uint32_t* stage = sm2 + ((K * G2_STRIDE + 3) & ~3);
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(64, WAVES) void umap_sched_build2_kernel(const Sche
     const int64_t capacity64 = P.grp_base[g + 1] - gbase;
     const uint32_t capacity = capacity64 > 0xffffffffLL ? 0xffffffffu : (uint32_t)capacity64;
     bool bad = gbase + capacity64 > 0xffffffffLL;
-    const int n_runs = (P.B + G2_TC - 1) / G2_TC;
+    const int n_runs = (P.B + TC - 1) / TC;
     uint32_t carry = 0;
     for (int k4 = 0; k4 < K; k4 += 4) {
         const int k = k4 + (lane >> 4), lr = lane & 15;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64, WAVES) void umap_sched_build2_kernel(const Sche
         if (k < K) {
             cnt[k * G2_STRIDE + lr] = ex;  // from here on: the write pointer of segment (k, row)
             if (lr < nr) P.hdr[(size_t)k * P.n_rows + r0 + lr] = make_uint2((uint32_t)gbase + ex, (v & 0xffffu) | (actl[(k / P.S) * G2_ROWS + lr] << 16));
-            if (lr == 0 && k % (G2_TC * P.S) == 0) tb[k / (G2_TC * P.S)] = ex;
+            if (lr == 0 && k % (TC * P.S) == 0) tb[k / (TC * P.S)] = ex;
         }
         carry += t0r + t1r + t2r + t3r;
     }
@@ -652,21 +652,21 @@ __global__ __launch_bounds__(64, WAVES) void umap_sched_build2_kernel(const Sche
     if (carry > capacity && lane == 0) atomicMax(P.err, 1);
     __syncthreads();
 
-    // phase 2: place the firings, one run of G2_TC iterations at a time, through the LDS stage.  Inside a run the firings
+    // phase 2: place the firings, one run of TC iterations at a time, through the LDS stage.  Inside a run the firings
     // are taken RANK-OUTER: pass p places, for every lane, the p-th firing of its edge in this run.  A segment then lists
     // a row's edges by (rank of the firing in the edge's own mask, period, column) -- a key made of the edge alone, so the
     // order does not depend on which chunk or lane the edge sits in (i.e. on the other rows of the group).
     for (int j = 0; j < n_runs; ++j) {
         const uint32_t sbase = tb[j], send = tb[j + 1];
-        const int tlo = j * G2_TC;
-        const uint32_t runmask = 0xffu << tlo;
+        const int tlo = j * TC;
+        const uint32_t runmask = ((1u << TC) - 1u) << tlo;
         auto put = [&](uint32_t pos, uint32_t col) {
             const uint32_t rel = pos - sbase;
             if (rel < (uint32_t)P.stage) stage[rel] = col;
             else if (pos < capacity) P.list[gbase + pos] = (int32_t)col;
         };
         uint32_t live = 0xfu;   // wavefront-uniform: chunk groups that may still hold firings of this run
-        for (int pass = 0; pass < G2_TC; ++pass) {
+        for (int pass = 0; pass < TC; ++pass) {
             bool any = false;
             // every atomic of the pass is issued before the first position is used (LDS returns in order)
             uint32_t pos[G2_STASH];
@@ -801,6 +801,11 @@ __device__ __forceinline__ int pass_negative_count(int n_levels, const uint32_t 
 // hash, and all slices in ONE launch spread over the XCDs (see the joint fields of SchedGradParams).
 // PAD instances serve any n_components <= NC: rows are P.nc floats wide, registers hold NC (zeros beyond P.nc contribute
 // nothing to distances or forces)
+// scratch builds only (tools/grad_ablate.sh): bit 0 row key without the hash rounds, bit 1 no binomial split (half of the
+// negatives per slice), bit 2 no pow, bit 3 one-multiply item hash, bit 4 rows not dealt by load
+#ifndef TDR_GRAD_ABLATE
+#define TDR_GRAD_ABLATE 0
+#endif
 template <int NC, int G, bool INJ, bool PAD = false>
 __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradParams P) {
     constexpr int U = 4;
@@ -868,9 +873,10 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
     const int npos = (int)(h.y & 0xffffu);
     int n_use = (int)(h.y >> 16) * P.neg_rate;
     if (n_use > P.n_negatives) n_use = P.n_negatives;
-    const uint32_t rkey = neg_row_key(P.seed, P.iter + (P.iter_base ? (uint32_t)*P.iter_base : 0u), (int64_t)gi);
+    const uint32_t rkey = (TDR_GRAD_ABLATE & 1) ? (gi * 0x9E3779B9u) ^ (P.iter * 0x85EBCA6Bu)
+                                                : neg_row_key(P.seed, P.iter + (P.iter_base ? (uint32_t)*P.iter_base : 0u), (int64_t)gi);
     // injected negatives: every column is visited and the ones outside this slice are masked
-    int nneg = INJ ? n_use : pass_negative_count<G>(P.n_levels, lvl_xor, lvl_upper, rkey, n_use, gl);
+    int nneg = INJ ? n_use : ((TDR_GRAD_ABLATE & 2) ? n_use / P.S : pass_negative_count<G>(P.n_levels, lvl_xor, lvl_upper, rkey, n_use, gl));
     if (!INJ && r_len == 0u) nneg = 0;
     const uint32_t ckey = rkey + 0x632BE5ABu * (uint32_t)(slice + 1) - (uint32_t)npos * 0x9E3779B9u;
     const int total = npos + nneg;
@@ -907,7 +913,8 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
                     jneg = j;
                 }
             } else {
-                const uint32_t x = mix32_item(ckey + (uint32_t)i * 0x9E3779B9u);  // column i - npos of this slice
+                const uint32_t x = (TDR_GRAD_ABLATE & 8) ? (ckey + (uint32_t)i * 0x9E3779B9u) * 0x7feb352du
+                                                         : mix32_item(ckey + (uint32_t)i * 0x9E3779B9u);  // column i - npos of this slice
                 const uint32_t rr = r_lo + __umulhi(x, r_len);
                 jneg = rr + (rr >= gi ? 1u : 0u);
             }
@@ -920,7 +927,7 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
         for (int u = 0; u < U; ++u) {
             float df[NC];
             const float d = sqdist<NC>(zi, zj[u], df);
-            const float pb = fast_pow(d, P.b);  // d = 0: exp2(b * log2 0) = exp2(-inf) = 0, no branch needed
+            const float pb = (TDR_GRAD_ABLATE & 4) ? d : fast_pow(d, P.b);  // d = 0: exp2(b * log2 0) = exp2(-inf) = 0, no branch needed
             const float den = 1.0f + P.a * pb;
             // attraction 2ab d^(b-1) / (1 + a d^b) (0 where d <= 0, umap.py:252-256) | repulsion -2b / ((d + eps)(1 + a d^b))
             const float num = isp[u] ? pb * two_ab : m2b;
@@ -1158,18 +1165,21 @@ static int launch_sched_build2(const SchedBuild2Params& P0, hipStream_t st, bool
     if (P.stage == 0) P.stage = G2_STAGE_DEFAULT;
     const int64_t n_groups = (P.n_rows + G2_ROWS - 1) / G2_ROWS;
     const size_t lds = sched_build2_lds(P.B, P.S, P.stage);
-#define TDR_BUILD2(W)                                                                                                 \
+#define TDR_BUILD2(W, T)                                                                                               \
     do {                                                                                                              \
         if (set_attr && lds > 32 * 1024) {                                                                            \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build2_kernel<W>),           \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build2_kernel<W, T>),        \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                \
             if (e != hipSuccess) return (int)e;                                                                       \
         }                                                                                                             \
-        hipLaunchKernelGGL(umap_sched_build2_kernel<W>, dim3((unsigned)n_groups), dim3(64), lds, st, P);              \
+        hipLaunchKernelGGL((umap_sched_build2_kernel<W, T>), dim3((unsigned)n_groups), dim3(64), lds, st, P);        \
     } while (0)
-    if (variant == 6) TDR_BUILD2(6);
-    else if (variant == 4) TDR_BUILD2(4);
-    else TDR_BUILD2(5);   // 96 registers (8 spilled): 1.10 ms per window at N = 1M; 4 -> 126 registers 1.19, 6 -> 80 (39 spilled) 1.65
+    const int tc4 = (P0.stage >> 20) & 1;    // tuning: runs of 4 iterations
+    if (tc4 && variant == 4) TDR_BUILD2(4, 4);
+    else if (tc4) TDR_BUILD2(5, 4);
+    else if (variant == 6) TDR_BUILD2(6, 8);
+    else if (variant == 4) TDR_BUILD2(4, 8);
+    else TDR_BUILD2(5, 8);   // 96 registers (8 spilled): 1.10 ms per window at N = 1M; 4 -> 126 registers 1.19, 6 -> 80 (39 spilled) 1.65
 #undef TDR_BUILD2
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TDR_OK : (int)e;
@@ -1511,7 +1521,7 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
         if (e != hipSuccess) { delete L; return (int)e; }
     }
     if (L->rs && sched_build2_lds(L->B, L->S, G2_STAGE_DEFAULT) > 32 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build2_kernel<5>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build2_kernel<5, 8>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sched_build2_lds(L->B, L->S, G2_STAGE_DEFAULT));
         if (e != hipSuccess) { delete L; return (int)e; }
     }

@@ -379,7 +379,9 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             ),
             "tdr_umap_sched_grad_f32",
         )
-        if prof:
+        if prof and self._sched_deferred:
+            self._prof_pending = (ev0, ev1, csr.nnz)     # closed after the combine + SGD-step kernel (_sgd_kernel): one whole iteration
+        elif prof:
             ev1.record()
             PROFILE.append(("grad", ev0, ev1, csr.nnz))
 
@@ -409,6 +411,10 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                                                _lib.ptr(self._nan_flag), int(self.n_iter_), _lib.stream_ptr()),
             "tdr_umap_sched_step_f32",
         )
+        pend = self.__dict__.pop("_prof_pending", None)
+        if pend is not None and PROFILE is not None:
+            pend[1].record()
+            PROFILE.append(("grad", pend[0], pend[1], pend[2]))
 
     # ---- whole-loop runner ---------------------------------------------------------------------------------------------
     def _loop_runner_eligible(self) -> bool:
