@@ -365,6 +365,13 @@ int tdr_ne_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64
 int tdr_sne_rowsum_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, float* R, void* stream);
 int tdr_sne_repulsion_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const float* R,
                           float coef, float* grad, void* stream);
+/* float64 twins (round 4): SNE's dense repulsion and PaCMAP's pair gradient for float64 inputs (tests/test_neighbor_embedding.py:34,
+ * 55-74 of the reference run every method in both dtypes); same argument meaning. */
+int tdr_sne_rowsum_f64(const double* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, double* R, void* stream);
+int tdr_sne_repulsion_f64(const double* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const double* R, double coef,
+                          double* grad, void* stream);
+int tdr_pacmap_grad_f64(const double* Z, int nc, int64_t n, const int64_t* near_idx, int m_near, double w_nb, const int64_t* mid_idx,
+                        int m_mid, double w_mn, const int64_t* far_idx, int m_far, double w_fp, double* grad, void* stream);
 /* COSNE (neighbor_embedding/cosne.py:162-193, float64 like the reference's ManifoldParameter): closed-form gradient of
  *   -sum P log Q (kNN graph) + log sum_ij Q_ij (dense, never materialised) + lam * mean (||x||^2 - d_H(z,0)^2)^2,
  *   Q = gamma / (d_H^2 + gamma^2), d_H^2 = arccosh(1 + 2|zi-zj|^2/((1-|zi|^2)(1-|zj|^2)) + 1e-8)^2

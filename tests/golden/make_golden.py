@@ -1005,6 +1005,93 @@ def grad64_fixture():
 
 
 
+def sampler_quality_fixture():
+    """End-to-end quality reference for the negative samplers: the REFERENCE's LargeVis and InfoTSNE (independent
+    uniform negatives, base.py:617-649) on a 20 000-point mixture, three seeds each -- embeddings are not kept, only what the
+    test compares: neighbourhood preservation (K = 15) and kNN label accuracy (k = 10) per seed.  X is regenerated by the
+    test (tests.conftest.gmm(20000, 32, 2.0, seed=3), labels = index mod 200)."""
+    from torchdr import InfoTSNE, LargeVis
+    from torchdr.eval import knn_label_accuracy, neighborhood_preservation
+
+    n = 20000
+    X = gmm(n, 32, 2.0, seed=3)
+    labels = torch.arange(n) % (n // 100)
+    out = {}
+    for name, cls, kw in (("largevis", LargeVis, dict(perplexity=10, max_iter=300)), ("infotsne", InfoTSNE, dict(perplexity=10, max_iter=300))):
+        nps, accs = [], []
+        for seed in (0, 1, 2):
+            torch.manual_seed(seed)
+            Z = cls(random_state=seed, backend=None, device="cpu", **kw).fit_transform(X)
+            nps.append(float(neighborhood_preservation(X, Z, K=15, backend=None, device="cpu")))
+            accs.append(float(knn_label_accuracy(Z, labels, k=10, backend=None, device="cpu")))
+            print(f"  {name} seed {seed}: neighbourhood preservation {nps[-1]:.4f}, label accuracy {accs[-1]:.4f}", flush=True)
+        out[f"{name}_np_K15"] = torch.tensor(nps, dtype=torch.float64)
+        out[f"{name}_acc_k10"] = torch.tensor(accs, dtype=torch.float64)
+    save("sampler_quality", **out)
+
+
+def ne2_step64_fixture():
+    """float64 inputs for the round-4 float64 twins: SNE (two steps: P, NN, embedding, autograd gradient, embedding after) and
+    PaCMAP (four steps, one per weight phase: near / mid-near / further tables, weights, gradient, Adam-updated embedding) of
+    the real reference on float64 data -- everything float64, as tests/test_neighbor_embedding.py:34,55-74 run them."""
+    from torchdr import PACMAP, SNE
+
+    out = {}
+    X = gmm(400, 16, 2.0, seed=53).double()
+    out["sne_X"] = X
+    rec = {}
+
+    class ProbeS(SNE):
+        def _training_step(self):
+            t = int(self.n_iter_)
+            if t < 2:
+                rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                rec[f"lr_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["lr"]), dtype=torch.float64)
+                rec[f"mom_{t}"] = torch.tensor(float(self.optimizer_.param_groups[0]["momentum"]), dtype=torch.float64)
+                rec[f"exag_{t}"] = torch.tensor(float(self.early_exaggeration_coeff_), dtype=torch.float64)
+                if t == 0:
+                    rec["P"] = self.affinity_in_.clone()
+                    rec["NN"] = self.NN_indices_.clone()
+            loss = super()._training_step()
+            if t < 2:
+                rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+            return loss
+
+    torch.manual_seed(2)
+    ProbeS(perplexity=6, max_iter=4, backend=None, init="normal", init_scaling=1.0, random_state=2).fit_transform(X)
+    assert rec["Z_0"].dtype == torch.float64 and rec["P"].dtype == torch.float64 and rec["grad_0"].dtype == torch.float64
+    for k_, v in rec.items():
+        out[f"sne_{k_}"] = v
+    X = gmm(400, 16, 2.0, seed=91).double()
+    out["pm_X"] = X
+    rec = {}
+
+    class ProbeP(PACMAP):
+        def _training_step(self):
+            t = int(self.n_iter_)
+            if t < 4:
+                rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                rec[f"neg_{t}"] = self.neg_indices_.clone()
+                rec[f"w_{t}"] = torch.tensor([float(self.w_NB), float(self.w_MN), float(self.w_FP)], dtype=torch.float64)
+                if t == 0:
+                    rec["NN"] = self.NN_indices_.clone()
+            loss = super()._training_step()
+            if t < 4:
+                rec[f"mid_{t}"] = self.mid_near_indices.clone()
+                rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+            return loss
+
+    torch.manual_seed(4)
+    ProbeP(n_neighbors=10, max_iter=5, iter_per_phase=1, backend=None, init="normal", init_scaling=1.0, random_state=4,
+           device="cpu").fit_transform(X)
+    assert rec["Z_0"].dtype == torch.float64 and rec["grad_0"].dtype == torch.float64
+    for k_, v in rec.items():
+        out[f"pm_{k_}"] = v
+    save("ne2_step64", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ALL = dict(knn=knn_fixtures, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
@@ -1012,7 +1099,7 @@ if __name__ == "__main__":
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
                cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture,
-               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, tsnekhorn_unrolled=tsnekhorn_unrolled_fixture, signatures=signatures_fixture, manifold=manifold_fixture, radam=radam_fixture, grad64=grad64_fixture)
+               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, tsnekhorn_unrolled=tsnekhorn_unrolled_fixture, signatures=signatures_fixture, manifold=manifold_fixture, radam=radam_fixture, grad64=grad64_fixture, sampler_quality=sampler_quality_fixture, ne2_step64=ne2_step64_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

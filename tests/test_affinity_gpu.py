@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+from tests.conftest import gmm
 from tests.test_oracle_golden import load
 
 pytestmark = pytest.mark.gpu
@@ -162,3 +163,35 @@ def test_dense_affinities_sparsity_false():
     assert idx is None and P.shape == (n, n)
     assert torch.allclose(P.cpu(), g["umap_P"], rtol=1e-4, atol=1e-7)
     assert torch.allclose(P, P.T)
+
+
+def test_symmetrisation_of_blocks_wider_than_the_row_local_kernels():
+    """k > 256 (the kNN stage serves up to 1024 neighbours; `UMAP(n_neighbors=300)`): the sort-and-coalesce form of
+    utils/sparse.py.  On a block the kernels DO take (k = 40) it must give the kernels' CSR -- same pattern, values to fp32
+    rounding -- for both modes; a 300-wide block against a dense evaluation; UMAP with 300 neighbours end to end."""
+    import torchdr_amd
+    from torchdr_amd.utils.sparse import _symmetrize_wide, symmetrize_to_csr
+
+    gen = torch.Generator().manual_seed(5)
+    n, k = 900, 40
+    I = torch.stack([torch.randperm(n, generator=gen)[:k] for _ in range(n)]).cuda()
+    P = torch.rand(n, k, generator=gen).cuda()
+    for mode in ("sum_minus_prod", "sum"):
+        a = symmetrize_to_csr(P, I, mode)
+        b = _symmetrize_wide(P, I, mode, 0, n, None)
+        assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.cols, b.cols)
+        assert torch.allclose(a.vals, b.vals, rtol=1e-6, atol=1e-7)
+    n, k = 700, 300
+    I = torch.stack([torch.randperm(n, generator=gen)[:k] for _ in range(n)]).cuda()
+    P = torch.rand(n, k, generator=gen).cuda()
+    c = symmetrize_to_csr(P, I, "sum_minus_prod")
+    D = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    D[torch.arange(n, device="cuda")[:, None].expand(n, k), I] = P.double()
+    Q = D + D.T - D * D.T
+    got = torch.zeros_like(Q)
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), c.rowptr[1:] - c.rowptr[:-1])
+    got[rows, c.cols.long()] = c.vals.double()
+    assert torch.equal(got != 0, Q != 0) and torch.allclose(got, Q, rtol=1e-6, atol=1e-7)
+    X = gmm(1500, 16, 2.0, seed=8).cuda()
+    Z = torchdr_amd.UMAP(n_neighbors=300, max_iter=40, random_state=0).fit_transform(X)
+    assert Z.shape == (1500, 2) and bool(torch.isfinite(Z).all())

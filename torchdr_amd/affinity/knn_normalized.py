@@ -120,6 +120,8 @@ class PACMAPAffinity(SparseAffinity):
     indices)`` -- PaCMAP uses the pairs only.  The search is K1 / K1s; the per-row rescale and re-selection
     (N x (n_neighbors + 50) elements) are device tensor ops.  Like the reference it refuses ``distributed``."""
 
+    _float64_kernels = True   # float64 inputs: the float64 kNN (tdr_knn_f64) and dtype-generic tensor ops
+
     def __init__(self, n_neighbors: float = 10, metric: str = "sqeuclidean", zero_diag: bool = True,
                  device: str = "auto", backend=None, verbose: bool = False, compile: bool = False,
                  distributed=False, _pre_processed: bool = False):

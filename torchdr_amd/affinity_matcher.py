@@ -189,6 +189,7 @@ class AffinityMatcher(DRModule):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             emb = pca_scores(X, self.n_components)
+        self._pca_deterministic = pca_scores.deterministic
         self._pca_prefetch = (side, emb)
 
     def _run_training_loop(self):
@@ -410,6 +411,7 @@ class AffinityMatcher(DRModule):
                 emb.record_stream(main)
             else:
                 emb = pca_scores(X, self.n_components)
+                self._pca_deterministic = pca_scores.deterministic
         else:
             raise ValueError(f"[TorchDR] ERROR : init {self.init} not supported in {self.__class__.__name__}.")
         self.embedding_ = (self.init_scaling * emb / emb[:, 0].std()).contiguous()
@@ -531,6 +533,7 @@ def pca_scores(X: torch.Tensor, n_components: int) -> torch.Tensor:
     ``tdr_pca_project_f32``.  Same subspace and signs, O(N D^2) on the GPU.  Initialisation only -- the scores are
     rescaled to std 1e-4 right after (A.5).  D > 256 or more than 4 components use torch ops."""
     n, d = X.shape
+    pca_scores.deterministic = False
     if d > 256 or n_components > 4 or not X.is_cuda or X.dtype != torch.float32:
         mean = X.mean(0, keepdim=True)
         Xc = X - mean
@@ -548,6 +551,9 @@ def pca_scores(X: torch.Tensor, n_components: int) -> torch.Tensor:
         ws = torch.empty(ws_floats, dtype=torch.float32, device=X.device)
         _lib.check(L.tdr_pca_gram_f32(_lib.ptr(X), n, d, X.stride(0), _lib.ptr(mean), _lib.ptr(G), _lib.ptr(ws), ws_floats,
                                       _lib.stream_ptr()), "tdr_pca_gram_f32")
+        # same bits on every rank of a row-sharded fit only on this branch (ordered fp64 combination of the Gram tiles, one-
+        # workgroup Jacobi): NeighborEmbedding._init_embedding skips the reference's broadcast (:421) when it was taken
+        pca_scores.deterministic = _opt("PCA_EIGH") == "jacobi"
         if _opt("PCA_EIGH") == "jacobi":    # one workgroup, no host read (csrc/tdr_prep.hip)
             evals = torch.empty(d, dtype=torch.float64, device=X.device)
             evecs = torch.empty((d, d), dtype=torch.float64, device=X.device)
@@ -565,3 +571,6 @@ def pca_scores(X: torch.Tensor, n_components: int) -> torch.Tensor:
     signs = torch.sign(E[idx, torch.arange(E.shape[1], device=E.device)])
     signs = torch.where(signs == 0, torch.ones_like(signs), signs)
     return E * signs[None, :]
+
+
+pca_scores.deterministic = False   # set by every call: True when the deterministic kernel path produced the scores

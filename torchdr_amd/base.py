@@ -75,6 +75,11 @@ class DRModule(BaseEstimator, nn.Module, ABC):
         self.embedding_ = None
         self.is_fitted_ = False
 
+    def _float64_ok(self, X) -> bool:
+        """Estimator-specific limits of the float64 kernels (`_float64_loop` estimators): False sends a float64 input down
+        the float32 path (computed in float32, handed back as float64) instead of failing on an unsupported shape."""
+        return True
+
     @handle_input_output()
     def fit(self, X, y: Optional[Any] = None):
         self.fit_transform(X, y=y)
@@ -88,7 +93,7 @@ class DRModule(BaseEstimator, nn.Module, ABC):
         # float64 in: estimators with float64 kernels for the whole path (`_float64_loop`: UMAP, LargeVis, TSNE, InfoTSNE;
         # single process, D <= 256) compute in float64 like the reference (which computes in its input's dtype); the
         # others compute in float32 and hand float64 back
-        if not (X.dtype == torch.float64 and getattr(self, "_float64_loop", False) and getattr(self, "world_size", 1) == 1
+        if not (X.dtype == torch.float64 and getattr(self, "_float64_loop", False) and self._float64_ok(X) and getattr(self, "world_size", 1) == 1
                 and X.dim() == 2 and X.shape[1] <= 256 and getattr(self, "metric", "sqeuclidean") in ("sqeuclidean", "euclidean", "angular")):
             X = as_float32(X)
         if getattr(self, "sharded_input", False) and getattr(self, "world_size", 1) > 1:

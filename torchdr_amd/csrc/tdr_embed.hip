@@ -409,13 +409,13 @@ __global__ __launch_bounds__(256) void ne_rowsum_kernel(const NeStepParams S, fl
     float s = 0.f;
     for (int col = gl; col < S.n_neg; col += G) {
         const PermKey K = perm_key(S.seed, S.iter, col, S.n_total);
-        const uint32_t j = perm_fwd((uint32_t)gi, K);
+        const uint32_t j = perm_succ(perm_inv((uint32_t)gi, K), K);     // never the row itself
         if ((int64_t)j < j_lo || (int64_t)j >= j_hi) continue;
         const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
         float d = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) { const float t = zi.v[c] - zj.v[c]; d += t * t; }
-        s += 1.0f / (1.0f + d);     // a self draw (probability 1/N) counts q = 1, as the pair (i, i) would
+        s += 1.0f / (1.0f + d);
     }
     s = group_sum<G>(s);
     if (gl == 0) {
@@ -477,25 +477,29 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
         // permutation sampler: item 2c = this row's own draw of column c, item 2c + 1 = the row whose draw of column c hit
         // this row; both are  +w (z_i - z_other)  on THIS row -- nothing is sent to the other endpoint
         const float own_inv = (S.kind == 3) ? 1.0f / S.rowsum[gi] : 0.f;
-        for (int it = gl; it < 2 * S.n_neg; it += G) {
-            const PermKey K = perm_key(S.seed, S.iter, it >> 1, S.n_total);
-            const bool inward = (it & 1) != 0;
-            const uint32_t j = inward ? perm_inv((uint32_t)gi, K) : perm_fwd((uint32_t)gi, K);
-            if ((int64_t)j == gi || (int64_t)j < j_lo || (int64_t)j >= j_hi) continue;
-            const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
-            float df[NC];
-            float d = 0.f;
+        for (int col = gl; col < S.n_neg; col += G) {
+            const PermKey K = perm_key(S.seed, S.iter, col, S.n_total);
+            const uint32_t a = perm_inv((uint32_t)gi, K);       // this row's place in the column's cyclic order
+            const uint32_t jj[2] = {perm_succ(a, K), perm_pred(a, K)};   // its own draw | the row that drew it
 #pragma unroll
-            for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d += df[c] * df[c]; }
-            float w;
-            if (S.kind == 3) {
-                const float q = 1.0f / (1.0f + d);
-                w = -S.rep_coef * q * q * (inward ? 1.0f / S.rowsum[j] : own_inv);   // the DRAWING row's normaliser
-            } else {
-                w = -S.rep_coef / ((1.0f + d) * (2.0f + d));
+            for (int side = 0; side < 2; ++side) {
+                const uint32_t j = jj[side];
+                if ((int64_t)j < j_lo || (int64_t)j >= j_hi) continue;
+                const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
+                float df[NC];
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d += df[c] * df[c]; }
+                float w;
+                if (S.kind == 3) {
+                    const float q = 1.0f / (1.0f + d);
+                    w = -S.rep_coef * q * q * (side ? 1.0f / S.rowsum[j] : own_inv);   // the DRAWING row's normaliser
+                } else {
+                    w = -S.rep_coef / ((1.0f + d) * (2.0f + d));
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) g[c] += w * df[c];
             }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) g[c] += w * df[c];
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -878,8 +882,9 @@ __global__ __launch_bounds__(256) void perm_debug_kernel(uint64_t seed, uint32_t
     const int64_t i = e / n_neg;
     const int c = (int)(e - i * n_neg);
     const PermKey K = perm_key(seed, iter, c, n_total);
-    fwd[e] = perm_fwd((uint32_t)i, K);
-    inv[e] = perm_inv((uint32_t)i, K);
+    const uint32_t a = perm_inv((uint32_t)i, K);
+    fwd[e] = perm_succ(a, K);
+    inv[e] = perm_pred(a, K);
 }
 
 template <int G, typename Prm>

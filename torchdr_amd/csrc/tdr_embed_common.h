@@ -73,9 +73,9 @@ __device__ __forceinline__ int64_t sample_negative(uint32_t row_key, int64_t gro
 // The reference draws, per row i and column c, a uniform j != i (neighbor_embedding/base.py:628-636) and autograd sends the
 // pair's force to BOTH endpoints.  With a hash sampler the far endpoint's share has to be scattered with atomics (10 M
 // device-scope fp32 atomics per LargeVis iteration at N = 1M: 0.5 of its 0.54 ms).  Here column c of iteration t is a keyed
-// pseudo-random PERMUTATION of the rows, j = P_{t,c}(i): every row's draws are still uniform over the rows and independent
-// across columns and iterations (the per-row law of the reference's sampler; i = j happens with probability 1/N and
-// contributes nothing), and the row that drew j is P^{-1}(j) -- so a row PULLS both its own draws and the draws that hit
+// pseudo-random PERMUTATION of the rows, j = P_{t,c}(i) (round 4: a fixed-point-free one, see perm_succ below): every row's
+// draws are uniform over the OTHER rows and independent across columns and iterations (the per-row law of the reference's
+// sampler), and the row that drew j is P^{-1}(j) -- so a row PULLS both its own draws and the draws that hit
 // it, and nothing is scattered.  What differs from independent draws is the joint law across rows of one column (no two
 // rows draw the same j): every row is the far endpoint of exactly n_negatives pairs instead of Poisson(n_negatives).
 // P = three rounds of (odd multiply + keyed add mod 2^b, xorshift by ceil(b/2)) on b = ceil(log2 N) bits with cycle walking
@@ -119,6 +119,15 @@ __device__ __forceinline__ uint32_t perm_inv(uint32_t x, const PermKey& K) {
     } while (x >= K.n);
     return x;
 }
+
+// Round 4: a row never draws ITSELF (the reference shifts self out: r ~ U{0..N-2}, +1 where r >= own index, base.py:634-636).
+// A keyed permutation has ~1 fixed point per column; the sampler therefore uses the permutation as a keyed CYCLIC ORDER of
+// the rows and lets every row draw its SUCCESSOR in it:  j = pi(pi^-1(i) + 1 mod N).  The map i -> j is one N-cycle -- a
+// bijection without fixed points -- and j is uniform over the N - 1 other rows (the reference's per-row law); the row that
+// drew i is its predecessor pi(pi^-1(i) - 1 mod N).  a = pi^-1(i) serves both: three permutation evaluations per (row,
+// column) for the pair (own draw, drawer).
+__device__ __forceinline__ uint32_t perm_succ(uint32_t a, const PermKey& K) { return perm_fwd(a + 1u == K.n ? 0u : a + 1u, K); }
+__device__ __forceinline__ uint32_t perm_pred(uint32_t a, const PermKey& K) { return perm_fwd(a == 0u ? K.n - 1u : a - 1u, K); }
 
 // d^b through the hardware log2 / exp2 (relative error ~ |b log2 d| * 2^-23, i.e. <= ~3e-6 for the
 // distances an embedding produces) and reciprocals through v_rcp_f32 (1 ulp): the force coefficients stay

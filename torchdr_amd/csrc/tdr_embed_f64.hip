@@ -288,6 +288,120 @@ __global__ __launch_bounds__(256) void tsne_repulsion_f64_kernel(const double* _
     if ((threadIdx.x & 63) == 0) atomicAdd(S, s);
 }
 
+// ---- SNE dense repulsion (sne.py:172-179) in float64: R_i = sum_j e^{-d_ij} (diagonal included), then
+// g_i += coef * sum_j e^{-d_ij} (1/R_i + 1/R_j) (z_i - z_j).  Plain LDS-tiled all-pairs loops, one thread per row.
+template <int NC, bool PAD>
+__global__ __launch_bounds__(256) void sne_rowsum_f64_kernel(const double* __restrict__ Z, int64_t n_total, int64_t row0, int64_t n_rows,
+                                                             double* __restrict__ R, int nc_) {
+    const int nc = PAD ? nc_ : NC;
+    __shared__ double tile[256 * NC];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = r < n_rows;
+    double zi[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) zi[c] = (have && c < nc) ? Z[(size_t)(row0 + r) * nc + c] : 0.0;
+    double s = 0.0;
+    for (int64_t j0 = 0; j0 < n_total; j0 += 256) {
+        __syncthreads();
+        const int64_t j = j0 + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) tile[threadIdx.x * NC + c] = (j < n_total && c < nc) ? Z[(size_t)j * nc + c] : 0.0;
+        __syncthreads();
+        const int lim = (int)((n_total - j0 < 256) ? (n_total - j0) : 256);
+        for (int t = 0; t < lim; ++t) {
+            double d = 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const double u = zi[c] - tile[t * NC + c]; d += u * u; }
+            s += exp(-d);
+        }
+    }
+    if (have) R[r] = s;
+}
+
+template <int NC, bool PAD>
+__global__ __launch_bounds__(256) void sne_repulsion_f64_kernel(const double* __restrict__ Z, int64_t n_total, int64_t row0, int64_t n_rows,
+                                                                const double* __restrict__ R, double coef, double* __restrict__ grad, int nc_) {
+    const int nc = PAD ? nc_ : NC;
+    __shared__ double tile[256 * (NC + 1)];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool have = r < n_rows;
+    double zi[NC], f[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { zi[c] = (have && c < nc) ? Z[(size_t)(row0 + r) * nc + c] : 0.0; f[c] = 0.0; }
+    const double inv_ri = have ? 1.0 / R[row0 + r] : 0.0;
+    for (int64_t j0 = 0; j0 < n_total; j0 += 256) {
+        __syncthreads();
+        const int64_t j = j0 + threadIdx.x;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) tile[threadIdx.x * (NC + 1) + c] = (j < n_total && c < nc) ? Z[(size_t)j * nc + c] : 0.0;
+        tile[threadIdx.x * (NC + 1) + NC] = (j < n_total) ? 1.0 / R[j] : 0.0;
+        __syncthreads();
+        const int lim = (int)((n_total - j0 < 256) ? (n_total - j0) : 256);
+        for (int t = 0; t < lim; ++t) {
+            double df[NC], d = 0.0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { df[c] = zi[c] - tile[t * (NC + 1) + c]; d += df[c] * df[c]; }
+            const double w = exp(-d) * (inv_ri + tile[t * (NC + 1) + NC]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) f[c] += w * df[c];
+        }
+    }
+    if (have) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+            if (c < nc) grad[(size_t)(row0 + r) * nc + c] += coef * f[c];
+    }
+}
+
+// ---- PaCMAP pair losses (pacmap.py:213-265) in float64: the closed-form gradient of tdr_pacmap_grad_f32 ------------------
+struct PacmapParamsD {
+    const double* Z;
+    int64_t n;
+    const int64_t* near; int m_near; double w_nb;
+    const int64_t* mid;  int m_mid;  double w_mn;
+    const int64_t* far_; int m_far;  double w_fp;
+    double* grad;
+    int nc;
+};
+
+template <int NC, int G, bool PAD>
+__global__ __launch_bounds__(256) void pacmap_grad_f64_kernel(const PacmapParamsD P) {
+    const int nc = PAD ? P.nc : NC;
+    const int gl = threadIdx.x % G;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (i >= P.n) return;
+    const VecD<NC> zi = load_zd<NC, PAD>(P.Z, i, nc);
+    double g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) g[c] = 0.0;
+    const int total = P.m_near + P.m_mid + P.m_far;
+    for (int p = gl; p < total; p += G) {
+        int64_t j;
+        double num, off, w;
+        if (p < P.m_near) { j = P.near[(size_t)i * P.m_near + p]; num = 10.0; off = 11.0; w = P.w_nb; }
+        else if (p < P.m_near + P.m_mid) { j = P.mid[(size_t)i * P.m_mid + (p - P.m_near)]; num = 1.0e4; off = 10001.0; w = P.w_mn; }
+        else { j = P.far_[(size_t)i * P.m_far + (p - P.m_near - P.m_mid)]; num = -1.0; off = 2.0; w = P.w_fp; }
+        if (w == 0.0) continue;
+        const VecD<NC> zj = load_zd<NC, PAD>(P.Z, j, nc);
+        double df[NC], d = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d += df[c] * df[c]; }
+        const double den = off + d;
+        const double coef = 2.0 * w * num / (den * den);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double t = coef * df[c];
+            g[c] += t;
+            if (c < nc) unsafeAtomicAdd(&P.grad[(size_t)j * nc + c], -t);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        g[c] = group_sum_d<G>(g[c]);
+        if (gl == 0 && c < nc) unsafeAtomicAdd(&P.grad[(size_t)i * nc + c], g[c]);
+    }
+}
+
 __global__ __launch_bounds__(256) void add_scaled_f64_kernel(double* __restrict__ grad, const double* __restrict__ F,
                                                              const double* __restrict__ S, double coef, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -414,6 +528,53 @@ int tdr_sgd_step_f64(double* Z, const double* grad, double* buf, int64_t n, doub
                        momentum, first, nan_flag, n_iter);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
+}
+
+/* float64 twins of tdr_sne_rowsum_f32 / tdr_sne_repulsion_f32 (sne.py:172-179): R (n_rows) = sum_j exp(-d_ij) over ALL n_total
+ * points (the all-gathered R of every point is what the second pass reads); grad rows [row0, row0 + n_rows) +=
+ * coef * sum_j exp(-d_ij) (1/R_i + 1/R_j) (z_i - z_j).  nc <= 16. */
+int tdr_sne_rowsum_f64(const double* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, double* R, void* stream) {
+    if (!Z || !R || n_rows <= 0 || n_total <= 0) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n_rows + 255) / 256);
+    if (nc == 2) hipLaunchKernelGGL((sne_rowsum_f64_kernel<2, false>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, nc);
+    else if (nc == 3) hipLaunchKernelGGL((sne_rowsum_f64_kernel<3, false>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, nc);
+    else if (nc >= 1 && nc <= 8) hipLaunchKernelGGL((sne_rowsum_f64_kernel<8, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, nc);
+    else if (nc >= 1 && nc <= 16) hipLaunchKernelGGL((sne_rowsum_f64_kernel<16, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, nc);
+    else return TDR_ERR_UNSUPPORTED;
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+int tdr_sne_repulsion_f64(const double* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const double* R, double coef,
+                          double* grad, void* stream) {
+    if (!Z || !R || !grad || n_rows <= 0 || n_total <= 0) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((n_rows + 255) / 256);
+    if (nc == 2) hipLaunchKernelGGL((sne_repulsion_f64_kernel<2, false>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad, nc);
+    else if (nc == 3) hipLaunchKernelGGL((sne_repulsion_f64_kernel<3, false>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad, nc);
+    else if (nc >= 1 && nc <= 8) hipLaunchKernelGGL((sne_repulsion_f64_kernel<8, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad, nc);
+    else if (nc >= 1 && nc <= 16) hipLaunchKernelGGL((sne_repulsion_f64_kernel<16, true>), dim3(grid), dim3(256), 0, st, Z, n_total, row0, n_rows, R, coef, grad, nc);
+    else return TDR_ERR_UNSUPPORTED;
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* float64 twin of tdr_pacmap_grad_f32 (pacmap.py:213-265): grad (n, nc) zero-initialised by the caller; nc <= 32. */
+int tdr_pacmap_grad_f64(const double* Z, int nc, int64_t n, const int64_t* near_idx, int m_near, double w_nb, const int64_t* mid_idx,
+                        int m_mid, double w_mn, const int64_t* far_idx, int m_far, double w_fp, double* grad, void* stream) {
+    if (!Z || !grad || n <= 0 || m_near < 0 || m_mid < 0 || m_far < 0) return TDR_ERR_BAD_ARG;
+    if ((m_near > 0 && !near_idx) || (m_mid > 0 && !mid_idx) || (m_far > 0 && !far_idx)) return TDR_ERR_BAD_ARG;
+    if (nc < 1 || nc > 32) return TDR_ERR_UNSUPPORTED;
+    PacmapParamsD P;
+    P.Z = Z; P.n = n; P.near = near_idx; P.m_near = m_near; P.w_nb = w_nb; P.mid = mid_idx; P.m_mid = m_mid; P.w_mn = w_mn;
+    P.far_ = far_idx; P.m_far = m_far; P.w_fp = w_fp; P.grad = grad; P.nc = nc;
+    hipStream_t st = (hipStream_t)stream;
+    if (nc == 2) return launch_group_d<16>(pacmap_grad_f64_kernel<2, 16, false>, P, n, st);
+    if (nc == 3) return launch_group_d<16>(pacmap_grad_f64_kernel<3, 16, false>, P, n, st);
+    if (nc <= 8) return launch_group_d<16>(pacmap_grad_f64_kernel<8, 16, true>, P, n, st);
+    if (nc <= 16) return launch_group_d<16>(pacmap_grad_f64_kernel<16, 16, true>, P, n, st);
+    return launch_group_d<16>(pacmap_grad_f64_kernel<32, 16, true>, P, n, st);
 }
 
 }  // extern "C"

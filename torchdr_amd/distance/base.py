@@ -44,7 +44,7 @@ import os as _os
 SCREEN_MODE = _os.environ.get("TDR_KNN_SCREEN", "auto")
 _SCREEN_MIN_PAIRS = 1 << 26  # nq * n_db below which the one-stage kernel is used
 _SCREEN_PILOT_MIN_Q = 32768   # searches with at least this many queries screen a pilot slice first
-_SCREEN_PILOT_Q = 1024   # 8 query groups x 32 database slices = 256 workgroups: 3.2 ms per tier at N = 1M (2048 queries x 16 slices: 6.5 ms)
+_SCREEN_PILOT_Q = 512    # 4 query groups x 32 database slices = 128 workgroups per tier: the two concurrent tier pilots fill the chip together (1024 queries: 256 workgroups each, 3.2 ms alone, ~6 ms side by side)
 _SCREEN_PILOT_MAX_FRAC = 0.05  # overflowed share of the pilot above which the one-stage kernel is used
 # counters of the last knn_packed call (tests / bench): path taken and number of overflowed queries
 LAST_KNN = {"path": None, "flagged": 0}

@@ -269,9 +269,14 @@ class NeighborEmbedding(AffinityMatcher):
         emb = super()._init_embedding(X)
         if getattr(self, "_perm", None) is not None:   # rows of the initial embedding in the loop's numbering
             self.embedding_ = emb.index_select(0, self._perm).contiguous()
-        if self.world_size > 1 and not (isinstance(self.init, str) and self.init == "pca"):
-            # reference :421.  init="pca" needs no exchange: every rank holds the full block and the PCA kernels are
-            # deterministic (ordered fp64 combination of the Gram tiles, one-workgroup Jacobi) -- same bits on every rank
+        from torchdr_amd.affinity_matcher import pca_scores
+
+        same_on_every_rank = isinstance(self.init, str) and self.init == "pca" and getattr(self, "_pca_deterministic", pca_scores.deterministic)
+        if self.world_size > 1 and not same_on_every_rank:
+            # reference :421.  init="pca" needs no exchange WHEN the deterministic PCA kernels produced it (float32 block on
+            # the device, D <= 256, <= 4 components, PCA_EIGH = "jacobi": ordered fp64 combination of the Gram tiles, one-
+            # workgroup Jacobi -- same bits on every rank); the torch fallback (library GEMM / eigh: split-K or atomic
+            # kernels may differ in rounding between ranks) keeps the reference's broadcast
             from torchdr_amd.parallel import broadcast_
             from torchdr_amd.utils.phases import phase
 

@@ -22,6 +22,8 @@ class PACMAP(NegativeSamplingNeighborEmbedding):
     (:238-239), i.e. the POSITION (0..5) of the second-closest of the six sampled candidates, not the candidate's
     index -- so the mid-near partners are the points 0..5.  Reproduced as is for result parity."""
 
+    _float64_loop = True   # float64 inputs are embedded in float64 (tdr_pacmap_grad_f64; the mid-near table through the torch form)
+
     def __init__(self, n_neighbors: float = 10, n_components: int = 2, lr: Union[float, str] = 1e0,
                  optimizer: Union[str, Type[torch.optim.Optimizer]] = "Adam",
                  optimizer_kwargs: Optional[Union[Dict, str]] = None,
@@ -97,7 +99,8 @@ class PACMAP(NegativeSamplingNeighborEmbedding):
 
     def _compute_gradients(self):
         n, nc = self.n_samples_in_, self.n_components
-        grad = torch.zeros((n, nc), dtype=torch.float32, device=self.device_)
+        dt = self.embedding_.dtype
+        grad = torch.zeros((n, nc), dtype=dt, device=self.device_)
         near = self.NN_indices_.to(torch.int64).contiguous()
         mid = None
         if self.w_MN > 0:
@@ -109,12 +112,12 @@ class PACMAP(NegativeSamplingNeighborEmbedding):
             raise RuntimeError("[torchdr_amd] PACMAP needs the further-pair table (discard_NNs=True path).")
         lam, rho = float(self.early_exaggeration_coeff_), float(self.repulsion_strength)
         _lib.check(
-            _lib.lib().tdr_pacmap_grad_f32(
+            _lib.fn("tdr_pacmap_grad", dt)(
                 _lib.ptr(self.embedding_), nc, n, _lib.ptr(near), near.shape[1], lam * float(self.w_NB),
                 _lib.ptr(mid), 0 if mid is None else mid.shape[1], lam * float(self.w_MN),
                 _lib.ptr(far), far.shape[1], rho * float(self.w_FP), _lib.ptr(grad), _lib.stream_ptr(),
             ),
-            "tdr_pacmap_grad_f32",
+            "tdr_pacmap_grad",
         )
         return grad, False
 

@@ -20,6 +20,8 @@ class SNE(NeighborEmbedding):
     (the reference evaluates the whole N x N sum on every rank and divides by the world size,
     ``sne.py:177-178``)."""
 
+    _float64_loop = True   # float64 inputs are embedded in float64 (csrc/tdr_embed_f64.hip: tdr_sne_rowsum_f64 / _repulsion_f64)
+
     def __init__(self, perplexity: float = 30, n_components: int = 2, lr: Union[float, str] = "auto",
                  optimizer: Union[str, Type[torch.optim.Optimizer]] = "SGD",
                  optimizer_kwargs: Union[Dict, str] = "auto",
@@ -56,33 +58,36 @@ class SNE(NeighborEmbedding):
         if hasattr(self, "_tgraph"):
             delattr(self, "_tgraph")
 
+    def _float64_ok(self, X) -> bool:
+        return int(self.n_components) <= 16      # register instances of the float64 all-pairs kernels
+
     def _compute_gradients(self):
         L = _lib.lib()
         n, nc = self.n_samples_in_, self.n_components
         st = _lib.stream_ptr()
-        grad = torch.zeros((n, nc), dtype=torch.float32, device=self.device_)
         P = self.affinity_in_
+        dt = P.dtype     # float64 inputs are embedded in float64 (csrc/tdr_embed_f64.hip), like the reference
+        grad = torch.zeros((n, nc), dtype=dt, device=self.device_)
         _lib.check(
-            L.tdr_ne_grad_f32(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
-                              _lib.ptr(self._nn_table), _lib.ptr(P), P.shape[1], _lib.ptr(self._tgraph[0]),
-                              _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]), 2,
-                              float(self.early_exaggeration_coeff_), 0.0, 0, None, 0, int(self.n_iter_),
-                              _lib.ptr(grad), st),
-            "tdr_ne_grad_f32",
+            _lib.fn("tdr_ne_grad", dt)(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
+                                       _lib.ptr(self._nn_table), _lib.ptr(P), P.shape[1], _lib.ptr(self._tgraph[0]),
+                                       _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]), 2,
+                                       float(self.early_exaggeration_coeff_), 0.0, 0, None, 0, int(self.n_iter_),
+                                       _lib.ptr(grad), st),
+            "tdr_ne_grad",
         )
-        R = torch.empty((self.chunk_size_, 1), dtype=torch.float32, device=self.device_)
+        R = torch.empty((self.chunk_size_, 1), dtype=dt, device=self.device_)
         _lib.check(
-            L.tdr_sne_rowsum_f32(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_, _lib.ptr(R),
-                                 st),
-            "tdr_sne_rowsum_f32",
+            _lib.fn("tdr_sne_rowsum", dt)(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_, _lib.ptr(R), st),
+            "tdr_sne_rowsum",
         )
         if self.world_size > 1:
             from torchdr_amd.parallel import allgather_rows
 
             R = allgather_rows(R, n, self.world_size)
         _lib.check(
-            L.tdr_sne_repulsion_f32(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
-                                    _lib.ptr(R), -2.0 * float(self.repulsion_strength) / n, _lib.ptr(grad), st),
-            "tdr_sne_repulsion_f32",
+            _lib.fn("tdr_sne_repulsion", dt)(_lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_,
+                                             _lib.ptr(R), -2.0 * float(self.repulsion_strength) / n, _lib.ptr(grad), st),
+            "tdr_sne_repulsion",
         )
         return grad, False

@@ -22,6 +22,10 @@ class TSNE(NeighborEmbedding):
     _relabel_rect = True   # single GPU, pruned search: the loop runs in the kNN stage's cluster-sorted numbering
     _float64_loop = True   # float64 inputs are embedded in float64 (csrc/tdr_embed_f64.hip; n_components <= 16)
 
+    def _float64_ok(self, X) -> bool:
+        # tdr_tsne_repulsion_f64 has register instances up to 16 components; the float32 kernels go to 32
+        return int(self.n_components) <= 16
+
     def __init__(self, perplexity: float = 30, n_components: int = 2, lr: Union[float, str] = "auto",
                  optimizer: Union[str, Type[torch.optim.Optimizer]] = "SGD",
                  optimizer_kwargs: Union[Dict, str] = "auto",

@@ -282,17 +282,41 @@ class RcclContext:
     # topology, channel set-up) -- per fit it would be most of a row-sharded fit_transform at 8 GPUs
     _shared = {}
 
+    @staticmethod
+    def _group_token():
+        """Identity of the current default process group: a communicator belongs to the group it was bootstrapped in -- after
+        destroy_process_group() / init_process_group() (tests, elastic restarts) the same (device, world, rank) may name
+        other peers."""
+        try:
+            return id(dist.distributed_c10d._get_default_group())
+        except Exception:
+            return None
+
     @classmethod
     def shared(cls, n_total: int, device):
-        """The process's communicator on `device`, re-targeted at an embedding of `n_total` rows; created (collectively:
-        every rank reaches its first call in the same fit) on first use.  None when RCCL is unavailable."""
+        """The process's communicator on `device` for the CURRENT process group, re-targeted at an embedding of `n_total` rows;
+        created (collectively: every rank reaches its first call in the same fit) on first use.  None when RCCL is
+        unavailable -- a failed creation is not remembered (the next fit tries again, collectively).  Fits of one process
+        share the communicator and its row count: they are expected one after the other (one fit at a time per process)."""
         from torchdr_amd import _lib
 
-        key = (torch.device(device).index, dist.get_world_size(), dist.get_rank())
-        if key not in cls._shared:
-            cls._shared[key] = cls.create(n_total, device)
-        ctx = cls._shared[key]
-        if ctx is not None and ctx.n_total != n_total:
+        token = cls._group_token()
+        for k in [k for k in cls._shared if k[3] != token]:     # communicators of a process group that no longer exists
+            ctx = cls._shared.pop(k)
+            if ctx is not None:
+                ctx.destroy()
+        key = (torch.device(device).index, dist.get_world_size(), dist.get_rank(), token)
+        ctx = cls._shared.get(key)
+        if ctx is None:
+            ctx = cls.create(n_total, device)
+            if ctx is None:
+                return None
+            if not cls._shared:
+                import atexit
+
+                atexit.register(cls.destroy_shared)
+            cls._shared[key] = ctx
+        if ctx.n_total != n_total:
             _lib.check(_lib.lib().tdr_ctx_set_rows(ctx.handle, n_total), "tdr_ctx_set_rows")
             ctx.n_total = n_total
         return ctx
@@ -321,6 +345,10 @@ class RcclContext:
 
     def allgather_rows_(self, Z: torch.Tensor):
         from torchdr_amd import _lib
+
+        if Z.shape[0] != self.n_total:      # another fit re-targeted the shared communicator in between
+            _lib.check(_lib.lib().tdr_ctx_set_rows(self.handle, Z.shape[0]), "tdr_ctx_set_rows")
+            self.n_total = Z.shape[0]
 
         _lib.check(_lib.lib().tdr_ctx_allgather_rows(self.handle, _lib.ptr(Z), Z.shape[1], _lib.stream_ptr()),
                    "tdr_ctx_allgather_rows")

@@ -65,10 +65,9 @@ def symmetrize_to_csr(values, indices, mode="sum_minus_prod", row_offset=0, n_to
     cols = indices.to(torch.int32).contiguous()
     n, k = vals.shape
     if k > 256:
-        raise NotImplementedError(
-            f"[torchdr_amd] symmetrize_sparse: the row-local symmetrisation kernels hold up to 256 entries per row (got {k}); "
-            "UMAP with more than 256 neighbours is not supported."
-        )
+        # the row-local kernels hold up to 256 entries per row; wider blocks (the kNN stage goes to 1024 neighbours) take the
+        # sort-and-coalesce form below: device-side torch ops, same values, same column-sorted rows
+        return _symmetrize_wide(values, indices, mode, row_offset, n_total if n_total else n, ext)
     dev = vals.device
     ws_bytes = L.tdr_sym_workspace_bytes(n, k)
     ws = torch.empty(ws_bytes // 8 + 1, dtype=torch.int64, device=dev)
@@ -107,6 +106,37 @@ def symmetrize_to_csr(values, indices, mode="sum_minus_prod", row_offset=0, n_to
                                         _MODE[mode], _lib.ptr(v64), st), "tdr_sym_values_f64")
         ovals = v64
     return CSRAffinity(rowptr, ocols, ovals, row_offset=row_offset, n_total=n_total if n_total else n)
+
+
+def _symmetrize_wide(values, indices, mode, row_offset, n_total, ext) -> CSRAffinity:
+    """``symmetrize_to_csr`` for blocks wider than the row-local kernels' 256 entries per row (sparse.py:7-206 semantics): the
+    directed entries (i, j, P_ij) and their transposes (rows of this rank only; `ext` = transposes received from other ranks)
+    are keyed by (row, column), coalesced with one device sort, and combined as P + P^T (- P o P^T).  torch ops on the
+    device, in the values' dtype; rows come out sorted by column like the kernels'."""
+    dev = values.device
+    n, k = values.shape
+    vals = values.contiguous()
+    if vals.dtype not in (torch.float32, torch.float64):
+        vals = vals.float()
+    cols = indices.to(torch.int64)
+    rows = (torch.arange(n, device=dev, dtype=torch.int64) + row_offset)[:, None].expand(n, k)
+    ok = cols >= 0
+    r_a, c_a, v_a = rows[ok], cols[ok], vals[ok]
+    local = (c_a >= row_offset) & (c_a < row_offset + n)
+    r_t, c_t, v_t = c_a[local], r_a[local], v_a[local]
+    if ext is not None and ext[0].numel() > 0:
+        r_t = torch.cat([r_t, ext[0].to(torch.int64) + row_offset])
+        c_t = torch.cat([c_t, ext[1].to(torch.int64)])
+        v_t = torch.cat([v_t, ext[2].to(vals.dtype)])
+    key = torch.cat([r_a * n_total + c_a, r_t * n_total + c_t])
+    uniq, inv = torch.unique(key, return_inverse=True)        # sorted: (row, column) order
+    a = torch.zeros(uniq.numel(), dtype=vals.dtype, device=dev).index_add_(0, inv[: r_a.numel()], v_a)
+    b = torch.zeros(uniq.numel(), dtype=vals.dtype, device=dev).index_add_(0, inv[r_a.numel():], v_t)
+    out = a + b - a * b if _MODE[mode] == 0 else a + b
+    r_u = torch.div(uniq, n_total, rounding_mode="floor") - row_offset
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.bincount(r_u, minlength=n).cumsum(0)
+    return CSRAffinity(rowptr, (uniq - (r_u + row_offset) * n_total).to(torch.int32), out, row_offset=row_offset, n_total=n_total)
 
 
 def symmetrize_sparse(values, indices, mode="sum_minus_prod"):
