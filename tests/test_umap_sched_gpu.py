@@ -710,10 +710,10 @@ def test_grouped_schedule_is_the_step_by_step_recurrence(S, B, t0):
                                                                    torch.repeat_interleave(length[k].cumsum(0) - length[k], length[k]))
             rows_g = torch.repeat_interleave(torch.arange(n), length[k])
             assert torch.equal(torch.sort(row_of[sel] * n + cp[sel].long()).values, torch.sort(rows_g * n + lst[idx]).values)
-            # order inside a segment: by (rank of this firing among the edge's firings of the 8-iteration run, the row's
+            # order inside a segment: by (rank of this firing among the edge's firings of the 4-iteration run, the row's
             # own edge order) -- a key made of the edge alone
             rank = torch.zeros(cp.numel(), dtype=torch.long)
-            for tq in range(t - t % 8, t):
+            for tq in range(t - t % 4, t):
                 rank += fires[tq].long()
             e_sel = torch.nonzero(sel).flatten()
             key = (row_of[e_sel] * 16 + rank[e_sel]) * cp.numel() + e_sel

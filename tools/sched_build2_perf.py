@@ -75,7 +75,7 @@ want = nxt.clone()
 hdr_rc = sc.hdr.clone()
 del sc
 
-for stage in (1024, 512 | 1 << 20, 768 | 1 << 20, 1024 | 1 << 20, 768 | 4 << 16 | 1 << 20):
+for stage in (0, 512, 768, 1024, 768 | 4 << 16):
     gs = GroupSched(rowptr, cols, eps_per, n, 32, S, stage=stage)
     ng = gs.to_group(eps_per)
     for t0 in (0, 32, 64):

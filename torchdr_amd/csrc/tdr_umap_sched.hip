@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) void umap_sched_layout_kernel(const int64_t* _
 constexpr int G2_ROWS = 16;    // rows per group (one wavefront)
 constexpr int G2_STRIDE = 17;  // counters of one (iteration, slice): 16 rows, odd stride
 constexpr int G2_STASH = 16;   // 64-edge chunks whose (mask, column, row | slice) stay in registers between the phases
-constexpr int G2_TC = 8;       // iterations per staged run
-constexpr int G2_STAGE_DEFAULT = 1024;  // staged list entries (LDS, >= 512); the mean run is 16 rows x 8.6 firings x 8 iterations = 1100
+constexpr int G2_TC = 4;       // iterations per staged run (part of the order key inside a segment: one value)
+constexpr int G2_STAGE_DEFAULT = 768;   // staged list entries (LDS, >= 512); the mean run is 16 rows x 8.6 firings x 4 iterations = 550
 
 // firing period -> class: 4 per octave (epochs_per_sample = max weight / weight >= 1); 2^15.5 and beyond, incl. the
 // never-firing edges (inf), share class 63.  Monotone in the period.
@@ -1174,12 +1174,12 @@ static int launch_sched_build2(const SchedBuild2Params& P0, hipStream_t st, bool
         }                                                                                                             \
         hipLaunchKernelGGL((umap_sched_build2_kernel<W, T>), dim3((unsigned)n_groups), dim3(64), lds, st, P);        \
     } while (0)
-    const int tc4 = (P0.stage >> 20) & 1;    // tuning: runs of 4 iterations
-    if (tc4 && variant == 4) TDR_BUILD2(4, 4);
-    else if (tc4) TDR_BUILD2(5, 4);
-    else if (variant == 6) TDR_BUILD2(6, 8);
-    else if (variant == 4) TDR_BUILD2(4, 8);
-    else TDR_BUILD2(5, 8);   // 96 registers (8 spilled): 1.10 ms per window at N = 1M; 4 -> 126 registers 1.19, 6 -> 80 (39 spilled) 1.65
+    // runs of G2_TC = 4 iterations with a 768-entry stage: 1.08 ms per window at N = 1M against 1.15 with runs of 8 and 1024
+    // entries (same box; the mean run is 550 entries, nearly all of them staged).  The run length enters the ORDER inside a
+    // segment (rank of a firing inside its run), so there is one production value; the register budget is a pure speed knob.
+    if (variant == 4) TDR_BUILD2(4, G2_TC);
+    else if (variant == 6) TDR_BUILD2(6, G2_TC);
+    else TDR_BUILD2(5, G2_TC);   // 96 registers (8 spilled); 4 -> 126 registers: +8 %, 6 -> 80 registers (39 spilled): +50 %
 #undef TDR_BUILD2
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TDR_OK : (int)e;
@@ -1521,7 +1521,7 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
         if (e != hipSuccess) { delete L; return (int)e; }
     }
     if (L->rs && sched_build2_lds(L->B, L->S, G2_STAGE_DEFAULT) > 32 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build2_kernel<5, 8>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(umap_sched_build2_kernel<5, G2_TC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sched_build2_lds(L->B, L->S, G2_STAGE_DEFAULT));
         if (e != hipSuccess) { delete L; return (int)e; }
     }
