@@ -334,6 +334,14 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
  * Z (n_rows, nc), in one kernel with the same bits as the two. */
 int tdr_umap_sched_step_f32(const float* acc, int n_slices, int nc, int64_t n_rows, float exag, float rep, float* grad, float* Z,
                             float* buf, float lr, float momentum, int first, int* nan_flag, int n_iter, void* stream);
+/* Round 4: the joint gradient launch with the combine + SGD step INSIDE it (last-arriving slice workgroup of a 64-row block;
+ * write-through planes + ticket, cdna_hip_programming.md Guideline 16): same bits as grad (geom 16 | 32) + step, no second
+ * kernel.  The stepped rows go to Znext (Z is gathered during the launch): the caller swaps the buffers.  nc = 2 only. */
+int64_t tdr_umap_sched_ticket_count(int64_t n_rows, int n_slices);
+int tdr_umap_sched_grad_step_f32(const float* Z, float* Znext, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list,
+                                 const void* hdr, int t_local, int n_slices, float a, float b, int n_iter, int neg_rate, int n_negatives,
+                                 uint64_t seed, float exag, float rep, float eps, float* grad, float* acc, int geom, float lr,
+                                 float momentum, int first, float* mom_buf, int* nan_flag, int* tickets, void* stream);
 /* The optimisation loop of affinity_matcher.py:288-352 for UMAP's closed-form step + torch.optim.SGD behind one handle
  * (csrc/tdr_umap_sched.hip): windows of <= block_iters iterations (schedule build + per iteration n_slices gradient
  * passes + the SGD step [+ a row all-gather]) are captured into HIP graphs and replayed; the iteration base lives in

@@ -53,6 +53,14 @@ RELABEL = True
 # row-major order when it is read.  False: the row-chunk kernel of rounds 2-3 (tdr_umap_sched_build_f32).
 GROUPED = True
 SCHED_STAGE = 0      # LDS stage entries of the grouped build (0 = library default)
+# FUSE_STEP: stock estimator, one GPU, n_components = 2, more than one L2 slice: the combine + SGD step run INSIDE the joint
+# gradient launch (tdr_umap_sched_grad_step_f32: the last-arriving slice workgroup of every 64-row block finishes its rows)
+# instead of in a second kernel (tdr_umap_sched_step_f32).  The stepped rows land in a second embedding buffer (the first is
+# being gathered by the whole grid); the two swap storage after every iteration.  Same bits (tests/test_umap_sched_gpu.py::
+# test_step_inside_the_gradient_launch_equals_the_two_kernel_form) -- and SLOWER: gradient + step 0.287 ms per iteration against
+# 0.277 ms with the separate 11 us kernel (N = 1M, same box, profiles/r04_fused_step.json): every workgroup now drains its
+# write-through stores and meets a barrier before it may leave, and half of them read the planes back through the fabric.  Off.
+FUSE_STEP = False
 
 def _opt(name):
     """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
@@ -223,7 +231,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
     def on_affinity_computation_end(self):
         # plans and buffers of a previous fit (kept until clear_memory, which a fit that raised never reached) are sized
         # for THAT graph: never reuse them
-        self._sched, self._grad_buf, self._sched_deferred, self._grad_ws, self._g = None, None, False, None, None
+        self._sched, self._grad_buf, self._sched_deferred, self._grad_ws, self._g, self._sched_stepped = None, None, False, None, None, False
         super().on_affinity_computation_end()
         csr: CSRAffinity = self._relabel()
         self._csr_loop = csr
@@ -368,6 +376,31 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         # them and steps the rows (`_sgd_kernel` below); anything that looks at the gradient in between keeps the form
         # with its own combine kernel
         self._sched_deferred = bool((geom & 16) and sc["S"] > 1 and self._fused_sgd and self._stock_step())
+        if (self._sched_deferred and _opt("FUSE_STEP") and self.n_components == 2 and self.world_size == 1 and neg is None
+                and self.embedding_.dtype == torch.float32 and self.chunk_size_ == self.n_samples_in_):
+            if "tickets" not in sc:
+                sc["tickets"] = torch.zeros(int(L.tdr_umap_sched_ticket_count(self.chunk_size_, sc["S"])), dtype=torch.int32, device=self.device_)
+                sc["Zalt"] = torch.empty_like(self.embedding_)
+            mom, first = float(self._sgd_momentum), 0
+            if mom != 0.0 and self._momentum_buf is None:
+                self._momentum_buf, first = torch.empty_like(self.embedding_), 1
+            holder = getattr(self, "optimizer_", None)
+            if isinstance(holder, torch.optim.Optimizer):
+                holder.param_groups[0]["lr"] = self._current_lr()
+            _lib.check(
+                L.tdr_umap_sched_grad_step_f32(
+                    _lib.ptr(self.embedding_), _lib.ptr(sc["Zalt"]), self.n_samples_in_, self.chunk_start_, self.chunk_size_,
+                    _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), t - sc["t0"], sc["S"], float(self._a), float(self._b), t,
+                    int(self.negative_sample_rate), int(self.n_negatives), self._neg_seed, float(self.early_exaggeration_coeff_),
+                    float(self.repulsion_strength), float(self._eps), _lib.ptr(grad), _lib.ptr(sc["acc"]), geom, self._current_lr(),
+                    mom, first, _lib.ptr(self._momentum_buf), _lib.ptr(self._nan_flag), _lib.ptr(sc["tickets"]), _lib.stream_ptr(),
+                ),
+                "tdr_umap_sched_grad_step_f32",
+            )
+            self._sched_stepped = True
+            if prof:
+                self._prof_pending = (ev0, ev1, csr.nnz)
+            return
         if self._sched_deferred:
             geom |= 32
         _lib.check(
@@ -400,6 +433,19 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             return super()._sgd_kernel(Z, grad, chunk=chunk)
         self._sched_deferred = False
         sc = self._sched
+        if getattr(self, "_sched_stepped", False):
+            # the gradient launch stepped the rows into the second buffer: the two swap storage (the tensor object, which the
+            # optimizer holder and the caller's references point to, stays)
+            self._sched_stepped = False
+            alt = sc["Zalt"]
+            cur = self.embedding_.data
+            self.embedding_.data = alt.data
+            alt.data = cur
+            pend = self.__dict__.pop("_prof_pending", None)
+            if pend is not None and PROFILE is not None:
+                pend[1].record()
+                PROFILE.append(("grad", pend[0], pend[1], pend[2]))
+            return
         mom = float(self._sgd_momentum)
         first = 0
         if mom != 0.0 and self._momentum_buf is None:
