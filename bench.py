@@ -427,6 +427,7 @@ def main():
                 keep["csr"] = m._csr
                 keep["a"], keep["b"] = m._a, m._b
                 keep["rccl_context"] = getattr(m, "_rccl_ctx", None) is not None
+                keep["exchange"] = type(getattr(m, "_rccl_ctx", None)).__name__ if getattr(m, "_rccl_ctx", None) is not None else "torch.distributed"
                 keep["loop_order"] = getattr(m, "loop_order_", None) is not None
                 _orig()
 
@@ -472,7 +473,12 @@ def main():
 
         Zt = torch.zeros((args.n, 2), dtype=torch.float32, device=dev)
         c0, c1 = chunk_bounds(args.n, rank, world)
-        ctx = RcclContext.shared(args.n, dev) if (keep.get("rccl_context") and dist.get_backend() == "nccl") else None
+        from torchdr_amd.parallel import PeerExchange
+
+        if keep.get("exchange") == "PeerExchange":      # the transport the loop used
+            ctx = PeerExchange.shared(args.n, 2, dev)
+        else:
+            ctx = RcclContext.shared(args.n, dev) if (keep.get("rccl_context") and dist.get_backend() == "nccl") else None
         reps = 50
         for timed in (False, True):
             barrier()
@@ -603,6 +609,7 @@ def main():
             out["backend"] = dist.get_backend()
             out["devices_shared"] = bool(devices_shared)
             out["rccl_context"] = bool(keep.get("rccl_context"))
+            out["row_exchange"] = keep.get("exchange")      # PeerExchange (direct peer writes), RcclContext (ring all-gather) or torch.distributed
             out["loop_in_cluster_order"] = bool(keep.get("loop_order"))
             out["allgather_us"] = allgather_us
             out["allgather_ms_per_fit"] = None if allgather_us is None else allgather_us * args.max_iter * 1e-3
@@ -623,6 +630,9 @@ def main():
 
         dist.barrier()
         RcclContext.destroy_shared()
+        from torchdr_amd.parallel import PeerExchange
+
+        PeerExchange.destroy_shared()
         dist.destroy_process_group()
 
 

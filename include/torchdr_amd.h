@@ -342,6 +342,19 @@ int tdr_umap_sched_grad_step_f32(const float* Z, float* Znext, int64_t n_total, 
                                  const void* hdr, int t_local, int n_slices, float a, float b, int n_iter, int neg_rate, int n_negatives,
                                  uint64_t seed, float exag, float rep, float eps, float* grad, float* acc, int geom, float lr,
                                  float momentum, int first, float* mom_buf, int* nan_flag, int* tickets, void* stream);
+/* Round 4: peer exchange (csrc/tdr_peerx.hip) -- tdr_ctx_allgather_rows's contract without a collective library: every rank
+ * writes its stepped rows into a (fine-grained) staging block of every peer over xGMI, raises a generation flag there, waits
+ * for the flags raised at it and copies the staged rows into its embedding; two launches per exchange.  Peers are mapped
+ * through HIP IPC handles (tdr_peerx_handles -> any transport -> tdr_peerx_open).  world <= 16, one node.
+ * tdr_peerx_allgather_rows has the signature of tdr_umap_loop_desc.gather. */
+int tdr_peerx_create(void** out, int rank, int world, int64_t capacity_floats);
+int tdr_peerx_handles(void* ctx, void* out128);
+int tdr_peerx_open(void* ctx, const void* all_handles);
+int tdr_peerx_set_rows(void* ctx, int64_t n_total);
+int tdr_peerx_fine_grained(void* ctx);
+int tdr_peerx_allgather_rows(void* ctx, float* Z, int nc, void* stream);
+int tdr_peerx_error(void* ctx);
+int tdr_peerx_destroy(void* ctx);
 /* The optimisation loop of affinity_matcher.py:288-352 for UMAP's closed-form step + torch.optim.SGD behind one handle
  * (csrc/tdr_umap_sched.hip): windows of <= block_iters iterations (schedule build + per iteration n_slices gradient
  * passes + the SGD step [+ a row all-gather]) are captured into HIP graphs and replayed; the iteration base lives in

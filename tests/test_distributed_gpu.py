@@ -130,11 +130,29 @@ def _worker(rank, world, port, ret, backend="gloo"):
         Zr = torchdr_amd.UMAP(n_neighbors=12, max_iter=20, random_state=0).fit_transform(X)
         Zs = torchdr_amd.UMAP(n_neighbors=12, max_iter=20, random_state=0, sharded_input=True).fit_transform(X[s:e].clone())
         assert Zs.shape == (n, 2) and torch.equal(Zs, Zr)
+        # --- the peer exchange itself (csrc/tdr_peerx.hip): mapped through HIP IPC (ranks of this test may share the device),
+        #     uneven chunks, several column counts, many generations; and the UMAP fits above went through it
+        from torchdr_amd.parallel import PeerExchange
+
+        px = PeerExchange.shared(n, 2, torch.device("cuda", local))
+        assert px is not None, "peer exchange unavailable (HIP IPC)"
+        assert mu.row_exchange_ == "PeerExchange" and m.row_exchange_ == "PeerExchange", (mu.row_exchange_, m.row_exchange_)
+        for rnd in range(40):
+            nc = 1 + rnd % 3
+            Zx = torch.full((n, nc), float("nan"), device="cuda")
+            Zx[s:e] = torch.arange(s, e, device="cuda", dtype=torch.float32)[:, None] * (rnd + 1) + torch.arange(nc, device="cuda")
+            px.allgather_rows_(Zx)
+            want = torch.arange(n, device="cuda", dtype=torch.float32)[:, None] * (rnd + 1) + torch.arange(nc, device="cuda")
+            assert torch.equal(Zx, want), rnd
+        assert not px.failed()
         ret[rank] = True
     finally:
         from torchdr_amd.parallel import RcclContext
 
         RcclContext.destroy_shared()    # the process's communicator (one per process, shared by every fit)
+        from torchdr_amd.parallel import PeerExchange
+
+        PeerExchange.destroy_shared()
         dist.destroy_process_group()
 
 
@@ -255,6 +273,9 @@ def _worker_rccl_even(rank, world, port, ret):
         from torchdr_amd.parallel import RcclContext
 
         RcclContext.destroy_shared()    # the process's communicator (one per process, shared by every fit)
+        from torchdr_amd.parallel import PeerExchange
+
+        PeerExchange.destroy_shared()
         dist.destroy_process_group()
 
 
@@ -318,8 +339,13 @@ def _worker_c4(rank, world, port, ret):
         assert csr.n == e - s and csr.row_offset == s
         assert torch.equal(csr.rowptr + b0, ref.rowptr[s:e + 1]) and torch.equal(csr.cols, ref.cols[b0:b1])
         assert torch.equal(csr.vals, ref.vals[b0:b1])
-        Zr = torchdr_amd.UMAP(n_neighbors=30, max_iter=60, random_state=0).fit_transform(X)
+        mr = torchdr_amd.UMAP(n_neighbors=30, max_iter=60, random_state=0)
+        Zr = mr.fit_transform(X)
         assert Zr.shape == (n, 2) and bool(torch.isfinite(Zr).all())
+        # eight ranks' rows travelled as direct peer writes (csrc/tdr_peerx.hip, mapped through HIP IPC): still the single-process fit
+        assert mr.row_exchange_ == "PeerExchange", mr.row_exchange_
+        Z1 = torchdr_amd.UMAP(n_neighbors=30, max_iter=60, random_state=0, distributed=False).fit_transform(X)
+        assert torch.equal(Zr, Z1), float((Zr - Z1).abs().max())
         h = Zr.detach().cpu()
         gathered = [torch.empty_like(h) for _ in range(world)]
         dist.all_gather(gathered, h)
@@ -331,6 +357,9 @@ def _worker_c4(rank, world, port, ret):
         from torchdr_amd.parallel import RcclContext
 
         RcclContext.destroy_shared()    # the process's communicator (one per process, shared by every fit)
+        from torchdr_amd.parallel import PeerExchange
+
+        PeerExchange.destroy_shared()
         dist.destroy_process_group()
 
 

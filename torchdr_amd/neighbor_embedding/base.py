@@ -19,6 +19,10 @@ RCCL_CONTEXT = True
 # LargeVis / InfoTSNE on one GPU: negatives drawn as keyed permutations of the rows, both shares of a pair pulled by the rows
 # themselves (tdr_ne_grad_perm_f32: no far-endpoint atomics; csrc/tdr_embed_common.h).  False = the hash sampler + atomics.
 PERM_NEGATIVES = True
+# PEER_EXCHANGE: row-sharded fits exchange the rows they stepped as direct peer writes over xGMI (parallel.PeerExchange,
+# csrc/tdr_peerx.hip) instead of an RCCL ring all-gather; falls back to RCCL / torch.distributed when HIP IPC or the stress
+# self-check fails on any rank.
+PEER_EXCHANGE = True
 
 def _opt(name):
     """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
@@ -251,10 +255,18 @@ class NeighborEmbedding(AffinityMatcher):
             cols = torch.arange(self.n_samples_in_, dtype=torch.int32, device=P.device)
             self._nn_table = cols.unsqueeze(0).expand(P.shape[0], -1).contiguous()
         self._rccl_ctx = None
-        if self.world_size > 1 and _opt("RCCL_CONTEXT") and dist.get_backend() == "nccl" and torch.cuda.is_available():
+        if self.world_size > 1 and _opt("PEER_EXCHANGE") and torch.cuda.is_available() and getattr(self, "_dtype", torch.float32) == torch.float32:
+            # the rows every rank stepped travel as direct peer writes (csrc/tdr_peerx.hip); None when the peers cannot be
+            # mapped or the stress self-check fails on any rank
+            from torchdr_amd.parallel import PeerExchange
+
+            self._rccl_ctx = PeerExchange.shared(self.n_samples_in_, self.n_components, self.device_)
+        if self._rccl_ctx is None and self.world_size > 1 and _opt("RCCL_CONTEXT") and dist.get_backend() == "nccl" and torch.cuda.is_available():
             from torchdr_amd.parallel import RcclContext
 
             self._rccl_ctx = RcclContext.shared(self.n_samples_in_, self.device_)   # one communicator per process
+        # how a row-sharded fit exchanged its rows (kept after clear_memory): "PeerExchange", "RcclContext" or "torch.distributed"
+        self.row_exchange_ = (type(self._rccl_ctx).__name__ if self._rccl_ctx is not None else "torch.distributed") if self.world_size > 1 else None
 
     def clear_memory(self):
         super().clear_memory()

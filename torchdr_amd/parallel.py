@@ -366,3 +366,136 @@ class RcclContext:
         if self.handle is not None:
             _lib.lib().tdr_ctx_destroy(self.handle)
             self.handle = None
+
+
+class PeerExchange:
+    """``tdr_peerx_*`` (csrc/tdr_peerx.hip): the per-iteration all-gather of the rows every rank stepped as direct peer writes
+    over xGMI -- each rank stores its chunk into a staging block of every peer (all links at once), raises a generation flag,
+    waits for the flags raised at it and copies the staged chunks into its embedding -- instead of a ring collective.  Same
+    interface as :class:`RcclContext` for the row exchange (``gather_fn`` / ``handle`` for the C loop object,
+    ``allgather_rows_``).  ``create`` returns None when the peers cannot be mapped (HIP IPC) or the stress self-check fails on
+    ANY rank: callers then keep RCCL / torch.distributed."""
+
+    _shared = {}
+    SELF_CHECK_ROUNDS = 12
+
+    def __init__(self, handle, n_total, capacity):
+        import ctypes
+
+        from torchdr_amd import _lib
+
+        self.handle, self.n_total, self.capacity = handle, n_total, capacity
+        self.gather_fn = ctypes.cast(_lib.lib().tdr_peerx_allgather_rows, ctypes.c_void_p)
+
+    @classmethod
+    def create(cls, n_total: int, nc: int, device):
+        import ctypes
+
+        from torchdr_amd import _lib
+
+        L = _lib.lib()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if world < 2 or world > 16:
+            return None
+        capacity = int(n_total) * max(int(nc), 3)
+        handle = ctypes.c_void_p()
+        ok = True
+        with torch.cuda.device(device):
+            ok = L.tdr_peerx_create(ctypes.byref(handle), rank, world, capacity) == 0
+            mine = ctypes.create_string_buffer(128)
+            ok = ok and L.tdr_peerx_handles(handle, mine) == 0
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (bool(ok), bytes(mine.raw)))
+        if not all(o for o, _ in everyone):
+            if handle.value:
+                L.tdr_peerx_destroy(handle)
+            return None
+        blob = b"".join(h for _, h in everyone)
+        with torch.cuda.device(device):
+            opened = L.tdr_peerx_open(handle, blob) == 0
+        ctx = cls(handle, n_total, capacity)
+        L.tdr_peerx_set_rows(handle, n_total)
+        good = opened and ctx._self_check(device, rank, world)
+        flag = torch.tensor([1.0 if good else 0.0], device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # every rank keeps the exchange or none does
+        if not bool(flag.item() > 0):
+            ctx.destroy()
+            return None
+        return ctx
+
+    def _self_check(self, device, rank, world) -> bool:
+        """Several exchanges of CHANGING patterns through the production kernels (1 / 2 / 3 columns, uneven chunks as they
+        come), every row compared on every rank after every round: what a stale cache line or a lost flag would break."""
+        from torchdr_amd import _lib
+
+        L = _lib.lib()
+        for rnd in range(self.SELF_CHECK_ROUNDS):
+            nc = 1 + rnd % 3
+            Z = torch.full((self.n_total, nc), -1.0, dtype=torch.float32, device=device)
+            s, e = chunk_bounds(self.n_total, rank, world)
+            Z[s:e] = float(1000 * rnd + rank + 1)
+            with torch.cuda.device(device):
+                if L.tdr_peerx_allgather_rows(self.handle, _lib.ptr(Z), nc, _lib.stream_ptr()) != 0:
+                    return False
+            want = torch.empty(self.n_total, dtype=torch.float32, device=device)
+            for r in range(world):
+                a, b = chunk_bounds(self.n_total, r, world)
+                want[a:b] = float(1000 * rnd + r + 1)
+            if not bool((Z == want[:, None]).all()):
+                return False
+        return L.tdr_peerx_error(self.handle) == 0
+
+    @classmethod
+    def shared(cls, n_total: int, nc: int, device):
+        """The process's exchange on `device` for the current process group (created collectively on first use, re-created when
+        an embedding no longer fits its stages); None when unavailable."""
+        from torchdr_amd import _lib
+
+        token = RcclContext._group_token()
+        for k in [k for k in cls._shared if k[3] != token]:
+            cls._shared.pop(k).destroy()
+        key = (torch.device(device).index, dist.get_world_size(), dist.get_rank(), token)
+        ctx = cls._shared.get(key)
+        if ctx is not None and int(n_total) * int(nc) > ctx.capacity:
+            cls._shared.pop(key).destroy()
+            ctx = None
+        if ctx is None:
+            ctx = cls.create(n_total, nc, device)
+            if ctx is None:
+                return None
+            if not cls._shared:
+                import atexit
+
+                atexit.register(cls.destroy_shared)
+            cls._shared[key] = ctx
+        if ctx.n_total != n_total:
+            _lib.check(_lib.lib().tdr_peerx_set_rows(ctx.handle, n_total), "tdr_peerx_set_rows")
+            ctx.n_total = n_total
+        return ctx
+
+    @classmethod
+    def destroy_shared(cls):
+        for ctx in cls._shared.values():
+            ctx.destroy()
+        cls._shared.clear()
+
+    def allgather_rows_(self, Z: torch.Tensor):
+        from torchdr_amd import _lib
+
+        if Z.shape[0] != self.n_total:
+            _lib.check(_lib.lib().tdr_peerx_set_rows(self.handle, Z.shape[0]), "tdr_peerx_set_rows")
+            self.n_total = Z.shape[0]
+        _lib.check(_lib.lib().tdr_peerx_allgather_rows(self.handle, _lib.ptr(Z), Z.shape[1], _lib.stream_ptr()), "tdr_peerx_allgather_rows")
+        return Z
+
+    def failed(self) -> bool:
+        from torchdr_amd import _lib
+
+        return _lib.lib().tdr_peerx_error(self.handle) != 0
+
+    def destroy(self):
+        from torchdr_amd import _lib
+
+        if self.handle is not None:
+            _lib.lib().tdr_peerx_destroy(self.handle)
+            self.handle = None
