@@ -234,6 +234,31 @@ def test_knn_more_neighbours_than_the_scan_lists_hold(metric, k, d):
         assert torch.equal(C.cpu(), Co)
 
 
+@pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean"])
+def test_knn_beyond_1024_neighbours(metric):
+    """k beyond the running top-k kernel's 1024 entries per query (the reference's kmin has no limit, utils/utils.py:203-216):
+    the same exact distance blocks, lists kept by device-side sorts in the canonical (distance, index) order -- bit-identical to
+    the CPU oracle, several database blocks."""
+    import oracle
+    from torchdr_amd.distance import base as dbase
+    from torchdr_amd.distance import pairwise_distances
+
+    X = gmm(2600, 24, 2.0, seed=29)
+    old = dbase._GENERAL_BD
+    dbase._GENERAL_BD = 1024
+    try:
+        C, I = pairwise_distances(X.cuda(), metric=metric, k=1500, exclude_diag=True, return_indices=True)
+    finally:
+        dbase._GENERAL_BD = old
+    assert dbase.LAST_KNN["path"].startswith("dense MFMA blocks + torch sort")
+    Co, Io = oracle.knn(X, 1500, metric, True)
+    assert torch.equal(I.cpu(), Io)
+    if metric == "euclidean":
+        assert torch.allclose(C.cpu(), Co, rtol=2e-7, atol=0)
+    else:
+        assert torch.equal(C.cpu(), Co)
+
+
 def test_knn_large_k_cross_set_ragged_and_chunked():
     """The same path on a cross search with ragged sizes, several query / database blocks and a row-sharded query chunk."""
     import oracle

@@ -989,7 +989,7 @@ def _knn_dense_merge(Q: "PackedPoints", Y: "PackedPoints", q0: int, q1: int, k: 
     dev, d = Y.device, Y.d
     nq, nd = q1 - q0, Y.n
     if k > int(L.tdr_topk_max_k()):
-        raise NotImplementedError(f"[torchdr_amd] k={k} > {int(L.tdr_topk_max_k())} neighbours is not supported by the running top-k kernel.")
+        return _knn_dense_wide(Q, Y, q0, q1, k, metric, exclude_self, q_offset)
     st = _lib.stream_ptr()
     keys = torch.empty((nq, k), dtype=torch.int64, device=dev)
     _lib.check(L.tdr_topk_init(_lib.ptr(keys), nq, k, st), "tdr_topk_init")
@@ -1016,6 +1016,50 @@ def _knn_dense_merge(Q: "PackedPoints", Y: "PackedPoints", q0: int, q1: int, k: 
     out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
     _lib.check(L.tdr_topk_emit_f32(_lib.ptr(keys), nq, k, mid, _lib.ptr(out_d), _lib.ptr(out_i), st), "tdr_topk_emit_f32")
     LAST_KNN["path"], LAST_KNN["flagged"] = "dense MFMA blocks + top-k merge", 0
+    return out_d, out_i
+
+
+def _knn_dense_wide(Q: "PackedPoints", Y: "PackedPoints", q0: int, q1: int, k: int, metric: str, exclude_self: bool, q_offset: int):
+    """k beyond the running top-k kernel's 1024 entries per query (the reference's ``kmin`` has no limit, utils/utils.py:203-216):
+    the SAME exact distance blocks from the dense fp32-MFMA kernel; the running lists are kept by device-side torch sorts in
+    the canonical (distance, index) order -- a side path for very wide requests (1024 queries x 65536 rows per block)."""
+    L = _lib.lib()
+    dev, d = Y.device, Y.d
+    nq, nd = q1 - q0, Y.n
+    st = _lib.stream_ptr()
+    tile = int(L.tdr_packed_floats(32, d))
+    mid = _METRIC_ID[metric]
+    dense_metric = 0 if mid == 1 else mid
+    bq = 1024
+    G = torch.empty((bq, min(_GENERAL_BD, (nd + 31) // 32 * 32)), dtype=torch.float32, device=dev)
+    out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    for c0 in range(0, nq, bq):
+        c1 = min(c0 + bq, nq)
+        run_d = torch.empty((c1 - c0, 0), dtype=torch.float32, device=dev)
+        run_i = torch.empty((c1 - c0, 0), dtype=torch.int32, device=dev)
+        for d0 in range(0, nd, _GENERAL_BD):
+            d1 = min(d0 + _GENERAL_BD, nd)
+            _lib.check(
+                L.tdr_dense_dist_packed_f32(_lib.ptr(Q.data[((q0 + c0) // 32) * tile:]), c1 - c0, 0, _lib.ptr(Y.data[(d0 // 32) * tile:]),
+                                            d1 - d0, d, dense_metric, 0, _DIAG_ADD, _lib.ptr(G), G.stride(0), st),
+                "tdr_dense_dist_packed_f32",
+            )
+            blk = G[: c1 - c0, : d1 - d0]
+            if exclude_self:
+                own = torch.arange(q_offset + q0 + c0, q_offset + q0 + c1, device=dev) - d0
+                hit = (own >= 0) & (own < d1 - d0)
+                rows = torch.nonzero(hit).squeeze(1)
+                blk = blk.clone()
+                blk[rows, own[rows]] = float("inf")
+            cand_d = torch.cat([run_d, blk], 1)
+            cand_i = torch.cat([run_i, torch.arange(d0, d1, dtype=torch.int32, device=dev).expand(c1 - c0, -1)], 1)
+            o = torch.argsort(cand_i, dim=1, stable=True)                 # by index, then (stable) by distance: canonical ties
+            cand_d, cand_i = cand_d.gather(1, o), cand_i.gather(1, o)
+            o = torch.argsort(cand_d, dim=1, stable=True)[:, :k]
+            run_d, run_i = cand_d.gather(1, o), cand_i.gather(1, o)
+        out_d[c0:c1], out_i[c0:c1] = (torch.sqrt(run_d) if mid == 1 else run_d), run_i
+    LAST_KNN["path"], LAST_KNN["flagged"] = "dense MFMA blocks + torch sort (k > 1024)", 0
     return out_d, out_i
 
 
