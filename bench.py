@@ -342,6 +342,9 @@ def main():
                     help="UMAP loop driver: replayed HIP graphs (default), plain launches from the C loop object, or one Python iteration per step")
     ap.add_argument("--replicated-input", action="store_true",
                     help="N > 1: every rank is handed the full block (the reference's calling convention) instead of its row shard")
+    ap.add_argument("--peer-exchange", action="store_true",
+                    help="N > 1: exchange the stepped rows as direct peer writes over HIP IPC (csrc/tdr_peerx.hip) instead of the RCCL "
+                         "all-gather; opt-in between distinct devices (never run there), automatic where ranks share a device")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of CPU work the kNN sample of cpu_baseline may take")
     args = ap.parse_args()
 
@@ -361,6 +364,10 @@ def main():
     from torchdr_amd.distance import base as dbase
     from torchdr_amd.neighbor_embedding import umap as umod
 
+    if args.peer_exchange:
+        from torchdr_amd.neighbor_embedding import base as nbase
+
+        nbase.PEER_EXCHANGE = True
     if args.loop != "auto":
         umod.LOOP_RUNNER = args.loop != "python"
         umod.LOOP_GRAPH = args.loop == "graph"

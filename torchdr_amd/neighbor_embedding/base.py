@@ -21,8 +21,11 @@ RCCL_CONTEXT = True
 PERM_NEGATIVES = True
 # PEER_EXCHANGE: row-sharded fits exchange the rows they stepped as direct peer writes over xGMI (parallel.PeerExchange,
 # csrc/tdr_peerx.hip) instead of an RCCL ring all-gather; falls back to RCCL / torch.distributed when HIP IPC or the stress
-# self-check fails on any rank.
-PEER_EXCHANGE = True
+# self-check fails on any rank.  True: always try; False: never; "auto": only where ranks SHARE a device (more ranks than GPUs:
+# the configurations this build could test -- there it replaces host-staged collectives).  Between distinct devices the path has
+# never run: a wrong assumption about peer mappings would be a memory fault, not a failed self-check, so it is opt-in there
+# (`bench.py --peer-exchange`, `config.options(PEER_EXCHANGE=True)`) until it has been seen on an 8-GPU node.
+PEER_EXCHANGE = "auto"
 
 def _opt(name):
     """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
@@ -255,7 +258,10 @@ class NeighborEmbedding(AffinityMatcher):
             cols = torch.arange(self.n_samples_in_, dtype=torch.int32, device=P.device)
             self._nn_table = cols.unsqueeze(0).expand(P.shape[0], -1).contiguous()
         self._rccl_ctx = None
-        if self.world_size > 1 and _opt("PEER_EXCHANGE") and torch.cuda.is_available() and getattr(self, "_dtype", torch.float32) == torch.float32:
+        px = _opt("PEER_EXCHANGE")
+        if px == "auto":
+            px = torch.cuda.is_available() and self.world_size > torch.cuda.device_count()
+        if self.world_size > 1 and px and torch.cuda.is_available() and getattr(self, "_dtype", torch.float32) == torch.float32:
             # the rows every rank stepped travel as direct peer writes (csrc/tdr_peerx.hip); None when the peers cannot be
             # mapped or the stress self-check fails on any rank
             from torchdr_amd.parallel import PeerExchange
