@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(256) void umap_sched_combine_sgd_kernel(const float
     for (int c = 0; c < NC; ++c) {
         const int64_t i = r * NC + c;
         float g = exag * fminf(fmaxf(ga[c], -4.f), 4.f) + rep * fminf(fmaxf(gr[c], -4.f), 4.f);
-        grad[i] = g;
+        if (grad) grad[i] = g;      // NULL where nobody reads the gradient of this iteration (8 of the pass's 56 MB at N = 1M)
         if (momentum != 0.f) {
             const float bprev = first ? 0.f : buf[i];
             g = first ? g : __fadd_rn(__fmul_rn(bprev, momentum), g);
@@ -1572,10 +1572,11 @@ int tdr_umap_sched_grad_step_f32(const float* Z, float* Znext, int64_t n_total, 
  * torch.optim.SGD(momentum) step of tdr_sgd_step_f32 on the rows Z (n_rows, nc) -- one kernel, same bits as the two. */
 int tdr_umap_sched_step_f32(const float* acc, int n_slices, int nc, int64_t n_rows, float exag, float rep, float* grad, float* Z,
                             float* buf, float lr, float momentum, int first, int* nan_flag, int n_iter, void* stream) {
-    if (!acc || !grad || !Z || !nan_flag || n_rows <= 0) return TDR_ERR_BAD_ARG;
+    if (!acc || !Z || !nan_flag || n_rows <= 0) return TDR_ERR_BAD_ARG;
     if (n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
     if (momentum != 0.f && !buf) return TDR_ERR_BAD_ARG;
     if (nc < 1 || nc > SCHED_NC_MAX) return TDR_ERR_UNSUPPORTED;
+    if (!grad && nc != 2 && nc != 3) return TDR_ERR_BAD_ARG;     // the elementwise form always writes the gradient
     const dim3 grid((unsigned)((n_rows + 255) / 256));
     if (nc != 2 && nc != 3) {
         hipLaunchKernelGGL(umap_sched_combine_any_kernel, dim3((unsigned)((n_rows * nc + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc,

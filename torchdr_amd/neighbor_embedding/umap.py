@@ -16,6 +16,7 @@ from torchdr_amd.utils.sparse import CSRAffinity
 # stream); None = no instrumentation.
 PROFILE = None
 PROFILE_EVERY = 25
+PROFILE_KEEP_GRAD = False     # True: the fused combine + step kernel writes the gradient at every iteration (debugging)
 
 # scheduled loop (csrc/tdr_umap_sched.hip): the epoch counters are advanced SCHED_BLOCK_ITERS iterations at a time and
 # the gradient kernel reads per-iteration lists of the edges that fire.  SCHEDULED = False selects the per-step kernel
@@ -450,9 +451,12 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         first = 0
         if mom != 0.0 and self._momentum_buf is None:
             self._momentum_buf, first = torch.empty_like(Z), 1
+        # the gradient itself is read at the inspected iterations only (`_grad_norm`, every check_interval-th, and by the
+        # hooks of subclasses, which never get here): elsewhere the pass does not write it
+        want_grad = self.n_components not in (2, 3) or int(self.n_iter_) % max(int(self.check_interval), 1) == 0 or PROFILE_KEEP_GRAD
         _lib.check(
             _lib.lib().tdr_umap_sched_step_f32(_lib.ptr(sc["acc"]), sc["S"], self.n_components, self.chunk_size_,
-                                               float(self.early_exaggeration_coeff_), float(self.repulsion_strength), _lib.ptr(grad),
+                                               float(self.early_exaggeration_coeff_), float(self.repulsion_strength), _lib.ptr(grad if want_grad else None),
                                                _lib.ptr(Z), _lib.ptr(self._momentum_buf), self._current_lr(), mom, first,
                                                _lib.ptr(self._nan_flag), int(self.n_iter_), _lib.stream_ptr()),
             "tdr_umap_sched_step_f32",
