@@ -37,8 +37,10 @@ LOOP_GRAPH = True
 LOOP_PROFILE = None
 SCHED_BLOCK_ITERS = 32
 # bit 6: the gradient kernel deals the 64 rows of a workgroup to its row groups in order of their active counts (a wavefront
-# runs as many rounds as its busiest row)
-SCHED_GEOM = 16 | 64
+# runs as many rounds as its busiest row): worth 5 % in round 2 (0.287 -> 0.274 ms), nothing since -- round 4, same box, whole
+# fits: 355.2 ms with it, 352.2 ms without (its three barriers, the LDS histogram and the partial-line plane writes now cost what
+# the saved rounds return).  Off; same gradient bit for bit either way.
+SCHED_GEOM = 16
 SCHED_SLICES = 0
 # RELABEL: when the kNN stage worked in a cluster-sorted row order (pruned search) and nothing outside this class looks at
 # rows during the optimisation (stock hooks, one GPU, no neighbour exclusion), the loop numbers the points in that order --
