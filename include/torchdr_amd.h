@@ -246,6 +246,11 @@ int tdr_indexed_sqdist_f64(const double* X, int64_t nx, int d, const double* Y, 
                            const int64_t* keys, double* out, void* stream);
 int tdr_sym_values_f64(const int64_t* rowptr, const int32_t* cols, int64_t n, const int32_t* nn, const double* P, int k,
                        int64_t row_offset, int mode, double* vals, void* stream);
+/* the same for one rank's rows of a row-sharded graph (utils/sparse.py:209-342): transposed entries from other ranks as a CSR
+ * over the local rows (ext_rowptr (n + 1), ext_col = global source row, ext_val) */
+int tdr_sym_values_ext_f64(const int64_t* rowptr, const int32_t* cols, int64_t n, const int32_t* nn, const double* P, int k,
+                           int64_t row_offset, int mode, const int64_t* ext_rowptr, const int32_t* ext_col, const double* ext_val,
+                           double* vals, void* stream);
 
 /* ---- K0: the steps either side of the path inside fit_transform (csrc/tdr_prep.hip) ---------------------------- */
 /* utils/validation.py:308 (torch.isfinite(X).all()): *count (device uint64, caller-zeroed) += number of inf / nan entries */

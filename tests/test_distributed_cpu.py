@@ -45,6 +45,11 @@ def _worker(rank, world, port, n_rows, ret):
         exp = sorted(zip((jj[m] - s).tolist(), ii[m].tolist(), vv[m].tolist()))
         got = sorted(zip(er.tolist(), ec.tolist(), ev.tolist()))
         assert got == exp, f"rank {rank}: routed edges differ"
+        # float64 graph (float64 input, round 4): the values travel in float64, not through a float32 buffer
+        P64 = P.double() * (1.0 + 2.0 ** -40)
+        er64, ec64, ev64 = exchange_transposed_edges(P64[s:e], I[s:e], s, n_rows, world)
+        assert ev64.dtype == torch.float64
+        assert sorted(zip(er64.tolist(), ec64.tolist(), ev64.tolist())) == sorted(zip((jj[m] - s).tolist(), ii[m].tolist(), P64.reshape(-1)[m].tolist()))
         # all-gather of uneven row chunks reassembles the full matrix
         full = torch.arange(n_rows * 2, dtype=torch.float32).reshape(n_rows, 2)
         out = allgather_rows(full[s:e].clone(), n_rows, world)

@@ -130,6 +130,37 @@ def _worker(rank, world, port, ret, backend="gloo"):
         Zr = torchdr_amd.UMAP(n_neighbors=12, max_iter=20, random_state=0).fit_transform(X)
         Zs = torchdr_amd.UMAP(n_neighbors=12, max_iter=20, random_state=0, sharded_input=True).fit_transform(X[s:e].clone())
         assert Zs.shape == (n, 2) and torch.equal(Zs, Zr)
+        # --- float64 input, row-sharded (round 4): float64 chunked search, float64 transposed edges, float64 loop.  The graph rows
+        #     are the single-process float64 graph's, bit for bit; the UMAP fit (sampler keyed by global row) likewise; the
+        #     estimators with a reduction over ranks agree to float64 rounding
+        X64 = X.double()
+        c64 = UMAPAffinity(n_neighbors=12, max_iter=100)(X64, return_csr=True)
+        r64 = UMAPAffinity(n_neighbors=12, max_iter=100, distributed=False)(X64, return_csr=True)
+        assert c64.vals.dtype == torch.float64 and r64.vals.dtype == torch.float64
+        b0, b1 = int(r64.rowptr[s]), int(r64.rowptr[e])
+        assert torch.equal(c64.rowptr + b0, r64.rowptr[s:e + 1]) and torch.equal(c64.cols, r64.cols[b0:b1])
+        assert torch.equal(c64.vals, r64.vals[b0:b1]), float((c64.vals - r64.vals[b0:b1]).abs().max())
+        assert float((c64.vals - c64.vals.float().double()).abs().max()) > 0      # float64 values, not widened float32 ones
+        for cls, kw in ((torchdr_amd.UMAP, dict(n_neighbors=12, max_iter=40)),
+                        (torchdr_amd.LargeVis, dict(perplexity=6, max_iter=25)),
+                        (torchdr_amd.TSNE, dict(perplexity=6, max_iter=25)),
+                        (torchdr_amd.SNE, dict(perplexity=6, max_iter=25)),
+                        (torchdr_amd.InfoTSNE, dict(perplexity=6, max_iter=25, n_negatives=30))):
+            m64 = cls(random_state=0, **kw)
+            Z64 = m64.fit_transform(X64)
+            assert Z64.dtype == torch.float64 and torch.isfinite(Z64).all() and m64._dtype == torch.float64, cls.__name__
+            h = Z64.detach().cpu()
+            gathered = [torch.empty_like(h) for _ in range(world)]
+            dist.all_gather(gathered, h)
+            assert torch.equal(gathered[0], gathered[1]), f"{cls.__name__} float64: ranks diverged"
+            Z1 = cls(random_state=0, distributed=False, **kw).fit_transform(X64)
+            if cls is torchdr_amd.UMAP:
+                assert torch.equal(Z64, Z1), float((Z64 - Z1).abs().max())
+            elif cls in (torchdr_amd.TSNE, torchdr_amd.SNE):
+                # no sampling: the single-process fit up to the bandwidth search's own tolerance (1e-6 on the entropy; the
+                # row-sharded search starts from a wider bracket -- no global bounds -- and stops at another point inside it)
+                assert float((Z64 - Z1).abs().max()) <= 1e-4 * float(Z1.abs().max()), (cls.__name__, float((Z64 - Z1).abs().max()), float(Z1.abs().max()))
+            assert float((Z64 - Z64.float().double()).abs().max()) > 0, cls.__name__     # computed in float64
         # --- the peer exchange itself (csrc/tdr_peerx.hip): mapped through HIP IPC (ranks of this test may share the device),
         #     uneven chunks, several column counts, many generations; and the UMAP fits above went through it
         from torchdr_amd.parallel import PeerExchange

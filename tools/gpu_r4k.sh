@@ -1,6 +1,6 @@
 #!/bin/bash
 export TMPDIR=/tmp
-for g in 16 80; do
+for g in 16 17 19; do
 TDR_GEOM=$g timeout 600 python - <<'PY' 2>&1 | tail -1
 import os, sys, json, io, contextlib, runpy
 from torchdr_amd.neighbor_embedding import umap as U

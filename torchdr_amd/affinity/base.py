@@ -46,7 +46,8 @@ class Affinity(nn.Module):
             X = to_torch(X)
         # float64 inputs keep their dtype where the float64 kernels cover the affinity (kNN-sparse entropic / UMAP
         # affinities, csrc/tdr_f64.hip), as the reference computes in its input's dtype; everything else runs in float32
-        if X.dtype == torch.float64 and getattr(self, "_float64_kernels", False) and not getattr(self, "is_multi_gpu", False):
+        # (row-sharded too: the float64 search takes the rank's chunk of queries, the transposed edges travel in float64)
+        if X.dtype == torch.float64 and getattr(self, "_float64_kernels", False):
             return X.to(compute_device(X, self.device))
         return as_float32(X).to(compute_device(X, self.device))
 

@@ -269,7 +269,10 @@ class AffinityMatcher(DRModule):
             self._sgd_kernel(rows, grad, chunk=True)
             ctx = getattr(self, "_rccl_ctx", None)
             if ctx is not None:
-                ctx.allgather_rows_(self.embedding_)   # on-stream RCCL through the C library
+                # on-stream RCCL through the C library; the context moves rows of floats, a float64 embedding goes through
+                # as twice as many float columns (a byte copy either way)
+                Z = self.embedding_
+                ctx.allgather_rows_(Z.view(torch.float32) if Z.dtype == torch.float64 else Z)
             else:
                 allgather_rows_(self.embedding_, c0, self.chunk_size_, world)
             self._lr_pos += 1

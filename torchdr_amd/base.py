@@ -90,10 +90,10 @@ class DRModule(BaseEstimator, nn.Module, ABC):
         """Fit and return the embedding.  Duplicate rows are embedded once and re-expanded
         (reference base.py:132-148)."""
         in_dtype = X.dtype
-        # float64 in: estimators with float64 kernels for the whole path (`_float64_loop`: UMAP, LargeVis, TSNE, InfoTSNE;
-        # single process, D <= 256) compute in float64 like the reference (which computes in its input's dtype); the
-        # others compute in float32 and hand float64 back
-        if not (X.dtype == torch.float64 and getattr(self, "_float64_loop", False) and self._float64_ok(X) and getattr(self, "world_size", 1) == 1
+        # float64 in: estimators with float64 kernels for the whole path (`_float64_loop`: UMAP, LargeVis, TSNE, InfoTSNE, SNE,
+        # PaCMAP; D <= 256; single process or row-sharded) compute in float64 like the reference (which computes in its
+        # input's dtype); the others compute in float32 and hand float64 back
+        if not (X.dtype == torch.float64 and getattr(self, "_float64_loop", False) and self._float64_ok(X)
                 and X.dim() == 2 and X.shape[1] <= 256 and getattr(self, "metric", "sqeuclidean") in ("sqeuclidean", "euclidean", "angular")):
             X = as_float32(X)
         if getattr(self, "sharded_input", False) and getattr(self, "world_size", 1) > 1:

@@ -279,7 +279,9 @@ __global__ __launch_bounds__(256) void indexed_sqdist_f64_kernel(const double* _
 // CSR row i gets P_ij + P_ji - P_ij P_ji (mode 0) or P_ij + P_ji (mode 1), duplicates of a column summed as scatter_add does
 __global__ __launch_bounds__(256) void sym_values_f64_kernel(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                              int64_t n, const int32_t* __restrict__ nn, const double* __restrict__ P,
-                                                             int k, int64_t row_offset, int mode, double* __restrict__ vals) {
+                                                             int k, int64_t row_offset, int mode, const int64_t* __restrict__ ext_rowptr,
+                                                             const int32_t* __restrict__ ext_col, const double* __restrict__ ext_val,
+                                                             double* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= n) return;
@@ -289,8 +291,11 @@ __global__ __launch_bounds__(256) void sym_values_f64_kernel(const int64_t* __re
         double pij = 0.0, pji = 0.0;
         for (int t = 0; t < k; ++t) if (nn[i * k + t] == j) pij += P[i * k + t];
         const int64_t lj = j - row_offset;
-        if (lj >= 0 && lj < n)
+        if (lj >= 0 && lj < n) {
             for (int t = 0; t < k; ++t) if (nn[lj * k + t] == gi) pji += P[lj * k + t];
+        } else if (ext_rowptr) {     // row j lives on another rank: its edge j -> i arrived as a transposed entry of row i
+            for (int64_t t = ext_rowptr[i]; t < ext_rowptr[i + 1]; ++t) if (ext_col[t] == j) pji += ext_val[t];
+        }
         vals[e] = mode == 0 ? (pij + pji) - pij * pji : pij + pji;
     }
 }
@@ -389,7 +394,21 @@ int tdr_sym_values_f64(const int64_t* rowptr, const int32_t* cols, int64_t n, co
                        int64_t row_offset, int mode, double* vals, void* stream) {
     if (!rowptr || !cols || !nn || !P || !vals || n <= 0 || k <= 0 || mode < 0 || mode > 1) return TDR_ERR_BAD_ARG;
     hipLaunchKernelGGL(sym_values_f64_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowptr, cols, n, nn, P, k,
-                       row_offset, mode, vals);
+                       row_offset, mode, (const int64_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, vals);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* The same for one rank's rows of a row-sharded graph (utils/sparse.py:209-342): the transposed entries whose source row
+ * lives on another rank come as a CSR over the LOCAL rows (ext_rowptr (n + 1), ext_col global source row, ext_val = P of
+ * that edge), as parallel.exchange_transposed_edges delivers them once sorted by row. */
+int tdr_sym_values_ext_f64(const int64_t* rowptr, const int32_t* cols, int64_t n, const int32_t* nn, const double* P, int k,
+                           int64_t row_offset, int mode, const int64_t* ext_rowptr, const int32_t* ext_col, const double* ext_val,
+                           double* vals, void* stream) {
+    if (!rowptr || !cols || !nn || !P || !vals || n <= 0 || k <= 0 || mode < 0 || mode > 1) return TDR_ERR_BAD_ARG;
+    if (!ext_rowptr || !ext_col || !ext_val) return TDR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(sym_values_f64_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, rowptr, cols, n, nn, P, k,
+                       row_offset, mode, ext_rowptr, ext_col, ext_val, vals);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

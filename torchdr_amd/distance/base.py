@@ -877,12 +877,35 @@ _F64_METRIC = {"sqeuclidean": 0, "euclidean": 1, "angular": 2}
 def _pairwise_f64(X, Y, metric, exclude_diag, k, return_indices, device, distributed_ctx):
     """float64 inputs on the float64 kernels (``tdr_knn_f64``: fp64 matrix pipe + in-kernel top-k, or the dense matrix),
     as the reference computes in the dtype of its input.  Returns NotImplemented when no float64 kernel covers the call."""
-    if metric not in _F64_METRIC or X.shape[1] > 256 or (distributed_ctx is not None and distributed_ctx.is_initialized):
+    if metric not in _F64_METRIC or X.shape[1] > 256:
         return NotImplemented
+    sharded = distributed_ctx is not None and distributed_ctx.is_initialized
+    if sharded and (k is None or Y is not None):
+        return NotImplemented     # the float32 path raises the reference's errors for these (base.py:160-175)
     L = _lib.lib()
     X = _to_device(X, device)
     _lib.require_gpu(X, "X")
     self_search = Y is None
+    if sharded:
+        # row-sharded (base.py:160-211): queries = this rank's chunk, database = all rows; the kernel excludes the
+        # query's own row by its global index (q_global0)
+        n_all = X.shape[0]
+        c0, c1 = distributed_ctx.compute_chunk_bounds(n_all)
+        kk = int(k)
+        if kk > n_all - (1 if exclude_diag else 0) or L.tdr_knn_f64_lds_bytes(X.shape[1], kk) == 0:
+            return NotImplemented
+        Xc = X if X.stride(1) == 1 else X.contiguous()
+        Q = Xc[c0:c1]
+        ws = torch.empty((c1 - c0) + n_all, dtype=torch.float64, device=Xc.device)
+        out_d = torch.empty((c1 - c0, kk), dtype=torch.float64, device=Xc.device)
+        out_i = torch.empty((c1 - c0, kk), dtype=torch.int32, device=Xc.device)
+        _lib.check(
+            L.tdr_knn_f64(_lib.ptr(Q), c1 - c0, Q.stride(0), c0, _lib.ptr(Xc), n_all, Xc.stride(0), X.shape[1], kk, _F64_METRIC[metric],
+                          1 if exclude_diag else 0, _DIAG_ADD, _lib.ptr(out_d), _lib.ptr(out_i), kk, _lib.ptr(ws), _lib.stream_ptr()),
+            "tdr_knn_f64",
+        )
+        LAST_KNN["path"], LAST_KNN["flagged"] = "f64", 0
+        return (out_d, out_i) if return_indices else out_d
     Yd = X if self_search else _to_device(Y, device).to(torch.float64)
     if X.shape[1] != Yd.shape[1]:
         raise ValueError("[TorchDR] ERROR : X and Y must have the same number of features.")

@@ -121,7 +121,7 @@ def route_edges(values: torch.Tensor, indices: torch.Tensor, chunk_start: int, n
 
 def exchange_transposed_edges(values, indices, chunk_start, n_total, world_size) -> Tuple[torch.Tensor, ...]:
     """All-to-all-v of the edges whose transpose lives on another rank (reference sparse.py:259-309).
-    Returns (ext_row int32 local, ext_col int32 global, ext_val fp32) for ``symmetrize_to_csr``."""
+    Returns (ext_row int32 local, ext_col int32 global, ext_val in the dtype of ``values``) for ``symmetrize_to_csr``."""
     rank = dist.get_rank()
     dev = values.device
     routed = route_edges(values, indices, chunk_start, n_total, world_size, rank)
@@ -134,11 +134,11 @@ def exchange_transposed_edges(values, indices, chunk_start, n_total, world_size)
         parts = [p[idx] for p in routed if p is not None and p[idx].numel() > 0]
         return torch.cat(parts) if parts else torch.empty(0, dtype=dtype, device=dev)
 
-    send_src, send_dst, send_v = cat(0, torch.int32), cat(1, torch.int32), cat(2, torch.float32)
+    send_src, send_dst, send_v = cat(0, torch.int32), cat(1, torch.int32), cat(2, values.dtype)
     total = int(sum(rc))
     recv_src = torch.empty(total, dtype=torch.int32, device=dev)
     recv_dst = torch.empty(total, dtype=torch.int32, device=dev)
-    recv_v = torch.empty(total, dtype=torch.float32, device=dev)
+    recv_v = torch.empty(total, dtype=values.dtype, device=dev)      # float32, or float64 on the float64 path
     _all_to_all_single(recv_src, send_src, rc, sc)
     _all_to_all_single(recv_dst, send_dst, rc, sc)
     _all_to_all_single(recv_v, send_v, rc, sc)

@@ -98,12 +98,22 @@ def symmetrize_to_csr(values, indices, mode="sum_minus_prod", row_offset=0, n_to
     )
     if values.dtype == torch.float64:
         # float64 input: the pattern above came from float(values); the float64 values P + P^T - P o P^T are evaluated on
-        # it from the float64 block (tdr_sym_values_f64).  Row-sharded runs carry float32 transposed edges: float32 only.
-        if n_ext:
-            raise NotImplementedError("[torchdr_amd] float64 symmetrisation is single-process.")
+        # it from the float64 block (tdr_sym_values_f64).  Row-sharded: the transposed entries received from the other ranks
+        # (float64, parallel.exchange_transposed_edges) enter as a CSR over the local rows (tdr_sym_values_ext_f64).
         v64 = torch.empty(nnz, dtype=torch.float64, device=dev)
-        _lib.check(L.tdr_sym_values_f64(_lib.ptr(rowptr), _lib.ptr(ocols), n, _lib.ptr(cols), _lib.ptr(values.contiguous()), k, row_offset,
-                                        _MODE[mode], _lib.ptr(v64), st), "tdr_sym_values_f64")
+        if n_ext:
+            if ext[2].dtype != torch.float64:
+                raise ValueError("[torchdr_amd] float64 symmetrisation needs the transposed entries in float64.")
+            order = torch.argsort(er.long(), stable=True)
+            e_ptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            e_ptr[1:] = torch.bincount(er.long(), minlength=n).cumsum(0)
+            e_col, e_val = ec[order].contiguous(), ext[2][order].contiguous()
+            _lib.check(L.tdr_sym_values_ext_f64(_lib.ptr(rowptr), _lib.ptr(ocols), n, _lib.ptr(cols), _lib.ptr(values.contiguous()), k,
+                                                row_offset, _MODE[mode], _lib.ptr(e_ptr), _lib.ptr(e_col), _lib.ptr(e_val), _lib.ptr(v64), st),
+                       "tdr_sym_values_ext_f64")
+        else:
+            _lib.check(L.tdr_sym_values_f64(_lib.ptr(rowptr), _lib.ptr(ocols), n, _lib.ptr(cols), _lib.ptr(values.contiguous()), k, row_offset,
+                                            _MODE[mode], _lib.ptr(v64), st), "tdr_sym_values_f64")
         ovals = v64
     return CSRAffinity(rowptr, ocols, ovals, row_offset=row_offset, n_total=n_total if n_total else n)
 
