@@ -567,8 +567,10 @@ def main():
     roof_grad = {
         "kernel": ("one whole UMAP iteration: tdr::umap_sched_grad_kernel<2,4,false> (ONE launch over both L2 slices of the embedding, "
                    "slices spread over the XCDs) + tdr::umap_sched_combine_sgd_kernel (clamps + SGD step) -- HIP events around "
-                   "every 25th iteration's two launches -- + 1/32 of tdr::umap_sched_build2_kernel (group-ordered schedule build, "
-                   "every build timed)" if umod.SCHEDULED else
+                   "every 25th iteration's two launches -- + 1/32 of tdr::umap_sched_build2_kernel (group-ordered schedule build; "
+                   + ("built one window AHEAD on a side stream, concurrent with the launches: its time is inside the sampled "
+                      "iterations, which cover every position of a window" if getattr(umod, "BUILD_AHEAD", False) else "every build timed")
+                   + ")" if umod.SCHEDULED else
                    "tdr::umap_grad_kernel<2,16,4,true> + 2 x tdr::umap_neg_dense_kernel<2,8,2> (one gradient evaluation)"),
         "bound": "hbm", "achieved": grad_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_gbs / HBM_PEAK_GBS,
         "traffic": pmc_traffic("r04_umap_sched_pmc.json" if umod.SCHEDULED else "r01_umap_grad_pmc.json"),

@@ -821,3 +821,39 @@ def test_step_inside_the_gradient_launch_equals_the_two_kernel_form(S, momentum)
     assert L.tdr_umap_sched_grad_step_f32(_lib.ptr(Z0), _lib.ptr(Z0), n, 0, n, _lib.ptr(sc.list), _lib.ptr(sc.hdr), 0, S, 1.577, 0.895, 0, 5, 150,
                                           99, 1.0, 1.0, 1e-3, None, _lib.ptr(sc.acc), 0, 0.3, 0.0, 0, None, _lib.ptr(flag), _lib.ptr(tickets),
                                           _lib.stream_ptr()) == -1
+
+
+@pytest.mark.parametrize("max_iter", [100, 75])
+def test_windows_built_ahead_on_the_side_stream_change_nothing(max_iter):
+    """BUILD_AHEAD: the lists of window w + 1 are built on a side stream, into a second buffer, while the gradient launches of
+    window w run.  The fit and the epoch counters it leaves are those of the in-place build; a ragged last window
+    (75 = 2 x 32 + 11) is covered.  Subclasses that hook into the loop keep the in-place build."""
+    import torchdr_amd
+    from torchdr_amd.neighbor_embedding import umap as umod
+
+    X = gmm(20_000, 16, 3.0, seed=5).cuda()
+    out = {}
+    for ahead in (False, True):
+        umod.BUILD_AHEAD = ahead
+        try:
+            m = torchdr_amd.UMAP(n_neighbors=10, max_iter=max_iter, random_state=0, check_interval=10_000)
+            # keep the loop's state after the fit
+            m.clear_memory = lambda: None
+            Z = m.fit_transform(X)
+            sc = m._sched
+            assert ("list2" in sc) == ahead
+            out[ahead] = (Z.clone(), m.epoch_of_next_sample.clone())
+        finally:
+            umod.BUILD_AHEAD = True
+    assert torch.equal(out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])
+
+    # a subclass that hooks into the loop may look at the counters: it keeps the in-place build (no second buffer)
+    class Hooked(torchdr_amd.UMAP):
+        def on_training_step_end(self):
+            super().on_training_step_end()
+
+    mh = Hooked(n_neighbors=10, max_iter=40, random_state=0, check_interval=10_000)
+    mh.clear_memory = lambda: None
+    mh.fit_transform(X)
+    assert "list2" not in mh._sched

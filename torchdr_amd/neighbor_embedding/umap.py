@@ -56,6 +56,11 @@ RELABEL = True
 # row-major order when it is read.  False: the row-chunk kernel of rounds 2-3 (tdr_umap_sched_build_f32).
 GROUPED = True
 SCHED_STAGE = 0      # LDS stage entries of the grouped build (0 = library default)
+# BUILD_AHEAD: the firing lists of window w + 1 depend on the epoch counters alone (the gradient launches never touch them), so
+# they are built on a SIDE stream into a second list / record buffer while the gradient launches of window w run: the build
+# fills the ramps and tails between the ~64 launches of a window instead of stopping the loop for a millisecond.  Same lists,
+# same order of everything that enters a result (tests/test_umap_sched_gpu.py); costs a second copy of the lists and records.
+BUILD_AHEAD = True
 # FUSE_STEP: stock estimator, one GPU, n_components = 2, more than one L2 slice: the combine + SGD step run INSIDE the joint
 # gradient launch (tdr_umap_sched_grad_step_f32: the last-arriving slice workgroup of every 64-row block finishes its rows)
 # instead of in a second kernel (tdr_umap_sched_step_f32).  The stepped rows land in a second embedding buffer (the first is
@@ -71,6 +76,12 @@ def _opt(name):
 
     return config.get(name, globals())
 
+
+
+def _stock_start():
+    from torchdr_amd.neighbor_embedding.base import NegativeSamplingNeighborEmbedding
+
+    return NegativeSamplingNeighborEmbedding.on_training_step_start
 
 
 def find_ab_params(spread, min_dist):
@@ -142,6 +153,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             raise AttributeError("epoch_of_next_sample")
         g = self.__dict__.get("_g")
         if g is not None and g["dirty"]:
+            self._join_build_ahead()      # a window being built ahead on the side stream is advancing the counters
             _lib.check(_lib.lib().tdr_umap_sched_ungroup_f32(_lib.ptr(self._csr_loop.rowptr), _lib.ptr(g["order"]), _lib.ptr(g["next"]),
                                                               self._csr_loop.n, _lib.ptr(self._next_rm), _lib.stream_ptr()),
                        "tdr_umap_sched_ungroup_f32")
@@ -153,6 +165,9 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         self._next_rm = value
         if self.__dict__.get("_g") is not None:   # a caller replaced the counters: the grouped copy follows
             g = self._g
+            self._join_build_ahead()
+            if self.__dict__.get("_sched"):
+                self._sched.pop("ahead", None)     # lists built ahead belong to the old counters: the next window is built in place
             g0 = self._csr_loop.rowptr[:-1:16]
             e0 = torch.repeat_interleave(g0, torch.cat([g0[1:], self._csr_loop.rowptr[-1:]]) - g0)
             g["next"] = value[e0 + g["order"].long()].contiguous()
@@ -161,6 +176,13 @@ class UMAP(NegativeSamplingNeighborEmbedding):
     @epoch_of_next_sample.deleter
     def epoch_of_next_sample(self):
         self.__dict__.pop("_next_rm", None)
+
+    def _join_build_ahead(self):
+        """Order the current stream after a schedule build that is still running on the side stream (BUILD_AHEAD)."""
+        sc = self.__dict__.get("_sched")
+        ah = sc.get("ahead") if sc else None
+        if ah is not None:
+            torch.cuda.current_stream(self.device_).wait_event(ah["done"])
 
     def _sched_slices(self) -> int:
         return int(_opt("SCHED_SLICES")) or int(_lib.lib().tdr_umap_sched_slices(self.n_samples_in_, self.n_components))
@@ -234,6 +256,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
     def on_affinity_computation_end(self):
         # plans and buffers of a previous fit (kept until clear_memory, which a fit that raised never reached) are sized
         # for THAT graph: never reuse them
+        self._join_build_ahead()
         self._sched, self._grad_buf, self._sched_deferred, self._grad_ws, self._g, self._sched_stepped = None, None, False, None, None, False
         super().on_affinity_computation_end()
         csr: CSRAffinity = self._relabel()
@@ -346,19 +369,31 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         t = int(self.n_iter_)
         if sc["t0"] is None or not (sc["t0"] <= t < sc["t0"] + sc["n"]):
             n = max(1, min(sc["B"], int(self.max_iter) - t))
+            g = getattr(self, "_g", None)
+            ah = sc.pop("ahead", None)
+            cur = torch.cuda.current_stream(self.device_)
+            if ah is not None:
+                cur.wait_event(ah["done"])
             if PROFILE is not None:
                 eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 eb0.record()
-            g = getattr(self, "_g", None)
-            if g is not None:
+
+            def build_groups(t_w, n_w, lst, hdr):
                 _lib.check(
                     L.tdr_umap_sched_build_groups_f32(_lib.ptr(csr.rowptr), _lib.ptr(g["cols"]), _lib.ptr(g["eps"]), _lib.ptr(g["rs"]),
-                                                      _lib.ptr(g["next"]), self.chunk_size_, t, n, sc["S"], _lib.ptr(sc["blk_base"]),
-                                                      _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), _lib.ptr(sc["err"]),
+                                                      _lib.ptr(g["next"]), self.chunk_size_, t_w, n_w, sc["S"], _lib.ptr(sc["blk_base"]),
+                                                      _lib.ptr(lst), _lib.ptr(hdr), _lib.ptr(sc["err"]),
                                                       int(_opt("SCHED_STAGE")), _lib.stream_ptr()),
                     "tdr_umap_sched_build_groups_f32",
                 )
                 g["dirty"] = True
+
+            if g is not None and ah is not None and ah["t0"] == t and ah["n"] == n:
+                # this window was built ahead, into the second buffer: the two swap roles
+                sc["list"], sc["list2"] = sc["list2"], sc["list"]
+                sc["hdr"], sc["hdr2"] = sc["hdr2"], sc["hdr"]
+            elif g is not None:
+                build_groups(t, n, sc["list"], sc["hdr"])
             else:
                 _lib.check(
                     L.tdr_umap_sched_build_f32(_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
@@ -371,6 +406,25 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                 eb1.record()
                 PROFILE.append(("build", eb0, eb1, n))
             sc["t0"], sc["n"] = t, n
+            t_next = t + n
+            # (stock estimators only: a subclass that hooks into the loop may look at the epoch counters, which a window built
+            # ahead has already advanced past the end of the NEXT window)
+            if (g is not None and _opt("BUILD_AHEAD") and t_next < int(self.max_iter) and not getattr(self, "_loop_graph", False)
+                    and self._stock_step() and type(self).on_training_step_start is _stock_start()):
+                # the next window's lists, on the side stream, into the buffer the window before this one was read from: ordered
+                # after everything enqueued so far (those reads, and this window's build when it ran here)
+                if "list2" not in sc:
+                    sc["list2"], sc["hdr2"] = torch.empty_like(sc["list"]), torch.empty_like(sc["hdr"])
+                    sc["side"] = torch.cuda.Stream(device=self.device_)
+                n_next = max(1, min(sc["B"], int(self.max_iter) - t_next))
+                here = torch.cuda.Event()
+                here.record(cur)
+                sc["side"].wait_event(here)
+                with torch.cuda.stream(sc["side"]):
+                    build_groups(t_next, n_next, sc["list2"], sc["hdr2"])
+                    done = torch.cuda.Event()
+                    done.record(sc["side"])
+                sc["ahead"] = {"t0": t_next, "n": n_next, "done": done}
         if prof:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -645,6 +699,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         return grad, True
 
     def clear_memory(self):
+        self._join_build_ahead()      # nothing of the loop's storage is released under a running build
         super().clear_memory()
         self.__dict__.pop("_g", None)
         for attr in ("_csr", "_csr_loop", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf", "_grad_ws", "_sched", "_loop_cols"):
