@@ -345,6 +345,9 @@ def main():
     ap.add_argument("--peer-exchange", action="store_true",
                     help="N > 1: exchange the stepped rows as direct peer writes over HIP IPC (csrc/tdr_peerx.hip) instead of the RCCL "
                          "all-gather; opt-in between distinct devices (never run there), automatic where ranks share a device")
+    ap.add_argument("--build-ahead", action="store_true",
+                    help="build the next window's firing lists on a side stream while the gradient launches run (neighbor_embedding.umap."
+                         "BUILD_AHEAD; +0.9 %, off by default because the overlapped kernels' trace durations no longer add up)")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of CPU work the kNN sample of cpu_baseline may take")
     args = ap.parse_args()
 
@@ -368,6 +371,8 @@ def main():
         from torchdr_amd.neighbor_embedding import base as nbase
 
         nbase.PEER_EXCHANGE = True
+    if args.build_ahead:
+        umod.BUILD_AHEAD = True
     if args.loop != "auto":
         umod.LOOP_RUNNER = args.loop != "python"
         umod.LOOP_GRAPH = args.loop == "graph"

@@ -844,7 +844,7 @@ def test_windows_built_ahead_on_the_side_stream_change_nothing(max_iter):
             assert ("list2" in sc) == ahead
             out[ahead] = (Z.clone(), m.epoch_of_next_sample.clone())
         finally:
-            umod.BUILD_AHEAD = True
+            umod.BUILD_AHEAD = False
     assert torch.equal(out[True][0], out[False][0])
     assert torch.equal(out[True][1], out[False][1])
 
@@ -853,7 +853,11 @@ def test_windows_built_ahead_on_the_side_stream_change_nothing(max_iter):
         def on_training_step_end(self):
             super().on_training_step_end()
 
-    mh = Hooked(n_neighbors=10, max_iter=40, random_state=0, check_interval=10_000)
-    mh.clear_memory = lambda: None
-    mh.fit_transform(X)
+    umod.BUILD_AHEAD = True
+    try:
+        mh = Hooked(n_neighbors=10, max_iter=40, random_state=0, check_interval=10_000)
+        mh.clear_memory = lambda: None
+        mh.fit_transform(X)
+    finally:
+        umod.BUILD_AHEAD = False
     assert "list2" not in mh._sched

@@ -58,9 +58,12 @@ GROUPED = True
 SCHED_STAGE = 0      # LDS stage entries of the grouped build (0 = library default)
 # BUILD_AHEAD: the firing lists of window w + 1 depend on the epoch counters alone (the gradient launches never touch them), so
 # they are built on a SIDE stream into a second list / record buffer while the gradient launches of window w run: the build
-# fills the ramps and tails between the ~64 launches of a window instead of stopping the loop for a millisecond.  Same lists,
-# same order of everything that enters a result (tests/test_umap_sched_gpu.py); costs a second copy of the lists and records.
-BUILD_AHEAD = True
+# was meant to fill the ramps and tails between the ~64 launches of a window instead of stopping the loop for a millisecond.  Same
+# lists, same order of everything that enters a result (tests/test_umap_sched_gpu.py); costs a second copy of the lists and
+# records.  Measured (profiles/r04_build_ahead.json): the device is work-bound across kernel boundaries -- the overlapped build
+# slows the gradient launches by its own work -- net 353.6 -> 350.3 ms per fit (0.9 %).  OFF by default: with it the per-kernel
+# durations of a trace overlap and no longer add up to the iteration, which is what the roofline line is audited against.
+BUILD_AHEAD = False
 # FUSE_STEP: stock estimator, one GPU, n_components = 2, more than one L2 slice: the combine + SGD step run INSIDE the joint
 # gradient launch (tdr_umap_sched_grad_step_f32: the last-arriving slice workgroup of every 64-row block finishes its rows)
 # instead of in a second kernel (tdr_umap_sched_step_f32).  The stepped rows land in a second embedding buffer (the first is
