@@ -227,6 +227,17 @@ class AffinityMatcher(DRModule):
         it = int(self._nan_flag.item())
         if it != 0:
             raise ValueError(f"[TorchDR] ERROR AffinityMatcher : NaNs in the embeddings at iter {it - 1}.")
+        ctx = getattr(self, "_rccl_ctx", None)
+        if ctx is not None and hasattr(ctx, "failed"):
+            # peer exchange (csrc/tdr_peerx.hip): a bounded wait for a peer's rows ran out -- rows of an older generation may
+            # have been used since.  Agreed between the ranks like the NaN flag, so that all of them raise.
+            bad = torch.tensor([1 if ctx.failed() else 0], dtype=torch.int32, device=self.embedding_.device)
+            from torchdr_amd.parallel import allreduce_max_
+
+            allreduce_max_(bad)
+            if int(bad.item()) != 0:
+                raise RuntimeError("[torchdr_amd] peer exchange: a rank's rows did not arrive within the wait limit "
+                                   "(neighbor_embedding.base.PEER_EXCHANGE = False selects the RCCL all-gather).")
 
     # ------------------------------------------------------------------------------------------
     def _training_step(self):
