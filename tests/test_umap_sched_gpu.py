@@ -382,11 +382,14 @@ def test_umap_estimator_scheduled_gradients_equal_per_step_kernel():
     assert bool(torch.isfinite(Z).all())
 
 
+@pytest.mark.parametrize("geom,momentum", [(0, 0.0), (16, 0.0), (16, 0.6)])
 @pytest.mark.parametrize("use_graph", [0, 1])
-def test_loop_runner_equals_the_call_by_call_sequence(use_graph):
+def test_loop_runner_equals_the_call_by_call_sequence(use_graph, geom, momentum):
     """tdr_umap_loop_run (whole windows enqueued at once, replayed as HIP graphs, iteration base in device memory)
     against the same windows issued call by call (build, S gradient passes, tdr_sgd_step_f32): bit-identical embedding
-    and epoch counters after 70 iterations (windows 32 + 32 + 6), squared gradient norms at the inspected iterations."""
+    and epoch counters after 70 iterations (windows 32 + 32 + 6), squared gradient norms at the inspected iterations.
+    geom 16 = the joint launch, which the loop object finishes with ONE combine-and-step kernel (round 4), with and without
+    momentum."""
     import ctypes
 
     from torchdr_amd import _lib
@@ -406,16 +409,18 @@ def test_loop_runner_equals_the_call_by_call_sequence(use_graph):
     sc = Sched(rowptr, cols_p, eps_p, n, 32, S)
     Z, nxt = Z0.clone(), eps_p.clone()
     flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    mom_a = torch.zeros_like(Z0) if momentum else None
+    mom_b = torch.zeros_like(Z0) if momentum else None
     norms, snaps = {}, {}
     for t0 in range(0, T, 32):
         nw = min(32, T - t0)
         sc.build(nxt, t0, nw)
         for tl in range(nw):
-            g = sc.grad(Z, tl, t0 + tl, a, b, 150, neg=None, seed=seed)
+            g = sc.grad(Z, tl, t0 + tl, a, b, 150, neg=None, seed=seed, geom=geom)
             if (t0 + tl) % ci == 0:
                 norms[(t0 + tl) // ci] = float((g.double() ** 2).sum())
-            _lib.check(L.tdr_sgd_step_f32(_lib.ptr(Z), _lib.ptr(g), None, Z.numel(), float(lr[t0 + tl]), 0.0, 0, _lib.ptr(flag),
-                                          t0 + tl, _lib.stream_ptr()), "sgd")
+            _lib.check(L.tdr_sgd_step_f32(_lib.ptr(Z), _lib.ptr(g), _lib.ptr(mom_a), Z.numel(), float(lr[t0 + tl]), momentum,
+                                          1 if t0 + tl == 0 else 0, _lib.ptr(flag), t0 + tl, _lib.stream_ptr()), "sgd")
             if (t0 + tl) % ci == 0:
                 snaps[t0 + tl] = Z.clone()
     # loop object
@@ -428,13 +433,13 @@ def test_loop_runner_equals_the_call_by_call_sequence(use_graph):
     d.Z, d.nc, d.n_total, d.row0, d.n_rows = _lib.ptr(Z2), 2, n, 0, n
     d.rowptr, d.cols, d.eps_per, d.next = _lib.ptr(rowptr), _lib.ptr(cols_p), _lib.ptr(eps_p), _lib.ptr(nxt2)
     d.blk_base, d.list, d.hdr, d.err = _lib.ptr(sc2.blk_base), _lib.ptr(sc2.list), _lib.ptr(sc2.hdr), _lib.ptr(sc2.err)
-    d.acc, d.grad, d.mom_buf = _lib.ptr(sc2.acc), _lib.ptr(grad), None
+    d.acc, d.grad, d.mom_buf = _lib.ptr(sc2.acc), _lib.ptr(grad), _lib.ptr(mom_b)
     d.a, d.b, d.neg_rate, d.n_negatives, d.seed = a, b, 5, 150, seed
     d.exag, d.rep, d.eps, d.n_slices, d.block_iters = 1.0, 1.0, 1e-3, S, 32
-    d.lr_table, d.max_iter, d.momentum, d.first_iter, d.check_interval = _lib.ptr(lr_d), T, 0.0, 0, ci
+    d.lr_table, d.max_iter, d.momentum, d.first_iter, d.check_interval = _lib.ptr(lr_d), T, momentum, 0, ci
     snap = torch.zeros((n, 2), device="cuda")
     d.norm2, d.snap, d.nan_flag, d.scratch, d.gather, d.gather_ctx, d.geom = (_lib.ptr(norm2), _lib.ptr(snap), _lib.ptr(flag2), _lib.ptr(scratch),
-                                                                               None, None, 0)
+                                                                               None, None, geom)
     h = ctypes.c_void_p()
     _lib.check(L.tdr_umap_loop_create(ctypes.byref(h), ctypes.byref(d)), "create")
     side = torch.cuda.Stream()       # graphs cannot be captured on the legacy default stream
@@ -445,6 +450,8 @@ def test_loop_runner_equals_the_call_by_call_sequence(use_graph):
             _lib.check(L.tdr_umap_loop_run(h, 64, 6, use_graph, _lib.stream_ptr()), "run")
         torch.cuda.synchronize()
         assert torch.equal(Z2, Z) and torch.equal(nxt2, nxt)
+        if momentum:
+            assert torch.equal(mom_b, mom_a)
         assert torch.equal(snap, snaps[(T - 1) // ci * ci])     # embedding right after the last inspected iteration
         for k, v in norms.items():
             assert abs(float(norm2[k]) - v) <= 1e-5 * v

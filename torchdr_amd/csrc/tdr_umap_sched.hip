@@ -1317,6 +1317,65 @@ __global__ __launch_bounds__(256) void sgd_table_step_kernel(float* __restrict__
     if (z != z) atomicCAS(nan_flag, 0, it + 1);
 }
 
+// The two kernels above in one pass for the joint launch of the loop object (round 4): umap_sched_combine_kernel's sums and
+// clamps followed by sgd_table_step_kernel's step, element for element the same operations -- one launch and the round trip of
+// the gradient through memory less per iteration (a rank of an 8-GPU fit at N = 1M spends ~40 us per iteration in kernels).
+// The gradient itself is written at the inspected iterations only (nobody reads it elsewhere).
+template <int NC>
+__global__ __launch_bounds__(256) void umap_sched_combine_table_step_kernel(const float* __restrict__ acc, int S, int64_t n_rows, float exag,
+                                                                            float rep, float* __restrict__ grad, float* __restrict__ Z,
+                                                                            float* __restrict__ buf, const float* __restrict__ lr_table,
+                                                                            const int* __restrict__ iter_base, int iter_off, float momentum,
+                                                                            int first_iter, int check_interval, float* __restrict__ norm2,
+                                                                            float* __restrict__ snap, int* __restrict__ nan_flag) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int it = *iter_base + iter_off;
+    const bool inspected = check_interval > 0 && it % check_interval == 0;
+    const bool have = r < n_rows;
+    float g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) g[c] = 0.f;
+    if (have) {
+        float ga[NC], gr[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { ga[c] = acc[(size_t)r * 2 * NC + c]; gr[c] = acc[(size_t)r * 2 * NC + NC + c]; }
+        for (int s = 1; s < S; ++s) {
+            const float* a = acc + ((size_t)s * n_rows + r) * 2 * NC;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { ga[c] = a[c] + ga[c]; gr[c] = a[NC + c] + gr[c]; }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) g[c] = exag * fminf(fmaxf(ga[c], -4.f), 4.f) + rep * fminf(fmaxf(gr[c], -4.f), 4.f);
+    }
+    if (inspected) {
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) q += g[c] * g[c];
+        q = wave_sum(q);
+        if ((threadIdx.x & 63) == 0 && q != 0.f) atomicAdd(&norm2[it / check_interval], q);
+    }
+    if (!have) return;
+    const float lr = lr_table[it];
+    const bool first = it == first_iter;
+    bool nan = false;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int64_t i = r * NC + c;
+        float gc = g[c];
+        if (inspected) grad[i] = gc;
+        if (momentum != 0.f) {
+            const float bprev = first ? 0.f : buf[i];
+            gc = first ? gc : __fadd_rn(__fmul_rn(bprev, momentum), gc);
+            buf[i] = gc;
+        }
+        const float z = fmaf(-lr, gc, Z[i]);
+        Z[i] = z;
+        if (inspected && snap) snap[i] = z;
+        nan = nan || z != z;
+    }
+    if (nan) atomicCAS(nan_flag, 0, it + 1);
+}
+
 typedef int (*tdr_collective_fn)(void* ctx, float* Z, int nc, void* stream);  // all-gather of the rows every rank stepped
 
 struct UmapLoop {
@@ -1362,11 +1421,23 @@ static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st) {
     for (int t = 0; t < n; ++t) {
         G.t_local = t; G.iter = (uint32_t)t;
         G.nc = L->nc;
-        const int rcg = launch_sched_grad_all(G, L->geom, st);
+        // joint launch, 2 or 3 components: the gradient kernel leaves the per-slice planes (geom bit 32) and ONE kernel combines
+        // them and steps the rows
+        const bool fused = (L->geom & 16) && L->S > 1 && (L->nc == 2 || L->nc == 3);
+        const int rcg = launch_sched_grad_all(G, fused ? (L->geom | 32) : L->geom, st);
         if (rcg != TDR_OK) return rcg;
-        hipLaunchKernelGGL(sgd_table_step_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st,
-                           L->Z + L->row0 * L->nc, (const float*)L->grad, L->mom_buf, n_el, L->lr_table, (const int*)L->iter_base, t,
-                           L->momentum, L->first_iter, L->check_interval, L->norm2, L->snap, L->nan_flag);
+        if (fused && L->nc == 2)
+            hipLaunchKernelGGL(umap_sched_combine_table_step_kernel<2>, dim3((unsigned)((L->n_rows + 255) / 256)), dim3(256), 0, st,
+                               (const float*)L->acc, L->S, L->n_rows, L->exag, L->rep, L->grad, L->Z + L->row0 * L->nc, L->mom_buf, L->lr_table,
+                               (const int*)L->iter_base, t, L->momentum, L->first_iter, L->check_interval, L->norm2, L->snap, L->nan_flag);
+        else if (fused)
+            hipLaunchKernelGGL(umap_sched_combine_table_step_kernel<3>, dim3((unsigned)((L->n_rows + 255) / 256)), dim3(256), 0, st,
+                               (const float*)L->acc, L->S, L->n_rows, L->exag, L->rep, L->grad, L->Z + L->row0 * L->nc, L->mom_buf, L->lr_table,
+                               (const int*)L->iter_base, t, L->momentum, L->first_iter, L->check_interval, L->norm2, L->snap, L->nan_flag);
+        else
+            hipLaunchKernelGGL(sgd_table_step_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st,
+                               L->Z + L->row0 * L->nc, (const float*)L->grad, L->mom_buf, n_el, L->lr_table, (const int*)L->iter_base, t,
+                               L->momentum, L->first_iter, L->check_interval, L->norm2, L->snap, L->nan_flag);
         if (L->gather) {
             const int rc = L->gather(L->gather_ctx, L->Z, L->nc, (void*)st);
             if (rc != TDR_OK) return rc;
