@@ -1395,7 +1395,9 @@ struct UmapLoop {
 
 // enqueue one window: schedule build for iterations [base + 0, base + n) and n x (S gradient passes + SGD step [+ row
 // all-gather]); `base` lives in L->iter_base on the device, so the SAME enqueued sequence serves any window
-static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st) {
+// host_base >= 0 (plain launches): the window's first iteration is known here and goes to the gradient kernel as an argument --
+// its row key, the head of every wavefront's dependency chain, then does not wait for a load of the device-side base
+static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st, int host_base = -1) {
     if (L->rs) {
         SchedBuild2Params B2;
         B2.rowptr = L->rowptr; B2.cols = L->cols; B2.eps_per = L->eps_per; B2.rs = L->rs; B2.next = L->next; B2.n_rows = L->n_rows;
@@ -1418,8 +1420,9 @@ static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st) {
     G.a = L->a; G.b = L->b; G.neg_rate = L->neg_rate; G.n_negatives = L->n_negatives; G.neg_inj = nullptr; G.seed = L->seed;
     G.iter_base = L->iter_base; G.exag = L->exag; G.rep = L->rep; G.eps = L->eps; G.grad = L->grad; G.acc = L->acc;
     const int64_t n_el = L->n_rows * L->nc;
+    if (host_base >= 0) G.iter_base = nullptr;
     for (int t = 0; t < n; ++t) {
-        G.t_local = t; G.iter = (uint32_t)t;
+        G.t_local = t; G.iter = (uint32_t)(t + (host_base >= 0 ? host_base : 0));
         G.nc = L->nc;
         // joint launch, 2 or 3 components: the gradient kernel leaves the per-slice planes (geom bit 32) and ONE kernel combines
         // them and steps the rows
@@ -1732,7 +1735,7 @@ int tdr_umap_loop_run(void* loop, int it0, int n_iters, int use_graph, void* str
                     if (e != hipSuccess) {  // e.g. the legacy default stream cannot be captured: plain launches from now on
                         (void)hipGetLastError();
                         use_graph = 0;
-                        const int rc0 = umap_loop_enqueue_window(L, n, st);
+                        const int rc0 = umap_loop_enqueue_window(L, n, st, it);
                         if (rc0 != TDR_OK) return rc0;
                         it += n;
                         continue;
@@ -1753,7 +1756,7 @@ int tdr_umap_loop_run(void* loop, int it0, int n_iters, int use_graph, void* str
             e = hipGraphLaunch(L->graphs[slot], st);
             if (e != hipSuccess) return (int)e;
         } else {
-            const int rc = umap_loop_enqueue_window(L, n, st);
+            const int rc = umap_loop_enqueue_window(L, n, st, it);
             if (rc != TDR_OK) return rc;
         }
         it += n;
