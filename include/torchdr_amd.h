@@ -398,6 +398,24 @@ int tdr_sne_repulsion_f64(const double* Z, int nc, int64_t n_total, int64_t row0
                           double* grad, void* stream);
 int tdr_pacmap_grad_f64(const double* Z, int nc, int64_t n, const int64_t* near_idx, int m_near, double w_nb, const int64_t* mid_idx,
                         int m_mid, double w_mn, const int64_t* far_idx, int m_far, double w_fp, double* grad, void* stream);
+/* float64 SNEkhorn (csrc/tdr_khorn_f64.hip; round 4): the reductions of tdr_sea_rowstats_f32 / tdr_sinkhorn_pass_f32 /
+ * tdr_student_matvec_f32 / tdr_khorn_grad_nc_f32 / tdr_khorn_grad_unrolled_f32 in float64 on a DENSE (n, n) float64 matrix of
+ * squared distances (tdr_knn_f64 with k = 0; symmetric), n <= tdr_pairs_f64_max_rows().  ws: tdr_pairs_f64_workspace_bytes(n,
+ * n_state) bytes, n_state = 3 (row statistics) / 1 (student sum) / nc (forces).
+ *   affinity/entropic.py:518-534: side (n, 2) = (mu, e) -> out (n, 3) = (sum p, sum p lp, sum p C), lp = (mu_i + mu_j - 2 C_ij) / (e_i + e_j)
+ *   affinity/entropic.py:728-748: side (n, nc + 1) = (z, v) -> out_j = sum_i v_i / (1 + |z_j - z_i|^2 [+ diag_add at i = j])
+ *   neighbor_embedding/tsnekhorn.py:210-230: side (n, nc + 3) = (mu, e, z, exp(dual)) -> grad (n, nc)
+ *   neighbor_embedding/tsnekhorn.py:134,224-227 (unrolling): side (n, nc + 12) = (mu, e, z, a[5], b[5]) -> grad (n, nc) */
+int64_t tdr_pairs_f64_max_rows(void);
+int64_t tdr_pairs_f64_workspace_bytes(int64_t n, int n_state);
+int tdr_sea_rowstats_dense_f64(const double* C, int64_t n, int64_t ldc, const double* side, double* out, void* ws, int64_t ws_bytes,
+                               void* stream);
+int tdr_student_sum_f64(const double* side, int nc, int64_t n, int zero_diag, double diag_add, double* out, void* ws, int64_t ws_bytes,
+                        void* stream);
+int tdr_khorn_grad_dense_f64(const double* C, int64_t n, int64_t ldc, const double* side, int nc, double log_n, double* grad, void* ws,
+                             int64_t ws_bytes, void* stream);
+int tdr_khorn_grad_unrolled_dense_f64(const double* C, int64_t n, int64_t ldc, const double* side, int nc, double log_n, double* grad,
+                                      void* ws, int64_t ws_bytes, void* stream);
 /* COSNE (neighbor_embedding/cosne.py:162-193, float64 like the reference's ManifoldParameter): closed-form gradient of
  *   -sum P log Q (kNN graph) + log sum_ij Q_ij (dense, never materialised) + lam * mean (||x||^2 - d_H(z,0)^2)^2,
  *   Q = gamma / (d_H^2 + gamma^2), d_H^2 = arccosh(1 + 2|zi-zj|^2/((1-|zi|^2)(1-|zj|^2)) + 1e-8)^2

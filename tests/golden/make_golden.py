@@ -1092,6 +1092,47 @@ def ne2_step64_fixture():
     save("ne2_step64", **out)
 
 
+def tsnekhorn64_fixture():
+    """float64 twins of the tsnekhorn / tsnekhorn3 / tsnekhorn_unrolled fixtures: the real reference on the float64 copy of the
+    same points -- symmetric entropic affinity (30 Adam steps on the duals: log P, eps, mu), and two optimisation steps of
+    TSNEkhorn (2 / 3 / 4 components, with and without unrolling): embedding before, Sinkhorn dual, autograd gradient, embedding
+    after.  Everything float64, as tests/test_neighbor_embedding.py:34,55-74 run the method."""
+    from torchdr import TSNEkhorn
+    from torchdr.affinity import SymmetricEntropicAffinity
+
+    X = gmm(256, 16, 2.0, seed=61).double()
+    out = {"X": X}
+    sea = SymmetricEntropicAffinity(perplexity=10, lr=1e-1, max_iter=30, tol=1e-3, zero_diag=False, backend=None)
+    logP = sea(X, log=True)
+    assert logP.dtype == torch.float64
+    out.update(sea_logP=logP, sea_eps=sea.eps_.detach(), sea_mu=sea.mu_.detach(), sea_n_iter=torch.tensor(int(sea.n_iter_)))
+    sea_z = SymmetricEntropicAffinity(perplexity=10, lr=1e-1, max_iter=8, tol=1e-3, zero_diag=True, backend=None)
+    out["sea_zd_logP"] = sea_z(X, log=True)
+    for name, kw in (("n2", dict()), ("n3", dict(n_components=3)), ("n4", dict(n_components=4)), ("u2", dict(unrolling=True)),
+                     ("u3", dict(unrolling=True, n_components=3))):
+        rec = {}
+
+        class Probe(TSNEkhorn):
+            def _training_step(self):
+                t = int(self.n_iter_)
+                if t < 2:
+                    rec[f"Z_{t}"] = self.embedding_.detach().clone()
+                loss = super()._training_step()
+                if t < 2:
+                    rec[f"grad_{t}"] = self.embedding_.grad.detach().clone()
+                    rec[f"dual_{t}"] = self.dual_sinkhorn_.detach().clone()
+                    rec[f"Zafter_{t}"] = self.embedding_.detach().clone()
+                return loss
+
+        torch.manual_seed(3)
+        Probe(perplexity=10, max_iter=3, max_iter_affinity_in=30, init="normal", init_scaling=1.0, min_grad_norm=1e-12, lr=1.0,
+              optimizer="SGD", optimizer_kwargs=None, backend=None, random_state=3, **kw).fit_transform(X)
+        assert rec["Z_0"].dtype == torch.float64 and rec["grad_0"].dtype == torch.float64
+        for k_, v in rec.items():
+            out[f"{name}_{k_}"] = v
+    save("tsnekhorn64", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     ALL = dict(knn=knn_fixtures, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
@@ -1099,7 +1140,7 @@ if __name__ == "__main__":
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,
                cosne=cosne_fixture, hyperbolic=hyperbolic_fixture, c1_tsne=c1_tsne_fixture, sinkhorn=sinkhorn_fixture, affinity64=affinity64_fixture,
-               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, tsnekhorn_unrolled=tsnekhorn_unrolled_fixture, signatures=signatures_fixture, manifold=manifold_fixture, radam=radam_fixture, grad64=grad64_fixture, sampler_quality=sampler_quality_fixture, ne2_step64=ne2_step64_fixture)
+               sea_lbfgs=sea_lbfgs_fixture, dense_ne=dense_ne_fixture, tsnekhorn3=tsnekhorn3_fixture, tsnekhorn_unrolled=tsnekhorn_unrolled_fixture, signatures=signatures_fixture, manifold=manifold_fixture, radam=radam_fixture, grad64=grad64_fixture, sampler_quality=sampler_quality_fixture, ne2_step64=ne2_step64_fixture, tsnekhorn64=tsnekhorn64_fixture)
     for name in (sys.argv[1:] or list(ALL)):  # optional: names of the fixtures to regenerate
         ALL[name]()
     print("reference version:", torchdr.__version__)

@@ -201,10 +201,45 @@ def pair_scan_workspace(n: int, n_state: int, device):
     return _lib.ptr(buf), nbytes, buf
 
 
-def sea_rowstats(packed: PackedPoints, mu: torch.Tensor, e: torch.Tensor, zero_diag: bool, energy: bool = False):
+class DensePoints64:
+    """float64 input of the symmetric entropic affinity: the DENSE (n, n) float64 matrix of squared distances (``tdr_knn_f64`` with
+    k = 0; + 1e12 on an excluded diagonal), which the float64 reductions of ``csrc/tdr_khorn_f64.hip`` read -- the reference
+    materialises the same matrix (entropic.py:452).  Parity runs: n <= ``tdr_pairs_f64_max_rows()``."""
+
+    def __init__(self, X: torch.Tensor, zero_diag: bool):
+        from torchdr_amd.distance.base import _pairwise_f64
+
+        C = _pairwise_f64(X, None, "sqeuclidean", bool(zero_diag), None, False, "auto", None)
+        if C is NotImplemented:
+            raise NotImplementedError("[torchdr_amd] float64 SymmetricEntropicAffinity: no float64 distance kernel for this input.")
+        self.C, self.n, self.d, self.zero_diag = C, X.shape[0], X.shape[1], bool(zero_diag)
+
+    @staticmethod
+    def eligible(X: torch.Tensor) -> bool:
+        return (X.dtype == torch.float64 and X.dim() == 2 and X.shape[1] <= 256
+                and X.shape[0] <= int(_lib.lib().tdr_pairs_f64_max_rows()))
+
+
+def pairs64_workspace(n: int, n_state: int, device):
+    nbytes = int(_lib.lib().tdr_pairs_f64_workspace_bytes(n, n_state))
+    return torch.empty(max(nbytes, 8), dtype=torch.uint8, device=device), nbytes
+
+
+def sea_rowstats(packed, mu: torch.Tensor, e: torch.Tensor, zero_diag: bool, energy: bool = False):
     """(P_sum, H) of the implicit matrix exp((mu_i+mu_j-2C_ij)/(e_i+e_j)) -- K7 ``tdr_sea_rowstats_f32``; with
-    ``energy`` also sum_j P_ij C_ij (the third term of the dual objective, ``tdr_sea_rowstats3_f32``)."""
+    ``energy`` also sum_j P_ij C_ij (the third term of the dual objective, ``tdr_sea_rowstats3_f32``).  float64 input
+    (``DensePoints64``): ``tdr_sea_rowstats_dense_f64``."""
     n = packed.n
+    if isinstance(packed, DensePoints64):
+        if bool(zero_diag) != packed.zero_diag:
+            raise ValueError("[torchdr_amd] the dense float64 distance matrix was built for another zero_diag.")
+        side = torch.stack([mu.double(), e.double()], dim=1).contiguous()
+        out = torch.empty((n, 3), dtype=torch.float64, device=side.device)
+        ws, ws_bytes = pairs64_workspace(n, 3, side.device)
+        _lib.check(_lib.lib().tdr_sea_rowstats_dense_f64(_lib.ptr(packed.C), n, packed.C.stride(0), _lib.ptr(side), _lib.ptr(out),
+                                                        _lib.ptr(ws), ws_bytes, _lib.stream_ptr()), "tdr_sea_rowstats_dense_f64")
+        psum, ent = out[:, 0].contiguous(), -(out[:, 1] - out[:, 0])
+        return (psum, ent, out[:, 2].contiguous()) if energy else (psum, ent)
     side = torch.stack([mu, e], dim=1).contiguous()
     psum = torch.empty(n, dtype=torch.float32, device=mu.device)
     ent = torch.empty(n, dtype=torch.float32, device=mu.device)
@@ -236,6 +271,9 @@ class SymmetricEntropicAffinity(LogAffinity):
     log-affinity like the reference does, for N up to ``_DENSE_LIMIT``.  First-order optimizers (reference :518-571)
     and LBFGS (:473-508) both run on the same row statistics."""
 
+    _float64_kernels = True   # float64 inputs: float64 duals on the dense float64 distance matrix (csrc/tdr_khorn_f64.hip), n <= 16384
+
+
     def __init__(self, perplexity: float = 30, lr: float = 1e-1, eps_square: bool = True, tol: float = 1e-3,
                  max_iter: int = 500, check_interval: int = 50, optimizer: str = "Adam",
                  metric: str = "sqeuclidean", zero_diag: bool = True, device: str = "auto", backend=None,
@@ -255,11 +293,16 @@ class SymmetricEntropicAffinity(LogAffinity):
         if self.metric != "sqeuclidean":
             raise NotImplementedError("[torchdr_amd] SymmetricEntropicAffinity supports metric='sqeuclidean'.")
         n = X.shape[0]
-        packed = PackedPoints(X)
+        # float64 input: float64 duals on the dense float64 distance matrix (the reference computes in its input's dtype);
+        # beyond the dense form's size the float32 matrix-free scan, like every other float64 input without a float64 kernel
+        if X.dtype == torch.float64 and not DensePoints64.eligible(X):
+            X = X.float()
+        dt = X.dtype
+        packed = DensePoints64(X, self.zero_diag) if dt == torch.float64 else PackedPoints(X)
         perplexity = check_neighbor_param(self.perplexity, n)
-        target = torch.log(torch.tensor(float(perplexity), dtype=torch.float32, device=X.device)) + 1
-        eps = torch.ones(n, dtype=torch.float32, device=X.device)
-        mu = torch.ones(n, dtype=torch.float32, device=X.device)
+        target = torch.log(torch.tensor(float(perplexity), dtype=dt, device=X.device)) + 1
+        eps = torch.ones(n, dtype=dt, device=X.device)
+        mu = torch.ones(n, dtype=dt, device=X.device)
         self.register_buffer("eps_", eps, persistent=False)
         self.register_buffer("mu_", mu, persistent=False)
         if self.optimizer == "LBFGS":
@@ -351,7 +394,7 @@ class SymmetricEntropicAffinity(LogAffinity):
             )
         packed = self.fit_duals(X)
         mu, e = self.dual_side()
-        C = dense_packed(packed, packed, "sqeuclidean", self.zero_diag)
+        C = packed.C if isinstance(packed, DensePoints64) else dense_packed(packed, packed, "sqeuclidean", self.zero_diag)
         log_P = (mu[:, None] + mu[None, :] - 2 * C) / (e[:, None] + e[None, :])
         log_P -= math.log(n)
         return log_P
@@ -379,6 +422,8 @@ def sinkhorn_student_dual(Z: torch.Tensor, init_dual, max_iter: int, tol: float,
     ``entropic.py:728-748``.  Returns (dual, n_iter).  ``record``: a list that receives, per update that ran,
     (Ef, 1 / s) with Ef = exp(f_before - max) and s_i = sum_j Ef_j / (1 + d_ij) -- what the adjoint of the update needs."""
     _lib.require_gpu(Z, "Z")
+    if Z.dtype == torch.float64:
+        return _sinkhorn_student_dual64(Z, init_dual, max_iter, tol, zero_diag, record)
     Zc = pad_embedding(Z)
     n, nc = Zc.shape
     f = torch.zeros(n, dtype=torch.float32, device=Z.device) if init_dual is None else init_dual.clone().float()
@@ -407,12 +452,53 @@ def sinkhorn_student_dual(Z: torch.Tensor, init_dual, max_iter: int, tol: float,
     return f, k
 
 
+def student_sum64(Z: torch.Tensor, v: torch.Tensor, zero_diag: bool):
+    """out_j = sum_i v_i / (1 + |z_j - z_i|^2) in float64 (``tdr_student_sum_f64``; + 1e12 in the diagonal's denominator when
+    zero_diag): the reduction of a Student-kernel Sinkhorn update and of its adjoint.  2, 3 or 4 components."""
+    n, nc = Z.shape
+    side = torch.cat([Z.detach().double(), v.double()[:, None]], dim=1).contiguous()
+    out = torch.empty(n, dtype=torch.float64, device=Z.device)
+    ws, ws_bytes = pairs64_workspace(n, 1, Z.device)
+    _lib.check(_lib.lib().tdr_student_sum_f64(_lib.ptr(side), nc, n, 1 if zero_diag else 0, 1e12, _lib.ptr(out), _lib.ptr(ws), ws_bytes,
+                                              _lib.stream_ptr()), "tdr_student_sum_f64")
+    return out
+
+
+def _sinkhorn_student_dual64(Z, init_dual, max_iter, tol, zero_diag, record):
+    """float64 form of :func:`sinkhorn_student_dual` (same update, same stopping test, same record)."""
+    n = Z.shape[0]
+    f = torch.zeros(n, dtype=torch.float64, device=Z.device) if init_dual is None else init_dual.clone().double()
+    k = 0
+    for k in range(max_iter):
+        fmax = float(f.max())
+        Ef = (f - fmax).exp()
+        s = student_sum64(Z, Ef, zero_diag)
+        red = -(fmax + s.log())
+        f_new = 0.5 * (f + red)
+        if record is not None:
+            record.append((Ef, 1.0 / s))
+        f = f_new
+        if float(torch.norm(f - red)) < tol:
+            break
+    return f, k
+
+
 def sinkhorn_student_adjoint(Z: torch.Tensor, record, g_final: torch.Tensor, zero_diag: bool = True, n_terms: int = 5):
     """Reverse sweep through the recorded updates f^k = (f^{k-1} - LSE_j(log K_ij + f^{k-1}_j)) / 2 (reference
     ``entropic.py:733-736`` under ``with_grad=True``): with S^k_ij = Ef^k_j w_ij / s^k_i the softmax update k reduces,
     the adjoints are g^{k-1} = (g^k - S^k^T g^k) / 2 -- one Student-kernel mat-vec each (``tdr_student_matvec_f32``) -- and
     the gradient w.r.t. log K_ij is -(1/2) sum_k g^k_i S^k_ij.  Returns (A, B), both (n, n_terms): A[:, k] = g^k / s^k,
     B[:, k] = Ef^k (zero columns for updates that did not run), so that sum_k g^k_i S^k_ij = w_ij sum_k A_ik B_jk."""
+    if Z.dtype == torch.float64:     # the same sweep on the float64 sum (tdr_student_sum_f64)
+        n = Z.shape[0]
+        A = torch.zeros((n, n_terms), dtype=torch.float64, device=Z.device)
+        B = torch.zeros((n, n_terms), dtype=torch.float64, device=Z.device)
+        g = g_final.double().contiguous()
+        for col, (Ef, inv_s) in enumerate(reversed(record)):
+            a = g * inv_s
+            A[:, col], B[:, col] = a, Ef
+            g = 0.5 * (g - Ef * student_sum64(Z, a, zero_diag))
+        return A, B
     Zc = pad_embedding(Z)
     n, nc = Zc.shape
     A = torch.zeros((n, n_terms), dtype=torch.float32, device=Z.device)

@@ -6,8 +6,8 @@ from typing import Dict, Optional, Type, Union
 import torch
 
 from torchdr_amd import _lib
-from torchdr_amd.affinity.entropic import (SinkhornAffinity, SymmetricEntropicAffinity, pad_embedding, pair_scan_workspace, sea_rowstats,
-                                           sinkhorn_student_adjoint, sinkhorn_student_dual)
+from torchdr_amd.affinity.entropic import (DensePoints64, SinkhornAffinity, SymmetricEntropicAffinity, pad_embedding, pair_scan_workspace,
+                                           pairs64_workspace, sea_rowstats, sinkhorn_student_adjoint, sinkhorn_student_dual)
 from torchdr_amd.neighbor_embedding.base import NeighborEmbedding
 from torchdr_amd.utils import bool_arg
 
@@ -30,6 +30,12 @@ class TSNEkhorn(NeighborEmbedding):
     ``symmetric_affinity=False`` is refused: the reference's own path fails at its first loss evaluation (the sparse
     ``(n, k)`` entropic affinity is multiplied with the dense ``(n, n)`` log Q: "The size of tensor a (k) must match the size of
     tensor b (n)"), so there is no behaviour to reproduce."""
+
+    # float64 inputs are embedded in float64 (csrc/tdr_khorn_f64.hip: dense float64 distance matrix, n <= 16384, 2-4 components)
+    _float64_loop = True
+
+    def _float64_ok(self, X) -> bool:
+        return 2 <= int(self.n_components) <= 4 and DensePoints64.eligible(X) and self.metric == "sqeuclidean"
 
     def __init__(self, perplexity: float = 30, n_components: int = 2, lr: Union[float, str] = "auto",
                  optimizer: Union[str, Type[torch.optim.Optimizer]] = "SGD",
@@ -78,7 +84,37 @@ class TSNEkhorn(NeighborEmbedding):
         self.dual_sinkhorn_ = None
         self._p_marginals = None
 
+    def _compute_gradients64(self):
+        """float64 form of the step below: the same five warm-started Sinkhorn updates and the same force, reduced by the float64
+        kernels over the dense float64 distance matrix of the input (``DensePoints64``)."""
+        n, nc = self.n_samples_in_, self.n_components
+        Z = self.embedding_.detach()
+        out = self.affinity_out
+        rec = [] if self.unrolling else None
+        dual, k = sinkhorn_student_dual(Z, self.dual_sinkhorn_, out.max_iter, out.tol, out.zero_diag, record=rec)
+        out.register_buffer("dual_", dual, persistent=False)
+        out.n_iter_ = k
+        self.dual_sinkhorn_ = dual.detach()
+        grad = torch.empty((n, nc), dtype=torch.float64, device=self.device_)
+        ws, ws_bytes = pairs64_workspace(n, nc, self.device_)
+        L, C = _lib.lib(), self._packed.C
+        if not self.unrolling:
+            side = torch.cat([self._mu[:, None], self._e[:, None], Z, dual.exp()[:, None]], dim=1).contiguous()
+            _lib.check(L.tdr_khorn_grad_dense_f64(_lib.ptr(C), n, C.stride(0), _lib.ptr(side), nc, math.log(n), _lib.ptr(grad), _lib.ptr(ws),
+                                                  ws_bytes, _lib.stream_ptr()), "tdr_khorn_grad_dense_f64")
+        else:
+            if self._p_marginals is None:
+                S, _ = sea_rowstats(self._packed, self._mu, self._e, False)
+                self._p_marginals = (2.0 / n) * S
+            A, B = sinkhorn_student_adjoint(Z, rec, -self._p_marginals, out.zero_diag)
+            side = torch.cat([self._mu[:, None], self._e[:, None], Z, 0.25 * A, B], dim=1).contiguous()
+            _lib.check(L.tdr_khorn_grad_unrolled_dense_f64(_lib.ptr(C), n, C.stride(0), _lib.ptr(side), nc, math.log(n), _lib.ptr(grad),
+                                                           _lib.ptr(ws), ws_bytes, _lib.stream_ptr()), "tdr_khorn_grad_unrolled_dense_f64")
+        return grad, False
+
     def _compute_gradients(self):
+        if isinstance(self._packed, DensePoints64):
+            return self._compute_gradients64()
         n = self.n_samples_in_
         nc = self.n_components
         Zp = pad_embedding(self.embedding_)
