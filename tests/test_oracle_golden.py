@@ -340,6 +340,43 @@ def test_tsnekhorn_unrolled_oracle():
         assert torch.allclose(R.tsnekhorn_grad(Z, log_P, dual, log_K), ref, rtol=1e-3, atol=1e-5 * float(ref.abs().max()))
 
 
+def test_tsnekhorn64_oracle():
+    """The same restatements in FLOAT64 against the reference run on float64 data (tests/golden/tsnekhorn64.npz): with float32
+    rounding out of the way the closed forms hold to 1e-9 -- duals of the symmetric entropic affinity after 30 Adam steps, log P,
+    Sinkhorn duals, the force with detached duals (2 / 3 / 4 components) and through the unrolled updates (2 / 3 components)."""
+    g = load("tsnekhorn64")
+    X = g["X"]
+    assert X.dtype == torch.float64
+    n = X.shape[0]
+    C = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+    eps, mu, logP, k = R.sea_affinity(C, 10, lr=1e-1, max_iter=30, tol=1e-3)
+    assert k == int(g["sea_n_iter"])
+    assert torch.allclose(eps, g["sea_eps"], rtol=1e-9, atol=1e-11) and torch.allclose(mu, g["sea_mu"], rtol=1e-9, atol=1e-11)
+    assert torch.allclose(logP, g["sea_logP"], rtol=1e-9, atol=1e-9)
+    log_P = g["sea_logP"]
+
+    def close(a, b, tol=1e-9):
+        return float((a - b).abs().max()) <= tol * float(b.abs().max())
+
+    for name in ("n2", "n3", "n4"):
+        init = None
+        for t in range(2):
+            Z = g[f"{name}_Z_{t}"]
+            dual, log_K, _ = R.sinkhorn_student(Z, init, 5, 1e-5)
+            init = dual
+            assert close(dual, g[f"{name}_dual_{t}"]), name
+            assert close(R.tsnekhorn_grad(Z, log_P, dual, log_K), g[f"{name}_grad_{t}"]), name
+    for name in ("u2", "u3"):
+        init = None
+        for t in range(2):
+            Z, ref = g[f"{name}_Z_{t}"], g[f"{name}_grad_{t}"]
+            grad, dual, _ = R.tsnekhorn_unrolled_grad(Z, log_P, init, 5, 1e-5)
+            gc, dc = R.tsnekhorn_unrolled_grad_closed(Z, log_P, init, 5, 1e-5)
+            assert close(dual, g[f"{name}_dual_{t}"]) and close(dc, dual)
+            assert close(grad, ref) and close(gc, ref), name
+            init = dual
+
+
 def test_numeric_helpers_cpu():
     """API-parity helpers (utils/utils.py, utils/root_search.py): the reference's own unit checks
     (test_utils.py:45-82: roots of x^2 - 1)."""
