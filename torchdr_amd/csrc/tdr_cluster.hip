@@ -76,13 +76,19 @@ __global__ __launch_bounds__(CL_TH) void cluster_maxmin_kernel(const float* __re
         }
         if (lane == 0) wbest[w] = key;
         __syncthreads();
-        if (tid == 0) {
-            unsigned long long k = wbest[0];
-            for (int i = 1; i < CL_TH / 64; ++i) k = wbest[i] > k ? wbest[i] : k;
-            winner = 0x7fffffff - (int)(unsigned)(k & 0xffffffffu);
-            const float delta = __uint_as_float((unsigned)(k >> 32));     // max-min distance of the NEXT seed
-            if (n_out && step + 1 >= c_min && step > 0 && delta < drop * prev_delta) stop_at = step + 1;
-            prev_delta = delta;
+        if (w == 0) {       // the 16 per-wavefront maxima: one more butterfly in the first wavefront (was a serial scan by thread 0)
+            unsigned long long k = lane < CL_TH / 64 ? wbest[lane] : 0ull;
+#pragma unroll
+            for (int o = CL_TH / 128; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(k, o, 64);
+                k = other > k ? other : k;
+            }
+            if (lane == 0) {
+                winner = 0x7fffffff - (int)(unsigned)(k & 0xffffffffu);
+                const float delta = __uint_as_float((unsigned)(k >> 32));     // max-min distance of the NEXT seed
+                if (n_out && step + 1 >= c_min && step > 0 && delta < drop * prev_delta) stop_at = step + 1;
+                prev_delta = delta;
+            }
         }
         __syncthreads();
         cur = winner;
