@@ -642,7 +642,10 @@ __global__ __launch_bounds__(64, WAVES) void umap_sched_build2_kernel(const Sche
         bad = bad || v > 65535u;
         if (k < K) {
             cnt[k * G2_STRIDE + lr] = ex;  // from here on: the write pointer of segment (k, row)
-            if (lr < nr) P.hdr[(size_t)k * P.n_rows + r0 + lr] = make_uint2((uint32_t)gbase + ex, (v & 0xffffu) | (actl[(k / P.S) * G2_ROWS + lr] << 16));
+            // records and lists are written once and read by the gradient launches of the window: streamed past the L2
+            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+            if (lr < nr) __builtin_nontemporal_store(u32x2_t{(uint32_t)gbase + ex, (v & 0xffffu) | (actl[(k / P.S) * G2_ROWS + lr] << 16)},
+                                                     reinterpret_cast<u32x2_t*>(P.hdr + (size_t)k * P.n_rows + r0 + lr));
             if (lr == 0 && k % (TC * P.S) == 0) tb[k / (TC * P.S)] = ex;
         }
         carry += t0r + t1r + t2r + t3r;
@@ -720,7 +723,7 @@ __global__ __launch_bounds__(64, WAVES) void umap_sched_build2_kernel(const Sche
         if (n_st > (uint32_t)P.stage) n_st = (uint32_t)P.stage;
         if (sbase >= capacity) n_st = 0;
         else if (n_st > capacity - sbase) n_st = capacity - sbase;
-        for (uint32_t i = lane; i < n_st; i += 64) P.list[gbase + sbase + i] = (int32_t)stage[i];
+        for (uint32_t i = lane; i < n_st; i += 64) __builtin_nontemporal_store((int32_t)stage[i], P.list + gbase + sbase + i);
         __syncthreads();
     }
     // the counters of the chunks beyond the register-resident ones (phase 1 left them as they were)
@@ -886,7 +889,9 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
         r = blk * 64 + s_row[slot];
         h = s_hdr[slot];
     } else if (r < P.n_rows) {
-        h = P.hdr[(size_t)(P.t_local * P.S + slice) * P.n_rows + r];
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t hv = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(P.hdr + (size_t)(P.t_local * P.S + slice) * P.n_rows + r));
+        h = make_uint2(hv.x, hv.y);
     }
     // rows beyond the chunk: gone, unless the step is fused into this launch (every thread must reach its barrier)
     const bool fuse = NC == 2 && !PAD && G == 4 && P.joint && P.fuse;
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
         i32x4 l4 = {0, 0, 0, 0};
         if (__ballot(i0 < npos)) {  // wavefront-uniform: rounds made of negatives only skip the read
             const int32_t* lp = lst + (i0 < npos ? i0 : 0);
-            __builtin_memcpy(&l4, lp, 16);
+            __builtin_memcpy(&l4, lp, 16);     // (not streamed: the next round of a long row reads on in the same lines -- measured)
         }
         uint32_t jn[U];
         bool v[U], isp[U];
@@ -1010,7 +1015,9 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
     if (gl == 0 && P.joint) {  // this slice's partial sums; umap_sched_combine_kernel adds the planes in slice order
         float* acc = P.acc + ((size_t)slice * P.n_rows + r) * 2 * nc;
         if (NC == 2 && !PAD) {
-            *reinterpret_cast<float4*>(acc) = make_float4(ga[0], ga[1], gr[0], gr[1]);
+            // streamed out: the planes are read next by the combine kernel (other workgroups, other XCDs) and would only push
+            // lines of this XCD's slice of Z out of its L2
+            __builtin_nontemporal_store(sched_f32x4{ga[0], ga[1], gr[0], gr[1]}, reinterpret_cast<sched_f32x4*>(acc));
         } else {
 #pragma unroll
             for (int c = 0; c < NC; ++c)
