@@ -158,3 +158,45 @@ def test_embedding_padding_and_new_switches_cpu():
             assert dbase._opt("TILE_BOUNDS") is False
         assert dbase._opt("TILE_BOUNDS") == "force"
     assert dbase._opt("TILE_BOUNDS") is True
+
+
+def test_round4_switches_and_float64_eligibility_cpu():
+    """Host logic of round 4 that needs no device: the new behaviour switches are registered with the scoped override and have
+    the documented defaults; which float64 inputs the dense float64 SNEkhorn form takes; the chunk rule shared by the peer
+    exchange and the reference (distributed/__init__.py:209-219)."""
+    import torch
+
+    from torchdr_amd import TSNEkhorn, config
+    from torchdr_amd.affinity.entropic import DensePoints64
+    from torchdr_amd.distributed import chunk_bounds
+    from torchdr_amd.neighbor_embedding import base as nbase
+    from torchdr_amd.neighbor_embedding import umap as umod
+
+    assert umod._opt("GROUPED") is True and umod._opt("BUILD_AHEAD") is False and umod._opt("FUSE_STEP") is False
+    assert umod._opt("SCHED_GEOM") == 16
+    assert nbase._opt("PEER_EXCHANGE") == "auto"
+    with config.options(BUILD_AHEAD=True, FUSE_STEP=True, GROUPED=False, PEER_EXCHANGE=False):
+        assert umod._opt("BUILD_AHEAD") is True and umod._opt("FUSE_STEP") is True and umod._opt("GROUPED") is False
+        assert nbase._opt("PEER_EXCHANGE") is False
+    assert umod._opt("BUILD_AHEAD") is False and nbase._opt("PEER_EXCHANGE") == "auto"
+    with pytest.raises(Exception):
+        with config.options(NO_SUCH_SWITCH=1):
+            pass
+
+    limit = 16384
+    assert DensePoints64.eligible(torch.zeros(100, 16, dtype=torch.float64))
+    assert DensePoints64.eligible(torch.zeros(limit, 2, dtype=torch.float64))
+    assert not DensePoints64.eligible(torch.zeros(limit + 1, 2, dtype=torch.float64))        # dense float64 matrix beyond 2 GiB
+    assert not DensePoints64.eligible(torch.zeros(100, 257, dtype=torch.float64))            # no float64 distance kernel
+    assert not DensePoints64.eligible(torch.zeros(100, 16, dtype=torch.float32))
+    X = torch.zeros(100, 16, dtype=torch.float64)
+    assert TSNEkhorn(n_components=2)._float64_ok(X) and TSNEkhorn(n_components=4)._float64_ok(X)
+    assert not TSNEkhorn(n_components=5)._float64_ok(X)                                    # register instances: 2, 3, 4
+    assert not TSNEkhorn(n_components=2)._float64_ok(torch.zeros(limit + 1, 4, dtype=torch.float64))
+
+    for n, w in ((3001, 2), (8003, 8), (10, 16), (1_000_000, 8)):
+        bounds = [chunk_bounds(n, r, w) for r in range(w)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == n
+        assert all(bounds[r][1] == bounds[r + 1][0] for r in range(w - 1))
+        sizes = [e - s for s, e in bounds]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)      # the first n % w ranks hold one more row
