@@ -351,11 +351,13 @@ int tdr_umap_sched_grad_step_f32(const float* Z, float* Znext, int64_t n_total, 
  * writes its stepped rows into a (fine-grained) staging block of every peer over xGMI, raises a generation flag there, waits
  * for the flags raised at it and copies the staged rows into its embedding; two launches per exchange.  Peers are mapped
  * through HIP IPC handles (tdr_peerx_handles -> any transport -> tdr_peerx_open).  world <= 16, one node.
- * tdr_peerx_allgather_rows has the signature of tdr_umap_loop_desc.gather. */
+ * tdr_peerx_allgather_rows has the signature of tdr_umap_loop_desc.gather (never captured into a graph, see there).
+ * tdr_peerx_error stays 1 once a wait ran out: the context is then to be destroyed on every rank (a new one starts clean). */
 int tdr_peerx_create(void** out, int rank, int world, int64_t capacity_floats);
 int tdr_peerx_handles(void* ctx, void* out128);
 int tdr_peerx_open(void* ctx, const void* all_handles);
 int tdr_peerx_set_rows(void* ctx, int64_t n_total);
+int tdr_peerx_set_wait_limit(void* ctx, int64_t spins);   /* bounded flag wait of a pull (default 2^22 spins, a few seconds) */
 int tdr_peerx_fine_grained(void* ctx);
 int tdr_peerx_allgather_rows(void* ctx, float* Z, int nc, void* stream);
 int tdr_peerx_error(void* ctx);
@@ -367,7 +369,9 @@ int tdr_peerx_destroy(void* ctx);
  * (squared gradient norm at the iterations the reference inspects, :331-349); nan_flag: device int (first NaN iteration
  * + 1, :315); snap: optional (n_rows, nc) copy of the stepped rows taken at those iterations (lets a host that runs whole
  * windows ahead return the state at which the reference stops, :343-349); scratch: >= 4 bytes of device memory; gather: optional `int (*)(void* ctx, float* Z, int nc, void* stream)`
- * run after every step (tdr_ctx_allgather_rows of a tdr_ctx_create context), NULL = single process. */
+ * run after every step (tdr_ctx_allgather_rows of a tdr_ctx_create context, or tdr_peerx_allgather_rows), NULL = single
+ * process.  With a gather callback tdr_umap_loop_run ignores use_graph and enqueues plain launches: the exchange's
+ * generation counter / stage parity are host-side values fixed at enqueue time and must not be replayed. */
 typedef struct tdr_umap_loop_desc {
     float* Z; int nc; int64_t n_total, row0, n_rows;
     const int64_t* rowptr; const int32_t* cols; const float* eps_per; float* next;

@@ -9,8 +9,24 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+AUDIT_ONLY = False      # --tolerance-audit: record every tolerance figure, assert none (a measurement pass, never a test run)
+
+
+def pytest_addoption(parser):
+    parser.addoption("--tolerance-audit", action="store_true", default=False,
+                     help="measurement pass: grade64 / grade32 record their figures to gpurun_out/tolerance_audit.json without "
+                          "asserting the budgets (the run is reported as such; not a parity run)")
+
+
 def pytest_configure(config):
+    global AUDIT_ONLY
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+    AUDIT_ONLY = bool(config.getoption("--tolerance-audit", default=False))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if AUDIT_ONLY:
+        terminalreporter.write_sep("!", "--tolerance-audit: tolerance budgets were RECORDED, NOT ASSERTED -- this is not a parity run")
 
 
 @pytest.fixture(scope="session", autouse=True)
@@ -45,7 +61,7 @@ def grade64(name, got, ref64, budget=1e-5):
     ref64 = ref64.double().cpu()
     err = float((got.detach().double().cpu() - ref64).abs().max() / ref64.abs().max())
     AUDIT[name] = {"err_vs_float64": err, "budget": budget}
-    if os.environ.get("TDR_AUDIT_ONLY") != "1":      # measurement pass: record every figure, assert nothing
+    if not AUDIT_ONLY:      # --tolerance-audit (an explicit command-line option, never the environment): record, assert nothing
         assert err <= budget, (name, err, budget)
     return err
 
@@ -55,7 +71,7 @@ def grade32(name, got, ref32, budget=1e-5):
     ref32 = ref32.double().cpu()
     err = float((got.detach().double().cpu() - ref32).abs().max() / ref32.abs().max())
     AUDIT[name] = {"err_vs_reference_float32": err, "budget": budget}
-    if os.environ.get("TDR_AUDIT_ONLY") != "1":
+    if not AUDIT_ONLY:
         assert err <= budget, (name, err, budget)
     return err
 

@@ -236,8 +236,15 @@ class AffinityMatcher(DRModule):
 
             allreduce_max_(bad)
             if int(bad.item()) != 0:
+                # every rank is here (the flag was agreed): drop the exchange everywhere -- its error word, flags and
+                # generation counters die with it -- so that later fits of this process do not inherit the failure
+                from torchdr_amd.parallel import PeerExchange
+
+                PeerExchange.retire_shared()
+                self._rccl_ctx = None
                 raise RuntimeError("[torchdr_amd] peer exchange: a rank's rows did not arrive within the wait limit "
-                                   "(neighbor_embedding.base.PEER_EXCHANGE = False selects the RCCL all-gather).")
+                                   "(a rank fell behind by more than parallel.PeerExchange.WAIT_LIMIT spins, or was lost); the exchange has "
+                                   "been retired for this process group: later fits use the RCCL all-gather.")
 
     # ------------------------------------------------------------------------------------------
     def _training_step(self):

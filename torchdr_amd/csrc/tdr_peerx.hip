@@ -46,6 +46,7 @@ struct PeerX {
     int gen;
     int fine_grained;
     bool opened;
+    long long spin_limit;       // bounded flag wait of the pull kernel (tdr_peerx_set_wait_limit)
 };
 
 struct PushParams {
@@ -85,6 +86,7 @@ struct PullParams {
     int64_t total;              // n_total * nc
     int world, rank, gen;
     int* err;
+    long long spin_limit;
 };
 
 __global__ __launch_bounds__(256) void peerx_pull_kernel(const PullParams P) {
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void peerx_pull_kernel(const PullParams P) {
         // generations only grow: "reached" = not behind (wrap-safe signed difference)
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - P.gen < 0) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > PX_SPIN_LIMIT) { atomicExch(P.err, 1); break; }
+            if (++spins > P.spin_limit) { atomicExch(P.err, 1); break; }
         }
     }
     __syncthreads();
@@ -122,7 +124,7 @@ int tdr_peerx_create(void** out, int rank, int world, int64_t capacity_floats) {
     if (!out || world < 2 || world > PX_MAX_WORLD || rank < 0 || rank >= world || capacity_floats <= 0) return TDR_ERR_BAD_ARG;
     PeerX* c = new PeerX();
     memset(c, 0, sizeof(PeerX));
-    c->rank = rank; c->world = world; c->capacity = capacity_floats; c->gen = 0; c->opened = false;
+    c->rank = rank; c->world = world; c->capacity = capacity_floats; c->gen = 0; c->opened = false; c->spin_limit = PX_SPIN_LIMIT;
     const size_t sbytes = 2 * (size_t)capacity_floats * sizeof(float);
     const size_t fbytes = (size_t)(PX_MAX_WORLD * PX_FLAG_STRIDE + 64) * sizeof(int);
     c->fine_grained = 1;
@@ -187,6 +189,16 @@ int tdr_peerx_set_rows(void* ctx, int64_t n_total) {
     return TDR_OK;
 }
 
+/* Spins (each ~ an s_sleep(8) + one system-scope load) a pull waits for a peer's flag before it gives up and sets the error
+ * word; the default (2^22, a few seconds) bounds the time a lost peer can hold the device.  Ranks that time-slice one device
+ * or a slow host may legitimately fall further behind: raise it there. */
+int tdr_peerx_set_wait_limit(void* ctx, int64_t spins) {
+    PeerX* c = (PeerX*)ctx;
+    if (!c || spins < 1) return TDR_ERR_BAD_ARG;
+    c->spin_limit = (long long)spins;
+    return TDR_OK;
+}
+
 int tdr_peerx_fine_grained(void* ctx) { return ctx ? ((PeerX*)ctx)->fine_grained : 0; }
 
 /* In-place all-gather of the row chunks of Z (n_total, nc) -- tdr_ctx_allgather_rows's contract and callback signature
@@ -212,7 +224,7 @@ int tdr_peerx_allgather_rows(void* ctx, float* Z, int nc, void* stream) {
     hipLaunchKernelGGL(peerx_push_kernel, dim3((unsigned)pb), dim3(256), 0, st, P);
     PullParams Q;
     Q.Z = Z; Q.stage = c->stage[par][c->rank]; Q.flags = c->flags[c->rank]; Q.own_off = start * nc; Q.own_count = rows * nc;
-    Q.total = c->n_total * nc; Q.world = c->world; Q.rank = c->rank; Q.gen = gen; Q.err = c->err;
+    Q.total = c->n_total * nc; Q.world = c->world; Q.rank = c->rank; Q.gen = gen; Q.err = c->err; Q.spin_limit = c->spin_limit;
     int64_t qb = (Q.total + 2047) / 2048;
     if (qb < 1) qb = 1;
     if (qb > 128) qb = 128;      // few blocks: they spin, and ranks that share a device (tests) must still get CUs

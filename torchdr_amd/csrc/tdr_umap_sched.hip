@@ -1720,11 +1720,16 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
 }
 
 /* Run iterations [it0, it0 + n_iters) (n_iters >= 1; it0 + n_iters <= max_iter).  use_graph != 0: windows are captured
- * into HIP graphs on first use (at most two distinct window lengths are kept) and replayed; 0: plain launches. */
+ * into HIP graphs on first use (at most two distinct window lengths are kept) and replayed; 0: plain launches.  A loop
+ * created with a `gather` callback always runs plain launches (use_graph is ignored): see below. */
 int tdr_umap_loop_run(void* loop, int it0, int n_iters, int use_graph, void* stream) {
     UmapLoop* L = (UmapLoop*)loop;
     if (!L || it0 < 0 || n_iters <= 0 || it0 + n_iters > L->max_iter) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    // A window with a row exchange is never captured: the exchange's arguments are not replayable (tdr_peerx_allgather_rows
+    // bakes its generation number and stage parity into the kernel arguments at enqueue time -- a replayed pull would find its
+    // flags already raised and copy stale rows; a communicator call belongs to its library's own capture rules).
+    if (L->gather) use_graph = 0;
     int it = it0;
     while (it < it0 + n_iters) {
         const int n = (it0 + n_iters - it < L->B) ? it0 + n_iters - it : L->B;

@@ -261,13 +261,20 @@ class NeighborEmbedding(AffinityMatcher):
         px = _opt("PEER_EXCHANGE")
         if px == "auto":
             px = torch.cuda.is_available() and self.world_size > torch.cuda.device_count()
+        # only estimators whose step exchanges ROWS use a context (closed-form gradients of the chunk's rows: UMAP and user
+        # subclasses following the reference's contract, affinity_matcher.py:384-413); LargeVis / TSNE / SNE all-reduce a full
+        # gradient and COSNE gathers through torch.distributed -- they would pay the IPC mapping, the stress self-check and the
+        # staging memory for nothing
+        uses_rows = bool(getattr(self, "_use_closed_form_gradients", False))
+        if not uses_rows:
+            px = False
         if self.world_size > 1 and px and torch.cuda.is_available() and getattr(self, "_dtype", torch.float32) == torch.float32:
             # the rows every rank stepped travel as direct peer writes (csrc/tdr_peerx.hip); None when the peers cannot be
             # mapped or the stress self-check fails on any rank
             from torchdr_amd.parallel import PeerExchange
 
             self._rccl_ctx = PeerExchange.shared(self.n_samples_in_, self.n_components, self.device_)
-        if self._rccl_ctx is None and self.world_size > 1 and _opt("RCCL_CONTEXT") and dist.get_backend() == "nccl" and torch.cuda.is_available():
+        if self._rccl_ctx is None and uses_rows and self.world_size > 1 and _opt("RCCL_CONTEXT") and dist.get_backend() == "nccl" and torch.cuda.is_available():
             from torchdr_amd.parallel import RcclContext
 
             self._rccl_ctx = RcclContext.shared(self.n_samples_in_, self.device_)   # one communicator per process

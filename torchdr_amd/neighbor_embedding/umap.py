@@ -484,8 +484,12 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         from torchdr_amd.neighbor_embedding.base import NeighborEmbedding
 
         cls = type(self)
+        # the deferred combine + step writes the gradient only at the inspected iterations: anything that could look at
+        # `_last_grad` in between (the step hooks, an own norm / convergence test, an own loop) keeps the undeferred form
         stock = (("on_training_step_end", NeighborEmbedding), ("_training_step", AffinityMatcher), ("_optimizer_step", AffinityMatcher),
-                 ("_sgd_kernel", UMAP), ("_compute_gradients", UMAP), ("_compute_gradients_scheduled", UMAP))
+                 ("_sgd_kernel", UMAP), ("_compute_gradients", UMAP), ("_compute_gradients_scheduled", UMAP),
+                 ("on_training_step_start", NegativeSamplingNeighborEmbedding), ("_grad_norm", AffinityMatcher),
+                 ("_converged", AffinityMatcher), ("_run_training_loop", UMAP))
         return all(getattr(cls, name) is getattr(owner, name) for name, owner in stock)
 
     def _sgd_kernel(self, Z, grad, chunk=False):

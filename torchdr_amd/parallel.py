@@ -286,11 +286,17 @@ class RcclContext:
     def _group_token():
         """Identity of the current default process group: a communicator belongs to the group it was bootstrapped in -- after
         destroy_process_group() / init_process_group() (tests, elastic restarts) the same (device, world, rank) may name
-        other peers."""
+        other peers.  A counter, not id(): the object of the group a token was issued for is kept alive until another group
+        takes its place, so a new group can never be handed the address -- and with it the communicator or the IPC mappings
+        -- of a dead one."""
+        global _GROUP_SEEN
         try:
-            return id(dist.distributed_c10d._get_default_group())
+            pg = dist.distributed_c10d._get_default_group()
         except Exception:
             return None
+        if _GROUP_SEEN is None or _GROUP_SEEN[0] is not pg:
+            _GROUP_SEEN = (pg, (_GROUP_SEEN[1] + 1) if _GROUP_SEEN is not None else 1)
+        return _GROUP_SEEN[1]
 
     @classmethod
     def shared(cls, n_total: int, device):
@@ -368,6 +374,9 @@ class RcclContext:
             self.handle = None
 
 
+_GROUP_SEEN = None      # (default process group object, its token): see RcclContext._group_token
+
+
 class PeerExchange:
     """``tdr_peerx_*`` (csrc/tdr_peerx.hip): the per-iteration all-gather of the rows every rank stepped as direct peer writes
     over xGMI -- each rank stores its chunk into a staging block of every peer (all links at once), raises a generation flag,
@@ -377,7 +386,9 @@ class PeerExchange:
     ANY rank: callers then keep RCCL / torch.distributed."""
 
     _shared = {}
+    _retired = set()        # process-group tokens whose exchange failed once: later fits of that group use RCCL / torch.distributed
     SELF_CHECK_ROUNDS = 12
+    WAIT_LIMIT = None       # spins of the bounded flag wait (None = the library's default, a few seconds); tdr_peerx_set_wait_limit
 
     def __init__(self, handle, n_total, capacity):
         import ctypes
@@ -415,6 +426,8 @@ class PeerExchange:
             opened = L.tdr_peerx_open(handle, blob) == 0
         ctx = cls(handle, n_total, capacity)
         L.tdr_peerx_set_rows(handle, n_total)
+        if cls.WAIT_LIMIT is not None:
+            L.tdr_peerx_set_wait_limit(handle, int(cls.WAIT_LIMIT))
         good = opened and ctx._self_check(device, rank, world)
         flag = torch.tensor([1.0 if good else 0.0], device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)     # every rank keeps the exchange or none does
@@ -454,6 +467,8 @@ class PeerExchange:
         token = RcclContext._group_token()
         for k in [k for k in cls._shared if k[3] != token]:
             cls._shared.pop(k).destroy()
+        if token in cls._retired:
+            return None
         key = (torch.device(device).index, dist.get_world_size(), dist.get_rank(), token)
         ctx = cls._shared.get(key)
         if ctx is not None and int(n_total) * int(nc) > ctx.capacity:
@@ -478,6 +493,17 @@ class PeerExchange:
         for ctx in cls._shared.values():
             ctx.destroy()
         cls._shared.clear()
+
+    @classmethod
+    def retire_shared(cls):
+        """After a wait of the exchange ran into its limit (every rank agreed on it, affinity_matcher._raise_if_nan): the
+        contexts are destroyed on all ranks -- stages, flags, the device-side error word and the host-side generation counters
+        go with them, so nothing of the failed exchange can leak into a later fit -- and the current process group falls back
+        to the RCCL all-gather / torch.distributed for the rest of its life."""
+        cls.destroy_shared()
+        token = RcclContext._group_token()
+        if token is not None:
+            cls._retired.add(token)
 
     def allgather_rows_(self, Z: torch.Tensor):
         from torchdr_amd import _lib
