@@ -180,6 +180,36 @@ int tdr_knn_screen_clustered_tb_f32(const float* x16, const float* X, int64_t ld
  * down; row_map (rows): source row or -1; xn (rows), cn (C): squared norms */
 int tdr_cluster_tile_cdist_f32(const float* d2, int64_t ld, int64_t rows, int C, int d, const int32_t* row_map, const float* xn,
                                const float* cn, float* out, void* stream);
+/* The UNPRUNED two-stage search as a threshold scan (round 5, csrc/tdr_knn_flat.hip; replaces the list-keeping kernel where no
+ * tile can be skipped -- distance/torch.py:82-122 on structureless data, benchmarks/faiss/run_benchmark.py:143-146):
+ * pilot (list-keeping kernel on the first 1/64 of the database) -> per-query threshold tau = a_(k) + 2E -> three passes of
+ * tdr_knn_flat_scan_f32 (every candidate with screening value <= tau is appended to the query's buffer; no lists in LDS, two
+ * query tiles per wavefront, two database tiles per barrier) with a tdr_knn_flat_select_f32 after each (list + appended -> the L
+ * smallest, new tau) -> the rescoring kernel.  Same operands, outputs and flag contract as tdr_knn_screen_f32; results are
+ * bit-identical.  terms: 1 (h.h') or 3; L: list length per query (k <= L <= 128).  The workspace query returns 0 when the
+ * threshold scan does not serve the search (D > 128, fewer than 4096 database tiles, unsupported terms / L). */
+int tdr_knn_flat_supported(int d);
+int64_t tdr_knn_screen_flat_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, int terms, int L);
+int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
+                            const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
+                            int metric, int exclude_self, int terms, int L, const uint32_t* meta, float* out_d, int32_t* out_i,
+                            int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
+/* its stages, exposed for tests and measurement.  scan: buf (nq, cap) keys (screening value bits << 32 | database row),
+ * cnt (nq) candidates met by THIS launch (> cap: the surplus was dropped); terms 1, 2 (h.h' + h.l') or 3; shape 0.
+ * select: list (nq, L) in/out ascending, sentinel 0xFF800000FFFFFFFF; extra = the scan's buf with extra_cnt = cnt (n_sets 1,
+ * stride cap), or n_sets x (nq, stride) full lists with extra_cnt NULL (then guard (nq) = the smallest last entry of a full
+ * set); tau (nq) out = min(a_(k) + 2E, a_(L) when full); lost (nq) set to 1 where cnt > stride. */
+int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
+                          int exclude_self, int tile_begin, int tile_end, const uint32_t* meta, const float* tau, uint64_t* buf,
+                          int32_t* cnt, int cap, int shape, void* stream);
+int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra, const int32_t* extra_cnt, int n_sets,
+                            int stride, const float* norms_q, const uint32_t* meta, int64_t nq, int d, int k, int L, int terms,
+                            float* tau, int32_t* lost, float* guard, void* stream);
+/* tdr_knn_screen_f32 in pilot mode (predict_unsplit = 1) with the prediction made for lists of pred_L entries */
+int tdr_knn_screen_pilot_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
+                             const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
+                             int metric, int exclude_self, int tier, int pred_L, const uint32_t* meta, float* out_d,
+                             int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
 /* Approximate IVF-style self search on the same cluster index (distance/faiss.py:331-349: nlist = n_clusters, nprobe):
  * a workgroup scans its own clusters and then the nearest ones, nprobe scans in all; candidates are rescored exactly.
  * out_d / out_i must be pre-filled by the caller (+inf / -1): rows with fewer than k candidates keep that tail. */

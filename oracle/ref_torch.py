@@ -611,3 +611,84 @@ def hyperbolic_init(noise, init_scaling=0.5):
     u = init_scaling * noise
     un = u.norm(dim=-1, keepdim=True).clamp_min(1e-15)
     return un.clamp(-15, 15).tanh() * u / un
+
+
+# --------------------------------------------------------------------------------------------
+# Approximate search -- distance/faiss.py:331-349 (IndexIVFFlat: nlist inverted lists, nprobe probed per query)
+# --------------------------------------------------------------------------------------------
+
+
+def ivf_search(X, row_map, tile_cluster, clus_dist, nprobe, k, metric="sqeuclidean", exclude_self=True, group_tiles=4):
+    """Deterministic restatement of an inverted-file search on a GIVEN index (Faiss is absent from the image; the reference
+    hands ``FaissConfig(index_type="IVF", nlist, nprobe)`` to ``faiss.IndexIVFFlat``, distance/faiss.py:331-349, whose
+    published algorithm is: assign every point to its nearest centroid's list, probe the ``nprobe`` lists whose centroids are
+    nearest, return the exact top-k over the union of the probed lists).
+
+    The index is the input (``row_map``: list-sorted, tile-padded row order, -1 = padding; ``tile_cluster``: list of every
+    32-row tile; ``clus_dist``: (nlist, nlist) centre distances) -- the restatement does not cluster.  Probe rule, as
+    documented for ``tdr_knn_ivf_f32``: queries are taken in blocks of ``group_tiles`` consecutive 32-row tiles of the sorted
+    order; a block probes the lists of its own tiles (all of them together are probe 1) and then the ``nprobe - 1`` other lists
+    in increasing (distance of the list's centre to the NEAREST of the block's own centres, list id) order.  Result per query:
+    exact top-k over the rows of the probed lists with the reference's arithmetic (``oracle.knn``: distance/torch.py:82-122)
+    in canonical (distance, index) order, self excluded (distance/torch.py:111-116); a query that finds fewer than k
+    candidates is searched exactly against all rows (Faiss would pad with -1; the package never lets -1 reach the affinity
+    stages).  Returns (C (n, k) float32, I (n, k) int32, short (n,) bool = rows that took the exact fallback)."""
+    import oracle
+
+    X = X.detach().cpu().contiguous().float()
+    row_map = row_map.detach().cpu().long()
+    tile_cluster = tile_cluster.detach().cpu().long()
+    clus_dist = clus_dist.detach().cpu().float()
+    n = X.shape[0]
+    nlist = clus_dist.shape[0]
+    n_tiles = tile_cluster.numel()
+    img_cluster = tile_cluster.repeat_interleave(32)[: row_map.numel()]
+    valid = row_map >= 0
+    cluster_of_row = torch.empty(n, dtype=torch.long)
+    cluster_of_row[row_map[valid]] = img_cluster[valid]
+    members = [torch.sort((cluster_of_row == c).nonzero().squeeze(1)).values for c in range(nlist)]
+    C = torch.empty((n, k), dtype=torch.float32)
+    I = torch.empty((n, k), dtype=torch.int32)
+    short = torch.zeros(n, dtype=torch.bool)
+    bits = clus_dist.clamp(min=0).contiguous().view(torch.int32).long()      # the kernel orders by the float's bit pattern
+    for t0 in range(0, n_tiles, group_tiles):
+        own = torch.unique(tile_cluster[t0:t0 + group_tiles])
+        key = bits[own].min(0).values                                         # (nlist,) distance to the nearest own centre
+        order = sorted(range(nlist), key=lambda c: (int(key[c]), c))
+        probed, others = [], 0
+        for c in order:
+            if int(key[c]) == 0:
+                probed.append(c)                                              # own lists (and centres that coincide with one)
+            elif others < nprobe - 1:
+                probed.append(c)
+                others += 1
+        cand = torch.sort(torch.cat([members[c] for c in probed])).values   # ascending source index: ties break as in the full search
+        q = row_map[t0 * 32:(t0 + group_tiles) * 32]
+        q = q[q >= 0]
+        if q.numel() == 0:
+            continue
+        Yc = X[cand]
+        # one call per block: top-(k + 1) WITHOUT exclusion in canonical order, then the query's own row is taken out of its
+        # list (dropping one entry of a canonical top-(k + 1) leaves the canonical top-k of the rest)
+        pos = torch.searchsorted(cand, q)
+        member = (pos < cand.numel()) & (cand[pos.clamp(max=cand.numel() - 1)] == q)
+        drop_self = member & bool(exclude_self)
+        avail = cand.numel() - drop_self.long()
+        ok = avail >= k
+        short[q[~ok]] = True
+        if not bool(ok.any()):
+            continue
+        kk = min(k + 1, cand.numel())
+        c1, i1 = oracle.knn(X[q[ok]], kk, metric, False, Y=Yc)
+        src = cand[i1.long()]
+        qs = q[ok]
+        keep = src != qs[:, None] if exclude_self else torch.ones_like(src, dtype=torch.bool)
+        for r in range(qs.numel()):
+            sel = keep[r].nonzero().squeeze(1)[:k]
+            C[qs[r]] = c1[r, sel]
+            I[qs[r]] = src[r, sel].int()
+    rows = short.nonzero().squeeze(1)
+    for qi in rows.tolist():
+        c1, i1 = oracle.knn(X[qi:qi + 1], k, metric, exclude_self, Y=X, q_offset=qi)
+        C[qi], I[qi] = c1[0], i1[0]
+    return C, I, short

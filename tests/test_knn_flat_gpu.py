@@ -1,0 +1,120 @@
+"""The unpruned two-stage search as a threshold scan (csrc/tdr_knn_flat.hip; round 5) -- the same results as the
+list-keeping kernel, the one-stage exact kernel and the CPU oracle, bit for bit: reference distance/torch.py:82-122
+(`pairwise_distances_torch` + `kmin`), the unstructured benchmark set of benchmarks/faiss/run_benchmark.py:143-146."""
+
+import ctypes
+
+import pytest
+import torch
+
+from tests.conftest import gmm
+
+pytestmark = pytest.mark.gpu
+
+
+def _search(X, k, metric="sqeuclidean", **opts):
+    from torchdr_amd import config
+    from torchdr_amd.distance import base as dbase
+    from torchdr_amd.distance import pairwise_distances
+
+    with config.options(**opts):
+        C, I = pairwise_distances(X, metric=metric, k=k, exclude_diag=True, return_indices=True)
+    return C, I, dict(dbase.LAST_KNN)
+
+
+@pytest.mark.parametrize("scale,d,k,metric", [(0.0, 128, 15, "sqeuclidean"), (2.0, 64, 30, "euclidean"), (1.0, 20, 10, "sqeuclidean"),
+                                              (6.0, 128, 30, "sqeuclidean")])
+def test_flat_scan_equals_list_kernel_and_exact(scale, d, k, metric):
+    """140k points (4375 tiles: just above the threshold scan's minimum), unpruned: threshold scan == list-keeping kernel ==
+    one-stage kernel on distances AND indices; 256 sampled rows == the CPU oracle."""
+    import oracle
+
+    n = 140_000
+    X = gmm(n, d, scale, seed=17).cuda()
+    Cf, If, info_f = _search(X, k, metric, PRUNE_MODE="0", FLAT_SCAN=True)
+    assert info_f["path"] == "screen" and info_f.get("flat_terms") in (1, 3), info_f
+    Cl, Il, info_l = _search(X, k, metric, PRUNE_MODE="0", FLAT_SCAN=False)
+    assert info_l.get("flat_terms") == 0
+    assert torch.equal(If, Il) and torch.equal(Cf, Cl)
+    Ce, Ie, _ = _search(X, k, metric, PRUNE_MODE="0", SCREEN_MODE="0")
+    assert torch.equal(If, Ie) and torch.equal(Cf, Ce)
+    rows = torch.arange(0, n, n // 256)[:256]
+    Xc = X.cpu()
+    for r in rows.tolist()[:64]:
+        Co, Io = oracle.knn(Xc[r:r + 1], k, metric, True, Y=Xc, q_offset=r)
+        assert torch.equal(If[r].cpu(), Io[0]) and torch.equal(Cf[r].cpu(), Co[0])
+
+
+def test_flat_scan_with_duplicates_and_flagged_rows():
+    """Exact duplicates (more copies than a list holds) overflow the band of their queries: those rows are flagged and
+    recomputed exactly; every row equals the one-stage kernel."""
+    n, d, k = 140_000, 32, 12
+    X = gmm(n, d, 1.5, seed=3)
+    X[1000:1400] = X[999]            # 401 identical points: their band holds > 128 candidates
+    X[5000:5040] = X[4999]           # 41 identical points: fits the lists
+    X = X.cuda()
+    Cf, If, info = _search(X, k, PRUNE_MODE="0", FLAT_SCAN=True)
+    assert info.get("flat_terms") in (1, 3) and info["flagged"] >= 400
+    Ce, Ie, _ = _search(X, k, PRUNE_MODE="0", SCREEN_MODE="0")
+    assert torch.equal(Cf, Ce) and torch.equal(If, Ie)
+
+
+def test_flat_stages_scan_and_select():
+    """tdr_knn_flat_scan_f32 / tdr_knn_flat_select_f32 on their own: with tau = +inf for a few queries and a tiny capacity the
+    count says what was met and `lost` is raised; with real thresholds the select returns the ascending L smallest of list +
+    appended (checked against a sort on the host)."""
+    from torchdr_amd import _lib
+    from torchdr_amd.distance import base as dbase
+
+    L = _lib.lib()
+    n, d, k, LL, cap = 140_000, 64, 10, 32, 64
+    X = gmm(n, d, 1.0, seed=5).cuda()
+    P = dbase.PackedPoints(X)
+    q16, y16, meta = dbase._screen_operands(P, P)
+    nq = 4096
+    tau = torch.full((nq,), 40.0, device="cuda")        # sq. distances inside a blob are ~ 2 * 64 * 0.25 = 32
+    tau[:8] = float("inf")
+    buf = torch.zeros((nq, cap), dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    n_tiles = (n + 31) // 32
+    for terms in (1, 2, 3):
+        _lib.check(L.tdr_knn_flat_scan_f32(_lib.ptr(q16), nq, 0, _lib.ptr(y16), n, d, terms, 1, 100, 1101, _lib.ptr(meta), _lib.ptr(tau),
+                                           _lib.ptr(buf), _lib.ptr(cnt), cap, 0, _lib.stream_ptr()), "scan")
+        c = cnt.cpu()
+        assert bool((c[:8] >= 1001 * 32 - 1).all())         # tau = inf: every row of the 1001 tiles (minus the query itself)
+        # reference: exact squared distances of the same block, thresholded with slack for the screening error
+        D = torch.cdist(X[:nq].double(), X[3200:35232].double()) ** 2
+        lo = (D <= 40.0 - 0.5).sum(1).cpu()
+        hi = (D <= 40.0 + 0.5).sum(1).cpu()
+        assert bool((c[8:] >= lo[8:] - 1).all()) and bool((c[8:] <= hi[8:]).all()), terms
+        # appended keys: value within the band of the exact distance of (query, row)
+        b = buf.cpu()
+        for qi in (8, 100, 4095):
+            m = min(int(c[qi]), cap)
+            if m == 0:
+                continue
+            keys = b[qi, :m]
+            rows = (keys & 0xFFFFFFFF).long()
+            bits = ((keys >> 32) & 0xFFFFFFFF)
+            bits = torch.where(bits >= 0x80000000, bits & 0x7FFFFFFF, (~bits) & 0xFFFFFFFF).to(torch.int32)
+            vals = bits.view(torch.float32)
+            ref = ((X[qi].double() - X[rows.cuda()].double()) ** 2).sum(1).cpu()
+            assert bool((rows >= 3200).all()) and bool((rows < 35232).all()) and bool((rows != qi).all())
+            assert torch.allclose(vals.double(), ref, atol=0.5), terms
+    # select: list (empty) + appended -> the LL smallest ascending
+    lst = torch.zeros((nq, LL), dtype=torch.int64, device="cuda")
+    tau2 = torch.empty(nq, device="cuda")
+    lost = torch.zeros(nq, dtype=torch.int32, device="cuda")
+    _lib.check(L.tdr_knn_flat_select_f32(_lib.ptr(lst), 0, _lib.ptr(buf), _lib.ptr(cnt), 1, cap, _lib.ptr(P.norms), _lib.ptr(meta), nq, d, k, LL,
+                                         3, _lib.ptr(tau2), _lib.ptr(lost), None, _lib.stream_ptr()), "select")
+    c, b, ls, lo_ = cnt.cpu(), buf.cpu(), lst.cpu(), lost.cpu()
+    SENT = -0x7FFFFF00000001     # 0xFF800000FFFFFFFF as int64
+    for qi in (0, 8, 9, 100, 2000, 4095):
+        m = min(int(c[qi]), cap)
+        assert int(lo_[qi]) == (1 if int(c[qi]) > cap else 0)
+        # keys compare as UNSIGNED 64-bit numbers
+        want = sorted((int(x) & 0xFFFFFFFFFFFFFFFF) for x in b[qi, :m].tolist())[:LL]
+        got = [int(x) & 0xFFFFFFFFFFFFFFFF for x in ls[qi].tolist()]
+        assert got[:len(want)] == want
+        assert all(g == 0xFF800000FFFFFFFF for g in got[len(want):])
+    assert SENT < 0

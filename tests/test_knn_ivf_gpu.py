@@ -170,3 +170,26 @@ def test_ivf_search_at_ten_million_points():
     hit = I[rows][ok] == Ie_k           # where the same neighbour sits in the same slot, the distance is the exact one
     assert torch.equal(C[rows][ok][hit], Ce_k[hit])
     assert sec < 30.0
+
+
+@pytest.mark.parametrize("metric", ["sqeuclidean", "euclidean"])
+def test_ivf_equals_the_cpu_restatement_on_the_same_index(metric):
+    """the approximate search pinned to a CPU restatement (oracle/ref_torch.py:ivf_search -- probe rule +
+    exact top-k over the probed lists with the reference's arithmetic + exact fallback for short rows).  The restatement is
+    fed the HIP index's own tables (sorted order, list of every tile, centre distances); indices AND distances must be equal
+    bit for bit at nprobe = 1, 8 and nlist."""
+    from oracle import ref_torch as R
+    from torchdr_amd.distance import base as dbase
+
+    n, d, k, nlist = 20000, 24, 10, 128
+    X = (gmm(n, d, 1.0, seed=11) + 0.3 * torch.randn(n, d, generator=torch.Generator().manual_seed(2))).cuda()
+    Yp = dbase.PackedPoints(X)
+    for nprobe in (1, 8, nlist):
+        C, I = dbase._knn_ivf(Yp, k, metric, True, nlist, nprobe)
+        ci = Yp._ivf_index[nlist]
+        assert ci.n_clusters == nlist
+        Co, Io, short = R.ivf_search(X.cpu(), ci.row_map, ci.tile_cluster, ci.dist.view(nlist, nlist), nprobe, k, metric, True)
+        # rows the kernel could not fill (fewer than k candidates in the probed lists) and ONLY those were searched exactly
+        assert dbase.LAST_KNN["flagged"] == int(short.sum()), (nprobe, dbase.LAST_KNN["flagged"], int(short.sum()))
+        assert torch.equal(I.cpu(), Io), (nprobe, float((I.cpu() != Io).float().mean()))
+        assert torch.equal(C.cpu(), Co), nprobe

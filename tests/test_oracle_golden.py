@@ -495,3 +495,40 @@ def test_riemannian_adam_optimizer_vs_reference():
     with pytest.raises(RuntimeError, match="does not support sparse gradients"):
         o.step()
     o.stabilize_group(grp)     # plain tensors and untouched parameters: nothing to do, no error
+
+
+def test_ivf_restatement_is_the_exact_search_when_every_list_is_probed():
+    """oracle.ref_torch.ivf_search (the CPU checker of tdr_knn_ivf_f32; Faiss is absent, distance/faiss.py:331-349): with
+    nprobe = nlist the union of the probed lists is the whole set, so the result must be the exact search's (itself pinned to
+    the reference's golden kNN above); fewer probes can only lose neighbours, never invent or mis-measure one."""
+    import oracle
+    from oracle import ref_torch as R
+
+    torch.manual_seed(3)
+    n, d, k, nlist = 2500, 12, 7, 10
+    X = torch.randn(n, d) + 3.0 * torch.randn(nlist, d)[torch.arange(n) % nlist]
+    cent = X[:nlist].clone()
+    assign = ((X[:, None, :] - cent[None]) ** 2).sum(-1).argmin(1)
+    row_map, tile_cluster = [], []
+    for c in range(nlist):
+        m = (assign == c).nonzero().squeeze(1).tolist()
+        pad = (-len(m)) % 32
+        row_map += m + [-1] * pad
+        tile_cluster += [c] * ((len(m) + pad) // 32)
+    row_map, tile_cluster = torch.tensor(row_map), torch.tensor(tile_cluster)
+    cd = torch.cdist(cent, cent)
+    for metric in ("sqeuclidean", "euclidean"):
+        Ce, Ie = oracle.knn(X, k, metric, True)
+        C, I, short = R.ivf_search(X, row_map, tile_cluster, cd, nlist, k, metric)
+        assert torch.equal(C, Ce) and torch.equal(I, Ie) and int(short.sum()) == 0
+        prev = 0.0
+        for nprobe in (1, 3, nlist):
+            C1, I1, _ = R.ivf_search(X, row_map, tile_cluster, cd, nprobe, k, metric)
+            hit = (I1[:, :, None] == Ie[:, None, :]).any(2)
+            rec = float(hit.float().mean())
+            assert rec >= prev - 1e-9
+            prev = rec
+            # every returned pair carries the exact distance of that pair
+            full = oracle.knn(X, 0, metric, False, want_full=True)[2]
+            assert torch.equal(C1, torch.gather(full, 1, I1.long()))
+        assert prev == 1.0

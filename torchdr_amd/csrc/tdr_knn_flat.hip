@@ -1,0 +1,518 @@
+// K1f -- the UNPRUNED screening scan of the two-stage exact kNN as a THRESHOLD scan (round 5).
+//
+// tdr_knn_screen.hip keeps, per query, a sorted list of the L smallest screening values in LDS and inserts into it while
+// it scans: 48-63 KiB of lists per workgroup (so 128 queries per workgroup, a barrier per 32 database rows, 8 matrix
+// instructions per barrier and wavefront in the one-term tier), ~450 cycles per insertion, and a matrix pipe that is busy
+// 53 % of the time (profiles/r01_knn_screen_pmc.json).  That form is right for the cluster-pruned scan, whose thresholds must
+// tighten WHILE it decides what to skip.  A scan that visits every tile anyway does not need lists:
+//
+//   pilot     the list-keeping kernel scans a small prefix of the database (1/64): the k-th smallest screening value a query
+//             meets there is an upper bound of its k-th smallest over the whole database;
+//   scan      (this file) the rest of the database is scanned against that FIXED per-query threshold tau = a_(k) + 2E: a
+//             candidate is one fma + min tree + compare, and a survivor (a <= tau; a few hundred per query over the whole scan)
+//             is appended to the query's buffer in HBM -- no lists, no insertion, nothing in LDS but the staged tiles;
+//   select    one wavefront per query merges (list so far + appended) into the L smallest, sorted, and re-derives tau; the scan
+//             runs in three passes over growing ranges ([1/64, 1/16), [1/16, 1/4), [1/4, 1)) with a select in between, so
+//             every pass appends ~3k entries per query;
+//   rescore   the unchanged knn_rescore_kernel of tdr_knn_screen.hip on the final lists.
+//
+// Exactness is the list kernel's argument verbatim (tdr_knn_screen.hip header): tau_q >= a_(k)(whole database) + 2E at every
+// moment, so every true neighbour passes; what a select drops lies beyond the L smallest seen so far and can never return;
+// the rescoring kernel flags a query whose final list is full inside its band, and the host recomputes it exactly.
+//
+// What the freed LDS and registers buy: a wavefront holds TWO query tiles (QB = 2: 64 queries, the database fragments are
+// read from LDS once for both), a step stages TWO database tiles (TPB = 2), so a barrier interval carries 4 blocks of 8
+// (one term) .. 16 (two terms) matrix instructions instead of one; the finished block's 16 fma + min tree per lane runs in the
+// shadow of the next block's matrix instructions (two accumulator sets, roles fixed at compile time: no register moves);
+// with no list length to fit, the ONE-term tier (h.h' only, a third of the matrix work) serves data whose band holds up to
+// ~100 candidates (lists of 128 live in HBM), the two-term tier (h.h' + h.l', band 2^-11 |x||y|) the rest.
+#include "tdr_common.h"
+#include "tdr_knn_screen_common.h"
+
+namespace tdr {
+namespace flat {
+
+using scr::f16x8;
+using scr::gptr_t;
+using scr::lptr_t;
+using scr::KEY_SENTINEL;
+
+constexpr int NW = 4;        // wavefronts per workgroup
+constexpr int WBUF = 128;    // survivor entries a wavefront buffers in LDS between flushes
+
+struct FlatParams {
+    const float* qp;       // fp16-split query images
+    const float* yp;       // fp16-split database images
+    const uint32_t* meta;
+    int64_t nq, q_offset, n_db;
+    int exclude_self;
+    int t_begin, t_end;    // database tiles [t_begin, t_end)
+    int dpad;
+    const float* tau;      // (nq) thresholds in screening units (a = c' + ||x||^2); +inf passes everything
+    uint64_t* buf;         // (nq, cap) appended keys (screening value bits << 32 | database row)
+    int32_t* cnt;          // (nq) entries this launch appended (> cap: the surplus was dropped -- overflow)
+    int cap;
+};
+
+__device__ __forceinline__ float reduce_tau(float tau, float xn) {
+    return (tau - xn) + 2.3841858e-07f * (fabsf(tau) + xn);  // + 4u (|tau| + xn): never rejects an a <= tau
+}
+
+// TERMS = 1: h.h'   TERMS = 2: h.h' + h.l' (query h only)   TERMS = 3: h.h' + h.l' + l.h'
+// A operand = database fragment (rows of the tile), B operand = query fragment; acc[r] of lane (q + 32 h) belongs to
+// database row 8 (r >> 2) + 4 h + (r & 3) of the tile and query q of the query tile.
+template <int KS, int TERMS, int QB, int TPB>
+__global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams P) {
+    static_assert((TPB * QB) % 2 == 0, "blocks per step must be even (static accumulator roles)");
+    constexpr int TILE_LDS = KS * 1024 * (TERMS == 1 ? 1 : 2);   // staged bytes of one tile
+    constexpr int STEP_LDS = TPB * TILE_LDS;
+    constexpr int TILE_F = KS * 512 + 64;                          // floats per tile image in HBM
+    constexpr int NBLK = 2 * KS;                                   // 1-KiB blocks per tile image
+    constexpr int NPIECE = (TERMS == 1) ? KS : NBLK;               // 1-KiB pieces staged per tile
+    constexpr int NSLOT = 4 * TPB;                                 // norm ring slots (+ 1 slot of +inf behind them)
+    // SEPARATE LDS objects: the compiler orders an LDS store / atomic behind every pending LDS-DMA it cannot prove disjoint
+    // (s_waitcnt vmcnt(0) -- it would wait for the NEXT step's tiles in the middle of this one); distinct variables are disjoint
+    __shared__ __attribute__((aligned(16))) char stage0[2 * STEP_LDS];
+    __shared__ __attribute__((aligned(16))) float nring[(NSLOT + 1) * 64];
+    __shared__ uint64_t wkeys_all[NW * WBUF];
+    __shared__ uint32_t wq_all[NW * WBUF];
+    __shared__ int cnt_all[NW * QB * 32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane & 31, h = lane >> 5;
+    uint64_t* wkeys = wkeys_all + wave * WBUF;
+    uint32_t* wq = wq_all + wave * WBUF;
+    int* cntw = cnt_all + wave * QB * 32;
+
+    const int64_t n_qtiles = (P.nq + 31) / 32;
+    const int64_t qt0 = ((int64_t)blockIdx.x * NW + wave) * QB;
+    const bool wave_active = qt0 < n_qtiles;
+
+    const int se = scr::scale_exp(P.meta[0]);
+    const float m2s = -2.0f * scr::pow2f(-2 * se);
+
+    f16x8 bh[QB][KS], bl[TERMS == 3 ? QB : 1][TERMS == 3 ? KS : 1];
+    float xn[QB], tau_r[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int64_t qt = qt0 + qb;
+        const bool blk_active = qt < n_qtiles;
+        xn[qb] = 0.f;
+        if (blk_active) {
+            const char* qimg = reinterpret_cast<const char*>(P.qp + (size_t)qt * TILE_F);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                bh[qb][s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s) * 1024 + lane * 16);
+                if constexpr (TERMS == 3) bl[qb][s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s + 1) * 1024 + lane * 16);
+            }
+            xn[qb] = reinterpret_cast<const float*>(qimg + KS * 2048)[q];
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bh[qb][s][e] = (_Float16)0.f;
+                if constexpr (TERMS == 3) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bl[qb][s][e] = (_Float16)0.f;
+                }
+            }
+        }
+        // rows beyond nq and padding rows (+inf norm) are not queries
+        const bool lane_valid = blk_active && (qt * 32 + q < P.nq) && (xn[qb] < __builtin_inff());
+        if (!lane_valid) xn[qb] = 0.f;
+        tau_r[qb] = lane_valid ? reduce_tau(P.tau[qt * 32 + q], xn[qb]) : -__builtin_inff();
+    }
+    for (int p = lane; p < QB * 32; p += 64) cntw[p] = 0;
+    if (tid < 64) nring[NSLOT * 64 + tid] = __builtin_inff();   // the slot a block without a predecessor "finishes"
+    int wcount = 0;   // wave-uniform: entries in this wavefront's survivor buffer
+
+    const int n_steps = (P.t_end - P.t_begin + TPB - 1) / TPB;
+
+    auto stage = [&](int s) {
+        char* dstbase = stage0 + (s & 1) * STEP_LDS;
+#pragma unroll
+        for (int tt = 0; tt < TPB; ++tt) {
+            const int T = P.t_begin + s * TPB + tt;
+            const int slot = (s * TPB + tt) & (NSLOT - 1);
+            if (T < P.t_end) {
+                const float* src = P.yp + (size_t)T * TILE_F;
+#pragma unroll
+                for (int p0 = 0; p0 < NPIECE; p0 += NW) {
+                    const int p = p0 + wave;
+                    const int sblk = (TERMS == 1) ? 2 * p : p;
+                    if (p < NPIECE)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(src + sblk * 256 + lane * 4),
+                                                         (lptr_t)(dstbase + tt * TILE_LDS + p * 1024), 16, 0, 0);
+                }
+                if (wave == ((tt + 1) & 3))
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + NBLK * 256 + lane), (lptr_t)(nring + slot * 64), 4, 0, 0);
+            } else if (wave == ((tt + 1) & 3)) {
+                nring[slot * 64 + lane] = __builtin_inff();   // a tile beyond the range: nothing of it can pass
+            }
+        }
+    };
+
+    // buffered survivors -> the queries' regions in HBM (slot = the query's running count)
+    bool lostw = false;   // wave-uniform: the buffer overflowed inside one block (degenerate data): all 64 queries are flagged
+    auto flush = [&]() {
+        for (int i = lane; i < wcount; i += 64) {
+            const uint64_t key = wkeys[i];
+            const uint32_t ql = wq[i];
+            const int slot = atomicAdd(&cntw[ql], 1);
+            if (slot < P.cap) P.buf[((size_t)qt0 * 32 + ql) * (size_t)P.cap + slot] = key;
+        }
+        wcount = 0;   // (LDS operations of a wavefront complete in order: later buffer writes cannot overtake these reads)
+    };
+
+    // the finished block: acc -> reduced screening values c' = ||y||^2 - 2 s^-2 acc, group minima
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    // norms of a block's tile rows are read while ITS matrix instructions run and used one block later, when it is finished
+    // (yn[c] belongs to the block whose accumulators are acc[c]); the first block of the scan finishes a block of +inf norms
+    f32x4 yn[2][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { yn[0][g] = f32x4{__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()}; yn[1][g] = yn[0][g]; }
+    int Tprev = 0;
+
+    auto finish_part = [&](const f32x16& a, const f32x4 (&yn)[4], int g, float (&dv)[16], float (&pm)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dv[4 * g + e] = __builtin_fmaf(m2s, a[4 * g + e], yn[g][e]);
+        pm[g] = fminf(fminf(dv[4 * g], dv[4 * g + 1]), fminf(dv[4 * g + 2], dv[4 * g + 3]));
+    };
+
+    // survivors of the finished block (rare): key = (a = c' + ||x||^2, database row) into the wavefront's buffer
+    const uint32_t n_db32 = (uint32_t)P.n_db;
+    auto survivors = [&](const float (&dv)[16], const float (&pm)[4], int pq) {
+        float tq = tau_r[0], xq = xn[0];
+        int64_t js64 = (qt0 * 32 + q) + P.q_offset;
+#pragma unroll
+        for (int b = 1; b < QB; ++b)
+            if (pq == b) { tq = tau_r[b]; xq = xn[b]; js64 = ((qt0 + b) * 32 + q) + P.q_offset; }
+        // database rows are < 2^31; a query index beyond that range matches none of them
+        const uint32_t jself = (P.exclude_self && js64 >= 0 && js64 < 0x7fffffffLL) ? (uint32_t)js64 : 0xffffffffu;
+        if (wcount >= WBUF / 2) flush();
+        const uint32_t jb = (uint32_t)Tprev * 32u + 4u * (uint32_t)h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (!__any(pm[g] <= tq)) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                const uint32_t j = jb + (uint32_t)(e + 8 * g);
+                const bool pass = dv[r] <= tq && dv[r] < __builtin_inff() && j < n_db32 && j != jself;
+                const unsigned long long m = __ballot(pass);
+                if (m == 0ull) continue;
+                const int nb = __popcll(m);
+                if (__builtin_amdgcn_readfirstlane(wcount + nb) > WBUF) { lostw = true; continue; }   // > 64 survivors in one block: not a neighbour search any more
+                if (pass) {
+                    const int pos = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    wkeys[pos] = mkkey(dv[r] + xq, j);
+                    wq[pos] = (uint32_t)(pq * 32 + q);
+                }
+                wcount = __builtin_amdgcn_readfirstlane(wcount + nb);
+            }
+        }
+    };
+
+    // one block: the matrix instructions of (tile fragments A, query block qb) into acc[CUR]; the finished block acc[1 - CUR]
+    // is reduced between them.  ROTATE: the fragments of the NEXT tile of this step replace each slice as soon as its last
+    // matrix instruction has been issued.
+#define TDR_FLAT_MMA(ACC, S, FIRST)                                                                                   \
+    do {                                                                                                              \
+        ACC = (FIRST) ? __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[S], bh[qb][S], zero16, 0, 0, 0)                     \
+                      : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[S], bh[qb][S], ACC, 0, 0, 0);                       \
+        if constexpr (TERMS >= 2) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[S], bh[qb][S], ACC, 0, 0, 0);       \
+        if constexpr (TERMS == 3) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[S], bl[qb][S], ACC, 0, 0, 0);       \
+    } while (0)
+
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
+    f16x8 ah[KS], al[TERMS >= 2 ? KS : 1];
+
+    auto load_frags = [&](const char* img) {
+        const char* ap = img + lane * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if constexpr (TERMS == 1) ah[s] = *reinterpret_cast<const f16x8*>(ap + s * 1024);
+            else {
+                ah[s] = *reinterpret_cast<const f16x8*>(ap + (2 * s) * 1024);
+                al[s] = *reinterpret_cast<const f16x8*>(ap + (2 * s + 1) * 1024);
+            }
+        }
+    };
+
+    stage(0);
+    __syncthreads();
+    for (int s = 0; s < n_steps; ++s) {
+        if (s + 1 < n_steps) stage(s + 1);
+        if (wave_active) {
+            if (wcount >= WBUF / 2) flush();   // early in the step: the stores have landed long before the step's barrier
+            const char* sbase = stage0 + (s & 1) * STEP_LDS;
+#pragma unroll
+            for (int tt = 0; tt < TPB; ++tt) {
+                const int T = P.t_begin + s * TPB + tt;
+                if (tt == 0) load_frags(sbase);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    const int cur = (tt * QB + qb) & 1;        // compile-time after unrolling
+                    const int pq = (qb == 0) ? QB - 1 : qb - 1;  // query block of the finished block
+                    const bool rotate = (qb == QB - 1) && (tt + 1 < TPB);
+                    const char* nap = sbase + (tt + 1) * TILE_LDS + lane * 16;
+                    float dv[16], pm[4];
+                    {   // this block's own norms, for the moment it is finished (one block later)
+                        const float* ynp = nring + ((s * TPB + tt) & (NSLOT - 1)) * 64 + 4 * h;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            if (cur == 0) yn[0][g] = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
+                            else yn[1][g] = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
+                        }
+                    }
+                    constexpr int PARTS = 4;
+                    constexpr int SPP = (KS + PARTS - 1) / PARTS;   // slices per part
+#pragma unroll
+                    for (int part = 0; part < PARTS; ++part) {
+#pragma unroll
+                        for (int u = 0; u < SPP; ++u) {
+                            const int s2 = part * SPP + u;
+                            if (s2 < KS) {
+                                if (cur == 0) TDR_FLAT_MMA(acc[0], s2, s2 == 0);
+                                else TDR_FLAT_MMA(acc[1], s2, s2 == 0);
+                                if (rotate) {
+                                    if constexpr (TERMS == 1) ah[s2] = *reinterpret_cast<const f16x8*>(nap + s2 * 1024);
+                                    else {
+                                        ah[s2] = *reinterpret_cast<const f16x8*>(nap + (2 * s2) * 1024);
+                                        al[s2] = *reinterpret_cast<const f16x8*>(nap + (2 * s2 + 1) * 1024);
+                                    }
+                                }
+                            }
+                        }
+                        if (cur == 0) finish_part(acc[1], yn[1], part, dv, pm);
+                        else finish_part(acc[0], yn[0], part, dv, pm);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    {
+                        float tq = tau_r[0];
+#pragma unroll
+                        for (int b = 1; b < QB; ++b)
+                            if (pq == b) tq = tau_r[b];
+                        const float mn = fminf(fminf(pm[0], pm[1]), fminf(pm[2], pm[3]));
+                        if (__any(mn <= tq)) survivors(dv, pm, pq);
+                    }
+                    Tprev = T;   // this block is the next one's finished block
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (wave_active) {
+        // drain: the last block (its accumulator set: blocks per step is even, so it is acc[1])
+        float dv[16], pm[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) finish_part(acc[1], yn[1], g, dv, pm);
+        const float mn = fminf(fminf(pm[0], pm[1]), fminf(pm[2], pm[3]));
+        if (__any(mn <= tau_r[QB - 1])) survivors(dv, pm, QB - 1);
+        flush();
+        for (int p = lane; p < QB * 32; p += 64) {
+            const int64_t qi = qt0 * 32 + p;
+            if (qi < P.nq) P.cnt[qi] = lostw ? P.cap + 1 : cntw[p];
+        }
+    }
+#undef TDR_FLAT_MMA
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Select: one wavefront per query.  (sorted list of L keys so far, may be NULL) + (n_extra keys in any order: the scan's
+// appended entries, or the pilot's per-slice lists) -> the L smallest, ascending, sentinel-padded; tau = min(a_(k) + 2E,
+// a_(L) if the list is full) for the next pass.  A query whose appended count exceeded its capacity lost entries: its
+// `lost` word is set (the host recomputes it exactly).
+// ---------------------------------------------------------------------------------------------------------
+struct SelectParams {
+    uint64_t* list;          // (nq, L) in/out
+    int have_list;           // 0: the list is empty on entry (first call)
+    const uint64_t* extra;   // (n_sets, nq, stride) keys
+    const int32_t* extra_cnt;// (nq) valid entries per query (NULL: all `stride`, sentinels allowed)
+    int n_sets, stride;
+    const float* norms_q;    // (nq) reference-order squared norms of the queries (screening order)
+    const uint32_t* meta;
+    int64_t nq;
+    int k, L, dpad, terms;
+    float* tau;              // (nq) out
+    int32_t* lost;           // (nq) |= 1 where extra_cnt > stride
+    float* guard;            // optional (nq) out, sets mode: the smallest LAST entry of a full set -- nothing a set dropped is smaller
+};
+
+__global__ __launch_bounds__(256) void knn_flat_select_kernel(const SelectParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int maxE = P.n_sets * P.stride;
+    uint64_t* lk = reinterpret_cast<uint64_t*>(smem_raw) + (size_t)wave * (P.L + maxE + P.L);  // list | extras | out
+    uint64_t* ek = lk + P.L;
+    uint64_t* ok = ek + maxE;
+    const int64_t qi = (int64_t)blockIdx.x * 4 + wave;
+    if (qi >= P.nq) return;   // wavefronts are independent (no block-level barrier below)
+    int nE = 0;
+    bool lost = false;
+    if (P.extra_cnt) {
+        const int c = P.extra_cnt[qi];
+        lost = c > P.stride;
+        nE = lost ? P.stride : c;
+        for (int p = lane; p < nE; p += 64) ek[p] = P.extra[(size_t)qi * P.stride + p];
+    } else {
+        nE = maxE;
+        for (int p = lane; p < maxE; p += 64) {
+            const int s = p / P.stride, r = p - s * P.stride;
+            ek[p] = P.extra[((size_t)s * P.nq + qi) * P.stride + r];
+        }
+    }
+    const int nL = P.have_list ? P.L : 0;
+    for (int p = lane; p < nL; p += 64) lk[p] = P.list[(size_t)qi * P.L + p];
+    for (int p = lane; p < P.L; p += 64) ok[p] = KEY_SENTINEL;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // rank of every key among (list + extras): a list entry's rank = its position + extras below it; an extra's rank =
+    // list entries below it + extras below it (keys are distinct except sentinels, which are never placed)
+    for (int p0 = 0; p0 < nL; p0 += 64) {
+        const int p = p0 + lane;
+        const uint64_t mine = (p < nL) ? lk[p] : KEY_SENTINEL;
+        int rank = p;
+        for (int e = 0; e < nE; ++e) rank += (ek[e] < mine) ? 1 : 0;
+        if (p < nL && mine != KEY_SENTINEL && rank < P.L) ok[rank] = mine;
+    }
+    for (int p0 = 0; p0 < nE; p0 += 64) {
+        const int p = p0 + lane;
+        const uint64_t mine = (p < nE) ? ek[p] : KEY_SENTINEL;
+        int rank = 0;
+        for (int e = 0; e < nE; ++e) rank += (ek[e] < mine) ? 1 : 0;
+        for (int e = 0; e < nL; ++e) rank += (lk[e] < mine) ? 1 : 0;
+        if (p < nE && mine != KEY_SENTINEL && rank < P.L) ok[rank] = mine;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    for (int p = lane; p < P.L; p += 64) P.list[(size_t)qi * P.L + p] = ok[p];
+    if (lane == 0) {
+        const uint64_t kk = ok[P.k - 1], kl = ok[P.L - 1];
+        float tau = __builtin_inff();
+        if (kk != KEY_SENTINEL) {
+            const int se = scr::scale_exp(P.meta[0]);
+            const float band = scr::screen_band(P.norms_q[qi], __uint_as_float(P.meta[1]), P.dpad, se, P.terms);
+            tau = u2f((uint32_t)(kk >> 32)) + band;
+            if (kl != KEY_SENTINEL) tau = fminf(tau, u2f((uint32_t)(kl >> 32)));
+        }
+        P.tau[qi] = tau;
+        if (lost) P.lost[qi] = 1;
+    }
+    if (P.guard && !P.extra_cnt) {
+        float g = __builtin_inff();
+        for (int s2 = lane; s2 < P.n_sets; s2 += 64) {
+            const uint64_t last = ek[s2 * P.stride + P.stride - 1];
+            if (last != KEY_SENTINEL) g = fminf(g, u2f((uint32_t)(last >> 32)));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) g = fminf(g, __shfl_xor(g, o, 64));
+        if (lane == 0) P.guard[qi] = g;
+    }
+}
+
+static int flat_ks(int d) {
+    if (d <= 32) return 2;
+    if (d <= 64) return 4;
+    if (d <= 128) return 8;
+    return 0;
+}
+
+template <int KS, int TERMS, int QB, int TPB>
+static int launch_flat(const FlatParams& P, hipStream_t st) {
+    const int64_t n_qtiles = (P.nq + 31) / 32;
+    const int64_t wgs = (n_qtiles + NW * QB - 1) / (NW * QB);
+    hipLaunchKernelGGL((knn_flat_scan_kernel<KS, TERMS, QB, TPB>), dim3((unsigned)wgs), dim3(256), 0, st, P);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+// shape of the workgroup per tier: one / two terms keep two query tiles per wavefront (the query's h fragments are 64
+// VGPRs), three terms one (h and l fragments: 64 VGPRs per query tile)
+template <int KS>
+static int launch_flat_ks(const FlatParams& P, int terms, int shape, hipStream_t st) {
+    // shape: 0 = default of the tier; 1..: the alternatives timed by tools/knn_flat_lab.py
+    if (terms == 1) {
+        if (shape == 1) return launch_flat<KS, 1, 1, 2>(P, st);
+        return launch_flat<KS, 1, 2, 2>(P, st);
+    }
+    if (terms == 2) {
+        if (shape == 1) return launch_flat<KS, 2, 1, 2>(P, st);
+        return launch_flat<KS, 2, 2, 1>(P, st);
+    }
+    return launch_flat<KS, 3, 1, 2>(P, st);
+}
+
+}  // namespace flat
+}  // namespace tdr
+
+using namespace tdr;
+
+extern "C" {
+
+/* 1 when the threshold scan serves feature dimension d (<= 128: the fragments of two query tiles fit the register file). */
+int tdr_knn_flat_supported(int d) { return flat::flat_ks(d) != 0 ? 1 : 0; }
+
+/*
+ * One pass of the threshold scan (tdr_knn_flat.hip header): every candidate of database tiles [tile_begin, tile_end) whose
+ * screening value is <= tau[q] is appended to buf[q * cap ...]; cnt[q] = the number met (entries beyond cap are dropped: the
+ * caller treats cnt > cap as lost).  q16 / y16: fp16-split images packed with the same meta; terms = 1, 2 or 3 (see
+ * screen_band in tdr_knn_screen_common.h for the band each needs).  shape = 0.
+ */
+int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
+                          int exclude_self, int tile_begin, int tile_end, const uint32_t* meta, const float* tau, uint64_t* buf,
+                          int32_t* cnt, int cap, int shape, void* stream) {
+    if (!q16 || !y16 || !meta || !tau || !buf || !cnt || nq <= 0 || n_db <= 0 || d <= 0 || cap <= 0) return TDR_ERR_BAD_ARG;
+    if (terms < 1 || terms > 3) return TDR_ERR_BAD_ARG;
+    const int ks = flat::flat_ks(d);
+    if (ks == 0) return TDR_ERR_UNSUPPORTED;
+    const int n_tiles = (int)((n_db + scr::TILE_ROWS - 1) / scr::TILE_ROWS);
+    if (tile_begin < 0 || tile_end > n_tiles || tile_begin >= tile_end) return TDR_ERR_BAD_ARG;
+    if (n_db > 0x7fffffffLL) return TDR_ERR_UNSUPPORTED;
+    flat::FlatParams P;
+    P.qp = q16; P.yp = y16; P.meta = meta; P.nq = nq; P.q_offset = q_offset; P.n_db = n_db; P.exclude_self = exclude_self;
+    P.t_begin = tile_begin; P.t_end = tile_end; P.dpad = ks * 16; P.tau = tau; P.buf = buf; P.cnt = cnt; P.cap = cap;
+    hipStream_t st = (hipStream_t)stream;
+    switch (ks) {
+        case 2: return flat::launch_flat_ks<2>(P, terms, shape, st);
+        case 4: return flat::launch_flat_ks<4>(P, terms, shape, st);
+        default: return flat::launch_flat_ks<8>(P, terms, shape, st);
+    }
+}
+
+/*
+ * Merge (list of L keys per query, ascending; ignored when have_list = 0) with n_sets x stride extra keys per query
+ * (extra_cnt != NULL: one set, extra_cnt[q] valid entries, > stride = entries were lost -> lost[q] = 1; NULL: every entry
+ * counts, sentinels allowed) into the L smallest, ascending, in place; tau[q] = min(a_(k) + 2E_q, a_(L) when the list is
+ * full), +inf while the query has met fewer than k candidates.  norms_q: the queries' reference-order squared norms.
+ * guard (optional, sets mode only): per query the smallest last entry over the FULL sets -- a set keeps its `stride` smallest,
+ * so nothing it dropped is below that value; the rescoring kernel flags a query whose band reaches it.
+ */
+int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra, const int32_t* extra_cnt, int n_sets,
+                            int stride, const float* norms_q, const uint32_t* meta, int64_t nq, int d, int k, int L, int terms,
+                            float* tau, int32_t* lost, float* guard, void* stream) {
+    if (!list || !extra || !norms_q || !meta || !tau || !lost || nq <= 0 || k < 1 || L < k || n_sets < 1 || stride < 1)
+        return TDR_ERR_BAD_ARG;
+    if (extra_cnt && n_sets != 1) return TDR_ERR_BAD_ARG;
+    const int ks = flat::flat_ks(d);
+    if (ks == 0) return TDR_ERR_UNSUPPORTED;
+    flat::SelectParams S;
+    S.list = list; S.have_list = have_list; S.extra = extra; S.extra_cnt = extra_cnt; S.n_sets = n_sets; S.stride = stride;
+    S.norms_q = norms_q; S.meta = meta; S.nq = nq; S.k = k; S.L = L; S.dpad = ks * 16; S.terms = terms; S.tau = tau; S.lost = lost; S.guard = guard;
+    const size_t lds = (size_t)4 * (2 * (size_t)L + (size_t)n_sets * stride) * sizeof(uint64_t);
+    if (lds > 160 * 1024) return TDR_ERR_UNSUPPORTED;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat::knn_flat_select_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(flat::knn_flat_select_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), lds, (hipStream_t)stream, S);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+}  // extern "C"

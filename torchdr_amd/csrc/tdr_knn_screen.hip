@@ -20,55 +20,11 @@
 // 64 x 64 cycles of v_mfma_f32_32x32x2_f32 -- 5.3x fewer matrix-pipe cycles -- with the same 16 KiB tile image,
 // LDS-DMA staging and software-pipelined epilogue as the one-stage kernel.
 #include "tdr_common.h"
+#include "tdr_knn_screen_common.h"
 #include <stdlib.h>
 
 namespace tdr {
 namespace scr {
-
-constexpr int TILE_ROWS = 32;
-constexpr uint64_t KEY_SENTINEL = 0xFF800000FFFFFFFFull;  // (+inf, 0xffffffff)
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-__device__ __forceinline__ float sqrt_rn(float x) { return (float)sqrt((double)x); }
-
-// tile image of 32 rows: ks slices x {H block, L block} of 1 KiB + 32 norms + 32 floats of padding
-__host__ __device__ __forceinline__ int64_t tile16_stride_floats(int ks) { return (int64_t)ks * 512 + 64; }
-
-// meta[0] = bits of max |x| over every element that will be packed, meta[1] = bits of max ||y||^2 (database)
-// scale s = 2^(13 - floor(log2(amax))): max |s x| in [2^13, 2^14) (fp16 max 65504; l stays normal down to
-// |s x| = 2^-3; below that it is subnormal or flushed, accounted for by c_den)
-__device__ __forceinline__ int scale_exp(uint32_t amax_bits) {
-    int ex = (int)((amax_bits >> 23) & 255u) - 127;
-    if ((amax_bits & 0x7fffffffu) == 0u) ex = 13;   // all-zero data: s = 1
-    if (ex < -100) ex = -100;                        // subnormal-range data: keep s finite
-    return 13 - ex;
-}
-__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((uint32_t)(e + 127) << 23); }
-
-// 2 * E_q (see the header): dpad = padded feature count, xn = ||x_q||^2, ymax2 = max ||y||^2, se = scale exponent.
-// Terms (u = 2^-24):  3 * 2^-22            fp16-split representation of both operands + the dropped l.l' product
-//                     2 (3 dpad + 16) u     fp32 accumulation of the 3*dpad products inside the matrix pipe, any
-//                                           order, allowing a truncating (1 ulp) adder
-//                     (dpad + 4) u          the reference's own k-ordered fp32 fma chain
-//                     8 u (xn + ymax2)      norm-sum association and the final roundings
-//                     2^-14 per element     l values below the fp16 normal range (covers a flush-to-zero pipe)
-// One-term screening (h.h' only, `terms` = 1) replaces the first term by 2 * 2^-11 + 2^-22 and has dpad products.
-__device__ __forceinline__ float screen_band(float xn, float ymax2, int dpad, int se, int terms) {
-    const float u = 5.9604645e-08f;  // 2^-24
-    // representation: three-term split 3 * 2^-22; one term (h.h' only) 2 * 2^-11 + 2^-22
-    const float c_repr = terms == 3 ? 3.0f * 2.3841858e-07f : (2.0f * 4.8828125e-04f + 2.3841858e-07f);
-    const float nprod = (float)(terms * dpad);
-    const float c_rel = 2.0f * (c_repr + 2.0f * (nprod + 16.0f) * u + (dpad + 4.0f) * u) * 1.01f;
-    const float c_abs = 8.0f * u;
-    const float inv_s = pow2f(-se);
-    const float c_den = 2.0f * 6.1035156e-05f * sqrtf((float)dpad) * 1.01f * inv_s;
-    const float nx = sqrtf(xn) * 1.0001f, ny = sqrtf(ymax2) * 1.0001f;
-    const float e = c_rel * nx * ny + c_abs * (xn + ymax2) + c_den * (nx + ny);
-    return 2.0f * e * 1.01f;
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // meta reductions
@@ -680,7 +636,8 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
         // taken by increasing distance of their centre to the NEAREST of the wavefronts' own centres: the own clusters
         // (distance 0) first, then max_visit - 1 others.  The candidates are the first max_visit entries of every wavefront's
         // visiting order (their union contains the max_visit nearest by that key); "next" = the smallest (key, cluster)
-        // above the last one taken, so no visited set is kept.  Clusters the exact bound excludes are never taken.
+        // above the last one taken, so no visited set is kept.  A cluster the exact bound excludes takes its probe but is
+        // not scanned.
         int visited = 0;
         unsigned long long prev = 0ull;  // (key bits << 32 | cluster) + 1 of the last cluster taken
         // exact mode: the distinct own clusters of the wavefronts, a cursor into the visiting order of each, whose turn it is
@@ -719,18 +676,14 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
                         if (cw[w] < 0) continue;
                         for (int i = tid; i < ncand; i += 256) {
                             const int c = P.clus_order[(size_t)cw[w] * P.n_clusters + i];
-                            const float rc = P.clus_radius[c];
-                            float key = __builtin_inff(), lb = __builtin_inff();
+                            float key = __builtin_inff();
 #pragma unroll
                             for (int w2 = 0; w2 < NW; ++w2) {
                                 if (cw[w2] < 0) continue;
-                                const float dc = P.clus_dist[(size_t)cw[w2] * P.n_clusters + c];
-                                key = fminf(key, dc);
-                                const float g = dc - P.clus_radius[cw[w2]] - rc;
-                                lb = fminf(lb, g > 0.f ? g * g : 0.f);
+                                key = fminf(key, P.clus_dist[(size_t)cw[w2] * P.n_clusters + c]);
                             }
                             const unsigned long long kc = (((unsigned long long)__float_as_uint(fmaxf(key, 0.f)) << 32) | (uint32_t)c) + 1ull;
-                            if (kc > prev && kc < best && !(lb * 0.9999f - band_wg > tau_wg)) best = kc;
+                            if (kc > prev && kc < best) best = kc;
                         }
                     }
 #pragma unroll
@@ -751,8 +704,23 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
                     if (own_cluster) --visited;  // undone below by the common increment
                     prev = best;
                     const int c = (int)(uint32_t)((best - 1ull) & 0xffffffffull);
-                    rb = P.clus_tile_begin[c];
-                    re = P.clus_tile_begin[c + 1];
+                    // The probe set is a function of the index alone (the lists by (centre distance to the nearest own centre,
+                    // id)): a list the exact bound excludes -- no member can enter any band of this workgroup -- still takes its
+                    // probe, it is just not scanned (scanning it would change nothing).  The result is therefore exactly "top-k
+                    // over the rows of the probed lists", which oracle/ref_torch.py:ivf_search restates on the CPU.
+                    float lbc = __builtin_inff();
+                    {
+                        const float rc = P.clus_radius[c];
+#pragma unroll
+                        for (int w2 = 0; w2 < NW; ++w2) {
+                            if (cw[w2] < 0) continue;
+                            const float g = P.clus_dist[(size_t)cw[w2] * P.n_clusters + c] - P.clus_radius[cw[w2]] - rc;
+                            lbc = fminf(lbc, g > 0.f ? g * g : 0.f);
+                        }
+                    }
+                    const bool excluded = lbc * 0.9999f - band_wg > tau_wg;
+                    rb = excluded ? 0 : P.clus_tile_begin[c];
+                    re = excluded ? 0 : P.clus_tile_begin[c + 1];
                     found = true;
                 }
                 // Exact mode.  A workgroup's four query tiles may lie in up to four clusters, and the layout order of the
@@ -852,7 +820,10 @@ struct RescoreParams {
     const uint32_t* meta;
     int64_t nq, ldq, ldy;
     int d, dpad, k, L, n_splits, metric, terms;
-    int predict_unsplit;   // pilot runs: also flag queries whose band holds >= L candidates over ALL slices
+    int predict_unsplit;   // pilot runs: also flag queries whose band holds >= pred_L candidates over ALL slices
+    int pred_L;            // list length the prediction is made for (the launch's own L, or the longer lists of the threshold scan)
+    const int32_t* lost;   // optional (nq): 1 = the threshold scan dropped candidates of this query (buffer capacity)
+    const float* guard;    // optional (nq): smallest screening value the pilot's full lists may have dropped
     const int32_t* row_map; // screening index -> source row (cluster-sorted search), NULL = identity
     int64_t q_begin, q_end; // screening positions handled by this launch
     float* out_d;
@@ -962,7 +933,9 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     // same search would; a pilot that stands for an unsliced run predicts from the merged band population instead.
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) in_band += __shfl_xor(in_band, o, 64);
-    const bool flag = any_ovf || (P.predict_unsplit && in_band >= P.L);
+    bool flag = any_ovf || (P.predict_unsplit && in_band >= P.pred_L);
+    if (P.lost && P.lost[qi] != 0) flag = true;
+    if (P.guard && P.guard[qi] <= thr) flag = true;   // a candidate inside the band may have fallen off a pilot list
     if (lane == 0) {
         P.flags[qs] = flag ? 1 : 0;
         if (flag) atomicAdd(P.n_flagged, 1);
@@ -1170,11 +1143,33 @@ struct ClusterTables {
     const float* tile_cdist;
 };
 
+static int launch_lists_scan(const ScreenParams& P, const ScreenCfg& cfg, int ks, int wgs, hipStream_t st) {
+    const size_t lds = screen_lds_bytes(ks, P.L, cfg.qb, cfg.terms);
+    switch (ks) {
+        case 2: return launch_screen_ks<2>(P, cfg, wgs, lds, st);
+        case 4: return launch_screen_ks<4>(P, cfg, wgs, lds, st);
+        case 8: return launch_screen_ks<8>(P, cfg, wgs, lds, st);
+        default: return launch_screen_ks<16>(P, cfg, wgs, lds, st);
+    }
+}
+
+static int launch_rescore(const RescoreParams& R, hipStream_t st) {
+    const int total = R.n_splits * R.L;
+    const int dq = (R.d + 3) & ~3;
+    const size_t rlds = (size_t)4 * ((size_t)2 * total * sizeof(uint64_t) + (size_t)dq * sizeof(float) + 16);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_rescore_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(knn_rescore_kernel, dim3((unsigned)((R.q_end - R.q_begin + 3) / 4)), dim3(256), rlds, st, R);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
 static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
                            const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
                            int metric, int exclude_self, int tier, int predict_unsplit, const uint32_t* meta, float* out_d,
                            int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes,
-                           const ClusterTables* ct, int64_t q_pos_begin, int64_t q_pos_end, void* stream) {
+                           const ClusterTables* ct, int64_t q_pos_begin, int64_t q_pos_end, void* stream, int pred_L = 0) {
     if (!q16 || !Xq || !norms_q || !y16 || !Y || !norms_y || !meta || !out_d || !out_i || !flags || !n_flagged || !ws)
         return TDR_ERR_BAD_ARG;
     if (nq <= 0 || n_db <= 0 || d <= 0 || ldq < d || ldy < d) return TDR_ERR_BAD_ARG;
@@ -1206,7 +1201,6 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     P.tile_cdist = ct ? ct->tile_cdist : nullptr;
     const int64_t need = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
     if (ws_bytes < need) return TDR_ERR_WORKSPACE;
-    const size_t lds = screen_lds_bytes(ks, L, cfg.qb, cfg.terms);
     int wgs = (int)((nq + 128 * cfg.qb - 1) / (128 * cfg.qb));
     int64_t q_lo = 0, q_hi = nq;
     if (ct && q_pos_end > q_pos_begin) {  // only the query batches covering [q_pos_begin, q_pos_end) of the sorted order
@@ -1215,28 +1209,15 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
         wgs = (int)((q_pos_end + qpw - 1) / qpw) - P.batch0;
         q_lo = q_pos_begin; q_hi = q_pos_end < nq ? q_pos_end : nq;
     }
-    int rc;
-    switch (ks) {
-        case 2: rc = launch_screen_ks<2>(P, cfg, wgs, lds, st); break;
-        case 4: rc = launch_screen_ks<4>(P, cfg, wgs, lds, st); break;
-        case 8: rc = launch_screen_ks<8>(P, cfg, wgs, lds, st); break;
-        default: rc = launch_screen_ks<16>(P, cfg, wgs, lds, st); break;
-    }
+    int rc = launch_lists_scan(P, cfg, ks, wgs, st);
     if (rc != TDR_OK) return rc;
 
     RescoreParams R;
     R.cand = P.cand; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq;
     R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.terms = cfg.terms; R.predict_unsplit = predict_unsplit; R.row_map = ct ? ct->row_map : nullptr; R.q_begin = q_lo; R.q_end = q_hi; R.out_d = out_d;
     R.out_i = out_i; R.flags = flags; R.n_flagged = n_flagged;
-    const int total = P.n_splits * L;
-    const int dq = (d + 3) & ~3;
-    const size_t rlds = (size_t)4 * ((size_t)2 * total * sizeof(uint64_t) + (size_t)dq * sizeof(float) + 16);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_rescore_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(knn_rescore_kernel, dim3((unsigned)((q_hi - q_lo + 3) / 4)), dim3(256), rlds, st, R);
-    TDR_CHECK_LAUNCH();
-    return TDR_OK;
+    R.pred_L = pred_L > 0 ? pred_L : L; R.lost = nullptr; R.guard = nullptr;
+    return launch_rescore(R, st);
 }
 
 int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
@@ -1245,6 +1226,139 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
                        int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
     return knn_screen_impl(q16, Xq, ldq, norms_q, nq, q_offset, y16, Y, ldy, norms_y, n_db, d, k, metric, exclude_self, tier,
                            predict_unsplit, meta, out_d, out_i, flags, n_flagged, ws, ws_bytes, nullptr, 0, 0, stream);
+}
+
+/* tdr_knn_screen_f32 with the pilot's prediction made for lists of pred_L entries (predict_unsplit = 1: flag the queries whose
+ * error band holds >= pred_L candidates over all database slices): the threshold scan below keeps longer lists than the
+ * list-keeping kernel can hold in LDS, and its tier is chosen by this prediction. */
+int tdr_knn_screen_pilot_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
+                             const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
+                             int metric, int exclude_self, int tier, int pred_L, const uint32_t* meta, float* out_d,
+                             int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+    return knn_screen_impl(q16, Xq, ldq, norms_q, nq, q_offset, y16, Y, ldy, norms_y, n_db, d, k, metric, exclude_self, tier,
+                           1, meta, out_d, out_i, flags, n_flagged, ws, ws_bytes, nullptr, 0, 0, stream, pred_L);
+}
+
+/* ---- the UNPRUNED two-stage search as a threshold scan (csrc/tdr_knn_flat.hip) ------------------------------------------ */
+int tdr_knn_flat_supported(int d);
+int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
+                          int exclude_self, int tile_begin, int tile_end, const uint32_t* meta, const float* tau, uint64_t* buf,
+                          int32_t* cnt, int cap, int shape, void* stream);
+int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra, const int32_t* extra_cnt, int n_sets,
+                            int stride, const float* norms_q, const uint32_t* meta, int64_t nq, int d, int k, int L, int terms,
+                            float* tau, int32_t* lost, float* guard, void* stream);
+
+namespace {
+constexpr int FLAT_CAP = 256;        // appended entries a query may collect per pass (~3k expected)
+constexpr int FLAT_MIN_TILES = 4096; // database tiles below which the list-keeping kernel serves the search
+
+struct FlatPlan {
+    ScreenCfg pilot_cfg;
+    int ks, pilot_tier, pilot_tiles, pilot_splits, Lp, L, n_tiles;
+    int64_t off_list, off_buf, off_cnt, off_tau, off_lost, off_guard, total;   // byte offsets into the workspace
+};
+
+// pilot = the list-keeping kernel of the same number of terms on the first 1/64 of the database tiles
+static bool flat_plan(int64_t nq, int64_t n_db, int d, int k, int terms, int L, FlatPlan* F) {
+    F->ks = pick_ks(d);
+    if (F->ks == 0 || F->ks > 8 || (terms != 1 && terms != 3) || L < k || L > 128) return false;
+    F->n_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
+    if (F->n_tiles < FLAT_MIN_TILES) return false;
+    F->pilot_tier = terms == 1 ? 0 : 1;
+    F->pilot_cfg = screen_cfg(F->ks, k, F->pilot_tier);
+    if (F->pilot_cfg.L == 0 || F->pilot_cfg.terms != terms) return false;
+    F->Lp = F->pilot_cfg.L;
+    F->L = L;
+    int pt = F->n_tiles / 64;
+    if (pt < 64) pt = 64;
+    F->pilot_tiles = pt & ~1;
+    F->pilot_splits = screen_splits(nq, F->pilot_tiles, F->pilot_cfg);
+    if (F->pilot_splits > 8) F->pilot_splits = 8;
+    int64_t o = 0;
+    o += (int64_t)F->pilot_splits * nq * F->Lp * 8;                 // pilot lists (offset 0)
+    F->off_list = o; o += nq * (int64_t)L * 8;
+    F->off_buf = o;  o += nq * (int64_t)FLAT_CAP * 8;
+    F->off_cnt = o;  o += ((nq * 4 + 15) / 16) * 16;
+    F->off_tau = o;  o += ((nq * 4 + 15) / 16) * 16;
+    F->off_lost = o; o += ((nq * 4 + 15) / 16) * 16;
+    F->off_guard = o; o += ((nq * 4 + 15) / 16) * 16;
+    F->total = o;
+    return true;
+}
+}  // namespace
+
+/* Workspace bytes of tdr_knn_screen_flat_f32, 0 when the threshold scan does not serve the search (D > 128, a small database,
+ * L outside [k, 128], terms other than 1 or 3). */
+int64_t tdr_knn_screen_flat_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, int terms, int L) {
+    FlatPlan F;
+    if (nq <= 0 || n_db <= 0 || k < 1 || !flat_plan(nq, n_db, d, k, terms, L, &F)) return 0;
+    return F.total;
+}
+
+/*
+ * tdr_knn_screen_f32's contract (same operands, same outputs, same flags: flagged rows must be recomputed with
+ * tdr_knn_packed_f32) for an UNPRUNED search of a large database, as pilot -> threshold scan -> select -> rescoring
+ * (csrc/tdr_knn_flat.hip).  terms = 1 (h.h') or 3; L = list length kept per query (k <= L <= 128; the band may hold L - k
+ * candidates before a query is flagged).  Everything is enqueued on `stream`; nothing is read back.
+ */
+int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
+                            const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
+                            int metric, int exclude_self, int terms, int L, const uint32_t* meta, float* out_d, int32_t* out_i,
+                            int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+    if (!q16 || !Xq || !norms_q || !y16 || !Y || !norms_y || !meta || !out_d || !out_i || !flags || !n_flagged || !ws)
+        return TDR_ERR_BAD_ARG;
+    if (nq <= 0 || n_db <= 0 || d <= 0 || ldq < d || ldy < d) return TDR_ERR_BAD_ARG;
+    if (metric != 0 && metric != 1) return TDR_ERR_UNSUPPORTED;
+    if (k < 1 || (int64_t)k > n_db - (exclude_self ? 1 : 0) || n_db > 0x7fffffffLL) return TDR_ERR_BAD_ARG;
+    FlatPlan F;
+    if (!flat_plan(nq, n_db, d, k, terms, L, &F)) return TDR_ERR_UNSUPPORTED;
+    if (ws_bytes < F.total) return TDR_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    char* w = (char*)ws;
+    uint64_t* pilot = (uint64_t*)w;
+    uint64_t* list = (uint64_t*)(w + F.off_list);
+    uint64_t* buf = (uint64_t*)(w + F.off_buf);
+    int32_t* cnt = (int32_t*)(w + F.off_cnt);
+    float* tau = (float*)(w + F.off_tau);
+    int32_t* lost = (int32_t*)(w + F.off_lost);
+    float* guard = (float*)(w + F.off_guard);
+    if (hipMemsetAsync(lost, 0, (size_t)nq * 4, st) != hipSuccess) return (int)hipGetLastError();
+
+    // 1. pilot: the list-keeping kernel over the first tiles
+    ScreenParams P;
+    P.qp = q16; P.yp = y16; P.meta = meta; P.nq = nq; P.q_offset = q_offset;
+    P.n_db = (int64_t)F.pilot_tiles * TILE_ROWS < n_db ? (int64_t)F.pilot_tiles * TILE_ROWS : n_db;
+    P.k = k; P.L = F.Lp; P.exclude_self = exclude_self;
+    P.n_db_tiles = F.pilot_tiles; P.n_splits = F.pilot_splits;
+    P.tiles_per_split = (P.n_db_tiles + P.n_splits - 1) / P.n_splits;
+    P.dpad = F.ks * 16; P.terms = terms; P.cand = pilot; P.n_clusters = 0; P.batch0 = 0;
+    P.tile_cluster = nullptr; P.clus_tile_begin = nullptr; P.clus_radius = nullptr; P.clus_dist = nullptr; P.clus_order = nullptr;
+    P.max_visit = 0; P.tile_cdist = nullptr;
+    const int wgs = (int)((nq + 128 * F.pilot_cfg.qb - 1) / (128 * F.pilot_cfg.qb));
+    int rc = launch_lists_scan(P, F.pilot_cfg, F.ks, wgs, st);
+    if (rc != TDR_OK) return rc;
+    // 2. its lists -> the first list of L, tau, and the guard (what a full pilot list may have dropped)
+    rc = tdr_knn_flat_select_f32(list, 0, pilot, nullptr, F.pilot_splits, F.Lp, norms_q, meta, nq, d, k, L, terms, tau, lost, guard, stream);
+    if (rc != TDR_OK) return rc;
+    // 3. threshold passes over growing ranges, a select after each
+    int bounds[4] = {F.pilot_tiles, (F.n_tiles / 16) & ~1, (F.n_tiles / 4) & ~1, F.n_tiles};
+    for (int i = 1; i < 4; ++i)
+        if (bounds[i] < bounds[i - 1]) bounds[i] = bounds[i - 1];
+    for (int i = 0; i < 3; ++i) {
+        if (bounds[i + 1] <= bounds[i]) continue;
+        rc = tdr_knn_flat_scan_f32(q16, nq, q_offset, y16, n_db, d, terms, exclude_self, bounds[i], bounds[i + 1], meta, tau, buf, cnt,
+                                   FLAT_CAP, 0, stream);
+        if (rc != TDR_OK) return rc;
+        rc = tdr_knn_flat_select_f32(list, 1, buf, cnt, 1, FLAT_CAP, norms_q, meta, nq, d, k, L, terms, tau, lost, nullptr, stream);
+        if (rc != TDR_OK) return rc;
+    }
+    // 4. rescoring of the final lists (one "split" of L entries per query)
+    RescoreParams R;
+    R.cand = list; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq; R.ldy = ldy;
+    R.d = d; R.dpad = F.ks * 16; R.k = k; R.L = L; R.n_splits = 1; R.metric = metric; R.terms = terms; R.predict_unsplit = 0;
+    R.pred_L = L; R.lost = lost; R.guard = guard; R.row_map = nullptr; R.q_begin = 0; R.q_end = nq; R.out_d = out_d; R.out_i = out_i;
+    R.flags = flags; R.n_flagged = n_flagged;
+    return launch_rescore(R, st);
 }
 
 /*
@@ -1298,7 +1412,8 @@ int tdr_knn_screen_clustered_tb_f32(const float* x16, const float* X, int64_t ld
 /* Approximate (IVF-style) self search on the same cluster index: distance/faiss.py:331-349 (`IndexIVFFlat`, nlist =
  * n_clusters, nprobe).  Same arguments as tdr_knn_screen_clustered_f32; a workgroup (128 consecutive rows of the sorted
  * order) scans its wavefronts' own clusters (together they are probe 1) and then the nprobe - 1 clusters whose centres are
- * nearest to ANY of those (clusters the exact search would skip by its bound are never taken).  Candidates are rescored exactly, so
+ * nearest to ANY of those, by (centre distance, id) -- a function of the index alone; a list the exact bound excludes keeps its
+ * probe and is merely not scanned, which cannot change the result.  Candidates are rescored exactly, so
  * every returned distance is the reference's value for that pair; neighbours that live in unvisited clusters are missed.
  * Rows with fewer than k candidates leave the tail of out_d / out_i as the caller initialised it (+inf / -1). */
 int tdr_knn_ivf_f32(const float* x16, const float* X, int64_t ldx, const float* norms, int64_t n_img, int d, int k, int metric,

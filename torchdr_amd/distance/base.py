@@ -402,6 +402,89 @@ def _screen_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier, p
     return flags, n_flagged
 
 
+# FLAT_SCAN: an UNPRUNED two-stage search of a large database runs as pilot -> threshold scan -> select -> rescoring
+# (csrc/tdr_knn_flat.hip, tdr_knn_screen_flat_f32) instead of the list-keeping kernel: same results bit for bit, lists of
+# _FLAT_L entries per query in HBM (the one-term tier then serves data whose error band holds up to ~100 candidates).
+FLAT_SCAN = True
+_FLAT_L = 128
+
+
+def _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier):
+    """Number of split terms (1 or 3) the threshold scan should use for this search, or 0 when it does not serve it.  `tier`
+    = the list-keeping tier the pilot chose (-1: none passed).  The one-term form is taken when a pilot slice predicts that
+    <= 5 % of the queries hold more than _FLAT_L candidates in the (wider) one-term band."""
+    L = _lib.lib()
+    if not _opt("FLAT_SCAN") or nq < _SCREEN_PILOT_MIN_Q or k > _FLAT_L - 8:
+        return 0
+    LL = min(_FLAT_L, max(k + 8, _FLAT_L))
+    ok1 = L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, Y.d, k, 1, LL) != 0
+    ok3 = L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, Y.d, k, 3, LL) != 0
+    if tier == 0 and ok1:
+        return 1
+    if ok1 and _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, 0, LL) <= _SCREEN_PILOT_MAX_FRAC:
+        return 1
+    if tier in (1, 2) and ok3:
+        return 3
+    if ok3 and _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, 1, LL) <= _SCREEN_PILOT_MAX_FRAC:
+        return 3
+    return 0
+
+
+def _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, tier, pred_L):
+    """Share of a pilot slice of queries whose error band (of list-keeping tier `tier`'s split) holds >= pred_L candidates."""
+    L = _lib.lib()
+    dev, d = Y.device, Y.d
+    q16, y16, meta = ops
+    nq = _SCREEN_PILOT_Q
+    t16 = L.tdr_packed16_floats(32, d)
+    ws_bytes = L.tdr_knn_screen_workspace_bytes(nq, Y.n, d, k, tier)
+    if ws_bytes == 0:
+        return 1.0
+    ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
+    pd = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    pi = torch.empty((nq, k), dtype=torch.int32, device=dev)
+    flags = torch.empty(nq, dtype=torch.int32, device=dev)
+    n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(
+        L.tdr_knn_screen_pilot_f32(
+            _lib.ptr(q16[(q0 // 32) * t16:]), _lib.ptr(Q.X[q0:]), Q.X.stride(0), _lib.ptr(Q.norms[q0:]), nq, q_offset + q0,
+            _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
+            1 if exclude_self else 0, tier, int(pred_L), _lib.ptr(meta), _lib.ptr(pd), _lib.ptr(pi),
+            _lib.ptr(flags), _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
+        ),
+        "tdr_knn_screen_pilot_f32",
+    )
+    return int(n_flagged.item()) / float(nq)
+
+
+def _flat_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, terms, out_d, out_i, profile):
+    """The unpruned two-stage search as a threshold scan (tdr_knn_screen_flat_f32).  Returns (flags, n_flagged)."""
+    L = _lib.lib()
+    dev, d = Y.device, Y.d
+    q16, y16, meta = ops
+    t16 = L.tdr_packed16_floats(32, d)
+    ws_bytes = L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, d, k, terms, _FLAT_L)
+    ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
+    flags = torch.empty(nq, dtype=torch.int32, device=dev)
+    n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
+    if profile:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    _lib.check(
+        L.tdr_knn_screen_flat_f32(
+            _lib.ptr(q16[(q0 // 32) * t16:]), _lib.ptr(Q.X[q0:]), Q.X.stride(0), _lib.ptr(Q.norms[q0:]), nq, q_offset + q0,
+            _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
+            1 if exclude_self else 0, int(terms), _FLAT_L, _lib.ptr(meta), _lib.ptr(out_d), _lib.ptr(out_i),
+            _lib.ptr(flags), _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
+        ),
+        "tdr_knn_screen_flat_f32",
+    )
+    if profile:
+        ev1.record()
+        PROFILE.append((ev0, ev1, nq, "screen-flat%d" % terms))
+    return flags, n_flagged
+
+
 _SIDE_STREAMS = {}
 
 
@@ -636,7 +719,19 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
                                        side_work=((lambda: _cluster_index_start(Y)), (lambda: _cluster_index(Y, ops))) if prune else None,
                                        scan_frac_of=(lambda tau: _pruned_share(Y, tau)) if prune else None)
         if tier < 0:
-            return -1
+            # no list-keeping tier holds the band: the threshold scan keeps longer lists (in HBM) and may still serve it
+            terms = _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, -1)
+            if terms == 0:
+                return -1
+            flags, n_flagged = _flat_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, terms, out_d, out_i,
+                                            profile=PROFILE is not None)
+            bad = int(n_flagged.item())
+            if bad:
+                _screen_fallback(Q, Y, q0, k, metric, exclude_self, q_offset, flags.nonzero().squeeze(1), out_d, out_i)
+            LAST_KNN["tier"], LAST_KNN["pruned"], LAST_KNN["tile_bounds"], LAST_KNN["flat_terms"] = tier, False, False, terms
+            if info is not None:
+                info["cluster_order"] = None
+            return bad
     if prune:
         ci = _cluster_index(Y, ops)
         # worth it only when the cluster balls are far apart relative to the neighbour distances: predicted from the
@@ -654,17 +749,25 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
                 prune = _opt("TILE_BOUNDS") == "force" or ci.scan_fraction_tiles(pilot_tau) <= _TILE_MAX_SCAN_FRACTION
                 if not prune:
                     tile_tab = None
+    flat_terms = 0
     if prune:
         flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, tile_cdist=tile_tab)
     else:
-        flags, n_flagged = _screen_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier, False, out_d, out_i,
-                                          profile=PROFILE is not None)
+        if pilot and nq >= _SCREEN_PILOT_MIN_Q:
+            flat_terms = _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier)
+        if flat_terms:
+            flags, n_flagged = _flat_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, flat_terms, out_d, out_i,
+                                            profile=PROFILE is not None)
+        else:
+            flags, n_flagged = _screen_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier, False, out_d, out_i,
+                                              profile=PROFILE is not None)
     bad = int(n_flagged.item())
     if bad:
         _screen_fallback(Q, Y, q0, k, metric, exclude_self, q_offset, flags.nonzero().squeeze(1), out_d, out_i)
     LAST_KNN["tier"] = tier
     LAST_KNN["pruned"] = bool(prune)
     LAST_KNN["tile_bounds"] = tile_tab is not None
+    LAST_KNN["flat_terms"] = flat_terms
     # the cluster-sorted row order of a pruned self search (perm: position -> source row, inv: row -> position; members
     # of a cluster by ascending row): callers that go on to gather rows by neighbour index (the UMAP loop) renumber the
     # points in it.  Handed to the caller through its `info` record, not through module state.
