@@ -361,9 +361,6 @@ def main():
     ap.add_argument("--peer-exchange", action="store_true",
                     help="N > 1: exchange the stepped rows as direct peer writes over HIP IPC (csrc/tdr_peerx.hip) instead of the RCCL "
                          "all-gather; opt-in between distinct devices (never run there), automatic where ranks share a device")
-    ap.add_argument("--build-ahead", action="store_true",
-                    help="build the next window's firing lists on a side stream while the gradient launches run (neighbor_embedding.umap."
-                         "BUILD_AHEAD; +0.9 %, off by default because the overlapped kernels' trace durations no longer add up)")
     ap.add_argument("--cpu-budget", type=float, default=600.0,
                     help="ceiling (seconds of CPU work) on the kNN sample of cpu_baseline; SURVEY 8d's 16 chunks need ~215 s and its 20 loop "
                          "iterations ~65 s on the 128-core box, so the default lets both complete")
@@ -389,8 +386,6 @@ def main():
         from torchdr_amd.neighbor_embedding import base as nbase
 
         nbase.PEER_EXCHANGE = True
-    if args.build_ahead:
-        umod.BUILD_AHEAD = True
     if args.loop != "auto":
         umod.LOOP_RUNNER = args.loop != "python"
         umod.LOOP_GRAPH = args.loop == "graph"
@@ -591,9 +586,7 @@ def main():
         "kernel": ("one whole UMAP iteration: tdr::umap_sched_grad_kernel<2,4,false> (ONE launch over both L2 slices of the embedding, "
                    "slices spread over the XCDs) + tdr::umap_sched_combine_sgd_kernel (clamps + SGD step) -- HIP events around "
                    "every 25th iteration's two launches -- + 1/32 of tdr::umap_sched_build2_kernel (group-ordered schedule build; "
-                   + ("built one window AHEAD on a side stream, concurrent with the launches: its time is inside the sampled "
-                      "iterations, which cover every position of a window" if getattr(umod, "BUILD_AHEAD", False) else "every build timed")
-                   + ")" if umod.SCHEDULED else
+                   "every build timed)" if umod.SCHEDULED else
                    "tdr::umap_grad_kernel<2,16,4,true> + 2 x tdr::umap_neg_dense_kernel<2,8,2> (one gradient evaluation)"),
         "bound": "hbm", "achieved": grad_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_gbs / HBM_PEAK_GBS,
         "traffic": pmc_traffic("r04_umap_sched_pmc.json" if umod.SCHEDULED else "r01_umap_grad_pmc.json"),

@@ -182,10 +182,10 @@ int tdr_cluster_tile_cdist_f32(const float* d2, int64_t ld, int64_t rows, int C,
                                const float* cn, float* out, void* stream);
 /* The UNPRUNED two-stage search as a threshold scan (round 5, csrc/tdr_knn_flat.hip; replaces the list-keeping kernel where no
  * tile can be skipped -- distance/torch.py:82-122 on structureless data, benchmarks/faiss/run_benchmark.py:143-146):
- * pilot (list-keeping kernel on the first 1/64 of the database) -> per-query threshold tau = a_(k) + 2E -> three passes of
- * tdr_knn_flat_scan_f32 (every candidate with screening value <= tau is appended to the query's buffer; no lists in LDS, two
- * query tiles per wavefront, two database tiles per barrier) with a tdr_knn_flat_select_f32 after each (list + appended -> the L
- * smallest, new tau) -> the rescoring kernel.  Same operands, outputs and flag contract as tdr_knn_screen_f32; results are
+ * pilot (list-keeping kernel with short lists on 1/64 of the database) -> select -> per-query threshold tau = a_(k) + 2E -> three
+ * passes of tdr_knn_flat_scan_f32 over growing ranges (every candidate with screening value <= tau is appended to the query's
+ * buffer; no lists in LDS, two query tiles per wavefront, two database tiles per barrier) with a tdr_knn_flat_select_f32 after
+ * each (list + appended -> the L smallest, new tau) -> the rescoring kernel.  Same operands, outputs and flag contract as tdr_knn_screen_f32; results are
  * bit-identical.  terms: 1 (h.h') or 3; L: list length per query (k <= L <= 128).  The workspace query returns 0 when the
  * threshold scan does not serve the search (D > 128, fewer than 4096 database tiles, unsupported terms / L). */
 int tdr_knn_flat_supported(int d);
@@ -194,17 +194,23 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
                             const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
                             int metric, int exclude_self, int terms, int L, const uint32_t* meta, float* out_d, int32_t* out_i,
                             int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
-/* its stages, exposed for tests and measurement.  scan: buf (nq, cap) keys (screening value bits << 32 | database row),
+/* its stages, exposed for tests and measurement.  Tiles are visited in the order position j -> tile (j * tile_stride) mod n_tiles
+ * (tile_stride coprime to the tile count; 1 = natural order): pilot and passes take ranges of POSITIONS, so each sees rows from all
+ * over the database.  scan: positions [tile_begin, tile_end); buf (nq, cap) keys (screening value bits << 32 | database row),
  * cnt (nq) candidates met by THIS launch (> cap: the surplus was dropped); terms 1, 2 (h.h' + h.l') or 3; shape 0.
  * select: list (nq, L) in/out ascending, sentinel 0xFF800000FFFFFFFF; extra = the scan's buf with extra_cnt = cnt (n_sets 1,
  * stride cap), or n_sets x (nq, stride) full lists with extra_cnt NULL (then guard (nq) = the smallest last entry of a full
  * set); tau (nq) out = min(a_(k) + 2E, a_(L) when full); lost (nq) set to 1 where cnt > stride. */
 int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
-                          int exclude_self, int tile_begin, int tile_end, const uint32_t* meta, const float* tau, uint64_t* buf,
-                          int32_t* cnt, int cap, int shape, void* stream);
+                          int exclude_self, int tile_begin, int tile_end, int tile_stride, const uint32_t* meta, const float* tau,
+                          uint64_t* buf, int32_t* cnt, int cap, int shape, void* stream);
 int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra, const int32_t* extra_cnt, int n_sets,
                             int stride, const float* norms_q, const uint32_t* meta, int64_t nq, int d, int k, int L, int terms,
                             float* tau, int32_t* lost, float* guard, void* stream);
+/* cluster index, step 3 (round 5): labels[i] = centre nearest to point i by the one-term screening value of the fp16-split images
+ * (same meta); approximate (2^-10 relative) and deterministic -- the clustering only decides how much a pruned search can skip */
+int tdr_cluster_assign16_f32(const float* x16, int64_t n, const float* c16, int n_centres, int d, const uint32_t* meta,
+                             int32_t* labels, void* stream);
 /* tdr_knn_screen_f32 in pilot mode (predict_unsplit = 1) with the prediction made for lists of pred_L entries */
 int tdr_knn_screen_pilot_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
                              const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
@@ -331,8 +337,7 @@ int tdr_umap_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t
  *          {1, 2, 4, 8} (tdr_umap_sched_slices = automatic choice); geom: low 4 bits = lanes per row (0 = default), bit 4
  *          (16) = all slices in ONE launch spread over the XCDs (workgroup b takes slice (b % 8) / (8 / n_slices)) plus a
  *          combine kernel -- acc then holds n_slices planes of (n_rows, 2 nc) floats; same gradient bit for bit; bit 5 (32):
- *          see tdr_umap_sched_step_f32; bit 6 (64): with 4 lanes per row, the 64 rows of a workgroup are dealt to its
- *          wavefronts in order of their active counts (fewer masked rounds; same gradient bit for bit). */
+ *          see tdr_umap_sched_step_f32. */
 int tdr_umap_sched_slices(int64_t n_total, int nc);
 /* loop layout: every row's (cols, eps_per) reordered by ascending eps_per (often-firing edges first) */
 int tdr_umap_sched_layout_f32(const int64_t* rowptr, const int32_t* cols, const float* eps_per, int64_t n_rows,
@@ -369,14 +374,6 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
  * Z (n_rows, nc), in one kernel with the same bits as the two. */
 int tdr_umap_sched_step_f32(const float* acc, int n_slices, int nc, int64_t n_rows, float exag, float rep, float* grad, float* Z,
                             float* buf, float lr, float momentum, int first, int* nan_flag, int n_iter, void* stream);
-/* Round 4: the joint gradient launch with the combine + SGD step INSIDE it (last-arriving slice workgroup of a 64-row block;
- * write-through planes + ticket, cdna_hip_programming.md Guideline 16): same bits as grad (geom 16 | 32) + step, no second
- * kernel.  The stepped rows go to Znext (Z is gathered during the launch): the caller swaps the buffers.  nc = 2 only. */
-int64_t tdr_umap_sched_ticket_count(int64_t n_rows, int n_slices);
-int tdr_umap_sched_grad_step_f32(const float* Z, float* Znext, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list,
-                                 const void* hdr, int t_local, int n_slices, float a, float b, int n_iter, int neg_rate, int n_negatives,
-                                 uint64_t seed, float exag, float rep, float eps, float* grad, float* acc, int geom, float lr,
-                                 float momentum, int first, float* mom_buf, int* nan_flag, int* tickets, void* stream);
 /* Round 4: peer exchange (csrc/tdr_peerx.hip) -- tdr_ctx_allgather_rows's contract without a collective library: every rank
  * writes its stepped rows into a (fine-grained) staging block of every peer over xGMI, raises a generation flag there, waits
  * for the flags raised at it and copies the staged rows into its embedding; two launches per exchange.  Peers are mapped

@@ -293,10 +293,6 @@ def test_joint_slice_launch_is_bit_identical(S, nc):
                 a = sc.grad(Z, tl, tl, 1.577, 0.895, 40, neg=inj, seed=99, geom=geom)
                 b = sc.grad(Z, tl, tl, 1.577, 0.895, 40, neg=inj, seed=99, geom=geom | 16)
                 assert torch.equal(a, b), (S, nc, tl, geom, inj is None)
-                if geom == 0:   # geom & 64: a workgroup's rows dealt to its row groups by active count -- same rows, same sums
-                    c = sc.grad(Z, tl, tl, 1.577, 0.895, 40, neg=inj, seed=99, geom=64)
-                    d = sc.grad(Z, tl, tl, 1.577, 0.895, 40, neg=inj, seed=99, geom=16 | 64)
-                    assert torch.equal(a, c) and torch.equal(a, d), (S, nc, tl, inj is None)
 
 
 def test_in_kernel_negatives_vs_oracle_large_and_wide():
@@ -777,94 +773,3 @@ def test_grouped_schedule_does_not_depend_on_the_group_composition():
                 m = int(ln_p[k, r])
                 assert torch.equal(lst_p[a:a + m], lst_f[b:b + m]), (r0, k, r)
         assert torch.equal(part.to_rows(nxp), full.to_rows(nx)[e0:])
-
-
-@pytest.mark.parametrize("S", [2, 4, 8])
-@pytest.mark.parametrize("momentum", [0.0, 0.7])
-def test_step_inside_the_gradient_launch_equals_the_two_kernel_form(S, momentum):
-    """tdr_umap_sched_grad_step_f32 (joint launch; the last-arriving slice workgroup of every 64-row block combines the planes
-    and steps its rows into a second buffer) against tdr_umap_sched_grad_f32 (geom 16 | 32 | 64) + tdr_umap_sched_step_f32:
-    gradient, stepped embedding and momentum buffer bit-identical over several iterations (the tickets return to zero after
-    every launch); a ragged last block; rows dealt by load or not."""
-    from torchdr_amd import _lib
-
-    L = _lib.lib()
-    n = 300_007            # > 64-row blocks spread over all XCDs, ragged tail
-    rowptr, cols, vals = random_graph(n, seed=50 + S, hub=300)
-    eps_per, nxt = prepare(vals.cuda(), 200)
-    sc = Sched(rowptr.cuda(), cols.cuda(), eps_per, n, 32, S)
-    sc.build(nxt, 0, 32)
-    gen = torch.Generator().manual_seed(8)
-    Z0 = (torch.randn(n, 2, generator=gen) * 3).cuda().contiguous()
-    tickets = torch.zeros(int(L.tdr_umap_sched_ticket_count(n, S)), dtype=torch.int32, device="cuda")
-    for geom_bits in (64, 0):
-        # two-kernel form
-        Za, bufa = Z0.clone(), (torch.empty_like(Z0) if momentum else None)
-        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
-        grads_a = []
-        for it in range(4):
-            g = torch.empty((n, 2), device="cuda")
-            _lib.check(L.tdr_umap_sched_grad_f32(_lib.ptr(Za), 2, n, 0, n, _lib.ptr(sc.list), _lib.ptr(sc.hdr), it, S, 1.577, 0.895, it, 5, 150,
-                                                 None, 99, 1.0, 1.0, 1e-3, _lib.ptr(g), _lib.ptr(sc.acc), 16 | 32 | geom_bits, _lib.stream_ptr()), "grad")
-            _lib.check(L.tdr_umap_sched_step_f32(_lib.ptr(sc.acc), S, 2, n, 1.0, 1.0, _lib.ptr(g), _lib.ptr(Za), _lib.ptr(bufa), 0.3, momentum,
-                                                 1 if it == 0 else 0, _lib.ptr(flag), it, _lib.stream_ptr()), "step")
-            grads_a.append(g.clone())
-        # step inside the launch, two buffers swapped by the caller
-        cur, alt, bufb = Z0.clone(), torch.empty_like(Z0), (torch.empty_like(Z0) if momentum else None)
-        for it in range(4):
-            g = torch.empty((n, 2), device="cuda")
-            _lib.check(L.tdr_umap_sched_grad_step_f32(_lib.ptr(cur), _lib.ptr(alt), n, 0, n, _lib.ptr(sc.list), _lib.ptr(sc.hdr), it, S, 1.577,
-                                                      0.895, it, 5, 150, 99, 1.0, 1.0, 1e-3, _lib.ptr(g), _lib.ptr(sc.acc), geom_bits, 0.3, momentum,
-                                                      1 if it == 0 else 0, _lib.ptr(bufb), _lib.ptr(flag), _lib.ptr(tickets), _lib.stream_ptr()),
-                       "grad_step")
-            cur, alt = alt, cur
-            assert torch.equal(g, grads_a[it]), (S, momentum, geom_bits, it)
-            assert int(tickets.abs().sum()) == 0
-        assert torch.equal(cur, Za), (S, momentum, geom_bits)
-        if momentum:
-            assert torch.equal(bufb, bufa)
-    assert int(flag.item()) == 0
-    # argument errors: in-place stepping is refused (the grid gathers Z during the launch)
-    assert L.tdr_umap_sched_grad_step_f32(_lib.ptr(Z0), _lib.ptr(Z0), n, 0, n, _lib.ptr(sc.list), _lib.ptr(sc.hdr), 0, S, 1.577, 0.895, 0, 5, 150,
-                                          99, 1.0, 1.0, 1e-3, None, _lib.ptr(sc.acc), 0, 0.3, 0.0, 0, None, _lib.ptr(flag), _lib.ptr(tickets),
-                                          _lib.stream_ptr()) == -1
-
-
-@pytest.mark.parametrize("max_iter", [100, 75])
-def test_windows_built_ahead_on_the_side_stream_change_nothing(max_iter):
-    """BUILD_AHEAD: the lists of window w + 1 are built on a side stream, into a second buffer, while the gradient launches of
-    window w run.  The fit and the epoch counters it leaves are those of the in-place build; a ragged last window
-    (75 = 2 x 32 + 11) is covered.  Subclasses that hook into the loop keep the in-place build."""
-    import torchdr_amd
-    from torchdr_amd.neighbor_embedding import umap as umod
-
-    X = gmm(20_000, 16, 3.0, seed=5).cuda()
-    out = {}
-    for ahead in (False, True):
-        umod.BUILD_AHEAD = ahead
-        try:
-            m = torchdr_amd.UMAP(n_neighbors=10, max_iter=max_iter, random_state=0, check_interval=10_000)
-            # keep the loop's state after the fit
-            m.clear_memory = lambda: None
-            Z = m.fit_transform(X)
-            sc = m._sched
-            assert ("list2" in sc) == ahead
-            out[ahead] = (Z.clone(), m.epoch_of_next_sample.clone())
-        finally:
-            umod.BUILD_AHEAD = False
-    assert torch.equal(out[True][0], out[False][0])
-    assert torch.equal(out[True][1], out[False][1])
-
-    # a subclass that hooks into the loop may look at the counters: it keeps the in-place build (no second buffer)
-    class Hooked(torchdr_amd.UMAP):
-        def on_training_step_end(self):
-            super().on_training_step_end()
-
-    umod.BUILD_AHEAD = True
-    try:
-        mh = Hooked(n_neighbors=10, max_iter=40, random_state=0, check_interval=10_000)
-        mh.clear_memory = lambda: None
-        mh.fit_transform(X)
-    finally:
-        umod.BUILD_AHEAD = False
-    assert "list2" not in mh._sched

@@ -34,6 +34,13 @@ def main():
     torch.manual_seed(42)
     sets = {"mixture_s2_k30": (gmm(n, d, 2.0), 30), "structureless_k30": (gmm(n, d, 0.0), 30), "uniform_k15": (torch.randn(n, d), 15)}
     keep = None
+    only_scan = len(sys.argv) > 2 and sys.argv[2] == "scan"
+    if only_scan:
+        X = sets["mixture_s2_k30"][0].cuda()
+        with config.options(PRUNE_MODE="0", FLAT_SCAN=True):
+            C, I = pairwise_distances(X, metric="sqeuclidean", k=30, exclude_diag=True, return_indices=True)
+        keep = (X, C)
+        sets = {}
     for name, (Xc, k) in sets.items():
         X = Xc.cuda()
         row = {}
@@ -65,9 +72,12 @@ def main():
     cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
     n_tiles = (n + 31) // 32
     scans = {}
-    for terms, shape in ((1, 0), (1, 1), (2, 0), (2, 1), (3, 0)):
+    shapes = ((1, 0), (1, 2), (1, 3), (1, 1), (1, 4), (2, 1), (2, 2), (3, 0), (3, 2))
+    if len(sys.argv) > 3:
+        shapes = tuple((int(a.split(":")[0]), int(a.split(":")[1])) for a in sys.argv[3].split(","))
+    for terms, shape in shapes:
         def run():
-            _lib.check(L.tdr_knn_flat_scan_f32(_lib.ptr(q16), n, 0, _lib.ptr(y16), n, d, terms, 1, 0, n_tiles, _lib.ptr(meta), _lib.ptr(tau),
+            _lib.check(L.tdr_knn_flat_scan_f32(_lib.ptr(q16), n, 0, _lib.ptr(y16), n, d, terms, 1, 0, n_tiles, 1, _lib.ptr(meta), _lib.ptr(tau),
                                                _lib.ptr(buf), _lib.ptr(cnt), cap, shape, _lib.stream_ptr()), "scan")
         t, _ = timed(run, reps=2)
         flops = 2.0 * n * n * d * terms
@@ -75,8 +85,10 @@ def main():
                                               "mean_appended": float(cnt.float().mean()), "max_appended": int(cnt.max())}
         print(json.dumps({f"scan_terms{terms}_shape{shape}": scans[f"terms{terms}_shape{shape}"]}), flush=True)
     res["scan_alone"] = scans
-    res["note"] = ("shape 0 = production (one / two terms: two query tiles per wavefront; three terms: one), shape 1 = one query tile "
-                   "per wavefront, two database tiles per barrier")
+    res["note"] = ("terms 1: shape 0 = two query tiles per wavefront, arithmetic between the matrix instructions (MODE 0); 2 = same, matrix "
+                   "instructions back to back then the arithmetic (MODE 1); 3 = both query tiles together, alternating accumulators "
+                   "(MODE 2); 1 / 4 = ONE query tile per wavefront, MODE 0 / 1.  terms 2: shape 1 / 2 = one query tile, MODE 0 / 1.  "
+                   "terms 3: shape 0 / 2 = one query tile, MODE 0 / 1")
     print(json.dumps(res), flush=True)
 
 

@@ -6,8 +6,8 @@
 // 53 % of the time (profiles/r01_knn_screen_pmc.json).  That form is right for the cluster-pruned scan, whose thresholds must
 // tighten WHILE it decides what to skip.  A scan that visits every tile anyway does not need lists:
 //
-//   pilot     the list-keeping kernel scans a small prefix of the database (1/64): the k-th smallest screening value a query
-//             meets there is an upper bound of its k-th smallest over the whole database;
+//   pilot     the list-keeping kernel scans 1/64 of the database (lists of k + 4 entries only): the k-th smallest screening
+//             value a query meets there is an upper bound of its k-th smallest over the whole database;
 //   scan      (this file) the rest of the database is scanned against that FIXED per-query threshold tau = a_(k) + 2E: a
 //             candidate is one fma + min tree + compare, and a survivor (a <= tau; a few hundred per query over the whole scan)
 //             is appended to the query's buffer in HBM -- no lists, no insertion, nothing in LDS but the staged tiles;
@@ -46,7 +46,9 @@ struct FlatParams {
     const uint32_t* meta;
     int64_t nq, q_offset, n_db;
     int exclude_self;
-    int t_begin, t_end;    // database tiles [t_begin, t_end)
+    int t_begin, t_end;    // positions [t_begin, t_end) of the tile visiting order
+    int n_tiles, stride;   // position j visits tile (j * stride) mod n_tiles (stride coprime to n_tiles; 1 = natural order): every
+                           // range of positions is spread over the whole database, whatever order its rows come in
     int dpad;
     const float* tau;      // (nq) thresholds in screening units (a = c' + ||x||^2); +inf passes everything
     uint64_t* buf;         // (nq, cap) appended keys (screening value bits << 32 | database row)
@@ -61,7 +63,19 @@ __device__ __forceinline__ float reduce_tau(float tau, float xn) {
 // TERMS = 1: h.h'   TERMS = 2: h.h' + h.l' (query h only)   TERMS = 3: h.h' + h.l' + l.h'
 // A operand = database fragment (rows of the tile), B operand = query fragment; acc[r] of lane (q + 32 h) belongs to
 // database row 8 (r >> 2) + 4 h + (r & 3) of the tile and query q of the query tile.
-template <int KS, int TERMS, int QB, int TPB>
+// SPARSE = false: a finished block's 16 candidate columns are kept and, when any of them survives, walked with a flush whenever
+//   the survivor buffer would not hold a column (a short range right after the pilot is DENSE: the same number of survivors per
+//   query falls on few rows, per cents of all candidates).
+// SPARSE = true (ranges of >= 2048 tiles, where a survivor is one candidate in thousands): each GROUP of four columns is tested
+//   and its survivors appended right where the group is reduced -- the event costs ~40 instructions instead of ~130 and no
+//   candidate column outlives its group; the buffer is flushed at the start of a step only (before the next tiles are
+//   requested, so the flush waits for nothing), and a wavefront that meets more than WBUF survivors between two flushes -- exact
+//   duplicates by the hundred -- reports all its queries lost (they are recomputed exactly).
+// Variants measured and dropped (profiles/r05_knn_flat_variants.json): all matrix instructions of a block back to back before
+// the arithmetic; both query tiles of a database tile on alternating accumulators; a three-deep staging ring with counted
+// vmcnt waits -- all within 4 % of this form: the scan runs at the rate the matrix pipe sustains at the clock the chip holds
+// under it (59 % busy at 1.79 GHz, r05_knn_flat_scan_pmc.json), not at a scheduling limit.
+template <int KS, int TERMS, int QB, int TPB, bool SPARSE>
 __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams P) {
     static_assert((TPB * QB) % 2 == 0, "blocks per step must be even (static accumulator roles)");
     constexpr int TILE_LDS = KS * 1024 * (TERMS == 1 ? 1 : 2);   // staged bytes of one tile
@@ -69,11 +83,11 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
     constexpr int TILE_F = KS * 512 + 64;                          // floats per tile image in HBM
     constexpr int NBLK = 2 * KS;                                   // 1-KiB blocks per tile image
     constexpr int NPIECE = (TERMS == 1) ? KS : NBLK;               // 1-KiB pieces staged per tile
-    constexpr int NSLOT = 4 * TPB;                                 // norm ring slots (+ 1 slot of +inf behind them)
+    constexpr int NSLOT = 4 * TPB;                                 // norm ring slots
     // SEPARATE LDS objects: the compiler orders an LDS store / atomic behind every pending LDS-DMA it cannot prove disjoint
     // (s_waitcnt vmcnt(0) -- it would wait for the NEXT step's tiles in the middle of this one); distinct variables are disjoint
     __shared__ __attribute__((aligned(16))) char stage0[2 * STEP_LDS];
-    __shared__ __attribute__((aligned(16))) float nring[(NSLOT + 1) * 64];
+    __shared__ __attribute__((aligned(16))) float nring[NSLOT * 64];
     __shared__ uint64_t wkeys_all[NW * WBUF];
     __shared__ uint32_t wq_all[NW * WBUF];
     __shared__ int cnt_all[NW * QB * 32];
@@ -125,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
         tau_r[qb] = lane_valid ? reduce_tau(P.tau[qt * 32 + q], xn[qb]) : -__builtin_inff();
     }
     for (int p = lane; p < QB * 32; p += 64) cntw[p] = 0;
-    if (tid < 64) nring[NSLOT * 64 + tid] = __builtin_inff();   // the slot a block without a predecessor "finishes"
-    int wcount = 0;   // wave-uniform: entries in this wavefront's survivor buffer
+    int wcount = 0;       // wave-uniform: entries in this wavefront's survivor buffer
+    bool lostw = false;   // wave-uniform (SPARSE): the buffer could not take a group's survivors: all queries of the wavefront are lost
 
     const int n_steps = (P.t_end - P.t_begin + TPB - 1) / TPB;
 
@@ -134,9 +148,10 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
         char* dstbase = stage0 + (s & 1) * STEP_LDS;
 #pragma unroll
         for (int tt = 0; tt < TPB; ++tt) {
-            const int T = P.t_begin + s * TPB + tt;
+            const int j = P.t_begin + s * TPB + tt;
             const int slot = (s * TPB + tt) & (NSLOT - 1);
-            if (T < P.t_end) {
+            if (j < P.t_end) {
+                const int T = (int)(((int64_t)j * P.stride) % P.n_tiles);
                 const float* src = P.yp + (size_t)T * TILE_F;
 #pragma unroll
                 for (int p0 = 0; p0 < NPIECE; p0 += NW) {
@@ -155,7 +170,6 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
     };
 
     // buffered survivors -> the queries' regions in HBM (slot = the query's running count)
-    bool lostw = false;   // wave-uniform: the buffer overflowed inside one block (degenerate data): all 64 queries are flagged
     auto flush = [&]() {
         for (int i = lane; i < wcount; i += 64) {
             const uint64_t key = wkeys[i];
@@ -166,7 +180,6 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
         wcount = 0;   // (LDS operations of a wavefront complete in order: later buffer writes cannot overtake these reads)
     };
 
-    // the finished block: acc -> reduced screening values c' = ||y||^2 - 2 s^-2 acc, group minima
     f32x16 acc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
@@ -176,44 +189,76 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
 #pragma unroll
     for (int g = 0; g < 4; ++g) { yn[0][g] = f32x4{__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()}; yn[1][g] = yn[0][g]; }
     int Tprev = 0;
-
-    auto finish_part = [&](const f32x16& a, const f32x4 (&yn)[4], int g, float (&dv)[16], float (&pm)[4]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dv[4 * g + e] = __builtin_fmaf(m2s, a[4 * g + e], yn[g][e]);
-        pm[g] = fminf(fminf(dv[4 * g], dv[4 * g + 1]), fminf(dv[4 * g + 2], dv[4 * g + 3]));
-    };
-
-    // survivors of the finished block (rare): key = (a = c' + ||x||^2, database row) into the wavefront's buffer
     const uint32_t n_db32 = (uint32_t)P.n_db;
-    auto survivors = [&](const float (&dv)[16], const float (&pm)[4], int pq) {
-        float tq = tau_r[0], xq = xn[0];
+
+    // one column of the finished block: append the lanes whose candidate survives
+    auto take_column = [&](float v, float tq, float xq, uint32_t j, uint32_t jself, int pq, bool& again, int r, int& r0) {
+        const bool pass = v <= tq && v < __builtin_inff() && j < n_db32 && j != jself;
+        const unsigned long long m = __ballot(pass);
+        if (m == 0ull) return;
+        const int nb = __popcll(m);
+        if (__builtin_amdgcn_readfirstlane(wcount + nb) > WBUF) {
+            if (SPARSE) lostw = true;
+            else { again = true; r0 = r; }
+            return;
+        }
+        if (pass) {
+            const int pos = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+            wkeys[pos] = mkkey(v + xq, j);
+            wq[pos] = (uint32_t)(pq * 32 + q);
+        }
+        wcount = __builtin_amdgcn_readfirstlane(wcount + nb);
+    };
+    auto query_of = [&](int pq, float& tq, float& xq, uint32_t& jself) {
+        tq = tau_r[0]; xq = xn[0];
         int64_t js64 = (qt0 * 32 + q) + P.q_offset;
 #pragma unroll
         for (int b = 1; b < QB; ++b)
             if (pq == b) { tq = tau_r[b]; xq = xn[b]; js64 = ((qt0 + b) * 32 + q) + P.q_offset; }
         // database rows are < 2^31; a query index beyond that range matches none of them
-        const uint32_t jself = (P.exclude_self && js64 >= 0 && js64 < 0x7fffffffLL) ? (uint32_t)js64 : 0xffffffffu;
-        if (wcount >= WBUF / 2) flush();
+        jself = (P.exclude_self && js64 >= 0 && js64 < 0x7fffffffLL) ? (uint32_t)js64 : 0xffffffffu;
+    };
+
+    // group g of the finished block: c' = ||y||^2 - 2 s^-2 acc of its four columns, their minimum
+    auto finish_part = [&](const f32x16& a, const f32x4 (&ynb)[4], int g, float (&dv)[16], float (&pm)[4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dv[4 * g + e] = __builtin_fmaf(m2s, a[4 * g + e], ynb[g][e]);
+        pm[g] = fminf(fminf(dv[4 * g], dv[4 * g + 1]), fminf(dv[4 * g + 2], dv[4 * g + 3]));
+    };
+    // SPARSE: the group's survivors, taken where the group is reduced
+    auto sparse_group = [&](const float (&dv)[16], const float (&pm)[4], int g, int pq) {
+        float tq, xq;
+        uint32_t jself;
+        query_of(pq, tq, xq, jself);
+        if (!__any(pm[g] <= tq)) return;
         const uint32_t jb = (uint32_t)Tprev * 32u + 4u * (uint32_t)h;
+        bool again = false;
+        int r0 = 0;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (!__any(pm[g] <= tq)) continue;
+        for (int e = 0; e < 4; ++e) take_column(dv[4 * g + e], tq, xq, jb + (uint32_t)(e + 8 * g), jself, pq, again, 4 * g + e, r0);
+    };
+    // dense form: all 16 columns of the finished block, ONE flush site (a column that does not fit sends the walk back to the top)
+    auto survivors = [&](const float (&dv)[16], const float (&pm)[4], int pq) {
+        float tq, xq;
+        uint32_t jself;
+        query_of(pq, tq, xq, jself);
+        const uint32_t jb = (uint32_t)Tprev * 32u + 4u * (uint32_t)h;
+        int r0 = 0;
+        for (;;) {
+            if (wcount >= WBUF / 2) flush();
+            bool again = false;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * g + e;
-                const uint32_t j = jb + (uint32_t)(e + 8 * g);
-                const bool pass = dv[r] <= tq && dv[r] < __builtin_inff() && j < n_db32 && j != jself;
-                const unsigned long long m = __ballot(pass);
-                if (m == 0ull) continue;
-                const int nb = __popcll(m);
-                if (__builtin_amdgcn_readfirstlane(wcount + nb) > WBUF) { lostw = true; continue; }   // > 64 survivors in one block: not a neighbour search any more
-                if (pass) {
-                    const int pos = wcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-                    wkeys[pos] = mkkey(dv[r] + xq, j);
-                    wq[pos] = (uint32_t)(pq * 32 + q);
+            for (int g = 0; g < 4; ++g) {
+                if (again || 4 * g + 3 < r0) continue;
+                if (!__any(pm[g] <= tq)) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    if (again || r < r0) continue;
+                    take_column(dv[r], tq, xq, jb + (uint32_t)(e + 8 * g), jself, pq, again, r, r0);
                 }
-                wcount = __builtin_amdgcn_readfirstlane(wcount + nb);
             }
+            if (!again) break;
         }
     };
 
@@ -248,17 +293,19 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
     stage(0);
     __syncthreads();
     for (int s = 0; s < n_steps; ++s) {
+        // first the flush (its stores and the LDS atomics the compiler orders behind pending LDS-DMA meet an empty queue), then
+        // the request for the next step's tiles
+        if (wave_active && wcount >= WBUF / 2) flush();
         if (s + 1 < n_steps) stage(s + 1);
         if (wave_active) {
-            if (wcount >= WBUF / 2) flush();   // early in the step: the stores have landed long before the step's barrier
             const char* sbase = stage0 + (s & 1) * STEP_LDS;
 #pragma unroll
             for (int tt = 0; tt < TPB; ++tt) {
-                const int T = P.t_begin + s * TPB + tt;
+                const int T = (int)(((int64_t)(P.t_begin + s * TPB + tt) * P.stride) % P.n_tiles);
                 if (tt == 0) load_frags(sbase);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
-                    const int cur = (tt * QB + qb) & 1;        // compile-time after unrolling
+                    const int cur = (tt * QB + qb) & 1;          // compile-time after unrolling
                     const int pq = (qb == 0) ? QB - 1 : qb - 1;  // query block of the finished block
                     const bool rotate = (qb == QB - 1) && (tt + 1 < TPB);
                     const char* nap = sbase + (tt + 1) * TILE_LDS + lane * 16;
@@ -292,9 +339,10 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
                         }
                         if (cur == 0) finish_part(acc[1], yn[1], part, dv, pm);
                         else finish_part(acc[0], yn[0], part, dv, pm);
+                        if constexpr (SPARSE) sparse_group(dv, pm, part, pq);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    {
+                    if constexpr (!SPARSE) {
                         float tq = tau_r[0];
 #pragma unroll
                         for (int b = 1; b < QB; ++b)
@@ -314,7 +362,14 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
 #pragma unroll
         for (int g = 0; g < 4; ++g) finish_part(acc[1], yn[1], g, dv, pm);
         const float mn = fminf(fminf(pm[0], pm[1]), fminf(pm[2], pm[3]));
-        if (__any(mn <= tau_r[QB - 1])) survivors(dv, pm, QB - 1);
+        if (__any(mn <= tau_r[QB - 1])) {
+            if constexpr (SPARSE) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) sparse_group(dv, pm, g, QB - 1);
+            } else {
+                survivors(dv, pm, QB - 1);
+            }
+        }
         flush();
         for (int p = lane; p < QB * 32; p += 64) {
             const int64_t qi = qt0 * 32 + p;
@@ -322,6 +377,60 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
         }
     }
 #undef TDR_FLAT_MMA
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Nearest centre of every point (cluster index of the pruned search, step 3): one-term screening values against the C
+// centres, arg-min per point.  The assignment only shapes the clusters -- the search result never depends on it -- so the
+// 2^-10 relative error of h.h' is irrelevant, and the kernel is deterministic (every rank builds the same index).  Replaces
+// an exact fp32-MFMA search with k = 1 (3.8 - 6.4 ms at N = 1M, C = 1000) by ~0.4 ms on the critical path of the kNN build.
+// ---------------------------------------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256) void nearest_centre_kernel(const float* __restrict__ x16, int64_t n, const float* __restrict__ c16,
+                                                             int n_centres, const uint32_t* __restrict__ meta, int32_t* __restrict__ labels) {
+    constexpr int TILE_F = KS * 512 + 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane & 31, h = lane >> 5;
+    const int64_t n_qtiles = (n + 31) / 32;
+    const int64_t qt = (int64_t)blockIdx.x * NW + wave;
+    if (qt >= n_qtiles) return;
+    const int se = scr::scale_exp(meta[0]);
+    const float m2s = -2.0f * scr::pow2f(-2 * se);
+    const char* qimg = reinterpret_cast<const char*>(x16 + (size_t)qt * TILE_F);
+    f16x8 bh[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bh[s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s) * 1024 + lane * 16);
+    float best = __builtin_inff();
+    int arg = 0x7fffffff;
+    const int c_tiles = (n_centres + 31) / 32;
+    for (int T = 0; T < c_tiles; ++T) {
+        const char* img = reinterpret_cast<const char*>(c16 + (size_t)T * TILE_F);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(img + (2 * s) * 1024 + lane * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc, 0, 0, 0);
+        }
+        const float* ynp = reinterpret_cast<const float*>(img + KS * 2048) + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 y4 = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = T * 32 + 8 * g + 4 * h + e;
+                const float v = __builtin_fmaf(m2s, acc[4 * g + e], y4[e]);     // ||c||^2 - 2 x.c (+inf for padding rows)
+                if (c < n_centres && (v < best || (v == best && c < arg))) { best = v; arg = c; }
+            }
+        }
+    }
+    // the two lanes of a point (rows 4 h .. of every group) meet
+    const float ob = __shfl_xor(best, 32, 64);
+    const int oa = __shfl_xor(arg, 32, 64);
+    if (ob < best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    const int64_t qi = qt * 32 + q;
+    if (h == 0 && qi < n) labels[qi] = arg == 0x7fffffff ? 0 : arg;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -374,21 +483,55 @@ __global__ __launch_bounds__(256) void knn_flat_select_kernel(const SelectParams
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     // rank of every key among (list + extras): a list entry's rank = its position + extras below it; an extra's rank =
-    // list entries below it + extras below it (keys are distinct except sentinels, which are never placed)
-    for (int p0 = 0; p0 < nL; p0 += 64) {
-        const int p = p0 + lane;
-        const uint64_t mine = (p < nL) ? lk[p] : KEY_SENTINEL;
-        int rank = p;
-        for (int e = 0; e < nE; ++e) rank += (ek[e] < mine) ? 1 : 0;
-        if (p < nL && mine != KEY_SENTINEL && rank < P.L) ok[rank] = mine;
+    // list entries below it + extras below it (keys are distinct except sentinels, which are never placed).  A lane keeps its
+    // keys (list entries lane, lane + 64; extras lane + 64 t) in registers and walks the LDS copies once.
+    constexpr int MAXE_PER_LANE = 32;   // maxE <= 2048
+    uint64_t ml[2];
+    int rl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int p = lane + 64 * t;
+        ml[t] = (p < nL) ? lk[p] : KEY_SENTINEL;
+        rl[t] = p;
     }
-    for (int p0 = 0; p0 < nE; p0 += 64) {
-        const int p = p0 + lane;
-        const uint64_t mine = (p < nE) ? ek[p] : KEY_SENTINEL;
-        int rank = 0;
-        for (int e = 0; e < nE; ++e) rank += (ek[e] < mine) ? 1 : 0;
-        for (int e = 0; e < nL; ++e) rank += (lk[e] < mine) ? 1 : 0;
-        if (p < nE && mine != KEY_SENTINEL && rank < P.L) ok[rank] = mine;
+    for (int e0 = 0; e0 < nE; e0 += 64 * 4) {
+        // four extras per lane and round
+        uint64_t me[4];
+        int re[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int p = e0 + lane + 64 * t;
+            me[t] = (p < nE) ? ek[p] : KEY_SENTINEL;
+            re[t] = 0;
+        }
+        for (int e = 0; e < nE; ++e) {
+            const uint64_t ke = ek[e];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) re[t] += (ke < me[t]) ? 1 : 0;
+        }
+        for (int e = 0; e < nL; ++e) {
+            const uint64_t ke = lk[e];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) re[t] += (ke < me[t]) ? 1 : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int p = e0 + lane + 64 * t;
+            if (p < nE && me[t] != KEY_SENTINEL && re[t] < P.L) ok[re[t]] = me[t];
+        }
+    }
+    (void)MAXE_PER_LANE;
+    if (nL > 0) {
+        for (int e = 0; e < nE; ++e) {
+            const uint64_t ke = ek[e];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) rl[t] += (ke < ml[t]) ? 1 : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int p = lane + 64 * t;
+            if (p < nL && ml[t] != KEY_SENTINEL && rl[t] < P.L) ok[rl[t]] = ml[t];
+        }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
@@ -424,29 +567,25 @@ static int flat_ks(int d) {
     return 0;
 }
 
-template <int KS, int TERMS, int QB, int TPB>
+template <int KS, int TERMS, int QB, int TPB, bool SPARSE>
 static int launch_flat(const FlatParams& P, hipStream_t st) {
     const int64_t n_qtiles = (P.nq + 31) / 32;
     const int64_t wgs = (n_qtiles + NW * QB - 1) / (NW * QB);
-    hipLaunchKernelGGL((knn_flat_scan_kernel<KS, TERMS, QB, TPB>), dim3((unsigned)wgs), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((knn_flat_scan_kernel<KS, TERMS, QB, TPB, SPARSE>), dim3((unsigned)wgs), dim3(256), 0, st, P);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
 
 // shape of the workgroup per tier: one / two terms keep two query tiles per wavefront (the query's h fragments are 64
-// VGPRs), three terms one (h and l fragments: 64 VGPRs per query tile)
+// VGPRs), three terms one (h and l fragments: 64 VGPRs per query tile).  shape: 0 = by the size of the range (sparse form from
+// SPARSE_MIN_TILES tiles), 1 = dense form, 2 = sparse form (tests, tools/knn_flat_lab.py)
+constexpr int SPARSE_MIN_TILES = 2048;
 template <int KS>
 static int launch_flat_ks(const FlatParams& P, int terms, int shape, hipStream_t st) {
-    // shape: 0 = default of the tier; 1..: the alternatives timed by tools/knn_flat_lab.py
-    if (terms == 1) {
-        if (shape == 1) return launch_flat<KS, 1, 1, 2>(P, st);
-        return launch_flat<KS, 1, 2, 2>(P, st);
-    }
-    if (terms == 2) {
-        if (shape == 1) return launch_flat<KS, 2, 1, 2>(P, st);
-        return launch_flat<KS, 2, 2, 1>(P, st);
-    }
-    return launch_flat<KS, 3, 1, 2>(P, st);
+    const bool sparse = shape == 2 || (shape == 0 && P.t_end - P.t_begin >= SPARSE_MIN_TILES);
+    if (terms == 1) return sparse ? launch_flat<KS, 1, 2, 2, true>(P, st) : launch_flat<KS, 1, 2, 2, false>(P, st);
+    if (terms == 2) return sparse ? launch_flat<KS, 2, 1, 2, true>(P, st) : launch_flat<KS, 2, 1, 2, false>(P, st);
+    return sparse ? launch_flat<KS, 3, 1, 2, true>(P, st) : launch_flat<KS, 3, 1, 2, false>(P, st);
 }
 
 }  // namespace flat
@@ -460,30 +599,53 @@ extern "C" {
 int tdr_knn_flat_supported(int d) { return flat::flat_ks(d) != 0 ? 1 : 0; }
 
 /*
- * One pass of the threshold scan (tdr_knn_flat.hip header): every candidate of database tiles [tile_begin, tile_end) whose
+ * One pass of the threshold scan (tdr_knn_flat.hip header): every candidate of the database tiles at positions [tile_begin,
+ * tile_end) of the visiting order (position j = tile (j * tile_stride) mod n_tiles; tile_stride coprime to n_tiles, 1 = natural) whose
  * screening value is <= tau[q] is appended to buf[q * cap ...]; cnt[q] = the number met (entries beyond cap are dropped: the
  * caller treats cnt > cap as lost).  q16 / y16: fp16-split images packed with the same meta; terms = 1, 2 or 3 (see
- * screen_band in tdr_knn_screen_common.h for the band each needs).  shape = 0.
+ * screen_band in tdr_knn_screen_common.h for the band each needs).  shape: 0 = by the size of the range, 1 = the dense form
+ * (every column of a hit block walked, flushes inside), 2 = the sparse form (survivors taken per group of four columns; a
+ * wavefront that meets more than 128 of them between two steps reports its queries lost: cnt = cap + 1).
  */
 int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
-                          int exclude_self, int tile_begin, int tile_end, const uint32_t* meta, const float* tau, uint64_t* buf,
-                          int32_t* cnt, int cap, int shape, void* stream) {
+                          int exclude_self, int tile_begin, int tile_end, int tile_stride, const uint32_t* meta, const float* tau,
+                          uint64_t* buf, int32_t* cnt, int cap, int shape, void* stream) {
     if (!q16 || !y16 || !meta || !tau || !buf || !cnt || nq <= 0 || n_db <= 0 || d <= 0 || cap <= 0) return TDR_ERR_BAD_ARG;
     if (terms < 1 || terms > 3) return TDR_ERR_BAD_ARG;
     const int ks = flat::flat_ks(d);
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     const int n_tiles = (int)((n_db + scr::TILE_ROWS - 1) / scr::TILE_ROWS);
-    if (tile_begin < 0 || tile_end > n_tiles || tile_begin >= tile_end) return TDR_ERR_BAD_ARG;
+    if (tile_begin < 0 || tile_end > n_tiles || tile_begin >= tile_end || tile_stride < 1) return TDR_ERR_BAD_ARG;
     if (n_db > 0x7fffffffLL) return TDR_ERR_UNSUPPORTED;
     flat::FlatParams P;
     P.qp = q16; P.yp = y16; P.meta = meta; P.nq = nq; P.q_offset = q_offset; P.n_db = n_db; P.exclude_self = exclude_self;
     P.t_begin = tile_begin; P.t_end = tile_end; P.dpad = ks * 16; P.tau = tau; P.buf = buf; P.cnt = cnt; P.cap = cap;
+    P.n_tiles = n_tiles; P.stride = tile_stride;
     hipStream_t st = (hipStream_t)stream;
     switch (ks) {
         case 2: return flat::launch_flat_ks<2>(P, terms, shape, st);
         case 4: return flat::launch_flat_ks<4>(P, terms, shape, st);
         default: return flat::launch_flat_ks<8>(P, terms, shape, st);
     }
+}
+
+/* labels[i] = the centre nearest to point i by the one-term screening value (x16 / c16: fp16-split images of the n points and
+ * of the n_centres centres, packed with the same meta).  An approximate arg-min (2^-10 relative): for building clusters. */
+int tdr_cluster_assign16_f32(const float* x16, int64_t n, const float* c16, int n_centres, int d, const uint32_t* meta,
+                             int32_t* labels, void* stream) {
+    if (!x16 || !c16 || !meta || !labels || n <= 0 || n_centres <= 0 || d <= 0) return TDR_ERR_BAD_ARG;
+    const int ks = flat::flat_ks(d);
+    if (ks == 0) return TDR_ERR_UNSUPPORTED;
+    const int64_t n_qtiles = (n + 31) / 32;
+    const dim3 grid((unsigned)((n_qtiles + flat::NW - 1) / flat::NW));
+    hipStream_t st = (hipStream_t)stream;
+    switch (ks) {
+        case 2: hipLaunchKernelGGL(flat::nearest_centre_kernel<2>, grid, dim3(256), 0, st, x16, n, c16, n_centres, meta, labels); break;
+        case 4: hipLaunchKernelGGL(flat::nearest_centre_kernel<4>, grid, dim3(256), 0, st, x16, n, c16, n_centres, meta, labels); break;
+        default: hipLaunchKernelGGL(flat::nearest_centre_kernel<8>, grid, dim3(256), 0, st, x16, n, c16, n_centres, meta, labels); break;
+    }
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
 }
 
 /*
@@ -500,6 +662,7 @@ int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra
     if (!list || !extra || !norms_q || !meta || !tau || !lost || nq <= 0 || k < 1 || L < k || n_sets < 1 || stride < 1)
         return TDR_ERR_BAD_ARG;
     if (extra_cnt && n_sets != 1) return TDR_ERR_BAD_ARG;
+    if (L > 128) return TDR_ERR_UNSUPPORTED;   // the select kernel keeps two list entries per lane
     const int ks = flat::flat_ks(d);
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     flat::SelectParams S;

@@ -135,6 +135,8 @@ struct ScreenParams {
     int max_visit;                  // approximate (IVF-style) search: clusters a workgroup may scan at most; 0 = exact
     const float* tile_cdist;        // optional (n_db_tiles, n_clusters): lower bound of min over the tile's rows of |x - c_c| --
                                     // the bound |x - y| >= |x - c_c| - R_c of the tile's own rows replaces the ball-to-ball bound
+    int tile_stride, tile_mod;      // tile_mod > 0 (the pilot of the threshold scan): position T of the range stands for tile
+                                    // (T * tile_stride) mod tile_mod -- a range of positions is spread over the whole database
 };
 
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
@@ -545,9 +547,10 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
     int t_end = t_begin + P.tiles_per_split;
     if (t_end > P.n_db_tiles) t_end = P.n_db_tiles;
 
+    auto tile_of = [&](int T) { return P.tile_mod > 0 ? (int)(((int64_t)T * P.tile_stride) % P.tile_mod) : T; };
     auto stage = [&](int T) {
         const int rel = T - t_begin;
-        const float* src = P.yp + (size_t)T * TILE_F;
+        const float* src = P.yp + (size_t)tile_of(T) * TILE_F;
         char* dst = (rel & 1) ? tile1 : tile0;
         constexpr int NSTG = (TERMS == 3) ? NBLK : KS;  // 1-KiB pieces to stage
 #pragma unroll
@@ -581,13 +584,13 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
         while (T < r_end) {
             if (T + 1 < r_end) stage(T + 1);
             const char* img = ((T - t_begin) & 1) ? tile1 : tile0;
-            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, img, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
+            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, img, bh, bl, accB, accA, TDR_YN(T - 1), tile_of(T - 1), tau_r);
             __syncthreads();
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) accA[qb] = accB[qb];
             ++T;
         }
-        if (wave_active) stile_drain<ITEMS, QB>(C, accA, TDR_YN(r_end - 1), r_end - 1, tau_r);
+        if (wave_active) stile_drain<ITEMS, QB>(C, accA, TDR_YN(r_end - 1), tile_of(r_end - 1), tau_r);
         __syncthreads();  // the last norm-ring slot / tile buffers may be restaged by the next range
     };
 
@@ -1199,6 +1202,7 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     P.clus_order = ct ? ct->clus_order : nullptr;
     P.max_visit = ct ? ct->max_visit : 0;
     P.tile_cdist = ct ? ct->tile_cdist : nullptr;
+    P.tile_stride = 1; P.tile_mod = 0;
     const int64_t need = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
     if (ws_bytes < need) return TDR_ERR_WORKSPACE;
     int wgs = (int)((nq + 128 * cfg.qb - 1) / (128 * cfg.qb));
@@ -1242,38 +1246,47 @@ int tdr_knn_screen_pilot_f32(const float* q16, const float* Xq, int64_t ldq, con
 /* ---- the UNPRUNED two-stage search as a threshold scan (csrc/tdr_knn_flat.hip) ------------------------------------------ */
 int tdr_knn_flat_supported(int d);
 int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
-                          int exclude_self, int tile_begin, int tile_end, const uint32_t* meta, const float* tau, uint64_t* buf,
-                          int32_t* cnt, int cap, int shape, void* stream);
+                          int exclude_self, int tile_begin, int tile_end, int tile_stride, const uint32_t* meta, const float* tau,
+                          uint64_t* buf, int32_t* cnt, int cap, int shape, void* stream);
 int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra, const int32_t* extra_cnt, int n_sets,
                             int stride, const float* norms_q, const uint32_t* meta, int64_t nq, int d, int k, int L, int terms,
                             float* tau, int32_t* lost, float* guard, void* stream);
 
 namespace {
-constexpr int FLAT_CAP = 256;        // appended entries a query may collect per pass (~3k expected)
+constexpr int FLAT_CAP = 256;        // appended entries a query may collect per pass
 constexpr int FLAT_MIN_TILES = 4096; // database tiles below which the list-keeping kernel serves the search
 
 struct FlatPlan {
     ScreenCfg pilot_cfg;
-    int ks, pilot_tier, pilot_tiles, pilot_splits, Lp, L, n_tiles;
-    int64_t off_list, off_buf, off_cnt, off_tau, off_lost, off_guard, total;   // byte offsets into the workspace
+    int ks, pilot_tiles, pilot_splits, Lp, L, n_tiles, stride;
+    int64_t off_list, off_buf, off_cnt, off_tau, off_lost, off_guard, total;   // byte offsets into the workspace (pilot lists at 0)
 };
 
-// pilot = the list-keeping kernel of the same number of terms on the first 1/64 of the database tiles
+// pilot = the list-keeping kernel of the same number of terms over the first 1/64 of the tile POSITIONS, with lists of k + 4
+// entries only: the pilot must deliver an upper bound of a_(k) and whatever of its range may belong to the final lists; a full
+// pilot list is covered by the guard (the rescoring kernel flags a query whose band reaches the smallest value a pilot list
+// may have dropped).  Short lists cut the pilot's sorted insertions -- L (1 + ln(n / L)) per query -- by three.
 static bool flat_plan(int64_t nq, int64_t n_db, int d, int k, int terms, int L, FlatPlan* F) {
     F->ks = pick_ks(d);
     if (F->ks == 0 || F->ks > 8 || (terms != 1 && terms != 3) || L < k || L > 128) return false;
     F->n_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
     if (F->n_tiles < FLAT_MIN_TILES) return false;
-    F->pilot_tier = terms == 1 ? 0 : 1;
-    F->pilot_cfg = screen_cfg(F->ks, k, F->pilot_tier);
-    if (F->pilot_cfg.L == 0 || F->pilot_cfg.terms != terms) return false;
-    F->Lp = F->pilot_cfg.L;
+    F->pilot_cfg = screen_cfg(F->ks, k, terms == 1 ? 0 : 1);
+    if (F->pilot_cfg.L == 0 || F->pilot_cfg.terms != terms || F->pilot_cfg.items != 1) return false;
+    F->Lp = k + 4 < F->pilot_cfg.L ? k + 4 : F->pilot_cfg.L;
     F->L = L;
     int pt = F->n_tiles / 64;
     if (pt < 64) pt = 64;
     F->pilot_tiles = pt & ~1;
     F->pilot_splits = screen_splits(nq, F->pilot_tiles, F->pilot_cfg);
     if (F->pilot_splits > 8) F->pilot_splits = 8;
+    // visiting order of the tiles: position j -> tile (j * stride) mod n_tiles, stride ~ 0.618 n_tiles and coprime to it: the
+    // pilot and every pass see rows from all over the database (a block sorted by class would otherwise take its thresholds
+    // from one class and flood the buffers of every other)
+    int st = (int)((double)F->n_tiles * 0.6180339887) | 1;
+    auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+    while (st < F->n_tiles && gcd(st, F->n_tiles) != 1) st += 2;
+    F->stride = st < F->n_tiles ? st : 1;
     int64_t o = 0;
     o += (int64_t)F->pilot_splits * nq * F->Lp * 8;                 // pilot lists (offset 0)
     F->off_list = o; o += nq * (int64_t)L * 8;
@@ -1324,30 +1337,30 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
     float* guard = (float*)(w + F.off_guard);
     if (hipMemsetAsync(lost, 0, (size_t)nq * 4, st) != hipSuccess) return (int)hipGetLastError();
 
-    // 1. pilot: the list-keeping kernel over the first tiles
+    // 1. pilot: the list-keeping kernel over the first positions of the visiting order, short lists
     ScreenParams P;
-    P.qp = q16; P.yp = y16; P.meta = meta; P.nq = nq; P.q_offset = q_offset;
-    P.n_db = (int64_t)F.pilot_tiles * TILE_ROWS < n_db ? (int64_t)F.pilot_tiles * TILE_ROWS : n_db;
+    P.qp = q16; P.yp = y16; P.meta = meta; P.nq = nq; P.q_offset = q_offset; P.n_db = n_db;
     P.k = k; P.L = F.Lp; P.exclude_self = exclude_self;
     P.n_db_tiles = F.pilot_tiles; P.n_splits = F.pilot_splits;
     P.tiles_per_split = (P.n_db_tiles + P.n_splits - 1) / P.n_splits;
     P.dpad = F.ks * 16; P.terms = terms; P.cand = pilot; P.n_clusters = 0; P.batch0 = 0;
     P.tile_cluster = nullptr; P.clus_tile_begin = nullptr; P.clus_radius = nullptr; P.clus_dist = nullptr; P.clus_order = nullptr;
     P.max_visit = 0; P.tile_cdist = nullptr;
+    P.tile_stride = F.stride; P.tile_mod = F.n_tiles;
     const int wgs = (int)((nq + 128 * F.pilot_cfg.qb - 1) / (128 * F.pilot_cfg.qb));
     int rc = launch_lists_scan(P, F.pilot_cfg, F.ks, wgs, st);
     if (rc != TDR_OK) return rc;
     // 2. its lists -> the first list of L, tau, and the guard (what a full pilot list may have dropped)
     rc = tdr_knn_flat_select_f32(list, 0, pilot, nullptr, F.pilot_splits, F.Lp, norms_q, meta, nq, d, k, L, terms, tau, lost, guard, stream);
     if (rc != TDR_OK) return rc;
-    // 3. threshold passes over growing ranges, a select after each
+    // 3. threshold passes over growing ranges of positions, a select after each
     int bounds[4] = {F.pilot_tiles, (F.n_tiles / 16) & ~1, (F.n_tiles / 4) & ~1, F.n_tiles};
     for (int i = 1; i < 4; ++i)
         if (bounds[i] < bounds[i - 1]) bounds[i] = bounds[i - 1];
     for (int i = 0; i < 3; ++i) {
         if (bounds[i + 1] <= bounds[i]) continue;
-        rc = tdr_knn_flat_scan_f32(q16, nq, q_offset, y16, n_db, d, terms, exclude_self, bounds[i], bounds[i + 1], meta, tau, buf, cnt,
-                                   FLAT_CAP, 0, stream);
+        rc = tdr_knn_flat_scan_f32(q16, nq, q_offset, y16, n_db, d, terms, exclude_self, bounds[i], bounds[i + 1], F.stride, meta, tau, buf,
+                                   cnt, FLAT_CAP, 0, stream);
         if (rc != TDR_OK) return rc;
         rc = tdr_knn_flat_select_f32(list, 1, buf, cnt, 1, FLAT_CAP, norms_q, meta, nq, d, k, L, terms, tau, lost, nullptr, stream);
         if (rc != TDR_OK) return rc;

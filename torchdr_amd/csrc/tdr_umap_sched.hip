@@ -759,35 +759,12 @@ struct SchedGradParams {
     // joint launch: ALL slices in one grid, workgroup b on XCD b % 8 (round-robin dispatch) takes slice (b % 8) / (8 / S),
     // so every XCD's L2 still holds one slice; partial sums go to plane `slice` of acc and a combine kernel finishes
     int joint;
-    int sort_rows;                  // 1: the 64 rows of a workgroup are dealt to its row groups in order of their active counts
     int nc;                         // actual row width of Z / grad / acc (PAD instances: NC is the padded register width)
     uint32_t j_r_lo[8], j_r_len[8], j_lvl_xor[8][3];
     int j_lvl_upper[8][3];
-    // round 4, joint launch with the combine + SGD step INSIDE it (nc = 2, 4 lanes per row): the slice workgroups of a
-    // 64-row block publish their partial sums write-through and draw a ticket; the last one adds the planes in slice
-    // order, clamps, writes the gradient and steps the rows into Znext (Z itself is being gathered by the whole grid)
-    int fuse;
-    float* Znext;
-    float lr, momentum;
-    int first;                      // 1: the momentum buffer is not initialised yet
-    float* mom_buf;
-    int* nan_flag;
-    int* tickets;                   // one per 64-row block, zero between launches
-    int step_iter;                  // iteration number reported by the NaN flag
 };
 
 typedef float sched_f32x4 __attribute__((ext_vector_type(4)));
-// write-through store / L2-bypassing load of 16 bytes: the hand-off of the partial-sum planes between workgroups that may
-// sit on different XCDs (whose L2s are not coherent with each other) -- cdna_hip_programming.md, Guideline 16
-__device__ __forceinline__ void store16_sc1(float* p, sched_f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ sched_f32x4 load16_sc1(const float* p) {
-    sched_f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
 // this slice's share of the row's n_use negatives: binomial halving level by level (= slice_count(),
 // tdr_embed_common.h) with the hash words spread over the G lanes of the row group and a DPP reduction.  Every level
 // flips FAIR coins, which is the exact multinomial split when the S slices of the reduced index range [0, N - 1) are
@@ -858,49 +835,12 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
     }
     int64_t r = (blk * 256 + threadIdx.x) / G;
     uint2 h;
-    if (G == 4 && P.sort_rows) {
-        // A wavefront runs as many rounds as the busiest of its 16 rows (a row has 5 negatives per fired edge: ~26 items
-        // per slice, sigma ~13, a round is 16 items: 4.0 rounds per wavefront in order, 2.9 dealt -- tools/round_model.py).  Counting sort of the workgroup's 64 rows by active count: rows with
-        // similar item counts share a wavefront.  Which row group evaluates a row does not enter its result.
-        __shared__ int s_hist[64];
-        __shared__ uint2 s_hdr[64];
-        __shared__ int s_row[64];
-        const int slot = threadIdx.x >> 2, lane = threadIdx.x & 63;
-        const bool have = r < P.n_rows;
-        uint2 h0 = make_uint2(0u, 0u);
-        if (have) h0 = P.hdr[(size_t)(P.t_local * P.S + slice) * P.n_rows + r];
-        int key = have ? (int)(h0.y >> 16) : 63;
-        key = key > 62 && have ? 62 : key;
-        if (threadIdx.x < 64) s_hist[threadIdx.x] = 0;
-        __syncthreads();
-        int within = 0;
-        if (gl == 0) within = atomicAdd(&s_hist[key], 1);
-        __syncthreads();
-        const int cnt = s_hist[lane];
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int up = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += up;
-        }
-        const int rank = __shfl(incl - cnt, key, 64) + within;
-        if (gl == 0) { s_hdr[rank] = h0; s_row[rank] = slot; }
-        __syncthreads();
-        r = blk * 64 + s_row[slot];
-        h = s_hdr[slot];
-    } else if (r < P.n_rows) {
+    if (r < P.n_rows) {
         typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
         const u32x2_t hv = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(P.hdr + (size_t)(P.t_local * P.S + slice) * P.n_rows + r));
         h = make_uint2(hv.x, hv.y);
     }
-    // rows beyond the chunk: gone, unless the step is fused into this launch (every thread must reach its barrier)
-    const bool fuse = NC == 2 && !PAD && G == 4 && P.joint && P.fuse;
-    const bool active = r < P.n_rows;
-    if (!active) {
-        if (!fuse) return;
-        h = make_uint2(0u, 0u);
-        r = 0;
-    }
+    if (r >= P.n_rows) return;   // rows beyond the chunk
     const uint32_t gi = (uint32_t)(P.row0 + r);
     const Vec<NC> zi = load_row(gi);
     const int32_t* lst = P.list + h.x;
@@ -975,43 +915,6 @@ __global__ __launch_bounds__(256) void umap_sched_grad_kernel(const SchedGradPar
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) { ga[c] = group_sum_dpp<G>(ga[c]); gr[c] = group_sum_dpp<G>(gr[c]); }
-    if (fuse) {
-        if (gl == 0 && active) store16_sc1(P.acc + ((size_t)slice * P.n_rows + r) * 4, sched_f32x4{ga[0], ga[1], gr[0], gr[1]});
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __shared__ int s_last;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            s_last = __hip_atomic_fetch_add(&P.tickets[blk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.S - 1 ? 1 : 0;
-        __syncthreads();
-        if (!s_last) return;
-        // last arriver of this row block: umap_sched_combine_sgd_kernel's arithmetic on its 64 rows
-        const int64_t rr = blk * 64 + threadIdx.x;
-        if (threadIdx.x < 64 && rr < P.n_rows) {
-            sched_f32x4 a = load16_sc1(P.acc + (size_t)rr * 4);
-            for (int sl = 1; sl < P.S; ++sl) {
-                const sched_f32x4 b4 = load16_sc1(P.acc + ((size_t)sl * P.n_rows + rr) * 4);
-                a = b4 + a;      // planes added in slice order: the association of the separate launches
-            }
-            bool nan = false;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const int64_t i = rr * 2 + c;
-                float g = P.exag * fminf(fmaxf(a[c], -4.f), 4.f) + P.rep * fminf(fmaxf(a[2 + c], -4.f), 4.f);
-                if (P.grad) P.grad[i] = g;
-                if (P.momentum != 0.f) {
-                    const float bprev = P.first ? 0.f : P.mom_buf[i];
-                    g = P.first ? g : __fadd_rn(__fmul_rn(bprev, P.momentum), g);
-                    P.mom_buf[i] = g;
-                }
-                const float z = fmaf(-P.lr, g, P.Z[(size_t)(P.row0 + rr) * 2 + c]);
-                P.Znext[(size_t)(P.row0 + rr) * 2 + c] = z;
-                nan = nan || z != z;
-            }
-            if (nan) atomicCAS(P.nan_flag, 0, P.step_iter + 1);
-        }
-        if (threadIdx.x == 0) __hip_atomic_store(&P.tickets[blk], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
     if (gl == 0 && P.joint) {  // this slice's partial sums; umap_sched_combine_kernel adds the planes in slice order
         float* acc = P.acc + ((size_t)slice * P.n_rows + r) * 2 * nc;
         if (NC == 2 && !PAD) {
@@ -1262,7 +1165,6 @@ static int launch_sched_build2(const SchedBuild2Params& P0, hipStream_t st, bool
 // slices spread over the XCDs and a combine kernel; acc must then hold S planes of (n_rows, 2 nc) floats
 static int launch_sched_grad_all(SchedGradParams& P, int geom, hipStream_t st) {
     P.joint = 0;
-    P.sort_rows = (geom & 64) ? 1 : 0;
     if ((geom & 16) && P.S > 1) {
         for (int s = 0; s < P.S; ++s) {
             sched_pass_constants(P, s);
@@ -1604,48 +1506,6 @@ int tdr_umap_sched_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row
     hipStream_t st = (hipStream_t)stream;
     P.nc = nc;
     return launch_sched_grad_all(P, geom, st);
-}
-
-/* Number of ticket counters (device int32, zero-initialised once by the caller) tdr_umap_sched_grad_step_f32 needs. */
-int64_t tdr_umap_sched_ticket_count(int64_t n_rows, int n_slices) {
-    if (n_rows <= 0 || (n_slices != 2 && n_slices != 4 && n_slices != 8)) return 0;
-    const int per = 8 / n_slices;
-    const int64_t blocks = (n_rows + 63) / 64;
-    return ((blocks + per - 1) / per) * per;
-}
-
-/* tdr_umap_sched_grad_f32 (joint launch, all slices in one grid) WITH the combine + torch.optim.SGD step inside the launch
- * (round 4): no combine kernel, no second pass over the planes.  The slice workgroups of a 64-row block store their partial
- * sums write-through and draw a ticket; the last one adds the planes in slice order (bit-identical to
- * tdr_umap_sched_step_f32), clamps (umap.py:262,290), writes grad (may be NULL) and steps the rows:
- * Znext[row] = Z[row] - lr * (momentum form of tdr_sgd_step_f32).  Z is gathered by the whole grid during the launch, so the
- * stepped rows go to a SECOND buffer (same shape as Z); the caller swaps the two.  nc = 2, n_slices in {2, 4, 8}, 4 lanes per row
- * (geom: only bit 6 is read).  tickets: tdr_umap_sched_ticket_count(...) ints, zero before the first call (every launch leaves
- * them zero).  acc: n_slices planes of (n_rows, 4) floats. */
-int tdr_umap_sched_grad_step_f32(const float* Z, float* Znext, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list,
-                                 const void* hdr, int t_local, int n_slices, float a, float b, int n_iter, int neg_rate, int n_negatives,
-                                 uint64_t seed, float exag, float rep, float eps, float* grad, float* acc, int geom, float lr,
-                                 float momentum, int first, float* mom_buf, int* nan_flag, int* tickets, void* stream) {
-    if (!Z || !Znext || Z == Znext || !list || !hdr || !acc || !nan_flag || !tickets || n_rows <= 0 || n_total < 2 || n_total >= 0x7fffffffLL)
-        return TDR_ERR_BAD_ARG;
-    if (t_local < 0 || t_local >= SCHED_BMAX || neg_rate < 0 || n_negatives < 0) return TDR_ERR_BAD_ARG;
-    if (n_slices != 2 && n_slices != 4 && n_slices != 8) return TDR_ERR_BAD_ARG;
-    if (momentum != 0.f && !mom_buf) return TDR_ERR_BAD_ARG;
-    SchedGradParams P = {};
-    P.Z = Z; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.list = list; P.hdr = (const uint2*)hdr;
-    P.t_local = t_local; P.S = n_slices; P.a = a; P.b = b; P.neg_rate = neg_rate; P.n_negatives = n_negatives;
-    P.neg_inj = nullptr; P.seed = seed; P.iter = (uint32_t)n_iter; P.iter_base = nullptr; P.exag = exag; P.rep = rep; P.eps = eps;
-    P.grad = grad; P.acc = acc; P.nc = 2;
-    P.fuse = 1; P.Znext = Znext; P.lr = lr; P.momentum = momentum; P.first = first; P.mom_buf = mom_buf; P.nan_flag = nan_flag;
-    P.tickets = tickets; P.step_iter = n_iter;
-    for (int sl = 0; sl < P.S; ++sl) {
-        sched_pass_constants(P, sl);
-        P.j_r_lo[sl] = P.r_lo; P.j_r_len[sl] = P.r_len;
-        for (int l = 0; l < 3; ++l) { P.j_lvl_xor[sl][l] = P.lvl_xor[l]; P.j_lvl_upper[sl][l] = P.lvl_upper[l]; }
-    }
-    P.joint = 1;
-    P.sort_rows = (geom & 64) ? 1 : 0;
-    return launch_sched_grad<2, 4>(P, (hipStream_t)stream);
 }
 
 /* Finish a joint evaluation (tdr_umap_sched_grad_f32 with geom & 48 == 48): gradient = exag * clamp(attraction) + rep *

@@ -239,7 +239,17 @@ class ClusterIndex:
             _, lab = knn_packed(Ps, PackedPoints(cent), 1, "sqeuclidean", exclude_self=False, _allow_screen=False)
             _lib.check(L.tdr_cluster_update_f32(_lib.ptr(Xs), S, D, _lib.ptr(lab), C, _lib.ptr(cent), _lib.ptr(ws), st),
                        "tdr_cluster_update_f32")
-        _, labels = knn_packed(P, PackedPoints(cent), 1, "sqeuclidean", exclude_self=False, _allow_screen=False)
+        if _opt("ASSIGN16") and L.tdr_knn_flat_supported(D) and N >= 65536:
+            # nearest centre by the one-term screening value on the f16 matrix pipe (0.4 ms at N = 1M, C = 1000, against 3.8-6.4 ms
+            # for the exact fp32 search with k = 1): the assignment shapes the clusters, no result depends on it
+            x16, meta16 = P.screen_image()
+            c16, _ = PackedPoints(cent).screen_image(meta16)
+            labels = torch.empty(N, dtype=torch.int32, device=dev)
+            _lib.check(L.tdr_cluster_assign16_f32(_lib.ptr(x16), N, _lib.ptr(c16), C, D, _lib.ptr(meta16), _lib.ptr(labels), st),
+                       "tdr_cluster_assign16_f32")
+            labels = labels.view(N, 1)
+        else:
+            _, labels = knn_packed(P, PackedPoints(cent), 1, "sqeuclidean", exclude_self=False, _allow_screen=False)
         # 4-5. radii (rounded up), padded cluster-sorted layout, centre distances (rounded down), visiting order
         cap = N + 32 * C
         radius = torch.empty(C, dtype=torch.float32, device=dev)
@@ -304,6 +314,14 @@ class ClusterIndex:
         visited = torch.mv((gap * gap <= tau).to(gap.dtype), t)
         return float((visited * t).sum() / (t.sum() ** 2))
 
+
+    def tiles_hopeless(self, tau: float) -> bool:
+        """True when NO per-tile bound can skip anything at threshold tau: a tile's bound to cluster c is at most
+        (|c_w - c_c| + R_w) - R_c (a row lies within R_w of its own centre), so if that stays below sqrt(tau) for every pair the
+        table (6-9 ms at N = 1M) would be built for nothing -- one Gaussian, uniform data: centre distances of a few units
+        under radii and neighbour distances several times that."""
+        reach = self.dist + self.radius[:, None] - self.radius[None, :]
+        return not bool((reach * reach.clamp(min=0) > tau).any())
 
     # ---- per-tile bounds: the second chance of data whose balls overlap ---------------------------------------------------
     def tile_table(self, P: "PackedPoints"):
@@ -407,6 +425,9 @@ def _screen_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier, p
 # _FLAT_L entries per query in HBM (the one-term tier then serves data whose error band holds up to ~100 candidates).
 FLAT_SCAN = True
 _FLAT_L = 128
+# ASSIGN16: the cluster index assigns the points to their nearest centres with the one-term f16 kernel (tdr_cluster_assign16_f32)
+# instead of the exact fp32 search with k = 1
+ASSIGN16 = True
 
 
 def _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier):
@@ -740,7 +761,7 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
             # the balls overlap too much for the ball-to-ball bound.  Second chance: the per-tile table (a few ms of dense
             # distances rows x centres) and its own prediction
             prune = False
-            if pilot_tau is not None and _opt("TILE_BOUNDS"):
+            if pilot_tau is not None and _opt("TILE_BOUNDS") and (_opt("TILE_BOUNDS") == "force" or not ci.tiles_hopeless(pilot_tau)):
                 tile_tab = ci.tile_table(Y)
                 # pilot_tau is the LARGEST k-th distance of the pilot rows and a workgroup prunes with its own, smaller,
                 # thresholds, so the prediction is pessimistic -- measured at N = 1M, D = 128 (unpruned -> tile bounds, ms):

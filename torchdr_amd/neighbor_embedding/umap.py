@@ -36,10 +36,9 @@ LOOP_GRAPH = True
 # bench.py sets this to a list to collect (start_event, end_event, n_iterations) per loop-runner segment
 LOOP_PROFILE = None
 SCHED_BLOCK_ITERS = 32
-# bit 6: the gradient kernel deals the 64 rows of a workgroup to its row groups in order of their active counts (a wavefront
-# runs as many rounds as its busiest row): worth 5 % in round 2 (0.287 -> 0.274 ms), nothing since -- round 4, same box, whole
-# fits: 355.2 ms with it, 352.2 ms without (its three barriers, the LDS histogram and the partial-line plane writes now cost what
-# the saved rounds return).  Off; same gradient bit for bit either way.
+# (round 5: the variants that were measured slower and kept behind switches -- rows of a workgroup dealt by load (geom bit 6),
+# the SGD step fused into the gradient launch, the schedule built one window ahead on a side stream -- are gone from the library;
+# their measurements stay in profiles/r04_grad_ablation.json, r04_fused_step.json, r04_build_ahead.json)
 SCHED_GEOM = 16
 SCHED_SLICES = 0
 # RELABEL: when the kNN stage worked in a cluster-sorted row order (pruned search) and nothing outside this class looks at
@@ -56,22 +55,6 @@ RELABEL = True
 # row-major order when it is read.  False: the row-chunk kernel of rounds 2-3 (tdr_umap_sched_build_f32).
 GROUPED = True
 SCHED_STAGE = 0      # LDS stage entries of the grouped build (0 = library default)
-# BUILD_AHEAD: the firing lists of window w + 1 depend on the epoch counters alone (the gradient launches never touch them), so
-# they are built on a SIDE stream into a second list / record buffer while the gradient launches of window w run: the build
-# was meant to fill the ramps and tails between the ~64 launches of a window instead of stopping the loop for a millisecond.  Same
-# lists, same order of everything that enters a result (tests/test_umap_sched_gpu.py); costs a second copy of the lists and
-# records.  Measured (profiles/r04_build_ahead.json): the device is work-bound across kernel boundaries -- the overlapped build
-# slows the gradient launches by its own work -- net 353.6 -> 350.3 ms per fit (0.9 %).  OFF by default: with it the per-kernel
-# durations of a trace overlap and no longer add up to the iteration, which is what the roofline line is audited against.
-BUILD_AHEAD = False
-# FUSE_STEP: stock estimator, one GPU, n_components = 2, more than one L2 slice: the combine + SGD step run INSIDE the joint
-# gradient launch (tdr_umap_sched_grad_step_f32: the last-arriving slice workgroup of every 64-row block finishes its rows)
-# instead of in a second kernel (tdr_umap_sched_step_f32).  The stepped rows land in a second embedding buffer (the first is
-# being gathered by the whole grid); the two swap storage after every iteration.  Same bits (tests/test_umap_sched_gpu.py::
-# test_step_inside_the_gradient_launch_equals_the_two_kernel_form) -- and SLOWER: gradient + step 0.287 ms per iteration against
-# 0.277 ms with the separate 11 us kernel (N = 1M, same box, profiles/r04_fused_step.json): every workgroup now drains its
-# write-through stores and meets a barrier before it may leave, and half of them read the planes back through the fabric.  Off.
-FUSE_STEP = False
 
 def _opt(name):
     """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
@@ -156,7 +139,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             raise AttributeError("epoch_of_next_sample")
         g = self.__dict__.get("_g")
         if g is not None and g["dirty"]:
-            self._join_build_ahead()      # a window being built ahead on the side stream is advancing the counters
             _lib.check(_lib.lib().tdr_umap_sched_ungroup_f32(_lib.ptr(self._csr_loop.rowptr), _lib.ptr(g["order"]), _lib.ptr(g["next"]),
                                                               self._csr_loop.n, _lib.ptr(self._next_rm), _lib.stream_ptr()),
                        "tdr_umap_sched_ungroup_f32")
@@ -168,9 +150,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         self._next_rm = value
         if self.__dict__.get("_g") is not None:   # a caller replaced the counters: the grouped copy follows
             g = self._g
-            self._join_build_ahead()
-            if self.__dict__.get("_sched"):
-                self._sched.pop("ahead", None)     # lists built ahead belong to the old counters: the next window is built in place
             g0 = self._csr_loop.rowptr[:-1:16]
             e0 = torch.repeat_interleave(g0, torch.cat([g0[1:], self._csr_loop.rowptr[-1:]]) - g0)
             g["next"] = value[e0 + g["order"].long()].contiguous()
@@ -179,13 +158,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
     @epoch_of_next_sample.deleter
     def epoch_of_next_sample(self):
         self.__dict__.pop("_next_rm", None)
-
-    def _join_build_ahead(self):
-        """Order the current stream after a schedule build that is still running on the side stream (BUILD_AHEAD)."""
-        sc = self.__dict__.get("_sched")
-        ah = sc.get("ahead") if sc else None
-        if ah is not None:
-            torch.cuda.current_stream(self.device_).wait_event(ah["done"])
 
     def _sched_slices(self) -> int:
         return int(_opt("SCHED_SLICES")) or int(_lib.lib().tdr_umap_sched_slices(self.n_samples_in_, self.n_components))
@@ -259,8 +231,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
     def on_affinity_computation_end(self):
         # plans and buffers of a previous fit (kept until clear_memory, which a fit that raised never reached) are sized
         # for THAT graph: never reuse them
-        self._join_build_ahead()
-        self._sched, self._grad_buf, self._sched_deferred, self._grad_ws, self._g, self._sched_stepped = None, None, False, None, None, False
+        self._sched, self._grad_buf, self._sched_deferred, self._grad_ws, self._g = None, None, False, None, None
         super().on_affinity_computation_end()
         csr: CSRAffinity = self._relabel()
         self._csr_loop = csr
@@ -373,30 +344,18 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         if sc["t0"] is None or not (sc["t0"] <= t < sc["t0"] + sc["n"]):
             n = max(1, min(sc["B"], int(self.max_iter) - t))
             g = getattr(self, "_g", None)
-            ah = sc.pop("ahead", None)
-            cur = torch.cuda.current_stream(self.device_)
-            if ah is not None:
-                cur.wait_event(ah["done"])
             if PROFILE is not None:
                 eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 eb0.record()
-
-            def build_groups(t_w, n_w, lst, hdr):
+            if g is not None:
                 _lib.check(
                     L.tdr_umap_sched_build_groups_f32(_lib.ptr(csr.rowptr), _lib.ptr(g["cols"]), _lib.ptr(g["eps"]), _lib.ptr(g["rs"]),
-                                                      _lib.ptr(g["next"]), self.chunk_size_, t_w, n_w, sc["S"], _lib.ptr(sc["blk_base"]),
-                                                      _lib.ptr(lst), _lib.ptr(hdr), _lib.ptr(sc["err"]),
+                                                      _lib.ptr(g["next"]), self.chunk_size_, t, n, sc["S"], _lib.ptr(sc["blk_base"]),
+                                                      _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), _lib.ptr(sc["err"]),
                                                       int(_opt("SCHED_STAGE")), _lib.stream_ptr()),
                     "tdr_umap_sched_build_groups_f32",
                 )
                 g["dirty"] = True
-
-            if g is not None and ah is not None and ah["t0"] == t and ah["n"] == n:
-                # this window was built ahead, into the second buffer: the two swap roles
-                sc["list"], sc["list2"] = sc["list2"], sc["list"]
-                sc["hdr"], sc["hdr2"] = sc["hdr2"], sc["hdr"]
-            elif g is not None:
-                build_groups(t, n, sc["list"], sc["hdr"])
             else:
                 _lib.check(
                     L.tdr_umap_sched_build_f32(_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample),
@@ -409,25 +368,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                 eb1.record()
                 PROFILE.append(("build", eb0, eb1, n))
             sc["t0"], sc["n"] = t, n
-            t_next = t + n
-            # (stock estimators only: a subclass that hooks into the loop may look at the epoch counters, which a window built
-            # ahead has already advanced past the end of the NEXT window)
-            if (g is not None and _opt("BUILD_AHEAD") and t_next < int(self.max_iter) and not getattr(self, "_loop_graph", False)
-                    and self._stock_step() and type(self).on_training_step_start is _stock_start()):
-                # the next window's lists, on the side stream, into the buffer the window before this one was read from: ordered
-                # after everything enqueued so far (those reads, and this window's build when it ran here)
-                if "list2" not in sc:
-                    sc["list2"], sc["hdr2"] = torch.empty_like(sc["list"]), torch.empty_like(sc["hdr"])
-                    sc["side"] = torch.cuda.Stream(device=self.device_)
-                n_next = max(1, min(sc["B"], int(self.max_iter) - t_next))
-                here = torch.cuda.Event()
-                here.record(cur)
-                sc["side"].wait_event(here)
-                with torch.cuda.stream(sc["side"]):
-                    build_groups(t_next, n_next, sc["list2"], sc["hdr2"])
-                    done = torch.cuda.Event()
-                    done.record(sc["side"])
-                sc["ahead"] = {"t0": t_next, "n": n_next, "done": done}
         if prof:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -436,31 +376,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         # them and steps the rows (`_sgd_kernel` below); anything that looks at the gradient in between keeps the form
         # with its own combine kernel
         self._sched_deferred = bool((geom & 16) and sc["S"] > 1 and self._fused_sgd and self._stock_step())
-        if (self._sched_deferred and _opt("FUSE_STEP") and self.n_components == 2 and self.world_size == 1 and neg is None
-                and self.embedding_.dtype == torch.float32 and self.chunk_size_ == self.n_samples_in_):
-            if "tickets" not in sc:
-                sc["tickets"] = torch.zeros(int(L.tdr_umap_sched_ticket_count(self.chunk_size_, sc["S"])), dtype=torch.int32, device=self.device_)
-                sc["Zalt"] = torch.empty_like(self.embedding_)
-            mom, first = float(self._sgd_momentum), 0
-            if mom != 0.0 and self._momentum_buf is None:
-                self._momentum_buf, first = torch.empty_like(self.embedding_), 1
-            holder = getattr(self, "optimizer_", None)
-            if isinstance(holder, torch.optim.Optimizer):
-                holder.param_groups[0]["lr"] = self._current_lr()
-            _lib.check(
-                L.tdr_umap_sched_grad_step_f32(
-                    _lib.ptr(self.embedding_), _lib.ptr(sc["Zalt"]), self.n_samples_in_, self.chunk_start_, self.chunk_size_,
-                    _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), t - sc["t0"], sc["S"], float(self._a), float(self._b), t,
-                    int(self.negative_sample_rate), int(self.n_negatives), self._neg_seed, float(self.early_exaggeration_coeff_),
-                    float(self.repulsion_strength), float(self._eps), _lib.ptr(grad), _lib.ptr(sc["acc"]), geom, self._current_lr(),
-                    mom, first, _lib.ptr(self._momentum_buf), _lib.ptr(self._nan_flag), _lib.ptr(sc["tickets"]), _lib.stream_ptr(),
-                ),
-                "tdr_umap_sched_grad_step_f32",
-            )
-            self._sched_stepped = True
-            if prof:
-                self._prof_pending = (ev0, ev1, csr.nnz)
-            return
         if self._sched_deferred:
             geom |= 32
         _lib.check(
@@ -497,19 +412,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             return super()._sgd_kernel(Z, grad, chunk=chunk)
         self._sched_deferred = False
         sc = self._sched
-        if getattr(self, "_sched_stepped", False):
-            # the gradient launch stepped the rows into the second buffer: the two swap storage (the tensor object, which the
-            # optimizer holder and the caller's references point to, stays)
-            self._sched_stepped = False
-            alt = sc["Zalt"]
-            cur = self.embedding_.data
-            self.embedding_.data = alt.data
-            alt.data = cur
-            pend = self.__dict__.pop("_prof_pending", None)
-            if pend is not None and PROFILE is not None:
-                pend[1].record()
-                PROFILE.append(("grad", pend[0], pend[1], pend[2]))
-            return
         mom = float(self._sgd_momentum)
         first = 0
         if mom != 0.0 and self._momentum_buf is None:
@@ -706,7 +608,6 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         return grad, True
 
     def clear_memory(self):
-        self._join_build_ahead()      # nothing of the loop's storage is released under a running build
         super().clear_memory()
         self.__dict__.pop("_g", None)
         for attr in ("_csr", "_csr_loop", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf", "_grad_ws", "_sched", "_loop_cols"):
