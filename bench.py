@@ -153,7 +153,8 @@ def knn_variants(X, args, dbase):
                 pairwise_distances(Xd, metric="sqeuclidean", k=args.k, exclude_diag=True, return_indices=True)
                 torch.cuda.synchronize()
                 best = min(best, time.perf_counter() - t0)
-            return best, dbase.LAST_KNN.get("path")
+            return best, dbase.LAST_KNN.get("path") + ("" if not dbase.LAST_KNN.get("flat_terms") else
+                                                        " (threshold scan, %d term%s)" % (dbase.LAST_KNN["flat_terms"], "" if dbase.LAST_KNN["flat_terms"] == 1 else "s"))
         finally:
             dbase.PRUNE_MODE, dbase.SCREEN_MODE = old
 
@@ -172,7 +173,9 @@ def knn_variants(X, args, dbase):
     out["knn_structureless_sec"] = t
     out["knn_structureless_path"] = path
     out["note"] = ("wall seconds of pairwise_distances(k=%d) incl. packing and pilots, best of 2, outside the timed region; "
-                   "structureless = the same generator with centre scale 0" % args.k)
+                   "structureless = the same generator with centre scale 0; unpruned searches of this size run as the threshold scan "
+                   "(csrc/tdr_knn_flat.hip: pilot -> fixed-threshold passes -> select -> rescoring; profiles/r05_knn_flat_scan_pmc.json: "
+                   "matrix pipe 59 %% busy at the 1.79 GHz the chip sustains under it)" % args.k)
     return out
 
 
@@ -193,6 +196,7 @@ def knn_uniform(args, dev, dbase):
         best = min(best, time.perf_counter() - t0)
     flops = 2.0 * args.n * args.n * args.d
     return {"sec": best, "k": 15, "path": dbase.LAST_KNN.get("path"), "tier": dbase.LAST_KNN.get("tier"),
+            "threshold_scan_terms": dbase.LAST_KNN.get("flat_terms"), "flagged_rows": dbase.LAST_KNN.get("flagged"),
             "algorithmic_tflops": flops / best / 1e12, "frac_of_f16_peak": flops / best / 1e12 / F16_MFMA_PEAK_TFLOPS,
             "reference_published_sec": 10.16, "reference_hardware": "1x NVIDIA B200, Faiss GpuIndexFlatL2 through torchdr.pairwise_distances",
             "note": "exact kNN of seed-42 randn(N, D), k = 15, wall incl. packing and pilots, best of 2, outside the timed region"}

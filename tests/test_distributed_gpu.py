@@ -167,7 +167,9 @@ def _worker(rank, world, port, ret, backend="gloo"):
 
         px = PeerExchange.shared(n, 2, torch.device("cuda", local))
         assert px is not None, "peer exchange unavailable (HIP IPC)"
-        assert mu.row_exchange_ == "PeerExchange" and m.row_exchange_ == "PeerExchange", (mu.row_exchange_, m.row_exchange_)
+        # UMAP exchanges rows (its step is the rows-only one); an estimator that all-reduces a full gradient or gathers through
+        # torch.distributed (the last of the loop above: COSNE) no longer builds an exchange context it would never use
+        assert mu.row_exchange_ == "PeerExchange" and m.row_exchange_ == "torch.distributed", (mu.row_exchange_, m.row_exchange_)
         for rnd in range(40):
             nc = 1 + rnd % 3
             Zx = torch.full((n, nc), float("nan"), device="cuda")

@@ -75,15 +75,25 @@ def main():
     shapes = ((1, 0), (1, 2), (1, 3), (1, 1), (1, 4), (2, 1), (2, 2), (3, 0), (3, 2))
     if len(sys.argv) > 3:
         shapes = tuple((int(a.split(":")[0]), int(a.split(":")[1])) for a in sys.argv[3].split(","))
+    stride = 1
     for terms, shape in shapes:
+        if shape >= 10:     # shape 1x: the same form with the strided visiting order of the production pipeline
+            shape -= 10
+            stride = int(n_tiles * 0.6180339887) | 1
+            import math
+            while math.gcd(stride, n_tiles) != 1:
+                stride += 2
+        else:
+            stride = 1
+
         def run():
-            _lib.check(L.tdr_knn_flat_scan_f32(_lib.ptr(q16), n, 0, _lib.ptr(y16), n, d, terms, 1, 0, n_tiles, 1, _lib.ptr(meta), _lib.ptr(tau),
+            _lib.check(L.tdr_knn_flat_scan_f32(_lib.ptr(q16), n, 0, _lib.ptr(y16), n, d, terms, 1, 0, n_tiles, stride, _lib.ptr(meta), _lib.ptr(tau),
                                                _lib.ptr(buf), _lib.ptr(cnt), cap, shape, _lib.stream_ptr()), "scan")
         t, _ = timed(run, reps=2)
         flops = 2.0 * n * n * d * terms
-        scans[f"terms{terms}_shape{shape}"] = {"sec": t, "executed_f16_tflops": flops / t / 1e12, "frac_f16_peak": flops / t / 2.5e15,
+        scans[f"terms{terms}_shape{shape}_stride{stride}"] = {"sec": t, "executed_f16_tflops": flops / t / 1e12, "frac_f16_peak": flops / t / 2.5e15,
                                               "mean_appended": float(cnt.float().mean()), "max_appended": int(cnt.max())}
-        print(json.dumps({f"scan_terms{terms}_shape{shape}": scans[f"terms{terms}_shape{shape}"]}), flush=True)
+        print(json.dumps({f"scan_terms{terms}_shape{shape}_stride{stride}": scans[f"terms{terms}_shape{shape}_stride{stride}"]}), flush=True)
     res["scan_alone"] = scans
     res["note"] = ("terms 1: shape 0 = two query tiles per wavefront, arithmetic between the matrix instructions (MODE 0); 2 = same, matrix "
                    "instructions back to back then the arithmetic (MODE 1); 3 = both query tiles together, alternating accumulators "

@@ -66,11 +66,10 @@ __device__ __forceinline__ float reduce_tau(float tau, float xn) {
 // SPARSE = false: a finished block's 16 candidate columns are kept and, when any of them survives, walked with a flush whenever
 //   the survivor buffer would not hold a column (a short range right after the pilot is DENSE: the same number of survivors per
 //   query falls on few rows, per cents of all candidates).
-// SPARSE = true (ranges of >= 2048 tiles, where a survivor is one candidate in thousands): each GROUP of four columns is tested
-//   and its survivors appended right where the group is reduced -- the event costs ~40 instructions instead of ~130 and no
-//   candidate column outlives its group; the buffer is flushed at the start of a step only (before the next tiles are
-//   requested, so the flush waits for nothing), and a wavefront that meets more than WBUF survivors between two flushes -- exact
-//   duplicates by the hundred -- reports all its queries lost (they are recomputed exactly).
+// SPARSE = true (ranges of >= 1024 tiles, where a survivor is one candidate in thousands): the same walk with the buffer emptied
+//   at the start of a step or of a block's walk only -- a single block that brings more survivors than the buffer holds (exact
+//   duplicates by the hundred) marks the wavefront's queries lost (they are recomputed exactly).  (Testing and appending per group of four columns right where the group is
+//   reduced was built and measured slower: +11 % on the big pass -- four more wave-wide tests per block on the hot path.)
 // Variants measured and dropped (profiles/r05_knn_flat_variants.json): all matrix instructions of a block back to back before
 // the arithmetic; both query tiles of a database tile on alternating accumulators; a three-deep staging ring with counted
 // vmcnt waits -- all within 4 % of this form: the scan runs at the rate the matrix pipe sustains at the clock the chip holds
@@ -143,6 +142,10 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
     bool lostw = false;   // wave-uniform (SPARSE): the buffer could not take a group's survivors: all queries of the wavefront are lost
 
     const int n_steps = (P.t_end - P.t_begin + TPB - 1) / TPB;
+    // tiles of the next position to stage / to multiply: position j visits tile (j * stride) mod n_tiles, walked by additions
+    // (a 64-bit modulo per tile is a ~100-instruction software division on this hardware: +12 % on the whole scan when it sat here)
+    int Tst = (int)(((int64_t)P.t_begin * P.stride) % P.n_tiles), Tcp = Tst;
+    auto advance = [&](int& T) { T += P.stride; if (T >= P.n_tiles) T -= P.n_tiles; };
 
     auto stage = [&](int s) {
         char* dstbase = stage0 + (s & 1) * STEP_LDS;
@@ -150,8 +153,9 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
         for (int tt = 0; tt < TPB; ++tt) {
             const int j = P.t_begin + s * TPB + tt;
             const int slot = (s * TPB + tt) & (NSLOT - 1);
+            const int T = Tst;
+            advance(Tst);
             if (j < P.t_end) {
-                const int T = (int)(((int64_t)j * P.stride) % P.n_tiles);
                 const float* src = P.yp + (size_t)T * TILE_F;
 #pragma unroll
                 for (int p0 = 0; p0 < NPIECE; p0 += NW) {
@@ -225,17 +229,22 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
         for (int e = 0; e < 4; ++e) dv[4 * g + e] = __builtin_fmaf(m2s, a[4 * g + e], ynb[g][e]);
         pm[g] = fminf(fminf(dv[4 * g], dv[4 * g + 1]), fminf(dv[4 * g + 2], dv[4 * g + 3]));
     };
-    // SPARSE: the group's survivors, taken where the group is reduced
-    auto sparse_group = [&](const float (&dv)[16], const float (&pm)[4], int g, int pq) {
+    // SPARSE: the block's survivors without a flush inside (the buffer is emptied at the start of a step; a block that would
+    // overflow it marks the wavefront's queries lost)
+    auto survivors_sparse = [&](const float (&dv)[16], const float (&pm)[4], int pq) {
         float tq, xq;
         uint32_t jself;
         query_of(pq, tq, xq, jself);
-        if (!__any(pm[g] <= tq)) return;
         const uint32_t jb = (uint32_t)Tprev * 32u + 4u * (uint32_t)h;
         bool again = false;
         int r0 = 0;
+        if (wcount >= WBUF / 2) flush();   // (then a single block must bring more than WBUF / 2 survivors to lose anything)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) take_column(dv[4 * g + e], tq, xq, jb + (uint32_t)(e + 8 * g), jself, pq, again, 4 * g + e, r0);
+        for (int g = 0; g < 4; ++g) {
+            if (!__any(pm[g] <= tq)) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) take_column(dv[4 * g + e], tq, xq, jb + (uint32_t)(e + 8 * g), jself, pq, again, 4 * g + e, r0);
+        }
     };
     // dense form: all 16 columns of the finished block, ONE flush site (a column that does not fit sends the walk back to the top)
     auto survivors = [&](const float (&dv)[16], const float (&pm)[4], int pq) {
@@ -301,7 +310,8 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
             const char* sbase = stage0 + (s & 1) * STEP_LDS;
 #pragma unroll
             for (int tt = 0; tt < TPB; ++tt) {
-                const int T = (int)(((int64_t)(P.t_begin + s * TPB + tt) * P.stride) % P.n_tiles);
+                const int T = Tcp;
+                advance(Tcp);
                 if (tt == 0) load_frags(sbase);
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
@@ -339,16 +349,18 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
                         }
                         if (cur == 0) finish_part(acc[1], yn[1], part, dv, pm);
                         else finish_part(acc[0], yn[0], part, dv, pm);
-                        if constexpr (SPARSE) sparse_group(dv, pm, part, pq);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if constexpr (!SPARSE) {
+                    {
                         float tq = tau_r[0];
 #pragma unroll
                         for (int b = 1; b < QB; ++b)
                             if (pq == b) tq = tau_r[b];
                         const float mn = fminf(fminf(pm[0], pm[1]), fminf(pm[2], pm[3]));
-                        if (__any(mn <= tq)) survivors(dv, pm, pq);
+                        if (__any(mn <= tq)) {
+                            if constexpr (SPARSE) survivors_sparse(dv, pm, pq);
+                            else survivors(dv, pm, pq);
+                        }
                     }
                     Tprev = T;   // this block is the next one's finished block
                 }
@@ -363,12 +375,8 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
         for (int g = 0; g < 4; ++g) finish_part(acc[1], yn[1], g, dv, pm);
         const float mn = fminf(fminf(pm[0], pm[1]), fminf(pm[2], pm[3]));
         if (__any(mn <= tau_r[QB - 1])) {
-            if constexpr (SPARSE) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) sparse_group(dv, pm, g, QB - 1);
-            } else {
-                survivors(dv, pm, QB - 1);
-            }
+            if constexpr (SPARSE) survivors_sparse(dv, pm, QB - 1);
+            else survivors(dv, pm, QB - 1);
         }
         flush();
         for (int p = lane; p < QB * 32; p += 64) {
@@ -579,7 +587,7 @@ static int launch_flat(const FlatParams& P, hipStream_t st) {
 // shape of the workgroup per tier: one / two terms keep two query tiles per wavefront (the query's h fragments are 64
 // VGPRs), three terms one (h and l fragments: 64 VGPRs per query tile).  shape: 0 = by the size of the range (sparse form from
 // SPARSE_MIN_TILES tiles), 1 = dense form, 2 = sparse form (tests, tools/knn_flat_lab.py)
-constexpr int SPARSE_MIN_TILES = 2048;
+constexpr int SPARSE_MIN_TILES = 1024;
 template <int KS>
 static int launch_flat_ks(const FlatParams& P, int terms, int shape, hipStream_t st) {
     const bool sparse = shape == 2 || (shape == 0 && P.t_end - P.t_begin >= SPARSE_MIN_TILES);
