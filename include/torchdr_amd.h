@@ -197,10 +197,10 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
 /* its stages, exposed for tests and measurement.  Tiles are visited in the order position j -> tile (j * tile_stride) mod n_tiles
  * (tile_stride coprime to the tile count; 1 = natural order): pilot and passes take ranges of POSITIONS, so each sees rows from all
  * over the database.  scan: positions [tile_begin, tile_end); buf (nq, cap) keys (screening value bits << 32 | database row),
- * cnt (nq) candidates met by THIS launch (> cap: the surplus was dropped); terms 1, 2 (h.h' + h.l') or 3; shape 0.
+ * cnt (nq) candidates met by THIS launch (> cap: the surplus was dropped; < 0: -(valid entries) - 1, the wavefront's survivor buffer overflowed); terms 1, 2 (h.h' + h.l') or 3; shape 0.
  * select: list (nq, L) in/out ascending, sentinel 0xFF800000FFFFFFFF; extra = the scan's buf with extra_cnt = cnt (n_sets 1,
  * stride cap), or n_sets x (nq, stride) full lists with extra_cnt NULL (then guard (nq) = the smallest last entry of a full
- * set); tau (nq) out = min(a_(k) + 2E, a_(L) when full); lost (nq) set to 1 where cnt > stride. */
+ * set); tau (nq) out = min(a_(k) + 2E, a_(L) when full); lost (nq) set to 1 where cnt > stride or cnt < 0. */
 int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
                           int exclude_self, int tile_begin, int tile_end, int tile_stride, const uint32_t* meta, const float* tau,
                           uint64_t* buf, int32_t* cnt, int cap, int shape, void* stream);

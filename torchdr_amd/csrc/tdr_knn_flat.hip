@@ -52,7 +52,8 @@ struct FlatParams {
     int dpad;
     const float* tau;      // (nq) thresholds in screening units (a = c' + ||x||^2); +inf passes everything
     uint64_t* buf;         // (nq, cap) appended keys (screening value bits << 32 | database row)
-    int32_t* cnt;          // (nq) entries this launch appended (> cap: the surplus was dropped -- overflow)
+    int32_t* cnt;          // (nq) entries this launch appended (> cap: the surplus was dropped; < 0: -(valid entries) - 1, the
+                           // wavefront dropped survivors of this or a neighbouring query)
     int cap;
 };
 
@@ -381,7 +382,9 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
         flush();
         for (int p = lane; p < QB * 32; p += 64) {
             const int64_t qi = qt0 * 32 + p;
-            if (qi < P.nq) P.cnt[qi] = lostw ? P.cap + 1 : cntw[p];
+            // a wavefront that dropped survivors reports -(valid entries) - 1: lost, and how much of the buffer may be read
+            const int have = cntw[p] < P.cap ? cntw[p] : P.cap;
+            if (qi < P.nq) P.cnt[qi] = lostw ? -have - 1 : cntw[p];
         }
     }
 #undef TDR_FLAT_MMA
@@ -475,8 +478,9 @@ __global__ __launch_bounds__(256) void knn_flat_select_kernel(const SelectParams
     bool lost = false;
     if (P.extra_cnt) {
         const int c = P.extra_cnt[qi];
-        lost = c > P.stride;
-        nE = lost ? P.stride : c;
+        lost = c > P.stride || c < 0;      // more than the region holds, or the scan's wavefront dropped survivors (-(valid) - 1)
+        nE = c < 0 ? -c - 1 : (c > P.stride ? P.stride : c);
+        if (nE > P.stride) nE = P.stride;
         for (int p = lane; p < nE; p += 64) ek[p] = P.extra[(size_t)qi * P.stride + p];
     } else {
         nE = maxE;
