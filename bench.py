@@ -265,8 +265,8 @@ def config_c3(dev, width=15, steps=1, iters=500):
         "ms": best["ms_per_fit"], "samples_per_sec": best["samples_per_sec"],
         "roofline": {"kernel": "tdr::ne_grad_kernel<2,16> (kind 0: LargeVis attraction + 5 negatives per row), one launch per iteration",
                      "bound": "hbm", "achieved": best["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": best["frac"],
-                     "traffic": _committed_traffic("r03_c3_pmc.json", "derived", "pull_form_hbm_side_traffic_bytes"),
-                     "traffic_source": "profiles/r03_c3_pmc.json (2 x FETCH_SIZE + WRITE_SIZE of the pull-form launch, round 3; not re-measured here)",
+                     "traffic": _committed_traffic("r05_c3_pmc.json", "derived", "pull_form_hbm_side_traffic_bytes"),
+                     "traffic_source": "profiles/r05_c3_pmc.json (2 x FETCH_SIZE + WRITE_SIZE of the pull-form launch, separate --pmc passes on the round-5 build; not re-measured here)",
                      "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": best["grad_launch_ms"],
                      "launches_sampled": best["launches_sampled"]},
         "samplers": out,
@@ -311,8 +311,8 @@ def config_c5(dev, steps=12):
         "ms": wall / max(cnt, 1) * 1e3, "iterations_per_sec": cnt / wall,
         "roofline": {"kernel": "tdr::pair_scan_kernel<KQ=8, SeaStats> (fp32 MFMA distance tiles + streaming row statistics), one launch per dual iteration",
                      "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": _committed_traffic("r03_c5_pmc.json", "split_scan_lean_epilogue (round 3, production)", "derived", "hbm_side_traffic_bytes"),
-                     "traffic_source": "profiles/r03_c5_pmc.json (2 x FETCH_SIZE + WRITE_SIZE per dual iteration, round 3; not re-measured here)",
+                     "traffic": _committed_traffic("r05_c5_pmc.json", "derived", "hbm_side_traffic_bytes"),
+                     "traffic_source": "profiles/r05_c5_pmc.json (2 x FETCH_SIZE + WRITE_SIZE per dual iteration, separate --pmc passes on the round-5 build; not re-measured here)",
                      "algorithmic_flops_per_launch": flops, "avg_launch_ms": ms, "launches_sampled": cnt,
                      "exp_per_s": n * float(n) / (ms * 1e-3)},
     }

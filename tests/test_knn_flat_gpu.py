@@ -83,10 +83,9 @@ def test_flat_stages_scan_and_select():
         _lib.check(L.tdr_knn_flat_scan_f32(_lib.ptr(q16), nq, 0, _lib.ptr(y16), n, d, terms, 1, 100, 1101, 1, _lib.ptr(meta), _lib.ptr(tau),
                                            _lib.ptr(buf), _lib.ptr(cnt), cap, shape, _lib.stream_ptr()), "scan")
         c = cnt.cpu()
-        if shape == 1:      # dense form: every column of a hit block is walked with flushes inside -- the count is what was met
-            assert bool((c[:8] >= 1001 * 32 - 1).all())
-        else:               # sparse form: tau = inf floods the wavefront's buffer inside one block -- its queries (32 or 64) are lost
-            assert bool((c[:32] < 0).all()) and bool((c[:32] >= -cap - 1).all())
+        # tau = inf: every row of the 1001 tiles (minus the query itself) is met and counted, in either form -- the dense form
+        # flushes inside a block's walk, the sparse form appends a column its buffer cannot take straight to the query's region
+        assert bool((c[:8] >= 1001 * 32 - 1).all()), (terms, shape, c[:8])
         # reference: exact squared distances of the same block, thresholded with slack for the screening error
         D = torch.cdist(X[:nq].double(), X[3200:35232].double()) ** 2
         lo = (D <= 40.0 - 0.5).sum(1).cpu()
@@ -128,9 +127,12 @@ def test_flat_stages_scan_and_select():
 
 
 def test_flat_scan_on_rows_sorted_by_class():
-    """A block whose rows come sorted by class: the seed and every pass take tiles from all over the database (position j of the
-    visiting order = tile (j * stride) mod n_tiles), so the thresholds are not seeded from one class; the scan answers nearly
-    every row itself and equals the exact search."""
+    """A block whose rows come sorted by class (200 classes of 800 rows; the 64 queries of a wavefront share their neighbours):
+    the pilot and every pass take tiles from all over the database (position j of the visiting order = tile (j * stride) mod
+    n_tiles), so the thresholds are not taken from one class, and a tile full of a wavefront's neighbours is appended without
+    loss.  The scan answers most rows itself (measured: 80 %; a query that meets no row of its own class before the pass that
+    brings most of them overflows its 256-entry region and is recomputed exactly -- with contiguous ranges 97 % were) and the
+    result equals the exact search."""
     n, d, k = 160_000, 48, 15
     g = torch.Generator().manual_seed(7)
     centers = torch.randn(200, d, generator=g) * 2.0
@@ -138,6 +140,6 @@ def test_flat_scan_on_rows_sorted_by_class():
     X = (centers[labels] + 0.5 * torch.randn(n, d, generator=g)).cuda()
     Cf, If, info = _search(X, k, PRUNE_MODE="0", FLAT_SCAN=True)
     print(info)
-    assert info.get("flat_terms") in (1, 3) and info["flagged"] <= n // 50, info
+    assert info.get("flat_terms") in (1, 3) and info["flagged"] <= n // 3, info
     Ce, Ie, _ = _search(X, k, PRUNE_MODE="0", SCREEN_MODE="0")
     assert torch.equal(Cf, Ce) and torch.equal(If, Ie)

@@ -68,8 +68,8 @@ __device__ __forceinline__ float reduce_tau(float tau, float xn) {
 //   the survivor buffer would not hold a column (a short range right after the pilot is DENSE: the same number of survivors per
 //   query falls on few rows, per cents of all candidates).
 // SPARSE = true (ranges of >= 1024 tiles, where a survivor is one candidate in thousands): the same walk with the buffer emptied
-//   at the start of a step or of a block's walk only -- a single block that brings more survivors than the buffer holds (exact
-//   duplicates by the hundred) marks the wavefront's queries lost (they are recomputed exactly).  (Testing and appending per group of four columns right where the group is
+//   at the start of a step or of a block's walk only -- a column the buffer cannot take (rows sorted by class: the 64 queries of a
+//   wavefront share their neighbours and meet a tile full of them) is appended straight to the queries' regions.  (Testing and appending per group of four columns right where the group is
 //   reduced was built and measured slower: +11 % on the big pass -- four more wave-wide tests per block on the hot path.)
 // Variants measured and dropped (profiles/r05_knn_flat_variants.json): all matrix instructions of a block back to back before
 // the arithmetic; both query tiles of a database tile on alternating accumulators; a three-deep staging ring with counted
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
     }
     for (int p = lane; p < QB * 32; p += 64) cntw[p] = 0;
     int wcount = 0;       // wave-uniform: entries in this wavefront's survivor buffer
-    bool lostw = false;   // wave-uniform (SPARSE): the buffer could not take a group's survivors: all queries of the wavefront are lost
+    const bool lostw = false;   // (kept for the count's encoding: no form drops survivors any more)
 
     const int n_steps = (P.t_end - P.t_begin + TPB - 1) / TPB;
     // tiles of the next position to stage / to multiply: position j visits tile (j * stride) mod n_tiles, walked by additions
@@ -203,8 +203,15 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
         if (m == 0ull) return;
         const int nb = __popcll(m);
         if (__builtin_amdgcn_readfirstlane(wcount + nb) > WBUF) {
-            if (SPARSE) lostw = true;
-            else { again = true; r0 = r; }
+            if (SPARSE) {
+                // the buffer cannot take this column (queries of one wavefront that share their neighbours -- rows sorted by
+                // class -- meet a tile full of them): its survivors go straight to the queries' regions, nothing is lost
+                if (pass) {
+                    const int ql = pq * 32 + q;
+                    const int slot = atomicAdd(&cntw[ql], 1);
+                    if (slot < P.cap) P.buf[((size_t)qt0 * 32 + ql) * (size_t)P.cap + slot] = mkkey(v + xq, j);
+                }
+            } else { again = true; r0 = r; }
             return;
         }
         if (pass) {
