@@ -126,6 +126,23 @@ def test_c2_umap_100k_knn_indices_vs_cpu_oracle_and_fit():
     from torchdr_amd.eval import knn_label_accuracy
 
     assert float(knn_label_accuracy(Z, lab.cuda(), k=10)) > 0.95
+    # the quality bar from the REFERENCE's own run: tests/golden/quality.json holds TorchDR's UMAP (backend=None,
+    # CPU, 500 iterations, two seeds) on the 20k-point instance of the same generator, scored with its own
+    # neighborhood_preservation (K = 15) and a 10-NN label accuracy (make_quality_golden.py; the 100k-point config cannot run
+    # through the reference's dense CPU path).  The same fit here must score within 10 % of it.
+    import json
+    import os
+
+    q = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quality.json")))
+    n2 = q["n"]
+    X2 = gmm(n2, q["d"], 2.0, seed=42).cuda()
+    ref_np = min(r["neighborhood_preservation_K15"] for r in q["runs"])
+    ref_acc = min(r["knn_label_accuracy_k10"] for r in q["runs"])
+    Z2 = torchdr_amd.UMAP(n_neighbors=q["n_neighbors"], max_iter=500, random_state=0).fit_transform(X2)
+    got_np = float(neighborhood_preservation(X2, Z2, K=15))
+    got_acc = float(knn_label_accuracy(Z2, (torch.arange(n2) % max(1, min(1000, n2 // 100))).cuda(), k=10))
+    print({"reference_np": ref_np, "np": got_np, "reference_acc": ref_acc, "acc": got_acc})
+    assert got_np >= 0.9 * ref_np and got_acc >= ref_acc - 0.01, (got_np, ref_np, got_acc, ref_acc)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -249,6 +266,32 @@ def test_c4_point_set_on_one_gpu():
     Z = torchdr_amd.UMAP(n_neighbors=k, max_iter=100, random_state=0).fit_transform(X)
     assert Z.shape == (n, 2) and bool(torch.isfinite(Z).all())
     assert torch.cuda.max_memory_allocated() < 64 * 2**30
+    del Z
+    # one sampled-gradient check at full size, as C3 has: the production gradient launch (in-kernel negatives,
+    # 8 L2 slices of the 32 MB embedding) of 2048 sampled rows against the oracle's closed form (umap.py:236-292) evaluated on
+    # the negatives the kernel draws, on the affinity graph of this point set
+    from tests.test_umap_sched_gpu import Sched, oracle_check, prepare
+    from torchdr_amd import _lib
+    from torchdr_amd.affinity import UMAPAffinity
+
+    csr = UMAPAffinity(n_neighbors=k, max_iter=100)(X, return_csr=True)
+    del X
+    eps_per, nxt = prepare(csr.vals, 500)
+    S = int(_lib.lib().tdr_umap_sched_slices(n, 2))
+    assert S == 8
+    sc = Sched(csr.rowptr, csr.cols, eps_per, n, 8, S)
+    before = None
+    for t0 in (0, 8):
+        before = nxt.clone()
+        sc.build(nxt, t0, 8)
+    gen = torch.Generator().manual_seed(1)
+    Zr = (torch.randn(n, 2, generator=gen) * 4).cuda().contiguous()
+    srows = torch.randperm(n, generator=gen)[:2048].sort().values
+    err = oracle_check(sc, Zr, before, 0, 8, 1.577, 0.895, 5 * k, 99, srows)
+    from tests.conftest import AUDIT
+
+    AUDIT["c4_umap_4m/sampled_gradient_vs_oracle"] = {"err_vs_reference_float32": err, "budget": 1e-5}
+    assert err < 1e-5, err
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -282,8 +325,34 @@ def test_c5_tsnekhorn_200k_symmetric_entropic_rows_vs_fp64():
     AUDIT["c5_sea_200k/row_entropy_relative_per_row"] = {"err_vs_float64": err_h, "budget": 3e-5}
     assert err_s < 3e-5 and err_h < 3e-5, (err_s, err_h)
     sea = torchdr_amd.SymmetricEntropicAffinity(perplexity=30, lr=1e-1, max_iter=5, zero_diag=False)
-    sea.fit_duals(X)
+    packed = sea.fit_duals(X)
     assert bool(torch.isfinite(sea.eps_).all()) and bool(torch.isfinite(sea.mu_).all())
+    # one sampled-gradient check at full size: the TSNEkhorn force scan (tdr_khorn_grad_f32: 4 sum_j (P_ij - Q_ij)
+    # / (1 + d_ij) (z_i - z_j), tsnekhorn.py:186-230 with the dual detached) on the duals just fitted, 128 sampled rows against a
+    # dense float64 evaluation of their 128 x 200k pairs on the host
+    import numpy as np
+
+    from torchdr_amd import _lib
+
+    mu_d, e_d = sea.dual_side()
+    Zr = (torch.randn(n, 2, generator=gen) * 3).cuda().contiguous()
+    dual = (torch.randn(n, generator=gen) * 0.1).cuda()
+    side = torch.stack([mu_d, e_d, Zr[:, 0], Zr[:, 1], dual.exp()], dim=1).contiguous()
+    grad = torch.empty((n, 2), device="cuda")
+    _lib.check(_lib.lib().tdr_khorn_grad_f32(_lib.ptr(packed.data), n, packed.d, _lib.ptr(side), float(np.log(n)), _lib.ptr(grad),
+                                             _lib.stream_ptr()), "khorn")
+    srows = torch.randperm(n, generator=gen)[:128]
+    Cs = (Xd[srows].pow(2).sum(1)[:, None] + Xd.pow(2).sum(1)[None, :] - 2.0 * Xd[srows] @ Xd.T)
+    mu_h, e_h, Zh, du_h = mu_d.cpu().double(), e_d.cpu().double(), Zr.cpu().double(), dual.cpu().double()
+    logP = (mu_h[srows, None] + mu_h[None, :] - 2 * Cs) / (e_h[srows, None] + e_h[None, :])
+    dz = Zh[srows][:, None, :] - Zh[None, :, :]
+    W = 1.0 / (1.0 + dz.pow(2).sum(-1))
+    Q = (du_h[srows, None] + du_h[None, :]).exp() * W / n
+    M = ((logP - float(np.log(n))).exp() - Q) * W       # P carries the 1/N of the joint affinity (tsnekhorn.py: log_P - log n)
+    g_ref = 4 * (M[:, :, None] * dz).sum(1)
+    from tests.conftest import grade64
+
+    grade64("c5_tsnekhorn_200k/sampled_force_rows_vs_float64", grad[srows.cuda()], g_ref, 3e-5)
     m = torchdr_amd.TSNEkhorn(perplexity=30, max_iter=3, max_iter_affinity_in=3, init="normal", init_scaling=1.0, lr=1.0,
                               optimizer="SGD", optimizer_kwargs=None, min_grad_norm=1e-30, random_state=0)
     Z = m.fit_transform(X)
