@@ -352,7 +352,7 @@ def test_c5_tsnekhorn_200k_symmetric_entropic_rows_vs_fp64():
     g_ref = 4 * (M[:, :, None] * dz).sum(1)
     from tests.conftest import grade64
 
-    grade64("c5_tsnekhorn_200k/sampled_force_rows_vs_float64", grad[srows.cuda()], g_ref, 3e-5)
+    grade64("c5_tsnekhorn_200k/sampled_force_rows_vs_float64", grad[srows.cuda()], g_ref, 1e-5)      # measured 6.4e-6
     m = torchdr_amd.TSNEkhorn(perplexity=30, max_iter=3, max_iter_affinity_in=3, init="normal", init_scaling=1.0, lr=1.0,
                               optimizer="SGD", optimizer_kwargs=None, min_grad_norm=1e-30, random_state=0)
     Z = m.fit_transform(X)

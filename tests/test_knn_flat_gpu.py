@@ -143,3 +143,40 @@ def test_flat_scan_on_rows_sorted_by_class():
     assert info.get("flat_terms") in (1, 3) and info["flagged"] <= n // 3, info
     Ce, Ie, _ = _search(X, k, PRUNE_MODE="0", SCREEN_MODE="0")
     assert torch.equal(Cf, Ce) and torch.equal(If, Ie)
+
+
+@pytest.mark.parametrize("separate", [False, True])
+def test_flat_scan_on_a_query_chunk_with_offset(separate):
+    """The row-chunked search of a sharded fit (distance/base.py:183-206 in the reference: a rank's chunk against the full
+    block, self excluded by GLOBAL index): queries = rows 3200 .. 43199 of the block, either as a row slice of the same packed
+    block or as a separate block with its own image and q_offset -- threshold scan == one-stage kernel, bit for bit; a cross
+    search without exclusion as well."""
+    from torchdr_amd import config
+    from torchdr_amd.distance import base as dbase
+
+    n, d, k, q0, nq = 140_000, 40, 12, 3200, 40_000
+    X = gmm(n, d, 1.0, seed=23).cuda()
+    Yp = dbase.PackedPoints(X)
+
+    def run(**opts):
+        with config.options(PRUNE_MODE="0", **opts):
+            if separate:
+                Qp = dbase.PackedPoints(X[q0:q0 + nq].clone())
+                out = dbase.knn_packed(Qp, Yp, k, "sqeuclidean", True, q_offset=q0)
+            else:
+                out = dbase.knn_packed(Yp, Yp, k, "sqeuclidean", True, q_rows=slice(q0, q0 + nq))
+        return out, dict(dbase.LAST_KNN)
+
+    (Cf, If), info = run(FLAT_SCAN=True)
+    assert info.get("flat_terms") in (1, 3) and info["flagged"] <= nq // 50, info
+    (Ce, Ie), _ = run(SCREEN_MODE="0")
+    assert torch.equal(If, Ie) and torch.equal(Cf, Ce)
+    assert not bool((If == torch.arange(q0, q0 + nq, device="cuda", dtype=torch.int32)[:, None]).any())
+    if separate:        # cross search, nothing excluded: a query's own row is its first neighbour
+        with config.options(PRUNE_MODE="0", FLAT_SCAN=True):
+            Qp = dbase.PackedPoints(X[q0:q0 + nq].clone())
+            Cx, Ix = dbase.knn_packed(Qp, Yp, k, "euclidean", False)
+            assert dbase.LAST_KNN.get("flat_terms") in (1, 3)
+        with config.options(PRUNE_MODE="0", SCREEN_MODE="0"):
+            Cy, Iy = dbase.knn_packed(Qp, Yp, k, "euclidean", False)
+        assert torch.equal(Ix, Iy) and torch.equal(Cx, Cy)
