@@ -477,6 +477,32 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
         // permutation sampler: item 2c = this row's own draw of column c, item 2c + 1 = the row whose draw of column c hit
         // this row; both are  +w (z_i - z_other)  on THIS row -- nothing is sent to the other endpoint
         const float own_inv = (S.kind == 3) ? 1.0f / S.rowsum[gi] : 0.f;
+        if (2 * S.n_neg <= G) {
+            // few negatives per row (LargeVis: 5): one (column, side) ITEM per lane -- 10 of the 16 lanes each issue one gather, instead
+            // of 5 lanes issuing two in a row (the launch is bound by the per-row dependency chain, profiles/r05_c3_pmc.json)
+            if (gl < 2 * S.n_neg) {
+                const int col = gl >> 1, side = gl & 1;
+                const PermKey K = perm_key(S.seed, S.iter, col, S.n_total);
+                const uint32_t a = perm_inv((uint32_t)gi, K);
+                const uint32_t j = side ? perm_pred(a, K) : perm_succ(a, K);
+                if ((int64_t)j >= j_lo && (int64_t)j < j_hi) {
+                    const Vec<NC> zj = load_zp<NC, PAD>(S.Z, j, nc);
+                    float df[NC];
+                    float d = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d += df[c] * df[c]; }
+                    float w;
+                    if (S.kind == 3) {
+                        const float q = 1.0f / (1.0f + d);
+                        w = -S.rep_coef * q * q * (side ? 1.0f / S.rowsum[j] : own_inv);
+                    } else {
+                        w = -S.rep_coef / ((1.0f + d) * (2.0f + d));
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) g[c] += w * df[c];
+                }
+            }
+        } else
         for (int col = gl; col < S.n_neg; col += G) {
             const PermKey K = perm_key(S.seed, S.iter, col, S.n_total);
             const uint32_t a = perm_inv((uint32_t)gi, K);       // this row's place in the column's cyclic order
