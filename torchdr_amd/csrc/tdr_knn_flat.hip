@@ -635,6 +635,13 @@ int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const 
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     const int n_tiles = (int)((n_db + scr::TILE_ROWS - 1) / scr::TILE_ROWS);
     if (tile_begin < 0 || tile_end > n_tiles || tile_begin >= tile_end || tile_stride < 1) return TDR_ERR_BAD_ARG;
+    {   // the visiting order must be a permutation of the tiles: stride below the tile count (the kernel walks it by additions)
+        // and coprime to it
+        if (tile_stride >= n_tiles && n_tiles > 1) return TDR_ERR_BAD_ARG;
+        int a = tile_stride, b = n_tiles;
+        while (b) { const int t = a % b; a = b; b = t; }
+        if (a != 1) return TDR_ERR_BAD_ARG;
+    }
     if (n_db > 0x7fffffffLL) return TDR_ERR_UNSUPPORTED;
     flat::FlatParams P;
     P.qp = q16; P.yp = y16; P.meta = meta; P.nq = nq; P.q_offset = q_offset; P.n_db = n_db; P.exclude_self = exclude_self;
