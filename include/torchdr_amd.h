@@ -182,8 +182,8 @@ int tdr_cluster_tile_cdist_f32(const float* d2, int64_t ld, int64_t rows, int C,
                                const float* cn, float* out, void* stream);
 /* The UNPRUNED two-stage search as a threshold scan (round 5, csrc/tdr_knn_flat.hip; replaces the list-keeping kernel where no
  * tile can be skipped -- distance/torch.py:82-122 on structureless data, benchmarks/faiss/run_benchmark.py:143-146):
- * pilot (list-keeping kernel with short lists on 1/64 of the database) -> select -> per-query threshold tau = a_(k) + 2E -> three
- * passes of tdr_knn_flat_scan_f32 over growing ranges (every candidate with screening value <= tau is appended to the query's
+ * seed (tdr_knn_flat_seed_f32: every screening value of 256 rows) -> select -> per-query threshold tau = a_(k) + 2E -> short passes
+ * of tdr_knn_flat_scan_f32 over ranges growing by four up to 1/64 of the database, then three long ones (every candidate with screening value <= tau is appended to the query's
  * buffer; no lists in LDS, two query tiles per wavefront, two database tiles per barrier) with a tdr_knn_flat_select_f32 after
  * each (list + appended -> the L smallest, new tau) -> the rescoring kernel.  Same operands, outputs and flag contract as tdr_knn_screen_f32; results are
  * bit-identical.  terms: 1 (h.h') or 3; L: list length per query (k <= L <= 128).  The workspace query returns 0 when the
@@ -196,17 +196,19 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
                             int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
 /* its stages, exposed for tests and measurement.  Tiles are visited in the order position j -> tile (j * tile_stride) mod n_tiles
  * (tile_stride coprime to the tile count; 1 = natural order): pilot and passes take ranges of POSITIONS, so each sees rows from all
- * over the database.  scan: positions [tile_begin, tile_end); buf (nq, cap) keys (screening value bits << 32 | database row),
+ * over the database.  seed: buf[q * cap + 32 j + r] = key of row r of the tile at position j < seed_tiles (sentinel for the query
+ * itself / padding).  scan: positions [tile_begin, tile_end); buf (nq, cap) keys (screening value bits << 32 | database row),
  * cnt (nq) candidates met by THIS launch (> cap: the surplus was dropped; < 0: -(valid entries) - 1, the wavefront's survivor buffer overflowed); terms 1, 2 (h.h' + h.l') or 3; shape 0.
  * select: list (nq, L) in/out ascending, sentinel 0xFF800000FFFFFFFF; extra = the scan's buf with extra_cnt = cnt (n_sets 1,
- * stride cap), or n_sets x (nq, stride) full lists with extra_cnt NULL (then guard (nq) = the smallest last entry of a full
- * set); tau (nq) out = min(a_(k) + 2E, a_(L) when full); lost (nq) set to 1 where cnt > stride or cnt < 0. */
+ * stride cap), or n_sets x (nq, stride) keys with extra_cnt NULL (every entry counts, sentinels allowed: the seed); tau (nq) out = min(a_(k) + 2E, a_(L) when full); lost (nq) set to 1 where cnt > stride or cnt < 0. */
+int tdr_knn_flat_seed_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
+                          int exclude_self, int seed_tiles, int tile_stride, const uint32_t* meta, uint64_t* buf, int cap, void* stream);
 int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
                           int exclude_self, int tile_begin, int tile_end, int tile_stride, const uint32_t* meta, const float* tau,
                           uint64_t* buf, int32_t* cnt, int cap, int shape, void* stream);
 int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra, const int32_t* extra_cnt, int n_sets,
                             int stride, const float* norms_q, const uint32_t* meta, int64_t nq, int d, int k, int L, int terms,
-                            float* tau, int32_t* lost, float* guard, void* stream);
+                            float* tau, int32_t* lost, void* stream);
 /* cluster index, step 3 (round 5): labels[i] = centre nearest to point i by the one-term screening value of the fp16-split images
  * (same meta); approximate (2^-10 relative) and deterministic -- the clustering only decides how much a pruned search can skip */
 int tdr_cluster_assign16_f32(const float* x16, int64_t n, const float* c16, int n_centres, int d, const uint32_t* meta,

@@ -110,7 +110,7 @@ def test_flat_stages_scan_and_select():
     tau2 = torch.empty(nq, device="cuda")
     lost = torch.zeros(nq, dtype=torch.int32, device="cuda")
     _lib.check(L.tdr_knn_flat_select_f32(_lib.ptr(lst), 0, _lib.ptr(buf), _lib.ptr(cnt), 1, cap, _lib.ptr(P.norms), _lib.ptr(meta), nq, d, k, LL,
-                                         3, _lib.ptr(tau2), _lib.ptr(lost), None, _lib.stream_ptr()), "select")
+                                         3, _lib.ptr(tau2), _lib.ptr(lost), _lib.stream_ptr()), "select")
     c, b, ls, lo_ = cnt.cpu(), buf.cpu(), lst.cpu(), lost.cpu()
     SENT = -0x7FFFFF00000001     # 0xFF800000FFFFFFFF as int64
     for qi in (0, 8, 64, 100, 2000, 4095):

@@ -6,8 +6,9 @@
 // 53 % of the time (profiles/r01_knn_screen_pmc.json).  That form is right for the cluster-pruned scan, whose thresholds must
 // tighten WHILE it decides what to skip.  A scan that visits every tile anyway does not need lists:
 //
-//   pilot     the list-keeping kernel scans 1/64 of the database (lists of k + 4 entries only): the k-th smallest screening
-//             value a query meets there is an upper bound of its k-th smallest over the whole database;
+//   seed      every screening value of 256 rows per query (knn_flat_seed_kernel) and three short dense passes over ranges growing by
+//             four bring every query to 1/64 of the database seen: the k-th smallest screening value a query has met is an
+//             upper bound of its k-th smallest over the whole database;
 //   scan      (this file) the rest of the database is scanned against that FIXED per-query threshold tau = a_(k) + 2E: a
 //             candidate is one fma + min tree + compare, and a survivor (a <= tau; a few hundred per query over the whole scan)
 //             is appended to the query's buffer in HBM -- no lists, no insertion, nothing in LDS but the staged tiles;
@@ -398,6 +399,80 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Seed: the screening values of EVERY row of the first `t_end` tile positions, per query, straight into the query's buffer
+// (key (a, row); the query itself, rows beyond the database and padding rows as sentinels).  One wavefront per query tile,
+// fragments read from HBM directly (a few tiles: nothing to stage).  The select that follows turns them into the first list
+// and the first threshold; short DENSE passes over ranges growing by four then bring every query to the point (1/64 of the
+// database seen) from which the three long passes start.  The list-keeping kernel as pilot over that 1/64 cost 33-35 ms at
+// N = 1M whatever its list length (its sorted insertions are front-loaded); seed + three short passes + their selects ~22.
+// ---------------------------------------------------------------------------------------------------------
+template <int KS, int TERMS>
+__global__ __launch_bounds__(256) void knn_flat_seed_kernel(const FlatParams P) {
+    constexpr int TILE_F = KS * 512 + 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane & 31, h = lane >> 5;
+    const int64_t n_qtiles = (P.nq + 31) / 32;
+    const int64_t qt = (int64_t)blockIdx.x * NW + wave;
+    if (qt >= n_qtiles) return;
+    const int se = scr::scale_exp(P.meta[0]);
+    const float m2s = -2.0f * scr::pow2f(-2 * se);
+    const char* qimg = reinterpret_cast<const char*>(P.qp + (size_t)qt * TILE_F);
+    f16x8 bh[KS], bl[TERMS == 3 ? KS : 1];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        bh[s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s) * 1024 + lane * 16);
+        if constexpr (TERMS == 3) bl[s] = *reinterpret_cast<const f16x8*>(qimg + (2 * s + 1) * 1024 + lane * 16);
+    }
+    float xq = reinterpret_cast<const float*>(qimg + KS * 2048)[q];
+    const int64_t qi = qt * 32 + q;
+    const bool q_valid = qi < P.nq && xq < __builtin_inff();
+    if (!q_valid) xq = 0.f;
+    const int64_t js64 = qi + P.q_offset;
+    const uint32_t jself = (P.exclude_self && js64 >= 0 && js64 < 0x7fffffffLL) ? (uint32_t)js64 : 0xffffffffu;
+    const uint32_t n_db32 = (uint32_t)P.n_db;
+    int T = (int)(((int64_t)P.t_begin * P.stride) % P.n_tiles);
+    for (int jt = P.t_begin; jt < P.t_end; ++jt) {
+        const char* img = reinterpret_cast<const char*>(P.yp + (size_t)T * TILE_F);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(img + (2 * s) * 1024 + lane * 16);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[s], acc, 0, 0, 0);
+            if constexpr (TERMS >= 2) {
+                const f16x8 al = *reinterpret_cast<const f16x8*>(img + (2 * s + 1) * 1024 + lane * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[s], acc, 0, 0, 0);
+            }
+            if constexpr (TERMS == 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc, 0, 0, 0);
+        }
+        const float* ynp = reinterpret_cast<const float*>(img + KS * 2048) + 4 * h;
+        if (q_valid) {
+            uint64_t* dst = P.buf + (size_t)qi * (size_t)P.cap + (size_t)(jt - P.t_begin) * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 y4 = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
+                uint64_t k4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t j = (uint32_t)T * 32u + (uint32_t)(8 * g + 4 * h + e);
+                    const float c = __builtin_fmaf(m2s, acc[4 * g + e], y4[e]);
+                    const bool ok = c < __builtin_inff() && j < n_db32 && j != jself;
+                    k4[e] = ok ? mkkey(c + xq, j) : KEY_SENTINEL;
+                }
+                // rows 8 g + 4 h .. + 3: four consecutive keys (32 bytes, sector-aligned)
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                u64x2* d2 = reinterpret_cast<u64x2*>(dst + 8 * g + 4 * h);
+                d2[0] = u64x2{k4[0], k4[1]};
+                d2[1] = u64x2{k4[2], k4[3]};
+            }
+        }
+        T += P.stride;
+        if (T >= P.n_tiles) T -= P.n_tiles;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Nearest centre of every point (cluster index of the pruned search, step 3): one-term screening values against the C
 // centres, arg-min per point.  The assignment only shapes the clusters -- the search result never depends on it -- so the
 // 2^-10 relative error of h.h' is irrelevant, and the kernel is deterministic (every rank builds the same index).  Replaces
@@ -469,7 +544,6 @@ struct SelectParams {
     int k, L, dpad, terms;
     float* tau;              // (nq) out
     int32_t* lost;           // (nq) |= 1 where extra_cnt > stride
-    float* guard;            // optional (nq) out, sets mode: the smallest LAST entry of a full set -- nothing a set dropped is smaller
 };
 
 __global__ __launch_bounds__(256) void knn_flat_select_kernel(const SelectParams P) {
@@ -567,16 +641,6 @@ __global__ __launch_bounds__(256) void knn_flat_select_kernel(const SelectParams
         P.tau[qi] = tau;
         if (lost) P.lost[qi] = 1;
     }
-    if (P.guard && !P.extra_cnt) {
-        float g = __builtin_inff();
-        for (int s2 = lane; s2 < P.n_sets; s2 += 64) {
-            const uint64_t last = ek[s2 * P.stride + P.stride - 1];
-            if (last != KEY_SENTINEL) g = fminf(g, u2f((uint32_t)(last >> 32)));
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) g = fminf(g, __shfl_xor(g, o, 64));
-        if (lane == 0) P.guard[qi] = g;
-    }
 }
 
 static int flat_ks(int d) {
@@ -655,6 +719,42 @@ int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const 
     }
 }
 
+/*
+ * Screening values of every row of the tiles at positions [0, seed_tiles) of the visiting order into buf[q * cap + 32 j + row]
+ * (cap >= 32 seed_tiles, a multiple of 4; sentinels for the query itself, padding rows and rows beyond the database) -- the seed
+ * of the threshold scan's lists.
+ */
+int tdr_knn_flat_seed_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
+                          int exclude_self, int seed_tiles, int tile_stride, const uint32_t* meta, uint64_t* buf, int cap, void* stream) {
+    if (!q16 || !y16 || !meta || !buf || nq <= 0 || n_db <= 0 || d <= 0 || seed_tiles < 1) return TDR_ERR_BAD_ARG;
+    if (terms < 1 || terms > 3 || cap < 32 * seed_tiles || (cap & 3) != 0) return TDR_ERR_BAD_ARG;
+    const int ks = flat::flat_ks(d);
+    if (ks == 0) return TDR_ERR_UNSUPPORTED;
+    const int n_tiles = (int)((n_db + scr::TILE_ROWS - 1) / scr::TILE_ROWS);
+    if (seed_tiles > n_tiles || n_db > 0x7fffffffLL || tile_stride < 1 || (tile_stride >= n_tiles && n_tiles > 1)) return TDR_ERR_BAD_ARG;
+    flat::FlatParams P;
+    P.qp = q16; P.yp = y16; P.meta = meta; P.nq = nq; P.q_offset = q_offset; P.n_db = n_db; P.exclude_self = exclude_self;
+    P.t_begin = 0; P.t_end = seed_tiles; P.dpad = ks * 16; P.tau = nullptr; P.buf = buf; P.cnt = nullptr; P.cap = cap;
+    P.n_tiles = n_tiles; P.stride = tile_stride;
+    const int64_t n_qtiles = (nq + 31) / 32;
+    const dim3 grid((unsigned)((n_qtiles + flat::NW - 1) / flat::NW));
+    hipStream_t st = (hipStream_t)stream;
+#define TDR_SEED(KS_)                                                                                                  \
+    do {                                                                                                               \
+        if (terms == 1) hipLaunchKernelGGL((flat::knn_flat_seed_kernel<KS_, 1>), grid, dim3(256), 0, st, P);           \
+        else if (terms == 2) hipLaunchKernelGGL((flat::knn_flat_seed_kernel<KS_, 2>), grid, dim3(256), 0, st, P);      \
+        else hipLaunchKernelGGL((flat::knn_flat_seed_kernel<KS_, 3>), grid, dim3(256), 0, st, P);                      \
+    } while (0)
+    switch (ks) {
+        case 2: TDR_SEED(2); break;
+        case 4: TDR_SEED(4); break;
+        default: TDR_SEED(8); break;
+    }
+#undef TDR_SEED
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
 /* labels[i] = the centre nearest to point i by the one-term screening value (x16 / c16: fp16-split images of the n points and
  * of the n_centres centres, packed with the same meta).  An approximate arg-min (2^-10 relative): for building clusters. */
 int tdr_cluster_assign16_f32(const float* x16, int64_t n, const float* c16, int n_centres, int d, const uint32_t* meta,
@@ -679,12 +779,10 @@ int tdr_cluster_assign16_f32(const float* x16, int64_t n, const float* c16, int 
  * (extra_cnt != NULL: one set, extra_cnt[q] valid entries, > stride = entries were lost -> lost[q] = 1; NULL: every entry
  * counts, sentinels allowed) into the L smallest, ascending, in place; tau[q] = min(a_(k) + 2E_q, a_(L) when the list is
  * full), +inf while the query has met fewer than k candidates.  norms_q: the queries' reference-order squared norms.
- * guard (optional, sets mode only): per query the smallest last entry over the FULL sets -- a set keeps its `stride` smallest,
- * so nothing it dropped is below that value; the rescoring kernel flags a query whose band reaches it.
  */
 int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra, const int32_t* extra_cnt, int n_sets,
                             int stride, const float* norms_q, const uint32_t* meta, int64_t nq, int d, int k, int L, int terms,
-                            float* tau, int32_t* lost, float* guard, void* stream) {
+                            float* tau, int32_t* lost, void* stream) {
     if (!list || !extra || !norms_q || !meta || !tau || !lost || nq <= 0 || k < 1 || L < k || n_sets < 1 || stride < 1)
         return TDR_ERR_BAD_ARG;
     if (extra_cnt && n_sets != 1) return TDR_ERR_BAD_ARG;
@@ -693,7 +791,7 @@ int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     flat::SelectParams S;
     S.list = list; S.have_list = have_list; S.extra = extra; S.extra_cnt = extra_cnt; S.n_sets = n_sets; S.stride = stride;
-    S.norms_q = norms_q; S.meta = meta; S.nq = nq; S.k = k; S.L = L; S.dpad = ks * 16; S.terms = terms; S.tau = tau; S.lost = lost; S.guard = guard;
+    S.norms_q = norms_q; S.meta = meta; S.nq = nq; S.k = k; S.L = L; S.dpad = ks * 16; S.terms = terms; S.tau = tau; S.lost = lost;
     const size_t lds = (size_t)4 * (2 * (size_t)L + (size_t)n_sets * stride) * sizeof(uint64_t);
     if (lds > 160 * 1024) return TDR_ERR_UNSUPPORTED;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(flat::knn_flat_select_kernel),

@@ -135,8 +135,6 @@ struct ScreenParams {
     int max_visit;                  // approximate (IVF-style) search: clusters a workgroup may scan at most; 0 = exact
     const float* tile_cdist;        // optional (n_db_tiles, n_clusters): lower bound of min over the tile's rows of |x - c_c| --
                                     // the bound |x - y| >= |x - c_c| - R_c of the tile's own rows replaces the ball-to-ball bound
-    int tile_stride, tile_mod;      // tile_mod > 0 (the pilot of the threshold scan): position T of the range stands for tile
-                                    // (T * tile_stride) mod tile_mod -- a range of positions is spread over the whole database
 };
 
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
@@ -547,10 +545,9 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
     int t_end = t_begin + P.tiles_per_split;
     if (t_end > P.n_db_tiles) t_end = P.n_db_tiles;
 
-    auto tile_of = [&](int T) { return P.tile_mod > 0 ? (int)(((int64_t)T * P.tile_stride) % P.tile_mod) : T; };
     auto stage = [&](int T) {
         const int rel = T - t_begin;
-        const float* src = P.yp + (size_t)tile_of(T) * TILE_F;
+        const float* src = P.yp + (size_t)T * TILE_F;
         char* dst = (rel & 1) ? tile1 : tile0;
         constexpr int NSTG = (TERMS == 3) ? NBLK : KS;  // 1-KiB pieces to stage
 #pragma unroll
@@ -584,13 +581,13 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
         while (T < r_end) {
             if (T + 1 < r_end) stage(T + 1);
             const char* img = ((T - t_begin) & 1) ? tile1 : tile0;
-            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, img, bh, bl, accB, accA, TDR_YN(T - 1), tile_of(T - 1), tau_r);
+            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, img, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
             __syncthreads();
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) accA[qb] = accB[qb];
             ++T;
         }
-        if (wave_active) stile_drain<ITEMS, QB>(C, accA, TDR_YN(r_end - 1), tile_of(r_end - 1), tau_r);
+        if (wave_active) stile_drain<ITEMS, QB>(C, accA, TDR_YN(r_end - 1), r_end - 1, tau_r);
         __syncthreads();  // the last norm-ring slot / tile buffers may be restaged by the next range
     };
 
@@ -826,7 +823,6 @@ struct RescoreParams {
     int predict_unsplit;   // pilot runs: also flag queries whose band holds >= pred_L candidates over ALL slices
     int pred_L;            // list length the prediction is made for (the launch's own L, or the longer lists of the threshold scan)
     const int32_t* lost;   // optional (nq): 1 = the threshold scan dropped candidates of this query (buffer capacity)
-    const float* guard;    // optional (nq): smallest screening value the pilot's full lists may have dropped
     const int32_t* row_map; // screening index -> source row (cluster-sorted search), NULL = identity
     int64_t q_begin, q_end; // screening positions handled by this launch
     float* out_d;
@@ -938,7 +934,6 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     for (int o = 32; o > 0; o >>= 1) in_band += __shfl_xor(in_band, o, 64);
     bool flag = any_ovf || (P.predict_unsplit && in_band >= P.pred_L);
     if (P.lost && P.lost[qi] != 0) flag = true;
-    if (P.guard && P.guard[qi] <= thr) flag = true;   // a candidate inside the band may have fallen off a pilot list
     if (lane == 0) {
         P.flags[qs] = flag ? 1 : 0;
         if (flag) atomicAdd(P.n_flagged, 1);
@@ -1202,7 +1197,6 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     P.clus_order = ct ? ct->clus_order : nullptr;
     P.max_visit = ct ? ct->max_visit : 0;
     P.tile_cdist = ct ? ct->tile_cdist : nullptr;
-    P.tile_stride = 1; P.tile_mod = 0;
     const int64_t need = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
     if (ws_bytes < need) return TDR_ERR_WORKSPACE;
     int wgs = (int)((nq + 128 * cfg.qb - 1) / (128 * cfg.qb));
@@ -1220,7 +1214,7 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     R.cand = P.cand; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq;
     R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.terms = cfg.terms; R.predict_unsplit = predict_unsplit; R.row_map = ct ? ct->row_map : nullptr; R.q_begin = q_lo; R.q_end = q_hi; R.out_d = out_d;
     R.out_i = out_i; R.flags = flags; R.n_flagged = n_flagged;
-    R.pred_L = pred_L > 0 ? pred_L : L; R.lost = nullptr; R.guard = nullptr;
+    R.pred_L = pred_L > 0 ? pred_L : L; R.lost = nullptr;
     return launch_rescore(R, st);
 }
 
@@ -1250,51 +1244,53 @@ int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const 
                           uint64_t* buf, int32_t* cnt, int cap, int shape, void* stream);
 int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra, const int32_t* extra_cnt, int n_sets,
                             int stride, const float* norms_q, const uint32_t* meta, int64_t nq, int d, int k, int L, int terms,
-                            float* tau, int32_t* lost, float* guard, void* stream);
+                            float* tau, int32_t* lost, void* stream);
+int tdr_knn_flat_seed_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
+                          int exclude_self, int seed_tiles, int tile_stride, const uint32_t* meta, uint64_t* buf, int cap, void* stream);
 
 namespace {
 constexpr int FLAT_CAP = 256;        // appended entries a query may collect per pass
 constexpr int FLAT_MIN_TILES = 4096; // database tiles below which the list-keeping kernel serves the search
 
+constexpr int FLAT_SEED_TILES = 8;   // 256 rows seed the lists (every screening value kept: FLAT_CAP entries per query)
+
 struct FlatPlan {
-    ScreenCfg pilot_cfg;
-    int ks, pilot_tiles, pilot_splits, Lp, L, n_tiles, stride;
-    int64_t off_list, off_buf, off_cnt, off_tau, off_lost, off_guard, total;   // byte offsets into the workspace (pilot lists at 0)
+    int ks, L, n_tiles, stride;
+    int n_bounds, bounds[12];          // pass i scans tile positions [bounds[i], bounds[i + 1])
+    int64_t off_buf, off_cnt, off_tau, off_lost, total;   // byte offsets into the workspace (the lists sit at offset 0)
 };
 
-// pilot = the list-keeping kernel of the same number of terms over the first 1/64 of the tile POSITIONS, with lists of k + 4
-// entries only: the pilot must deliver an upper bound of a_(k) and whatever of its range may belong to the final lists; a full
-// pilot list is covered by the guard (the rescoring kernel flags a query whose band reaches the smallest value a pilot list
-// may have dropped).  Short lists cut the pilot's sorted insertions -- L (1 + ln(n / L)) per query -- by three.
+// seed = every row of the first 8 tile positions; short passes over ranges growing by four up to 1/64 of the tiles (dense form:
+// the ~3 k survivors per query of a pass fall on few rows); then [1/64, 1/16), [1/16, 1/4), [1/4, 1)
 static bool flat_plan(int64_t nq, int64_t n_db, int d, int k, int terms, int L, FlatPlan* F) {
     F->ks = pick_ks(d);
-    if (F->ks == 0 || F->ks > 8 || (terms != 1 && terms != 3) || L < k || L > 128) return false;
+    if (F->ks == 0 || F->ks > 8 || (terms != 1 && terms != 3) || L < k || L > 128 || k > FLAT_SEED_TILES * 32 - 64) return false;
     F->n_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
     if (F->n_tiles < FLAT_MIN_TILES) return false;
-    F->pilot_cfg = screen_cfg(F->ks, k, terms == 1 ? 0 : 1);
-    if (F->pilot_cfg.L == 0 || F->pilot_cfg.terms != terms || F->pilot_cfg.items != 1) return false;
-    F->Lp = k + 4 < F->pilot_cfg.L ? k + 4 : F->pilot_cfg.L;
     F->L = L;
-    int pt = F->n_tiles / 64;
-    if (pt < 64) pt = 64;
-    F->pilot_tiles = pt & ~1;
-    F->pilot_splits = screen_splits(nq, F->pilot_tiles, F->pilot_cfg);
-    if (F->pilot_splits > 8) F->pilot_splits = 8;
+    int first = F->n_tiles / 64;
+    if (first < 64) first = 64;
+    first &= ~1;
+    int nb = 0;
+    F->bounds[nb++] = FLAT_SEED_TILES;
+    for (int64_t b = (int64_t)FLAT_SEED_TILES * 4; b * 2 < first; b *= 4) F->bounds[nb++] = (int)b;   // the last short range absorbs a remainder below 2x
+    const int longb[4] = {first, (F->n_tiles / 16) & ~1, (F->n_tiles / 4) & ~1, F->n_tiles};
+    for (int i = 0; i < 4; ++i)
+        if (longb[i] > F->bounds[nb - 1]) F->bounds[nb++] = longb[i];
+    F->n_bounds = nb;
     // visiting order of the tiles: position j -> tile (j * stride) mod n_tiles, stride ~ 0.618 n_tiles and coprime to it: the
-    // pilot and every pass see rows from all over the database (a block sorted by class would otherwise take its thresholds
+    // seed and every pass see rows from all over the database (a block sorted by class would otherwise take its thresholds
     // from one class and flood the buffers of every other)
     int st = (int)((double)F->n_tiles * 0.6180339887) | 1;
     auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
     while (st < F->n_tiles && gcd(st, F->n_tiles) != 1) st += 2;
     F->stride = st < F->n_tiles ? st : 1;
     int64_t o = 0;
-    o += (int64_t)F->pilot_splits * nq * F->Lp * 8;                 // pilot lists (offset 0)
-    F->off_list = o; o += nq * (int64_t)L * 8;
+    o += nq * (int64_t)L * 8;                                        // lists (offset 0)
     F->off_buf = o;  o += nq * (int64_t)FLAT_CAP * 8;
     F->off_cnt = o;  o += ((nq * 4 + 15) / 16) * 16;
     F->off_tau = o;  o += ((nq * 4 + 15) / 16) * 16;
     F->off_lost = o; o += ((nq * 4 + 15) / 16) * 16;
-    F->off_guard = o; o += ((nq * 4 + 15) / 16) * 16;
     F->total = o;
     return true;
 }
@@ -1310,7 +1306,7 @@ int64_t tdr_knn_screen_flat_workspace_bytes(int64_t nq, int64_t n_db, int d, int
 
 /*
  * tdr_knn_screen_f32's contract (same operands, same outputs, same flags: flagged rows must be recomputed with
- * tdr_knn_packed_f32) for an UNPRUNED search of a large database, as pilot -> threshold scan -> select -> rescoring
+ * tdr_knn_packed_f32) for an UNPRUNED search of a large database, as seed -> threshold passes with selects -> rescoring
  * (csrc/tdr_knn_flat.hip).  terms = 1 (h.h') or 3; L = list length kept per query (k <= L <= 128; the band may hold L - k
  * candidates before a query is flagged).  Everything is enqueued on `stream`; nothing is read back.
  */
@@ -1328,48 +1324,31 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
     if (ws_bytes < F.total) return TDR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
-    uint64_t* pilot = (uint64_t*)w;
-    uint64_t* list = (uint64_t*)(w + F.off_list);
+    uint64_t* list = (uint64_t*)w;
     uint64_t* buf = (uint64_t*)(w + F.off_buf);
     int32_t* cnt = (int32_t*)(w + F.off_cnt);
     float* tau = (float*)(w + F.off_tau);
     int32_t* lost = (int32_t*)(w + F.off_lost);
-    float* guard = (float*)(w + F.off_guard);
     if (hipMemsetAsync(lost, 0, (size_t)nq * 4, st) != hipSuccess) return (int)hipGetLastError();
 
-    // 1. pilot: the list-keeping kernel over the first positions of the visiting order, short lists
-    ScreenParams P;
-    P.qp = q16; P.yp = y16; P.meta = meta; P.nq = nq; P.q_offset = q_offset; P.n_db = n_db;
-    P.k = k; P.L = F.Lp; P.exclude_self = exclude_self;
-    P.n_db_tiles = F.pilot_tiles; P.n_splits = F.pilot_splits;
-    P.tiles_per_split = (P.n_db_tiles + P.n_splits - 1) / P.n_splits;
-    P.dpad = F.ks * 16; P.terms = terms; P.cand = pilot; P.n_clusters = 0; P.batch0 = 0;
-    P.tile_cluster = nullptr; P.clus_tile_begin = nullptr; P.clus_radius = nullptr; P.clus_dist = nullptr; P.clus_order = nullptr;
-    P.max_visit = 0; P.tile_cdist = nullptr;
-    P.tile_stride = F.stride; P.tile_mod = F.n_tiles;
-    const int wgs = (int)((nq + 128 * F.pilot_cfg.qb - 1) / (128 * F.pilot_cfg.qb));
-    int rc = launch_lists_scan(P, F.pilot_cfg, F.ks, wgs, st);
+    // 1. seed: every screening value of the first 256 rows of the visiting order; 2. the first lists and thresholds
+    int rc = tdr_knn_flat_seed_f32(q16, nq, q_offset, y16, n_db, d, terms, exclude_self, FLAT_SEED_TILES, F.stride, meta, buf, FLAT_CAP, stream);
     if (rc != TDR_OK) return rc;
-    // 2. its lists -> the first list of L, tau, and the guard (what a full pilot list may have dropped)
-    rc = tdr_knn_flat_select_f32(list, 0, pilot, nullptr, F.pilot_splits, F.Lp, norms_q, meta, nq, d, k, L, terms, tau, lost, guard, stream);
+    rc = tdr_knn_flat_select_f32(list, 0, buf, nullptr, 1, FLAT_CAP, norms_q, meta, nq, d, k, L, terms, tau, lost, stream);
     if (rc != TDR_OK) return rc;
     // 3. threshold passes over growing ranges of positions, a select after each
-    int bounds[4] = {F.pilot_tiles, (F.n_tiles / 16) & ~1, (F.n_tiles / 4) & ~1, F.n_tiles};
-    for (int i = 1; i < 4; ++i)
-        if (bounds[i] < bounds[i - 1]) bounds[i] = bounds[i - 1];
-    for (int i = 0; i < 3; ++i) {
-        if (bounds[i + 1] <= bounds[i]) continue;
-        rc = tdr_knn_flat_scan_f32(q16, nq, q_offset, y16, n_db, d, terms, exclude_self, bounds[i], bounds[i + 1], F.stride, meta, tau, buf,
+    for (int i = 0; i + 1 < F.n_bounds; ++i) {
+        rc = tdr_knn_flat_scan_f32(q16, nq, q_offset, y16, n_db, d, terms, exclude_self, F.bounds[i], F.bounds[i + 1], F.stride, meta, tau, buf,
                                    cnt, FLAT_CAP, 0, stream);
         if (rc != TDR_OK) return rc;
-        rc = tdr_knn_flat_select_f32(list, 1, buf, cnt, 1, FLAT_CAP, norms_q, meta, nq, d, k, L, terms, tau, lost, nullptr, stream);
+        rc = tdr_knn_flat_select_f32(list, 1, buf, cnt, 1, FLAT_CAP, norms_q, meta, nq, d, k, L, terms, tau, lost, stream);
         if (rc != TDR_OK) return rc;
     }
     // 4. rescoring of the final lists (one "split" of L entries per query)
     RescoreParams R;
     R.cand = list; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq; R.ldy = ldy;
     R.d = d; R.dpad = F.ks * 16; R.k = k; R.L = L; R.n_splits = 1; R.metric = metric; R.terms = terms; R.predict_unsplit = 0;
-    R.pred_L = L; R.lost = lost; R.guard = guard; R.row_map = nullptr; R.q_begin = 0; R.q_end = nq; R.out_d = out_d; R.out_i = out_i;
+    R.pred_L = L; R.lost = lost; R.row_map = nullptr; R.q_begin = 0; R.q_end = nq; R.out_d = out_d; R.out_i = out_i;
     R.flags = flags; R.n_flagged = n_flagged;
     return launch_rescore(R, st);
 }
