@@ -320,12 +320,16 @@ class ClusterIndex:
         built for nothing.  A tile's bound to cluster c is min over its rows of |x - c_c| - R_c; in high dimension |x - c_c|^2 ~
         |c_w - c_c|^2 + |x - c_w|^2 <= |c_w - c_c|^2 + R_w^2, so sqrt(|c_w - c_c|^2 + R_w^2) - R_c is what the BEST tile of
         cluster w can show against cluster c.  If that stays below sqrt(tau) for every pair -- one Gaussian, uniform data: centres a
-        few units apart under radii and neighbour distances several times that -- the search goes straight to the plain scan.  A
-        heuristic in one direction only: a wrong "hopeless" costs the pruning of a search that would have been pruned a little,
+        few units apart under radii and neighbour distances several times that -- the search goes straight to the plain scan ("every pair" weighted by tile counts: more
+        than _TILE_MAX_SCAN_FRACTION of the tiles would still be visited).  A heuristic in one direction only: a wrong "hopeless" costs the pruning of a search that would have been pruned a little,
         never a result (blobs at centre distance 16, radius 6.6, k-th neighbour at 8: 10.7 against 8, the table is built)."""
         best = (self.dist * self.dist + (self.radius * self.radius)[:, None]).sqrt() - self.radius[None, :]
         best.fill_diagonal_(0.0)
-        return not bool((best.clamp(min=0) ** 2 > tau).any())
+        # share of the tiles still visited if every tile showed that best bound (weighted by the clusters' tile counts, as
+        # scan_fraction does: a few small outlier clusters that could be skipped do not pay for the table)
+        t = self.tiles.to(best.dtype)
+        visited = torch.mv((best.clamp(min=0) ** 2 <= tau).to(best.dtype), t)
+        return float((visited * t).sum() / (t.sum() ** 2)) > _TILE_MAX_SCAN_FRACTION
 
     # ---- per-tile bounds: the second chance of data whose balls overlap ---------------------------------------------------
     def tile_table(self, P: "PackedPoints"):
