@@ -66,7 +66,7 @@ __device__ __forceinline__ float reduce_tau(float tau, float xn) {
 // A operand = database fragment (rows of the tile), B operand = query fragment; acc[r] of lane (q + 32 h) belongs to
 // database row 8 (r >> 2) + 4 h + (r & 3) of the tile and query q of the query tile.
 // SPARSE = false: a finished block's 16 candidate columns are kept and, when any of them survives, walked with a flush whenever
-//   the survivor buffer would not hold a column (a short range right after the pilot is DENSE: the same number of survivors per
+//   the survivor buffer would not hold a column (a short range right after the seed is DENSE: the same number of survivors per
 //   query falls on few rows, per cents of all candidates).
 // SPARSE = true (ranges of >= 1024 tiles, where a survivor is one candidate in thousands): the same walk with the buffer emptied
 //   at the start of a step or of a block's walk only -- a column the buffer cannot take (rows sorted by class: the 64 queries of a
