@@ -174,7 +174,7 @@ def knn_variants(X, args, dbase):
     out["knn_structureless_path"] = path
     out["note"] = ("wall seconds of pairwise_distances(k=%d) incl. packing and pilots, best of 2, outside the timed region; "
                    "structureless = the same generator with centre scale 0; unpruned searches of this size run as the threshold scan "
-                   "(csrc/tdr_knn_flat.hip: pilot -> fixed-threshold passes -> select -> rescoring; profiles/r05_knn_flat_scan_pmc.json: "
+                   "(csrc/tdr_knn_flat.hip: seed -> fixed-threshold passes with a select after each -> rescoring; profiles/r05_knn_flat_scan_pmc.json: "
                    "matrix pipe 59 %% busy at the 1.79 GHz the chip sustains under it)" % args.k)
     return out
 

@@ -428,7 +428,7 @@ def _screen_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier, p
     return flags, n_flagged
 
 
-# FLAT_SCAN: an UNPRUNED two-stage search of a large database runs as pilot -> threshold scan -> select -> rescoring
+# FLAT_SCAN: an UNPRUNED two-stage search of a large database runs as seed -> threshold passes with a select after each -> rescoring
 # (csrc/tdr_knn_flat.hip, tdr_knn_screen_flat_f32) instead of the list-keeping kernel: same results bit for bit, lists of
 # _FLAT_L entries per query in HBM (the one-term tier then serves data whose error band holds up to ~100 candidates).
 FLAT_SCAN = True
