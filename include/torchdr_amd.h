@@ -198,7 +198,8 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
  * (tile_stride coprime to the tile count; 1 = natural order): pilot and passes take ranges of POSITIONS, so each sees rows from all
  * over the database.  seed: buf[q * cap + 32 j + r] = key of row r of the tile at position j < seed_tiles (sentinel for the query
  * itself / padding).  scan: positions [tile_begin, tile_end); buf (nq, cap) keys (screening value bits << 32 | database row),
- * cnt (nq) candidates met by THIS launch (> cap: the surplus was dropped; < 0: -(valid entries) - 1, the wavefront's survivor buffer overflowed); terms 1, 2 (h.h' + h.l') or 3; shape 0.
+ * cnt (nq) candidates met by THIS launch (> cap: the surplus was dropped); terms 1, 2 (h.h' + h.l') or 3; shape 0 = form chosen by
+ * the size of the range, 1 = dense form (many survivors per tile: right after the seed), 2 = sparse form; both append the same entries.
  * select: list (nq, L) in/out ascending, sentinel 0xFF800000FFFFFFFF; extra = the scan's buf with extra_cnt = cnt (n_sets 1,
  * stride cap), or n_sets x (nq, stride) keys with extra_cnt NULL (every entry counts, sentinels allowed: the seed); tau (nq) out = min(a_(k) + 2E, a_(L) when full); lost (nq) set to 1 where cnt > stride or cnt < 0. */
 int tdr_knn_flat_seed_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,

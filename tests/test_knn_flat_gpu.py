@@ -46,6 +46,22 @@ def test_flat_scan_equals_list_kernel_and_exact(scale, d, k, metric):
         assert torch.equal(If[r].cpu(), Io[0]) and torch.equal(Cf[r].cpu(), Co[0])
 
 
+@pytest.mark.parametrize("n,k,data", [(500_000, 30, "gauss"), (250_000, 100, "randn"), (262_144, 120, "gauss")])
+def test_flat_scan_pass_plan_keeps_the_buffers_from_overflowing(n, k, data):
+    """The passes' growth factor follows k (a pass that takes a query from n seen rows to r n appends ~ (r - 1) k entries to a
+    256-entry region): structureless data at sizes / k where a fixed plan overflowed -- N = 500k had a pass growing 7.6x (8 % of
+    the queries lost and recomputed, profiles/r05_knn_flat_matrix.jsonl), k = 100 lost every query.  Few flagged rows, and the
+    list-keeping kernel's results bit for bit."""
+    torch.manual_seed(11)
+    X = (torch.randn(n, 128) if data == "randn" else gmm(n, 128, 0.0, seed=11)).cuda()
+    Cf, If, info = _search(X, k, FLAT_SCAN=True)
+    assert info["path"] == "screen" and info.get("flat_terms") in (1, 3), info
+    assert info["flagged"] <= n // 200, info
+    Cl, Il, info_l = _search(X, k, FLAT_SCAN=False)
+    assert info_l.get("flat_terms") == 0
+    assert torch.equal(If, Il) and torch.equal(Cf, Cl)
+
+
 def test_flat_scan_with_duplicates_and_flagged_rows():
     """Exact duplicates (more copies than a list holds) overflow the band of their queries: those rows are flagged and
     recomputed exactly; every row equals the one-stage kernel."""

@@ -697,7 +697,7 @@ int tdr_knn_flat_supported(int d) { return flat::flat_ks(d) != 0 ? 1 : 0; }
  * caller treats cnt > cap as lost).  q16 / y16: fp16-split images packed with the same meta; terms = 1, 2 or 3 (see
  * screen_band in tdr_knn_screen_common.h for the band each needs).  shape: 0 = by the size of the range, 1 = the dense form
  * (every column of a hit block walked, flushes inside), 2 = the sparse form (survivors taken per group of four columns; a
- * wavefront that meets more than 128 of them between two steps reports its queries lost: cnt = cap + 1).
+ * column the wavefront's buffer cannot take is appended straight to the queries' regions).  Both forms append the same entries.
  */
 int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
                           int exclude_self, int tile_begin, int tile_end, int tile_stride, const uint32_t* meta, const float* tau,

@@ -1252,31 +1252,45 @@ namespace {
 constexpr int FLAT_CAP = 256;        // appended entries a query may collect per pass
 constexpr int FLAT_MIN_TILES = 4096; // database tiles below which the list-keeping kernel serves the search
 
+constexpr int FLAT_MAX_PASSES = 30;
 constexpr int FLAT_SEED_TILES = 8;   // 256 rows seed the lists (every screening value kept: FLAT_CAP entries per query)
 
 struct FlatPlan {
     int ks, L, n_tiles, stride;
-    int n_bounds, bounds[12];          // pass i scans tile positions [bounds[i], bounds[i + 1])
+    int n_bounds, bounds[FLAT_MAX_PASSES + 2];   // pass i scans tile positions [bounds[i], bounds[i + 1])
     int64_t off_buf, off_cnt, off_tau, off_lost, total;   // byte offsets into the workspace (the lists sit at offset 0)
 };
 
-// seed = every row of the first 8 tile positions; short passes over ranges growing by four up to 1/64 of the tiles (dense form:
-// the ~3 k survivors per query of a pass fall on few rows); then [1/64, 1/16), [1/16, 1/4), [1/4, 1)
+// seed = every row of the first 8 tile positions, then passes over ranges of positions growing geometrically up to the whole
+// database, a select after each.  A pass that takes a query from n seen rows to r n appends ~ (r - 1) (k + B n / N) entries (B =
+// the candidates inside the query's error band over the whole database, <= L - k or the query is flagged anyway), most in the last
+// pass: (r - 1) (k + (L - k) / r).  The growth factor is the largest <= 4 that keeps this at 0.8 FLAT_CAP (k = 30: 4, six passes at
+// N = 1M; k = 100: 2.9), and the passes share the range evenly (ratio = (n_tiles / 8)^(1 / passes)): a pass that grew by 7.6 at
+// N = 500k (r05_knn_flat_matrix.jsonl, first form of these bounds) lost 8 % of the queries to full buffers.
 static bool flat_plan(int64_t nq, int64_t n_db, int d, int k, int terms, int L, FlatPlan* F) {
     F->ks = pick_ks(d);
     if (F->ks == 0 || F->ks > 8 || (terms != 1 && terms != 3) || L < k || L > 128 || k > FLAT_SEED_TILES * 32 - 64) return false;
     F->n_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
     if (F->n_tiles < FLAT_MIN_TILES) return false;
     F->L = L;
-    int first = F->n_tiles / 64;
-    if (first < 64) first = 64;
-    first &= ~1;
+    double r = 4.0;
+    while (r > 1.5 && (r - 1.0) * ((double)k + (double)(L - k) / r) > 0.8 * FLAT_CAP) r -= 0.05;
+    const double span = (double)F->n_tiles / FLAT_SEED_TILES;
+    int passes = (int)ceil(log(span) / log(r) - 1e-9);
+    if (passes < 1) passes = 1;
+    if (passes > FLAT_MAX_PASSES) return false;
+    const double ratio = pow(span, 1.0 / passes);
     int nb = 0;
     F->bounds[nb++] = FLAT_SEED_TILES;
-    for (int64_t b = (int64_t)FLAT_SEED_TILES * 4; b * 2 < first; b *= 4) F->bounds[nb++] = (int)b;   // the last short range absorbs a remainder below 2x
-    const int longb[4] = {first, (F->n_tiles / 16) & ~1, (F->n_tiles / 4) & ~1, F->n_tiles};
-    for (int i = 0; i < 4; ++i)
-        if (longb[i] > F->bounds[nb - 1]) F->bounds[nb++] = longb[i];
+    double b = FLAT_SEED_TILES;
+    for (int i = 1; i < passes; ++i) {
+        b *= ratio;
+        int e = ((int)(b + 0.5) + 1) & ~1;
+        if (e <= F->bounds[nb - 1]) e = F->bounds[nb - 1] + 2;
+        if (e >= F->n_tiles) break;
+        F->bounds[nb++] = e;
+    }
+    F->bounds[nb++] = F->n_tiles;
     F->n_bounds = nb;
     // visiting order of the tiles: position j -> tile (j * stride) mod n_tiles, stride ~ 0.618 n_tiles and coprime to it: the
     // seed and every pass see rows from all over the database (a block sorted by class would otherwise take its thresholds
@@ -1338,8 +1352,11 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
     if (rc != TDR_OK) return rc;
     // 3. threshold passes over growing ranges of positions, a select after each
     for (int i = 0; i + 1 < F.n_bounds; ++i) {
+        // after n seen rows a candidate survives with probability ~ k / n: 64 k / position survivors per block of 32 rows x 64
+        // queries; the dense form (every column of a hit block walked) while that is more than a few
+        const int shape = 64.0 * k / (double)F.bounds[i] < 6.0 ? 2 : 1;
         rc = tdr_knn_flat_scan_f32(q16, nq, q_offset, y16, n_db, d, terms, exclude_self, F.bounds[i], F.bounds[i + 1], F.stride, meta, tau, buf,
-                                   cnt, FLAT_CAP, 0, stream);
+                                   cnt, FLAT_CAP, shape, stream);
         if (rc != TDR_OK) return rc;
         rc = tdr_knn_flat_select_f32(list, 1, buf, cnt, 1, FLAT_CAP, norms_q, meta, nq, d, k, L, terms, tau, lost, stream);
         if (rc != TDR_OK) return rc;
