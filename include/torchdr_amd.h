@@ -187,7 +187,7 @@ int tdr_cluster_tile_cdist_f32(const float* d2, int64_t ld, int64_t rows, int C,
  * buffer; no lists in LDS, two query tiles per wavefront, two database tiles per barrier) with a tdr_knn_flat_select_f32 after
  * each (list + appended -> the L smallest, new tau) -> the rescoring kernel.  Same operands, outputs and flag contract as tdr_knn_screen_f32; results are
  * bit-identical.  terms: 1 (h.h') or 3; L: list length per query (k <= L <= 128).  The workspace query returns 0 when the
- * threshold scan does not serve the search (D > 128, fewer than 4096 database tiles, unsupported terms / L). */
+ * threshold scan does not serve the search (D > 256, or D > 128 with three terms; fewer than 4096 database tiles; unsupported terms / L). */
 int tdr_knn_flat_supported(int d);
 int64_t tdr_knn_screen_flat_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, int terms, int L);
 int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,

@@ -658,6 +658,12 @@ static int flat_ks(int d) {
     if (d <= 128) return 8;
     return 0;
 }
+// the scan and its seed also serve 128 < d <= 256 with ONE term and one query tile per wavefront (64 registers of query
+// fragments, 16-KiB tiles: 70 KiB of LDS per workgroup, two workgroups per CU)
+static int flat_scan_ks(int d, int terms) {
+    if (d <= 128) return flat_ks(d);
+    return (d <= 256 && terms == 1) ? 16 : 0;
+}
 
 template <int KS, int TERMS, int QB, int TPB, bool SPARSE>
 static int launch_flat(const FlatParams& P, hipStream_t st) {
@@ -675,9 +681,14 @@ constexpr int SPARSE_MIN_TILES = 1024;
 template <int KS>
 static int launch_flat_ks(const FlatParams& P, int terms, int shape, hipStream_t st) {
     const bool sparse = shape == 2 || (shape == 0 && P.t_end - P.t_begin >= SPARSE_MIN_TILES);
-    if (terms == 1) return sparse ? launch_flat<KS, 1, 2, 2, true>(P, st) : launch_flat<KS, 1, 2, 2, false>(P, st);
-    if (terms == 2) return sparse ? launch_flat<KS, 2, 1, 2, true>(P, st) : launch_flat<KS, 2, 1, 2, false>(P, st);
-    return sparse ? launch_flat<KS, 3, 1, 2, true>(P, st) : launch_flat<KS, 3, 1, 2, false>(P, st);
+    if constexpr (KS == 16) {
+        if (terms != 1) return TDR_ERR_UNSUPPORTED;
+        return sparse ? launch_flat<16, 1, 1, 2, true>(P, st) : launch_flat<16, 1, 1, 2, false>(P, st);
+    } else {
+        if (terms == 1) return sparse ? launch_flat<KS, 1, 2, 2, true>(P, st) : launch_flat<KS, 1, 2, 2, false>(P, st);
+        if (terms == 2) return sparse ? launch_flat<KS, 2, 1, 2, true>(P, st) : launch_flat<KS, 2, 1, 2, false>(P, st);
+        return sparse ? launch_flat<KS, 3, 1, 2, true>(P, st) : launch_flat<KS, 3, 1, 2, false>(P, st);
+    }
 }
 
 }  // namespace flat
@@ -687,7 +698,8 @@ using namespace tdr;
 
 extern "C" {
 
-/* 1 when the threshold scan serves feature dimension d (<= 128: the fragments of two query tiles fit the register file). */
+/* 1 when the f16 kernels of this file that hold two query tiles per wavefront serve feature dimension d (<= 128; the threshold
+ * scan itself also serves d <= 256 with one term: tdr_knn_screen_flat_workspace_bytes says what it takes). */
 int tdr_knn_flat_supported(int d) { return flat::flat_ks(d) != 0 ? 1 : 0; }
 
 /*
@@ -704,7 +716,7 @@ int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const 
                           uint64_t* buf, int32_t* cnt, int cap, int shape, void* stream) {
     if (!q16 || !y16 || !meta || !tau || !buf || !cnt || nq <= 0 || n_db <= 0 || d <= 0 || cap <= 0) return TDR_ERR_BAD_ARG;
     if (terms < 1 || terms > 3) return TDR_ERR_BAD_ARG;
-    const int ks = flat::flat_ks(d);
+    const int ks = flat::flat_scan_ks(d, terms);
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     const int n_tiles = (int)((n_db + scr::TILE_ROWS - 1) / scr::TILE_ROWS);
     if (tile_begin < 0 || tile_end > n_tiles || tile_begin >= tile_end || tile_stride < 1) return TDR_ERR_BAD_ARG;
@@ -724,6 +736,7 @@ int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const 
     switch (ks) {
         case 2: return flat::launch_flat_ks<2>(P, terms, shape, st);
         case 4: return flat::launch_flat_ks<4>(P, terms, shape, st);
+        case 16: return flat::launch_flat_ks<16>(P, terms, shape, st);
         default: return flat::launch_flat_ks<8>(P, terms, shape, st);
     }
 }
@@ -737,7 +750,7 @@ int tdr_knn_flat_seed_f32(const float* q16, int64_t nq, int64_t q_offset, const 
                           int exclude_self, int seed_tiles, int tile_stride, const uint32_t* meta, uint64_t* buf, int cap, void* stream) {
     if (!q16 || !y16 || !meta || !buf || nq <= 0 || n_db <= 0 || d <= 0 || seed_tiles < 1) return TDR_ERR_BAD_ARG;
     if (terms < 1 || terms > 3 || cap < 32 * seed_tiles || (cap & 3) != 0) return TDR_ERR_BAD_ARG;
-    const int ks = flat::flat_ks(d);
+    const int ks = flat::flat_scan_ks(d, terms);
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     const int n_tiles = (int)((n_db + scr::TILE_ROWS - 1) / scr::TILE_ROWS);
     if (seed_tiles > n_tiles || n_db > 0x7fffffffLL || tile_stride < 1 || (tile_stride >= n_tiles && n_tiles > 1)) return TDR_ERR_BAD_ARG;
@@ -757,6 +770,7 @@ int tdr_knn_flat_seed_f32(const float* q16, int64_t nq, int64_t q_offset, const 
     switch (ks) {
         case 2: TDR_SEED(2); break;
         case 4: TDR_SEED(4); break;
+        case 16: hipLaunchKernelGGL((flat::knn_flat_seed_kernel<16, 1>), grid, dim3(256), 0, st, P); break;
         default: TDR_SEED(8); break;
     }
 #undef TDR_SEED
@@ -796,7 +810,7 @@ int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra
         return TDR_ERR_BAD_ARG;
     if (extra_cnt && n_sets != 1) return TDR_ERR_BAD_ARG;
     if (L > 128) return TDR_ERR_UNSUPPORTED;   // the select kernel keeps two list entries per lane
-    const int ks = flat::flat_ks(d);
+    const int ks = flat::flat_scan_ks(d, terms);
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     flat::SelectParams S;
     S.list = list; S.have_list = have_list; S.extra = extra; S.extra_cnt = extra_cnt; S.n_sets = n_sets; S.stride = stride;

@@ -1264,17 +1264,25 @@ struct FlatPlan {
 // seed = every row of the first 8 tile positions, then passes over ranges of positions growing geometrically up to the whole
 // database, a select after each.  A pass that takes a query from n seen rows to r n appends ~ (r - 1) (k + B n / N) entries (B =
 // the candidates inside the query's error band over the whole database, <= L - k or the query is flagged anyway), most in the last
-// pass: (r - 1) (k + (L - k) / r).  The growth factor is the largest <= 4 that keeps this at 0.8 FLAT_CAP (k = 30: 4, six passes at
-// N = 1M; k = 100: 2.9), and the passes share the range evenly (ratio = (n_tiles / 8)^(1 / passes)): a pass that grew by 7.6 at
+// pass: (r - 1) (k + (L - k) / r).  The growth factor is the largest <= 4 that keeps this (+ 4 sigma) inside FLAT_CAP (k = 30: 4, six
+// passes at N = 1M; k = 100: 2.55, nine), and the passes share the range evenly (ratio = (n_tiles / 8)^(1 / passes)): a pass that grew by 7.6 at
 // N = 500k (r05_knn_flat_matrix.jsonl, first form of these bounds) lost 8 % of the queries to full buffers.
 static bool flat_plan(int64_t nq, int64_t n_db, int d, int k, int terms, int L, FlatPlan* F) {
     F->ks = pick_ks(d);
-    if (F->ks == 0 || F->ks > 8 || (terms != 1 && terms != 3) || L < k || L > 128 || k > FLAT_SEED_TILES * 32 - 64) return false;
+    // 128 < d <= 256: the scan holds ONE query tile per wavefront and serves the one-term tier only (tdr_knn_flat.hip, flat_scan_ks)
+    if (F->ks == 0 || F->ks > 16 || (F->ks == 16 && terms != 1) || (terms != 1 && terms != 3) || L < k || L > 128 ||
+        k > FLAT_SEED_TILES * 32 - 64)
+        return false;
     F->n_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
     if (F->n_tiles < FLAT_MIN_TILES) return false;
     F->L = L;
+    // entries of the last pass: mean (r - 1) (k + (L - k) / r); the k-part is the number of later rows below the k-th order
+    // statistic of the seen ones (variance = mean x r), the band part about Poisson -- mean + 4 sigma must fit the region
     double r = 4.0;
-    while (r > 1.5 && (r - 1.0) * ((double)k + (double)(L - k) / r) > 0.8 * FLAT_CAP) r -= 0.05;
+    for (; r > 1.5; r -= 0.05) {
+        const double band = (r - 1.0) * (double)(L - k) / r, mean = (r - 1.0) * k + band;
+        if (mean + 4.0 * sqrt((r - 1.0) * r * k + band) <= (double)FLAT_CAP) break;
+    }
     const double span = (double)F->n_tiles / FLAT_SEED_TILES;
     int passes = (int)ceil(log(span) / log(r) - 1e-9);
     if (passes < 1) passes = 1;
@@ -1310,7 +1318,7 @@ static bool flat_plan(int64_t nq, int64_t n_db, int d, int k, int terms, int L, 
 }
 }  // namespace
 
-/* Workspace bytes of tdr_knn_screen_flat_f32, 0 when the threshold scan does not serve the search (D > 128, a small database,
+/* Workspace bytes of tdr_knn_screen_flat_f32, 0 when the threshold scan does not serve the search (D > 256, D > 128 with three terms, a small database,
  * L outside [k, 128], terms other than 1 or 3). */
 int64_t tdr_knn_screen_flat_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, int terms, int L) {
     FlatPlan F;
