@@ -214,10 +214,11 @@ int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra
  * (same meta); approximate (2^-10 relative) and deterministic -- the clustering only decides how much a pruned search can skip */
 int tdr_cluster_assign16_f32(const float* x16, int64_t n, const float* c16, int n_centres, int d, const uint32_t* meta,
                              int32_t* labels, void* stream);
-/* tdr_knn_screen_f32 in pilot mode (predict_unsplit = 1) with the prediction made for lists of pred_L entries */
+/* tdr_knn_screen_f32 in pilot mode (predict_unsplit = 1) with the prediction made for lists of pred_L entries; pred_terms = 0: the
+ * band of the pilot's own tier, 2 (tier >= 1): the band of the two-term split h.h' + h.l' counted on the three-term pilot's values */
 int tdr_knn_screen_pilot_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
                              const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
-                             int metric, int exclude_self, int tier, int pred_L, const uint32_t* meta, float* out_d,
+                             int metric, int exclude_self, int tier, int pred_L, int pred_terms, const uint32_t* meta, float* out_d,
                              int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
 /* Approximate IVF-style self search on the same cluster index (distance/faiss.py:331-349: nlist = n_clusters, nprobe):
  * a workgroup scans its own clusters and then the nearest ones, nprobe scans in all; candidates are rescored exactly.

@@ -32,7 +32,7 @@ def test_flat_scan_equals_list_kernel_and_exact(scale, d, k, metric):
     n = 140_000
     X = gmm(n, d, scale, seed=17).cuda()
     Cf, If, info_f = _search(X, k, metric, PRUNE_MODE="0", FLAT_SCAN=True)
-    assert info_f["path"] == "screen" and info_f.get("flat_terms") in ((1,) if d > 128 else (1, 3)), info_f   # 128 < d <= 256: one term only
+    assert info_f["path"] == "screen" and info_f.get("flat_terms") in ((1,) if d > 128 else (1, 2, 3)), info_f   # 128 < d <= 256: one term only
     assert info_f["flagged"] <= n // 50, info_f       # the scan answered (a flagged row is recomputed exactly: equality alone proves nothing)
     Cl, Il, info_l = _search(X, k, metric, PRUNE_MODE="0", FLAT_SCAN=False)
     assert info_l.get("flat_terms") == 0
@@ -55,11 +55,25 @@ def test_flat_scan_pass_plan_keeps_the_buffers_from_overflowing(n, k, data):
     torch.manual_seed(11)
     X = (torch.randn(n, 128) if data == "randn" else gmm(n, 128, 0.0, seed=11)).cuda()
     Cf, If, info = _search(X, k, FLAT_SCAN=True)
-    assert info["path"] == "screen" and info.get("flat_terms") in (1, 3), info
+    assert info["path"] == "screen" and info.get("flat_terms") in (1, 2, 3), info
     assert info["flagged"] <= n // 200, info
     Cl, Il, info_l = _search(X, k, FLAT_SCAN=False)
     assert info_l.get("flat_terms") == 0
     assert torch.equal(If, Il) and torch.equal(Cf, Cl)
+
+
+@pytest.mark.parametrize("terms", [1, 2, 3])
+def test_flat_scan_every_tier_equals_exact(terms):
+    """Each tier of the threshold scan forced in turn (h.h'; h.h' + h.l'; all three products) on the tie-rich mixture: the
+    one-stage kernel's distances and indices bit for bit; the wider the band, the more rows are flagged, never the other way."""
+    n, d, k = 200_000, 96, 20
+    X = gmm(n, d, 3.0, seed=23).cuda()
+    Cf, If, info = _search(X, k, PRUNE_MODE="0", FLAT_SCAN=True, FLAT_FORCE_TERMS=terms)
+    assert info.get("flat_terms") == terms and info["flagged"] <= n // 4, info
+    Ce, Ie, _ = _search(X, k, PRUNE_MODE="0", SCREEN_MODE="0")
+    assert torch.equal(Cf, Ce) and torch.equal(If, Ie)
+    if terms == 3:
+        assert info["flagged"] <= n // 1000, info
 
 
 def test_flat_scan_with_duplicates_and_flagged_rows():
@@ -72,7 +86,7 @@ def test_flat_scan_with_duplicates_and_flagged_rows():
     X = X.cuda()
     Cf, If, info = _search(X, k, PRUNE_MODE="0", FLAT_SCAN=True)
     print(info)
-    assert info.get("flat_terms") in (1, 3) and 400 <= info["flagged"] <= n // 10, info
+    assert info.get("flat_terms") in (1, 2, 3) and 400 <= info["flagged"] <= n // 10, info
     Ce, Ie, _ = _search(X, k, PRUNE_MODE="0", SCREEN_MODE="0")
     assert torch.equal(Cf, Ce) and torch.equal(If, Ie)
 
@@ -95,7 +109,7 @@ def test_flat_stages_scan_and_select():
     buf = torch.zeros((nq, cap), dtype=torch.int64, device="cuda")
     cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
     n_tiles = (n + 31) // 32
-    for terms, shape in ((1, 1), (2, 1), (3, 1), (1, 2), (3, 2)):
+    for terms, shape in ((1, 1), (2, 1), (3, 1), (1, 2), (2, 2), (3, 2)):
         _lib.check(L.tdr_knn_flat_scan_f32(_lib.ptr(q16), nq, 0, _lib.ptr(y16), n, d, terms, 1, 100, 1101, 1, _lib.ptr(meta), _lib.ptr(tau),
                                            _lib.ptr(buf), _lib.ptr(cnt), cap, shape, _lib.stream_ptr()), "scan")
         c = cnt.cpu()
@@ -156,7 +170,7 @@ def test_flat_scan_on_rows_sorted_by_class():
     X = (centers[labels] + 0.5 * torch.randn(n, d, generator=g)).cuda()
     Cf, If, info = _search(X, k, PRUNE_MODE="0", FLAT_SCAN=True)
     print(info)
-    assert info.get("flat_terms") in (1, 3) and info["flagged"] <= n // 3, info
+    assert info.get("flat_terms") in (1, 2, 3) and info["flagged"] <= n // 3, info
     Ce, Ie, _ = _search(X, k, PRUNE_MODE="0", SCREEN_MODE="0")
     assert torch.equal(Cf, Ce) and torch.equal(If, Ie)
 
@@ -184,7 +198,7 @@ def test_flat_scan_on_a_query_chunk_with_offset(separate):
         return out, dict(dbase.LAST_KNN)
 
     (Cf, If), info = run(FLAT_SCAN=True)
-    assert info.get("flat_terms") in (1, 3) and info["flagged"] <= nq // 50, info
+    assert info.get("flat_terms") in (1, 2, 3) and info["flagged"] <= nq // 50, info
     (Ce, Ie), _ = run(SCREEN_MODE="0")
     assert torch.equal(If, Ie) and torch.equal(Cf, Ce)
     assert not bool((If == torch.arange(q0, q0 + nq, device="cuda", dtype=torch.int32)[:, None]).any())
@@ -192,7 +206,7 @@ def test_flat_scan_on_a_query_chunk_with_offset(separate):
         with config.options(PRUNE_MODE="0", FLAT_SCAN=True):
             Qp = dbase.PackedPoints(X[q0:q0 + nq].clone())
             Cx, Ix = dbase.knn_packed(Qp, Yp, k, "euclidean", False)
-            assert dbase.LAST_KNN.get("flat_terms") in (1, 3)
+            assert dbase.LAST_KNN.get("flat_terms") in (1, 2, 3)
         with config.options(PRUNE_MODE="0", SCREEN_MODE="0"):
             Cy, Iy = dbase.knn_packed(Qp, Yp, k, "euclidean", False)
         assert torch.equal(Ix, Iy) and torch.equal(Cx, Cy)

@@ -822,6 +822,8 @@ struct RescoreParams {
     int d, dpad, k, L, n_splits, metric, terms;
     int predict_unsplit;   // pilot runs: also flag queries whose band holds >= pred_L candidates over ALL slices
     int pred_L;            // list length the prediction is made for (the launch's own L, or the longer lists of the threshold scan)
+    int pred_terms;        // 0: the prediction counts the launch's own band; 2: the (wider) band of the two-term split h.h' + h.l', counted
+                           // on a three-term pilot's near-exact screening values -- the threshold scan's two-term tier is chosen by it
     const int32_t* lost;   // optional (nq): 1 = the threshold scan dropped candidates of this query (buffer capacity)
     const int32_t* row_map; // screening index -> source row (cluster-sorted search), NULL = identity
     int64_t q_begin, q_end; // screening positions handled by this launch
@@ -859,6 +861,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     const float nx = P.norms_q[qs];
     const int se = scale_exp(P.meta[0]);
     const float band = screen_band(nx, __uint_as_float(P.meta[1]), P.dpad, se, P.terms);
+    const float band_pred = P.pred_terms ? screen_band(nx, __uint_as_float(P.meta[1]), P.dpad, se, P.pred_terms) : band;
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
@@ -882,14 +885,16 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
     const float thr = u2f(sc[0]) + band;
+    const float thr_pred = u2f(sc[0]) + band_pred;
 
     // exact distances of the candidates inside the band
-    int in_band = 0;
+    int in_band = 0, in_pred = 0;
     for (int p0 = 0; p0 < total; p0 += 64) {
         const int p = p0 + lane;
         uint64_t key = KEY_SENTINEL;
         if (p < total) {
             const uint64_t mine = ak[p];
+            if (mine != KEY_SENTINEL && u2f((uint32_t)(mine >> 32)) <= thr_pred) ++in_pred;
             if (mine != KEY_SENTINEL && u2f((uint32_t)(mine >> 32)) <= thr) {
                 ++in_band;
                 const uint32_t jp = (uint32_t)(mine & 0xffffffffu);
@@ -931,8 +936,8 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     // A database-sliced launch keeps L entries PER SLICE, so it overflows far less than the unsliced launch of the
     // same search would; a pilot that stands for an unsliced run predicts from the merged band population instead.
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) in_band += __shfl_xor(in_band, o, 64);
-    bool flag = any_ovf || (P.predict_unsplit && in_band >= P.pred_L);
+    for (int o = 32; o > 0; o >>= 1) { in_band += __shfl_xor(in_band, o, 64); in_pred += __shfl_xor(in_pred, o, 64); }
+    bool flag = any_ovf || (P.predict_unsplit && (P.pred_terms ? in_pred : in_band) >= P.pred_L);
     if (P.lost && P.lost[qi] != 0) flag = true;
     if (lane == 0) {
         P.flags[qs] = flag ? 1 : 0;
@@ -1167,7 +1172,8 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
                            const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
                            int metric, int exclude_self, int tier, int predict_unsplit, const uint32_t* meta, float* out_d,
                            int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes,
-                           const ClusterTables* ct, int64_t q_pos_begin, int64_t q_pos_end, void* stream, int pred_L = 0) {
+                           const ClusterTables* ct, int64_t q_pos_begin, int64_t q_pos_end, void* stream, int pred_L = 0,
+                           int pred_terms = 0) {
     if (!q16 || !Xq || !norms_q || !y16 || !Y || !norms_y || !meta || !out_d || !out_i || !flags || !n_flagged || !ws)
         return TDR_ERR_BAD_ARG;
     if (nq <= 0 || n_db <= 0 || d <= 0 || ldq < d || ldy < d) return TDR_ERR_BAD_ARG;
@@ -1214,7 +1220,7 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     R.cand = P.cand; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq;
     R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.terms = cfg.terms; R.predict_unsplit = predict_unsplit; R.row_map = ct ? ct->row_map : nullptr; R.q_begin = q_lo; R.q_end = q_hi; R.out_d = out_d;
     R.out_i = out_i; R.flags = flags; R.n_flagged = n_flagged;
-    R.pred_L = pred_L > 0 ? pred_L : L; R.lost = nullptr;
+    R.pred_L = pred_L > 0 ? pred_L : L; R.pred_terms = pred_terms; R.lost = nullptr;
     return launch_rescore(R, st);
 }
 
@@ -1228,13 +1234,15 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
 
 /* tdr_knn_screen_f32 with the pilot's prediction made for lists of pred_L entries (predict_unsplit = 1: flag the queries whose
  * error band holds >= pred_L candidates over all database slices): the threshold scan below keeps longer lists than the
- * list-keeping kernel can hold in LDS, and its tier is chosen by this prediction. */
+ * list-keeping kernel can hold in LDS, and its tier is chosen by this prediction.  pred_terms = 0: the band of the pilot's own
+ * tier; 2 (with tier >= 1): the band of the two-term split, counted on the three-term pilot's screening values. */
 int tdr_knn_screen_pilot_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
                              const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
-                             int metric, int exclude_self, int tier, int pred_L, const uint32_t* meta, float* out_d,
+                             int metric, int exclude_self, int tier, int pred_L, int pred_terms, const uint32_t* meta, float* out_d,
                              int32_t* out_i, int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream) {
+    if (pred_terms != 0 && (pred_terms != 2 || tier < 1)) return TDR_ERR_BAD_ARG;
     return knn_screen_impl(q16, Xq, ldq, norms_q, nq, q_offset, y16, Y, ldy, norms_y, n_db, d, k, metric, exclude_self, tier,
-                           1, meta, out_d, out_i, flags, n_flagged, ws, ws_bytes, nullptr, 0, 0, stream, pred_L);
+                           1, meta, out_d, out_i, flags, n_flagged, ws, ws_bytes, nullptr, 0, 0, stream, pred_L, pred_terms);
 }
 
 /* ---- the UNPRUNED two-stage search as a threshold scan (csrc/tdr_knn_flat.hip) ------------------------------------------ */
@@ -1270,7 +1278,7 @@ struct FlatPlan {
 static bool flat_plan(int64_t nq, int64_t n_db, int d, int k, int terms, int L, FlatPlan* F) {
     F->ks = pick_ks(d);
     // 128 < d <= 256: the scan holds ONE query tile per wavefront and serves the one-term tier only (tdr_knn_flat.hip, flat_scan_ks)
-    if (F->ks == 0 || F->ks > 16 || (F->ks == 16 && terms != 1) || (terms != 1 && terms != 3) || L < k || L > 128 ||
+    if (F->ks == 0 || F->ks > 16 || (F->ks == 16 && terms != 1) || terms < 1 || terms > 3 || L < k || L > 128 ||
         k > FLAT_SEED_TILES * 32 - 64)
         return false;
     F->n_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
@@ -1329,7 +1337,7 @@ int64_t tdr_knn_screen_flat_workspace_bytes(int64_t nq, int64_t n_db, int d, int
 /*
  * tdr_knn_screen_f32's contract (same operands, same outputs, same flags: flagged rows must be recomputed with
  * tdr_knn_packed_f32) for an UNPRUNED search of a large database, as seed -> threshold passes with selects -> rescoring
- * (csrc/tdr_knn_flat.hip).  terms = 1 (h.h') or 3; L = list length kept per query (k <= L <= 128; the band may hold L - k
+ * (csrc/tdr_knn_flat.hip).  terms = 1 (h.h'), 2 (h.h' + h.l': a third less matrix work than 3, half of 1's band) or 3; L = list length kept per query (k <= L <= 128; the band may hold L - k
  * candidates before a query is flagged).  Everything is enqueued on `stream`; nothing is read back.
  */
 int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
@@ -1373,7 +1381,7 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
     RescoreParams R;
     R.cand = list; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq; R.ldy = ldy;
     R.d = d; R.dpad = F.ks * 16; R.k = k; R.L = L; R.n_splits = 1; R.metric = metric; R.terms = terms; R.predict_unsplit = 0;
-    R.pred_L = L; R.lost = lost; R.row_map = nullptr; R.q_begin = 0; R.q_end = nq; R.out_d = out_d; R.out_i = out_i;
+    R.pred_L = L; R.pred_terms = 0; R.lost = lost; R.row_map = nullptr; R.q_begin = 0; R.q_end = nq; R.out_d = out_d; R.out_i = out_i;
     R.flags = flags; R.n_flagged = n_flagged;
     return launch_rescore(R, st);
 }

@@ -432,6 +432,8 @@ def _screen_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier, p
 # (csrc/tdr_knn_flat.hip, tdr_knn_screen_flat_f32) instead of the list-keeping kernel: same results bit for bit, lists of
 # _FLAT_L entries per query in HBM (the one-term tier then serves data whose error band holds up to ~100 candidates).
 FLAT_SCAN = True
+FLAT_TWO_TERMS = True      # the two-term tier of the threshold scan between one and three terms
+FLAT_FORCE_TERMS = 0       # 1 / 2 / 3: the threshold scan with that many terms whatever the pilots say (tests, measurement)
 _FLAT_L = 128
 # ASSIGN16: the cluster index assigns the points to their nearest centres with the one-term f16 kernel (tdr_cluster_assign16_f32)
 # instead of the exact fp32 search with k = 1
@@ -439,28 +441,35 @@ ASSIGN16 = True
 
 
 def _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier):
-    """Number of split terms (1 or 3) the threshold scan should use for this search, or 0 when it does not serve it.  `tier`
-    = the list-keeping tier the pilot chose (-1: none passed).  The one-term form is taken when a pilot slice predicts that
-    <= 5 % of the queries hold more than _FLAT_L candidates in the (wider) one-term band."""
+    """Number of split terms (1, 2 or 3) the threshold scan should use for this search, or 0 when it does not serve it.  `tier`
+    = the list-keeping tier the pilot chose (-1: none passed).  The one-term form (h.h') is taken when a pilot slice predicts that
+    <= 5 % of the queries hold more than _FLAT_L candidates in its (wider) band; else the two-term form (h.h' + h.l': a third less
+    matrix work than three terms, half of one term's band) on the same prediction made for ITS band on a three-term pilot's
+    near-exact screening values; else three terms."""
     L = _lib.lib()
     if not _opt("FLAT_SCAN") or nq < _SCREEN_PILOT_MIN_Q or k > _FLAT_L - 8:
         return 0
     LL = min(_FLAT_L, max(k + 8, _FLAT_L))
-    ok1 = L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, Y.d, k, 1, LL) != 0
-    ok3 = L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, Y.d, k, 3, LL) != 0
-    if tier == 0 and ok1:
+    ok = [False] + [L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, Y.d, k, t, LL) != 0 for t in (1, 2, 3)]
+    forced = int(_opt("FLAT_FORCE_TERMS"))
+    if forced:
+        return forced if ok[forced] else 0
+    if tier == 0 and ok[1]:
         return 1
-    if ok1 and _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, 0, LL) <= _SCREEN_PILOT_MAX_FRAC:
+    if ok[1] and _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, 0, LL) <= _SCREEN_PILOT_MAX_FRAC:
         return 1
-    if tier in (1, 2) and ok3:
+    if ok[2] and _opt("FLAT_TWO_TERMS") and _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, 1, LL, 2) <= _SCREEN_PILOT_MAX_FRAC:
+        return 2
+    if tier in (1, 2) and ok[3]:
         return 3
-    if ok3 and _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, 1, LL) <= _SCREEN_PILOT_MAX_FRAC:
+    if ok[3] and _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, 1, LL) <= _SCREEN_PILOT_MAX_FRAC:
         return 3
     return 0
 
 
-def _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, tier, pred_L):
-    """Share of a pilot slice of queries whose error band (of list-keeping tier `tier`'s split) holds >= pred_L candidates."""
+def _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, tier, pred_L, pred_terms=0):
+    """Share of a pilot slice of queries whose error band (of list-keeping tier `tier`'s split; pred_terms = 2: of the two-term
+    split, counted on tier 1's screening values) holds >= pred_L candidates."""
     L = _lib.lib()
     dev, d = Y.device, Y.d
     q16, y16, meta = ops
@@ -478,7 +487,7 @@ def _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, tier, pred_L):
         L.tdr_knn_screen_pilot_f32(
             _lib.ptr(q16[(q0 // 32) * t16:]), _lib.ptr(Q.X[q0:]), Q.X.stride(0), _lib.ptr(Q.norms[q0:]), nq, q_offset + q0,
             _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
-            1 if exclude_self else 0, tier, int(pred_L), _lib.ptr(meta), _lib.ptr(pd), _lib.ptr(pi),
+            1 if exclude_self else 0, tier, int(pred_L), int(pred_terms), _lib.ptr(meta), _lib.ptr(pd), _lib.ptr(pi),
             _lib.ptr(flags), _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
         ),
         "tdr_knn_screen_pilot_f32",
