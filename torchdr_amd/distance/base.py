@@ -435,36 +435,39 @@ FLAT_SCAN = True
 FLAT_TWO_TERMS = True      # the two-term tier of the threshold scan between one and three terms
 FLAT_FORCE_TERMS = 0       # 1 / 2 / 3: the threshold scan with that many terms whatever the pilots say (tests, measurement)
 _FLAT_L = 128
+_FLAT_L_SHORT = 64         # list length when the list-keeping tier 0 (lists of <= 64) passed its pilot
 # ASSIGN16: the cluster index assigns the points to their nearest centres with the one-term f16 kernel (tdr_cluster_assign16_f32)
 # instead of the exact fp32 search with k = 1
 ASSIGN16 = True
 
 
 def _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier):
-    """Number of split terms (1, 2 or 3) the threshold scan should use for this search, or 0 when it does not serve it.  `tier`
-    = the list-keeping tier the pilot chose (-1: none passed).  The one-term form (h.h') is taken when a pilot slice predicts that
-    <= 5 % of the queries hold more than _FLAT_L candidates in its (wider) band; else the two-term form (h.h' + h.l': a third less
-    matrix work than three terms, half of one term's band) on the same prediction made for ITS band on a three-term pilot's
+    """(terms, L): number of split terms (1, 2 or 3) and list length the threshold scan should use for this search, or (0, 0)
+    when it does not serve it.  `tier` = the list-keeping tier the pilot chose (-1: none passed).  Tier 0 passed: one term with
+    lists of _FLAT_L_SHORT entries (the list-keeping kernel's own tier-0 lists are no longer: the band fits them, and selects and
+    rescoring cost half of what lists of 128 do).  Else the one-term form (h.h') with lists of _FLAT_L when a pilot slice predicts
+    that <= 5 % of the queries hold more than _FLAT_L candidates in its (wider) band; else the two-term form (h.h' + h.l': a third
+    less matrix work than three terms, half of one term's band) on the same prediction made for ITS band on a three-term pilot's
     near-exact screening values; else three terms."""
     L = _lib.lib()
     if not _opt("FLAT_SCAN") or nq < _SCREEN_PILOT_MIN_Q or k > _FLAT_L - 8:
-        return 0
-    LL = min(_FLAT_L, max(k + 8, _FLAT_L))
+        return 0, 0
+    LL = _FLAT_L
     ok = [False] + [L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, Y.d, k, t, LL) != 0 for t in (1, 2, 3)]
     forced = int(_opt("FLAT_FORCE_TERMS"))
     if forced:
-        return forced if ok[forced] else 0
+        return (forced, LL) if ok[forced] else (0, 0)
     if tier == 0 and ok[1]:
-        return 1
+        return 1, (_FLAT_L_SHORT if k + 16 <= _FLAT_L_SHORT else LL)
     if ok[1] and _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, 0, LL) <= _SCREEN_PILOT_MAX_FRAC:
-        return 1
+        return 1, LL
     if ok[2] and _opt("FLAT_TWO_TERMS") and _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, 1, LL, 2) <= _SCREEN_PILOT_MAX_FRAC:
-        return 2
+        return 2, LL
     if tier in (1, 2) and ok[3]:
-        return 3
+        return 3, LL
     if ok[3] and _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, 1, LL) <= _SCREEN_PILOT_MAX_FRAC:
-        return 3
-    return 0
+        return 3, LL
+    return 0, 0
 
 
 def _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, tier, pred_L, pred_terms=0):
@@ -495,13 +498,13 @@ def _flat_pilot(Q, Y, ops, q0, k, metric, exclude_self, q_offset, tier, pred_L, 
     return int(n_flagged.item()) / float(nq)
 
 
-def _flat_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, terms, out_d, out_i, profile):
+def _flat_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, terms, LL, out_d, out_i, profile):
     """The unpruned two-stage search as a threshold scan (tdr_knn_screen_flat_f32).  Returns (flags, n_flagged)."""
     L = _lib.lib()
     dev, d = Y.device, Y.d
     q16, y16, meta = ops
     t16 = L.tdr_packed16_floats(32, d)
-    ws_bytes = L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, d, k, terms, _FLAT_L)
+    ws_bytes = L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, d, k, terms, int(LL))
     ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
     flags = torch.empty(nq, dtype=torch.int32, device=dev)
     n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -512,7 +515,7 @@ def _flat_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, terms, ou
         L.tdr_knn_screen_flat_f32(
             _lib.ptr(q16[(q0 // 32) * t16:]), _lib.ptr(Q.X[q0:]), Q.X.stride(0), _lib.ptr(Q.norms[q0:]), nq, q_offset + q0,
             _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
-            1 if exclude_self else 0, int(terms), _FLAT_L, _lib.ptr(meta), _lib.ptr(out_d), _lib.ptr(out_i),
+            1 if exclude_self else 0, int(terms), int(LL), _lib.ptr(meta), _lib.ptr(out_d), _lib.ptr(out_i),
             _lib.ptr(flags), _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
         ),
         "tdr_knn_screen_flat_f32",
@@ -758,10 +761,10 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
                                        scan_frac_of=(lambda tau: _pruned_share(Y, tau)) if prune else None)
         if tier < 0:
             # no list-keeping tier holds the band: the threshold scan keeps longer lists (in HBM) and may still serve it
-            terms = _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, -1)
+            terms, flat_L = _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, -1)
             if terms == 0:
                 return -1
-            flags, n_flagged = _flat_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, terms, out_d, out_i,
+            flags, n_flagged = _flat_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, terms, flat_L, out_d, out_i,
                                             profile=PROFILE is not None)
             bad = int(n_flagged.item())
             if bad:
@@ -792,9 +795,9 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
         flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, tile_cdist=tile_tab)
     else:
         if pilot and nq >= _SCREEN_PILOT_MIN_Q:
-            flat_terms = _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier)
+            flat_terms, flat_L = _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier)
         if flat_terms:
-            flags, n_flagged = _flat_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, flat_terms, out_d, out_i,
+            flags, n_flagged = _flat_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, flat_terms, flat_L, out_d, out_i,
                                             profile=PROFILE is not None)
         else:
             flags, n_flagged = _screen_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier, False, out_d, out_i,
