@@ -201,7 +201,7 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
  * cnt (nq) candidates met by THIS launch (> cap: the surplus was dropped); terms 1, 2 (h.h' + h.l') or 3; shape 0 = form chosen by
  * the size of the range, 1 = dense form (many survivors per tile: right after the seed), 2 = sparse form; both append the same entries.
  * select: list (nq, L) in/out ascending, sentinel 0xFF800000FFFFFFFF; extra = the scan's buf with extra_cnt = cnt (n_sets 1,
- * stride cap), or n_sets x (nq, stride) keys with extra_cnt NULL (every entry counts, sentinels allowed: the seed); tau (nq) out = min(a_(k) + 2E, a_(L) when full); lost (nq) set to 1 where cnt > stride or cnt < 0. */
+ * stride cap), or n_sets x (nq, stride) keys with extra_cnt NULL (every entry counts, sentinels allowed: the seed); tau (nq) out = min(a_(k) + 2E, a_(L) when full); lost (nq) set to 1 where cnt > stride. */
 int tdr_knn_flat_seed_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
                           int exclude_self, int seed_tiles, int tile_stride, const uint32_t* meta, uint64_t* buf, int cap, void* stream);
 int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,

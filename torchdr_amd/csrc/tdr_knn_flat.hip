@@ -6,15 +6,15 @@
 // 53 % of the time (profiles/r01_knn_screen_pmc.json).  That form is right for the cluster-pruned scan, whose thresholds must
 // tighten WHILE it decides what to skip.  A scan that visits every tile anyway does not need lists:
 //
-//   seed      every screening value of 256 rows per query (knn_flat_seed_kernel) and three short dense passes over ranges growing by
-//             four bring every query to 1/64 of the database seen: the k-th smallest screening value a query has met is an
-//             upper bound of its k-th smallest over the whole database;
-//   scan      (this file) the rest of the database is scanned against that FIXED per-query threshold tau = a_(k) + 2E: a
-//             candidate is one fma + min tree + compare, and a survivor (a <= tau; a few hundred per query over the whole scan)
-//             is appended to the query's buffer in HBM -- no lists, no insertion, nothing in LDS but the staged tiles;
+//   seed      every screening value of 256 rows per query (knn_flat_seed_kernel): the k-th smallest screening value a query has met
+//             is an upper bound of its k-th smallest over the whole database;
+//   scan      (this file) the rest of the database is scanned against a FIXED per-query threshold tau = a_(k) + 2E: a
+//             candidate is one fma + min tree + compare, and a survivor (a <= tau) is appended to the query's region in HBM -- no
+//             lists, no insertion, nothing in LDS but the staged tiles;
 //   select    one wavefront per query merges (list so far + appended) into the L smallest, sorted, and re-derives tau; the scan
-//             runs in three passes over growing ranges ([1/64, 1/16), [1/16, 1/4), [1/4, 1)) with a select in between, so
-//             every pass appends ~3k entries per query;
+//             runs in passes over ranges of tile positions that grow geometrically from the seed to the whole database (x4 for
+//             k <= 30: six passes at N = 1M; the factor follows k so that a pass's ~ (r - 1) k entries fit the region:
+//             flat_plan in tdr_knn_screen.hip) with a select after each;
 //   rescore   the unchanged knn_rescore_kernel of tdr_knn_screen.hip on the final lists.
 //
 // Exactness is the list kernel's argument verbatim (tdr_knn_screen.hip header): tau_q >= a_(k)(whole database) + 2E at every
@@ -26,7 +26,8 @@
 // (one term) .. 16 (two terms) matrix instructions instead of one; the finished block's 16 fma + min tree per lane runs in the
 // shadow of the next block's matrix instructions (two accumulator sets, roles fixed at compile time: no register moves);
 // with no list length to fit, the ONE-term tier (h.h' only, a third of the matrix work) serves data whose band holds up to
-// ~100 candidates (lists of 128 live in HBM), the two-term tier (h.h' + h.l', band 2^-11 |x||y|) the rest.
+// ~100 candidates (lists of 128 live in HBM), the two-term tier (h.h' + h.l', half of that band, one query tile per wavefront)
+// what it cannot, the three-term tier the rest.  128 < d <= 256: one term, one query tile per wavefront (flat_scan_ks).
 #include "tdr_common.h"
 #include "tdr_knn_screen_common.h"
 
@@ -53,8 +54,7 @@ struct FlatParams {
     int dpad;
     const float* tau;      // (nq) thresholds in screening units (a = c' + ||x||^2); +inf passes everything
     uint64_t* buf;         // (nq, cap) appended keys (screening value bits << 32 | database row)
-    int32_t* cnt;          // (nq) entries this launch appended (> cap: the surplus was dropped; < 0: -(valid entries) - 1, the
-                           // wavefront dropped survivors of this or a neighbouring query)
+    int32_t* cnt;          // (nq) candidates this launch met (> cap: the surplus was dropped)
     int cap;
 };
 
@@ -141,7 +141,6 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
     }
     for (int p = lane; p < QB * 32; p += 64) cntw[p] = 0;
     int wcount = 0;       // wave-uniform: entries in this wavefront's survivor buffer
-    const bool lostw = false;   // (kept for the count's encoding: no form drops survivors any more)
 
     const int n_steps = (P.t_end - P.t_begin + TPB - 1) / TPB;
     // tiles of the next position to stage / to multiply: position j visits tile (j * stride) mod n_tiles, walked by additions
@@ -390,9 +389,7 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
         flush();
         for (int p = lane; p < QB * 32; p += 64) {
             const int64_t qi = qt0 * 32 + p;
-            // a wavefront that dropped survivors reports -(valid entries) - 1: lost, and how much of the buffer may be read
-            const int have = cntw[p] < P.cap ? cntw[p] : P.cap;
-            if (qi < P.nq) P.cnt[qi] = lostw ? -have - 1 : cntw[p];
+            if (qi < P.nq) P.cnt[qi] = cntw[p];     // > cap: the entries beyond the region were dropped, the select marks the query lost
         }
     }
 #undef TDR_FLAT_MMA
@@ -559,9 +556,8 @@ __global__ __launch_bounds__(256) void knn_flat_select_kernel(const SelectParams
     bool lost = false;
     if (P.extra_cnt) {
         const int c = P.extra_cnt[qi];
-        lost = c > P.stride || c < 0;      // more than the region holds, or the scan's wavefront dropped survivors (-(valid) - 1)
-        nE = c < 0 ? -c - 1 : (c > P.stride ? P.stride : c);
-        if (nE > P.stride) nE = P.stride;
+        lost = c > P.stride;               // the pass met more candidates than the region holds: the query is recomputed exactly
+        nE = c > P.stride ? P.stride : (c < 0 ? 0 : c);
         for (int p = lane; p < nE; p += 64) ek[p] = P.extra[(size_t)qi * P.stride + p];
     } else {
         nE = maxE;
