@@ -198,15 +198,14 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
  * (tile_stride coprime to the tile count; 1 = natural order): pilot and passes take ranges of POSITIONS, so each sees rows from all
  * over the database.  seed: buf[q * cap + 32 j + r] = key of row r of the tile at position j < seed_tiles (sentinel for the query
  * itself / padding).  scan: positions [tile_begin, tile_end); buf (nq, cap) keys (screening value bits << 32 | database row),
- * cnt (nq) candidates met by THIS launch (> cap: the surplus was dropped); terms 1, 2 (h.h' + h.l') or 3; shape 0 = form chosen by
- * the size of the range, 1 = dense form (many survivors per tile: right after the seed), 2 = sparse form; both append the same entries.
+ * cnt (nq) candidates met by THIS launch (> cap: the surplus was dropped); terms 1, 2 (h.h' + h.l') or 3.
  * select: list (nq, L) in/out ascending, sentinel 0xFF800000FFFFFFFF; extra = the scan's buf with extra_cnt = cnt (n_sets 1,
  * stride cap), or n_sets x (nq, stride) keys with extra_cnt NULL (every entry counts, sentinels allowed: the seed); tau (nq) out = min(a_(k) + 2E, a_(L) when full); lost (nq) set to 1 where cnt > stride. */
 int tdr_knn_flat_seed_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
                           int exclude_self, int seed_tiles, int tile_stride, const uint32_t* meta, uint64_t* buf, int cap, void* stream);
 int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
                           int exclude_self, int tile_begin, int tile_end, int tile_stride, const uint32_t* meta, const float* tau,
-                          uint64_t* buf, int32_t* cnt, int cap, int shape, void* stream);
+                          uint64_t* buf, int32_t* cnt, int cap, void* stream);
 int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra, const int32_t* extra_cnt, int n_sets,
                             int stride, const float* norms_q, const uint32_t* meta, int64_t nq, int d, int k, int L, int terms,
                             float* tau, int32_t* lost, void* stream);

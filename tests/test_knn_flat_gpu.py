@@ -109,13 +109,13 @@ def test_flat_stages_scan_and_select():
     buf = torch.zeros((nq, cap), dtype=torch.int64, device="cuda")
     cnt = torch.zeros(nq, dtype=torch.int32, device="cuda")
     n_tiles = (n + 31) // 32
-    for terms, shape in ((1, 1), (2, 1), (3, 1), (1, 2), (2, 2), (3, 2)):
+    for terms in (1, 2, 3):
         _lib.check(L.tdr_knn_flat_scan_f32(_lib.ptr(q16), nq, 0, _lib.ptr(y16), n, d, terms, 1, 100, 1101, 1, _lib.ptr(meta), _lib.ptr(tau),
-                                           _lib.ptr(buf), _lib.ptr(cnt), cap, shape, _lib.stream_ptr()), "scan")
+                                           _lib.ptr(buf), _lib.ptr(cnt), cap, _lib.stream_ptr()), "scan")
         c = cnt.cpu()
-        # tau = inf: every row of the 1001 tiles (minus the query itself) is met and counted, in either form -- the dense form
-        # flushes inside a block's walk, the sparse form appends a column its buffer cannot take straight to the query's region
-        assert bool((c[:8] >= 1001 * 32 - 1).all()), (terms, shape, c[:8])
+        # tau = inf: every row of the 1001 tiles (minus the query itself) is met and counted -- a column the wavefront's buffer
+        # cannot take is appended straight to the query's region
+        assert bool((c[:8] >= 1001 * 32 - 1).all()), (terms, c[:8])
         # reference: exact squared distances of the same block, thresholded with slack for the screening error
         D = torch.cdist(X[:nq].double(), X[3200:35232].double()) ** 2
         lo = (D <= 40.0 - 0.5).sum(1).cpu()

@@ -12,4 +12,4 @@ cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $
 cd $R
 f=$(ls -t $O/prof_bench/*/*kernel_stats.csv | head -1); echo "== $f"; head -14 "$f" | cut -c1-200; cp "$f" $O/bench_kernel_stats.csv
 for w in uniform structureless mixture; do timeout 200 python tools/knn_flat_search.py 1000000 $w 2>&1 | grep sec | tail -1; done | tee $O/flat_search.log
-timeout 900 bash tools/pmc_flat.sh 1 0 2>&1 | tail -12
+timeout 900 bash tools/pmc_flat.sh 1 2>&1 | tail -12

@@ -72,7 +72,7 @@ def main():
     cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
     n_tiles = (n + 31) // 32
     scans = {}
-    shapes = ((1, 0), (1, 2), (1, 3), (1, 1), (1, 4), (2, 1), (2, 2), (3, 0), (3, 2))
+    shapes = ((1, 0), (2, 0), (3, 0), (1, 10), (3, 10))     # (terms, 0 = natural tile order / 10 = the production pipeline's strided order)
     if len(sys.argv) > 3:
         shapes = tuple((int(a.split(":")[0]), int(a.split(":")[1])) for a in sys.argv[3].split(","))
     stride = 1
@@ -88,17 +88,14 @@ def main():
 
         def run():
             _lib.check(L.tdr_knn_flat_scan_f32(_lib.ptr(q16), n, 0, _lib.ptr(y16), n, d, terms, 1, 0, n_tiles, stride, _lib.ptr(meta), _lib.ptr(tau),
-                                               _lib.ptr(buf), _lib.ptr(cnt), cap, shape, _lib.stream_ptr()), "scan")
+                                               _lib.ptr(buf), _lib.ptr(cnt), cap, _lib.stream_ptr()), "scan")
         t, _ = timed(run, reps=2)
         flops = 2.0 * n * n * d * terms
         scans[f"terms{terms}_shape{shape}_stride{stride}"] = {"sec": t, "executed_f16_tflops": flops / t / 1e12, "frac_f16_peak": flops / t / 2.5e15,
                                               "mean_appended": float(cnt.float().mean()), "max_appended": int(cnt.max())}
         print(json.dumps({f"scan_terms{terms}_shape{shape}_stride{stride}": scans[f"terms{terms}_shape{shape}_stride{stride}"]}), flush=True)
     res["scan_alone"] = scans
-    res["note"] = ("terms 1: shape 0 = two query tiles per wavefront, arithmetic between the matrix instructions (MODE 0); 2 = same, matrix "
-                   "instructions back to back then the arithmetic (MODE 1); 3 = both query tiles together, alternating accumulators "
-                   "(MODE 2); 1 / 4 = ONE query tile per wavefront, MODE 0 / 1.  terms 2: shape 1 / 2 = one query tile, MODE 0 / 1.  "
-                   "terms 3: shape 0 / 2 = one query tile, MODE 0 / 1")
+    res["note"] = "one launch over all tiles per (terms, visiting order); the scheduling variants of profiles/r05_knn_flat_variants.json are no longer in the library"
     print(json.dumps(res), flush=True)
 
 

@@ -1,5 +1,5 @@
 """Two launches of the threshold-scan kernel over the whole database (N = 1M, D = 128, one term, thresholds = exact k-th
-distance + band) for rocprofv3 --pmc passes (tools/pmc_flat.sh).  argv: n terms shape"""
+distance + band) for rocprofv3 --pmc passes (tools/pmc_flat.sh).  argv: n terms"""
 import os
 import sys
 
@@ -14,7 +14,6 @@ from torchdr_amd.distance import pairwise_distances
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 terms = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-shape = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 d, k = 128, 30
 X = gmm(n, d, 2.0).cuda()
 with config.options(PRUNE_MODE="auto", FLAT_SCAN=False):      # the pruned search: no threshold-scan launches of its own
@@ -31,7 +30,7 @@ for _ in range(2):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     _lib.check(L.tdr_knn_flat_scan_f32(_lib.ptr(q16), n, 0, _lib.ptr(y16), n, d, terms, 1, 0, n_tiles, 1, _lib.ptr(meta), _lib.ptr(tau),
-                                       _lib.ptr(buf), _lib.ptr(cnt), cap, shape, _lib.stream_ptr()), "scan")
+                                       _lib.ptr(buf), _lib.ptr(cnt), cap, _lib.stream_ptr()), "scan")
     e1.record()
     torch.cuda.synchronize()
     print({"scan_ms": e0.elapsed_time(e1), "mean_appended": float(cnt.float().mean())}, flush=True)

@@ -65,18 +65,19 @@ __device__ __forceinline__ float reduce_tau(float tau, float xn) {
 // TERMS = 1: h.h'   TERMS = 2: h.h' + h.l' (query h only)   TERMS = 3: h.h' + h.l' + l.h'
 // A operand = database fragment (rows of the tile), B operand = query fragment; acc[r] of lane (q + 32 h) belongs to
 // database row 8 (r >> 2) + 4 h + (r & 3) of the tile and query q of the query tile.
-// SPARSE = false: a finished block's 16 candidate columns are kept and, when any of them survives, walked with a flush whenever
-//   the survivor buffer would not hold a column (a short range right after the seed is DENSE: the same number of survivors per
-//   query falls on few rows, per cents of all candidates).
-// SPARSE = true (ranges of >= 1024 tiles, where a survivor is one candidate in thousands): the same walk with the buffer emptied
-//   at the start of a step or of a block's walk only -- a column the buffer cannot take (rows sorted by class: the 64 queries of a
-//   wavefront share their neighbours and meet a tile full of them) is appended straight to the queries' regions.  (Testing and appending per group of four columns right where the group is
-//   reduced was built and measured slower: +11 % on the big pass -- four more wave-wide tests per block on the hot path.)
+// Survivors: when a finished block holds any, its groups of four columns are tested and the hit columns' survivors go to a
+// 128-entry buffer of the wavefront in LDS, emptied (to the queries' regions in HBM) at the start of a step or of a block's walk; a
+// column the buffer cannot take (right after the seed, where per cents of all candidates survive; rows sorted by class, where the 64
+// queries of a wavefront share their neighbours and meet a tile full of them) is appended straight to the regions.  A second,
+// "dense" form of the walk (every column walked, flushes inside the walk) served the first passes until it was measured against
+// this one on them: 0.7-2.8 % slower in six of six searches (profiles/r05_knn_flat_variants.json) -- removed.  (Testing and
+// appending per group of four columns right where the group is reduced: +11 % on the big pass -- four more wave-wide tests per
+// block on the hot path.)
 // Variants measured and dropped (profiles/r05_knn_flat_variants.json): all matrix instructions of a block back to back before
 // the arithmetic; both query tiles of a database tile on alternating accumulators; a three-deep staging ring with counted
 // vmcnt waits -- all within 4 % of this form: the scan runs at the rate the matrix pipe sustains at the clock the chip holds
 // under it (59 % busy at 1.79 GHz, r05_knn_flat_scan_pmc.json), not at a scheduling limit.
-template <int KS, int TERMS, int QB, int TPB, bool SPARSE>
+template <int KS, int TERMS, int QB, int TPB>
 __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams P) {
     static_assert((TPB * QB) % 2 == 0, "blocks per step must be even (static accumulator roles)");
     constexpr int TILE_LDS = KS * 1024 * (TERMS == 1 ? 1 : 2);   // staged bytes of one tile
@@ -197,21 +198,18 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
     const uint32_t n_db32 = (uint32_t)P.n_db;
 
     // one column of the finished block: append the lanes whose candidate survives
-    auto take_column = [&](float v, float tq, float xq, uint32_t j, uint32_t jself, int pq, bool& again, int r, int& r0) {
+    auto take_column = [&](float v, float tq, float xq, uint32_t j, uint32_t jself, int pq) {
         const bool pass = v <= tq && v < __builtin_inff() && j < n_db32 && j != jself;
         const unsigned long long m = __ballot(pass);
         if (m == 0ull) return;
         const int nb = __popcll(m);
         if (__builtin_amdgcn_readfirstlane(wcount + nb) > WBUF) {
-            if (SPARSE) {
-                // the buffer cannot take this column (queries of one wavefront that share their neighbours -- rows sorted by
-                // class -- meet a tile full of them): its survivors go straight to the queries' regions, nothing is lost
-                if (pass) {
-                    const int ql = pq * 32 + q;
-                    const int slot = atomicAdd(&cntw[ql], 1);
-                    if (slot < P.cap) P.buf[((size_t)qt0 * 32 + ql) * (size_t)P.cap + slot] = mkkey(v + xq, j);
-                }
-            } else { again = true; r0 = r; }
+            // the buffer cannot take this column: its survivors go straight to the queries' regions, nothing is lost
+            if (pass) {
+                const int ql = pq * 32 + q;
+                const int slot = atomicAdd(&cntw[ql], 1);
+                if (slot < P.cap) P.buf[((size_t)qt0 * 32 + ql) * (size_t)P.cap + slot] = mkkey(v + xq, j);
+            }
             return;
         }
         if (pass) {
@@ -237,45 +235,18 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
         for (int e = 0; e < 4; ++e) dv[4 * g + e] = __builtin_fmaf(m2s, a[4 * g + e], ynb[g][e]);
         pm[g] = fminf(fminf(dv[4 * g], dv[4 * g + 1]), fminf(dv[4 * g + 2], dv[4 * g + 3]));
     };
-    // SPARSE: the block's survivors without a flush inside (the buffer is emptied at the start of a step; a block that would
-    // overflow it marks the wavefront's queries lost)
-    auto survivors_sparse = [&](const float (&dv)[16], const float (&pm)[4], int pq) {
-        float tq, xq;
-        uint32_t jself;
-        query_of(pq, tq, xq, jself);
-        const uint32_t jb = (uint32_t)Tprev * 32u + 4u * (uint32_t)h;
-        bool again = false;
-        int r0 = 0;
-        if (wcount >= WBUF / 2) flush();   // (then a single block must bring more than WBUF / 2 survivors to lose anything)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (!__any(pm[g] <= tq)) continue;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) take_column(dv[4 * g + e], tq, xq, jb + (uint32_t)(e + 8 * g), jself, pq, again, 4 * g + e, r0);
-        }
-    };
-    // dense form: all 16 columns of the finished block, ONE flush site (a column that does not fit sends the walk back to the top)
+    // the finished block's survivors (the buffer is emptied here, at the head of the walk, when it is half full)
     auto survivors = [&](const float (&dv)[16], const float (&pm)[4], int pq) {
         float tq, xq;
         uint32_t jself;
         query_of(pq, tq, xq, jself);
         const uint32_t jb = (uint32_t)Tprev * 32u + 4u * (uint32_t)h;
-        int r0 = 0;
-        for (;;) {
-            if (wcount >= WBUF / 2) flush();
-            bool again = false;
+        if (wcount >= WBUF / 2) flush();
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (again || 4 * g + 3 < r0) continue;
-                if (!__any(pm[g] <= tq)) continue;
+        for (int g = 0; g < 4; ++g) {
+            if (!__any(pm[g] <= tq)) continue;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    if (again || r < r0) continue;
-                    take_column(dv[r], tq, xq, jb + (uint32_t)(e + 8 * g), jself, pq, again, r, r0);
-                }
-            }
-            if (!again) break;
+            for (int e = 0; e < 4; ++e) take_column(dv[4 * g + e], tq, xq, jb + (uint32_t)(e + 8 * g), jself, pq);
         }
     };
 
@@ -365,10 +336,7 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
                         for (int b = 1; b < QB; ++b)
                             if (pq == b) tq = tau_r[b];
                         const float mn = fminf(fminf(pm[0], pm[1]), fminf(pm[2], pm[3]));
-                        if (__any(mn <= tq)) {
-                            if constexpr (SPARSE) survivors_sparse(dv, pm, pq);
-                            else survivors(dv, pm, pq);
-                        }
+                        if (__any(mn <= tq)) survivors(dv, pm, pq);
                     }
                     Tprev = T;   // this block is the next one's finished block
                 }
@@ -382,10 +350,7 @@ __global__ __launch_bounds__(256, 2) void knn_flat_scan_kernel(const FlatParams 
 #pragma unroll
         for (int g = 0; g < 4; ++g) finish_part(acc[1], yn[1], g, dv, pm);
         const float mn = fminf(fminf(pm[0], pm[1]), fminf(pm[2], pm[3]));
-        if (__any(mn <= tau_r[QB - 1])) {
-            if constexpr (SPARSE) survivors_sparse(dv, pm, QB - 1);
-            else survivors(dv, pm, QB - 1);
-        }
+        if (__any(mn <= tau_r[QB - 1])) survivors(dv, pm, QB - 1);
         flush();
         for (int p = lane; p < QB * 32; p += 64) {
             const int64_t qi = qt0 * 32 + p;
@@ -661,29 +626,26 @@ static int flat_scan_ks(int d, int terms) {
     return (d <= 256 && terms == 1) ? 16 : 0;
 }
 
-template <int KS, int TERMS, int QB, int TPB, bool SPARSE>
+template <int KS, int TERMS, int QB, int TPB>
 static int launch_flat(const FlatParams& P, hipStream_t st) {
     const int64_t n_qtiles = (P.nq + 31) / 32;
     const int64_t wgs = (n_qtiles + NW * QB - 1) / (NW * QB);
-    hipLaunchKernelGGL((knn_flat_scan_kernel<KS, TERMS, QB, TPB, SPARSE>), dim3((unsigned)wgs), dim3(256), 0, st, P);
+    hipLaunchKernelGGL((knn_flat_scan_kernel<KS, TERMS, QB, TPB>), dim3((unsigned)wgs), dim3(256), 0, st, P);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
 
-// shape of the workgroup per tier: one / two terms keep two query tiles per wavefront (the query's h fragments are 64
-// VGPRs), three terms one (h and l fragments: 64 VGPRs per query tile).  shape: 0 = by the size of the range (sparse form from
-// SPARSE_MIN_TILES tiles), 1 = dense form, 2 = sparse form (tests, tools/knn_flat_lab.py)
-constexpr int SPARSE_MIN_TILES = 1024;
+// shape of the workgroup per tier: one term keeps two query tiles per wavefront (the query's h fragments are 64 VGPRs), two and
+// three terms one; 128 < d <= 256 (KS = 16): one term, one query tile
 template <int KS>
-static int launch_flat_ks(const FlatParams& P, int terms, int shape, hipStream_t st) {
-    const bool sparse = shape == 2 || (shape == 0 && P.t_end - P.t_begin >= SPARSE_MIN_TILES);
+static int launch_flat_ks(const FlatParams& P, int terms, hipStream_t st) {
     if constexpr (KS == 16) {
         if (terms != 1) return TDR_ERR_UNSUPPORTED;
-        return sparse ? launch_flat<16, 1, 1, 2, true>(P, st) : launch_flat<16, 1, 1, 2, false>(P, st);
+        return launch_flat<16, 1, 1, 2>(P, st);
     } else {
-        if (terms == 1) return sparse ? launch_flat<KS, 1, 2, 2, true>(P, st) : launch_flat<KS, 1, 2, 2, false>(P, st);
-        if (terms == 2) return sparse ? launch_flat<KS, 2, 1, 2, true>(P, st) : launch_flat<KS, 2, 1, 2, false>(P, st);
-        return sparse ? launch_flat<KS, 3, 1, 2, true>(P, st) : launch_flat<KS, 3, 1, 2, false>(P, st);
+        if (terms == 1) return launch_flat<KS, 1, 2, 2>(P, st);
+        if (terms == 2) return launch_flat<KS, 2, 1, 2>(P, st);
+        return launch_flat<KS, 3, 1, 2>(P, st);
     }
 }
 
@@ -703,13 +665,11 @@ int tdr_knn_flat_supported(int d) { return flat::flat_ks(d) != 0 ? 1 : 0; }
  * tile_end) of the visiting order (position j = tile (j * tile_stride) mod n_tiles; tile_stride coprime to n_tiles, 1 = natural) whose
  * screening value is <= tau[q] is appended to buf[q * cap ...]; cnt[q] = the number met (entries beyond cap are dropped: the
  * caller treats cnt > cap as lost).  q16 / y16: fp16-split images packed with the same meta; terms = 1, 2 or 3 (see
- * screen_band in tdr_knn_screen_common.h for the band each needs).  shape: 0 = by the size of the range, 1 = the dense form
- * (every column of a hit block walked, flushes inside), 2 = the sparse form (survivors taken per group of four columns; a
- * column the wavefront's buffer cannot take is appended straight to the queries' regions).  Both forms append the same entries.
+ * screen_band in tdr_knn_screen_common.h for the band each needs).
  */
 int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
                           int exclude_self, int tile_begin, int tile_end, int tile_stride, const uint32_t* meta, const float* tau,
-                          uint64_t* buf, int32_t* cnt, int cap, int shape, void* stream) {
+                          uint64_t* buf, int32_t* cnt, int cap, void* stream) {
     if (!q16 || !y16 || !meta || !tau || !buf || !cnt || nq <= 0 || n_db <= 0 || d <= 0 || cap <= 0) return TDR_ERR_BAD_ARG;
     if (terms < 1 || terms > 3) return TDR_ERR_BAD_ARG;
     const int ks = flat::flat_scan_ks(d, terms);
@@ -730,10 +690,10 @@ int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const 
     P.n_tiles = n_tiles; P.stride = tile_stride;
     hipStream_t st = (hipStream_t)stream;
     switch (ks) {
-        case 2: return flat::launch_flat_ks<2>(P, terms, shape, st);
-        case 4: return flat::launch_flat_ks<4>(P, terms, shape, st);
-        case 16: return flat::launch_flat_ks<16>(P, terms, shape, st);
-        default: return flat::launch_flat_ks<8>(P, terms, shape, st);
+        case 2: return flat::launch_flat_ks<2>(P, terms, st);
+        case 4: return flat::launch_flat_ks<4>(P, terms, st);
+        case 16: return flat::launch_flat_ks<16>(P, terms, st);
+        default: return flat::launch_flat_ks<8>(P, terms, st);
     }
 }
 

@@ -1249,7 +1249,7 @@ int tdr_knn_screen_pilot_f32(const float* q16, const float* Xq, int64_t ldq, con
 int tdr_knn_flat_supported(int d);
 int tdr_knn_flat_scan_f32(const float* q16, int64_t nq, int64_t q_offset, const float* y16, int64_t n_db, int d, int terms,
                           int exclude_self, int tile_begin, int tile_end, int tile_stride, const uint32_t* meta, const float* tau,
-                          uint64_t* buf, int32_t* cnt, int cap, int shape, void* stream);
+                          uint64_t* buf, int32_t* cnt, int cap, void* stream);
 int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra, const int32_t* extra_cnt, int n_sets,
                             int stride, const float* norms_q, const uint32_t* meta, int64_t nq, int d, int k, int L, int terms,
                             float* tau, int32_t* lost, void* stream);
@@ -1368,11 +1368,8 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
     if (rc != TDR_OK) return rc;
     // 3. threshold passes over growing ranges of positions, a select after each
     for (int i = 0; i + 1 < F.n_bounds; ++i) {
-        // after n seen rows a candidate survives with probability ~ k / n: 64 k / position survivors per block of 32 rows x 64
-        // queries; the dense form (every column of a hit block walked) while that is more than a few
-        const int shape = 64.0 * k / (double)F.bounds[i] < 6.0 ? 2 : 1;
         rc = tdr_knn_flat_scan_f32(q16, nq, q_offset, y16, n_db, d, terms, exclude_self, F.bounds[i], F.bounds[i + 1], F.stride, meta, tau, buf,
-                                   cnt, FLAT_CAP, shape, stream);
+                                   cnt, FLAT_CAP, stream);
         if (rc != TDR_OK) return rc;
         rc = tdr_knn_flat_select_f32(list, 1, buf, cnt, 1, FLAT_CAP, norms_q, meta, nq, d, k, L, terms, tau, lost, stream);
         if (rc != TDR_OK) return rc;
