@@ -182,12 +182,14 @@ int tdr_cluster_tile_cdist_f32(const float* d2, int64_t ld, int64_t rows, int C,
                                const float* cn, float* out, void* stream);
 /* The UNPRUNED two-stage search as a threshold scan (round 5, csrc/tdr_knn_flat.hip; replaces the list-keeping kernel where no
  * tile can be skipped -- distance/torch.py:82-122 on structureless data, benchmarks/faiss/run_benchmark.py:143-146):
- * seed (tdr_knn_flat_seed_f32: every screening value of 256 rows) -> select -> per-query threshold tau = a_(k) + 2E -> short passes
- * of tdr_knn_flat_scan_f32 over ranges growing by four up to 1/64 of the database, then three long ones (every candidate with screening value <= tau is appended to the query's
- * buffer; no lists in LDS, two query tiles per wavefront, two database tiles per barrier) with a tdr_knn_flat_select_f32 after
- * each (list + appended -> the L smallest, new tau) -> the rescoring kernel.  Same operands, outputs and flag contract as tdr_knn_screen_f32; results are
- * bit-identical.  terms: 1 (h.h') or 3; L: list length per query (k <= L <= 128).  The workspace query returns 0 when the
- * threshold scan does not serve the search (D > 256, or D > 128 with three terms; fewer than 4096 database tiles; unsupported terms / L). */
+ * seed (tdr_knn_flat_seed_f32: every screening value of 256 rows) -> select -> per-query threshold tau = a_(k) + 2E -> passes of
+ * tdr_knn_flat_scan_f32 over ranges of tile positions growing geometrically to the whole database (by 4 for k <= 30, by less for
+ * larger k: a pass appends ~ (r - 1) k entries to a query's 256-entry region; every candidate with screening value <= tau is
+ * appended; no lists in LDS, two query tiles per wavefront, two database tiles per barrier) with a tdr_knn_flat_select_f32 after
+ * each (list + appended -> the L smallest, new tau) -> the rescoring kernel.  Same operands, outputs and flag contract as
+ * tdr_knn_screen_f32; results are bit-identical.  terms: 1 (h.h'), 2 (h.h' + h.l') or 3; L: list length per query (k <= L <= 128).
+ * The workspace query returns 0 when the threshold scan does not serve the search (D > 256, or D > 128 with more than one term;
+ * fewer than 4096 database tiles; unsupported terms / L). */
 int tdr_knn_flat_supported(int d);
 int64_t tdr_knn_screen_flat_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, int terms, int L);
 int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
@@ -195,7 +197,7 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
                             int metric, int exclude_self, int terms, int L, const uint32_t* meta, float* out_d, int32_t* out_i,
                             int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
 /* its stages, exposed for tests and measurement.  Tiles are visited in the order position j -> tile (j * tile_stride) mod n_tiles
- * (tile_stride coprime to the tile count; 1 = natural order): pilot and passes take ranges of POSITIONS, so each sees rows from all
+ * (tile_stride coprime to the tile count; 1 = natural order): seed and passes take ranges of POSITIONS, so each sees rows from all
  * over the database.  seed: buf[q * cap + 32 j + r] = key of row r of the tile at position j < seed_tiles (sentinel for the query
  * itself / padding).  scan: positions [tile_begin, tile_end); buf (nq, cap) keys (screening value bits << 32 | database row),
  * cnt (nq) candidates met by THIS launch (> cap: the surplus was dropped); terms 1, 2 (h.h' + h.l') or 3.
