@@ -192,6 +192,9 @@ int tdr_cluster_tile_cdist_f32(const float* d2, int64_t ld, int64_t rows, int C,
  * fewer than 4096 database tiles; unsupported terms / L). */
 int tdr_knn_flat_supported(int d);
 int64_t tdr_knn_screen_flat_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, int terms, int L);
+/* its pass plan (host arithmetic only): bounds[0 .. n) tile positions -- seed [0, bounds[0]), pass i [bounds[i], bounds[i + 1]) --,
+ * *stride = stride of the visiting order; returns n, 0 when the search is not served */
+int tdr_knn_screen_flat_plan(int64_t nq, int64_t n_db, int d, int k, int terms, int L, int32_t* bounds, int max_bounds, int32_t* stride);
 int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, const float* norms_q, int64_t nq, int64_t q_offset,
                             const float* y16, const float* Y, int64_t ldy, const float* norms_y, int64_t n_db, int d, int k,
                             int metric, int exclude_self, int terms, int L, const uint32_t* meta, float* out_d, int32_t* out_i,

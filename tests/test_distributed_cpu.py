@@ -540,3 +540,54 @@ def test_host_root_searches():
         r = search(lambda x: x ** 3 - t, 64, dtype=torch.float64)
         assert float((r ** 3 - t).abs().max()) < 1e-6
     assert torchdr_amd.false_position is false_position and torchdr_amd.binary_search is binary_search
+
+
+def test_threshold_scan_pass_plan_on_the_host():
+    """tdr_knn_screen_flat_plan (host arithmetic of csrc/tdr_knn_screen.hip's flat_plan; no device): the passes of the unpruned
+    threshold scan cover every tile position once, grow by at most 4 and by no more than k allows -- a pass that takes a query from
+    n seen rows to r n appends ~ (r - 1) (k + (L - k) / r) entries (+ 4 sigma, variance = mean x r for the k-part) to a 256-entry
+    region; round 5's first plan grew 7.6x at N = 500k and ignored k (profiles/r05_knn_flat_matrix.jsonl) --, and the visiting
+    order's stride is coprime to the tile count.  Shapes the scan does not serve return 0."""
+    import ctypes
+    import math
+
+    from torchdr_amd import _lib
+
+    L = _lib.lib()
+    bounds = (ctypes.c_int32 * 40)()
+    stride = ctypes.c_int32(0)
+
+    def plan(n, d, k, terms, LL=128, nq=None):
+        nb = L.tdr_knn_screen_flat_plan(nq or n, n, d, k, terms, LL, bounds, 40, ctypes.byref(stride))
+        return nb, [int(bounds[i]) for i in range(max(nb, 0))], int(stride.value)
+
+    for n in (131_072, 200_000, 300_000, 500_000, 999_983, 1_000_000, 2_000_000, 16_000_000, 100_000_000):
+        n_tiles = (n + 31) // 32
+        for k in (1, 5, 15, 30, 48, 64, 100, 120):
+            for d, terms in ((16, 1), (64, 3), (128, 1), (128, 2), (128, 3), (200, 1)):
+                for LL in (64, 128):
+                    if LL < k + 8:
+                        continue
+                    nb, b, st = plan(n, d, k, terms, LL)
+                    assert nb >= 2, (n, d, k, terms, LL, nb)
+                    assert b[0] == 8 and b[-1] == n_tiles and all(x < y for x, y in zip(b, b[1:])), b
+                    assert all(x % 2 == 0 for x in b[:-1]), b
+                    assert 0 < st < n_tiles and math.gcd(st, n_tiles) == 1
+                    for lo, hi in zip(b, b[1:]):
+                        r = hi / lo
+                        assert r <= 4.3, (n, k, b)
+                        band = (r - 1.0) * (LL - k) / r
+                        mean = (r - 1.0) * k + band
+                        # bounds are rounded to even positions: a little slack on the region's 256 entries
+                        assert mean + 4.0 * math.sqrt((r - 1.0) * r * k + band) <= 256 * 1.12, (n, k, LL, lo, hi, mean)
+    # N = 1M, k = 30: six passes of about x4 (the measured configuration of DESIGN section 3)
+    nb, b, _ = plan(1_000_000, 128, 30, 1)
+    assert nb == 7 and b == [8, 32, 126, 500, 1984, 7876, 31250], b
+    # not served: small databases, D > 256, more than one term above D = 128, lists shorter than k, terms outside 1 .. 3
+    assert plan(100_000, 128, 30, 1)[0] == 0
+    assert plan(1_000_000, 300, 30, 1)[0] == 0
+    assert plan(1_000_000, 200, 30, 3)[0] == 0 and plan(1_000_000, 200, 30, 2)[0] == 0
+    assert plan(1_000_000, 128, 30, 1, LL=20)[0] == 0
+    assert plan(1_000_000, 128, 30, 4)[0] == 0 and plan(1_000_000, 128, 30, 0)[0] == 0
+    assert L.tdr_knn_screen_flat_workspace_bytes(1_000_000, 1_000_000, 128, 30, 2, 128) > 0
+    assert L.tdr_knn_screen_flat_workspace_bytes(1_000_000, 1_000_000, 256, 30, 1, 128) > 0

@@ -1326,12 +1326,26 @@ static bool flat_plan(int64_t nq, int64_t n_db, int d, int k, int terms, int L, 
 }
 }  // namespace
 
-/* Workspace bytes of tdr_knn_screen_flat_f32, 0 when the threshold scan does not serve the search (D > 256, D > 128 with three terms, a small database,
- * L outside [k, 128], terms other than 1 or 3). */
+/* Workspace bytes of tdr_knn_screen_flat_f32, 0 when the threshold scan does not serve the search (D > 256, D > 128 with more
+ * than one term, a small database, L outside [k, 128], terms outside 1 .. 3). */
 int64_t tdr_knn_screen_flat_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, int terms, int L) {
     FlatPlan F;
     if (nq <= 0 || n_db <= 0 || k < 1 || !flat_plan(nq, n_db, d, k, terms, L, &F)) return 0;
     return F.total;
+}
+
+/* The pass plan of tdr_knn_screen_flat_f32 (host arithmetic only: no device is touched): bounds[0 .. n) = tile positions -- the seed
+ * covers [0, bounds[0]), pass i scans [bounds[i], bounds[i + 1]), bounds[n - 1] = number of tiles; *stride = the visiting order's
+ * stride (position j -> tile (j * stride) mod tiles).  Returns n (<= max_bounds), 0 when the threshold scan does not serve the
+ * search, a negative error code for bad arguments. */
+int tdr_knn_screen_flat_plan(int64_t nq, int64_t n_db, int d, int k, int terms, int L, int32_t* bounds, int max_bounds, int32_t* stride) {
+    if (!bounds || max_bounds < 2 || nq <= 0 || n_db <= 0 || k < 1) return TDR_ERR_BAD_ARG;
+    FlatPlan F;
+    if (!flat_plan(nq, n_db, d, k, terms, L, &F)) return 0;
+    if (F.n_bounds > max_bounds) return TDR_ERR_WORKSPACE;
+    for (int i = 0; i < F.n_bounds; ++i) bounds[i] = F.bounds[i];
+    if (stride) *stride = F.stride;
+    return F.n_bounds;
 }
 
 /*
