@@ -206,3 +206,55 @@ def test_round4_switches_and_float64_eligibility_cpu():
         assert all(bounds[r][1] == bounds[r + 1][0] for r in range(w - 1))
         sizes = [e - s for s, e in bounds]
         assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)      # the first n % w ranks hold one more row
+
+
+def test_threshold_scan_tier_choice_on_the_host(monkeypatch):
+    """`distance/base.py:_flat_terms` -- which tier (1 = h.h', 2 = h.h' + h.l', 3 = all three products) and list length the
+    unpruned threshold scan takes -- with the pilot launches replaced by fixed answers (no device): tier 0 passed -> one term with
+    short lists and NO further pilot; else the one-term, the two-term (counted on the three-term pilot's values) and the three-term
+    predictions in this order; D > 128 is served with one term only; small query counts, large k and the switches turn it off."""
+    from types import SimpleNamespace
+
+    from torchdr_amd import config
+    from torchdr_amd.distance import base as dbase
+
+    calls = []
+
+    def pilot_answers(share_by_key):
+        def fake(Q, Y, ops, q0, k, metric, exclude_self, q_offset, tier, pred_L, pred_terms=0):
+            calls.append((tier, pred_L, pred_terms))
+            return share_by_key[(tier, pred_terms)]
+        return fake
+
+    Y = SimpleNamespace(n=1_000_000, d=128)
+    args = (None, Y, None, 0, 1_000_000, 30, "sqeuclidean", True, 0)
+    ok, bad = 0.01, 0.5
+    monkeypatch.setattr(dbase, "_flat_pilot", pilot_answers({(0, 0): bad, (1, 2): bad, (1, 0): bad}))
+    assert dbase._flat_terms(*args, 0) == (1, dbase._FLAT_L_SHORT) and calls == []          # tier 0 passed its own pilot
+    assert dbase._flat_terms(*args[:5], 60, *args[6:], 0) == (1, dbase._FLAT_L)              # k + 16 beyond the short lists
+    assert dbase._flat_terms(*args, 1) == (3, dbase._FLAT_L)                                 # tier 1 passed: three terms without a pilot of their own
+    assert calls == [(0, 128, 0), (1, 128, 2)]
+    calls.clear()
+    assert dbase._flat_terms(*args, -1) == (0, 0) and calls == [(0, 128, 0), (1, 128, 2), (1, 128, 0)]
+    monkeypatch.setattr(dbase, "_flat_pilot", pilot_answers({(0, 0): ok, (1, 2): ok, (1, 0): ok}))
+    assert dbase._flat_terms(*args, 1) == (1, dbase._FLAT_L)
+    monkeypatch.setattr(dbase, "_flat_pilot", pilot_answers({(0, 0): bad, (1, 2): ok, (1, 0): ok}))
+    assert dbase._flat_terms(*args, 1) == (2, dbase._FLAT_L) and dbase._flat_terms(*args, -1) == (2, dbase._FLAT_L)
+    with config.options(FLAT_TWO_TERMS=False):
+        assert dbase._flat_terms(*args, 2) == (3, dbase._FLAT_L) and dbase._flat_terms(*args, -1) == (3, dbase._FLAT_L)
+    with config.options(FLAT_FORCE_TERMS=2):
+        assert dbase._flat_terms(*args, 0) == (2, dbase._FLAT_L)
+    with config.options(FLAT_SCAN=False):
+        assert dbase._flat_terms(*args, 0) == (0, 0)
+    # 128 < D <= 256: one term or nothing
+    Y256 = SimpleNamespace(n=1_000_000, d=256)
+    a256 = (None, Y256) + args[2:]
+    assert dbase._flat_terms(*a256, 0) == (1, dbase._FLAT_L_SHORT)
+    assert dbase._flat_terms(*a256, 1) == (0, 0)                      # one-term pilot fails: two / three terms are not instantiated there
+    with config.options(FLAT_FORCE_TERMS=3):
+        assert dbase._flat_terms(*a256, 0) == (0, 0)
+    # not served: few queries (no pilot slice), k beyond the lists, small databases, D > 256
+    assert dbase._flat_terms(*args[:4], 1000, *args[5:], 0) == (0, 0)
+    assert dbase._flat_terms(*args[:5], 121, *args[6:], 0) == (0, 0)
+    assert dbase._flat_terms(None, SimpleNamespace(n=100_000, d=128), *args[2:], 0) == (0, 0)
+    assert dbase._flat_terms(None, SimpleNamespace(n=1_000_000, d=300), *args[2:], 0) == (0, 0)
