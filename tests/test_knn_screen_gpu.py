@@ -234,6 +234,34 @@ def test_headline_size_search_sampled_against_the_one_stage_kernel():
     assert bool((back | (C[j.reshape(-1), k - 1].reshape(len(rows), k) <= dij)).all())
 
 
+def test_long_list_tier_competes_when_flagged_rows_would_be_costly():
+    """N = 1M, D = 256, centre scale 5, k = 15 (`profiles/r05_knn_pruned_matrix.jsonl`): the three-term tier passes its 512-query
+    pilot just below 5 % flagged, and every flagged row costs a full one-stage scan of a 1M x 256 database -- 6.4 % of the rows were
+    recomputed, 322 ms instead of 69.  The long-list tier's pilot now runs whenever the best candidate's predicted re-search is worth
+    more than a pilot launch, and the cost model picks between them: few flagged rows, results checked on sampled rows against the
+    one-stage kernel."""
+    from torchdr_amd.distance import base as dbase
+    from torchdr_amd.distance import pairwise_distances
+
+    n, d, k = 1_000_000, 256, 15
+    X = gmm(n, d, 5.0).cuda()
+    C, I = pairwise_distances(X, metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True)
+    info = dict(dbase.LAST_KNN)
+    assert info["path"] == "screen-pruned" and info["flagged"] <= n // 100, info
+    rows = torch.randint(0, n, (2048,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    old = dbase.SCREEN_MODE
+    dbase.SCREEN_MODE = "0"
+    try:
+        Ce, Ie = pairwise_distances(X[rows].contiguous(), X, metric="sqeuclidean", k=k + 1, return_indices=True)
+    finally:
+        dbase.SCREEN_MODE = old
+    keep = Ie != rows[:, None].int()
+    ok = keep.sum(1) == k
+    assert float(ok.float().mean()) > 0.999
+    assert torch.equal(Ie[ok][keep[ok]].reshape(-1, k), I[rows][ok])
+    assert torch.equal(Ce[ok][keep[ok]].reshape(-1, k), C[rows][ok])
+
+
 def test_cluster_index_is_the_same_on_every_run():
     """The Lloyd update sums a cluster's members in sample order (no atomics): centres equal the per-label means, and two
     builds of the index give the same labels bit for bit -- callers renumber their points by this order (UMAP's loop)."""

@@ -607,16 +607,31 @@ def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset, side_work=Non
         if f <= _SCREEN_PILOT_MAX_FRAC:
             kth = pd[:, -1]
             cands.append((tier, f, float((kth * kth if metric == "euclidean" else kth).max())))
+    nq_all = Q.n if Q is not Y else Y.n
+    if cands and 2 in tiers and 2 not in runs:
+        # A tier that passes with a few per cent flagged can still be the wrong one: every flagged row is recomputed by a full
+        # one-stage scan (N = 1M, D = 256: 4 us per row -- 5 % flagged = 200 ms against a pruned scan of 30-70).  When the best
+        # candidate's predicted re-search costs more than a pilot launch, the long-list tier gets its pilot too and competes
+        # (N = 1M, D = 256, centre scale 5, k = 15: tier 1 passed at < 5 % in a 512-query pilot, flagged 6.4 % of the rows and took
+        # 322 ms; tier 2 takes 69: profiles/r05_knn_pruned_matrix.jsonl)
+        _, f_best, _ = _pick_tier(cands, nq_all, Y.n, d, scan_frac_of)
+        if f_best * float(nq_all) * float(Y.n) * d * 2.0 / _EXACT_RATE > _LONG_TIER_PILOT_SEC:
+            pd, n_flagged = runs[2] = launch(2)
+            f = int(n_flagged.item()) / float(_SCREEN_PILOT_Q)
+            if f <= _SCREEN_PILOT_MAX_FRAC:
+                kth = pd[:, -1]
+                cands.append((2, f, float((kth * kth if metric == "euclidean" else kth).max())))
     LAST_KNN["tier_candidates"] = [(t, round(f, 4)) for t, f, _ in cands]
     if not cands:
         return -1, None
-    tier, _, tau = _pick_tier(cands, Q.n if Q is not Y else Y.n, Y.n, d, scan_frac_of)
+    tier, _, tau = _pick_tier(cands, nq_all, Y.n, d, scan_frac_of)
     return tier, tau
 
 
 # matrix work of a tier relative to the one-term tier, and the two rates of the cost model (effective flop/s of the
 # one-term screening scan and of the one-stage exact kernel at the headline size)
 _TIER_REL_COST = {0: 1.0, 1: 1.9, 2: 2.3}
+_LONG_TIER_PILOT_SEC = 0.010     # predicted exact re-search beyond which the long-list tier's pilot (~6 ms) is worth running
 _SCREEN_RATE, _EXACT_RATE = 6.2e14, 1.26e14
 
 
