@@ -539,10 +539,11 @@ def _side_streams(dev, n):
 
 
 def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset, side_work=None, scan_frac_of=None):
-    """Pilot: screen a 1024-query slice with the tiers (one-term, three-term, three-term with long lists), flagging what
+    """Pilot: screen a slice of _SCREEN_PILOT_Q (512) queries with the tiers (one-term, three-term, three-term with long lists), flagging what
     an UNSLICED launch would flag; among the tiers with <= 5 % flagged the one with the smallest estimated total time wins
     (`_pick_tier`; ``scan_frac_of``: callable tau -> predicted scan share of a pruned search, evaluated after the side work
-    -- the cluster index -- is complete).  Returns (tier, tau) with tau the largest
+    -- the cluster index -- is complete; the long-list tier gets its pilot only when nothing passed or when the best candidate's
+    predicted exact re-search of flagged rows is worth more than a pilot launch).  Returns (tier, tau) with tau the largest
     k-th neighbour distance (squared) of the slice, or (-1, None) when the worst-case band swallows the spare list slots
     for a sizeable share of the queries under every tier (large ||x|| ||y|| relative to the neighbour spacing): the
     one-stage kernel serves such data.
