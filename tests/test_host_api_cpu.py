@@ -258,3 +258,41 @@ def test_threshold_scan_tier_choice_on_the_host(monkeypatch):
     assert dbase._flat_terms(*args[:5], 121, *args[6:], 0) == (0, 0)
     assert dbase._flat_terms(None, SimpleNamespace(n=100_000, d=128), *args[2:], 0) == (0, 0)
     assert dbase._flat_terms(None, SimpleNamespace(n=1_000_000, d=300), *args[2:], 0) == (0, 0)
+
+
+def test_tile_table_is_skipped_only_where_no_tile_bound_can_help():
+    """`ClusterIndex.tiles_hopeless` on hand-made index tables (no device): one Gaussian cut into balls (centres a few units
+    apart, radii and neighbour distances several times that) -> the per-tile table is not built; blobs whose balls overlap but
+    whose tiles can still be told apart (centre distance 16, radius 6.6, k-th neighbour at 8: sqrt(16^2 + 6.6^2) - 6.6 = 10.7 > 8)
+    -> it is; and a few outlier clusters do not pay for a table when nearly every tile would still be visited."""
+    from types import SimpleNamespace
+
+    import torch
+
+    from torchdr_amd.distance import base as dbase
+
+    def hopeless(dist, radius, tiles, tau):
+        ci = SimpleNamespace(dist=dist, radius=radius, tiles=tiles)
+        return dbase.ClusterIndex.tiles_hopeless(ci, tau)
+
+    C = 64
+    g = torch.Generator().manual_seed(0)
+    tiles = torch.full((C,), 30, dtype=torch.int32)
+    # structureless: centre distances ~3, radii ~11, k-th neighbour distance^2 ~ 150
+    dist = 3.0 + torch.rand(C, C, generator=g)
+    dist = (dist + dist.T) / 2
+    dist.fill_diagonal_(0.0)
+    assert hopeless(dist, torch.full((C,), 11.0), tiles, 150.0) is True
+    # overlapping blobs that tiles still separate
+    dist = torch.full((C, C), 16.0)
+    dist.fill_diagonal_(0.0)
+    assert hopeless(dist, torch.full((C,), 6.6), tiles, 64.0) is False
+    # the same blobs with a threshold beyond the best bound: every tile would be visited
+    assert hopeless(dist, torch.full((C,), 6.6), tiles, 10.8 ** 2) is True
+    # one far outlier cluster of a single tile among overlapping ones: skipping it alone is not worth a table
+    dist = 3.0 * torch.ones(C, C)
+    dist[0, :] = dist[:, 0] = 200.0
+    dist.fill_diagonal_(0.0)
+    t2 = tiles.clone()
+    t2[0] = 1
+    assert hopeless(dist, torch.full((C,), 11.0), t2, 150.0) is True
