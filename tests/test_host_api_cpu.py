@@ -296,3 +296,24 @@ def test_tile_table_is_skipped_only_where_no_tile_bound_can_help():
     t2 = tiles.clone()
     t2[0] = 1
     assert hopeless(dist, torch.full((C,), 11.0), t2, 150.0) is True
+
+
+def test_tier_cost_model_on_the_host():
+    """`distance/base.py:_pick_tier` (no device): estimated time = scan + exact re-search of the rows a tier will flag.  On an
+    unpruned scan a few per cent of flagged rows cost next to nothing against the scan, so the cheaper tier wins; on a pruned scan
+    (a few per cent of the tiles visited) the same rows cost several scans, and the tier that flags none wins -- round 3's k = 15
+    case at the headline size and round 5's N = 1M, D = 256 case (tier 1 at 4.9 % against the long-list tier)."""
+    from torchdr_amd.distance import base as dbase
+
+    n, d = 1_000_000, 128
+    # unpruned: one term with 2 % flagged (20 ms of re-search) against three terms (0.4 s more scan)
+    assert dbase._pick_tier([(0, 0.02, 50.0), (1, 0.0, 50.0)], n, n, d, None)[0] == 0
+    # pruned to ~3 % of the tiles: the 20 ms are several scans
+    assert dbase._pick_tier([(0, 0.02, 50.0), (1, 0.0, 50.0)], n, n, d, lambda tau: 0.03)[0] == 1
+    # nothing flagged anywhere: the cheapest matrix work
+    assert dbase._pick_tier([(0, 0.0, 50.0), (1, 0.0, 50.0)], n, n, d, lambda tau: 0.03)[0] == 0
+    # D = 256: 4.9 % of 1M rows re-searched at 4 us each (200 ms) against the long-list tier's scan
+    assert dbase._pick_tier([(1, 0.049, 900.0), (2, 0.0, 900.0)], n, n, 256, lambda tau: 0.05)[0] == 2
+    # the rule that gives the long-list tier its pilot: predicted re-search of the best candidate beyond _LONG_TIER_PILOT_SEC
+    pairs = float(n) * n * 256 * 2.0
+    assert 0.049 * pairs / dbase._EXACT_RATE > dbase._LONG_TIER_PILOT_SEC > 0.0005 * float(n) * n * d * 2.0 / dbase._EXACT_RATE
