@@ -50,6 +50,31 @@ def gmm(n, d, scale, seed=42):
     return (centers[labels] + 0.5 * torch.randn(n, d, generator=g)).contiguous()
 
 
+def regime_data(name, n, seed=42):
+    """Data regimes of the embedding-quality gates (tests/golden/quality2.json holds the REFERENCE's scores on them;
+    make_quality2_golden.py).  Returns (X float32 (n, d), labels int64 (n,) or None)."""
+    g = torch.Generator().manual_seed(seed)
+    if name == "gmm2":          # the benchmark mixture (well separated blobs)
+        return gmm(n, 128, 2.0, seed), torch.arange(n) % max(1, min(1000, n // 100))
+    if name == "overlap":       # blobs that overlap: centre scale 0.5 in 64 dimensions
+        return gmm(n, 64, 0.5, seed), torch.arange(n) % max(1, min(1000, n // 100))
+    if name == "swiss":         # a 2-d manifold (swiss roll) rotated into 50 dimensions + noise; labels = position along the roll (10 bands)
+        t = 1.5 * torch.pi * (1 + 2 * torch.rand(n, generator=g))
+        h = 21 * torch.rand(n, generator=g)
+        P = torch.stack([t * torch.cos(t), h, t * torch.sin(t)], 1)
+        Q, _ = torch.linalg.qr(torch.randn(50, 50, generator=g))
+        X = P @ Q[:3] + 0.05 * torch.randn(n, 50, generator=g)
+        lab = ((t - t.min()) / (t.max() - t.min() + 1e-9) * 10).long().clamp_(max=9)
+        return X.float().contiguous(), lab
+    if name == "heavytail":     # cluster sizes ~ Zipf (a few large clusters, many small ones), 32 dimensions
+        nc = max(4, min(300, n // 50))
+        w = 1.0 / torch.arange(1, nc + 1, dtype=torch.float64)
+        lab = torch.multinomial(w / w.sum(), n, replacement=True, generator=g)
+        centers = torch.randn(nc, 32, generator=g) * 2.0
+        return (centers[lab] + 0.5 * torch.randn(n, 32, generator=g)).contiguous(), lab
+    raise ValueError(name)
+
+
 # ---- tolerance audit (VERDICT r03 #3): float32 kernels graded against a FLOAT64 evaluation of the reference's loss ---------
 # tests/golden/grad64.npz holds, for every gradient fixture, the reference's own loss differentiated in float64 at the
 # float32 state of the recorded step (make_golden.py: grad_in_float64).  `grade64` measures max |got - ref64| / max |ref64|,

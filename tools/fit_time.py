@@ -21,6 +21,10 @@ if "RELABEL" in os.environ:
     U.RELABEL = os.environ["RELABEL"] == "1"
 if "GEOM" in os.environ:
     U.SCHED_GEOM = int(os.environ["GEOM"])
+if "NEGATIVES" in os.environ:
+    U.NEGATIVES = os.environ["NEGATIVES"]
+if "POOL_GEOM" in os.environ:
+    U.POOL_GEOM = int(os.environ["POOL_GEOM"])
 from torchdr_amd import affinity_matcher as AM
 
 if "PREFETCH" in os.environ:
@@ -36,5 +40,5 @@ for r in range(reps + 1):
     Z = m.fit_transform(X)
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
-print(json.dumps({"n": n, "prefetch": AM.PCA_PREFETCH, "eigh": AM.PCA_EIGH, "relabel": U.RELABEL, "geom": U.SCHED_GEOM, "relabelled": m.loop_order_ is not None,
+print(json.dumps({"n": n, "negatives": U.NEGATIVES, "pool_geom": U.POOL_GEOM, "prefetch": AM.PCA_PREFETCH, "eigh": AM.PCA_EIGH, "relabel": U.RELABEL, "geom": U.SCHED_GEOM, "relabelled": m.loop_order_ is not None,
                   "ms_per_fit": ts[1:], "finite": bool(torch.isfinite(Z).all())}))

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void knn_flat_seed_kernel(const FlatParams P) 
             if constexpr (TERMS == 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[s], acc, 0, 0, 0);
         }
         const float* ynp = reinterpret_cast<const float*>(img + KS * 2048) + 4 * h;
-        if (q_valid) {
+        if (qi < P.nq) {   // a query whose packed norm is +inf (non-finite or overflowing row) gets sentinels, not an unwritten region
             uint64_t* dst = P.buf + (size_t)qi * (size_t)P.cap + (size_t)(jt - P.t_begin) * 32;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void knn_flat_seed_kernel(const FlatParams P) 
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t j = (uint32_t)T * 32u + (uint32_t)(8 * g + 4 * h + e);
                     const float c = __builtin_fmaf(m2s, acc[4 * g + e], y4[e]);
-                    const bool ok = c < __builtin_inff() && j < n_db32 && j != jself;
+                    const bool ok = q_valid && c < __builtin_inff() && j < n_db32 && j != jself;
                     k4[e] = ok ? mkkey(c + xq, j) : KEY_SENTINEL;
                 }
                 // rows 8 g + 4 h .. + 3: four consecutive keys (32 bytes, sector-aligned)

@@ -26,6 +26,7 @@
 // in a select.  Partial (attraction, repulsion) sums travel between the slice passes; the last pass clamps each to
 // [-4, 4] (umap.py:262,290) and writes the gradient.
 #include "tdr_embed_common.h"
+#include "tdr_umap_pool.h"
 #include "../../include/torchdr_amd.h"
 
 namespace tdr {
@@ -1298,6 +1299,7 @@ struct UmapLoop {
     tdr_collective_fn gather; void* gather_ctx;
     int geom;
     const uint8_t* rs;              // non-null: group-ordered loop state (cols / eps_per / next / blk_base of tdr_umap_sched_group_f32 / _plan_groups_f32)
+    int pool;                       // g + 1: negatives from the LDS pool (tdr_umap_pool.hip, geometry g), 0: i.i.d. gathers
     // captured windows: graph_len[i] iterations each
     hipGraphExec_t graphs[2]; int graph_len[2];
 };
@@ -1330,9 +1332,26 @@ static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st, int host
     G.iter_base = L->iter_base; G.exag = L->exag; G.rep = L->rep; G.eps = L->eps; G.grad = L->grad; G.acc = L->acc;
     const int64_t n_el = L->n_rows * L->nc;
     if (host_base >= 0) G.iter_base = nullptr;
+    PoolGradParams Pp = {};
+    Pp.Z = L->Z; Pp.nc = L->nc; Pp.n_total = L->n_total; Pp.row0 = L->row0; Pp.n_rows = L->n_rows; Pp.list = L->list; Pp.hdr = L->hdr;
+    Pp.a = L->a; Pp.b = L->b; Pp.neg_rate = L->neg_rate; Pp.n_negatives = L->n_negatives; Pp.seed = L->seed; Pp.iter_base = G.iter_base;
+    Pp.exag = L->exag; Pp.rep = L->rep; Pp.eps = L->eps; Pp.grad = L->grad; Pp.n_runs = (uint32_t)((L->n_total + 15) / 16);
     for (int t = 0; t < n; ++t) {
         G.t_local = t; G.iter = (uint32_t)(t + (host_base >= 0 ? host_base : 0));
         G.nc = L->nc;
+        if (L->pool) {
+            Pp.t_local = t; Pp.iter = G.iter;
+            const int rcp = launch_pool_grad(Pp, L->pool - 1, st);
+            if (rcp != TDR_OK) return rcp;
+            hipLaunchKernelGGL(sgd_table_step_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, st,
+                               L->Z + L->row0 * L->nc, (const float*)L->grad, L->mom_buf, n_el, L->lr_table, (const int*)L->iter_base, t,
+                               L->momentum, L->first_iter, L->check_interval, L->norm2, L->snap, L->nan_flag);
+            if (L->gather) {
+                const int rc = L->gather(L->gather_ctx, L->Z, L->nc, (void*)st);
+                if (rc != TDR_OK) return rc;
+            }
+            continue;
+        }
         // joint launch, 2 or 3 components: the gradient kernel leaves the per-slice planes (geom bit 32) and ONE kernel combines
         // them and steps the rows
         const bool fused = (L->geom & 16) && L->S > 1 && (L->nc == 2 || L->nc == 3);
@@ -1560,6 +1579,8 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
     L->first_iter = d->first_iter; L->check_interval = d->check_interval; L->norm2 = d->norm2; L->snap = d->snap; L->nan_flag = d->nan_flag;
     L->iter_base = (int*)d->scratch; L->gather = (tdr_collective_fn)d->gather; L->gather_ctx = d->gather_ctx; L->geom = d->geom;
     L->rs = d->rs;
+    L->pool = d->pool;
+    if (L->pool < 0 || L->pool > 6 || (L->pool && (L->S != 1 || !tdr_umap_pool_supported(L->nc) || ((uintptr_t)L->Z & 15u)))) { delete L; return TDR_ERR_BAD_ARG; }
     L->graphs[0] = L->graphs[1] = nullptr; L->graph_len[0] = L->graph_len[1] = 0;
     const size_t lds = (size_t)L->B * L->S * CNT_STRIDE * sizeof(uint32_t);
     if (lds > 32 * 1024) {  // raised here, outside graph capture, for every instance the launcher may pick

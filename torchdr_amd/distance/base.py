@@ -171,6 +171,14 @@ class ClusterIndex:
 
     _pending = None   # instances assembled from broadcast tables (row-sharded search) have nothing left to read
 
+    @staticmethod
+    def builds_at_once(N: int, n_clusters: Optional[int] = None) -> bool:
+        """True when the constructor needs no host read of the seed count (the default count already equals the largest
+        one the adaptive seeding may reach): ``defer=True`` then enqueues the whole build at once."""
+        C = int(n_clusters or min(2048, max(8, N // 1000)))
+        c_max = C if n_clusters else int(min(2048, max(C, N // 64)))
+        return c_max <= C
+
     def __init__(self, P: "PackedPoints", n_clusters: Optional[int] = None, iters: int = 2, defer: bool = False):
         """``defer``: enqueue the build and return; ``finish()`` (the one host read, of the padded image's row count) is
         called later -- the pruned search enqueues its pilot launches in between, so that the single-workgroup seeding
@@ -243,6 +251,9 @@ class ClusterIndex:
             # nearest centre by the one-term screening value on the f16 matrix pipe (0.4 ms at N = 1M, C = 1000, against 3.8-6.4 ms
             # for the exact fp32 search with k = 1): the assignment shapes the clusters, no result depends on it
             x16, meta16 = P.screen_image()
+            # the cached image may have been packed under another stream (the caller's): tell the allocator it is read here
+            x16.record_stream(torch.cuda.current_stream(dev))
+            meta16.record_stream(torch.cuda.current_stream(dev))
             c16, _ = PackedPoints(cent).screen_image(meta16)
             labels = torch.empty(N, dtype=torch.int32, device=dev)
             _lib.check(L.tdr_cluster_assign16_f32(_lib.ptr(x16), N, _lib.ptr(c16), C, D, _lib.ptr(meta16), _lib.ptr(labels), st),
@@ -435,6 +446,8 @@ FLAT_SCAN = True
 FLAT_TWO_TERMS = True      # the two-term tier of the threshold scan between one and three terms
 FLAT_FORCE_TERMS = 0       # 1 / 2 / 3: the threshold scan with that many terms whatever the pilots say (tests, measurement)
 _FLAT_L = 128
+FLAT_WS_LIMIT = 0          # bytes of threshold-scan workspace beyond which the queries go in blocks (0: a quarter of the free memory, >= 4 GB)
+_FLAT_QUERY_BLOCK = 262144  # rows per block then (a multiple of the 32-row tile; 1024 workgroups: the chip stays full)
 _FLAT_L_SHORT = 64         # list length when the list-keeping tier 0 (lists of <= 64) passed its pilot
 # ASSIGN16: the cluster index assigns the points to their nearest centres with the one-term f16 kernel (tdr_cluster_assign16_f32)
 # instead of the exact fp32 search with k = 1
@@ -456,6 +469,8 @@ def _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier):
     ok = [False] + [L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, Y.d, k, t, LL) != 0 for t in (1, 2, 3)]
     forced = int(_opt("FLAT_FORCE_TERMS"))
     if forced:
+        if forced not in (1, 2, 3):
+            raise ValueError(f"[torchdr_amd] FLAT_FORCE_TERMS must be 0 (pilots decide), 1, 2 or 3 (got {forced}).")
         return (forced, LL) if ok[forced] else (0, 0)
     if tier == 0 and ok[1]:
         return 1, (_FLAT_L_SHORT if k + 16 <= _FLAT_L_SHORT else LL)
@@ -504,22 +519,33 @@ def _flat_launch(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, terms, LL
     dev, d = Y.device, Y.d
     q16, y16, meta = ops
     t16 = L.tdr_packed16_floats(32, d)
-    ws_bytes = L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, d, k, terms, int(LL))
+    # lists and survivor regions are per query (nq * (8 L + 2060) bytes: 3.1 GB at 1M queries, 12 GB at 4M): one piece while it
+    # is a small part of the free memory, else query blocks of FLAT_QUERY_BLOCK rows (independent searches, same results)
+    limit = int(_opt("FLAT_WS_LIMIT")) or max(4 << 30, torch.cuda.mem_get_info(dev)[0] // 4)
+    blk = nq
+    if L.tdr_knn_screen_flat_workspace_bytes(nq, Y.n, d, k, terms, int(LL)) > limit and nq > _FLAT_QUERY_BLOCK:
+        blk = _FLAT_QUERY_BLOCK
+    ws_bytes = L.tdr_knn_screen_flat_workspace_bytes(min(blk, nq), Y.n, d, k, terms, int(LL))
     ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
     flags = torch.empty(nq, dtype=torch.int32, device=dev)
     n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
     if profile:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    _lib.check(
-        L.tdr_knn_screen_flat_f32(
-            _lib.ptr(q16[(q0 // 32) * t16:]), _lib.ptr(Q.X[q0:]), Q.X.stride(0), _lib.ptr(Q.norms[q0:]), nq, q_offset + q0,
-            _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
-            1 if exclude_self else 0, int(terms), int(LL), _lib.ptr(meta), _lib.ptr(out_d), _lib.ptr(out_i),
-            _lib.ptr(flags), _lib.ptr(n_flagged), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
-        ),
-        "tdr_knn_screen_flat_f32",
-    )
+    for o in range(0, nq, blk):
+        m = min(blk, nq - o)
+        nf = n_flagged if blk == nq else torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(
+            L.tdr_knn_screen_flat_f32(
+                _lib.ptr(q16[((q0 + o) // 32) * t16:]), _lib.ptr(Q.X[q0 + o:]), Q.X.stride(0), _lib.ptr(Q.norms[q0 + o:]), m,
+                q_offset + q0 + o, _lib.ptr(y16), _lib.ptr(Y.X), Y.X.stride(0), _lib.ptr(Y.norms), Y.n, d, k, _METRIC_ID[metric],
+                1 if exclude_self else 0, int(terms), int(LL), _lib.ptr(meta), _lib.ptr(out_d[o:]), _lib.ptr(out_i[o:]),
+                _lib.ptr(flags[o:]), _lib.ptr(nf), _lib.ptr(ws), ws_bytes, _lib.stream_ptr(),
+            ),
+            "tdr_knn_screen_flat_f32",
+        )
+        if nf is not n_flagged:
+            n_flagged += nf
     if profile:
         ev1.record()
         PROFILE.append((ev0, ev1, nq, "screen-flat%d" % terms))
@@ -696,6 +722,13 @@ def _cluster_index_early(Y):
         return
     dev = Y.device
     side = _side_streams(dev, 2)[1]
+    if ClusterIndex.builds_at_once(Y.n) and _opt("ASSIGN16"):
+        # N >= 2 048 000: the seed count is fixed, so the constructor runs the WHOLE build here and now, on the side stream --
+        # including the f16 nearest-centre assignment, which reads the block's screening image.  That image is cached on the
+        # block and shared with the pilots (main stream, first side stream): pack it on the main stream FIRST, so that every
+        # later reader is ordered behind the pack by the wait below / the waits of `_choose_tier` (packed by the
+        # side stream, the pilots read a half-written image and chose tier and tau from garbage)
+        Y.screen_image()
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
         _cluster_index_start(Y)

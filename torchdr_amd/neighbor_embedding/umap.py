@@ -55,6 +55,16 @@ RELABEL = True
 # row-major order when it is read.  False: the row-chunk kernel of rounds 2-3 (tdr_umap_sched_build_f32).
 GROUPED = True
 SCHED_STAGE = 0      # LDS stage entries of the grouped build (0 = library default)
+# NEGATIVES: where the scheduled loop's negatives come from (neighbor_embedding/base.py:617-649).
+#   "pool": per iteration every block of POOL rows stages runs of 16 consecutive rows of Z -- each run uniform over the data
+#           set -- into LDS and its rows draw their negatives from that pool (csrc/tdr_umap_pool.hip): uniform marginal law,
+#           rows of a block share the iteration's pool; one L2 request per staged LINE instead of one per negative, no L2
+#           slices, one lane per row.  float32, 2 or 3 components, no injected / excluded negatives; anything else falls
+#           back to "iid" on the same (one-slice) lists.
+#   "iid" : every negative an independent uniform draw gathered from L2 (csrc/tdr_umap_sched.hip): the reference's joint
+#           law -- the parity path (injected-negative tests, `discard_NNs`).
+NEGATIVES = "pool"
+POOL_GEOM = 0        # geometry of the pool kernel (0 = library default; tuning knob, changes the sampler's stream)
 
 def _opt(name):
     """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
@@ -160,7 +170,20 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         self.__dict__.pop("_next_rm", None)
 
     def _sched_slices(self) -> int:
+        if self._pool_negatives():
+            return 1    # negatives come from LDS and the fired edges are local in the loop's numbering: nothing to slice
         return int(_opt("SCHED_SLICES")) or int(_lib.lib().tdr_umap_sched_slices(self.n_samples_in_, self.n_components))
+
+    def _pool_negatives(self) -> bool:
+        """Decided once per fit (the loop layout depends on it): the pool sampler serves this fit."""
+        p = self.__dict__.get("_pool")
+        if p is None:
+            L = _lib.lib()
+            p = bool(_opt("NEGATIVES") == "pool" and _opt("SCHEDULED") and not _opt("SCHED_SLICES") and not self.discard_NNs
+                     and self.neg_indices_ is None and L.tdr_umap_pool_supported(int(self.n_components))
+                     and self.n_samples_in_ < 2**31 - 1)
+            self._pool = p
+        return p
 
     # the affinity stays in CSR on the device (the reference's padded (N, max_deg) layout is 5-8x larger)
     def _compute_affinity_in(self, X):
@@ -232,6 +255,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         # plans and buffers of a previous fit (kept until clear_memory, which a fit that raised never reached) are sized
         # for THAT graph: never reuse them
         self._sched, self._grad_buf, self._sched_deferred, self._grad_ws, self._g = None, None, False, None, None
+        self._pool = None
         super().on_affinity_computation_end()
         csr: CSRAffinity = self._relabel()
         self._csr_loop = csr
@@ -378,6 +402,19 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         self._sched_deferred = bool((geom & 16) and sc["S"] > 1 and self._fused_sgd and self._stock_step())
         if self._sched_deferred:
             geom |= 32
+        if self._pool_negatives() and neg is None and self.embedding_.data_ptr() % 16 == 0:
+            _lib.check(
+                L.tdr_umap_pool_grad_f32(
+                    _lib.ptr(self.embedding_), self.n_components, self.n_samples_in_, self.chunk_start_, self.chunk_size_,
+                    _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), t - sc["t0"], float(self._a), float(self._b), t,
+                    int(self.negative_sample_rate), int(self.n_negatives), self._neg_seed, float(self.early_exaggeration_coeff_),
+                    float(self.repulsion_strength), float(self._eps), _lib.ptr(grad), int(_opt("POOL_GEOM")), _lib.stream_ptr(),
+                ),
+                "tdr_umap_pool_grad_f32",
+            )
+            if prof:
+                self._prof_pending = (ev0, ev1, csr.nnz)     # closed after the SGD step (_sgd_kernel): one whole iteration
+            return
         _lib.check(
             L.tdr_umap_sched_grad_f32(
                 _lib.ptr(self.embedding_), self.n_components, self.n_samples_in_, self.chunk_start_, self.chunk_size_,
@@ -409,7 +446,12 @@ class UMAP(NegativeSamplingNeighborEmbedding):
 
     def _sgd_kernel(self, Z, grad, chunk=False):
         if not getattr(self, "_sched_deferred", False):
-            return super()._sgd_kernel(Z, grad, chunk=chunk)
+            super()._sgd_kernel(Z, grad, chunk=chunk)
+            pend = self.__dict__.pop("_prof_pending", None)
+            if pend is not None and PROFILE is not None:
+                pend[1].record()
+                PROFILE.append(("grad", pend[0], pend[1], pend[2]))
+            return
         self._sched_deferred = False
         sc = self._sched
         mom = float(self._sgd_momentum)
@@ -493,6 +535,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         ctx = getattr(self, "_rccl_ctx", None)
         d.gather, d.gather_ctx = (ctx.gather_fn, ctx.handle) if ctx is not None else (None, None)
         d.geom = sc["geom"]
+        d.pool = int(_opt("POOL_GEOM")) + 1 if (self._pool_negatives() and self.embedding_.data_ptr() % 16 == 0) else 0
         handle = ctypes.c_void_p()
         _lib.check(L.tdr_umap_loop_create(ctypes.byref(handle), ctypes.byref(d)), "tdr_umap_loop_create")
         # graphs cannot be captured on the legacy default stream: the loop runs on a side stream ordered after the
@@ -610,6 +653,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
     def clear_memory(self):
         super().clear_memory()
         self.__dict__.pop("_g", None)
+        self.__dict__.pop("_pool", None)
         for attr in ("_csr", "_csr_loop", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf", "_grad_ws", "_sched", "_loop_cols"):
             if hasattr(self, attr):
                 delattr(self, attr)
