@@ -384,13 +384,15 @@ int tdr_umap_sched_step_f32(const float* acc, int n_slices, int nc, int64_t n_ro
                             float* buf, float lr, float momentum, int first, int* nan_flag, int n_iter, void* stream);
 /* Round 6: the same gradient with the negatives served from LDS (csrc/tdr_umap_pool.hip; replaces the sampling of
  * neighbor_embedding/base.py:617-649 for the UMAP loop).  Lists and records of a ONE-slice schedule (n_slices = 1 in plan /
- * build).  A workgroup owns a global block of rows and stages, per iteration, a pool of runs of 16 consecutive rows of Z
+ * build).  A workgroup owns a global block of rows and stages, per iteration, a pool of runs of 16 (8) consecutive rows of Z
  * (each run uniform over the ceil(N / 16) runs, counter hash of (seed, iteration, block, slot)) into LDS with coalesced loads;
  * every row draws its min(neg_rate * act, n_negatives) items uniformly from the pool.  Marginal law of an item: uniform over
  * the rows; a draw of the row itself or of the padding of the last run contributes zero (dropped).  One lane per row, rows of a
  * block sorted by active count; a row's sums depend on the row alone (a row-sharded launch gives the same bits).  Z must be
- * 16-byte aligned; nc in {2, 3} (tdr_umap_pool_supported).  geom: 0 = default (512 rows / 256 runs per block), 1..5 = tuning
- * geometries (256/256, 512/256, 512/512, 1024/256, 1024/512) -- the sampler's stream depends on it.
+ * 16-byte aligned; nc in {2, 3} (tdr_umap_pool_supported).  geom: 0 = the default geometry (512 threads x 2 rows, 256 runs of 8 rows), 1..6 = tuning geometries
+ * (threads per block / rows per thread / pool runs / rows per run: TDR_POOL_GEOMS of csrc/tdr_umap_pool.hip) -- the sampler's
+ * stream depends on rows per block, runs and run length.  tdr_umap_pool_grad_debug_f32: measurement hook (tools/umap_pool_perf.py):
+ * the same launch through an instrumented instance with parts switched off (`ablate`) and per-block phase time stamps (`times`).
  * tdr_umap_pool_debug_negatives: test hook, the global row of every item drawn for rows with nuse[r] items into out (n_rows,
  * width) int64: -1 beyond the row's count, -2 a dropped draw. */
 int tdr_umap_pool_supported(int nc);
@@ -399,6 +401,9 @@ int tdr_umap_pool_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0
                            float rep, float eps, float* grad, int geom, void* stream);
 int tdr_umap_pool_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nuse, int geom,
                                   int width, int64_t* out, void* stream);
+int tdr_umap_pool_grad_debug_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list, const void* hdr,
+                                 int t_local, float a, float b, int n_iter, int neg_rate, int n_negatives, uint64_t seed, float* grad,
+                                 int geom, int ablate, void* times, void* stream);
 /* Round 4: peer exchange (csrc/tdr_peerx.hip) -- tdr_ctx_allgather_rows's contract without a collective library: every rank
  * writes its stepped rows into a (fine-grained) staging block of every peer over xGMI, raises a generation flag there, waits
  * for the flags raised at it and copies the staged rows into its embedding; two launches per exchange.  Peers are mapped

@@ -22,7 +22,8 @@ from tests.test_umap_sched_gpu import Sched, csr_rows_to_padded, padded_to_csr, 
 
 pytestmark = pytest.mark.gpu
 
-GEOMS = {0: (512, 256), 1: (256, 256), 2: (512, 256), 3: (512, 512), 4: (1024, 256), 5: (1024, 512)}
+# geometry -> (rows per block, pool runs, rows per run): TDR_POOL_GEOMS of csrc/tdr_umap_pool.hip; 0 = the production default
+GEOMS = {0: (1024, 256, 8), 1: (512, 256, 16), 2: (1024, 256, 16), 3: (1024, 128, 16), 4: (512, 256, 8), 5: (1024, 512, 8), 6: (1024, 256, 16)}
 
 
 def pool_grad(sc, Z, t_local, n_iter, a, b, n_neg, seed, geom=0, neg_rate=5):
@@ -93,7 +94,7 @@ def test_pool_gradient_vs_oracle_fixture_graph(nc):
             for t in range(tl):
                 act = nb <= np.float32(t + 1)
                 nb[act] += ep[act]
-            for geom in range(6):
+            for geom in GEOMS:
                 err = oracle_check_pool(sc, Z, nb, tl, tl, a, b, 50, 1234567, rows, geom=geom)
                 assert err < 1e-5, (nc, n, tl, geom, err)
 
@@ -118,7 +119,7 @@ def test_pool_gradient_vs_oracle_large_and_wide():
     assert err < 1e-5, err
 
 
-@pytest.mark.parametrize("geom", [0, 1, 5])
+@pytest.mark.parametrize("geom", [0, 1, 4, 6])
 def test_pool_row_shard_gives_the_bits_of_the_full_launch(geom):
     """Chunks that start and end inside a row block: the rows' gradients equal the full launch bit for bit (the pool is keyed by
     the GLOBAL row block, a row's sums by the row alone)."""
@@ -143,15 +144,15 @@ def test_pool_row_shard_gives_the_bits_of_the_full_launch(geom):
         assert torch.equal(part, full[c0:c1]), (geom, c0, c1)
 
 
-@pytest.mark.parametrize("geom", [0, 5])
+@pytest.mark.parametrize("geom", [0, 1, 5])
 def test_pool_sampler_law(geom):
     """Marginal law of an item: uniform over the rows (chi-square on 5003 rows, ragged last run), dropped draws = the row
-    itself or the 13 padding rows of the last run at the expected rate; pools are redrawn per iteration and per block
+    itself or the padding rows of the last run at the expected rate; pools are redrawn per iteration and per block
     (the runs staged by two iterations / two blocks overlap as independent uniform samples do)."""
     n = 5003
-    rows_per_block, runs = GEOMS[geom]
-    n_runs = (n + 15) // 16
-    p_drop = (16 * n_runs - n + 1) / (16 * n_runs)   # padding rows (16 n_runs - n of 16 n_runs slots) + self (1 slot)
+    rows_per_block, runs, rl = GEOMS[geom]
+    n_runs = (n + rl - 1) // rl
+    p_drop = (rl * n_runs - n + 1) / (rl * n_runs)   # padding rows (rl n_runs - n of rl n_runs slots) + self (1 slot)
     for width, iters in ((2, 200), (150, 30)):
         nuse = torch.full((n,), width, dtype=torch.int32, device="cuda")
         counts = torch.zeros(n, dtype=torch.float64)
@@ -167,11 +168,11 @@ def test_pool_sampler_law(geom):
             total += neg.numel()
             if width > 2:   # the pool a block used this iteration ~ the set of runs its rows drew from
                 blk = [neg[b * rows_per_block:(b + 1) * rows_per_block] for b in range(2)]
-                pools.append([set((x[x >= 0] // 16).tolist()) for x in blk])
+                pools.append([set((x[x >= 0] // rl).tolist()) for x in blk])
         # rows of a block share the iteration's pool (and the 16 rows of a run enter it together): counts are over-dispersed
         # against i.i.d. draws by 1 + (draws per pool row) -- the drop rate by the same factor
-        infl = 1.0 + rows_per_block * width / (16.0 * runs)
-        assert abs(dropped / total - p_drop) < 6 * np.sqrt(p_drop * infl * 16 / total) + 1e-4, (width, dropped / total, p_drop)
+        infl = 1.0 + rows_per_block * width / float(rl * runs)
+        assert abs(dropped / total - p_drop) < 6 * np.sqrt(p_drop * infl * rl / total) + 1e-4, (width, dropped / total, p_drop)
         kept = counts.sum()
         chi2 = float(((counts - kept / n) ** 2 / (kept / n)).sum())
         assert 0.6 * (n - 1) * infl < chi2 + (n - 1) * (infl - 1) * 0.6 and chi2 < 1.5 * (n - 1) * infl, (width, chi2, n, infl)
@@ -212,13 +213,14 @@ def test_pool_sampler_gives_the_reference_quality(regime, n):
     X, lab = regime_data(regime, n)
     Xc = X.cuda()
     out = {}
+    geom = int(os.environ.get("TDR_TEST_POOL_GEOM", "0"))     # measurement runs: another pool geometry than the default
     for mode in ("pool", "iid"):
-        with config.options(NEGATIVES=mode):
+        with config.options(NEGATIVES=mode, POOL_GEOM=geom):
             s = [_scores(Xc, torchdr_amd.UMAP(n_neighbors=30, max_iter=500, random_state=seed).fit_transform(Xc), lab) for seed in (0, 1)]
         out[mode] = {k: min(r[k] for r in s) for k in s[0]}
     ref = {"np": [c["neighborhood_preservation_K15"] for c in q], "acc": [c["knn_label_accuracy_k10"] for c in q],
            "sil": [c["silhouette"] for c in q]}
-    rec = {"regime": regime, "n": n, "reference": {k: min(v) for k, v in ref.items()}, **out}
+    rec = {"regime": regime, "n": n, "pool_geom": geom, "reference": {k: min(v) for k, v in ref.items()}, **out}
     print(rec)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/pool_quality.jsonl", "a") as f:

@@ -3,13 +3,20 @@
 #pragma once
 #include "tdr_common.h"
 
-// default geometry (geom = 0): rows per workgroup / pool runs of 16 rows
-#ifndef TDR_POOL_ROWS
-#define TDR_POOL_ROWS 512
+// default geometry (geom = 0): threads per block, rows per thread, pool runs, rows per run
+#ifndef TDR_POOL_THREADS
+#define TDR_POOL_THREADS 512
+#endif
+#ifndef TDR_POOL_RPT
+#define TDR_POOL_RPT 2
 #endif
 #ifndef TDR_POOL_RUNS
 #define TDR_POOL_RUNS 256
 #endif
+#ifndef TDR_POOL_RUNLEN
+#define TDR_POOL_RUNLEN 8
+#endif
+#define TDR_POOL_NGEOM 6     // tuning geometries 1..6 (TDR_POOL_GEOMS of tdr_umap_pool.hip)
 
 namespace tdr {
 
@@ -27,8 +34,11 @@ struct PoolGradParams {
     const int* iter_base;      // optional device int added to iter (graph replays)
     float exag, rep, eps;
     float* grad;               // (n_rows, nc)
-    uint32_t n_runs;           // ceil(n_total / 16)
+    uint32_t n_runs;           // ceil(n_total / rows per run) (set by the launcher)
     int64_t gb0;               // first global row block of the launch (set by the launcher)
+    int exact5;                // neg_rate == 5 and n_negatives % 5 == 0: a row's items come in whole groups of five
+    unsigned long long* dbg_times;   // measurement only (DBG instances): 8 time stamps per block
+    int ablate;                // measurement only: 1 no pool staging, 2 no attraction, 4 no negatives, 8 rows not sorted
 };
 
 int launch_pool_grad(const PoolGradParams& P, int geom, hipStream_t st);

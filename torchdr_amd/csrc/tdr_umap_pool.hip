@@ -46,16 +46,54 @@ __device__ __forceinline__ uint32_t pool_block_key(uint64_t seed, uint32_t iter,
 __device__ __forceinline__ uint32_t pool_run(uint32_t bkey, uint32_t slot, uint32_t n_runs) {
     return __umulhi(mix32_item(bkey + slot * 0x9E3779B9u), n_runs);
 }
-__device__ __forceinline__ uint32_t pool_row_key(uint64_t seed, uint32_t iter, int64_t gi) {
-    return neg_row_key(seed, iter, gi) ^ 0x68E31DA4u;    // decorrelated from the i.i.d. sampler's stream of the same row
+// A row's items walk the pool in a per-row arithmetic progression: item k reads pool row (alpha + k beta) >> (32 - LOGP) with
+// alpha, beta (odd) hashed from (seed, iteration, row).  Every item is uniform over the pool (alpha is), any two items of a row
+// are independent (their difference (k' - k) beta is uniform), the items of a row never coincide while it has fewer items than
+// the pool has rows, and two rows share a progression with probability 2^-31 -- for ONE add per item where a strong hash of the
+// item index costs two 32-bit multiplies (quarter rate: a third of the instruction cycles of an item).
+struct PoolRowKey { uint32_t alpha, beta; };
+__device__ __forceinline__ PoolRowKey pool_row_key(uint64_t seed, uint32_t iter, int64_t gi) {
+    PoolRowKey K;
+    K.alpha = neg_row_key(seed, iter, gi) ^ 0x68E31DA4u;    // decorrelated from the i.i.d. sampler's stream of the same row
+    K.beta = mix32_item(K.alpha + 0x632BE5ABu) | 1u;
+    return K;
 }
-// pool row (0 .. 16 RUNS - 1) of item k of a row
+// pool row (0 .. POOL_ROWS - 1) of item k of a row
 template <int LOGP>
-__device__ __forceinline__ uint32_t pool_item(uint32_t rkey, uint32_t k) {
-    return mix32_item(rkey + k * 0x9E3779B9u) >> (32 - LOGP);
+__device__ __forceinline__ uint32_t pool_item(const PoolRowKey& K, uint32_t k) {
+    return (K.alpha + k * K.beta) >> (32 - LOGP);
 }
 
 constexpr int ilog2(int x) { return x <= 1 ? 0 : 1 + ilog2(x >> 1); }
+
+// squared distance with fused multiply-adds (this kernel is compared with the oracle at 1e-5, not bit for bit with the other
+// gradient kernels; the library is built with -ffp-contract=off, so the fusion is explicit)
+template <int NC>
+__device__ __forceinline__ float sqdist_fma(const Vec<NC>& a, const Vec<NC>& b, float (&df)[NC]) {
+    df[0] = a.v[0] - b.v[0];
+    float d = df[0] * df[0];
+#pragma unroll
+    for (int c = 1; c < NC; ++c) { df[c] = a.v[c] - b.v[c]; d = __builtin_fmaf(df[c], df[c], d); }
+    return d;
+}
+
+// Row gather through a buffer descriptor: a lane whose byte offset lies beyond the descriptor's range gets zeros and issues NO
+// request -- the branch-free way to leave lanes out of a gather (the L1 serves divergent 8-byte gathers at ~0.44 lanes per clock
+// and CU, tools/gather_bench.hip: what bounds the attraction phase is the number of lanes that ask)
+typedef int pool_i32x2 __attribute__((ext_vector_type(2)));
+typedef int pool_i32x3 __attribute__((ext_vector_type(3)));
+template <int NC>
+__device__ __forceinline__ Vec<NC> gather_z(__amdgpu_buffer_rsrc_t rs, uint32_t voff) {
+    Vec<NC> r;
+    if (NC == 2) {
+        const pool_i32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0);
+        r.v[0] = __int_as_float(t.x); r.v[1] = __int_as_float(t.y);
+    } else {
+        const pool_i32x3 t = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)voff, 0, 0);
+        r.v[0] = __int_as_float(t.x); r.v[1] = __int_as_float(t.y); r.v[NC - 1] = __int_as_float(t.z);
+    }
+    return r;
+}
 
 template <int NC>
 __device__ __forceinline__ Vec<NC> pool_read(const float* pool, uint32_t s) {
@@ -70,17 +108,33 @@ __device__ __forceinline__ Vec<NC> pool_read(const float* pool, uint32_t s) {
     return r;
 }
 
-// ROWS threads = ROWS rows of a global row block; RUNS pool runs of 16 rows
-template <int NC, int ROWS, int RUNS>
-__global__ __launch_bounds__(ROWS) void umap_pool_grad_kernel(const PoolGradParams P) {
-    constexpr int POOL_ROWS = RUNS * 16;
-    constexpr int LOGP = ilog2(POOL_ROWS);
-    static_assert((1 << LOGP) == POOL_ROWS, "pool rows must be a power of two");
-    constexpr int PPR = 4 * NC;                 // 16-byte pieces per run
+// THREADS lanes evaluate the ROWS = RPT x THREADS rows of a global row block against a pool of RUNS runs of RUNLEN rows.
+// RPT = 2 ("folded"): position p of the sorted order and position ROWS - 1 - p go to the same lane, one after the other -- a
+// wavefront then carries a busy and a quiet batch and all wavefronts of the block end together (sorted but unfolded, the first
+// wavefront holds the 64 busiest rows, runs ~2.7x the average and keeps the block's LDS allocated while the others idle).
+// DBG instances (tools/umap_pool_perf.py only) honour the ablation switches of P.ablate and write phase time stamps of every
+// block's first wavefront to P.dbg_times; the production instance carries neither.
+// (An LDS window of the rows around the block for the fired-edge gathers -- in the loop's cluster-sorted numbering 42 % of the
+// fired edges end in the row's own block, all within 1024 rows -- was built in three forms and measured slower every time:
+// profiles/r06_pool_window.json.)
+template <int NC, int THREADS, int RPT, int RUNS, int RUNLEN, bool DBG>
+__global__ __launch_bounds__(THREADS, NC == 2 ? 8 : 4) void umap_pool_grad_kernel(const PoolGradParams P) {   // 2 components: <= 64 registers, four 512-thread blocks per CU
+    const int ablate = DBG ? P.ablate : 0;
+    auto stamp = [&](int i) {
+        if (DBG && P.dbg_times && (threadIdx.x & 63) == 0)
+            P.dbg_times[((size_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6)) * 8 + i] = (unsigned long long)__builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    constexpr int ROWS = THREADS * RPT;
+    constexpr int POOL_ROWS = RUNS * RUNLEN;
+    constexpr int LOGP = ilog2(POOL_ROWS), LOGR = ilog2(RUNLEN);
+    static_assert((1 << LOGP) == POOL_ROWS && (1 << LOGR) == RUNLEN, "pool rows / run length must be powers of two");
+    constexpr int PPR = RUNLEN * NC / 4;        // 16-byte pieces per run
+    static_assert(PPR * 4 == RUNLEN * NC, "a run must be made of whole 16-byte pieces");
     constexpr int PIECES = RUNS * PPR;
-    constexpr int NW = ROWS / 64;
-    static_assert(PIECES % ROWS == 0, "pool pieces must divide over the threads");
-    constexpr int NIT = PIECES / ROWS;
+    constexpr int NW = THREADS / 64;
+    static_assert(PIECES % THREADS == 0, "pool pieces must divide over the threads");
+    constexpr int NIT = PIECES / THREADS;
     constexpr int U = 4;
     __shared__ __attribute__((aligned(16))) float pool[POOL_ROWS * NC];
     __shared__ uint32_t hist[64];
@@ -92,47 +146,55 @@ __global__ __launch_bounds__(ROWS) void umap_pool_grad_kernel(const PoolGradPara
     const int64_t gb = P.gb0 + (int64_t)blockIdx.x;
     const uint32_t bkey = pool_block_key(P.seed, iter, (uint32_t)gb);
 
-    // 1. the pool: NIT LDS-DMA instructions per wavefront (a lane moves 16 bytes; the 4 NC lanes of a run one 64 NC-byte run)
-    const bool ragged = (P.n_total & 15) != 0;
+    // 1. the pool: NIT LDS-DMA instructions per wavefront (a lane moves 16 bytes; the PPR lanes of a run one whole run)
+    const bool ragged = (P.n_total & (RUNLEN - 1)) != 0;
     const int64_t z_floats = P.n_total * NC;
     uint32_t fix = 0;
+    if (!(ablate & 1))
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int p = (it * NW + wave) * 64 + lane;
         const uint32_t slot = (uint32_t)p / PPR, part = (uint32_t)p % PPR;
         const uint32_t run = pool_run(bkey, slot, P.n_runs);
-        const int64_t off = (int64_t)run * (16 * NC) + part * 4;
+        const int64_t off = (int64_t)run * (RUNLEN * NC) + part * 4;
         const bool last = ragged && run == P.n_runs - 1u;
         if (last) fix |= 1u << it;
         const float* src = (last && off + 4 > z_floats) ? P.Z : P.Z + off;
         __builtin_amdgcn_global_load_lds((pgptr_t)src, (plptr_t)(pool + (it * NW + wave) * 256), 16, 0, 0);
     }
-    // 2. this thread's row and its record of the iteration
+    // 2. the records of this thread's RPT rows of the block (rows t, t + THREADS, ...) and their sort keys
     if (t < 64) hist[t] = 0;
-    const int64_t gi0 = gb * ROWS + t;
-    const int64_t r0 = gi0 - P.row0;
-    uint2 h = make_uint2(0u, 0u);
-    if (r0 >= 0 && r0 < P.n_rows) {
-        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-        const u32x2_t hv = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(P.hdr + (size_t)P.t_local * P.n_rows + r0));
-        h = make_uint2(hv.x, hv.y);
+    uint2 h[RPT];
+    uint32_t key[RPT], rank[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int64_t r0 = gb * ROWS + q * THREADS + t - P.row0;
+        h[q] = make_uint2(0u, 0u);
+        if (r0 >= 0 && r0 < P.n_rows) {
+            typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t hv = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(P.hdr + (size_t)P.t_local * P.n_rows + r0));
+            h[q] = make_uint2(hv.x, hv.y);
+        }
+        const uint32_t act0 = (ablate & 8) ? 0u : h[q].y >> 16;
+        key[q] = 63u - (act0 < 63u ? act0 : 63u);     // busiest rows first
     }
-    const uint32_t act0 = h.y >> 16;
-    const uint32_t key = 63u - (act0 < 63u ? act0 : 63u);     // busiest rows first
+    stamp(1);
     __syncthreads();   // pool staged (the barrier waits for the wavefront's DMA), histogram zeroed
+    stamp(2);
     if (fix) {
-        // padding rows of the last run (N % 16 != 0): the pieces of that run are rewritten float by float, rows >= N as sentinels
+        // padding rows of the last run (N % RUNLEN != 0): the pieces of that run are rewritten float by float, rows >= N as sentinels
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (!(fix >> it & 1u)) continue;
             const int p = (it * NW + wave) * 64 + lane;
             const uint32_t part = (uint32_t)p % PPR;
-            const int64_t off = (int64_t)(P.n_runs - 1u) * (16 * NC) + part * 4;
+            const int64_t off = (int64_t)(P.n_runs - 1u) * (RUNLEN * NC) + part * 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) pool[p * 4 + e] = off + e < z_floats ? P.Z[off + e] : POOL_SENTINEL;
         }
     }
-    const uint32_t rank = atomicAdd(&hist[key], 1u);
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) rank[q] = atomicAdd(&hist[key[q]], 1u);
     __syncthreads();
     if (t < 64) {   // exclusive scan of the 64 bins
         const uint32_t v = hist[t];
@@ -145,116 +207,173 @@ __global__ __launch_bounds__(ROWS) void umap_pool_grad_kernel(const PoolGradPara
         hist[t] = s - v;
     }
     __syncthreads();
-    order[hist[key] + rank] = (uint16_t)t;
-    rec[t] = h;
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        order[hist[key[q]] + rank[q]] = (uint16_t)(q * THREADS + t);
+        rec[q * THREADS + t] = h[q];
+    }
     __syncthreads();
-    // 3. the row this lane evaluates (position t of the sorted order)
-    const int my = order[t];
-    h = rec[my];
-    const int64_t gi64 = gb * ROWS + my;
-    const int64_t r = gi64 - P.row0;
-    if (r < 0 || r >= P.n_rows) return;
-    const uint32_t gi = (uint32_t)gi64;
-    const Vec<NC> zi = load_z<NC>(P.Z, gi64);
-    const int npos = (int)(h.y & 0xffffu);
-    int n_use = (int)(h.y >> 16) * P.neg_rate;
-    if (n_use > P.n_negatives) n_use = P.n_negatives;
+    stamp(3);
     const float two_ab = 2.0f * P.a * P.b, m2b = -2.0f * P.b;
-    float ga[NC], gr[NC];
+    const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.Z), 0, (int)(uint32_t)(z_floats * 4), 0x00020000);
+    // 3. the rows this lane evaluates: position t of the sorted order, then (RPT = 2) position ROWS - 1 - t
+#pragma unroll 1
+    for (int q = 0; q < RPT; ++q) {
+        const int my = order[q == 0 ? t : ROWS - 1 - t];
+        const uint2 hh = rec[my];
+        const int64_t gi64 = gb * ROWS + my;
+        const int64_t r = gi64 - P.row0;
+        if (r < 0 || r >= P.n_rows) continue;
+        const uint32_t gi = (uint32_t)gi64;
+        const Vec<NC> zi = load_z<NC>(P.Z, gi64);
+        const int npos = (ablate & 2) ? 0 : (int)(hh.y & 0xffffu);
+        int n_use = (int)(hh.y >> 16) * P.neg_rate;
+        if (n_use > P.n_negatives) n_use = P.n_negatives;
+        if (ablate & 4) n_use = 0;
+        float ga[NC], gr[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) { ga[c] = 0.f; gr[c] = 0.f; }
-    // attraction: the row's fired edges, four list entries per 16-byte read (the list carries 64 entries of slack)
-    const int32_t* lst = P.list + h.x;
-    for (int k = 0; k < npos; k += U) {
+        for (int c = 0; c < NC; ++c) { ga[c] = 0.f; gr[c] = 0.f; }
+        // attraction: the row's fired edges, four list entries per 16-byte read (the list carries 64 entries of slack).
+        // 2ab d^(b-1) / (1 + a d^b) = 2ab d^b / (d (1 + a d^b)), 0 where d <= 0 (umap.py:252-256): d = 0 makes d^b = 0 and the
+        // guarded reciprocal finite, so the coefficient is 0 without a test -- and a slot beyond the row's count reads the row
+        // itself (d = 0): no masks in the loop
+        // Two memory round trips per round (entries, then the rows they name) in a chain as long as the row's list bound the
+        // launch (the busiest wavefront of a block walks ~30 entries: 16 dependent trips at four entries per round): rounds of
+        // EIGHT entries, the entries of round r + 1 requested before the gathers of round r are issued -- and, between issuing
+        // the gathers of a round and using them, the wavefront evaluates the NEGATIVES that belong to those entries (five per
+        // fired edge, served from LDS: pure vector work), so the trip is hidden inside the wavefront itself.
+        // repulsion: n_use items from the pool; -2b / ((d + eps)(1 + a d^b)) (umap.py:272-281).  n_use = neg_rate x (fired
+        // edges): with the reference's rate of 5 (and a cap that is a multiple of it) the items come in whole groups of five and
+        // the loop carries no masks
+        const int32_t* lst = P.list + hh.x;
         typedef int i32x4 __attribute__((ext_vector_type(4)));
-        i32x4 l4;
-        __builtin_memcpy(&l4, lst + k, 16);
-        Vec<NC> zj[U];
+        const PoolRowKey rk = pool_row_key(P.seed, iter, gi64);
+        uint32_t x = rk.alpha;
+        int kn = 0;                 // negatives done
+        i32x4 ln[2];
+        const bool ab_list = ablate & 32, ab_gather = ablate & 16;      // DBG instances: no list reads / no gathers
+        ln[0] = ln[1] = i32x4{(int)gi, (int)gi, (int)gi, (int)gi};
+        if (npos > 0 && !ab_list) { __builtin_memcpy(&ln[0], lst, 16); __builtin_memcpy(&ln[1], lst + 4, 16); }
+        for (int k = 0; k < npos; k += 2 * U) {
+            const i32x4 lc[2] = {ln[0], ln[1]};
+            if (k + 2 * U < npos && !ab_list) { __builtin_memcpy(&ln[0], lst + k + 2 * U, 16); __builtin_memcpy(&ln[1], lst + k + 3 * U, 16); }
+            Vec<NC> zj[2 * U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) zj[u] = load_z<NC>(P.Z, (int64_t)(k + u < npos ? (uint32_t)l4[u] : gi));
+            for (int u = 0; u < 2 * U; ++u) {
+                // a slot beyond the row's count takes no part in the gather (offset outside the descriptor's range: no request and
+                // no branch -- a branch per slot breaks the eight loads into eight issue / wait groups: 0.088 vs 0.075 ms per launch)
+                const bool valid = k + u < npos;
+                const uint32_t j = (uint32_t)lc[u >> 2][u & 3];
+                if (DBG && ab_gather) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float df[NC];
-            const float d = sqdist<NC>(zi, zj[u], df);
-            const float pb = fast_pow(d, P.b);
-            // 2ab d^(b-1) / (1 + a d^b), 0 where d <= 0 (umap.py:252-256)
-            float coef = pb * two_ab * fast_rcp(d * (1.0f + P.a * pb));
-            if (!(k + u < npos) || !(d > 0.f)) coef = 0.f;
+                    for (int c = 0; c < NC; ++c) zj[u].v[c] = zi.v[c] + __uint_as_float((j & 0xffffu) | 0x3f000000u);
+                } else {
+                    zj[u] = gather_z<NC>(zrs, valid ? j * (uint32_t)(NC * 4) : 0xffffffffu);
+                }
 #pragma unroll
-            for (int c = 0; c < NC; ++c) ga[c] += coef * df[c];
+                for (int c = 0; c < NC; ++c) zj[u].v[c] = valid ? zj[u].v[c] : zi.v[c];
+            }
+            if (P.exact5) {
+#pragma unroll 1
+                for (int q = 0; q < 2 * U && kn < n_use; ++q, kn += 5) {
+                    Vec<NC> zn[5];
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) { zn[u] = pool_read<NC>(pool, x >> (32 - LOGP)); x += rk.beta; }
+#pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        float df[NC];
+                        const float d = sqdist_fma<NC>(zi, zn[u], df);
+                        const float coef = m2b * fast_rcp((d + P.eps) * __builtin_fmaf(P.a, fast_pow(d, P.b), 1.0f));
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) gr[c] = __builtin_fmaf(coef, df[c], gr[c]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2 * U; ++u) {
+                float df[NC];
+                const float d = sqdist_fma<NC>(zi, zj[u], df);
+                const float pb = fast_pow(d, P.b);
+                const float coef = pb * two_ab * fast_rcp(fmaxf(d * __builtin_fmaf(P.a, pb, 1.0f), 1e-37f));
+#pragma unroll
+                for (int c = 0; c < NC; ++c) ga[c] = __builtin_fmaf(coef, df[c], ga[c]);
+            }
         }
-    }
-    // repulsion: n_use items from the pool; -2b / ((d + eps)(1 + a d^b)) (umap.py:272-281)
-    const uint32_t rkey = pool_row_key(P.seed, iter, gi64);
-    for (int k = 0; k < n_use; k += U) {
-        Vec<NC> zj[U];
+        // what is left of the negatives (a rate other than 5, or more items than five per listed edge)
+        for (; kn < n_use; kn += U) {
+            Vec<NC> zn[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) zj[u] = pool_read<NC>(pool, pool_item<LOGP>(rkey, (uint32_t)(k + u)));
+            for (int u = 0; u < U; ++u) { zn[u] = pool_read<NC>(pool, x >> (32 - LOGP)); x += rk.beta; }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float df[NC];
-            const float d = sqdist<NC>(zi, zj[u], df);
-            const float pb = fast_pow(d, P.b);
-            float coef = m2b * fast_rcp((d + P.eps) * (1.0f + P.a * pb));
-            if (!(k + u < n_use)) coef = 0.f;
+            for (int u = 0; u < U; ++u) {
+                float df[NC];
+                const float d = sqdist_fma<NC>(zi, zn[u], df);
+                float coef = m2b * fast_rcp((d + P.eps) * __builtin_fmaf(P.a, fast_pow(d, P.b), 1.0f));
+                if (!(kn + u < n_use)) coef = 0.f;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) gr[c] += coef * df[c];
+                for (int c = 0; c < NC; ++c) gr[c] = __builtin_fmaf(coef, df[c], gr[c]);
+            }
         }
-    }
-    float g[NC];
+        float g[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) g[c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
-    if (NC == 2) {
-        *reinterpret_cast<float2*>(P.grad + (size_t)r * 2) = make_float2(g[0], g[1]);
-    } else {
+        for (int c = 0; c < NC; ++c) g[c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
+        if (NC == 2) {
+            *reinterpret_cast<float2*>(P.grad + (size_t)r * 2) = make_float2(g[0], g[1]);
+        } else {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) P.grad[(size_t)r * NC + c] = g[c];
+            for (int c = 0; c < NC; ++c) P.grad[(size_t)r * NC + c] = g[c];
+        }
+        stamp(4 + q);
     }
 }
 
 // test hook: the global row of every item the gradient kernel draws for rows with nuse[r] items (-1: beyond the row's count;
 // -2: a dropped draw -- the row itself or the padding of the last run)
-template <int ROWS, int RUNS>
+template <int ROWS, int RUNS, int RUNLEN>
 __global__ __launch_bounds__(256) void umap_pool_debug_kernel(uint64_t seed, uint32_t iter, int64_t n_total, int64_t row0, int64_t n_rows,
                                                               const int32_t* __restrict__ nuse, int width, int64_t* __restrict__ out) {
-    constexpr int LOGP = ilog2(RUNS * 16);
+    constexpr int LOGP = ilog2(RUNS * RUNLEN), LOGR = ilog2(RUNLEN);
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n_rows) return;
     const int64_t gi = row0 + r;
-    const uint32_t n_runs = (uint32_t)((n_total + 15) / 16);
+    const uint32_t n_runs = (uint32_t)((n_total + RUNLEN - 1) / RUNLEN);
     const uint32_t bkey = pool_block_key(seed, iter, (uint32_t)(gi / ROWS));
-    const uint32_t rkey = pool_row_key(seed, iter, gi);
+    const PoolRowKey rkey = pool_row_key(seed, iter, gi);
     const int n = nuse[r];
     for (int k = 0; k < width; ++k) {
         int64_t j = -1;
         if (k < n) {
             const uint32_t s = pool_item<LOGP>(rkey, (uint32_t)k);
-            j = (int64_t)pool_run(bkey, s >> 4, n_runs) * 16 + (s & 15u);
+            j = (int64_t)pool_run(bkey, s >> LOGR, n_runs) * RUNLEN + (s & (uint32_t)(RUNLEN - 1));
             if (j >= n_total || j == gi) j = -2;
         }
         out[(size_t)r * width + k] = j;
     }
 }
 
-template <int NC, int ROWS, int RUNS>
+template <int NC, int THREADS, int RPT, int RUNS, int RUNLEN>
 static int launch_pool(const PoolGradParams& P0, hipStream_t st) {
+    const bool dbg = P0.ablate != 0 || P0.dbg_times != nullptr;
+    constexpr int ROWS = THREADS * RPT;
     PoolGradParams P = P0;
     P.gb0 = P.row0 / ROWS;
+    P.n_runs = (uint32_t)((P.n_total + RUNLEN - 1) / RUNLEN);
     const int64_t gb1 = (P.row0 + P.n_rows - 1) / ROWS;
-    hipLaunchKernelGGL((umap_pool_grad_kernel<NC, ROWS, RUNS>), dim3((unsigned)(gb1 - P.gb0 + 1)), dim3(ROWS), 0, st, P);
+    if (dbg) hipLaunchKernelGGL((umap_pool_grad_kernel<NC, THREADS, RPT, RUNS, RUNLEN, true>), dim3((unsigned)(gb1 - P.gb0 + 1)), dim3(THREADS), 0, st, P);
+    else hipLaunchKernelGGL((umap_pool_grad_kernel<NC, THREADS, RPT, RUNS, RUNLEN, false>), dim3((unsigned)(gb1 - P.gb0 + 1)), dim3(THREADS), 0, st, P);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TDR_OK : (int)e;
 }
 
+// geometries: threads per block, rows per thread, pool runs, rows per run -- TDR_POOL_GEOMS lists them for the debug kernel too
+#define TDR_POOL_GEOMS(X) X(1, 512, 1, 256, 16) X(2, 512, 2, 256, 16) X(3, 512, 2, 128, 16) X(4, 256, 2, 256, 8) X(5, 512, 2, 512, 8) X(6, 1024, 1, 256, 16)
 template <int NC>
 static int launch_pool_geom(const PoolGradParams& P, int geom, hipStream_t st) {
     switch (geom) {
-        case 1: return launch_pool<NC, 256, 256>(P, st);
-        case 2: return launch_pool<NC, 512, 256>(P, st);
-        case 3: return launch_pool<NC, 512, 512>(P, st);
-        case 4: return launch_pool<NC, 1024, 256>(P, st);
-        case 5: return launch_pool<NC, 1024, 512>(P, st);
-        default: return launch_pool<NC, TDR_POOL_ROWS, TDR_POOL_RUNS>(P, st);
+#define TDR_POOL_CASE(G, T, R, Q, L) case G: return launch_pool<NC, T, R, Q, L>(P, st);
+        TDR_POOL_GEOMS(TDR_POOL_CASE)
+#undef TDR_POOL_CASE
+        default: return launch_pool<NC, TDR_POOL_THREADS, TDR_POOL_RPT, TDR_POOL_RUNS, TDR_POOL_RUNLEN>(P, st);
     }
 }
 
@@ -278,29 +397,44 @@ int tdr_umap_pool_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0
                            int t_local, float a, float b, int n_iter, int neg_rate, int n_negatives, uint64_t seed, float exag,
                            float rep, float eps, float* grad, int geom, void* stream) {
     if (!Z || !list || !hdr || !grad || n_rows <= 0 || row0 < 0 || n_total < 2 || n_total >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
-    if (t_local < 0 || t_local >= 32 || neg_rate < 0 || n_negatives < 0 || geom < 0 || geom > 5) return TDR_ERR_BAD_ARG;
-    if (((uintptr_t)Z & 15u) != 0) return TDR_ERR_BAD_ARG;
+    if (t_local < 0 || t_local >= 32 || neg_rate < 0 || n_negatives < 0 || geom < 0 || geom > TDR_POOL_NGEOM) return TDR_ERR_BAD_ARG;
+    if (((uintptr_t)Z & 15u) != 0 || n_total * nc * 4 >= 0xffffffffLL) return TDR_ERR_BAD_ARG;   // Z behind one buffer descriptor
     if (!tdr_umap_pool_supported(nc)) return TDR_ERR_UNSUPPORTED;
     PoolGradParams P = {};
     P.Z = Z; P.nc = nc; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.list = list; P.hdr = (const uint2*)hdr;
     P.t_local = t_local; P.a = a; P.b = b; P.neg_rate = neg_rate; P.n_negatives = n_negatives; P.seed = seed; P.iter = (uint32_t)n_iter;
-    P.iter_base = nullptr; P.exag = exag; P.rep = rep; P.eps = eps; P.grad = grad; P.n_runs = (uint32_t)((n_total + 15) / 16);
+    P.iter_base = nullptr; P.exag = exag; P.rep = rep; P.eps = eps; P.grad = grad;
+    P.exact5 = (neg_rate == 5 && n_negatives % 5 == 0) ? 1 : 0;
+    return launch_pool_grad(P, geom, (hipStream_t)stream);
+}
+
+/* measurement hook: one launch of the DBG instance with the switches `ablate` (1 no pool staging, 2 no attraction, 4 no negatives,
+ * 8 rows not sorted, 16 no gathers, 32 no list reads); times (optional): 8 uint64 shader-clock stamps per wavefront (block-major) -- start, before / after the first barrier, after the sort, after each row pass. */
+int tdr_umap_pool_grad_debug_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list, const void* hdr,
+                                 int t_local, float a, float b, int n_iter, int neg_rate, int n_negatives, uint64_t seed, float* grad,
+                                 int geom, int ablate, void* times, void* stream) {
+    if (!Z || !list || !hdr || !grad || n_rows <= 0 || row0 < 0 || n_total < 2 || n_total >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
+    if (t_local < 0 || t_local >= 32 || geom < 0 || geom > TDR_POOL_NGEOM || ((uintptr_t)Z & 15u) != 0) return TDR_ERR_BAD_ARG;
+    if (!tdr_umap_pool_supported(nc)) return TDR_ERR_UNSUPPORTED;
+    PoolGradParams P = {};
+    P.Z = Z; P.nc = nc; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.list = list; P.hdr = (const uint2*)hdr;
+    P.t_local = t_local; P.a = a; P.b = b; P.neg_rate = neg_rate; P.n_negatives = n_negatives; P.seed = seed; P.iter = (uint32_t)n_iter;
+    P.exag = 1.f; P.rep = 1.f; P.eps = 1e-3f; P.grad = grad; P.ablate = ablate | 0x40000000; P.dbg_times = (unsigned long long*)times;
+    P.exact5 = (neg_rate == 5 && n_negatives % 5 == 0) ? 1 : 0;
     return launch_pool_grad(P, geom, (hipStream_t)stream);
 }
 
 int tdr_umap_pool_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nuse, int geom,
                                   int width, int64_t* out, void* stream) {
-    if (!nuse || !out || n_rows <= 0 || width <= 0 || n_total < 2 || geom < 0 || geom > 5) return TDR_ERR_BAD_ARG;
+    if (!nuse || !out || n_rows <= 0 || width <= 0 || n_total < 2 || geom < 0 || geom > TDR_POOL_NGEOM) return TDR_ERR_BAD_ARG;
     const dim3 grid((unsigned)((n_rows + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
-#define TDR_POOL_DBG(R, Q) hipLaunchKernelGGL((umap_pool_debug_kernel<R, Q>), grid, dim3(256), 0, st, seed, (uint32_t)n_iter, n_total, row0, n_rows, nuse, width, out)
+#define TDR_POOL_DBG(R, Q, L) hipLaunchKernelGGL((umap_pool_debug_kernel<R, Q, L>), grid, dim3(256), 0, st, seed, (uint32_t)n_iter, n_total, row0, n_rows, nuse, width, out)
     switch (geom) {
-        case 1: TDR_POOL_DBG(256, 256); break;
-        case 2: TDR_POOL_DBG(512, 256); break;
-        case 3: TDR_POOL_DBG(512, 512); break;
-        case 4: TDR_POOL_DBG(1024, 256); break;
-        case 5: TDR_POOL_DBG(1024, 512); break;
-        default: TDR_POOL_DBG(TDR_POOL_ROWS, TDR_POOL_RUNS); break;
+#define TDR_POOL_CASE(G, T, R, Q, L) case G: TDR_POOL_DBG(T * R, Q, L); break;
+        TDR_POOL_GEOMS(TDR_POOL_CASE)
+#undef TDR_POOL_CASE
+        default: TDR_POOL_DBG(TDR_POOL_THREADS * TDR_POOL_RPT, TDR_POOL_RUNS, TDR_POOL_RUNLEN); break;
     }
 #undef TDR_POOL_DBG
     TDR_CHECK_LAUNCH();

@@ -1335,7 +1335,7 @@ static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st, int host
     PoolGradParams Pp = {};
     Pp.Z = L->Z; Pp.nc = L->nc; Pp.n_total = L->n_total; Pp.row0 = L->row0; Pp.n_rows = L->n_rows; Pp.list = L->list; Pp.hdr = L->hdr;
     Pp.a = L->a; Pp.b = L->b; Pp.neg_rate = L->neg_rate; Pp.n_negatives = L->n_negatives; Pp.seed = L->seed; Pp.iter_base = G.iter_base;
-    Pp.exag = L->exag; Pp.rep = L->rep; Pp.eps = L->eps; Pp.grad = L->grad; Pp.n_runs = (uint32_t)((L->n_total + 15) / 16);
+    Pp.exag = L->exag; Pp.rep = L->rep; Pp.eps = L->eps; Pp.grad = L->grad; Pp.exact5 = (L->neg_rate == 5 && L->n_negatives % 5 == 0) ? 1 : 0;
     for (int t = 0; t < n; ++t) {
         G.t_local = t; G.iter = (uint32_t)(t + (host_base >= 0 ? host_base : 0));
         G.nc = L->nc;
@@ -1580,7 +1580,7 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
     L->iter_base = (int*)d->scratch; L->gather = (tdr_collective_fn)d->gather; L->gather_ctx = d->gather_ctx; L->geom = d->geom;
     L->rs = d->rs;
     L->pool = d->pool;
-    if (L->pool < 0 || L->pool > 6 || (L->pool && (L->S != 1 || !tdr_umap_pool_supported(L->nc) || ((uintptr_t)L->Z & 15u)))) { delete L; return TDR_ERR_BAD_ARG; }
+    if (L->pool < 0 || L->pool > TDR_POOL_NGEOM + 1 || (L->pool && (L->S != 1 || !tdr_umap_pool_supported(L->nc) || ((uintptr_t)L->Z & 15u) || L->n_total * L->nc * 4 >= 0xffffffffLL))) { delete L; return TDR_ERR_BAD_ARG; }
     L->graphs[0] = L->graphs[1] = nullptr; L->graph_len[0] = L->graph_len[1] = 0;
     const size_t lds = (size_t)L->B * L->S * CNT_STRIDE * sizeof(uint32_t);
     if (lds > 32 * 1024) {  // raised here, outside graph capture, for every instance the launcher may pick

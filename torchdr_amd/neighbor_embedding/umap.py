@@ -181,7 +181,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             L = _lib.lib()
             p = bool(_opt("NEGATIVES") == "pool" and _opt("SCHEDULED") and not _opt("SCHED_SLICES") and not self.discard_NNs
                      and self.neg_indices_ is None and L.tdr_umap_pool_supported(int(self.n_components))
-                     and self.n_samples_in_ < 2**31 - 1)
+                     and self.n_samples_in_ * int(self.n_components) * 4 < 2**32 - 1)
             self._pool = p
         return p
 
