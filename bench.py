@@ -368,7 +368,18 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=600.0,
                     help="ceiling (seconds of CPU work) on the kNN sample of cpu_baseline; SURVEY 8d's 16 chunks need ~215 s and its 20 loop "
                          "iterations ~65 s on the 128-core box, so the default lets both complete")
+    ap.add_argument("--emulate-rank", type=int, default=None,
+                    help="with --world W: run what rank r of a W-rank fit runs, ALONE on this GPU (torchdr_amd/utils/emulation.py; the edge "
+                         "exchange served from the other ranks' graphs, the row exchange as a loopback copy) and print its phase split")
+    ap.add_argument("--world", type=int, default=8)
     args = ap.parse_args()
+
+    if args.emulate_rank is not None:
+        from tools.rank_share import measure
+
+        recs = measure(args.n, args.d, args.k, args.max_iter, [args.world], [str(args.emulate_rank)], scale=args.scale, emit=lambda *a, **k: None)
+        print(json.dumps({"emulated_rank_share": recs[-1], "single_process": recs[0]}), flush=True)
+        return
 
     if args.gpus > 1 and "RANK" not in os.environ and "LOCAL_RANK" not in os.environ:
         self_launch(args.gpus)
@@ -586,27 +597,52 @@ def main():
                  "fp32-MFMA kernel)" + ("; cluster-bound pruning skips most tiles, so `achieved` is algorithmic flops / time, "
                                         "not matrix-pipe utilisation" if path.endswith("pruned") else "")),
     }
+    pool = bool(getattr(umod, "NEGATIVES", "iid") == "pool") and umod.SCHEDULED
+    pmc_file = "r06_umap_pool_pmc.json" if pool else ("r04_umap_sched_pmc.json" if umod.SCHEDULED else "r01_umap_grad_pmc.json")
     roof_grad = {
-        "kernel": ("one whole UMAP iteration: tdr::umap_sched_grad_kernel<2,4,false> (ONE launch over both L2 slices of the embedding, "
+        "kernel": ("one whole UMAP iteration: tdr::umap_pool_grad_kernel<2,512,2,256,8> (fired edges from the per-iteration lists, negatives from a "
+                   "per-block LDS pool of 256 uniformly chosen 8-row runs of the embedding) + tdr::sgd_step_kernel -- HIP events around every "
+                   "25th iteration's two launches -- + 1/32 of tdr::umap_sched_build2_kernel (group-ordered schedule build; every build timed)"
+                   if pool else
+                   "one whole UMAP iteration: tdr::umap_sched_grad_kernel<2,4,false> (ONE launch over both L2 slices of the embedding, "
                    "slices spread over the XCDs) + tdr::umap_sched_combine_sgd_kernel (clamps + SGD step) -- HIP events around "
                    "every 25th iteration's two launches -- + 1/32 of tdr::umap_sched_build2_kernel (group-ordered schedule build; "
                    "every build timed)" if umod.SCHEDULED else
                    "tdr::umap_grad_kernel<2,16,4,true> + 2 x tdr::umap_neg_dense_kernel<2,8,2> (one gradient evaluation)"),
         "bound": "hbm", "achieved": grad_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": grad_gbs / HBM_PEAK_GBS,
-        "traffic": pmc_traffic("r04_umap_sched_pmc.json" if umod.SCHEDULED else "r01_umap_grad_pmc.json"),
-        "traffic_source": "profiles/r04_umap_sched_pmc.json: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the same "
-                          "three kernels at this shape, per iteration; not re-measured inside this run",
+        "traffic": pmc_traffic(pmc_file),
+        "traffic_source": "profiles/" + pmc_file + ": separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over this bench command on this round's "
+                          "build (tools/pmc_bench.sh), per iteration; not re-measured inside this run",
         "algorithmic_bytes_per_launch": grad_bytes, "avg_launch_ms": grad_avg_ms, "evaluations_sampled": n_sampled,
         "grad_passes_ms": grad_only_ms, "schedule_build_ms_per_iteration": build_avg_ms,
-        "note": ("algorithmic bytes = SURVEY 8d's per-step edge stream (12 B x nnz + gathers); the scheduled loop reads "
+        "note": ("algorithmic bytes = SURVEY 8d K5: the per-step edge stream 12 B x nnz + per row 8.6 x 12 + 43 x 8 + 16 B.  The loop reads "
+                 "per-iteration firing lists instead of the edge stream and, since round 6, serves the 43 negatives per row from LDS (one "
+                 "128-byte line per 16 staged rows instead of one L2 request per negative): it moves a fraction of those bytes (`traffic`), so "
+                 "`frac` can exceed 1 -- it is SURVEY 8d's figure, not an HBM pin; what binds the launch is `binding_resource`"
+                 if pool else
+                 "algorithmic bytes = SURVEY 8d's per-step edge stream (12 B x nnz + gathers); the scheduled loop reads "
                  "per-iteration firing lists instead (~8.6 x 4 B per row), so what bounds the passes is the L2 gather "
                  "request rate of the ~52 random 8-byte reads of Z per row and iteration; see DESIGN.md section 6"),
     }
+    if pool and world == 1 and (args.n, args.d, args.k) == (1_000_000, 128, 30):
+        try:
+            gp = json.load(open(os.path.join(ROOT, "profiles", "r06_pool_pmc.json")))
+            # vector ALU busy share of the gradient launch: SQ_ACTIVE_INST_VALU counts 4-cycle quads per SIMD, summed over the chip
+            busy = 4.0 * float(gp["SQ_ACTIVE_INST_VALU"]) / (1024.0 * float(gp["GRBM_GUI_ACTIVE"]) / 8.0)
+            roof_grad["binding_resource"] = {
+                "name": "vector instruction issue of the gradient launch (one lane per row; 5 negatives per fired edge, each ~16 vector "
+                        "instructions of which 3 run at quarter rate)",
+                "valu_busy_frac": busy, "vector_instructions_per_wavefront": float(gp["SQ_INSTS_VALU"]) / float(gp["SQ_WAVES"]),
+                "l2_read_requests_per_launch": float(gp.get("TCP_TCC_READ_REQ_sum", 0.0)),
+                "source": "profiles/r06_pool_pmc.json (tools/pmc_pool.sh: separate --pmc passes over the launch at this shape on this round's build)",
+            }
+        except Exception:
+            pass
     # what actually bounds the gradient launch: the scheduled loop gathers ~52 random 8-byte rows of Z per
     # row and iteration out of the XCD's L2; the request count per launch comes from the committed TCP_TCC_READ_REQ pass
     # (same kernel, same shape), the time from this run's HIP events, the ceiling from tools/gather_bench.hip (random 8-byte
     # gathers from an L2-resident 4 MB table, every CU busy: 266-273 G requests/s on this chip, profiles/r04_grad_pmc.json)
-    if umod.SCHEDULED and world == 1 and (args.n, args.d, args.k) == (1_000_000, 128, 30):
+    if umod.SCHEDULED and not pool and world == 1 and (args.n, args.d, args.k) == (1_000_000, 128, 30):
         try:
             gp = json.load(open(os.path.join(ROOT, "profiles", "r04_grad_pmc.json")))
             req = float(gp["counters"]["TCP_TCC_READ_REQ_sum"])
@@ -625,7 +661,47 @@ def main():
     dominant, secondary = (roof_grad, roof_knn) if loop_ms >= scan_avg_ms else (roof_knn, roof_grad)
 
     if rank == 0:
-        out = {
+        # The driver keeps the LAST ~2000 characters of the line: everything that is context goes first (and, in full, into the side
+        # file named by `detail_file`), the contract keys, both halves of the metric, `roofline` and `cpu_baseline` come last.
+        detail = {
+            "phases_ms": phase_ms,
+            "hbm_peak_gb": [round(v, 2) for v in hbm_peak.tolist()],
+            "knn_scan_sec": scan_avg_ms * 1e-3,
+            "knn_path": path,
+            "roofline_detail": dominant,
+            "roofline_secondary": secondary,
+        }
+        if world > 1:
+            detail["backend"] = dist.get_backend()
+            detail["devices_shared"] = bool(devices_shared)
+            detail["rccl_context"] = bool(keep.get("rccl_context"))
+            detail["row_exchange"] = keep.get("exchange")      # PeerExchange (direct peer writes), RcclContext (ring all-gather) or torch.distributed
+            detail["loop_in_cluster_order"] = bool(keep.get("loop_order"))
+            detail["allgather_us"] = allgather_us
+            detail["allgather_ms_per_fit"] = None if allgather_us is None else allgather_us * args.max_iter * 1e-3
+        if not args.no_knn_variants and world == 1:
+            detail["knn_context"] = knn_variants(X, args, dbase)
+            detail["knn_uniform"] = knn_uniform(args, dev, dbase)
+        if not args.no_configs and world == 1:
+            del X
+            torch.cuda.empty_cache()
+            detail["configs"] = {"c3": config_c3(dev), "c5": config_c5(dev),
+                                 "note": "BASELINE.json configs[2] and configs[4], run once each after the timed region; per-kernel roofline "
+                                         "by HIP events around the C-ABI entry point on the launch stream"}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(X_cpu, args.k, args.max_iter, keep, budget_s=args.cpu_budget)
+            detail["cpu_baseline_detail"] = dict(cpu)
+        detail_file = None
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            detail_file = os.path.join("gpurun_out", "bench_detail.json")
+            json.dump(detail, open(os.path.join(ROOT, detail_file), "w"), indent=1)
+        except OSError:
+            detail_file = None
+        out = dict(detail)
+        out["detail_file"] = detail_file
+        out.update({
             "metric": "samples/sec (fit_transform) + kNN-graph build sec, UMAP N=1M D=128 k=30",
             "value": args.n * args.steps / elapsed,
             "unit": "samples/sec",
@@ -645,33 +721,19 @@ def main():
                 "parallelism": f"rows sharded over {world} GPU(s)" + ("" if world == 1 else
                                (", row-sharded input" if sharded else ", replicated input")),
             },
-            "phases_ms": phase_ms,
-            "hbm_peak_gb": [round(v, 2) for v in hbm_peak.tolist()],
             "knn_build_sec": knn_build_ms * 1e-3,
-            "knn_scan_sec": scan_avg_ms * 1e-3,
-            "knn_path": path,
-            "roofline": dominant,
-            "roofline_secondary": secondary,
-        }
-        if world > 1:
-            out["backend"] = dist.get_backend()
-            out["devices_shared"] = bool(devices_shared)
-            out["rccl_context"] = bool(keep.get("rccl_context"))
-            out["row_exchange"] = keep.get("exchange")      # PeerExchange (direct peer writes), RcclContext (ring all-gather) or torch.distributed
-            out["loop_in_cluster_order"] = bool(keep.get("loop_order"))
-            out["allgather_us"] = allgather_us
-            out["allgather_ms_per_fit"] = None if allgather_us is None else allgather_us * args.max_iter * 1e-3
-        if not args.no_knn_variants and world == 1:
-            out["knn_context"] = knn_variants(X, args, dbase)
-            out["knn_uniform"] = knn_uniform(args, dev, dbase)
-        if not args.no_configs and world == 1:
-            del X
-            torch.cuda.empty_cache()
-            out["configs"] = {"c3": config_c3(dev), "c5": config_c5(dev),
-                              "note": "BASELINE.json configs[2] and configs[4], run once each after the timed region; per-kernel roofline "
-                                      "by HIP events around the C-ABI entry point on the launch stream"}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(X_cpu, args.k, args.max_iter, keep, budget_s=args.cpu_budget)
+            "loop_ms_per_iteration": grad_avg_ms,
+            # the contract's compact objects (the long forms are `roofline_detail` / `cpu_baseline_detail` above)
+            "roofline": {k_: dominant.get(k_) for k_ in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms")}
+                        | {"kernel": dominant["kernel"].split(" (")[0][:90],
+                           "binding": ({"what": "vector issue", "valu_busy_frac": round(dominant["binding_resource"].get("valu_busy_frac", 0.0), 3)}
+                                       if "valu_busy_frac" in dominant.get("binding_resource", {}) else
+                                       ({"what": "L2 gather requests", "frac": round(dominant["binding_resource"]["frac"], 3)}
+                                        if "binding_resource" in dominant else None))},
+        })
+        if cpu is not None:
+            out["cpu_baseline"] = {"value": cpu["value"], "unit": cpu["unit"], "cores": cpu["cores"], "kind": cpu["kind"],
+                                   "sample": cpu["sample"][:420], "knn_build_sec_est": cpu["knn_build_sec_est"]}
         print(json.dumps(out), flush=True)
     if distributed:
         from torchdr_amd.parallel import RcclContext

@@ -419,6 +419,12 @@ int tdr_peerx_fine_grained(void* ctx);
 int tdr_peerx_allgather_rows(void* ctx, float* Z, int nc, void* stream);
 int tdr_peerx_error(void* ctx);
 int tdr_peerx_destroy(void* ctx);
+/* Round 6, measurement only (tools/rank_share.py, bench.py --emulate-rank): loopback stand-in of the exchange for ONE rank of a
+ * `world`-rank fit run alone on one GPU -- the bytes it would send (its chunk, world - 1 times) and receive (every other row, as
+ * they stood at the first call) are moved inside the device; tdr_emulx_allgather_rows has tdr_umap_loop_desc.gather's signature. */
+int tdr_emulx_create(void** out, int rank, int world, int64_t n_total, int nc);
+int tdr_emulx_allgather_rows(void* ctx, float* Z, int nc, void* stream);
+int tdr_emulx_destroy(void* ctx);
 /* The optimisation loop of affinity_matcher.py:288-352 for UMAP's closed-form step + torch.optim.SGD behind one handle
  * (csrc/tdr_umap_sched.hip): windows of <= block_iters iterations (schedule build + per iteration n_slices gradient
  * passes + the SGD step [+ a row all-gather]) are captured into HIP graphs and replayed; the iteration base lives in

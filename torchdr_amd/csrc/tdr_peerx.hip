@@ -116,6 +116,35 @@ inline void chunk_of(int64_t n, int world, int r, int64_t* start, int64_t* rows)
 
 }  // namespace
 
+// ---- loopback stand-in of one exchange (measurement of a rank's share on ONE GPU, tools/rank_share.py) -----------------------
+// Rank r of a W-rank fit is run alone; what the exchange would move is moved locally: push = the rank's chunk written W - 1
+// times (what it sends over its W - 1 links), pull = the N - chunk staged rows of the peers copied into the embedding (they
+// hold the peers' rows as they stood at the start of the fit: the peers do not exist).  Same two launches, same bytes, no link.
+struct EmulX {
+    int rank, world;
+    int64_t n_total, capacity;     // rows of the embedding; floats of the stage
+    float* stage;                  // the peers' rows (n_total x nc), filled from the embedding at the first exchange
+    float* scratch;                // (W - 1) copies of the rank's chunk
+    bool primed;
+};
+__global__ __launch_bounds__(256) void emulx_push_kernel(const float* __restrict__ src, int64_t count, float* __restrict__ dst, int copies) {
+    const int64_t n4 = count >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(src)[i];
+        for (int c = 0; c < copies; ++c) reinterpret_cast<float4*>(dst + (size_t)c * count)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3))
+        for (int c = 0; c < copies; ++c) dst[(size_t)c * count + (n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
+}
+__global__ __launch_bounds__(256) void emulx_pull_kernel(const float* __restrict__ stage, float* __restrict__ Z, int64_t lo, int64_t hi, int64_t total) {
+    // floats [0, lo) and [hi, total) of the stage into Z (the rank's own floats [lo, hi) stay)
+    const int64_t n = total - (hi - lo);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t j = i < lo ? i : i + (hi - lo);
+        Z[j] = stage[j];
+    }
+}
+
 extern "C" {
 
 /* Context of the peer exchange for `world` <= 16 ranks on one node (this process = `rank`, its GPU = the current HIP device):
@@ -253,6 +282,44 @@ int tdr_peerx_destroy(void* ctx) {
     }
     (void)hipFree(c->own_stage);
     (void)hipFree(c->own_flags);
+    delete c;
+    return TDR_OK;
+}
+
+
+/* Loopback stand-in of tdr_peerx_allgather_rows for a rank that runs ALONE (measurement only; same callback signature): the
+ * bytes a rank of `world` would send (its chunk, world - 1 times) and receive (all other rows) are moved inside this GPU. */
+int tdr_emulx_create(void** out, int rank, int world, int64_t n_total, int nc) {
+    if (!out || world < 2 || world > PX_MAX_WORLD || rank < 0 || rank >= world || n_total <= 0 || nc <= 0) return TDR_ERR_BAD_ARG;
+    EmulX* c = new EmulX();
+    c->rank = rank; c->world = world; c->n_total = n_total; c->capacity = n_total * nc; c->primed = false;
+    const int64_t chunk = (n_total + world - 1) / world * nc;
+    if (hipMalloc((void**)&c->stage, (size_t)c->capacity * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&c->scratch, (size_t)chunk * (world - 1) * sizeof(float)) != hipSuccess) { delete c; return TDR_ERR_WORKSPACE; }
+    *out = c;
+    return TDR_OK;
+}
+int tdr_emulx_allgather_rows(void* ctx, float* Z, int nc, void* stream) {
+    EmulX* c = (EmulX*)ctx;
+    if (!c || !Z || nc <= 0 || c->n_total * nc > c->capacity) return TDR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t base = c->n_total / c->world, rem = c->n_total % c->world;
+    const int64_t r0 = c->rank < rem ? c->rank * (base + 1) : c->rank * base + rem;
+    const int64_t rows = base + (c->rank < rem ? 1 : 0);
+    const int64_t total = c->n_total * nc, lo = r0 * nc, hi = (r0 + rows) * nc;
+    if (!c->primed) {
+        if (hipMemcpyAsync(c->stage, Z, (size_t)total * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return TDR_ERR_WORKSPACE;
+        c->primed = true;
+    }
+    hipLaunchKernelGGL(emulx_push_kernel, dim3(256), dim3(256), 0, st, (const float*)(Z + lo), hi - lo, c->scratch, c->world - 1);
+    hipLaunchKernelGGL(emulx_pull_kernel, dim3(1024), dim3(256), 0, st, (const float*)c->stage, Z, lo, hi, total);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+int tdr_emulx_destroy(void* ctx) {
+    EmulX* c = (EmulX*)ctx;
+    if (!c) return TDR_ERR_BAD_ARG;
+    (void)hipFree(c->stage); (void)hipFree(c->scratch);
     delete c;
     return TDR_OK;
 }

@@ -278,6 +278,10 @@ class NeighborEmbedding(AffinityMatcher):
             from torchdr_amd.parallel import RcclContext
 
             self._rccl_ctx = RcclContext.shared(self.n_samples_in_, self.device_)   # one communicator per process
+        from torchdr_amd import parallel as _par
+
+        if _par.EMULATION is not None and uses_rows and self.world_size > 1:    # one rank of W run alone: loopback exchange
+            self._rccl_ctx = _par.EMULATION.exchange(self.n_samples_in_, self.n_components, self.device_)
         # how a row-sharded fit exchanged its rows (kept after clear_memory): "PeerExchange", "RcclContext" or "torch.distributed"
         self.row_exchange_ = (type(self._rccl_ctx).__name__ if self._rccl_ctx is not None else "torch.distributed") if self.world_size > 1 else None
 

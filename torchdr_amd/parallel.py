@@ -16,6 +16,13 @@ import torch.distributed as dist
 from torchdr_amd.distributed import DistributedContext, chunk_bounds
 
 
+# Measurement of ONE rank's share of a W-rank fit on one GPU (utils/emulation.py, tools/rank_share.py, bench.py --emulate-rank): the
+# process group is torch's "fake" backend (rank r of W, collectives that move nothing) and the two exchanges that CARRY data are
+# served by this object -- the transposed edges of the symmetrisation from the other ranks' graphs (computed beforehand), the
+# per-iteration row exchange as a local copy of the same bytes.  None in every real run.
+EMULATION = None
+
+
 def _host_staged() -> bool:
     """gloo has no device collectives for every op used here; stage through host memory then
     (CPU-side tests and single-GPU multi-process debugging).  RCCL ("nccl") works on device buffers."""
@@ -87,6 +94,8 @@ def allgather_rows_(full: torch.Tensor, chunk_start: int, chunk_size: int, world
     updated rows; on return every rank's rows are in ``full``.  With equal chunks the rank's send buffer IS its slot of
     the receive buffer (the in-place all-gather RCCL supports: no staging copy, no scratch allocation per iteration);
     uneven chunks or host-staged backends fall back to :func:`allgather_rows`."""
+    if EMULATION is not None:
+        return EMULATION.allgather_rows_(full)
     n = full.shape[0]
     if n == chunk_size * world_size and full.is_contiguous() and not (_host_staged() and full.is_cuda):
         dist.all_gather_into_tensor(full, full[chunk_start: chunk_start + chunk_size])
@@ -122,6 +131,8 @@ def route_edges(values: torch.Tensor, indices: torch.Tensor, chunk_start: int, n
 def exchange_transposed_edges(values, indices, chunk_start, n_total, world_size) -> Tuple[torch.Tensor, ...]:
     """All-to-all-v of the edges whose transpose lives on another rank (reference sparse.py:259-309).
     Returns (ext_row int32 local, ext_col int32 global, ext_val in the dtype of ``values``) for ``symmetrize_to_csr``."""
+    if EMULATION is not None:
+        return EMULATION.transposed_edges(values, indices, chunk_start, n_total, world_size)
     rank = dist.get_rank()
     dev = values.device
     routed = route_edges(values, indices, chunk_start, n_total, world_size, rank)
