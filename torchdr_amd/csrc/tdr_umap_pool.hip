@@ -108,6 +108,28 @@ __device__ __forceinline__ Vec<NC> pool_read(const float* pool, uint32_t s) {
     return r;
 }
 
+// parts of a row that fires `act` edges, and the end of part j's share of `n` units (entries or groups of negatives)
+constexpr uint32_t POOL_CH = 16, POOL_MMAX = 8;
+__device__ __forceinline__ uint32_t pool_parts(uint32_t act) {
+    if (act <= POOL_CH) return 1u;
+    const uint32_t m = (act + POOL_CH - 1u) / POOL_CH;
+    return m < POOL_MMAX ? m : POOL_MMAX;
+}
+__device__ __forceinline__ uint32_t pool_part_end(uint32_t n, uint32_t j, uint32_t m) { return n * j / m; }
+
+template <int NC>
+__device__ __forceinline__ void pool_store_grad(const PoolGradParams& P, int64_t r, const float (&ga)[NC], const float (&gr)[NC]) {
+    float g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) g[c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
+    if (NC == 2) {
+        *reinterpret_cast<float2*>(P.grad + (size_t)r * 2) = make_float2(g[0], g[1]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) P.grad[(size_t)r * NC + c] = g[c];
+    }
+}
+
 // THREADS lanes evaluate the ROWS = RPT x THREADS rows of a global row block against a pool of RUNS runs of RUNLEN rows.
 // RPT = 2 ("folded"): position p of the sorted order and position ROWS - 1 - p go to the same lane, one after the other -- a
 // wavefront then carries a busy and a quiet batch and all wavefronts of the block end together (sorted but unfolded, the first
@@ -118,7 +140,7 @@ __device__ __forceinline__ Vec<NC> pool_read(const float* pool, uint32_t s) {
 // fired edges end in the row's own block, all within 1024 rows -- was built in three forms and measured slower every time:
 // profiles/r06_pool_window.json.)
 template <int NC, int THREADS, int RPT, int RUNS, int RUNLEN, bool DBG>
-__global__ __launch_bounds__(THREADS, NC == 2 ? 8 : 4) void umap_pool_grad_kernel(const PoolGradParams P) {   // 2 components: <= 64 registers, four 512-thread blocks per CU
+__global__ __launch_bounds__(THREADS, NC == 2 ? 6 : 4) void umap_pool_grad_kernel(const PoolGradParams P) {   // 2 components: <= 80 registers (capping at 64 spills ten and measured slower)
     const int ablate = DBG ? P.ablate : 0;
     auto stamp = [&](int i) {
         if (DBG && P.dbg_times && (threadIdx.x & 63) == 0)
@@ -136,10 +158,26 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 8 : 4) void umap_pool_grad_kerne
     static_assert(PIECES % THREADS == 0, "pool pieces must divide over the threads");
     constexpr int NIT = PIECES / THREADS;
     constexpr int U = 4;
+    // PARTS: a row that fires more than POOL_CH edges is cut into m = ceil(act / POOL_CH) <= POOL_MMAX parts (even shares of its
+    // listed edges and of its groups of negatives) that different lanes evaluate; the parts' sums meet in LDS and are added in part
+    // order.  Without it the lane that holds a hub row (a few rows per block fire 40-150 edges where the mean is 8.6) runs 5-15x as
+    // long as its neighbours and its wavefront decides when the block ends (profiles/r06_pool_phases.json: the first wavefront of the
+    // sorted order took 2x the others').  m is a function of the row alone and the parts are added in order whoever evaluates them
+    // (a row whose parts do not fit the block's XCAP slots is evaluated by ONE lane part by part): the bits of a row do not depend on
+    // the block, the launch or the sharding.
+    constexpr int XCAP = 384;                   // part slots of split rows per block
+    constexpr int ITEMS = ROWS + XCAP;          // base items (one per row: part 0, or the whole row) + extra items (parts >= 1)
+    constexpr int NPASS = (ITEMS + THREADS - 1) / THREADS;
     __shared__ __attribute__((aligned(16))) float pool[POOL_ROWS * NC];
     __shared__ uint32_t hist[64];
-    __shared__ uint16_t order[ROWS];
+    __shared__ uint32_t xcount;                 // part slots handed out
+    __shared__ uint32_t scount;                 // split rows
+    __shared__ uint16_t order[ITEMS];
     __shared__ uint2 rec[ROWS];
+    __shared__ uint32_t rowx[ROWS];             // parts m (low 8 bits) | first part slot + 1 << 8 (0: not split)
+    __shared__ uint32_t xitem[XCAP];            // extra item e: row | part << 16
+    __shared__ uint32_t srow[XCAP / 2];         // split rows
+    __shared__ float psum[XCAP * 2 * NC];       // (attraction, repulsion) sums of the parts of split rows
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t iter = P.iter + (P.iter_base ? (uint32_t)*P.iter_base : 0u);
@@ -162,10 +200,10 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 8 : 4) void umap_pool_grad_kerne
         const float* src = (last && off + 4 > z_floats) ? P.Z : P.Z + off;
         __builtin_amdgcn_global_load_lds((pgptr_t)src, (plptr_t)(pool + (it * NW + wave) * 256), 16, 0, 0);
     }
-    // 2. the records of this thread's RPT rows of the block (rows t, t + THREADS, ...) and their sort keys
+    // 2. the records of this thread's RPT rows of the block (rows t, t + THREADS, ...), their parts and the sort keys of their items
     if (t < 64) hist[t] = 0;
+    if (t == 0) { xcount = 0; scount = 0; }
     uint2 h[RPT];
-    uint32_t key[RPT], rank[RPT];
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
         const int64_t r0 = gb * ROWS + q * THREADS + t - P.row0;
@@ -175,11 +213,9 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 8 : 4) void umap_pool_grad_kerne
             const u32x2_t hv = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(P.hdr + (size_t)P.t_local * P.n_rows + r0));
             h[q] = make_uint2(hv.x, hv.y);
         }
-        const uint32_t act0 = (ablate & 8) ? 0u : h[q].y >> 16;
-        key[q] = 63u - (act0 < 63u ? act0 : 63u);     // busiest rows first
     }
     stamp(1);
-    __syncthreads();   // pool staged (the barrier waits for the wavefront's DMA), histogram zeroed
+    __syncthreads();   // pool staged (the barrier waits for the wavefront's DMA), counters zeroed
     stamp(2);
     if (fix) {
         // padding rows of the last run (N % RUNLEN != 0): the pieces of that run are rewritten float by float, rows >= N as sentinels
@@ -193,137 +229,230 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 8 : 4) void umap_pool_grad_kerne
             for (int e = 0; e < 4; ++e) pool[p * 4 + e] = off + e < z_floats ? P.Z[off + e] : POOL_SENTINEL;
         }
     }
+    uint32_t key[RPT], rank[RPT];
 #pragma unroll
-    for (int q = 0; q < RPT; ++q) rank[q] = atomicAdd(&hist[key[q]], 1u);
+    for (int q = 0; q < RPT; ++q) {
+        const int row = q * THREADS + t;
+        const uint32_t act = (ablate & 8) ? 0u : h[q].y >> 16;      // one slice: the row's listed edges = its fired edges
+        const uint32_t m = pool_parts(act);
+        uint32_t base = 0;                                          // first part slot + 1
+        if (m > 1 && !(ablate & 64)) {
+            const uint32_t b0 = atomicAdd(&xcount, m);
+            if (b0 + m <= (uint32_t)XCAP) {
+                base = b0 + 1u;
+                srow[atomicAdd(&scount, 1u)] = (uint32_t)row;
+                for (uint32_t j = 1; j < m; ++j) xitem[b0 + j] = (uint32_t)row | j << 16;    // slot b0 itself is part 0: the row's base item
+            }
+        }
+        rowx[row] = m | base << 8;
+        rec[row] = h[q];
+        const uint32_t work = base ? pool_part_end(act, 1u, m) : act;   // entries of the base item
+        key[q] = 63u - (work < 63u ? work : 63u);                        // busiest items first
+        rank[q] = atomicAdd(&hist[key[q]], 1u);
+    }
+    __syncthreads();
+    // extra items = the part slots >= 1 of the split rows.  A slot is an item only if a split row owns it as part >= 1 (part-0
+    // slots belong to base items; a refused request advanced the counter without owning anything): the split rows flag theirs
+    const uint32_t n_slots = xcount < (uint32_t)XCAP ? xcount : (uint32_t)XCAP;
+    constexpr int XPT = (XCAP + THREADS - 1) / THREADS;      // slots a thread looks at
+    uint32_t xkey[XPT], xrank[XPT];
+    bool have_x[XPT];
+    __shared__ uint32_t xvalid[(XCAP + 31) / 32];
+    if (t < (XCAP + 31) / 32) xvalid[t] = 0;
+    __syncthreads();
+    for (uint32_t sidx = (uint32_t)t; sidx < scount; sidx += THREADS) {
+        const uint32_t row = srow[sidx];
+        const uint32_t rx = rowx[row], m = rx & 255u, b0 = (rx >> 8) - 1u;
+        for (uint32_t j = 1; j < m; ++j) atomicOr(&xvalid[(b0 + j) >> 5], 1u << ((b0 + j) & 31u));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int xq = 0; xq < XPT; ++xq) {
+        const uint32_t e = (uint32_t)(xq * THREADS + t);
+        have_x[xq] = e < n_slots && (xvalid[e >> 5] >> (e & 31u) & 1u);
+        xkey[xq] = 0; xrank[xq] = 0;
+        if (have_x[xq]) {
+            const uint32_t xi = xitem[e];
+            const uint32_t row = xi & 0xffffu, j = xi >> 16;
+            const uint32_t act = rec[row].y >> 16, m = rowx[row] & 255u;
+            const uint32_t work = pool_part_end(act, j + 1u, m) - pool_part_end(act, j, m);
+            xkey[xq] = 63u - (work < 63u ? work : 63u);
+            xrank[xq] = atomicAdd(&hist[xkey[xq]], 1u);
+        }
+    }
     __syncthreads();
     if (t < 64) {   // exclusive scan of the 64 bins
         const uint32_t v = hist[t];
-        uint32_t s = v;
+        uint32_t s2 = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u = __shfl_up(s, o, 64);
-            if (lane >= o) s += u;
+            const uint32_t u = __shfl_up(s2, o, 64);
+            if (lane >= o) s2 += u;
         }
-        hist[t] = s - v;
+        hist[t] = s2 - v;
+        if (t == 63) xcount = s2;      // total number of items (reuses the counter)
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        order[hist[key[q]] + rank[q]] = (uint16_t)(q * THREADS + t);
-        rec[q * THREADS + t] = h[q];
-    }
+    for (int q = 0; q < RPT; ++q) order[hist[key[q]] + rank[q]] = (uint16_t)(q * THREADS + t);
+#pragma unroll
+    for (int xq = 0; xq < XPT; ++xq)
+        if (have_x[xq]) order[hist[xkey[xq]] + xrank[xq]] = (uint16_t)(ROWS + xq * THREADS + t);
     __syncthreads();
     stamp(3);
+    const int n_items = (int)xcount;
     const float two_ab = 2.0f * P.a * P.b, m2b = -2.0f * P.b;
     const __amdgpu_buffer_rsrc_t zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.Z), 0, (int)(uint32_t)(z_floats * 4), 0x00020000);
-    // 3. the rows this lane evaluates: position t of the sorted order, then (RPT = 2) position ROWS - 1 - t
+    // 3. the items this lane evaluates: positions t, 2 THREADS - 1 - t, 2 THREADS + t, ... of the sorted order (busy and quiet
+    //    batches alternate per wavefront)
 #pragma unroll 1
-    for (int q = 0; q < RPT; ++q) {
-        const int my = order[q == 0 ? t : ROWS - 1 - t];
+    for (int q = 0; q < NPASS; ++q) {
+        const int pos = (q & 1) ? (q + 1) * THREADS - 1 - t : q * THREADS + t;
+        if (pos >= n_items) continue;
+        const int it = order[pos];
+        int my, j0, j1, slot0 = -1;          // row, parts [j0, j1), first part slot of a split row
+        uint32_t m;
+        if (it < ROWS) {
+            my = it;
+            const uint32_t rx = rowx[my];
+            m = rx & 255u;
+            j0 = 0;
+            if (rx >> 8) { j1 = 1; slot0 = (int)(rx >> 8) - 1; } else j1 = (int)m;
+        } else {
+            const uint32_t xi = xitem[it - ROWS];
+            my = (int)(xi & 0xffffu);
+            const uint32_t rx = rowx[my];
+            m = rx & 255u;
+            j0 = (int)(xi >> 16); j1 = j0 + 1; slot0 = (int)(rx >> 8) - 1;
+        }
         const uint2 hh = rec[my];
         const int64_t gi64 = gb * ROWS + my;
         const int64_t r = gi64 - P.row0;
         if (r < 0 || r >= P.n_rows) continue;
         const uint32_t gi = (uint32_t)gi64;
         const Vec<NC> zi = load_z<NC>(P.Z, gi64);
-        const int npos = (ablate & 2) ? 0 : (int)(hh.y & 0xffffu);
-        int n_use = (int)(hh.y >> 16) * P.neg_rate;
+        const uint32_t act = hh.y >> 16;
+        const int npos_row = (ablate & 2) ? 0 : (int)(hh.y & 0xffffu);
+        int n_use = (int)act * P.neg_rate;
         if (n_use > P.n_negatives) n_use = P.n_negatives;
         if (ablate & 4) n_use = 0;
+        const int n_grp = P.exact5 ? n_use / 5 : n_use;          // units the negatives are shared out in
+        const PoolRowKey rk = pool_row_key(P.seed, iter, gi64);
+        const int32_t* lst = P.list + hh.x;
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const bool ab_list = ablate & 32, ab_gather = ablate & 16;      // DBG instances: no list reads / no gathers
         float ga[NC], gr[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) { ga[c] = 0.f; gr[c] = 0.f; }
-        // attraction: the row's fired edges, four list entries per 16-byte read (the list carries 64 entries of slack).
-        // 2ab d^(b-1) / (1 + a d^b) = 2ab d^b / (d (1 + a d^b)), 0 where d <= 0 (umap.py:252-256): d = 0 makes d^b = 0 and the
-        // guarded reciprocal finite, so the coefficient is 0 without a test -- and a slot beyond the row's count reads the row
-        // itself (d = 0): no masks in the loop
-        // Two memory round trips per round (entries, then the rows they name) in a chain as long as the row's list bound the
-        // launch (the busiest wavefront of a block walks ~30 entries: 16 dependent trips at four entries per round): rounds of
-        // EIGHT entries, the entries of round r + 1 requested before the gathers of round r are issued -- and, between issuing
-        // the gathers of a round and using them, the wavefront evaluates the NEGATIVES that belong to those entries (five per
-        // fired edge, served from LDS: pure vector work), so the trip is hidden inside the wavefront itself.
-        // repulsion: n_use items from the pool; -2b / ((d + eps)(1 + a d^b)) (umap.py:272-281).  n_use = neg_rate x (fired
-        // edges): with the reference's rate of 5 (and a cap that is a multiple of it) the items come in whole groups of five and
-        // the loop carries no masks
-        const int32_t* lst = P.list + hh.x;
-        typedef int i32x4 __attribute__((ext_vector_type(4)));
-        const PoolRowKey rk = pool_row_key(P.seed, iter, gi64);
-        uint32_t x = rk.alpha;
-        int kn = 0;                 // negatives done
-        i32x4 ln[2];
-        const bool ab_list = ablate & 32, ab_gather = ablate & 16;      // DBG instances: no list reads / no gathers
-        ln[0] = ln[1] = i32x4{(int)gi, (int)gi, (int)gi, (int)gi};
-        if (npos > 0 && !ab_list) { __builtin_memcpy(&ln[0], lst, 16); __builtin_memcpy(&ln[1], lst + 4, 16); }
-        for (int k = 0; k < npos; k += 2 * U) {
-            const i32x4 lc[2] = {ln[0], ln[1]};
-            if (k + 2 * U < npos && !ab_list) { __builtin_memcpy(&ln[0], lst + k + 2 * U, 16); __builtin_memcpy(&ln[1], lst + k + 3 * U, 16); }
-            Vec<NC> zj[2 * U];
-#pragma unroll
-            for (int u = 0; u < 2 * U; ++u) {
-                // a slot beyond the row's count takes no part in the gather (offset outside the descriptor's range: no request and
-                // no branch -- a branch per slot breaks the eight loads into eight issue / wait groups: 0.088 vs 0.075 ms per launch)
-                const bool valid = k + u < npos;
-                const uint32_t j = (uint32_t)lc[u >> 2][u & 3];
-                if (DBG && ab_gather) {
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) zj[u].v[c] = zi.v[c] + __uint_as_float((j & 0xffffu) | 0x3f000000u);
-                } else {
-                    zj[u] = gather_z<NC>(zrs, valid ? j * (uint32_t)(NC * 4) : 0xffffffffu);
-                }
-#pragma unroll
-                for (int c = 0; c < NC; ++c) zj[u].v[c] = valid ? zj[u].v[c] : zi.v[c];
-            }
-            if (P.exact5) {
 #pragma unroll 1
-                for (int q = 0; q < 2 * U && kn < n_use; ++q, kn += 5) {
-                    Vec<NC> zn[5];
+        for (int j = j0; j < j1; ++j) {
+            // part j: listed edges [e0, e1), negatives [kn, kn1)
+            const int e0 = (int)pool_part_end((uint32_t)npos_row, (uint32_t)j, m), e1 = (int)pool_part_end((uint32_t)npos_row, (uint32_t)j + 1u, m);
+            int kn = (int)pool_part_end((uint32_t)n_grp, (uint32_t)j, m) * (P.exact5 ? 5 : 1);
+            const int kn1 = (int)pool_part_end((uint32_t)n_grp, (uint32_t)j + 1u, m) * (P.exact5 ? 5 : 1);
+            uint32_t x = rk.alpha + (uint32_t)kn * rk.beta;
+            float pa[NC], pr[NC];
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) { zn[u] = pool_read<NC>(pool, x >> (32 - LOGP)); x += rk.beta; }
+            for (int c = 0; c < NC; ++c) { pa[c] = 0.f; pr[c] = 0.f; }
+            // attraction: 2ab d^(b-1) / (1 + a d^b) = 2ab d^b / (d (1 + a d^b)), 0 where d <= 0 (umap.py:252-256): d = 0 makes d^b = 0
+            // and the guarded reciprocal finite, so the coefficient is 0 without a test -- and a slot beyond the part's count reads
+            // the row itself (d = 0): no masks in the loop.  Rounds of EIGHT entries (two 16-byte list reads; the list carries 64
+            // entries of slack), the entries of round r + 1 requested before the gathers of round r are issued, and between issuing
+            // the gathers of a round and using them the lane evaluates the NEGATIVES that belong to those entries (five per fired
+            // edge, served from LDS: pure vector work): -2b / ((d + eps)(1 + a d^b)) (umap.py:272-281).  With the reference's rate
+            // of 5 (and a cap that is a multiple of it) the negatives come in whole groups of five: no masks there either
+            i32x4 ln[2];
+            ln[0] = ln[1] = i32x4{(int)gi, (int)gi, (int)gi, (int)gi};
+            if (e1 > e0 && !ab_list) { __builtin_memcpy(&ln[0], lst + e0, 16); __builtin_memcpy(&ln[1], lst + e0 + 4, 16); }
+            for (int k = e0; k < e1; k += 2 * U) {
+                const i32x4 lc[2] = {ln[0], ln[1]};
+                if (k + 2 * U < e1 && !ab_list) { __builtin_memcpy(&ln[0], lst + k + 2 * U, 16); __builtin_memcpy(&ln[1], lst + k + 3 * U, 16); }
+                Vec<NC> zj[2 * U];
 #pragma unroll
-                    for (int u = 0; u < 5; ++u) {
-                        float df[NC];
-                        const float d = sqdist_fma<NC>(zi, zn[u], df);
-                        const float coef = m2b * fast_rcp((d + P.eps) * __builtin_fmaf(P.a, fast_pow(d, P.b), 1.0f));
+                for (int u = 0; u < 2 * U; ++u) {
+                    // a slot beyond the part's count takes no part in the gather (offset outside the descriptor's range: no request
+                    // and no branch -- a branch per slot breaks the eight loads into eight issue / wait groups)
+                    const bool valid = k + u < e1;
+                    const uint32_t jc = (uint32_t)lc[u >> 2][u & 3];
+                    if (DBG && ab_gather) {
 #pragma unroll
-                        for (int c = 0; c < NC; ++c) gr[c] = __builtin_fmaf(coef, df[c], gr[c]);
+                        for (int c = 0; c < NC; ++c) zj[u].v[c] = zi.v[c] + __uint_as_float((jc & 0xffffu) | 0x3f000000u);
+                    } else {
+                        zj[u] = gather_z<NC>(zrs, valid ? jc * (uint32_t)(NC * 4) : 0xffffffffu);
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) zj[u].v[c] = valid ? zj[u].v[c] : zi.v[c];
+                }
+                if (P.exact5) {
+#pragma unroll 1
+                    for (int g = 0; g < 2 * U && kn < kn1; ++g, kn += 5) {
+                        Vec<NC> zn[5];
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) { zn[u] = pool_read<NC>(pool, x >> (32 - LOGP)); x += rk.beta; }
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) {
+                            float df[NC];
+                            const float d = sqdist_fma<NC>(zi, zn[u], df);
+                            const float coef = m2b * fast_rcp((d + P.eps) * __builtin_fmaf(P.a, fast_pow(d, P.b), 1.0f));
+#pragma unroll
+                            for (int c = 0; c < NC; ++c) pr[c] = __builtin_fmaf(coef, df[c], pr[c]);
+                        }
                     }
                 }
+#pragma unroll
+                for (int u = 0; u < 2 * U; ++u) {
+                    float df[NC];
+                    const float d = sqdist_fma<NC>(zi, zj[u], df);
+                    const float pb = fast_pow(d, P.b);
+                    const float coef = pb * two_ab * fast_rcp(fmaxf(d * __builtin_fmaf(P.a, pb, 1.0f), 1e-37f));
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) pa[c] = __builtin_fmaf(coef, df[c], pa[c]);
+                }
             }
+            // what is left of the part's negatives (a rate other than 5, or more items than five per listed edge)
+            for (; kn < kn1; kn += U) {
+                Vec<NC> zn[U];
 #pragma unroll
-            for (int u = 0; u < 2 * U; ++u) {
-                float df[NC];
-                const float d = sqdist_fma<NC>(zi, zj[u], df);
-                const float pb = fast_pow(d, P.b);
-                const float coef = pb * two_ab * fast_rcp(fmaxf(d * __builtin_fmaf(P.a, pb, 1.0f), 1e-37f));
+                for (int u = 0; u < U; ++u) { zn[u] = pool_read<NC>(pool, x >> (32 - LOGP)); x += rk.beta; }
 #pragma unroll
-                for (int c = 0; c < NC; ++c) ga[c] = __builtin_fmaf(coef, df[c], ga[c]);
+                for (int u = 0; u < U; ++u) {
+                    float df[NC];
+                    const float d = sqdist_fma<NC>(zi, zn[u], df);
+                    float coef = m2b * fast_rcp((d + P.eps) * __builtin_fmaf(P.a, fast_pow(d, P.b), 1.0f));
+                    if (!(kn + u < kn1)) coef = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) pr[c] = __builtin_fmaf(coef, df[c], pr[c]);
+                }
+            }
+            if (slot0 >= 0) {       // a part of a split row: its sums go to the row's slot
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { psum[(slot0 + j) * 2 * NC + c] = pa[c]; psum[(slot0 + j) * 2 * NC + NC + c] = pr[c]; }
+            } else if (j == 0) {    // parts are ADDED in order (the same association as the split form)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { ga[c] = pa[c]; gr[c] = pr[c]; }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { ga[c] += pa[c]; gr[c] += pr[c]; }
             }
         }
-        // what is left of the negatives (a rate other than 5, or more items than five per listed edge)
-        for (; kn < n_use; kn += U) {
-            Vec<NC> zn[U];
+        if (slot0 < 0) pool_store_grad<NC>(P, r, ga, gr);
+        if (q < 2) stamp(4 + q);
+    }
+    // 4. split rows: their parts' sums in part order
+    __syncthreads();
+    for (uint32_t sidx = (uint32_t)t; sidx < scount; sidx += THREADS) {
+        const uint32_t row = srow[sidx];
+        const uint32_t rx = rowx[row], m = rx & 255u, b0 = (rx >> 8) - 1u;
+        const int64_t r = gb * ROWS + row - P.row0;
+        if (r < 0 || r >= P.n_rows) continue;
+        float ga[NC], gr[NC];
 #pragma unroll
-            for (int u = 0; u < U; ++u) { zn[u] = pool_read<NC>(pool, x >> (32 - LOGP)); x += rk.beta; }
+        for (int c = 0; c < NC; ++c) { ga[c] = psum[b0 * 2 * NC + c]; gr[c] = psum[b0 * 2 * NC + NC + c]; }
+        for (uint32_t j = 1; j < m; ++j) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float df[NC];
-                const float d = sqdist_fma<NC>(zi, zn[u], df);
-                float coef = m2b * fast_rcp((d + P.eps) * __builtin_fmaf(P.a, fast_pow(d, P.b), 1.0f));
-                if (!(kn + u < n_use)) coef = 0.f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) gr[c] = __builtin_fmaf(coef, df[c], gr[c]);
-            }
+            for (int c = 0; c < NC; ++c) { ga[c] += psum[(b0 + j) * 2 * NC + c]; gr[c] += psum[(b0 + j) * 2 * NC + NC + c]; }
         }
-        float g[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) g[c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
-        if (NC == 2) {
-            *reinterpret_cast<float2*>(P.grad + (size_t)r * 2) = make_float2(g[0], g[1]);
-        } else {
-#pragma unroll
-            for (int c = 0; c < NC; ++c) P.grad[(size_t)r * NC + c] = g[c];
-        }
-        stamp(4 + q);
+        pool_store_grad<NC>(P, r, ga, gr);
     }
 }
 
