@@ -216,6 +216,7 @@ int tdr_knn_flat_select_f32(uint64_t* list, int have_list, const uint64_t* extra
                             float* tau, int32_t* lost, void* stream);
 /* cluster index, step 3 (round 5): labels[i] = centre nearest to point i by the one-term screening value of the fp16-split images
  * (same meta); approximate (2^-10 relative) and deterministic -- the clustering only decides how much a pruned search can skip */
+int tdr_cluster_assign16_supported(int d);
 int tdr_cluster_assign16_f32(const float* x16, int64_t n, const float* c16, int n_centres, int d, const uint32_t* meta,
                              int32_t* labels, void* stream);
 /* tdr_knn_screen_f32 in pilot mode (predict_unsplit = 1) with the prediction made for lists of pred_L entries; pred_terms = 0: the
@@ -433,8 +434,9 @@ int tdr_emulx_destroy(void* ctx);
  * + 1, :315); snap: optional (n_rows, nc) copy of the stepped rows taken at those iterations (lets a host that runs whole
  * windows ahead return the state at which the reference stops, :343-349); scratch: >= 4 bytes of device memory; gather: optional `int (*)(void* ctx, float* Z, int nc, void* stream)`
  * run after every step (tdr_ctx_allgather_rows of a tdr_ctx_create context, or tdr_peerx_allgather_rows), NULL = single
- * process.  With a gather callback tdr_umap_loop_run ignores use_graph and enqueues plain launches: the exchange's
- * generation counter / stage parity are host-side values fixed at enqueue time and must not be replayed. */
+ * process.  With a gather callback tdr_umap_loop_run ignores use_graph and enqueues plain launches unless the descriptor says
+ * `gather_capturable` (a communicator call belongs to its library's capture rules; the peer exchange keeps its generation in
+ * device memory since round 6 and may be replayed). */
 typedef struct tdr_umap_loop_desc {
     float* Z; int nc; int64_t n_total, row0, n_rows;
     const int64_t* rowptr; const int32_t* cols; const float* eps_per; float* next;
@@ -444,6 +446,8 @@ typedef struct tdr_umap_loop_desc {
     void* scratch; void* gather; void* gather_ctx; int geom;
     const uint8_t* rs;   /* non-NULL: cols / eps_per / next are group-ordered (tdr_umap_sched_group_f32), blk_base = grp_base */
     int pool;            /* 0: i.i.d. negatives gathered from L2; g + 1: negatives from the LDS pool, geometry g (tdr_umap_pool_grad_f32; n_slices = 1) */
+    int gather_capturable;   /* 1: the gather callback enqueues kernels only and bakes no per-call state into their arguments
+                                (tdr_peerx_allgather_rows since round 6, tdr_emulx_allgather_rows): windows are captured and replayed with it */
 } tdr_umap_loop_desc;
 int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d);
 int tdr_umap_loop_run(void* loop, int it0, int n_iters, int use_graph, void* stream);

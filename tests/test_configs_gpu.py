@@ -321,9 +321,10 @@ def test_c5_tsnekhorn_200k_symmetric_entropic_rows_vs_fp64():
     err_h = float(((H.cpu().double()[rows] - H_ref) / H_ref.abs().clamp(min=1.0)).abs().max())
     from tests.conftest import AUDIT
     # per-ROW relative error of float32 sums over 200 000 columns (tile sums combined in order): measured 1.6e-5 / 1.05e-5
-    AUDIT["c5_sea_200k/row_sum_relative_per_row"] = {"err_vs_float64": err_s, "budget": 3e-5}
-    AUDIT["c5_sea_200k/row_entropy_relative_per_row"] = {"err_vs_float64": err_h, "budget": 3e-5}
-    assert err_s < 3e-5 and err_h < 3e-5, (err_s, err_h)
+    # round 6: the row sums are compensated (SeaStats: quarter-tile sums + Kahan) -- north_star's 1e-5 holds per row
+    AUDIT["c5_sea_200k/row_sum_relative_per_row"] = {"err_vs_float64": err_s, "budget": 1e-5}
+    AUDIT["c5_sea_200k/row_entropy_relative_per_row"] = {"err_vs_float64": err_h, "budget": 1e-5}
+    assert err_s < 1e-5 and err_h < 1e-5, (err_s, err_h)
     sea = torchdr_amd.SymmetricEntropicAffinity(perplexity=30, lr=1e-1, max_iter=5, zero_diag=False)
     packed = sea.fit_duals(X)
     assert bool(torch.isfinite(sea.eps_).all()) and bool(torch.isfinite(sea.mu_).all())

@@ -351,6 +351,31 @@ def test_bench_starts_its_own_ranks():
         assert name in rec["phases_ms"], sorted(rec["phases_ms"])
 
 
+def test_first_contact_script_runs_end_to_end(tmp_path):
+    """tools/gpu_first_contact.sh -- the one command for the first node with more than one GPU -- at a small size on THIS box (ranks share
+    the device when it has one): every step returns 0, the per-N summary holds a measured line per (gpus, exchange) with its phase
+    split and the transport that ran, the emulated rank share beside it, and their ratio."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(FC_SKIP_TESTS="1", FC_SIZES="70000:32", FC_WORLDS="1 2", FC_MAX_ITER="60", TDR_KNN_PRUNE="force", TDR_KNN_SCREEN="force")
+    out = subprocess.run(["bash", os.path.join(root, "tools", "gpu_first_contact.sh"), str(tmp_path)], env=env, capture_output=True, text=True,
+                         timeout=1500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    steps = [json.loads(ln) for ln in open(tmp_path / "steps.jsonl")]
+    assert steps and all(s_["rc"] == 0 for s_ in steps), steps
+    rec = json.load(open(tmp_path / "first_contact_n70000.json"))
+    got = {(m["gpus"], m["exchange_requested"]) for m in rec["measured"]}
+    assert got == {(1, "rccl"), (2, "rccl"), (2, "peer")}, got
+    for m in rec["measured"]:
+        assert m["ms_per_step"] > 0 and "loop" in m["phases_ms"]
+        if m["gpus"] == 2:
+            assert m["row_exchange"] in ("PeerExchange", "RcclContext", "torch.distributed") and m["measured_over_emulated"] > 0
+    assert rec["emulated"] and rec["emulated"][0]["world"] == 2 and rec["emulated"][0]["exchange_bytes"]["received_per_iteration"] > 0
+
+
 def _worker_c4(rank, world, port, ret):
     """BASELINE config C4's shape (D = 256, k = 30, rows sharded over 8 ranks) at a size one GPU can host 8 times."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),

@@ -52,8 +52,8 @@ def test_sea_rowstats_vs_oracle_medium():
     S_ref = lp.exp().sum(1)
     H_ref = -(lp.exp() * (lp - 1)).sum(1)
     S, H = sea_rowstats(PackedPoints(X.cuda()), mu.cuda(), e.cuda(), False)
-    assert torch.allclose(S.cpu().double(), S_ref, rtol=2e-5)
-    assert torch.allclose(H.cpu().double(), H_ref, rtol=2e-5, atol=1e-4)
+    assert torch.allclose(S.cpu().double(), S_ref, rtol=1e-5)
+    assert torch.allclose(H.cpu().double(), H_ref, rtol=1e-5, atol=1e-4)
 
 
 def test_split_pair_scan_equals_the_unsplit_scan():

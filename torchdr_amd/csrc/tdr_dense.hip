@@ -41,31 +41,68 @@ struct PairScanParams {
 // H_i = -sum_j exp(lp_ij) (lp_ij - 1)   (entropic.py:522-525; P is NOT normalised inside the entropy).
 struct SeaStats {
     static constexpr int SIDE = 2;  // mu, e (= eps^2 or eps)
+    // Round 6: the three running sums are COMPENSATED (Kahan): a row of C5 adds 200 000 terms, and plain fp32 accumulation left the
+    // row sums / entropies 1.6e-5 / 1.05e-5 from a float64 evaluation (north_star asks 1e-5).  The four pairs a lane meets per
+    // quarter tile are summed on their own first (one rescale to the running maximum per quarter instead of a test per pair) and
+    // enter the running sums with one compensated addition each: ~3 vector instructions per pair more than the plain form, less
+    // the per-pair maximum test.
+    static constexpr bool BLOCK4 = true;
     float mu_i, e_i, m, s, t, u;   // u = sum_j exp(lp_ij - m) C_ij (the energy term of the dual objective, entropic.py:487)
-    __device__ __forceinline__ void init(const float* qs) { mu_i = qs[0]; e_i = qs[1]; m = -__builtin_inff(); s = 0.f; t = 0.f; u = 0.f; }
+    float cs, ct, cu;               // compensation terms of s, t, u
+    __device__ __forceinline__ void init(const float* qs) {
+        mu_i = qs[0]; e_i = qs[1]; m = -__builtin_inff(); s = 0.f; t = 0.f; u = 0.f; cs = 0.f; ct = 0.f; cu = 0.f;
+    }
+    static __device__ __forceinline__ void kahan(float& sum, float& comp, float x) {
+        const float y = __fsub_rn(x, comp);
+        const float tt = __fadd_rn(sum, y);
+        comp = __fsub_rn(__fsub_rn(tt, sum), y);
+        sum = tt;
+    }
+    __device__ __forceinline__ void rescale_to(float mm) {
+        const float sc = __expf(m - mm);      // m = -inf: 0 (the sums are 0 then)
+        s *= sc; t *= sc; u *= sc; cs *= sc; ct *= sc; cu *= sc; m = mm;
+    }
     __device__ __forceinline__ void add(float c, const float* sj, const PairScanParams&) {
         const float lp = (mu_i + sj[0] - 2.0f * c) * __builtin_amdgcn_rcpf(e_i + sj[1]);
-        if (lp > m) {  // rescale running sums to the new maximum
-            const float sc = __expf(m - lp);
-            s *= sc; t *= sc; u *= sc; m = lp;
-        }
+        if (lp > m) rescale_to(lp);
         const float p = __expf(lp - m);
-        s += p;
-        t = fmaf(p, lp, t);
-        u = (p > 0.f) ? fmaf(p, c, u) : u;   // the excluded diagonal carries c = 1e12 and p = 0
+        kahan(s, cs, p);
+        kahan(t, ct, p * lp);
+        if (p > 0.f) kahan(u, cu, p * c);   // the excluded diagonal carries c = 1e12 and p = 0
+    }
+    // four pairs of an interior tile (no diagonal, no padding rows)
+    __device__ __forceinline__ void add4(const float (&c)[4], const float (&sj)[4][SIDE], const PairScanParams&) {
+        float lp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lp[e] = (mu_i + sj[e][0] - 2.0f * c[e]) * __builtin_amdgcn_rcpf(e_i + sj[e][1]);
+        const float mx = fmaxf(fmaxf(lp[0], lp[1]), fmaxf(lp[2], lp[3]));
+        if (mx > m) rescale_to(mx);
+        float ls = 0.f, lt = 0.f, lu = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float p = __expf(lp[e] - m);
+            ls += p;
+            lt = fmaf(p, lp[e], lt);
+            lu = fmaf(p, c[e], lu);
+        }
+        kahan(s, cs, ls);
+        kahan(t, ct, lt);
+        kahan(u, cu, lu);
     }
     __device__ __forceinline__ void merge(const SeaStats& o) {
         const float mm = fmaxf(m, o.m);
         const float a = (m == -__builtin_inff()) ? 0.f : __expf(m - mm);
         const float b = (o.m == -__builtin_inff()) ? 0.f : __expf(o.m - mm);
         s = s * a + o.s * b; t = t * a + o.t * b; u = u * a + o.u * b; m = mm;
+        cs = 0.f; ct = 0.f; cu = 0.f;
     }
     __device__ __forceinline__ void shfl_from(const SeaStats& x, int src) {
         m = __shfl(x.m, src, 64); s = __shfl(x.s, src, 64); t = __shfl(x.t, src, 64); u = __shfl(x.u, src, 64); mu_i = x.mu_i; e_i = x.e_i;
+        cs = 0.f; ct = 0.f; cu = 0.f;
     }
     static constexpr int NSTATE = 4;
     __device__ __forceinline__ void save(float* p) const { p[0] = m; p[1] = s; p[2] = t; p[3] = u; }
-    __device__ __forceinline__ void load(const float* p) { m = p[0]; s = p[1]; t = p[2]; u = p[3]; }
+    __device__ __forceinline__ void load(const float* p) { m = p[0]; s = p[1]; t = p[2]; u = p[3]; cs = 0.f; ct = 0.f; cu = 0.f; }
     __device__ __forceinline__ void store(int64_t row, const PairScanParams& P) const {
         const float em = expf(m);
         const float S = em * s, T = em * t;
@@ -214,6 +251,10 @@ struct KhornForceUnrolled {
 typedef __attribute__((address_space(1))) const void* dgptr_t;
 typedef __attribute__((address_space(3))) void* dlptr_t;
 
+// an epilogue that takes the four pairs of a quarter tile at once (SeaStats) says so with `static constexpr bool BLOCK4 = true`
+template <class E, class = void> struct epi_block4 { static constexpr bool value = false; };
+template <class E> struct epi_block4<E, decltype((void)E::BLOCK4)> { static constexpr bool value = E::BLOCK4; };
+
 // One tile step, software pipelined like the kNN scan (tdr_knn.hip): the MFMA chain of tile T runs with the
 // row reduction of tile T-1 (held in `accp`) placed BETWEEN its MFMAs, so the exp-heavy epilogue executes in
 // the shadow of the 64-cycle matrix instructions.  Quarter `g` of the previous tile = its rows 8g+4h .. +3.
@@ -226,6 +267,18 @@ __device__ __forceinline__ void reduce_part(Epi& epi, const PairScanParams& P, c
     constexpr int SIDE = Epi::SIDE;
     const f32x4 y4 = *reinterpret_cast<const f32x4*>(ynp + 8 * g);
     if (!edge) {
+        if constexpr (epi_block4<Epi>::value) {
+            float c4[4], sj4[4][SIDE];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = e + 8 * g + 4 * h;  // database row inside the tile
+                c4[e] = __builtin_fmaf(-2.0f, accp[4 * g + e], __fadd_rn(xn, y4[e]));
+#pragma unroll
+                for (int s_ = 0; s_ < SIDE; ++s_) sj4[e][s_] = sd[i * SIDE + s_];
+            }
+            epi.add4(c4, sj4, P);
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int i = e + 8 * g + 4 * h;  // database row inside the tile

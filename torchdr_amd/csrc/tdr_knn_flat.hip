@@ -659,6 +659,8 @@ extern "C" {
 /* 1 when the f16 kernels of this file that hold two query tiles per wavefront serve feature dimension d (<= 128; the threshold
  * scan itself also serves d <= 256 with one term: tdr_knn_screen_flat_workspace_bytes says what it takes). */
 int tdr_knn_flat_supported(int d) { return flat::flat_ks(d) != 0 ? 1 : 0; }
+/* 1 when tdr_cluster_assign16_f32 serves feature dimension d (<= 256). */
+int tdr_cluster_assign16_supported(int d) { return flat::flat_scan_ks(d, 1) != 0 ? 1 : 0; }
 
 /*
  * One pass of the threshold scan (tdr_knn_flat.hip header): every candidate of the database tiles at positions [tile_begin,
@@ -739,7 +741,7 @@ int tdr_knn_flat_seed_f32(const float* q16, int64_t nq, int64_t q_offset, const 
 int tdr_cluster_assign16_f32(const float* x16, int64_t n, const float* c16, int n_centres, int d, const uint32_t* meta,
                              int32_t* labels, void* stream) {
     if (!x16 || !c16 || !meta || !labels || n <= 0 || n_centres <= 0 || d <= 0) return TDR_ERR_BAD_ARG;
-    const int ks = flat::flat_ks(d);
+    const int ks = flat::flat_scan_ks(d, 1);     // one term: 128 < d <= 256 too (64 registers of query fragments)
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     const int64_t n_qtiles = (n + 31) / 32;
     const dim3 grid((unsigned)((n_qtiles + flat::NW - 1) / flat::NW));
@@ -747,6 +749,7 @@ int tdr_cluster_assign16_f32(const float* x16, int64_t n, const float* c16, int 
     switch (ks) {
         case 2: hipLaunchKernelGGL(flat::nearest_centre_kernel<2>, grid, dim3(256), 0, st, x16, n, c16, n_centres, meta, labels); break;
         case 4: hipLaunchKernelGGL(flat::nearest_centre_kernel<4>, grid, dim3(256), 0, st, x16, n, c16, n_centres, meta, labels); break;
+        case 16: hipLaunchKernelGGL(flat::nearest_centre_kernel<16>, grid, dim3(256), 0, st, x16, n, c16, n_centres, meta, labels); break;
         default: hipLaunchKernelGGL(flat::nearest_centre_kernel<8>, grid, dim3(256), 0, st, x16, n, c16, n_centres, meta, labels); break;
     }
     TDR_CHECK_LAUNCH();

@@ -41,7 +41,9 @@ struct PeerX {
     void* own_flags;
     void* mapped_stage[PX_MAX_WORLD];
     void* mapped_flags[PX_MAX_WORLD];
-    int* ticket;                // device int (push kernel's last-block counter)
+    int* ticket;                // device ints: [0] push kernel's last-block counter, [1] pull kernel's, [2] the GENERATION of the last
+                                // completed exchange (device-resident since round 6: an exchange bakes nothing into its kernel arguments,
+                                // so windows that contain it can be captured into HIP graphs and replayed)
     int* err;                   // device int: 1 = a wait ran into its limit
     int gen;
     int fine_grained;
@@ -53,18 +55,20 @@ struct PushParams {
     const float* src;           // this rank's rows in the embedding
     int64_t count;              // floats
     int64_t dst_off;            // offset of this rank's chunk in a stage
-    float* dst[PX_MAX_WORLD];
+    float* dst[2][PX_MAX_WORLD];   // [parity][rank]
     int* flag[PX_MAX_WORLD];    // flag word of THIS rank at every peer
-    int world, rank, gen;
-    int* ticket;
+    int world, rank;
+    int* ticket;                // [0] this kernel's counter, [2] generation of the last completed exchange
 };
 
 __global__ __launch_bounds__(256) void peerx_push_kernel(const PushParams P) {
+    const int gen = P.ticket[2] + 1;      // this exchange (the pull kernel of the previous one stored its generation before this launch began)
+    const int par = gen & 1;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.count; i += stride) {
         const float v = P.src[i];
         for (int p = 0; p < P.world; ++p)
-            if (p != P.rank) P.dst[p][P.dst_off + i] = v;
+            if (p != P.rank) P.dst[par][p][P.dst_off + i] = v;
     }
     __threadfence_system();
     __shared__ int last;
@@ -75,26 +79,29 @@ __global__ __launch_bounds__(256) void peerx_push_kernel(const PushParams P) {
     if (threadIdx.x == 0) *P.ticket = 0;
     __threadfence_system();
     if ((int)threadIdx.x < P.world && (int)threadIdx.x != P.rank)
-        __hip_atomic_store(P.flag[threadIdx.x], P.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(P.flag[threadIdx.x], gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 struct PullParams {
     float* Z;                   // the embedding (n_total x nc floats)
-    const float* stage;         // this rank's stage of this parity
+    const float* stage[2];      // this rank's stages, by parity
     const int* flags;           // this rank's flag block
     int64_t own_off, own_count; // floats of this rank's own chunk (not copied)
     int64_t total;              // n_total * nc
-    int world, rank, gen;
+    int world, rank;
+    int* ticket;                // [1] this kernel's counter, [2] generation of the last completed exchange
     int* err;
     long long spin_limit;
 };
 
 __global__ __launch_bounds__(256) void peerx_pull_kernel(const PullParams P) {
+    const int gen = P.ticket[2] + 1;
+    const float* stage = P.stage[gen & 1];
     if ((int)threadIdx.x < P.world && (int)threadIdx.x != P.rank) {
         const int* f = P.flags + (size_t)threadIdx.x * PX_FLAG_STRIDE;
         long long spins = 0;
         // generations only grow: "reached" = not behind (wrap-safe signed difference)
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - P.gen < 0) {
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - gen < 0) {
             __builtin_amdgcn_s_sleep(8);
             if (++spins > P.spin_limit) { atomicExch(P.err, 1); break; }
         }
@@ -104,8 +111,14 @@ __global__ __launch_bounds__(256) void peerx_pull_kernel(const PullParams P) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.total; i += stride) {
         if (i >= P.own_off && i < P.own_off + P.own_count) continue;
-        P.Z[i] = __builtin_nontemporal_load(P.stage + i);
+        P.Z[i] = __builtin_nontemporal_load(stage + i);
     }
+    // the last block to finish closes the exchange: every block has read the generation by the time it draws its ticket
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(P.ticket + 1, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (last && threadIdx.x == 0) { P.ticket[1] = 0; P.ticket[2] = gen; }
 }
 
 inline void chunk_of(int64_t n, int world, int r, int64_t* start, int64_t* rows) {
@@ -241,19 +254,22 @@ int tdr_peerx_allgather_rows(void* ctx, float* Z, int nc, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int64_t start, rows;
     chunk_of(c->n_total, c->world, c->rank, &start, &rows);
-    const int gen = ++c->gen;
-    const int par = gen & 1;
+    ++c->gen;       // host-side count of enqueued exchanges (statistics only: the kernels read the generation from device memory)
     PushParams P;
-    P.src = Z + (size_t)start * nc; P.count = rows * nc; P.dst_off = start * nc; P.world = c->world; P.rank = c->rank; P.gen = gen;
+    P.src = Z + (size_t)start * nc; P.count = rows * nc; P.dst_off = start * nc; P.world = c->world; P.rank = c->rank;
     P.ticket = c->ticket;
-    for (int p = 0; p < c->world; ++p) { P.dst[p] = c->stage[par][p]; P.flag[p] = c->flags[p] + (size_t)c->rank * PX_FLAG_STRIDE; }
+    for (int p = 0; p < c->world; ++p) {
+        P.dst[0][p] = c->stage[0][p]; P.dst[1][p] = c->stage[1][p];
+        P.flag[p] = c->flags[p] + (size_t)c->rank * PX_FLAG_STRIDE;
+    }
     int64_t pb = (P.count + 1023) / 1024;
     if (pb < 1) pb = 1;
     if (pb > 256) pb = 256;
     hipLaunchKernelGGL(peerx_push_kernel, dim3((unsigned)pb), dim3(256), 0, st, P);
     PullParams Q;
-    Q.Z = Z; Q.stage = c->stage[par][c->rank]; Q.flags = c->flags[c->rank]; Q.own_off = start * nc; Q.own_count = rows * nc;
-    Q.total = c->n_total * nc; Q.world = c->world; Q.rank = c->rank; Q.gen = gen; Q.err = c->err; Q.spin_limit = c->spin_limit;
+    Q.Z = Z; Q.stage[0] = c->stage[0][c->rank]; Q.stage[1] = c->stage[1][c->rank]; Q.flags = c->flags[c->rank];
+    Q.own_off = start * nc; Q.own_count = rows * nc;
+    Q.total = c->n_total * nc; Q.world = c->world; Q.rank = c->rank; Q.ticket = c->ticket; Q.err = c->err; Q.spin_limit = c->spin_limit;
     int64_t qb = (Q.total + 2047) / 2048;
     if (qb < 1) qb = 1;
     if (qb > 128) qb = 128;      // few blocks: they spin, and ranks that share a device (tests) must still get CUs

@@ -1300,6 +1300,7 @@ struct UmapLoop {
     int geom;
     const uint8_t* rs;              // non-null: group-ordered loop state (cols / eps_per / next / blk_base of tdr_umap_sched_group_f32 / _plan_groups_f32)
     int pool;                       // g + 1: negatives from the LDS pool (tdr_umap_pool.hip, geometry g), 0: i.i.d. gathers
+    int gather_capturable;          // the gather callback may be captured into the window graphs
     // captured windows: graph_len[i] iterations each
     hipGraphExec_t graphs[2]; int graph_len[2];
 };
@@ -1580,6 +1581,7 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
     L->iter_base = (int*)d->scratch; L->gather = (tdr_collective_fn)d->gather; L->gather_ctx = d->gather_ctx; L->geom = d->geom;
     L->rs = d->rs;
     L->pool = d->pool;
+    L->gather_capturable = d->gather_capturable;
     if (L->pool < 0 || L->pool > TDR_POOL_NGEOM + 1 || (L->pool && (L->S != 1 || !tdr_umap_pool_supported(L->nc) || ((uintptr_t)L->Z & 15u) || L->n_total * L->nc * 4 >= 0xffffffffLL))) { delete L; return TDR_ERR_BAD_ARG; }
     L->graphs[0] = L->graphs[1] = nullptr; L->graph_len[0] = L->graph_len[1] = 0;
     const size_t lds = (size_t)L->B * L->S * CNT_STRIDE * sizeof(uint32_t);
@@ -1607,10 +1609,10 @@ int tdr_umap_loop_run(void* loop, int it0, int n_iters, int use_graph, void* str
     UmapLoop* L = (UmapLoop*)loop;
     if (!L || it0 < 0 || n_iters <= 0 || it0 + n_iters > L->max_iter) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    // A window with a row exchange is never captured: the exchange's arguments are not replayable (tdr_peerx_allgather_rows
-    // bakes its generation number and stage parity into the kernel arguments at enqueue time -- a replayed pull would find its
-    // flags already raised and copy stale rows; a communicator call belongs to its library's own capture rules).
-    if (L->gather) use_graph = 0;
+    // A window with a row exchange is captured only when the exchange says it may be (`gather_capturable`: kernels only, nothing
+    // of the call baked into their arguments -- the peer exchange reads its generation and stage parity from device memory since
+    // round 6; a communicator call belongs to its library's own capture rules and stays out).
+    if (L->gather && !L->gather_capturable) use_graph = 0;
     int it = it0;
     while (it < it0 + n_iters) {
         const int n = (it0 + n_iters - it < L->B) ? it0 + n_iters - it : L->B;

@@ -247,7 +247,7 @@ class ClusterIndex:
             _, lab = knn_packed(Ps, PackedPoints(cent), 1, "sqeuclidean", exclude_self=False, _allow_screen=False)
             _lib.check(L.tdr_cluster_update_f32(_lib.ptr(Xs), S, D, _lib.ptr(lab), C, _lib.ptr(cent), _lib.ptr(ws), st),
                        "tdr_cluster_update_f32")
-        if _opt("ASSIGN16") and L.tdr_knn_flat_supported(D) and N >= 65536:
+        if _opt("ASSIGN16") and L.tdr_cluster_assign16_supported(D) and N >= 65536:
             # nearest centre by the one-term screening value on the f16 matrix pipe (0.4 ms at N = 1M, C = 1000, against 3.8-6.4 ms
             # for the exact fp32 search with k = 1): the assignment shapes the clusters, no result depends on it
             x16, meta16 = P.screen_image()

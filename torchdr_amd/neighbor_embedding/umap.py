@@ -534,16 +534,18 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                                                   _lib.ptr(keep["scratch"]))
         ctx = getattr(self, "_rccl_ctx", None)
         d.gather, d.gather_ctx = (ctx.gather_fn, ctx.handle) if ctx is not None else (None, None)
+        capturable = ctx is not None and bool(getattr(ctx, "capturable", False))
+        d.gather_capturable = 1 if capturable else 0
         d.geom = sc["geom"]
         d.pool = int(_opt("POOL_GEOM")) + 1 if (self._pool_negatives() and self.embedding_.data_ptr() % 16 == 0) else 0
         handle = ctypes.c_void_p()
         _lib.check(L.tdr_umap_loop_create(ctypes.byref(handle), ctypes.byref(d)), "tdr_umap_loop_create")
         # graphs cannot be captured on the legacy default stream: the loop runs on a side stream ordered after the
         # caller's stream, and the caller's stream waits for it at the end
-        # windows that contain RCCL calls are enqueued as plain launches: captured collectives have never run on hardware
-        # here, and at the ~100 us an iteration takes when the rows are sharded the 8 us of host work per iteration of the
-        # plain form are hidden anyway
-        self._loop_graph = bool(_opt("LOOP_GRAPH")) and ctx is None
+        # windows that contain RCCL calls are enqueued as plain launches (captured collectives have never run on hardware here);
+        # the peer exchange (and its loopback stand-in) keeps nothing on the host and is replayed with the window: at W = 8 a rank's
+        # iteration is a few tens of microseconds of kernels and four launches of host work are as long (profiles/r06_rank_share*)
+        self._loop_graph = bool(_opt("LOOP_GRAPH")) and (ctx is None or capturable)
         outer = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(device=dev) if self._loop_graph else outer
         side.wait_stream(outer)

@@ -396,6 +396,7 @@ class PeerExchange:
     ``allgather_rows_``).  ``create`` returns None when the peers cannot be mapped (HIP IPC) or the stress self-check fails on
     ANY rank: callers then keep RCCL / torch.distributed."""
 
+    capturable = True       # the exchange's generation lives in device memory: windows that contain it replay as HIP graphs
     _shared = {}
     _retired = set()        # process-group tokens whose exchange failed once: later fits of that group use RCCL / torch.distributed
     SELF_CHECK_ROUNDS = 12

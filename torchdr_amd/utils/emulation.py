@@ -33,6 +33,8 @@ class _Collected(Exception):
 class _LoopbackExchange:
     """``RcclContext`` / ``PeerExchange`` look-alike around ``tdr_emulx_*``."""
 
+    capturable = True
+
     def __init__(self, rank, world, n_total, nc, device):
         self.handle = ctypes.c_void_p()
         with torch.cuda.device(device):
