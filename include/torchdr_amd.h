@@ -400,6 +400,12 @@ int tdr_umap_pool_supported(int nc);
 int tdr_umap_pool_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list, const void* hdr,
                            int t_local, float a, float b, int n_iter, int neg_rate, int n_negatives, uint64_t seed, float exag,
                            float rep, float eps, float* grad, int geom, void* stream);
+/* the same launch with torch.optim.SGD's step (affinity_matcher.py:427; momentum 0) in it: stepped rows z - lr g -> Z_out, the OTHER
+ * embedding buffer (n_total, nc) -- every row of the launch reads the old positions in Z --, nan_flag as tdr_sgd_step_f32 sets it
+ * (:315); grad may be NULL (nobody reads the gradient of this iteration). */
+int tdr_umap_pool_grad_step_f32(const float* Z, float* Z_out, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list,
+                                const void* hdr, int t_local, float a, float b, int n_iter, int neg_rate, int n_negatives, uint64_t seed,
+                                float exag, float rep, float eps, float* grad, float lr, int* nan_flag, int geom, void* stream);
 int tdr_umap_pool_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nuse, int geom,
                                   int width, int64_t* out, void* stream);
 int tdr_umap_pool_grad_debug_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list, const void* hdr,

@@ -591,3 +591,30 @@ def test_threshold_scan_pass_plan_on_the_host():
     assert plan(1_000_000, 128, 30, 4)[0] == 0 and plan(1_000_000, 128, 30, 0)[0] == 0
     assert L.tdr_knn_screen_flat_workspace_bytes(1_000_000, 1_000_000, 128, 30, 2, 128) > 0
     assert L.tdr_knn_screen_flat_workspace_bytes(1_000_000, 1_000_000, 256, 30, 1, 128) > 0
+
+
+def test_emulated_rank_receives_the_edges_a_real_exchange_would_deliver():
+    """utils/emulation.py (one rank of a W-rank fit run alone): the edges `EmulatedRank.prepare(r)` hands rank r are
+    exactly the transposes a real all-to-all-v would deliver -- every directed edge (i -> j, v) of another rank's rows whose target j
+    lies in r's chunk, as (j local, i global, v), ordered by source rank -- checked against a direct evaluation on random graphs
+    with uneven chunks (reference utils/sparse.py:259-309)."""
+    from torchdr_amd.distributed import DistributedContext, chunk_bounds
+    from torchdr_amd.utils.emulation import EmulatedRank
+
+    n, k, W = 103, 6, 4
+    gen = torch.Generator().manual_seed(0)
+    idx = torch.randint(0, n, (n, k), generator=gen, dtype=torch.int32)
+    val = torch.rand(n, k, generator=gen)
+    em = EmulatedRank(W)
+    for r in range(W):
+        c0, c1 = chunk_bounds(n, r, W)
+        em.graphs[r] = (val[c0:c1].clone(), idx[c0:c1].clone(), c0)
+    owner = DistributedContext.get_rank_for_indices(torch.arange(n), n, W)
+    for r in range(W):
+        src, dst, v = em.prepare(r, n)
+        c0, c1 = chunk_bounds(n, r, W)
+        want = [(int(i), int(j), float(val[i, s])) for i in range(n) if int(owner[i]) != r for s, j in enumerate(idx[i].tolist()) if c0 <= j < c1]
+        got = list(zip(src.tolist(), dst.tolist(), [float(x) for x in v]))
+        assert sorted(got) == sorted(want)
+        assert [int(owner[i]) for i, _, _ in got] == sorted(int(owner[i]) for i, _, _ in got)      # delivered in source-rank order
+        assert em.edge_exchange_bytes == 12 * len(want)

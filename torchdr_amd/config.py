@@ -27,7 +27,7 @@ SWITCHES = {
     "SCHED_GEOM": "torchdr_amd.neighbor_embedding.umap", "SCHED_SLICES": "torchdr_amd.neighbor_embedding.umap",
     "SCHED_BLOCK_ITERS": "torchdr_amd.neighbor_embedding.umap", "GROUPED": "torchdr_amd.neighbor_embedding.umap",
     "SCHED_STAGE": "torchdr_amd.neighbor_embedding.umap", "NEGATIVES": "torchdr_amd.neighbor_embedding.umap",
-    "POOL_GEOM": "torchdr_amd.neighbor_embedding.umap",
+    "POOL_GEOM": "torchdr_amd.neighbor_embedding.umap", "POOL_FUSED_STEP": "torchdr_amd.neighbor_embedding.umap",
     "PCA_EIGH": "torchdr_amd.affinity_matcher", "PCA_PREFETCH": "torchdr_amd.affinity_matcher",
     "RCCL_CONTEXT": "torchdr_amd.neighbor_embedding.base", "PERM_NEGATIVES": "torchdr_amd.neighbor_embedding.base",
     "PEER_EXCHANGE": "torchdr_amd.neighbor_embedding.base",

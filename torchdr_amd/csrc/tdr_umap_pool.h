@@ -33,7 +33,10 @@ struct PoolGradParams {
     uint32_t iter;
     const int* iter_base;      // optional device int added to iter (graph replays)
     float exag, rep, eps;
-    float* grad;               // (n_rows, nc)
+    float* grad;               // (n_rows, nc), or NULL with Z_out
+    float* Z_out;              // non-NULL: the launch also steps its rows, z - lr g -> Z_out (n_total, nc): the other embedding buffer
+    float lr;
+    int* nan_flag;
     uint32_t n_runs;           // ceil(n_total / rows per run) (set by the launcher)
     int64_t gb0;               // first global row block of the launch (set by the launcher)
     int exact5;                // neg_rate == 5 and n_negatives % 5 == 0: a row's items come in whole groups of five

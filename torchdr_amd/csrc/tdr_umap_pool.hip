@@ -117,16 +117,35 @@ __device__ __forceinline__ uint32_t pool_parts(uint32_t act) {
 }
 __device__ __forceinline__ uint32_t pool_part_end(uint32_t n, uint32_t j, uint32_t m) { return n * j / m; }
 
+// the row's gradient (clamps of umap.py:262,290) and, when the launch carries the step (P.Z_out), torch.optim.SGD's update of the
+// row written to the OTHER embedding buffer (every row of this launch still reads the old one) with check_NaNs' flag
+// (affinity_matcher.py:315,427)
 template <int NC>
-__device__ __forceinline__ void pool_store_grad(const PoolGradParams& P, int64_t r, const float (&ga)[NC], const float (&gr)[NC]) {
+__device__ __forceinline__ void pool_store_grad(const PoolGradParams& P, int64_t r, int64_t gi, const Vec<NC>& zi, uint32_t iter,
+                                                const float (&ga)[NC], const float (&gr)[NC]) {
     float g[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) g[c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
-    if (NC == 2) {
-        *reinterpret_cast<float2*>(P.grad + (size_t)r * 2) = make_float2(g[0], g[1]);
-    } else {
+    if (P.grad) {
+        if (NC == 2) {
+            *reinterpret_cast<float2*>(P.grad + (size_t)r * 2) = make_float2(g[0], g[1]);
+        } else {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) P.grad[(size_t)r * NC + c] = g[c];
+            for (int c = 0; c < NC; ++c) P.grad[(size_t)r * NC + c] = g[c];
+        }
+    }
+    if (P.Z_out) {
+        float z[NC];
+        bool nan = false;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { z[c] = __builtin_fmaf(-P.lr, g[c], zi.v[c]); nan = nan || z[c] != z[c]; }
+        if (NC == 2) {
+            *reinterpret_cast<float2*>(P.Z_out + (size_t)gi * 2) = make_float2(z[0], z[1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) P.Z_out[(size_t)gi * NC + c] = z[c];
+        }
+        if (nan) atomicCAS(P.nan_flag, 0, (int)iter + 1);
     }
 }
 
@@ -435,7 +454,7 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 6 : 4) void umap_pool_grad_kerne
                 for (int c = 0; c < NC; ++c) { ga[c] += pa[c]; gr[c] += pr[c]; }
             }
         }
-        if (slot0 < 0) pool_store_grad<NC>(P, r, ga, gr);
+        if (slot0 < 0) pool_store_grad<NC>(P, r, gi64, zi, iter, ga, gr);
         if (q < 2) stamp(4 + q);
     }
     // 4. split rows: their parts' sums in part order
@@ -452,7 +471,7 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 6 : 4) void umap_pool_grad_kerne
 #pragma unroll
             for (int c = 0; c < NC; ++c) { ga[c] += psum[(b0 + j) * 2 * NC + c]; gr[c] += psum[(b0 + j) * 2 * NC + NC + c]; }
         }
-        pool_store_grad<NC>(P, r, ga, gr);
+        pool_store_grad<NC>(P, r, gb * ROWS + row, load_z<NC>(P.Z, gb * ROWS + row), iter, ga, gr);
     }
 }
 
@@ -533,6 +552,24 @@ int tdr_umap_pool_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0
     P.Z = Z; P.nc = nc; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.list = list; P.hdr = (const uint2*)hdr;
     P.t_local = t_local; P.a = a; P.b = b; P.neg_rate = neg_rate; P.n_negatives = n_negatives; P.seed = seed; P.iter = (uint32_t)n_iter;
     P.iter_base = nullptr; P.exag = exag; P.rep = rep; P.eps = eps; P.grad = grad;
+    P.exact5 = (neg_rate == 5 && n_negatives % 5 == 0) ? 1 : 0;
+    return launch_pool_grad(P, geom, (hipStream_t)stream);
+}
+
+/* tdr_umap_pool_grad_f32 with torch.optim.SGD's step in the same launch (affinity_matcher.py:427, momentum 0): the stepped rows
+ * z - lr g go to Z_out (the OTHER embedding buffer, same shape as Z: every row of the launch reads the old positions), nan_flag
+ * as tdr_sgd_step_f32 sets it; grad may be NULL (nobody reads the gradient of this iteration). */
+int tdr_umap_pool_grad_step_f32(const float* Z, float* Z_out, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* list,
+                                const void* hdr, int t_local, float a, float b, int n_iter, int neg_rate, int n_negatives, uint64_t seed,
+                                float exag, float rep, float eps, float* grad, float lr, int* nan_flag, int geom, void* stream) {
+    if (!Z || !Z_out || Z == Z_out || !list || !hdr || !nan_flag || n_rows <= 0 || row0 < 0 || n_total < 2 || n_total >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
+    if (t_local < 0 || t_local >= 32 || neg_rate < 0 || n_negatives < 0 || geom < 0 || geom > TDR_POOL_NGEOM) return TDR_ERR_BAD_ARG;
+    if (((uintptr_t)Z & 15u) != 0 || ((uintptr_t)Z_out & 7u) != 0 || n_total * nc * 4 >= 0xffffffffLL) return TDR_ERR_BAD_ARG;
+    if (!tdr_umap_pool_supported(nc)) return TDR_ERR_UNSUPPORTED;
+    PoolGradParams P = {};
+    P.Z = Z; P.nc = nc; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.list = list; P.hdr = (const uint2*)hdr;
+    P.t_local = t_local; P.a = a; P.b = b; P.neg_rate = neg_rate; P.n_negatives = n_negatives; P.seed = seed; P.iter = (uint32_t)n_iter;
+    P.iter_base = nullptr; P.exag = exag; P.rep = rep; P.eps = eps; P.grad = grad; P.Z_out = Z_out; P.lr = lr; P.nan_flag = nan_flag;
     P.exact5 = (neg_rate == 5 && n_negatives % 5 == 0) ? 1 : 0;
     return launch_pool_grad(P, geom, (hipStream_t)stream);
 }

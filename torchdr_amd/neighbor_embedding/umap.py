@@ -65,6 +65,7 @@ SCHED_STAGE = 0      # LDS stage entries of the grouped build (0 = library defau
 #           law -- the parity path (injected-negative tests, `discard_NNs`).
 NEGATIVES = "pool"
 POOL_GEOM = 0        # geometry of the pool kernel (0 = library default; tuning knob, changes the sampler's stream)
+POOL_FUSED_STEP = True   # torch.optim.SGD's step inside the pool gradient launch (stock step, no momentum), two embedding buffers
 
 def _opt(name):
     """A behaviour switch of this module: the scoped override (torchdr_amd.config.options) or the module attribute."""
@@ -403,15 +404,38 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         if self._sched_deferred:
             geom |= 32
         if self._pool_negatives() and neg is None and self.embedding_.data_ptr() % 16 == 0:
-            _lib.check(
-                L.tdr_umap_pool_grad_f32(
-                    _lib.ptr(self.embedding_), self.n_components, self.n_samples_in_, self.chunk_start_, self.chunk_size_,
-                    _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), t - sc["t0"], float(self._a), float(self._b), t,
-                    int(self.negative_sample_rate), int(self.n_negatives), self._neg_seed, float(self.early_exaggeration_coeff_),
-                    float(self.repulsion_strength), float(self._eps), _lib.ptr(grad), int(_opt("POOL_GEOM")), _lib.stream_ptr(),
-                ),
-                "tdr_umap_pool_grad_f32",
-            )
+            # POOL_FUSED_STEP: the launch also applies torch.optim.SGD's step (affinity_matcher.py:427) -- the stepped rows go to a
+            # second embedding buffer and the two swap roles (`_sgd_kernel` below) -- when the step is the stock one without
+            # momentum and nobody reads the gradient of this iteration (the reference inspects it every check_interval-th)
+            fuse = (_opt("POOL_FUSED_STEP") and self._fused_sgd and float(self._sgd_momentum) == 0.0 and self._stock_step()
+                    and t % max(int(self.check_interval), 1) != 0 and not PROFILE_KEEP_GRAD)
+            if fuse:
+                alt = self.__dict__.get("_Z_alt")
+                if alt is None or alt.shape != self.embedding_.shape or alt.data_ptr() == self.embedding_.data_ptr():
+                    alt = self._Z_alt = torch.empty_like(self.embedding_)
+                    if self.world_size > 1:
+                        alt.copy_(self.embedding_)      # the rows of other ranks arrive by the exchange; before the first one they must be valid
+                _lib.check(
+                    L.tdr_umap_pool_grad_step_f32(
+                        _lib.ptr(self.embedding_), _lib.ptr(alt), self.n_components, self.n_samples_in_, self.chunk_start_, self.chunk_size_,
+                        _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), t - sc["t0"], float(self._a), float(self._b), t,
+                        int(self.negative_sample_rate), int(self.n_negatives), self._neg_seed, float(self.early_exaggeration_coeff_),
+                        float(self.repulsion_strength), float(self._eps), None, self._current_lr(), _lib.ptr(self._nan_flag),
+                        int(_opt("POOL_GEOM")), _lib.stream_ptr(),
+                    ),
+                    "tdr_umap_pool_grad_step_f32",
+                )
+                self._pool_stepped = True
+            else:
+                _lib.check(
+                    L.tdr_umap_pool_grad_f32(
+                        _lib.ptr(self.embedding_), self.n_components, self.n_samples_in_, self.chunk_start_, self.chunk_size_,
+                        _lib.ptr(sc["list"]), _lib.ptr(sc["hdr"]), t - sc["t0"], float(self._a), float(self._b), t,
+                        int(self.negative_sample_rate), int(self.n_negatives), self._neg_seed, float(self.early_exaggeration_coeff_),
+                        float(self.repulsion_strength), float(self._eps), _lib.ptr(grad), int(_opt("POOL_GEOM")), _lib.stream_ptr(),
+                    ),
+                    "tdr_umap_pool_grad_f32",
+                )
             if prof:
                 self._prof_pending = (ev0, ev1, csr.nnz)     # closed after the SGD step (_sgd_kernel): one whole iteration
             return
@@ -446,7 +470,12 @@ class UMAP(NegativeSamplingNeighborEmbedding):
 
     def _sgd_kernel(self, Z, grad, chunk=False):
         if not getattr(self, "_sched_deferred", False):
-            super()._sgd_kernel(Z, grad, chunk=chunk)
+            if self.__dict__.pop("_pool_stepped", False):
+                # the gradient launch already wrote the stepped rows into the other buffer: the buffers swap roles (world_size > 1:
+                # the exchange that follows fills in the other ranks' rows there)
+                self.embedding_, self._Z_alt = self._Z_alt, self.embedding_
+            else:
+                super()._sgd_kernel(Z, grad, chunk=chunk)
             pend = self.__dict__.pop("_prof_pending", None)
             if pend is not None and PROFILE is not None:
                 pend[1].record()
@@ -656,6 +685,8 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         super().clear_memory()
         self.__dict__.pop("_g", None)
         self.__dict__.pop("_pool", None)
+        self.__dict__.pop("_Z_alt", None)
+        self.__dict__.pop("_pool_stepped", None)
         for attr in ("_csr", "_csr_loop", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf", "_grad_ws", "_sched", "_loop_cols"):
             if hasattr(self, attr):
                 delattr(self, attr)
