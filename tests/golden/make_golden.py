@@ -68,6 +68,17 @@ def knn_fixtures():
     save("knn", **flat)
 
 
+def knn_wide_fixture():
+    """D = 784 (MNIST-shaped): beyond K ~ 380 MKL's sgemm splits the contraction, so the reference's distances are no longer ONE
+    k-ordered fma chain (oracle/knn_oracle.c header; distance/torch.py:82-91) -- the fixture pins what the real reference returns
+    there; the points are regenerated from the seed by the tests (gmm(2048, 784, 2.0, seed=14))."""
+    X = gmm(2048, 784, 2.0, seed=14)
+    k = 15
+    C, I = pairwise_distances(X, metric="sqeuclidean", backend=None, exclude_diag=True, k=k, return_indices=True)
+    Cw, _ = pairwise_distances(X, metric="sqeuclidean", backend=None, exclude_diag=True, k=k + 8, return_indices=True)
+    save("knn_wide", n=2048, d=784, s=2.0, seed=14, k=k, C=C, I=I.to(torch.int32), Cw=Cw)
+
+
 def indexed_fixture():
     g = torch.Generator().manual_seed(5)
     Z = torch.randn(50, 2, generator=g)
@@ -1135,7 +1146,7 @@ def tsnekhorn64_fixture():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    ALL = dict(knn=knn_fixtures, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
+    ALL = dict(knn=knn_fixtures, knn_wide=knn_wide_fixture, indexed=indexed_fixture, affinity=affinity_fixtures, symmetrize=symmetrize_fixture,
                umap_step=umap_step_fixture, ne_step=ne_step_fixture, ne_step64=ne_step64_fixture, ne2_step=ne2_step_fixture,
                distributed=distributed_fixture, tsnekhorn=tsnekhorn_fixture, affinity_dense=dense_affinity_fixture,
                eval=eval_fixture, pacmap=pacmap_fixture, manhattan=manhattan_fixture,

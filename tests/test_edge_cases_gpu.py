@@ -289,3 +289,26 @@ def test_tsne_perplexity_100_runs():
     m = torchdr_amd.TSNE(perplexity=100, max_iter=30, random_state=0)
     Z = m.fit_transform(X)
     assert Z.shape == (3000, 2) and bool(torch.isfinite(Z).all())
+
+
+def test_wide_scan_at_d784_against_the_real_reference_reports_the_mismatch():
+    """the K-chunked MFMA scan (D > 256; one k-ordered fma chain per pair) against the REAL reference's output at
+    N = 2048, D = 784 (tests/golden/knn_wide.npz; MKL splits the contraction there, distance/torch.py:82-91): the mismatch is
+    REPORTED (gpurun_out/tolerance_audit.json) and bounded -- distances to the rounding of a 784-term sum, neighbour sets equal
+    wherever the k-th / (k+1)-th reference distances are 1e-4 apart -- and the scan equals the CPU oracle (same chain) bit for bit."""
+    import oracle
+    from tests.conftest import AUDIT, gmm
+    from tests.test_oracle_golden import load, wide_mismatch_report
+    from torchdr_amd.distance import pairwise_distances
+
+    g = load("knn_wide")
+    X = gmm(int(g["n"]), int(g["d"]), float(g["s"]), seed=int(g["seed"]))
+    k = int(g["k"])
+    C, I = pairwise_distances(X.cuda(), metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True)
+    rep = wide_mismatch_report(C.cpu(), I.cpu(), g)
+    AUDIT["knn_wide_d784/vs_real_reference"] = rep
+    print(rep)
+    assert rep["max_rel_distance_error"] < 1e-4 and rep["safe_rows_with_another_neighbour_set"] == 0.0, rep
+    assert rep["rows_with_another_neighbour_set"] < 0.02, rep
+    Co, Io = oracle.knn(X, k, "sqeuclidean", True)
+    assert torch.equal(C.cpu(), Co)

@@ -1285,11 +1285,10 @@ _GENERAL_BD = 65536   # database rows per block (4096 x 65536 fp32 = 1 GiB)
 
 def _knn_general(Xq, Y, k, metric, exclude_self, q_global0=0):
     """Exact kNN outside the LDS-resident lists of the scan kernels (k beyond their capacity, sqhyperbolic, and the
-    manhattan tile pass): per (query chunk x database chunk) block a plain library GEMM (``torch.mm`` = rocBLAS /
-    hipBLASLt) forms X Y^T and ``tdr_topk_merge_f32`` does the rest of the reference's op sequence (norm expansion,
-    self exclusion, running top-k in the canonical (distance, index) order).  Values agree with the reference to fp32
-    rounding (the library's summation order is not MKL's), not bit for bit.  D > 256 with an MFMA metric goes to
-    ``_knn_wide`` first."""
+    manhattan tile pass): per (query chunk x database chunk) block the package's own fp32-MFMA tile kernel forms X Y^T
+    (``_gram``; a library GEMM until round 6) and ``tdr_topk_merge_f32`` does the rest of the reference's op sequence (norm
+    expansion, self exclusion, running top-k in the canonical (distance, index) order).  D > 256 with an MFMA metric goes
+    to ``_knn_wide`` first."""
     L = _lib.lib()
     nq, nd = Xq.shape[0], Y.shape[0]
     if metric in ("sqeuclidean", "euclidean", "angular") and Y.shape[1] > 256 and _opt("WIDE_SCAN"):
@@ -1313,7 +1312,7 @@ def _knn_general(Xq, Y, k, metric, exclude_self, q_global0=0):
         Xc = Xq[q0:q1]
         for d0 in range(0, nd, _GENERAL_BD):
             d1 = min(d0 + _GENERAL_BD, nd)
-            G = _l1_block(Xc, Y[d0:d1]) if l1 else torch.mm(Xc, Y[d0:d1].t())
+            G = _l1_block(Xc, Y[d0:d1]) if l1 else _gram(Xc, Y[d0:d1])
             _lib.check(
                 L.tdr_topk_merge_f32(_lib.ptr(G), G.stride(0), q1 - q0, d1 - d0, _lib.ptr(None if l1 else xn[q0:q1]),
                                      _lib.ptr(None if l1 else yn[d0:d1]),
@@ -1323,7 +1322,7 @@ def _knn_general(Xq, Y, k, metric, exclude_self, q_global0=0):
     out_d = torch.empty((nq, k), dtype=torch.float32, device=dev)
     out_i = torch.empty((nq, k), dtype=torch.int32, device=dev)
     _lib.check(L.tdr_topk_emit_f32(_lib.ptr(keys), nq, k, mid, _lib.ptr(out_d), _lib.ptr(out_i), st), "tdr_topk_emit_f32")
-    LAST_KNN["path"] = "manhattan (L1 tile kernel + top-k merge)" if l1 else "general-D (library GEMM + top-k merge)"
+    LAST_KNN["path"] = "manhattan (L1 tile kernel + top-k merge)" if l1 else "general-D (MFMA Gram tiles + top-k merge)"
     LAST_KNN["flagged"] = 0
     return out_d, out_i
 
@@ -1416,6 +1415,23 @@ def _l1_block(X, Y):
     return out
 
 
+def _gram(X, Y):
+    """X Y^T by the package's own fp32-MFMA tile kernels (the "angular" epilogue is -x.y): one k-ordered fma chain per entry -- what
+    the reference's sgemm computes for D <= ~380 -- instead of a library GEMM (round 6: the last two `torch.mm` call sites on the
+    path -- the sqhyperbolic forms and the comparison form of the general-D search -- went through rocBLAS)."""
+    if X.shape[1] <= 256:
+        return dense_packed(PackedPoints(X), PackedPoints(Y), "angular", False).neg_()
+    Yp = WidePackedPoints(Y)
+    Qp = Yp if X is Y else WidePackedPoints(X)
+    out = torch.empty((Qp.n, Yp.n), dtype=torch.float32, device=Yp.device)
+    _lib.check(
+        _lib.lib().tdr_dense_dist_wide_f32(_lib.ptr(Qp.data), Qp.n, 0, _lib.ptr(Yp.data), Yp.n, Yp.d, _METRIC_ID["angular"], 0, _DIAG_ADD,
+                                           _lib.ptr(out), out.stride(0), _lib.stream_ptr()),
+        "tdr_dense_dist_wide_f32",
+    )
+    return out.neg_()
+
+
 def _dense_general(X, Y, metric, exclude_self):
     """Dense distance matrix outside the register-resident kernels (distance/torch.py:82-116): D > 256 on the wide tile
     kernel, sqhyperbolic with a library GEMM, manhattan on the L1 kernel."""
@@ -1435,7 +1451,7 @@ def _dense_general(X, Y, metric, exclude_self):
             "tdr_dense_dist_wide_f32",
         )
         return out
-    G = torch.mm(X, Y.t())
+    G = _gram(X, Y) if Y.shape[0] <= 65535 * 32 else torch.mm(X, Y.t())
     if metric == "sqhyperbolic":  # distance/torch.py:101-107
         xn, yn = (X * X).sum(1).contiguous(), (Y * Y).sum(1).contiguous()
         for r0 in range(0, G.shape[0], 32768):
