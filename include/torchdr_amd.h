@@ -317,6 +317,10 @@ int tdr_pca_project_f32(const float* X, int64_t n, int d, int64_t ldx, const flo
  * Jacobi in one workgroup, no host read -- evals (d) descending, evecs (d, d) row-major with column r the eigenvector of
  * evals[r]; G symmetric positive semi-definite, d <= 256; ws = 2 d^2 doubles. */
 int tdr_eigh_jacobi_f64(const double* G, int d, double* evals, double* evecs, double* ws, void* stream);
+/* the same eigenproblem when only the nc <= 4 LEADING pairs are wanted (n_components of the PCA initialisation): Householder
+ * tridiagonalisation + Sturm multisection + inverse iteration in one workgroup, no host read, same bits on every rank -- evals
+ * (nc) descending, evecs (d, nc) row-major with unit columns; G symmetric, d <= 256, nc <= min(d, 4); ws = d^2 doubles. */
+int tdr_eigh_top_f64(const double* G, int d, int nc, double* evals, double* evecs, double* ws, void* stream);
 
 /* ---- K5 / K6 / K9: embedding loop ----------------------------------------------------------------- */
 /* neighbor_embedding/umap.py:215-234 */

@@ -115,16 +115,85 @@ def test_jacobi_eigh_vs_lapack(d):
     assert float((V.T @ V - torch.eye(d, dtype=torch.float64)).abs().max()) < 1e-11
 
 
-def test_pca_scores_same_with_either_eigensolver():
+@pytest.mark.parametrize("d", [1, 2, 3, 7, 50, 64, 128, 129, 200, 256])
+def test_top_eigh_vs_lapack(d):
+    """tdr_eigh_top_f64 (the leading pairs of the PCA initialisation's eigenproblem: Householder + Sturm multisection + inverse
+    iteration) against LAPACK in float64 on the host: eigenvalues to 1e-12 of the largest, residual |G V - V diag(lambda)| and
+    orthonormality at the same level, for every nc the kernel serves; rank-deficient Gram matrices included."""
+    from torchdr_amd import _lib
+
+    gen = torch.Generator().manual_seed(100 + d)
+    n = 40 if d in (50, 129) else 2000          # 40 < d: rank-deficient
+    X = torch.randn(n, d, generator=gen, dtype=torch.float64) * (torch.rand(d, generator=gen, dtype=torch.float64) * 3 + 0.1)
+    X = X - X.mean(0)
+    G = (X.T @ X).contiguous()
+    ref = torch.linalg.eigvalsh(G).flip(0)
+    scale = float(ref[0])
+    Gd = G.cuda()
+    ws = torch.empty(d * d, dtype=torch.float64, device="cuda")
+    for nc in range(1, min(d, 4) + 1):
+        evals = torch.empty(nc, dtype=torch.float64, device="cuda")
+        evecs = torch.empty((d, nc), dtype=torch.float64, device="cuda")
+        _lib.check(_lib.lib().tdr_eigh_top_f64(_lib.ptr(Gd), d, nc, _lib.ptr(evals), _lib.ptr(evecs), _lib.ptr(ws), _lib.stream_ptr()),
+                   "tdr_eigh_top_f64")
+        ev, V = evals.cpu(), evecs.cpu()
+        assert float((ev - ref[:nc]).abs().max()) < 1e-12 * scale, (d, nc)
+        assert float((G @ V - V * ev[None, :]).abs().max()) < 1e-11 * scale, (d, nc)
+        assert float((V.T @ V - torch.eye(nc, dtype=torch.float64)).abs().max()) < 1e-11, (d, nc)
+    assert torch.equal(Gd.cpu(), G)       # the input is left alone
+
+
+def test_top_eigh_degenerate_spectra():
+    """Equal leading eigenvalues (any orthonormal basis of the eigenspace is an answer: residual + orthonormality), an already
+    diagonal matrix (every Householder step is the identity), the zero matrix, and the bad-argument returns."""
+    from torchdr_amd import _lib
+
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(5)
+    Q, _ = torch.linalg.qr(torch.randn(40, 40, generator=gen, dtype=torch.float64))
+    cases = [Q @ torch.diag(torch.cat([torch.full((3,), 7.0), torch.ones(37)]).double()) @ Q.T,
+             torch.diag(torch.tensor([5.0, 5.0, 5.0, 1.0, 1.0], dtype=torch.float64)),
+             torch.ones(5, 5, dtype=torch.float64), torch.zeros(4, 4, dtype=torch.float64)]
+    for G in cases:
+        G = ((G + G.T) / 2).contiguous()
+        d = G.shape[0]
+        ref = torch.linalg.eigvalsh(G).flip(0)
+        evals = torch.empty(4, dtype=torch.float64, device="cuda")
+        evecs = torch.empty((d, 4), dtype=torch.float64, device="cuda")
+        ws = torch.empty(d * d, dtype=torch.float64, device="cuda")
+        _lib.check(L.tdr_eigh_top_f64(_lib.ptr(G.cuda()), d, 4, _lib.ptr(evals), _lib.ptr(evecs), _lib.ptr(ws), _lib.stream_ptr()), "top")
+        ev, V = evals.cpu(), evecs.cpu()
+        scale = max(float(ref[0].abs()), 1.0)
+        assert float((ev - ref[:4]).abs().max()) < 1e-12 * scale
+        assert float((G @ V - V * ev[None, :]).abs().max()) < 1e-11 * scale
+        assert float((V.T @ V - torch.eye(4, dtype=torch.float64)).abs().max()) < 1e-11
+    g = torch.eye(3, dtype=torch.float64, device="cuda")
+    out = torch.empty(16, dtype=torch.float64, device="cuda")
+    assert L.tdr_eigh_top_f64(_lib.ptr(g), 3, 4, _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), None) != 0      # nc > d
+    assert L.tdr_eigh_top_f64(_lib.ptr(g), 3, 0, _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), None) != 0
+    assert L.tdr_eigh_top_f64(_lib.ptr(g), 257, 2, _lib.ptr(out), _lib.ptr(out), _lib.ptr(out), None) != 0
+
+
+def test_pca_scores_same_with_every_eigensolver():
     from torchdr_amd import affinity_matcher as am
 
-    X = gmm(20000, 64, 2.0, seed=9).cuda()
-    old = am.PCA_EIGH
-    try:
-        am.PCA_EIGH = "jacobi"
-        a = am.pca_scores(X, 2)
-        am.PCA_EIGH = "library"
-        b = am.pca_scores(X, 2)
-    finally:
-        am.PCA_EIGH = old
-    assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max()))
+    for n, d, nc in ((20000, 64, 2), (5000, 256, 3), (3000, 100, 4)):
+        X = gmm(n, d, 2.0, seed=9).cuda()
+        old = am.PCA_EIGH
+        got = {}
+        try:
+            for mode in ("top", "jacobi", "library"):
+                am.PCA_EIGH = mode
+                got[mode] = am.pca_scores(X, nc)
+                assert am.pca_scores.deterministic == (mode != "library")
+        finally:
+            am.PCA_EIGH = old
+        b = got["library"]
+        for mode in ("top", "jacobi"):
+            assert torch.allclose(got[mode], b, rtol=1e-4, atol=1e-4 * float(b.abs().max())), (mode, n, d)
+        # same bits from call to call (what lets a row-sharded fit skip the reference's broadcast of the initial embedding)
+        am.PCA_EIGH = "top"
+        try:
+            assert torch.equal(am.pca_scores(X, nc), got["top"])
+        finally:
+            am.PCA_EIGH = old

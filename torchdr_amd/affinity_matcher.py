@@ -178,7 +178,7 @@ class AffinityMatcher(DRModule):
         reads anything back) are enqueued on a side stream now and run under the kNN search; `_init_embedding` waits for
         that stream.  3.5 ms of the N = 1M fit."""
         self._pca_prefetch = None
-        if not (_opt("PCA_PREFETCH") and _opt("PCA_EIGH") == "jacobi" and isinstance(self.init, str) and self.init == "pca"):
+        if not (_opt("PCA_PREFETCH") and _opt("PCA_EIGH") in ("top", "jacobi") and isinstance(self.init, str) and self.init == "pca"):
             return
         if not X.is_cuda or X.dtype != torch.float32 or X.shape[1] > 256 or self.n_components > 4:
             return
@@ -529,9 +529,11 @@ class AffinityMatcher(DRModule):
             self.embedding_ = self.embedding_.detach()
 
 
-# D x D eigenproblem of the PCA initialisation: "jacobi" = tdr_eigh_jacobi_f64 (one workgroup, no host read), "library" =
-# torch.linalg.eigh (rocSOLVER; reads its status word back, i.e. synchronises the host with the stream)
-PCA_EIGH = "jacobi"
+# D x D eigenproblem of the PCA initialisation: "top" = tdr_eigh_top_f64 (the n_components leading pairs by Householder +
+# multisection + inverse iteration: one workgroup, no host read, ~0.5 ms at D = 128), "jacobi" = tdr_eigh_jacobi_f64 (the whole
+# decomposition, one workgroup, no host read: 12.5 ms at D = 128, 127 ms at D = 256), "library" = torch.linalg.eigh (rocSOLVER;
+# reads its status word back, i.e. synchronises the host with the stream)
+PCA_EIGH = "top"
 # enqueue the PCA initialisation on a side stream at the start of the fit (it runs under the kNN search)
 PCA_PREFETCH = True
 _PREFETCH_STREAMS = {}
@@ -550,7 +552,7 @@ def pca_scores(X: torch.Tensor, n_components: int) -> torch.Tensor:
 
     Computed from the D x D covariance eigen-decomposition instead of a thin SVD of the N x D block: column means and
     the Gram matrix of the centred block by ``tdr_pca_gram_f32`` (fp32 matrix pipe, deterministic fp64 combination), the
-    D x D eigenproblem by ``tdr_eigh_jacobi_f64`` (one-sided Jacobi in one workgroup), and the projection by
+    leading pairs of the D x D eigenproblem by ``tdr_eigh_top_f64`` (one workgroup, no host read), and the projection by
     ``tdr_pca_project_f32``.  Same subspace and signs, O(N D^2) on the GPU.  Initialisation only -- the scores are
     rescaled to std 1e-4 right after (A.5).  D > 256 or more than 4 components use torch ops."""
     n, d = X.shape
@@ -573,9 +575,16 @@ def pca_scores(X: torch.Tensor, n_components: int) -> torch.Tensor:
         _lib.check(L.tdr_pca_gram_f32(_lib.ptr(X), n, d, X.stride(0), _lib.ptr(mean), _lib.ptr(G), _lib.ptr(ws), ws_floats,
                                       _lib.stream_ptr()), "tdr_pca_gram_f32")
         # same bits on every rank of a row-sharded fit only on this branch (ordered fp64 combination of the Gram tiles, one-
-        # workgroup Jacobi): NeighborEmbedding._init_embedding skips the reference's broadcast (:421) when it was taken
-        pca_scores.deterministic = _opt("PCA_EIGH") == "jacobi"
-        if _opt("PCA_EIGH") == "jacobi":    # one workgroup, no host read (csrc/tdr_prep.hip)
+        # workgroup eigensolver): NeighborEmbedding._init_embedding skips the reference's broadcast (:421) when it was taken
+        pca_scores.deterministic = _opt("PCA_EIGH") in ("top", "jacobi")
+        if _opt("PCA_EIGH") == "top" and n_components <= d:    # leading pairs only, one workgroup, no host read (csrc/tdr_prep.hip)
+            evals = torch.empty(n_components, dtype=torch.float64, device=X.device)
+            evecs = torch.empty((d, n_components), dtype=torch.float64, device=X.device)
+            ews = torch.empty(d * d, dtype=torch.float64, device=X.device)
+            _lib.check(L.tdr_eigh_top_f64(_lib.ptr(G), d, n_components, _lib.ptr(evals), _lib.ptr(evecs), _lib.ptr(ews),
+                                          _lib.stream_ptr()), "tdr_eigh_top_f64")
+            V = evecs.to(torch.float32).contiguous()
+        elif _opt("PCA_EIGH") in ("top", "jacobi"):    # the whole decomposition, one workgroup, no host read
             evals = torch.empty(d, dtype=torch.float64, device=X.device)
             evecs = torch.empty((d, d), dtype=torch.float64, device=X.device)
             ews = torch.empty(2 * d * d, dtype=torch.float64, device=X.device)

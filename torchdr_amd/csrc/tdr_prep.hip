@@ -320,6 +320,266 @@ __global__ __launch_bounds__(EIG_TH) void eigh_jacobi_kernel(const double* __res
     }
 }
 
+// ---- the LEADING eigenpairs only (round 6; what the PCA initialisation needs: n_components <= 4 of D <= 256) ----------------
+// The one-workgroup Jacobi above decomposes the whole matrix: 12.5 ms at D = 128 and 127 ms at D = 256 -- hidden under the kNN
+// search of a single-GPU fit, but as long as a rank's whole kNN stage in an 8-rank fit (profiles/r06_rank_share_c4_first.jsonl:
+// the projection waited for it).  Here, still ONE workgroup and no host read (same bits on every rank):
+//   1. Householder tridiagonalisation of the full symmetric matrix in the workspace A (L2-resident): D - 2 steps of one
+//      column-sum product p = beta A v (thread (g, j) sums rows i = g mod G of column j: coalesced), w = p - (beta v.p / 2) v and
+//      the rank-2 update A -= v w^T + w v^T (rounded products added, so A stays symmetric bit for bit); reflector k stays in
+//      row k of A for step 4;
+//   2. the nc largest eigenvalues of the tridiagonal matrix by Sturm-count MULTISECTION: 256 threads per eigenvalue evaluate
+//      the count at 256 interior points of the bracket, 9 rounds shrink it 257^9-fold (below one ulp);
+//   3. inverse iteration on T - lambda I (tridiagonal LU with partial pivoting, one thread per eigenvalue, three solves from a
+//      hashed start vector), then modified Gram-Schmidt among the nc vectors (equal / close eigenvalues);
+//   4. back-transformation by the reflectors in reverse order, one wavefront per vector (butterfly sums: same bits in all lanes).
+constexpr int EIGT_TH = 1024;
+constexpr int EIGT_MAX_NC = 4;
+__device__ __forceinline__ double wave_sum_f64(double s) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    return s;
+}
+__global__ __launch_bounds__(EIGT_TH) void eigh_top_kernel(const double* __restrict__ G, int d, int nc, double* A,
+                                                           double* __restrict__ evals, double* __restrict__ evecs) {
+    constexpr int MD = EIG_MAX_D;
+    __shared__ double diag[MD], off[MD], betas[MD];
+    __shared__ double scal[8];
+    __shared__ double un[MD + 4 * 4 * MD + EIGT_MAX_NC * MD];   // phase 1: x, v, w, part[1024]; phase 2: e2, lu[4][4][MD], y[4][MD]
+    __shared__ unsigned char piv[EIGT_MAX_NC][MD];
+    __shared__ int cnt[EIGT_MAX_NC];
+    __shared__ double lam[EIGT_MAX_NC];
+    double* x = un;
+    double* v = un + MD;
+    double* w = un + 2 * MD;
+    double* part = un + 3 * MD;       // G_ * dc = 1024 entries
+    double* e2 = un;
+    double* lu = un + MD;             // [q][4][MD]: dl, b, c, du2
+    double* yv = un + MD + 4 * 4 * MD;    // [q][MD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    int dc = 64;
+    while (dc < d) dc <<= 1;
+    const int G_ = EIGT_TH / dc, g = tid / dc, j = tid % dc;
+    const int npl = dc / 64;          // elements of a length-d vector a lane of ONE wavefront holds (lane + 64 c)
+    for (int e = tid; e < d * d; e += EIGT_TH) A[e] = G[e];
+    __threadfence_block();  // one workgroup = one CU = one L1 (as in eigh_jacobi_kernel)
+    __syncthreads();
+    // 1. tridiagonalisation
+    for (int k = 0; k + 2 < d; ++k) {
+        if (g == 0 && j < d) x[j] = j > k ? A[(size_t)k * d + j] : 0.0;
+        if (tid == 0) diag[k] = A[(size_t)k * d + k];
+        __syncthreads();
+        if (tid < 64) {
+            double s = 0.0;
+            for (int c = 0; c < npl; ++c) { const int jj = lane + 64 * c; const double xv = jj < d ? x[jj] : 0.0; s = fma(xv, xv, s); }
+            s = wave_sum_f64(s);
+            const double x1 = x[k + 1];
+            double alpha = 0.0, beta = 0.0;
+            if (s > 0.0) {
+                alpha = x1 >= 0.0 ? -sqrt(s) : sqrt(s);
+                beta = 2.0 / (2.0 * s - 2.0 * alpha * x1);
+            }
+            for (int c = 0; c < npl; ++c) {
+                const int jj = lane + 64 * c;
+                if (jj < MD) v[jj] = (jj < d && s > 0.0) ? (jj == k + 1 ? x1 - alpha : x[jj]) : 0.0;
+            }
+            if (lane == 0) { off[k] = alpha; betas[k] = beta; scal[0] = beta; }
+        }
+        __syncthreads();
+        const double beta = scal[0];
+        if (beta != 0.0) {   // the same for every thread
+            const bool mine = j < d && j > k;
+            if (g == 0 && mine) A[(size_t)k * d + j] = v[j];
+            if (mine) {
+                double s = 0.0;
+                for (int i = k + 1 + g; i < d; i += G_) s = fma(A[(size_t)i * d + j], v[i], s);
+                part[g * dc + j] = s;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                double pj[EIG_MAX_D / 64];
+                double kp = 0.0;
+                for (int c = 0; c < npl; ++c) {
+                    const int jj = lane + 64 * c;
+                    pj[c] = 0.0;
+                    if (jj < d && jj > k) {
+                        double s = 0.0;
+                        for (int gg = 0; gg < G_; ++gg) s += part[gg * dc + jj];
+                        pj[c] = beta * s;
+                        kp = fma(v[jj], pj[c], kp);
+                    }
+                }
+                kp = wave_sum_f64(kp);
+                const double K = 0.5 * beta * kp;
+                for (int c = 0; c < npl; ++c) {
+                    const int jj = lane + 64 * c;
+                    if (jj < MD) w[jj] = (jj < d && jj > k) ? pj[c] - K * v[jj] : 0.0;
+                }
+            }
+            __syncthreads();
+            if (mine) {
+                const double vj = v[j], wj = w[j];
+                for (int i = k + 1 + g; i < d; i += G_) {
+                    const double t1 = v[i] * wj, t2 = w[i] * vj;     // (i, j) and (j, i) add the same two rounded products
+                    A[(size_t)i * d + j] -= t1 + t2;
+                }
+            }
+            __threadfence_block();
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (d >= 2) { diag[d - 2] = A[(size_t)(d - 2) * d + d - 2]; off[d - 2] = A[(size_t)(d - 2) * d + d - 1]; }
+        diag[d - 1] = A[(size_t)(d - 1) * d + d - 1];
+        off[d - 1] = 0.0;
+    }
+    __syncthreads();
+    // 2. brackets (Gershgorin), pivot floor, squared off-diagonals
+    if (tid < 64) {
+        double tn = 0.0, glo = 1e300, ghi = -1e300;
+        for (int c = 0; c < npl; ++c) {
+            const int jj = lane + 64 * c;
+            if (jj < d) {
+                const double r = fabs(off[jj]) + (jj > 0 ? fabs(off[jj - 1]) : 0.0);
+                tn = fmax(tn, fmax(fabs(diag[jj]), fabs(off[jj])));
+                glo = fmin(glo, diag[jj] - r);
+                ghi = fmax(ghi, diag[jj] + r);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            tn = fmax(tn, __shfl_xor(tn, o, 64)); glo = fmin(glo, __shfl_xor(glo, o, 64)); ghi = fmax(ghi, __shfl_xor(ghi, o, 64));
+        }
+        if (lane == 0) {
+            const double et = 2.220446049250313e-16 * tn;
+            const double pivmin = fmax(2.2250738585072014e-298, et * et);
+            const double span = ghi - glo;
+            scal[1] = tn; scal[2] = glo - (1e-12 * span + pivmin); scal[3] = ghi + (1e-12 * span + pivmin); scal[4] = pivmin;
+        }
+    }
+    __syncthreads();   // phase 1's x, v, w, part are dead from here
+    if (g == 0 && j < d) e2[j] = off[j] * off[j];
+    const double tn = scal[1], pivmin = scal[4];
+    const int q = tid >> 8, t = tid & 255;
+    const bool active = q < nc;
+    if (tn == 0.0) {       // the zero matrix
+        if (tid < nc) evals[tid] = 0.0;
+        for (int e = tid; e < d * nc; e += EIGT_TH) evecs[e] = (e / nc == e % nc) ? 1.0 : 0.0;
+        return;
+    }
+    __syncthreads();
+    {
+        double lo = scal[2], hi = scal[3];
+        const int idx = d - 1 - q;      // ascending index of the q-th largest eigenvalue
+        for (int it = 0; it < 9; ++it) {
+            if (t == 0 && active) cnt[q] = 0;
+            __syncthreads();
+            if (active) {
+                const double xs = lo + (hi - lo) * ((double)(t + 1) / 257.0);
+                int c = 0;
+                double qq = diag[0] - xs;
+                if (fabs(qq) < pivmin) qq = -pivmin;
+                c += qq < 0.0;
+                for (int i = 1; i < d; ++i) {
+                    qq = diag[i] - xs - e2[i - 1] / qq;
+                    if (fabs(qq) < pivmin) qq = -pivmin;
+                    c += qq < 0.0;
+                }
+                if (c <= idx) atomicAdd(&cnt[q], 1);
+            }
+            __syncthreads();
+            if (active) {
+                const int T = cnt[q];
+                const double nlo = T > 0 ? lo + (hi - lo) * ((double)T / 257.0) : lo;
+                const double nhi = T < 256 ? lo + (hi - lo) * ((double)(T + 1) / 257.0) : hi;
+                lo = nlo; hi = nhi;
+            }
+            __syncthreads();
+        }
+        if (active && t == 0) lam[q] = 0.5 * (lo + hi);
+    }
+    __syncthreads();
+    // 3. inverse iteration, one thread per eigenvalue
+    if (active && t == 0) {
+        double* dl = lu + (size_t)q * 4 * MD;
+        double* b = dl + MD;
+        double* c = b + MD;
+        double* du2 = c + MD;
+        double* y = yv + (size_t)q * MD;
+        const double l = lam[q], eps3 = 2.220446049250313e-16 * tn;
+        for (int i = 0; i < d; ++i) { dl[i] = off[i]; b[i] = diag[i] - l; c[i] = i + 1 < d ? off[i] : 0.0; du2[i] = 0.0; piv[q][i] = 0; }
+        for (int i = 0; i + 1 < d; ++i) {
+            if (fabs(b[i]) >= fabs(dl[i])) {
+                if (b[i] == 0.0) b[i] = eps3;
+                const double f = dl[i] / b[i];
+                dl[i] = f; b[i + 1] -= f * c[i];
+            } else {
+                const double f = b[i] / dl[i];
+                b[i] = dl[i]; dl[i] = f;
+                const double tmp = c[i];
+                c[i] = b[i + 1]; b[i + 1] = tmp - f * c[i];
+                du2[i] = c[i + 1]; c[i + 1] = -f * du2[i];
+                piv[q][i] = 1;
+            }
+        }
+        if (b[d - 1] == 0.0) b[d - 1] = eps3;
+        for (int i = 0; i < d; ++i) y[i] = (double)(mix64((uint64_t)(i * 4 + q + 1)) >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+        for (int itr = 0; itr < 3; ++itr) {
+            for (int i = 0; i + 1 < d; ++i) {
+                if (!piv[q][i]) y[i + 1] -= dl[i] * y[i];
+                else { const double tmp = y[i]; y[i] = y[i + 1]; y[i + 1] = tmp - dl[i] * y[i + 1]; }
+            }
+            y[d - 1] /= b[d - 1];
+            if (d >= 2) y[d - 2] = (y[d - 2] - c[d - 2] * y[d - 1]) / b[d - 2];
+            for (int i = d - 3; i >= 0; --i) y[i] = (y[i] - c[i] * y[i + 1] - du2[i] * y[i + 2]) / b[i];
+            double m = 0.0;
+            for (int i = 0; i < d; ++i) m = fmax(m, fabs(y[i]));
+            const double r = 1.0 / m;
+            for (int i = 0; i < d; ++i) y[i] *= r;
+        }
+    }
+    __syncthreads();
+    // modified Gram-Schmidt among the nc vectors (wavefront 0), unit norm
+    if (tid < 64) {
+        for (int a = 0; a < nc; ++a) {
+            double ya[EIG_MAX_D / 64];
+            for (int c = 0; c < npl; ++c) { const int jj = lane + 64 * c; ya[c] = jj < d ? yv[a * MD + jj] : 0.0; }
+            for (int p = 0; p < a; ++p) {
+                double s = 0.0;
+                for (int c = 0; c < npl; ++c) { const int jj = lane + 64 * c; if (jj < d) s = fma(ya[c], yv[p * MD + jj], s); }
+                s = wave_sum_f64(s);
+                for (int c = 0; c < npl; ++c) { const int jj = lane + 64 * c; if (jj < d) ya[c] -= s * yv[p * MD + jj]; }
+            }
+            double s = 0.0;
+            for (int c = 0; c < npl; ++c) s = fma(ya[c], ya[c], s);
+            s = 1.0 / sqrt(wave_sum_f64(s));
+            for (int c = 0; c < npl; ++c) { const int jj = lane + 64 * c; if (jj < d) yv[a * MD + jj] = ya[c] * s; }
+        }
+    }
+    __syncthreads();
+    // 4. back-transformation: wavefront a applies the reflectors d-3 .. 0 to vector a
+    const int a = tid >> 6;
+    if (a < nc) {
+        double ya[EIG_MAX_D / 64];
+        for (int c = 0; c < npl; ++c) { const int jj = lane + 64 * c; ya[c] = jj < d ? yv[a * MD + jj] : 0.0; }
+        for (int k = d - 3; k >= 0; --k) {
+            const double beta = betas[k];
+            if (beta == 0.0) continue;
+            double vr[EIG_MAX_D / 64];
+            double s = 0.0;
+            for (int c = 0; c < npl; ++c) {
+                const int jj = lane + 64 * c;
+                vr[c] = (jj < d && jj > k) ? A[(size_t)k * d + jj] : 0.0;
+                s = fma(vr[c], ya[c], s);
+            }
+            s = beta * wave_sum_f64(s);
+            for (int c = 0; c < npl; ++c) ya[c] -= s * vr[c];
+        }
+        for (int c = 0; c < npl; ++c) { const int jj = lane + 64 * c; if (jj < d) evecs[(size_t)jj * nc + a] = ya[c]; }
+        if (lane == 0) evals[a] = lam[a];
+    }
+}
+
 }  // namespace tdr
 
 using namespace tdr;
@@ -439,6 +699,17 @@ int tdr_eigh_jacobi_f64(const double* G, int d, double* evals, double* evecs, do
     if (d > EIG_MAX_D) return TDR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(eigh_jacobi_kernel, dim3(1), dim3(EIG_TH), 0, (hipStream_t)stream, G, d, ws, ws + (size_t)d * d, evals, evecs, 40,
                        1e-15);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* The nc <= 4 LARGEST eigenpairs of a symmetric d x d matrix (d <= 256, nc <= d) without a host read: evals (nc) descending,
+ * evecs (d, nc) row-major with unit columns; ws = d^2 doubles (eigh_top_kernel: Householder + Sturm multisection + inverse
+ * iteration in one workgroup; ~0.5 ms at d = 128 where the full Jacobi decomposition takes 12.5). */
+int tdr_eigh_top_f64(const double* G, int d, int nc, double* evals, double* evecs, double* ws, void* stream) {
+    if (!G || !evals || !evecs || !ws || d <= 0 || nc <= 0 || nc > d) return TDR_ERR_BAD_ARG;
+    if (d > EIG_MAX_D || nc > EIGT_MAX_NC) return TDR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(eigh_top_kernel, dim3(1), dim3(EIGT_TH), 0, (hipStream_t)stream, G, d, nc, ws, evals, evecs);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
