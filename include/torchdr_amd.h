@@ -458,6 +458,9 @@ typedef struct tdr_umap_loop_desc {
     int pool;            /* 0: i.i.d. negatives gathered from L2; g + 1: negatives from the LDS pool, geometry g (tdr_umap_pool_grad_f32; n_slices = 1) */
     int gather_capturable;   /* 1: the gather callback enqueues kernels only and bakes no per-call state into their arguments
                                 (tdr_peerx_allgather_rows since round 6, tdr_emulx_allgather_rows): windows are captured and replayed with it */
+    float* Z_alt;            /* optional second embedding buffer (n_total, nc), 16-byte aligned, != Z: with pool negatives and momentum 0 the
+                                gradient launch carries the SGD step -- iteration t of a window reads buffer t & 1 and writes the other, the
+                                gather callback is handed the written one; every window ends with the current rows in Z */
 } tdr_umap_loop_desc;
 int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d);
 int tdr_umap_loop_run(void* loop, int it0, int n_iters, int use_graph, void* stream);
@@ -532,6 +535,10 @@ int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_i
  * visit per row), 0 (default) = split where the negatives dominate a row (>= 64 items) and the gathered tables exceed an XCD's
  * L2; returns the previous value */
 int tdr_ne_grad_perm_halves(int mode);
+/* measurement / test switch of tdr_ne_grad_perm_f32's LargeVis launch (kind 0, <= 8 negatives, 2 / 3 components): lanes per row --
+ * 4 (default since round 6: every lane issues all its index loads and gathers before it uses any) or 16 (rounds 3-5); same terms,
+ * another association of a row's fp32 sum; returns the previous value */
+int tdr_ne_grad_perm_lanes(int lanes);
 /* tdr_ne_grad_f32 with the negatives drawn as keyed permutations of the rows (kinds 0 = LargeVis, 3 = InfoTSNE): a row pulls
  * its own draws j = P(i) AND the draws that hit it (i' = P^-1(i)) -- no atomics on the far endpoints.  Per row the draws are
  * uniform and independent across columns / iterations like neighbor_embedding/base.py:628-636; within one column they are

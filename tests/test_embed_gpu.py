@@ -647,6 +647,74 @@ def test_permutation_gradient_equals_the_scatter_form_on_the_same_negatives(kind
     grade32(f"perm_pull_vs_oracle_closed_form/kind={kind}", g1, ref, BUDGET)
 
 
+@pytest.mark.parametrize("nc,k,n_neg", [(2, 15, 5), (3, 15, 5), (2, 45, 8), (2, 7, 1)])
+def test_four_lanes_per_row_pull_kernel_equals_the_sixteen_lane_form(nc, k, n_neg):
+    """LargeVis with the permutation sampler: ne_pull4_kernel (4 lanes per row, every index load and gather of a lane issued before
+    the first use; round 6) against ne_grad_kernel (16 lanes per row) on the same graph -- a kNN block wider than one batch
+    (k = 45), hub rows with hundreds of in-edges, rows without in-edges, row counts that end inside a workgroup.  Same terms,
+    another association of a row's fp32 sum; and against the closed form in float64 on sampled rows."""
+    from torchdr_amd import _lib
+    from torchdr_amd.neighbor_embedding.base import build_transposed_graph
+
+    L = _lib.lib()
+    n = 30_011
+    gen = torch.Generator().manual_seed(nc * 100 + k)
+    NN = torch.randint(0, n - 1, (n, k), generator=gen)
+    NN[:, 0] = torch.randint(0, 40, (n,), generator=gen)          # 40 hub rows collect ~750 in-edges each
+    NN = NN + (NN >= torch.arange(n)[:, None]).long()             # no self edges
+    NN = NN.to(torch.int32).cuda().contiguous()
+    P = (torch.rand(n, k, generator=gen) / k).cuda().contiguous()
+    Z = (torch.randn(n, nc, generator=gen) * 2).cuda().contiguous()
+    tg = build_transposed_graph(P, NN, 0, n, 1)
+    ws = torch.empty(n, dtype=torch.float32, device="cuda")
+
+    def run(lanes):
+        old = L.tdr_ne_grad_perm_lanes(lanes)
+        try:
+            g = torch.zeros((n, nc), device="cuda")
+            _lib.check(L.tdr_ne_grad_perm_f32(_lib.ptr(Z), nc, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]),
+                                              _lib.ptr(tg[2]), 0, 3.0, 2.0 / n, n_neg, 77, 3, _lib.ptr(ws), _lib.ptr(g), _lib.stream_ptr()), "perm")
+        finally:
+            L.tdr_ne_grad_perm_lanes(old)
+        return g
+
+    four, sixteen = run(4), run(16)
+    assert L.tdr_ne_grad_perm_lanes(4) == 4          # the default
+    assert float(sixteen.abs().max()) > 0 and bool(torch.isfinite(four).all())
+    assert torch.equal(run(4), four)
+    grade32(f"ne_pull4_vs_sixteen_lanes/nc={nc}/k={k}/n_neg={n_neg}", four, sixteen, BUDGET)
+    # closed form in float64 on the hubs and on sampled rows
+    fwd = torch.empty((n, n_neg), dtype=torch.int64, device="cuda")
+    inv = torch.empty((n, n_neg), dtype=torch.int64, device="cuda")
+    _lib.check(L.tdr_perm_negatives_debug(77, 3, n, n_neg, _lib.ptr(fwd), _lib.ptr(inv), _lib.stream_ptr()), "perm_debug")
+    Zd, NNc, Pd, fw, iv = Z.double().cpu(), NN.cpu().long(), P.double().cpu(), fwd.cpu(), inv.cpu()
+    rows = torch.cat([torch.arange(0, 48), torch.arange(48, n, 997)])
+    src_of = {int(r): [] for r in rows}
+    wanted = set(src_of)
+    NNl = NNc.tolist()
+    for i in range(n):
+        for p, j in enumerate(NNl[i]):
+            if j in wanted:
+                src_of[j].append((i, p))
+    ref = torch.zeros((rows.numel(), nc), dtype=torch.float64)
+    for a_, r in enumerate(rows.tolist()):
+        zi = Zd[r]
+        acc = torch.zeros(nc, dtype=torch.float64)
+        for p in range(k):
+            df = zi - Zd[NNc[r, p]]
+            acc += 3.0 * 2.0 * Pd[r, p] / (2.0 + (df * df).sum()) * df
+        for (i, p) in src_of[r]:
+            df = zi - Zd[i]
+            acc += 3.0 * 2.0 * Pd[i, p] / (2.0 + (df * df).sum()) * df
+        for c in range(n_neg):
+            for j in (int(fw[r, c]), int(iv[r, c])):
+                df = zi - Zd[j]
+                d = (df * df).sum()
+                acc += -(2.0 / n) / ((1.0 + d) * (2.0 + d)) * df
+        ref[a_] = acc
+    grade64(f"ne_pull4_vs_float64_closed_form/nc={nc}/k={k}", four.cpu()[rows], ref, BUDGET)
+
+
 @pytest.mark.parametrize("n,nc", [(20_000, 2), (33_333, 3), (9_000, 5)])
 def test_tsne_repulsion_with_column_segments_equals_the_unsplit_launch(n, nc):
     """tdr_tsne_repulsion_split_f32 cuts the columns into segments (several workgroups per row block) and adds the per-segment

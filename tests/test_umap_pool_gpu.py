@@ -134,6 +134,10 @@ def test_pool_row_shard_gives_the_bits_of_the_full_launch(geom):
     full = pool_grad(sc, Z, 9, 9, 1.577, 0.895, 40, 4242, geom=geom)
     again = pool_grad(sc, Z, 9, 9, 1.577, 0.895, 40, 4242, geom=geom)
     assert torch.equal(full, again)
+    if geom == 0:
+        # a block worked by 1, 2, 4 or 8 workgroups (what the launcher picks by launch size: small shards fill the chip): same bits
+        for g2 in (17, 18, 20, 24):
+            assert torch.equal(pool_grad(sc, Z, 9, 9, 1.577, 0.895, 40, 4242, geom=g2), full), g2
     for c0, c1 in ((0, 2338), (2338, 4676), (4676, n), (1000, 1001), (300, 1500)):
         rp = (rowptr[c0:c1 + 1] - rowptr[c0]).cuda()
         e0, e1 = int(rowptr[c0]), int(rowptr[c1])
@@ -142,6 +146,84 @@ def test_pool_row_shard_gives_the_bits_of_the_full_launch(geom):
         sub.build(nx, 0, 32)
         part = pool_grad(sub, Z, 9, 9, 1.577, 0.895, 40, 4242, geom=geom)
         assert torch.equal(part, full[c0:c1]), (geom, c0, c1)
+
+
+@pytest.mark.parametrize("with_alt,T", [(True, 71), (True, 70), (False, 71)])
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_loop_object_with_the_step_in_the_pool_launch(use_graph, with_alt, T):
+    """tdr_umap_loop_run on pool negatives against the same windows issued call by call (build, tdr_umap_pool_grad_f32,
+    tdr_sgd_step_f32): with a second embedding buffer the gradient launch carries the step (learning rate from the device table,
+    gradient / norm / snapshot at the inspected iterations) and the buffers swap roles every iteration -- bit-identical embedding
+    after 70 / 71 iterations (windows 32 + 32 + 6 or 7: an odd window copies the rows back), same snapshot and norms; without
+    the second buffer the unfused sequence runs as before."""
+    import ctypes
+
+    from torchdr_amd import _lib
+    from tests.test_umap_sched_gpu import layout
+
+    L = _lib.lib()
+    n, ci = 20000, 25
+    gen = torch.Generator().manual_seed(3)
+    rowptr, cols, vals = random_graph(n, seed=9, hub=300)
+    eps_csr, _ = prepare(vals.cuda(), 200)
+    cols_p, eps_p = layout(rowptr.cuda(), cols.cuda(), eps_csr)
+    rowptr = rowptr.cuda()
+    lr = torch.linspace(1.0, 0.0, T + 1)[:T].contiguous()
+    Z0 = (torch.randn(n, 2, generator=gen) * 3).cuda()
+    a, b, seed = 1.577, 0.895, 4242
+    sc = Sched(rowptr, cols_p, eps_p, n, 32, 1)
+    Z, nxt = Z0.clone(), eps_p.clone()
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    norms, snaps = {}, {}
+    for t0 in range(0, T, 32):
+        nw = min(32, T - t0)
+        sc.build(nxt, t0, nw)
+        for tl in range(nw):
+            g = pool_grad(sc, Z, tl, t0 + tl, a, b, 150, seed)
+            if (t0 + tl) % ci == 0:
+                norms[(t0 + tl) // ci] = float((g.double() ** 2).sum())
+            _lib.check(L.tdr_sgd_step_f32(_lib.ptr(Z), _lib.ptr(g), None, Z.numel(), float(lr[t0 + tl]), 0.0,
+                                          1 if t0 + tl == 0 else 0, _lib.ptr(flag), t0 + tl, _lib.stream_ptr()), "sgd")
+            if (t0 + tl) % ci == 0:
+                snaps[t0 + tl] = Z.clone()
+    sc2 = Sched(rowptr, cols_p, eps_p, n, 32, 1)
+    Z2, nxt2 = Z0.clone(), eps_p.clone()
+    Zalt = torch.full_like(Z0, float("nan"))
+    grad = torch.empty((n, 2), device="cuda")
+    lr_d, norm2 = lr.cuda(), torch.zeros(T // ci + 2, device="cuda")
+    flag2, scratch = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(16, dtype=torch.int32, device="cuda")
+    snap = torch.zeros((n, 2), device="cuda")
+    d = _lib.UmapLoopDesc()
+    d.Z, d.nc, d.n_total, d.row0, d.n_rows = _lib.ptr(Z2), 2, n, 0, n
+    d.rowptr, d.cols, d.eps_per, d.next = _lib.ptr(rowptr), _lib.ptr(cols_p), _lib.ptr(eps_p), _lib.ptr(nxt2)
+    d.blk_base, d.list, d.hdr, d.err = _lib.ptr(sc2.blk_base), _lib.ptr(sc2.list), _lib.ptr(sc2.hdr), _lib.ptr(sc2.err)
+    d.acc, d.grad, d.mom_buf = None, _lib.ptr(grad), None
+    d.a, d.b, d.neg_rate, d.n_negatives, d.seed = a, b, 5, 150, seed
+    d.exag, d.rep, d.eps, d.n_slices, d.block_iters = 1.0, 1.0, 1e-3, 1, 32
+    d.lr_table, d.max_iter, d.momentum, d.first_iter, d.check_interval = _lib.ptr(lr_d), T, 0.0, 0, ci
+    d.norm2, d.snap, d.nan_flag, d.scratch, d.gather, d.gather_ctx, d.geom = (_lib.ptr(norm2), _lib.ptr(snap), _lib.ptr(flag2), _lib.ptr(scratch),
+                                                                               None, None, 0)
+    d.pool = 1
+    d.Z_alt = _lib.ptr(Zalt) if with_alt else None
+    h = ctypes.c_void_p()
+    _lib.check(L.tdr_umap_loop_create(ctypes.byref(h), ctypes.byref(d)), "create")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    try:
+        with torch.cuda.stream(side):
+            _lib.check(L.tdr_umap_loop_run(h, 0, 64, use_graph, _lib.stream_ptr()), "run")
+            _lib.check(L.tdr_umap_loop_run(h, 64, T - 64, use_graph, _lib.stream_ptr()), "run")
+        torch.cuda.synchronize()
+        assert torch.equal(Z2, Z) and torch.equal(nxt2, nxt)
+        assert torch.equal(snap, snaps[(T - 1) // ci * ci])
+        for k, v in norms.items():
+            assert abs(float(norm2[k]) - v) <= 1e-5 * v
+    finally:
+        L.tdr_umap_loop_destroy(h)
+    assert int(sc2.err.item()) == 0 and int(flag2.item()) == 0
+    # the second buffer must be a different, 16-byte aligned one
+    d.Z_alt = _lib.ptr(Z2)
+    assert L.tdr_umap_loop_create(ctypes.byref(h), ctypes.byref(d)) != 0
 
 
 @pytest.mark.parametrize("geom", [0, 1, 5])

@@ -124,5 +124,5 @@ class UmapLoopDesc(ctypes.Structure):
         ("exag", c_f32), ("rep", c_f32), ("eps", c_f32), ("n_slices", c_i32), ("block_iters", c_i32),
         ("lr_table", c_ptr), ("max_iter", c_i32), ("momentum", c_f32), ("first_iter", c_i32), ("check_interval", c_i32),
         ("norm2", c_ptr), ("snap", c_ptr), ("nan_flag", c_ptr), ("scratch", c_ptr), ("gather", c_ptr), ("gather_ctx", c_ptr), ("geom", c_i32),
-        ("rs", c_ptr), ("pool", c_i32), ("gather_capturable", c_i32),
+        ("rs", c_ptr), ("pool", c_i32), ("gather_capturable", c_i32), ("Z_alt", c_ptr),
     ]

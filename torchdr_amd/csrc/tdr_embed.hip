@@ -582,6 +582,126 @@ __global__ __launch_bounds__(256) void ne_grad_kernel(const NeStepParams S) {
     }
 }
 
+// ---- LargeVis pull form, FOUR lanes per row (round 6) -----------------------------------------------------------------
+// ne_grad_kernel<NC, 16> with the permutation sampler is bound by its dependency chains, not by bytes or instructions
+// (profiles/r05_c3_pmc.json: every SIMD full of wavefronts that each live ~7 us, 96 G L2 requests/s of a 268 G/s ceiling, 89 vector
+// instructions per row): a lane holds ONE edge, so a wavefront has 64 gathers in flight for 4 rows and walks row pointer -> source
+// id -> gather one round trip at a time.  Here a row is worked by 4 lanes (16 rows per wavefront) and a lane issues everything it
+// will need before it uses anything: 4 neighbour ids + weights, the in-edge range, then -- while those are in flight -- the keyed
+// permutation arithmetic of its <= 4 negative items and their gathers, the in-edge source ids, the out-edge gathers, the in-edge
+// gathers: up to 12 gathers per lane behind three index loads.  Same terms and formulas as ne_grad_kernel; a row's sum is taken
+// lane by lane and then over the 4 lanes (another association of the same fp32 terms).  Kind 0 (LargeVis) with n_neg <= 8,
+// 2 / 3 components, no halves; each row's gradient is STORED (every row is written exactly once: nothing is scattered).
+template <int NC>
+__global__ __launch_bounds__(256) void ne_pull4_kernel(const NeStepParams S) {
+    constexpr int G = 4, U = 4, UN = 4;
+    const int gl = threadIdx.x & (G - 1);
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (r >= S.n_rows) return;
+    const int64_t gi = S.row0 + r;
+    const int k = S.k;
+    // 1. index loads of the first batches
+    int32_t jo[U];
+    float po[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int p = gl + G * u;
+        jo[u] = p < k ? S.nn[(size_t)r * k + p] : (int32_t)gi;
+        po[u] = p < k ? S.P[(size_t)r * k + p] : 0.f;
+    }
+    const int64_t e0 = S.t_rowptr[r], e1 = S.t_rowptr[r + 1];
+    const Vec<NC> zi = load_z<NC>(S.Z, gi);
+    // 2. negative items of this lane: item = (column, side); side 0 = the row's own draw, 1 = the row whose draw hit it
+    const int n_items = 2 * S.n_neg;
+    uint32_t jn[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        const int it = gl + G * u;
+        jn[u] = (uint32_t)gi;
+        if (it < n_items) {
+            const PermKey K = perm_key(S.seed, S.iter, it >> 1, S.n_total);
+            const uint32_t a = perm_inv((uint32_t)gi, K);
+            jn[u] = (it & 1) ? perm_pred(a, K) : perm_succ(a, K);
+        }
+    }
+    Vec<NC> zn[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) zn[u] = load_z<NC>(S.Z, jn[u]);
+    // 3. in-edge ids of the first batch, out-edge gathers, in-edge gathers
+    int32_t js[U];
+    float ps[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t e = e0 + gl + G * u;
+        js[u] = e < e1 ? S.t_src[e] : (int32_t)gi;
+        ps[u] = e < e1 ? S.t_val[e] : 0.f;
+    }
+    Vec<NC> zo[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) zo[u] = load_z<NC>(S.Z, jo[u]);
+    Vec<NC> zs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) zs[u] = load_z<NC>(S.Z, js[u]);
+    float g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) g[c] = 0.f;
+    // negatives: -rep_coef / ((1 + d)(2 + d)) (largevis.py:181-201); an unused slot holds the row itself (zero difference)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+        float df[NC];
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zn[u].v[c]; d += df[c] * df[c]; }
+        const float w = -S.rep_coef / ((1.0f + d) * (2.0f + d));
+#pragma unroll
+        for (int c = 0; c < NC; ++c) g[c] += w * df[c];
+    }
+    // out-edges (weight 0 beyond the row's k), further batches for k > 16
+    auto edge = [&](const Vec<NC>& zj, float pij) {
+        float df[NC];
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d += df[c] * df[c]; }
+        const float w = S.exag * 2.0f * pij * (1.0f / (2.0f + d));
+#pragma unroll
+        for (int c = 0; c < NC; ++c) g[c] += w * df[c];
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) edge(zo[u], po[u]);
+    for (int p0 = G * U; p0 < k; p0 += G * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + gl + G * u;
+            jo[u] = p < k ? S.nn[(size_t)r * k + p] : (int32_t)gi;
+            po[u] = p < k ? S.P[(size_t)r * k + p] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) zo[u] = load_z<NC>(S.Z, jo[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) edge(zo[u], po[u]);
+    }
+    // in-edges s -> i: the same expression (see ne_grad_kernel)
+#pragma unroll
+    for (int u = 0; u < U; ++u) edge(zs[u], ps[u]);
+    for (int64_t eb = e0 + G * U; eb < e1; eb += G * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t e = eb + gl + G * u;
+            js[u] = e < e1 ? S.t_src[e] : (int32_t)gi;
+            ps[u] = e < e1 ? S.t_val[e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) zs[u] = load_z<NC>(S.Z, js[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) edge(zs[u], ps[u]);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        g[c] = group_sum<G>(g[c]);
+        if (gl == 0) S.grad[(size_t)gi * NC + c] = g[c];
+    }
+}
+
 // ---- TSNE dense repulsion (tsne.py:172-180): S = sum_ij w_ij, F_i = sum_j (z_i - z_j) w_ij^2 ---------
 // The 256 columns of a tile are staged pair-interleaved (x0 x1 | y0 y1 | ..) and two columns are evaluated at once with
 // packed fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma: two results per lane and issue slot); the weights come from
@@ -1011,6 +1131,7 @@ int tdr_umap_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int
     return launch_group<16>(umap_grad_kernel<3, 16, 4>, P, n_rows, st);
 }
 
+static int g_ne_pull4 = 1;         // 0: tdr_ne_grad_perm_f32 keeps the 16-lanes-per-row kernel (tdr_ne_grad_perm_lanes: measurements, equality test)
 static int g_ne_halves_mode = 0;   // 0 = by size, 1 = never (tdr_ne_grad_perm_halves: measurements and the equality test)
 
 static int ne_grad_launch(NeStepParams& S, float* rowsum, hipStream_t st) {
@@ -1041,6 +1162,13 @@ static int ne_grad_launch(NeStepParams& S, float* rowsum, hipStream_t st) {
         if (nc <= 16) TDR_NE2((ne_grad_kernel<16, 16, true>))
         TDR_NE2((ne_grad_kernel<32, 16, true>))
 #undef TDR_NE2
+    }
+    if (g_ne_pull4 && S.perm_neg && S.kind == 0 && S.t_rowptr && !S.neg_inj && S.n_neg <= 8 && S.neg_halves != 2 && (nc == 2 || nc == 3)) {
+        const dim3 grid((unsigned)((n_rows + 63) / 64));
+        if (nc == 2) hipLaunchKernelGGL(ne_pull4_kernel<2>, grid, dim3(256), 0, st, S);
+        else hipLaunchKernelGGL(ne_pull4_kernel<3>, grid, dim3(256), 0, st, S);
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? TDR_OK : (int)e;
     }
     // exact instances for 2 and 3 components, zero-padded register instances for any other width up to 32
     if (nc == 2) return launch_group<16>(ne_grad_kernel<2, 16>, S, n_rows, st);
@@ -1100,6 +1228,14 @@ int tdr_ne_grad_perm_f32(const float* Z, int nc, int64_t n_total, int64_t row0, 
     S.iter = (uint32_t)n_iter; S.grad = grad;
     S.t_rowptr = t_rowptr; S.t_src = t_src; S.t_val = t_val;
     return ne_grad_launch(S, kind == 3 ? rowsum_ws : nullptr, (hipStream_t)stream);
+}
+
+/* Measurement / test switch: lanes per row of tdr_ne_grad_perm_f32's LargeVis launch -- 4 (default: ne_pull4_kernel) or 16
+ * (ne_grad_kernel, the form of rounds 3-5).  Returns the previous value. */
+int tdr_ne_grad_perm_lanes(int lanes) {
+    const int old = g_ne_pull4 ? 4 : 16;
+    if (lanes == 4 || lanes == 16) g_ne_pull4 = lanes == 4;
+    return old;
 }
 
 /* Measurement / test switch: 1 = tdr_ne_grad_perm_f32 never splits its launch into the two halves of the index range, 0 (default)

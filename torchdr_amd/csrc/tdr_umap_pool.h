@@ -17,6 +17,9 @@
 #define TDR_POOL_RUNLEN 8
 #endif
 #define TDR_POOL_NGEOM 6     // tuning geometries 1..6 (TDR_POOL_GEOMS of tdr_umap_pool.hip)
+// 0 = default (workgroups per block chosen by the launch size), 1..6 tuning geometries, 16 + s = default with s in {1, 2, 4, 8} workgroups
+// per block (s > 1: one row per lane)
+static inline bool tdr_pool_geom_ok(int geom) { return (geom >= 0 && geom <= TDR_POOL_NGEOM) || geom == 17 || geom == 18 || geom == 20 || geom == 24; }
 
 namespace tdr {
 
@@ -36,6 +39,10 @@ struct PoolGradParams {
     float* grad;               // (n_rows, nc), or NULL with Z_out
     float* Z_out;              // non-NULL: the launch also steps its rows, z - lr g -> Z_out (n_total, nc): the other embedding buffer
     float lr;
+    const float* lr_table;     // loop object: the learning rate of absolute iteration i is lr_table[i] (then `lr` is unused), and at the
+    int check_interval;        //   iterations the reference inspects (i % check_interval == 0) the launch also writes grad, snap (stepped
+    float* norm2;              //   rows, (n_rows, nc)) and adds the squared gradient norm to norm2[i / check_interval]
+    float* snap;
     int* nan_flag;
     uint32_t n_runs;           // ceil(n_total / rows per run) (set by the launcher)
     int64_t gb0;               // first global row block of the launch (set by the launcher)

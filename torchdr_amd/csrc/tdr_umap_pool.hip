@@ -120,13 +120,22 @@ __device__ __forceinline__ uint32_t pool_part_end(uint32_t n, uint32_t j, uint32
 // the row's gradient (clamps of umap.py:262,290) and, when the launch carries the step (P.Z_out), torch.optim.SGD's update of the
 // row written to the OTHER embedding buffer (every row of this launch still reads the old one) with check_NaNs' flag
 // (affinity_matcher.py:315,427)
+// In the loop object (P.lr_table) the learning rate comes from the device table at the iteration, and at the iterations the
+// reference inspects (iteration % check_interval == 0, affinity_matcher.py:331-349) the row also leaves its gradient, its stepped
+// position in `snap` and its share of the squared gradient norm (returned; the caller adds the block's shares to norm2) -- what
+// sgd_table_step_kernel does for the unfused sequence.
 template <int NC>
-__device__ __forceinline__ void pool_store_grad(const PoolGradParams& P, int64_t r, int64_t gi, const Vec<NC>& zi, uint32_t iter,
-                                                const float (&ga)[NC], const float (&gr)[NC]) {
+__device__ __forceinline__ float pool_store_grad(const PoolGradParams& P, int64_t r, int64_t gi, const Vec<NC>& zi, uint32_t iter,
+                                                 bool inspected, const float (&ga)[NC], const float (&gr)[NC]) {
     float g[NC];
+    float q = 0.f;
 #pragma unroll
     for (int c = 0; c < NC; ++c) g[c] = P.exag * fminf(fmaxf(ga[c], -4.f), 4.f) + P.rep * fminf(fmaxf(gr[c], -4.f), 4.f);
-    if (P.grad) {
+    if (inspected) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) q += g[c] * g[c];
+    }
+    if (P.grad && (inspected || !P.lr_table)) {
         if (NC == 2) {
             *reinterpret_cast<float2*>(P.grad + (size_t)r * 2) = make_float2(g[0], g[1]);
         } else {
@@ -137,16 +146,22 @@ __device__ __forceinline__ void pool_store_grad(const PoolGradParams& P, int64_t
     if (P.Z_out) {
         float z[NC];
         bool nan = false;
+        const float lr = P.lr_table ? P.lr_table[iter] : P.lr;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { z[c] = __builtin_fmaf(-P.lr, g[c], zi.v[c]); nan = nan || z[c] != z[c]; }
+        for (int c = 0; c < NC; ++c) { z[c] = __builtin_fmaf(-lr, g[c], zi.v[c]); nan = nan || z[c] != z[c]; }
         if (NC == 2) {
             *reinterpret_cast<float2*>(P.Z_out + (size_t)gi * 2) = make_float2(z[0], z[1]);
         } else {
 #pragma unroll
             for (int c = 0; c < NC; ++c) P.Z_out[(size_t)gi * NC + c] = z[c];
         }
+        if (inspected && P.snap) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) P.snap[(size_t)r * NC + c] = z[c];
+        }
         if (nan) atomicCAS(P.nan_flag, 0, (int)iter + 1);
     }
+    return q;
 }
 
 // THREADS lanes evaluate the ROWS = RPT x THREADS rows of a global row block against a pool of RUNS runs of RUNLEN rows.
@@ -158,7 +173,12 @@ __device__ __forceinline__ void pool_store_grad(const PoolGradParams& P, int64_t
 // (An LDS window of the rows around the block for the fired-edge gathers -- in the loop's cluster-sorted numbering 42 % of the
 // fired edges end in the row's own block, all within 1024 rows -- was built in three forms and measured slower every time:
 // profiles/r06_pool_window.json.)
-template <int NC, int THREADS, int RPT, int RUNS, int RUNLEN, bool DBG>
+// SPLIT > 1: the global row block (and its pool) stays BROWS = SPLIT x ROWS rows, but SPLIT workgroups share it, each staging the
+// whole pool and evaluating ROWS of its rows -- a row's sums are a function of the row alone, so the bits are those of the unsplit
+// launch; what changes is the number of wavefronts and the rows a lane evaluates one after the other: a rank of an 8-rank fit at
+// N = 1M holds 123 blocks of 1024 rows = 984 wavefronts of two rows per lane, one per SIMD, 21.5 us per launch where an eighth of
+// the single-process launch would be 7.
+template <int NC, int THREADS, int RPT, int RUNS, int RUNLEN, int SPLIT, bool DBG>
 __global__ __launch_bounds__(THREADS, NC == 2 ? 6 : 4) void umap_pool_grad_kernel(const PoolGradParams P) {   // 2 components: <= 80 registers (capping at 64 spills ten and measured slower)
     const int ablate = DBG ? P.ablate : 0;
     auto stamp = [&](int i) {
@@ -166,7 +186,8 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 6 : 4) void umap_pool_grad_kerne
             P.dbg_times[((size_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6)) * 8 + i] = (unsigned long long)__builtin_amdgcn_s_memtime();
     };
     stamp(0);
-    constexpr int ROWS = THREADS * RPT;
+    constexpr int ROWS = THREADS * RPT;          // rows of this workgroup
+    constexpr int BROWS = ROWS * SPLIT;          // rows of the global block (the unit the pool is keyed by)
     constexpr int POOL_ROWS = RUNS * RUNLEN;
     constexpr int LOGP = ilog2(POOL_ROWS), LOGR = ilog2(RUNLEN);
     static_assert((1 << LOGP) == POOL_ROWS && (1 << LOGR) == RUNLEN, "pool rows / run length must be powers of two");
@@ -200,7 +221,11 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 6 : 4) void umap_pool_grad_kerne
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t iter = P.iter + (P.iter_base ? (uint32_t)*P.iter_base : 0u);
-    const int64_t gb = P.gb0 + (int64_t)blockIdx.x;
+    const int64_t gb = P.gb0 + (int64_t)(blockIdx.x / SPLIT);
+    const int64_t rowbase = gb * BROWS + (int64_t)(blockIdx.x % SPLIT) * ROWS;      // first (global) row of this workgroup
+    if (SPLIT > 1 && (rowbase + ROWS <= P.row0 || rowbase >= P.row0 + P.n_rows)) return;   // none of the launch's rows here
+    const bool inspected = P.lr_table && P.check_interval > 0 && iter % (uint32_t)P.check_interval == 0u;
+    float q2 = 0.f;      // this thread's share of the squared gradient norm (inspected iterations)
     const uint32_t bkey = pool_block_key(P.seed, iter, (uint32_t)gb);
 
     // 1. the pool: NIT LDS-DMA instructions per wavefront (a lane moves 16 bytes; the PPR lanes of a run one whole run)
@@ -225,7 +250,7 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 6 : 4) void umap_pool_grad_kerne
     uint2 h[RPT];
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
-        const int64_t r0 = gb * ROWS + q * THREADS + t - P.row0;
+        const int64_t r0 = rowbase + q * THREADS + t - P.row0;
         h[q] = make_uint2(0u, 0u);
         if (r0 >= 0 && r0 < P.n_rows) {
             typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -345,7 +370,7 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 6 : 4) void umap_pool_grad_kerne
             j0 = (int)(xi >> 16); j1 = j0 + 1; slot0 = (int)(rx >> 8) - 1;
         }
         const uint2 hh = rec[my];
-        const int64_t gi64 = gb * ROWS + my;
+        const int64_t gi64 = rowbase + my;
         const int64_t r = gi64 - P.row0;
         if (r < 0 || r >= P.n_rows) continue;
         const uint32_t gi = (uint32_t)gi64;
@@ -454,7 +479,7 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 6 : 4) void umap_pool_grad_kerne
                 for (int c = 0; c < NC; ++c) { ga[c] += pa[c]; gr[c] += pr[c]; }
             }
         }
-        if (slot0 < 0) pool_store_grad<NC>(P, r, gi64, zi, iter, ga, gr);
+        if (slot0 < 0) q2 += pool_store_grad<NC>(P, r, gi64, zi, iter, inspected, ga, gr);
         if (q < 2) stamp(4 + q);
     }
     // 4. split rows: their parts' sums in part order
@@ -462,7 +487,7 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 6 : 4) void umap_pool_grad_kerne
     for (uint32_t sidx = (uint32_t)t; sidx < scount; sidx += THREADS) {
         const uint32_t row = srow[sidx];
         const uint32_t rx = rowx[row], m = rx & 255u, b0 = (rx >> 8) - 1u;
-        const int64_t r = gb * ROWS + row - P.row0;
+        const int64_t r = rowbase + row - P.row0;
         if (r < 0 || r >= P.n_rows) continue;
         float ga[NC], gr[NC];
 #pragma unroll
@@ -471,7 +496,11 @@ __global__ __launch_bounds__(THREADS, NC == 2 ? 6 : 4) void umap_pool_grad_kerne
 #pragma unroll
             for (int c = 0; c < NC; ++c) { ga[c] += psum[(b0 + j) * 2 * NC + c]; gr[c] += psum[(b0 + j) * 2 * NC + NC + c]; }
         }
-        pool_store_grad<NC>(P, r, gb * ROWS + row, load_z<NC>(P.Z, gb * ROWS + row), iter, ga, gr);
+        q2 += pool_store_grad<NC>(P, r, rowbase + row, load_z<NC>(P.Z, rowbase + row), iter, inspected, ga, gr);
+    }
+    if (inspected && P.norm2) {      // the same for every thread of the launch
+        q2 = wave_sum(q2);
+        if (lane == 0 && q2 != 0.f) atomicAdd(&P.norm2[iter / (uint32_t)P.check_interval], q2);
     }
 }
 
@@ -499,16 +528,28 @@ __global__ __launch_bounds__(256) void umap_pool_debug_kernel(uint64_t seed, uin
     }
 }
 
-template <int NC, int THREADS, int RPT, int RUNS, int RUNLEN>
-static int launch_pool(const PoolGradParams& P0, hipStream_t st) {
+// launches of fewer than this many global blocks (8 wavefronts each: fewer than two per SIMD) go to the split form with ONE row per
+// lane -- twice the wavefronts, half the serial work in each: 30.7 -> 24.6 us per call at 123 blocks, 32.2 -> 31.3 at 245, nothing
+// from 489 blocks on (profiles/r06_pool_split.jsonl).  (Splitting alone, two rows per lane in smaller workgroups, changed nothing
+// at 123 blocks: every wavefront already had a SIMD to itself and ran as long as before.)
+constexpr int64_t POOL_SPLIT_BELOW = 256;
+template <int NC, int THREADS, int RPT, int RUNS, int RUNLEN, bool SPLITS = false>
+static int launch_pool(const PoolGradParams& P0, hipStream_t st, int split = 0) {
     const bool dbg = P0.ablate != 0 || P0.dbg_times != nullptr;
     constexpr int ROWS = THREADS * RPT;
     PoolGradParams P = P0;
     P.gb0 = P.row0 / ROWS;
     P.n_runs = (uint32_t)((P.n_total + RUNLEN - 1) / RUNLEN);
     const int64_t gb1 = (P.row0 + P.n_rows - 1) / ROWS;
-    if (dbg) hipLaunchKernelGGL((umap_pool_grad_kernel<NC, THREADS, RPT, RUNS, RUNLEN, true>), dim3((unsigned)(gb1 - P.gb0 + 1)), dim3(THREADS), 0, st, P);
-    else hipLaunchKernelGGL((umap_pool_grad_kernel<NC, THREADS, RPT, RUNS, RUNLEN, false>), dim3((unsigned)(gb1 - P.gb0 + 1)), dim3(THREADS), 0, st, P);
+    const int64_t nb = gb1 - P.gb0 + 1;
+    if (dbg) hipLaunchKernelGGL((umap_pool_grad_kernel<NC, THREADS, RPT, RUNS, RUNLEN, 1, true>), dim3((unsigned)nb), dim3(THREADS), 0, st, P);
+    else if (SPLITS && RPT == 2 && split == 4)
+        hipLaunchKernelGGL((umap_pool_grad_kernel<NC, SPLITS ? THREADS / 2 : THREADS, SPLITS ? 1 : RPT, RUNS, RUNLEN, SPLITS ? 4 : 1, false>), dim3((unsigned)(nb * 4)), dim3(THREADS / 2), 0, st, P);
+    else if (SPLITS && RPT == 2 && split == 8)
+        hipLaunchKernelGGL((umap_pool_grad_kernel<NC, SPLITS ? THREADS / 4 : THREADS, SPLITS ? 1 : RPT, RUNS, RUNLEN, SPLITS ? 8 : 1, false>), dim3((unsigned)(nb * 8)), dim3(THREADS / 4), 0, st, P);
+    else if (SPLITS && RPT == 2 && (split == 2 || (split == 0 && nb < POOL_SPLIT_BELOW)))
+        hipLaunchKernelGGL((umap_pool_grad_kernel<NC, THREADS, SPLITS ? 1 : RPT, RUNS, RUNLEN, SPLITS ? 2 : 1, false>), dim3((unsigned)(nb * 2)), dim3(THREADS), 0, st, P);
+    else hipLaunchKernelGGL((umap_pool_grad_kernel<NC, THREADS, RPT, RUNS, RUNLEN, 1, false>), dim3((unsigned)nb), dim3(THREADS), 0, st, P);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? TDR_OK : (int)e;
 }
@@ -521,7 +562,12 @@ static int launch_pool_geom(const PoolGradParams& P, int geom, hipStream_t st) {
 #define TDR_POOL_CASE(G, T, R, Q, L) case G: return launch_pool<NC, T, R, Q, L>(P, st);
         TDR_POOL_GEOMS(TDR_POOL_CASE)
 #undef TDR_POOL_CASE
-        default: return launch_pool<NC, TDR_POOL_THREADS, TDR_POOL_RPT, TDR_POOL_RUNS, TDR_POOL_RUNLEN>(P, st);
+        // geometries 16 + s (s = 1, 2, 4): the default geometry with s workgroups per block whatever the launch size (tests, measurement)
+        case 17: return launch_pool<NC, TDR_POOL_THREADS, TDR_POOL_RPT, TDR_POOL_RUNS, TDR_POOL_RUNLEN, true>(P, st, 1);
+        case 18: return launch_pool<NC, TDR_POOL_THREADS, TDR_POOL_RPT, TDR_POOL_RUNS, TDR_POOL_RUNLEN, true>(P, st, 2);
+        case 20: return launch_pool<NC, TDR_POOL_THREADS, TDR_POOL_RPT, TDR_POOL_RUNS, TDR_POOL_RUNLEN, true>(P, st, 4);
+        case 24: return launch_pool<NC, TDR_POOL_THREADS, TDR_POOL_RPT, TDR_POOL_RUNS, TDR_POOL_RUNLEN, true>(P, st, 8);
+        default: return launch_pool<NC, TDR_POOL_THREADS, TDR_POOL_RPT, TDR_POOL_RUNS, TDR_POOL_RUNLEN, true>(P, st);
     }
 }
 
@@ -545,7 +591,7 @@ int tdr_umap_pool_grad_f32(const float* Z, int nc, int64_t n_total, int64_t row0
                            int t_local, float a, float b, int n_iter, int neg_rate, int n_negatives, uint64_t seed, float exag,
                            float rep, float eps, float* grad, int geom, void* stream) {
     if (!Z || !list || !hdr || !grad || n_rows <= 0 || row0 < 0 || n_total < 2 || n_total >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
-    if (t_local < 0 || t_local >= 32 || neg_rate < 0 || n_negatives < 0 || geom < 0 || geom > TDR_POOL_NGEOM) return TDR_ERR_BAD_ARG;
+    if (t_local < 0 || t_local >= 32 || neg_rate < 0 || n_negatives < 0 || !tdr_pool_geom_ok(geom)) return TDR_ERR_BAD_ARG;
     if (((uintptr_t)Z & 15u) != 0 || n_total * nc * 4 >= 0xffffffffLL) return TDR_ERR_BAD_ARG;   // Z behind one buffer descriptor
     if (!tdr_umap_pool_supported(nc)) return TDR_ERR_UNSUPPORTED;
     PoolGradParams P = {};
@@ -563,7 +609,7 @@ int tdr_umap_pool_grad_step_f32(const float* Z, float* Z_out, int nc, int64_t n_
                                 const void* hdr, int t_local, float a, float b, int n_iter, int neg_rate, int n_negatives, uint64_t seed,
                                 float exag, float rep, float eps, float* grad, float lr, int* nan_flag, int geom, void* stream) {
     if (!Z || !Z_out || Z == Z_out || !list || !hdr || !nan_flag || n_rows <= 0 || row0 < 0 || n_total < 2 || n_total >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
-    if (t_local < 0 || t_local >= 32 || neg_rate < 0 || n_negatives < 0 || geom < 0 || geom > TDR_POOL_NGEOM) return TDR_ERR_BAD_ARG;
+    if (t_local < 0 || t_local >= 32 || neg_rate < 0 || n_negatives < 0 || !tdr_pool_geom_ok(geom)) return TDR_ERR_BAD_ARG;
     if (((uintptr_t)Z & 15u) != 0 || ((uintptr_t)Z_out & 7u) != 0 || n_total * nc * 4 >= 0xffffffffLL) return TDR_ERR_BAD_ARG;
     if (!tdr_umap_pool_supported(nc)) return TDR_ERR_UNSUPPORTED;
     PoolGradParams P = {};
@@ -580,7 +626,7 @@ int tdr_umap_pool_grad_debug_f32(const float* Z, int nc, int64_t n_total, int64_
                                  int t_local, float a, float b, int n_iter, int neg_rate, int n_negatives, uint64_t seed, float* grad,
                                  int geom, int ablate, void* times, void* stream) {
     if (!Z || !list || !hdr || !grad || n_rows <= 0 || row0 < 0 || n_total < 2 || n_total >= 0x7fffffffLL) return TDR_ERR_BAD_ARG;
-    if (t_local < 0 || t_local >= 32 || geom < 0 || geom > TDR_POOL_NGEOM || ((uintptr_t)Z & 15u) != 0) return TDR_ERR_BAD_ARG;
+    if (t_local < 0 || t_local >= 32 || !tdr_pool_geom_ok(geom) || ((uintptr_t)Z & 15u) != 0) return TDR_ERR_BAD_ARG;
     if (!tdr_umap_pool_supported(nc)) return TDR_ERR_UNSUPPORTED;
     PoolGradParams P = {};
     P.Z = Z; P.nc = nc; P.n_total = n_total; P.row0 = row0; P.n_rows = n_rows; P.list = list; P.hdr = (const uint2*)hdr;
@@ -592,7 +638,7 @@ int tdr_umap_pool_grad_debug_f32(const float* Z, int nc, int64_t n_total, int64_
 
 int tdr_umap_pool_debug_negatives(uint64_t seed, int n_iter, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nuse, int geom,
                                   int width, int64_t* out, void* stream) {
-    if (!nuse || !out || n_rows <= 0 || width <= 0 || n_total < 2 || geom < 0 || geom > TDR_POOL_NGEOM) return TDR_ERR_BAD_ARG;
+    if (!nuse || !out || n_rows <= 0 || width <= 0 || n_total < 2 || !tdr_pool_geom_ok(geom)) return TDR_ERR_BAD_ARG;
     const dim3 grid((unsigned)((n_rows + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
 #define TDR_POOL_DBG(R, Q, L) hipLaunchKernelGGL((umap_pool_debug_kernel<R, Q, L>), grid, dim3(256), 0, st, seed, (uint32_t)n_iter, n_total, row0, n_rows, nuse, width, out)

@@ -1301,6 +1301,7 @@ struct UmapLoop {
     const uint8_t* rs;              // non-null: group-ordered loop state (cols / eps_per / next / blk_base of tdr_umap_sched_group_f32 / _plan_groups_f32)
     int pool;                       // g + 1: negatives from the LDS pool (tdr_umap_pool.hip, geometry g), 0: i.i.d. gathers
     int gather_capturable;          // the gather callback may be captured into the window graphs
+    float* Z_alt;                   // second embedding buffer: the pool gradient launch carries the SGD step (momentum 0) and the two swap roles
     // captured windows: graph_len[i] iterations each
     hipGraphExec_t graphs[2]; int graph_len[2];
 };
@@ -1340,6 +1341,27 @@ static int umap_loop_enqueue_window(UmapLoop* L, int n, hipStream_t st, int host
     for (int t = 0; t < n; ++t) {
         G.t_local = t; G.iter = (uint32_t)(t + (host_base >= 0 ? host_base : 0));
         G.nc = L->nc;
+        if (L->pool && L->Z_alt && L->momentum == 0.f) {
+            // gradient + torch.optim.SGD step in ONE launch (round 6): iteration t of the window reads buffer t & 1 and writes the
+            // stepped rows of this rank into the other one, where the exchange then delivers the other ranks' rows; learning rate,
+            // NaN flag, and at the inspected iterations gradient / norm / snapshot as sgd_table_step_kernel leaves them.  A window
+            // of odd length ends with the current rows in Z_alt: they are copied back, so every window starts from L->Z.
+            float* cur = (t & 1) ? L->Z_alt : L->Z;
+            float* nxt = (t & 1) ? L->Z : L->Z_alt;
+            Pp.t_local = t; Pp.iter = G.iter; Pp.Z = cur; Pp.Z_out = nxt; Pp.lr_table = L->lr_table; Pp.check_interval = L->check_interval;
+            Pp.norm2 = L->norm2; Pp.snap = L->snap; Pp.nan_flag = L->nan_flag;
+            const int rcp = launch_pool_grad(Pp, L->pool - 1, st);
+            if (rcp != TDR_OK) return rcp;
+            if (L->gather) {
+                const int rc = L->gather(L->gather_ctx, nxt, L->nc, (void*)st);
+                if (rc != TDR_OK) return rc;
+            }
+            if (t == n - 1 && (n & 1)) {
+                hipError_t ec = hipMemcpyAsync(L->Z, L->Z_alt, (size_t)L->n_total * L->nc * sizeof(float), hipMemcpyDeviceToDevice, st);
+                if (ec != hipSuccess) return (int)ec;
+            }
+            continue;
+        }
         if (L->pool) {
             Pp.t_local = t; Pp.iter = G.iter;
             const int rcp = launch_pool_grad(Pp, L->pool - 1, st);
@@ -1582,7 +1604,9 @@ int tdr_umap_loop_create(void** out, const tdr_umap_loop_desc* d) {
     L->rs = d->rs;
     L->pool = d->pool;
     L->gather_capturable = d->gather_capturable;
-    if (L->pool < 0 || L->pool > TDR_POOL_NGEOM + 1 || (L->pool && (L->S != 1 || !tdr_umap_pool_supported(L->nc) || ((uintptr_t)L->Z & 15u) || L->n_total * L->nc * 4 >= 0xffffffffLL))) { delete L; return TDR_ERR_BAD_ARG; }
+    L->Z_alt = d->Z_alt;
+    if (L->Z_alt && (L->Z_alt == L->Z || ((uintptr_t)L->Z_alt & 15u))) { delete L; return TDR_ERR_BAD_ARG; }
+    if (L->pool < 0 || (L->pool && !tdr_pool_geom_ok(L->pool - 1)) || (L->pool && (L->S != 1 || !tdr_umap_pool_supported(L->nc) || ((uintptr_t)L->Z & 15u) || L->n_total * L->nc * 4 >= 0xffffffffLL))) { delete L; return TDR_ERR_BAD_ARG; }
     L->graphs[0] = L->graphs[1] = nullptr; L->graph_len[0] = L->graph_len[1] = 0;
     const size_t lds = (size_t)L->B * L->S * CNT_STRIDE * sizeof(uint32_t);
     if (lds > 32 * 1024) {  // raised here, outside graph capture, for every instance the launcher may pick

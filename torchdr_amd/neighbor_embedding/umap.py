@@ -567,6 +567,11 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         d.gather_capturable = 1 if capturable else 0
         d.geom = sc["geom"]
         d.pool = int(_opt("POOL_GEOM")) + 1 if (self._pool_negatives() and self.embedding_.data_ptr() % 16 == 0) else 0
+        # POOL_FUSED_STEP: the step rides in the gradient launch (two embedding buffers; other ranks' rows of the second one are
+        # delivered by the exchange of the iteration that writes it)
+        if d.pool and _opt("POOL_FUSED_STEP") and mom == 0.0:
+            keep["Z_alt"] = self.embedding_.clone()
+            d.Z_alt = _lib.ptr(keep["Z_alt"])
         handle = ctypes.c_void_p()
         _lib.check(L.tdr_umap_loop_create(ctypes.byref(handle), ctypes.byref(d)), "tdr_umap_loop_create")
         # graphs cannot be captured on the legacy default stream: the loop runs on a side stream ordered after the
