@@ -11,8 +11,10 @@ import json
 import sys
 from collections import defaultdict
 
-KERNELS = {"umap_sched_grad_kernel": 1.0, "umap_sched_combine_sgd_kernel": 1.0, "umap_sched_build2_kernel": 1.0 / 32,
-           "umap_sched_build_kernel": 1.0 / 32}
+# launches per iteration.  Round 6 (pool negatives): the gradient launch carries the SGD step except at the iterations the reference
+# inspects (every check_interval-th = 50th), where tdr::sgd_step_kernel runs after it
+KERNELS = {"umap_pool_grad_kernel": 1.0, "sgd_step_kernel": 1.0 / 50, "umap_sched_grad_kernel": 1.0, "umap_sched_combine_sgd_kernel": 1.0,
+           "umap_sched_build2_kernel": 1.0 / 32, "umap_sched_build_kernel": 1.0 / 32}
 
 
 def per_launch(d, counter):
@@ -44,6 +46,7 @@ for k, share in KERNELS.items():
     W += w * share
 out["FETCH_SIZE"], out["WRITE_SIZE"] = F, W
 out["bytes_per_iteration"] = (2.0 * F + W) * 1024.0
-out["FETCH_SIZE_WRITE_SIZE_meaning"] = ("one UMAP iteration of the production loop = gradient launch + combine-and-step launch + 1/32 of a schedule "
-                                        "build; bench.py: roofline.traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024")
+out["FETCH_SIZE_WRITE_SIZE_meaning"] = ("one UMAP iteration of the production loop = the kernels listed under `kernels`, each weighted by its launches per "
+                                        "iteration (gradient [+ step] launch, 1/32 of a schedule build); bench.py: roofline.traffic = (2 x FETCH_SIZE + "
+                                        "WRITE_SIZE) x 1024")
 print(json.dumps(out, indent=1))
