@@ -245,7 +245,8 @@ def config_c3(dev, width=15, steps=1, iters=500):
     perp = width // 3
     nbytes = n * width * (4 + 4 + 8 + 8) + n * n_neg * (8 + 8) + 2 * n * (8 + 8)
     out = {}
-    for name, perm, entry in (("permutation", True, "tdr_ne_grad_perm_f32"), ("independent", False, "tdr_ne_grad_f32")):
+    for name, perm, entry in (("permutation", True, "tdr_ne_grad_perm_f32"), ("run-permutation", "runs", "tdr_ne_grad_runs_f32"),
+                              ("independent", False, "tdr_ne_grad_f32")):
         with config.options(PERM_NEGATIVES=perm):
             t.LargeVis(perplexity=perp, max_iter=20, random_state=0).fit_transform(X)   # warm-up
             tm = _TimedEntry(entry, every=10)
@@ -258,15 +259,20 @@ def config_c3(dev, width=15, steps=1, iters=500):
             ms, cnt = tm.close()
         out[name] = {"ms_per_fit": wall * 1e3, "samples_per_sec": n / wall, "grad_launch_ms": ms, "launches_sampled": cnt,
                      "hbm_gbs": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    best = out["permutation"]
+    from torchdr_amd.neighbor_embedding import base as _nb
+    default = {True: "permutation", "runs": "run-permutation", False: "independent"}[_nb.PERM_NEGATIVES]
+    best = out[default]
+    kern = {"permutation": "tdr::ne_pull4_kernel<2> (4 lanes per row, every negative gathered)",
+            "run-permutation": "tdr::ne_pull4_runs_kernel<2> (4 lanes per row, negatives staged into LDS run by run)",
+            "independent": "tdr::ne_grad_kernel<2,16> (hash sampler + far-endpoint atomics)"}[default]
     return {
         "workload": f"BASELINE config C3: LargeVis fit_transform N={n} D={d} perplexity={perp} (kNN width {width}) n_negatives={n_neg} "
                     f"max_iter={iters}, Gaussian mixture (1000 clusters, centre scale 2, sigma 0.5, seed 42)",
         "ms": best["ms_per_fit"], "samples_per_sec": best["samples_per_sec"],
-        "roofline": {"kernel": "tdr::ne_grad_kernel<2,16> (kind 0: LargeVis attraction + 5 negatives per row), one launch per iteration",
+        "roofline": {"kernel": kern + " (kind 0: LargeVis attraction + 5 negatives per row), one launch per iteration; the one-GPU default sampler: " + default,
                      "bound": "hbm", "achieved": best["hbm_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": best["frac"],
-                     "traffic": _committed_traffic("r05_c3_pmc.json", "derived", "pull_form_hbm_side_traffic_bytes"),
-                     "traffic_source": "profiles/r05_c3_pmc.json (2 x FETCH_SIZE + WRITE_SIZE of the pull-form launch, separate --pmc passes on the round-5 build; not re-measured here)",
+                     "traffic": _committed_traffic("r06_c3_pmc.json", "derived", default + "_hbm_side_traffic_bytes"),
+                     "traffic_source": "profiles/r06_c3_pmc.json (2 x FETCH_SIZE + WRITE_SIZE of the default sampler's launch, separate --pmc passes on this round's build; not re-measured here)",
                      "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": best["grad_launch_ms"],
                      "launches_sampled": best["launches_sampled"]},
         "samplers": out,

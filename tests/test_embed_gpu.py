@@ -647,6 +647,122 @@ def test_permutation_gradient_equals_the_scatter_form_on_the_same_negatives(kind
     grade32(f"perm_pull_vs_oracle_closed_form/kind={kind}", g1, ref, BUDGET)
 
 
+def _runs_tables(seed, it, n, n_neg):
+    from torchdr_amd import _lib
+
+    f = torch.empty((n, n_neg), dtype=torch.int64, device="cuda")
+    i = torch.empty((n, n_neg), dtype=torch.int64, device="cuda")
+    _lib.check(_lib.lib().tdr_runs_negatives_debug(seed, it, n, n_neg, _lib.ptr(f), _lib.ptr(i), _lib.stream_ptr()), "runs_debug")
+    return f.cpu(), i.cpu()
+
+
+@pytest.mark.parametrize("n", [4096, 70_000, 50_007])
+def test_run_permutation_sampler_properties(n):
+    """tdr_runs_negatives_debug (the sampler of tdr_ne_grad_runs_f32): with N a multiple of 16 every column is a permutation of the
+    rows without fixed points whose inverse table inverts it; a row never draws from its own run of 16; the 16 rows of a run draw
+    the 16 rows of ONE other run; with a ragged last run the only missing pairs are those with an endpoint in its padding (at most 15
+    per column and side) and the two tables stay each other's inverse on the rest; the draws of a block of rows are uniform over the
+    index range (chi-square over 64 bins); columns and iterations are different maps."""
+    n_neg, iters = 5, 4
+    ar = torch.arange(n)
+    allf = []
+    for t in range(iters):
+        f, i = _runs_tables(777, t, n, n_neg)
+        allf.append(f)
+        for c in range(n_neg):
+            fc, ic = f[:, c], i[:, c]
+            ok_f, ok_i = fc >= 0, ic >= 0
+            assert int((~ok_f).sum()) <= 15 and int((~ok_i).sum()) <= 15
+            if n % 16 == 0:
+                assert bool(ok_f.all()) and bool(ok_i.all())
+                assert torch.equal(fc.sort().values, ar)
+            assert torch.equal(ic[fc[ok_f]], ar[ok_f]) and torch.equal(fc[ic[ok_i]], ar[ok_i])      # each other's inverse
+            assert fc[ok_f].unique().numel() == int(ok_f.sum())                                      # nobody is drawn twice
+            assert not bool(((fc // 16) == (ar // 16))[ok_f].any())                                  # never from the own run
+            # the rows of a run land in one run
+            full = n // 16 * 16
+            tgt = (fc[:full] // 16).view(-1, 16)
+            valid = (fc[:full] >= 0).view(-1, 16)
+            lo = torch.where(valid, tgt, torch.full_like(tgt, 1 << 40)).min(1).values
+            hi = torch.where(valid, tgt, torch.full_like(tgt, -1)).max(1).values
+            assert bool(((lo == hi) | ~valid.any(1)).all())
+    allf = torch.stack(allf, 0)
+    assert float((allf[0, :, 0] == allf[0, :, 1]).float().mean()) < 0.01 and float((allf[0, :, 0] == allf[1, :, 0]).float().mean()) < 0.01
+    rows = slice(0, min(n, 2048))
+    draws = allf[:, rows, :].reshape(-1)
+    draws = draws[draws >= 0]
+    counts = torch.bincount((draws * 64 // n).clamp(max=63), minlength=64).double()
+    expected = torch.bincount((ar * 64 // n).clamp(max=63), minlength=64).double() * draws.numel() / n
+    chi2 = float(((counts - expected) ** 2 / expected).sum())
+    # the 16 rows of a run share their target run: 16-fold clumping of the counts, i.e. the statistic is ~16 x a chi-square(63)
+    assert chi2 < 16 * (63 + 6 * (2 * 63) ** 0.5), chi2
+
+
+@pytest.mark.parametrize("nc,n,k,n_neg", [(2, 30_016, 15, 5), (3, 30_011, 15, 5), (2, 20_003, 45, 8), (2, 1000, 7, 1)])
+def test_run_permutation_gradient_against_the_closed_form_and_the_scatter_form(nc, n, k, n_neg):
+    """tdr_ne_grad_runs_f32 (negatives staged into LDS run by run, both shares of every pair pulled) on a graph with hub rows, a kNN
+    block wider than one batch and a ragged last run: against the closed form in float64 on the sampler's own tables (hubs and sampled
+    rows, incl. the last rows) and, where every pair exists (N a multiple of 16), against tdr_ne_grad_f32 scattering the same table."""
+    from torchdr_amd import _lib
+    from torchdr_amd.neighbor_embedding.base import build_transposed_graph
+
+    L = _lib.lib()
+    assert L.tdr_ne_grad_runs_supported(nc, n, n_neg) == 1 and L.tdr_ne_grad_runs_supported(4, n, n_neg) == 0
+    assert L.tdr_ne_grad_runs_supported(nc, 32, n_neg) == 0 and L.tdr_ne_grad_runs_supported(nc, n, 9) == 0
+    gen = torch.Generator().manual_seed(nc * 1000 + k)
+    NN = torch.randint(0, n - 1, (n, k), generator=gen)
+    NN[:, 0] = torch.randint(0, 40, (n,), generator=gen)
+    NN = NN + (NN >= torch.arange(n)[:, None]).long()
+    NN = NN.to(torch.int32).cuda().contiguous()
+    P = (torch.rand(n, k, generator=gen) / k).cuda().contiguous()
+    Z = (torch.randn(n, nc, generator=gen) * 2).cuda().contiguous()
+    tg = build_transposed_graph(P, NN, 0, n, 1)
+    rep = 2.0 / n * 500.0       # weigh the repulsion up: it is what this kernel changes
+    g = torch.full((n, nc), float("nan"), device="cuda")
+    _lib.check(L.tdr_ne_grad_runs_f32(_lib.ptr(Z), nc, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]),
+                                      3.0, rep, n_neg, 77, 3, _lib.ptr(g), _lib.stream_ptr()), "runs")
+    assert bool(torch.isfinite(g).all())
+    g_again = torch.empty_like(g)
+    _lib.check(L.tdr_ne_grad_runs_f32(_lib.ptr(Z), nc, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]),
+                                      3.0, rep, n_neg, 77, 3, _lib.ptr(g_again), _lib.stream_ptr()), "runs")
+    assert torch.equal(g, g_again)
+    fw, iv = _runs_tables(77, 3, n, n_neg)
+    Zd, NNc, Pd = Z.double().cpu(), NN.cpu().long(), P.double().cpu()
+    rows = torch.cat([torch.arange(0, 48), torch.arange(48, n - 40, 997), torch.arange(n - 40, n)])
+    wanted = set(rows.tolist())
+    src_of = {r: [] for r in wanted}
+    NNl = NNc.tolist()
+    for i in range(n):
+        for p, j in enumerate(NNl[i]):
+            if j in wanted:
+                src_of[j].append((i, p))
+    ref = torch.zeros((rows.numel(), nc), dtype=torch.float64)
+    for a_, r in enumerate(rows.tolist()):
+        zi = Zd[r]
+        acc = torch.zeros(nc, dtype=torch.float64)
+        for p in range(k):
+            df = zi - Zd[NNc[r, p]]
+            acc += 3.0 * 2.0 * Pd[r, p] / (2.0 + (df * df).sum()) * df
+        for (i, p) in src_of[r]:
+            df = zi - Zd[i]
+            acc += 3.0 * 2.0 * Pd[i, p] / (2.0 + (df * df).sum()) * df
+        for c in range(n_neg):
+            for j in (int(fw[r, c]), int(iv[r, c])):
+                if j < 0:
+                    continue
+                df = zi - Zd[j]
+                d = (df * df).sum()
+                acc += -rep / ((1.0 + d) * (2.0 + d)) * df
+        ref[a_] = acc
+    grade64(f"ne_runs_vs_float64_closed_form/nc={nc}/n={n}/k={k}", g.cpu()[rows], ref, BUDGET)
+    if n % 16 == 0:
+        g2 = torch.zeros((n, nc), device="cuda")
+        fwd = fw.cuda().contiguous()
+        _lib.check(L.tdr_ne_grad_f32(_lib.ptr(Z), nc, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]),
+                                     0, 3.0, rep, n_neg, _lib.ptr(fwd), 0, 3, _lib.ptr(g2), _lib.stream_ptr()), "scatter")
+        grade32(f"ne_runs_vs_scatter_form/nc={nc}/n={n}", g, g2, BUDGET)
+
+
 @pytest.mark.parametrize("nc,k,n_neg", [(2, 15, 5), (3, 15, 5), (2, 45, 8), (2, 7, 1)])
 def test_four_lanes_per_row_pull_kernel_equals_the_sixteen_lane_form(nc, k, n_neg):
     """LargeVis with the permutation sampler: ne_pull4_kernel (4 lanes per row, every index load and gather of a lane issued before
@@ -789,6 +905,49 @@ def test_two_half_launch_of_the_permutation_gradient_equals_the_single_visit(kin
     assert torch.equal(again, two)
 
 
+@pytest.mark.parametrize("regime", ["gmm2", "overlap", "swiss", "heavytail"])
+@pytest.mark.parametrize("n", [5000, 20000])
+def test_largevis_samplers_reach_the_reference_scores_on_four_regimes(regime, n):
+    """The gate of the run-permutation sampler (round 6): the same LargeVis fit (perplexity 10, 500 iterations) as the REFERENCE's
+    runs recorded in tests/golden/quality3.json (make_quality3_golden.py imports TorchDR), with each of the three samplers --
+    run-permutation (negatives from LDS), row permutation, independent draws: neighbourhood preservation (K = 15), 10-NN label
+    accuracy and silhouette must reach the reference's worst seed up to its own seed-to-seed spread (floors 10 % / 0.02 / 0.05)."""
+    import json
+    import os
+
+    import torchdr_amd
+    from sklearn.metrics import silhouette_score
+    from tests.conftest import regime_data
+    from torchdr_amd import config
+    from torchdr_amd.eval import knn_label_accuracy, neighborhood_preservation
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "quality3.json")
+    q = [c for c in json.load(open(path))["cases"] if c["regime"] == regime and c["n"] == n]
+    assert len(q) >= 2
+    X, lab = regime_data(regime, n)
+    Xc = X.cuda()
+    out = {}
+    for mode, name in (("runs", "run-permutation"), (True, "permutation"), (False, "independent")):
+        rs = []
+        for seed in (0, 1):
+            with config.options(PERM_NEGATIVES=mode):
+                Z = torchdr_amd.LargeVis(perplexity=10, max_iter=500, random_state=seed).fit_transform(Xc)
+            rs.append({"np": float(neighborhood_preservation(Xc, Z, K=15)), "acc": float(knn_label_accuracy(Z, lab.cuda(), k=10)),
+                       "sil": float(silhouette_score(Z.cpu().numpy(), lab.numpy(), sample_size=5000, random_state=0))})
+        out[name] = {k: min(r[k] for r in rs) for k in rs[0]}
+    ref = {"np": [c["neighborhood_preservation_K15"] for c in q], "acc": [c["knn_label_accuracy_k10"] for c in q],
+           "sil": [c["silhouette"] for c in q]}
+    rec = {"regime": regime, "n": n, "reference": {k: min(v) for k, v in ref.items()}, **out}
+    print(rec)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/largevis_quality.jsonl", "a") as f:
+        f.write(json.dumps(rec) + "\n")
+    for name, got in out.items():
+        assert got["np"] >= min(ref["np"]) - max(0.1 * min(ref["np"]), max(ref["np"]) - min(ref["np"])), (name, got, ref)
+        assert got["acc"] >= min(ref["acc"]) - max(0.02, max(ref["acc"]) - min(ref["acc"])), (name, got, ref)
+        assert got["sil"] >= min(ref["sil"]) - max(0.05, max(ref["sil"]) - min(ref["sil"])), (name, got, ref)
+
+
 @pytest.mark.parametrize("cls_name", ["LargeVis", "InfoTSNE"])
 def test_negative_samplers_give_the_reference_quality(cls_name):
     """the one-GPU default draws negatives from a fixed-point-free PERMUTATION per column (every row the far
@@ -809,7 +968,8 @@ def test_negative_samplers_give_the_reference_quality(cls_name):
     labels = (torch.arange(n) % (n // 100)).cuda()
     cls = getattr(torchdr_amd, cls_name)
     got = {}
-    for perm in (True, False):
+    modes = (True, False, "runs") if cls_name == "LargeVis" else (True, False)
+    for perm in modes:
         nps, accs = [], []
         for seed in (0, 1, 2):
             with config.options(PERM_NEGATIVES=perm):
@@ -819,13 +979,15 @@ def test_negative_samplers_give_the_reference_quality(cls_name):
         got[perm] = (torch.tensor(nps, dtype=torch.float64), torch.tensor(accs, dtype=torch.float64))
     from tests.conftest import AUDIT
 
-    for perm in (True, False):
+    for perm in modes:
         for what, ours, ref in (("np_K15", got[perm][0], ref_np), ("acc_k10", got[perm][1], ref_acc)):
             slack = 2.0 * float(ref.max() - ref.min()) + 0.02
-            AUDIT[f"sampler_quality/{name}/{'permutation' if perm else 'independent'}/{what}"] = {
+            AUDIT[f"sampler_quality/{name}/{ {True: 'permutation', False: 'independent', 'runs': 'run-permutation'}[perm] }/{what}"] = {
                 "ours_mean": float(ours.mean()), "reference_mean": float(ref.mean()), "reference_spread": float(ref.max() - ref.min()), "budget": slack}
             assert float(ours.mean()) > float(ref.min()) - slack, (cls_name, perm, what, ours.tolist(), ref.tolist())
     for i in (0, 1):
         ref = (ref_np, ref_acc)[i]
         slack = 2.0 * float(ref.max() - ref.min()) + 0.02
         assert abs(float(got[True][i].mean() - got[False][i].mean())) < slack, (cls_name, i, got[True][i].tolist(), got[False][i].tolist())
+        if "runs" in got:
+            assert abs(float(got["runs"][i].mean() - got[False][i].mean())) < slack, (cls_name, i, got["runs"][i].tolist(), got[False][i].tolist())

@@ -702,6 +702,190 @@ __global__ __launch_bounds__(256) void ne_pull4_kernel(const NeStepParams S) {
     }
 }
 
+// ---- LargeVis pull form with the negatives served from LDS: the RUN-PERMUTATION sampler (round 6) ----------------------------
+// ne_pull4_kernel still issues 40 divergent 8-byte gathers per row (15 out-edges, ~15 in-edges, 2 x 5 negative items) and the L1
+// serves those at ~0.44 lanes per clock and CU (tools/gather_bench.hip): 40 M lanes are >= 169 us at N = 1M whatever the kernel does
+// with them -- 0.35 of the HBM roofline on SURVEY 8d's bytes is the CEILING of any formulation that gathers every negative.  The
+// negatives are the part whose position nobody prescribes.  Here the keyed cyclic order of the permutation sampler runs over RUNS of
+// 16 consecutive rows instead of rows: in column c of iteration t, run a draws run succ_c(a), row (a, o) draws row (succ_c(a),
+// (o + delta) & 15) with delta hashed from (column key, a), and the row that drew (a, o) is (pred_c(a), (o - delta') & 15) with
+// delta' the shift of pred_c(a).  A workgroup of 64 rows = 4 runs therefore needs, per column, 4 + 4 runs of 128 bytes (nc = 2):
+// 40 coalesced line reads per 64 rows staged into LDS instead of 640 gathers, and a lane reads its negatives from LDS.
+//   * per-row law: a row's draw is uniform over the rows OUTSIDE its own run (the run order is a keyed pseudo-random cyclic order,
+//     the offset a hashed rotation): uniform over N - 16 of the reference's N - 1 candidates (base.py:628-636), never the row itself,
+//     independent across columns and iterations;
+//   * across rows: every row is the far endpoint of exactly n_neg pairs (as with the row permutation); the 16 rows of a run draw the
+//     16 rows of ONE other run (a rotation of them), where the row permutation sends them to 16 unrelated rows;
+//   * N not a multiple of 16: pairs with an endpoint in the padding of the last run do not exist (both of its shares are dropped:
+//     up to 15 rows lose one pair per column and side).
+// Both shares of every pair are still PULLED (nothing is scattered), the neighbour edges are ne_pull4_kernel's.
+constexpr int RUNP_LEN = 16;
+struct RunSlot { uint32_t run, shift; };
+// side 0: the run that run `a` draws in column `col`; side 1: the run that draws run `a`; shift = the drawing run's offset rotation
+__device__ __forceinline__ RunSlot runperm_slot(uint64_t seed, uint32_t iter, int col, uint32_t a, int side, uint32_t n_runs) {
+    const PermKey K = perm_key(seed, iter, col, (int64_t)n_runs);
+    const uint32_t pa = perm_inv(a, K);
+    RunSlot sl;
+    sl.run = side ? perm_pred(pa, K) : perm_succ(pa, K);
+    const uint32_t drawer = side ? sl.run : a;
+    sl.shift = mix32(K.a2 ^ (drawer * 0x9E3779B1u)) & (uint32_t)(RUNP_LEN - 1);
+    return sl;
+}
+__device__ __forceinline__ uint32_t runperm_offset(uint32_t o, uint32_t shift, int side) {
+    return (side ? o - shift : o + shift) & (uint32_t)(RUNP_LEN - 1);
+}
+
+__global__ __launch_bounds__(256) void runperm_debug_kernel(uint64_t seed, uint32_t iter, int64_t n_total, int n_neg,
+                                                            int64_t* __restrict__ fwd, int64_t* __restrict__ inv) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_total * n_neg) return;
+    const int64_t i = e / n_neg;
+    const int c = (int)(e - i * n_neg);
+    const uint32_t n_runs = (uint32_t)((n_total + RUNP_LEN - 1) / RUNP_LEN);
+    const uint32_t a = (uint32_t)(i / RUNP_LEN), o = (uint32_t)(i % RUNP_LEN);
+    const RunSlot s0 = runperm_slot(seed, iter, c, a, 0, n_runs), s1 = runperm_slot(seed, iter, c, a, 1, n_runs);
+    const int64_t j0 = (int64_t)s0.run * RUNP_LEN + runperm_offset(o, s0.shift, 0);
+    const int64_t j1 = (int64_t)s1.run * RUNP_LEN + runperm_offset(o, s1.shift, 1);
+    fwd[e] = j0 < n_total ? j0 : -1;
+    inv[e] = j1 < n_total ? j1 : -1;
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void ne_pull4_runs_kernel(const NeStepParams S) {
+    constexpr int G = 4, U = 4, UN = 4, RL = RUNP_LEN, RPW = 64 / RL, SLOTS = RPW * 16, PPR = RL * NC / 4;
+    __shared__ uint32_t s_run[SLOTS], s_shift[SLOTS];
+    __shared__ __attribute__((aligned(16))) float buf[SLOTS * RL * NC];
+    const int tid = threadIdx.x, gl = tid & (G - 1), rl = tid >> 2;      // rl: row of the workgroup (0..63)
+    const int64_t r = (int64_t)blockIdx.x * 64 + rl;
+    const bool active = r < S.n_rows;
+    const int64_t gi = active ? S.row0 + r : S.row0;                     // idle lanes shadow row 0 of the launch and store nothing
+    const int k = S.k;
+    const int n_items = 2 * S.n_neg;
+    const uint32_t n_runs = (uint32_t)((S.n_total + RL - 1) / RL);
+    // 1. index loads of the first batches (as ne_pull4_kernel)
+    int32_t jo[U];
+    float po[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int p = gl + G * u;
+        jo[u] = (active && p < k) ? S.nn[(size_t)r * k + p] : (int32_t)gi;
+        po[u] = (active && p < k) ? S.P[(size_t)r * k + p] : 0.f;
+    }
+    const int64_t e0 = active ? S.t_rowptr[r] : 0, e1 = active ? S.t_rowptr[r + 1] : 0;
+    const Vec<NC> zi = load_z<NC>(S.Z, gi);
+    // 2. the runs this workgroup's 4 runs draw / are drawn by: one thread per (run, item)
+    if (tid < SLOTS) {
+        const uint32_t a = (uint32_t)blockIdx.x * RPW + (uint32_t)(tid >> 4);
+        const int item = tid & 15;
+        uint32_t run = 0xffffffffu, shift = 0u;
+        if (item < n_items && a < n_runs) {
+            const RunSlot sl = runperm_slot(S.seed, S.iter, item >> 1, a, item & 1, n_runs);
+            run = sl.run; shift = sl.shift;
+        }
+        s_run[tid] = run; s_shift[tid] = shift;
+    }
+    int32_t js[U];
+    float ps[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t e = e0 + gl + G * u;
+        js[u] = e < e1 ? S.t_src[e] : (int32_t)gi;
+        ps[u] = e < e1 ? S.t_val[e] : 0.f;
+    }
+    Vec<NC> zo[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) zo[u] = load_z<NC>(S.Z, jo[u]);
+    __syncthreads();
+    // 3. stage the runs: 16-byte pieces, coalesced (a run is RL * NC * 4 bytes, 16-byte aligned)
+    const int64_t z_floats = S.n_total * NC;
+    for (int p = tid; p < SLOTS * PPR; p += 256) {
+        const int slot = p / PPR, piece = p - slot * PPR;
+        const uint32_t run = s_run[slot];
+        if (run == 0xffffffffu) continue;
+        const int64_t off = (int64_t)run * (RL * NC) + piece * 4;
+        float4 v;
+        if (off + 4 <= z_floats) v = *reinterpret_cast<const float4*>(S.Z + off);
+        else {
+            v.x = off < z_floats ? S.Z[off] : 0.f; v.y = off + 1 < z_floats ? S.Z[off + 1] : 0.f;
+            v.z = off + 2 < z_floats ? S.Z[off + 2] : 0.f; v.w = 0.f;
+        }
+        *reinterpret_cast<float4*>(buf + (size_t)slot * (RL * NC) + piece * 4) = v;
+    }
+    Vec<NC> zs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) zs[u] = load_z<NC>(S.Z, js[u]);
+    __syncthreads();
+    float g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) g[c] = 0.f;
+    // 4. negatives from LDS: item = (column, side); a pair whose other endpoint is padding does not exist
+    {
+        const int a_local = rl >> 4;
+        const uint32_t o = (uint32_t)(rl & 15);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int it = gl + G * u;
+            if (it < n_items && active) {
+                const int slot = a_local * 16 + it;
+                const uint32_t run = s_run[slot];
+                const uint32_t o2 = runperm_offset(o, s_shift[slot], it & 1);
+                if ((int64_t)run * RL + o2 < S.n_total) {
+                    const float* q = buf + (size_t)slot * (RL * NC) + o2 * NC;
+                    float df[NC];
+                    float d = 0.f;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - q[c]; d += df[c] * df[c]; }
+                    const float w = -S.rep_coef / ((1.0f + d) * (2.0f + d));
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) g[c] += w * df[c];
+                }
+            }
+        }
+    }
+    auto edge = [&](const Vec<NC>& zj, float pij) {
+        float df[NC];
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { df[c] = zi.v[c] - zj.v[c]; d += df[c] * df[c]; }
+        const float w = S.exag * 2.0f * pij * (1.0f / (2.0f + d));
+#pragma unroll
+        for (int c = 0; c < NC; ++c) g[c] += w * df[c];
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) edge(zo[u], po[u]);
+    for (int p0 = G * U; active && p0 < k; p0 += G * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int p = p0 + gl + G * u;
+            jo[u] = p < k ? S.nn[(size_t)r * k + p] : (int32_t)gi;
+            po[u] = p < k ? S.P[(size_t)r * k + p] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) zo[u] = load_z<NC>(S.Z, jo[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) edge(zo[u], po[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) edge(zs[u], ps[u]);
+    for (int64_t eb = e0 + G * U; eb < e1; eb += G * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t e = eb + gl + G * u;
+            js[u] = e < e1 ? S.t_src[e] : (int32_t)gi;
+            ps[u] = e < e1 ? S.t_val[e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) zs[u] = load_z<NC>(S.Z, js[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) edge(zs[u], ps[u]);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        g[c] = group_sum<G>(g[c]);
+        if (gl == 0 && active) S.grad[(size_t)gi * NC + c] = g[c];
+    }
+}
+
 // ---- TSNE dense repulsion (tsne.py:172-180): S = sum_ij w_ij, F_i = sum_j (z_i - z_j) w_ij^2 ---------
 // The 256 columns of a tile are staged pair-interleaved (x0 x1 | y0 y1 | ..) and two columns are evaluated at once with
 // packed fp32 instructions (v_pk_add / v_pk_mul / v_pk_fma: two results per lane and issue slot); the weights come from
@@ -1228,6 +1412,42 @@ int tdr_ne_grad_perm_f32(const float* Z, int nc, int64_t n_total, int64_t row0, 
     S.iter = (uint32_t)n_iter; S.grad = grad;
     S.t_rowptr = t_rowptr; S.t_src = t_src; S.t_val = t_val;
     return ne_grad_launch(S, kind == 3 ? rowsum_ws : nullptr, (hipStream_t)stream);
+}
+
+/* 1 when tdr_ne_grad_runs_f32 serves the shape: 2 / 3 components, 1..8 negatives, at least two runs of 16 rows. */
+int tdr_ne_grad_runs_supported(int nc, int64_t n_total, int n_neg) {
+    return (nc == 2 || nc == 3) && n_neg >= 1 && n_neg <= 8 && n_total > 2 * RUNP_LEN && n_total <= 0x7fffffffLL;
+}
+
+/* LargeVis gradient (kind 0 of tdr_ne_grad_perm_f32, all rows: row0 = 0, n_rows = n_total) with the negatives drawn by the
+ * RUN-permutation sampler and served from LDS (ne_pull4_runs_kernel above: law, padding rule).  grad (n_total, nc) is written
+ * (every row once).  Z 16-byte aligned. */
+int tdr_ne_grad_runs_f32(const float* Z, int nc, int64_t n_total, const int32_t* nn, const float* P_, int k, const int64_t* t_rowptr,
+                         const int32_t* t_src, const float* t_val, float exag, float rep_coef, int n_neg, uint64_t seed, int n_iter,
+                         float* grad, void* stream) {
+    if (!Z || !nn || !P_ || !grad || !t_rowptr || !t_src || !t_val || k <= 0 || ((uintptr_t)Z & 15u)) return TDR_ERR_BAD_ARG;
+    if (!tdr_ne_grad_runs_supported(nc, n_total, n_neg)) return TDR_ERR_UNSUPPORTED;
+    NeStepParams S;
+    S.nc = nc; S.perm_neg = 1; S.rowsum = nullptr; S.neg_halves = 1;
+    S.Z = Z; S.n_total = n_total; S.row0 = 0; S.n_rows = n_total; S.nn = nn; S.P = P_; S.k = k; S.kind = 0;
+    S.exag = exag; S.rep_coef = rep_coef; S.n_neg = n_neg; S.neg_inj = nullptr; S.seed = seed; S.iter = (uint32_t)n_iter; S.grad = grad;
+    S.t_rowptr = t_rowptr; S.t_src = t_src; S.t_val = t_val;
+    const dim3 grid((unsigned)((n_total + 63) / 64));
+    if (nc == 2) hipLaunchKernelGGL(ne_pull4_runs_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, S);
+    else hipLaunchKernelGGL(ne_pull4_runs_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, S);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
+}
+
+/* test hook: fwd[i, c] = the row that row i draws in column c, inv[i, c] = the row whose draw of column c hits row i (-1: the pair
+ * does not exist -- its other endpoint is padding of the last run) */
+int tdr_runs_negatives_debug(uint64_t seed, int n_iter, int64_t n_total, int n_neg, int64_t* fwd, int64_t* inv, void* stream) {
+    if (!fwd || !inv || n_total <= 2 * RUNP_LEN || n_total > 0x7fffffffLL || n_neg <= 0) return TDR_ERR_BAD_ARG;
+    const int64_t total = n_total * n_neg;
+    hipLaunchKernelGGL(runperm_debug_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       (uint32_t)n_iter, n_total, n_neg, fwd, inv);
+    TDR_CHECK_LAUNCH();
+    return TDR_OK;
 }
 
 /* Measurement / test switch: lanes per row of tdr_ne_grad_perm_f32's LargeVis launch -- 4 (default: ne_pull4_kernel) or 16

@@ -17,8 +17,12 @@ from torchdr_amd.affinity_matcher import AffinityMatcher
 # compute stream, graph-capturable) when the process group runs on RCCL; False keeps every collective in torch.distributed
 RCCL_CONTEXT = True
 # LargeVis / InfoTSNE on one GPU: negatives drawn as keyed permutations of the rows, both shares of a pair pulled by the rows
-# themselves (tdr_ne_grad_perm_f32: no far-endpoint atomics; csrc/tdr_embed_common.h).  False = the hash sampler + atomics.
-PERM_NEGATIVES = True
+# themselves (tdr_ne_grad_perm_f32: no far-endpoint atomics; csrc/tdr_embed_common.h).  False = the hash sampler + atomics (the
+# reference's independent draws, base.py:628-636; what every row-sharded fit and every injected table uses).  "runs" (LargeVis,
+# round 6): the permutation over RUNS of 16 consecutive rows, negatives served from LDS (tdr_ne_grad_runs_f32; InfoTSNE treats it
+# as True).  Default since round 6 after the quality gate of tests/test_embed_gpu.py::test_largevis_samplers_reach_the_reference_
+# scores_on_four_regimes (profiles/r06_largevis_quality.jsonl): C3's gradient launch 0.211 -> 0.143 ms, fit 146 -> 107 ms.
+PERM_NEGATIVES = "runs"
 # PEER_EXCHANGE: row-sharded fits exchange the rows they stepped as direct peer writes over xGMI (parallel.PeerExchange,
 # csrc/tdr_peerx.hip) instead of an RCCL ring all-gather; falls back to RCCL / torch.distributed when HIP IPC or the stress
 # self-check fails on any rank.  True: always try; False: never; "auto": only where ranks SHARE a device (more ranks than GPUs:

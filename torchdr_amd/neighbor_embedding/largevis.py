@@ -60,6 +60,21 @@ class LargeVis(NegativeSamplingNeighborEmbedding):
         grad = torch.zeros((n, nc), dtype=P.dtype, device=self.device_)
         nn = self._nn_table
         neg = self._neg_ptr_tensor()
+        L = _lib.lib()
+        if (neg is None and _nb._opt("PERM_NEGATIVES") == "runs" and self.world_size == 1 and P.dtype == torch.float32
+                and L.tdr_ne_grad_runs_supported(nc, n, int(self.n_negatives)) and self.embedding_.data_ptr() % 16 == 0):
+            # one GPU, no injected table: RUN-permutation sampler -- the pairs' shares pulled as below, the negatives staged into LDS
+            # run by run instead of gathered one by one (csrc/tdr_embed.hip: ne_pull4_runs_kernel)
+            _lib.check(
+                L.tdr_ne_grad_runs_f32(
+                    _lib.ptr(self.embedding_), nc, n, _lib.ptr(nn), _lib.ptr(P), P.shape[1], _lib.ptr(self._tgraph[0]),
+                    _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]), float(self.early_exaggeration_coeff_),
+                    float(self.repulsion_strength) * 2.0 / n, int(self.n_negatives), self._neg_seed, int(self.n_iter_),
+                    _lib.ptr(grad), _lib.stream_ptr(),
+                ),
+                "tdr_ne_grad_runs_f32",
+            )
+            return grad, False
         if neg is None and _nb._opt("PERM_NEGATIVES") and self.world_size == 1 and P.dtype == torch.float32 and self.n_negatives > 0:
             # one GPU, no injected table: permutation sampler, every pair's two shares pulled (no atomics)
             _lib.check(
