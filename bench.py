@@ -607,8 +607,9 @@ def main():
     pmc_file = "r06_umap_pool_pmc.json" if pool else ("r04_umap_sched_pmc.json" if umod.SCHEDULED else "r01_umap_grad_pmc.json")
     roof_grad = {
         "kernel": ("one whole UMAP iteration: tdr::umap_pool_grad_kernel<2,512,2,256,8> (fired edges from the per-iteration lists, negatives from a "
-                   "per-block LDS pool of 256 uniformly chosen 8-row runs of the embedding) + tdr::sgd_step_kernel -- HIP events around every "
-                   "25th iteration's two launches -- + 1/32 of tdr::umap_sched_build2_kernel (group-ordered schedule build; every build timed)"
+                   "per-block LDS pool of 256 uniformly chosen 8-row runs of the embedding; the launch carries torch.optim.SGD's step: two embedding "
+                   "buffers) -- HIP events around every 25th iteration's launch -- + 1/32 of tdr::umap_sched_build2_kernel (group-ordered schedule "
+                   "build; every build timed)"
                    if pool else
                    "one whole UMAP iteration: tdr::umap_sched_grad_kernel<2,4,false> (ONE launch over both L2 slices of the embedding, "
                    "slices spread over the XCDs) + tdr::umap_sched_combine_sgd_kernel (clamps + SGD step) -- HIP events around "

@@ -12,7 +12,7 @@ from torchdr_amd.utils.sparse import CSRAffinity
 
 
 # bench.py sets this to a list to collect ("grad", start_event, end_event, nnz) around every PROFILE_EVERY-th gradient
-# evaluation and ("build", start_event, end_event, n_iters) around every schedule build (HIP events on the launch
+# evaluation (iterations PROFILE_EVERY // 2, + PROFILE_EVERY, ...) and ("build", start_event, end_event, n_iters) around every schedule build (HIP events on the launch
 # stream); None = no instrumentation.
 PROFILE = None
 PROFILE_EVERY = 25
@@ -659,7 +659,8 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                 "tdr_umap_grad_f64",
             )
             return grad, True
-        prof = PROFILE is not None and int(self.n_iter_) % PROFILE_EVERY == 0
+        # sampled iterations sit between the inspected ones (every check_interval-th, where the step is a launch of its own)
+        prof = PROFILE is not None and int(self.n_iter_) % PROFILE_EVERY == PROFILE_EVERY // 2
         if _opt("SCHEDULED") and self.n_samples_in_ < 2**31 - 1:
             self._compute_gradients_scheduled(grad, neg, prof)
             return grad, True
