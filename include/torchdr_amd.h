@@ -535,15 +535,16 @@ int tdr_pacmap_grad_f32(const float* Z, int nc, int64_t n, const int64_t* near_i
  * visit per row), 0 (default) = split where the negatives dominate a row (>= 64 items) and the gathered tables exceed an XCD's
  * L2; returns the previous value */
 int tdr_ne_grad_perm_halves(int mode);
-/* Round 6: LargeVis's gradient (neighbor_embedding/largevis.py:181-201; all rows of one process) with the negatives drawn by the
+/* Round 6: LargeVis's gradient (neighbor_embedding/largevis.py:181-201) of rows [row0, row0 + n_rows) -- nn / P (n_rows, k) and the
+ * in-edges t_* of those rows, grad (n_rows, nc) COMPLETE for them: a rank of a row-sharded fit steps its rows -- with the negatives drawn by the
  * RUN-permutation sampler -- the keyed cyclic order of tdr_ne_grad_perm_f32 over runs of 16 consecutive rows, a hashed rotation
  * inside the run -- and served from LDS: a row's draw is uniform over the rows outside its own run, every row is the far endpoint of
  * n_neg pairs, both shares of a pair are pulled (csrc/tdr_embed.hip, ne_pull4_runs_kernel).  grad is WRITTEN.  2 / 3 components,
  * n_neg <= 8, Z 16-byte aligned. */
 int tdr_ne_grad_runs_supported(int nc, int64_t n_total, int n_neg);
-int tdr_ne_grad_runs_f32(const float* Z, int nc, int64_t n_total, const int32_t* nn, const float* P, int k, const int64_t* t_rowptr,
-                         const int32_t* t_src, const float* t_val, float exag, float rep_coef, int n_neg, uint64_t seed, int n_iter,
-                         float* grad, void* stream);
+int tdr_ne_grad_runs_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nn, const float* P, int k,
+                         const int64_t* t_rowptr, const int32_t* t_src, const float* t_val, float exag, float rep_coef, int n_neg,
+                         uint64_t seed, int n_iter, float* grad, void* stream);
 int tdr_runs_negatives_debug(uint64_t seed, int n_iter, int64_t n_total, int n_neg, int64_t* fwd, int64_t* inv, void* stream);
 /* measurement / test switch of tdr_ne_grad_perm_f32's LargeVis launch (kind 0, <= 8 negatives, 2 / 3 components): lanes per row --
  * 4 (default since round 6: every lane issues all its index loads and gathers before it uses any) or 16 (rounds 3-5); same terms,

@@ -111,6 +111,13 @@ def _worker(rank, world, port, ret, backend="gloo"):
                 # one negative-sampling seed for all ranks, keyed by global row: the sharded fit IS the single-process fit
                 Z1 = cls(random_state=0, distributed=False, **kw).fit_transform(X)
                 assert torch.equal(Z, Z1), float((Z - Z1).abs().max())
+            if cls is torchdr_amd.LargeVis:
+                # round 6: the run-permutation sampler serves every world size (each rank pulls the complete gradient of ITS rows
+                # and steps them; keyed by global rows; in-edges summed by ascending source): the SAME draws as the single-process
+                # fit, so the embeddings agree to the rounding of the affinity's global normaliser (a sum reduced over ranks) --
+                # with the independent sampler of rounds 1-5 the two fits only shared a law
+                Z1 = cls(random_state=0, distributed=False, **kw).fit_transform(X)
+                assert torch.allclose(Z, Z1, rtol=1e-4, atol=1e-5 * float(Z1.abs().max())), float((Z - Z1).abs().max())
         # --- UMAP with the pruned search: ranks keep their range of the cluster-sorted order, the loop runs in that
         #     numbering on every rank (no kNN row exchange, no index broadcast) -- and is still the single-process fit,
         #     bit for bit, in the caller's order

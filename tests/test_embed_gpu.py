@@ -719,13 +719,27 @@ def test_run_permutation_gradient_against_the_closed_form_and_the_scatter_form(n
     tg = build_transposed_graph(P, NN, 0, n, 1)
     rep = 2.0 / n * 500.0       # weigh the repulsion up: it is what this kernel changes
     g = torch.full((n, nc), float("nan"), device="cuda")
-    _lib.check(L.tdr_ne_grad_runs_f32(_lib.ptr(Z), nc, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]),
+    _lib.check(L.tdr_ne_grad_runs_f32(_lib.ptr(Z), nc, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]),
                                       3.0, rep, n_neg, 77, 3, _lib.ptr(g), _lib.stream_ptr()), "runs")
     assert bool(torch.isfinite(g).all())
     g_again = torch.empty_like(g)
-    _lib.check(L.tdr_ne_grad_runs_f32(_lib.ptr(Z), nc, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]),
+    _lib.check(L.tdr_ne_grad_runs_f32(_lib.ptr(Z), nc, n, 0, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]),
                                       3.0, rep, n_neg, 77, 3, _lib.ptr(g_again), _lib.stream_ptr()), "runs")
     assert torch.equal(g, g_again)
+    # a row chunk (what a rank of a row-sharded fit evaluates; bounds inside a 64-row block and inside a run): the bits of the same
+    # rows of the full launch -- the sampler is keyed by global rows and runs, a row's sum by the row alone
+    for c0, c1 in ((0, n // 3), (n // 3, 2 * (n // 3) + 5), (2 * (n // 3) + 5, n), (1000 % n, 1000 % n + 1)):
+        e0, e1 = int(tg[0][c0]), int(tg[0][c1])
+        rp = (tg[0][c0:c1 + 1] - tg[0][c0]).contiguous()
+        ts, tv = tg[1][e0:e1].contiguous(), tg[2][e0:e1].contiguous()
+        if ts.numel() == 0:
+            ts, tv = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(1, device="cuda")
+        gc = torch.full((c1 - c0, nc), float("nan"), device="cuda")
+        _lib.check(L.tdr_ne_grad_runs_f32(_lib.ptr(Z), nc, n, c0, c1 - c0, _lib.ptr(NN[c0:c1].contiguous()), _lib.ptr(P[c0:c1].contiguous()), k,
+                                          _lib.ptr(rp), _lib.ptr(ts), _lib.ptr(tv), 3.0, rep, n_neg, 77, 3, _lib.ptr(gc), _lib.stream_ptr()), "runs chunk")
+        assert torch.equal(gc, g[c0:c1]), (c0, c1)
+    assert L.tdr_ne_grad_runs_f32(_lib.ptr(Z), nc, n, 5, n, _lib.ptr(NN), _lib.ptr(P), k, _lib.ptr(tg[0]), _lib.ptr(tg[1]), _lib.ptr(tg[2]),
+                                  3.0, rep, n_neg, 77, 3, _lib.ptr(g_again), None) != 0          # chunk beyond the last row
     fw, iv = _runs_tables(77, 3, n, n_neg)
     Zd, NNc, Pd = Z.double().cpu(), NN.cpu().long(), P.double().cpu()
     rows = torch.cat([torch.arange(0, 48), torch.arange(48, n - 40, 997), torch.arange(n - 40, n)])

@@ -756,8 +756,11 @@ __global__ __launch_bounds__(256) void ne_pull4_runs_kernel(const NeStepParams S
     __shared__ uint32_t s_run[SLOTS], s_shift[SLOTS];
     __shared__ __attribute__((aligned(16))) float buf[SLOTS * RL * NC];
     const int tid = threadIdx.x, gl = tid & (G - 1), rl = tid >> 2;      // rl: row of the workgroup (0..63)
-    const int64_t r = (int64_t)blockIdx.x * 64 + rl;
-    const bool active = r < S.n_rows;
+    // a workgroup owns a GLOBAL block of 64 rows = 4 runs (the same partition whatever the row sharding: a rank's launch covers
+    // the blocks its chunk touches and leaves the rows outside the chunk idle)
+    const int64_t gblk = S.row0 / 64 + (int64_t)blockIdx.x;
+    const int64_t r = gblk * 64 + rl - S.row0;                           // local row of the launch
+    const bool active = r >= 0 && r < S.n_rows;
     const int64_t gi = active ? S.row0 + r : S.row0;                     // idle lanes shadow row 0 of the launch and store nothing
     const int k = S.k;
     const int n_items = 2 * S.n_neg;
@@ -775,7 +778,7 @@ __global__ __launch_bounds__(256) void ne_pull4_runs_kernel(const NeStepParams S
     const Vec<NC> zi = load_z<NC>(S.Z, gi);
     // 2. the runs this workgroup's 4 runs draw / are drawn by: one thread per (run, item)
     if (tid < SLOTS) {
-        const uint32_t a = (uint32_t)blockIdx.x * RPW + (uint32_t)(tid >> 4);
+        const uint32_t a = (uint32_t)gblk * RPW + (uint32_t)(tid >> 4);
         const int item = tid & 15;
         uint32_t run = 0xffffffffu, shift = 0u;
         if (item < n_items && a < n_runs) {
@@ -882,7 +885,7 @@ __global__ __launch_bounds__(256) void ne_pull4_runs_kernel(const NeStepParams S
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         g[c] = group_sum<G>(g[c]);
-        if (gl == 0 && active) S.grad[(size_t)gi * NC + c] = g[c];
+        if (gl == 0 && active) S.grad[(size_t)r * NC + c] = g[c];
     }
 }
 
@@ -1419,20 +1422,23 @@ int tdr_ne_grad_runs_supported(int nc, int64_t n_total, int n_neg) {
     return (nc == 2 || nc == 3) && n_neg >= 1 && n_neg <= 8 && n_total > 2 * RUNP_LEN && n_total <= 0x7fffffffLL;
 }
 
-/* LargeVis gradient (kind 0 of tdr_ne_grad_perm_f32, all rows: row0 = 0, n_rows = n_total) with the negatives drawn by the
- * RUN-permutation sampler and served from LDS (ne_pull4_runs_kernel above: law, padding rule).  grad (n_total, nc) is written
- * (every row once).  Z 16-byte aligned. */
-int tdr_ne_grad_runs_f32(const float* Z, int nc, int64_t n_total, const int32_t* nn, const float* P_, int k, const int64_t* t_rowptr,
-                         const int32_t* t_src, const float* t_val, float exag, float rep_coef, int n_neg, uint64_t seed, int n_iter,
-                         float* grad, void* stream) {
+/* LargeVis gradient (kind 0 of tdr_ne_grad_perm_f32) of rows [row0, row0 + n_rows) with the negatives drawn by the RUN-permutation
+ * sampler and served from LDS (ne_pull4_runs_kernel above: law, padding rule).  nn / P (n_rows, k), t_* = in-edges of those rows,
+ * Z (n_total, nc) the whole embedding, 16-byte aligned; grad (n_rows, nc) is WRITTEN (every row once, complete: nothing is sent to
+ * other rows, so a rank of a row-sharded fit steps its own rows from it).  The sampler is keyed by global rows and runs: a row
+ * chunk gives the bits of the same rows of the full launch. */
+int tdr_ne_grad_runs_f32(const float* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, const int32_t* nn, const float* P_, int k,
+                         const int64_t* t_rowptr, const int32_t* t_src, const float* t_val, float exag, float rep_coef, int n_neg,
+                         uint64_t seed, int n_iter, float* grad, void* stream) {
     if (!Z || !nn || !P_ || !grad || !t_rowptr || !t_src || !t_val || k <= 0 || ((uintptr_t)Z & 15u)) return TDR_ERR_BAD_ARG;
+    if (row0 < 0 || n_rows <= 0 || row0 + n_rows > n_total) return TDR_ERR_BAD_ARG;
     if (!tdr_ne_grad_runs_supported(nc, n_total, n_neg)) return TDR_ERR_UNSUPPORTED;
     NeStepParams S;
     S.nc = nc; S.perm_neg = 1; S.rowsum = nullptr; S.neg_halves = 1;
-    S.Z = Z; S.n_total = n_total; S.row0 = 0; S.n_rows = n_total; S.nn = nn; S.P = P_; S.k = k; S.kind = 0;
+    S.Z = Z; S.n_total = n_total; S.row0 = row0; S.n_rows = n_rows; S.nn = nn; S.P = P_; S.k = k; S.kind = 0;
     S.exag = exag; S.rep_coef = rep_coef; S.n_neg = n_neg; S.neg_inj = nullptr; S.seed = seed; S.iter = (uint32_t)n_iter; S.grad = grad;
     S.t_rowptr = t_rowptr; S.t_src = t_src; S.t_val = t_val;
-    const dim3 grid((unsigned)((n_total + 63) / 64));
+    const dim3 grid((unsigned)((row0 + n_rows - 1) / 64 - row0 / 64 + 1));
     if (nc == 2) hipLaunchKernelGGL(ne_pull4_runs_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, S);
     else hipLaunchKernelGGL(ne_pull4_runs_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, S);
     TDR_CHECK_LAUNCH();

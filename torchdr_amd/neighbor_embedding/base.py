@@ -338,7 +338,9 @@ def build_transposed_graph(P, NN, chunk_start, n_total, world_size):
         vals = torch.cat([val[local], ev])
     else:
         rows, srcs, vals = dst, src, val
-    order = torch.argsort(rows, stable=True)
+    # in-edges of a row by ascending source row: the order of a row's sum then does not depend on how the edges arrived (local
+    # edges first, then the exchanged ones rank by rank) -- a row-sharded fit adds the same terms in the same order as one process
+    order = torch.argsort(rows * int(n_total) + srcs, stable=True)
     counts = torch.bincount(rows, minlength=n)
     rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     rowptr[1:] = counts.cumsum(0)

@@ -61,20 +61,23 @@ class LargeVis(NegativeSamplingNeighborEmbedding):
         nn = self._nn_table
         neg = self._neg_ptr_tensor()
         L = _lib.lib()
-        if (neg is None and _nb._opt("PERM_NEGATIVES") == "runs" and self.world_size == 1 and P.dtype == torch.float32
+        if (neg is None and _nb._opt("PERM_NEGATIVES") == "runs" and P.dtype == torch.float32
                 and L.tdr_ne_grad_runs_supported(nc, n, int(self.n_negatives)) and self.embedding_.data_ptr() % 16 == 0):
-            # one GPU, no injected table: RUN-permutation sampler -- the pairs' shares pulled as below, the negatives staged into LDS
-            # run by run instead of gathered one by one (csrc/tdr_embed.hip: ne_pull4_runs_kernel)
+            # no injected table: RUN-permutation sampler -- both shares of every pair pulled by the rows themselves, the negatives
+            # staged into LDS run by run (csrc/tdr_embed.hip: ne_pull4_runs_kernel).  The gradient of a rank's rows is COMPLETE
+            # (nothing is sent to other rows): in a row-sharded fit the rank hands back its chunk (`rows_only`: it steps its rows
+            # and the rows are all-gathered, affinity_matcher.py) -- the same sampler, keyed by global rows, for every world size
+            gchunk = grad if self.world_size == 1 else torch.empty((self.chunk_size_, nc), dtype=P.dtype, device=self.device_)
             _lib.check(
                 L.tdr_ne_grad_runs_f32(
-                    _lib.ptr(self.embedding_), nc, n, _lib.ptr(nn), _lib.ptr(P), P.shape[1], _lib.ptr(self._tgraph[0]),
-                    _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]), float(self.early_exaggeration_coeff_),
-                    float(self.repulsion_strength) * 2.0 / n, int(self.n_negatives), self._neg_seed, int(self.n_iter_),
-                    _lib.ptr(grad), _lib.stream_ptr(),
+                    _lib.ptr(self.embedding_), nc, n, self.chunk_start_, self.chunk_size_, _lib.ptr(nn), _lib.ptr(P), P.shape[1],
+                    _lib.ptr(self._tgraph[0]), _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]),
+                    float(self.early_exaggeration_coeff_), float(self.repulsion_strength) * 2.0 / n, int(self.n_negatives),
+                    self._neg_seed, int(self.n_iter_), _lib.ptr(gchunk), _lib.stream_ptr(),
                 ),
                 "tdr_ne_grad_runs_f32",
             )
-            return grad, False
+            return gchunk, self.world_size > 1
         if neg is None and _nb._opt("PERM_NEGATIVES") and self.world_size == 1 and P.dtype == torch.float32 and self.n_negatives > 0:
             # one GPU, no injected table: permutation sampler, every pair's two shares pulled (no atomics)
             _lib.check(
