@@ -175,6 +175,10 @@ int tdr_knn_screen_clustered_tb_f32(const float* x16, const float* X, int64_t ld
                                     const float* clus_radius, const float* clus_dist, const int32_t* clus_order,
                                     const float* tile_cdist, int64_t q_pos_begin, int64_t q_pos_end, float* out_d, int32_t* out_i,
                                     int32_t* flags, int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
+/* predicted share of the database tiles a pruned scan still visits at threshold tau: out (2 x uint64, caller-zeroed) = {sum over
+ * cluster pairs (w, c) with max(0, dist[w, c] - radius[w] - radius[c])^2 <= tau of tiles[w] tiles[c], sum of tiles}; share = out[0] /
+ * out[1]^2 (ClusterIndex.scan_fraction; exact integers, the same on every rank) */
+int tdr_cluster_scan_fraction_f32(const float* dist, const float* radius, const int32_t* tiles, int C, float tau, void* out, void* stream);
 /* rows of that table from a block of exact squared distances d2 (rows, C) of consecutive rows of the padded sorted order to the
  * C centres: out (rows / 32, C) = sqrt(max(0, min over the tile's valid rows of d2 - (d + 16) 2^-23 (|x|^2 + |c|^2))) rounded
  * down; row_map (rows): source row or -1; xn (rows), cn (C): squared norms */

@@ -287,6 +287,18 @@ def test_cluster_index_is_the_same_on_every_run():
     a, b = ClusterIndex(PackedPoints(X)), ClusterIndex(PackedPoints(X))
     assert a.n_img == b.n_img and torch.equal(a.tile_cluster, b.tile_cluster) and torch.equal(a.radius, b.radius)
     assert torch.equal(a.row_map.sort().values, b.row_map.sort().values)
+    # the predicted scan share (one launch, exact integer sums: tdr_cluster_scan_fraction_f32) against the tensor formulation it
+    # replaced, over thresholds from "own cluster only" to "everything"; asked twice, the second answer comes from the memo
+    t = a.tiles.to(torch.float32)
+    seen = []
+    for tau in (0.0, 0.5, 4.0, 30.0, 200.0, 1e9):
+        gap = (a.dist - a.radius[:, None] - a.radius[None, :]).clamp_(min=0)
+        ref = float((torch.mv((gap * gap <= tau).float(), t) * t).sum() / (t.sum() ** 2))
+        got = a.scan_fraction(tau)
+        assert abs(got - ref) < 1e-5, (tau, got, ref)
+        assert a.scan_fraction(tau) == got and b.scan_fraction(tau) == got
+        seen.append(got)
+    assert seen == sorted(seen) and seen[-1] == 1.0 and seen[0] > 0.0
 
 
 def test_cluster_index_reads_the_number_of_groups_off_the_data():

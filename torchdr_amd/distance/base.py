@@ -305,7 +305,9 @@ class ClusterIndex:
         self.n_img = max(int(n_img.item()), 32)
         self.row_map = row_map[: self.n_img]
         self.tile_cluster = tile_cluster[: self.n_img // 32]
+        self._tiles_i32 = tiles
         self.tiles = tiles.to(torch.int64)
+        self._scan_fraction_memo = {}
         return self
 
     def record_stream(self, stream):
@@ -320,10 +322,24 @@ class ClusterIndex:
     def scan_fraction(self, tau: float) -> float:
         """Share of the database tiles a query block still has to visit when its thresholds are <= tau (squared
         distance units): clusters c with max(0, |c_w - c_c| - R_w - R_c)^2 <= tau, averaged over the blocks."""
+        memo = self.__dict__.setdefault("_scan_fraction_memo", {})
+        key = float(tau)
+        if key in memo:      # the tier choice and the pruning decision ask for the same thresholds
+            return memo[key]
+        t32 = getattr(self, "_tiles_i32", None)
+        if t32 is not None and self.dist.is_cuda and self.dist.dtype == torch.float32:
+            # one launch, exact integer sums, one host read (tdr_cluster_scan_fraction_f32)
+            out = torch.zeros(2, dtype=torch.int64, device=self.dist.device)
+            _lib.check(_lib.lib().tdr_cluster_scan_fraction_f32(_lib.ptr(self.dist), _lib.ptr(self.radius), _lib.ptr(t32), self.n_clusters,
+                                                                key, _lib.ptr(out), _lib.stream_ptr()), "tdr_cluster_scan_fraction_f32")
+            num, tot = out.tolist()
+            memo[key] = float(num) / float(tot * tot) if tot else 1.0
+            return memo[key]
         gap = (self.dist - self.radius[:, None] - self.radius[None, :]).clamp_(min=0)
         t = self.tiles.to(gap.dtype)
         visited = torch.mv((gap * gap <= tau).to(gap.dtype), t)
-        return float((visited * t).sum() / (t.sum() ** 2))
+        memo[key] = float((visited * t).sum() / (t.sum() ** 2))
+        return memo[key]
 
 
     def tiles_hopeless(self, tau: float) -> bool:
