@@ -165,6 +165,14 @@ int tdr_knn_screen_clustered_f32(const float* x16, const float* X, int64_t ldx, 
                                  const float* clus_radius, const float* clus_dist, const int32_t* clus_order,
                                  int64_t q_pos_begin, int64_t q_pos_end, float* out_d, int32_t* out_i, int32_t* flags,
                                  int32_t* n_flagged, void* ws, int64_t ws_bytes, void* stream);
+/* workspace bytes of the cluster-pruned searches (this one, _tb_f32, tdr_knn_ivf_f32) over n_img image rows; never less than
+ * tdr_knn_screen_workspace_bytes(n_img, n_img, d, k, tier); 0 = unsupported */
+int64_t tdr_knn_screen_clustered_workspace_bytes(int64_t n_img, int d, int k, int tier);
+/* measurement / test switch of the exact cluster-pruned searches: 1 (default since round 6) = per-query UNSORTED candidate buffers
+ * in LDS (up to 126 entries), every lane appending its own survivors, compacted -- bisection for the k-th smallest screening value,
+ * entries beyond it + the error band dropped -- only when full and at the end of a cluster; 0 = the sorted lists of rounds 2-5.
+ * Same neighbours either way; returns the previous value */
+int tdr_knn_screen_clustered_lists(int lazy);
 /* tdr_knn_screen_clustered_f32 with a per-tile table: tile_cdist (n_img / 32, n_clusters) = for every 32-row tile of the sorted
  * order a LOWER bound of the distance from any of its rows to every cluster centre (tdr_cluster_tile_cdist_f32).  A cluster is
  * skipped when |x - c| - R_c of the workgroup's own query rows already exceeds their thresholds: sharper than the ball-to-ball

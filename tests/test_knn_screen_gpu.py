@@ -187,6 +187,52 @@ def test_screen_cluster_pruned_scan_equals_exact(scale, n, d, k, tier):
     assert torch.equal(C0, C1)
 
 
+@pytest.mark.parametrize("scale,n,d,k,tier,dups", [(2.0, 40000, 128, 30, 1, 0), (2.0, 40000, 128, 60, 1, 0), (0.7, 30000, 64, 15, 0, 0),
+                                                   (3.0, 25000, 256, 30, 1, 0), (2.0, 30000, 128, 30, 1, 400), (5.0, 6000, 16, 5, 1, 0),
+                                                   (2.0, 20000, 100, 70, 1, 0)])
+def test_pruned_scan_lazy_buffers_equal_sorted_lists_and_exact(scale, n, d, k, tier, dups):
+    """The exact cluster-pruned search keeps UNSORTED per-query candidate buffers, compacted when full (round 6,
+    tdr_knn_screen_clustered_lists(1), the default), instead of the sorted lists of rounds 2-5 (0): both give the one-stage
+    kernel's rows bit for bit -- tight blobs (nearly every tile of a query's own cluster holds survivors), overlapping blobs,
+    k above what the buffers serve (the sorted lists take over), D = 256 (shorter buffers), tiny k, and `dups` copies of one
+    point (more candidates inside the error band than a buffer holds: those queries are reported lost and recomputed exactly)."""
+    from torchdr_amd import _lib
+    from torchdr_amd.distance import base as dbase
+
+    L = _lib.lib()
+    base = gmm(n, d, scale, seed=5 + d + k)
+    parts = [base, base[:300]]
+    if dups:
+        parts.append(base[1234:1235].expand(dups, d))
+    X = torch.cat(parts).cuda()
+    old = (dbase.SCREEN_MODE, dbase.PRUNE_MODE)
+    res = {}
+    try:
+        dbase.SCREEN_MODE, dbase.PRUNE_MODE = "0", "0"
+        Xp = dbase.PackedPoints(X)
+        C0, I0 = dbase.knn_packed(Xp, Xp, k, "sqeuclidean", True)
+        dbase.PRUNE_MODE = "force"
+        for mode in (1, 0):
+            prev = L.tdr_knn_screen_clustered_lists(mode)
+            try:
+                C1 = torch.empty_like(C0)
+                I1 = torch.empty_like(I0)
+                bad = dbase._knn_screen(Xp, Xp, 0, Xp.n, k, "sqeuclidean", True, 0, C1, I1, pilot=False, tier=tier)
+                assert dbase.LAST_KNN["pruned"]
+                res[mode] = (C1, I1, bad)
+            finally:
+                L.tdr_knn_screen_clustered_lists(prev)
+    finally:
+        dbase.SCREEN_MODE, dbase.PRUNE_MODE = old
+    assert L.tdr_knn_screen_clustered_lists(1) == 1      # the default
+    for mode in (1, 0):
+        C1, I1, bad = res[mode]
+        assert torch.equal(I0, I1), f"lists mode {mode}: {int((I0 != I1).any(1).sum())} rows differ"
+        assert torch.equal(C0, C1)
+    if dups:
+        assert res[1][2] >= dups      # every copy has the other copies at distance 0 inside its band
+
+
 def test_headline_size_search_sampled_against_the_one_stage_kernel():
     """BASELINE's full size (N = 1M, D = 128, k = 30), default dispatch (pilot -> tier -> cluster-pruned two-stage search):
     256 sampled rows searched by the CPU oracle against the whole set, and 8192 sampled rows re-searched by the one-stage exact fp32 kernel -- itself bit-exact against the CPU oracle at the
@@ -299,6 +345,42 @@ def test_cluster_index_is_the_same_on_every_run():
         assert a.scan_fraction(tau) == got and b.scan_fraction(tau) == got
         seen.append(got)
     assert seen == sorted(seen) and seen[-1] == 1.0 and seen[0] > 0.0
+
+
+@pytest.mark.parametrize("S,C,d,blobs", [(2000, 200, 16, 0), (8000, 1000, 32, 1000), (16384, 2048, 8, 300), (777, 777, 4, 0)])
+def test_farthest_point_seeding_equals_the_greedy_selection(S, C, d, blobs):
+    """tdr_cluster_maxmin_f32 / _adaptive_f32 against a greedy farthest-point selection in numpy on the same fp32 matrix (ties:
+    smallest index), incl. a sample as large as the kernel's capacity and C = S (every point); the adaptive form returns a prefix
+    of the fixed form's seeds."""
+    import numpy as np
+
+    from torchdr_amd import _lib
+
+    L = _lib.lib()
+    gen = torch.Generator().manual_seed(S + C)
+    if blobs:
+        X = torch.randn(blobs, d, generator=gen)[torch.randint(0, blobs, (S,), generator=gen)] * 6 + torch.randn(S, d, generator=gen) * 0.3
+    else:
+        X = torch.randn(S, d, generator=gen)
+    D2 = torch.cdist(X.double(), X.double()).pow(2).float().cuda().contiguous()
+    assert S <= L.tdr_cluster_maxmin_capacity()
+    seeds = torch.full((C,), -1, dtype=torch.int32, device="cuda")
+    _lib.check(L.tdr_cluster_maxmin_f32(_lib.ptr(D2), D2.stride(0), S, C, _lib.ptr(seeds), _lib.stream_ptr()), "maxmin")
+    got = seeds.cpu()
+    ad = torch.full((C,), -1, dtype=torch.int32, device="cuda")
+    n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(L.tdr_cluster_maxmin_adaptive_f32(_lib.ptr(D2), D2.stride(0), S, max(C // 4, 1), C, 0.25, _lib.ptr(ad), _lib.ptr(n),
+                                                 _lib.stream_ptr()), "maxmin_adaptive")
+    na = int(n.item())
+    assert max(C // 4, 1) <= na <= C and torch.equal(ad.cpu()[:na], got[:na])
+    Dn = D2.cpu().numpy()
+    mind = np.full(S, 3.0e38, dtype=np.float32)
+    cur, ref = 0, []
+    for _ in range(min(C, 300)):
+        ref.append(cur)
+        mind = np.minimum(mind, Dn[cur])
+        cur = int(np.argmax(np.maximum(mind, 0)))       # first (smallest) index among equal maxima
+    assert got[: len(ref)].tolist() == ref
 
 
 def test_cluster_index_reads_the_number_of_groups_off_the_data():

@@ -26,6 +26,15 @@
 namespace tdr {
 namespace scr {
 
+#ifdef TDR_SCREEN_STATS
+// measurement build only (tools/screen_stats.py): [0] wave cycles of knn_screen_kernel, [1] cycles inside the list updates,
+// [2] merge events (query, tile), [3] survivors merged, [4] serial insertions tried, [5] tile steps, [6] cycles at workgroup barriers
+__device__ unsigned long long g_screen_stats[8][64];   // 64 slots per counter (by workgroup): the host adds them up
+#define TDR_STAT_ADD(i, v) do { if (C.lane == 0) atomicAdd(&g_screen_stats[i][blockIdx.x & 63], (unsigned long long)(v)); } while (0)
+#else
+#define TDR_STAT_ADD(i, v) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // meta reductions
 // ---------------------------------------------------------------------------------------------------------
@@ -135,6 +144,7 @@ struct ScreenParams {
     int max_visit;                  // approximate (IVF-style) search: clusters a workgroup may scan at most; 0 = exact
     const float* tile_cdist;        // optional (n_db_tiles, n_clusters): lower bound of min over the tile's rows of |x - c_c| --
                                     // the bound |x - y| >= |x - c_c| - R_c of the tile's own rows replaces the ball-to-ball bound
+    int32_t* lost;                  // LAZY kernels: (nq, caller-zeroed) 1 = the query's error band held more candidates than its buffer
 };
 
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
@@ -217,6 +227,7 @@ __device__ __forceinline__ void screen_insert_serial(const SCtx<QB>& C, const fl
                     if (!(cred < __builtin_inff())) continue;  // padding row (norm +inf)
                     const float xq = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, C.xn[qb]), sq));
                     uint64_t nk, nt;
+                    TDR_STAT_ADD(4, 1);
                     if (coop_insert2<ITEMS>(C.keys + ((size_t)qb * 32 + sq) * P.L, P.L, P.k - 1, mkkey(cred + xq, (uint32_t)j),
                                             C.lane, nk, nt)) {
                         if (C.q == sq)
@@ -294,6 +305,8 @@ __device__ __forceinline__ void screen_insert_merge(const SCtx<QB>& C, const flo
                     }
                 }
             }
+            TDR_STAT_ADD(2, 1);
+            TDR_STAT_ADD(3, nb);
             // rank
             const uint64_t Bv = ((uint64_t)Bhi << 32) | (uint64_t)Blo;
             int cntS = 0, rankB = 0;
@@ -327,6 +340,219 @@ __device__ __forceinline__ void screen_insert_merge(const SCtx<QB>& C, const flo
             const uint64_t nk = Lst[P.k - 1], nt = Lst[L - 1];
             if (C.q == sq)
                 tau_r[qb] = reduce_tau(fminf(u2f((uint32_t)(nk >> 32)) + C.band[qb], u2f((uint32_t)(nt >> 32))), C.xn[qb]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LAZY candidate buffers (round 6, the cluster-pruned scan).  The sorted lists above pay per (query, tile) with a survivor:
+// on the headline data a query meets survivors in 27 of the 32 tiles of its own cluster (5.7 each: neighbours and
+// non-neighbours of one blob are a few per cent apart), ~300 + 56 nb cycles every time, one query after the other -- 61 % of
+// the wave cycles of the pruned scan (tools/screen_stats.py).  Here a query's region is an UNSORTED buffer of L entries
+// (L as large as the LDS of a whole CU allows: 126 at D <= 128) with its count in a register of the query's two lanes:
+//   append   every lane stores its own survivors at (count + its offset inside the lane pair) -- all 32 queries of the
+//            wavefront at once, no ranking, no shuffling;
+//   compact  only when a buffer cannot take a tile's survivors (and at the end of a cluster, to refresh the threshold the
+//            pruning test reads): an upper bound U of the k-th smallest screening value of the buffer by bisection on the
+//            ordered bit images (ballot + popcount per step), tau = U + 2E, entries above tau dropped, the rest moved up.
+// Exactness is the list form's argument: tau_q >= a_(k)(everything seen) + 2E at every moment (U >= a_(k) of a subset of
+// what was seen), so no true neighbour is ever refused or dropped; a buffer that is still full after a compaction holds L
+// candidates inside the band -- the query is marked lost and the host recomputes it (the sorted lists flag the same state).
+// ---------------------------------------------------------------------------------------------------------
+struct LazyState {
+    int cnt;     // entries in the buffer of this lane's query (the same in both lanes of the query)
+    int fresh;   // entries appended since the last compaction
+    int lost;
+};
+
+// lane primitives of the lazy buffers (tools/lab/lane_test.hip checks them on the device)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// value of the other lane of a query's pair (lane ^ 32): v_permlane32_swap instead of a trip through the LDS crossbar
+__device__ __forceinline__ int pair_other(int v, int h) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)(h ? r[0] : r[1]);
+}
+// wave-wide max / min of unsigned values by DPP row shifts and row broadcasts (the result lands in lane 63)
+template <bool MAX>
+__device__ __forceinline__ uint32_t wave_extreme_u32(uint32_t v) {
+#define TDR_DPP_STEP(CTRL, RM)                                                                                     \
+    {                                                                                                              \
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, RM, 0xf, false);            \
+        v = MAX ? (o > v ? o : v) : (o < v ? o : v);                                                               \
+    }
+    TDR_DPP_STEP(0x111, 0xf) TDR_DPP_STEP(0x112, 0xf) TDR_DPP_STEP(0x114, 0xf) TDR_DPP_STEP(0x118, 0xf)
+    TDR_DPP_STEP(0x142, 0xa) TDR_DPP_STEP(0x143, 0xc)
+#undef TDR_DPP_STEP
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// compaction of the buffer of query sq (n entries, k <= n, wave-uniform); returns the new count
+template <int ITEMS>
+__device__ __forceinline__ int lazy_compact(const SCtx<1>& C, int sq, int n, float& tau_new) {
+    const ScreenParams& P = *C.P;
+#ifdef TDR_SCREEN_STATS
+    const unsigned long long tc0 = __builtin_readcyclecounter();
+    int n_it = 0;
+#endif
+    uint64_t* Lst = C.keys + (size_t)sq * P.L;
+    uint64_t cur[ITEMS];
+    uint32_t v[ITEMS];      // bit images; 0xffffffff (above every image) where the lane holds no entry
+    uint32_t vmin = 0xffffffffu, vmax = 0u;
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+        const int p = C.lane + 64 * t;
+        const bool valid = p < n;
+        cur[t] = valid ? Lst[p] : ~0ull;
+        v[t] = (uint32_t)(cur[t] >> 32);
+        vmin = v[t] < vmin ? v[t] : vmin;
+        if (valid) vmax = v[t] > vmax ? v[t] : vmax;
+    }
+    uint32_t lo = wave_extreme_u32<false>(vmin), hi = wave_extreme_u32<true>(vmax);
+    // invariant: at least k entries have an image <= hi.  The bisection ends as soon as a bound holds k .. k + slack entries (a few
+    // entries more than the k smallest stay in the buffer: nothing next to the band's own population) -- about log2(n / slack)
+    // steps on values spread over the range (4.1 on the headline data), each a compare + ballot + popcount per 64 entries.  A
+    // wavefront that has its SIMD to itself issues an instruction every ~5 cycles, so what counts is their number: the first
+    // form ran 20 steps behind two bpermute reductions and cost ~3.5 k cycles per compaction (tools/screen_stats.py), the early
+    // end brought 2.35 k, DPP reductions the rest.
+    const int slack = P.k >= 32 ? P.k >> 3 : 4;
+    for (int it = 0; it < 32 && lo < hi; ++it) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+#ifdef TDR_SCREEN_STATS
+        ++n_it;
+#endif
+#pragma unroll
+        for (int t = 0; t < ITEMS; ++t) c += __popcll(ballot64(v[t] <= mid));
+        if (c >= P.k) {
+            hi = mid;
+            if (c <= P.k + slack) break;
+        } else {
+            lo = mid + 1u;
+        }
+    }
+    const float band = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, C.band[0]), sq));
+    tau_new = u2f(hi) + band;
+    int base = 0;
+#pragma unroll
+    for (int t = 0; t < ITEMS; ++t) {
+        const bool keep = v[t] != 0xffffffffu && u2f(v[t]) <= tau_new;
+        const unsigned long long mk = ballot64(keep);
+        const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0));
+        if (keep) Lst[pos] = cur[t];     // pos <= own position, and every entry was read above (LDS operations of a wavefront are in order)
+        base += __popcll(mk);
+    }
+    TDR_STAT_ADD(2, 1);
+#ifdef TDR_SCREEN_STATS
+    TDR_STAT_ADD(3, __builtin_readcyclecounter() - tc0);
+    TDR_STAT_ADD(4, n_it);
+#endif
+    return base;
+}
+
+// the finished tile's survivors into the buffers
+template <int ITEMS>
+__device__ __forceinline__ void screen_append_lazy(const SCtx<1>& C, const float (&dv)[1][16], int Tprev, float (&tau_r)[1], LazyState& S) {
+    const ScreenParams& P = *C.P;
+    const int L = P.L;
+    const uint32_t jb = (uint32_t)Tprev * 32u + 4u * (uint32_t)C.h;
+    const float xq = C.xn[0];
+    // candidates that can never enter: padding rows carry +inf norms (their reduced value is +inf: refused by a finite threshold,
+    // and the threshold is clamped to the largest finite value); rows beyond the database and the query's own row are rare and
+    // wave-uniform to detect (a tile at the end of the database, the query tile's own tile)
+    float tq = fminf(tau_r[0], 3.4028234663852886e38f);
+    uint32_t dead = 0u;
+    const int64_t self0 = C.qt0 * 32 + P.q_offset;      // the wavefront's own rows: [self0, self0 + 32)
+    if ((int64_t)Tprev * 32 + 32 > P.n_db || (P.exclude_self && (int64_t)Tprev * 32 + 31 >= self0 && (int64_t)Tprev * 32 <= self0 + 31)) {
+        const int64_t jself = self0 + C.q;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t j = (int64_t)jb + (r & 3) + 8 * (r >> 2);
+            dead |= (j >= P.n_db || (P.exclude_self && j == jself)) ? (1u << r) : 0u;
+        }
+    }
+    uint32_t smask = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) smask |= (dv[0][r] <= tq) ? (1u << r) : 0u;
+    smask &= ~dead;
+    uint64_t* Lst = C.keys + (size_t)C.q * L;
+    for (;;) {
+        if (ballot64(smask != 0u) == 0ull) break;
+        const int n_mine = __popc(smask);
+        const int n_oth = pair_other(n_mine, C.h);
+        int pos = S.cnt + (C.h ? n_oth : 0);    // the lower lane of the pair stores first
+        if (ballot64(S.cnt + n_mine + n_oth > L) == 0ull) {
+            // every buffer of the wavefront takes its survivors (all but the few steps that fill one): no bound checks
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if ((smask >> r) & 1u) {
+                    Lst[pos] = mkkey(dv[0][r] + xq, jb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+                    ++pos;
+                }
+            }
+            S.cnt += n_mine + n_oth;
+            S.fresh += n_mine + n_oth;
+            break;
+        }
+        int wrote = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (((smask >> r) & 1u) && pos < L) {
+                Lst[pos] = mkkey(dv[0][r] + xq, jb + (uint32_t)((r & 3) + 8 * (r >> 2)));
+                ++pos;
+                ++wrote;
+                smask &= ~(1u << r);
+            }
+        }
+        wrote += pair_other(wrote, C.h);
+        S.cnt += wrote;
+        S.fresh += wrote;
+        const unsigned long long pend = ballot64(smask != 0u);
+        if (pend == 0ull) break;
+        // a query with survivors left over has a full buffer: compact it, then test the leftovers against the new threshold
+        uint32_t qmask = (uint32_t)pend | (uint32_t)(pend >> 32);
+        while (qmask) {
+            const int sq = __builtin_amdgcn_readfirstlane(__builtin_ctz(qmask));
+            qmask &= qmask - 1u;
+            float tau_new;
+            const int newn = lazy_compact<ITEMS>(C, sq, L, tau_new);
+            if (C.q == sq) {
+                if (newn >= L) {
+                    // L candidates inside the band: nothing can be dropped and nothing more can be taken
+                    S.lost = 1;
+                    smask = 0u;
+                    tau_r[0] = -__builtin_inff();
+                } else {
+                    S.cnt = newn;
+                    S.fresh = 0;
+                    tau_r[0] = reduce_tau(tau_new, xq);
+                }
+            }
+        }
+        tq = fminf(tau_r[0], 3.4028234663852886e38f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (((smask >> r) & 1u) && !(dv[0][r] <= tq)) smask &= ~(1u << r);
+    }
+}
+
+// thresholds brought up to date (end of a cluster): the queries that took at least min_fresh entries since their last compaction,
+// or that have met k candidates and still have no threshold
+template <int ITEMS>
+__device__ __forceinline__ void lazy_refresh(const SCtx<1>& C, float (&tau_r)[1], LazyState& S, int min_fresh) {
+    const ScreenParams& P = *C.P;
+    const bool want = !S.lost && S.cnt >= P.k && (S.fresh >= min_fresh || (S.fresh > 0 && tau_r[0] == __builtin_inff()));
+    const unsigned long long m = __ballot(want);
+    uint32_t qmask = (uint32_t)m | (uint32_t)(m >> 32);
+    while (qmask) {
+        const int sq = __builtin_amdgcn_readfirstlane(__builtin_ctz(qmask));
+        qmask &= qmask - 1u;
+        const int n = __builtin_amdgcn_readlane(S.cnt, sq);
+        float tau_new;
+        const int newn = lazy_compact<ITEMS>(C, sq, n, tau_new);
+        if (C.q == sq) {
+            S.cnt = newn;
+            S.fresh = 0;
+            tau_r[0] = reduce_tau(tau_new, C.xn[0]);
         }
     }
 }
@@ -387,10 +613,10 @@ __device__ __forceinline__ int survivor_lanes(const float (&pmin)[QB][4], const 
 
 // One tile step: multiply tile T (A fragments from LDS) into acc and finish tile T-1 out of `prev` between the
 // MFMA groups.  Slices are processed in double-buffered groups of GS.
-template <int KS, int ITEMS, int QB, int TERMS, bool HAVE_PREV>
+template <int KS, int ITEMS, int QB, int TERMS, bool HAVE_PREV, bool LAZY>
 __device__ __forceinline__ void stile_step(const SCtx<QB>& C, const char* __restrict__ img, const f16x8 (&bh)[QB][KS],
                                            const f16x8 (&bl)[QB][KS], f32x16 (&acc)[QB], const f32x16 (&prev)[QB],
-                                           const float* ynp_prev, int Tprev, float (&tau_r)[QB]) {
+                                           const float* ynp_prev, int Tprev, float (&tau_r)[QB], LazyState& S) {
     constexpr int GS = (KS >= 2) ? 2 : 1, NG = KS / GS;
     constexpr int PPG = (4 + NG - 1) / NG;
 #pragma unroll
@@ -459,13 +685,23 @@ __device__ __forceinline__ void stile_step(const SCtx<QB>& C, const char* __rest
     }
     if (HAVE_PREV) {
         const int lanes = survivor_lanes<QB>(pmin, tau_r);
-        if (lanes) screen_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_r, lanes);
+        TDR_STAT_ADD(5, 1);
+#ifdef TDR_SCREEN_STATS
+        const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+        if (lanes) {
+            if constexpr (LAZY) screen_append_lazy<ITEMS>(C, dv, Tprev, tau_r, S);
+            else screen_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_r, lanes);
+        }
+#ifdef TDR_SCREEN_STATS
+        TDR_STAT_ADD(1, __builtin_readcyclecounter() - ts0);
+#endif
     }
 }
 
-template <int ITEMS, int QB>
+template <int ITEMS, int QB, bool LAZY>
 __device__ __forceinline__ void stile_drain(const SCtx<QB>& C, const f32x16 (&prev)[QB], const float* ynp_prev, int Tprev,
-                                            float (&tau_r)[QB]) {
+                                            float (&tau_r)[QB], LazyState& S) {
     float dv[QB][16];
     float pmin[QB][4];
     f32x4 yn[4];
@@ -474,15 +710,25 @@ __device__ __forceinline__ void stile_drain(const SCtx<QB>& C, const f32x16 (&pr
 #pragma unroll
     for (int g = 0; g < 4; ++g) sform_part<QB>(C, prev, yn, g, dv, pmin);
     const int lanes = survivor_lanes<QB>(pmin, tau_r);
-    if (lanes) screen_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_r, lanes);
+#ifdef TDR_SCREEN_STATS
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+    if (lanes) {
+        if constexpr (LAZY) screen_append_lazy<ITEMS>(C, dv, Tprev, tau_r, S);
+        else screen_insert<ITEMS, QB>(C, dv, pmin, Tprev, tau_r, lanes);
+    }
+#ifdef TDR_SCREEN_STATS
+    TDR_STAT_ADD(1, __builtin_readcyclecounter() - ts0);
+#endif
 }
 
 // Workgroup = 4 wavefronts x QB query blocks of 32.  QB = 1: 128 queries, two workgroups per CU (two wavefronts
 // per SIMD) when the lists fit 80 KiB.  QB = 2: 256 queries, one workgroup per CU, one wavefront per SIMD driving
 // two MFMA chains off the same A fragments -- half the LDS reads, LDS-DMA instructions and barriers per matrix
 // instruction.
-template <int KS, int ITEMS, int QB, int TERMS>
+template <int KS, int ITEMS, int QB, int TERMS, bool LAZY = false>
 __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) void knn_screen_kernel(const ScreenParams P) {
+    static_assert(!LAZY || QB == 1, "lazy buffers: one query tile per wavefront");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int NW = 4;
     constexpr int IMG_B = KS * 2048;                 // bytes of the fragment blocks of one tile image in HBM
@@ -499,6 +745,13 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
     const int lane = tid & 63, wave = tid >> 6;
     const int q = lane & 31, h = lane >> 5;
     uint64_t* keys = keys_all + (size_t)wave * QB * Ln * 32;
+#ifdef TDR_SCREEN_STATS
+    const unsigned long long t_kernel0 = __builtin_readcyclecounter();
+    unsigned long long t_bar = 0;
+#define TDR_SYNC() do { const unsigned long long b0_ = __builtin_readcyclecounter(); __syncthreads(); t_bar += __builtin_readcyclecounter() - b0_; } while (0)
+#else
+#define TDR_SYNC() __syncthreads()
+#endif
 
     const int64_t n_qtiles = (P.nq + 31) / 32;
     const int64_t qt0 = (((int64_t)blockIdx.x + P.batch0) * NW + wave) * QB;
@@ -539,6 +792,7 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
         tau_r[qb] = lane_valid ? __builtin_inff() : -__builtin_inff();
     }
     for (int p = lane; p < QB * Ln * 32; p += 64) keys[p] = KEY_SENTINEL;
+    LazyState S = {0, 0, 0};
 
     const int split = blockIdx.y;
     int t_begin = split * P.tiles_per_split;  // also the origin of the tile / norm ring indices of the current range
@@ -568,12 +822,12 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
         if (r_begin >= r_end) return;
         t_begin = r_begin;
         stage(r_begin);
-        __syncthreads();
+        TDR_SYNC();
         int T = r_begin;
         {
             if (T + 1 < r_end) stage(T + 1);
-            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, false>(C, tile0, bh, bl, accA, accA, nring, T, tau_r);
-            __syncthreads();
+            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, false, LAZY>(C, tile0, bh, bl, accA, accA, nring, T, tau_r, S);
+            TDR_SYNC();
             ++T;
         }
         // ONE copy of the steady-state step (the kernel is ~100 KB of code against a 64 KB instruction cache): the
@@ -581,14 +835,20 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
         while (T < r_end) {
             if (T + 1 < r_end) stage(T + 1);
             const char* img = ((T - t_begin) & 1) ? tile1 : tile0;
-            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true>(C, img, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r);
-            __syncthreads();
+#ifdef TDR_SCREEN_STATS
+            const unsigned long long tstep0 = __builtin_readcyclecounter();
+#endif
+            if (wave_active) stile_step<KS, ITEMS, QB, TERMS, true, LAZY>(C, img, bh, bl, accB, accA, TDR_YN(T - 1), T - 1, tau_r, S);
+#ifdef TDR_SCREEN_STATS
+            TDR_STAT_ADD(7, __builtin_readcyclecounter() - tstep0);
+#endif
+            TDR_SYNC();
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) accA[qb] = accB[qb];
             ++T;
         }
-        if (wave_active) stile_drain<ITEMS, QB>(C, accA, TDR_YN(r_end - 1), r_end - 1, tau_r);
-        __syncthreads();  // the last norm-ring slot / tile buffers may be restaged by the next range
+        if (wave_active) stile_drain<ITEMS, QB, LAZY>(C, accA, TDR_YN(r_end - 1), r_end - 1, tau_r, S);
+        TDR_SYNC();  // the last norm-ring slot / tile buffers may be restaged by the next range
     };
 
     {
@@ -663,6 +923,7 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
         }
         while (more) {
             int rb = t_begin, re = t_end;
+            int c_found = -1;    // exact pruned mode: the cluster about to be scanned
             if (!pruned) {
                 more = false;
             } else {
@@ -786,22 +1047,72 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
                     if (tid == 0) vis[c >> 5] |= 1u << (c & 31);     // read again only after the barriers of the scan below
                     rb = P.clus_tile_begin[c];
                     re = P.clus_tile_begin[c + 1];
+                    c_found = c;
                     found = true;
                 }
                 if (!found) break;
                 ++visited;
             }
+            if constexpr (LAZY) {
+                // The lazy buffers refresh a threshold only when a buffer fills up, and the test above read them as they were.  Before
+                // a cluster is actually scanned: bring the thresholds of every wavefront up to date and test THIS cluster again -- a
+                // workgroup whose stale thresholds already exclude everything (the headline data after its own cluster) never pays
+                // for the refresh.
+                if (pruned && P.max_visit <= 0 && c_found >= 0) {
+                    const bool stale = wave_active && __any(!S.lost && S.cnt >= P.k && (S.fresh >= 8 || (S.fresh > 0 && tau_r[0] == __builtin_inff())));
+                    if (lane == 0) wmask[wave] = stale ? 1ull : 0ull;
+                    __syncthreads();
+                    const bool any_stale = (wmask[0] | wmask[1] | wmask[2] | wmask[3]) != 0ull;
+                    __syncthreads();
+                    if (any_stale) {
+                        if (wave_active) lazy_refresh<ITEMS>(C, tau_r, S, 8);
+                        wg_threshold(tau_wg, band_wg);
+                        const float rc = P.clus_radius[c_found];
+                        float lb = __builtin_inff();
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            if (cw[w] < 0) continue;
+                            float g = P.clus_dist[(size_t)cw[w] * P.n_clusters + c_found] - P.clus_radius[cw[w]] - rc;
+                            if (P.tile_cdist) {
+#pragma unroll
+                                for (int qb = 0; qb < QB; ++qb)
+                                    g = fmaxf(g, P.tile_cdist[(size_t)(qtile[w] + qb) * P.n_clusters + c_found] - rc);
+                            }
+                            lb = fminf(lb, g > 0.f ? g * g : 0.f);
+                        }
+                        if (lb * 0.9999f - band_wg > tau_wg) { rb = 0; re = 0; }   // excluded after all (its bit in `vis` stays: thresholds only fall)
+                    }
+                }
+            }
             scan_range(rb, re);
         }
     }
 #undef TDR_YN
+#ifdef TDR_SCREEN_STATS
+    if (lane == 0 && wave_active) {
+        atomicAdd(&g_screen_stats[0][blockIdx.x & 63], __builtin_readcyclecounter() - t_kernel0);
+        atomicAdd(&g_screen_stats[6][blockIdx.x & 63], t_bar);
+    }
+#endif
+#undef TDR_SYNC
 
     if (wave_active) {
         for (int jq = 0; jq < 32 * QB; ++jq) {
             const int64_t qi = qt0 * 32 + jq;
             if (qi >= P.nq) break;
-            for (int p = lane; p < Ln; p += 64)
-                P.cand[((size_t)split * P.nq + qi) * Ln + p] = keys[(size_t)jq * Ln + p];
+            if constexpr (LAZY) {
+                // the buffer's entries in arrival order, sentinels behind them (the rescoring kernel ranks by counting)
+                const int nj = __builtin_amdgcn_readlane(S.cnt, jq);
+                for (int p = lane; p < Ln; p += 64)
+                    P.cand[((size_t)split * P.nq + qi) * Ln + p] = p < nj ? keys[(size_t)jq * Ln + p] : KEY_SENTINEL;
+            } else {
+                for (int p = lane; p < Ln; p += 64)
+                    P.cand[((size_t)split * P.nq + qi) * Ln + p] = keys[(size_t)jq * Ln + p];
+            }
+        }
+        if constexpr (LAZY) {
+            const int64_t qi = qt0 * 32 + q;
+            if (h == 0 && qi < P.nq && S.lost && P.lost) P.lost[qi] = 1;
         }
     }
 }
@@ -825,6 +1136,7 @@ struct RescoreParams {
     int pred_terms;        // 0: the prediction counts the launch's own band; 2: the (wider) band of the two-term split h.h' + h.l', counted
                            // on a three-term pilot's near-exact screening values -- the threshold scan's two-term tier is chosen by it
     const int32_t* lost;   // optional (nq): 1 = the threshold scan dropped candidates of this query (buffer capacity)
+    int unsorted;          // 1: the lists are the lazy buffers of the pruned scan (any order, overflow reported through `lost`)
     const int32_t* row_map; // screening index -> source row (cluster-sorted search), NULL = identity
     int64_t q_begin, q_end; // screening positions handled by this launch
     float* out_d;
@@ -867,66 +1179,90 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
 
     // overflow test per split: list full and its last entry inside that split's band
     bool ovf = false;
-    for (int s = lane; s < P.n_splits; s += 64) {
+    for (int s = lane; s < (P.unsorted ? 0 : P.n_splits); s += 64) {
         const uint64_t kl = ak[s * P.L + P.L - 1], kk = ak[s * P.L + P.k - 1];
         if (kl != KEY_SENTINEL && P.L > P.k) ovf |= u2f((uint32_t)(kl >> 32)) <= u2f((uint32_t)(kk >> 32)) + band;
         if (P.L == P.k) ovf = true;
     }
     const bool any_ovf = __any(ovf);
 
-    // global k-th smallest screening key (rank by counting; keys are distinct except sentinels)
+    // global k-th smallest screening VALUE: the smallest bit image with at least k entries at or below it, by bisection (a ballot
+    // and a popcount per 64 entries and step).  Rounds 1-5 ranked every key against every other -- total^2 / 64 compares per
+    // lane: 1.2-2 ms for the 512 queries of a pilot (32 slices x L entries each, on the critical path of the kNN build) and, with
+    // the 126-entry buffers of the lazy pruned scan, 4.3 ms at N = 1M.
+    int nv = 0;
     for (int p0 = 0; p0 < total; p0 += 64) {
         const int p = p0 + lane;
-        const uint64_t mine = (p < total) ? ak[p] : KEY_SENTINEL;
-        int rank = 0;
-        for (int pp = 0; pp < total; ++pp) rank += (ak[pp] < mine) ? 1 : 0;
-        if (p < total && mine != KEY_SENTINEL && rank == P.k - 1) sc[0] = (uint32_t)(mine >> 32);
+        nv += __popcll(__ballot(p < total && ak[p] != KEY_SENTINEL));
     }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    const float thr = u2f(sc[0]) + band;
-    const float thr_pred = u2f(sc[0]) + band_pred;
-
-    // exact distances of the candidates inside the band
-    int in_band = 0, in_pred = 0;
-    for (int p0 = 0; p0 < total; p0 += 64) {
-        const int p = p0 + lane;
-        uint64_t key = KEY_SENTINEL;
-        if (p < total) {
-            const uint64_t mine = ak[p];
-            if (mine != KEY_SENTINEL && u2f((uint32_t)(mine >> 32)) <= thr_pred) ++in_pred;
-            if (mine != KEY_SENTINEL && u2f((uint32_t)(mine >> 32)) <= thr) {
-                ++in_band;
-                const uint32_t jp = (uint32_t)(mine & 0xffffffffu);
-                const uint32_t j = P.row_map ? (uint32_t)P.row_map[jp] : jp;
-                const float* yr = P.Y + (size_t)j * P.ldy;
-                float acc = 0.f;
-                int c = 0;
-                if ((P.ldy & 3) == 0 && ((uintptr_t)P.Y & 15) == 0) {
-                    for (; c + 4 <= P.d; c += 4) {
-                        const f32x4 yv = *reinterpret_cast<const f32x4*>(yr + c);
-                        acc = __builtin_fmaf(xq[c], yv[0], acc);
-                        acc = __builtin_fmaf(xq[c + 1], yv[1], acc);
-                        acc = __builtin_fmaf(xq[c + 2], yv[2], acc);
-                        acc = __builtin_fmaf(xq[c + 3], yv[3], acc);
-                    }
-                }
-                for (; c < P.d; ++c) acc = __builtin_fmaf(xq[c], yr[c], acc);
-                const float cval = __builtin_fmaf(-2.0f, acc, __fadd_rn(nx, P.norms_y[j]));
-                key = mkkey(cval, j);
+    uint32_t kth = 0xFF800000u;      // fewer than k candidates: +inf, everything is inside the band
+    if (nv >= P.k) {
+        uint32_t lo = 0u, hi = 0xFF7FFFFFu;    // images of finite values lie below that of +inf (0xFF800000, the sentinels')
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            int c = 0;
+            for (int p0 = 0; p0 < total; p0 += 64) {
+                const int p = p0 + lane;
+                c += __popcll(__ballot(p < total && (uint32_t)(ak[p] >> 32) <= mid));
             }
+            if (c >= P.k) hi = mid;
+            else lo = mid + 1u;
         }
-        if (p < total) ek[p] = key;
+        kth = hi;
+    }
+    const float thr = u2f(kth) + band;
+    const float thr_pred = u2f(kth) + band_pred;
+
+    // the candidates inside the band, packed: ek[0 .. m)
+    int m = 0, in_pred = 0;
+    for (int p0 = 0; p0 < total; p0 += 64) {
+        const int p = p0 + lane;
+        const uint64_t key = (p < total) ? ak[p] : KEY_SENTINEL;
+        const float av = u2f((uint32_t)(key >> 32));
+        const bool inb = key != KEY_SENTINEL && av <= thr;
+        in_pred += __popcll(__ballot(key != KEY_SENTINEL && av <= thr_pred));
+        const unsigned long long mk = __ballot(inb);
+        if (inb) ek[m + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0))] = key;
+        m += __popcll(mk);
+    }
+    const int in_band = m;
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    // their exact distances (reference arithmetic), one candidate per lane: ak[0 .. m) (the screening keys are not needed any more)
+    for (int p0 = 0; p0 < m; p0 += 64) {
+        const int p = p0 + lane;
+        if (p < m) {
+            const uint64_t mine = ek[p];
+            const uint32_t jp = (uint32_t)(mine & 0xffffffffu);
+            const uint32_t j = P.row_map ? (uint32_t)P.row_map[jp] : jp;
+            const float* yr = P.Y + (size_t)j * P.ldy;
+            float acc = 0.f;
+            int c = 0;
+            if ((P.ldy & 3) == 0 && ((uintptr_t)P.Y & 15) == 0) {
+                for (; c + 4 <= P.d; c += 4) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(yr + c);
+                    acc = __builtin_fmaf(xq[c], yv[0], acc);
+                    acc = __builtin_fmaf(xq[c + 1], yv[1], acc);
+                    acc = __builtin_fmaf(xq[c + 2], yv[2], acc);
+                    acc = __builtin_fmaf(xq[c + 3], yv[3], acc);
+                }
+            }
+            for (; c < P.d; ++c) acc = __builtin_fmaf(xq[c], yr[c], acc);
+            const float cval = __builtin_fmaf(-2.0f, acc, __fadd_rn(nx, P.norms_y[j]));
+            ak[p] = mkkey(cval, j);
+        }
     }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
-    for (int p0 = 0; p0 < total; p0 += 64) {
+    // rank by (distance, index) among the m rescored candidates
+    for (int p0 = 0; p0 < m; p0 += 64) {
         const int p = p0 + lane;
-        const uint64_t mine = (p < total) ? ek[p] : KEY_SENTINEL;
+        const uint64_t mine = (p < m) ? ak[p] : KEY_SENTINEL;
         int rank = 0;
-        for (int pp = 0; pp < total; ++pp) rank += (ek[pp] < mine) ? 1 : 0;
-        if (p < total && mine != KEY_SENTINEL && rank < P.k) {
+        for (int pp = 0; pp < m; ++pp) rank += (ak[pp] < mine) ? 1 : 0;
+        if (p < m && rank < P.k) {
             float c = u2f((uint32_t)(mine >> 32));
             if (P.metric == 1) c = sqrt_rn(fmaxf(c, 0.f));
             P.out_d[(size_t)qs * P.k + rank] = c;
@@ -935,8 +1271,6 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     }
     // A database-sliced launch keeps L entries PER SLICE, so it overflows far less than the unsliced launch of the
     // same search would; a pilot that stands for an unsliced run predicts from the merged band population instead.
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { in_band += __shfl_xor(in_band, o, 64); in_pred += __shfl_xor(in_pred, o, 64); }
     bool flag = any_ovf || (P.predict_unsplit && (P.pred_terms ? in_pred : in_band) >= P.pred_L);
     if (P.lost && P.lost[qi] != 0) flag = true;
     if (lane == 0) {
@@ -965,7 +1299,7 @@ static size_t screen_lds_bytes(int ks, int L, int qb, int terms) {
 //   tier 1: three terms, band ~1e-4 ||x|| ||y||, k + ~17..24 spare slots, two workgroups per CU (80 KiB each);
 //           larger k: one workgroup per CU, two list entries per lane (L <= 128).
 //   tier 2: three terms, one workgroup per CU, up to k + 72 spare slots.
-struct ScreenCfg { int qb, L, items, wg_per_cu, terms; };
+struct ScreenCfg { int qb, L, items, wg_per_cu, terms, lazy; };
 
 static int screen_qb_pref() { return 1; }  // 256 queries per workgroup measured slower (786 vs 759 ms at 1M)
 
@@ -977,7 +1311,7 @@ static int max_list_len(int ks, int qb, int terms, size_t budget, int cap) {
 
 static ScreenCfg screen_cfg(int ks, int k, int tier) {
     const int spare_min = 8;
-    ScreenCfg c = {0, 0, 0, 0, 3};
+    ScreenCfg c = {0, 0, 0, 0, 3, 0};
     if (tier == 0) {
         const int L2 = max_list_len(ks, 1, 1, (ks > 8 ? 160 : 80) * 1024, 64);
         if (k + 16 <= L2) { c.qb = 1; c.L = L2; c.items = 1; c.wg_per_cu = ks > 8 ? 1 : 2; c.terms = 1; }
@@ -994,6 +1328,20 @@ static ScreenCfg screen_cfg(int ks, int k, int tier) {
     const int L1 = max_list_len(ks, 1, 3, 160 * 1024, 128);
     const int spare = tier == 1 ? 32 : 72;
     if (k + spare_min <= L1) { c.qb = 1; c.L = (k + spare < L1) ? k + spare : L1; c.items = c.L > 64 ? 2 : 1; c.wg_per_cu = 1; return c; }
+    return c;
+}
+
+// The cluster-pruned scan with lazy buffers (screen_append_lazy): one workgroup per CU, the buffers take what the tiles leave of
+// the CU's 160 KiB (126 entries per query at D <= 128, 94 at D <= 256); worth it only while a buffer holds a tile's survivors
+// next to the k + band entries a compaction keeps (L >= 2 k, L >= k + 40), otherwise the sorted lists serve the search.
+static int g_clustered_lazy = 1;     // tdr_knn_screen_clustered_lists
+static ScreenCfg lazy_cfg(int ks, int k, const ScreenCfg& base) {
+    ScreenCfg c = base;
+    c.lazy = 0;
+    if (!g_clustered_lazy || base.L == 0) return c;
+    const int Lz = max_list_len(ks, 1, base.terms, 160 * 1024, 128) & ~1;
+    if (Lz < 2 * k || Lz < k + 40 || Lz <= base.L) return c;
+    c.qb = 1; c.L = Lz; c.items = 2; c.wg_per_cu = 1; c.lazy = 1;
     return c;
 }
 
@@ -1024,18 +1372,19 @@ static int screen_splits(int64_t nq, int n_db_tiles, const ScreenCfg& c) {
     return (int)s;
 }
 
-template <int KS, int ITEMS, int QB, int TERMS>
+template <int KS, int ITEMS, int QB, int TERMS, bool LAZY = false>
 static int launch_screen(const ScreenParams& P, int n_wgs, size_t lds, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<KS, ITEMS, QB, TERMS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_screen_kernel<KS, ITEMS, QB, TERMS, LAZY>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((knn_screen_kernel<KS, ITEMS, QB, TERMS>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((knn_screen_kernel<KS, ITEMS, QB, TERMS, LAZY>), dim3((unsigned)n_wgs, (unsigned)P.n_splits), dim3(256), lds, st, P);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
 
 template <int KS>
 static int launch_screen_ks(const ScreenParams& P, const ScreenCfg& c, int n_wgs, size_t lds, hipStream_t st) {
+    if (c.lazy) return c.terms == 1 ? launch_screen<KS, 2, 1, 1, true>(P, n_wgs, lds, st) : launch_screen<KS, 2, 1, 3, true>(P, n_wgs, lds, st);
     if (c.terms == 1) return launch_screen<KS, 1, 1, 1>(P, n_wgs, lds, st);
     if constexpr (KS <= 8) {
         if (c.qb == 2) return launch_screen<KS, 1, 2, 3>(P, n_wgs, lds, st);
@@ -1182,9 +1531,11 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     if (ks == 0) return TDR_ERR_UNSUPPORTED;
     if (k < 1 || (int64_t)k > n_db - (exclude_self ? 1 : 0)) return TDR_ERR_BAD_ARG;
     if (tier < 0 || tier > 2) return TDR_ERR_BAD_ARG;
-    const ScreenCfg cfg = screen_cfg(ks, k, tier);
+    const ScreenCfg cfg0 = screen_cfg(ks, k, tier);
+    if (cfg0.L == 0) return TDR_ERR_UNSUPPORTED;
+    // exact pruned searches keep lazy buffers (the approximate search stays on the sorted lists its CPU restatement was pinned with)
+    const ScreenCfg cfg = (ct && ct->max_visit == 0) ? lazy_cfg(ks, k, cfg0) : cfg0;
     const int L = cfg.L;
-    if (L == 0) return TDR_ERR_UNSUPPORTED;
     if (n_db > 0x7fffffffLL) return TDR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     ScreenParams P;
@@ -1203,8 +1554,11 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     P.clus_order = ct ? ct->clus_order : nullptr;
     P.max_visit = ct ? ct->max_visit : 0;
     P.tile_cdist = ct ? ct->tile_cdist : nullptr;
-    const int64_t need = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
+    const int64_t lists_bytes = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
+    const int64_t need = lists_bytes + (cfg.lazy ? ((nq * 4 + 15) / 16) * 16 : 0);
     if (ws_bytes < need) return TDR_ERR_WORKSPACE;
+    P.lost = cfg.lazy ? (int32_t*)((char*)ws + lists_bytes) : nullptr;
+    if (cfg.lazy && hipMemsetAsync(P.lost, 0, (size_t)nq * 4, st) != hipSuccess) return (int)hipGetLastError();
     int wgs = (int)((nq + 128 * cfg.qb - 1) / (128 * cfg.qb));
     int64_t q_lo = 0, q_hi = nq;
     if (ct && q_pos_end > q_pos_begin) {  // only the query batches covering [q_pos_begin, q_pos_end) of the sorted order
@@ -1220,7 +1574,7 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     R.cand = P.cand; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq;
     R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.terms = cfg.terms; R.predict_unsplit = predict_unsplit; R.row_map = ct ? ct->row_map : nullptr; R.q_begin = q_lo; R.q_end = q_hi; R.out_d = out_d;
     R.out_i = out_i; R.flags = flags; R.n_flagged = n_flagged;
-    R.pred_L = pred_L > 0 ? pred_L : L; R.pred_terms = pred_terms; R.lost = nullptr;
+    R.pred_L = pred_L > 0 ? pred_L : L; R.pred_terms = pred_terms; R.lost = P.lost; R.unsorted = cfg.lazy;
     return launch_rescore(R, st);
 }
 
@@ -1392,9 +1746,32 @@ int tdr_knn_screen_flat_f32(const float* q16, const float* Xq, int64_t ldq, cons
     RescoreParams R;
     R.cand = list; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq; R.ldy = ldy;
     R.d = d; R.dpad = F.ks * 16; R.k = k; R.L = L; R.n_splits = 1; R.metric = metric; R.terms = terms; R.predict_unsplit = 0;
-    R.pred_L = L; R.pred_terms = 0; R.lost = lost; R.row_map = nullptr; R.q_begin = 0; R.q_end = nq; R.out_d = out_d; R.out_i = out_i;
+    R.pred_L = L; R.pred_terms = 0; R.lost = lost; R.unsorted = 0; R.row_map = nullptr; R.q_begin = 0; R.q_end = nq; R.out_d = out_d; R.out_i = out_i;
     R.flags = flags; R.n_flagged = n_flagged;
     return launch_rescore(R, st);
+}
+
+/* Workspace bytes of the cluster-pruned searches below (tdr_knn_screen_clustered_f32 / _tb_f32 / tdr_knn_ivf_f32) over n_img image
+ * rows: the candidate buffers of the launch they will make (lazy buffers: up to 126 entries per query + a word per query) --
+ * never less than tdr_knn_screen_workspace_bytes(n_img, n_img, d, k, tier); 0 when the search is not supported. */
+int64_t tdr_knn_screen_clustered_workspace_bytes(int64_t n_img, int d, int k, int tier) {
+    const int ks = pick_ks(d);
+    if (ks == 0 || n_img <= 0 || k < 1 || tier < 0 || tier > 2) return 0;
+    const ScreenCfg c0 = screen_cfg(ks, k, tier);
+    if (c0.L == 0) return 0;
+    const ScreenCfg c = lazy_cfg(ks, k, c0);
+    const int64_t plain = n_img * (int64_t)c0.L * 8;
+    const int64_t lazy = c.lazy ? n_img * (int64_t)c.L * 8 + ((n_img * 4 + 15) / 16) * 16 : 0;
+    return plain > lazy ? plain : lazy;
+}
+
+/* measurement / test switch of the exact cluster-pruned searches: 1 (default since round 6) = unsorted candidate buffers,
+ * compacted when full (screen_append_lazy in csrc/tdr_knn_screen.hip), 0 = the sorted lists of rounds 2-5; the same results
+ * either way (only which rows get flagged for the exact kernel can differ); returns the previous value */
+int tdr_knn_screen_clustered_lists(int lazy) {
+    const int old = g_clustered_lazy;
+    if (lazy == 0 || lazy == 1) g_clustered_lazy = lazy;
+    return old;
 }
 
 /*
@@ -1465,5 +1842,23 @@ int tdr_knn_ivf_f32(const float* x16, const float* X, int64_t ldx, const float* 
     return knn_screen_impl(x16, X, ldx, norms, n_img, 0, x16, X, ldx, norms, n_img, d, k, metric, exclude_self, tier, 0, meta,
                            out_d, out_i, flags, n_flagged, ws, ws_bytes, &ct, 0, 0, stream);
 }
+
+#ifdef TDR_SCREEN_STATS
+/* measurement build only: copy the counters of the list-keeping scan to the host and (reset != 0) clear them */
+int tdr_debug_screen_stats(unsigned long long* out, int reset) {
+    static unsigned long long h[8][64];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(tdr::scr::g_screen_stats), sizeof(h)) != hipSuccess) return (int)hipGetLastError();
+    for (int i = 0; i < 8; ++i) {
+        out[i] = 0;
+        for (int j = 0; j < 64; ++j) out[i] += h[i][j];
+    }
+    if (reset) {
+        for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 64; ++j) h[i][j] = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(tdr::scr::g_screen_stats), h, sizeof(h)) != hipSuccess) return (int)hipGetLastError();
+    }
+    return TDR_OK;
+}
+#endif
 
 }  // extern "C"

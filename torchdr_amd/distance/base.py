@@ -779,7 +779,7 @@ def _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_
     out_d / out_i are indexed by SOURCE row.  Returns (flags indexed by source row, n_flagged)."""
     L = _lib.lib()
     dev, d = Y.device, Y.d
-    ws_bytes = L.tdr_knn_screen_workspace_bytes(ci.n_img, ci.n_img, d, k, tier)
+    ws_bytes = L.tdr_knn_screen_clustered_workspace_bytes(ci.n_img, d, k, tier)
     ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
     flags = torch.zeros(Y.n, dtype=torch.int32, device=dev)
     n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -925,7 +925,7 @@ def _knn_ivf(Y: "PackedPoints", k: int, metric: str, exclude_self: bool, nlist: 
                                            _lib.ptr(ci.row_map), _lib.ptr(ci.img16), _lib.stream_ptr()), "tdr_pack16_mapped_f32")
     out_d = torch.full((Y.n, k), float("inf"), dtype=torch.float32, device=dev)
     out_i = torch.full((Y.n, k), -1, dtype=torch.int32, device=dev)
-    ws_bytes = L.tdr_knn_screen_workspace_bytes(ci.n_img, ci.n_img, d, k, tier)
+    ws_bytes = L.tdr_knn_screen_clustered_workspace_bytes(ci.n_img, d, k, tier)
     ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
     flags = torch.zeros(Y.n, dtype=torch.int32, device=dev)
     n_flagged = torch.zeros(1, dtype=torch.int32, device=dev)
