@@ -137,6 +137,11 @@ int tdr_knn_screen_f32(const float* q16, const float* Xq, int64_t ldq, const flo
  * rounding, padded cluster-sorted layout. */
 int tdr_cluster_sample_i32(int64_t n, int S, uint32_t seed, int32_t* sample_idx, void* stream);
 int tdr_cluster_maxmin_capacity(void);
+/* measurement / test switch of the farthest-point seeding: 1 (default since round 6) = every dependent step finds winner AND
+ * runner-up and reads both rows of the distance matrix; the runner-up is taken as the following seed when it is at least as far from
+ * the winner as from the seeds before (it is then exactly the next greedy pick); 0 = one seed per step; same seeds; returns the
+ * previous value */
+int tdr_cluster_maxmin_mode(int two_per_step);
 int tdr_cluster_maxmin_f32(const float* D2, int64_t ld, int S, int C, int32_t* seeds, void* stream);
 /* the same with the number of seeds read off the data: up to c_max seeds, ended at the first step t >= c_min at which the
  * max-min squared distance falls below `drop` x the previous one (every well-separated group holds a seed); no such step:

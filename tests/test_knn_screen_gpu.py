@@ -347,32 +347,46 @@ def test_cluster_index_is_the_same_on_every_run():
     assert seen == sorted(seen) and seen[-1] == 1.0 and seen[0] > 0.0
 
 
-@pytest.mark.parametrize("S,C,d,blobs", [(2000, 200, 16, 0), (8000, 1000, 32, 1000), (16384, 2048, 8, 300), (777, 777, 4, 0)])
+@pytest.mark.parametrize("S,C,d,blobs", [(2000, 200, 16, 0), (8000, 1000, 32, 1000), (16384, 2048, 8, 300), (777, 777, 4, 0), (1500, 400, 2, -1)])
 def test_farthest_point_seeding_equals_the_greedy_selection(S, C, d, blobs):
-    """tdr_cluster_maxmin_f32 / _adaptive_f32 against a greedy farthest-point selection in numpy on the same fp32 matrix (ties:
-    smallest index), incl. a sample as large as the kernel's capacity and C = S (every point); the adaptive form returns a prefix
-    of the fixed form's seeds."""
+    """tdr_cluster_maxmin_f32 / _adaptive_f32 -- two seeds per dependent step (round 6, the default) and the one-chain kernel of
+    rounds 2-5 -- against each other and against a greedy farthest-point selection in numpy on the same fp32 matrix (ties: smallest
+    index), incl. a sample as large as the kernel's capacity and C = S (every point; duplicates at distance 0); the adaptive form
+    returns a prefix of the fixed form's seeds and stops at the same count in both kernels."""
     import numpy as np
 
     from torchdr_amd import _lib
 
     L = _lib.lib()
     gen = torch.Generator().manual_seed(S + C)
-    if blobs:
+    if blobs < 0:
+        X = torch.randint(0, 12, (S, d), generator=gen).float()     # 144 distinct points: every max-min distance is 0 after 144 seeds
+    elif blobs:
         X = torch.randn(blobs, d, generator=gen)[torch.randint(0, blobs, (S,), generator=gen)] * 6 + torch.randn(S, d, generator=gen) * 0.3
     else:
         X = torch.randn(S, d, generator=gen)
     D2 = torch.cdist(X.double(), X.double()).pow(2).float().cuda().contiguous()
     assert S <= L.tdr_cluster_maxmin_capacity()
-    seeds = torch.full((C,), -1, dtype=torch.int32, device="cuda")
-    _lib.check(L.tdr_cluster_maxmin_f32(_lib.ptr(D2), D2.stride(0), S, C, _lib.ptr(seeds), _lib.stream_ptr()), "maxmin")
-    got = seeds.cpu()
-    ad = torch.full((C,), -1, dtype=torch.int32, device="cuda")
-    n = torch.zeros(1, dtype=torch.int32, device="cuda")
-    _lib.check(L.tdr_cluster_maxmin_adaptive_f32(_lib.ptr(D2), D2.stride(0), S, max(C // 4, 1), C, 0.25, _lib.ptr(ad), _lib.ptr(n),
-                                                 _lib.stream_ptr()), "maxmin_adaptive")
-    na = int(n.item())
-    assert max(C // 4, 1) <= na <= C and torch.equal(ad.cpu()[:na], got[:na])
+    assert L.tdr_cluster_maxmin_mode(1) == 1     # two seeds per dependent step is the default
+    runs = {}
+    for mode in (1, 0):
+        prev = L.tdr_cluster_maxmin_mode(mode)
+        try:
+            seeds = torch.full((C,), -1, dtype=torch.int32, device="cuda")
+            _lib.check(L.tdr_cluster_maxmin_f32(_lib.ptr(D2), D2.stride(0), S, C, _lib.ptr(seeds), _lib.stream_ptr()), "maxmin")
+            ad = torch.full((C,), -1, dtype=torch.int32, device="cuda")
+            n = torch.zeros(1, dtype=torch.int32, device="cuda")
+            for drop in (0.25, 0.9):
+                _lib.check(L.tdr_cluster_maxmin_adaptive_f32(_lib.ptr(D2), D2.stride(0), S, max(C // 4, 1), C, drop, _lib.ptr(ad), _lib.ptr(n),
+                                                             _lib.stream_ptr()), "maxmin_adaptive")
+                na = int(n.item())
+                assert max(C // 4, 1) <= na <= C and torch.equal(ad.cpu()[:na], seeds.cpu()[:na])
+                runs[(mode, drop)] = na
+            runs[mode] = seeds.cpu()
+        finally:
+            L.tdr_cluster_maxmin_mode(prev)
+    assert torch.equal(runs[1], runs[0]) and runs[(1, 0.25)] == runs[(0, 0.25)] and runs[(1, 0.9)] == runs[(0, 0.9)]
+    got = runs[1]
     Dn = D2.cpu().numpy()
     mind = np.full(S, 3.0e38, dtype=np.float32)
     cur, ref = 0, []

@@ -97,6 +97,130 @@ __global__ __launch_bounds__(CL_TH) void cluster_maxmin_kernel(const float* __re
     if (tid == 0 && n_out) *n_out = stop_at >= 0 ? stop_at : c_min;
 }
 
+// ---- 2b. the same seeding, TWO seeds per dependent step (round 6) -----------------------------------------------------------
+// A step of cluster_maxmin_kernel is one dependent chain -- arg-max -> read that row of D2 (32 KiB of a 256 MB matrix: 2-3 us of
+// latency) -> update -> arg-max: 3.2 us per seed alone, 4.5 us next to the pilots of a kNN build (4.5 ms at 1000 seeds, the longest
+// link of the build's critical path).  Adding the winner w lowers the min-distances only around it: if the RUNNER-UP r of the same
+// arg-max is at least as far from w as from the seeds so far (D2[w][r] >= mind[r] > 0), then after the update mind[r] is unchanged
+// and every other point's value has not grown -- r is exactly the next greedy pick (keys are distinct: (value, smaller index
+// first)).  So a step finds winner AND runner-up, reads both rows (and D2[w][r]) at once, and takes the runner-up as the following
+// seed when that test holds; when it fails, only the winner is taken.  The seeds are those of the one-chain kernel bit for bit,
+// fixed and adaptive count.  (Round 6 first tried PREFETCHING the runner-up's row under the next arg-max: one arg-max per seed
+// stayed on the chain and the extra registers cost more than the overlap gained -- 3.30 vs 3.17 ms, dropped.)
+// Reductions by DPP row shifts (no LDS round trips); one barrier per arg-max, the per-wavefront slots double-buffered.
+__device__ __forceinline__ unsigned long long dpp_max_step_u64(unsigned long long v, unsigned long long o) { return o > v ? o : v; }
+#define TDR_DPP_U64(V, CTRL, RM)                                                                                         \
+    {                                                                                                                    \
+        const unsigned lo_ = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(V), (int)(unsigned)(V), CTRL, RM, 0xf, false);                 \
+        const unsigned hi_ = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)((V) >> 32), (int)(unsigned)((V) >> 32), CTRL, RM, 0xf, false); \
+        V = dpp_max_step_u64(V, ((unsigned long long)hi_ << 32) | lo_);                                                  \
+    }
+// max over the wavefront, valid in lane 63
+__device__ __forceinline__ unsigned long long wave_max_u64_lane63(unsigned long long v) {
+    TDR_DPP_U64(v, 0x111, 0xf) TDR_DPP_U64(v, 0x112, 0xf) TDR_DPP_U64(v, 0x114, 0xf) TDR_DPP_U64(v, 0x118, 0xf)
+    TDR_DPP_U64(v, 0x142, 0xa) TDR_DPP_U64(v, 0x143, 0xc)
+    return v;
+}
+// max over the 16 lanes of a row (lanes 0..15 hold the per-wavefront values), valid in lane 15
+__device__ __forceinline__ unsigned long long row_max_u64_lane15(unsigned long long v) {
+    TDR_DPP_U64(v, 0x111, 0xf) TDR_DPP_U64(v, 0x112, 0xf) TDR_DPP_U64(v, 0x114, 0xf) TDR_DPP_U64(v, 0x118, 0xf)
+    return v;
+}
+__device__ __forceinline__ unsigned long long readlane_u64c(unsigned long long v, int l) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+}
+
+__global__ __launch_bounds__(CL_TH) void cluster_maxmin2_kernel(const float* __restrict__ D2, int64_t ld, int S, int C,
+                                                               int32_t* __restrict__ seeds, int c_min, float drop,
+                                                               int32_t* __restrict__ n_out) {
+    constexpr int NWV = CL_TH / 64;
+    static_assert(NWV == 16, "one DPP row of per-wavefront maxima");
+    __shared__ unsigned long long wslot[4][NWV];     // [parity of the step][winner / runner-up pass]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float mind[CL_PP];
+#pragma unroll
+    for (int p = 0; p < CL_PP; ++p) mind[p] = 3.0e38f;
+    // workgroup arg-max of (min-distance clamped at 0, smaller index first), the entry `skip` left out; the same value in every thread
+    auto argmax = [&](int slot, int skip) -> unsigned long long {
+        unsigned long long key = 0ull;     // below every real key (index part >= 0x7fffffff - S > 0)
+#pragma unroll
+        for (int p = 0; p < CL_PP; ++p) {
+            const int i = p * CL_TH + tid;
+            if (i < S && i != skip) {
+                const unsigned long long k = ((unsigned long long)__float_as_uint(fmaxf(mind[p], 0.f)) << 32) | (unsigned)(0x7fffffff - i);
+                key = k > key ? k : key;
+            }
+        }
+        key = wave_max_u64_lane63(key);
+        if (lane == 63) wslot[slot][w] = key;
+        __syncthreads();
+        unsigned long long g = lane < NWV ? wslot[slot][lane] : 0ull;
+        g = row_max_u64_lane15(g);
+        return readlane_u64c(g, 15);
+    };
+    int n_seeds = 1, stop_at = -1;
+    float prev_delta = 3.0e38f;
+    if (tid == 0) seeds[0] = 0;
+    {   // the first seed: sample point 0
+        const float* row = D2;
+#pragma unroll
+        for (int p = 0; p < CL_PP; ++p) { const int i = p * CL_TH + tid; if (i < S) mind[p] = fminf(mind[p], row[i]); }
+    }
+    int par = 0;
+    while (n_seeds < C) {
+        // winner: the next seed (its key's value part = the max-min distance at which it is taken)
+        const unsigned long long kw = argmax(2 * par, -1);
+        const int wi = 0x7fffffff - (int)(unsigned)(kw & 0xffffffffu);
+        const float dw = __uint_as_float((unsigned)(kw >> 32));
+        if (n_out && n_seeds >= c_min && n_seeds > 1 && dw < drop * prev_delta) { stop_at = n_seeds; break; }
+        prev_delta = dw;
+        const float* rowW = D2 + (size_t)wi * ld;
+        float rw[CL_PP];
+#pragma unroll
+        for (int p = 0; p < CL_PP; ++p) { const int i = p * CL_TH + tid; rw[p] = i < S ? rowW[i] : 0.f; }
+        if (tid == 0) seeds[n_seeds] = wi;
+        ++n_seeds;
+        if (n_seeds >= C) {
+#pragma unroll
+            for (int p = 0; p < CL_PP; ++p) mind[p] = fminf(mind[p], rw[p]);
+            break;
+        }
+        // runner-up of the same arg-max (the winner's row is on its way)
+        const unsigned long long kr = argmax(2 * par + 1, wi);
+        par ^= 1;
+        const int ri = 0x7fffffff - (int)(unsigned)(kr & 0xffffffffu);
+        const float dr = __uint_as_float((unsigned)(kr >> 32));
+        const bool have_runner = kr != 0ull && dr > 0.f;
+        float rr[CL_PP];
+        float dwr = -1.f;
+        if (have_runner) {
+            const float* rowR = D2 + (size_t)ri * ld;
+            dwr = rowW[ri];
+#pragma unroll
+            for (int p = 0; p < CL_PP; ++p) { const int i = p * CL_TH + tid; rr[p] = i < S ? rowR[i] : 0.f; }
+        }
+#pragma unroll
+        for (int p = 0; p < CL_PP; ++p) mind[p] = fminf(mind[p], rw[p]);
+        if (have_runner && dwr >= dr) {
+            // the runner-up is the next greedy pick: its own stopping test, then its row
+            if (n_out && n_seeds >= c_min && dr < drop * prev_delta) { stop_at = n_seeds; break; }
+            prev_delta = dr;
+#pragma unroll
+            for (int p = 0; p < CL_PP; ++p) mind[p] = fminf(mind[p], rr[p]);
+            if (tid == 0) seeds[n_seeds] = ri;
+            ++n_seeds;
+        }
+    }
+    if (n_out && stop_at < 0 && n_seeds >= C && C >= c_min && C > 1) {
+        // the one-chain kernel also tests the distance that a (C + 1)-th seed would have
+        const unsigned long long kw = argmax(2 * par, -1);
+        if (__uint_as_float((unsigned)(kw >> 32)) < drop * prev_delta) stop_at = C;
+    }
+    if (tid == 0 && n_out) *n_out = stop_at >= 0 ? stop_at : c_min;
+}
+#undef TDR_DPP_U64
+
 // ---- predicted scan share of a pruned search (tdr_cluster_scan_fraction_f32): one workgroup per query cluster -------------
 __global__ __launch_bounds__(256) void scan_fraction_kernel(const float* __restrict__ dist, const float* __restrict__ radius,
                                                             const int32_t* __restrict__ tiles, int C, float tau,
@@ -377,15 +501,28 @@ int tdr_cluster_sample_i32(int64_t n, int S, uint32_t seed, int32_t* sample_idx,
 }
 
 /* largest sample the seeding workgroup handles */
+static int g_maxmin_two = 1;   // 0: the one-chain kernel of rounds 2-5 (tdr_cluster_maxmin_mode: measurements, equality test)
 int tdr_cluster_maxmin_capacity(void) { return CL_PP * CL_TH; }
+/* Measurement / test switch of the seeding: 1 (default) = winner and runner-up per dependent step (the runner-up becomes the next
+ * seed when it is at least as far from the winner as from the seeds before), 0 = one seed per step; the same seeds either way.
+ * Returns the previous value. */
+int tdr_cluster_maxmin_mode(int two_per_step) {
+    const int old = g_maxmin_two;
+    if (two_per_step == 0 || two_per_step == 1) g_maxmin_two = two_per_step;
+    return old;
+}
 
 /* 2. C farthest-point seeds (indices into the sample) from the sample's S x S squared-distance matrix D2 (row stride ld);
  * S <= tdr_cluster_maxmin_capacity(). */
 int tdr_cluster_maxmin_f32(const float* D2, int64_t ld, int S, int C, int32_t* seeds, void* stream) {
     if (!D2 || !seeds || S <= 0 || C <= 0 || C > S || ld < S) return TDR_ERR_BAD_ARG;
     if (S > CL_PP * CL_TH) return TDR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(cluster_maxmin_kernel, dim3(1), dim3(CL_TH), 0, (hipStream_t)stream, D2, ld, S, C, seeds, C, 0.f,
-                       (int32_t*)nullptr);
+    if (g_maxmin_two)
+        hipLaunchKernelGGL(cluster_maxmin2_kernel, dim3(1), dim3(CL_TH), 0, (hipStream_t)stream, D2, ld, S, C, seeds, C, 0.f,
+                           (int32_t*)nullptr);
+    else
+        hipLaunchKernelGGL(cluster_maxmin_kernel, dim3(1), dim3(CL_TH), 0, (hipStream_t)stream, D2, ld, S, C, seeds, C, 0.f,
+                           (int32_t*)nullptr);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
@@ -399,8 +536,12 @@ int tdr_cluster_maxmin_adaptive_f32(const float* D2, int64_t ld, int S, int c_mi
     if (!D2 || !seeds || !n_seeds || S <= 0 || c_min <= 0 || c_max < c_min || c_max > S || ld < S || !(drop > 0.f && drop < 1.f))
         return TDR_ERR_BAD_ARG;
     if (S > CL_PP * CL_TH) return TDR_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(cluster_maxmin_kernel, dim3(1), dim3(CL_TH), 0, (hipStream_t)stream, D2, ld, S, c_max, seeds, c_min, drop,
-                       n_seeds);
+    if (g_maxmin_two)
+        hipLaunchKernelGGL(cluster_maxmin2_kernel, dim3(1), dim3(CL_TH), 0, (hipStream_t)stream, D2, ld, S, c_max, seeds, c_min, drop,
+                           n_seeds);
+    else
+        hipLaunchKernelGGL(cluster_maxmin_kernel, dim3(1), dim3(CL_TH), 0, (hipStream_t)stream, D2, ld, S, c_max, seeds, c_min, drop,
+                           n_seeds);
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

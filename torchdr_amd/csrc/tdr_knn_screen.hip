@@ -145,6 +145,8 @@ struct ScreenParams {
     const float* tile_cdist;        // optional (n_db_tiles, n_clusters): lower bound of min over the tile's rows of |x - c_c| --
                                     // the bound |x - y| >= |x - c_c| - R_c of the tile's own rows replaces the ball-to-ball bound
     int32_t* lost;                  // LAZY kernels: (nq, caller-zeroed) 1 = the query's error band held more candidates than its buffer
+    int L_out;                      // entries written per (split, query) list (row stride of `cand`); LAZY kernels with L_out < L compact
+                                    // every buffer once more at the end and report a query whose band population exceeds L_out as lost
 };
 
 __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int src) {
@@ -388,7 +390,7 @@ __device__ __forceinline__ uint32_t wave_extreme_u32(uint32_t v) {
 
 // compaction of the buffer of query sq (n entries, k <= n, wave-uniform); returns the new count
 template <int ITEMS>
-__device__ __forceinline__ int lazy_compact(const SCtx<1>& C, int sq, int n, float& tau_new) {
+__device__ __forceinline__ int lazy_compact(const SCtx<1>& C, int sq, int n, float& tau_new, bool exact = false) {
     const ScreenParams& P = *C.P;
 #ifdef TDR_SCREEN_STATS
     const unsigned long long tc0 = __builtin_readcyclecounter();
@@ -414,7 +416,7 @@ __device__ __forceinline__ int lazy_compact(const SCtx<1>& C, int sq, int n, flo
     // wavefront that has its SIMD to itself issues an instruction every ~5 cycles, so what counts is their number: the first
     // form ran 20 steps behind two bpermute reductions and cost ~3.5 k cycles per compaction (tools/screen_stats.py), the early
     // end brought 2.35 k, DPP reductions the rest.
-    const int slack = P.k >= 32 ? P.k >> 3 : 4;
+    const int slack = exact ? 0 : (P.k >= 32 ? P.k >> 3 : 4);    // exact: the bisection runs on to the k-th smallest image itself
     for (int it = 0; it < 32 && lo < hi; ++it) {
         const uint32_t mid = lo + ((hi - lo) >> 1);
         int c = 0;
@@ -538,9 +540,9 @@ __device__ __forceinline__ void screen_append_lazy(const SCtx<1>& C, const float
 // thresholds brought up to date (end of a cluster): the queries that took at least min_fresh entries since their last compaction,
 // or that have met k candidates and still have no threshold
 template <int ITEMS>
-__device__ __forceinline__ void lazy_refresh(const SCtx<1>& C, float (&tau_r)[1], LazyState& S, int min_fresh) {
+__device__ __forceinline__ void lazy_refresh(const SCtx<1>& C, float (&tau_r)[1], LazyState& S, int min_fresh, bool exact = false) {
     const ScreenParams& P = *C.P;
-    const bool want = !S.lost && S.cnt >= P.k && (S.fresh >= min_fresh || (S.fresh > 0 && tau_r[0] == __builtin_inff()));
+    const bool want = !S.lost && S.cnt >= P.k && (exact || S.fresh >= min_fresh || (S.fresh > 0 && tau_r[0] == __builtin_inff()));
     const unsigned long long m = __ballot(want);
     uint32_t qmask = (uint32_t)m | (uint32_t)(m >> 32);
     while (qmask) {
@@ -548,7 +550,7 @@ __device__ __forceinline__ void lazy_refresh(const SCtx<1>& C, float (&tau_r)[1]
         qmask &= qmask - 1u;
         const int n = __builtin_amdgcn_readlane(S.cnt, sq);
         float tau_new;
-        const int newn = lazy_compact<ITEMS>(C, sq, n, tau_new);
+        const int newn = lazy_compact<ITEMS>(C, sq, n, tau_new, exact);
         if (C.q == sq) {
             S.cnt = newn;
             S.fresh = 0;
@@ -1097,14 +1099,23 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
 #undef TDR_SYNC
 
     if (wave_active) {
+        const int Lo = P.L_out;
+        if constexpr (LAZY) {
+            if (Lo < Ln) {
+                // short output lists (the pilots: 64 slices x 512 queries meet in the rescoring kernel's LDS): one last compaction
+                // leaves k + the band's population in every buffer; more than the list takes = the sorted list would have overflowed
+                lazy_refresh<ITEMS>(C, tau_r, S, 1, true);
+                if (S.cnt >= Lo && S.cnt >= P.k) S.lost = 1;     // the state in which a sorted list of Lo entries is full inside its band
+            }
+        }
         for (int jq = 0; jq < 32 * QB; ++jq) {
             const int64_t qi = qt0 * 32 + jq;
             if (qi >= P.nq) break;
             if constexpr (LAZY) {
                 // the buffer's entries in arrival order, sentinels behind them (the rescoring kernel ranks by counting)
                 const int nj = __builtin_amdgcn_readlane(S.cnt, jq);
-                for (int p = lane; p < Ln; p += 64)
-                    P.cand[((size_t)split * P.nq + qi) * Ln + p] = p < nj ? keys[(size_t)jq * Ln + p] : KEY_SENTINEL;
+                for (int p = lane; p < Lo; p += 64)
+                    P.cand[((size_t)split * P.nq + qi) * Lo + p] = p < nj ? keys[(size_t)jq * Ln + p] : KEY_SENTINEL;
             } else {
                 for (int p = lane; p < Ln; p += 64)
                     P.cand[((size_t)split * P.nq + qi) * Ln + p] = keys[(size_t)jq * Ln + p];
@@ -1122,6 +1133,11 @@ __global__ __launch_bounds__(256, (KS <= 8 && QB == 1 && ITEMS == 1) ? 2 : 1) vo
 // exact fp32 distance of every candidate inside the band (reference arithmetic) -> rank by (distance, index).
 // A query whose spare list slots overflowed in any split is flagged for the exact one-stage kernel.
 // ---------------------------------------------------------------------------------------------------------
+// The rescoring kernel packs the candidates inside the band before it evaluates them: room for all of them when the lists are
+// short, for 512 otherwise (a pilot over 64 database slices brings ~4000 list entries per query; a band that holds more than 512
+// of them is far beyond every list length a launch could keep -- the query is flagged)
+__host__ __device__ __forceinline__ int rescore_band_cap(int total) { return total < 512 ? total : 512; }
+
 struct RescoreParams {
     const uint64_t* cand;  // (n_splits, nq, L)
     const float* Xq;       // (nq, d) row-major queries, row stride ldq
@@ -1151,11 +1167,12 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     const int total = P.n_splits * P.L;
     const int dq = (P.d + 3) & ~3;
     // per-wave LDS: approx keys [total], exact keys [total], query row [dq], scalar
-    const size_t per_wave = (size_t)2 * total * sizeof(uint64_t) + (size_t)dq * sizeof(float) + 16;
+    const int ecap = rescore_band_cap(total);    // packed in-band candidates a wavefront can hold (more: the query is flagged)
+    const size_t per_wave = (size_t)(total + ecap) * sizeof(uint64_t) + (size_t)dq * sizeof(float) + 16;
     char* base = smem_raw + (size_t)wave * per_wave;
     uint64_t* ak = reinterpret_cast<uint64_t*>(base);
     uint64_t* ek = ak + total;
-    float* xq = reinterpret_cast<float*>(ek + total);
+    float* xq = reinterpret_cast<float*>(ek + ecap);
     uint32_t* sc = reinterpret_cast<uint32_t*>(xq + dq);
     const int64_t qi = P.q_begin + (int64_t)blockIdx.x * 4 + wave;
     if (qi >= P.q_end) return;  // no block-level barrier below: wavefronts are independent
@@ -1222,10 +1239,13 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
         const bool inb = key != KEY_SENTINEL && av <= thr;
         in_pred += __popcll(__ballot(key != KEY_SENTINEL && av <= thr_pred));
         const unsigned long long mk = __ballot(inb);
-        if (inb) ek[m + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0))] = key;
+        const int pos = m + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0));
+        if (inb && pos < ecap) ek[pos] = key;
         m += __popcll(mk);
     }
     const int in_band = m;
+    const bool band_overflow = m > ecap;
+    if (band_overflow) m = ecap;
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
@@ -1271,7 +1291,7 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     }
     // A database-sliced launch keeps L entries PER SLICE, so it overflows far less than the unsliced launch of the
     // same search would; a pilot that stands for an unsliced run predicts from the merged band population instead.
-    bool flag = any_ovf || (P.predict_unsplit && (P.pred_terms ? in_pred : in_band) >= P.pred_L);
+    bool flag = any_ovf || band_overflow || (P.predict_unsplit && (P.pred_terms ? in_pred : in_band) >= P.pred_L);
     if (P.lost && P.lost[qi] != 0) flag = true;
     if (lane == 0) {
         P.flags[qs] = flag ? 1 : 0;
@@ -1339,7 +1359,9 @@ static ScreenCfg lazy_cfg(int ks, int k, const ScreenCfg& base) {
     ScreenCfg c = base;
     c.lazy = 0;
     if (!g_clustered_lazy || base.L == 0) return c;
-    const int Lz = max_list_len(ks, 1, base.terms, 160 * 1024, 128) & ~1;
+    // an ODD number of 8-byte entries per query: the 32 queries of a wavefront store to 32 different bank pairs (126 entries: a
+    // row stride of 252 dwords puts them on 16)
+    const int Lz = (max_list_len(ks, 1, base.terms, 160 * 1024, 128) - 1) | 1;
     if (Lz < 2 * k || Lz < k + 40 || Lz <= base.L) return c;
     c.qb = 1; c.L = Lz; c.items = 2; c.wg_per_cu = 1; c.lazy = 1;
     return c;
@@ -1365,9 +1387,12 @@ static int screen_splits(int64_t nq, int n_db_tiles, const ScreenCfg& c) {
     const int64_t max_by_tiles = n_db_tiles / 64 > 0 ? n_db_tiles / 64 : 1;
     if (s > max_by_tiles) s = max_by_tiles;
     // the rescoring kernel keeps 2 x splits x L keys per wavefront in LDS: 4 wavefronts x 16 B x splits x L <= ~144 KiB
-    const int64_t max_by_lds = (144 * 1024) / (64 * (int64_t)(c.L > 0 ? c.L : 1));
+    // the rescoring kernel keeps splits x L list entries + up to 512 packed candidates per wavefront in LDS (4 wavefronts, 8 B each)
+    const int64_t max_by_lds = (36 * 1024 / 8 - 512) / (int64_t)(c.L > 0 ? c.L : 1);
     if (s > max_by_lds) s = max_by_lds;
-    if (s > 32) s = 32;
+    // 64 slices (32 until round 6): a pilot of 512 queries is 4 query groups x 64 slices = 256 workgroups of ~490 tile steps -- its
+    // time is the length of that dependent chain (the next tile's load is issued one step ahead), not the amount of work
+    if (s > 64) s = 64;
     if (s < 1) s = 1;
     return (int)s;
 }
@@ -1469,7 +1494,8 @@ int64_t tdr_knn_screen_workspace_bytes(int64_t nq, int64_t n_db, int d, int k, i
     if (c.L == 0) return 0;
     const int n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
     const int splits = screen_splits(nq, n_db_tiles, c);
-    return (int64_t)splits * nq * c.L * (int64_t)sizeof(uint64_t);
+    // + one word per query: the lost marks of the launches that keep lazy buffers (pilots)
+    return (int64_t)splits * nq * c.L * (int64_t)sizeof(uint64_t) + ((nq * 4 + 15) / 16) * 16;
 }
 
 /*
@@ -1508,7 +1534,7 @@ static int launch_lists_scan(const ScreenParams& P, const ScreenCfg& cfg, int ks
 static int launch_rescore(const RescoreParams& R, hipStream_t st) {
     const int total = R.n_splits * R.L;
     const int dq = (R.d + 3) & ~3;
-    const size_t rlds = (size_t)4 * ((size_t)2 * total * sizeof(uint64_t) + (size_t)dq * sizeof(float) + 16);
+    const size_t rlds = (size_t)4 * ((size_t)(total + rescore_band_cap(total)) * sizeof(uint64_t) + (size_t)dq * sizeof(float) + 16);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_rescore_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds);
     if (e != hipSuccess) return (int)e;
@@ -1533,16 +1559,25 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     if (tier < 0 || tier > 2) return TDR_ERR_BAD_ARG;
     const ScreenCfg cfg0 = screen_cfg(ks, k, tier);
     if (cfg0.L == 0) return TDR_ERR_UNSUPPORTED;
-    // exact pruned searches keep lazy buffers (the approximate search stays on the sorted lists its CPU restatement was pinned with)
-    const ScreenCfg cfg = (ct && ct->max_visit == 0) ? lazy_cfg(ks, k, cfg0) : cfg0;
+    // exact pruned searches keep lazy buffers (the approximate search stays on the sorted lists its CPU restatement was pinned with);
+    // so do the pilots (predict_unsplit): every database slice of a sorted-list launch fills and sorts its own lists from scratch --
+    // ~400 insertions per (query, slice), 3.7 / 7 ms for 512 queries over 64 slices -- whereas buffers take the same candidates by
+    // plain stores.  A pilot compacts once more at the end and writes lists of the sorted form's length (same workspace, same
+    // prediction: flags are raised for the band population an unsliced launch with THAT list length could not hold)
+    const bool lazy_pilot = !ct && predict_unsplit;
+    const ScreenCfg cfg = ((ct && ct->max_visit == 0) || lazy_pilot) ? lazy_cfg(ks, k, cfg0) : cfg0;
     const int L = cfg.L;
+    const int L_out = (cfg.lazy && lazy_pilot) ? cfg0.L : L;
     if (n_db > 0x7fffffffLL) return TDR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     ScreenParams P;
     P.qp = q16; P.yp = y16; P.meta = meta; P.nq = nq; P.q_offset = q_offset; P.n_db = n_db; P.k = k; P.L = L;
     P.exclude_self = exclude_self;
     P.n_db_tiles = (int)((n_db + TILE_ROWS - 1) / TILE_ROWS);
-    P.n_splits = ct ? 1 : screen_splits(nq, P.n_db_tiles, cfg);  // the pruned scan walks clusters, not database slices
+    ScreenCfg cfg_split = cfg;
+    cfg_split.L = L_out;    // the rescoring kernel's LDS holds splits x L_out entries
+    P.n_splits = ct ? 1 : screen_splits(nq, P.n_db_tiles, cfg_split);  // the pruned scan walks clusters, not database slices
+    P.L_out = L_out;
     P.tiles_per_split = (P.n_db_tiles + P.n_splits - 1) / P.n_splits;
     P.dpad = ks * 16;
     P.terms = cfg.terms;
@@ -1554,7 +1589,7 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
     P.clus_order = ct ? ct->clus_order : nullptr;
     P.max_visit = ct ? ct->max_visit : 0;
     P.tile_cdist = ct ? ct->tile_cdist : nullptr;
-    const int64_t lists_bytes = (int64_t)P.n_splits * nq * L * (int64_t)sizeof(uint64_t);
+    const int64_t lists_bytes = (int64_t)P.n_splits * nq * L_out * (int64_t)sizeof(uint64_t);
     const int64_t need = lists_bytes + (cfg.lazy ? ((nq * 4 + 15) / 16) * 16 : 0);
     if (ws_bytes < need) return TDR_ERR_WORKSPACE;
     P.lost = cfg.lazy ? (int32_t*)((char*)ws + lists_bytes) : nullptr;
@@ -1572,9 +1607,9 @@ static int knn_screen_impl(const float* q16, const float* Xq, int64_t ldq, const
 
     RescoreParams R;
     R.cand = P.cand; R.Xq = Xq; R.Y = Y; R.norms_q = norms_q; R.norms_y = norms_y; R.meta = meta; R.nq = nq; R.ldq = ldq;
-    R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L; R.n_splits = P.n_splits; R.metric = metric; R.terms = cfg.terms; R.predict_unsplit = predict_unsplit; R.row_map = ct ? ct->row_map : nullptr; R.q_begin = q_lo; R.q_end = q_hi; R.out_d = out_d;
+    R.ldy = ldy; R.d = d; R.dpad = P.dpad; R.k = k; R.L = L_out; R.n_splits = P.n_splits; R.metric = metric; R.terms = cfg.terms; R.predict_unsplit = predict_unsplit; R.row_map = ct ? ct->row_map : nullptr; R.q_begin = q_lo; R.q_end = q_hi; R.out_d = out_d;
     R.out_i = out_i; R.flags = flags; R.n_flagged = n_flagged;
-    R.pred_L = pred_L > 0 ? pred_L : L; R.pred_terms = pred_terms; R.lost = P.lost; R.unsorted = cfg.lazy;
+    R.pred_L = pred_L > 0 ? pred_L : L_out; R.pred_terms = pred_terms; R.lost = P.lost; R.unsorted = cfg.lazy;
     return launch_rescore(R, st);
 }
 
