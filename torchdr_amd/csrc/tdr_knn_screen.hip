@@ -1214,7 +1214,18 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
     }
     uint32_t kth = 0xFF800000u;      // fewer than k candidates: +inf, everything is inside the band
     if (nv >= P.k) {
-        uint32_t lo = 0u, hi = 0xFF7FFFFFu;    // images of finite values lie below that of +inf (0xFF800000, the sentinels')
+        // the range of the finite images (their smallest and largest: DPP reductions), then the bisection.  A pilot needs the k-th
+        // value itself (its flags count the band's population); any other launch may stop at a bound that holds up to 4 entries
+        // more than k -- a few more candidates get their exact distance in the same pass, the result is the same
+        uint32_t vmin = 0xffffffffu, vmax = 0u;
+        for (int p0 = 0; p0 < total; p0 += 64) {
+            const int p = p0 + lane;
+            const uint32_t v = (p < total) ? (uint32_t)(ak[p] >> 32) : 0xFF800000u;
+            vmin = v < vmin ? v : vmin;
+            if (v < 0xFF800000u) vmax = v > vmax ? v : vmax;
+        }
+        uint32_t lo = wave_extreme_u32<false>(vmin), hi = wave_extreme_u32<true>(vmax);
+        const int slack = P.predict_unsplit ? 0 : 4;
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
             int c = 0;
@@ -1222,8 +1233,12 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(const RescoreParams P)
                 const int p = p0 + lane;
                 c += __popcll(__ballot(p < total && (uint32_t)(ak[p] >> 32) <= mid));
             }
-            if (c >= P.k) hi = mid;
-            else lo = mid + 1u;
+            if (c >= P.k) {
+                hi = mid;
+                if (c <= P.k + slack) break;
+            } else {
+                lo = mid + 1u;
+            }
         }
         kth = hi;
     }
