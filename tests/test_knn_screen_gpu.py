@@ -233,6 +233,24 @@ def test_pruned_scan_lazy_buffers_equal_sorted_lists_and_exact(scale, n, d, k, t
         assert res[1][2] >= dups      # every copy has the other copies at distance 0 inside its band
 
 
+def test_pruned_search_picks_its_list_form_by_the_predicted_scan_share():
+    """Default dispatch (pilot -> tier -> cluster-pruned search): separated blobs are predicted to visit a per mille of the tiles
+    and take the lazy buffers; `config.options(PRUNED_LISTS=...)` forces either form; all three return the same rows."""
+    from torchdr_amd import config
+    from torchdr_amd.distance import base as dbase
+    from torchdr_amd.distance import pairwise_distances
+
+    X = gmm(200_000, 64, 2.0, seed=3).cuda()
+    C0, I0 = pairwise_distances(X, metric="sqeuclidean", k=20, exclude_diag=True, return_indices=True)
+    assert dbase.LAST_KNN["path"] == "screen-pruned" and dbase.LAST_KNN["lists"] == "lazy"
+    assert dbase.LAST_KNN["predicted_share"] is not None and dbase.LAST_KNN["predicted_share"] <= dbase._LAZY_MAX_SHARE
+    for want in ("sorted", "lazy"):
+        with config.options(PRUNED_LISTS=want):
+            C1, I1 = pairwise_distances(X, metric="sqeuclidean", k=20, exclude_diag=True, return_indices=True)
+        assert dbase.LAST_KNN["path"] == "screen-pruned" and dbase.LAST_KNN["lists"] == want
+        assert torch.equal(C0, C1) and torch.equal(I0, I1)
+
+
 def test_headline_size_search_sampled_against_the_one_stage_kernel():
     """BASELINE's full size (N = 1M, D = 128, k = 30), default dispatch (pilot -> tier -> cluster-pruned two-stage search):
     256 sampled rows searched by the CPU oracle against the whole set, and 8192 sampled rows re-searched by the one-stage exact fp32 kernel -- itself bit-exact against the CPU oracle at the

@@ -1,7 +1,8 @@
-"""The exact kNN build across shapes and data regimes with the cluster-pruned scan's two list forms -- lazy candidate buffers
-(round 6, the default) and the sorted lists of rounds 2-5 (tdr_knn_screen_clustered_lists(0): also the pilots' form) -- one JSON
-line per case: path, tier, flagged rows, best-of-3 wall time of pairwise_distances(k) for each form, and whether both returned the
-same rows bit for bit.
+"""The exact kNN build across shapes and data regimes: the default dispatch of round 6 (lazy pilots; the pruned scan with lazy
+candidate buffers where the predicted scan share is <= distance/base.py:_LAZY_MAX_SHARE, sorted lists above it; PRUNED_LISTS=lazy
+in the environment forces the buffers everywhere: the calibration run) against the sorted lists of rounds 2-5 everywhere
+(tdr_knn_screen_clustered_lists(0): also the pilots' form) -- one JSON line per case: path, tier, flagged rows, predicted share,
+list form taken, best-of-3 wall time of pairwise_distances(k), and whether both returned the same rows bit for bit.
 
     python tools/knn_lists_matrix.py > profiles/r06_knn_lists_matrix.jsonl
 """
@@ -35,9 +36,12 @@ CASES = [
     ("headline mixture", lambda: gmm(1_000_000, 128, 2.0), 30),
     ("mixture, k = 15", lambda: gmm(1_000_000, 128, 2.0), 15),
     ("mixture, k = 60", lambda: gmm(1_000_000, 128, 2.0), 60),
+    ("mixture, centre scale 1.6", lambda: gmm(1_000_000, 128, 1.6), 30),
     ("mixture, centre scale 1.3 (tile bounds)", lambda: gmm(1_000_000, 128, 1.3), 30),
+    ("mixture, centre scale 1.15 (tile bounds)", lambda: gmm(1_000_000, 128, 1.15), 30),
     ("mixture, centre scale 1.0 (tile bounds)", lambda: gmm(1_000_000, 128, 1.0), 30),
     ("mixture, D = 64", lambda: gmm(1_000_000, 64, 2.0), 30),
+    ("mixture, D = 64, centre scale 1.0 (tile bounds)", lambda: gmm(1_000_000, 64, 1.0), 30),
     ("mixture, D = 256, k = 15", lambda: gmm(1_000_000, 256, 2.0), 15),
     ("mixture, D = 256, centre scale 5, k = 15", lambda: gmm(1_000_000, 256, 5.0), 15),
     ("mixture, N = 300k", lambda: gmm(300_000, 128, 2.0), 30),
@@ -53,7 +57,9 @@ for name, make, k in CASES:
     X = make().float().cuda().contiguous()
     rec = {"case": name, "n": int(X.shape[0]), "d": int(X.shape[1]), "k": k}
     outs = {}
-    for mode, label in ((1, "lazy_buffers"), (0, "sorted_lists")):
+    if os.environ.get("PRUNED_LISTS"):
+        dbase.PRUNED_LISTS = os.environ["PRUNED_LISTS"]
+    for mode, label in ((1, "default_dispatch"), (0, "sorted_lists")):
         prev = L.tdr_knn_screen_clustered_lists(mode)
         try:
             best = 1e9
@@ -65,12 +71,12 @@ for name, make, k in CASES:
                 best = min(best, time.perf_counter() - t0)
             LK = dbase.LAST_KNN
             rec[label] = {"ms": round(best * 1e3, 2), "path": LK.get("path"), "tier": LK.get("tier"), "tile_bounds": LK.get("tile_bounds"),
-                          "flagged_rows": LK.get("flagged")}
+                          "flagged_rows": LK.get("flagged"), "predicted_share": LK.get("predicted_share"), "lists": LK.get("lists")}
             outs[mode] = (C, I)
         finally:
             L.tdr_knn_screen_clustered_lists(prev)
     rec["same_rows_bit_for_bit"] = bool(torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]))
-    rec["speedup"] = round(rec["sorted_lists"]["ms"] / rec["lazy_buffers"]["ms"], 2)
+    rec["speedup"] = round(rec["sorted_lists"]["ms"] / rec["default_dispatch"]["ms"], 2)
     print(json.dumps(rec), flush=True)
     del X, outs, C, I
     torch.cuda.empty_cache()

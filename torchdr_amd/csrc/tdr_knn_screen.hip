@@ -1815,9 +1815,11 @@ int64_t tdr_knn_screen_clustered_workspace_bytes(int64_t n_img, int d, int k, in
     return plain > lazy ? plain : lazy;
 }
 
-/* measurement / test switch of the exact cluster-pruned searches: 1 (default since round 6) = unsorted candidate buffers,
- * compacted when full (screen_append_lazy in csrc/tdr_knn_screen.hip), 0 = the sorted lists of rounds 2-5; the same results
- * either way (only which rows get flagged for the exact kernel can differ); returns the previous value */
+/* list form of the exact cluster-pruned searches and of the pilots: 1 (default since round 6) = unsorted candidate buffers,
+ * compacted when full (screen_append_lazy in csrc/tdr_knn_screen.hip), 0 = the sorted lists of rounds 2-5; any other value
+ * only reads the setting.  The same results either way (only which rows get flagged for the exact kernel can differ);
+ * returns the previous value.  The host picks per search (distance/base.py:_pruned_launch: lazy where a query's work is its
+ * own cluster, sorted where most of it is the steady scan of many clusters). */
 int tdr_knn_screen_clustered_lists(int lazy) {
     const int old = g_clustered_lazy;
     if (lazy == 0 || lazy == 1) g_clustered_lazy = lazy;

@@ -379,10 +379,23 @@ __global__ __launch_bounds__(256) void umap_sched_layout_kernel(const int64_t* _
         const float mine = have ? eps_per[b + lane] : __builtin_inff();
         const int32_t col = have ? cols[b + lane] : 0;
         int rank = 0;
-        for (int q = 0; q < len; ++q) {
-            const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), q));
-            const int32_t oc = __builtin_amdgcn_readlane(col, q);
-            rank += (o < mine || (o == mine && (oc < col || (oc == col && q < lane)))) ? 1 : 0;
+        // periods are positive (or +inf) and columns non-negative: (period bits, column) as ONE 64-bit key orders like the pair, and
+        // a rank step is two broadcasts, one 64-bit compare and an add instead of five compares joined through scalar masks (the
+        // kernel was 2.9 ms of a 117 ms fit at N = 1M).  Anything else (a negative or NaN period) takes the general comparison.
+        const uint32_t mbits = __float_as_uint(mine);
+        if (__builtin_amdgcn_ballot_w64(have && ((mbits >> 31) != 0u || mine != mine || col < 0)) == 0ull) {
+            const unsigned long long key = ((unsigned long long)mbits << 32) | (uint32_t)col;
+            for (int q = 0; q < len; ++q) {
+                const unsigned long long ok = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mbits, q) << 32) |
+                                              (uint32_t)__builtin_amdgcn_readlane(col, q);
+                rank += (ok < key || (ok == key && q < lane)) ? 1 : 0;
+            }
+        } else {
+            for (int q = 0; q < len; ++q) {
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), q));
+                const int32_t oc = __builtin_amdgcn_readlane(col, q);
+                rank += (o < mine || (o == mine && (oc < col || (oc == col && q < lane)))) ? 1 : 0;
+            }
         }
         if (have) { cols_out[b + rank] = col; eps_out[b + rank] = mine; }
         return;

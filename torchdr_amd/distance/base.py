@@ -386,6 +386,9 @@ class ClusterIndex:
     def scan_fraction_tiles(self, tau: float) -> float:
         """Predicted share of the database tiles a query tile still visits under the per-tile bound at threshold tau (squared
         units), from ~512 tiles spread over the sorted order."""
+        memo = self.__dict__.setdefault("_tiles_share_memo", {})
+        if tau in memo:
+            return memo[tau]
         T = self.tile_cdist
         step = max(T.shape[0] // 512, 1)
         sub = T[::step]
@@ -393,7 +396,8 @@ class ClusterIndex:
         gap = (sub - self.radius[None, :]).clamp_(min=0)
         t = self.tiles.to(gap.dtype)
         visited = torch.mv((gap * gap <= tau).to(gap.dtype), t)
-        return float(visited.mean() / t.sum())
+        memo[tau] = float(visited.mean() / t.sum())
+        return memo[tau]
 
 
 def _use_screen(Q, Y, nq, k, metric):
@@ -774,10 +778,34 @@ def _cluster_index(Y, ops, build=True):
     return ci
 
 
-def _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range=(0, 0), tile_cdist=None):
+PRUNED_LISTS = "auto"       # candidate lists of the pruned scan: "lazy" buffers, "sorted" lists, "auto" = by the predicted scan share
+_LAZY_MAX_SHARE = 0.05      # predicted share of the tiles still visited up to which the lazy buffers are taken: at N = 1M they were
+                            # 1.4-3x faster on every search predicted at <= 0.028 and 0.55x at 0.23 / 0.49 (profiles/r06_knn_lists_matrix.jsonl)
+
+
+def _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range=(0, 0), tile_cdist=None, share=None):
     """Cluster-pruned self search of Y (all of it, or the queries at positions pos_range of the sorted order): rows of
-    out_d / out_i are indexed by SOURCE row.  Returns (flags indexed by source row, n_flagged)."""
+    out_d / out_i are indexed by SOURCE row.  Returns (flags indexed by source row, n_flagged).
+    ``share``: the predicted share of the database tiles a workgroup still visits (None: unknown).  The lazy candidate buffers
+    (one workgroup per CU, 125 entries per query) win where a query's work is its own cluster -- list maintenance -- and lose
+    where most of it is the steady scan of many clusters with few survivors, which the sorted-list kernel runs with two
+    workgroups per CU (`profiles/r06_knn_lists_matrix.jsonl`)."""
     L = _lib.lib()
+    dev, d = Y.device, Y.d
+    want = _opt("PRUNED_LISTS")
+    lazy = want == "lazy" or (want != "sorted" and (share is None or share <= _LAZY_MAX_SHARE))
+    LAST_KNN["predicted_share"], LAST_KNN["lists"] = share, "lazy" if lazy else "sorted"
+    prev_lists = L.tdr_knn_screen_clustered_lists(-1)
+    if not prev_lists:
+        lazy = False            # the library-wide switch is off (measurement runs of the sorted lists)
+    L.tdr_knn_screen_clustered_lists(1 if lazy else 0)
+    try:
+        return _pruned_launch_impl(L, Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range, tile_cdist)
+    finally:
+        L.tdr_knn_screen_clustered_lists(prev_lists)
+
+
+def _pruned_launch_impl(L, Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range, tile_cdist):
     dev, d = Y.device, Y.d
     ws_bytes = L.tdr_knn_screen_clustered_workspace_bytes(ci.n_img, d, k, tier)
     ws = torch.empty(max(ws_bytes, 8) // 8, dtype=torch.int64, device=dev)
@@ -857,7 +885,10 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
                     tile_tab = None
     flat_terms = 0
     if prune:
-        flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, tile_cdist=tile_tab)
+        share = None
+        if pilot_tau is not None:
+            share = ci.scan_fraction_tiles(pilot_tau) if tile_tab is not None else ci.scan_fraction(2.0 * pilot_tau)
+        flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, tile_cdist=tile_tab, share=share)
     else:
         if pilot and nq >= _SCREEN_PILOT_MIN_Q:
             flat_terms, flat_L = _flat_terms(Q, Y, ops, q0, nq, k, metric, exclude_self, q_offset, tier)
@@ -1003,8 +1034,9 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
     out_i = torch.empty((n, k), dtype=torch.int32, device=dev)
     rows = ci.perm[c0:c1].long()
     with phase("knn: pruned scan + rescoring"):
+        share = ci.scan_fraction_tiles(tau) if tile_tab is not None else ci.scan_fraction(2.0 * tau)    # the same on every rank
         flags, n_flagged = _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_range=(p0, p1),
-                                          tile_cdist=tile_tab)
+                                          tile_cdist=tile_tab, share=share)
         if int(n_flagged.item()):
             mine = rows[flags[rows] != 0]
             if mine.numel():
