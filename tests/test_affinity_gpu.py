@@ -84,6 +84,32 @@ def test_symmetrize_vs_reference():
         assert csr.nnz == int((a[f"umap{nn}_Isym"] >= 0).sum())
 
 
+def test_symmetrize_rows_of_every_length_class_vs_oracle():
+    """Hub columns: symmetrised rows of 20 .. ~2500 entries -- the one-entry-per-lane sort, the register-resident forms of 2 / 4 / 8 /
+    16 entries per lane (65 .. 1024 entries) and the general path beyond -- against the CPU restatement of utils/sparse.py:22-165."""
+    from oracle import ref_torch as R
+    from torchdr_amd.utils.sparse import symmetrize_sparse
+
+    n, k = 3000, 20
+    gen = torch.Generator().manual_seed(4)
+    idx = torch.empty((n, k), dtype=torch.int64)
+    # column classes by how often they are drawn: in-degrees of ~2800, ~650, ~330, ~170, ~80 and ~7
+    w = torch.ones(n)
+    w[:4], w[4:12], w[12:20], w[20:40], w[40:100] = 900.0, 100.0, 50.0, 25.0, 12.0
+    for i in range(n):
+        ww = w.clone()
+        ww[i] = 0                                   # no self loops
+        idx[i] = torch.multinomial(ww, k, replacement=False, generator=gen)
+    vals = torch.rand((n, k), generator=gen)
+    V, J = symmetrize_sparse(vals.cuda(), idx.cuda())
+    V2, J2 = R.symmetrize_sparse(vals, idx)
+    deg = (J2 >= 0).sum(1)
+    for lo, hi in ((0, 64), (65, 128), (129, 256), (257, 512), (513, 1024), (1025, 10**6)):
+        assert bool(((deg >= lo) & (deg <= hi)).any()), (lo, hi, deg.max())
+    assert torch.equal(J.cpu(), J2)
+    assert torch.allclose(V.cpu(), V2, rtol=0, atol=1e-7)
+
+
 def test_symmetrize_chunked_with_ext_edges_equals_single():
     """Multi-GPU symmetrisation logic on one device: split rows into 3 'ranks', route the
     transposed edges by hand (parallel.route_edges), symmetrise each chunk -> must equal the

@@ -121,6 +121,34 @@ def test_loop_layout_sorts_every_row_by_firing_period():
         assert torch.equal(cp[e0:e1], cols[e0:e1][order])
 
 
+def test_loop_layout_rows_of_every_length_class():
+    """Rows of 1 .. 64 edges (one entry per lane), 65 .. 1024 (2 / 4 / 8 / 16 entries per lane in registers) and beyond (general
+    path), with tied periods and -- in a second pass -- a negative period that sends its row to the general comparison: every row
+    sorted by (epochs_per_sample, column)."""
+    gen = torch.Generator().manual_seed(8)
+    degs = [1, 2, 63, 64, 65, 100, 128, 129, 200, 256, 257, 400, 512, 513, 900, 1024, 1025, 1500, 0, 33]
+    n = len(degs)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.tensor(degs).cumsum(0)
+    nnz = int(rowptr[-1])
+    cols = torch.cat([torch.randperm(5000, generator=gen)[:d] for d in degs]).to(torch.int32)
+    eps = torch.randint(1, 40, (nnz,), generator=gen).float() * 0.5        # many ties: the column decides
+    eps[torch.rand(nnz, generator=gen) < 0.1] = float("inf")
+    for neg in (False, True):
+        ep = eps.clone()
+        if neg:
+            ep[rowptr[8] + 5] = -1.0      # row of 200 edges
+            ep[rowptr[2] + 7] = -2.0      # row of 63 edges
+        cols_p, eps_p = layout(rowptr.cuda(), cols.cuda(), ep.cuda())
+        cp, epp = cols_p.cpu(), eps_p.cpu()
+        for r in range(n):
+            e0, e1 = int(rowptr[r]), int(rowptr[r + 1])
+            by_col = torch.sort(cols[e0:e1], stable=True).indices
+            order = by_col[torch.sort(ep[e0:e1][by_col], stable=True).indices]
+            assert torch.equal(epp[e0:e1], ep[e0:e1][order]), (neg, r, degs[r])
+            assert torch.equal(cp[e0:e1], cols[e0:e1][order]), (neg, r, degs[r])
+
+
 @pytest.mark.parametrize("S", [1, 2, 4, 8])
 @pytest.mark.parametrize("B,t0", [(32, 0), (7, 37)])
 def test_schedule_is_the_step_by_step_recurrence(S, B, t0):

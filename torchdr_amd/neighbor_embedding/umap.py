@@ -1,5 +1,6 @@
 """UMAP on MI355X -- mirror of ``torchdr/neighbor_embedding/umap.py`` (reference :19-292)."""
 
+import functools
 from typing import Dict, Optional, Type, Union
 
 import numpy as np
@@ -81,9 +82,11 @@ def _stock_start():
     return NegativeSamplingNeighborEmbedding.on_training_step_start
 
 
+@functools.lru_cache(maxsize=64)
 def find_ab_params(spread, min_dist):
     """Fit a, b of 1/(1 + a x^(2b)) to the smooth-step target curve (reference :19-36: same grid,
-    scipy ``curve_fit``; defaults give a = 1.5769..., b = 0.8950...)."""
+    scipy ``curve_fit``; defaults give a = 1.5769..., b = 0.8950...).  A pure function of its two arguments: the fit
+    (0.5 ms of scipy per constructor call) is kept per (spread, min_dist)."""
     from scipy.optimize import curve_fit
 
     def curve(x, a, b):
