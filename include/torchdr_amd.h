@@ -268,9 +268,18 @@ int64_t tdr_sym_workspace_bytes(int64_t n, int k);
 int tdr_sym_count_f32(const float* vals, const int32_t* cols, int64_t n, int k, int64_t row_offset,
                       const int32_t* ext_row, const int32_t* ext_col, int64_t n_ext, void* ws, int64_t ws_bytes,
                       int64_t* rowptr, void* stream);
+/* tdr_sym_count_f32 with a visit order of the rows (optional int32 permutation of 0 .. n - 1, position -> local row, e.g. the
+ * cluster-sorted order of the kNN search that produced the block): same outputs, local visits of the transposed rows;
+ * tdr_sym_fill_ordered_f32 takes the same order for the second phase. */
+int tdr_sym_count_ordered_f32(const float* vals, const int32_t* cols, int64_t n, int k, int64_t row_offset,
+                              const int32_t* ext_row, const int32_t* ext_col, int64_t n_ext, const int32_t* order, void* ws,
+                              int64_t ws_bytes, int64_t* rowptr, void* stream);
 int tdr_sym_fill_f32(int64_t n, int k, int64_t row_offset, int mode, const int32_t* ext_row, const int32_t* ext_col,
                      const float* ext_val, int64_t n_ext, void* ws, const int64_t* rowptr, int32_t* tcols,
                      float* tvals, int32_t* cols, float* vals, void* stream);
+int tdr_sym_fill_ordered_f32(int64_t n, int k, int64_t row_offset, int mode, const int32_t* ext_row, const int32_t* ext_col,
+                             const float* ext_val, int64_t n_ext, const int32_t* order, void* ws, const int64_t* rowptr, int32_t* tcols,
+                             float* tvals, int32_t* cols, float* vals, void* stream);
 /* CSR -> padded (n, width) with (0, -1) fill (pack_to_rowwise, utils/sparse.py:89-135). */
 int tdr_csr_to_padded_f32(const int64_t* rowptr, const int32_t* cols, const float* vals, int64_t n, int64_t width,
                           float* pv, int64_t* pi, void* stream);

@@ -108,6 +108,12 @@ def test_symmetrize_rows_of_every_length_class_vs_oracle():
         assert bool(((deg >= lo) & (deg <= hi)).any()), (lo, hi, deg.max())
     assert torch.equal(J.cpu(), J2)
     assert torch.allclose(V.cpu(), V2, rtol=0, atol=1e-7)
+    # a visit order of the rows (the kNN search's cluster order in the fit) changes nothing in the result
+    from torchdr_amd.utils.sparse import symmetrize_to_csr
+
+    a = symmetrize_to_csr(vals.cuda(), idx.cuda())
+    b = symmetrize_to_csr(vals.cuda(), idx.cuda(), order=torch.randperm(n, generator=gen).cuda())
+    assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.cols, b.cols) and torch.equal(a.vals, b.vals)
 
 
 def test_symmetrize_chunked_with_ext_edges_equals_single():

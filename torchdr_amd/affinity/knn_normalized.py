@@ -105,7 +105,9 @@ class UMAPAffinity(SparseAffinity):
                                         n_total=n_samples_in, ext=ext)
         else:
             with phase("symmetrise"):
-                csr = symmetrize_to_csr(P, indices, "sum_minus_prod", n_total=n_samples_in)
+                # the rows are visited in the search's cluster-sorted order when there is one (same result, local look-ups)
+                order = self._row_order[0] if self._row_order is not None else None
+                csr = symmetrize_to_csr(P, indices, "sum_minus_prod", n_total=n_samples_in, order=order)
         self._csr_ = csr
         if return_csr:
             return csr

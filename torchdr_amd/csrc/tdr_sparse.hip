@@ -117,11 +117,16 @@ __device__ __forceinline__ int bsearch_row(const int32_t* __restrict__ c, int le
 constexpr uint32_t VT_MISSING = 0xFFC0DEADu;  // a NaN pattern no arithmetic produces: row j has no entry for column i
 __global__ __launch_bounds__(256) void sym_count_kernel(const float* __restrict__ svals, const int32_t* __restrict__ scols,
                                                         const int32_t* __restrict__ slen, int64_t n, int k, int64_t row_offset,
-                                                        int32_t* __restrict__ incnt, uint32_t* __restrict__ vt) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                        int32_t* __restrict__ incnt, uint32_t* __restrict__ vt,
+                                                        const int32_t* __restrict__ order) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n * k) return;
-    const int64_t i = idx / k;
+    int64_t i = idx / k;
     const int p = (int)(idx - i * k);
+    // `order` (optional): position -> row.  The rows are VISITED in that order -- the cluster-sorted order of a pruned kNN search,
+    // in which a row's neighbours are rows of the same few clusters: the random visits of row j then fall into ~100 KB of rows
+    // that the L2 already holds instead of 30 M distinct lines spread over the whole block (sym_count 2.24 -> see DESIGN)
+    if (order) { i = order[i]; idx = i * k + p; }
     if (p >= slen[i]) return;
     const int64_t j = scols[idx];
     const int64_t lj = j - row_offset;
@@ -222,11 +227,13 @@ __global__ __launch_bounds__(256) void sym_fill_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ slen, int64_t n, int k,
                                                        int64_t row_offset, int mode, const int64_t* __restrict__ rowptr,
                                                        int32_t* __restrict__ cursor, const uint32_t* __restrict__ vtw,
-                                                       int32_t* __restrict__ tcols, float* __restrict__ tvals) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                       int32_t* __restrict__ tcols, float* __restrict__ tvals,
+                                                       const int32_t* __restrict__ order) {
+    int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n * k) return;
-    const int64_t i = idx / k;
+    int64_t i = idx / k;
     const int p = (int)(idx - i * k);
+    if (order) { i = order[i]; idx = i * k + p; }      // visit order of the rows (see sym_count_kernel): local appends to the rows j
     if (p >= slen[i]) return;
     const int32_t j = scols[idx];
     const float v = svals[idx];
@@ -391,9 +398,20 @@ int64_t tdr_sym_workspace_bytes(int64_t n, int k) {
  * back to size the CSR arrays -- the one host sync of the symmetrisation, as in the reference
  * (sparse.py:119 `.max().item()`).
  */
+int tdr_sym_count_ordered_f32(const float* vals, const int32_t* cols, int64_t n, int k, int64_t row_offset,
+                              const int32_t* ext_row, const int32_t* ext_col, int64_t n_ext, const int32_t* order, void* ws,
+                              int64_t ws_bytes, int64_t* rowptr, void* stream);
 int tdr_sym_count_f32(const float* vals, const int32_t* cols, int64_t n, int k, int64_t row_offset,
                       const int32_t* ext_row, const int32_t* ext_col, int64_t n_ext, void* ws, int64_t ws_bytes,
                       int64_t* rowptr, void* stream) {
+    return tdr_sym_count_ordered_f32(vals, cols, n, k, row_offset, ext_row, ext_col, n_ext, nullptr, ws, ws_bytes, rowptr, stream);
+}
+
+/* tdr_sym_count_f32 with a VISIT ORDER of the rows (optional int32 permutation of 0 .. n - 1, position -> local row): same
+ * outputs; only the order in which the count pass walks the rows -- and with it the locality of its visits of rows j -- changes. */
+int tdr_sym_count_ordered_f32(const float* vals, const int32_t* cols, int64_t n, int k, int64_t row_offset,
+                              const int32_t* ext_row, const int32_t* ext_col, int64_t n_ext, const int32_t* order, void* ws,
+                              int64_t ws_bytes, int64_t* rowptr, void* stream) {
     if (!vals || !cols || !ws || !rowptr || n <= 0 || k <= 0 || k > 256) return TDR_ERR_BAD_ARG;
     if (ws_bytes < tdr_sym_workspace_bytes(n, k)) return TDR_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -414,7 +432,7 @@ int tdr_sym_count_f32(const float* vals, const int32_t* cols, int64_t n, int k, 
     e = hipMemsetAsync(total, 0, 16, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(sym_rowsort_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, vals, cols, n, k, svals, scols, slen);
-    hipLaunchKernelGGL(sym_count_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, svals, scols, slen, n, k, row_offset, incnt, vt);
+    hipLaunchKernelGGL(sym_count_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, svals, scols, slen, n, k, row_offset, incnt, vt, order);
     if (n_ext > 0) {
         if (!ext_row || !ext_col) return TDR_ERR_BAD_ARG;
         hipLaunchKernelGGL(sym_count_ext_kernel, dim3((unsigned)((n_ext + 255) / 256)), dim3(256), 0, st, scols, slen, k, ext_row, ext_col, n_ext, incnt);
@@ -429,9 +447,20 @@ int tdr_sym_count_f32(const float* vals, const int32_t* cols, int64_t n, int k, 
 
 /* Phase B: fill + finalize into caller-allocated CSR arrays (cols int32, vals fp32, nnz entries) using
  * two nnz-sized temporaries. mode 0 = sum_minus_prod, 1 = sum. */
+int tdr_sym_fill_ordered_f32(int64_t n, int k, int64_t row_offset, int mode, const int32_t* ext_row, const int32_t* ext_col,
+                             const float* ext_val, int64_t n_ext, const int32_t* order, void* ws, const int64_t* rowptr, int32_t* tcols,
+                             float* tvals, int32_t* cols, float* vals, void* stream);
 int tdr_sym_fill_f32(int64_t n, int k, int64_t row_offset, int mode, const int32_t* ext_row, const int32_t* ext_col,
                      const float* ext_val, int64_t n_ext, void* ws, const int64_t* rowptr, int32_t* tcols,
                      float* tvals, int32_t* cols, float* vals, void* stream) {
+    return tdr_sym_fill_ordered_f32(n, k, row_offset, mode, ext_row, ext_col, ext_val, n_ext, nullptr, ws, rowptr, tcols, tvals, cols, vals, stream);
+}
+
+/* tdr_sym_fill_f32 with the visit order of tdr_sym_count_ordered_f32 (optional): same CSR (the column sort that ends the
+ * phase makes the order in which transposed entries were appended irrelevant). */
+int tdr_sym_fill_ordered_f32(int64_t n, int k, int64_t row_offset, int mode, const int32_t* ext_row, const int32_t* ext_col,
+                             const float* ext_val, int64_t n_ext, const int32_t* order, void* ws, const int64_t* rowptr, int32_t* tcols,
+                             float* tvals, int32_t* cols, float* vals, void* stream) {
     if (!ws || !rowptr || !tcols || !tvals || !cols || !vals || n <= 0 || k <= 0) return TDR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     char* w = (char*)ws;
@@ -444,7 +473,7 @@ int tdr_sym_fill_f32(int64_t n, int k, int64_t row_offset, int mode, const int32
     w = (char*)(((uintptr_t)w + 7) & ~(uintptr_t)7);
     w += nb * 8 + 16;  // block sums, total + max_deg
     const uint32_t* vt = (const uint32_t*)w;
-    hipLaunchKernelGGL(sym_fill_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, svals, scols, slen, n, k, row_offset, mode, rowptr, cursor, vt, tcols, tvals);
+    hipLaunchKernelGGL(sym_fill_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, st, svals, scols, slen, n, k, row_offset, mode, rowptr, cursor, vt, tcols, tvals, order);
     if (n_ext > 0) {
         if (!ext_row || !ext_col || !ext_val) return TDR_ERR_BAD_ARG;
         hipLaunchKernelGGL(sym_fill_ext_kernel, dim3((unsigned)((n_ext + 255) / 256)), dim3(256), 0, st, svals, scols, slen, k, mode, rowptr, cursor, ext_row, ext_col, ext_val, n_ext, tcols, tvals);

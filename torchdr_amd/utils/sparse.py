@@ -52,11 +52,13 @@ class CSRAffinity:
 _MODE = {"sum_minus_prod": 0, "sum": 1}
 
 
-def symmetrize_to_csr(values, indices, mode="sum_minus_prod", row_offset=0, n_total=None, ext=None) -> CSRAffinity:
+def symmetrize_to_csr(values, indices, mode="sum_minus_prod", row_offset=0, n_total=None, ext=None, order=None) -> CSRAffinity:
     """``Q = P + P^T - P o P^T`` (or ``P + P^T``) of the row-wise (n, k) block -> CSR.
 
     ``ext`` = (rows int32 local, cols int32 global, vals fp32): transposed edges received from
-    other ranks (multi-GPU path, reference ``sparse.py:209-342``)."""
+    other ranks (multi-GPU path, reference ``sparse.py:209-342``).  ``order``: optional permutation of the local rows
+    (position -> row) in which the count pass visits them -- the cluster-sorted order of the kNN search keeps its look-ups of the
+    transposed rows inside the L2; the result does not depend on it."""
     if mode not in _MODE:
         raise ValueError(f"Unsupported mode {mode!r}")
     _lib.require_gpu(values, "values")
@@ -80,10 +82,14 @@ def symmetrize_to_csr(values, indices, mode="sum_minus_prod", row_offset=0, n_to
         er = ec = ev = None
         n_ext = 0
     st = _lib.stream_ptr()
+    if order is not None:
+        order = order.to(torch.int32).contiguous()
+        if order.numel() != n:
+            order = None
     _lib.check(
-        L.tdr_sym_count_f32(_lib.ptr(vals), _lib.ptr(cols), n, k, row_offset, _lib.ptr(er), _lib.ptr(ec), n_ext,
-                            _lib.ptr(ws), ws_bytes, _lib.ptr(rowptr), st),
-        "tdr_sym_count_f32",
+        L.tdr_sym_count_ordered_f32(_lib.ptr(vals), _lib.ptr(cols), n, k, row_offset, _lib.ptr(er), _lib.ptr(ec), n_ext,
+                                    _lib.ptr(order), _lib.ptr(ws), ws_bytes, _lib.ptr(rowptr), st),
+        "tdr_sym_count_ordered_f32",
     )
     nnz = int(rowptr[n].item())  # the one host sync (reference: sparse.py:119 `.max().item()`)
     tcols = torch.empty(nnz, dtype=torch.int32, device=dev)
@@ -91,10 +97,10 @@ def symmetrize_to_csr(values, indices, mode="sum_minus_prod", row_offset=0, n_to
     ocols = torch.empty(nnz, dtype=torch.int32, device=dev)
     ovals = torch.empty(nnz, dtype=torch.float32, device=dev)
     _lib.check(
-        L.tdr_sym_fill_f32(n, k, row_offset, _MODE[mode], _lib.ptr(er), _lib.ptr(ec), _lib.ptr(ev), n_ext,
-                           _lib.ptr(ws), _lib.ptr(rowptr), _lib.ptr(tcols), _lib.ptr(tvals), _lib.ptr(ocols),
-                           _lib.ptr(ovals), st),
-        "tdr_sym_fill_f32",
+        L.tdr_sym_fill_ordered_f32(n, k, row_offset, _MODE[mode], _lib.ptr(er), _lib.ptr(ec), _lib.ptr(ev), n_ext, _lib.ptr(order),
+                                   _lib.ptr(ws), _lib.ptr(rowptr), _lib.ptr(tcols), _lib.ptr(tvals), _lib.ptr(ocols),
+                                   _lib.ptr(ovals), st),
+        "tdr_sym_fill_ordered_f32",
     )
     if values.dtype == torch.float64:
         # float64 input: the pattern above came from float(values); the float64 values P + P^T - P o P^T are evaluated on
