@@ -25,6 +25,8 @@ if "NEGATIVES" in os.environ:
     U.NEGATIVES = os.environ["NEGATIVES"]
 if "POOL_GEOM" in os.environ:
     U.POOL_GEOM = int(os.environ["POOL_GEOM"])
+if "SCHED_STAGE" in os.environ:
+    U.SCHED_STAGE = int(os.environ["SCHED_STAGE"])
 from torchdr_amd import affinity_matcher as AM
 
 if "PREFETCH" in os.environ:
@@ -40,5 +42,5 @@ for r in range(reps + 1):
     Z = m.fit_transform(X)
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
-print(json.dumps({"n": n, "negatives": U.NEGATIVES, "pool_geom": U.POOL_GEOM, "prefetch": AM.PCA_PREFETCH, "eigh": AM.PCA_EIGH, "relabel": U.RELABEL, "geom": U.SCHED_GEOM, "relabelled": m.loop_order_ is not None,
+print(json.dumps({"n": n, "negatives": U.NEGATIVES, "sched_stage": U.SCHED_STAGE, "pool_geom": U.POOL_GEOM, "prefetch": AM.PCA_PREFETCH, "eigh": AM.PCA_EIGH, "relabel": U.RELABEL, "geom": U.SCHED_GEOM, "relabelled": m.loop_order_ is not None,
                   "ms_per_fit": ts[1:], "finite": bool(torch.isfinite(Z).all())}))
