@@ -1,6 +1,6 @@
 """GPU probe: wall time of the headline fit (UMAP N = 1M D = 128 k = 30, 1000 iterations) without bench.py's context legs.
 
-    python tools/fit_time.py [N] [reps]        env RELABEL=0/1, GEOM=<int>, PREFETCH=0/1, EIGH=jacobi/library override the module defaults
+    python tools/fit_time.py [N] [reps]        env LIBPATH=<scratch .so>, RELABEL=0/1, GEOM=<int>, PREFETCH=0/1, EIGH=jacobi/library override the module defaults
 """
 import json
 import os
@@ -33,6 +33,9 @@ if "PREFETCH" in os.environ:
     AM.PCA_PREFETCH = os.environ["PREFETCH"] == "1"
 if "EIGH" in os.environ:
     AM.PCA_EIGH = os.environ["EIGH"]
+if "LIBPATH" in os.environ:      # a scratch build of the library (measurement switches), path relative to the repo root
+    from torchdr_amd import _lib as _L
+    _L.LIB_PATH = os.path.join(ROOT, os.environ["LIBPATH"])
 X = gmm(n, 128, 2.0).cuda()
 ts = []
 for r in range(reps + 1):
