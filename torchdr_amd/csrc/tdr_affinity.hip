@@ -18,6 +18,20 @@ namespace tdr {
 
 constexpr int MAX_ITEMS = 4;  // k <= 64 * 4
 
+// group reductions of the row searches: groups of up to 16 lanes stay on the DPP path (one instruction per step, no LDS round trip);
+// max is exact whatever the pairing, the sum's pairing differs from the shuffle butterfly's in rounding only
+template <int G>
+__device__ __forceinline__ float search_group_max(float v) {
+    if (G > 16) return group_max<G>(v);
+    if (G >= 2) v = fmaxf(v, dpp_mov_f<0xB1>(v));
+    if (G >= 4) v = fmaxf(v, dpp_mov_f<0x4E>(v));
+    if (G >= 8) v = fmaxf(v, dpp_mov_f<0x141>(v));
+    if (G >= 16) v = fmaxf(v, dpp_mov_f<0x140>(v));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ float search_group_sum(float v) { return G > 16 ? group_sum<G>(v) : group_sum_dpp<G>(v); }
+
 struct UmapF {
     float rho, target;
     template <int G, int ITEMS>
@@ -29,11 +43,11 @@ struct UmapF {
             lp[t] = valid[t] ? (-(c[t] - rho)) / eps : -__builtin_inff();
             m = fmaxf(m, lp[t]);
         }
-        m = group_max<G>(m);
+        m = search_group_max<G>(m);
         float s = 0.f;
 #pragma unroll
         for (int t = 0; t < ITEMS; ++t) s += valid[t] ? expf(lp[t] - m) : 0.f;
-        s = group_sum<G>(s);
+        s = search_group_sum<G>(s);
         const float lse = m + logf(s);
         return expf(lse) - target;
     }
@@ -387,7 +401,9 @@ int tdr_umap_search_f32(const float* C, int64_t n, int k, float target, int max_
         TDR_CHECK_LAUNCH();
         return TDR_OK;
     }
-    if (k <= 32) return launch_rows(umap_search_kernel<32, 1>, 32, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
+    // 8 lanes x 4 entries for the usual widths (eight rows per wavefront, three DPP steps per reduction): 1.46 -> 0.94 (16 x 2) -> see
+    // DESIGN section 6 at N = 1M, k = 30
+    if (k <= 32) return launch_rows(umap_search_kernel<8, 4>, 8, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
     if (k <= 64) return launch_rows(umap_search_kernel<64, 1>, 64, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
     if (k <= 128) return launch_rows(umap_search_kernel<64, 2>, 64, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
     return launch_rows(umap_search_kernel<64, 4>, 64, n, st, C, n, k, target, max_iter, tol, rho, eps, P);
