@@ -102,6 +102,33 @@ def test_discard_nns_and_nan_guard():
         torchdr_amd.TSNE(perplexity=8, max_iter=60, init=bad, random_state=0).fit_transform(X.cuda())
 
 
+def test_umap_check_iterations_read_flags_and_norm_in_one_pass():
+    """UMAP's check iterations (affinity_matcher.py:315-349) fetch the NaN flag, the schedule's error words and the gradient norm
+    with one host read: the same norms as the four separate reads, the same stop, the same NaN error."""
+    import torchdr_amd
+    from torchdr_amd import config
+
+    X = gmm(3000, 16, 2.0, seed=2).cuda()
+    seen = {}
+    for merged in (True, False):
+        with config.options(MERGED_CHECK=merged):
+            m = torchdr_amd.UMAP(n_neighbors=10, max_iter=120, check_interval=25, random_state=0)
+            rec = seen.setdefault(merged, [])
+            m._converged = lambda step, gn, rec=rec: rec.append((step, gn)) or False      # instance attribute: the class stays stock
+            Z = m.fit_transform(X)
+            seen[("Z", merged)] = Z.cpu()
+    assert [s for s, _ in seen[True]] == [0, 25, 50, 75, 100]
+    assert seen[True] == seen[False]
+    assert torch.equal(seen[("Z", True)], seen[("Z", False)])
+    m = torchdr_amd.UMAP(n_neighbors=10, max_iter=120, min_grad_norm=1e30, random_state=0)
+    m.fit_transform(X)
+    assert int(m.n_iter_) == 0          # stopped at the first check
+    bad = np.random.RandomState(0).randn(3000, 2).astype(np.float32)
+    bad[17, 1] = np.nan
+    with pytest.raises(ValueError, match="NaNs in the embeddings at iter 0"):
+        torchdr_amd.UMAP(n_neighbors=10, max_iter=60, init=bad, random_state=0).fit_transform(X)
+
+
 def test_indexed_distances_block_forms():
     """1-D / None index forms of pairwise_distances_indexed (reference base.py:335-376)."""
     import oracle

@@ -24,7 +24,7 @@ SWITCHES = {
     "TILE_BOUNDS": "torchdr_amd.distance.base", "PRUNED_LISTS": "torchdr_amd.distance.base", "FLAT_SCAN": "torchdr_amd.distance.base", "FLAT_TWO_TERMS": "torchdr_amd.distance.base", "FLAT_FORCE_TERMS": "torchdr_amd.distance.base", "ASSIGN16": "torchdr_amd.distance.base", "FLAT_WS_LIMIT": "torchdr_amd.distance.base",
     "SCHEDULED": "torchdr_amd.neighbor_embedding.umap", "RELABEL": "torchdr_amd.neighbor_embedding.umap",
     "LOOP_RUNNER": "torchdr_amd.neighbor_embedding.umap", "LOOP_GRAPH": "torchdr_amd.neighbor_embedding.umap",
-    "SCHED_GEOM": "torchdr_amd.neighbor_embedding.umap", "SCHED_SLICES": "torchdr_amd.neighbor_embedding.umap",
+    "SCHED_GEOM": "torchdr_amd.neighbor_embedding.umap", "MERGED_CHECK": "torchdr_amd.neighbor_embedding.umap", "SCHED_SLICES": "torchdr_amd.neighbor_embedding.umap",
     "SCHED_BLOCK_ITERS": "torchdr_amd.neighbor_embedding.umap", "GROUPED": "torchdr_amd.neighbor_embedding.umap",
     "SCHED_STAGE": "torchdr_amd.neighbor_embedding.umap", "NEGATIVES": "torchdr_amd.neighbor_embedding.umap",
     "POOL_GEOM": "torchdr_amd.neighbor_embedding.umap", "POOL_FUSED_STEP": "torchdr_amd.neighbor_embedding.umap",

@@ -36,6 +36,7 @@ LOOP_RUNNER = "auto"
 LOOP_GRAPH = True
 # bench.py sets this to a list to collect (start_event, end_event, n_iterations) per loop-runner segment
 LOOP_PROFILE = None
+MERGED_CHECK = True      # single process: the NaN flag, the schedule's error words and |grad| of a check iteration come back in ONE host read
 SCHED_BLOCK_ITERS = 32
 # (round 5: the variants that were measured slower and kept behind switches -- rows of a workgroup dealt by load (geom bit 6),
 # the SGD step fused into the gradient launch, the schedule built one window ahead on a side stream -- are gone from the library;
@@ -218,7 +219,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         stock = (
             ("on_training_step_start", NegativeSamplingNeighborEmbedding), ("on_training_step_end", NeighborEmbedding),
             ("_training_step", AffinityMatcher), ("_optimizer_step", AffinityMatcher), ("_sgd_kernel", UMAP),
-            ("_compute_gradients", UMAP), ("_compute_gradients_scheduled", UMAP), ("_grad_norm", AffinityMatcher),
+            ("_compute_gradients", UMAP), ("_compute_gradients_scheduled", UMAP), ("_grad_norm", UMAP),
             ("_init_embedding", NeighborEmbedding), ("_run_training_loop", UMAP), ("_loop_segments", UMAP), ("_fit_transform", UMAP),
             ("on_affinity_computation_end", UMAP), ("_compute_affinity_in", UMAP), ("_converged", AffinityMatcher),
         )
@@ -264,6 +265,9 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         csr: CSRAffinity = self._relabel()
         self._csr_loop = csr
         L = _lib.lib()
+        # the words the host looks at every check_interval iterations live in ONE buffer -- NaN flag, error words of the grouped layout and
+        # of the schedule build, |grad| -- so that a check is one read instead of four (`_raise_if_nan` below)
+        self._flagbuf = torch.zeros(4, dtype=torch.int32, device=csr.vals.device)
         if csr.vals.dtype == torch.float64:
             # float64 graph (float64 input): the epoch counters are float64 like the reference's (umap.py:215-234 in the
             # affinity's dtype) and the loop is the per-step float64 kernel, which reads the CSR as it is
@@ -299,7 +303,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             g = {"cols": torch.empty_like(csr.cols), "eps": torch.empty_like(csr.vals),
                  "rs": torch.empty(nnz, dtype=torch.uint8, device=dev), "order": torch.empty(nnz, dtype=torch.int32, device=dev),
                  "S": self._sched_slices(), "dirty": False}
-            sc = self._sched_err = torch.zeros(1, dtype=torch.int32, device=dev)
+            sc = self._sched_err = self._flagbuf[1:2]
             _lib.check(
                 L.tdr_umap_sched_group_f32(_lib.ptr(csr.rowptr), _lib.ptr(self._loop_cols), _lib.ptr(self.epochs_per_sample), csr.n,
                                            self.n_samples_in_, g["S"], _lib.ptr(g["cols"]), _lib.ptr(g["eps"]), _lib.ptr(g["rs"]),
@@ -358,7 +362,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
             "B": B, "S": S, "blk_base": blk_base, "t0": None, "n": 0,
             "list": torch.empty(cap + 64, dtype=torch.int32, device=dev),  # slack: idle lanes read entry 0 of a segment
             "hdr": torch.empty(2 * int(L.tdr_umap_sched_hdr_entries(n_rows, B, S)), dtype=torch.int32, device=dev),
-            "err": torch.zeros(1, dtype=torch.int32, device=dev),
+            "err": self._flagbuf[2:3] if self.__dict__.get("_flagbuf") is not None else torch.zeros(1, dtype=torch.int32, device=dev),
             "geom": geom,
             # partial sums between the slice passes; the joint launch (geom & 16) keeps one plane per slice
             "acc": torch.empty(((S if geom & 16 else 1) * n_rows, 2 * nc), dtype=torch.float32, device=dev) if S > 1 else None,
@@ -467,7 +471,7 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         # `_last_grad` in between (the step hooks, an own norm / convergence test, an own loop) keeps the undeferred form
         stock = (("on_training_step_end", NeighborEmbedding), ("_training_step", AffinityMatcher), ("_optimizer_step", AffinityMatcher),
                  ("_sgd_kernel", UMAP), ("_compute_gradients", UMAP), ("_compute_gradients_scheduled", UMAP),
-                 ("on_training_step_start", NegativeSamplingNeighborEmbedding), ("_grad_norm", AffinityMatcher),
+                 ("on_training_step_start", NegativeSamplingNeighborEmbedding), ("_grad_norm", UMAP),
                  ("_converged", AffinityMatcher), ("_run_training_loop", UMAP))
         return all(getattr(cls, name) is getattr(owner, name) for name, owner in stock)
 
@@ -524,11 +528,15 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         stock = (
             ("on_training_step_start", NegativeSamplingNeighborEmbedding), ("on_training_step_end", NeighborEmbedding),
             ("_training_step", AffinityMatcher), ("_optimizer_step", AffinityMatcher), ("_sgd_kernel", UMAP),
-            ("_compute_gradients", UMAP), ("_compute_gradients_scheduled", UMAP), ("_grad_norm", AffinityMatcher),
+            ("_compute_gradients", UMAP), ("_compute_gradients_scheduled", UMAP), ("_grad_norm", UMAP),
         )
         return all(getattr(cls, name) is getattr(owner, name) for name, owner in stock)
 
     def _run_training_loop(self):
+        fb = self.__dict__.get("_flagbuf")
+        if fb is not None and fb.device == self._nan_flag.device:
+            fb[0:1].copy_(self._nan_flag)
+            self._nan_flag = fb[0:1]
         if not self._loop_runner_eligible():
             return super()._run_training_loop()
         import ctypes
@@ -633,6 +641,29 @@ class UMAP(NegativeSamplingNeighborEmbedding):
                 self._lr_pos = w0 + n
 
     def _raise_if_nan(self):
+        fb = self.__dict__.get("_flagbuf")
+        merged = (fb is not None and _opt("MERGED_CHECK") and self.world_size == 1 and getattr(self, "_fused_sgd", True) and getattr(self, "_rccl_ctx", None) is None
+                  and self._nan_flag.data_ptr() == fb.data_ptr())
+        if merged:
+            # single process: ONE host read per check for the NaN flag, both schedule error words and the gradient norm (four round
+            # trips before, each with the device idle behind it: ~1 ms of a 112 ms fit at 21 checks)
+            import struct
+
+            g = getattr(self, "_last_grad", None)
+            have_norm = g is not None and not getattr(self, "_last_grad_is_chunk", False)
+            if have_norm:
+                fb.view(torch.float32)[3:4].copy_(g.norm(2).reshape(1))        # the value `_grad_norm` computes (affinity_matcher.py)
+            nan_it, ge_v, se_v, nbits = fb.tolist()
+            if have_norm:
+                self._norm_cache = (g, struct.unpack("f", struct.pack("i", nbits))[0])
+            if nan_it != 0:
+                raise ValueError(f"[TorchDR] ERROR AffinityMatcher : NaNs in the embeddings at iter {nan_it - 1}.")
+            if ge_v != 0 and self.__dict__.get("_sched_err") is not None:
+                raise RuntimeError("[torchdr_amd] UMAP: a group of 16 rows holds more than 2^31 edges; set neighbor_embedding.umap.GROUPED = False.")
+            if se_v != 0 and getattr(self, "_sched", None) is not None:
+                raise RuntimeError("[torchdr_amd] UMAP: schedule build failed (list region overflow, a segment beyond 65535 "
+                                   "entries or a list beyond 2^32 entries); set neighbor_embedding.umap.SCHEDULED = False.")
+            return
         super()._raise_if_nan()
         sc = getattr(self, "_sched", None)
         ge = getattr(self, "_sched_err", None)
@@ -641,6 +672,12 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         if sc is not None and int(sc["err"].item()) != 0:
             raise RuntimeError("[torchdr_amd] UMAP: schedule build failed (list region overflow, a segment beyond 65535 "
                                "entries or a list beyond 2^32 entries); set neighbor_embedding.umap.SCHEDULED = False.")
+
+    def _grad_norm(self) -> float:
+        c = self.__dict__.pop("_norm_cache", None)
+        if c is not None and c[0] is getattr(self, "_last_grad", None):
+            return c[1]          # read together with the flags by `_raise_if_nan` of this check
+        return super()._grad_norm()
 
     def _compute_gradients(self):
         csr: CSRAffinity = self._csr_loop
@@ -696,6 +733,9 @@ class UMAP(NegativeSamplingNeighborEmbedding):
         self.__dict__.pop("_pool", None)
         self.__dict__.pop("_Z_alt", None)
         self.__dict__.pop("_pool_stepped", None)
+        self.__dict__.pop("_flagbuf", None)
+        self.__dict__.pop("_norm_cache", None)
+        self.__dict__.pop("_sched_err", None)
         for attr in ("_csr", "_csr_loop", "epochs_per_sample", "epoch_of_next_sample", "_exclusion", "_grad_buf", "_grad_ws", "_sched", "_loop_cols"):
             if hasattr(self, attr):
                 delattr(self, attr)
