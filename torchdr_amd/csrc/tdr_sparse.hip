@@ -171,13 +171,32 @@ __global__ __launch_bounds__(256) void scan_partial_kernel(const int32_t* __rest
     if (threadIdx.x == 0) { block_sums[blockIdx.x] = red[0]; atomicMax(max_deg, redm[0]); }
 }
 
-__global__ void scan_blocks_kernel(int64_t* __restrict__ block_sums, int64_t nb, int64_t* __restrict__ total) {
-    // single thread block, serial over chunks of 1024 block sums (nb <= ~4M/1024)
-    if (threadIdx.x == 0) {
-        int64_t run = 0;
-        for (int64_t b = 0; b < nb; ++b) { const int64_t v = block_sums[b]; block_sums[b] = run; run += v; }
-        *total = run;
+__global__ __launch_bounds__(256) void scan_blocks_kernel(int64_t* __restrict__ block_sums, int64_t nb, int64_t* __restrict__ total) {
+    // ONE workgroup of 256 threads: exclusive scan of the block sums, 256 at a time with a running carry (a single thread walking
+    // the ~1000 sums of the headline took 0.11 ms on the symmetrisation's critical path)
+    __shared__ int64_t sh[256];
+    __shared__ int64_t carry;
+    const int t = threadIdx.x;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 256) {
+        const int64_t i = base + t;
+        const int64_t v = i < nb ? block_sums[i] : 0;
+        sh[t] = v;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {
+            const int64_t a = t >= o ? sh[t - o] : 0;
+            __syncthreads();
+            sh[t] += a;
+            __syncthreads();
+        }
+        const int64_t incl = sh[t], c0 = carry;
+        if (i < nb) block_sums[i] = c0 + incl - v;
+        __syncthreads();
+        if (t == 255) carry = c0 + incl;
+        __syncthreads();
     }
+    if (t == 0) *total = carry;
 }
 
 __global__ __launch_bounds__(256) void scan_final_kernel(const int32_t* __restrict__ slen, const int32_t* __restrict__ incnt,
@@ -438,7 +457,7 @@ int tdr_sym_count_ordered_f32(const float* vals, const int32_t* cols, int64_t n,
         hipLaunchKernelGGL(sym_count_ext_kernel, dim3((unsigned)((n_ext + 255) / 256)), dim3(256), 0, st, scols, slen, k, ext_row, ext_col, n_ext, incnt);
     }
     hipLaunchKernelGGL(scan_partial_kernel, dim3((unsigned)nb), dim3(256), 0, st, slen, incnt, n, block_sums, max_deg);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(64), 0, st, block_sums, nb, total);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(256), 0, st, block_sums, nb, total);
     hipLaunchKernelGGL(scan_final_kernel, dim3((unsigned)nb), dim3(256), 0, st, slen, incnt, n, block_sums, rowptr);
     hipLaunchKernelGGL(scan_tail_kernel, dim3(1), dim3(64), 0, st, total, n, rowptr);
     TDR_CHECK_LAUNCH();
