@@ -532,7 +532,7 @@ int tdr_khorn_grad_unrolled_dense_f64(const double* C, int64_t n, int64_t ldc, c
  *   Q = gamma / (d_H^2 + gamma^2), d_H^2 = arccosh(1 + 2|zi-zj|^2/((1-|zi|^2)(1-|zj|^2)) + 1e-8)^2
  * (distance/torch.py:101-107, distance/base.py:392-398).  Pass 1 = all-pairs sums for the chunk rows (rowsum of Q +
  * unscaled gradient sums kept in ws), pass 2 = attraction over both ends of every kNN edge + scaling by S = sum of all
- * rowsums (device scalar, all-reduced by the caller) + norm term.  nc in 2..4. */
+ * rowsums (device scalar, all-reduced by the caller) + norm term.  nc in 2..8. */
 int tdr_cosne_splits(int64_t n_total, int64_t n_rows);
 int64_t tdr_cosne_workspace_bytes(int64_t n_total, int64_t n_rows, int nc);
 int tdr_cosne_pairs_f64(const double* Z, int nc, int64_t n_total, int64_t row0, int64_t n_rows, double gamma,

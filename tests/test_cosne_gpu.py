@@ -58,13 +58,13 @@ def test_gradient_matches_oracle_and_reference(pre, tol_oracle, tol_golden):
 
 
 def test_gradient_against_autograd_of_the_restated_loss():
-    """Independent of the fixture: random interior points, n_components = 2 and 3, exaggeration and repulsion weights."""
+    """Independent of the fixture: random interior points, n_components = 2 .. 8, exaggeration and repulsion weights."""
     from oracle import ref_torch as R
     from torchdr_amd import _lib
     from torchdr_amd.neighbor_embedding.base import build_transposed_graph
 
     gen = torch.Generator().manual_seed(3)
-    for nc, n, k in ((2, 700, 12), (3, 333, 7), (4, 257, 5)):
+    for nc, n, k in ((2, 700, 12), (3, 333, 7), (4, 257, 5), (5, 300, 6), (8, 411, 9)):
         Z = R.hyperbolic_init(torch.randn(n, nc, generator=gen, dtype=torch.float64), 0.7)
         NN = torch.stack([torch.randperm(n, generator=gen)[:k] for _ in range(n)]).int()
         P = torch.rand(n, k, generator=gen)
@@ -151,5 +151,7 @@ def test_estimator_surface():
     assert Z3.shape == (600, 3)
     with pytest.raises(ValueError, match="init pca not supported"):
         torchdr_amd.COSNE(perplexity=15, init="pca").fit_transform(X.cuda())
+    Z6 = torchdr_amd.COSNE(perplexity=15, max_iter=10, n_components=6, lr=0.05).fit_transform(X.cuda())
+    assert Z6.shape == (600, 6) and bool(torch.isfinite(Z6).all()) and float(Z6.norm(dim=1).max()) < 1.0
     with pytest.raises(NotImplementedError, match="n_components"):
-        torchdr_amd.COSNE(perplexity=15, n_components=5).fit_transform(X.cuda())
+        torchdr_amd.COSNE(perplexity=15, n_components=9).fit_transform(X.cuda())

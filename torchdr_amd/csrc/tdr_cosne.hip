@@ -19,7 +19,7 @@
 namespace tdr {
 
 constexpr int CO_TILE = 256;
-constexpr int CO_MAXC = 4;   // embedding dimensions supported (the reference's use is 2)
+constexpr int CO_MAXC = 8;   // embedding dimensions supported (the reference's use is 2)
 
 struct CosnePairsParams {
     const double* Z; int nc; int64_t n_total, row0, n_rows;
@@ -246,15 +246,18 @@ __global__ __launch_bounds__(256) void cosne_radam_kernel(const RadamParams P) {
     if (bad && P.nan_flag) atomicMax(P.nan_flag, P.n_iter + 1);
 }
 
-template <typename F2, typename F3, typename F4>
-static int dispatch_nc(int nc, F2 f2, F3 f3, F4 f4) {
-    switch (nc) {
-        case 2: f2(); return TDR_OK;
-        case 3: f3(); return TDR_OK;
-        case 4: f4(); return TDR_OK;
-        default: return TDR_ERR_UNSUPPORTED;
+// one instance per embedding dimension 2 .. CO_MAXC
+#define TDR_COSNE_DISPATCH(NCV, KERNEL, GRID, BLOCK, ST, ARG)                                        \
+    switch (NCV) {                                                                                   \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, BLOCK, 0, ST, ARG); break;                       \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, GRID, BLOCK, 0, ST, ARG); break;                       \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, GRID, BLOCK, 0, ST, ARG); break;                       \
+        case 5: hipLaunchKernelGGL(KERNEL<5>, GRID, BLOCK, 0, ST, ARG); break;                       \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, GRID, BLOCK, 0, ST, ARG); break;                       \
+        case 7: hipLaunchKernelGGL(KERNEL<7>, GRID, BLOCK, 0, ST, ARG); break;                       \
+        case 8: hipLaunchKernelGGL(KERNEL<8>, GRID, BLOCK, 0, ST, ARG); break;                       \
+        default: return TDR_ERR_UNSUPPORTED;                                                         \
     }
-}
 
 }  // namespace tdr
 
@@ -288,11 +291,7 @@ int tdr_cosne_pairs_f64(const double* Z, int nc, int64_t n_total, int64_t row0, 
     P.n_split = tdr_cosne_splits(n_total, n_rows); P.part = (double*)ws;
     const dim3 grid((unsigned)((n_rows + CO_TILE - 1) / CO_TILE), (unsigned)P.n_split);
     hipStream_t st = (hipStream_t)stream;
-    const int rc = dispatch_nc(
-        nc, [&] { hipLaunchKernelGGL(cosne_pairs_kernel<2>, grid, dim3(CO_TILE), 0, st, P); },
-        [&] { hipLaunchKernelGGL(cosne_pairs_kernel<3>, grid, dim3(CO_TILE), 0, st, P); },
-        [&] { hipLaunchKernelGGL(cosne_pairs_kernel<4>, grid, dim3(CO_TILE), 0, st, P); });
-    if (rc != TDR_OK) return rc;
+    TDR_COSNE_DISPATCH(nc, cosne_pairs_kernel, grid, dim3(CO_TILE), st, P)
     TDR_CHECK_LAUNCH();
     hipLaunchKernelGGL(cosne_rowsum_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, (const double*)ws,
                        P.n_split, n_rows, nc + 1, rowsum);
@@ -317,11 +316,7 @@ int tdr_cosne_grad_f64(const double* Z, int nc, int64_t n_total, int64_t row0, i
     P.exag = exag; P.rep = rep; P.grad = grad;
     const dim3 grid((unsigned)((n_rows + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
-    const int rc = dispatch_nc(
-        nc, [&] { hipLaunchKernelGGL(cosne_finish_kernel<2>, grid, dim3(256), 0, st, P); },
-        [&] { hipLaunchKernelGGL(cosne_finish_kernel<3>, grid, dim3(256), 0, st, P); },
-        [&] { hipLaunchKernelGGL(cosne_finish_kernel<4>, grid, dim3(256), 0, st, P); });
-    if (rc != TDR_OK) return rc;
+    TDR_COSNE_DISPATCH(nc, cosne_finish_kernel, grid, dim3(256), st, P)
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }
@@ -340,11 +335,7 @@ int tdr_radam_poincare_f64(double* Z, const double* egrad, double* exp_avg, doub
     P.nan_flag = nan_flag; P.n_iter = n_iter;
     const dim3 grid((unsigned)((n_rows + 255) / 256));
     hipStream_t st = (hipStream_t)stream;
-    const int rc = dispatch_nc(
-        nc, [&] { hipLaunchKernelGGL(cosne_radam_kernel<2>, grid, dim3(256), 0, st, P); },
-        [&] { hipLaunchKernelGGL(cosne_radam_kernel<3>, grid, dim3(256), 0, st, P); },
-        [&] { hipLaunchKernelGGL(cosne_radam_kernel<4>, grid, dim3(256), 0, st, P); });
-    if (rc != TDR_OK) return rc;
+    TDR_COSNE_DISPATCH(nc, cosne_radam_kernel, grid, dim3(256), st, P)
     TDR_CHECK_LAUNCH();
     return TDR_OK;
 }

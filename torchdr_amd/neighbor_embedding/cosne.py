@@ -50,8 +50,8 @@ class COSNE(NeighborEmbedding):
 
     # --- fit ------------------------------------------------------------------------------------
     def _fit_transform(self, X: torch.Tensor, y: Optional[Any] = None) -> torch.Tensor:
-        if not (2 <= self.n_components <= 4):
-            raise NotImplementedError("[torchdr_amd] COSNE supports n_components in 2..4.")
+        if not (2 <= self.n_components <= 8):
+            raise NotImplementedError("[torchdr_amd] COSNE supports n_components in 2..8.")
         if not self.sparsity:
             raise NotImplementedError("[torchdr_amd] COSNE runs on the sparse (kNN) entropic affinity.")
         self._x_sqnorm_full = (X.float() ** 2).sum(-1)           # cosne.py:158 (whole set; sliced to the chunk below)
