@@ -64,10 +64,16 @@ def test_gradient_against_autograd_of_the_restated_loss():
     from torchdr_amd.neighbor_embedding.base import build_transposed_graph
 
     gen = torch.Generator().manual_seed(3)
-    for nc, n, k in ((2, 700, 12), (3, 333, 7), (4, 257, 5), (5, 300, 6), (8, 411, 9)):
+    for nc, n, k in ((2, 700, 12), (3, 333, 7), (4, 257, 5), (5, 300, 6), (8, 411, 9), (2, 150, 0), (3, 97, 0)):
         Z = R.hyperbolic_init(torch.randn(n, nc, generator=gen, dtype=torch.float64), 0.7)
-        NN = torch.stack([torch.randperm(n, generator=gen)[:k] for _ in range(n)]).int()
-        P = torch.rand(n, k, generator=gen)
+        if k == 0:       # sparsity=False: the dense affinity as a graph of width n (row i lists 0 .. n - 1, zero diagonal)
+            k = n
+            NN = torch.arange(n, dtype=torch.int32).unsqueeze(0).expand(n, -1).contiguous()
+            P = torch.rand(n, n, generator=gen)
+            P.fill_diagonal_(0.0)
+        else:
+            NN = torch.stack([torch.randperm(n, generator=gen)[:k] for _ in range(n)]).int()
+            P = torch.rand(n, k, generator=gen)
         Xn = torch.rand(n, generator=gen) * 5
         Zr = Z.clone().requires_grad_()
         R.cosne_loss(Zr, P, NN, Xn, 1.5, 0.3, exag=4.0, rep=0.7).backward()
@@ -155,3 +161,12 @@ def test_estimator_surface():
     assert Z6.shape == (600, 6) and bool(torch.isfinite(Z6).all()) and float(Z6.norm(dim=1).max()) < 1.0
     with pytest.raises(NotImplementedError, match="n_components"):
         torchdr_amd.COSNE(perplexity=15, n_components=9).fit_transform(X.cuda())
+    # sparsity=False: the dense (N, N) entropic affinity (reference cosne.py:162-171 with NN_indices_ = None)
+    md = torchdr_amd.COSNE(perplexity=15, max_iter=40, lr=0.05, random_state=0, sparsity=False)
+    Zd2 = md.fit_transform(X.cuda())
+    assert Zd2.shape == (600, 2) and bool(torch.isfinite(Zd2).all()) and float(Zd2.norm(dim=1).max()) < 1.0
+    Pd, _ = EntropicAffinity(perplexity=15, sparsity=False)(X.cuda(), return_indices=True)
+    NNd = torch.arange(600).unsqueeze(0).expand(600, -1)
+    md0 = torchdr_amd.COSNE(perplexity=15, max_iter=1, lr=1e-12, random_state=0, sparsity=False)
+    Zd0 = md0.fit_transform(X.cuda())
+    assert float(R.cosne_loss(Zd2.cpu(), Pd.cpu(), NNd, Xn, 2.0, 0.1)) < float(R.cosne_loss(Zd0.cpu(), Pd.cpu(), NNd, Xn, 2.0, 0.1))

@@ -52,8 +52,8 @@ class COSNE(NeighborEmbedding):
     def _fit_transform(self, X: torch.Tensor, y: Optional[Any] = None) -> torch.Tensor:
         if not (2 <= self.n_components <= 8):
             raise NotImplementedError("[torchdr_amd] COSNE supports n_components in 2..8.")
-        if not self.sparsity:
-            raise NotImplementedError("[torchdr_amd] COSNE runs on the sparse (kNN) entropic affinity.")
+        if not self.sparsity and self.world_size > 1:
+            raise NotImplementedError("[torchdr_amd] COSNE(sparsity=False) runs in a single process (the dense (N, N) affinity is not sharded).")
         self._x_sqnorm_full = (X.float() ** 2).sum(-1)           # cosne.py:158 (whole set; sliced to the chunk below)
         return super()._fit_transform(X, y)
 
@@ -63,7 +63,10 @@ class COSNE(NeighborEmbedding):
         c0 = self.chunk_start_
         self._x_sqnorm = self._x_sqnorm_full.to(dev)[c0:c0 + self.chunk_size_].contiguous()
         del self._x_sqnorm_full
-        self._tgraph = build_transposed_graph(self.affinity_in_, self.NN_indices_, c0, self.n_samples_in_,
+        # sparsity=False: the dense (N, N) affinity as a graph of width N whose row i lists 0 .. N - 1 (`_nn_table` of the base class;
+        # the reference's attraction then runs over all pairs, cosne.py:162-171 with NN_indices_ = None)
+        self._nn_graph = self.NN_indices_ if self.NN_indices_ is not None else self._nn_table
+        self._tgraph = build_transposed_graph(self.affinity_in_, self._nn_graph, c0, self.n_samples_in_,
                                               self.world_size)
 
     def _init_embedding(self, X):
@@ -120,8 +123,11 @@ class COSNE(NeighborEmbedding):
 
             allreduce_(S)
         P = self.affinity_in_
+        nn = self.__dict__.get("_nn_graph")
+        if nn is None:
+            nn = self.NN_indices_
         _lib.check(
-            L.tdr_cosne_grad_f64(_lib.ptr(Z), nc, n, c0, m, _lib.ptr(self.NN_indices_), _lib.ptr(P), P.shape[1],
+            L.tdr_cosne_grad_f64(_lib.ptr(Z), nc, n, c0, m, _lib.ptr(nn), _lib.ptr(P), P.shape[1],
                                  _lib.ptr(self._tgraph[0]), _lib.ptr(self._tgraph[1]), _lib.ptr(self._tgraph[2]),
                                  _lib.ptr(S), _lib.ptr(self._x_sqnorm), float(self.gamma),
                                  float(self.learning_rate_for_h_loss), float(self.early_exaggeration_coeff_),
@@ -148,6 +154,6 @@ class COSNE(NeighborEmbedding):
 
     def clear_memory(self):
         super().clear_memory()
-        for attr in ("_tgraph", "_ws", "_rowsum", "_egrad", "_x_sqnorm", "_radam"):
+        for attr in ("_tgraph", "_nn_graph", "_ws", "_rowsum", "_egrad", "_x_sqnorm", "_radam"):
             if hasattr(self, attr):
                 delattr(self, attr)
