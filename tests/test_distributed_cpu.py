@@ -175,7 +175,7 @@ def test_abi_argument_checks_run_before_any_device_work():
     assert L.tdr_topk_merge_f32(p, 8, 4, 8, null, null, 0, 0, 5, 4, 0, p, null) == -1   # sqhyperbolic needs the norms
     assert L.tdr_topk_merge_f32(p, 8, 4, 8, null, null, 0, 0, 5, 7, 0, p, null) == -1   # unknown metric
     assert L.tdr_hyperbolic_from_gram_f32(p, 4, 2, 8, p, p, null) == -1              # ld < nd
-    assert L.tdr_cosne_pairs_f64(p, 5, 100, 0, 100, 2.0, p, p, 1 << 30, null) == -2  # n_components > 4
+    assert L.tdr_cosne_pairs_f64(p, 9, 100, 0, 100, 2.0, p, p, 1 << 30, null) == -2  # n_components > 8
     assert L.tdr_cosne_pairs_f64(p, 2, 100, 50, 100, 2.0, p, p, 1 << 30, null) == -1  # chunk outside the point set
     assert L.tdr_cosne_pairs_f64(p, 2, 100, 0, 100, 2.0, p, p, 8, null) == -1        # workspace too small
     assert L.tdr_radam_poincare_f64(p, p, p, p, null, 10, 1, 0.9, 0.999, 1e-8, 0.1, 1.0, null, 0, null) == -2
