@@ -251,6 +251,37 @@ def test_pruned_search_picks_its_list_form_by_the_predicted_scan_share():
         assert torch.equal(C0, C1) and torch.equal(I0, I1)
 
 
+def test_index_refinement_and_robust_pilot_threshold_on_heavy_tailed_group_sizes():
+    """More separated groups than the first seeding finds (Zipf-sized groups, the small ones absent from the 8192-point sample): every
+    stray group sets the radius of the ball that absorbs it and rows of groups with fewer than k members have far k-th neighbours.
+    The index is re-seeded on the points far from every centre (ClusterIndex._refine) and the predictions are made for the pilot's
+    90th-percentile k-th distance (`_pilot_tau`): the search is pruned -- and returns the rows of the unrefined, unpruned search."""
+    from torchdr_amd import config
+    from torchdr_amd.distance import base as dbase
+    from torchdr_amd.distance import pairwise_distances
+
+    n, d, k, groups = 300_000, 64, 30, 2500
+    g = torch.Generator().manual_seed(1)
+    w = 1.0 / torch.arange(1, groups + 1, dtype=torch.float64) ** 1.1
+    lab = torch.multinomial(w / w.sum(), n, replacement=True, generator=g)
+    X = (torch.randn(groups, d, generator=g)[lab] * 2.0 + 0.5 * torch.randn(n, d, generator=g)).float().cuda().contiguous()
+    dbase.LAST_KNN.pop("index_refined", None)
+    C0, I0 = pairwise_distances(X, metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True)
+    L = dict(dbase.LAST_KNN)
+    assert L["path"] == "screen-pruned" and L.get("index_refined"), L
+    assert L["pilot_tau"][0] == "q90" and L["pilot_tau"][1] > 4 * L["pilot_tau"][2]
+    first, last = L["index_refined"][0], L["index_refined"][-1]
+    assert last[1] > first[0] and last[1] <= 4096           # balls were added, within the tables' limit
+    with config.options(REFINE_INDEX=False, PRUNE_MODE="0"):
+        C1, I1 = pairwise_distances(X.clone(), metric="sqeuclidean", k=k, exclude_diag=True, return_indices=True)
+    assert dbase.LAST_KNN["path"] != "screen-pruned"
+    assert torch.equal(C0, C1) and torch.equal(I0, I1)
+    # the benchmark's mixture never triggers either mechanism (equal groups, homogeneous radii)
+    dbase.LAST_KNN.pop("index_refined", None)
+    pairwise_distances(gmm(200_000, 64, 2.0, seed=3).cuda(), metric="sqeuclidean", k=20, exclude_diag=True)
+    assert not dbase.LAST_KNN.get("index_refined") and dbase.LAST_KNN["pilot_tau"][0] == "max"
+
+
 def test_headline_size_search_sampled_against_the_one_stage_kernel():
     """BASELINE's full size (N = 1M, D = 128, k = 30), default dispatch (pilot -> tier -> cluster-pruned two-stage search):
     256 sampled rows searched by the CPU oracle against the whole set, and 8192 sampled rows re-searched by the one-stage exact fp32 kernel -- itself bit-exact against the CPU oracle at the

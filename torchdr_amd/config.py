@@ -21,7 +21,7 @@ _OVERRIDES = contextvars.ContextVar("torchdr_amd_options", default=None)
 SWITCHES = {
     "SCREEN_MODE": "torchdr_amd.distance.base", "PRUNE_MODE": "torchdr_amd.distance.base",
     "PILOT_CONCURRENT": "torchdr_amd.distance.base", "WIDE_SCAN": "torchdr_amd.distance.base",
-    "TILE_BOUNDS": "torchdr_amd.distance.base", "PRUNED_LISTS": "torchdr_amd.distance.base", "FLAT_SCAN": "torchdr_amd.distance.base", "FLAT_TWO_TERMS": "torchdr_amd.distance.base", "FLAT_FORCE_TERMS": "torchdr_amd.distance.base", "ASSIGN16": "torchdr_amd.distance.base", "FLAT_WS_LIMIT": "torchdr_amd.distance.base",
+    "TILE_BOUNDS": "torchdr_amd.distance.base", "REFINE_INDEX": "torchdr_amd.distance.base", "PRUNED_LISTS": "torchdr_amd.distance.base", "FLAT_SCAN": "torchdr_amd.distance.base", "FLAT_TWO_TERMS": "torchdr_amd.distance.base", "FLAT_FORCE_TERMS": "torchdr_amd.distance.base", "ASSIGN16": "torchdr_amd.distance.base", "FLAT_WS_LIMIT": "torchdr_amd.distance.base",
     "SCHEDULED": "torchdr_amd.neighbor_embedding.umap", "RELABEL": "torchdr_amd.neighbor_embedding.umap",
     "LOOP_RUNNER": "torchdr_amd.neighbor_embedding.umap", "LOOP_GRAPH": "torchdr_amd.neighbor_embedding.umap",
     "SCHED_GEOM": "torchdr_amd.neighbor_embedding.umap", "MERGED_CHECK": "torchdr_amd.neighbor_embedding.umap", "SCHED_SLICES": "torchdr_amd.neighbor_embedding.umap",

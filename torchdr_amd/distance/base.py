@@ -160,6 +160,12 @@ TILE_BOUNDS = True   # per-tile bounds as the second chance of a pruned search (
 _TILE_MAX_SCAN_FRACTION = 0.97
 _SEED_DROP = 0.25    # adaptive seeding: a max-min SQUARED distance below a quarter of the previous one ends the seeding
 _PRUNE_MIN_N = 65536
+REFINE_INDEX = True            # second-chance seeds for the points far from every ball centre (ClusterIndex._refine)
+_REFINE_MAX_PASSES = 3
+_REFINE_FAR = 2.0              # a point farther than this many lower-quartile radii from its centre is re-seeded (members of a ball
+                               # without strays lie within ~1 such radius; in 64 dimensions the NEAREST of a few hundred foreign
+                               # centres is only ~3 radii away, so the trigger ratio itself would cut nothing)
+_REFINE_RADIUS_RATIO = 3.0     # ... when the largest ball radius exceeds this many lower-quartile radii
 _PRUNE_MAX_SCAN_FRACTION = 0.5  # predicted share of tiles still visited above which the plain scan is used
 
 
@@ -187,6 +193,7 @@ class ClusterIndex:
         dev = X.device
         N, D = X.shape
         L = _lib.lib()
+        self._auto_count = n_clusters is None
         # more than 2048 balls measured slower at N = 4M (3.5 s vs 2.7 s): Gaussian blobs in high dimension are not
         # resolved further by splitting them -- the sub-balls overlap and all of them are scanned anyway
         C = int(n_clusters or min(2048, max(8, N // 1000)))
@@ -247,6 +254,20 @@ class ClusterIndex:
             _, lab = knn_packed(Ps, PackedPoints(cent), 1, "sqeuclidean", exclude_self=False, _allow_screen=False)
             _lib.check(L.tdr_cluster_update_f32(_lib.ptr(Xs), S, D, _lib.ptr(lab), C, _lib.ptr(cent), _lib.ptr(ws), st),
                        "tdr_cluster_update_f32")
+        self._refinable = bool(self.__dict__.get("_auto_count", False))      # the caller left the count to the data
+        self._assign_and_tables(P, cent, ws)
+
+    def _assign_and_tables(self, P, cent, ws=None):
+        """Steps 3b-5 of the build for the centres `cent`: nearest-centre assignment of all points, radii, padded cluster-sorted
+        layout, centre tables.  Leaves `_pending` for `finish()`."""
+        X = P.X
+        dev = X.device
+        N, D = X.shape
+        C = int(cent.shape[0])
+        L = _lib.lib()
+        st = _lib.stream_ptr()
+        if ws is None or ws.numel() < max(int(L.tdr_cluster_tables_workspace_bytes(N, C)) // 4, C * D + 3 * C) + 1:
+            ws = torch.empty(max(int(L.tdr_cluster_tables_workspace_bytes(N, C)) // 4, C * D + 3 * C) + 1, dtype=torch.int32, device=dev)
         if _opt("ASSIGN16") and L.tdr_cluster_assign16_supported(D) and N >= 65536:
             # nearest centre by the one-term screening value on the f16 matrix pipe (0.4 ms at N = 1M, C = 1000, against 3.8-6.4 ms
             # for the exact fp32 search with k = 1): the assignment shapes the clusters, no result depends on it
@@ -292,6 +313,7 @@ class ClusterIndex:
         self.order = order
         self.img16 = None
         self._pending = (n_img, row_map, tile_cluster, tiles)
+        self._points, self._labels = P, labels
 
     _seeded = None
 
@@ -302,13 +324,74 @@ class ClusterIndex:
             return self
         n_img, row_map, tile_cluster, tiles = self._pending
         self._pending = None
-        self.n_img = max(int(n_img.item()), 32)
+        # one host read: the padded image's row count and, when the ball count was left to the data, the largest and the median
+        # radius -- a ball that absorbed a stray group carries that group's distance as its radius and cannot be pruned by anyone
+        passes = int(self.__dict__.get("_refine_passes", 0))
+        refinable = (bool(self.__dict__.get("_refinable", False)) and _opt("REFINE_INDEX") and self.n_clusters < 4096 - 16
+                     and passes < _REFINE_MAX_PASSES)
+        if refinable:
+            r = self.radius
+            # (the LOWER QUARTILE stands for a ball without strays: with more groups than balls most balls have absorbed one)
+            r_low = r.kthvalue(max(1, int(r.numel()) // 4)).values
+            n_img_v, r_max, r_med = torch.cat([n_img.double().reshape(1), r.max().double().reshape(1), r_low.double().reshape(1)]).tolist()
+            LAST_KNN["index_radii"] = (round(r_max, 3), round(r_med, 3), int(r.numel()))
+            self._refine_passes = passes + 1
+            if r_med > 0.0 and r_max > _REFINE_RADIUS_RATIO * r_med and self._refine(float(r_med)):
+                return self.finish()          # the refined tables are pending now; at most _REFINE_MAX_PASSES rounds
+            n_img = int(n_img_v)
+        else:
+            n_img = int(n_img.item())
+        self.__dict__.pop("_points", None)
+        self.__dict__.pop("_labels", None)
+        self.n_img = max(n_img, 32)
         self.row_map = row_map[: self.n_img]
         self.tile_cluster = tile_cluster[: self.n_img // 32]
         self._tiles_i32 = tiles
         self.tiles = tiles.to(torch.int64)
         self._scan_fraction_memo = {}
         return self
+
+    def _refine(self, r_med: float) -> bool:
+        """Second-chance seeds for the points the first seeding did not cover: the sample of 8192 points the seeds are chosen from
+        does not contain small groups at all (3000 groups with heavy-tailed sizes: `profiles/r06_knn_regimes.jsonl`), each of them
+        is absorbed by some ball and sets its radius.  Points farther than _REFINE_FAR lower-quartile radii from their centre are sampled again,
+        seeded by the same farthest-point rule (up to 4096 balls in all), and everything is assigned anew.  Deterministic (the same
+        index on every rank); the search result does not depend on it.  Returns False when there is nothing to refine."""
+        P, labels = self._points, self._labels
+        X = P.X
+        dev = X.device
+        N, D = X.shape
+        L = _lib.lib()
+        st = _lib.stream_ptr()
+        cent, C = self.centres, self.n_clusters
+        thr = (_REFINE_FAR * r_med) ** 2
+        far = torch.empty(N, dtype=torch.bool, device=dev)
+        lab = labels.reshape(-1).long()
+        for b in range(0, N, 262144):      # |x - c(x)|^2 block by block (N x D temporaries only for a block)
+            e = min(N, b + 262144)
+            far[b:e] = ((X[b:e] - cent[lab[b:e]]) ** 2).sum(1) > thr
+        res = far.nonzero().squeeze(1)
+        n_res = int(res.numel())
+        if n_res < max(64, N // 5000):
+            return False
+        S2 = int(min(n_res, 8192, L.tdr_cluster_maxmin_capacity()))
+        pick = res[torch.linspace(0, n_res - 1, S2, device=dev).long()].to(torch.int32)
+        Xs2 = torch.empty((S2, D), dtype=torch.float32, device=dev)
+        _lib.check(L.tdr_gather_rows_f32(_lib.ptr(X), X.stride(0), D, _lib.ptr(pick), None, S2, _lib.ptr(Xs2), st), "tdr_gather_rows_f32")
+        Ps2 = PackedPoints(Xs2)
+        D2 = dense_packed(Ps2, Ps2, "sqeuclidean", False)
+        c_extra = int(min(4096 - C, S2))
+        seeds2 = torch.empty(c_extra, dtype=torch.int32, device=dev)
+        n2 = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.tdr_cluster_maxmin_adaptive_f32(_lib.ptr(D2), D2.stride(0), S2, min(8, c_extra), c_extra, _SEED_DROP, _lib.ptr(seeds2),
+                                                     _lib.ptr(n2), st), "tdr_cluster_maxmin_adaptive_f32")
+        k2 = int(n2.item())
+        if k2 <= 0:
+            return False
+        cent2 = torch.cat([cent, Xs2[seeds2[:k2].long()]]).contiguous()
+        LAST_KNN["index_refined"] = (LAST_KNN.get("index_refined") or []) + [(C, C + k2, n_res)]
+        self._assign_and_tables(P, cent2)
+        return True
 
     def record_stream(self, stream):
         """The tables may have been allocated while a side stream was current (the build runs next to the pilots); the
@@ -584,6 +667,20 @@ def _side_streams(dev, n):
     return have[:n]
 
 
+def _pilot_tau(kth2: torch.Tensor) -> float:
+    """The k-th neighbour distance (squared) the PREDICTIONS of a search are made for -- scan shares, tile bounds, list form; no
+    result depends on it: the largest of the pilot rows, unless that one is an outlier (more than four times the median: rows of groups
+    with fewer than k members, whose neighbours sit in other groups -- `profiles/r06_knn_regimes.jsonl`, heavy-tailed group sizes: 2 %
+    of the rows made every prediction read "nothing can be pruned"); then the 90th percentile.  One host read."""
+    v = kth2.float()
+    mx, med, q90 = torch.stack([v.max(), v.median(), torch.quantile(v, 0.9)]).tolist()
+    if med > 0.0 and mx > 4.0 * med:
+        LAST_KNN["pilot_tau"] = ("q90", mx, q90)
+        return float(max(q90, med))
+    LAST_KNN["pilot_tau"] = ("max", mx, q90)
+    return float(mx)
+
+
 def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset, side_work=None, scan_frac_of=None):
     """Pilot: screen a slice of _SCREEN_PILOT_Q (512) queries with the tiers (one-term, three-term, three-term with long lists), flagging what
     an UNSLICED launch would flag; among the tiers with <= 5 % flagged the one with the smallest estimated total time wins
@@ -653,7 +750,7 @@ def _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset, side_work=Non
         f = int(n_flagged.item()) / float(_SCREEN_PILOT_Q)
         if f <= _SCREEN_PILOT_MAX_FRAC:
             kth = pd[:, -1]
-            cands.append((tier, f, float((kth * kth if metric == "euclidean" else kth).max())))
+            cands.append((tier, f, _pilot_tau(kth * kth if metric == "euclidean" else kth)))
     nq_all = Q.n if Q is not Y else Y.n
     if cands and 2 in tiers and 2 not in runs:
         # A tier that passes with a few per cent flagged can still be the wrong one: every flagged row is recomputed by a full
@@ -794,6 +891,10 @@ def _pruned_launch(Y, ops, ci, k, metric, exclude_self, tier, out_d, out_i, pos_
     dev, d = Y.device, Y.d
     want = _opt("PRUNED_LISTS")
     lazy = want == "lazy" or (want != "sorted" and (share is None or share <= _LAZY_MAX_SHARE))
+    if lazy and want != "lazy" and (LAST_KNN.get("pilot_tau") or ("max",))[0] == "q90":
+        # the share was predicted for the 90th percentile of the pilot's k-th distances: a tenth of the rows have (much) farther
+        # neighbours and scan steadily -- the sorted lists' regime (heavy-tailed group sizes: 249 ms lazy, 184 ms sorted)
+        lazy = False
     LAST_KNN["predicted_share"], LAST_KNN["lists"] = share, "lazy" if lazy else "sorted"
     prev_lists = L.tdr_knn_screen_clustered_lists(-1)
     if not prev_lists:
