@@ -260,7 +260,7 @@ def test_index_refinement_and_robust_pilot_threshold_on_heavy_tailed_group_sizes
     from torchdr_amd.distance import base as dbase
     from torchdr_amd.distance import pairwise_distances
 
-    n, d, k, groups = 300_000, 64, 30, 2500
+    n, d, k, groups = 300_000, 128, 30, 2500
     g = torch.Generator().manual_seed(1)
     w = 1.0 / torch.arange(1, groups + 1, dtype=torch.float64) ** 1.1
     lab = torch.multinomial(w / w.sum(), n, replacement=True, generator=g)

@@ -162,6 +162,8 @@ _SEED_DROP = 0.25    # adaptive seeding: a max-min SQUARED distance below a quar
 _PRUNE_MIN_N = 65536
 REFINE_INDEX = True            # second-chance seeds for the points far from every ball centre (ClusterIndex._refine)
 _REFINE_MAX_PASSES = 3
+_REFINE_MIN_SEEDS = 32         # a round that finds fewer new seeds than this is dropped (mixtures of groups of different widths: 8 seeds per
+                               # round, three rounds of re-assignment for nothing: 285 -> 317 ms, tools/lab/refine_probe.py)
 _REFINE_FAR = 2.0              # a point farther than this many lower-quartile radii from its centre is re-seeded (members of a ball
                                # without strays lie within ~1 such radius; in 64 dimensions the NEAREST of a few hundred foreign
                                # centres is only ~3 radii away, so the trigger ratio itself would cut nothing)
@@ -374,19 +376,36 @@ class ClusterIndex:
         n_res = int(res.numel())
         if n_res < max(64, N // 5000):
             return False
+        def seed_far(S2, c_lo, c_hi):
+            """Farthest-point seeds (adaptive count) on S2 evenly spaced far points: (sample rows, seeds, count)."""
+            pick = res[torch.linspace(0, n_res - 1, S2, device=dev).long()].to(torch.int32)
+            Xs2 = torch.empty((S2, D), dtype=torch.float32, device=dev)
+            _lib.check(L.tdr_gather_rows_f32(_lib.ptr(X), X.stride(0), D, _lib.ptr(pick), None, S2, _lib.ptr(Xs2), st), "tdr_gather_rows_f32")
+            Ps2 = PackedPoints(Xs2)
+            D2 = dense_packed(Ps2, Ps2, "sqeuclidean", False)
+            seeds2 = torch.empty(c_hi, dtype=torch.int32, device=dev)
+            n2 = torch.zeros(1, dtype=torch.int32, device=dev)
+            _lib.check(L.tdr_cluster_maxmin_adaptive_f32(_lib.ptr(D2), D2.stride(0), S2, c_lo, c_hi, _SEED_DROP, _lib.ptr(seeds2),
+                                                         _lib.ptr(n2), st), "tdr_cluster_maxmin_adaptive_f32")
+            return Xs2, seeds2, int(n2.item())
+
+        if int(self.__dict__.get("_refine_passes", 1)) <= 1 and n_res > 1024:
+            # first round: a PROBE on 1024 far points (every one of them may become a seed: 512 short steps, ~1.5 ms) before the full round (up to 3800 dependent
+            # seeding steps: 7 ms when the max-min distance never collapses, which is what far points of merely WIDE groups do)
+            _, _, kp = seed_far(1024, 8, 1024)
+            LAST_KNN["index_refine_probe"] = kp
+            if kp < _REFINE_MIN_SEEDS:
+                self._refine_passes = _REFINE_MAX_PASSES
+                return False
         S2 = int(min(n_res, 8192, L.tdr_cluster_maxmin_capacity()))
-        pick = res[torch.linspace(0, n_res - 1, S2, device=dev).long()].to(torch.int32)
-        Xs2 = torch.empty((S2, D), dtype=torch.float32, device=dev)
-        _lib.check(L.tdr_gather_rows_f32(_lib.ptr(X), X.stride(0), D, _lib.ptr(pick), None, S2, _lib.ptr(Xs2), st), "tdr_gather_rows_f32")
-        Ps2 = PackedPoints(Xs2)
-        D2 = dense_packed(Ps2, Ps2, "sqeuclidean", False)
         c_extra = int(min(4096 - C, S2))
-        seeds2 = torch.empty(c_extra, dtype=torch.int32, device=dev)
-        n2 = torch.zeros(1, dtype=torch.int32, device=dev)
-        _lib.check(L.tdr_cluster_maxmin_adaptive_f32(_lib.ptr(D2), D2.stride(0), S2, min(8, c_extra), c_extra, _SEED_DROP, _lib.ptr(seeds2),
-                                                     _lib.ptr(n2), st), "tdr_cluster_maxmin_adaptive_f32")
-        k2 = int(n2.item())
-        if k2 <= 0:
+        Xs2, seeds2, k2 = seed_far(S2, min(8, c_extra), c_extra)
+        LAST_KNN["index_refine_try"] = (C, k2, n_res, S2)
+        if k2 < _REFINE_MIN_SEEDS:
+            # the far points are not separated groups: the farthest-point rule found no collapse of the max-min distance and hands back
+            # its minimum count (members of WIDE groups among narrow ones, radii that differ by the data's nature; also groups whose
+            # spacing shrinks gradually, as in 64 dimensions) -- nothing to gain from more balls, and no further round
+            self._refine_passes = _REFINE_MAX_PASSES
             return False
         cent2 = torch.cat([cent, Xs2[seeds2[:k2].long()]]).contiguous()
         LAST_KNN["index_refined"] = (LAST_KNN.get("index_refined") or []) + [(C, C + k2, n_res)]
