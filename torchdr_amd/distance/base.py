@@ -337,20 +337,36 @@ class ClusterIndex:
             r_low = r.kthvalue(max(1, int(r.numel()) // 4)).values
             n_img_v, r_max, r_med = torch.cat([n_img.double().reshape(1), r.max().double().reshape(1), r_low.double().reshape(1)]).tolist()
             LAST_KNN["index_radii"] = (round(r_max, 3), round(r_med, 3), int(r.numel()))
-            self._refine_passes = passes + 1
-            if r_med > 0.0 and r_max > _REFINE_RADIUS_RATIO * r_med and self._refine(float(r_med)):
-                return self.finish()          # the refined tables are pending now; at most _REFINE_MAX_PASSES rounds
             n_img = int(n_img_v)
+            # the re-seeding itself waits for `refine_if_needed()`: this read usually happens on the side stream of the index build,
+            # beside the pilot launches, where a round's small kernels and host reads cost ~10 ms of contention (3 ms alone)
+            self._refine_want = float(r_med) if (r_med > 0.0 and r_max > _REFINE_RADIUS_RATIO * r_med) else None
         else:
             n_img = int(n_img.item())
-        self.__dict__.pop("_points", None)
-        self.__dict__.pop("_labels", None)
+            self._refine_want = None
+        if self._refine_want is None:
+            self.__dict__.pop("_points", None)
+            self.__dict__.pop("_labels", None)
         self.n_img = max(n_img, 32)
         self.row_map = row_map[: self.n_img]
         self.tile_cluster = tile_cluster[: self.n_img // 32]
         self._tiles_i32 = tiles
         self.tiles = tiles.to(torch.int64)
         self._scan_fraction_memo = {}
+        return self
+
+    def refine_if_needed(self):
+        """Run the re-seeding rounds `finish()` found a reason for (call it where nothing else competes for the device: after the
+        pilot streams have joined).  Each round ends with its own `finish()`."""
+        while self.__dict__.get("_refine_want") is not None:
+            r_low = self._refine_want
+            self._refine_want = None
+            self._refine_passes = int(self.__dict__.get("_refine_passes", 0)) + 1
+            if not self._refine(r_low):
+                break
+            self.finish()          # reads the refined tables' size and decides about another round
+        self.__dict__.pop("_points", None)
+        self.__dict__.pop("_labels", None)
         return self
 
     def _refine(self, r_med: float) -> bool:
@@ -390,9 +406,9 @@ class ClusterIndex:
             return Xs2, seeds2, int(n2.item())
 
         if int(self.__dict__.get("_refine_passes", 1)) <= 1 and n_res > 1024:
-            # first round: a PROBE on 1024 far points (every one of them may become a seed: 512 short steps, ~1.5 ms) before the full round (up to 3800 dependent
+            # first round: a PROBE on 1024 far points and at most 768 seeds (~2 ms) before the full round (up to 3800 dependent
             # seeding steps: 7 ms when the max-min distance never collapses, which is what far points of merely WIDE groups do)
-            _, _, kp = seed_far(1024, 8, 1024)
+            _, _, kp = seed_far(1024, 8, 768)      # fewer seeds than points: with as many, the rule always ends in a "collapse" (to zero)
             LAST_KNN["index_refine_probe"] = kp
             if kp < _REFINE_MIN_SEEDS:
                 self._refine_passes = _REFINE_MAX_PASSES
@@ -845,6 +861,7 @@ def _pruned_share(Y, tau):
     if ci is None:
         return 1.0
     ci.finish()
+    ci.refine_if_needed()       # (the pilot streams have joined by now)
     share = ci.scan_fraction(tau)
     return share if (_opt("PRUNE_MODE") == "force" or share <= _PRUNE_MAX_SCAN_FRACTION) else 1.0
 
@@ -878,12 +895,14 @@ def _cluster_index_start(Y):
     return ci
 
 
-def _cluster_index(Y, ops, build=True):
+def _cluster_index(Y, ops, build=True, refine=True):
     ci = getattr(Y, "_cluster_index", None)
     if ci is None and build:
         ci = Y._cluster_index = ClusterIndex(Y)
     if ci is not None:
         ci.finish()
+        if refine:
+            ci.refine_if_needed()
         ci.record_stream(torch.cuda.current_stream(Y.device))
     if ci is not None and ci.img16 is None:
         L = _lib.lib()
@@ -970,7 +989,7 @@ def _knn_screen(Q, Y, q0, nq, k, metric, exclude_self, q_offset, out_d, out_i, p
     if pilot and nq >= _SCREEN_PILOT_MIN_Q:
         # the index build does not depend on the pilot's outcome: it runs next to it
         tier, pilot_tau = _choose_tier(Q, Y, ops, q0, k, metric, exclude_self, q_offset,
-                                       side_work=((lambda: _cluster_index_start(Y)), (lambda: _cluster_index(Y, ops))) if prune else None,
+                                       side_work=((lambda: _cluster_index_start(Y)), (lambda: _cluster_index(Y, ops, refine=False))) if prune else None,
                                        scan_frac_of=(lambda tau: _pruned_share(Y, tau)) if prune else None)
         if tier < 0:
             # no list-keeping tier holds the band: the threshold scan keeps longer lists (in HBM) and may still serve it
@@ -1126,7 +1145,7 @@ def knn_pruned_sharded(Y: "PackedPoints", k: int, metric: str, exclude_self: boo
         ops = _screen_operands(Y, Y)
         q0 = max(0, min((c0 // 32) * 32, ((n - _SCREEN_PILOT_Q) // 32) * 32))
         tier, tau = _choose_tier(Y, Y, ops, q0, k, metric, exclude_self, 0,
-                                 side_work=((lambda: _cluster_index_start(Y)), (lambda: _cluster_index(Y, ops))),
+                                 side_work=((lambda: _cluster_index_start(Y)), (lambda: _cluster_index(Y, ops, refine=False))),
                                  scan_frac_of=lambda t: _pruned_share(Y, t))
     # one decision for all ranks: any rank without a usable tier -> nobody prunes; else the most conservative tier and
     # the largest threshold estimate (element-wise MAX all-reduce)
